@@ -1,0 +1,9 @@
+"""healnet_amd -- MI355X-native (gfx950) implementation of HEALNet's iterative cross-attention
+fusion stack, a drop-in for ``healnet.models.HealNet`` / ``healnet.models.Attention`` of
+konst-int-i/healnet.  ``import healnet_amd as healnet`` keeps ``from healnet import HealNet`` style code working.
+"""
+from .healnet import Attention, FeedForward, HealNet, PreNorm, fourier_encode_concat
+from .etl import MMDataset
+
+__all__ = ["HealNet", "Attention", "PreNorm", "FeedForward", "MMDataset", "fourier_encode_concat"]
+__version__ = "0.1.0"

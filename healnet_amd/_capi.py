@@ -1,0 +1,125 @@
+"""ctypes binding of libhealnet_hip.so (C ABI declared in include/healnet_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or a call fails, a
+RuntimeError is raised -- the product path never computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import sys
+from typing import Optional
+
+HN_MAX_AXES = 4
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhealnet_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+SOURCES = ["api.hip", "gemm.hip", "attention.hip", "encode.hip", "misc.hip"]
+
+c_float_p = C.POINTER(C.c_float)
+
+
+class AttnParams(C.Structure):
+    _fields_ = [
+        ("heads", C.c_int), ("dim_head", C.c_int), ("query_dim", C.c_int),
+        ("norm_w", C.c_void_p), ("norm_b", C.c_void_p),
+        ("ctx_gamma", C.c_void_p), ("ctx_beta", C.c_void_p),
+        ("w_q", C.c_void_p), ("w_kv", C.c_void_p), ("w_out", C.c_void_p), ("b_out", C.c_void_p),
+    ]
+
+
+class FFParams(C.Structure):
+    _fields_ = [
+        ("dim", C.c_int), ("gate", C.c_int),
+        ("norm_w", C.c_void_p), ("norm_b", C.c_void_p),
+        ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p),
+    ]
+
+
+class ModalityInput(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("spatial", C.c_int * HN_MAX_AXES)]
+
+
+class Model(C.Structure):
+    _fields_ = [
+        ("n_modalities", C.c_int), ("depth", C.c_int), ("l_c", C.c_int), ("l_d", C.c_int),
+        ("self_per_cross_attn", C.c_int), ("final_classifier_head", C.c_int), ("out_dims", C.c_int),
+        ("num_freq_bands", C.c_int), ("max_freq", C.c_float), ("fourier_encode_data", C.c_int),
+        ("channel_dims", C.POINTER(C.c_int)), ("num_spatial_axes", C.POINTER(C.c_int)),
+        ("latents", C.c_void_p),
+        ("cross_attn", C.POINTER(AttnParams)), ("cross_ff", C.POINTER(FFParams)),
+        ("self_attn", C.POINTER(AttnParams)), ("self_ff", C.POINTER(FFParams)),
+        ("head_norm_w", C.c_void_p), ("head_norm_b", C.c_void_p), ("head_w", C.c_void_p), ("head_b", C.c_void_p),
+    ]
+
+
+class Profile(C.Structure):
+    _fields_ = [("ev_start", C.POINTER(C.c_void_p)), ("ev_stop", C.POINTER(C.c_void_p)),
+                ("n_events", C.c_int), ("n_recorded", C.c_int)]
+
+
+# every symbol include/healnet_hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "hn_abi_version": (C.c_int, []),
+    "hn_last_error_string": (C.c_char_p, []),
+    "hn_fourier_encode_concat": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_float,
+                                           C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "hn_encode_norm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_float, C.c_int,
+                                 C.c_float, C.c_void_p, C.c_int, C.c_void_p]),
+    "hn_context_pitch": (C.c_int, [C.c_int, C.c_int]),
+    "hn_attn_fwd": (C.c_int, [C.POINTER(AttnParams), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                              C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "hn_attn_workspace_bytes": (C.c_size_t, [C.POINTER(AttnParams), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "hn_attn_probs": (C.c_int, [C.POINTER(AttnParams), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "hn_ff_fwd": (C.c_int, [C.POINTER(FFParams), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "hn_ff_workspace_bytes": (C.c_size_t, [C.POINTER(FFParams), C.c_int]),
+    "hn_head_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                              C.c_void_p, C.c_void_p]),
+    "hn_fusion_forward": (C.c_int, [C.POINTER(Model), C.POINTER(ModalityInput), C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                    C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p, C.c_size_t,
+                                    C.c_void_p, C.POINTER(Profile)]),
+    "hn_fusion_workspace_bytes": (C.c_size_t, [C.POINTER(Model), C.POINTER(ModalityInput), C.c_int]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP translation unit for gfx950 into healnet_amd/libhealnet_hip.so (in-tree)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(_HERE, "..", "include", "healnet_hip.h")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return LIB_PATH
+
+
+def lib() -> C.CDLL:
+    """Load the library once; raise loudly when it is absent (no CPU fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"healnet_amd: {LIB_PATH} is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)   # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        if handle.hn_abi_version() != 1:
+            raise RuntimeError("healnet_amd: ABI version mismatch between _capi.py and libhealnet_hip.so")
+        _lib = handle
+    return _lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = lib().hn_last_error_string()
+        raise RuntimeError(f"healnet_hip {what} failed (status {status}): {msg.decode() if msg else '?'}")

@@ -1,0 +1,430 @@
+// C-ABI entry points of libhealnet_hip.so and the host-side orchestration of the fusion forward
+// (the launch schedule that replaces HealNet.forward :190-250 of the reference).
+#include "common.h"
+
+#include <math.h>
+#include <string.h>
+
+namespace hn {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+static inline int pad_head_dim(int dh) { return dh <= 16 ? 16 : dh <= 32 ? 32 : dh <= 64 ? 64 : dh <= 128 ? 128 : 0; }
+static inline int round16(int v) { return (v + 15) / 16 * 16; }
+
+// ------------------------------------------------------------------------------------------------
+// attention block
+// ------------------------------------------------------------------------------------------------
+struct AttnPlan {
+  int heads, dh, inner, dhp, Lp, N, D, dp;
+  bool rank_d, self_attn;
+  int nsplit, chunk;
+  float cscale;
+  // workspace carve
+  float *obuf, *q, *qf, *kv, *opart, *mpart, *lpart;
+  size_t bytes;
+};
+
+static int plan_attn(const hn_attn_params *p, bool has_ctx, int ld_ctx, int b, int L, int N, int D, void *ws,
+                     size_t ws_bytes, AttnPlan *pl) {
+  HN_REQUIRE(p, HN_E_NULL, "attn: params NULL");
+  HN_REQUIRE(p->heads > 0 && p->dim_head > 0 && p->query_dim > 0 && b > 0 && L > 0, HN_E_SHAPE,
+             "attn: heads=%d dim_head=%d query_dim=%d b=%d L=%d", p->heads, p->dim_head, p->query_dim, b, L);
+  pl->heads = p->heads;
+  pl->dh = p->dim_head;
+  pl->inner = p->heads * p->dim_head;
+  pl->dhp = pad_head_dim(p->dim_head);
+  HN_REQUIRE(pl->dhp != 0, HN_E_UNSUPPORTED, "attn: dim_head=%d > 128 is not supported", p->dim_head);
+  pl->Lp = round16(L);
+  pl->self_attn = !has_ctx;
+  pl->N = has_ctx ? N : L;
+  pl->D = has_ctx ? D : p->query_dim;
+  HN_REQUIRE(pl->N > 0 && pl->D > 0, HN_E_SHAPE, "attn: N=%d D=%d", pl->N, pl->D);
+  HN_REQUIRE(!has_ctx || ld_ctx >= D, HN_E_SHAPE, "attn: ld_ctx=%d < D=%d", ld_ctx, D);
+  pl->rank_d = has_ctx && (ld_ctx == 16 || ld_ctx == 32) && D <= ld_ctx && ld_ctx <= pl->dhp;
+  pl->dp = pl->rank_d ? ld_ctx : pl->dhp;
+  pl->cscale = 2.0f * (1.0f / sqrtf((float)p->dim_head)) * 1.44269504088896340736f;  // (1/0.5) * dh^-1/2 * log2(e)
+  attn_core_geometry(b, p->heads, pl->Lp, pl->N, pl->dp, &pl->nsplit, &pl->chunk);
+
+  Arena ar(ws, ws_bytes);
+  const size_t rows = (size_t)b * L;
+  pl->obuf = ar.take<float>(rows * pl->inner);
+  if (pl->rank_d) {
+    pl->q = ar.take<float>(rows * pl->inner);
+    pl->qf = ar.take<float>((size_t)b * p->heads * pl->Lp * pl->dp);
+    pl->kv = nullptr;
+  } else {
+    pl->q = ar.take<float>(rows * p->heads * pl->dhp);
+    pl->qf = nullptr;
+    pl->kv = ar.take<float>((size_t)b * pl->N * 2 * p->heads * pl->dhp);
+  }
+  const size_t prow = (size_t)b * p->heads * pl->nsplit * pl->Lp;
+  pl->opart = ar.take<float>(prow * pl->dp);
+  pl->mpart = ar.take<float>(prow);
+  pl->lpart = ar.take<float>(prow);
+  pl->bytes = ar.off;
+  if (ws != nullptr && ar.overflow)
+    return fail(HN_E_WORKSPACE, "attn: workspace %zu bytes < required %zu", ws_bytes, ar.off);
+  return HN_OK;
+}
+
+static int check_ws(void *ws, size_t ws_bytes, size_t need, const char *who) {
+  HN_REQUIRE(ws != nullptr, HN_E_WORKSPACE, "%s: workspace is NULL (need %zu bytes)", who, need);
+  HN_REQUIRE(((uintptr_t)ws & 255) == 0, HN_E_WORKSPACE, "%s: workspace must be 256-byte aligned", who);
+  HN_REQUIRE(ws_bytes >= need, HN_E_WORKSPACE, "%s: workspace %zu bytes < required %zu", who, ws_bytes, need);
+  return HN_OK;
+}
+
+static GemmArgs gemm_defaults() {
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.batch = 1;
+  g.alpha = 1.0f;
+  g.eps = 1e-5f;
+  return g;
+}
+
+// Steps shared by hn_attn_fwd and hn_attn_probs: the scaled query operand of the attention core and
+// (explicit path) the projected keys / values.
+static int attn_prepare(const hn_attn_params *p, const AttnPlan &pl, const float *x_in, const float *ctx, int ld_ctx,
+                        int b, int L, hipStream_t s, AttnCoreArgs *core) {
+  const int rows = b * L;
+  GemmArgs gq = gemm_defaults();
+  gq.A = x_in; gq.lda = p->query_dim;
+  gq.W = p->w_q; gq.ldw = p->query_dim;
+  gq.M = rows; gq.N = pl.inner; gq.K = p->query_dim;
+  if (p->norm_w) { gq.pro = PRO_LAYERNORM; gq.gamma = p->norm_w; gq.beta = p->norm_b; }
+  memset(core, 0, sizeof(*core));
+  core->b = b; core->h = p->heads; core->Lq = L; core->Lp = pl.Lp; core->N = pl.N; core->dp = pl.dp;
+  core->nsplit = pl.nsplit; core->chunk = pl.chunk;
+  core->Opart = pl.opart; core->Mpart = pl.mpart; core->Lpart = pl.lpart;
+  int rc;
+  if (pl.rank_d) {
+    gq.C = pl.q; gq.ldc = pl.inner;
+    if ((rc = launch_gemm(gq, s)) != HN_OK) return rc;
+    if ((rc = launch_qfold(pl.q, pl.inner, p->w_kv, pl.D, p->ctx_gamma, pl.cscale, pl.qf, b, p->heads, L, pl.Lp, pl.dh,
+                           pl.dp, s)) != HN_OK) return rc;
+    core->Q = pl.qf; core->q_b = (long)p->heads * pl.Lp * pl.dp; core->q_h = (long)pl.Lp * pl.dp; core->ldq = pl.dp;
+    core->Kp = ctx; core->k_b = (long)pl.N * ld_ctx; core->k_h = 0; core->ldk = ld_ctx;
+    core->Vp = ctx; core->v_b = core->k_b; core->v_h = 0; core->ldv = ld_ctx;
+  } else {
+    const int qpitch = p->heads * pl.dhp, kvpitch = 2 * p->heads * pl.dhp;
+    if (pl.dhp != pl.dh) {
+      HN_HIP_CHECK(hipMemsetAsync(pl.q, 0, (size_t)rows * qpitch * sizeof(float), s));
+      HN_HIP_CHECK(hipMemsetAsync(pl.kv, 0, (size_t)b * pl.N * kvpitch * sizeof(float), s));
+    }
+    gq.C = pl.q; gq.ldc = qpitch; gq.alpha = pl.cscale;
+    gq.col_group = pl.dh; gq.col_group_pitch = pl.dhp;
+    if ((rc = launch_gemm(gq, s)) != HN_OK) return rc;
+    GemmArgs gk = gemm_defaults();
+    if (ctx) {
+      gk.A = ctx; gk.lda = ld_ctx; gk.M = b * pl.N; gk.K = pl.D;
+      if (p->ctx_gamma) { gk.pro = PRO_AFFINE; gk.gamma = p->ctx_gamma; gk.beta = p->ctx_beta; }
+    } else {   // self-attention: context = normalised x (healnet.py:404)
+      gk.A = x_in; gk.lda = p->query_dim; gk.M = rows; gk.K = p->query_dim;
+      if (p->norm_w) { gk.pro = PRO_LAYERNORM; gk.gamma = p->norm_w; gk.beta = p->norm_b; }
+    }
+    gk.W = p->w_kv; gk.ldw = pl.D;
+    gk.N = 2 * pl.inner;
+    gk.C = pl.kv; gk.ldc = kvpitch; gk.col_group = pl.dh; gk.col_group_pitch = pl.dhp;
+    if ((rc = launch_gemm(gk, s)) != HN_OK) return rc;
+    core->Q = pl.q; core->q_b = (long)L * qpitch; core->q_h = pl.dhp; core->ldq = qpitch;
+    core->Kp = pl.kv; core->k_b = (long)pl.N * kvpitch; core->k_h = pl.dhp; core->ldk = kvpitch;
+    core->Vp = pl.kv + (long)p->heads * pl.dhp; core->v_b = core->k_b; core->v_h = pl.dhp; core->ldv = kvpitch;
+  }
+  return HN_OK;
+}
+
+static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_out, int residual, const float *ctx,
+                         int ld_ctx, int b, int L, int N, int D, const uint8_t *mask, float *stats, void *ws,
+                         size_t ws_bytes, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+  HN_REQUIRE(x_in && x_out, HN_E_NULL, "attn: x is NULL");
+  HN_REQUIRE(p && p->w_q && p->w_kv && p->w_out, HN_E_NULL, "attn: weight pointer is NULL");
+  AttnPlan pl;
+  int rc = plan_attn(p, ctx != nullptr, ld_ctx, b, L, N, D, nullptr, 0, &pl);
+  if (rc != HN_OK) return rc;
+  if ((rc = check_ws(ws, ws_bytes, pl.bytes, "attn")) != HN_OK) return rc;
+  if ((rc = plan_attn(p, ctx != nullptr, ld_ctx, b, L, N, D, ws, ws_bytes, &pl)) != HN_OK) return rc;
+
+  AttnCoreArgs core;
+  if ((rc = attn_prepare(p, pl, x_in, ctx, ld_ctx, b, L, s, &core)) != HN_OK) return rc;
+  core.mask = mask;
+  if (ev0) HN_HIP_CHECK(hipEventRecord(ev0, s));
+  if ((rc = launch_attn_core(core, s)) != HN_OK) return rc;
+  if (ev1) HN_HIP_CHECK(hipEventRecord(ev1, s));
+  if (pl.rank_d) {
+    rc = launch_merge_vproj(pl.opart, pl.mpart, pl.lpart, pl.nsplit, b, p->heads, L, pl.Lp, pl.dp, pl.D, p->ctx_gamma,
+                            p->ctx_beta, p->w_kv + (long)pl.inner * pl.D, pl.dh, pl.obuf, pl.inner, stats, s);
+  } else {
+    rc = launch_merge_explicit(pl.opart, pl.mpart, pl.lpart, pl.nsplit, b, p->heads, L, pl.Lp, pl.dp, pl.dh, pl.obuf,
+                               pl.inner, stats, s);
+  }
+  if (rc != HN_OK) return rc;
+
+  GemmArgs go = gemm_defaults();
+  go.A = pl.obuf; go.lda = pl.inner;
+  go.W = p->w_out; go.ldw = pl.inner;
+  go.C = x_out; go.ldc = p->query_dim;
+  go.bias = p->b_out;
+  go.M = b * L; go.N = p->query_dim; go.K = pl.inner;
+  go.act = ACT_LEAKY;
+  if (residual) { go.R = x_in; go.ldr = p->query_dim; }
+  return launch_gemm(go, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// feed-forward block
+// ------------------------------------------------------------------------------------------------
+static int ff_fwd_impl(const hn_ff_params *p, const float *x_in, float *x_out, int residual, int rows, void *ws,
+                       size_t ws_bytes, hipStream_t s) {
+  HN_REQUIRE(p && x_in && x_out, HN_E_NULL, "ff: NULL pointer");
+  HN_REQUIRE(p->w1 && p->b1 && p->w2 && p->b2, HN_E_NULL, "ff: weight pointer is NULL");
+  HN_REQUIRE(p->dim > 0 && rows > 0, HN_E_SHAPE, "ff: dim=%d rows=%d", p->dim, rows);
+  HN_REQUIRE(p->gate == HN_GATE_SELU || p->gate == HN_GATE_GELU, HN_E_UNSUPPORTED, "ff: gate=%d", p->gate);
+  const int hid = 4 * p->dim;
+  const size_t need = align_up((size_t)rows * hid * sizeof(float), 256);
+  int rc = check_ws(ws, ws_bytes, need, "ff");
+  if (rc != HN_OK) return rc;
+  float *hidden = (float *)ws;
+  GemmArgs g1 = gemm_defaults();
+  g1.A = x_in; g1.lda = p->dim;
+  g1.W = p->w1; g1.ldw = p->dim;
+  g1.C = hidden; g1.ldc = hid;
+  g1.bias = p->b1;
+  g1.M = rows; g1.N = hid; g1.K = p->dim;
+  g1.act = p->gate == HN_GATE_SELU ? ACT_GLU_SELU : ACT_GLU_GELU;
+  g1.glu_offset = hid;
+  if (p->norm_w) { g1.pro = PRO_LAYERNORM; g1.gamma = p->norm_w; g1.beta = p->norm_b; }
+  if ((rc = launch_gemm(g1, s)) != HN_OK) return rc;
+  GemmArgs g2 = gemm_defaults();
+  g2.A = hidden; g2.lda = hid;
+  g2.W = p->w2; g2.ldw = hid;
+  g2.C = x_out; g2.ldc = p->dim;
+  g2.bias = p->b2;
+  g2.M = rows; g2.N = p->dim; g2.K = hid;
+  if (residual) { g2.R = x_in; g2.ldr = p->dim; }
+  return launch_gemm(g2, s);
+}
+
+static int context_pitch(int D, int dim_head) {
+  const int dhp = pad_head_dim(dim_head);
+  int dp = D <= 16 ? 16 : (D <= 32 ? 32 : 0);
+  if (dp != 0 && dhp != 0 && dp <= dhp) return dp;
+  return (D + 3) / 4 * 4;
+}
+
+// ------------------------------------------------------------------------------------------------
+// whole forward
+// ------------------------------------------------------------------------------------------------
+struct FusionPlan {
+  float *x;
+  float *z[16];
+  int ldz[16], N[16], D[16];
+  void *op_ws;
+  size_t op_ws_bytes, bytes;
+  int dominant;   // modality with the most tokens among the present ones
+};
+
+static int plan_fusion(const hn_model *m, const hn_modality_input *in, int b, void *ws, size_t ws_bytes, FusionPlan *fp) {
+  HN_REQUIRE(m && in, HN_E_NULL, "fusion: NULL model / inputs");
+  HN_REQUIRE(m->n_modalities >= 1 && m->n_modalities <= 16, HN_E_UNSUPPORTED, "fusion: n_modalities=%d (1..16)", m->n_modalities);
+  HN_REQUIRE(m->depth >= 1 && m->l_c >= 1 && m->l_d >= 1 && b >= 1, HN_E_SHAPE, "fusion: depth=%d l_c=%d l_d=%d b=%d",
+             m->depth, m->l_c, m->l_d, b);
+  HN_REQUIRE(m->self_per_cross_attn == 0 || m->self_per_cross_attn == 1, HN_E_UNSUPPORTED,
+             "fusion: self_per_cross_attn=%d (the reference only runs 0 or 1, healnet.py:242)", m->self_per_cross_attn);
+  Arena ar(ws, ws_bytes);
+  fp->x = ar.take<float>((size_t)b * m->l_c * m->l_d);
+  size_t op_max = 0;
+  fp->dominant = -1;
+  long best = -1;
+  for (int i = 0; i < m->n_modalities; ++i) {
+    fp->z[i] = nullptr;
+    if (in[i].data == nullptr) continue;
+    const int axes = m->num_spatial_axes[i];
+    HN_REQUIRE(axes >= 1 && axes <= HN_MAX_AXES, HN_E_UNSUPPORTED, "fusion: modality %d has %d spatial axes (1..%d)", i, axes,
+               HN_MAX_AXES);
+    long n = 1;
+    for (int a = 0; a < axes; ++a) {
+      HN_REQUIRE(in[i].spatial[a] > 0, HN_E_SHAPE, "fusion: modality %d spatial[%d]=%d", i, a, in[i].spatial[a]);
+      n *= in[i].spatial[a];
+    }
+    HN_REQUIRE(n < (1L << 31) / 16, HN_E_UNSUPPORTED, "fusion: modality %d has too many tokens", i);
+    fp->N[i] = (int)n;
+    fp->D[i] = m->channel_dims[i] + (m->fourier_encode_data ? axes * (2 * m->num_freq_bands + 1) : 0);
+    const hn_attn_params *ap = &m->cross_attn[i];
+    fp->ldz[i] = context_pitch(fp->D[i], ap->dim_head);
+    fp->z[i] = ar.take<float>((size_t)b * n * fp->ldz[i]);
+    if (n > best) { best = n; fp->dominant = i; }
+    for (int layer = 0; layer < m->depth; ++layer) {
+      AttnPlan pl;
+      int rc = plan_attn(&m->cross_attn[layer * m->n_modalities + i], true, fp->ldz[i], b, m->l_c, (int)n, fp->D[i], nullptr,
+                         0, &pl);
+      if (rc != HN_OK) return rc;
+      if (pl.bytes > op_max) op_max = pl.bytes;
+    }
+  }
+  HN_REQUIRE(fp->dominant >= 0, HN_E_SHAPE, "fusion: every modality is missing");
+  if (m->self_per_cross_attn > 0) {
+    for (int layer = 0; layer < m->depth; ++layer) {
+      AttnPlan pl;
+      int rc = plan_attn(&m->self_attn[layer], false, 0, b, m->l_c, m->l_c, m->l_d, nullptr, 0, &pl);
+      if (rc != HN_OK) return rc;
+      if (pl.bytes > op_max) op_max = pl.bytes;
+    }
+  }
+  const size_t ffb = align_up((size_t)b * m->l_c * 4 * m->l_d * sizeof(float), 256);
+  if (ffb > op_max) op_max = ffb;
+  fp->op_ws_bytes = op_max;
+  fp->op_ws = ar.take<char>(op_max);
+  fp->bytes = ar.off;
+  if (ws != nullptr && ar.overflow) return fail(HN_E_WORKSPACE, "fusion: workspace %zu bytes < required %zu", ws_bytes, ar.off);
+  return HN_OK;
+}
+
+}  // namespace hn
+
+using namespace hn;
+
+extern "C" {
+
+int hn_abi_version(void) { return HN_ABI_VERSION; }
+const char *hn_last_error_string(void) { return g_err; }
+
+int hn_context_pitch(int D, int dim_head) { return context_pitch(D, dim_head); }
+
+int hn_fourier_encode_concat(const float *data, int b, int n_axes, const int *spatial, int channels, int num_freq_bands,
+                             float max_freq, int fourier, float *ctx, int ld_out, void *stream) {
+  return launch_encode(data, b, n_axes, spatial, channels, num_freq_bands, max_freq, fourier, 0, 0.0f, ctx, ld_out,
+                       (hipStream_t)stream);
+}
+
+int hn_encode_norm(const float *data, int b, int n_axes, const int *spatial, int channels, int num_freq_bands,
+                   float max_freq, int fourier, float eps, float *z, int ld_out, void *stream) {
+  return launch_encode(data, b, n_axes, spatial, channels, num_freq_bands, max_freq, fourier, 1, eps, z, ld_out,
+                       (hipStream_t)stream);
+}
+
+size_t hn_attn_workspace_bytes(const hn_attn_params *p, int has_ctx, int ld_ctx, int b, int L, int N, int D) {
+  AttnPlan pl;
+  if (plan_attn(p, has_ctx != 0, ld_ctx, b, L, N, D, nullptr, 0, &pl) != HN_OK) return 0;
+  return pl.bytes;
+}
+
+int hn_attn_fwd(const hn_attn_params *p, const float *x_in, float *x_out, int residual, const float *ctx, int ld_ctx,
+                int b, int L, int N, int D, const uint8_t *mask, float *stats, void *workspace, size_t workspace_bytes,
+                void *stream) {
+  return attn_fwd_impl(p, x_in, x_out, residual, ctx, ld_ctx, b, L, N, D, mask, stats, workspace, workspace_bytes,
+                       (hipStream_t)stream, nullptr, nullptr);
+}
+
+int hn_attn_probs(const hn_attn_params *p, const float *x_in, const float *ctx, int ld_ctx, int b, int L, int N, int D,
+                  const uint8_t *mask, const float *stats, float *probs, void *workspace, size_t workspace_bytes,
+                  void *stream) {
+  HN_REQUIRE(p && x_in && stats && probs, HN_E_NULL, "attn_probs: NULL pointer");
+  hipStream_t s = (hipStream_t)stream;
+  AttnPlan pl;
+  int rc = plan_attn(p, ctx != nullptr, ld_ctx, b, L, N, D, nullptr, 0, &pl);
+  if (rc != HN_OK) return rc;
+  if ((rc = check_ws(workspace, workspace_bytes, pl.bytes, "attn_probs")) != HN_OK) return rc;
+  if ((rc = plan_attn(p, ctx != nullptr, ld_ctx, b, L, N, D, workspace, workspace_bytes, &pl)) != HN_OK) return rc;
+  AttnCoreArgs core;
+  if ((rc = attn_prepare(p, pl, x_in, ctx, ld_ctx, b, L, s, &core)) != HN_OK) return rc;
+  return launch_probs(core.Q, core.q_b, core.q_h, core.ldq, pl.rank_d ? pl.D : pl.dh, core.Kp, core.k_b, core.k_h, core.ldk,
+                      mask, stats, probs, b, p->heads, L, pl.N, s);
+}
+
+size_t hn_ff_workspace_bytes(const hn_ff_params *p, int rows) {
+  if (!p || p->dim <= 0 || rows <= 0) return 0;
+  return align_up((size_t)rows * 4 * p->dim * sizeof(float), 256);
+}
+
+int hn_ff_fwd(const hn_ff_params *p, const float *x_in, float *x_out, int residual, int rows, void *workspace,
+              size_t workspace_bytes, void *stream) {
+  return ff_fwd_impl(p, x_in, x_out, residual, rows, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int hn_head_fwd(const float *x, int b, int L, int d, const float *norm_w, const float *norm_b, const float *w,
+                const float *bias, int out_dims, float *logits, void *stream) {
+  return launch_head(x, b, L, d, norm_w, norm_b, w, bias, out_dims, logits, (hipStream_t)stream);
+}
+
+size_t hn_fusion_workspace_bytes(const hn_model *model, const hn_modality_input *inputs, int b) {
+  FusionPlan fp;
+  if (plan_fusion(model, inputs, b, nullptr, 0, &fp) != HN_OK) return 0;
+  return fp.bytes;
+}
+
+int hn_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, const uint8_t *mask, int skip_self_on_missing,
+                      int return_embeddings, float *out, float **attn_stats, float **x_trace, void *workspace,
+                      size_t workspace_bytes, void *stream, hn_profile *prof) {
+  hipStream_t s = (hipStream_t)stream;
+  HN_REQUIRE(out, HN_E_NULL, "fusion: out is NULL");
+  FusionPlan fp;
+  int rc = plan_fusion(m, in, b, nullptr, 0, &fp);
+  if (rc != HN_OK) return rc;
+  if ((rc = check_ws(workspace, workspace_bytes, fp.bytes, "fusion")) != HN_OK) return rc;
+  if ((rc = plan_fusion(m, in, b, workspace, workspace_bytes, &fp)) != HN_OK) return rc;
+  const int M = m->n_modalities, L = m->l_c, d = m->l_d;
+  const size_t xbytes = (size_t)b * L * d * sizeof(float);
+  if (prof) prof->n_recorded = 0;
+
+  // K1 once per forward: the normalised context of every present modality (layer independent)
+  for (int i = 0; i < M; ++i) {
+    if (!in[i].data) continue;
+    if ((rc = launch_encode(in[i].data, b, m->num_spatial_axes[i], in[i].spatial, m->channel_dims[i], m->num_freq_bands,
+                            m->max_freq, m->fourier_encode_data, 1, 1e-5f, fp.z[i], fp.ldz[i], s)) != HN_OK)
+      return rc;
+  }
+  if ((rc = launch_broadcast_rows(m->latents, fp.x, (long)L * d, b, s)) != HN_OK) return rc;   // :225
+
+  const bool head = m->final_classifier_head && !return_embeddings;
+  for (int layer = 0; layer < m->depth; ++layer) {
+    for (int i = 0; i < M; ++i) {
+      const bool present = in[i].data != nullptr;
+      if (!present && skip_self_on_missing) continue;                                       // verbose quirk :229-232
+      const int slot = layer * (M + 1);
+      if (present) {
+        const hn_attn_params *ap = &m->cross_attn[layer * M + i];
+        if (x_trace && x_trace[slot + i]) HN_HIP_CHECK(hipMemcpyAsync(x_trace[slot + i], fp.x, xbytes, hipMemcpyDeviceToDevice, s));
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (prof && i == fp.dominant && prof->n_recorded < prof->n_events) {
+          e0 = (hipEvent_t)prof->ev_start[prof->n_recorded];
+          e1 = (hipEvent_t)prof->ev_stop[prof->n_recorded];
+          prof->n_recorded++;
+        }
+        if ((rc = attn_fwd_impl(ap, fp.x, fp.x, 1, fp.z[i], fp.ldz[i], b, L, fp.N[i], fp.D[i], mask,
+                                attn_stats ? attn_stats[slot + i] : nullptr, fp.op_ws, fp.op_ws_bytes, s, e0, e1)) != HN_OK)
+          return rc;
+        if ((rc = ff_fwd_impl(&m->cross_ff[layer * M + i], fp.x, fp.x, 1, b * L, fp.op_ws, fp.op_ws_bytes, s)) != HN_OK)
+          return rc;
+      }
+      if (m->self_per_cross_attn > 0) {                                                     // :241-245
+        if (x_trace && x_trace[slot + M]) HN_HIP_CHECK(hipMemcpyAsync(x_trace[slot + M], fp.x, xbytes, hipMemcpyDeviceToDevice, s));
+        if ((rc = attn_fwd_impl(&m->self_attn[layer], fp.x, fp.x, 1, nullptr, 0, b, L, L, d, nullptr,
+                                attn_stats ? attn_stats[slot + M] : nullptr, fp.op_ws, fp.op_ws_bytes, s, nullptr, nullptr)) != HN_OK)
+          return rc;
+        if ((rc = ff_fwd_impl(&m->self_ff[layer], fp.x, fp.x, 1, b * L, fp.op_ws, fp.op_ws_bytes, s)) != HN_OK) return rc;
+      }
+    }
+  }
+  if (head) return launch_head(fp.x, b, L, d, m->head_norm_w, m->head_norm_b, m->head_w, m->head_b, m->out_dims, out, s);
+  HN_HIP_CHECK(hipMemcpyAsync(out, fp.x, xbytes, hipMemcpyDeviceToDevice, s));
+  return HN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,434 @@
+// Split-KV flash attention for a short latent query block against a long context, exact fp32 on the
+// CDNA4 matrix cores (v_mfma_f32_16x16x4_f32).
+//
+// Replaces the materialised-score attention of the reference (healnet/models/healnet.py
+// Attention.forward :407-425: einsum QK^T :409, *scale :409, mask :411-415, softmax(x/0.5) :419/:364-365,
+// einsum PV :424): the (b*h, L, N) score / probability tensors never exist.
+//
+// Shape regime.  The query side is the latent array: L = l_c rows (128 by default), while the context
+// has N = 1 .. 6e5 tokens.  Tiling over queries (classic flash attention) gives no parallelism, so the
+// grid splits the TOKENS: one wave owns NQ 16-row query tiles of one (sample, head) and walks a
+// contiguous token range in 16-token steps, keeping running (max, sum, O) per query row; a merge
+// kernel combines the splits in fixed order (deterministic).
+//
+// Register-only dataflow (no LDS, no barriers; waves are fully independent):
+//   S^T = K Q^T is computed with A = K tile (M = 16 tokens), B = Q tile (N = 16 query rows).  With the
+//   16x16x4 C/D map (col = lane & 15, row = 4*(lane >> 4) + reg) lane (g, j) then holds the scores of
+//   query row j for tokens 4g + r, r = 0..3 -- which is exactly the A-operand layout of the P V product
+//   (A[i = lane & 15][k = lane >> 4]) if the k-chunk of MFMA r is defined as tokens {4g + r : g = 0..3}.
+//   Token order inside a sum is free, so P never leaves its registers: exp2 in place, feed to PV.
+//   The contraction index of QK^T is likewise permuted (step (s, c) uses d = 16 s + 4 g + c) so that
+//   both operand fragments are contiguous 16-byte loads.
+//
+// Softmax: logits arrive pre-scaled to log2 units (2 * dim_head^-1/2 * log2(e) folded into Q), running
+// max with a lazy rescale (only when some score exceeds the running max by > 2^8), masked / out-of-range
+// tokens contribute exactly 0.
+//
+// Two operand bindings share the kernel:
+//   explicit  : K, V = projected keys / values, dp = dim_head padded to 16/32/64/128
+//   rank-D    : K = V = the normalised context z (b, N, dp) shared by all heads, queries pre-folded
+//               with W_k and gamma (qfold_kernel), values projected after the reduction
+//               (merge_vproj_kernel).  Used when D (13 for an RGB image + 2-axis Fourier features)
+//               is below dim_head: 4.5x fewer executed FLOPs, identical math up to fp32 rounding.
+#include "common.h"
+
+namespace hn {
+
+constexpr float kNegBig = -1.0e30f;
+constexpr float kRescaleThreshold = 8.0f;
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+template <int DT, int NQ>
+__global__ __launch_bounds__(256) void attn_core_kernel(AttnCoreArgs a, int ngroups, int gy, int waves_per_block) {
+  constexpr int DP = 16 * DT;
+  const int L = a.Lq;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, j = lane & 15;
+
+  // XCD-aware block remap: consecutive work items of one sample stay on one XCD (blocks are dealt
+  // round-robin to the 8 XCDs), so the sample's context is fetched into one L2 only.  Speed only.
+  long total = (long)gridDim.x;
+  long id = blockIdx.x;
+  if ((total & 7) == 0) id = (id & 7) * (total >> 3) + (id >> 3);
+  const int split = (int)(id % a.nsplit);
+  const int yb = (int)((id / a.nsplit) % gy);
+  const int bh = (int)(id / ((long)a.nsplit * gy));
+  const int qg = yb * waves_per_block + wave;
+  if (qg >= ngroups) return;
+  const int bi = bh / a.h, hi = bh % a.h;
+
+  // ---- query fragments (B operand): lane (g, j) holds Q[row = tile*16 + j][16 s + 4 g + c]
+  float4 qf[NQ][DT];
+  const float *qbase = a.Q + (long)bi * a.q_b + (long)hi * a.q_h;
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    const int row = (qg * NQ + i) * 16 + j;
+#pragma unroll
+    for (int s = 0; s < DT; ++s) {
+      qf[i][s] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < L) qf[i][s] = *(const float4 *)(qbase + (long)row * a.ldq + 16 * s + 4 * g);
+    }
+  }
+
+  f32x4 O[NQ][DT];
+  float m[NQ], l[NQ];
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    m[i] = kNegBig;
+    l[i] = 0.0f;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) O[i][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+
+  const int t_begin = split * a.chunk;
+  const int t_end = min(a.N, t_begin + a.chunk);
+  const float *kbase = a.Kp + (long)bi * a.k_b + (long)hi * a.k_h;
+  const float *vbase = a.Vp + (long)bi * a.v_b + (long)hi * a.v_h;
+  const uint8_t *mrow = a.mask ? a.mask + (long)bi * a.N : nullptr;
+
+  auto load_kv = [&](int t0, float4 (&kf)[DT], float (&vf)[DT][4]) {
+    const int tk = min(t0 + j, a.N - 1);
+    const float *kp = kbase + (long)tk * a.ldk + 4 * g;
+#pragma unroll
+    for (int s = 0; s < DT; ++s) kf[s] = *(const float4 *)(kp + 16 * s);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int tv = min(t0 + 4 * g + r, a.N - 1);
+      const float *vp = vbase + (long)tv * a.ldv + j;
+#pragma unroll
+      for (int d = 0; d < DT; ++d) vf[d][r] = vp[16 * d];
+    }
+  };
+
+  float4 kf[DT];
+  float vf[DT][4];
+  if (t_begin < t_end) load_kv(t_begin, kf, vf);
+
+  for (int t0 = t_begin; t0 < t_end; t0 += 16) {
+    float4 kn[DT];
+    float vn[DT][4];
+    const bool more = t0 + 16 < t_end;
+    if (more) load_kv(t0 + 16, kn, vn);
+
+    // ---- S^T tile = K Q^T  (DT*4 chained MFMAs per query tile, NQ independent chains)
+    f32x4 S[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) S[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < DT; ++s) {
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) S[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].x, qf[i][s].x, S[i], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) S[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].y, qf[i][s].y, S[i], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) S[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].z, qf[i][s].z, S[i], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) S[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].w, qf[i][s].w, S[i], 0, 0, 0);
+    }
+
+    // ---- mask / ragged tail: lane (g, j) holds tokens t0 + 4 g + r
+    if (mrow != nullptr || t0 + 16 > t_end) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int tok = t0 + 4 * g + r;
+        bool ok = tok < t_end;
+        if (ok && mrow) ok = mrow[tok] != 0;
+        if (!ok) {
+#pragma unroll
+          for (int i = 0; i < NQ; ++i) S[i][r] = -__builtin_inff();
+        }
+      }
+    }
+
+    // ---- online softmax with lazy rescale
+    bool need = false;
+    float tmax[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      tmax[i] = fmaxf(fmaxf(S[i][0], S[i][1]), fmaxf(S[i][2], S[i][3]));
+      need |= tmax[i] > m[i] + kRescaleThreshold;
+    }
+    if (__any(need)) {
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) {
+        float tm = tmax[i];
+        tm = fmaxf(tm, __shfl_xor(tm, 16));
+        tm = fmaxf(tm, __shfl_xor(tm, 32));
+        const float mn = fmaxf(m[i], tm);
+        const float alpha = fast_exp2(m[i] - mn);
+        l[i] *= alpha;
+        // accumulator reg r of lane (g, d) belongs to query row 4 g + r, whose alpha lives in lane 4 g + r
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float ar = __shfl(alpha, 4 * g + r);
+#pragma unroll
+          for (int d = 0; d < DT; ++d) O[i][d][r] *= ar;
+        }
+        m[i] = mn;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = fast_exp2(S[i][r] - m[i]);
+        l[i] += p;
+        S[i][r] = p;
+      }
+    }
+
+    // ---- O += P V   (A = P straight from the score registers, B = V rows 4 g + r)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i)
+          O[i][d] = __builtin_amdgcn_mfma_f32_16x16x4f32(S[i][r], vf[d][r], O[i][d], 0, 0, 0);
+      }
+    }
+
+    if (more) {
+#pragma unroll
+      for (int s = 0; s < DT; ++s) kf[s] = kn[s];
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vf[d][r] = vn[d][r];
+    }
+  }
+
+  // ---- write the partial (O, m, l) of this split
+  const long prow = ((long)bh * a.nsplit + split) * a.Lp;
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    const int tile = qg * NQ + i;
+    if (tile * 16 >= a.Lp) continue;
+    float li = l[i];
+    li += __shfl_xor(li, 16);
+    li += __shfl_xor(li, 32);
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        a.Opart[(prow + tile * 16 + 4 * g + r) * DP + 16 * d + j] = O[i][d][r];
+    if (g == 0) {
+      a.Mpart[prow + tile * 16 + j] = m[i];
+      a.Lpart[prow + tile * 16 + j] = li;
+    }
+  }
+}
+
+static int nq_for(int dt) { return dt == 1 ? 4 : (dt == 2 ? 2 : (dt == 4 ? 2 : 1)); }
+
+void attn_core_geometry(int b, int h, int Lp, int N, int dp, int *nsplit, int *chunk) {
+  const int dt = dp / 16;
+  const int ngroups = ceil_div(Lp / 16, nq_for(dt));
+  const long target_waves = 256L * 4 * 4;
+  long want = ceil_div_ll(target_waves, (long)b * h * ngroups);
+  long max_splits = N / 128;
+  if (max_splits < 1) max_splits = 1;
+  if (want > max_splits) want = max_splits;
+  if (want < 1) want = 1;
+  int c = (int)ceil_div_ll(N, want);
+  c = ceil_div(c, 16) * 16;
+  *chunk = c;
+  *nsplit = ceil_div(N, c);
+}
+
+int launch_attn_core(const AttnCoreArgs &a, hipStream_t s) {
+  HN_REQUIRE(a.dp == 16 || a.dp == 32 || a.dp == 64 || a.dp == 128, HN_E_UNSUPPORTED, "attn_core: dp=%d", a.dp);
+  HN_REQUIRE(a.Lp % 16 == 0 && a.chunk % 16 == 0 && a.nsplit >= 1, HN_E_SHAPE, "attn_core: Lp=%d chunk=%d", a.Lp, a.chunk);
+  HN_REQUIRE((a.ldq % 4) == 0 && (a.ldk % 4) == 0, HN_E_SHAPE, "attn_core: ldq=%d ldk=%d must be multiples of 4", a.ldq, a.ldk);
+  const int dt = a.dp / 16, nq = nq_for(dt);
+  const int ngroups = ceil_div(a.Lp / 16, nq);
+  const int wpb = ngroups < 4 ? ngroups : 4;
+  const int gy = ceil_div(ngroups, wpb);
+  const long blocks = (long)a.nsplit * gy * a.b * a.h;
+  HN_REQUIRE(blocks < (1L << 31), HN_E_UNSUPPORTED, "attn_core: grid too large");
+  dim3 grid((unsigned)blocks), block(64 * wpb);
+  switch (dt) {
+    case 1: hipLaunchKernelGGL((attn_core_kernel<1, 4>), grid, block, 0, s, a, ngroups, gy, wpb); break;
+    case 2: hipLaunchKernelGGL((attn_core_kernel<2, 2>), grid, block, 0, s, a, ngroups, gy, wpb); break;
+    case 4: hipLaunchKernelGGL((attn_core_kernel<4, 2>), grid, block, 0, s, a, ngroups, gy, wpb); break;
+    default: hipLaunchKernelGGL((attn_core_kernel<8, 1>), grid, block, 0, s, a, ngroups, gy, wpb); break;
+  }
+  HN_LAUNCH_CHECK("attn_core");
+  return HN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// rank-D path, query side: Qf[b,h,q,d] = cscale * gamma[d] * sum_e Q[b,q,h*dh+e] * W_k[h*dh+e, d]
+// (S = Q_h K_h^T with K = (z*gamma + beta) W_k^T; the beta term is constant along the softmax axis and
+// cancels).  Tiny: L*dp outputs of a dh-long dot product per (sample, head).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void qfold_kernel(const float *__restrict__ Q, int ldq_row, const float *__restrict__ w_k,
+                                                    int D, const float *__restrict__ gamma, float cscale,
+                                                    float *__restrict__ Qf, int h, int L, int Lp, int dh, int dp) {
+  extern __shared__ float wk[];  // [dh][dp]
+  const int bh = blockIdx.x, bi = bh / h, hi = bh % h;
+  for (int idx = threadIdx.x; idx < dh * dp; idx += blockDim.x) {
+    const int e = idx / dp, d = idx % dp;
+    wk[idx] = d < D ? w_k[(long)(hi * dh + e) * D + d] * (gamma ? gamma[d] : 1.0f) * cscale : 0.0f;
+  }
+  __syncthreads();
+  float *dst = Qf + (long)bh * Lp * dp;
+  for (int idx = threadIdx.x; idx < Lp * dp; idx += blockDim.x) {
+    const int q = idx / dp, d = idx % dp;
+    float acc = 0.0f;
+    if (q < L && d < D) {
+      const float *qr = Q + ((long)bi * L + q) * ldq_row + hi * dh;
+      for (int e = 0; e < dh; ++e) acc = fmaf(qr[e], wk[e * dp + d], acc);
+    }
+    dst[idx] = acc;
+  }
+}
+
+int launch_qfold(const float *Q, int ldq_row, const float *w_k, int D, const float *gamma, float cscale, float *Qf,
+                 int b, int h, int L, int Lp, int dh, int dp, hipStream_t s) {
+  size_t lds = (size_t)dh * dp * sizeof(float);
+  hipLaunchKernelGGL(qfold_kernel, dim3(b * h), dim3(256), lds, s, Q, ldq_row, w_k, D, gamma, cscale, Qf, h, L, Lp, dh, dp);
+  HN_LAUNCH_CHECK("qfold");
+  return HN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// merge of the token splits (fixed order) and, for the rank-D path, the value projection
+//   O'[q,:] = sum_s 2^(m_s - M) O_s[q,:] / sum_s 2^(m_s - M) l_s ;   O_h = (O' * gamma + beta) W_v,h^T
+// ------------------------------------------------------------------------------------------------
+constexpr int MERGE_ROWS = 32;
+
+__device__ __forceinline__ float merged_value(const float *Opart, const float *Mpart, const float *Lpart, long pbase,
+                                              int nsplit, int Lp, int dp, int q, int d, float *Mout, float *Lout) {
+  float M = kNegBig;
+  for (int s = 0; s < nsplit; ++s) M = fmaxf(M, Mpart[pbase + (long)s * Lp + q]);
+  float acc = 0.0f, lsum = 0.0f;
+  for (int s = 0; s < nsplit; ++s) {
+    const float w = fast_exp2(Mpart[pbase + (long)s * Lp + q] - M);
+    lsum = fmaf(w, Lpart[pbase + (long)s * Lp + q], lsum);
+    acc = fmaf(w, Opart[(pbase + (long)s * Lp + q) * dp + d], acc);
+  }
+  *Mout = M;
+  *Lout = lsum;
+  return acc / lsum;
+}
+
+__global__ __launch_bounds__(256) void merge_vproj_kernel(const float *__restrict__ Opart, const float *__restrict__ Mpart,
+                                                          const float *__restrict__ Lpart, int nsplit, int h, int L, int Lp,
+                                                          int dp, int D, const float *__restrict__ gamma,
+                                                          const float *__restrict__ beta, const float *__restrict__ w_v,
+                                                          int dh, float *__restrict__ O, int ldo, float *__restrict__ stats) {
+  extern __shared__ float sm[];
+  float *oh = sm;                        // [MERGE_ROWS][dp + 1]
+  float *wv = sm + MERGE_ROWS * (dp + 1);  // [dh][D + 1]
+  const int bh = blockIdx.x, bi = bh / h, hi = bh % h;
+  const int q0 = blockIdx.y * MERGE_ROWS;
+  const long pbase = (long)bh * nsplit * Lp;
+  for (int idx = threadIdx.x; idx < MERGE_ROWS * dp; idx += blockDim.x) {
+    const int qq = idx / dp, d = idx % dp, q = q0 + qq;
+    float v = 0.0f;
+    if (q < L && d < D) {
+      float M, Ls;
+      v = merged_value(Opart, Mpart, Lpart, pbase, nsplit, Lp, dp, q, d, &M, &Ls);
+      v = v * (gamma ? gamma[d] : 1.0f) + (beta ? beta[d] : 0.0f);
+      if (stats && d == 0) {
+        stats[((long)bh * L + q) * 2 + 0] = M;
+        stats[((long)bh * L + q) * 2 + 1] = Ls;
+      }
+    }
+    oh[qq * (dp + 1) + d] = v;
+  }
+  for (int idx = threadIdx.x; idx < dh * D; idx += blockDim.x) {
+    const int e = idx / D, d = idx % D;
+    wv[e * (D + 1) + d] = w_v[(long)(hi * dh + e) * D + d];
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < MERGE_ROWS * dh; idx += blockDim.x) {
+    const int qq = idx / dh, e = idx % dh, q = q0 + qq;
+    if (q >= L) continue;
+    float acc = 0.0f;
+    for (int d = 0; d < D; ++d) acc = fmaf(oh[qq * (dp + 1) + d], wv[e * (D + 1) + d], acc);
+    O[((long)bi * L + q) * ldo + hi * dh + e] = acc;
+  }
+}
+
+int launch_merge_vproj(const float *Opart, const float *Mpart, const float *Lpart, int nsplit, int b, int h, int L,
+                       int Lp, int dp, int D, const float *gamma, const float *beta, const float *w_v, int dh,
+                       float *O, int ldo, float *stats, hipStream_t s) {
+  size_t lds = ((size_t)MERGE_ROWS * (dp + 1) + (size_t)dh * (D + 1)) * sizeof(float);
+  hipLaunchKernelGGL(merge_vproj_kernel, dim3(b * h, ceil_div(L, MERGE_ROWS)), dim3(256), lds, s, Opart, Mpart, Lpart,
+                     nsplit, h, L, Lp, dp, D, gamma, beta, w_v, dh, O, ldo, stats);
+  HN_LAUNCH_CHECK("merge_vproj");
+  return HN_OK;
+}
+
+__global__ __launch_bounds__(256) void merge_explicit_kernel(const float *__restrict__ Opart, const float *__restrict__ Mpart,
+                                                             const float *__restrict__ Lpart, int nsplit, int h, int L,
+                                                             int Lp, int dp, int dh, float *__restrict__ O, int ldo,
+                                                             float *__restrict__ stats) {
+  const int bh = blockIdx.x, bi = bh / h, hi = bh % h;
+  const int q0 = blockIdx.y * MERGE_ROWS;
+  const long pbase = (long)bh * nsplit * Lp;
+  for (int idx = threadIdx.x; idx < MERGE_ROWS * dh; idx += blockDim.x) {
+    const int qq = idx / dh, e = idx % dh, q = q0 + qq;
+    if (q >= L) continue;
+    float M, Ls;
+    const float v = merged_value(Opart, Mpart, Lpart, pbase, nsplit, Lp, dp, q, e, &M, &Ls);
+    O[((long)bi * L + q) * ldo + hi * dh + e] = v;
+    if (stats && e == 0) {
+      stats[((long)bh * L + q) * 2 + 0] = M;
+      stats[((long)bh * L + q) * 2 + 1] = Ls;
+    }
+  }
+}
+
+int launch_merge_explicit(const float *Opart, const float *Mpart, const float *Lpart, int nsplit, int b, int h, int L,
+                          int Lp, int dp, int dh, float *O, int ldo, float *stats, hipStream_t s) {
+  hipLaunchKernelGGL(merge_explicit_kernel, dim3(b * h, ceil_div(L, MERGE_ROWS)), dim3(256), 0, s, Opart, Mpart, Lpart,
+                     nsplit, h, L, Lp, dp, dh, O, ldo, stats);
+  HN_LAUNCH_CHECK("merge_explicit");
+  return HN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Attention.attn_weights (:420) on demand:  P[bh, q, t] = 2^(Q[q,:].K[t,:] - M_q) / L_q  (0 when masked)
+// Opt-in export path (the reference always keeps this (b*h, L, N) tensor; 6.6 GB per image block at
+// b = 32).  Plain VALU kernel, 64 tokens x all rows per workgroup.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void probs_kernel(const float *__restrict__ Q, long q_b, long q_h, int ldq, int dp,
+                                                    const float *__restrict__ Kp, long k_b, long k_h, int ldk,
+                                                    const uint8_t *__restrict__ mask,
+                                                    const float *__restrict__ stats, float *__restrict__ P, int h, int L,
+                                                    int N) {
+  extern __shared__ float ks[];  // [64][dp + 1]
+  const int bh = blockIdx.y, bi = bh / h, hi = bh % h;
+  const int t0 = blockIdx.x * 64;
+  const float *kbase = Kp + (long)bi * k_b + (long)hi * k_h;
+  for (int idx = threadIdx.x; idx < 64 * dp; idx += blockDim.x) {
+    const int tt = idx / dp, d = idx % dp;
+    const int t = min(t0 + tt, N - 1);
+    ks[tt * (dp + 1) + d] = kbase[(long)t * ldk + d];
+  }
+  __syncthreads();
+  const int tt = threadIdx.x & 63, t = t0 + tt;
+  const bool live = t < N && (!mask || mask[(long)bi * N + t] != 0);
+  const float *qb = Q + (long)bi * q_b + (long)hi * q_h;
+  for (int q = threadIdx.x >> 6; q < L; q += 4) {
+    float acc = 0.0f;
+    for (int d = 0; d < dp; ++d) acc = fmaf(qb[(long)q * ldq + d], ks[tt * (dp + 1) + d], acc);
+    const float M = stats[((long)bh * L + q) * 2 + 0], Ls = stats[((long)bh * L + q) * 2 + 1];
+    if (t < N) P[((long)bh * L + q) * N + t] = live ? fast_exp2(acc - M) / Ls : 0.0f;
+  }
+}
+
+int launch_probs(const float *Q, long q_b, long q_h, int ldq, int dp, const float *Kp, long k_b, long k_h, int ldk,
+                 const uint8_t *mask, const float *stats, float *P, int b, int h, int L, int N, hipStream_t s) {
+  size_t lds = (size_t)64 * (dp + 1) * sizeof(float);
+  hipLaunchKernelGGL(probs_kernel, dim3(ceil_div(N, 64), b * h), dim3(256), lds, s, Q, q_b, q_h, ldq, dp, Kp, k_b, k_h, ldk,
+                     mask, stats, P, h, L, N);
+  HN_LAUNCH_CHECK("probs");
+  return HN_OK;
+}
+
+}  // namespace hn

@@ -1,0 +1,115 @@
+// Internal helpers shared by the HIP translation units of libhealnet_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/healnet_hip.h"
+
+namespace hn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// thread-local error string behind hn_last_error_string()
+void set_error(const char *fmt, ...);
+int fail(int code, const char *fmt, ...);
+
+#define HN_HIP_CHECK(expr)                                                                       \
+  do {                                                                                           \
+    hipError_t _e = (expr);                                                                      \
+    if (_e != hipSuccess) return ::hn::fail(HN_E_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+  } while (0)
+
+#define HN_LAUNCH_CHECK(name)                                                                    \
+  do {                                                                                           \
+    hipError_t _e = hipGetLastError();                                                           \
+    if (_e != hipSuccess) return ::hn::fail(HN_E_HIP, "launch of %s failed: %s", name, hipGetErrorString(_e)); \
+  } while (0)
+
+#define HN_REQUIRE(cond, code, ...)                                                              \
+  do {                                                                                           \
+    if (!(cond)) return ::hn::fail(code, __VA_ARGS__);                                           \
+  } while (0)
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline long long ceil_div_ll(long long a, long long b) { return (a + b - 1) / b; }
+
+// bump allocator over the caller-provided workspace
+struct Arena {
+  char *base;
+  size_t size, off;
+  bool overflow;
+  Arena(void *p, size_t n) : base((char *)p), size(n), off(0), overflow(false) {}
+  template <typename T> T *take(size_t count) {
+    size_t bytes = align_up(count * sizeof(T), 256);
+    if (base == nullptr) { off += bytes; return nullptr; }   // sizing pass
+    if (off + bytes > size) { overflow = true; off += bytes; return nullptr; }
+    T *r = (T *)(base + off);
+    off += bytes;
+    return r;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// generic fused GEMM:  C[m, col(n)] = act( alpha * sum_k pro(A[m,k]) * W[n,k] + bias[n] ) (+ R[m,n])
+// ------------------------------------------------------------------------------------------------
+enum { PRO_NONE = 0, PRO_AFFINE = 1, PRO_LAYERNORM = 2 };
+enum { ACT_NONE = 0, ACT_LEAKY = 1, ACT_GLU_SELU = 2, ACT_GLU_GELU = 3 };
+
+struct GemmArgs {
+  const float *A; long lda; long strideA;
+  const float *W; long ldw; long strideW;      // W[n][k], NT
+  float *C; long ldc; long strideC;
+  const float *bias; long strideBias;          // may be NULL
+  const float *R; long ldr; long strideR;      // residual, may be NULL (may alias C)
+  int M, N, K, batch;
+  int pro; const float *gamma; const float *beta; float eps;   // prologue on A (over k)
+  float alpha;
+  int act;
+  int glu_offset;                              // row offset of the gate half in W / bias (GLU acts)
+  int col_group, col_group_pitch;              // out col = (n / col_group) * col_group_pitch + n % col_group (0 = identity)
+};
+int launch_gemm(const GemmArgs &g, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// encode
+// ------------------------------------------------------------------------------------------------
+int launch_encode(const float *data, int b, int n_axes, const int *spatial, int C, int F, float max_freq,
+                  int fourier, int normalize, float eps, float *out, int ld_out, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// attention pieces
+// ------------------------------------------------------------------------------------------------
+struct AttnCoreArgs {
+  const float *Q;  long q_b, q_h; int ldq;      // (b, h, Lp rows, DP) pre-scaled queries, zero padded rows/cols
+  const float *Kp; long k_b, k_h; int ldk;      // key rows:   Kp + b*k_b + h*k_h + t*ldk + d
+  const float *Vp; long v_b, v_h; int ldv;      // value rows
+  const uint8_t *mask;                          // (b, N) or NULL
+  float *Opart, *Mpart, *Lpart;                 // (b, h, nsplit, Lp, DP), (b, h, nsplit, Lp) x2
+  int b, h, Lq, Lp, N, dp;                      // Lq valid query rows, Lp = Lq rounded up to 16, dp in {16,32,64,128}
+  int nsplit, chunk;                            // tokens per split (multiple of 16)
+};
+int launch_attn_core(const AttnCoreArgs &a, hipStream_t s);
+void attn_core_geometry(int b, int h, int Lp, int N, int dp, int *nsplit, int *chunk);
+
+int launch_qfold(const float *Q, int ldq_row, const float *w_k, int D, const float *gamma, float cscale,
+                 float *Qf, int b, int h, int L, int Lp, int dh, int dp, hipStream_t s);
+int launch_merge_vproj(const float *Opart, const float *Mpart, const float *Lpart, int nsplit, int b, int h,
+                       int L, int Lp, int dp, int D, const float *gamma, const float *beta, const float *w_v,
+                       int dh, float *O, int ldo, float *stats, hipStream_t s);
+int launch_merge_explicit(const float *Opart, const float *Mpart, const float *Lpart, int nsplit, int b, int h,
+                          int L, int Lp, int dp, int dh, float *O, int ldo, float *stats, hipStream_t s);
+int launch_probs(const float *Q, long q_b, long q_h, int ldq, int dp, const float *Kp, long k_b, long k_h, int ldk,
+                 const uint8_t *mask, const float *stats, float *P, int b, int h, int L, int N, hipStream_t s);
+
+// misc
+int launch_broadcast_rows(const float *src, float *dst, long n_per, int b, hipStream_t s);
+int launch_head(const float *x, int b, int L, int d, const float *nw, const float *nb, const float *w,
+                const float *bias, int out_dims, float *logits, hipStream_t s);
+int launch_pad_rows(const float *src, int ld_src, float *dst, int ld_dst, long rows, int cols, hipStream_t s);
+
+}  // namespace hn

@@ -1,0 +1,185 @@
+// K1: Fourier positional encode + concat + flatten (+ optional affine-free LayerNorm) for one modality.
+//
+// Replaces HealNet.forward :200-222 and fourier_encode :292-302 of the reference
+// (healnet/models/healnet.py).  Pure HBM-bound elementwise work: every token is read once and
+// written once; positions are a function of the token index, so no position tensor exists.
+//
+// Two kernels:
+//   encode_token_kernel : one thread per token, for narrow modalities (D <= 32: images, volumes).
+//                         Consecutive lanes own consecutive tokens, so the C-float reads and the
+//                         ld_out-float writes of a wave form one contiguous span each.
+//   encode_wave_kernel  : one 64-lane wave per token for wide modalities (tabular / patch bags,
+//                         C up to thousands): lanes stride over channels, wave-level reductions for
+//                         the LayerNorm moments.
+#include "common.h"
+
+namespace hn {
+
+struct EncGeom {
+  int n_axes;
+  int S[HN_MAX_AXES];
+  int C, F, D, ld_out;
+  long N;
+  float max_freq;
+  int fourier, normalize;
+  float eps;
+};
+
+// torch.linspace(-1, 1, S)[i] in fp32 (ATen's symmetric formulation: ascending from the start for the
+// first half, descending from the end for the second), healnet.py:212.
+__device__ __forceinline__ float axis_pos(int i, int S) {
+  if (S == 1) return -1.0f;
+  float step = __fdiv_rn(2.0f, (float)(S - 1));
+  if (i < S / 2) return __fadd_rn(-1.0f, __fmul_rn(step, (float)i));
+  return __fsub_rn(1.0f, __fmul_rn(step, (float)(S - 1 - i)));
+}
+
+// torch.linspace(1, max_freq/2, F)[f], healnet.py:296
+__device__ __forceinline__ float band_scale(int f, int F, float max_freq) {
+  float end = max_freq * 0.5f;
+  if (F == 1) return 1.0f;
+  float step = __fdiv_rn(end - 1.0f, (float)(F - 1));
+  if (f < F / 2) return __fadd_rn(1.0f, __fmul_rn(step, (float)f));
+  return __fsub_rn(end, __fmul_rn(step, (float)(F - 1 - f)));
+}
+
+__device__ __forceinline__ void token_coords(long n, const EncGeom &g, int *idx) {
+#pragma unroll
+  for (int a = HN_MAX_AXES - 1; a >= 0; --a) {
+    if (a < g.n_axes) {
+      idx[a] = (int)(n % g.S[a]);
+      n /= g.S[a];
+    } else {
+      idx[a] = 0;
+    }
+  }
+}
+
+// positional feature j (0 <= j < n_axes*(2F+1)) of a token with coordinates idx
+__device__ __forceinline__ float pos_feature(int j, const int *idx, const EncGeom &g) {
+  const int per = 2 * g.F + 1;
+  int a = j / per, w = j - a * per;
+  float p = axis_pos(idx[a], g.S[a]);
+  if (w == 2 * g.F) return p;
+  int f = (w < g.F) ? w : w - g.F;
+  float arg = __fmul_rn(__fmul_rn(p, band_scale(f, g.F, g.max_freq)), 3.14159265358979323846f);  // (p*s)*pi, :299
+  return (w < g.F) ? sinf(arg) : cosf(arg);
+}
+
+constexpr int kMaxNarrow = 32;
+
+__global__ __launch_bounds__(256) void encode_token_kernel(const float *__restrict__ data, float *__restrict__ out,
+                                                           EncGeom g, long total) {
+  long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= total) return;
+  long n = gid % g.N;
+  int idx[HN_MAX_AXES];
+  token_coords(n, g, idx);
+  float v[kMaxNarrow];
+  const float *src = data + gid * g.C;
+#pragma unroll
+  for (int c = 0; c < kMaxNarrow; ++c) {
+    float x = 0.0f;
+    if (c < g.C) x = src[c];
+    else if (c < g.D) x = pos_feature(c - g.C, idx, g);
+    v[c] = x;
+  }
+  if (g.normalize) {
+    float sum = 0.0f;
+#pragma unroll
+    for (int c = 0; c < kMaxNarrow; ++c) sum += (c < g.D) ? v[c] : 0.0f;
+    float mean = sum / (float)g.D;
+    float sq = 0.0f;
+#pragma unroll
+    for (int c = 0; c < kMaxNarrow; ++c) {
+      float d = (c < g.D) ? v[c] - mean : 0.0f;
+      sq += d * d;
+    }
+    float rstd = 1.0f / sqrtf(sq / (float)g.D + g.eps);
+#pragma unroll
+    for (int c = 0; c < kMaxNarrow; ++c) v[c] = (c < g.D) ? (v[c] - mean) * rstd : 0.0f;
+  }
+  float *dst = out + gid * (long)g.ld_out;
+  if ((g.ld_out & 3) == 0) {
+#pragma unroll
+    for (int c = 0; c < kMaxNarrow; c += 4)
+      if (c < g.ld_out) *(float4 *)(dst + c) = make_float4(v[c], v[c + 1], v[c + 2], v[c + 3]);
+  } else {
+#pragma unroll
+    for (int c = 0; c < kMaxNarrow; ++c)
+      if (c < g.ld_out) dst[c] = v[c];
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void encode_wave_kernel(const float *__restrict__ data, float *__restrict__ out,
+                                                          EncGeom g, long total) {
+  const int lane = threadIdx.x & 63;
+  long tok = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (tok >= total) return;
+  long n = tok % g.N;
+  int idx[HN_MAX_AXES];
+  token_coords(n, g, idx);
+  const float *src = data + tok * g.C;
+  float *dst = out + tok * (long)g.ld_out;
+  const int n_pos = g.D - g.C;
+  float mean = 0.0f, rstd = 1.0f;
+  if (g.normalize) {
+    float s = 0.0f;
+    for (int c = lane; c < g.C; c += 64) s += src[c];
+    for (int j = lane; j < n_pos; j += 64) s += pos_feature(j, idx, g);
+    mean = wave_sum(s) / (float)g.D;
+    float q = 0.0f;
+    for (int c = lane; c < g.C; c += 64) { float d = src[c] - mean; q += d * d; }
+    for (int j = lane; j < n_pos; j += 64) { float d = pos_feature(j, idx, g) - mean; q += d * d; }
+    rstd = 1.0f / sqrtf(wave_sum(q) / (float)g.D + g.eps);
+  }
+  for (int c = lane; c < g.C; c += 64) dst[c] = g.normalize ? (src[c] - mean) * rstd : src[c];
+  for (int j = lane; j < n_pos; j += 64) {
+    float p = pos_feature(j, idx, g);
+    dst[g.C + j] = g.normalize ? (p - mean) * rstd : p;
+  }
+  for (int c = g.D + lane; c < g.ld_out; c += 64) dst[c] = 0.0f;
+}
+
+int launch_encode(const float *data, int b, int n_axes, const int *spatial, int C, int F, float max_freq,
+                  int fourier, int normalize, float eps, float *out, int ld_out, hipStream_t s) {
+  HN_REQUIRE(data && out && spatial, HN_E_NULL, "encode: NULL pointer");
+  HN_REQUIRE(b > 0 && C > 0 && n_axes >= 1 && n_axes <= HN_MAX_AXES, HN_E_SHAPE,
+             "encode: b=%d C=%d n_axes=%d (1..%d axes supported)", b, C, n_axes, HN_MAX_AXES);
+  HN_REQUIRE(!fourier || F >= 1, HN_E_SHAPE, "encode: num_freq_bands=%d", F);
+  EncGeom g;
+  g.n_axes = n_axes;
+  g.N = 1;
+  for (int a = 0; a < HN_MAX_AXES; ++a) {
+    g.S[a] = a < n_axes ? spatial[a] : 1;
+    HN_REQUIRE(g.S[a] > 0, HN_E_SHAPE, "encode: spatial[%d]=%d", a, g.S[a]);
+    g.N *= g.S[a];
+  }
+  g.C = C;
+  g.F = F;
+  g.D = C + (fourier ? n_axes * (2 * F + 1) : 0);
+  g.ld_out = ld_out;
+  g.max_freq = max_freq;
+  g.fourier = fourier;
+  g.normalize = normalize;
+  g.eps = eps;
+  HN_REQUIRE(ld_out >= g.D, HN_E_SHAPE, "encode: ld_out=%d < D=%d", ld_out, g.D);
+  long total = (long)b * g.N;
+  if (g.D <= kMaxNarrow && ld_out <= kMaxNarrow) {
+    long blocks = ceil_div_ll(total, 256);
+    hipLaunchKernelGGL(encode_token_kernel, dim3((unsigned)blocks), dim3(256), 0, s, data, out, g, total);
+  } else {
+    long blocks = ceil_div_ll(total, 4);
+    hipLaunchKernelGGL(encode_wave_kernel, dim3((unsigned)blocks), dim3(256), 0, s, data, out, g, total);
+  }
+  HN_LAUNCH_CHECK("encode");
+  return HN_OK;
+}
+
+}  // namespace hn

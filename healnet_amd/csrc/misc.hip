@@ -1,0 +1,91 @@
+// Small support kernels: latent broadcast (healnet.py:225), classifier head (to_logits :181-185).
+#include "common.h"
+
+namespace hn {
+
+__global__ __launch_bounds__(256) void broadcast_rows_kernel(const float *__restrict__ src, float *__restrict__ dst,
+                                                             long n_per, long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+    dst[i] = src[i % n_per];
+}
+
+int launch_broadcast_rows(const float *src, float *dst, long n_per, int b, hipStream_t s) {
+  long total = n_per * b;
+  long blocks = ceil_div_ll(total, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(broadcast_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, n_per, total);
+  HN_LAUNCH_CHECK("broadcast_rows");
+  return HN_OK;
+}
+
+__global__ __launch_bounds__(256) void pad_rows_kernel(const float *__restrict__ src, int ld_src, float *__restrict__ dst,
+                                                       int ld_dst, long rows, int cols) {
+  long total = rows * ld_dst;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    long r = i / ld_dst;
+    int c = (int)(i % ld_dst);
+    dst[i] = c < cols ? src[r * ld_src + c] : 0.0f;
+  }
+}
+
+int launch_pad_rows(const float *src, int ld_src, float *dst, int ld_dst, long rows, int cols, hipStream_t s) {
+  long blocks = ceil_div_ll(rows * ld_dst, 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, ld_src, dst, ld_dst, rows, cols);
+  HN_LAUNCH_CHECK("pad_rows");
+  return HN_OK;
+}
+
+// One workgroup per sample: column means over the L latent rows -> LayerNorm(d) -> Linear(d, out).
+__global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ x, int L, int d, const float *__restrict__ nw,
+                                                   const float *__restrict__ nb, const float *__restrict__ w,
+                                                   const float *__restrict__ bias, int out_dims, float *__restrict__ logits) {
+  extern __shared__ float sm[];  // pooled[d] + 8 scratch
+  float *pooled = sm;
+  float *red = sm + d;
+  const int bi = blockIdx.x, tid = threadIdx.x;
+  const float *xb = x + (long)bi * L * d;
+  for (int c = tid; c < d; c += blockDim.x) {
+    float s = 0.0f;
+    for (int r = 0; r < L; ++r) s += xb[(long)r * d + c];
+    pooled[c] = s / (float)L;
+  }
+  __syncthreads();
+  // mean
+  float s = 0.0f;
+  for (int c = tid; c < d; c += blockDim.x) s += pooled[c];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  __syncthreads();
+  const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)d;
+  __syncthreads();
+  float q = 0.0f;
+  for (int c = tid; c < d; c += blockDim.x) { float t = pooled[c] - mean; q += t * t; }
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+  if ((tid & 63) == 0) red[tid >> 6] = q;
+  __syncthreads();
+  const float rstd = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)d + 1e-5f);
+  __syncthreads();
+  for (int c = tid; c < d; c += blockDim.x) pooled[c] = (pooled[c] - mean) * rstd * nw[c] + nb[c];
+  __syncthreads();
+  const int wave = tid >> 6, lane = tid & 63;
+  for (int o = wave; o < out_dims; o += 4) {
+    float acc = 0.0f;
+    for (int c = lane; c < d; c += 64) acc = fmaf(pooled[c], w[(long)o * d + c], acc);
+    for (int k = 32; k > 0; k >>= 1) acc += __shfl_xor(acc, k);
+    if (lane == 0) logits[(long)bi * out_dims + o] = acc + (bias ? bias[o] : 0.0f);
+  }
+}
+
+int launch_head(const float *x, int b, int L, int d, const float *nw, const float *nb, const float *w, const float *bias,
+                int out_dims, float *logits, hipStream_t s) {
+  HN_REQUIRE(x && nw && nb && w && logits, HN_E_NULL, "head: NULL pointer");
+  HN_REQUIRE(b > 0 && L > 0 && d > 0 && out_dims > 0, HN_E_SHAPE, "head: b=%d L=%d d=%d out=%d", b, L, d, out_dims);
+  size_t lds = (size_t)(d + 8) * sizeof(float);
+  HN_REQUIRE(lds <= 64 * 1024, HN_E_UNSUPPORTED, "head: l_d=%d too large", d);
+  hipLaunchKernelGGL(head_kernel, dim3(b), dim3(256), lds, s, x, L, d, nw, nb, w, bias, out_dims, logits);
+  HN_LAUNCH_CHECK("head");
+  return HN_OK;
+}
+
+}  // namespace hn

@@ -1,0 +1,182 @@
+/*
+ * healnet_hip.h -- C ABI of libhealnet_hip.so (gfx950 / MI355X).
+ *
+ * The reference (konst-int-i/healnet) has no native boundary: its hot path is the Python class
+ * surface of healnet/models/healnet.py.  This header is the boundary the MI355X build puts
+ * UNDERNEATH that surface; each entry point names the reference code it replaces (file:line are
+ * relative to the reference repository, healnet/models/healnet.py unless stated).
+ *
+ * Conventions (all entry points):
+ *   - plain C types only: raw DEVICE pointers (fp32, row-major, innermost dimension contiguous unless a
+ *     leading dimension is passed), explicit sizes, a hipStream_t passed as void*;
+ *   - return 0 on success or a negative hn_status; never throw, never exit; the message for the
+ *     last failure on the calling thread is available from hn_last_error_string();
+ *   - never allocate or free device memory: scratch comes from the caller-provided workspace whose
+ *     size the matching hn_*_workspace_bytes() returns (256-byte aligned base required);
+ *   - no global mutable state besides the thread-local error string: re-entrant across streams,
+ *     devices and threads (callable from PyTorch's autograd thread);
+ *   - all work is enqueued on `stream`; nothing synchronises the device.
+ */
+#ifndef HEALNET_HIP_H
+#define HEALNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HN_ABI_VERSION 1
+#define HN_MAX_AXES 4
+
+typedef enum hn_status {
+  HN_OK = 0,
+  HN_E_SHAPE = -1,       /* inconsistent or non-positive sizes                                   */
+  HN_E_UNSUPPORTED = -2, /* valid request the kernels do not cover (e.g. dim_head > 128)         */
+  HN_E_WORKSPACE = -3,   /* workspace NULL, misaligned or smaller than hn_*_workspace_bytes()    */
+  HN_E_HIP = -4,         /* a HIP runtime call / kernel launch failed                            */
+  HN_E_NULL = -5         /* a required pointer is NULL                                           */
+} hn_status;
+
+/* Gate of the feed-forward block: SELU (healnet.py:328-331, snn=True) or GELU (:323-326). */
+typedef enum hn_gate { HN_GATE_SELU = 0, HN_GATE_GELU = 1 } hn_gate;
+
+int hn_abi_version(void);
+const char *hn_last_error_string(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * K1  positional encode + concat + flatten            replaces HealNet.forward :200-222 and
+ *                                                     fourier_encode :292-302
+ * data (b, S_1..S_a, C) -> ctx (b, N = prod S, D = C + a*(2F+1)), data channels first, then per axis
+ * [sin(p s_0 pi) .. sin(p s_{F-1} pi), cos(..) .., p].  fourier == 0 copies the data channels only
+ * (fourier_encode_data=False).  ld_out >= D is the row pitch of ctx in floats.
+ * ------------------------------------------------------------------------------------------- */
+int hn_fourier_encode_concat(const float *data, int b, int n_axes, const int *spatial, int channels,
+                             int num_freq_bands, float max_freq, int fourier, float *ctx, int ld_out,
+                             void *stream);
+
+/* Same walk, but writes the context already LayerNorm-normalised WITHOUT affine:
+ * z = (ctx - mean_D) * rsqrt(var_D + eps), columns D..ld_out-1 zero filled.  This is the
+ * layer-independent half of PreNorm.norm_context (:316-319); gamma/beta of each layer are applied
+ * inside hn_attn_fwd (hn_attn_params.ctx_gamma / ctx_beta). */
+int hn_encode_norm(const float *data, int b, int n_axes, const int *spatial, int channels,
+                   int num_freq_bands, float max_freq, int fourier, float eps, float *z, int ld_out,
+                   void *stream);
+
+/* Row pitch hn_fusion_forward uses for the normalised context of a modality with D encoded channels
+ * when attending with `dim_head`: 16/32 for the rank-D reassociated path, else D rounded up to 4. */
+int hn_context_pitch(int D, int dim_head);
+
+/* ---------------------------------------------------------------------------------------------
+ * Attention block                                      replaces PreNorm.forward :313-321 +
+ *                                                      Attention.forward :400-426 (+ residual :236/:244)
+ * ------------------------------------------------------------------------------------------- */
+typedef struct hn_attn_params {
+  int heads, dim_head;    /* inner = heads * dim_head                                          */
+  int query_dim;          /* l_d                                                               */
+  const float *norm_w;    /* LayerNorm(query_dim) on x; NULL -> x is used as given             */
+  const float *norm_b;
+  const float *ctx_gamma; /* affine of LayerNorm(D) applied to an already normalised context;   */
+  const float *ctx_beta;  /* NULL -> context is used as given                                  */
+  const float *w_q;       /* to_q.weight      (inner, query_dim)                               */
+  const float *w_kv;      /* to_kv.weight     (2*inner, D)   rows [0,inner) = K, rest = V      */
+  const float *w_out;     /* to_out.0.weight  (query_dim, inner)                               */
+  const float *b_out;     /* to_out.0.bias    (query_dim)                                      */
+} hn_attn_params;
+
+/* y = LeakyReLU_0.01( concat_h( softmax(2 * dim_head^-1/2 * Q_h K_h^T) V_h ) W_out^T + b_out )  [+ x_in]
+ *   x_in  (b, L, query_dim); x_out may alias x_in;  residual != 0 adds the un-normalised x_in (:236).
+ *   ctx   (b, N, ld_ctx) with D valid columns, or NULL for self-attention (context = normalised x, :404).
+ *   mask  (b, N) bytes, 0 = masked out (sim <- -FLT_MAX, :411-415), or NULL.
+ *   stats optional (b, heads, L, 2): per row {max of scaled logits in log2 units, sum of 2^(s-max)};
+ *         with it hn_attn_probs re-creates Attention.attn_weights (:420) on demand.
+ * The kernels pick the rank-D reassociated path when ld_ctx is a hn_context_pitch() pitch of 16/32
+ * and D < dim_head, and the explicit K/V path otherwise. */
+int hn_attn_fwd(const hn_attn_params *p, const float *x_in, float *x_out, int residual,
+                const float *ctx, int ld_ctx, int b, int L, int N, int D, const uint8_t *mask,
+                float *stats, void *workspace, size_t workspace_bytes, void *stream);
+size_t hn_attn_workspace_bytes(const hn_attn_params *p, int has_ctx, int ld_ctx, int b, int L, int N, int D);
+
+/* Attention.attn_weights (:420), shape (b*heads, L, N), recomputed from x_in (the block INPUT) and stats. */
+int hn_attn_probs(const hn_attn_params *p, const float *x_in, const float *ctx, int ld_ctx, int b, int L,
+                  int N, int D, const uint8_t *mask, const float *stats, float *probs, void *workspace,
+                  size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Gated feed-forward block                             replaces PreNorm :313-321 + FeedForward :339-351
+ * x_out = ( a * gate(g) ) W2^T + b2 [+ x_in],  [a|g] = LN(x_in) W1^T + b1
+ * ------------------------------------------------------------------------------------------- */
+typedef struct hn_ff_params {
+  int dim;             /* l_d; hidden = 4*dim, W1 (8*dim, dim), W2 (dim, 4*dim)                  */
+  int gate;            /* hn_gate                                                               */
+  const float *norm_w; /* NULL -> no LayerNorm (bare FeedForward)                               */
+  const float *norm_b;
+  const float *w1, *b1, *w2, *b2;
+} hn_ff_params;
+
+int hn_ff_fwd(const hn_ff_params *p, const float *x_in, float *x_out, int residual, int rows,
+              void *workspace, size_t workspace_bytes, void *stream);
+size_t hn_ff_workspace_bytes(const hn_ff_params *p, int rows);
+
+/* ---------------------------------------------------------------------------------------------
+ * Head                                                 replaces to_logits :181-185
+ * logits = LN(mean_n x) W^T + bias ;  x (b, L, d) -> (b, out_dims)
+ * ------------------------------------------------------------------------------------------- */
+int hn_head_fwd(const float *x, int b, int L, int d, const float *norm_w, const float *norm_b,
+                const float *w, const float *bias, int out_dims, float *logits, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Whole fusion forward                                 replaces HealNet.forward :190-250
+ * ------------------------------------------------------------------------------------------- */
+typedef struct hn_modality_input {
+  const float *data;         /* (b, S_1..S_a, C) or NULL for a missing modality (Appendix B-1)   */
+  int spatial[HN_MAX_AXES];  /* S_1..S_a (a = num_spatial_axes[m])                               */
+} hn_modality_input;
+
+typedef struct hn_model {
+  int n_modalities, depth, l_c, l_d;
+  int self_per_cross_attn;     /* 0 or 1 (>= 2 fails in the reference, :242)                     */
+  int final_classifier_head;   /* 0 -> forward returns the latent array                          */
+  int out_dims;
+  int num_freq_bands;
+  float max_freq;
+  int fourier_encode_data;
+  const int *channel_dims;       /* [M] */
+  const int *num_spatial_axes;   /* [M] */
+  const float *latents;          /* (l_c, l_d) */
+  const hn_attn_params *cross_attn; /* [depth * M], index layer*M + m                           */
+  const hn_ff_params *cross_ff;     /* [depth * M]                                              */
+  const hn_attn_params *self_attn;  /* [depth]  (unused when self_per_cross_attn == 0)           */
+  const hn_ff_params *self_ff;      /* [depth]                                                  */
+  const float *head_norm_w, *head_norm_b, *head_w, *head_b;
+} hn_model;
+
+/* Optional timing hooks: when non-NULL, hn_fusion_forward records ev_start[i] / ev_stop[i]
+ * (hipEvent_t, created by the caller) on `stream` around the i-th launch of the dominant kernel
+ * (the split-KV attention kernel of each cross-attention block whose context has the most tokens),
+ * for i < n_events.  n_recorded returns how many pairs were recorded. */
+typedef struct hn_profile {
+  void **ev_start;
+  void **ev_stop;
+  int n_events;
+  int n_recorded;
+} hn_profile;
+
+/* out: (b, out_dims) logits, or (b, l_c, l_d) when return_embeddings != 0 or the model has no head.
+ * skip_self_on_missing reproduces the reference's verbose=True quirk (:229-232): a missing
+ * modality then also skips that iteration's latent self block.
+ * attn_stats: optional array of depth*(M+1) pointers (layer-major: cross_0..cross_{M-1}, self), each
+ *             NULL or a (b, heads, l_c, 2) buffer receiving that block's softmax statistics.
+ * x_trace:    optional; receives the latent array (b, l_c, l_d) fed INTO every attention block
+ *             in the same depth*(M+1) order (needed by hn_attn_probs); NULL entries are skipped. */
+int hn_fusion_forward(const hn_model *model, const hn_modality_input *inputs, int b, const uint8_t *mask,
+                      int skip_self_on_missing, int return_embeddings, float *out, float **attn_stats,
+                      float **x_trace, void *workspace, size_t workspace_bytes, void *stream,
+                      hn_profile *profile);
+size_t hn_fusion_workspace_bytes(const hn_model *model, const hn_modality_input *inputs, int b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HEALNET_HIP_H */

@@ -1,0 +1,142 @@
+"""GPU: whole-model parity of the fused forward (hn_fusion_forward) against reference-generated
+fixtures, the CPU oracle, and size-independent properties at the BASELINE configs' full sizes."""
+import pytest
+import torch
+
+from conftest import assert_close, load_golden, rel_err
+from oracle import healnet_cpu as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-3          # BASELINE.json north_star: 1e-3 rel fp32 on identical inputs
+
+
+@pytest.fixture(scope="module")
+def hn():
+    import healnet_amd
+    return healnet_amd
+
+
+G5 = ["m1_d1", "m2_d3", "m3_d3", "m2_d3_tied", "m2_d2_noself", "m2_d2_nofourier", "m2_d2_gelu", "m2_d2_nohead",
+      "m2_d2_bands4", "m2_d2_masked"]
+
+
+@pytest.mark.parametrize("name", G5)
+def test_tiny_models_match_reference_fixtures(hn, name, manifest):
+    g = load_golden("g5_" + name)
+    kw = manifest["g5_" + name]["kwargs"]
+    model = hn.HealNet(**kw).eval()
+    model.load_state_dict({k[4:]: v for k, v in g.items() if k.startswith("sd::")}, strict=True)
+    model.to(DEV)
+    ins = [g[f"in{i}"].to(DEV) for i in range(kw["n_modalities"])]
+    mask = g["mask"].to(DEV) if "mask" in g else None
+    y = model(list(ins), mask=mask)
+    assert_close(y.cpu(), g["logits"], rel=2e-4, what=name + ".logits")
+    if "emb" in g:
+        assert_close(model(list(ins), mask=mask, return_embeddings=True).cpu(), g["emb"], rel=2e-4, what=name + ".emb")
+    if "attn0" in g:
+        model(list(ins), mask=mask)
+        got = model.get_attention_weights()
+        i = 0
+        while f"attn{i}" in g:
+            assert got[i].shape == g[f"attn{i}"].shape
+            assert_close(got[i].cpu(), g[f"attn{i}"], rel=5e-4, floor=1e-3, what=f"{name}.attn{i}")
+            i += 1
+        assert i == len(got)
+    if "logits_missing1" in g:
+        miss = [ins[0], None] + ins[2:]
+        assert_close(model(list(miss)).cpu(), g["logits_missing1"], rel=2e-4, what=name + ".missing1")
+        assert_close(model(list(miss), verbose=True).cpu(), g["logits_missing1_verbose"], rel=2e-4, what=name + ".missing1v")
+        if kw["n_modalities"] == 2:
+            assert_close(model([ins[0]]).cpu(), g["logits_missing1"], rel=2e-4, what=name + ".short-list")
+    if "logits_missing0" in g:
+        assert_close(model([None, ins[1]]).cpu(), g["logits_missing0"], rel=2e-4, what=name + ".missing0")
+
+
+@pytest.mark.parametrize("name", ["cfg1", "cfg3s", "cfg4", "tuned"])
+def test_default_size_configs_match_reference_fixtures(hn, name, manifest):
+    """BASELINE shapes, default hyper-parameters, closed-form weights; expected logits / embeddings /
+    latent-mean attention rows were produced by the reference itself."""
+    m = manifest["g6_" + name]
+    cfg = O.FusionConfig(**m["kwargs"])
+    model = hn.HealNet(**m["kwargs"]).eval()
+    model.load_state_dict(O.filler_state_dict(cfg, gain=m["gain"]), strict=True)
+    model.to(DEV)
+    ins = [O.filler_input(s, 20 + i).to(DEV) for i, s in enumerate(m["shapes"])]
+    g = load_golden("g6_" + name)
+    y = model(list(ins))
+    assert_close(y.cpu(), g["logits"], rel=TOL, what=name + ".logits")
+    assert_close(model(list(ins), return_embeddings=True).cpu(), g["emb"], rel=TOL, what=name + ".emb")
+    big = int(g["attn_mean_index"])
+    model(list(ins))
+    p = model.layers[0][2 * big].fn.attn_weights
+    assert_close(p.mean(dim=1)[:, :4096].cpu(), g["attn_mean"], rel=TOL, floor=1e-2, what=name + ".attn_mean")
+
+
+def test_kat0_seed_route(hn, manifest):
+    """torch.manual_seed(0) model + seed-continued torch.rand inputs -> the reference's logits (KAT-0)."""
+    g = load_golden("kat0")
+    torch.manual_seed(0)
+    model = hn.HealNet(**manifest["kat0"]["kwargs"]).eval()
+    tab = torch.rand(4, 1, 2000)
+    img = torch.rand(4, 224, 224, 3)
+    model.to(DEV)
+    y = model([tab.to(DEV), img.to(DEV)]).cpu()
+    assert_close(y, g["logits"], rel=TOL, what="kat0.logits")
+    want_row0 = torch.tensor([1.24044466, 0.22287285, 0.77036822, -0.45615000])
+    assert (y[0] - want_row0).abs().max() < 1e-3
+    emb = model([tab.to(DEV), img.to(DEV)], return_embeddings=True)
+    assert abs(float(emb.mean()) - float(g["emb_mean"])) < 1e-4
+    assert_close(emb[0, :4, :8].cpu(), g["emb_row0"], rel=TOL, what="kat0.emb")
+
+
+def _cfg2_model(hn, seed=0):
+    torch.manual_seed(seed)
+    return hn.HealNet(n_modalities=2, channel_dims=[2000, 3], num_spatial_axes=[1, 2], out_dims=4).eval().to(DEV)
+
+
+def test_cfg2_full_size_properties(hn):
+    """b=32 at the headline config: (i) bitwise determinism, (ii) every sample's logits equal the
+    logits of that sample run in a smaller batch (no cross-sample coupling; different split-KV
+    geometry), (iii) sample permutation equivariance, (iv) oracle parity on a 2-sample slice."""
+    model = _cfg2_model(hn)
+    gen = torch.Generator().manual_seed(1234)
+    tab = torch.rand(32, 1, 2000, generator=gen)
+    img = torch.rand(32, 224, 224, 3, generator=gen)
+    tab_d, img_d = tab.to(DEV), img.to(DEV)
+    y1 = model([tab_d, img_d])
+    y2 = model([tab_d, img_d])
+    assert torch.equal(y1, y2)
+    y_small = torch.cat([model([tab_d[i:i + 4], img_d[i:i + 4]]) for i in range(0, 32, 4)])
+    assert_close(y_small.cpu(), y1.cpu(), rel=1e-4, what="batch-slicing")
+    perm = torch.randperm(32, generator=gen)
+    y_perm = model([tab_d[perm.to(DEV)], img_d[perm.to(DEV)]])
+    assert_close(y_perm.cpu(), y1.cpu()[perm], rel=1e-5, what="permutation")
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    cfg = O.FusionConfig(n_modalities=2, channel_dims=[2000, 3], num_spatial_axes=[1, 2], out_dims=4)
+    with torch.no_grad():
+        want = O.fusion_forward(sd, cfg, [tab[:2], img[:2]])
+    assert_close(y1[:2].cpu(), want, rel=TOL, what="cfg2 vs oracle")
+
+
+def test_list_mutation_compat_flag(hn):
+    model = hn.HealNet(n_modalities=2, channel_dims=[20, 3], num_spatial_axes=[1, 2], out_dims=3, l_c=8, l_d=16, x_heads=2,
+                       l_heads=2, cross_dim_head=4, latent_dim_head=4).eval().to(DEV)
+    tab, img = torch.rand(2, 1, 20).to(DEV), torch.rand(2, 6, 5, 3).to(DEV)
+    lst = [tab, img]
+    model(lst)
+    assert lst[0] is tab and lst[1] is img                 # default: caller's list untouched
+    model.compat_mutate_inputs = True
+    model(lst)
+    assert lst[0].shape == (2, 1, 25) and lst[1].shape == (2, 30, 13)      # reference behaviour (:222)
+    with pytest.raises(AssertionError):
+        model(lst)                                                          # second call fails the axis check, as in the reference
+
+
+def test_shape_errors_raise_instead_of_being_swallowed(hn):
+    model = hn.HealNet(n_modalities=2, channel_dims=[20, 3], num_spatial_axes=[1, 2], out_dims=3, l_c=8, l_d=16, x_heads=2,
+                       l_heads=2, cross_dim_head=4, latent_dim_head=4).eval().to(DEV)
+    with pytest.raises(ValueError):
+        model([torch.rand(2, 6, 5, 3).to(DEV)])            # image in the tabular slot (main.py:536-538 pattern)
+    with pytest.raises(AssertionError):
+        model([torch.rand(2, 20).to(DEV), None])

@@ -1,0 +1,163 @@
+"""GPU: per-op parity of the HIP kernels (through the C ABI) against the committed golden fixtures
+(generated from the reference) and against the CPU oracle on seeded inputs."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import assert_close, load_golden, rel_err
+from oracle import healnet_cpu as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def hn():
+    import healnet_amd
+    return healnet_amd
+
+
+# ---------------------------------------------------------------------------------------------- K1
+def test_encode_matches_reference_fixtures(hn):
+    g = load_golden("g2_preprocess")
+    for name in ("tab", "img", "vol", "one"):
+        got = hn.fourier_encode_concat(g[name + "_in"].to(DEV)).cpu()
+        assert_close(got, g[name + "_enc"], rel=2e-6, what=f"encode[{name}]")
+
+
+@pytest.mark.parametrize("shape,bands,maxf", [((2, 224, 224, 3), 2, 10.0), ((3, 1, 2000), 2, 10.0),
+                                              ((2, 257, 768), 2, 10.0), ((1, 5, 7, 9, 2), 4, 2.0),
+                                              ((2, 3, 4, 5, 6, 2), 2, 10.0), ((1, 1, 1), 1, 10.0)])
+def test_encode_vs_oracle(hn, shape, bands, maxf):
+    x = torch.rand(*shape, generator=torch.Generator().manual_seed(3))
+    want = O.encode_modality(x, bands, maxf, True)
+    got = hn.fourier_encode_concat(x.to(DEV), bands, maxf).cpu()
+    assert_close(got, want, rel=3e-6, what=f"encode{shape}")
+    got2 = hn.fourier_encode_concat(x.to(DEV), bands, maxf, fourier_encode_data=False).cpu()
+    assert torch.equal(got2, x.reshape(shape[0], -1, shape[-1]))
+
+
+def test_encode_norm_is_affine_free_layernorm(hn):
+    from healnet_amd.healnet import _normalise_context
+    for shape in [(2, 100, 13), (2, 7, 773), (3, 1, 2005), (1, 33, 18)]:
+        ctx = torch.randn(*shape, generator=torch.Generator().manual_seed(1)) * 3 + 1
+        pitch = {13: 16, 18: 32, 773: 776, 2005: 2008}[shape[-1]]
+        z = _normalise_context(ctx.to(DEV), pitch).cpu()
+        want = F.layer_norm(ctx, (shape[-1],))
+        assert_close(z[..., : shape[-1]], want, rel=2e-5, what=f"norm{shape}")
+        assert (z[..., shape[-1]:] == 0).all()
+
+
+# ------------------------------------------------------------------------------------------ attention
+def _attention_from_golden(hn, g, name, c):
+    att = hn.Attention(c["qd"], c["cd"], heads=c["heads"], dim_head=c["dh"]).to(DEV)
+    with torch.no_grad():
+        att.to_q.weight.copy_(g[name + "_wq"])
+        att.to_kv.weight.copy_(g[name + "_wkv"])
+        att.to_out[0].weight.copy_(g[name + "_wo"])
+        att.to_out[0].bias.copy_(g[name + "_bo"])
+    return att
+
+
+def test_attention_matches_reference_fixtures(hn, manifest):
+    g = load_golden("g3_attention")
+    for name, c in manifest["g3_attention"]["cases"].items():
+        att = _attention_from_golden(hn, g, name, c)
+        ctx = g.get(name + "_ctx")
+        mask = g.get(name + "_mask")
+        y = att(g[name + "_x"].to(DEV), context=None if ctx is None else ctx.to(DEV),
+                mask=None if mask is None else mask.to(DEV))
+        assert_close(y.cpu(), g[name + "_y"], rel=1e-4, what=f"attention[{name}].y")
+        p = att.attn_weights
+        assert p.shape == g[name + "_p"].shape
+        assert_close(p.cpu(), g[name + "_p"], rel=1e-4, floor=1e-4, what=f"attention[{name}].p")
+
+
+@pytest.mark.parametrize("b,L,N,D,heads,dh", [(2, 128, 5000, 13, 8, 64), (1, 128, 777, 18, 8, 64), (2, 25, 300, 96, 1, 63),
+                                              (2, 17, 65, 40, 4, 27), (1, 128, 4096, 773, 8, 64), (3, 128, 1, 2005, 8, 64),
+                                              (2, 16, 33, 12, 2, 103), (2, 256, 1, 2189, 8, 64)])
+def test_prenorm_cross_attention_vs_oracle(hn, b, L, N, D, heads, dh):
+    gen = torch.Generator().manual_seed(b * 1000 + N)
+    qd = 128 if L == 128 else 32
+    blk = hn.PreNorm(qd, hn.Attention(qd, D, heads=heads, dim_head=dh), context_dim=D).to(DEV)
+    with torch.no_grad():
+        for p_ in blk.parameters():
+            if p_.dim() == 1:
+                p_.add_(0.2 * torch.randn(p_.shape, generator=gen).to(DEV))
+        blk.fn.to_q.weight.mul_(2.0)
+        blk.fn.to_kv.weight.mul_(2.0)
+    x = torch.randn(b, L, qd, generator=gen)
+    ctx = torch.rand(b, N, D, generator=gen) * 2
+    sd = {k: v.detach().cpu() for k, v in blk.state_dict().items()}
+    xn = O.layer_norm(x, sd["norm.weight"], sd["norm.bias"])
+    cn = O.layer_norm(ctx, sd["norm_context.weight"], sd["norm_context.bias"])
+    want, pw = O.attention(xn, cn, sd["fn.to_q.weight"], sd["fn.to_kv.weight"], sd["fn.to_out.0.weight"],
+                           sd["fn.to_out.0.bias"], heads, return_weights=True)
+    got = blk(x.to(DEV), context=ctx.to(DEV))
+    assert_close(got.cpu(), want, rel=2e-4, what="cross.y")
+    if N <= 5000:
+        assert_close(blk.fn.attn_weights.cpu(), pw, rel=5e-4, floor=1e-3, what="cross.p")
+
+
+def test_forced_softmax_rescale_branch(hn):
+    """One key far above the rest, placed late in the token stream: the lazy-rescale branch of the
+    split-KV kernel must fire mid-stream (cdna guide §5.4 rule 26)."""
+    gen = torch.Generator().manual_seed(11)
+    b, L, N, D, heads, dh = 1, 32, 3000, 13, 2, 64
+    att = hn.Attention(16, D, heads=heads, dim_head=dh).to(DEV)
+    x = torch.randn(b, L, 16, generator=gen)
+    ctx = torch.randn(b, N, D, generator=gen) * 0.2
+    ctx[0, 2500] = 25.0 * torch.sign(torch.randn(D, generator=gen))
+    ctx[0, 100] = -18.0
+    with torch.no_grad():
+        att.to_q.weight.mul_(4.0)
+    sd = {k: v.detach().cpu() for k, v in att.state_dict().items()}
+    want, pw = O.attention(x, ctx, sd["to_q.weight"], sd["to_kv.weight"], sd["to_out.0.weight"], sd["to_out.0.bias"], heads,
+                           return_weights=True)
+    assert pw.max() > 0.5          # the spike really dominates some rows
+    ctx16 = torch.zeros(b, N, 16)
+    ctx16[..., :D] = ctx
+    got = att(x.to(DEV), context=ctx.to(DEV))
+    assert_close(got.cpu(), want, rel=2e-4, what="spike.y")
+
+
+def test_self_attention_block_vs_oracle(hn):
+    gen = torch.Generator().manual_seed(5)
+    blk = hn.PreNorm(128, hn.Attention(128, heads=8, dim_head=64)).to(DEV)
+    x = torch.randn(4, 128, 128, generator=gen) * 1.5
+    sd = {k: v.detach().cpu() for k, v in blk.state_dict().items()}
+    xn = O.layer_norm(x, sd["norm.weight"], sd["norm.bias"])
+    want = O.attention(xn, None, sd["fn.to_q.weight"], sd["fn.to_kv.weight"], sd["fn.to_out.0.weight"], sd["fn.to_out.0.bias"], 8)
+    got = blk(x.to(DEV))
+    assert_close(got.cpu(), want, rel=2e-4, what="self.y")
+
+
+def test_fully_masked_row_is_nan_like_reference(hn):
+    att = hn.Attention(16, 8, heads=2, dim_head=8).to(DEV)
+    x = torch.randn(1, 4, 16)
+    ctx = torch.randn(1, 6, 8)
+    mask = torch.zeros(1, 6, dtype=torch.bool)
+    y = att(x.to(DEV), context=ctx.to(DEV), mask=mask.to(DEV))
+    assert torch.isnan(y).all()
+
+
+# ------------------------------------------------------------------------------------------ feed-forward / head
+def test_feedforward_matches_reference_fixtures(hn):
+    g = load_golden("g4_feedforward")
+    for tag, snn in (("selu", True), ("gelu", False)):
+        ffn = hn.FeedForward(16, snn=snn).to(DEV)
+        with torch.no_grad():
+            ffn.net[0].weight.copy_(g[tag + "_w1"]); ffn.net[0].bias.copy_(g[tag + "_b1"])
+            ffn.net[2].weight.copy_(g[tag + "_w2"]); ffn.net[2].bias.copy_(g[tag + "_b2"])
+        assert_close(ffn(g[tag + "_x"].to(DEV)).cpu(), g[tag + "_y"], rel=1e-5, what="ff." + tag)
+
+
+@pytest.mark.parametrize("dim,rows", [(128, 4096), (119, 75), (16, 1)])
+def test_prenorm_feedforward_vs_oracle(hn, dim, rows):
+    gen = torch.Generator().manual_seed(dim)
+    blk = hn.PreNorm(dim, hn.FeedForward(dim, snn=True)).to(DEV)
+    x = torch.randn(1, rows, dim, generator=gen) * 2
+    sd = {k: v.detach().cpu() for k, v in blk.state_dict().items()}
+    want = O.feed_forward(O.layer_norm(x, sd["norm.weight"], sd["norm.bias"]), sd["fn.net.0.weight"], sd["fn.net.0.bias"],
+                          sd["fn.net.2.weight"], sd["fn.net.2.bias"], True)
+    assert_close(blk(x.to(DEV)).cpu(), want, rel=1e-4, what="prenorm.ff")

@@ -1,0 +1,130 @@
+"""CPU: host-side logic of the drop-in package (no compute): constructor / state_dict / RNG-order
+parity with the reference, error behaviour, and the C-ABI library's exported symbols."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, ROOT
+from healnet_amd import Attention, HealNet, MMDataset, _capi
+from oracle import healnet_cpu as O
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "healnet_hip.h")).read()
+    declared = set(re.findall(r"\b(hn_[a-z_0-9]+)\s*\(", header))
+    declared -= {"hn_status", "hn_gate"}
+    assert declared == set(_capi.SIGNATURES), declared ^ set(_capi.SIGNATURES)
+    lib = _capi.lib()                      # raises if the .so is missing: build() must have run
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.hn_abi_version() == 1
+    assert lib.hn_context_pitch(13, 64) == 16 and lib.hn_context_pitch(18, 64) == 32
+    assert lib.hn_context_pitch(773, 64) == 776 and lib.hn_context_pitch(2005, 64) == 2008
+    assert lib.hn_context_pitch(20, 16) == 20          # rank-D path would not pay: dp 32 > dim_head 16
+
+
+def test_error_codes_without_gpu():
+    lib = _capi.lib()
+    p = _capi.AttnParams(heads=8, dim_head=200, query_dim=128)
+    assert lib.hn_attn_workspace_bytes(ctypes.byref(p), 1, 16, 2, 128, 100, 13) == 0
+    assert b"dim_head" in lib.hn_last_error_string()
+    p = _capi.AttnParams(heads=8, dim_head=64, query_dim=128)
+    need = lib.hn_attn_workspace_bytes(ctypes.byref(p), 1, 16, 32, 128, 50176, 13)
+    assert 0 < need < 200 << 20
+    f = _capi.FFParams(dim=128, gate=0)
+    assert lib.hn_ff_workspace_bytes(ctypes.byref(f), 4096) == 4096 * 512 * 4
+    # NULL pointers are reported, not dereferenced
+    rc = lib.hn_head_fwd(None, 1, 1, 1, None, None, None, None, 1, None, None)
+    assert rc == -5
+
+
+def test_constructor_assertions_match_reference():
+    with pytest.raises(AssertionError):
+        HealNet(n_modalities=1, channel_dims=[2189, 100], num_spatial_axes=[1, 1], out_dims=4)   # tests/test_healnet.py:63-67
+    with pytest.raises(AssertionError):
+        HealNet(n_modalities=2, channel_dims=[3], num_spatial_axes=[1], out_dims=4)
+
+
+def _key_sums(model):
+    sd = model.state_dict()
+    keys = sorted(sd.keys())
+    return keys, np.array([float(sd[k].double().sum()) for k in keys]), np.array([float(sd[k].double().abs().sum()) for k in keys])
+
+
+def test_seeded_init_is_bit_compatible_with_reference(manifest):
+    """Same RNG consumption order as the reference constructor (a1): identical per-key checksums."""
+    g = load_golden("kat0")
+    torch.manual_seed(0)
+    model = HealNet(**manifest["kat0"]["kwargs"])
+    keys, sums, abssums = _key_sums(model)
+    assert keys == manifest["kat0"]["state_keys"]
+    assert len(keys) == 125 and sum(p.numel() for p in model.parameters()) == 9587024
+    np.testing.assert_allclose(sums, g["key_sums"].numpy(), rtol=0, atol=1e-9)
+    np.testing.assert_allclose(abssums, g["key_abssums"].numpy(), rtol=0, atol=1e-9)
+    assert torch.allclose(model.latents[0, :3], torch.tensor([-1.12583983, -1.15236020, -0.25057858]))
+
+
+@pytest.mark.parametrize("tag", ["tied", "m3", "noself"])
+def test_init_variants_keys_and_tying(tag, manifest):
+    m = manifest["kat_init_" + tag]
+    g = load_golden("kat_init_" + tag)
+    torch.manual_seed(5)
+    model = HealNet(**m["kwargs"])
+    keys, sums, abssums = _key_sums(model)
+    assert keys == m["state_keys"]
+    np.testing.assert_allclose(sums, g["key_sums"].numpy(), atol=1e-9)
+    np.testing.assert_allclose(abssums, g["key_abssums"].numpy(), atol=1e-9)
+    assert sum(p.numel() for p in model.parameters()) == m["n_params"]
+    sd = model.state_dict()
+    groups = {}
+    for k in keys:
+        groups.setdefault(sd[k].data_ptr(), []).append(k)
+    mine = sorted(sorted(v) for v in groups.values() if len(v) > 1)
+    assert mine == sorted(sorted(v) for v in m["shared_groups"])
+
+
+def test_state_dict_roundtrip_with_oracle_layout():
+    kw = dict(n_modalities=2, channel_dims=[20, 3], num_spatial_axes=[1, 2], out_dims=3, l_c=8, l_d=16, x_heads=2,
+              l_heads=2, cross_dim_head=4, latent_dim_head=4)
+    model = HealNet(**kw)
+    shapes = O.state_dict_shapes(O.FusionConfig(**kw))
+    sd = model.state_dict()
+    assert set(sd) == set(shapes)
+    for k, s in shapes.items():
+        assert tuple(sd[k].shape) == tuple(s), k
+    model.load_state_dict(O.filler_state_dict(O.FusionConfig(**kw)), strict=True)
+
+
+def test_cpu_tensors_are_rejected_loudly():
+    model = HealNet(n_modalities=1, channel_dims=[4], num_spatial_axes=[1], out_dims=2, l_c=4, l_d=8, x_heads=1,
+                    l_heads=1, cross_dim_head=4, latent_dim_head=4).eval()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model([torch.rand(2, 3, 4)])
+    att = Attention(8, 5, heads=2, dim_head=4)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        att(torch.rand(1, 3, 8), context=torch.rand(1, 4, 5))
+
+
+def test_unsupported_modes_raise():
+    m = HealNet(n_modalities=1, channel_dims=[4], num_spatial_axes=[1], out_dims=2, l_c=4, l_d=8, x_heads=1, l_heads=1,
+                cross_dim_head=4, latent_dim_head=4, attn_dropout=0.1)
+    m.train()
+    with pytest.raises(NotImplementedError):
+        m([torch.rand(2, 3, 4)])
+    m2 = HealNet(n_modalities=1, channel_dims=[4], num_spatial_axes=[1], out_dims=2, l_c=4, l_d=8, x_heads=1, l_heads=1,
+                 cross_dim_head=4, latent_dim_head=4, self_per_cross_attn=2).eval()
+    with pytest.raises(ValueError):
+        m2([torch.rand(2, 3, 4)])
+
+
+def test_mmdataset_semantics():
+    a, b_ = torch.arange(6).reshape(3, 2), torch.arange(12).reshape(3, 4)
+    ds = MMDataset([a, b_])
+    assert len(ds) == 3 and torch.equal(ds[1][0], a[1]) and torch.equal(ds[1][1], b_[1])
+    ds2 = MMDataset([a, b_], target=torch.tensor([7, 8, 9]))
+    sample, y = ds2[2]
+    assert int(y) == 9 and torch.equal(sample[1], b_[2])
