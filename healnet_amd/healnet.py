@@ -411,14 +411,17 @@ class HealNet(nn.Module):
         inputs = (_capi.ModalityInput * M)()
         held: List[Optional[torch.Tensor]] = [None] * M
         b = None
+        for i in range(M):                    # the reference's sanity check (:206-208), all modalities first
+            if i in missing_idx:
+                continue
+            assert tensors[i].dim() - 2 == self.input_axes[i], (f'input data for modality {i + 1} must hav'
+                                                                f' the same number of axis as the input axis parameter')
         for i in range(M):
             if i in missing_idx:
                 continue
             data = tensors[i]
             _require_gpu(data, f"modality {i + 1}")
             bb, *axis, ch = data.shape
-            assert len(axis) == self.input_axes[i], (f'input data for modality {i + 1} must hav'
-                                                     f' the same number of axis as the input axis parameter')
             if ch != self.input_channels[i]:
                 raise ValueError(f"modality {i + 1}: expected {self.input_channels[i]} channels, got {ch} (the reference "
                                  "would silently skip every block of this modality, Appendix B-7)")

@@ -43,8 +43,9 @@ def rel_err(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
-def assert_close(a, b, rel=1e-3, floor=1e-5, what=""):
-    """max-norm relative check plus an elementwise check with an absolute floor."""
+def assert_close(a, b, rel=1e-3, floor=1e-4, abs_floor=0.0, what=""):
+    """Two checks: (i) max-norm relative error <= rel; (ii) elementwise |a-b| <= rel*|b| + floor*max|b| + abs_floor.
+    BASELINE.md §3's logits criterion is rel=1e-3 with abs_floor=1e-5 (pass floor=0 for exactly that)."""
     a = a.double().cpu()
     b = b.double().cpu()
     assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
@@ -52,5 +53,5 @@ def assert_close(a, b, rel=1e-3, floor=1e-5, what=""):
     e = rel_err(a, b)
     assert e <= rel, f"{what}: max-norm rel err {e:.3e} > {rel:.1e}"
     scale = b.abs().max().clamp_min(1e-30)
-    elem = ((a - b).abs() / (b.abs() + floor * scale + 1e-30)).max()
-    assert float(elem) <= 50 * rel, f"{what}: elementwise rel err {float(elem):.3e}"
+    excess = ((a - b).abs() - (rel * b.abs() + floor * scale + abs_floor)).max()
+    assert float(excess) <= 0, f"{what}: elementwise criterion violated by {float(excess):.3e} (scale {float(scale):.3e})"

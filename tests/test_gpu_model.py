@@ -40,7 +40,7 @@ def test_tiny_models_match_reference_fixtures(hn, name, manifest):
         i = 0
         while f"attn{i}" in g:
             assert got[i].shape == g[f"attn{i}"].shape
-            assert_close(got[i].cpu(), g[f"attn{i}"], rel=5e-4, floor=1e-3, what=f"{name}.attn{i}")
+            assert_close(got[i].cpu(), g[f"attn{i}"], rel=5e-4, what=f"{name}.attn{i}")
             i += 1
         assert i == len(got)
     if "logits_missing1" in g:
@@ -65,12 +65,12 @@ def test_default_size_configs_match_reference_fixtures(hn, name, manifest):
     ins = [O.filler_input(s, 20 + i).to(DEV) for i, s in enumerate(m["shapes"])]
     g = load_golden("g6_" + name)
     y = model(list(ins))
-    assert_close(y.cpu(), g["logits"], rel=TOL, what=name + ".logits")
+    assert_close(y.cpu(), g["logits"], rel=TOL, floor=0.0, abs_floor=1e-5, what=name + ".logits")
     assert_close(model(list(ins), return_embeddings=True).cpu(), g["emb"], rel=TOL, what=name + ".emb")
     big = int(g["attn_mean_index"])
     model(list(ins))
     p = model.layers[0][2 * big].fn.attn_weights
-    assert_close(p.mean(dim=1)[:, :4096].cpu(), g["attn_mean"], rel=TOL, floor=1e-2, what=name + ".attn_mean")
+    assert_close(p.mean(dim=1)[:, :4096].cpu(), g["attn_mean"], rel=TOL, floor=1e-3, what=name + ".attn_mean")
 
 
 def test_kat0_seed_route(hn, manifest):
@@ -137,6 +137,6 @@ def test_shape_errors_raise_instead_of_being_swallowed(hn):
     model = hn.HealNet(n_modalities=2, channel_dims=[20, 3], num_spatial_axes=[1, 2], out_dims=3, l_c=8, l_d=16, x_heads=2,
                        l_heads=2, cross_dim_head=4, latent_dim_head=4).eval().to(DEV)
     with pytest.raises(ValueError):
-        model([torch.rand(2, 6, 5, 3).to(DEV)])            # image in the tabular slot (main.py:536-538 pattern)
+        model([torch.rand(2, 7, 33).to(DEV)])              # patch bag in the tabular slot (main.py:536-538 pattern)
     with pytest.raises(AssertionError):
         model([torch.rand(2, 20).to(DEV), None])
