@@ -32,7 +32,7 @@ static inline int round16(int v) { return (v + 15) / 16 * 16; }
 // ------------------------------------------------------------------------------------------------
 struct AttnPlan {
   int heads, dh, inner, dhp, Lp, N, D, dp;
-  bool rank_d, self_attn;
+  bool rank_d, self_attn, ones;
   int nsplit, chunk;
   float cscale;
   // workspace carve
@@ -57,6 +57,7 @@ static int plan_attn(const hn_attn_params *p, bool has_ctx, int ld_ctx, int b, i
   HN_REQUIRE(pl->N > 0 && pl->D > 0, HN_E_SHAPE, "attn: N=%d D=%d", pl->N, pl->D);
   HN_REQUIRE(!has_ctx || ld_ctx >= D, HN_E_SHAPE, "attn: ld_ctx=%d < D=%d", ld_ctx, D);
   pl->rank_d = has_ctx && (ld_ctx == 16 || ld_ctx == 32) && D <= ld_ctx && ld_ctx <= pl->dhp;
+  pl->ones = pl->rank_d && D <= ld_ctx - 1;
   pl->dp = pl->rank_d ? ld_ctx : pl->dhp;
   pl->cscale = 2.0f * (1.0f / sqrtf((float)p->dim_head)) * 1.44269504088896340736f;  // (1/0.5) * dh^-1/2 * log2(e)
   attn_core_geometry(b, p->heads, pl->Lp, pl->N, pl->dp, &pl->nsplit, &pl->chunk);
@@ -122,6 +123,7 @@ static int attn_prepare(const hn_attn_params *p, const AttnPlan &pl, const float
     core->Q = pl.qf; core->q_b = (long)p->heads * pl.Lp * pl.dp; core->q_h = (long)pl.Lp * pl.dp; core->ldq = pl.dp;
     core->Kp = ctx; core->k_b = (long)pl.N * ld_ctx; core->k_h = 0; core->ldk = ld_ctx;
     core->Vp = ctx; core->v_b = core->k_b; core->v_h = 0; core->ldv = ld_ctx;
+    core->ones_col = pl.ones ? 1 : 0;
   } else {
     const int qpitch = p->heads * pl.dhp, kvpitch = 2 * p->heads * pl.dhp;
     if (pl.dhp != pl.dh) {
@@ -223,7 +225,7 @@ static int ff_fwd_impl(const hn_ff_params *p, const float *x_in, float *x_out, i
 
 static int context_pitch(int D, int dim_head) {
   const int dhp = pad_head_dim(dim_head);
-  int dp = D <= 16 ? 16 : (D <= 32 ? 32 : 0);
+  int dp = D <= 15 ? 16 : (D <= 31 ? 32 : 0);   // leave column dp-1 free for the kernel's synthetic ones column
   if (dp != 0 && dhp != 0 && dp <= dhp) return dp;
   return (D + 3) / 4 * 4;
 }

@@ -39,7 +39,30 @@ constexpr float kRescaleThreshold = 8.0f;
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-template <int DT, int NQ>
+// Raw buffer loads through an SGPR buffer descriptor (V#).  Bound to the LLVM intrinsics by name: in this
+// toolchain (ROCm 7.2) the __builtin_amdgcn_raw_buffer_load_b128 builtin is lowered to a single dword load.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ f32x4 hn_buffer_load_x4(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+__device__ float hn_buffer_load_x1(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
+__device__ __forceinline__ i32x4 make_rsrc(const void *base, int bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  i32x4 r;
+  r.x = (int)(a & 0xffffffffu);
+  r.y = (int)((a >> 32) & 0xffffu);   // stride 0: raw buffer, byte-offset range check against num_records
+  r.z = bytes;
+  r.w = 0x00020000;                   // DATA_FORMAT = 32-bit
+  return r;
+}
+
+// ONES (rank-D binding only; requires D <= DP - 1): column DP-1 of the shared context row is a synthetic
+// ones column injected in registers (memory keeps its zero padding):
+//   * QK^T: the K fragment carries 1 there and the Q fragment carries -m (the running reference max of
+//     its query row), so the MFMA chain itself delivers s - m: no per-score subtraction on the VALU;
+//   * P V : the V fragment carries 1 there, so accumulator column DP-1 is sum_t p = the softmax
+//     denominator: no per-score addition on the VALU, and it is rescaled together with O.
+// What is left per score is one v_exp_f32 and 3/4 of a max (overflow guard on p), which matters because
+// the fp32 MFMA leaves only ~7 issue slots per 32-cycle MFMA for everything else on the SIMD.
+template <int DT, int NQ, bool ONES>
 __global__ __launch_bounds__(256) void attn_core_kernel(AttnCoreArgs a, int ngroups, int gy, int waves_per_block) {
   constexpr int DP = 16 * DT;
   const int L = a.Lq;
@@ -69,17 +92,19 @@ __global__ __launch_bounds__(256) void attn_core_kernel(AttnCoreArgs a, int ngro
       qf[i][s] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (row < L) qf[i][s] = *(const float4 *)(qbase + (long)row * a.ldq + 16 * s + 4 * g);
     }
+    if (ONES && g == 3) qf[i][DT - 1].w = 0.0f;       // -m with m = 0
   }
 
   f32x4 O[NQ][DT];
   float m[NQ], l[NQ];
 #pragma unroll
   for (int i = 0; i < NQ; ++i) {
-    m[i] = kNegBig;
+    m[i] = ONES ? 0.0f : kNegBig;
     l[i] = 0.0f;
 #pragma unroll
     for (int d = 0; d < DT; ++d) O[i][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
+  bool unset = true;      // ONES: no unmasked token seen yet (wave-uniform)
 
   const int t_begin = split * a.chunk;
   const int t_end = min(a.N, t_begin + a.chunk);
@@ -87,29 +112,41 @@ __global__ __launch_bounds__(256) void attn_core_kernel(AttnCoreArgs a, int ngro
   const float *vbase = a.Vp + (long)bi * a.v_b + (long)hi * a.v_h;
   const uint8_t *mrow = a.mask ? a.mask + (long)bi * a.N : nullptr;
 
-  auto load_kv = [&](int t0, float4 (&kf)[DT], float (&vf)[DT][4]) {
-    const int tk = min(t0 + j, a.N - 1);
-    const float *kp = kbase + (long)tk * a.ldk + 4 * g;
+  // K / V fragments come through buffer descriptors (SRSRC): the per-lane offsets are loop invariant and the
+  // tile base advances in an SGPR, so the steady-state loop spends no VALU on addressing, and rows past the
+  // end of the context read as 0 (hardware range check) instead of needing clamped indices.
+  const int kbytes = (int)(((long)(a.N - 1) * a.ldk + DP) * 4), vbytes = (int)(((long)(a.N - 1) * a.ldv + DP) * 4);
+  const i32x4 krs = make_rsrc(kbase, kbytes), vrs = make_rsrc(vbase, vbytes);
+  const int koff = (j * a.ldk + 4 * g) * 4;
+  int voff[4];
 #pragma unroll
-    for (int s = 0; s < DT; ++s) kf[s] = *(const float4 *)(kp + 16 * s);
+  for (int r = 0; r < 4; ++r) voff[r] = ((4 * g + r) * a.ldv + j) * 4;
+
+  auto load_kv = [&](int t0, float4 (&kf)[DT], float (&vf)[DT][4]) {
+    const int ks = t0 * a.ldk * 4, vs = t0 * a.ldv * 4;
+#pragma unroll
+    for (int s = 0; s < DT; ++s) {
+      const f32x4 w = hn_buffer_load_x4(krs, koff + 64 * s, ks, 0);
+      kf[s] = make_float4(w.x, w.y, w.z, w.w);
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int tv = min(t0 + 4 * g + r, a.N - 1);
-      const float *vp = vbase + (long)tv * a.ldv + j;
 #pragma unroll
-      for (int d = 0; d < DT; ++d) vf[d][r] = vp[16 * d];
+      for (int d = 0; d < DT; ++d)
+        vf[d][r] = hn_buffer_load_x1(vrs, voff[r] + 64 * d, vs, 0);
     }
   };
 
-  float4 kf[DT];
-  float vf[DT][4];
-  if (t_begin < t_end) load_kv(t_begin, kf, vf);
-
-  for (int t0 = t_begin; t0 < t_end; t0 += 16) {
-    float4 kn[DT];
-    float vn[DT][4];
-    const bool more = t0 + 16 < t_end;
-    if (more) load_kv(t0 + 16, kn, vn);
+  // one 16-token step on the (kf, vf) fragments; prefetches the following tile into (kn, vn)
+  auto step = [&](int t0, float4 (&kf)[DT], float (&vf)[DT][4], float4 (&kn)[DT], float (&vn)[DT][4]) {
+    if (t0 + 16 < t_end) load_kv(t0 + 16, kn, vn);
+    if (ONES) {
+      if (g == 3) kf[DT - 1].w = 1.0f;
+      if (j == 15) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vf[DT - 1][r] = 1.0f;
+      }
+    }
 
     // ---- S^T tile = K Q^T  (DT*4 chained MFMAs per query tile, NQ independent chains)
     f32x4 S[NQ];
@@ -128,94 +165,139 @@ __global__ __launch_bounds__(256) void attn_core_kernel(AttnCoreArgs a, int ngro
     }
 
     // ---- mask / ragged tail: lane (g, j) holds tokens t0 + 4 g + r
+    bool any_live = true;
     if (mrow != nullptr || t0 + 16 > t_end) {
+      bool live = false;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int tok = t0 + 4 * g + r;
         bool ok = tok < t_end;
         if (ok && mrow) ok = mrow[tok] != 0;
+        live |= ok;
         if (!ok) {
 #pragma unroll
           for (int i = 0; i < NQ; ++i) S[i][r] = -__builtin_inff();
         }
       }
+      any_live = __any(live);
     }
 
-    // ---- online softmax with lazy rescale
-    bool need = false;
-    float tmax[NQ];
-#pragma unroll
-    for (int i = 0; i < NQ; ++i) {
-      tmax[i] = fmaxf(fmaxf(S[i][0], S[i][1]), fmaxf(S[i][2], S[i][3]));
-      need |= tmax[i] > m[i] + kRescaleThreshold;
-    }
-    if (__any(need)) {
+    f32x4 P[NQ];
+    if (ONES) {
+      // S already holds s - m.  Guard: rescale when some p would exceed 2^threshold (or on the first live tile).
+      bool need = false;
 #pragma unroll
       for (int i = 0; i < NQ; ++i) {
-        float tm = tmax[i];
-        tm = fmaxf(tm, __shfl_xor(tm, 16));
-        tm = fmaxf(tm, __shfl_xor(tm, 32));
-        const float mn = fmaxf(m[i], tm);
-        const float alpha = fast_exp2(m[i] - mn);
-        l[i] *= alpha;
-        // accumulator reg r of lane (g, d) belongs to query row 4 g + r, whose alpha lives in lane 4 g + r
+#pragma unroll
+        for (int r = 0; r < 4; ++r) P[i][r] = fast_exp2(S[i][r]);
+        const float pm = fmaxf(fmaxf(P[i][0], P[i][1]), fmaxf(P[i][2], P[i][3]));
+        need |= pm > 256.0f;
+      }
+      need |= unset;
+      if (__any(need) && any_live) {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+          float tm = fmaxf(fmaxf(S[i][0], S[i][1]), fmaxf(S[i][2], S[i][3]));
+          tm = fmaxf(tm, __shfl_xor(tm, 16));
+          tm = fmaxf(tm, __shfl_xor(tm, 32));
+          float delta = unset ? tm : fmaxf(tm, 0.0f);
+          if (!(delta > -3.0e38f)) delta = 0.0f;          // row saw only -inf scores: keep the reference
+          const float alpha = unset ? 1.0f : fast_exp2(-delta);
+          m[i] += delta;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float ar = __shfl(alpha, 4 * g + r);
+#pragma unroll
+            for (int d = 0; d < DT; ++d) O[i][d][r] *= ar;
+            P[i][r] = fast_exp2(S[i][r] - delta);
+          }
+          if (g == 3) qf[i][DT - 1].w = -m[i];
+        }
+        unset = false;
+      }
+    } else {
+      bool need = false;
+      float tmax[NQ];
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) {
+        tmax[i] = fmaxf(fmaxf(S[i][0], S[i][1]), fmaxf(S[i][2], S[i][3]));
+        need |= tmax[i] > m[i] + kRescaleThreshold;
+      }
+      if (__any(need)) {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+          float tm = tmax[i];
+          tm = fmaxf(tm, __shfl_xor(tm, 16));
+          tm = fmaxf(tm, __shfl_xor(tm, 32));
+          const float mn = fmaxf(m[i], tm);
+          const float alpha = fast_exp2(m[i] - mn);
+          l[i] *= alpha;
+          // accumulator reg r of lane (g, d) belongs to query row 4 g + r, whose alpha lives in lane 4 g + r
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float ar = __shfl(alpha, 4 * g + r);
+#pragma unroll
+            for (int d = 0; d < DT; ++d) O[i][d][r] *= ar;
+          }
+          m[i] = mn;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float ar = __shfl(alpha, 4 * g + r);
-#pragma unroll
-          for (int d = 0; d < DT; ++d) O[i][d][r] *= ar;
+          const float p = fast_exp2(S[i][r] - m[i]);
+          l[i] += p;
+          P[i][r] = p;
         }
-        m[i] = mn;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < NQ; ++i) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float p = fast_exp2(S[i][r] - m[i]);
-        l[i] += p;
-        S[i][r] = p;
       }
     }
 
-    // ---- O += P V   (A = P straight from the score registers, B = V rows 4 g + r)
+    // ---- O += P V   (A = P straight from registers, B = V rows 4 g + r)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
 #pragma unroll
       for (int d = 0; d < DT; ++d) {
 #pragma unroll
         for (int i = 0; i < NQ; ++i)
-          O[i][d] = __builtin_amdgcn_mfma_f32_16x16x4f32(S[i][r], vf[d][r], O[i][d], 0, 0, 0);
+          O[i][d] = __builtin_amdgcn_mfma_f32_16x16x4f32(P[i][r], vf[d][r], O[i][d], 0, 0, 0);
       }
     }
+  };
 
-    if (more) {
-#pragma unroll
-      for (int s = 0; s < DT; ++s) kf[s] = kn[s];
-#pragma unroll
-      for (int d = 0; d < DT; ++d)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) vf[d][r] = vn[d][r];
-    }
+  float4 kA[DT], kB[DT];
+  float vA[DT][4], vB[DT][4];
+  if (t_begin < t_end) load_kv(t_begin, kA, vA);
+  for (int t0 = t_begin; t0 < t_end; t0 += 32) {
+    step(t0, kA, vA, kB, vB);
+    if (t0 + 16 < t_end) step(t0 + 16, kB, vB, kA, vA);
   }
 
-  // ---- write the partial (O, m, l) of this split
+  // ---- write the partial (O, m, l) of this split.  ONES: l sits in accumulator column DP-1.
   const long prow = ((long)bh * a.nsplit + split) * a.Lp;
 #pragma unroll
   for (int i = 0; i < NQ; ++i) {
     const int tile = qg * NQ + i;
     if (tile * 16 >= a.Lp) continue;
-    float li = l[i];
-    li += __shfl_xor(li, 16);
-    li += __shfl_xor(li, 32);
 #pragma unroll
     for (int d = 0; d < DT; ++d)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         a.Opart[(prow + tile * 16 + 4 * g + r) * DP + 16 * d + j] = O[i][d][r];
-    if (g == 0) {
-      a.Mpart[prow + tile * 16 + j] = m[i];
-      a.Lpart[prow + tile * 16 + j] = li;
+    if (ONES) {
+      if (g == 0) a.Mpart[prow + tile * 16 + j] = m[i];
+      if (j == 15) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a.Lpart[prow + tile * 16 + 4 * g + r] = O[i][DT - 1][r];
+      }
+    } else {
+      float li = l[i];
+      li += __shfl_xor(li, 16);
+      li += __shfl_xor(li, 32);
+      if (g == 0) {
+        a.Mpart[prow + tile * 16 + j] = m[i];
+        a.Lpart[prow + tile * 16 + j] = li;
+      }
     }
   }
 }
@@ -241,6 +323,9 @@ int launch_attn_core(const AttnCoreArgs &a, hipStream_t s) {
   HN_REQUIRE(a.dp == 16 || a.dp == 32 || a.dp == 64 || a.dp == 128, HN_E_UNSUPPORTED, "attn_core: dp=%d", a.dp);
   HN_REQUIRE(a.Lp % 16 == 0 && a.chunk % 16 == 0 && a.nsplit >= 1, HN_E_SHAPE, "attn_core: Lp=%d chunk=%d", a.Lp, a.chunk);
   HN_REQUIRE((a.ldq % 4) == 0 && (a.ldk % 4) == 0, HN_E_SHAPE, "attn_core: ldq=%d ldk=%d must be multiples of 4", a.ldq, a.ldk);
+  HN_REQUIRE(((long)a.N * a.ldk + a.dp) * 4 < (1L << 31) && ((long)a.N * a.ldv + a.dp) * 4 < (1L << 31), HN_E_UNSUPPORTED,
+             "attn_core: one sample's K/V rows must span < 2 GiB (N=%d ld=%d)", a.N, a.ldk);
+  HN_REQUIRE(!a.ones_col || (a.dp <= 32 && a.Kp == a.Vp), HN_E_UNSUPPORTED, "attn_core: ones column needs the shared-context binding");
   const int dt = a.dp / 16, nq = nq_for(dt);
   const int ngroups = ceil_div(a.Lp / 16, nq);
   const int wpb = ngroups < 4 ? ngroups : 4;
@@ -249,10 +334,16 @@ int launch_attn_core(const AttnCoreArgs &a, hipStream_t s) {
   HN_REQUIRE(blocks < (1L << 31), HN_E_UNSUPPORTED, "attn_core: grid too large");
   dim3 grid((unsigned)blocks), block(64 * wpb);
   switch (dt) {
-    case 1: hipLaunchKernelGGL((attn_core_kernel<1, 4>), grid, block, 0, s, a, ngroups, gy, wpb); break;
-    case 2: hipLaunchKernelGGL((attn_core_kernel<2, 2>), grid, block, 0, s, a, ngroups, gy, wpb); break;
-    case 4: hipLaunchKernelGGL((attn_core_kernel<4, 2>), grid, block, 0, s, a, ngroups, gy, wpb); break;
-    default: hipLaunchKernelGGL((attn_core_kernel<8, 1>), grid, block, 0, s, a, ngroups, gy, wpb); break;
+    case 1:
+      if (a.ones_col) hipLaunchKernelGGL((attn_core_kernel<1, 4, true>), grid, block, 0, s, a, ngroups, gy, wpb);
+      else hipLaunchKernelGGL((attn_core_kernel<1, 4, false>), grid, block, 0, s, a, ngroups, gy, wpb);
+      break;
+    case 2:
+      if (a.ones_col) hipLaunchKernelGGL((attn_core_kernel<2, 2, true>), grid, block, 0, s, a, ngroups, gy, wpb);
+      else hipLaunchKernelGGL((attn_core_kernel<2, 2, false>), grid, block, 0, s, a, ngroups, gy, wpb);
+      break;
+    case 4: hipLaunchKernelGGL((attn_core_kernel<4, 2, false>), grid, block, 0, s, a, ngroups, gy, wpb); break;
+    default: hipLaunchKernelGGL((attn_core_kernel<8, 1, false>), grid, block, 0, s, a, ngroups, gy, wpb); break;
   }
   HN_LAUNCH_CHECK("attn_core");
   return HN_OK;

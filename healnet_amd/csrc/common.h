@@ -92,6 +92,7 @@ struct AttnCoreArgs {
   float *Opart, *Mpart, *Lpart;                 // (b, h, nsplit, Lp, DP), (b, h, nsplit, Lp) x2
   int b, h, Lq, Lp, N, dp;                      // Lq valid query rows, Lp = Lq rounded up to 16, dp in {16,32,64,128}
   int nsplit, chunk;                            // tokens per split (multiple of 16)
+  int ones_col;                                 // rank-D binding with D <= dp-1: synthetic ones column dp-1 (see attention.hip)
 };
 int launch_attn_core(const AttnCoreArgs &a, hipStream_t s);
 void attn_core_geometry(int b, int h, int Lp, int N, int dp, int *nsplit, int *chunk);
