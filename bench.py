@@ -128,8 +128,8 @@ def main():
     dev = torch.device("cuda", local_rank)
     if distributed:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        from healnet_amd import dist as hdist
+        hdist.init_from_env("nccl")                       # RCCL; one process per GPU
 
     import healnet_amd
     from healnet_amd import _capi
@@ -170,9 +170,7 @@ def main():
     assert torch.isfinite(out).all()
 
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = hdist.max_over_ranks(elapsed, dev)      # the slowest rank defines the step time
 
     if rank == 0:
         total_samples = b * args.steps * world

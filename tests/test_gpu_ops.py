@@ -161,3 +161,30 @@ def test_prenorm_feedforward_vs_oracle(hn, dim, rows):
     want = O.feed_forward(O.layer_norm(x, sd["norm.weight"], sd["norm.bias"]), sd["fn.net.0.weight"], sd["fn.net.0.bias"],
                           sd["fn.net.2.weight"], sd["fn.net.2.bias"], True)
     assert_close(blk(x.to(DEV)).cpu(), want, rel=1e-4, what="prenorm.ff")
+
+
+# ------------------------------------------------------------------------------------------ torch.ops surface
+def test_torch_ops_surface(hn):
+    gen = torch.Generator().manual_seed(9)
+    x = torch.rand(2, 6, 5, 3, generator=gen)
+    got = torch.ops.healnet_hip.fourier_encode_concat(x.to(DEV), 2, 10.0, True)
+    assert_close(got.cpu(), O.encode_modality(x, 2, 10.0), rel=3e-6, what="ops.encode")
+    z = torch.ops.healnet_hip.encode_norm(x.to(DEV), 2, 10.0, True, 16)
+    assert_close(z[..., :13].cpu(), F.layer_norm(O.encode_modality(x, 2, 10.0), (13,)), rel=2e-5, what="ops.encode_norm")
+    # attention + feed-forward + head chained exactly like one (cross, ff) step followed by the head
+    d, heads, dh = 32, 2, 16
+    lat = torch.randn(2, 8, d, generator=gen)
+    p = {k: torch.randn(*s, generator=gen) * 0.3 for k, s in dict(nw=(d,), nb=(d,), cg=(13,), cb=(13,), wq=(heads * dh, d),
+         wkv=(2 * heads * dh, 13), wo=(d, heads * dh), bo=(d,), w1=(8 * d, d), b1=(8 * d,), w2=(d, 4 * d), b2=(d,),
+         hw=(3, d), hb=(3,)).items()}
+    P = {k: v.to(DEV) for k, v in p.items()}
+    y = torch.ops.healnet_hip.attention(lat.to(DEV), z, None, P["nw"], P["nb"], P["cg"], P["cb"], P["wq"], P["wkv"], P["wo"],
+                                        P["bo"], heads, True)
+    y = torch.ops.healnet_hip.feed_forward(y, P["nw"], P["nb"], P["w1"], P["b1"], P["w2"], P["b2"], False, True)
+    logits = torch.ops.healnet_hip.head(y, P["nw"], P["nb"], P["hw"], P["hb"])
+    ctx = O.encode_modality(x, 2, 10.0)
+    want = O.attention(O.layer_norm(lat, p["nw"], p["nb"]), O.layer_norm(ctx, p["cg"], p["cb"]), p["wq"], p["wkv"], p["wo"],
+                       p["bo"], heads) + lat
+    want = O.feed_forward(O.layer_norm(want, p["nw"], p["nb"]), p["w1"], p["b1"], p["w2"], p["b2"], True) + want
+    want = O.layer_norm(want.mean(1), p["nw"], p["nb"]) @ p["hw"].t() + p["hb"]
+    assert_close(logits.cpu(), want, rel=1e-4, what="ops.chain")
