@@ -153,20 +153,29 @@ def main():
     with torch.no_grad():
         for _ in range(args.warmup):
             model([tab, img])
+        # ---- timed region: exactly K steps, barrier + synchronize on both sides, no instrumentation
         barrier()
         t0 = time.perf_counter()
-        recorded = 0
         for step in range(args.steps):
-            # hand the C ABI the next n_core event pairs of this step
+            out = model([tab, img])
+        barrier()
+        elapsed = time.perf_counter() - t0
+
+        # ---- instrumented replay of the same K steps: HIP events recorded on the launch stream around every
+        # launch of the dominant kernel (recording timing events between kernels costs ~1 ms per forward on
+        # this runtime, so it is kept out of the region `value` is computed from)
+        recorded = 0
+        t1 = time.perf_counter()
+        for step in range(args.steps):
             off = step * n_core * ctypes.sizeof(ctypes.c_void_p)
             prof.ev_start = ctypes.cast(ctypes.addressof(events.start) + off, ctypes.POINTER(ctypes.c_void_p))
             prof.ev_stop = ctypes.cast(ctypes.addressof(events.stop) + off, ctypes.POINTER(ctypes.c_void_p))
             prof.n_events = n_core
             prof.n_recorded = 0
-            out = model([tab, img], _profile=ctypes.byref(prof))
+            model([tab, img], _profile=ctypes.byref(prof))
             recorded += prof.n_recorded
         barrier()
-        elapsed = time.perf_counter() - t0
+        elapsed_instrumented = time.perf_counter() - t1
     assert torch.isfinite(out).all()
 
     if distributed:
@@ -205,6 +214,9 @@ def main():
                 "frac": None if exec_tf is None else round(exec_tf / PEAK_FP32_MFMA_TFLOPS, 4),
                 "traffic": None,
                 "avg_launch_ms": round(avg_core_ms, 4),
+                "timing": "hipEvent pairs on the launch stream around each of the 3 launches per forward, recorded in an "
+                          "instrumented replay of the same K steps right after the timed region",
+                "instrumented_ms_per_step": round(elapsed_instrumented / args.steps * 1e3, 4),
                 "launches_timed": len(core_ms),
                 "flops_per_launch_executed": EXEC_FLOPS_CORE_PER_SAMPLE * b,
                 "flops_per_launch_algorithmic": ALGO_FLOPS_CORE_PER_SAMPLE * b,

@@ -31,6 +31,7 @@
 //               (merge_vproj_kernel).  Used when D (13 for an RGB image + 2-axis Fourier features)
 //               is below dim_head: 4.5x fewer executed FLOPs, identical math up to fp32 rounding.
 #include "common.h"
+#include <stdlib.h>
 
 namespace hn {
 
@@ -39,29 +40,18 @@ constexpr float kRescaleThreshold = 8.0f;
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-// Raw buffer loads through an SGPR buffer descriptor (V#).  Bound to the LLVM intrinsics by name: in this
-// toolchain (ROCm 7.2) the __builtin_amdgcn_raw_buffer_load_b128 builtin is lowered to a single dword load.
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-__device__ f32x4 hn_buffer_load_x4(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
-__device__ float hn_buffer_load_x1(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
-__device__ __forceinline__ i32x4 make_rsrc(const void *base, int bytes) {
-  const unsigned long long a = (unsigned long long)base;
-  i32x4 r;
-  r.x = (int)(a & 0xffffffffu);
-  r.y = (int)((a >> 32) & 0xffffu);   // stride 0: raw buffer, byte-offset range check against num_records
-  r.z = bytes;
-  r.w = 0x00020000;                   // DATA_FORMAT = 32-bit
-  return r;
-}
-
 // ONES (rank-D binding only; requires D <= DP - 1): column DP-1 of the shared context row is a synthetic
 // ones column injected in registers (memory keeps its zero padding):
 //   * QK^T: the K fragment carries 1 there and the Q fragment carries -m (the running reference max of
 //     its query row), so the MFMA chain itself delivers s - m: no per-score subtraction on the VALU;
 //   * P V : the V fragment carries 1 there, so accumulator column DP-1 is sum_t p = the softmax
 //     denominator: no per-score addition on the VALU, and it is rescaled together with O.
-// What is left per score is one v_exp_f32 and 3/4 of a max (overflow guard on p), which matters because
-// the fp32 MFMA leaves only ~7 issue slots per 32-cycle MFMA for everything else on the SIMD.
+// What is left per score is one v_exp_f32 and 3/4 of a max (overflow guard on p).  This matters more than
+// on the bf16 path: measured MFMA-pipe utilisation tracks  MFMA cycles / (MFMA cycles + VALU cycles) of the
+// loop (58 % at ~150 VALU ops per 32 MFMAs, 66 % at ~110, 74 % at ~60) and interleaving the two inside a
+// wave (software pipelining QK^T(t+1) under softmax(t): tried, 6 % slower) does not help -- the fp32 MFMA
+// runs at exactly the fp32 vector rate and evidently competes with VALU work for the SIMD's fp32 lanes, so
+// every VALU op removed from the loop is MFMA time gained.
 template <int DT, int NQ, bool ONES>
 __global__ __launch_bounds__(256) void attn_core_kernel(AttnCoreArgs a, int ngroups, int gy, int waves_per_block) {
   constexpr int DP = 16 * DT;
@@ -115,7 +105,7 @@ __global__ __launch_bounds__(256) void attn_core_kernel(AttnCoreArgs a, int ngro
   // K / V fragments come through buffer descriptors (SRSRC): the per-lane offsets are loop invariant and the
   // tile base advances in an SGPR, so the steady-state loop spends no VALU on addressing, and rows past the
   // end of the context read as 0 (hardware range check) instead of needing clamped indices.
-  const int kbytes = (int)(((long)(a.N - 1) * a.ldk + DP) * 4), vbytes = (int)(((long)(a.N - 1) * a.ldv + DP) * 4);
+  const unsigned kbytes = (unsigned)(((long)(a.N - 1) * a.ldk + DP) * 4), vbytes = (unsigned)(((long)(a.N - 1) * a.ldv + DP) * 4);
   const i32x4 krs = make_rsrc(kbase, kbytes), vrs = make_rsrc(vbase, vbytes);
   const int koff = (j * a.ldk + 4 * g) * 4;
   int voff[4];
@@ -185,15 +175,16 @@ __global__ __launch_bounds__(256) void attn_core_kernel(AttnCoreArgs a, int ngro
     f32x4 P[NQ];
     if (ONES) {
       // S already holds s - m.  Guard: rescale when some p would exceed 2^threshold (or on the first live tile).
-      bool need = false;
+      float pm = 0.0f;                                  // one running max over all NQ*4 values -> v_max3 chain
 #pragma unroll
       for (int i = 0; i < NQ; ++i) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) P[i][r] = fast_exp2(S[i][r]);
-        const float pm = fmaxf(fmaxf(P[i][0], P[i][1]), fmaxf(P[i][2], P[i][3]));
-        need |= pm > 256.0f;
+        for (int r = 0; r < 4; ++r) {
+          P[i][r] = fast_exp2(S[i][r]);
+          pm = fmaxf(pm, P[i][r]);
+        }
       }
-      need |= unset;
+      const bool need = pm > 256.0f || unset;
       if (__any(need) && any_live) {
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
@@ -302,12 +293,23 @@ __global__ __launch_bounds__(256) void attn_core_kernel(AttnCoreArgs a, int ngro
   }
 }
 
-static int nq_for(int dt) { return dt == 1 ? 4 : (dt == 2 ? 2 : (dt == 4 ? 2 : 1)); }
+// development knob: HN_CORE_NQ overrides the query tiles per wave of the dp = 16 binding (2, 4 or 8)
+static int nq_dt1() {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("HN_CORE_NQ");
+    v = e ? atoi(e) : 4;
+    if (v != 2 && v != 4 && v != 8) v = 4;
+  }
+  return v;
+}
+static int nq_for(int dt) { return dt == 1 ? nq_dt1() : (dt == 2 ? 2 : (dt == 4 ? 2 : 1)); }
 
 void attn_core_geometry(int b, int h, int Lp, int N, int dp, int *nsplit, int *chunk) {
   const int dt = dp / 16;
   const int ngroups = ceil_div(Lp / 16, nq_for(dt));
-  const long target_waves = 256L * 4 * 4;
+  static long target_waves = 0;   // development knob HN_CORE_WAVES: resident waves the token split aims for
+  if (target_waves == 0) { const char *e = getenv("HN_CORE_WAVES"); target_waves = e ? atol(e) : 256L * 4 * 4; if (target_waves < 64) target_waves = 4096; }
   long want = ceil_div_ll(target_waves, (long)b * h * ngroups);
   long max_splits = N / 128;
   if (max_splits < 1) max_splits = 1;
@@ -335,7 +337,11 @@ int launch_attn_core(const AttnCoreArgs &a, hipStream_t s) {
   dim3 grid((unsigned)blocks), block(64 * wpb);
   switch (dt) {
     case 1:
-      if (a.ones_col) hipLaunchKernelGGL((attn_core_kernel<1, 4, true>), grid, block, 0, s, a, ngroups, gy, wpb);
+      if (a.ones_col && nq == 8) hipLaunchKernelGGL((attn_core_kernel<1, 8, true>), grid, block, 0, s, a, ngroups, gy, wpb);
+      else if (a.ones_col && nq == 2) hipLaunchKernelGGL((attn_core_kernel<1, 2, true>), grid, block, 0, s, a, ngroups, gy, wpb);
+      else if (a.ones_col) hipLaunchKernelGGL((attn_core_kernel<1, 4, true>), grid, block, 0, s, a, ngroups, gy, wpb);
+      else if (nq == 8) hipLaunchKernelGGL((attn_core_kernel<1, 8, false>), grid, block, 0, s, a, ngroups, gy, wpb);
+      else if (nq == 2) hipLaunchKernelGGL((attn_core_kernel<1, 2, false>), grid, block, 0, s, a, ngroups, gy, wpb);
       else hipLaunchKernelGGL((attn_core_kernel<1, 4, false>), grid, block, 0, s, a, ngroups, gy, wpb);
       break;
     case 2:

@@ -34,6 +34,31 @@ int fail(int code, const char *fmt, ...);
     if (!(cond)) return ::hn::fail(code, __VA_ARGS__);                                           \
   } while (0)
 
+// Raw buffer loads through an SGPR buffer descriptor (V#), bound to the LLVM intrinsics by name (in this toolchain,
+// ROCm 7.2, the __builtin_amdgcn_raw_buffer_load_b128 builtin is lowered to a single dword load).
+// Why every guarded operand load in this library goes through them: a "load or 0" on a per-lane predicate makes
+// hipcc branch around the load and wait vmcnt(0) right behind it, i.e. one serialized memory round trip per
+// element (and it re-sinks the load into the branch even when the source loads unconditionally and selects).
+// With a descriptor whose num_records ends at the last valid row, out-of-range rows simply read as 0 in
+// hardware: no predicate, no branch, all loads of a tile in flight together.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ f32x4 hn_buffer_load_x4(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+__device__ float hn_buffer_load_x1(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
+__device__ __forceinline__ i32x4 make_rsrc(const void *base, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  i32x4 r;
+  r.x = (int)(a & 0xffffffffu);
+  r.y = (int)((a >> 32) & 0xffffu);   // stride 0: raw buffer, byte-offset range check against num_records
+  r.z = (int)bytes;
+  r.w = 0x00020000;                   // DATA_FORMAT = 32-bit
+  return r;
+}
+__device__ __forceinline__ float4 buf4(i32x4 rsrc, int byte_off) {
+  const f32x4 v = hn_buffer_load_x4(rsrc, byte_off, 0, 0);
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__host__ __device__ static inline unsigned rsrc_bytes(long rows, long ld, long width) { return (unsigned)(((rows - 1) * ld + width) * 4); }
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline long long ceil_div_ll(long long a, long long b) { return (a + b - 1) / b; }

@@ -1,8 +1,8 @@
-// Fused fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, 64 FLOP/clk/SIMD).
+// Fused fp32 GEMMs on the CDNA4 matrix cores (exact fp32 MFMA: v_mfma_f32_32x32x2_f32 / 16x16x4_f32).
 //
-//   C[m, col(n)] = act( alpha * sum_k pro(A[m,k]) * W[n,k] + bias[n] ) (+ R[m,n])
+//   C[m, col(n)] = act( alpha * sum_k pro(A[m,k]) * W[n,k] + bias[n] ) (+ R[m,n])          W in nn.Linear layout
 //
-// Every dense projection of the fusion stack goes through this one kernel (reference:
+// Every dense projection of the fusion stack goes through launch_gemm() (reference:
 // healnet/models/healnet.py  to_q :403, to_kv :405, to_out :426, FeedForward.net :343-348), with the
 // surrounding elementwise work fused in:
 //   prologue on A : LayerNorm over k with in-kernel row moments (PreNorm.norm :314), or the affine
@@ -10,18 +10,18 @@
 //   epilogue      : bias, LeakyReLU(0.01) (:385), SELU/GELU gated linear unit (:323-331),
 //                   residual add (:236-245), per-head column re-pitching.
 //
-// Tile: 64x64 per 256-thread workgroup, BK = 32; four waves in a 2x2 grid, each owning one 32x32
-// accumulator (16 VGPRs).  Operands are staged through LDS with a 36-float row pitch, which makes the
-// ds_read_b128 fragment reads bank-conflict free (row*36 mod 64 hits 16 distinct 4-bank slots per
-// 16-lane service group).  Global loads are one dword per lane with lanes running along k, so every
-// wave-level load covers two full 128-byte row segments regardless of K / leading-dimension alignment
-// (the tuned HEALNet configs use odd sizes: l_d 119, D 13/773/2005).  The kernel is bound by the fp32
-// MFMA rate (16 x 64-cycle MFMAs per wave per k-tile vs. 16 dword loads), not by the loader.
+// Four kernels behind one launcher:
+//   gemm_kernel         64x64 tile, dword loads with lanes along k: any alignment (context-side projections with
+//                       odd K / leading dimension: D = 13, 773, 2005; tuned configs with l_d = 119)
+//   gemm_t32_kernel     32x64 tile, 16-byte loads, operands streamed (aligned operands, K > 512)
+//   gemm_t32a_kernel    32x64 tile, A block resident (aligned, K <= 512): all latent-side GEMMs of the default model
+//   gemm_skinny_kernel  M <= 32 rows: weight-streaming GEMV batch (one-token tabular context)
+//
+// All operand loads are raw buffer loads (see common.h): rows past the end read as 0 in hardware, so the loaders
+// carry no per-lane predicates (hipcc turns "load or 0" into branch + load + s_waitcnt vmcnt(0) per element).
 #include "common.h"
 
 namespace hn {
-
-constexpr int BM = 64, BN = 64, BK = 32, LDS_PITCH = 36;
 
 __device__ __forceinline__ float selu_exact(float x) {
   const float alpha = 1.6732632423543772848170429916717f, scale = 1.0507009873554804934193349852946f;
@@ -30,9 +30,33 @@ __device__ __forceinline__ float selu_exact(float x) {
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 template <bool GLU>
+__device__ __forceinline__ float epilogue_value(const GemmArgs &g, float acc, float accg, float bv, float bgv) {
+  float v = g.alpha * acc + bv;
+  if (GLU) {
+    const float gate = g.alpha * accg + bgv;
+    v *= (g.act == ACT_GLU_SELU) ? selu_exact(gate) : gelu_f(gate);
+  } else if (g.act == ACT_LEAKY) {
+    v = v > 0.0f ? v : 0.01f * v;
+  }
+  return v;
+}
+
+__device__ __forceinline__ long out_col(const GemmArgs &g, int n) {
+  return g.col_group > 0 ? (long)(n / g.col_group) * g.col_group_pitch + (n % g.col_group) : n;
+}
+
+// ------------------------------------------------------------------------------------------------
+// General kernel.  64x64 tile per 256-thread workgroup, BK = 32, four waves in a 2x2 grid, one 32x32 accumulator
+// each.  LDS pitch 36 floats: ds_read_b128 fragment reads are conflict free (row*36 mod 64 hits 16 distinct
+// 4-bank slots per 16-lane service group).  One dword per lane with lanes along k: every wave-level load covers
+// two full 128-byte row segments regardless of alignment.
+// ------------------------------------------------------------------------------------------------
+constexpr int BM = 64, BN = 64, BK = 32, LDS_PITCH = 36;
+
+template <bool GLU>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
-  __shared__ float As[BM * LDS_PITCH];
-  __shared__ float Bs[(GLU ? 2 : 1) * BN * LDS_PITCH];
+  __shared__ __attribute__((aligned(16))) float As[BM * LDS_PITCH];
+  __shared__ __attribute__((aligned(16))) float Bs[(GLU ? 2 : 1) * BN * LDS_PITCH];
   __shared__ float row_mu[BM], row_rs[BM];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -42,48 +66,44 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   float *__restrict__ C = g.C + (long)z * g.strideC;
   const float *bias = g.bias ? g.bias + (long)z * g.strideBias : nullptr;
   const float *R = g.R ? g.R + (long)z * g.strideR : nullptr;
+  const i32x4 rsA = make_rsrc(A, rsrc_bytes(g.M, g.lda, g.K));
+  const i32x4 rsW = make_rsrc(W, rsrc_bytes(GLU ? g.N + g.glu_offset : g.N, g.ldw, g.K));
 
-  // ---- LayerNorm prologue: per-row mean / rstd over the whole K extent (two-pass, 4 lanes per row)
+  // ---- LayerNorm prologue: shifted one-pass moments, 4 lanes per row
   if (g.pro == PRO_LAYERNORM) {
     const int r = tid >> 2, part = tid & 3;
-    const int m = m0 + r;
-    float s = 0.0f;
-    if (m < g.M)
-      for (int k = part; k < g.K; k += 4) s += A[(long)m * g.lda + k];
-    s += __shfl_xor(s, 1);
-    s += __shfl_xor(s, 2);
-    const float mu = s / (float)g.K;
-    float q = 0.0f;
-    if (m < g.M)
-      for (int k = part; k < g.K; k += 4) { float d = A[(long)m * g.lda + k] - mu; q += d * d; }
-    q += __shfl_xor(q, 1);
-    q += __shfl_xor(q, 2);
-    if (part == 0) { row_mu[r] = mu; row_rs[r] = 1.0f / sqrtf(q / (float)g.K + g.eps); }
+    const int rowb = (m0 + r) * (int)g.lda * 4;
+    const float x0 = hn_buffer_load_x1(rsA, rowb, 0, 0);
+    float s1 = 0.0f, s2 = 0.0f;
+    for (int k = part; k < g.K; k += 4) {
+      const float d = hn_buffer_load_x1(rsA, rowb + k * 4, 0, 0) - x0;
+      s1 += d;
+      s2 += d * d;
+    }
+    s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2);
+    s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2);
+    const float inv_k = 1.0f / (float)g.K, dm = s1 * inv_k;
+    if (part == 0) { row_mu[r] = x0 + dm; row_rs[r] = 1.0f / sqrtf(fmaxf(s2 * inv_k - dm * dm, 0.0f) + g.eps); }
     __syncthreads();
   }
 
-  // ---- loader geometry: lane runs along k, 8 row groups
-  const int lk = tid & 31, lr = tid >> 5;
+  const int lk = tid & 31, lr = tid >> 5;     // loader: lane runs along k, 8 row groups
   float ra[8], rb[8], rg[GLU ? 8 : 1];
-
   auto load_tile = [&](int k0) {
     const int k = k0 + lk;
-    const bool kin = k < g.K;
+    const float km = k < g.K ? 1.0f : 0.0f;
+    const int kc = min(k, g.K - 1);
     float gam = 1.0f, bet = 0.0f;
-    if (g.pro != PRO_NONE && kin) { gam = g.gamma ? g.gamma[k] : 1.0f; bet = g.beta ? g.beta[k] : 0.0f; }
+    if (g.pro != PRO_NONE) { gam = g.gamma[kc]; bet = g.beta[kc]; }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int r = lr + 8 * j;
-      const int m = m0 + r, n = n0 + r;
-      float a = 0.0f;
-      if (kin && m < g.M) {
-        a = A[(long)m * g.lda + k];
-        if (g.pro == PRO_LAYERNORM) a = (a - row_mu[r]) * row_rs[r] * gam + bet;
-        else if (g.pro == PRO_AFFINE) a = a * gam + bet;
-      }
-      ra[j] = a;
-      rb[j] = (kin && n < g.N) ? W[(long)n * g.ldw + k] : 0.0f;
-      if (GLU) rg[j] = (kin && n < g.N) ? W[(long)(n + g.glu_offset) * g.ldw + k] : 0.0f;
+      float a = hn_buffer_load_x1(rsA, ((m0 + r) * (int)g.lda + kc) * 4, 0, 0);
+      if (g.pro == PRO_LAYERNORM) a = (a - row_mu[r]) * row_rs[r] * gam + bet;
+      else if (g.pro == PRO_AFFINE) a = a * gam + bet;
+      ra[j] = a * km;      // masked along k only: rows past M produce values nobody stores
+      rb[j] = hn_buffer_load_x1(rsW, ((n0 + r) * (int)g.ldw + kc) * 4, 0, 0);
+      if (GLU) rg[j] = hn_buffer_load_x1(rsW, ((n0 + r + g.glu_offset) * (int)g.ldw + kc) * 4, 0, 0);
     }
   };
   auto store_tile = [&]() {
@@ -139,18 +159,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   if (n < g.N) {
     const float bv = bias ? bias[n] : 0.0f;
     const float bgv = (GLU && bias) ? bias[n + g.glu_offset] : 0.0f;
-    const long ocol = g.col_group > 0 ? (long)(n / g.col_group) * g.col_group_pitch + (n % g.col_group) : n;
+    const long ocol = out_col(g, n);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
       if (m < g.M) {
-        float v = g.alpha * acc[r] + bv;
-        if (GLU) {
-          const float gate = g.alpha * accg[r] + bgv;
-          v *= (g.act == ACT_GLU_SELU) ? selu_exact(gate) : gelu_f(gate);
-        } else if (g.act == ACT_LEAKY) {
-          v = v > 0.0f ? v : 0.01f * v;
-        }
+        float v = epilogue_value<GLU>(g, acc[r], accg[r], bv, bgv);
         if (R) v += R[(long)m * g.ldr + n];
         C[(long)m * g.ldc + ocol] = v;
       }
@@ -159,174 +173,284 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Register-direct variant for 16-byte aligned operands with K % 32 == 0 (every latent-side projection of
-// the default model: K = l_d = 128 or K = inner / 4*l_d = 512).
+// Aligned kernels (16-byte aligned operands, K % 4 == 0).  32 x 64 output tile -> 256 workgroups even for
+// M = 4096, N = 128; operands move in full 128-byte lines (8 lanes x 16 B per row of a 32-wide k-tile) into an
+// XOR-swizzled LDS image (slot = c ^ (row & 7), pitch 32 floats, no padding): conflict free for the
+// ds_write_b128 of the loader and for the ds_read_b128 fragment reads of the 16x16x4 MFMA; double-buffered
+// W tiles with the global loads two k-tiles ahead in registers, ONE barrier per k-tile.
 //
-// No LDS, no barriers: one wave owns a 32-row block and walks `nt` 32-column tiles of it; lane
-// (r = lane & 31, h = lane >> 5) loads its MFMA fragments straight from global memory as 16-byte vectors
-// (A[m0 + r][k0 + 16 h ..], W[n0 + r][k0 + 16 h ..]: each wave-level load covers 32 full 64-byte half
-// rows).  The latent-side GEMMs are small (M = b*l_c rows, 0.5-1 GFLOP) and latency-bound, so what matters
-// is many independent waves with their loads in flight, not operand reuse through LDS: the LDS-staged
-// kernel above needs 74 us for M=4096, N=128, K=512 (128 workgroups, one barrier pair per k-tile).
-// With K <= 128 the wave keeps its whole (LayerNorm-ed) A block in registers and only streams W.
+// gemm_t32a_kernel (K <= 32*KT) additionally requests its whole 32 x K block of A, and the residual values of its
+// epilogue, before anything else: A was written by the previous kernel, usually from another XCD, so its first
+// touch is an Infinity-Cache / HBM round trip; issued together they cost one round trip instead of one per
+// k-tile.  LayerNorm moments come from those same registers (the 8 loader lanes of a row hold the entire row).
 // ------------------------------------------------------------------------------------------------
+constexpr int TM = 32, TN = 64, TK = 32;
+
+struct WStage { float4 b0, b1, g0, g1; };
+
 template <bool GLU>
-__device__ __forceinline__ void direct_epilogue(const GemmArgs &g, const f32x16 &acc, const f32x16 &accg, int m0, int n,
-                                                int fhalf, const float *bias, const float *R, float *C) {
+__device__ __forceinline__ void load_w_stage(const GemmArgs &g, const i32x4 &rsW, int n0, int lr, int lc, int kt, WStage &st) {
+  const int kc = min(kt * TK + lc * 4, g.K - 4);       // a clamped k only re-reads columns whose A side is zero
+  const int ldw = (int)g.ldw;
+  st.b0 = buf4(rsW, ((n0 + lr) * ldw + kc) * 4);
+  st.b1 = buf4(rsW, ((n0 + lr + 32) * ldw + kc) * 4);
+  if (GLU) {
+    st.g0 = buf4(rsW, ((n0 + lr + g.glu_offset) * ldw + kc) * 4);
+    st.g1 = buf4(rsW, ((n0 + lr + 32 + g.glu_offset) * ldw + kc) * 4);
+  }
+}
+
+template <bool GLU>
+__device__ __forceinline__ void store_w_stage(float *Bs, int lr, int sw, const WStage &st) {
+  *(float4 *)&Bs[lr * TK + sw] = st.b0;
+  *(float4 *)&Bs[(lr + 32) * TK + sw] = st.b1;
+  if (GLU) {
+    *(float4 *)&Bs[(TN + lr) * TK + sw] = st.g0;
+    *(float4 *)&Bs[(TN + lr + 32) * TK + sw] = st.g1;
+  }
+}
+
+// 16 (32 with GLU) MFMAs of one 32-wide k-tile; the accumulator chains are interleaved
+template <bool GLU>
+__device__ __forceinline__ void tile_mfma(const float *At, const float *Bt, int arow, int br0, int fg, f32x4 &acc0, f32x4 &acc1,
+                                          f32x4 &accg0, f32x4 &accg1) {
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+    const int c = 4 * s2 + fg;                       // logical 16-byte slot: k = 16 s2 + 4 fg .. +3
+    const float4 a4 = *(const float4 *)&At[arow * TK + ((c ^ (arow & 7)) * 4)];
+    const int bsl = (c ^ (br0 & 7)) * 4;             // rows br0, br0 + 16 (and + TN) share (row & 7)
+    const float4 b0 = *(const float4 *)&Bt[br0 * TK + bsl];
+    const float4 b1 = *(const float4 *)&Bt[(br0 + 16) * TK + bsl];
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b0.x, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b1.x, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b0.y, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b1.y, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b0.z, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b1.z, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b0.w, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b1.w, acc1, 0, 0, 0);
+    if (GLU) {
+      const float4 g0 = *(const float4 *)&Bt[(TN + br0) * TK + bsl];
+      const float4 g1 = *(const float4 *)&Bt[(TN + br0 + 16) * TK + bsl];
+      accg0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, g0.x, accg0, 0, 0, 0);
+      accg1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, g1.x, accg1, 0, 0, 0);
+      accg0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, g0.y, accg0, 0, 0, 0);
+      accg1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, g1.y, accg1, 0, 0, 0);
+      accg0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, g0.z, accg0, 0, 0, 0);
+      accg1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, g1.z, accg1, 0, 0, 0);
+      accg0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, g0.w, accg0, 0, 0, 0);
+      accg1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, g1.w, accg1, 0, 0, 0);
+    }
+  }
+}
+
+// epilogue of the 32x64 tile.  16x16 C/D map: col = lane & 15, row = 4 * (lane >> 4) + r.  `res` holds the residual
+// values when they were prefetched (t32a), otherwise they are read here.
+template <bool GLU, bool PREFETCHED>
+__device__ __forceinline__ void tile_store(const GemmArgs &g, const f32x4 &av, const f32x4 &gv, int m_base, int n, const float *bias,
+                                           const float *R, float *C, const float (&res)[4]) {
   if (n >= g.N) return;
   const float bv = bias ? bias[n] : 0.0f;
   const float bgv = (GLU && bias) ? bias[n + g.glu_offset] : 0.0f;
-  const long ocol = g.col_group > 0 ? (long)(n / g.col_group) * g.col_group_pitch + (n % g.col_group) : n;
+  const long ocol = out_col(g, n);
+  const float a4[4] = {av.x, av.y, av.z, av.w};
+  const float g4[4] = {gv.x, gv.y, gv.z, gv.w};
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+  for (int r = 0; r < 4; ++r) {
+    const int m = m_base + r;
     if (m < g.M) {
-      float v = g.alpha * acc[r] + bv;
-      if (GLU) {
-        const float gate = g.alpha * accg[r] + bgv;
-        v *= (g.act == ACT_GLU_SELU) ? selu_exact(gate) : gelu_f(gate);
-      } else if (g.act == ACT_LEAKY) {
-        v = v > 0.0f ? v : 0.01f * v;
-      }
-      if (R) v += R[(long)m * g.ldr + n];
+      float v = epilogue_value<GLU>(g, a4[r], g4[r], bv, bgv);
+      if (PREFETCHED) v += res[r];
+      else if (R) v += R[(long)m * g.ldr + n];
       C[(long)m * g.ldc + ocol] = v;
     }
   }
 }
 
-#define HN_MFMA4(ACC, AV, BV)                                                   \
-  ACC = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).x, (BV).x, ACC, 0, 0, 0);     \
-  ACC = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).y, (BV).y, ACC, 0, 0, 0);     \
-  ACC = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).z, (BV).z, ACC, 0, 0, 0);     \
-  ACC = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).w, (BV).w, ACC, 0, 0, 0);
+template <bool GLU>
+__global__ __launch_bounds__(256) void gemm_t32_kernel(GemmArgs g) {
+  constexpr int NB = GLU ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) float As[2][TM * TK];
+  __shared__ __attribute__((aligned(16))) float Bs[2][NB * TN * TK];
+  __shared__ float row_mu[TM], row_rs[TM];
 
-// KS > 0: K == 32*KS, A resident in registers.  KS == 0: A streamed, any K % 32 == 0.
-template <int KS, bool GLU>
-__global__ __launch_bounds__(256) void gemm_direct_kernel(GemmArgs g, int nt) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int fr = lane & 31, fh = lane >> 5;
-  const int m0 = blockIdx.x * 32, z = blockIdx.z;
-  const int tile0 = (blockIdx.y * 4 + wave) * nt;
-  if (tile0 * 32 >= g.N) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fg = lane >> 4, fi = lane & 15;
+  const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN, z = blockIdx.z;
   const float *__restrict__ A = g.A + (long)z * g.strideA;
   const float *__restrict__ W = g.W + (long)z * g.strideW;
   float *__restrict__ C = g.C + (long)z * g.strideC;
   const float *bias = g.bias ? g.bias + (long)z * g.strideBias : nullptr;
   const float *R = g.R ? g.R + (long)z * g.strideR : nullptr;
-  const int mrow = min(m0 + fr, g.M - 1);
-  const float *arow = A + (long)mrow * g.lda + 16 * fh;
+  const i32x4 rsA = make_rsrc(A, rsrc_bytes(g.M, g.lda, g.K));
+  const i32x4 rsW = make_rsrc(W, rsrc_bytes(GLU ? g.N + g.glu_offset : g.N, g.ldw, g.K));
 
-  constexpr int NA = KS > 0 ? KS * 4 : 1;
-  float4 areg[NA];
-  if constexpr (KS > 0) {
-#pragma unroll
-    for (int i = 0; i < NA; ++i) areg[i] = *(const float4 *)(arow + 32 * (i >> 2) + 4 * (i & 3));
-    if (g.pro == PRO_LAYERNORM) {
-      float s = 0.0f;
-#pragma unroll
-      for (int i = 0; i < NA; ++i) s += (areg[i].x + areg[i].y) + (areg[i].z + areg[i].w);
-      s += __shfl_xor(s, 32);
-      const float mu = s / (float)g.K;
-      float q = 0.0f;
-#pragma unroll
-      for (int i = 0; i < NA; ++i) {
-        const float dx = areg[i].x - mu, dy = areg[i].y - mu, dz = areg[i].z - mu, dw = areg[i].w - mu;
-        q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
-      }
-      q += __shfl_xor(q, 32);
-      const float rs = 1.0f / sqrtf(q / (float)g.K + g.eps);
-#pragma unroll
-      for (int i = 0; i < NA; ++i) {
-        areg[i].x = (areg[i].x - mu) * rs; areg[i].y = (areg[i].y - mu) * rs;
-        areg[i].z = (areg[i].z - mu) * rs; areg[i].w = (areg[i].w - mu) * rs;
-      }
+  const int lr = tid >> 3, lc = tid & 7;        // loader: row 0..31, 16-byte slot 0..7 of the k-tile
+  const int arowb = (m0 + lr) * (int)g.lda * 4;
+  if (g.pro == PRO_LAYERNORM) {                 // shifted one-pass moments, 8 lanes per row
+    const float x0 = hn_buffer_load_x1(rsA, arowb, 0, 0);
+    float s1 = 0.0f, s2 = 0.0f;
+    for (int k = lc * 4; k < g.K; k += 32) {
+      const float4 v = buf4(rsA, arowb + k * 4);
+      const float dx = v.x - x0, dy = v.y - x0, dz = v.z - x0, dw = v.w - x0;
+      s1 += (dx + dy) + (dz + dw);
+      s2 += (dx * dx + dy * dy) + (dz * dz + dw * dw);
     }
+    s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2); s1 += __shfl_xor(s1, 4);
+    s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2); s2 += __shfl_xor(s2, 4);
+    const float inv_k = 1.0f / (float)g.K, dm = s1 * inv_k;
+    if (lc == 0) { row_mu[lr] = x0 + dm; row_rs[lr] = 1.0f / sqrtf(fmaxf(s2 * inv_k - dm * dm, 0.0f) + g.eps); }
+    __syncthreads();
+  }
+
+  auto load_a = [&](int kt) -> float4 {
+    const int k = kt * TK + lc * 4;
+    const float km = k < g.K ? 1.0f : 0.0f;
+    const int kc = min(k, g.K - 4);
+    float4 a = buf4(rsA, arowb + kc * 4);
     if (g.pro != PRO_NONE) {
-#pragma unroll
-      for (int i = 0; i < NA; ++i) {
-        const int k = 32 * (i >> 2) + 4 * (i & 3) + 16 * fh;
-        const float4 gm = g.gamma ? *(const float4 *)(g.gamma + k) : make_float4(1.f, 1.f, 1.f, 1.f);
-        const float4 bt = g.beta ? *(const float4 *)(g.beta + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-        areg[i].x = areg[i].x * gm.x + bt.x; areg[i].y = areg[i].y * gm.y + bt.y;
-        areg[i].z = areg[i].z * gm.z + bt.z; areg[i].w = areg[i].w * gm.w + bt.w;
-      }
+      const float4 gm = *(const float4 *)(g.gamma + kc);
+      const float4 bt = *(const float4 *)(g.beta + kc);
+      float mu = 0.0f, rs = 1.0f;
+      if (g.pro == PRO_LAYERNORM) { mu = row_mu[lr]; rs = row_rs[lr]; }
+      a.x = (a.x - mu) * rs * gm.x + bt.x; a.y = (a.y - mu) * rs * gm.y + bt.y;
+      a.z = (a.z - mu) * rs * gm.z + bt.z; a.w = (a.w - mu) * rs * gm.w + bt.w;
     }
+    return make_float4(a.x * km, a.y * km, a.z * km, a.w * km);
+  };
+  const int sw = (lc ^ (lr & 7)) * 4;
+
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, accg0 = {0.f, 0.f, 0.f, 0.f}, accg1 = {0.f, 0.f, 0.f, 0.f};
+  const int arow = wm * 16 + fi, br0 = wn * 32 + fi;
+  const int nk = (g.K + TK - 1) / TK;
+
+  // pipeline: LDS holds tile t (computing) and t+1 (being written); registers hold t+1 / t+2 in flight
+  WStage wa, wb;
+  float4 aa, ab;
+  aa = load_a(0);
+  load_w_stage<GLU>(g, rsW, n0, lr, lc, 0, wa);
+  *(float4 *)&As[0][lr * TK + sw] = aa;
+  store_w_stage<GLU>(Bs[0], lr, sw, wa);
+  __syncthreads();
+  if (nk > 1) { aa = load_a(1); load_w_stage<GLU>(g, rsW, n0, lr, lc, 1, wa); }
+  for (int kt = 0; kt < nk; kt += 2) {
+    if (kt + 2 < nk) { ab = load_a(kt + 2); load_w_stage<GLU>(g, rsW, n0, lr, lc, kt + 2, wb); }
+    tile_mfma<GLU>(As[0], Bs[0], arow, br0, fg, acc0, acc1, accg0, accg1);
+    if (kt + 1 < nk) { *(float4 *)&As[1][lr * TK + sw] = aa; store_w_stage<GLU>(Bs[1], lr, sw, wa); }
+    __syncthreads();
+    if (kt + 1 >= nk) break;
+    if (kt + 3 < nk) { aa = load_a(kt + 3); load_w_stage<GLU>(g, rsW, n0, lr, lc, kt + 3, wa); }
+    tile_mfma<GLU>(As[1], Bs[1], arow, br0, fg, acc0, acc1, accg0, accg1);
+    if (kt + 2 < nk) { *(float4 *)&As[0][lr * TK + sw] = ab; store_w_stage<GLU>(Bs[0], lr, sw, wb); }
+    __syncthreads();
   }
 
-  for (int t = 0; t < nt; ++t) {
-    const int n0 = (tile0 + t) * 32;
-    if (n0 >= g.N) break;
-    const int nrow = min(n0 + fr, g.N - 1);
-    const float *wrow = W + (long)nrow * g.ldw + 16 * fh;
-    const float *grow = W + (long)(nrow + (GLU ? g.glu_offset : 0)) * g.ldw + 16 * fh;
-    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    f32x16 accg = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if constexpr (KS > 0) {
-      float4 wc[4], gc[4], wn[4], gn[4];
+  const float none[4] = {0.f, 0.f, 0.f, 0.f};
+  tile_store<GLU, false>(g, acc0, accg0, m0 + wm * 16 + 4 * fg, n0 + wn * 32 + fi, bias, R, C, none);
+  tile_store<GLU, false>(g, acc1, accg1, m0 + wm * 16 + 4 * fg, n0 + wn * 32 + 16 + fi, bias, R, C, none);
+}
+
+template <bool GLU, int KT>
+__global__ __launch_bounds__(256) void gemm_t32a_kernel(GemmArgs g) {
+  constexpr int NB = GLU ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) float As[KT * TM * TK];
+  __shared__ __attribute__((aligned(16))) float Bs[2][NB * TN * TK];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fg = lane >> 4, fi = lane & 15;
+  const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN, z = blockIdx.z;
+  const float *__restrict__ A = g.A + (long)z * g.strideA;
+  const float *__restrict__ W = g.W + (long)z * g.strideW;
+  float *__restrict__ C = g.C + (long)z * g.strideC;
+  const float *bias = g.bias ? g.bias + (long)z * g.strideBias : nullptr;
+  const float *R = g.R ? g.R + (long)z * g.strideR : nullptr;
+  const i32x4 rsA = make_rsrc(A, rsrc_bytes(g.M, g.lda, g.K));
+  const i32x4 rsW = make_rsrc(W, rsrc_bytes(GLU ? g.N + g.glu_offset : g.N, g.ldw, g.K));
+  const int lr = tid >> 3, lc = tid & 7;
+  const int nk = (g.K + TK - 1) / TK;
+  const int sw = (lc ^ (lr & 7)) * 4;
+
+  // ---- everything that comes from far away is requested first: the whole A block, the residual values, W tiles 0/1
+  float4 av[KT];
+  const int arowb = (m0 + lr) * (int)g.lda * 4;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { wc[i] = *(const float4 *)(wrow + 4 * i); if (GLU) gc[i] = *(const float4 *)(grow + 4 * i); }
+  for (int t = 0; t < KT; ++t) av[t] = buf4(rsA, arowb + min(t * TK + lc * 4, g.K - 4) * 4);
+  float res0[4] = {0.f, 0.f, 0.f, 0.f}, res1[4] = {0.f, 0.f, 0.f, 0.f};
+  if (R) {
+    const i32x4 rsR = make_rsrc(R, rsrc_bytes(g.M, g.ldr, g.N));
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        if (s + 1 < KS) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            wn[i] = *(const float4 *)(wrow + 32 * (s + 1) + 4 * i);
-            if (GLU) gn[i] = *(const float4 *)(grow + 32 * (s + 1) + 4 * i);
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          HN_MFMA4(acc, areg[4 * s + i], wc[i])
-          if (GLU) { HN_MFMA4(accg, areg[4 * s + i], gc[i]) }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { wc[i] = wn[i]; if (GLU) gc[i] = gn[i]; }
-      }
-    } else {
-      const int nsteps = g.K >> 5;
-      float4 ac[4], wc[4], gc[4], an[4], wn[4], gn[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        ac[i] = *(const float4 *)(arow + 4 * i);
-        wc[i] = *(const float4 *)(wrow + 4 * i);
-        if (GLU) gc[i] = *(const float4 *)(grow + 4 * i);
-      }
-      for (int s = 0; s < nsteps; ++s) {
-        if (s + 1 < nsteps) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            an[i] = *(const float4 *)(arow + 32 * (s + 1) + 4 * i);
-            wn[i] = *(const float4 *)(wrow + 32 * (s + 1) + 4 * i);
-            if (GLU) gn[i] = *(const float4 *)(grow + 32 * (s + 1) + 4 * i);
-          }
-        }
-        if (g.pro == PRO_AFFINE) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int k = 32 * s + 4 * i + 16 * fh;
-            const float4 gm = g.gamma ? *(const float4 *)(g.gamma + k) : make_float4(1.f, 1.f, 1.f, 1.f);
-            const float4 bt = g.beta ? *(const float4 *)(g.beta + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-            ac[i].x = ac[i].x * gm.x + bt.x; ac[i].y = ac[i].y * gm.y + bt.y;
-            ac[i].z = ac[i].z * gm.z + bt.z; ac[i].w = ac[i].w * gm.w + bt.w;
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          HN_MFMA4(acc, ac[i], wc[i])
-          if (GLU) { HN_MFMA4(accg, ac[i], gc[i]) }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { ac[i] = an[i]; wc[i] = wn[i]; if (GLU) gc[i] = gn[i]; }
-      }
+    for (int r = 0; r < 4; ++r) {
+      const int off = ((m0 + wm * 16 + 4 * fg + r) * (int)g.ldr + n0 + wn * 32 + fi) * 4;
+      res0[r] = hn_buffer_load_x1(rsR, off, 0, 0);
+      res1[r] = hn_buffer_load_x1(rsR, off + 64, 0, 0);
     }
-    direct_epilogue<GLU>(g, acc, accg, m0, n0 + fr, fh, bias, R, C);
   }
+  WStage wa, wb;
+  load_w_stage<GLU>(g, rsW, n0, lr, lc, 0, wa);
+  if (nk > 1) load_w_stage<GLU>(g, rsW, n0, lr, lc, 1, wb);
+
+  // ---- prologue on the register-resident A block, then park it in LDS (swizzled per k-tile)
+  float mu = 0.0f, rs = 1.0f;
+  if (g.pro == PRO_LAYERNORM) {
+    const float x0 = __shfl(av[0].x, lane & ~7);          // first element of the row (loader lane lc == 0)
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+      const float km = (t * TK + lc * 4) < g.K ? 1.0f : 0.0f;
+      const float dx = av[t].x - x0, dy = av[t].y - x0, dz = av[t].z - x0, dw = av[t].w - x0;
+      s1 += km * ((dx + dy) + (dz + dw));
+      s2 += km * ((dx * dx + dy * dy) + (dz * dz + dw * dw));
+    }
+    s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2); s1 += __shfl_xor(s1, 4);
+    s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2); s2 += __shfl_xor(s2, 4);
+    const float inv_k = 1.0f / (float)g.K, dm = s1 * inv_k;
+    mu = x0 + dm;
+    rs = 1.0f / sqrtf(fmaxf(s2 * inv_k - dm * dm, 0.0f) + g.eps);
+  }
+#pragma unroll
+  for (int t = 0; t < KT; ++t) {
+    if (t < nk) {
+      const int k = t * TK + lc * 4;
+      float4 v = av[t];
+      if (g.pro != PRO_NONE) {
+        const int kc = min(k, g.K - 4);
+        const float4 gm = *(const float4 *)(g.gamma + kc);
+        const float4 bt = *(const float4 *)(g.beta + kc);
+        v.x = (v.x - mu) * rs * gm.x + bt.x; v.y = (v.y - mu) * rs * gm.y + bt.y;
+        v.z = (v.z - mu) * rs * gm.z + bt.z; v.w = (v.w - mu) * rs * gm.w + bt.w;
+      }
+      const float km = k < g.K ? 1.0f : 0.0f;
+      *(float4 *)&As[t * TM * TK + lr * TK + sw] = make_float4(v.x * km, v.y * km, v.z * km, v.w * km);
+    }
+  }
+  store_w_stage<GLU>(Bs[0], lr, sw, wa);
+  __syncthreads();
+
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, accg0 = {0.f, 0.f, 0.f, 0.f}, accg1 = {0.f, 0.f, 0.f, 0.f};
+  const int arow = wm * 16 + fi, br0 = wn * 32 + fi;
+  // W pipeline: LDS holds tile t and t+1, registers hold t+1 / t+2
+  for (int kt = 0; kt < nk; kt += 2) {
+    if (kt + 2 < nk) load_w_stage<GLU>(g, rsW, n0, lr, lc, kt + 2, wa);
+    tile_mfma<GLU>(As + kt * TM * TK, Bs[0], arow, br0, fg, acc0, acc1, accg0, accg1);
+    if (kt + 1 < nk) store_w_stage<GLU>(Bs[1], lr, sw, wb);
+    __syncthreads();
+    if (kt + 1 >= nk) break;
+    if (kt + 3 < nk) load_w_stage<GLU>(g, rsW, n0, lr, lc, kt + 3, wb);
+    tile_mfma<GLU>(As + (kt + 1) * TM * TK, Bs[1], arow, br0, fg, acc0, acc1, accg0, accg1);
+    if (kt + 2 < nk) store_w_stage<GLU>(Bs[0], lr, sw, wa);
+    __syncthreads();
+  }
+
+  tile_store<GLU, true>(g, acc0, accg0, m0 + wm * 16 + 4 * fg, n0 + wn * 32 + fi, bias, R, C, res0);
+  tile_store<GLU, true>(g, acc1, accg1, m0 + wm * 16 + 4 * fg, n0 + wn * 32 + 16 + fi, bias, R, C, res1);
 }
 
 // ------------------------------------------------------------------------------------------------
 // Skinny variant for M <= 32 rows (the tabular / omic modality: one context token per sample, so the
 // K/V projection is b rows x 2005 features against an 8.2 MB weight -- a weight-streaming, HBM-bound
-// GEMV batch, not MFMA work).  One workgroup produces TN = 4 output columns for all rows: lanes run
+// GEMV batch, not MFMA work).  One workgroup produces 4 output columns for all rows: lanes run
 // along k (coalesced dword loads of the weight rows, no alignment requirement), the four waves split
 // the k range, every lane keeps 32 x 4 partial sums which are folded across the wave with a
 // reduce-scatter butterfly (126 shuffles instead of 768) and across the waves through LDS.
@@ -343,29 +467,33 @@ __device__ __forceinline__ void fold_half(float (&v)[128], int lane, int mask) {
 }
 
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
-  constexpr int TN = 4, TM = 32;
-  __shared__ float part[4][TM * TN];
+  constexpr int SN = 4, SM = 32;
+  __shared__ float part[4][SM * SN];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n0 = blockIdx.x * TN, z = blockIdx.z;
-  const float *__restrict__ A = g.A + (long)z * g.strideA;
-  const float *__restrict__ W = g.W + (long)z * g.strideW;
-  float acc[TM * TN];
+  const int n0 = blockIdx.x * SN, z = blockIdx.z;
+  const i32x4 rsA = make_rsrc(g.A + (long)z * g.strideA, rsrc_bytes(g.M, g.lda, g.K));
+  const i32x4 rsW = make_rsrc(g.W + (long)z * g.strideW, rsrc_bytes(g.N, g.ldw, g.K));
+  float acc[SM * SN];
 #pragma unroll
-  for (int i = 0; i < TM * TN; ++i) acc[i] = 0.0f;
+  for (int i = 0; i < SM * SN; ++i) acc[i] = 0.0f;
   for (int k0 = wave * 64; k0 < g.K; k0 += 256) {
     const int k = k0 + lane;
-    const bool kin = k < g.K;
-    float w[TN];
+    const float km = k < g.K ? 1.0f : 0.0f;
+    const int kc = min(k, g.K - 1);
+    float w[SN], av[SM];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) w[j] = (kin && n0 + j < g.N) ? W[(long)(n0 + j) * g.ldw + k] : 0.0f;
+    for (int j = 0; j < SN; ++j) w[j] = hn_buffer_load_x1(rsW, ((n0 + j) * (int)g.ldw + kc) * 4, 0, 0);
+#pragma unroll
+    for (int m = 0; m < SM; ++m) av[m] = hn_buffer_load_x1(rsA, (m * (int)g.lda + kc) * 4, 0, 0);
     float gam = 1.0f, bet = 0.0f;
-    if (g.pro == PRO_AFFINE && kin) { gam = g.gamma ? g.gamma[k] : 1.0f; bet = g.beta ? g.beta[k] : 0.0f; }
+    if (g.pro == PRO_AFFINE) { gam = g.gamma[kc]; bet = g.beta[kc]; }
+    gam *= km;
+    bet *= km;
 #pragma unroll
-    for (int m = 0; m < TM; ++m) {
-      float a = 0.0f;
-      if (kin && m < g.M) a = A[(long)m * g.lda + k] * gam + bet;
+    for (int m = 0; m < SM; ++m) {
+      const float a = av[m] * gam + bet;           // rows past M carry beta only, into outputs nobody stores
 #pragma unroll
-      for (int j = 0; j < TN; ++j) acc[m * TN + j] = fmaf(a, w[j], acc[m * TN + j]);
+      for (int j = 0; j < SN; ++j) acc[m * SN + j] = fmaf(a, w[j], acc[m * SN + j]);
     }
   }
   fold_half<64>(acc, lane, 32);
@@ -374,66 +502,62 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
   fold_half<8>(acc, lane, 4);
   fold_half<4>(acc, lane, 2);
   fold_half<2>(acc, lane, 1);
-  part[wave][2 * lane] = acc[0];          // lane now owns flattened outputs 2*lane, 2*lane + 1 (index = m*TN + j)
+  part[wave][2 * lane] = acc[0];          // lane now owns flattened outputs 2*lane, 2*lane + 1 (index = m*SN + j)
   part[wave][2 * lane + 1] = acc[1];
   __syncthreads();
-  if (threadIdx.x < TM * TN) {
-    const int idx = threadIdx.x, m = idx / TN, n = n0 + idx % TN;
+  if (threadIdx.x < SM * SN) {
+    const int idx = threadIdx.x, m = idx / SN, n = n0 + idx % SN;
     if (m < g.M && n < g.N) {
       float v = g.alpha * (part[0][idx] + part[1][idx] + part[2][idx] + part[3][idx]);
       if (g.bias) v += g.bias[(long)z * g.strideBias + n];
       if (g.act == ACT_LEAKY) v = v > 0.0f ? v : 0.01f * v;
       if (g.R) v += g.R[(long)z * g.strideR + (long)m * g.ldr + n];
-      const long ocol = g.col_group > 0 ? (long)(n / g.col_group) * g.col_group_pitch + (n % g.col_group) : n;
-      g.C[(long)z * g.strideC + (long)m * g.ldc + ocol] = v;
+      g.C[(long)z * g.strideC + (long)m * g.ldc + out_col(g, n)] = v;
     }
   }
 }
 
-static bool direct_eligible(const GemmArgs &g) {
+static bool aligned_eligible(const GemmArgs &g) {
   auto al16 = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
-  if (g.K % 32 != 0 || g.lda % 4 != 0 || g.ldw % 4 != 0) return false;
+  if (g.K % 4 != 0 || g.lda % 4 != 0 || g.ldw % 4 != 0) return false;
   if (g.strideA % 4 != 0 || g.strideW % 4 != 0) return false;
   if (!al16(g.A) || !al16(g.W)) return false;
-  if (g.pro != PRO_NONE && ((g.gamma && !al16(g.gamma)) || (g.beta && !al16(g.beta)))) return false;
-  if (g.pro == PRO_LAYERNORM && g.K > 128) return false;   // LN needs the row resident in registers
+  if (g.pro != PRO_NONE && (!al16(g.gamma) || !al16(g.beta))) return false;
   return true;
-}
-
-template <bool GLU>
-static void launch_direct(const GemmArgs &g, hipStream_t s) {
-  const int mt = ceil_div(g.M, 32), ntiles = ceil_div(g.N, 32);
-  // enough waves to cover the chip a few times over, but let a wave reuse its A block when N is large
-  int nt = 1;
-  while (nt < 4 && (long)mt * ceil_div(ntiles, nt * 2) >= 2048) nt *= 2;
-  dim3 grid(mt, ceil_div(ntiles, 4 * nt), g.batch);
-  const int ks = g.K <= 128 ? g.K / 32 : 0;
-  switch (ks) {
-    case 1: hipLaunchKernelGGL((gemm_direct_kernel<1, GLU>), grid, dim3(256), 0, s, g, nt); break;
-    case 2: hipLaunchKernelGGL((gemm_direct_kernel<2, GLU>), grid, dim3(256), 0, s, g, nt); break;
-    case 3: hipLaunchKernelGGL((gemm_direct_kernel<3, GLU>), grid, dim3(256), 0, s, g, nt); break;
-    case 4: hipLaunchKernelGGL((gemm_direct_kernel<4, GLU>), grid, dim3(256), 0, s, g, nt); break;
-    default: hipLaunchKernelGGL((gemm_direct_kernel<0, GLU>), grid, dim3(256), 0, s, g, nt); break;
-  }
 }
 
 int launch_gemm(const GemmArgs &g, hipStream_t s) {
   HN_REQUIRE(g.A && g.W && g.C, HN_E_NULL, "gemm: NULL operand");
   HN_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.batch > 0, HN_E_SHAPE, "gemm: M=%d N=%d K=%d batch=%d", g.M, g.N,
              g.K, g.batch);
-  dim3 grid(ceil_div(g.M, BM), ceil_div(g.N, BN), g.batch);
-  HN_REQUIRE(grid.y <= 65535 && grid.z <= 65535, HN_E_UNSUPPORTED, "gemm: grid too large (N=%d batch=%d)", g.N, g.batch);
+  HN_REQUIRE(g.pro == PRO_NONE || (g.gamma && g.beta), HN_E_NULL, "gemm: prologue needs gamma and beta");
   const bool glu = g.act == ACT_GLU_SELU || g.act == ACT_GLU_GELU;
+  // the buffer descriptors address operands with 32-bit byte offsets
+  const long a_span = ((long)(g.M + 64) * g.lda) * 4, w_span = ((long)(g.N + (glu ? g.glu_offset : 0) + 64) * g.ldw) * 4;
+  HN_REQUIRE(a_span < (1L << 31) && w_span < (1L << 31) && (long)(g.M + 64) * g.ldr * 4 < (1L << 31), HN_E_UNSUPPORTED,
+             "gemm: an operand spans more than 2 GiB (M=%d lda=%ld N=%d ldw=%ld)", g.M, g.lda, g.N, g.ldw);
   if (g.M <= 32 && !glu && g.pro != PRO_LAYERNORM && g.K >= 512) {
     hipLaunchKernelGGL(gemm_skinny_kernel, dim3(ceil_div(g.N, 4), 1, g.batch), dim3(256), 0, s, g);
     HN_LAUNCH_CHECK("gemm_skinny");
     return HN_OK;
   }
-  if (direct_eligible(g) && ceil_div(g.N, 128) <= 65535) {
-    if (glu) launch_direct<true>(g, s); else launch_direct<false>(g, s);
-    HN_LAUNCH_CHECK("gemm_direct");
+  if (aligned_eligible(g) && ceil_div(g.N, TN) <= 65535) {
+    dim3 grid32(ceil_div(g.M, TM), ceil_div(g.N, TN), g.batch);
+    if (g.K <= 128) {
+      if (glu) hipLaunchKernelGGL((gemm_t32a_kernel<true, 4>), grid32, dim3(256), 0, s, g);
+      else hipLaunchKernelGGL((gemm_t32a_kernel<false, 4>), grid32, dim3(256), 0, s, g);
+    } else if (g.K <= 512 && !glu) {
+      hipLaunchKernelGGL((gemm_t32a_kernel<false, 16>), grid32, dim3(256), 0, s, g);
+    } else if (glu) {
+      hipLaunchKernelGGL(gemm_t32_kernel<true>, grid32, dim3(256), 0, s, g);
+    } else {
+      hipLaunchKernelGGL(gemm_t32_kernel<false>, grid32, dim3(256), 0, s, g);
+    }
+    HN_LAUNCH_CHECK("gemm_t32");
     return HN_OK;
   }
+  dim3 grid(ceil_div(g.M, BM), ceil_div(g.N, BN), g.batch);
+  HN_REQUIRE(grid.y <= 65535 && grid.z <= 65535, HN_E_UNSUPPORTED, "gemm: grid too large (N=%d batch=%d)", g.N, g.batch);
   if (glu)
     hipLaunchKernelGGL(gemm_kernel<true>, grid, dim3(256), 0, s, g);
   else

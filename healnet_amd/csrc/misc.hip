@@ -40,16 +40,22 @@ int launch_pad_rows(const float *src, int ld_src, float *dst, int ld_dst, long r
 __global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ x, int L, int d, const float *__restrict__ nw,
                                                    const float *__restrict__ nb, const float *__restrict__ w,
                                                    const float *__restrict__ bias, int out_dims, float *__restrict__ logits) {
-  extern __shared__ float sm[];  // pooled[d] + 8 scratch
+  extern __shared__ float sm[];  // pooled[d] + 8 scratch + 4 x d partial column sums
   float *pooled = sm;
   float *red = sm + d;
+  float *part = sm + d + 8;
   const int bi = blockIdx.x, tid = threadIdx.x;
   const float *xb = x + (long)bi * L * d;
-  for (int c = tid; c < d; c += blockDim.x) {
-    float s = 0.0f;
-    for (int r = 0; r < L; ++r) s += xb[(long)r * d + c];
-    pooled[c] = s / (float)L;
+  {   // column means: the four waves take rows w, w+4, ...; lanes run along the columns (coalesced rows)
+    const int w = tid >> 6, ln = tid & 63;
+    for (int c = ln; c < d; c += 64) {
+      float s = 0.0f;
+      for (int r = w; r < L; r += 4) s += xb[(long)r * d + c];
+      part[w * d + c] = s;
+    }
   }
+  __syncthreads();
+  for (int c = tid; c < d; c += blockDim.x) pooled[c] = (part[c] + part[d + c] + part[2 * d + c] + part[3 * d + c]) / (float)L;
   __syncthreads();
   // mean
   float s = 0.0f;
@@ -81,7 +87,7 @@ int launch_head(const float *x, int b, int L, int d, const float *nw, const floa
                 int out_dims, float *logits, hipStream_t s) {
   HN_REQUIRE(x && nw && nb && w && logits, HN_E_NULL, "head: NULL pointer");
   HN_REQUIRE(b > 0 && L > 0 && d > 0 && out_dims > 0, HN_E_SHAPE, "head: b=%d L=%d d=%d out=%d", b, L, d, out_dims);
-  size_t lds = (size_t)(d + 8) * sizeof(float);
+  size_t lds = (size_t)(5 * d + 8) * sizeof(float);
   HN_REQUIRE(lds <= 64 * 1024, HN_E_UNSUPPORTED, "head: l_d=%d too large", d);
   hipLaunchKernelGGL(head_kernel, dim3(b), dim3(256), lds, s, x, L, d, nw, nb, w, bias, out_dims, logits);
   HN_LAUNCH_CHECK("head");
