@@ -163,16 +163,41 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
   if ((rc = check_ws(ws, ws_bytes, pl.bytes, "attn")) != HN_OK) return rc;
   if ((rc = plan_attn(p, ctx != nullptr, ld_ctx, b, L, N, D, ws, ws_bytes, &pl)) != HN_OK) return rc;
 
+  // ---- one-token context without a mask (tabular / omic modality): softmax over a single key is exactly 1, so the
+  // block reduces to y = LeakyReLU(W_out (W_v c) + b_out) broadcast over the latent rows; Q and K are dead
+  // (SURVEY.md Appendix A-7).  Two skinny GEMMs on b rows instead of the b*L-row pipeline.
+  if (ctx != nullptr && pl.N == 1 && mask == nullptr) {
+    float *vbuf = pl.q, *ybuf = pl.obuf;                   // (b, inner), (b, query_dim)
+    GemmArgs gv = gemm_defaults();
+    gv.A = ctx; gv.lda = ld_ctx; gv.M = b; gv.K = pl.D;
+    if (p->ctx_gamma) { gv.pro = PRO_AFFINE; gv.gamma = p->ctx_gamma; gv.beta = p->ctx_beta; }
+    gv.W = p->w_kv + (long)pl.inner * pl.D; gv.ldw = pl.D; gv.N = pl.inner;
+    gv.C = vbuf; gv.ldc = pl.inner;
+    if ((rc = launch_gemm(gv, s)) != HN_OK) return rc;
+    GemmArgs gy = gemm_defaults();
+    gy.A = vbuf; gy.lda = pl.inner; gy.M = b; gy.K = pl.inner;
+    gy.W = p->w_out; gy.ldw = pl.inner; gy.N = p->query_dim;
+    gy.bias = p->b_out; gy.act = ACT_LEAKY;
+    gy.C = ybuf; gy.ldc = p->query_dim;
+    if ((rc = launch_gemm(gy, s)) != HN_OK) return rc;
+    if (stats) {   // p == 1: any (max, sum) pair with sum 1 and max == the score reproduces it; hn_attn_probs special-cases N == 1
+      if ((rc = launch_fill(stats, 1.0f, (long)b * p->heads * L * 2, s)) != HN_OK) return rc;
+    }
+    return launch_add_row_broadcast(ybuf, residual ? x_in : nullptr, x_out, b, L, p->query_dim, s);
+  }
+
   AttnCoreArgs core;
   if ((rc = attn_prepare(p, pl, x_in, ctx, ld_ctx, b, L, s, &core)) != HN_OK) return rc;
   core.mask = mask;
+  const bool direct = !pl.rank_d && pl.nsplit == 1;
+  if (direct) { core.Ofinal = pl.obuf; core.ldo = pl.inner; core.dh = pl.dh; core.stats = stats; }
   if (ev0) HN_HIP_CHECK(hipEventRecord(ev0, s));
   if ((rc = launch_attn_core(core, s)) != HN_OK) return rc;
   if (ev1) HN_HIP_CHECK(hipEventRecord(ev1, s));
   if (pl.rank_d) {
     rc = launch_merge_vproj(pl.opart, pl.mpart, pl.lpart, pl.nsplit, b, p->heads, L, pl.Lp, pl.dp, pl.D, p->ctx_gamma,
                             p->ctx_beta, p->w_kv + (long)pl.inner * pl.D, pl.dh, pl.obuf, pl.inner, stats, s);
-  } else {
+  } else if (!direct) {
     rc = launch_merge_explicit(pl.opart, pl.mpart, pl.lpart, pl.nsplit, b, p->heads, L, pl.Lp, pl.dp, pl.dh, pl.obuf,
                                pl.inner, stats, s);
   }
@@ -344,6 +369,7 @@ int hn_attn_probs(const hn_attn_params *p, const float *x_in, const float *ctx, 
   if (rc != HN_OK) return rc;
   if ((rc = check_ws(workspace, workspace_bytes, pl.bytes, "attn_probs")) != HN_OK) return rc;
   if ((rc = plan_attn(p, ctx != nullptr, ld_ctx, b, L, N, D, workspace, workspace_bytes, &pl)) != HN_OK) return rc;
+  if (ctx != nullptr && pl.N == 1 && mask == nullptr) return launch_fill(probs, 1.0f, (long)b * p->heads * L, s);
   AttnCoreArgs core;
   if ((rc = attn_prepare(p, pl, x_in, ctx, ld_ctx, b, L, s, &core)) != HN_OK) return rc;
   return launch_probs(core.Q, core.q_b, core.q_h, core.ldq, pl.rank_d ? pl.D : pl.dh, core.Kp, core.k_b, core.k_h, core.ldk,

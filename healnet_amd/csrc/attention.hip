@@ -264,30 +264,58 @@ __global__ __launch_bounds__(256) void attn_core_kernel(AttnCoreArgs a, int ngro
     if (t0 + 16 < t_end) step(t0 + 16, kB, vB, kA, vA);
   }
 
+  // ---- single split (latent self-attention, short contexts): normalise and write O in its final layout
+  if (!ONES && a.Ofinal != nullptr) {
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int tile = qg * NQ + i;
+      float li = l[i];
+      li += __shfl_xor(li, 16);
+      li += __shfl_xor(li, 32);
+      const float inv = 1.0f / li;                         // lane (g, j): row j of the tile
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float ir = __shfl(inv, 4 * g + r);           // accumulator reg r of lane (g, d) belongs to row 4 g + r
+        const int q = tile * 16 + 4 * g + r;
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+          const int col = 16 * d + j;
+          if (q < L && col < a.dh) a.Ofinal[((long)bi * L + q) * a.ldo + hi * a.dh + col] = O[i][d][r] * ir;
+        }
+      }
+      if (a.stats && g == 0 && tile * 16 + j < L) {
+        a.stats[((long)bh * L + tile * 16 + j) * 2 + 0] = m[i];
+        a.stats[((long)bh * L + tile * 16 + j) * 2 + 1] = li;
+      }
+    }
+    return;
+  }
+
   // ---- write the partial (O, m, l) of this split.  ONES: l sits in accumulator column DP-1.
   const long prow = ((long)bh * a.nsplit + split) * a.Lp;
 #pragma unroll
   for (int i = 0; i < NQ; ++i) {
     const int tile = qg * NQ + i;
-    if (tile * 16 >= a.Lp) continue;
+    if (tile * 16 < a.Lp) {
 #pragma unroll
-    for (int d = 0; d < DT; ++d)
+      for (int d = 0; d < DT; ++d)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        a.Opart[(prow + tile * 16 + 4 * g + r) * DP + 16 * d + j] = O[i][d][r];
-    if (ONES) {
-      if (g == 0) a.Mpart[prow + tile * 16 + j] = m[i];
-      if (j == 15) {
+        for (int r = 0; r < 4; ++r)
+          a.Opart[(prow + tile * 16 + 4 * g + r) * DP + 16 * d + j] = O[i][d][r];
+      if (ONES) {
+        if (g == 0) a.Mpart[prow + tile * 16 + j] = m[i];
+        if (j == 15) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) a.Lpart[prow + tile * 16 + 4 * g + r] = O[i][DT - 1][r];
-      }
-    } else {
-      float li = l[i];
-      li += __shfl_xor(li, 16);
-      li += __shfl_xor(li, 32);
-      if (g == 0) {
-        a.Mpart[prow + tile * 16 + j] = m[i];
-        a.Lpart[prow + tile * 16 + j] = li;
+          for (int r = 0; r < 4; ++r) a.Lpart[prow + tile * 16 + 4 * g + r] = O[i][DT - 1][r];
+        }
+      } else {
+        float li = l[i];
+        li += __shfl_xor(li, 16);
+        li += __shfl_xor(li, 32);
+        if (g == 0) {
+          a.Mpart[prow + tile * 16 + j] = m[i];
+          a.Lpart[prow + tile * 16 + j] = li;
+        }
       }
     }
   }
@@ -327,6 +355,7 @@ int launch_attn_core(const AttnCoreArgs &a, hipStream_t s) {
   HN_REQUIRE((a.ldq % 4) == 0 && (a.ldk % 4) == 0, HN_E_SHAPE, "attn_core: ldq=%d ldk=%d must be multiples of 4", a.ldq, a.ldk);
   HN_REQUIRE(((long)a.N * a.ldk + a.dp) * 4 < (1L << 31) && ((long)a.N * a.ldv + a.dp) * 4 < (1L << 31), HN_E_UNSUPPORTED,
              "attn_core: one sample's K/V rows must span < 2 GiB (N=%d ld=%d)", a.N, a.ldk);
+  HN_REQUIRE(a.Ofinal == nullptr || (a.nsplit == 1 && !a.ones_col), HN_E_SHAPE, "attn_core: direct output needs a single split");
   HN_REQUIRE(!a.ones_col || (a.dp <= 32 && a.Kp == a.Vp), HN_E_UNSUPPORTED, "attn_core: ones column needs the shared-context binding");
   const int dt = a.dp / 16, nq = nq_for(dt);
   const int ngroups = ceil_div(a.Lp / 16, nq);

@@ -118,6 +118,7 @@ struct AttnCoreArgs {
   int b, h, Lq, Lp, N, dp;                      // Lq valid query rows, Lp = Lq rounded up to 16, dp in {16,32,64,128}
   int nsplit, chunk;                            // tokens per split (multiple of 16)
   int ones_col;                                 // rank-D binding with D <= dp-1: synthetic ones column dp-1 (see attention.hip)
+  float *Ofinal; int ldo, dh; float *stats;     // nsplit == 1 only: write the normalised O (b*Lq, ldo) + stats directly (no merge kernel)
 };
 int launch_attn_core(const AttnCoreArgs &a, hipStream_t s);
 void attn_core_geometry(int b, int h, int Lp, int N, int dp, int *nsplit, int *chunk);
@@ -137,5 +138,7 @@ int launch_broadcast_rows(const float *src, float *dst, long n_per, int b, hipSt
 int launch_head(const float *x, int b, int L, int d, const float *nw, const float *nb, const float *w,
                 const float *bias, int out_dims, float *logits, hipStream_t s);
 int launch_pad_rows(const float *src, int ld_src, float *dst, int ld_dst, long rows, int cols, hipStream_t s);
+int launch_add_row_broadcast(const float *y, const float *x_in, float *x_out, int b, int L, int d, hipStream_t s);
+int launch_fill(float *dst, float value, long n, hipStream_t s);
 
 }  // namespace hn

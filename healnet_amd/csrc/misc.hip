@@ -36,6 +36,38 @@ int launch_pad_rows(const float *src, int ld_src, float *dst, int ld_dst, long r
   return HN_OK;
 }
 
+// x_out[b, l, :] = y[b, :] (+ x_in[b, l, :]) -- epilogue of the one-token attention path
+__global__ __launch_bounds__(256) void add_row_broadcast_kernel(const float *__restrict__ y, const float *x_in,
+                                                                float *x_out, int L, int d, long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / d;
+    const int c = (int)(i - row * d);
+    const float v = y[(row / L) * d + c];
+    x_out[i] = x_in ? v + x_in[i] : v;
+  }
+}
+
+int launch_add_row_broadcast(const float *y, const float *x_in, float *x_out, int b, int L, int d, hipStream_t s) {
+  const long total = (long)b * L * d;
+  long blocks = ceil_div_ll(total, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(add_row_broadcast_kernel, dim3((unsigned)blocks), dim3(256), 0, s, y, x_in, x_out, L, d, total);
+  HN_LAUNCH_CHECK("add_row_broadcast");
+  return HN_OK;
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(float *__restrict__ dst, float value, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = value;
+}
+
+int launch_fill(float *dst, float value, long n, hipStream_t s) {
+  long blocks = ceil_div_ll(n, 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dst, value, n);
+  HN_LAUNCH_CHECK("fill");
+  return HN_OK;
+}
+
 // One workgroup per sample: column means over the L latent rows -> LayerNorm(d) -> Linear(d, out).
 __global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ x, int L, int d, const float *__restrict__ nw,
                                                    const float *__restrict__ nb, const float *__restrict__ w,

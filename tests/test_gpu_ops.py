@@ -188,3 +188,17 @@ def test_torch_ops_surface(hn):
     want = O.feed_forward(O.layer_norm(want, p["nw"], p["nb"]), p["w1"], p["b1"], p["w2"], p["b2"], True) + want
     want = O.layer_norm(want.mean(1), p["nw"], p["nb"]) @ p["hw"].t() + p["hb"]
     assert_close(logits.cpu(), want, rel=1e-4, what="ops.chain")
+
+
+def test_one_token_context_paths_agree(hn):
+    """N == 1 takes the degenerate fast path (P == 1); with an all-true mask the general split-KV path runs."""
+    gen = torch.Generator().manual_seed(21)
+    blk = hn.PreNorm(128, hn.Attention(128, 2005, heads=8, dim_head=64), context_dim=2005).to(DEV)
+    x = torch.randn(5, 128, 128, generator=gen).to(DEV)
+    ctx = torch.rand(5, 1, 2005, generator=gen).to(DEV)
+    fast = blk(x, context=ctx)
+    p_fast = blk.fn.attn_weights
+    general = blk(x, context=ctx, mask=torch.ones(5, 1, dtype=torch.bool, device=DEV))
+    p_general = blk.fn.attn_weights
+    assert_close(fast.cpu(), general.cpu(), rel=1e-5, what="one-token fast vs general")
+    assert torch.equal(p_fast, torch.ones_like(p_fast)) and torch.allclose(p_general, p_fast, atol=1e-6)
