@@ -140,3 +140,63 @@ def test_shape_errors_raise_instead_of_being_swallowed(hn):
         model([torch.rand(2, 7, 33).to(DEV)])              # patch bag in the tabular slot (main.py:536-538 pattern)
     with pytest.raises(AssertionError):
         model([torch.rand(2, 20).to(DEV), None])
+
+
+# ------------------------------------------------------------------------------------------------
+# the other BASELINE.json configurations at their full shapes
+# ------------------------------------------------------------------------------------------------
+def _oracle_logits(model, kw, ins):
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        return O.fusion_forward(sd, O.FusionConfig(**kw), [None if t is None else t.cpu() for t in ins])
+
+
+def test_cfg4_full_size_vs_oracle(hn):
+    """TCGA-BRCA-shaped: omic (8,1,2000) + WSI patch bag (8,4096,768), explicit K/V path at N=4096, D=773."""
+    kw = dict(n_modalities=2, channel_dims=[2000, 768], num_spatial_axes=[1, 1], out_dims=4)
+    torch.manual_seed(3)
+    model = hn.HealNet(**kw).eval().to(DEV)
+    gen = torch.Generator().manual_seed(77)
+    ins = [torch.rand(8, 1, 2000, generator=gen).to(DEV), torch.rand(8, 4096, 768, generator=gen).to(DEV)]
+    y = model(list(ins))
+    assert_close(y.cpu(), _oracle_logits(model, kw, ins), rel=TOL, floor=0.0, abs_floor=1e-5, what="cfg4 logits")
+    y2 = torch.cat([model([t[i:i + 3] for t in ins]) for i in range(0, 8, 3)])
+    assert_close(y2.cpu(), y.cpu(), rel=1e-4, what="cfg4 batch-slicing")
+
+
+def test_cfg3_volume_vs_oracle_and_properties(hn):
+    """3-modality incl. the 12x224x224x3 volume (N = 602 112 tokens, D = 18 -> rank-D path with dp = 32):
+    oracle parity on one sample (the CPU side needs ~18 GB for the materialised scores), then b=4 consistency."""
+    kw = dict(n_modalities=3, channel_dims=[2000, 3, 3], num_spatial_axes=[1, 2, 3], out_dims=4)
+    torch.manual_seed(4)
+    model = hn.HealNet(**kw).eval().to(DEV)
+    gen = torch.Generator().manual_seed(78)
+    ins = [torch.rand(4, 1, 2000, generator=gen).to(DEV), torch.rand(4, 224, 224, 3, generator=gen).to(DEV),
+           torch.rand(4, 12, 224, 224, 3, generator=gen).to(DEV)]
+    y = model(list(ins))
+    assert torch.isfinite(y).all()
+    want = _oracle_logits(model, kw, [t[:1] for t in ins])
+    assert_close(y[:1].cpu(), want, rel=TOL, floor=0.0, abs_floor=1e-5, what="cfg3 logits (sample 0)")
+    y1 = torch.cat([model([t[i:i + 1] for t in ins]) for i in range(4)])
+    assert_close(y1.cpu(), y.cpu(), rel=1e-4, what="cfg3 batch-slicing")
+    # missing volume == 2-modality schedule with the self blocks of the skipped iterations still running
+    y_missing = model([ins[0], ins[1], None])
+    want_missing = _oracle_logits(model, kw, [ins[0][:1], ins[1][:1], None])
+    assert_close(y_missing[:1].cpu(), want_missing, rel=TOL, floor=0.0, abs_floor=1e-5, what="cfg3 missing volume")
+
+
+def test_cfg5_shape_depth8_properties(hn):
+    """4 modalities (tab + 2 WSI bags + volume), depth 8: determinism, slicing invariance, permutation equivariance
+    at b = 4 per GPU (the config's per-GPU share of its global batch 32 on 8 GPUs)."""
+    kw = dict(n_modalities=4, channel_dims=[2000, 768, 768, 3], num_spatial_axes=[1, 1, 1, 3], out_dims=4, depth=8)
+    torch.manual_seed(5)
+    model = hn.HealNet(**kw).eval().to(DEV)
+    gen = torch.Generator().manual_seed(79)
+    ins = [torch.rand(4, 1, 2000, generator=gen).to(DEV), torch.rand(4, 4096, 768, generator=gen).to(DEV),
+           torch.rand(4, 4096, 768, generator=gen).to(DEV), torch.rand(4, 12, 224, 224, 3, generator=gen).to(DEV)]
+    y = model(list(ins))
+    assert torch.isfinite(y).all() and torch.equal(y, model(list(ins)))
+    y2 = torch.cat([model([t[i:i + 2] for t in ins]) for i in range(0, 4, 2)])
+    assert_close(y2.cpu(), y.cpu(), rel=1e-4, what="cfg5 batch-slicing")
+    perm = torch.tensor([2, 0, 3, 1], device=DEV)
+    assert_close(model([t[perm] for t in ins]).cpu(), y[perm].cpu(), rel=1e-5, what="cfg5 permutation")
