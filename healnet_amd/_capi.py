@@ -15,7 +15,7 @@ HN_MAX_AXES = 4
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhealnet_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["api.hip", "gemm.hip", "attention.hip", "encode.hip", "misc.hip"]
+SOURCES = ["api.hip", "gemm.hip", "attention.hip", "encode.hip", "misc.hip", "backward.hip"]
 
 c_float_p = C.POINTER(C.c_float)
 
@@ -35,6 +35,11 @@ class FFParams(C.Structure):
         ("norm_w", C.c_void_p), ("norm_b", C.c_void_p),
         ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p),
     ]
+
+
+class FFGrads(C.Structure):
+    _fields_ = [("norm_w", C.c_void_p), ("norm_b", C.c_void_p), ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p),
+                ("b2", C.c_void_p)]
 
 
 class ModalityInput(C.Structure):
@@ -75,6 +80,12 @@ SIGNATURES = {
                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "hn_ff_fwd": (C.c_int, [C.POINTER(FFParams), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "hn_ff_workspace_bytes": (C.c_size_t, [C.POINTER(FFParams), C.c_int]),
+    "hn_ff_bwd": (C.c_int, [C.POINTER(FFParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(FFGrads),
+                            C.c_void_p, C.c_size_t, C.c_void_p]),
+    "hn_ff_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(FFParams), C.c_int]),
+    "hn_head_bwd": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "hn_head_bwd_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "hn_head_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                               C.c_void_p, C.c_void_p]),
     "hn_fusion_forward": (C.c_int, [C.POINTER(Model), C.POINTER(ModalityInput), C.c_int, C.c_void_p, C.c_int, C.c_int,

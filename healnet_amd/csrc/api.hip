@@ -248,6 +248,81 @@ static int ff_fwd_impl(const hn_ff_params *p, const float *x_in, float *x_out, i
   return launch_gemm(g2, s);
 }
 
+// ------------------------------------------------------------------------------------------------
+// feed-forward block, backward
+// ------------------------------------------------------------------------------------------------
+struct FFBwdPlan { float *u, *h, *dh, *xhat, *dxhat, *lns; size_t bytes; };
+
+static void plan_ff_bwd(const hn_ff_params *p, int rows, void *ws, size_t ws_bytes, FFBwdPlan *pl) {
+  Arena ar(ws, ws_bytes);
+  const size_t hid = 4 * (size_t)p->dim;
+  pl->u = ar.take<float>((size_t)rows * 2 * hid);
+  pl->h = ar.take<float>((size_t)rows * hid);
+  pl->dh = ar.take<float>((size_t)rows * hid);
+  pl->xhat = ar.take<float>((size_t)rows * p->dim);
+  pl->dxhat = ar.take<float>((size_t)rows * p->dim);
+  pl->lns = ar.take<float>(ln_bwd_scratch_floats(rows, p->dim));
+  pl->bytes = ar.off;
+}
+
+static int ff_bwd_impl(const hn_ff_params *p, const float *x_in, const float *dy, float *dx, int residual, int rows,
+                       const hn_ff_grads *g, void *ws, size_t ws_bytes, hipStream_t s) {
+  HN_REQUIRE(p && x_in && dy && dx && g, HN_E_NULL, "ff_bwd: NULL pointer");
+  HN_REQUIRE(p->w1 && p->b1 && p->w2 && p->b2, HN_E_NULL, "ff_bwd: weight pointer is NULL");
+  HN_REQUIRE(p->dim > 0 && rows > 0, HN_E_SHAPE, "ff_bwd: dim=%d rows=%d", p->dim, rows);
+  FFBwdPlan pl;
+  plan_ff_bwd(p, rows, nullptr, 0, &pl);
+  int rc = check_ws(ws, ws_bytes, pl.bytes, "ff_bwd");
+  if (rc != HN_OK) return rc;
+  plan_ff_bwd(p, rows, ws, ws_bytes, &pl);
+  const int d = p->dim, hid = 4 * d;
+  // recompute the pre-activations u = [a | g] = LN(x) W1^T + b1 and the normalised operand
+  GemmArgs g1 = gemm_defaults();
+  g1.A = x_in; g1.lda = d; g1.W = p->w1; g1.ldw = d; g1.C = pl.u; g1.ldc = 2 * hid; g1.bias = p->b1;
+  g1.M = rows; g1.N = 2 * hid; g1.K = d;
+  if (p->norm_w) { g1.pro = PRO_LAYERNORM; g1.gamma = p->norm_w; g1.beta = p->norm_b; }
+  if ((rc = launch_gemm(g1, s)) != HN_OK) return rc;
+  const float *xhat = x_in;
+  if (p->norm_w) {
+    if ((rc = launch_ln_fwd(x_in, p->norm_w, p->norm_b, rows, d, pl.xhat, s)) != HN_OK) return rc;
+    xhat = pl.xhat;
+  }
+  // dh = dy W2          (W2 is (d, hid): B(j = k, c = n) = W2[n, k])
+  GemmExArgs e = {};
+  e.batch = 1; e.alpha = 1.0f;
+  e.A = dy; e.a_rs = d; e.a_cs = 1; e.B = p->w2; e.b_rs = 1; e.b_cs = hid; e.C = pl.dh; e.ldc = hid; e.M = rows; e.N = hid; e.K = d;
+  if ((rc = launch_gemm_ex(e, s)) != HN_OK) return rc;
+  // h = a * act(g);  u <- du
+  if ((rc = launch_glu_bwd(pl.u, pl.dh, pl.h, rows, hid, p->gate == HN_GATE_GELU, s)) != HN_OK) return rc;
+  if (g->w2) {   // dW2 += dy^T h
+    GemmExArgs w = {};
+    w.batch = 1; w.alpha = 1.0f; w.accumulate = 1;
+    w.A = dy; w.a_rs = 1; w.a_cs = d; w.B = pl.h; w.b_rs = 1; w.b_cs = hid; w.C = g->w2; w.ldc = hid; w.M = d; w.N = hid; w.K = rows;
+    if ((rc = launch_gemm_ex(w, s)) != HN_OK) return rc;
+  }
+  if (g->b2 && (rc = launch_colsum(dy, d, rows, d, 1.0f, g->b2, 1, s)) != HN_OK) return rc;
+  if (g->w1) {   // dW1 += du^T x_hat
+    GemmExArgs w = {};
+    w.batch = 1; w.alpha = 1.0f; w.accumulate = 1;
+    w.A = pl.u; w.a_rs = 1; w.a_cs = 2 * hid; w.B = xhat; w.b_rs = 1; w.b_cs = d; w.C = g->w1; w.ldc = d; w.M = 2 * hid; w.N = d; w.K = rows;
+    if ((rc = launch_gemm_ex(w, s)) != HN_OK) return rc;
+  }
+  if (g->b1 && (rc = launch_colsum(pl.u, 2 * hid, rows, 2 * hid, 1.0f, g->b1, 1, s)) != HN_OK) return rc;
+  // dx_hat = du W1      (W1 is (2 hid, d): B(j = k, c = n) = W1[n, k])
+  GemmExArgs x = {};
+  x.batch = 1; x.alpha = 1.0f;
+  x.A = pl.u; x.a_rs = 2 * hid; x.a_cs = 1; x.B = p->w1; x.b_rs = 1; x.b_cs = d; x.M = rows; x.N = d; x.K = 2 * hid;
+  if (p->norm_w) {
+    x.C = pl.dxhat; x.ldc = d;
+    if ((rc = launch_gemm_ex(x, s)) != HN_OK) return rc;
+    if (residual) { if (dx != dy && (rc = launch_add_into(dy, dx, (long)rows * d, 0, s)) != HN_OK) return rc; }
+    return launch_ln_bwd(x_in, pl.dxhat, p->norm_w, rows, d, dx, residual ? 1 : 0, g->norm_w, g->norm_b, pl.lns, s);
+  }
+  if (residual) { if (dx != dy && (rc = launch_add_into(dy, dx, (long)rows * d, 0, s)) != HN_OK) return rc; }
+  x.C = dx; x.ldc = d; x.accumulate = residual ? 1 : 0;
+  return launch_gemm_ex(x, s);
+}
+
 static int context_pitch(int D, int dim_head) {
   const int dhp = pad_head_dim(dim_head);
   int dp = D <= 15 ? 16 : (D <= 31 ? 32 : 0);   // leave column dp-1 free for the kernel's synthetic ones column
@@ -389,6 +464,29 @@ int hn_ff_fwd(const hn_ff_params *p, const float *x_in, float *x_out, int residu
 int hn_head_fwd(const float *x, int b, int L, int d, const float *norm_w, const float *norm_b, const float *w,
                 const float *bias, int out_dims, float *logits, void *stream) {
   return launch_head(x, b, L, d, norm_w, norm_b, w, bias, out_dims, logits, (hipStream_t)stream);
+}
+
+size_t hn_ff_bwd_workspace_bytes(const hn_ff_params *p, int rows) {
+  if (!p || p->dim <= 0 || rows <= 0) return 0;
+  FFBwdPlan pl;
+  plan_ff_bwd(p, rows, nullptr, 0, &pl);
+  return pl.bytes;
+}
+
+int hn_ff_bwd(const hn_ff_params *p, const float *x_in, const float *dy, float *dx, int residual, int rows,
+              const hn_ff_grads *grads, void *workspace, size_t workspace_bytes, void *stream) {
+  return ff_bwd_impl(p, x_in, dy, dx, residual, rows, grads, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+size_t hn_head_bwd_workspace_bytes(int b, int d, int out_dims) { return align_up(head_bwd_scratch_floats(b, d, out_dims) * sizeof(float), 256); }
+
+int hn_head_bwd(const float *x, int b, int L, int d, const float *norm_w, const float *norm_b, const float *w, int out_dims,
+                const float *dlogits, float *dx, float *d_norm_w, float *d_norm_b, float *d_w, float *d_bias, void *workspace,
+                size_t workspace_bytes, void *stream) {
+  int rc = check_ws(workspace, workspace_bytes, hn_head_bwd_workspace_bytes(b, d, out_dims), "head_bwd");
+  if (rc != HN_OK) return rc;
+  return launch_head_bwd(x, b, L, d, norm_w, norm_b, w, out_dims, dlogits, dx, d_norm_w, d_norm_b, d_w, d_bias,
+                         (float *)workspace, (hipStream_t)stream);
 }
 
 size_t hn_fusion_workspace_bytes(const hn_model *model, const hn_modality_input *inputs, int b) {

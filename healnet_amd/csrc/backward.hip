@@ -1,0 +1,407 @@
+// Backward building blocks of the fusion stack (the reference has no explicit backward: autograd of
+// healnet/models/healnet.py, driven by surv_loss.backward() at healnet/main.py:464).  Only parameter gradients
+// and the gradient of the latent array flow; the modality inputs need no gradient.
+//
+//   gemm_ex_kernel   C[i,j] (+)= alpha * sum_c A(i,c) B(j,c) with arbitrary operand strides: the three GEMM
+//                    flavours of a Linear layer's backward (dX = dY W, dW = dY^T X) on the fp32 matrix cores
+//   colsum_kernel    bias gradients and every other "sum over rows"
+//   ln_bwd_kernel    LayerNorm backward (dx and per-block partials of dgamma / dbeta)
+//   leaky_bwd / glu_bwd / head_bwd   elementwise and head pieces
+#include "common.h"
+
+namespace hn {
+
+// ------------------------------------------------------------------------------------------------
+// strided GEMM: operand element (row r, contraction c) lives at base + r*rs + c*cs
+// ------------------------------------------------------------------------------------------------
+constexpr int XM = 64, XN = 64, XK = 32, XP = 36;
+
+__global__ __launch_bounds__(256) void gemm_ex_kernel(GemmExArgs g) {
+  __shared__ __attribute__((aligned(16))) float As[XM * XP];
+  __shared__ __attribute__((aligned(16))) float Bs[XN * XP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i0 = blockIdx.x * XM, j0 = blockIdx.y * XN, z = blockIdx.z;
+  const float *__restrict__ A = g.A + (long)z * g.strideA;
+  const float *__restrict__ B = g.B + (long)z * g.strideB;
+  float *__restrict__ C = g.C + (long)z * g.strideC;
+
+  // loader geometry per operand: lanes run along whichever index is contiguous in memory
+  const bool a_c_contig = g.a_cs == 1, b_c_contig = g.b_cs == 1;
+  float ra[8], rb[8];
+  auto load_operand = [&](const float *P, long rs, long cs, bool c_contig, int r0, int rmax, int c0, float (&reg)[8]) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      int r, c;
+      if (c_contig) { c = tid & 31; r = (tid >> 5) + 8 * t; }       // 32 lanes along c, 8 row groups
+      else { r = tid & 63; c = (tid >> 6) + 4 * t; }                 // 64 lanes along r, 4 column groups
+      const int rr = r0 + r, cc = c0 + c;
+      const float ok = (rr < rmax && cc < g.K) ? 1.0f : 0.0f;
+      const float v = P[(long)min(rr, rmax - 1) * rs + (long)min(cc, g.K - 1) * cs];     // clamped: always valid
+      reg[t] = v * ok;
+    }
+  };
+  auto store_operand = [&](float *S, bool c_contig, const float (&reg)[8]) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      int r, c;
+      if (c_contig) { c = tid & 31; r = (tid >> 5) + 8 * t; }
+      else { r = tid & 63; c = (tid >> 6) + 4 * t; }
+      S[r * XP + c] = reg[t];
+    }
+  };
+
+  const int wm = wave >> 1, wn = wave & 1;
+  const int frow = lane & 31, fhalf = lane >> 5;
+  f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const int nk = (g.K + XK - 1) / XK;
+  load_operand(A, g.a_rs, g.a_cs, a_c_contig, i0, g.M, 0, ra);
+  load_operand(B, g.b_rs, g.b_cs, b_c_contig, j0, g.N, 0, rb);
+  for (int kt = 0; kt < nk; ++kt) {
+    store_operand(As, a_c_contig, ra);
+    store_operand(Bs, b_c_contig, rb);
+    __syncthreads();
+    if (kt + 1 < nk) {
+      load_operand(A, g.a_rs, g.a_cs, a_c_contig, i0, g.M, (kt + 1) * XK, ra);
+      load_operand(B, g.b_rs, g.b_cs, b_c_contig, j0, g.N, (kt + 1) * XK, rb);
+    }
+    const float4 *ap = (const float4 *)(As + (wm * 32 + frow) * XP + 16 * fhalf);
+    const float4 *bp = (const float4 *)(Bs + (wn * 32 + frow) * XP + 16 * fhalf);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 a4 = ap[q], b4 = bp[q];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const int j = j0 + wn * 32 + frow;
+  if (j < g.N) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = i0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+      if (i < g.M) {
+        float *dst = C + (long)i * g.ldc + j;
+        const float v = g.alpha * acc[r];
+        *dst = g.accumulate ? *dst + v : v;
+      }
+    }
+  }
+}
+
+int launch_gemm_ex(const GemmExArgs &g, hipStream_t s) {
+  HN_REQUIRE(g.A && g.B && g.C, HN_E_NULL, "gemm_ex: NULL operand");
+  HN_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.batch > 0, HN_E_SHAPE, "gemm_ex: M=%d N=%d K=%d", g.M, g.N, g.K);
+  dim3 grid(ceil_div(g.M, XM), ceil_div(g.N, XN), g.batch);
+  HN_REQUIRE(grid.y <= 65535 && grid.z <= 65535, HN_E_UNSUPPORTED, "gemm_ex: grid too large");
+  hipLaunchKernelGGL(gemm_ex_kernel, grid, dim3(256), 0, s, g);
+  HN_LAUNCH_CHECK("gemm_ex");
+  return HN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// out[n] (+)= scale * sum_m X[m, n]   (fixed summation order: deterministic)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ X, long ld, long rows, int cols, float scale,
+                                                     float *__restrict__ out, int accumulate) {
+  __shared__ float part[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+  float s = 0.0f;
+  if (c < cols)
+    for (long r = w; r < rows; r += 4) s += X[r * ld + c];
+  part[w][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (w == 0 && c < cols) {
+    const float v = scale * (part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+    out[c] = accumulate ? out[c] + v : v;
+  }
+}
+
+int launch_colsum(const float *X, long ld, long rows, int cols, float scale, float *out, int accumulate, hipStream_t s) {
+  HN_REQUIRE(X && out && rows > 0 && cols > 0, HN_E_SHAPE, "colsum: rows=%ld cols=%d", rows, cols);
+  hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(cols, 64)), dim3(256), 0, s, X, ld, rows, cols, scale, out, accumulate);
+  HN_LAUNCH_CHECK("colsum");
+  return HN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm backward.  y = (x - mu) * rs * gamma + beta per row of length d.
+//   dx (+)= rs * (dyg - mean(dyg) - xn * mean(dyg * xn)),  dyg = dy * gamma,  xn = (x - mu) * rs
+//   partial[block, 0:d] = sum_rows dy * xn ;  partial[block, d:2d] = sum_rows dy     (reduced by colsum)
+// One wave per row (lanes along d), LN_ROWS rows per workgroup.
+// ------------------------------------------------------------------------------------------------
+constexpr int LN_ROWS = 32, LN_MAXC = 16;   // d <= 64 * LN_MAXC
+
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+                                                     const float *__restrict__ gamma, float eps, long rows, int d,
+                                                     float *__restrict__ dx, int dx_accumulate, float *__restrict__ partial) {
+  extern __shared__ float red[];   // [4 waves][2 d]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float gsum[LN_MAXC], bsum[LN_MAXC];
+#pragma unroll
+  for (int k = 0; k < LN_MAXC; ++k) { gsum[k] = 0.0f; bsum[k] = 0.0f; }
+  const long r0 = (long)blockIdx.x * LN_ROWS;
+  for (int rr = wave; rr < LN_ROWS; rr += 4) {
+    const long r = r0 + rr;
+    if (r >= rows) break;
+    const float *xr = x + r * d, *dyr = dy + r * d;
+    float xv[LN_MAXC], dv[LN_MAXC];
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXC; ++k) {
+      const int c = lane + 64 * k;
+      xv[k] = c < d ? xr[c] : 0.0f;
+      dv[k] = c < d ? dyr[c] : 0.0f;
+      s += xv[k];
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mu = s / (float)d;
+    float q = 0.0f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXC; ++k) {
+      const int c = lane + 64 * k;
+      const float t = c < d ? xv[k] - mu : 0.0f;
+      q += t * t;
+    }
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rs = 1.0f / sqrtf(q / (float)d + eps);
+    float m1 = 0.0f, m2 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXC; ++k) {
+      const int c = lane + 64 * k;
+      if (c < d) {
+        const float xn = (xv[k] - mu) * rs;
+        const float dyg = dv[k] * gamma[c];
+        gsum[k] += dv[k] * xn;
+        bsum[k] += dv[k];
+        m1 += dyg;
+        m2 += dyg * xn;
+        xv[k] = xn;
+        dv[k] = dyg;
+      }
+    }
+    for (int o = 32; o > 0; o >>= 1) { m1 += __shfl_xor(m1, o); m2 += __shfl_xor(m2, o); }
+    m1 /= (float)d;
+    m2 /= (float)d;
+#pragma unroll
+    for (int k = 0; k < LN_MAXC; ++k) {
+      const int c = lane + 64 * k;
+      if (c < d) {
+        const float v = rs * (dv[k] - m1 - xv[k] * m2);
+        dx[r * d + c] = dx_accumulate ? dx[r * d + c] + v : v;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < LN_MAXC; ++k) {
+    const int c = lane + 64 * k;
+    if (c < d) { red[wave * 2 * d + c] = gsum[k]; red[wave * 2 * d + d + c] = bsum[k]; }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * d; c += blockDim.x)
+    partial[(long)blockIdx.x * 2 * d + c] = red[c] + red[2 * d + c] + red[4 * d + c] + red[6 * d + c];
+}
+
+// dgamma / dbeta accumulate into their gradient buffers; `scratch` needs ln_bwd_scratch_floats(rows, d) floats
+size_t ln_bwd_scratch_floats(long rows, int d) { return (size_t)ceil_div_ll(rows, LN_ROWS) * 2 * d; }
+
+int launch_ln_bwd(const float *x, const float *dy, const float *gamma, long rows, int d, float *dx, int dx_accumulate,
+                  float *dgamma, float *dbeta, float *scratch, hipStream_t s) {
+  HN_REQUIRE(x && dy && gamma && dx && scratch, HN_E_NULL, "ln_bwd: NULL pointer");
+  HN_REQUIRE(d > 0 && d <= 64 * LN_MAXC, HN_E_UNSUPPORTED, "ln_bwd: d=%d (<= %d supported)", d, 64 * LN_MAXC);
+  const int blocks = (int)ceil_div_ll(rows, LN_ROWS);
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), (size_t)8 * d * sizeof(float), s, x, dy, gamma, 1e-5f, rows, d, dx,
+                     dx_accumulate, scratch);
+  HN_LAUNCH_CHECK("ln_bwd");
+  int rc;
+  if (dgamma && (rc = launch_colsum(scratch, 2 * d, blocks, d, 1.0f, dgamma, 1, s)) != HN_OK) return rc;
+  if (dbeta && (rc = launch_colsum(scratch + d, 2 * d, blocks, d, 1.0f, dbeta, 1, s)) != HN_OK) return rc;
+  return HN_OK;
+}
+
+// y = LayerNorm(x) * gamma + beta materialised (the backward needs the normalised operand of dW = dY^T x_hat)
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                     const float *__restrict__ beta, float eps, long rows, int d,
+                                                     float *__restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float *xr = x + r * d;
+  float s = 0.0f;
+  for (int c = lane; c < d; c += 64) s += xr[c];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mu = s / (float)d;
+  float q = 0.0f;
+  for (int c = lane; c < d; c += 64) { const float t = xr[c] - mu; q += t * t; }
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+  const float rs = 1.0f / sqrtf(q / (float)d + eps);
+  for (int c = lane; c < d; c += 64) y[r * d + c] = (xr[c] - mu) * rs * gamma[c] + beta[c];
+}
+
+int launch_ln_fwd(const float *x, const float *gamma, const float *beta, long rows, int d, float *y, hipStream_t s) {
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)ceil_div_ll(rows, 4)), dim3(256), 0, s, x, gamma, beta, 1e-5f, rows, d, y);
+  HN_LAUNCH_CHECK("ln_fwd");
+  return HN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// elementwise pieces
+// ------------------------------------------------------------------------------------------------
+// dpre = dy * LeakyReLU'(pre); sign(pre) == sign(y) with y = x_out - x_in (or x_out itself without residual)
+__global__ __launch_bounds__(256) void leaky_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x_out,
+                                                        const float *x_in, float *__restrict__ dpre, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float y = x_in ? x_out[i] - x_in[i] : x_out[i];
+    dpre[i] = dy[i] * (y > 0.0f ? 1.0f : 0.01f);
+  }
+}
+
+int launch_leaky_bwd(const float *dy, const float *x_out, const float *x_in, float *dpre, long n, hipStream_t s) {
+  long blocks = ceil_div_ll(n, 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(leaky_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dy, x_out, x_in, dpre, n);
+  HN_LAUNCH_CHECK("leaky_bwd");
+  return HN_OK;
+}
+
+// u = [a | g] (rows, 2*hid) pre-activations; dh (rows, hid).  Writes h = a * act(g) (rows, hid) when requested and
+// du = [dh * act(g) | dh * a * act'(g)] in place of u.
+__global__ __launch_bounds__(256) void glu_bwd_kernel(float *__restrict__ u, const float *__restrict__ dh, float *h_out,
+                                                      long rows, int hid, int gelu) {
+  const long n = rows * hid;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / hid;
+    const int c = (int)(i - r * hid);
+    float *ua = u + r * 2 * hid + c, *ug = ua + hid;
+    const float a = *ua, gt = *ug;
+    float act, dact;
+    if (gelu) {
+      const float cdf = 0.5f * (1.0f + erff(gt * 0.70710678118654752440f));
+      act = gt * cdf;
+      dact = cdf + gt * 0.3989422804014327f * expf(-0.5f * gt * gt);
+    } else {
+      const float alpha = 1.6732632423543772848170429916717f, scale = 1.0507009873554804934193349852946f;
+      act = scale * (gt > 0.0f ? gt : alpha * expm1f(gt));
+      dact = scale * (gt > 0.0f ? 1.0f : alpha * expf(gt));
+    }
+    if (h_out) h_out[i] = a * act;
+    if (dh) {
+      const float d = dh[i];
+      *ua = d * act;
+      *ug = d * a * dact;
+    }
+  }
+}
+
+int launch_glu_bwd(float *u, const float *dh, float *h_out, long rows, int hid, int gelu, hipStream_t s) {
+  long blocks = ceil_div_ll(rows * hid, 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(glu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, u, dh, h_out, rows, hid, gelu);
+  HN_LAUNCH_CHECK("glu_bwd");
+  return HN_OK;
+}
+
+// dst (+)= src elementwise
+__global__ __launch_bounds__(256) void axpy_kernel(const float *__restrict__ src, float *__restrict__ dst, long n, int accumulate) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    dst[i] = accumulate ? dst[i] + src[i] : src[i];
+}
+
+int launch_add_into(const float *src, float *dst, long n, int accumulate, hipStream_t s) {
+  long blocks = ceil_div_ll(n, 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, n, accumulate);
+  HN_LAUNCH_CHECK("add_into");
+  return HN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Head backward (to_logits :181-185): logits = LN(mean_n x) W^T + bias.  One workgroup per sample writes
+// dx[b, l, :] = dpooled[b, :] / L and its own row of parameter-gradient partials
+// [dW (out*d) | dgamma (d) | dbeta (d) | dbias (out)]; colsum over the samples accumulates them (deterministic).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float *__restrict__ x, int L, int d, const float *__restrict__ nw,
+                                                       const float *__restrict__ nb, const float *__restrict__ w, int out_dims,
+                                                       const float *__restrict__ dlogits, float *__restrict__ dx,
+                                                       float *__restrict__ partial) {
+  extern __shared__ float sm[];
+  float *pooled = sm, *xn = sm + d, *dyn = sm + 2 * d, *red = sm + 3 * d, *part = sm + 3 * d + 8;   // part[4][d]
+  const int tid = threadIdx.x, bi = blockIdx.x;
+  const float *xb = x + (long)bi * L * d;
+  float *prow = partial + (long)bi * ((long)out_dims * d + 2 * d + out_dims);
+  {
+    const int wv = tid >> 6, ln = tid & 63;
+    for (int c = ln; c < d; c += 64) {
+      float s = 0.0f;
+      for (int r = wv; r < L; r += 4) s += xb[(long)r * d + c];
+      part[wv * d + c] = s;
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < d; c += blockDim.x) pooled[c] = (part[c] + part[d + c] + part[2 * d + c] + part[3 * d + c]) / (float)L;
+  __syncthreads();
+  float s = 0.0f;
+  for (int c = tid; c < d; c += blockDim.x) s += pooled[c];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  __syncthreads();
+  const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)d;
+  __syncthreads();
+  float q = 0.0f;
+  for (int c = tid; c < d; c += blockDim.x) { const float t = pooled[c] - mean; q += t * t; }
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+  if ((tid & 63) == 0) red[tid >> 6] = q;
+  __syncthreads();
+  const float rstd = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)d + 1e-5f);
+  __syncthreads();
+  float m1 = 0.0f, m2 = 0.0f;
+  for (int c = tid; c < d; c += blockDim.x) {
+    const float n = (pooled[c] - mean) * rstd;
+    const float yh = n * nw[c] + nb[c];
+    float dyh = 0.0f;
+    for (int o = 0; o < out_dims; ++o) {
+      const float dl = dlogits[(long)bi * out_dims + o];
+      dyh += dl * w[(long)o * d + c];
+      prow[(long)o * d + c] = dl * yh;
+    }
+    prow[(long)out_dims * d + c] = dyh * n;
+    prow[(long)out_dims * d + d + c] = dyh;
+    const float dyg = dyh * nw[c];
+    xn[c] = n;
+    dyn[c] = dyg;
+    m1 += dyg;
+    m2 += dyg * n;
+  }
+  if (tid < out_dims) prow[(long)out_dims * d + 2 * d + tid] = dlogits[(long)bi * out_dims + tid];
+  for (int o = 32; o > 0; o >>= 1) { m1 += __shfl_xor(m1, o); m2 += __shfl_xor(m2, o); }
+  if ((tid & 63) == 0) { red[tid >> 6] = m1; red[4 + (tid >> 6)] = m2; }
+  __syncthreads();
+  const float mm1 = (red[0] + red[1] + red[2] + red[3]) / (float)d, mm2 = (red[4] + red[5] + red[6] + red[7]) / (float)d;
+  for (int c = tid; c < d; c += blockDim.x) pooled[c] = rstd * (dyn[c] - mm1 - xn[c] * mm2) / (float)L;   // d pooled / L
+  __syncthreads();
+  float *dxb = dx + (long)bi * L * d;
+  for (long i = tid; i < (long)L * d; i += blockDim.x) dxb[i] = pooled[i % d];
+}
+
+size_t head_bwd_scratch_floats(int b, int d, int out_dims) { return (size_t)b * ((size_t)out_dims * d + 2 * d + out_dims); }
+
+int launch_head_bwd(const float *x, int b, int L, int d, const float *nw, const float *nb, const float *w, int out_dims,
+                    const float *dlogits, float *dx, float *dnw, float *dnb, float *dw, float *dbias, float *scratch,
+                    hipStream_t s) {
+  HN_REQUIRE(x && nw && nb && w && dlogits && dx && scratch, HN_E_NULL, "head_bwd: NULL pointer");
+  HN_REQUIRE(out_dims <= 256, HN_E_UNSUPPORTED, "head_bwd: out_dims=%d (<= 256)", out_dims);
+  const size_t lds = (size_t)(7 * d + 8) * sizeof(float);
+  HN_REQUIRE(lds <= 64 * 1024, HN_E_UNSUPPORTED, "head_bwd: l_d=%d too large", d);
+  hipLaunchKernelGGL(head_bwd_kernel, dim3(b), dim3(256), lds, s, x, L, d, nw, nb, w, out_dims, dlogits, dx, scratch);
+  HN_LAUNCH_CHECK("head_bwd");
+  const long pitch = (long)out_dims * d + 2 * d + out_dims;
+  int rc;
+  if (dw && (rc = launch_colsum(scratch, pitch, b, out_dims * d, 1.0f, dw, 1, s)) != HN_OK) return rc;
+  if (dnw && (rc = launch_colsum(scratch + (long)out_dims * d, pitch, b, d, 1.0f, dnw, 1, s)) != HN_OK) return rc;
+  if (dnb && (rc = launch_colsum(scratch + (long)out_dims * d + d, pitch, b, d, 1.0f, dnb, 1, s)) != HN_OK) return rc;
+  if (dbias && (rc = launch_colsum(scratch + (long)out_dims * d + 2 * d, pitch, b, out_dims, 1.0f, dbias, 1, s)) != HN_OK) return rc;
+  return HN_OK;
+}
+
+}  // namespace hn

@@ -133,6 +133,31 @@ int launch_merge_explicit(const float *Opart, const float *Mpart, const float *L
 int launch_probs(const float *Q, long q_b, long q_h, int ldq, int dp, const float *Kp, long k_b, long k_h, int ldk,
                  const uint8_t *mask, const float *stats, float *P, int b, int h, int L, int N, hipStream_t s);
 
+// ------------------------------------------------------------------------------------------------
+// backward building blocks (backward.hip)
+// ------------------------------------------------------------------------------------------------
+struct GemmExArgs {                              // C[i,j] (+)= alpha * sum_c A(i,c) * B(j,c)
+  const float *A; long a_rs, a_cs, strideA;      // element (row i, contraction c) at A + i*a_rs + c*a_cs
+  const float *B; long b_rs, b_cs, strideB;
+  float *C; long ldc, strideC;
+  int M, N, K, batch;
+  float alpha;
+  int accumulate;
+};
+int launch_gemm_ex(const GemmExArgs &g, hipStream_t s);
+int launch_colsum(const float *X, long ld, long rows, int cols, float scale, float *out, int accumulate, hipStream_t s);
+size_t ln_bwd_scratch_floats(long rows, int d);
+int launch_ln_bwd(const float *x, const float *dy, const float *gamma, long rows, int d, float *dx, int dx_accumulate,
+                  float *dgamma, float *dbeta, float *scratch, hipStream_t s);
+int launch_ln_fwd(const float *x, const float *gamma, const float *beta, long rows, int d, float *y, hipStream_t s);
+int launch_leaky_bwd(const float *dy, const float *x_out, const float *x_in, float *dpre, long n, hipStream_t s);
+int launch_glu_bwd(float *u, const float *dh, float *h_out, long rows, int hid, int gelu, hipStream_t s);
+int launch_add_into(const float *src, float *dst, long n, int accumulate, hipStream_t s);
+size_t head_bwd_scratch_floats(int b, int d, int out_dims);
+int launch_head_bwd(const float *x, int b, int L, int d, const float *nw, const float *nb, const float *w, int out_dims,
+                    const float *dlogits, float *dx, float *dnw, float *dnb, float *dw, float *dbias, float *scratch,
+                    hipStream_t s);
+
 // misc
 int launch_broadcast_rows(const float *src, float *dst, long n_per, int b, hipStream_t s);
 int launch_head(const float *x, int b, int L, int d, const float *nw, const float *nb, const float *w,

@@ -119,12 +119,28 @@ int hn_ff_fwd(const hn_ff_params *p, const float *x_in, float *x_out, int residu
               void *workspace, size_t workspace_bytes, void *stream);
 size_t hn_ff_workspace_bytes(const hn_ff_params *p, int rows);
 
+/* Backward of the block (autograd of the same reference lines).  dy = gradient w.r.t. the block output; dx receives the
+ * gradient w.r.t. x_in (dx may alias dy); with residual != 0 the skip connection's dy is included.  Parameter
+ * gradients are ACCUMULATED (+=) into the non-NULL entries of hn_ff_grads (shapes of the parameters). */
+typedef struct hn_ff_grads {
+  float *norm_w, *norm_b, *w1, *b1, *w2, *b2;
+} hn_ff_grads;
+int hn_ff_bwd(const hn_ff_params *p, const float *x_in, const float *dy, float *dx, int residual, int rows,
+              const hn_ff_grads *grads, void *workspace, size_t workspace_bytes, void *stream);
+size_t hn_ff_bwd_workspace_bytes(const hn_ff_params *p, int rows);
+
 /* ---------------------------------------------------------------------------------------------
  * Head                                                 replaces to_logits :181-185
  * logits = LN(mean_n x) W^T + bias ;  x (b, L, d) -> (b, out_dims)
  * ------------------------------------------------------------------------------------------- */
 int hn_head_fwd(const float *x, int b, int L, int d, const float *norm_w, const float *norm_b,
                 const float *w, const float *bias, int out_dims, float *logits, void *stream);
+
+/* Backward of the head: dlogits (b, out_dims) -> dx (b, L, d); parameter gradients accumulated into non-NULL pointers. */
+int hn_head_bwd(const float *x, int b, int L, int d, const float *norm_w, const float *norm_b, const float *w,
+                int out_dims, const float *dlogits, float *dx, float *d_norm_w, float *d_norm_b, float *d_w,
+                float *d_bias, void *workspace, size_t workspace_bytes, void *stream);
+size_t hn_head_bwd_workspace_bytes(int b, int d, int out_dims);
 
 /* ---------------------------------------------------------------------------------------------
  * Whole fusion forward                                 replaces HealNet.forward :190-250
