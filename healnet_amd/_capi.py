@@ -15,7 +15,7 @@ HN_MAX_AXES = 4
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhealnet_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["api.hip", "gemm.hip", "attention.hip", "encode.hip", "misc.hip", "backward.hip"]
+SOURCES = ["api.hip", "gemm.hip", "attention.hip", "attention_bwd.hip", "encode.hip", "misc.hip", "backward.hip"]
 
 c_float_p = C.POINTER(C.c_float)
 
@@ -35,6 +35,11 @@ class FFParams(C.Structure):
         ("norm_w", C.c_void_p), ("norm_b", C.c_void_p),
         ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p),
     ]
+
+
+class AttnGrads(C.Structure):
+    _fields_ = [("norm_w", C.c_void_p), ("norm_b", C.c_void_p), ("ctx_gamma", C.c_void_p), ("ctx_beta", C.c_void_p),
+                ("w_q", C.c_void_p), ("w_kv", C.c_void_p), ("w_out", C.c_void_p), ("b_out", C.c_void_p)]
 
 
 class FFGrads(C.Structure):
@@ -80,6 +85,13 @@ SIGNATURES = {
                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "hn_ff_fwd": (C.c_int, [C.POINTER(FFParams), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "hn_ff_workspace_bytes": (C.c_size_t, [C.POINTER(FFParams), C.c_int]),
+    "hn_attn_saved_floats": (C.c_size_t, [C.POINTER(AttnParams)] + [C.c_int] * 7),
+    "hn_attn_fwd_train": (C.c_int, [C.POINTER(AttnParams), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                    C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "hn_attn_bwd": (C.c_int, [C.POINTER(AttnParams), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                              C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(AttnGrads),
+                              C.c_void_p, C.c_size_t, C.c_void_p]),
+    "hn_attn_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(AttnParams)] + [C.c_int] * 7),
     "hn_ff_bwd": (C.c_int, [C.POINTER(FFParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(FFGrads),
                             C.c_void_p, C.c_size_t, C.c_void_p]),
     "hn_ff_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(FFParams), C.c_int]),

@@ -154,7 +154,7 @@ static int attn_prepare(const hn_attn_params *p, const AttnPlan &pl, const float
 
 static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_out, int residual, const float *ctx,
                          int ld_ctx, int b, int L, int N, int D, const uint8_t *mask, float *stats, void *ws,
-                         size_t ws_bytes, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+                         size_t ws_bytes, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, float *o_save = nullptr) {
   HN_REQUIRE(x_in && x_out, HN_E_NULL, "attn: x is NULL");
   HN_REQUIRE(p && p->w_q && p->w_kv && p->w_out, HN_E_NULL, "attn: weight pointer is NULL");
   AttnPlan pl;
@@ -174,6 +174,7 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
     gv.W = p->w_kv + (long)pl.inner * pl.D; gv.ldw = pl.D; gv.N = pl.inner;
     gv.C = vbuf; gv.ldc = pl.inner;
     if ((rc = launch_gemm(gv, s)) != HN_OK) return rc;
+    if (o_save) HN_HIP_CHECK(hipMemcpyAsync(o_save, vbuf, (size_t)b * pl.inner * sizeof(float), hipMemcpyDeviceToDevice, s));
     GemmArgs gy = gemm_defaults();
     gy.A = vbuf; gy.lda = pl.inner; gy.M = b; gy.K = pl.inner;
     gy.W = p->w_out; gy.ldw = pl.inner; gy.N = p->query_dim;
@@ -196,12 +197,14 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
   if (ev1) HN_HIP_CHECK(hipEventRecord(ev1, s));
   if (pl.rank_d) {
     rc = launch_merge_vproj(pl.opart, pl.mpart, pl.lpart, pl.nsplit, b, p->heads, L, pl.Lp, pl.dp, pl.D, p->ctx_gamma,
-                            p->ctx_beta, p->w_kv + (long)pl.inner * pl.D, pl.dh, pl.obuf, pl.inner, stats, s);
+                            p->ctx_beta, p->w_kv + (long)pl.inner * pl.D, pl.dh, pl.obuf, pl.inner, stats, o_save, s);
   } else if (!direct) {
     rc = launch_merge_explicit(pl.opart, pl.mpart, pl.lpart, pl.nsplit, b, p->heads, L, pl.Lp, pl.dp, pl.dh, pl.obuf,
                                pl.inner, stats, s);
   }
   if (rc != HN_OK) return rc;
+  if (o_save && !pl.rank_d)
+    HN_HIP_CHECK(hipMemcpyAsync(o_save, pl.obuf, (size_t)b * L * pl.inner * sizeof(float), hipMemcpyDeviceToDevice, s));
 
   GemmArgs go = gemm_defaults();
   go.A = pl.obuf; go.lda = pl.inner;
@@ -212,6 +215,251 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
   go.act = ACT_LEAKY;
   if (residual) { go.R = x_in; go.ldr = p->query_dim; }
   return launch_gemm(go, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// attention block, backward
+// ------------------------------------------------------------------------------------------------
+// What the training forward keeps per attention block besides the softmax statistics:
+//   explicit K/V binding : O (b*L, inner), the normalised attention output
+//   rank-D binding       : P z (b*L, heads*dp), the normalised context average (O is recomputed from it)
+//   one-token context    : V (b, inner)
+static size_t attn_saved_floats(const AttnPlan &pl, bool has_ctx, bool masked, int b, int L) {
+  if (has_ctx && pl.N == 1 && !masked) return (size_t)b * pl.inner;
+  if (pl.rank_d) return (size_t)b * L * pl.heads * pl.dp;
+  return (size_t)b * L * pl.inner;
+}
+
+struct AttnBwdPlan {
+  float *dpre, *dO, *xhat, *dxhat, *lns, *delta, *dOp, *dQpart, *dQ, *dKV, *G, *cs, *Abuf, *dA, *E, *T, *dT, *dyb, *dV;
+  void *fwd_ws; size_t fwd_bytes, bytes;
+};
+
+static int plan_attn_bwd(const hn_attn_params *p, const AttnPlan &pl, bool has_ctx, bool masked, int b, int L, void *ws,
+                         size_t ws_bytes, AttnBwdPlan *bp) {
+  Arena ar(ws, ws_bytes);
+  const size_t rows = (size_t)b * L, qd = p->query_dim, inner = pl.inner, h = p->heads;
+  memset(bp, 0, sizeof(*bp));
+  bp->fwd_bytes = pl.bytes;
+  bp->fwd_ws = ar.take<char>(pl.bytes);
+  bp->dpre = ar.take<float>(rows * qd);
+  if (has_ctx && pl.N == 1 && !masked) {
+    bp->dyb = ar.take<float>((size_t)b * qd);
+    bp->dV = ar.take<float>((size_t)b * inner);
+    bp->G = ar.take<float>(inner * pl.D);
+    bp->cs = ar.take<float>(inner);
+  } else {
+    bp->dO = ar.take<float>(rows * inner);
+    bp->xhat = ar.take<float>(rows * qd);
+    bp->dxhat = ar.take<float>(rows * qd);
+    bp->lns = ar.take<float>(ln_bwd_scratch_floats(rows, (int)qd));
+    bp->delta = ar.take<float>((size_t)b * h * L);
+    bp->dQpart = ar.take<float>((size_t)b * h * pl.nsplit * pl.Lp * pl.dp);
+    bp->dQ = ar.take<float>(rows * inner);
+    if (pl.rank_d) {
+      const size_t hp = rows * h * pl.dp;
+      bp->Abuf = ar.take<float>(hp);
+      bp->dA = ar.take<float>(hp);
+      bp->dOp = ar.take<float>(hp);
+      bp->E = ar.take<float>(hp);
+      bp->T = ar.take<float>(hp);
+      bp->dT = ar.take<float>(hp);
+    } else {
+      bp->dOp = ar.take<float>(rows * h * pl.dhp);
+      bp->dKV = ar.take<float>((size_t)b * pl.N * 2 * inner);
+      if (has_ctx) {
+        bp->G = ar.take<float>(2 * inner * pl.D);
+        bp->cs = ar.take<float>(2 * inner);
+      }
+    }
+  }
+  bp->bytes = ar.off;
+  if (ws != nullptr && ar.overflow) return fail(HN_E_WORKSPACE, "attn_bwd: workspace %zu bytes < required %zu", ws_bytes, ar.off);
+  return HN_OK;
+}
+
+static GemmExArgs gex(const float *A, long a_rs, long a_cs, const float *B, long b_rs, long b_cs, float *C, long ldc, int M,
+                      int N, int K, int accumulate) {
+  GemmExArgs e;
+  memset(&e, 0, sizeof(e));
+  e.A = A; e.a_rs = a_rs; e.a_cs = a_cs; e.B = B; e.b_rs = b_rs; e.b_cs = b_cs; e.C = C; e.ldc = ldc;
+  e.M = M; e.N = N; e.K = K; e.batch = 1; e.alpha = 1.0f; e.accumulate = accumulate;
+  return e;
+}
+
+static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float *x_out, int residual, const float *ctx,
+                         int ld_ctx, int b, int L, int N, int D, const uint8_t *mask, const float *stats, const float *saved,
+                         const float *dy, float *dx, const hn_attn_grads *g, void *ws, size_t ws_bytes, hipStream_t s) {
+  HN_REQUIRE(p && x_in && x_out && stats && saved && dy && dx && g, HN_E_NULL, "attn_bwd: NULL pointer");
+  HN_REQUIRE(p->w_q && p->w_kv && p->w_out, HN_E_NULL, "attn_bwd: weight pointer is NULL");
+  const bool has_ctx = ctx != nullptr;
+  AttnPlan pl;
+  int rc = plan_attn(p, has_ctx, ld_ctx, b, L, N, D, nullptr, 0, &pl);
+  if (rc != HN_OK) return rc;
+  AttnBwdPlan bp;
+  if ((rc = plan_attn_bwd(p, pl, has_ctx, mask != nullptr, b, L, nullptr, 0, &bp)) != HN_OK) return rc;
+  if ((rc = check_ws(ws, ws_bytes, bp.bytes, "attn_bwd")) != HN_OK) return rc;
+  if ((rc = plan_attn_bwd(p, pl, has_ctx, mask != nullptr, b, L, ws, ws_bytes, &bp)) != HN_OK) return rc;
+  if ((rc = plan_attn(p, has_ctx, ld_ctx, b, L, N, D, bp.fwd_ws, bp.fwd_bytes, &pl)) != HN_OK) return rc;
+
+  const int rows = b * L, qd = p->query_dim, inner = pl.inner, h = p->heads, dh = pl.dh;
+  const float two_scale = 2.0f / sqrtf((float)dh);
+  // dpre = dy * LeakyReLU'(pre); the sign of pre is the sign of y = x_out - x_in
+  if ((rc = launch_leaky_bwd(dy, x_out, residual ? x_in : nullptr, bp.dpre, (long)rows * qd, s)) != HN_OK) return rc;
+
+  if (has_ctx && pl.N == 1 && mask == nullptr) {   // ---- one-token context: y_b = LeakyReLU(W_out V_b + b_out) for every row
+    if ((rc = launch_segsum(bp.dpre, L, qd, b, bp.dyb, s)) != HN_OK) return rc;
+    if (g->b_out && (rc = launch_colsum(bp.dyb, qd, b, qd, 1.0f, g->b_out, 1, s)) != HN_OK) return rc;
+    if (g->w_out) {   // dWo += dyb^T V
+      GemmExArgs e = gex(bp.dyb, 1, qd, saved, 1, inner, g->w_out, inner, qd, inner, b, 1);
+      if ((rc = launch_gemm_ex(e, s)) != HN_OK) return rc;
+    }
+    {   // dV = dyb Wo
+      GemmExArgs e = gex(bp.dyb, qd, 1, p->w_out, 1, inner, bp.dV, inner, b, inner, qd, 0);
+      if ((rc = launch_gemm_ex(e, s)) != HN_OK) return rc;
+    }
+    {   // G = dV^T z, cs = colsum(dV)  -> gradients of the V half of to_kv and of the context LayerNorm affine
+      GemmExArgs e = gex(bp.dV, 1, inner, ctx, 1, ld_ctx, bp.G, pl.D, inner, pl.D, b, 0);
+      if ((rc = launch_gemm_ex(e, s)) != HN_OK) return rc;
+      if ((rc = launch_colsum(bp.dV, inner, b, inner, 1.0f, bp.cs, 0, s)) != HN_OK) return rc;
+      if ((rc = launch_kv_weight_grads(bp.G, bp.cs, p->w_kv + (long)inner * pl.D, p->ctx_gamma, p->ctx_beta, inner, pl.D,
+                                       g->w_kv ? g->w_kv + (long)inner * pl.D : nullptr, g->ctx_gamma, g->ctx_beta, s)) != HN_OK)
+        return rc;
+    }
+    if (residual) { if (dx != dy) return launch_add_into(dy, dx, (long)rows * qd, 0, s); return HN_OK; }
+    HN_HIP_CHECK(hipMemsetAsync(dx, 0, (size_t)rows * qd * sizeof(float), s));
+    return HN_OK;
+  }
+
+  // ---- output projection: dWo += dpre^T O, dbo += colsum(dpre), dO = dpre Wo
+  const float *O = saved;
+  if (pl.rank_d) {   // O = (P z * gamma + beta) W_v^T is recomputed from the saved P z
+    if ((rc = launch_head_affine(saved, h * pl.dp, pl.dp, nullptr, 0, 0, p->ctx_gamma, p->ctx_beta, 1.0f, h, pl.D, pl.dp,
+                                 h * pl.dp, rows, bp.Abuf, s)) != HN_OK) return rc;
+    GemmExArgs e = gex(bp.Abuf, (long)h * pl.dp, 1, p->w_kv + (long)inner * pl.D, pl.D, 1, pl.obuf, inner, rows, dh, pl.D, 0);
+    e.batch = h; e.strideA = pl.dp; e.strideB = (long)dh * pl.D; e.strideC = dh;
+    if ((rc = launch_gemm_ex(e, s)) != HN_OK) return rc;
+    O = pl.obuf;
+  }
+  if (g->w_out) {
+    GemmExArgs e = gex(bp.dpre, 1, qd, O, 1, inner, g->w_out, inner, qd, inner, rows, 1);
+    if ((rc = launch_gemm_ex(e, s)) != HN_OK) return rc;
+  }
+  if (g->b_out && (rc = launch_colsum(bp.dpre, qd, rows, qd, 1.0f, g->b_out, 1, s)) != HN_OK) return rc;
+  {
+    GemmExArgs e = gex(bp.dpre, qd, 1, p->w_out, 1, inner, bp.dO, inner, rows, inner, qd, 0);
+    if ((rc = launch_gemm_ex(e, s)) != HN_OK) return rc;
+  }
+
+  // ---- recompute the operands of the core (scaled Q, and K/V or the folded queries)
+  AttnCoreArgs core;
+  if ((rc = attn_prepare(p, pl, x_in, ctx, ld_ctx, b, L, s, &core)) != HN_OK) return rc;
+  const float *xhat = x_in;
+  if (p->norm_w) {
+    if ((rc = launch_ln_fwd(x_in, p->norm_w, p->norm_b, rows, qd, bp.xhat, s)) != HN_OK) return rc;
+    xhat = bp.xhat;
+  }
+  AttnBwdArgs ba;
+  memset(&ba, 0, sizeof(ba));
+  ba.Q = core.Q; ba.q_b = core.q_b; ba.q_h = core.q_h; ba.ldq = core.ldq;
+  ba.Kp = core.Kp; ba.k_b = core.k_b; ba.k_h = core.k_h; ba.ldk = core.ldk;
+  ba.Vp = core.Vp; ba.v_b = core.v_b; ba.v_h = core.v_h; ba.ldv = core.ldv;
+  ba.mask = mask; ba.stats = stats; ba.delta = bp.delta; ba.dQpart = bp.dQpart;
+  ba.b = b; ba.h = h; ba.Lq = L; ba.Lp = pl.Lp; ba.N = pl.N; ba.dp = pl.dp; ba.nsplit = pl.nsplit; ba.chunk = pl.chunk;
+
+  if (pl.rank_d) {
+    const int hp = h * pl.dp;
+    const float *wv = p->w_kv + (long)inner * pl.D, *wk = p->w_kv;
+    float *dwv = g->w_kv ? g->w_kv + (long)inner * pl.D : nullptr, *dwk = g->w_kv;
+    // O_h = A_h W_v,h^T with A = P z * gamma + beta:  dW_v,h += dO_h^T A_h ;  dA_h = dO_h W_v,h
+    if (dwv) {
+      GemmExArgs e = gex(bp.dO, 1, inner, bp.Abuf, 1, hp, dwv, pl.D, dh, pl.D, rows, 1);
+      e.batch = h; e.strideA = dh; e.strideB = pl.dp; e.strideC = (long)dh * pl.D;
+      if ((rc = launch_gemm_ex(e, s)) != HN_OK) return rc;
+    }
+    HN_HIP_CHECK(hipMemsetAsync(bp.dA, 0, (size_t)rows * hp * sizeof(float), s));
+    {
+      GemmExArgs e = gex(bp.dO, inner, 1, wv, 1, pl.D, bp.dA, hp, rows, pl.D, dh, 0);
+      e.batch = h; e.strideA = dh; e.strideB = (long)dh * pl.D; e.strideC = pl.dp;
+      if ((rc = launch_gemm_ex(e, s)) != HN_OK) return rc;
+    }
+    if (p->ctx_gamma) {   // dgamma += sum dA * (P z) ; dbeta += sum dA   (over rows and heads)
+      if ((rc = launch_head_affine(bp.dA, hp, pl.dp, saved, hp, pl.dp, nullptr, nullptr, 1.0f, h, pl.D, pl.dp, hp, rows, bp.E, s)) != HN_OK) return rc;
+      if (g->ctx_gamma && (rc = launch_colsum(bp.E, pl.dp, (long)rows * h, pl.D, 1.0f, g->ctx_gamma, 1, s)) != HN_OK) return rc;
+      if (g->ctx_beta && (rc = launch_colsum(bp.dA, pl.dp, (long)rows * h, pl.D, 1.0f, g->ctx_beta, 1, s)) != HN_OK) return rc;
+    }
+    // d(P z) = dA * gamma ;  delta = rowsum(d(P z) * P z)
+    if ((rc = launch_head_affine(bp.dA, hp, pl.dp, nullptr, 0, 0, p->ctx_gamma, nullptr, 1.0f, h, pl.D, pl.dp, hp, rows, bp.dOp, s)) != HN_OK) return rc;
+    if ((rc = launch_rowdot_heads(bp.dOp, hp, pl.dp, saved, hp, pl.dp, h, L, pl.D, rows, bp.delta, s)) != HN_OK) return rc;
+    ba.dO = bp.dOp; ba.do_b = (long)L * hp; ba.do_h = pl.dp; ba.lddo = hp;
+    if ((rc = launch_attn_bwd_dq(ba, s)) != HN_OK) return rc;
+    // dQacc (rows, h*dp) = sum over splits; folded-query chain  Qf = c * gamma * T,  T = Q_h W_k,h
+    if ((rc = launch_dq_reduce(bp.dQpart, pl.nsplit, b, h, L, pl.Lp, pl.dp, pl.dp, 1.0f, bp.E, hp, pl.dp, s)) != HN_OK) return rc;
+    HN_HIP_CHECK(hipMemsetAsync(bp.T, 0, (size_t)rows * hp * sizeof(float), s));
+    {   // T = Qraw_h W_k,h   (Qraw = x_hat W_q^T lives in pl.q after attn_prepare)
+      GemmExArgs e = gex(pl.q, inner, 1, wk, 1, pl.D, bp.T, hp, rows, pl.D, dh, 0);
+      e.batch = h; e.strideA = dh; e.strideB = (long)dh * pl.D; e.strideC = pl.dp;
+      if ((rc = launch_gemm_ex(e, s)) != HN_OK) return rc;
+    }
+    if (p->ctx_gamma && g->ctx_gamma) {   // dgamma += 2 scale * sum T * dQacc
+      if ((rc = launch_head_affine(bp.T, hp, pl.dp, bp.E, hp, pl.dp, nullptr, nullptr, two_scale, h, pl.D, pl.dp, hp, rows, bp.dT, s)) != HN_OK) return rc;
+      if ((rc = launch_colsum(bp.dT, pl.dp, (long)rows * h, pl.D, 1.0f, g->ctx_gamma, 1, s)) != HN_OK) return rc;
+    }
+    // dT = 2 scale * gamma * dQacc
+    if ((rc = launch_head_affine(bp.E, hp, pl.dp, nullptr, 0, 0, p->ctx_gamma, nullptr, two_scale, h, pl.D, pl.dp, hp, rows, bp.dT, s)) != HN_OK) return rc;
+    if (dwk) {   // dW_k,h += Qraw_h^T dT_h
+      GemmExArgs e = gex(pl.q, 1, inner, bp.dT, 1, hp, dwk, pl.D, dh, pl.D, rows, 1);
+      e.batch = h; e.strideA = dh; e.strideB = pl.dp; e.strideC = (long)dh * pl.D;
+      if ((rc = launch_gemm_ex(e, s)) != HN_OK) return rc;
+    }
+    {   // dQ_h = dT_h W_k,h^T
+      GemmExArgs e = gex(bp.dT, hp, 1, wk, pl.D, 1, bp.dQ, inner, rows, dh, pl.D, 0);
+      e.batch = h; e.strideA = pl.dp; e.strideB = (long)dh * pl.D; e.strideC = dh;
+      if ((rc = launch_gemm_ex(e, s)) != HN_OK) return rc;
+    }
+  } else {
+    const int qp = h * pl.dhp;
+    if ((rc = launch_rowdot_heads(bp.dO, inner, dh, O, inner, dh, h, L, dh, rows, bp.delta, s)) != HN_OK) return rc;
+    if ((rc = launch_head_affine(bp.dO, inner, dh, nullptr, 0, 0, nullptr, nullptr, 1.0f, h, dh, pl.dhp, qp, rows, bp.dOp, s)) != HN_OK) return rc;
+    ba.dO = bp.dOp; ba.do_b = (long)L * qp; ba.do_h = pl.dhp; ba.lddo = qp;
+    if ((rc = launch_attn_bwd_dq(ba, s)) != HN_OK) return rc;
+    if ((rc = launch_dq_reduce(bp.dQpart, pl.nsplit, b, h, L, pl.Lp, pl.dp, dh, two_scale, bp.dQ, inner, dh, s)) != HN_OK) return rc;
+    ba.dKV = bp.dKV; ba.dk_scale = 0.69314718055994530942f;
+    if ((rc = launch_attn_bwd_dkv(ba, dh, inner, s)) != HN_OK) return rc;
+    const long krows = (long)b * pl.N;
+    if (has_ctx) {   // gradients of to_kv and of the context LayerNorm affine from G = dKV^T z and colsum(dKV)
+      GemmExArgs e = gex(bp.dKV, 1, 2 * inner, ctx, 1, ld_ctx, bp.G, pl.D, 2 * inner, pl.D, (int)krows, 0);
+      if ((rc = launch_gemm_ex(e, s)) != HN_OK) return rc;
+      if ((rc = launch_colsum(bp.dKV, 2 * inner, krows, 2 * inner, 1.0f, bp.cs, 0, s)) != HN_OK) return rc;
+      if ((rc = launch_kv_weight_grads(bp.G, bp.cs, p->w_kv, p->ctx_gamma, p->ctx_beta, 2 * inner, pl.D, g->w_kv, g->ctx_gamma,
+                                       g->ctx_beta, s)) != HN_OK) return rc;
+    } else if (g->w_kv) {   // self-attention: K, V come from x_hat
+      GemmExArgs e = gex(bp.dKV, 1, 2 * inner, xhat, 1, qd, g->w_kv, qd, 2 * inner, qd, rows, 1);
+      if ((rc = launch_gemm_ex(e, s)) != HN_OK) return rc;
+    }
+  }
+
+  // ---- query projection: dWq += dQ^T x_hat ; dx_hat = dQ Wq (+ dKV Wkv for self-attention)
+  if (g->w_q) {
+    GemmExArgs e = gex(bp.dQ, 1, inner, xhat, 1, qd, g->w_q, qd, inner, qd, rows, 1);
+    if ((rc = launch_gemm_ex(e, s)) != HN_OK) return rc;
+  }
+  float *dxh = p->norm_w ? bp.dxhat : dx;
+  const bool direct_acc = !p->norm_w && residual;     // no LayerNorm: dx = dy + dQ Wq directly
+  if (direct_acc && dx != dy && (rc = launch_add_into(dy, dx, (long)rows * qd, 0, s)) != HN_OK) return rc;
+  {
+    GemmExArgs e = gex(bp.dQ, inner, 1, p->w_q, 1, qd, dxh, qd, rows, qd, inner, direct_acc ? 1 : 0);
+    if ((rc = launch_gemm_ex(e, s)) != HN_OK) return rc;
+  }
+  if (!has_ctx) {
+    GemmExArgs e = gex(bp.dKV, 2 * inner, 1, p->w_kv, 1, qd, dxh, qd, rows, qd, 2 * inner, 1);
+    if ((rc = launch_gemm_ex(e, s)) != HN_OK) return rc;
+  }
+  if (p->norm_w) {
+    if (residual) { if (dx != dy && (rc = launch_add_into(dy, dx, (long)rows * qd, 0, s)) != HN_OK) return rc; }
+    return launch_ln_bwd(x_in, bp.dxhat, p->norm_w, rows, qd, dx, residual ? 1 : 0, g->norm_w, g->norm_b, bp.lns, s);
+  }
+  return HN_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -449,6 +697,35 @@ int hn_attn_probs(const hn_attn_params *p, const float *x_in, const float *ctx, 
   if ((rc = attn_prepare(p, pl, x_in, ctx, ld_ctx, b, L, s, &core)) != HN_OK) return rc;
   return launch_probs(core.Q, core.q_b, core.q_h, core.ldq, pl.rank_d ? pl.D : pl.dh, core.Kp, core.k_b, core.k_h, core.ldk,
                       mask, stats, probs, b, p->heads, L, pl.N, s);
+}
+
+size_t hn_attn_saved_floats(const hn_attn_params *p, int has_ctx, int ld_ctx, int b, int L, int N, int D, int masked) {
+  AttnPlan pl;
+  if (plan_attn(p, has_ctx != 0, ld_ctx, b, L, N, D, nullptr, 0, &pl) != HN_OK) return 0;
+  return attn_saved_floats(pl, has_ctx != 0, masked != 0, b, L);
+}
+
+int hn_attn_fwd_train(const hn_attn_params *p, const float *x_in, float *x_out, int residual, const float *ctx, int ld_ctx,
+                      int b, int L, int N, int D, const uint8_t *mask, float *stats, float *saved, void *workspace,
+                      size_t workspace_bytes, void *stream) {
+  HN_REQUIRE(stats && saved, HN_E_NULL, "attn_fwd_train: stats and saved are required");
+  return attn_fwd_impl(p, x_in, x_out, residual, ctx, ld_ctx, b, L, N, D, mask, stats, workspace, workspace_bytes,
+                       (hipStream_t)stream, nullptr, nullptr, saved);
+}
+
+size_t hn_attn_bwd_workspace_bytes(const hn_attn_params *p, int has_ctx, int ld_ctx, int b, int L, int N, int D, int masked) {
+  AttnPlan pl;
+  if (plan_attn(p, has_ctx != 0, ld_ctx, b, L, N, D, nullptr, 0, &pl) != HN_OK) return 0;
+  AttnBwdPlan bp;
+  if (plan_attn_bwd(p, pl, has_ctx != 0, masked != 0, b, L, nullptr, 0, &bp) != HN_OK) return 0;
+  return bp.bytes;
+}
+
+int hn_attn_bwd(const hn_attn_params *p, const float *x_in, const float *x_out, int residual, const float *ctx, int ld_ctx, int b,
+                int L, int N, int D, const uint8_t *mask, const float *stats, const float *saved, const float *dy, float *dx,
+                const hn_attn_grads *grads, void *workspace, size_t workspace_bytes, void *stream) {
+  return attn_bwd_impl(p, x_in, x_out, residual, ctx, ld_ctx, b, L, N, D, mask, stats, saved, dy, dx, grads, workspace,
+                       workspace_bytes, (hipStream_t)stream);
 }
 
 size_t hn_ff_workspace_bytes(const hn_ff_params *p, int rows) {

@@ -444,7 +444,8 @@ __global__ __launch_bounds__(256) void merge_vproj_kernel(const float *__restric
                                                           const float *__restrict__ Lpart, int nsplit, int h, int L, int Lp,
                                                           int dp, int D, const float *__restrict__ gamma,
                                                           const float *__restrict__ beta, const float *__restrict__ w_v,
-                                                          int dh, float *__restrict__ O, int ldo, float *__restrict__ stats) {
+                                                          int dh, float *__restrict__ O, int ldo, float *__restrict__ stats,
+                                                          float *__restrict__ oprime_save) {
   extern __shared__ float sm[];
   float *oh = sm;                        // [MERGE_ROWS][dp + 1]
   float *wv = sm + MERGE_ROWS * (dp + 1);  // [dh][D + 1]
@@ -457,6 +458,7 @@ __global__ __launch_bounds__(256) void merge_vproj_kernel(const float *__restric
     if (q < L && d < D) {
       float M, Ls;
       v = merged_value(Opart, Mpart, Lpart, pbase, nsplit, Lp, dp, q, d, &M, &Ls);
+      if (oprime_save) oprime_save[((long)bi * L + q) * (h * dp) + hi * dp + d] = v;      // training: normalised P z
       v = v * (gamma ? gamma[d] : 1.0f) + (beta ? beta[d] : 0.0f);
       if (stats && d == 0) {
         stats[((long)bh * L + q) * 2 + 0] = M;
@@ -481,10 +483,10 @@ __global__ __launch_bounds__(256) void merge_vproj_kernel(const float *__restric
 
 int launch_merge_vproj(const float *Opart, const float *Mpart, const float *Lpart, int nsplit, int b, int h, int L,
                        int Lp, int dp, int D, const float *gamma, const float *beta, const float *w_v, int dh,
-                       float *O, int ldo, float *stats, hipStream_t s) {
+                       float *O, int ldo, float *stats, float *oprime_save, hipStream_t s) {
   size_t lds = ((size_t)MERGE_ROWS * (dp + 1) + (size_t)dh * (D + 1)) * sizeof(float);
   hipLaunchKernelGGL(merge_vproj_kernel, dim3(b * h, ceil_div(L, MERGE_ROWS)), dim3(256), lds, s, Opart, Mpart, Lpart,
-                     nsplit, h, L, Lp, dp, D, gamma, beta, w_v, dh, O, ldo, stats);
+                     nsplit, h, L, Lp, dp, D, gamma, beta, w_v, dh, O, ldo, stats, oprime_save);
   HN_LAUNCH_CHECK("merge_vproj");
   return HN_OK;
 }

@@ -1,0 +1,377 @@
+// Backward of the split-KV attention core (autograd of healnet/models/healnet.py Attention.forward :409-424), exact
+// fp32 on the matrix cores, recompute-based: the forward keeps only the per-row softmax statistics (max, sum) and
+// the normalised output; P is re-formed tile by tile from Q K^T and those statistics.
+//
+// With  P = softmax(s),  O = P V,  D_q = sum_d dO[q,d] O[q,d]  (flash-attention identity):
+//     dP = dO V^T          dS = P * (dP - D)          dQ = dS K          dK = dS^T Q          dV = P^T dO
+// Scores are kept in log2 units (S = Qs K^T with Qs = 2 dh^-1/2 log2(e) q), the kernels accumulate the plain sums
+// sum dS K / sum dS^T Qs / sum P^T dO and the callers apply the constant factors.
+//
+// Two kernels, mirroring the two kinds of outputs:
+//   attn_bwd_dq_kernel   query-parallel, token range split across waves exactly like the forward core; output
+//                        partial dQ (reduced over splits by dq_reduce_kernel).  This is all the rank-D binding
+//                        needs (K = V = normalised context z, which has no gradient).
+//   attn_bwd_dkv_kernel  token-parallel (explicit K/V only): a wave owns one 16-token tile, walks all query tiles
+//                        and keeps dK / dV of its tokens in registers: no cross-wave reduction, deterministic.
+#include "common.h"
+
+namespace hn {
+
+__device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// ------------------------------------------------------------------------------------------------
+// dQ.  Register layout as in the forward core: S^T = K Q^T (A = K tile, B = Q tile) leaves lane (g, j) with the
+// scores of query row j for tokens 4 g + r;  dP^T = V dO^T has the same shape with the dO fragment in the place of
+// the Q fragment;  dQ += dS K uses dS straight from registers as the A operand and K rows 4 g + r as B.
+// ------------------------------------------------------------------------------------------------
+template <int DT, int NQ, bool SHARED_KV>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a, int ngroups, int gy, int waves_per_block) {
+  constexpr int DP = 16 * DT;
+  const int L = a.Lq;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, j = lane & 15;
+  long total = (long)gridDim.x, id = blockIdx.x;
+  if ((total & 7) == 0) id = (id & 7) * (total >> 3) + (id >> 3);
+  const int split = (int)(id % a.nsplit);
+  const int yb = (int)((id / a.nsplit) % gy);
+  const int bh = (int)(id / ((long)a.nsplit * gy));
+  const int qg = yb * waves_per_block + wave;
+  if (qg >= ngroups) return;
+  const int bi = bh / a.h, hi = bh % a.h;
+
+  const i32x4 rsQ = make_rsrc(a.Q + (long)bi * a.q_b + (long)hi * a.q_h, rsrc_bytes(L, a.ldq, DP));
+  const i32x4 rsG = make_rsrc(a.dO + (long)bi * a.do_b + (long)hi * a.do_h, rsrc_bytes(L, a.lddo, DP));
+  float4 qf[NQ][DT], gf[NQ][DT];
+  float mrow[NQ], invl[NQ], drow[NQ];
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    const int row = (qg * NQ + i) * 16 + j;
+#pragma unroll
+    for (int s = 0; s < DT; ++s) {
+      qf[i][s] = buf4(rsQ, (row * a.ldq + 16 * s + 4 * g) * 4);
+      gf[i][s] = buf4(rsG, (row * a.lddo + 16 * s + 4 * g) * 4);
+    }
+    const int rc = min(row, L - 1);
+    mrow[i] = a.stats[((long)bh * L + rc) * 2 + 0];
+    invl[i] = 1.0f / a.stats[((long)bh * L + rc) * 2 + 1];
+    drow[i] = a.delta[(long)bh * L + rc];
+  }
+
+  f32x4 dQ[NQ][DT];
+#pragma unroll
+  for (int i = 0; i < NQ; ++i)
+#pragma unroll
+    for (int d = 0; d < DT; ++d) dQ[i][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int t_begin = split * a.chunk;
+  const int t_end = min(a.N, t_begin + a.chunk);
+  const float *kbase = a.Kp + (long)bi * a.k_b + (long)hi * a.k_h;
+  const float *vbase = a.Vp + (long)bi * a.v_b + (long)hi * a.v_h;
+  const uint8_t *mask = a.mask ? a.mask + (long)bi * a.N : nullptr;
+  const i32x4 krs = make_rsrc(kbase, rsrc_bytes(a.N, a.ldk, DP)), vrs = make_rsrc(vbase, rsrc_bytes(a.N, a.ldv, DP));
+  const int koff = (j * a.ldk + 4 * g) * 4, vkoff = (j * a.ldv + 4 * g) * 4;
+  int kroff[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) kroff[r] = ((4 * g + r) * a.ldk + j) * 4;
+
+  for (int t0 = t_begin; t0 < t_end; t0 += 16) {
+    const int ks = t0 * a.ldk * 4, vs = t0 * a.ldv * 4;
+    float4 kf[DT], vf[DT];
+    float kr[DT][4];
+#pragma unroll
+    for (int s = 0; s < DT; ++s) {
+      kf[s] = buf4s(krs, koff + 64 * s, ks);
+      if (!SHARED_KV) vf[s] = buf4s(vrs, vkoff + 64 * s, vs);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int d = 0; d < DT; ++d) kr[d][r] = hn_buffer_load_x1(krs, kroff[r] + 64 * d, ks, 0);
+
+    f32x4 S[NQ], dP[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) { S[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dP[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int s = 0; s < DT; ++s) {
+      const float4 vv = SHARED_KV ? kf[s] : vf[s];
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) {
+        S[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].x, qf[i][s].x, S[i], 0, 0, 0);
+        dP[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.x, gf[i][s].x, dP[i], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) {
+        S[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].y, qf[i][s].y, S[i], 0, 0, 0);
+        dP[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.y, gf[i][s].y, dP[i], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) {
+        S[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].z, qf[i][s].z, S[i], 0, 0, 0);
+        dP[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.z, gf[i][s].z, dP[i], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) {
+        S[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].w, qf[i][s].w, S[i], 0, 0, 0);
+        dP[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.w, gf[i][s].w, dP[i], 0, 0, 0);
+      }
+    }
+    // token validity of lane (g, j): tokens t0 + 4 g + r
+    float live[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int tok = t0 + 4 * g + r;
+      float ok = tok < t_end ? 1.0f : 0.0f;
+      if (mask) ok *= mask[min(tok, a.N - 1)] ? 1.0f : 0.0f;
+      live[r] = ok;
+    }
+#pragma unroll
+    for (int i = 0; i < NQ; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = fexp2(S[i][r] - mrow[i]) * invl[i] * live[r];
+        S[i][r] = p * (dP[i][r] - drow[i]);                  // dS
+      }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int i = 0; i < NQ; ++i)
+          dQ[i][d] = __builtin_amdgcn_mfma_f32_16x16x4f32(S[i][r], kr[d][r], dQ[i][d], 0, 0, 0);
+  }
+
+  const long prow = ((long)bh * a.nsplit + split) * a.Lp;
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    const int tile = qg * NQ + i;
+    if (tile * 16 < a.Lp) {
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a.dQpart[(prow + tile * 16 + 4 * g + r) * DP + 16 * d + j] = dQ[i][d][r];
+    }
+  }
+}
+
+static int bwd_nq(int dt) { return dt == 1 ? 4 : (dt == 2 ? 2 : (dt == 4 ? 2 : 1)); }
+
+int launch_attn_bwd_dq(const AttnBwdArgs &a, hipStream_t s) {
+  HN_REQUIRE(a.dp == 16 || a.dp == 32 || a.dp == 64 || a.dp == 128, HN_E_UNSUPPORTED, "attn_bwd_dq: dp=%d", a.dp);
+  const int dt = a.dp / 16, nq = bwd_nq(dt);
+  const int ngroups = ceil_div(a.Lp / 16, nq);
+  const int wpb = ngroups < 4 ? ngroups : 4;
+  const int gy = ceil_div(ngroups, wpb);
+  const long blocks = (long)a.nsplit * gy * a.b * a.h;
+  HN_REQUIRE(blocks < (1L << 31), HN_E_UNSUPPORTED, "attn_bwd_dq: grid too large");
+  dim3 grid((unsigned)blocks), block(64 * wpb);
+  const bool shared = a.Kp == a.Vp;
+#define HN_DQ(DT_, NQ_)                                                                                          \
+  if (shared) hipLaunchKernelGGL((attn_bwd_dq_kernel<DT_, NQ_, true>), grid, block, 0, s, a, ngroups, gy, wpb);   \
+  else hipLaunchKernelGGL((attn_bwd_dq_kernel<DT_, NQ_, false>), grid, block, 0, s, a, ngroups, gy, wpb);
+  switch (dt) {
+    case 1: HN_DQ(1, 4) break;
+    case 2: HN_DQ(2, 2) break;
+    case 4: HN_DQ(4, 2) break;
+    default: HN_DQ(8, 1) break;
+  }
+#undef HN_DQ
+  HN_LAUNCH_CHECK("attn_bwd_dq");
+  return HN_OK;
+}
+
+// sum of the split partials in fixed order, scaled, written as (b*L rows, h heads, `width` of dp columns) with row pitch ld_out
+__global__ __launch_bounds__(256) void dq_reduce_kernel(const float *__restrict__ part, int nsplit, int h, int L, int Lp, int dp,
+                                                        int width, float scale, float *__restrict__ out, int ld_out, int head_pitch,
+                                                        long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int d = (int)(i % width);
+    const long t = i / width;
+    const int q = (int)(t % L);
+    const long bh = t / L;
+    float acc = 0.0f;
+    for (int s = 0; s < nsplit; ++s) acc += part[((bh * nsplit + s) * Lp + q) * dp + d];
+    const long bi = bh / h;
+    const int hi = (int)(bh % h);
+    out[(bi * L + q) * ld_out + (long)hi * head_pitch + d] = acc * scale;
+  }
+}
+
+int launch_dq_reduce(const float *part, int nsplit, int b, int h, int L, int Lp, int dp, int width, float scale, float *out,
+                     int ld_out, int head_pitch, hipStream_t s) {
+  const long total = (long)b * h * L * width;
+  long blocks = ceil_div_ll(total, 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(dq_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, part, nsplit, h, L, Lp, dp, width, scale, out,
+                     ld_out, head_pitch, total);
+  HN_LAUNCH_CHECK("dq_reduce");
+  return HN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// dK, dV (explicit K/V binding).  S is formed the other way round -- A = Q tile (M = query rows), B = K tile
+// (N = tokens) -- so lane (g, j) holds S[q = 4 g + r][t = j]: P^T and dS^T are then directly the A operands of
+// dV += P^T dO and dK += dS^T Q with k-chunk r = query rows {4 g + r}.
+// ------------------------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs a, int ntiles, int dh, int inner) {
+  constexpr int DP = 16 * DT;
+  const int L = a.Lq;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, j = lane & 15;
+  const int tile = blockIdx.x * 4 + wave;
+  const int bh = blockIdx.y, bi = bh / a.h, hi = bh % a.h;
+  if (tile >= ntiles) return;
+  const int t0 = tile * 16;
+
+  const i32x4 rsQ = make_rsrc(a.Q + (long)bi * a.q_b + (long)hi * a.q_h, rsrc_bytes(L, a.ldq, DP));
+  const i32x4 rsG = make_rsrc(a.dO + (long)bi * a.do_b + (long)hi * a.do_h, rsrc_bytes(L, a.lddo, DP));
+  const i32x4 krs = make_rsrc(a.Kp + (long)bi * a.k_b + (long)hi * a.k_h, rsrc_bytes(a.N, a.ldk, DP));
+  const i32x4 vrs = make_rsrc(a.Vp + (long)bi * a.v_b + (long)hi * a.v_h, rsrc_bytes(a.N, a.ldv, DP));
+  float4 kf[DT], vf[DT];                         // B operands: lane (g, j = t) holds K[t][16 s + 4 g ..]
+#pragma unroll
+  for (int s = 0; s < DT; ++s) {
+    kf[s] = buf4(krs, ((t0 + j) * a.ldk + 16 * s + 4 * g) * 4);
+    vf[s] = buf4(vrs, ((t0 + j) * a.ldv + 16 * s + 4 * g) * 4);
+  }
+  float live = (t0 + j) < a.N ? 1.0f : 0.0f;
+  if (a.mask) live *= a.mask[(long)bi * a.N + min(t0 + j, a.N - 1)] ? 1.0f : 0.0f;
+
+  f32x4 dK[DT], dV[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d) { dK[d] = (f32x4){0.f, 0.f, 0.f, 0.f}; dV[d] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+  for (int q0 = 0; q0 < L; q0 += 16) {
+    float4 qa[DT], ga[DT];                       // A operands: lane (g, i = q) holds Q[q][16 s + 4 g ..]
+    float qb[DT][4], gb[DT][4];                  // B operands of the second products: rows 4 g + r, column 16 d + j
+#pragma unroll
+    for (int s = 0; s < DT; ++s) {
+      qa[s] = buf4(rsQ, ((q0 + j) * a.ldq + 16 * s + 4 * g) * 4);
+      ga[s] = buf4(rsG, ((q0 + j) * a.lddo + 16 * s + 4 * g) * 4);
+    }
+    float mr[4], il[4], dl[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int q = q0 + 4 * g + r;
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        qb[d][r] = hn_buffer_load_x1(rsQ, (q * a.ldq + 16 * d + j) * 4, 0, 0);
+        gb[d][r] = hn_buffer_load_x1(rsG, (q * a.lddo + 16 * d + j) * 4, 0, 0);
+      }
+      const int qc = min(q, L - 1);
+      mr[r] = a.stats[((long)bh * L + qc) * 2 + 0];
+      il[r] = q < L ? 1.0f / a.stats[((long)bh * L + qc) * 2 + 1] : 0.0f;      // rows past L contribute nothing
+      dl[r] = a.delta[(long)bh * L + qc];
+    }
+    f32x4 S = {0.f, 0.f, 0.f, 0.f}, dP = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < DT; ++s) {
+      S = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s].x, kf[s].x, S, 0, 0, 0);
+      dP = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s].x, vf[s].x, dP, 0, 0, 0);
+      S = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s].y, kf[s].y, S, 0, 0, 0);
+      dP = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s].y, vf[s].y, dP, 0, 0, 0);
+      S = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s].z, kf[s].z, S, 0, 0, 0);
+      dP = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s].z, vf[s].z, dP, 0, 0, 0);
+      S = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s].w, kf[s].w, S, 0, 0, 0);
+      dP = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s].w, vf[s].w, dP, 0, 0, 0);
+    }
+    f32x4 P, dS;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      P[r] = fexp2(S[r] - mr[r]) * il[r] * live;
+      dS[r] = P[r] * (dP[r] - dl[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        dV[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(P[r], gb[d][r], dV[d], 0, 0, 0);
+        dK[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(dS[r], qb[d][r], dK[d], 0, 0, 0);
+      }
+  }
+  // C/D map: col = lane & 15 -> d, row = 4 g + r -> token.  Compact (b*N, 2*inner) layout: [dK | dV]
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int tok = t0 + 4 * g + r, col = 16 * d + j;
+      if (tok < a.N && col < dh) {
+        float *row = a.dKV + ((long)bi * a.N + tok) * (2 * inner) + hi * dh + col;
+        row[0] = dK[d][r] * a.dk_scale;
+        row[inner] = dV[d][r];
+      }
+    }
+}
+
+int launch_attn_bwd_dkv(const AttnBwdArgs &a, int dh, int inner, hipStream_t s) {
+  HN_REQUIRE(a.dp == 16 || a.dp == 32 || a.dp == 64 || a.dp == 128, HN_E_UNSUPPORTED, "attn_bwd_dkv: dp=%d", a.dp);
+  const int ntiles = ceil_div(a.N, 16);
+  dim3 grid(ceil_div(ntiles, 4), a.b * a.h), block(256);
+  HN_REQUIRE(grid.y <= 65535, HN_E_UNSUPPORTED, "attn_bwd_dkv: b*h too large");
+  switch (a.dp / 16) {
+    case 1: hipLaunchKernelGGL((attn_bwd_dkv_kernel<1>), grid, block, 0, s, a, ntiles, dh, inner); break;
+    case 2: hipLaunchKernelGGL((attn_bwd_dkv_kernel<2>), grid, block, 0, s, a, ntiles, dh, inner); break;
+    case 4: hipLaunchKernelGGL((attn_bwd_dkv_kernel<4>), grid, block, 0, s, a, ntiles, dh, inner); break;
+    default: hipLaunchKernelGGL((attn_bwd_dkv_kernel<8>), grid, block, 0, s, a, ntiles, dh, inner); break;
+  }
+  HN_LAUNCH_CHECK("attn_bwd_dkv");
+  return HN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// small per-head elementwise helpers on "head-pitched" matrices: rows = b*L, head hi at column hi*pitch, `width`
+// valid columns per head
+// ------------------------------------------------------------------------------------------------
+// delta[b, h, q] = sum_d X[row, h, d] * Y[row, h, d]
+__global__ __launch_bounds__(256) void rowdot_heads_kernel(const float *__restrict__ X, int ldx, int xpitch, const float *__restrict__ Y,
+                                                           int ldy, int ypitch, int h, int L, int width, long rows,
+                                                           float *__restrict__ delta) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * h) return;
+  const long row = i / h;
+  const int hi = (int)(i % h);
+  const float *x = X + row * ldx + (long)hi * xpitch, *y = Y + row * ldy + (long)hi * ypitch;
+  float s = 0.0f;
+  for (int d = 0; d < width; ++d) s = fmaf(x[d], y[d], s);
+  delta[((row / L) * h + hi) * L + (row % L)] = s;
+}
+
+int launch_rowdot_heads(const float *X, int ldx, int xpitch, const float *Y, int ldy, int ypitch, int h, int L, int width,
+                        long rows, float *delta, hipStream_t s) {
+  hipLaunchKernelGGL(rowdot_heads_kernel, dim3((unsigned)ceil_div_ll(rows * h, 256)), dim3(256), 0, s, X, ldx, xpitch, Y, ldy,
+                     ypitch, h, L, width, rows, delta);
+  HN_LAUNCH_CHECK("rowdot_heads");
+  return HN_OK;
+}
+
+// dst[row, h, d] = (src[row, h, d] (* mul[row, h, d])) * colscale[d] * scale + coladd[d]   for d < width, 0 for width <= d < pitch
+__global__ __launch_bounds__(256) void head_affine_kernel(const float *__restrict__ src, int lds, int spitch, const float *mul, int ldm,
+                                                          int mpitch, const float *colscale, const float *coladd, float scale,
+                                                          int h, int width, int dpitch, int ldd, long rows, float *__restrict__ dst) {
+  const long total = rows * h * dpitch;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int d = (int)(i % dpitch);
+    const long t = i / dpitch;
+    const int hi = (int)(t % h);
+    const long row = t / h;
+    float v = 0.0f;
+    if (d < width) {
+      v = src[row * lds + (long)hi * spitch + d];
+      if (mul) v *= mul[row * ldm + (long)hi * mpitch + d];
+      v = v * (colscale ? colscale[d] : 1.0f) * scale + (coladd ? coladd[d] : 0.0f);
+    }
+    dst[row * ldd + (long)hi * dpitch + d] = v;
+  }
+}
+
+int launch_head_affine(const float *src, int lds, int spitch, const float *mul, int ldm, int mpitch, const float *colscale,
+                       const float *coladd, float scale, int h, int width, int dpitch, int ldd, long rows, float *dst,
+                       hipStream_t s) {
+  long blocks = ceil_div_ll(rows * h * dpitch, 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(head_affine_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, lds, spitch, mul, ldm, mpitch, colscale, coladd,
+                     scale, h, width, dpitch, ldd, rows, dst);
+  HN_LAUNCH_CHECK("head_affine");
+  return HN_OK;
+}
+
+}  // namespace hn

@@ -220,6 +220,57 @@ int launch_ln_bwd(const float *x, const float *dy, const float *gamma, long rows
   return HN_OK;
 }
 
+// Parameter gradients of a K/V projection applied to an affine-normalised context c_hat = z * gamma + beta, from
+//   G = dKV^T z  (nrows, D)   and   cs = colsum(dKV)  (nrows):
+//   dW[n, d] += G[n, d] * gamma[d] + cs[n] * beta[d];  dgamma[d] += sum_n W[n, d] G[n, d];  dbeta[d] += sum_n W[n, d] cs[n]
+// (c_hat and its gradient are never materialised).  gamma == NULL: plain dW += G.
+__global__ __launch_bounds__(256) void kv_weight_grads_kernel(const float *__restrict__ G, const float *__restrict__ cs,
+                                                              const float *__restrict__ w, const float *gamma, const float *beta,
+                                                              int nrows, int D, float *dw, float *dgamma, float *dbeta) {
+  __shared__ float pg[4][64], pb[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), wv = threadIdx.x >> 6;
+  float sg = 0.0f, sb = 0.0f;
+  if (c < D) {
+    const float gm = gamma ? gamma[c] : 1.0f, bt = beta ? beta[c] : 0.0f;
+    for (int n = wv; n < nrows; n += 4) {
+      const float gv = G[(long)n * D + c], wv_ = w[(long)n * D + c], csn = cs[n];
+      if (dw) dw[(long)n * D + c] += gv * gm + csn * bt;
+      sg += wv_ * gv;
+      sb += wv_ * csn;
+    }
+  }
+  pg[wv][threadIdx.x & 63] = sg;
+  pb[wv][threadIdx.x & 63] = sb;
+  __syncthreads();
+  if (wv == 0 && c < D && gamma) {
+    if (dgamma) dgamma[c] += pg[0][threadIdx.x] + pg[1][threadIdx.x] + pg[2][threadIdx.x] + pg[3][threadIdx.x];
+    if (dbeta) dbeta[c] += pb[0][threadIdx.x] + pb[1][threadIdx.x] + pb[2][threadIdx.x] + pb[3][threadIdx.x];
+  }
+}
+
+int launch_kv_weight_grads(const float *G, const float *cs, const float *w, const float *gamma, const float *beta, int nrows, int D,
+                           float *dw, float *dgamma, float *dbeta, hipStream_t s) {
+  hipLaunchKernelGGL(kv_weight_grads_kernel, dim3(ceil_div(D, 64)), dim3(256), 0, s, G, cs, w, gamma, beta, nrows, D, dw, dgamma, dbeta);
+  HN_LAUNCH_CHECK("kv_weight_grads");
+  return HN_OK;
+}
+
+// out[seg, c] = sum of `seg` consecutive rows of X (nseg segments): per-sample sums over the latent rows
+__global__ __launch_bounds__(256) void segsum_kernel(const float *__restrict__ X, int seg, int cols, float *__restrict__ out) {
+  const int sidx = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.0f;
+  for (int r = 0; r < seg; ++r) s += X[((long)sidx * seg + r) * cols + c];
+  out[(long)sidx * cols + c] = s;
+}
+
+int launch_segsum(const float *X, int seg, int cols, int nseg, float *out, hipStream_t s) {
+  hipLaunchKernelGGL(segsum_kernel, dim3(ceil_div(cols, 256), nseg), dim3(256), 0, s, X, seg, cols, out);
+  HN_LAUNCH_CHECK("segsum");
+  return HN_OK;
+}
+
 // y = LayerNorm(x) * gamma + beta materialised (the backward needs the normalised operand of dW = dY^T x_hat)
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
                                                      const float *__restrict__ beta, float eps, long rows, int d,

@@ -57,6 +57,10 @@ __device__ __forceinline__ float4 buf4(i32x4 rsrc, int byte_off) {
   const f32x4 v = hn_buffer_load_x4(rsrc, byte_off, 0, 0);
   return make_float4(v.x, v.y, v.z, v.w);
 }
+__device__ __forceinline__ float4 buf4s(i32x4 rsrc, int byte_off, int sgpr_off) {
+  const f32x4 v = hn_buffer_load_x4(rsrc, byte_off, sgpr_off, 0);
+  return make_float4(v.x, v.y, v.z, v.w);
+}
 __host__ __device__ static inline unsigned rsrc_bytes(long rows, long ld, long width) { return (unsigned)(((rows - 1) * ld + width) * 4); }
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -127,7 +131,7 @@ int launch_qfold(const float *Q, int ldq_row, const float *w_k, int D, const flo
                  float *Qf, int b, int h, int L, int Lp, int dh, int dp, hipStream_t s);
 int launch_merge_vproj(const float *Opart, const float *Mpart, const float *Lpart, int nsplit, int b, int h,
                        int L, int Lp, int dp, int D, const float *gamma, const float *beta, const float *w_v,
-                       int dh, float *O, int ldo, float *stats, hipStream_t s);
+                       int dh, float *O, int ldo, float *stats, float *oprime_save, hipStream_t s);
 int launch_merge_explicit(const float *Opart, const float *Mpart, const float *Lpart, int nsplit, int b, int h,
                           int L, int Lp, int dp, int dh, float *O, int ldo, float *stats, hipStream_t s);
 int launch_probs(const float *Q, long q_b, long q_h, int ldq, int dp, const float *Kp, long k_b, long k_h, int ldk,
@@ -157,6 +161,34 @@ size_t head_bwd_scratch_floats(int b, int d, int out_dims);
 int launch_head_bwd(const float *x, int b, int L, int d, const float *nw, const float *nb, const float *w, int out_dims,
                     const float *dlogits, float *dx, float *dnw, float *dnb, float *dw, float *dbias, float *scratch,
                     hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// attention backward (attention_bwd.hip)
+// ------------------------------------------------------------------------------------------------
+struct AttnBwdArgs {
+  const float *Q;  long q_b, q_h; int ldq;      // scaled query operand of the forward core
+  const float *dO; long do_b, do_h; int lddo;   // gradient of the (normalised) attention output, same fragment layout
+  const float *Kp; long k_b, k_h; int ldk;
+  const float *Vp; long v_b, v_h; int ldv;
+  const uint8_t *mask;
+  const float *stats;                            // (b, h, Lq, 2) from the forward
+  const float *delta;                            // (b, h, Lq): sum_d dO * O
+  float *dQpart;                                 // (b, h, nsplit, Lp, dp)
+  float *dKV; float dk_scale;                    // dkv kernel: compact (b*N, 2*inner) output
+  int b, h, Lq, Lp, N, dp, nsplit, chunk;
+};
+int launch_attn_bwd_dq(const AttnBwdArgs &a, hipStream_t s);
+int launch_dq_reduce(const float *part, int nsplit, int b, int h, int L, int Lp, int dp, int width, float scale, float *out,
+                     int ld_out, int head_pitch, hipStream_t s);
+int launch_attn_bwd_dkv(const AttnBwdArgs &a, int dh, int inner, hipStream_t s);
+int launch_rowdot_heads(const float *X, int ldx, int xpitch, const float *Y, int ldy, int ypitch, int h, int L, int width,
+                        long rows, float *delta, hipStream_t s);
+int launch_head_affine(const float *src, int lds, int spitch, const float *mul, int ldm, int mpitch, const float *colscale,
+                       const float *coladd, float scale, int h, int width, int dpitch, int ldd, long rows, float *dst,
+                       hipStream_t s);
+int launch_kv_weight_grads(const float *G, const float *cs, const float *w, const float *gamma, const float *beta, int nrows, int D,
+                           float *dw, float *dgamma, float *dbeta, hipStream_t s);
+int launch_segsum(const float *X, int seg, int cols, int nseg, float *out, hipStream_t s);
 
 // misc
 int launch_broadcast_rows(const float *src, float *dst, long n_per, int b, hipStream_t s);

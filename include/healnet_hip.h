@@ -103,6 +103,26 @@ int hn_attn_probs(const hn_attn_params *p, const float *x_in, const float *ctx, 
                   int N, int D, const uint8_t *mask, const float *stats, float *probs, void *workspace,
                   size_t workspace_bytes, void *stream);
 
+/* Training forward: identical to hn_attn_fwd but also keeps what hn_attn_bwd needs: `stats` (required) and `saved`
+ * (hn_attn_saved_floats() floats: the normalised attention output O for the explicit binding, the normalised
+ * context average P z for the rank-D binding, V for a one-token context). */
+size_t hn_attn_saved_floats(const hn_attn_params *p, int has_ctx, int ld_ctx, int b, int L, int N, int D, int masked);
+int hn_attn_fwd_train(const hn_attn_params *p, const float *x_in, float *x_out, int residual, const float *ctx,
+                      int ld_ctx, int b, int L, int N, int D, const uint8_t *mask, float *stats, float *saved,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
+/* Backward of the block (autograd of :313-321 + :400-426).  x_out is the block OUTPUT of the forward (used for the sign
+ * of the LeakyReLU pre-activation), dy the gradient w.r.t. it; dx receives the gradient w.r.t. x_in (may alias dy).
+ * No gradient flows to the context.  Parameter gradients are ACCUMULATED (+=) into the non-NULL entries. */
+typedef struct hn_attn_grads {
+  float *norm_w, *norm_b, *ctx_gamma, *ctx_beta, *w_q, *w_kv, *w_out, *b_out;
+} hn_attn_grads;
+int hn_attn_bwd(const hn_attn_params *p, const float *x_in, const float *x_out, int residual, const float *ctx,
+                int ld_ctx, int b, int L, int N, int D, const uint8_t *mask, const float *stats, const float *saved,
+                const float *dy, float *dx, const hn_attn_grads *grads, void *workspace, size_t workspace_bytes,
+                void *stream);
+size_t hn_attn_bwd_workspace_bytes(const hn_attn_params *p, int has_ctx, int ld_ctx, int b, int L, int N, int D, int masked);
+
 /* ---------------------------------------------------------------------------------------------
  * Gated feed-forward block                             replaces PreNorm :313-321 + FeedForward :339-351
  * x_out = ( a * gate(g) ) W2^T + b2 [+ x_in],  [a|g] = LN(x_in) W1^T + b1

@@ -82,3 +82,85 @@ def test_head_backward(capi, b, L, d, out):
     assert_close(dx.cpu(), x.grad, rel=2e-4, what="head.dx")
     for got, want, nm in zip(g, (nw, nb, w, bias), ("dnw", "dnb", "dw", "dbias")):
         assert_close(got.cpu(), want.grad, rel=2e-4, what="head." + nm)
+
+
+def _attn_case(capi, b, L, N, D, heads, dh, qd, self_attn=False, masked=False, norm=True, residual=True, seed=0):
+    import healnet_amd.healnet as H
+    gen = torch.Generator().manual_seed(seed)
+    inner = heads * dh
+    kdim = qd if self_attn else D
+    P = {"nw": 1 + 0.3 * torch.randn(qd, generator=gen), "nb": 0.3 * torch.randn(qd, generator=gen),
+         "cg": 1 + 0.3 * torch.randn(kdim, generator=gen), "cb": 0.3 * torch.randn(kdim, generator=gen),
+         "wq": 2.0 * torch.randn(inner, qd, generator=gen) * qd ** -0.5, "wkv": 2.0 * torch.randn(2 * inner, kdim, generator=gen) * kdim ** -0.5,
+         "wo": torch.randn(qd, inner, generator=gen) * inner ** -0.5, "bo": 0.2 * torch.randn(qd, generator=gen)}
+    P = {k: v.requires_grad_(True) for k, v in P.items()}
+    x = (torch.randn(b, L, qd, generator=gen) * 1.3).requires_grad_(True)
+    ctx = None if self_attn else torch.rand(b, N, D, generator=gen) * 2
+    mask = None
+    if masked:
+        mask = torch.rand(b, N, generator=gen) > 0.3
+        mask[:, 0] = True
+    dy = torch.randn(b, L, qd, generator=gen)
+    xn = O.layer_norm(x, P["nw"], P["nb"]) if norm else x
+    cn = None if self_attn else (O.layer_norm(ctx, P["cg"], P["cb"]) if norm else ctx)
+    y = O.attention(xn, cn, P["wq"], P["wkv"], P["wo"], P["bo"], heads, mask) + (x if residual else 0)
+    y.backward(dy)
+
+    d = {k: v.detach().to(DEV).contiguous() for k, v in P.items()}
+    gr = {k: torch.zeros_like(v) for k, v in d.items()}
+    lib = capi.lib()
+    params = capi.AttnParams(heads=heads, dim_head=dh, query_dim=qd, norm_w=d["nw"].data_ptr() if norm else None,
+                             norm_b=d["nb"].data_ptr() if norm else None,
+                             ctx_gamma=d["cg"].data_ptr() if (norm and not self_attn) else None,
+                             ctx_beta=d["cb"].data_ptr() if (norm and not self_attn) else None, w_q=d["wq"].data_ptr(),
+                             w_kv=d["wkv"].data_ptr(), w_out=d["wo"].data_ptr(), b_out=d["bo"].data_ptr())
+    grads = capi.AttnGrads(norm_w=gr["nw"].data_ptr() if norm else None, norm_b=gr["nb"].data_ptr() if norm else None,
+                           ctx_gamma=gr["cg"].data_ptr() if (norm and not self_attn) else None,
+                           ctx_beta=gr["cb"].data_ptr() if (norm and not self_attn) else None, w_q=gr["wq"].data_ptr(),
+                           w_kv=gr["wkv"].data_ptr(), w_out=gr["wo"].data_ptr(), b_out=gr["bo"].data_ptr())
+    xd, dyd = x.detach().to(DEV).contiguous(), dy.to(DEV).contiguous()
+    z, ld, has_ctx = None, 0, 0
+    if not self_attn:
+        has_ctx = 1
+        if norm:
+            ld = lib.hn_context_pitch(D, dh)
+            z = H._normalise_context(ctx.to(DEV).contiguous(), ld)
+        else:
+            z, ld = ctx.to(DEV).contiguous(), D
+    m8 = None if mask is None else mask.to(DEV).to(torch.uint8).contiguous()
+    Nn, Dd = (L, qd) if self_attn else (N, D)
+    nsaved = lib.hn_attn_saved_floats(C.byref(params), has_ctx, ld, b, L, Nn, Dd, int(masked))
+    saved = torch.empty(nsaved, dtype=torch.float32, device=DEV)
+    stats = torch.empty(b, heads, L, 2, dtype=torch.float32, device=DEV)
+    ws = _ws(max(lib.hn_attn_workspace_bytes(C.byref(params), has_ctx, ld, b, L, Nn, Dd),
+                 lib.hn_attn_bwd_workspace_bytes(C.byref(params), has_ctx, ld, b, L, Nn, Dd, int(masked))))
+    xo = torch.empty_like(xd)
+    zp = None if z is None else z.data_ptr()
+    mp = None if m8 is None else m8.data_ptr()
+    capi.check(lib.hn_attn_fwd_train(C.byref(params), xd.data_ptr(), xo.data_ptr(), int(residual), zp, ld, b, L, Nn, Dd, mp,
+                                     stats.data_ptr(), saved.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "fwd_train")
+    assert_close(xo.cpu(), y.detach(), rel=2e-4, what="attn.fwd_train")
+    dx = torch.empty_like(xd)
+    capi.check(lib.hn_attn_bwd(C.byref(params), xd.data_ptr(), xo.data_ptr(), int(residual), zp, ld, b, L, Nn, Dd, mp,
+                               stats.data_ptr(), saved.data_ptr(), dyd.data_ptr(), dx.data_ptr(), C.byref(grads), ws.data_ptr(),
+                               ws.numel(), _stream()), "hn_attn_bwd")
+    assert_close(dx.cpu(), x.grad, rel=5e-4, what="attn.dx")
+    names = ["wq", "wkv", "wo", "bo"] + (["nw", "nb"] if norm else []) + (["cg", "cb"] if (norm and not self_attn) else [])
+    for k in names:
+        want = P[k].grad if P[k].grad is not None else torch.zeros_like(P[k])
+        assert_close(gr[k].cpu(), want, rel=5e-4, floor=2e-4, what="attn.d" + k)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(b=2, L=128, N=600, D=13, heads=8, dh=64, qd=128),                       # rank-D (image-like), several splits
+    dict(b=2, L=25, N=77, D=18, heads=2, dh=63, qd=32),                          # rank-D dp=32, odd sizes
+    dict(b=2, L=16, N=300, D=13, heads=2, dh=64, qd=32, masked=True),            # rank-D with a mask
+    dict(b=2, L=128, N=512, D=96, heads=8, dh=64, qd=128),                       # explicit cross
+    dict(b=3, L=17, N=65, D=40, heads=4, dh=27, qd=32, masked=True),             # explicit cross, padded head dim, mask
+    dict(b=2, L=128, N=0, D=0, heads=8, dh=64, qd=128, self_attn=True),          # latent self-attention
+    dict(b=2, L=24, N=0, D=0, heads=2, dh=16, qd=32, self_attn=True, norm=False, residual=False),
+    dict(b=4, L=128, N=1, D=2005, heads=8, dh=64, qd=128),                       # one-token (tabular) context
+    dict(b=2, L=16, N=50, D=13, heads=2, dh=16, qd=32, norm=False),              # bare Attention, raw 13-wide context
+])
+def test_attention_backward(capi, kw):
+    _attn_case(capi, seed=hash(tuple(sorted(kw.items()))) % 1000, **kw)
