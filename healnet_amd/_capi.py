@@ -64,6 +64,12 @@ class Model(C.Structure):
     ]
 
 
+class ModelGrads(C.Structure):
+    _fields_ = [("latents", C.c_void_p), ("cross_attn", C.POINTER(AttnGrads)), ("cross_ff", C.POINTER(FFGrads)),
+                ("self_attn", C.POINTER(AttnGrads)), ("self_ff", C.POINTER(FFGrads)),
+                ("head_norm_w", C.c_void_p), ("head_norm_b", C.c_void_p), ("head_w", C.c_void_p), ("head_b", C.c_void_p)]
+
+
 class Profile(C.Structure):
     _fields_ = [("ev_start", C.POINTER(C.c_void_p)), ("ev_stop", C.POINTER(C.c_void_p)),
                 ("n_events", C.c_int), ("n_recorded", C.c_int)]
@@ -103,6 +109,12 @@ SIGNATURES = {
     "hn_fusion_forward": (C.c_int, [C.POINTER(Model), C.POINTER(ModalityInput), C.c_int, C.c_void_p, C.c_int, C.c_int,
                                     C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p, C.c_size_t,
                                     C.c_void_p, C.POINTER(Profile)]),
+    "hn_fusion_tape_bytes": (C.c_size_t, [C.POINTER(Model), C.POINTER(ModalityInput), C.c_int, C.c_int, C.c_int]),
+    "hn_fusion_forward_train": (C.c_int, [C.POINTER(Model), C.POINTER(ModalityInput), C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                          C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "hn_fusion_backward_workspace_bytes": (C.c_size_t, [C.POINTER(Model), C.POINTER(ModalityInput), C.c_int, C.c_int]),
+    "hn_fusion_backward": (C.c_int, [C.POINTER(Model), C.POINTER(ModalityInput), C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                     C.c_void_p, C.POINTER(ModelGrads), C.c_void_p, C.c_size_t, C.c_void_p]),
     "hn_fusion_workspace_bytes": (C.c_size_t, [C.POINTER(Model), C.POINTER(ModalityInput), C.c_int]),
 }
 

@@ -646,6 +646,111 @@ static int plan_fusion(const hn_model *m, const hn_modality_input *in, int b, vo
   return HN_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// training: block schedule, tape layout, backward workspace
+// ------------------------------------------------------------------------------------------------
+enum StepKind { STEP_CROSS_ATTN, STEP_CROSS_FF, STEP_SELF_ATTN, STEP_SELF_FF };
+struct Step { int kind, layer, m; };
+
+// the executed blocks in order, identical for the training forward and the backward (healnet.py:227-245)
+static int build_schedule(const hn_model *m, const hn_modality_input *in, int skip_self_on_missing, Step *steps, int cap) {
+  int n = 0;
+  for (int layer = 0; layer < m->depth; ++layer)
+    for (int i = 0; i < m->n_modalities; ++i) {
+      const bool present = in[i].data != nullptr;
+      if (!present && skip_self_on_missing) continue;
+      if (present) {
+        if (n + 2 > cap) return -1;
+        steps[n++] = {STEP_CROSS_ATTN, layer, i};
+        steps[n++] = {STEP_CROSS_FF, layer, i};
+      }
+      if (m->self_per_cross_attn > 0) {
+        if (n + 2 > cap) return -1;
+        steps[n++] = {STEP_SELF_ATTN, layer, i};
+        steps[n++] = {STEP_SELF_FF, layer, i};
+      }
+    }
+  return n;
+}
+
+constexpr int kMaxSteps = 4096;
+
+struct TapePlan {
+  int nsteps;
+  Step steps[kMaxSteps];
+  size_t x_off[kMaxSteps + 1];       // float offsets of the latent array before step k (x_off[nsteps] = final)
+  size_t stats_off[kMaxSteps], saved_off[kMaxSteps];
+  size_t floats;
+};
+
+static int plan_tape(const hn_model *m, const hn_modality_input *in, int b, int masked, int skip_self, const FusionPlan &fp, TapePlan *tp) {
+  tp->nsteps = build_schedule(m, in, skip_self, tp->steps, kMaxSteps);
+  HN_REQUIRE(tp->nsteps >= 0, HN_E_UNSUPPORTED, "fusion: more than %d blocks", kMaxSteps);
+  const size_t xn = (size_t)b * m->l_c * m->l_d;
+  size_t off = 0;
+  for (int k = 0; k <= tp->nsteps; ++k) { tp->x_off[k] = off; off += align_up(xn, 64); }
+  for (int k = 0; k < tp->nsteps; ++k) {
+    const Step &st = tp->steps[k];
+    tp->stats_off[k] = tp->saved_off[k] = 0;
+    if (st.kind == STEP_CROSS_ATTN || st.kind == STEP_SELF_ATTN) {
+      const bool cross = st.kind == STEP_CROSS_ATTN;
+      const hn_attn_params *ap = cross ? &m->cross_attn[st.layer * m->n_modalities + st.m] : &m->self_attn[st.layer];
+      AttnPlan pl;
+      int rc = plan_attn(ap, cross, cross ? fp.ldz[st.m] : 0, b, m->l_c, cross ? fp.N[st.m] : m->l_c, cross ? fp.D[st.m] : m->l_d,
+                         nullptr, 0, &pl);
+      if (rc != HN_OK) return rc;
+      tp->stats_off[k] = off; off += align_up((size_t)b * ap->heads * m->l_c * 2, 64);
+      tp->saved_off[k] = off; off += align_up(attn_saved_floats(pl, cross, cross && masked, b, m->l_c), 64);
+    }
+  }
+  tp->floats = off;
+  return HN_OK;
+}
+
+static int fusion_bwd_workspace(const hn_model *m, const hn_modality_input *in, int b, int masked, void *ws, size_t ws_bytes,
+                                FusionPlan *fp, float **dX, float **head_scratch, void **op_ws, size_t *op_bytes, size_t *total) {
+  // same z / x carve as the forward (x is unused), then the backward scratch
+  int rc = plan_fusion(m, in, b, nullptr, 0, fp);
+  if (rc != HN_OK) return rc;
+  Arena ar(ws, ws_bytes);
+  for (int i = 0; i < m->n_modalities; ++i) {
+    fp->z[i] = nullptr;
+    if (in[i].data) fp->z[i] = ar.take<float>((size_t)b * fp->N[i] * fp->ldz[i]);
+  }
+  *dX = ar.take<float>((size_t)b * m->l_c * m->l_d);
+  *head_scratch = ar.take<float>(head_bwd_scratch_floats(b, m->l_d, m->out_dims > 0 ? m->out_dims : 1));
+  size_t need = 0;
+  for (int layer = 0; layer < m->depth; ++layer) {
+    for (int i = 0; i < m->n_modalities; ++i) {
+      if (!in[i].data) continue;
+      const hn_attn_params *ap = &m->cross_attn[layer * m->n_modalities + i];
+      AttnPlan pl;
+      if ((rc = plan_attn(ap, true, fp->ldz[i], b, m->l_c, fp->N[i], fp->D[i], nullptr, 0, &pl)) != HN_OK) return rc;
+      AttnBwdPlan bp;
+      if ((rc = plan_attn_bwd(ap, pl, true, masked != 0, b, m->l_c, nullptr, 0, &bp)) != HN_OK) return rc;
+      if (bp.bytes > need) need = bp.bytes;
+    }
+    if (m->self_per_cross_attn > 0) {
+      AttnPlan pl;
+      if ((rc = plan_attn(&m->self_attn[layer], false, 0, b, m->l_c, m->l_c, m->l_d, nullptr, 0, &pl)) != HN_OK) return rc;
+      AttnBwdPlan bp;
+      if ((rc = plan_attn_bwd(&m->self_attn[layer], pl, false, false, b, m->l_c, nullptr, 0, &bp)) != HN_OK) return rc;
+      if (bp.bytes > need) need = bp.bytes;
+    }
+  }
+  hn_ff_params ffp;
+  memset(&ffp, 0, sizeof(ffp));
+  ffp.dim = m->l_d;
+  FFBwdPlan fb;
+  plan_ff_bwd(&ffp, b * m->l_c, nullptr, 0, &fb);
+  if (fb.bytes > need) need = fb.bytes;
+  *op_bytes = need;
+  *op_ws = ar.take<char>(need);
+  *total = ar.off;
+  if (ws != nullptr && ar.overflow) return fail(HN_E_WORKSPACE, "fusion_backward: workspace %zu bytes < required %zu", ws_bytes, ar.off);
+  return HN_OK;
+}
+
 }  // namespace hn
 
 using namespace hn;
@@ -827,6 +932,135 @@ int hn_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, con
   }
   if (head) return launch_head(fp.x, b, L, d, m->head_norm_w, m->head_norm_b, m->head_w, m->head_b, m->out_dims, out, s);
   HN_HIP_CHECK(hipMemcpyAsync(out, fp.x, xbytes, hipMemcpyDeviceToDevice, s));
+  return HN_OK;
+}
+
+size_t hn_fusion_tape_bytes(const hn_model *m, const hn_modality_input *in, int b, int masked, int skip_self_on_missing) {
+  FusionPlan fp;
+  if (plan_fusion(m, in, b, nullptr, 0, &fp) != HN_OK) return 0;
+  static thread_local TapePlan tp;
+  if (plan_tape(m, in, b, masked, skip_self_on_missing, fp, &tp) != HN_OK) return 0;
+  return align_up(tp.floats * sizeof(float), 256);
+}
+
+int hn_fusion_forward_train(const hn_model *m, const hn_modality_input *in, int b, const uint8_t *mask, int skip_self_on_missing,
+                            int return_embeddings, float *out, void *tape, size_t tape_bytes, void *workspace,
+                            size_t workspace_bytes, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  HN_REQUIRE(out && tape, HN_E_NULL, "fusion_forward_train: out / tape is NULL");
+  FusionPlan fp;
+  int rc = plan_fusion(m, in, b, nullptr, 0, &fp);
+  if (rc != HN_OK) return rc;
+  if ((rc = check_ws(workspace, workspace_bytes, fp.bytes, "fusion_forward_train")) != HN_OK) return rc;
+  if ((rc = plan_fusion(m, in, b, workspace, workspace_bytes, &fp)) != HN_OK) return rc;
+  static thread_local TapePlan tp;
+  if ((rc = plan_tape(m, in, b, mask != nullptr, skip_self_on_missing, fp, &tp)) != HN_OK) return rc;
+  HN_REQUIRE(tape_bytes >= tp.floats * sizeof(float) && ((uintptr_t)tape & 255) == 0, HN_E_WORKSPACE,
+             "fusion_forward_train: tape %zu bytes < required %zu (256-byte aligned)", tape_bytes, tp.floats * sizeof(float));
+  float *T = (float *)tape;
+  const int M = m->n_modalities, L = m->l_c, d = m->l_d;
+  for (int i = 0; i < M; ++i) {
+    if (!in[i].data) continue;
+    if ((rc = launch_encode(in[i].data, b, m->num_spatial_axes[i], in[i].spatial, m->channel_dims[i], m->num_freq_bands,
+                            m->max_freq, m->fourier_encode_data, 1, 1e-5f, fp.z[i], fp.ldz[i], s)) != HN_OK)
+      return rc;
+  }
+  if ((rc = launch_broadcast_rows(m->latents, T + tp.x_off[0], (long)L * d, b, s)) != HN_OK) return rc;
+  for (int k = 0; k < tp.nsteps; ++k) {
+    const Step &st = tp.steps[k];
+    const float *xin = T + tp.x_off[k];
+    float *xout = T + tp.x_off[k + 1];
+    switch (st.kind) {
+      case STEP_CROSS_ATTN:
+        rc = attn_fwd_impl(&m->cross_attn[st.layer * M + st.m], xin, xout, 1, fp.z[st.m], fp.ldz[st.m], b, L, fp.N[st.m], fp.D[st.m],
+                           mask, T + tp.stats_off[k], fp.op_ws, fp.op_ws_bytes, s, nullptr, nullptr, T + tp.saved_off[k]);
+        break;
+      case STEP_SELF_ATTN:
+        rc = attn_fwd_impl(&m->self_attn[st.layer], xin, xout, 1, nullptr, 0, b, L, L, d, nullptr, T + tp.stats_off[k], fp.op_ws,
+                           fp.op_ws_bytes, s, nullptr, nullptr, T + tp.saved_off[k]);
+        break;
+      case STEP_CROSS_FF:
+        rc = ff_fwd_impl(&m->cross_ff[st.layer * M + st.m], xin, xout, 1, b * L, fp.op_ws, fp.op_ws_bytes, s);
+        break;
+      default:
+        rc = ff_fwd_impl(&m->self_ff[st.layer], xin, xout, 1, b * L, fp.op_ws, fp.op_ws_bytes, s);
+        break;
+    }
+    if (rc != HN_OK) return rc;
+  }
+  const float *xf = T + tp.x_off[tp.nsteps];
+  if (m->final_classifier_head && !return_embeddings)
+    return launch_head(xf, b, L, d, m->head_norm_w, m->head_norm_b, m->head_w, m->head_b, m->out_dims, out, s);
+  HN_HIP_CHECK(hipMemcpyAsync(out, xf, (size_t)b * L * d * sizeof(float), hipMemcpyDeviceToDevice, s));
+  return HN_OK;
+}
+
+size_t hn_fusion_backward_workspace_bytes(const hn_model *m, const hn_modality_input *in, int b, int masked) {
+  FusionPlan fp;
+  float *dX, *hs;
+  void *op;
+  size_t opb, total;
+  if (fusion_bwd_workspace(m, in, b, masked, nullptr, 0, &fp, &dX, &hs, &op, &opb, &total) != HN_OK) return 0;
+  return total;
+}
+
+int hn_fusion_backward(const hn_model *m, const hn_modality_input *in, int b, const uint8_t *mask, int skip_self_on_missing,
+                       int return_embeddings, const float *dout, const void *tape, const hn_model_grads *g, void *workspace,
+                       size_t workspace_bytes, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  HN_REQUIRE(dout && tape && g, HN_E_NULL, "fusion_backward: NULL pointer");
+  FusionPlan fp;
+  float *dX, *hs;
+  void *op;
+  size_t opb, total;
+  int rc = fusion_bwd_workspace(m, in, b, mask != nullptr, nullptr, 0, &fp, &dX, &hs, &op, &opb, &total);
+  if (rc != HN_OK) return rc;
+  if ((rc = check_ws(workspace, workspace_bytes, total, "fusion_backward")) != HN_OK) return rc;
+  if ((rc = fusion_bwd_workspace(m, in, b, mask != nullptr, workspace, workspace_bytes, &fp, &dX, &hs, &op, &opb, &total)) != HN_OK) return rc;
+  static thread_local TapePlan tp;
+  if ((rc = plan_tape(m, in, b, mask != nullptr, skip_self_on_missing, fp, &tp)) != HN_OK) return rc;
+  const float *T = (const float *)tape;
+  const int M = m->n_modalities, L = m->l_c, d = m->l_d;
+  const size_t xn = (size_t)b * L * d;
+  for (int i = 0; i < M; ++i) {     // the normalised contexts are recomputed (one HBM pass) rather than kept on the tape
+    if (!in[i].data) continue;
+    if ((rc = launch_encode(in[i].data, b, m->num_spatial_axes[i], in[i].spatial, m->channel_dims[i], m->num_freq_bands,
+                            m->max_freq, m->fourier_encode_data, 1, 1e-5f, fp.z[i], fp.ldz[i], s)) != HN_OK)
+      return rc;
+  }
+  const float *xf = T + tp.x_off[tp.nsteps];
+  if (m->final_classifier_head && !return_embeddings) {
+    if ((rc = launch_head_bwd(xf, b, L, d, m->head_norm_w, m->head_norm_b, m->head_w, m->out_dims, dout, dX, g->head_norm_w,
+                              g->head_norm_b, g->head_w, g->head_b, hs, s)) != HN_OK) return rc;
+  } else {
+    HN_HIP_CHECK(hipMemcpyAsync(dX, dout, xn * sizeof(float), hipMemcpyDeviceToDevice, s));
+  }
+  static const hn_attn_grads no_attn = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  static const hn_ff_grads no_ff = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  for (int k = tp.nsteps - 1; k >= 0; --k) {
+    const Step &st = tp.steps[k];
+    const float *xin = T + tp.x_off[k], *xout = T + tp.x_off[k + 1];
+    switch (st.kind) {
+      case STEP_CROSS_ATTN:
+        rc = attn_bwd_impl(&m->cross_attn[st.layer * M + st.m], xin, xout, 1, fp.z[st.m], fp.ldz[st.m], b, L, fp.N[st.m], fp.D[st.m],
+                           mask, T + tp.stats_off[k], T + tp.saved_off[k], dX, dX, g->cross_attn ? &g->cross_attn[st.layer * M + st.m] : &no_attn,
+                           op, opb, s);
+        break;
+      case STEP_SELF_ATTN:
+        rc = attn_bwd_impl(&m->self_attn[st.layer], xin, xout, 1, nullptr, 0, b, L, L, d, nullptr, T + tp.stats_off[k],
+                           T + tp.saved_off[k], dX, dX, g->self_attn ? &g->self_attn[st.layer] : &no_attn, op, opb, s);
+        break;
+      case STEP_CROSS_FF:
+        rc = ff_bwd_impl(&m->cross_ff[st.layer * M + st.m], xin, dX, dX, 1, b * L, g->cross_ff ? &g->cross_ff[st.layer * M + st.m] : &no_ff,
+                         op, opb, s);
+        break;
+      default:
+        rc = ff_bwd_impl(&m->self_ff[st.layer], xin, dX, dX, 1, b * L, g->self_ff ? &g->self_ff[st.layer] : &no_ff, op, opb, s);
+        break;
+    }
+    if (rc != HN_OK) return rc;
+  }
+  if (g->latents) return launch_colsum(dX, (long)L * d, b, L * d, 1.0f, g->latents, 1, s);   // x0 = latents broadcast over the batch
   return HN_OK;
 }
 

@@ -17,7 +17,7 @@ Deliberate deviations from the reference (documented in DESIGN.md):
   * the caller's list is not overwritten with the encoded context (:222) unless
     ``compat_mutate_inputs=True``;
   * ``attn_weights`` (:420) is materialised lazily on request instead of being kept for every block;
-  * dropout > 0 in training mode and autograd through the fused path are not implemented yet (raise).
+  * dropout > 0 in training mode is not implemented yet (raises); autograd runs through hn_fusion_backward.
 """
 from __future__ import annotations
 
@@ -152,6 +152,14 @@ class Attention(nn.Module):
             w_q=_ptr(self.to_q.weight), w_kv=_ptr(self.to_kv.weight),
             w_out=_ptr(self.to_out[0].weight), b_out=_ptr(self.to_out[0].bias))
 
+    def _grads(self, norm: Optional[nn.LayerNorm], norm_context: Optional[nn.LayerNorm], gmap) -> _capi.AttnGrads:
+        gp = lambda t: None if t is None or id(t) not in gmap else gmap[id(t)].data_ptr()   # noqa: E731
+        return _capi.AttnGrads(
+            norm_w=gp(norm.weight) if norm is not None else None, norm_b=gp(norm.bias) if norm is not None else None,
+            ctx_gamma=gp(norm_context.weight) if norm_context is not None else None,
+            ctx_beta=gp(norm_context.bias) if norm_context is not None else None,
+            w_q=gp(self.to_q.weight), w_kv=gp(self.to_kv.weight), w_out=gp(self.to_out[0].weight), b_out=gp(self.to_out[0].bias))
+
     def _check_mode(self) -> None:
         if self.training and self.dropout_p > 0.0:
             raise NotImplementedError("healnet_amd: attention dropout > 0 in training mode is not implemented "
@@ -227,6 +235,11 @@ class FeedForward(nn.Module):
                               w1=_ptr(self.net[0].weight), b1=_ptr(self.net[0].bias),
                               w2=_ptr(self.net[2].weight), b2=_ptr(self.net[2].bias))
 
+    def _grads(self, norm: Optional[nn.LayerNorm], gmap) -> _capi.FFGrads:
+        gp = lambda t: None if t is None or id(t) not in gmap else gmap[id(t)].data_ptr()   # noqa: E731
+        return _capi.FFGrads(norm_w=gp(norm.weight) if norm is not None else None, norm_b=gp(norm.bias) if norm is not None else None,
+                             w1=gp(self.net[0].weight), b1=gp(self.net[0].bias), w2=gp(self.net[2].weight), b2=gp(self.net[2].bias))
+
     def _run(self, x: torch.Tensor, norm: Optional[nn.LayerNorm], residual: bool) -> torch.Tensor:
         if self.training and self.dropout_p > 0.0:
             raise NotImplementedError("healnet_amd: ff_dropout > 0 in training mode is not implemented (SURVEY.md §8 f2)")
@@ -290,6 +303,54 @@ class _Memo:
         if key not in self._store:
             self._store[key] = self._factory()
         return self._store[key]
+
+
+# ------------------------------------------------------------------------------------------------
+# autograd: one Function for the whole fusion stack (hn_fusion_forward_train / hn_fusion_backward)
+# ------------------------------------------------------------------------------------------------
+class _FusionFunction(torch.autograd.Function):
+    """Differentiable w.r.t. every parameter of the model (incl. the latent array); the modality inputs get no
+    gradient, as in the reference's training loop (healnet/main.py:432-465)."""
+
+    @staticmethod
+    def forward(ctx, module, inputs, held, mask_u8, b, skip_self, embeddings, *params):
+        lib = _capi.lib()
+        device = module.latents.device
+        model, keep = module._descriptor()
+        masked = int(mask_u8 is not None)
+        tape_bytes = lib.hn_fusion_tape_bytes(C.byref(model), inputs, b, masked, int(skip_self))
+        need = lib.hn_fusion_workspace_bytes(C.byref(model), inputs, b)
+        if tape_bytes == 0 or need == 0:
+            _capi.check(-1, "hn_fusion_tape_bytes")
+        tape = torch.empty(tape_bytes, dtype=torch.uint8, device=device)
+        ws = _WS.get(device, need)
+        out = torch.empty((b, module.l_c, module.l_d) if embeddings else (b, module.out_dims), dtype=torch.float32,
+                          device=device)
+        _capi.check(lib.hn_fusion_forward_train(C.byref(model), inputs, b, _ptr(mask_u8), int(skip_self), int(embeddings),
+                                                out.data_ptr(), tape.data_ptr(), tape.numel(), ws.data_ptr(), ws.numel(),
+                                                _stream_ptr(device)), "hn_fusion_forward_train")
+        ctx.module, ctx.inputs, ctx.held, ctx.mask_u8 = module, inputs, held, mask_u8
+        ctx.b, ctx.skip_self, ctx.embeddings, ctx.tape, ctx.params = b, skip_self, embeddings, tape, params
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _capi.lib()
+        module, params = ctx.module, ctx.params
+        device = module.latents.device
+        model, keep = module._descriptor()
+        gmap = {id(p): torch.zeros_like(p, dtype=torch.float32) for p in params if p.requires_grad}
+        grads, keep_g = module._grad_descriptor(gmap)
+        masked = int(ctx.mask_u8 is not None)
+        need = lib.hn_fusion_backward_workspace_bytes(C.byref(model), ctx.inputs, ctx.b, masked)
+        if need == 0:
+            _capi.check(-1, "hn_fusion_backward_workspace_bytes")
+        ws = _WS.get(device, need)
+        dout = dout.contiguous().float()
+        _capi.check(lib.hn_fusion_backward(C.byref(model), ctx.inputs, ctx.b, _ptr(ctx.mask_u8), int(ctx.skip_self),
+                                           int(ctx.embeddings), dout.data_ptr(), ctx.tape.data_ptr(), C.byref(grads),
+                                           ws.data_ptr(), ws.numel(), _stream_ptr(device)), "hn_fusion_backward")
+        return (None,) * 7 + tuple(gmap.get(id(p)) for p in params)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -386,6 +447,33 @@ class HealNet(nn.Module):
         keep.extend([cross_attn, cross_ff, self_attn, self_ff, cd, ax])
         return model, keep
 
+    def _grad_descriptor(self, gmap):
+        """hn_model_grads whose entries point into the per-parameter gradient buffers of ``gmap`` (id(param) -> tensor);
+        tied parameters share one buffer, into which the backward accumulates."""
+        M, depth = self.modalities, self.depth
+        cross_attn = (_capi.AttnGrads * (depth * M))()
+        cross_ff = (_capi.FFGrads * (depth * M))()
+        self_attn = (_capi.AttnGrads * depth)()
+        self_ff = (_capi.FFGrads * depth)()
+        for layer in range(depth):
+            mods = self.layers[layer]
+            for m in range(M):
+                blk, ffn = mods[2 * m], mods[2 * m + 1]
+                cross_attn[layer * M + m] = blk.fn._grads(blk.norm, blk.norm_context, gmap)
+                cross_ff[layer * M + m] = ffn.fn._grads(ffn.norm, gmap)
+            if self.self_per_cross_attn >= 1:
+                blk, ffn = mods[2 * M][0], mods[2 * M][1]
+                self_attn[layer] = blk.fn._grads(blk.norm, None, gmap)
+                self_ff[layer] = ffn.fn._grads(ffn.norm, gmap)
+        gp = lambda t: None if id(t) not in gmap else gmap[id(t)].data_ptr()   # noqa: E731
+        head = self.final_classifier_head
+        grads = _capi.ModelGrads(latents=gp(self.latents), cross_attn=cross_attn, cross_ff=cross_ff, self_attn=self_attn,
+                                 self_ff=self_ff, head_norm_w=gp(self.to_logits[1].weight) if head else None,
+                                 head_norm_b=gp(self.to_logits[1].bias) if head else None,
+                                 head_w=gp(self.to_logits[2].weight) if head else None,
+                                 head_b=gp(self.to_logits[2].bias) if head else None)
+        return grads, [cross_attn, cross_ff, self_attn, self_ff]
+
     def _check_mode(self) -> None:
         if self.self_per_cross_attn >= 2:
             raise ValueError("self_per_cross_attn >= 2 fails in the reference as well (healnet.py:242: "
@@ -448,6 +536,20 @@ class HealNet(nn.Module):
                         raise ValueError(f"mask {tuple(mask.shape)} does not match modality {i + 1} (b={b}, N={n_i}); "
                                          "the mask is applied to every modality's cross-attention (Appendix B-5)")
             mask_u8 = flat.to(device=device, dtype=torch.uint8).contiguous()
+
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            if _profile is not None:
+                raise ValueError("profiling hooks are only available on the inference path")
+            embeddings = return_embeddings or not self.final_classifier_head
+            params = [p for p in self.parameters()]
+            out = _FusionFunction.apply(self, inputs, held, mask_u8, b, bool(verbose), embeddings, *params)
+            if verbose:
+                for layer in range(self.depth):
+                    for i in missing_idx:
+                        print(f"Skipping update in fusion layer {layer + 1} for missing modality {i + 1}")
+            self._last = None
+            self._bind_lazy_probs()
+            return out
 
         lib = _capi.lib()
         model, keep = self._descriptor()

@@ -212,6 +212,31 @@ int hn_fusion_forward(const hn_model *model, const hn_modality_input *inputs, in
                       hn_profile *profile);
 size_t hn_fusion_workspace_bytes(const hn_model *model, const hn_modality_input *inputs, int b);
 
+/* ---------------------------------------------------------------------------------------------
+ * Training: forward that records a tape, and the matching backward   (autograd of HealNet.forward :190-250, driven by
+ * surv_loss.backward() at healnet/main.py:464).  The tape holds the latent array before every executed block, the
+ * softmax statistics and the small per-attention tensors of hn_attn_fwd_train.  hn_fusion_backward ACCUMULATES (+=)
+ * into every non-NULL gradient pointer of hn_model_grads (same shapes / indexing as hn_model; tied weights simply point
+ * several entries at one buffer); the modality inputs receive no gradient.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct hn_model_grads {
+  float *latents;
+  const hn_attn_grads *cross_attn; /* [depth * M] or NULL */
+  const hn_ff_grads *cross_ff;     /* [depth * M] or NULL */
+  const hn_attn_grads *self_attn;  /* [depth] or NULL */
+  const hn_ff_grads *self_ff;      /* [depth] or NULL */
+  float *head_norm_w, *head_norm_b, *head_w, *head_b;
+} hn_model_grads;
+
+size_t hn_fusion_tape_bytes(const hn_model *model, const hn_modality_input *inputs, int b, int masked, int skip_self_on_missing);
+int hn_fusion_forward_train(const hn_model *model, const hn_modality_input *inputs, int b, const uint8_t *mask,
+                            int skip_self_on_missing, int return_embeddings, float *out, void *tape, size_t tape_bytes,
+                            void *workspace, size_t workspace_bytes, void *stream);
+size_t hn_fusion_backward_workspace_bytes(const hn_model *model, const hn_modality_input *inputs, int b, int masked);
+int hn_fusion_backward(const hn_model *model, const hn_modality_input *inputs, int b, const uint8_t *mask,
+                       int skip_self_on_missing, int return_embeddings, const float *dout, const void *tape,
+                       const hn_model_grads *grads, void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -164,3 +164,63 @@ def _attn_case(capi, b, L, N, D, heads, dh, qd, self_attn=False, masked=False, n
 ])
 def test_attention_backward(capi, kw):
     _attn_case(capi, seed=hash(tuple(sorted(kw.items()))) % 1000, **kw)
+
+
+# ------------------------------------------------------------------------------------------------
+# whole-model gradients: reference-generated fixtures (tiny models) and oracle autograd (larger ones)
+# ------------------------------------------------------------------------------------------------
+def test_model_gradients_match_reference_fixtures(manifest_):
+    import healnet_amd as hn
+    from conftest import load_golden
+    for name in ["m1_d1", "m2_d3", "m3_d3", "m2_d3_tied", "m2_d2_noself", "m2_d2_nofourier", "m2_d2_gelu", "m2_d2_nohead",
+                 "m2_d2_bands4"]:
+        g = load_golden("g5_" + name)
+        kw = manifest_["g5_" + name]["kwargs"]
+        model = hn.HealNet(**kw).train()
+        model.load_state_dict({k[4:]: v for k, v in g.items() if k.startswith("sd::")}, strict=True)
+        model.to(DEV)
+        ins = [g[f"in{i}"].to(DEV) for i in range(kw["n_modalities"])]
+        out = model(list(ins))
+        assert_close(out.detach().cpu(), g["logits"] if "logits" in g else out.detach().cpu(), rel=2e-4, what=name + ".fwd_train")
+        (out * O.filler_input(out.shape, 77).to(DEV)).sum().backward()
+        for k, p in model.named_parameters():
+            want = g["grad::" + k]
+            assert p.grad is not None, k
+            assert_close(p.grad.cpu(), want, rel=1e-3, floor=5e-4, what=f"{name}.grad[{k}]")
+
+
+@pytest.fixture(scope="module")
+def manifest_():
+    import json, os
+    from conftest import GOLD
+    with open(os.path.join(GOLD, "manifest.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("cfg", ["cfg1_b2", "cfg4_b2", "missing"])
+def test_model_gradients_vs_oracle_autograd(cfg):
+    import healnet_amd as hn
+    gen = torch.Generator().manual_seed(31)
+    if cfg == "cfg1_b2":
+        kw = dict(n_modalities=2, channel_dims=[2000, 3], num_spatial_axes=[1, 2], out_dims=4, depth=2)
+        ins = [torch.rand(2, 1, 2000, generator=gen), torch.rand(2, 48, 40, 3, generator=gen)]
+    elif cfg == "cfg4_b2":
+        kw = dict(n_modalities=2, channel_dims=[2000, 768], num_spatial_axes=[1, 1], out_dims=4, depth=2)
+        ins = [torch.rand(2, 1, 2000, generator=gen), torch.rand(2, 300, 768, generator=gen)]
+    else:
+        kw = dict(n_modalities=3, channel_dims=[50, 3, 64], num_spatial_axes=[1, 2, 1], out_dims=3, depth=2, l_c=32, l_d=64,
+                  x_heads=4, l_heads=4, cross_dim_head=32, latent_dim_head=16)
+        ins = [torch.rand(3, 1, 50, generator=gen), None, torch.rand(3, 90, 64, generator=gen)]
+    torch.manual_seed(11)
+    model = hn.HealNet(**kw).train()
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    want = O.fusion_forward(sd, O.FusionConfig(**kw), ins)
+    dl = torch.randn(want.shape, generator=gen)
+    (want * dl).sum().backward()
+    model.to(DEV)
+    got = model([None if t is None else t.to(DEV) for t in ins])
+    assert_close(got.detach().cpu(), want.detach(), rel=1e-3, what=cfg + ".fwd_train")
+    (got * dl.to(DEV)).sum().backward()
+    for k, p in model.named_parameters():
+        ref = sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])
+        assert_close(p.grad.cpu(), ref, rel=2e-3, floor=1e-3, what=f"{cfg}.grad[{k}]")
