@@ -231,7 +231,7 @@ static size_t attn_saved_floats(const AttnPlan &pl, bool has_ctx, bool masked, i
 }
 
 struct AttnBwdPlan {
-  float *dpre, *dO, *xhat, *dxhat, *lns, *delta, *dOp, *dQpart, *dQ, *dKV, *G, *cs, *Abuf, *dA, *E, *T, *dT, *dyb, *dV;
+  float *dpre, *dO, *xhat, *dxhat, *lns, *delta, *dOp, *dQpart, *dQ, *dKV, *G, *cs, *Abuf, *dA, *E, *T, *dT, *dyb, *dV, *red;
   void *fwd_ws; size_t fwd_bytes, bytes;
 };
 
@@ -243,6 +243,10 @@ static int plan_attn_bwd(const hn_attn_params *p, const AttnPlan &pl, bool has_c
   bp->fwd_bytes = pl.bytes;
   bp->fwd_ws = ar.take<char>(pl.bytes);
   bp->dpre = ar.take<float>(rows * qd);
+  {
+    const long kdim = pl.D > (int)qd ? pl.D : (long)qd;
+    bp->red = ar.take<float>(reduce_scratch_floats(2L * inner * kdim, (int)(2 * inner > qd ? 2 * inner : qd)));
+  }
   if (has_ctx && pl.N == 1 && !masked) {
     bp->dyb = ar.take<float>((size_t)b * qd);
     bp->dV = ar.take<float>((size_t)b * inner);
@@ -309,19 +313,19 @@ static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float
 
   if (has_ctx && pl.N == 1 && mask == nullptr) {   // ---- one-token context: y_b = LeakyReLU(W_out V_b + b_out) for every row
     if ((rc = launch_segsum(bp.dpre, L, qd, b, bp.dyb, s)) != HN_OK) return rc;
-    if (g->b_out && (rc = launch_colsum(bp.dyb, qd, b, qd, 1.0f, g->b_out, 1, s)) != HN_OK) return rc;
+    if (g->b_out && (rc = launch_colsum(bp.dyb, qd, b, qd, 1.0f, g->b_out, 1, s, bp.red)) != HN_OK) return rc;
     if (g->w_out) {   // dWo += dyb^T V
       GemmExArgs e = gex(bp.dyb, 1, qd, saved, 1, inner, g->w_out, inner, qd, inner, b, 1);
-      if ((rc = launch_gemm_ex(e, s)) != HN_OK) return rc;
+      if ((rc = launch_gemm_ex(e, s, bp.red)) != HN_OK) return rc;
     }
     {   // dV = dyb Wo
       GemmExArgs e = gex(bp.dyb, qd, 1, p->w_out, 1, inner, bp.dV, inner, b, inner, qd, 0);
-      if ((rc = launch_gemm_ex(e, s)) != HN_OK) return rc;
+      if ((rc = launch_gemm_ex(e, s, bp.red)) != HN_OK) return rc;
     }
     {   // G = dV^T z, cs = colsum(dV)  -> gradients of the V half of to_kv and of the context LayerNorm affine
       GemmExArgs e = gex(bp.dV, 1, inner, ctx, 1, ld_ctx, bp.G, pl.D, inner, pl.D, b, 0);
-      if ((rc = launch_gemm_ex(e, s)) != HN_OK) return rc;
-      if ((rc = launch_colsum(bp.dV, inner, b, inner, 1.0f, bp.cs, 0, s)) != HN_OK) return rc;
+      if ((rc = launch_gemm_ex(e, s, bp.red)) != HN_OK) return rc;
+      if ((rc = launch_colsum(bp.dV, inner, b, inner, 1.0f, bp.cs, 0, s, bp.red)) != HN_OK) return rc;
       if ((rc = launch_kv_weight_grads(bp.G, bp.cs, p->w_kv + (long)inner * pl.D, p->ctx_gamma, p->ctx_beta, inner, pl.D,
                                        g->w_kv ? g->w_kv + (long)inner * pl.D : nullptr, g->ctx_gamma, g->ctx_beta, s)) != HN_OK)
         return rc;
@@ -338,17 +342,17 @@ static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float
                                  h * pl.dp, rows, bp.Abuf, s)) != HN_OK) return rc;
     GemmExArgs e = gex(bp.Abuf, (long)h * pl.dp, 1, p->w_kv + (long)inner * pl.D, pl.D, 1, pl.obuf, inner, rows, dh, pl.D, 0);
     e.batch = h; e.strideA = pl.dp; e.strideB = (long)dh * pl.D; e.strideC = dh;
-    if ((rc = launch_gemm_ex(e, s)) != HN_OK) return rc;
+    if ((rc = launch_gemm_ex(e, s, bp.red)) != HN_OK) return rc;
     O = pl.obuf;
   }
   if (g->w_out) {
     GemmExArgs e = gex(bp.dpre, 1, qd, O, 1, inner, g->w_out, inner, qd, inner, rows, 1);
-    if ((rc = launch_gemm_ex(e, s)) != HN_OK) return rc;
+    if ((rc = launch_gemm_ex(e, s, bp.red)) != HN_OK) return rc;
   }
-  if (g->b_out && (rc = launch_colsum(bp.dpre, qd, rows, qd, 1.0f, g->b_out, 1, s)) != HN_OK) return rc;
+  if (g->b_out && (rc = launch_colsum(bp.dpre, qd, rows, qd, 1.0f, g->b_out, 1, s, bp.red)) != HN_OK) return rc;
   {
     GemmExArgs e = gex(bp.dpre, qd, 1, p->w_out, 1, inner, bp.dO, inner, rows, inner, qd, 0);
-    if ((rc = launch_gemm_ex(e, s)) != HN_OK) return rc;
+    if ((rc = launch_gemm_ex(e, s, bp.red)) != HN_OK) return rc;
   }
 
   // ---- recompute the operands of the core (scaled Q, and K/V or the folded queries)
@@ -375,18 +379,18 @@ static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float
     if (dwv) {
       GemmExArgs e = gex(bp.dO, 1, inner, bp.Abuf, 1, hp, dwv, pl.D, dh, pl.D, rows, 1);
       e.batch = h; e.strideA = dh; e.strideB = pl.dp; e.strideC = (long)dh * pl.D;
-      if ((rc = launch_gemm_ex(e, s)) != HN_OK) return rc;
+      if ((rc = launch_gemm_ex(e, s, bp.red)) != HN_OK) return rc;
     }
     HN_HIP_CHECK(hipMemsetAsync(bp.dA, 0, (size_t)rows * hp * sizeof(float), s));
     {
       GemmExArgs e = gex(bp.dO, inner, 1, wv, 1, pl.D, bp.dA, hp, rows, pl.D, dh, 0);
       e.batch = h; e.strideA = dh; e.strideB = (long)dh * pl.D; e.strideC = pl.dp;
-      if ((rc = launch_gemm_ex(e, s)) != HN_OK) return rc;
+      if ((rc = launch_gemm_ex(e, s, bp.red)) != HN_OK) return rc;
     }
     if (p->ctx_gamma) {   // dgamma += sum dA * (P z) ; dbeta += sum dA   (over rows and heads)
       if ((rc = launch_head_affine(bp.dA, hp, pl.dp, saved, hp, pl.dp, nullptr, nullptr, 1.0f, h, pl.D, pl.dp, hp, rows, bp.E, s)) != HN_OK) return rc;
-      if (g->ctx_gamma && (rc = launch_colsum(bp.E, pl.dp, (long)rows * h, pl.D, 1.0f, g->ctx_gamma, 1, s)) != HN_OK) return rc;
-      if (g->ctx_beta && (rc = launch_colsum(bp.dA, pl.dp, (long)rows * h, pl.D, 1.0f, g->ctx_beta, 1, s)) != HN_OK) return rc;
+      if (g->ctx_gamma && (rc = launch_colsum(bp.E, pl.dp, (long)rows * h, pl.D, 1.0f, g->ctx_gamma, 1, s, bp.red)) != HN_OK) return rc;
+      if (g->ctx_beta && (rc = launch_colsum(bp.dA, pl.dp, (long)rows * h, pl.D, 1.0f, g->ctx_beta, 1, s, bp.red)) != HN_OK) return rc;
     }
     // d(P z) = dA * gamma ;  delta = rowsum(d(P z) * P z)
     if ((rc = launch_head_affine(bp.dA, hp, pl.dp, nullptr, 0, 0, p->ctx_gamma, nullptr, 1.0f, h, pl.D, pl.dp, hp, rows, bp.dOp, s)) != HN_OK) return rc;
@@ -399,23 +403,23 @@ static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float
     {   // T = Qraw_h W_k,h   (Qraw = x_hat W_q^T lives in pl.q after attn_prepare)
       GemmExArgs e = gex(pl.q, inner, 1, wk, 1, pl.D, bp.T, hp, rows, pl.D, dh, 0);
       e.batch = h; e.strideA = dh; e.strideB = (long)dh * pl.D; e.strideC = pl.dp;
-      if ((rc = launch_gemm_ex(e, s)) != HN_OK) return rc;
+      if ((rc = launch_gemm_ex(e, s, bp.red)) != HN_OK) return rc;
     }
     if (p->ctx_gamma && g->ctx_gamma) {   // dgamma += 2 scale * sum T * dQacc
       if ((rc = launch_head_affine(bp.T, hp, pl.dp, bp.E, hp, pl.dp, nullptr, nullptr, two_scale, h, pl.D, pl.dp, hp, rows, bp.dT, s)) != HN_OK) return rc;
-      if ((rc = launch_colsum(bp.dT, pl.dp, (long)rows * h, pl.D, 1.0f, g->ctx_gamma, 1, s)) != HN_OK) return rc;
+      if ((rc = launch_colsum(bp.dT, pl.dp, (long)rows * h, pl.D, 1.0f, g->ctx_gamma, 1, s, bp.red)) != HN_OK) return rc;
     }
     // dT = 2 scale * gamma * dQacc
     if ((rc = launch_head_affine(bp.E, hp, pl.dp, nullptr, 0, 0, p->ctx_gamma, nullptr, two_scale, h, pl.D, pl.dp, hp, rows, bp.dT, s)) != HN_OK) return rc;
     if (dwk) {   // dW_k,h += Qraw_h^T dT_h
       GemmExArgs e = gex(pl.q, 1, inner, bp.dT, 1, hp, dwk, pl.D, dh, pl.D, rows, 1);
       e.batch = h; e.strideA = dh; e.strideB = pl.dp; e.strideC = (long)dh * pl.D;
-      if ((rc = launch_gemm_ex(e, s)) != HN_OK) return rc;
+      if ((rc = launch_gemm_ex(e, s, bp.red)) != HN_OK) return rc;
     }
     {   // dQ_h = dT_h W_k,h^T
       GemmExArgs e = gex(bp.dT, hp, 1, wk, pl.D, 1, bp.dQ, inner, rows, dh, pl.D, 0);
       e.batch = h; e.strideA = pl.dp; e.strideB = (long)dh * pl.D; e.strideC = dh;
-      if ((rc = launch_gemm_ex(e, s)) != HN_OK) return rc;
+      if ((rc = launch_gemm_ex(e, s, bp.red)) != HN_OK) return rc;
     }
   } else {
     const int qp = h * pl.dhp;
@@ -429,31 +433,31 @@ static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float
     const long krows = (long)b * pl.N;
     if (has_ctx) {   // gradients of to_kv and of the context LayerNorm affine from G = dKV^T z and colsum(dKV)
       GemmExArgs e = gex(bp.dKV, 1, 2 * inner, ctx, 1, ld_ctx, bp.G, pl.D, 2 * inner, pl.D, (int)krows, 0);
-      if ((rc = launch_gemm_ex(e, s)) != HN_OK) return rc;
-      if ((rc = launch_colsum(bp.dKV, 2 * inner, krows, 2 * inner, 1.0f, bp.cs, 0, s)) != HN_OK) return rc;
+      if ((rc = launch_gemm_ex(e, s, bp.red)) != HN_OK) return rc;
+      if ((rc = launch_colsum(bp.dKV, 2 * inner, krows, 2 * inner, 1.0f, bp.cs, 0, s, bp.red)) != HN_OK) return rc;
       if ((rc = launch_kv_weight_grads(bp.G, bp.cs, p->w_kv, p->ctx_gamma, p->ctx_beta, 2 * inner, pl.D, g->w_kv, g->ctx_gamma,
                                        g->ctx_beta, s)) != HN_OK) return rc;
     } else if (g->w_kv) {   // self-attention: K, V come from x_hat
       GemmExArgs e = gex(bp.dKV, 1, 2 * inner, xhat, 1, qd, g->w_kv, qd, 2 * inner, qd, rows, 1);
-      if ((rc = launch_gemm_ex(e, s)) != HN_OK) return rc;
+      if ((rc = launch_gemm_ex(e, s, bp.red)) != HN_OK) return rc;
     }
   }
 
   // ---- query projection: dWq += dQ^T x_hat ; dx_hat = dQ Wq (+ dKV Wkv for self-attention)
   if (g->w_q) {
     GemmExArgs e = gex(bp.dQ, 1, inner, xhat, 1, qd, g->w_q, qd, inner, qd, rows, 1);
-    if ((rc = launch_gemm_ex(e, s)) != HN_OK) return rc;
+    if ((rc = launch_gemm_ex(e, s, bp.red)) != HN_OK) return rc;
   }
   float *dxh = p->norm_w ? bp.dxhat : dx;
   const bool direct_acc = !p->norm_w && residual;     // no LayerNorm: dx = dy + dQ Wq directly
   if (direct_acc && dx != dy && (rc = launch_add_into(dy, dx, (long)rows * qd, 0, s)) != HN_OK) return rc;
   {
     GemmExArgs e = gex(bp.dQ, inner, 1, p->w_q, 1, qd, dxh, qd, rows, qd, inner, direct_acc ? 1 : 0);
-    if ((rc = launch_gemm_ex(e, s)) != HN_OK) return rc;
+    if ((rc = launch_gemm_ex(e, s, bp.red)) != HN_OK) return rc;
   }
   if (!has_ctx) {
     GemmExArgs e = gex(bp.dKV, 2 * inner, 1, p->w_kv, 1, qd, dxh, qd, rows, qd, 2 * inner, 1);
-    if ((rc = launch_gemm_ex(e, s)) != HN_OK) return rc;
+    if ((rc = launch_gemm_ex(e, s, bp.red)) != HN_OK) return rc;
   }
   if (p->norm_w) {
     if (residual) { if (dx != dy && (rc = launch_add_into(dy, dx, (long)rows * qd, 0, s)) != HN_OK) return rc; }
@@ -499,7 +503,7 @@ static int ff_fwd_impl(const hn_ff_params *p, const float *x_in, float *x_out, i
 // ------------------------------------------------------------------------------------------------
 // feed-forward block, backward
 // ------------------------------------------------------------------------------------------------
-struct FFBwdPlan { float *u, *h, *dh, *xhat, *dxhat, *lns; size_t bytes; };
+struct FFBwdPlan { float *u, *h, *dh, *xhat, *dxhat, *lns, *red; size_t bytes; };
 
 static void plan_ff_bwd(const hn_ff_params *p, int rows, void *ws, size_t ws_bytes, FFBwdPlan *pl) {
   Arena ar(ws, ws_bytes);
@@ -510,6 +514,7 @@ static void plan_ff_bwd(const hn_ff_params *p, int rows, void *ws, size_t ws_byt
   pl->xhat = ar.take<float>((size_t)rows * p->dim);
   pl->dxhat = ar.take<float>((size_t)rows * p->dim);
   pl->lns = ar.take<float>(ln_bwd_scratch_floats(rows, p->dim));
+  pl->red = ar.take<float>(reduce_scratch_floats(8L * p->dim * p->dim, 8 * p->dim));
   pl->bytes = ar.off;
 }
 
@@ -546,16 +551,16 @@ static int ff_bwd_impl(const hn_ff_params *p, const float *x_in, const float *dy
     GemmExArgs w = {};
     w.batch = 1; w.alpha = 1.0f; w.accumulate = 1;
     w.A = dy; w.a_rs = 1; w.a_cs = d; w.B = pl.h; w.b_rs = 1; w.b_cs = hid; w.C = g->w2; w.ldc = hid; w.M = d; w.N = hid; w.K = rows;
-    if ((rc = launch_gemm_ex(w, s)) != HN_OK) return rc;
+    if ((rc = launch_gemm_ex(w, s, pl.red)) != HN_OK) return rc;
   }
-  if (g->b2 && (rc = launch_colsum(dy, d, rows, d, 1.0f, g->b2, 1, s)) != HN_OK) return rc;
+  if (g->b2 && (rc = launch_colsum(dy, d, rows, d, 1.0f, g->b2, 1, s, pl.red)) != HN_OK) return rc;
   if (g->w1) {   // dW1 += du^T x_hat
     GemmExArgs w = {};
     w.batch = 1; w.alpha = 1.0f; w.accumulate = 1;
     w.A = pl.u; w.a_rs = 1; w.a_cs = 2 * hid; w.B = xhat; w.b_rs = 1; w.b_cs = d; w.C = g->w1; w.ldc = d; w.M = 2 * hid; w.N = d; w.K = rows;
-    if ((rc = launch_gemm_ex(w, s)) != HN_OK) return rc;
+    if ((rc = launch_gemm_ex(w, s, pl.red)) != HN_OK) return rc;
   }
-  if (g->b1 && (rc = launch_colsum(pl.u, 2 * hid, rows, 2 * hid, 1.0f, g->b1, 1, s)) != HN_OK) return rc;
+  if (g->b1 && (rc = launch_colsum(pl.u, 2 * hid, rows, 2 * hid, 1.0f, g->b1, 1, s, pl.red)) != HN_OK) return rc;
   // dx_hat = du W1      (W1 is (2 hid, d): B(j = k, c = n) = W1[n, k])
   GemmExArgs x = {};
   x.batch = 1; x.alpha = 1.0f;
@@ -944,8 +949,8 @@ size_t hn_fusion_tape_bytes(const hn_model *m, const hn_modality_input *in, int 
 }
 
 int hn_fusion_forward_train(const hn_model *m, const hn_modality_input *in, int b, const uint8_t *mask, int skip_self_on_missing,
-                            int return_embeddings, float *out, void *tape, size_t tape_bytes, void *workspace,
-                            size_t workspace_bytes, void *stream) {
+                            int return_embeddings, float *out, float **attn_stats, float **x_trace, void *tape,
+                            size_t tape_bytes, void *workspace, size_t workspace_bytes, void *stream) {
   hipStream_t s = (hipStream_t)stream;
   HN_REQUIRE(out && tape, HN_E_NULL, "fusion_forward_train: out / tape is NULL");
   FusionPlan fp;
@@ -987,6 +992,14 @@ int hn_fusion_forward_train(const hn_model *m, const hn_modality_input *in, int 
         break;
     }
     if (rc != HN_OK) return rc;
+    if (st.kind == STEP_CROSS_ATTN || st.kind == STEP_SELF_ATTN) {     // optional copies for hn_attn_probs (same slots as hn_fusion_forward)
+      const int slot = st.layer * (M + 1) + (st.kind == STEP_CROSS_ATTN ? st.m : M);
+      const int heads = st.kind == STEP_CROSS_ATTN ? m->cross_attn[st.layer * M + st.m].heads : m->self_attn[st.layer].heads;
+      if (attn_stats && attn_stats[slot])
+        HN_HIP_CHECK(hipMemcpyAsync(attn_stats[slot], T + tp.stats_off[k], (size_t)b * heads * L * 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
+      if (x_trace && x_trace[slot])
+        HN_HIP_CHECK(hipMemcpyAsync(x_trace[slot], xin, (size_t)b * L * d * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
   }
   const float *xf = T + tp.x_off[tp.nsteps];
   if (m->final_classifier_head && !return_embeddings)

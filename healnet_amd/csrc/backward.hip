@@ -24,6 +24,8 @@ __global__ __launch_bounds__(256) void gemm_ex_kernel(GemmExArgs g) {
   const float *__restrict__ A = g.A + (long)z * g.strideA;
   const float *__restrict__ B = g.B + (long)z * g.strideB;
   float *__restrict__ C = g.C + (long)z * g.strideC;
+  // split-k launch: slice z covers contraction indices [z*K, min(k_total, (z+1)*K))
+  const int Kz = g.k_total > 0 ? min(g.K, g.k_total - z * g.K) : g.K;
 
   // loader geometry per operand: lanes run along whichever index is contiguous in memory
   const bool a_c_contig = g.a_cs == 1, b_c_contig = g.b_cs == 1;
@@ -35,8 +37,8 @@ __global__ __launch_bounds__(256) void gemm_ex_kernel(GemmExArgs g) {
       if (c_contig) { c = tid & 31; r = (tid >> 5) + 8 * t; }       // 32 lanes along c, 8 row groups
       else { r = tid & 63; c = (tid >> 6) + 4 * t; }                 // 64 lanes along r, 4 column groups
       const int rr = r0 + r, cc = c0 + c;
-      const float ok = (rr < rmax && cc < g.K) ? 1.0f : 0.0f;
-      const float v = P[(long)min(rr, rmax - 1) * rs + (long)min(cc, g.K - 1) * cs];     // clamped: always valid
+      const float ok = (rr < rmax && cc < Kz) ? 1.0f : 0.0f;
+      const float v = P[(long)min(rr, rmax - 1) * rs + (long)min(cc, Kz - 1) * cs];     // clamped: always valid
       reg[t] = v * ok;
     }
   };
@@ -53,7 +55,7 @@ __global__ __launch_bounds__(256) void gemm_ex_kernel(GemmExArgs g) {
   const int wm = wave >> 1, wn = wave & 1;
   const int frow = lane & 31, fhalf = lane >> 5;
   f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  const int nk = (g.K + XK - 1) / XK;
+  const int nk = (Kz + XK - 1) / XK;
   load_operand(A, g.a_rs, g.a_cs, a_c_contig, i0, g.M, 0, ra);
   load_operand(B, g.b_rs, g.b_cs, b_c_contig, j0, g.N, 0, rb);
   for (int kt = 0; kt < nk; ++kt) {
@@ -90,9 +92,43 @@ __global__ __launch_bounds__(256) void gemm_ex_kernel(GemmExArgs g) {
   }
 }
 
-int launch_gemm_ex(const GemmExArgs &g, hipStream_t s) {
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ part, int nsplit, long mn, int N, float *__restrict__ C,
+                                                            long ldc, int accumulate) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < mn; i += (long)gridDim.x * blockDim.x) {
+    float acc = 0.0f;
+    for (int k = 0; k < nsplit; ++k) acc += part[(long)k * mn + i];
+    float *dst = C + (i / N) * ldc + (i % N);
+    *dst = accumulate ? *dst + acc : acc;
+  }
+}
+
+// Weight-gradient shaped products (small M x N, very long contraction over the b*L or b*N rows) start only a
+// handful of 64x64 tiles; with `scratch` (GEMM_EX_SPLITS * M * N floats) the contraction is cut into GEMM_EX_SPLITS
+// slices that run as extra grid.z entries into scratch and are then summed in fixed order (deterministic).
+int launch_gemm_ex(const GemmExArgs &g, hipStream_t s, float *scratch) {
   HN_REQUIRE(g.A && g.B && g.C, HN_E_NULL, "gemm_ex: NULL operand");
   HN_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.batch > 0, HN_E_SHAPE, "gemm_ex: M=%d N=%d K=%d", g.M, g.N, g.K);
+  const int tiles = ceil_div(g.M, XM) * ceil_div(g.N, XN) * g.batch;
+  if (scratch && g.batch == 1 && g.K >= 2048 && tiles <= 128) {
+    GemmExArgs p = g;
+    const int ksl = ceil_div(ceil_div(g.K, GEMM_EX_SPLITS), XK) * XK;       // slice length, multiple of the k-tile
+    const int nsl = ceil_div(g.K, ksl);
+    p.batch = nsl;
+    p.K = ksl;                                   // the last slice is cut by k_total below
+    p.k_total = g.K;
+    p.strideA = (long)ksl * g.a_cs;
+    p.strideB = (long)ksl * g.b_cs;
+    p.C = scratch; p.ldc = g.N; p.strideC = (long)g.M * g.N; p.accumulate = 0;
+    dim3 grid(ceil_div(g.M, XM), ceil_div(g.N, XN), nsl);
+    hipLaunchKernelGGL(gemm_ex_kernel, grid, dim3(256), 0, s, p);
+    HN_LAUNCH_CHECK("gemm_ex(split-k)");
+    const long mn = (long)g.M * g.N;
+    long blocks = ceil_div_ll(mn, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, scratch, nsl, mn, g.N, g.C, g.ldc, g.accumulate);
+    HN_LAUNCH_CHECK("splitk_reduce");
+    return HN_OK;
+  }
   dim3 grid(ceil_div(g.M, XM), ceil_div(g.N, XN), g.batch);
   HN_REQUIRE(grid.y <= 65535 && grid.z <= 65535, HN_E_UNSUPPORTED, "gemm_ex: grid too large");
   hipLaunchKernelGGL(gemm_ex_kernel, grid, dim3(256), 0, s, g);
@@ -101,28 +137,49 @@ int launch_gemm_ex(const GemmExArgs &g, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// out[n] (+)= scale * sum_m X[m, n]   (fixed summation order: deterministic)
+// out[n] (+)= scale * sum_m X[m, n]   (fixed summation order: deterministic).  Tall inputs are reduced in two
+// stages through `scratch` (COLSUM_CHUNKS x cols floats) so that the row range is spread over the chip.
 // ------------------------------------------------------------------------------------------------
+constexpr int COLSUM_CHUNKS = 128;
+
 __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ X, long ld, long rows, int cols, float scale,
-                                                     float *__restrict__ out, int accumulate) {
+                                                     float *__restrict__ out, long out_pitch, int accumulate) {
   __shared__ float part[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+  const long chunk = (rows + gridDim.y - 1) / gridDim.y;
+  const long r0 = (long)blockIdx.y * chunk, r1 = min(rows, r0 + chunk);
   float s = 0.0f;
   if (c < cols)
-    for (long r = w; r < rows; r += 4) s += X[r * ld + c];
+    for (long r = r0 + w; r < r1; r += 4) s += X[r * ld + c];
   part[w][threadIdx.x & 63] = s;
   __syncthreads();
   if (w == 0 && c < cols) {
     const float v = scale * (part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
-    out[c] = accumulate ? out[c] + v : v;
+    float *dst = out + (long)blockIdx.y * out_pitch + c;
+    *dst = accumulate ? *dst + v : v;
   }
 }
 
-int launch_colsum(const float *X, long ld, long rows, int cols, float scale, float *out, int accumulate, hipStream_t s) {
+int launch_colsum(const float *X, long ld, long rows, int cols, float scale, float *out, int accumulate, hipStream_t s,
+                  float *scratch) {
   HN_REQUIRE(X && out && rows > 0 && cols > 0, HN_E_SHAPE, "colsum: rows=%ld cols=%d", rows, cols);
-  hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(cols, 64)), dim3(256), 0, s, X, ld, rows, cols, scale, out, accumulate);
+  if (scratch && rows >= 4096) {
+    hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(cols, 64), COLSUM_CHUNKS), dim3(256), 0, s, X, ld, rows, cols, 1.0f, scratch,
+                       (long)cols, 0);
+    HN_LAUNCH_CHECK("colsum(stage 1)");
+    hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(cols, 64), 1), dim3(256), 0, s, scratch, (long)cols, (long)COLSUM_CHUNKS, cols,
+                       scale, out, 0L, accumulate);
+    HN_LAUNCH_CHECK("colsum(stage 2)");
+    return HN_OK;
+  }
+  hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(cols, 64), 1), dim3(256), 0, s, X, ld, rows, cols, scale, out, 0L, accumulate);
   HN_LAUNCH_CHECK("colsum");
   return HN_OK;
+}
+
+size_t reduce_scratch_floats(long max_mn, int max_cols) {
+  const size_t a = (size_t)GEMM_EX_SPLITS * max_mn, c = (size_t)COLSUM_CHUNKS * max_cols;
+  return a > c ? a : c;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -147,9 +147,13 @@ struct GemmExArgs {                              // C[i,j] (+)= alpha * sum_c A(
   int M, N, K, batch;
   float alpha;
   int accumulate;
+  int k_total;                                   // internal (split-k launches): full contraction length, 0 otherwise
 };
-int launch_gemm_ex(const GemmExArgs &g, hipStream_t s);
-int launch_colsum(const float *X, long ld, long rows, int cols, float scale, float *out, int accumulate, hipStream_t s);
+constexpr int GEMM_EX_SPLITS = 32;
+int launch_gemm_ex(const GemmExArgs &g, hipStream_t s, float *scratch = nullptr);
+int launch_colsum(const float *X, long ld, long rows, int cols, float scale, float *out, int accumulate, hipStream_t s,
+                  float *scratch = nullptr);
+size_t reduce_scratch_floats(long max_mn, int max_cols);
 size_t ln_bwd_scratch_floats(long rows, int d);
 int launch_ln_bwd(const float *x, const float *dy, const float *gamma, long rows, int d, float *dx, int dx_accumulate,
                   float *dgamma, float *dbeta, float *scratch, hipStream_t s);

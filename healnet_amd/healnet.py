@@ -313,7 +313,7 @@ class _FusionFunction(torch.autograd.Function):
     gradient, as in the reference's training loop (healnet/main.py:432-465)."""
 
     @staticmethod
-    def forward(ctx, module, inputs, held, mask_u8, b, skip_self, embeddings, *params):
+    def forward(ctx, module, inputs, held, mask_u8, b, skip_self, embeddings, stats_ptrs, x_ptrs, *params):
         lib = _capi.lib()
         device = module.latents.device
         model, keep = module._descriptor()
@@ -327,8 +327,8 @@ class _FusionFunction(torch.autograd.Function):
         out = torch.empty((b, module.l_c, module.l_d) if embeddings else (b, module.out_dims), dtype=torch.float32,
                           device=device)
         _capi.check(lib.hn_fusion_forward_train(C.byref(model), inputs, b, _ptr(mask_u8), int(skip_self), int(embeddings),
-                                                out.data_ptr(), tape.data_ptr(), tape.numel(), ws.data_ptr(), ws.numel(),
-                                                _stream_ptr(device)), "hn_fusion_forward_train")
+                                                out.data_ptr(), stats_ptrs, x_ptrs, tape.data_ptr(), tape.numel(), ws.data_ptr(),
+                                                ws.numel(), _stream_ptr(device)), "hn_fusion_forward_train")
         ctx.module, ctx.inputs, ctx.held, ctx.mask_u8 = module, inputs, held, mask_u8
         ctx.b, ctx.skip_self, ctx.embeddings, ctx.tape, ctx.params = b, skip_self, embeddings, tape, params
         return out
@@ -350,7 +350,7 @@ class _FusionFunction(torch.autograd.Function):
         _capi.check(lib.hn_fusion_backward(C.byref(model), ctx.inputs, ctx.b, _ptr(ctx.mask_u8), int(ctx.skip_self),
                                            int(ctx.embeddings), dout.data_ptr(), ctx.tape.data_ptr(), C.byref(grads),
                                            ws.data_ptr(), ws.numel(), _stream_ptr(device)), "hn_fusion_backward")
-        return (None,) * 7 + tuple(gmap.get(id(p)) for p in params)
+        return (None,) * 9 + tuple(gmap.get(id(p)) for p in params)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -537,20 +537,6 @@ class HealNet(nn.Module):
                                          "the mask is applied to every modality's cross-attention (Appendix B-5)")
             mask_u8 = flat.to(device=device, dtype=torch.uint8).contiguous()
 
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            if _profile is not None:
-                raise ValueError("profiling hooks are only available on the inference path")
-            embeddings = return_embeddings or not self.final_classifier_head
-            params = [p for p in self.parameters()]
-            out = _FusionFunction.apply(self, inputs, held, mask_u8, b, bool(verbose), embeddings, *params)
-            if verbose:
-                for layer in range(self.depth):
-                    for i in missing_idx:
-                        print(f"Skipping update in fusion layer {layer + 1} for missing modality {i + 1}")
-            self._last = None
-            self._bind_lazy_probs()
-            return out
-
         lib = _capi.lib()
         model, keep = self._descriptor()
         need = lib.hn_fusion_workspace_bytes(C.byref(model), inputs, b)
@@ -578,9 +564,16 @@ class HealNet(nn.Module):
                     stats_ptrs[layer * (M + 1) + j] = stats_t[layer * (M + 1) + j].data_ptr()
                     x_ptrs[layer * (M + 1) + j] = trace_t[layer * (M + 1) + j].data_ptr()
 
-        _capi.check(lib.hn_fusion_forward(C.byref(model), inputs, b, _ptr(mask_u8), int(bool(verbose)), int(embeddings),
-                                          out.data_ptr(), stats_ptrs, x_ptrs, ws.data_ptr(), ws.numel(), _stream_ptr(device),
-                                          _profile), "hn_fusion_forward")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # autograd path (train or eval mode alike, as in PyTorch): tape-recording forward + hn_fusion_backward
+            if _profile is not None:
+                raise ValueError("profiling hooks are only available under torch.no_grad()")
+            out = _FusionFunction.apply(self, inputs, held, mask_u8, b, bool(verbose), embeddings, stats_ptrs, x_ptrs,
+                                        *list(self.parameters()))
+        else:
+            _capi.check(lib.hn_fusion_forward(C.byref(model), inputs, b, _ptr(mask_u8), int(bool(verbose)), int(embeddings),
+                                              out.data_ptr(), stats_ptrs, x_ptrs, ws.data_ptr(), ws.numel(),
+                                              _stream_ptr(device), _profile), "hn_fusion_forward")
         if verbose:
             for layer in range(self.depth):
                 for i in missing_idx:

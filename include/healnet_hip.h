@@ -230,8 +230,9 @@ typedef struct hn_model_grads {
 
 size_t hn_fusion_tape_bytes(const hn_model *model, const hn_modality_input *inputs, int b, int masked, int skip_self_on_missing);
 int hn_fusion_forward_train(const hn_model *model, const hn_modality_input *inputs, int b, const uint8_t *mask,
-                            int skip_self_on_missing, int return_embeddings, float *out, void *tape, size_t tape_bytes,
-                            void *workspace, size_t workspace_bytes, void *stream);
+                            int skip_self_on_missing, int return_embeddings, float *out, float **attn_stats,
+                            float **x_trace, void *tape, size_t tape_bytes, void *workspace, size_t workspace_bytes,
+                            void *stream);
 size_t hn_fusion_backward_workspace_bytes(const hn_model *model, const hn_modality_input *inputs, int b, int masked);
 int hn_fusion_backward(const hn_model *model, const hn_modality_input *inputs, int b, const uint8_t *mask,
                        int skip_self_on_missing, int return_embeddings, const float *dout, const void *tape,
