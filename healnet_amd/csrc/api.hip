@@ -154,7 +154,8 @@ static int attn_prepare(const hn_attn_params *p, const AttnPlan &pl, const float
 
 static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_out, int residual, const float *ctx,
                          int ld_ctx, int b, int L, int N, int D, const uint8_t *mask, float *stats, void *ws,
-                         size_t ws_bytes, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, float *o_save = nullptr) {
+                         size_t ws_bytes, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, float *o_save = nullptr,
+                         bool ctx_has_ones = false) {
   HN_REQUIRE(x_in && x_out, HN_E_NULL, "attn: x is NULL");
   HN_REQUIRE(p && p->w_q && p->w_kv && p->w_out, HN_E_NULL, "attn: weight pointer is NULL");
   AttnPlan pl;
@@ -190,6 +191,7 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
   AttnCoreArgs core;
   if ((rc = attn_prepare(p, pl, x_in, ctx, ld_ctx, b, L, s, &core)) != HN_OK) return rc;
   core.mask = mask;
+  core.ones_in_mem = (ctx_has_ones && pl.ones) ? 1 : 0;
   const bool direct = !pl.rank_d && pl.nsplit == 1;
   if (direct) { core.Ofinal = pl.obuf; core.ldo = pl.inner; core.dh = pl.dh; core.stats = stats; }
   if (ev0) HN_HIP_CHECK(hipEventRecord(ev0, s));
@@ -590,6 +592,7 @@ struct FusionPlan {
   float *x;
   float *z[16];
   int ldz[16], N[16], D[16];
+  bool ones[16];   // z carries the synthetic ones column (rank-D pitch with a free last column)
   void *op_ws;
   size_t op_ws_bytes, bytes;
   int dominant;   // modality with the most tokens among the present ones
@@ -623,6 +626,7 @@ static int plan_fusion(const hn_model *m, const hn_modality_input *in, int b, vo
     fp->D[i] = m->channel_dims[i] + (m->fourier_encode_data ? axes * (2 * m->num_freq_bands + 1) : 0);
     const hn_attn_params *ap = &m->cross_attn[i];
     fp->ldz[i] = context_pitch(fp->D[i], ap->dim_head);
+    fp->ones[i] = (fp->ldz[i] == 16 || fp->ldz[i] == 32) && fp->D[i] <= fp->ldz[i] - 1;
     fp->z[i] = ar.take<float>((size_t)b * n * fp->ldz[i]);
     if (n > best) { best = n; fp->dominant = i; }
     for (int layer = 0; layer < m->depth; ++layer) {
@@ -900,7 +904,7 @@ int hn_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, con
   for (int i = 0; i < M; ++i) {
     if (!in[i].data) continue;
     if ((rc = launch_encode(in[i].data, b, m->num_spatial_axes[i], in[i].spatial, m->channel_dims[i], m->num_freq_bands,
-                            m->max_freq, m->fourier_encode_data, 1, 1e-5f, fp.z[i], fp.ldz[i], s)) != HN_OK)
+                            m->max_freq, m->fourier_encode_data, 1, 1e-5f, fp.z[i], fp.ldz[i], s, fp.ones[i] ? fp.ldz[i] - 1 : -1)) != HN_OK)
       return rc;
   }
   if ((rc = launch_broadcast_rows(m->latents, fp.x, (long)L * d, b, s)) != HN_OK) return rc;   // :225
@@ -921,7 +925,8 @@ int hn_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, con
           prof->n_recorded++;
         }
         if ((rc = attn_fwd_impl(ap, fp.x, fp.x, 1, fp.z[i], fp.ldz[i], b, L, fp.N[i], fp.D[i], mask,
-                                attn_stats ? attn_stats[slot + i] : nullptr, fp.op_ws, fp.op_ws_bytes, s, e0, e1)) != HN_OK)
+                                attn_stats ? attn_stats[slot + i] : nullptr, fp.op_ws, fp.op_ws_bytes, s, e0, e1, nullptr,
+                                fp.ones[i])) != HN_OK)
           return rc;
         if ((rc = ff_fwd_impl(&m->cross_ff[layer * M + i], fp.x, fp.x, 1, b * L, fp.op_ws, fp.op_ws_bytes, s)) != HN_OK)
           return rc;

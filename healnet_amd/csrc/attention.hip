@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void attn_core_kernel(AttnCoreArgs a, int ngro
   // one 16-token step on the (kf, vf) fragments; prefetches the following tile into (kn, vn)
   auto step = [&](int t0, float4 (&kf)[DT], float (&vf)[DT][4], float4 (&kn)[DT], float (&vn)[DT][4]) {
     if (t0 + 16 < t_end) load_kv(t0 + 16, kn, vn);
-    if (ONES) {
+    if (ONES && !a.ones_in_mem) {      // hn_fusion_forward has K1 write the ones column into z itself
       if (g == 3) kf[DT - 1].w = 1.0f;
       if (j == 15) {
 #pragma unroll
@@ -175,16 +175,17 @@ __global__ __launch_bounds__(256) void attn_core_kernel(AttnCoreArgs a, int ngro
     f32x4 P[NQ];
     if (ONES) {
       // S already holds s - m.  Guard: rescale when some p would exceed 2^threshold (or on the first live tile).
-      float pm = 0.0f;                                  // one running max over all NQ*4 values -> v_max3 chain
+      // The guard tests the SUM of the step's p values (p >= 0, so sum >= max): packed adds cost about half of a
+      // max3 chain, and with an up-to-date reference the sum of 16 values stays <= 16.
+      float ps0 = 0.0f, ps1 = 0.0f;
 #pragma unroll
       for (int i = 0; i < NQ; ++i) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          P[i][r] = fast_exp2(S[i][r]);
-          pm = fmaxf(pm, P[i][r]);
-        }
+        for (int r = 0; r < 4; ++r) P[i][r] = fast_exp2(S[i][r]);
+        ps0 += P[i][0] + P[i][2];
+        ps1 += P[i][1] + P[i][3];
       }
-      const bool need = pm > 256.0f || unset;
+      const bool need = !(ps0 + ps1 <= 256.0f) || unset;
       if (__any(need) && any_live) {
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {

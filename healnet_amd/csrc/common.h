@@ -108,7 +108,7 @@ int launch_gemm(const GemmArgs &g, hipStream_t s);
 // encode
 // ------------------------------------------------------------------------------------------------
 int launch_encode(const float *data, int b, int n_axes, const int *spatial, int C, int F, float max_freq,
-                  int fourier, int normalize, float eps, float *out, int ld_out, hipStream_t s);
+                  int fourier, int normalize, float eps, float *out, int ld_out, hipStream_t s, int ones_col = -1);
 
 // ------------------------------------------------------------------------------------------------
 // attention pieces
@@ -122,6 +122,7 @@ struct AttnCoreArgs {
   int b, h, Lq, Lp, N, dp;                      // Lq valid query rows, Lp = Lq rounded up to 16, dp in {16,32,64,128}
   int nsplit, chunk;                            // tokens per split (multiple of 16)
   int ones_col;                                 // rank-D binding with D <= dp-1: synthetic ones column dp-1 (see attention.hip)
+  int ones_in_mem;                              // ... and the context rows already carry 1.0 there (written by K1)
   float *Ofinal; int ldo, dh; float *stats;     // nsplit == 1 only: write the normalised O (b*Lq, ldo) + stats directly (no merge kernel)
 };
 int launch_attn_core(const AttnCoreArgs &a, hipStream_t s);

@@ -23,6 +23,7 @@ struct EncGeom {
   float max_freq;
   int fourier, normalize;
   float eps;
+  int ones_col;   // >= 0: this padding column is written as 1.0 (the attention core's synthetic ones column)
 };
 
 // torch.linspace(-1, 1, S)[i] in fp32 (ATen's symmetric formulation: ascending from the start for the
@@ -99,6 +100,9 @@ __global__ __launch_bounds__(256) void encode_token_kernel(const float *__restri
 #pragma unroll
     for (int c = 0; c < kMaxNarrow; ++c) v[c] = (c < g.D) ? (v[c] - mean) * rstd : 0.0f;
   }
+#pragma unroll
+  for (int c = 0; c < kMaxNarrow; ++c)
+    if (c == g.ones_col) v[c] = 1.0f;
   float *dst = out + gid * (long)g.ld_out;
   if ((g.ld_out & 3) == 0) {
 #pragma unroll
@@ -144,11 +148,11 @@ __global__ __launch_bounds__(256) void encode_wave_kernel(const float *__restric
     float p = pos_feature(j, idx, g);
     dst[g.C + j] = g.normalize ? (p - mean) * rstd : p;
   }
-  for (int c = g.D + lane; c < g.ld_out; c += 64) dst[c] = 0.0f;
+  for (int c = g.D + lane; c < g.ld_out; c += 64) dst[c] = c == g.ones_col ? 1.0f : 0.0f;
 }
 
 int launch_encode(const float *data, int b, int n_axes, const int *spatial, int C, int F, float max_freq,
-                  int fourier, int normalize, float eps, float *out, int ld_out, hipStream_t s) {
+                  int fourier, int normalize, float eps, float *out, int ld_out, hipStream_t s, int ones_col) {
   HN_REQUIRE(data && out && spatial, HN_E_NULL, "encode: NULL pointer");
   HN_REQUIRE(b > 0 && C > 0 && n_axes >= 1 && n_axes <= HN_MAX_AXES, HN_E_SHAPE,
              "encode: b=%d C=%d n_axes=%d (1..%d axes supported)", b, C, n_axes, HN_MAX_AXES);
@@ -169,6 +173,7 @@ int launch_encode(const float *data, int b, int n_axes, const int *spatial, int 
   g.fourier = fourier;
   g.normalize = normalize;
   g.eps = eps;
+  g.ones_col = (ones_col >= g.D && ones_col < ld_out) ? ones_col : -1;
   HN_REQUIRE(ld_out >= g.D, HN_E_SHAPE, "encode: ld_out=%d < D=%d", ld_out, g.D);
   long total = (long)b * g.N;
   if (g.D <= kMaxNarrow && ld_out <= kMaxNarrow) {
