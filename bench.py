@@ -39,9 +39,11 @@ TAB = (1, 2000)
 # algorithmic FLOPs per sample of the whole forward and of one image cross-attention's
 # QK^T + PV (reference formulation), and what the rank-D reassociated kernel actually executes.
 FLOPS_FORWARD_PER_SAMPLE = 45.68e9
-L_C, HEADS, DIM_HEAD, N_IMG, DP = 128, 8, 64, 224 * 224, 16
+L_C, HEADS, DIM_HEAD, N_IMG, DP, QK_DIM = 128, 8, 64, 224 * 224, 16, 12
 ALGO_FLOPS_CORE_PER_SAMPLE = 4.0 * L_C * N_IMG * DIM_HEAD * HEADS        # 13.15 GF
-EXEC_FLOPS_CORE_PER_SAMPLE = 4.0 * L_C * N_IMG * DP * HEADS              # 3.29 GF (contraction dim 16, not 64)
+# executed: QK^T over the 12 kept channels of the packed context (3 MFMA k-steps), P V over 16 columns (12 channels,
+# the softmax-denominator ones column, 3 idle) -> 2.88 GF (contraction dims 12 / 16, not 64 / 64)
+EXEC_FLOPS_CORE_PER_SAMPLE = 2.0 * L_C * N_IMG * (QK_DIM + DP) * HEADS
 PEAK_FP32_MFMA_TFLOPS = 157.3                                            # MI355X_MICROARCH.md chip table
 
 
@@ -226,7 +228,7 @@ def main():
                        "no data-path collective)", "seed": "model torch.manual_seed(0); inputs 1234+rank"},
             "forward_tflops_algorithmic": round(FLOPS_FORWARD_PER_SAMPLE * total_samples / elapsed / 1e12, 2),
             "roofline": {
-                "kernel": "hn::attn_core_kernel<1,4> (split-KV attention core of the image cross-attention, N=50176)",
+                "kernel": "hn::attn_core_kernel<1,4,true,3> (split-KV attention core of the image cross-attention, N=50176)",
                 "bound": "mfma",
                 "achieved": None if exec_tf is None else round(exec_tf, 2),
                 "peak": PEAK_FP32_MFMA_TFLOPS,
@@ -241,8 +243,9 @@ def main():
                 "flops_per_launch_executed": EXEC_FLOPS_CORE_PER_SAMPLE * b,
                 "flops_per_launch_algorithmic": ALGO_FLOPS_CORE_PER_SAMPLE * b,
                 "effective_algorithmic_tflops": None if algo_tf is None else round(algo_tf, 2),
-                "note": "achieved/frac use EXECUTED fp32-MFMA FLOPs (rank-D reassociation: contraction dim 16 instead of "
-                        "dim_head 64, 4x fewer than the reference formulation, SURVEY.md §8d); effective_algorithmic_tflops "
+                "note": "achieved/frac use EXECUTED fp32-MFMA FLOPs (rank-D reassociation + packed context: QK^T contracts 12 "
+                        "channels and P V 16 columns instead of dim_head 64 each, 4.6x fewer than the reference formulation, "
+                        "SURVEY.md §8d); effective_algorithmic_tflops "
                         "prices the same launch at the reference formulation's 13.15 GF/sample",
             },
         }

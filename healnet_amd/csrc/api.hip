@@ -103,7 +103,7 @@ static GemmArgs gemm_defaults() {
 // Steps shared by hn_attn_fwd and hn_attn_probs: the scaled query operand of the attention core and
 // (explicit path) the projected keys / values.
 static int attn_prepare(const hn_attn_params *p, const AttnPlan &pl, const float *x_in, const float *ctx, int ld_ctx,
-                        int b, int L, hipStream_t s, AttnCoreArgs *core) {
+                        int b, int L, hipStream_t s, AttnCoreArgs *core, int pack_ks = 0) {
   const int rows = b * L;
   GemmArgs gq = gemm_defaults();
   gq.A = x_in; gq.lda = p->query_dim;
@@ -119,7 +119,8 @@ static int attn_prepare(const hn_attn_params *p, const AttnPlan &pl, const float
     gq.C = pl.q; gq.ldc = pl.inner;
     if ((rc = launch_gemm(gq, s)) != HN_OK) return rc;
     if ((rc = launch_qfold(pl.q, pl.inner, p->w_kv, pl.D, p->ctx_gamma, pl.cscale, pl.qf, b, p->heads, L, pl.Lp, pl.dh,
-                           pl.dp, s)) != HN_OK) return rc;
+                           pl.dp, s, pack_ks)) != HN_OK) return rc;
+    core->qk_steps = pack_ks;
     core->Q = pl.qf; core->q_b = (long)p->heads * pl.Lp * pl.dp; core->q_h = (long)pl.Lp * pl.dp; core->ldq = pl.dp;
     core->Kp = ctx; core->k_b = (long)pl.N * ld_ctx; core->k_h = 0; core->ldk = ld_ctx;
     core->Vp = ctx; core->v_b = core->k_b; core->v_h = 0; core->ldv = ld_ctx;
@@ -155,7 +156,7 @@ static int attn_prepare(const hn_attn_params *p, const AttnPlan &pl, const float
 static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_out, int residual, const float *ctx,
                          int ld_ctx, int b, int L, int N, int D, const uint8_t *mask, float *stats, void *ws,
                          size_t ws_bytes, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, float *o_save = nullptr,
-                         bool ctx_has_ones = false) {
+                         bool ctx_has_ones = false, int ctx_pack_ks = 0) {
   HN_REQUIRE(x_in && x_out, HN_E_NULL, "attn: x is NULL");
   HN_REQUIRE(p && p->w_q && p->w_kv && p->w_out, HN_E_NULL, "attn: weight pointer is NULL");
   AttnPlan pl;
@@ -189,7 +190,8 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
   }
 
   AttnCoreArgs core;
-  if ((rc = attn_prepare(p, pl, x_in, ctx, ld_ctx, b, L, s, &core)) != HN_OK) return rc;
+  const int pack_ks = (pl.rank_d && pl.ones && ctx_has_ones && p->ctx_gamma) ? ctx_pack_ks : 0;
+  if ((rc = attn_prepare(p, pl, x_in, ctx, ld_ctx, b, L, s, &core, pack_ks)) != HN_OK) return rc;
   core.mask = mask;
   core.ones_in_mem = (ctx_has_ones && pl.ones) ? 1 : 0;
   const bool direct = !pl.rank_d && pl.nsplit == 1;
@@ -199,7 +201,7 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
   if (ev1) HN_HIP_CHECK(hipEventRecord(ev1, s));
   if (pl.rank_d) {
     rc = launch_merge_vproj(pl.opart, pl.mpart, pl.lpart, pl.nsplit, b, p->heads, L, pl.Lp, pl.dp, pl.D, p->ctx_gamma,
-                            p->ctx_beta, p->w_kv + (long)pl.inner * pl.D, pl.dh, pl.obuf, pl.inner, stats, o_save, s);
+                            p->ctx_beta, p->w_kv + (long)pl.inner * pl.D, pl.dh, pl.obuf, pl.inner, stats, o_save, s, pack_ks);
   } else if (!direct) {
     rc = launch_merge_explicit(pl.opart, pl.mpart, pl.lpart, pl.nsplit, b, p->heads, L, pl.Lp, pl.dp, pl.dh, pl.obuf,
                                pl.inner, stats, s);
@@ -593,6 +595,7 @@ struct FusionPlan {
   float *z[16];
   int ldz[16], N[16], D[16];
   bool ones[16];   // z carries the synthetic ones column (rank-D pitch with a free last column)
+  int pack[16];    // ... and uses the packed channel layout with this many QK^T k-steps (0 = natural)
   void *op_ws;
   size_t op_ws_bytes, bytes;
   int dominant;   // modality with the most tokens among the present ones
@@ -627,6 +630,7 @@ static int plan_fusion(const hn_model *m, const hn_modality_input *in, int b, vo
     const hn_attn_params *ap = &m->cross_attn[i];
     fp->ldz[i] = context_pitch(fp->D[i], ap->dim_head);
     fp->ones[i] = (fp->ldz[i] == 16 || fp->ldz[i] == 32) && fp->D[i] <= fp->ldz[i] - 1;
+    fp->pack[i] = fp->ones[i] ? packed_steps(fp->D[i], fp->ldz[i]) : 0;
     fp->z[i] = ar.take<float>((size_t)b * n * fp->ldz[i]);
     if (n > best) { best = n; fp->dominant = i; }
     for (int layer = 0; layer < m->depth; ++layer) {
@@ -904,7 +908,8 @@ int hn_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, con
   for (int i = 0; i < M; ++i) {
     if (!in[i].data) continue;
     if ((rc = launch_encode(in[i].data, b, m->num_spatial_axes[i], in[i].spatial, m->channel_dims[i], m->num_freq_bands,
-                            m->max_freq, m->fourier_encode_data, 1, 1e-5f, fp.z[i], fp.ldz[i], s, fp.ones[i] ? fp.ldz[i] - 1 : -1)) != HN_OK)
+                            m->max_freq, m->fourier_encode_data, 1, 1e-5f, fp.z[i], fp.ldz[i], s, fp.ones[i] ? fp.ldz[i] - 1 : -1,
+                            fp.pack[i])) != HN_OK)
       return rc;
   }
   if ((rc = launch_broadcast_rows(m->latents, fp.x, (long)L * d, b, s)) != HN_OK) return rc;   // :225
@@ -926,7 +931,7 @@ int hn_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, con
         }
         if ((rc = attn_fwd_impl(ap, fp.x, fp.x, 1, fp.z[i], fp.ldz[i], b, L, fp.N[i], fp.D[i], mask,
                                 attn_stats ? attn_stats[slot + i] : nullptr, fp.op_ws, fp.op_ws_bytes, s, e0, e1, nullptr,
-                                fp.ones[i])) != HN_OK)
+                                fp.ones[i], fp.pack[i])) != HN_OK)
           return rc;
         if ((rc = ff_fwd_impl(&m->cross_ff[layer * M + i], fp.x, fp.x, 1, b * L, fp.op_ws, fp.op_ws_bytes, s)) != HN_OK)
           return rc;

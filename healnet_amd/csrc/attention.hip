@@ -42,8 +42,9 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 
 // ONES (rank-D binding only; requires D <= DP - 1): column DP-1 of the shared context row is a synthetic
 // ones column injected in registers (memory keeps its zero padding):
-//   * QK^T: the K fragment carries 1 there and the Q fragment carries -m (the running reference max of
-//     its query row), so the MFMA chain itself delivers s - m: no per-score subtraction on the VALU;
+//   * QK^T: the first MFMA of the chain takes -m (the running reference max of its query row, replicated in a
+//     persistent register quad that only changes on a rescale) as its C operand, so the chain itself delivers
+//     s - m: no per-score subtraction on the VALU;
 //   * P V : the V fragment carries 1 there, so accumulator column DP-1 is sum_t p = the softmax
 //     denominator: no per-score addition on the VALU, and it is rescaled together with O.
 // What is left per score is one v_exp_f32 and 3/4 of a max (overflow guard on p).  This matters more than
@@ -52,7 +53,10 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 // wave (software pipelining QK^T(t+1) under softmax(t): tried, 6 % slower) does not help -- the fp32 MFMA
 // runs at exactly the fp32 vector rate and evidently competes with VALU work for the SIMD's fp32 lanes, so
 // every VALU op removed from the loop is MFMA time gained.
-template <int DT, int NQ, bool ONES>
+// KS = number of QK^T k-steps (4 per 16-column block); < 4*DT only with the packed context layout (common.h).
+__device__ __forceinline__ float f4c(const float4 &v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); }
+
+template <int DT, int NQ, bool ONES, int KS = 4 * DT>
 __global__ __launch_bounds__(256) void attn_core_kernel(AttnCoreArgs a, int ngroups, int gy, int waves_per_block) {
   constexpr int DP = 16 * DT;
   const int L = a.Lq;
@@ -82,13 +86,14 @@ __global__ __launch_bounds__(256) void attn_core_kernel(AttnCoreArgs a, int ngro
       qf[i][s] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (row < L) qf[i][s] = *(const float4 *)(qbase + (long)row * a.ldq + 16 * s + 4 * g);
     }
-    if (ONES && g == 3) qf[i][DT - 1].w = 0.0f;       // -m with m = 0
   }
 
   f32x4 O[NQ][DT];
+  f32x4 negm[NQ];            // ONES: -m replicated, the C operand of the first QK^T MFMA (delivers s - m for free)
   float m[NQ], l[NQ];
 #pragma unroll
   for (int i = 0; i < NQ; ++i) {
+    negm[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     m[i] = ONES ? 0.0f : kNegBig;
     l[i] = 0.0f;
 #pragma unroll
@@ -138,20 +143,14 @@ __global__ __launch_bounds__(256) void attn_core_kernel(AttnCoreArgs a, int ngro
       }
     }
 
-    // ---- S^T tile = K Q^T  (DT*4 chained MFMAs per query tile, NQ independent chains)
+    // ---- S^T tile = K Q^T  (KS chained MFMAs per query tile, NQ independent chains; C operand = -m with ONES)
     f32x4 S[NQ];
 #pragma unroll
-    for (int i = 0; i < NQ; ++i) S[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int st = 0; st < KS; ++st) {
 #pragma unroll
-    for (int s = 0; s < DT; ++s) {
-#pragma unroll
-      for (int i = 0; i < NQ; ++i) S[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].x, qf[i][s].x, S[i], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < NQ; ++i) S[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].y, qf[i][s].y, S[i], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < NQ; ++i) S[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].z, qf[i][s].z, S[i], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < NQ; ++i) S[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].w, qf[i][s].w, S[i], 0, 0, 0);
+      for (int i = 0; i < NQ; ++i)
+        S[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(kf[st >> 2], st & 3), f4c(qf[i][st >> 2], st & 3),
+                                                    st == 0 ? (ONES ? negm[i] : (f32x4){0.f, 0.f, 0.f, 0.f}) : S[i], 0, 0, 0);
     }
 
     // ---- mask / ragged tail: lane (g, j) holds tokens t0 + 4 g + r
@@ -203,7 +202,7 @@ __global__ __launch_bounds__(256) void attn_core_kernel(AttnCoreArgs a, int ngro
             for (int d = 0; d < DT; ++d) O[i][d][r] *= ar;
             P[i][r] = fast_exp2(S[i][r] - delta);
           }
-          if (g == 3) qf[i][DT - 1].w = -m[i];
+          negm[i] = (f32x4){-m[i], -m[i], -m[i], -m[i]};
         }
         unset = false;
       }
@@ -365,22 +364,34 @@ int launch_attn_core(const AttnCoreArgs &a, hipStream_t s) {
   const long blocks = (long)a.nsplit * gy * a.b * a.h;
   HN_REQUIRE(blocks < (1L << 31), HN_E_UNSUPPORTED, "attn_core: grid too large");
   dim3 grid((unsigned)blocks), block(64 * wpb);
-  switch (dt) {
-    case 1:
-      if (a.ones_col && nq == 8) hipLaunchKernelGGL((attn_core_kernel<1, 8, true>), grid, block, 0, s, a, ngroups, gy, wpb);
-      else if (a.ones_col && nq == 2) hipLaunchKernelGGL((attn_core_kernel<1, 2, true>), grid, block, 0, s, a, ngroups, gy, wpb);
-      else if (a.ones_col) hipLaunchKernelGGL((attn_core_kernel<1, 4, true>), grid, block, 0, s, a, ngroups, gy, wpb);
-      else if (nq == 8) hipLaunchKernelGGL((attn_core_kernel<1, 8, false>), grid, block, 0, s, a, ngroups, gy, wpb);
-      else if (nq == 2) hipLaunchKernelGGL((attn_core_kernel<1, 2, false>), grid, block, 0, s, a, ngroups, gy, wpb);
-      else hipLaunchKernelGGL((attn_core_kernel<1, 4, false>), grid, block, 0, s, a, ngroups, gy, wpb);
-      break;
-    case 2:
-      if (a.ones_col) hipLaunchKernelGGL((attn_core_kernel<2, 2, true>), grid, block, 0, s, a, ngroups, gy, wpb);
-      else hipLaunchKernelGGL((attn_core_kernel<2, 2, false>), grid, block, 0, s, a, ngroups, gy, wpb);
-      break;
-    case 4: hipLaunchKernelGGL((attn_core_kernel<4, 2, false>), grid, block, 0, s, a, ngroups, gy, wpb); break;
-    default: hipLaunchKernelGGL((attn_core_kernel<8, 1, false>), grid, block, 0, s, a, ngroups, gy, wpb); break;
+  const int ks = a.qk_steps > 0 ? a.qk_steps : 4 * dt;
+  HN_REQUIRE(ks >= 1 && ks <= 4 * dt && (ks == 4 * dt || (a.ones_col && a.ones_in_mem)), HN_E_SHAPE, "attn_core: qk_steps=%d", a.qk_steps);
+#define HN_CORE(DT_, NQ_, ONES_, KS_) hipLaunchKernelGGL((attn_core_kernel<DT_, NQ_, ONES_, KS_>), grid, block, 0, s, a, ngroups, gy, wpb)
+  if (dt == 1 && a.ones_col) {
+    if (nq == 8) HN_CORE(1, 8, true, 4);
+    else if (nq == 2) HN_CORE(1, 2, true, 4);
+    else if (ks == 1) HN_CORE(1, 4, true, 1);
+    else if (ks == 2) HN_CORE(1, 4, true, 2);
+    else if (ks == 3) HN_CORE(1, 4, true, 3);
+    else HN_CORE(1, 4, true, 4);
+  } else if (dt == 1) {
+    if (nq == 8) HN_CORE(1, 8, false, 4);
+    else if (nq == 2) HN_CORE(1, 2, false, 4);
+    else HN_CORE(1, 4, false, 4);
+  } else if (dt == 2 && a.ones_col) {
+    if (ks == 4) HN_CORE(2, 2, true, 4);
+    else if (ks == 5) HN_CORE(2, 2, true, 5);
+    else if (ks == 6) HN_CORE(2, 2, true, 6);
+    else if (ks == 7) HN_CORE(2, 2, true, 7);
+    else HN_CORE(2, 2, true, 8);
+  } else if (dt == 2) {
+    HN_CORE(2, 2, false, 8);
+  } else if (dt == 4) {
+    HN_CORE(4, 2, false, 16);
+  } else {
+    HN_CORE(8, 1, false, 32);
   }
+#undef HN_CORE
   HN_LAUNCH_CHECK("attn_core");
   return HN_OK;
 }
@@ -392,19 +403,30 @@ int launch_attn_core(const AttnCoreArgs &a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void qfold_kernel(const float *__restrict__ Q, int ldq_row, const float *__restrict__ w_k,
                                                     int D, const float *__restrict__ gamma, float cscale,
-                                                    float *__restrict__ Qf, int h, int L, int Lp, int dh, int dp) {
+                                                    float *__restrict__ Qf, int h, int L, int Lp, int dh, int dp, int pack_ks) {
   extern __shared__ float wk[];  // [dh][dp]
   const int bh = blockIdx.x, bi = bh / h, hi = bh % h;
   for (int idx = threadIdx.x; idx < dh * dp; idx += blockDim.x) {
     const int e = idx / dp, d = idx % dp;
-    wk[idx] = d < D ? w_k[(long)(hi * dh + e) * D + d] * (gamma ? gamma[d] : 1.0f) * cscale : 0.0f;
+    const float *wr = w_k + (long)(hi * dh + e) * D;
+    float w = 0.0f;
+    if (pack_ks == 0) {
+      if (d < D) w = wr[d] * (gamma ? gamma[d] : 1.0f);
+    } else {
+      // packed layout: column d holds kept channel c with weight (gamma_c W_c - gamma_{D-1} W_{D-1}): the context
+      // rows sum to zero, so the last channel's score contribution moves onto the others
+      const int c = packed_chan(d, pack_ks);
+      if (c >= 0 && c < D - 1) w = wr[c] * (gamma ? gamma[c] : 1.0f) - wr[D - 1] * (gamma ? gamma[D - 1] : 1.0f);
+    }
+    wk[idx] = w * cscale;
   }
   __syncthreads();
   float *dst = Qf + (long)bh * Lp * dp;
+  const int dlim = pack_ks ? dp : D;
   for (int idx = threadIdx.x; idx < Lp * dp; idx += blockDim.x) {
     const int q = idx / dp, d = idx % dp;
     float acc = 0.0f;
-    if (q < L && d < D) {
+    if (q < L && d < dlim) {
       const float *qr = Q + ((long)bi * L + q) * ldq_row + hi * dh;
       for (int e = 0; e < dh; ++e) acc = fmaf(qr[e], wk[e * dp + d], acc);
     }
@@ -413,9 +435,9 @@ __global__ __launch_bounds__(256) void qfold_kernel(const float *__restrict__ Q,
 }
 
 int launch_qfold(const float *Q, int ldq_row, const float *w_k, int D, const float *gamma, float cscale, float *Qf,
-                 int b, int h, int L, int Lp, int dh, int dp, hipStream_t s) {
+                 int b, int h, int L, int Lp, int dh, int dp, hipStream_t s, int pack_ks) {
   size_t lds = (size_t)dh * dp * sizeof(float);
-  hipLaunchKernelGGL(qfold_kernel, dim3(b * h), dim3(256), lds, s, Q, ldq_row, w_k, D, gamma, cscale, Qf, h, L, Lp, dh, dp);
+  hipLaunchKernelGGL(qfold_kernel, dim3(b * h), dim3(256), lds, s, Q, ldq_row, w_k, D, gamma, cscale, Qf, h, L, Lp, dh, dp, pack_ks);
   HN_LAUNCH_CHECK("qfold");
   return HN_OK;
 }
@@ -446,21 +468,21 @@ __global__ __launch_bounds__(256) void merge_vproj_kernel(const float *__restric
                                                           int dp, int D, const float *__restrict__ gamma,
                                                           const float *__restrict__ beta, const float *__restrict__ w_v,
                                                           int dh, float *__restrict__ O, int ldo, float *__restrict__ stats,
-                                                          float *__restrict__ oprime_save) {
+                                                          float *__restrict__ oprime_save, int pack_ks) {
   extern __shared__ float sm[];
   float *oh = sm;                        // [MERGE_ROWS][dp + 1]
-  float *wv = sm + MERGE_ROWS * (dp + 1);  // [dh][D + 1]
+  float *wv = sm + MERGE_ROWS * (dp + 1);  // [dh][dp + 1]: gamma folded in; [dp] = the beta term
   const int bh = blockIdx.x, bi = bh / h, hi = bh % h;
   const int q0 = blockIdx.y * MERGE_ROWS;
   const long pbase = (long)bh * nsplit * Lp;
+  const int dlim = pack_ks ? dp : D;
   for (int idx = threadIdx.x; idx < MERGE_ROWS * dp; idx += blockDim.x) {
     const int qq = idx / dp, d = idx % dp, q = q0 + qq;
     float v = 0.0f;
-    if (q < L && d < D) {
+    if (q < L && d < dlim) {
       float M, Ls;
       v = merged_value(Opart, Mpart, Lpart, pbase, nsplit, Lp, dp, q, d, &M, &Ls);
       if (oprime_save) oprime_save[((long)bi * L + q) * (h * dp) + hi * dp + d] = v;      // training: normalised P z
-      v = v * (gamma ? gamma[d] : 1.0f) + (beta ? beta[d] : 0.0f);
       if (stats && d == 0) {
         stats[((long)bh * L + q) * 2 + 0] = M;
         stats[((long)bh * L + q) * 2 + 1] = Ls;
@@ -468,26 +490,38 @@ __global__ __launch_bounds__(256) void merge_vproj_kernel(const float *__restric
     }
     oh[qq * (dp + 1) + d] = v;
   }
-  for (int idx = threadIdx.x; idx < dh * D; idx += blockDim.x) {
-    const int e = idx / D, d = idx % D;
-    wv[e * (D + 1) + d] = w_v[(long)(hi * dh + e) * D + d];
+  for (int idx = threadIdx.x; idx < dh * (dp + 1); idx += blockDim.x) {
+    const int e = idx / (dp + 1), d = idx % (dp + 1);
+    const float *wr = w_v + (long)(hi * dh + e) * D;
+    float w = 0.0f;
+    if (d == dp) {
+      if (beta) for (int c = 0; c < D; ++c) w = fmaf(beta[c], wr[c], w);
+    } else if (pack_ks == 0) {
+      if (d < D) w = wr[d] * (gamma ? gamma[d] : 1.0f);
+    } else {
+      // packed layout: the dropped channel of the averaged row is minus the sum of the kept ones
+      const int c = packed_chan(d, pack_ks);
+      if (c >= 0 && c < D - 1) w = wr[c] * (gamma ? gamma[c] : 1.0f) - wr[D - 1] * (gamma ? gamma[D - 1] : 1.0f);
+    }
+    wv[idx] = w;
   }
   __syncthreads();
   for (int idx = threadIdx.x; idx < MERGE_ROWS * dh; idx += blockDim.x) {
     const int qq = idx / dh, e = idx % dh, q = q0 + qq;
     if (q >= L) continue;
-    float acc = 0.0f;
-    for (int d = 0; d < D; ++d) acc = fmaf(oh[qq * (dp + 1) + d], wv[e * (D + 1) + d], acc);
+    float acc = wv[e * (dp + 1) + dp];
+    for (int d = 0; d < dlim; ++d) acc = fmaf(oh[qq * (dp + 1) + d], wv[e * (dp + 1) + d], acc);
     O[((long)bi * L + q) * ldo + hi * dh + e] = acc;
   }
 }
 
 int launch_merge_vproj(const float *Opart, const float *Mpart, const float *Lpart, int nsplit, int b, int h, int L,
                        int Lp, int dp, int D, const float *gamma, const float *beta, const float *w_v, int dh,
-                       float *O, int ldo, float *stats, float *oprime_save, hipStream_t s) {
-  size_t lds = ((size_t)MERGE_ROWS * (dp + 1) + (size_t)dh * (D + 1)) * sizeof(float);
+                       float *O, int ldo, float *stats, float *oprime_save, hipStream_t s, int pack_ks) {
+  size_t lds = ((size_t)MERGE_ROWS * (dp + 1) + (size_t)dh * (dp + 1)) * sizeof(float);
+  HN_REQUIRE(!(pack_ks && oprime_save), HN_E_SHAPE, "merge_vproj: the training tape keeps the natural channel layout");
   hipLaunchKernelGGL(merge_vproj_kernel, dim3(b * h, ceil_div(L, MERGE_ROWS)), dim3(256), lds, s, Opart, Mpart, Lpart,
-                     nsplit, h, L, Lp, dp, D, gamma, beta, w_v, dh, O, ldo, stats, oprime_save);
+                     nsplit, h, L, Lp, dp, D, gamma, beta, w_v, dh, O, ldo, stats, oprime_save, pack_ks);
   HN_LAUNCH_CHECK("merge_vproj");
   return HN_OK;
 }

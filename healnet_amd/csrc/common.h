@@ -63,6 +63,25 @@ __device__ __forceinline__ float4 buf4s(i32x4 rsrc, int byte_off, int sgpr_off) 
 }
 __host__ __device__ static inline unsigned rsrc_bytes(long rows, long ld, long width) { return (unsigned)(((rows - 1) * ld + width) * 4); }
 
+// Packed context layout of the fused forward (rank-D binding, LayerNorm-ed context).  A normalised row sums to
+// zero, so the last of its D channels is redundant: s = sum_{d<D} q_d z_d = sum_{d<D-1} (q_d - q_{D-1}) z_d.  The
+// D-1 kept channels are stored in the columns that the first `ks` k-steps of the QK^T MFMA chain read
+// (step c of 16-column block s touches columns 16 s + 4 g + c), so the chain runs ks = ceil((D-1)/4) steps
+// instead of dp/4: 3 instead of 4 for an RGB image (D = 13), 5 instead of 8 for a volume (D = 18).
+__host__ __device__ constexpr int packed_slot(int c, int ks) {
+  return ks <= 4 ? (c / ks) * 4 + c % ks
+                 : (c < 16 ? c : 16 + ((c - 16) / (ks - 4)) * 4 + (c - 16) % (ks - 4));
+}
+// inverse: kept channel stored in column `slot`, or -1 for an unused column
+__host__ __device__ constexpr int packed_chan(int slot, int ks) {
+  return ks <= 4 ? ((slot & 3) < ks ? (slot >> 2) * ks + (slot & 3) : -1)
+                 : (slot < 16 ? slot : (((slot - 16) & 3) < ks - 4 ? 16 + ((slot - 16) >> 2) * (ks - 4) + ((slot - 16) & 3) : -1));
+}
+static inline int packed_steps(int D, int dp) {           // 0: keep the natural layout
+  const int ks = (D - 1 + 3) / 4;
+  return (D >= 2 && D <= dp - 1 && ks >= 1 && ks < dp / 4) ? ks : 0;
+}
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline long long ceil_div_ll(long long a, long long b) { return (a + b - 1) / b; }
@@ -108,7 +127,8 @@ int launch_gemm(const GemmArgs &g, hipStream_t s);
 // encode
 // ------------------------------------------------------------------------------------------------
 int launch_encode(const float *data, int b, int n_axes, const int *spatial, int C, int F, float max_freq,
-                  int fourier, int normalize, float eps, float *out, int ld_out, hipStream_t s, int ones_col = -1);
+                  int fourier, int normalize, float eps, float *out, int ld_out, hipStream_t s, int ones_col = -1,
+                  int pack_ks = 0);
 
 // ------------------------------------------------------------------------------------------------
 // attention pieces
@@ -123,16 +143,17 @@ struct AttnCoreArgs {
   int nsplit, chunk;                            // tokens per split (multiple of 16)
   int ones_col;                                 // rank-D binding with D <= dp-1: synthetic ones column dp-1 (see attention.hip)
   int ones_in_mem;                              // ... and the context rows already carry 1.0 there (written by K1)
+  int qk_steps;                                 // packed context layout: QK^T k-steps to run (0 = all dp/4)
   float *Ofinal; int ldo, dh; float *stats;     // nsplit == 1 only: write the normalised O (b*Lq, ldo) + stats directly (no merge kernel)
 };
 int launch_attn_core(const AttnCoreArgs &a, hipStream_t s);
 void attn_core_geometry(int b, int h, int Lp, int N, int dp, int *nsplit, int *chunk);
 
 int launch_qfold(const float *Q, int ldq_row, const float *w_k, int D, const float *gamma, float cscale,
-                 float *Qf, int b, int h, int L, int Lp, int dh, int dp, hipStream_t s);
+                 float *Qf, int b, int h, int L, int Lp, int dh, int dp, hipStream_t s, int pack_ks = 0);
 int launch_merge_vproj(const float *Opart, const float *Mpart, const float *Lpart, int nsplit, int b, int h,
                        int L, int Lp, int dp, int D, const float *gamma, const float *beta, const float *w_v,
-                       int dh, float *O, int ldo, float *stats, float *oprime_save, hipStream_t s);
+                       int dh, float *O, int ldo, float *stats, float *oprime_save, hipStream_t s, int pack_ks = 0);
 int launch_merge_explicit(const float *Opart, const float *Mpart, const float *Lpart, int nsplit, int b, int h,
                           int L, int Lp, int dp, int dh, float *O, int ldo, float *stats, hipStream_t s);
 int launch_probs(const float *Q, long q_b, long q_h, int ldq, int dp, const float *Kp, long k_b, long k_h, int ldk,

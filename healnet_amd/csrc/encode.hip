@@ -69,6 +69,9 @@ __device__ __forceinline__ float pos_feature(int j, const int *idx, const EncGeo
 
 constexpr int kMaxNarrow = 32;
 
+// PACK > 0: packed context layout (common.h): the D-1 kept channels go to packed_slot(c, PACK), the last channel is
+// dropped (it is minus the sum of the others after normalisation).
+template <int PACK>
 __global__ __launch_bounds__(256) void encode_token_kernel(const float *__restrict__ data, float *__restrict__ out,
                                                            EncGeom g, long total) {
   long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -99,6 +102,16 @@ __global__ __launch_bounds__(256) void encode_token_kernel(const float *__restri
     float rstd = 1.0f / sqrtf(sq / (float)g.D + g.eps);
 #pragma unroll
     for (int c = 0; c < kMaxNarrow; ++c) v[c] = (c < g.D) ? (v[c] - mean) * rstd : 0.0f;
+  }
+  if (PACK > 0) {
+    float o[kMaxNarrow];
+#pragma unroll
+    for (int c = 0; c < kMaxNarrow; ++c) o[c] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < (PACK <= 4 ? 4 * PACK : 16 + 4 * (PACK - 4)); ++c)
+      if (c < g.D - 1) o[packed_slot(c, PACK)] = v[c];
+#pragma unroll
+    for (int c = 0; c < kMaxNarrow; ++c) v[c] = o[c];
   }
 #pragma unroll
   for (int c = 0; c < kMaxNarrow; ++c)
@@ -152,7 +165,7 @@ __global__ __launch_bounds__(256) void encode_wave_kernel(const float *__restric
 }
 
 int launch_encode(const float *data, int b, int n_axes, const int *spatial, int C, int F, float max_freq,
-                  int fourier, int normalize, float eps, float *out, int ld_out, hipStream_t s, int ones_col) {
+                  int fourier, int normalize, float eps, float *out, int ld_out, hipStream_t s, int ones_col, int pack_ks) {
   HN_REQUIRE(data && out && spatial, HN_E_NULL, "encode: NULL pointer");
   HN_REQUIRE(b > 0 && C > 0 && n_axes >= 1 && n_axes <= HN_MAX_AXES, HN_E_SHAPE,
              "encode: b=%d C=%d n_axes=%d (1..%d axes supported)", b, C, n_axes, HN_MAX_AXES);
@@ -178,8 +191,19 @@ int launch_encode(const float *data, int b, int n_axes, const int *spatial, int 
   long total = (long)b * g.N;
   if (g.D <= kMaxNarrow && ld_out <= kMaxNarrow) {
     long blocks = ceil_div_ll(total, 256);
-    hipLaunchKernelGGL(encode_token_kernel, dim3((unsigned)blocks), dim3(256), 0, s, data, out, g, total);
+    HN_REQUIRE(pack_ks == 0 || (normalize && pack_ks == packed_steps(g.D, ld_out)), HN_E_SHAPE, "encode: pack_ks=%d", pack_ks);
+    switch (pack_ks) {
+      case 1: hipLaunchKernelGGL(encode_token_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, data, out, g, total); break;
+      case 2: hipLaunchKernelGGL(encode_token_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, data, out, g, total); break;
+      case 3: hipLaunchKernelGGL(encode_token_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, s, data, out, g, total); break;
+      case 4: hipLaunchKernelGGL(encode_token_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, data, out, g, total); break;
+      case 5: hipLaunchKernelGGL(encode_token_kernel<5>, dim3((unsigned)blocks), dim3(256), 0, s, data, out, g, total); break;
+      case 6: hipLaunchKernelGGL(encode_token_kernel<6>, dim3((unsigned)blocks), dim3(256), 0, s, data, out, g, total); break;
+      case 7: hipLaunchKernelGGL(encode_token_kernel<7>, dim3((unsigned)blocks), dim3(256), 0, s, data, out, g, total); break;
+      default: hipLaunchKernelGGL(encode_token_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, s, data, out, g, total); break;
+    }
   } else {
+    HN_REQUIRE(pack_ks == 0, HN_E_SHAPE, "encode: packed layout needs a narrow modality");
     long blocks = ceil_div_ll(total, 4);
     hipLaunchKernelGGL(encode_wave_kernel, dim3((unsigned)blocks), dim3(256), 0, s, data, out, g, total);
   }
