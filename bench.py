@@ -130,6 +130,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH, help="samples per GPU per step (headline config: 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--core-precision", choices=["fp32", "bf16"], default="fp32",
+                    help="development switch: bf16 MFMA in the image cross-attention core (the headline is fp32)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -149,7 +151,7 @@ def main():
     import healnet_amd
     from healnet_amd import _capi
     torch.manual_seed(0)                                   # every replica holds the same seed-0 default-init model
-    model = healnet_amd.HealNet(**KW).eval().to(dev)
+    model = healnet_amd.HealNet(**KW, core_precision=args.core_precision).eval().to(dev)
     model.keep_attention_stats = False
     gen = torch.Generator().manual_seed(1234 + rank)       # SURVEY.md §8d synthetic inputs, U[0,1)
     b = args.batch
@@ -207,7 +209,11 @@ def main():
         total_samples = b * args.steps * world
         core_ms = events.elapsed_ms(recorded)
         avg_core_ms = sum(core_ms) / max(1, len(core_ms))
-        exec_tf = EXEC_FLOPS_CORE_PER_SAMPLE * b / (avg_core_ms * 1e-3) / 1e12 if core_ms else None
+        bf16_core = args.core_precision == "bf16"
+        # bf16 development switch: QK^T contracts 32 channel slots, P V 16 columns, on v_mfma_f32_16x16x32_bf16
+        exec_flops = (2.0 * L_C * N_IMG * (32 + DP) * HEADS) if bf16_core else EXEC_FLOPS_CORE_PER_SAMPLE
+        peak = 2500.0 if bf16_core else PEAK_FP32_MFMA_TFLOPS
+        exec_tf = exec_flops * b / (avg_core_ms * 1e-3) / 1e12 if core_ms else None
         algo_tf = ALGO_FLOPS_CORE_PER_SAMPLE * b / (avg_core_ms * 1e-3) / 1e12 if core_ms else None
         result = {
             "metric": "fusion-forward samples/sec (2-modality, b=32)",
@@ -220,7 +226,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "bf16 attention-core operands, f32 elsewhere (development switch, not the headline)" if bf16_core else "f32",
             "data": "synthetic",
             "config": {"workload": "cfg2: HealNet(2,[2000,3],[1,2],4) default hyper-parameters, forward (logits) on "
                                    "tab (b,1,2000) + img (b,224,224,3) U[0,1) fp32 resident in HBM, eval/no_grad",
@@ -228,19 +234,20 @@ def main():
                        "no data-path collective)", "seed": "model torch.manual_seed(0); inputs 1234+rank"},
             "forward_tflops_algorithmic": round(FLOPS_FORWARD_PER_SAMPLE * total_samples / elapsed / 1e12, 2),
             "roofline": {
-                "kernel": "hn::attn_core_kernel<1,4,true,3> (split-KV attention core of the image cross-attention, N=50176)",
+                "kernel": ("hn::attn_core_bf16_kernel<1,4>" if bf16_core else "hn::attn_core_kernel<1,4,true,3>") +
+                          " (split-KV attention core of the image cross-attention, N=50176)",
                 "bound": "mfma",
                 "achieved": None if exec_tf is None else round(exec_tf, 2),
-                "peak": PEAK_FP32_MFMA_TFLOPS,
+                "peak": peak,
                 "unit": "TFLOP/s",
-                "frac": None if exec_tf is None else round(exec_tf / PEAK_FP32_MFMA_TFLOPS, 4),
-                "traffic": pmc_traffic(),
+                "frac": None if exec_tf is None else round(exec_tf / peak, 4),
+                "traffic": None if bf16_core else pmc_traffic(),
                 "avg_launch_ms": round(avg_core_ms, 4),
                 "timing": "hipEvent pairs on the launch stream around each of the 3 launches per forward, recorded in an "
                           "instrumented replay of the same K steps right after the timed region",
                 "instrumented_ms_per_step": round(elapsed_instrumented / args.steps * 1e3, 4),
                 "launches_timed": len(core_ms),
-                "flops_per_launch_executed": EXEC_FLOPS_CORE_PER_SAMPLE * b,
+                "flops_per_launch_executed": exec_flops * b,
                 "flops_per_launch_algorithmic": ALGO_FLOPS_CORE_PER_SAMPLE * b,
                 "effective_algorithmic_tflops": None if algo_tf is None else round(algo_tf, 2),
                 "note": "achieved/frac use EXECUTED fp32-MFMA FLOPs (rank-D reassociation + packed context: QK^T contracts 12 "

@@ -12,10 +12,14 @@ import sys
 from typing import Optional
 
 HN_MAX_AXES = 4
+HN_ABI_VERSION = 2
+HN_F32, HN_BF16 = 0, 1
+HN_CORE_F32, HN_CORE_BF16 = 0, 1
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhealnet_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["api.hip", "gemm.hip", "attention.hip", "attention_bwd.hip", "encode.hip", "misc.hip", "backward.hip"]
+SOURCES = ["api.hip", "gemm.hip", "attention.hip", "attention_bf16.hip", "attention_bwd.hip", "encode.hip", "misc.hip",
+           "backward.hip"]
 
 c_float_p = C.POINTER(C.c_float)
 
@@ -48,7 +52,7 @@ class FFGrads(C.Structure):
 
 
 class ModalityInput(C.Structure):
-    _fields_ = [("data", C.c_void_p), ("spatial", C.c_int * HN_MAX_AXES)]
+    _fields_ = [("data", C.c_void_p), ("spatial", C.c_int * HN_MAX_AXES), ("dtype", C.c_int)]
 
 
 class Model(C.Structure):
@@ -61,6 +65,7 @@ class Model(C.Structure):
         ("cross_attn", C.POINTER(AttnParams)), ("cross_ff", C.POINTER(FFParams)),
         ("self_attn", C.POINTER(AttnParams)), ("self_ff", C.POINTER(FFParams)),
         ("head_norm_w", C.c_void_p), ("head_norm_b", C.c_void_p), ("head_w", C.c_void_p), ("head_b", C.c_void_p),
+        ("core_precision", C.c_int),
     ]
 
 
@@ -152,7 +157,7 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)   # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if handle.hn_abi_version() != 1:
+        if handle.hn_abi_version() != HN_ABI_VERSION:
             raise RuntimeError("healnet_amd: ABI version mismatch between _capi.py and libhealnet_hip.so")
         _lib = handle
     return _lib

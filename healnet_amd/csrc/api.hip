@@ -30,9 +30,14 @@ static inline int round16(int v) { return (v + 15) / 16 * 16; }
 // ------------------------------------------------------------------------------------------------
 // attention block
 // ------------------------------------------------------------------------------------------------
+struct Bf16Context {              // bf16 images of one modality's normalised context (encode.hip)
+  const uint16_t *zb, *zT;
+  int Np, DV;
+};
+
 struct AttnPlan {
   int heads, dh, inner, dhp, Lp, N, D, dp;
-  bool rank_d, self_attn, ones;
+  bool rank_d, self_attn, ones, bf16core;
   int nsplit, chunk;
   float cscale;
   // workspace carve
@@ -41,7 +46,7 @@ struct AttnPlan {
 };
 
 static int plan_attn(const hn_attn_params *p, bool has_ctx, int ld_ctx, int b, int L, int N, int D, void *ws,
-                     size_t ws_bytes, AttnPlan *pl) {
+                     size_t ws_bytes, AttnPlan *pl, bool bf16core = false) {
   HN_REQUIRE(p, HN_E_NULL, "attn: params NULL");
   HN_REQUIRE(p->heads > 0 && p->dim_head > 0 && p->query_dim > 0 && b > 0 && L > 0, HN_E_SHAPE,
              "attn: heads=%d dim_head=%d query_dim=%d b=%d L=%d", p->heads, p->dim_head, p->query_dim, b, L);
@@ -61,6 +66,11 @@ static int plan_attn(const hn_attn_params *p, bool has_ctx, int ld_ctx, int b, i
   pl->dp = pl->rank_d ? ld_ctx : pl->dhp;
   pl->cscale = 2.0f * (1.0f / sqrtf((float)p->dim_head)) * 1.44269504088896340736f;  // (1/0.5) * dh^-1/2 * log2(e)
   attn_core_geometry(b, p->heads, pl->Lp, pl->N, pl->dp, &pl->nsplit, &pl->chunk);
+  pl->bf16core = bf16core && pl->ones && pl->N > 1;
+  if (pl->bf16core) {                     // the bf16 core walks 32-token steps
+    pl->chunk = (pl->chunk + 31) / 32 * 32;
+    pl->nsplit = (pl->N + pl->chunk - 1) / pl->chunk;
+  }
 
   Arena ar(ws, ws_bytes);
   const size_t rows = (size_t)b * L;
@@ -156,14 +166,14 @@ static int attn_prepare(const hn_attn_params *p, const AttnPlan &pl, const float
 static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_out, int residual, const float *ctx,
                          int ld_ctx, int b, int L, int N, int D, const uint8_t *mask, float *stats, void *ws,
                          size_t ws_bytes, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, float *o_save = nullptr,
-                         bool ctx_has_ones = false, int ctx_pack_ks = 0) {
+                         bool ctx_has_ones = false, int ctx_pack_ks = 0, const Bf16Context *bc = nullptr) {
   HN_REQUIRE(x_in && x_out, HN_E_NULL, "attn: x is NULL");
   HN_REQUIRE(p && p->w_q && p->w_kv && p->w_out, HN_E_NULL, "attn: weight pointer is NULL");
   AttnPlan pl;
-  int rc = plan_attn(p, ctx != nullptr, ld_ctx, b, L, N, D, nullptr, 0, &pl);
+  int rc = plan_attn(p, ctx != nullptr, ld_ctx, b, L, N, D, nullptr, 0, &pl, bc != nullptr);
   if (rc != HN_OK) return rc;
   if ((rc = check_ws(ws, ws_bytes, pl.bytes, "attn")) != HN_OK) return rc;
-  if ((rc = plan_attn(p, ctx != nullptr, ld_ctx, b, L, N, D, ws, ws_bytes, &pl)) != HN_OK) return rc;
+  if ((rc = plan_attn(p, ctx != nullptr, ld_ctx, b, L, N, D, ws, ws_bytes, &pl, bc != nullptr)) != HN_OK) return rc;
 
   // ---- one-token context without a mask (tabular / omic modality): softmax over a single key is exactly 1, so the
   // block reduces to y = LeakyReLU(W_out (W_v c) + b_out) broadcast over the latent rows; Q and K are dead
@@ -187,6 +197,41 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
       if ((rc = launch_fill(stats, 1.0f, (long)b * p->heads * L * 2, s)) != HN_OK) return rc;
     }
     return launch_add_row_broadcast(ybuf, residual ? x_in : nullptr, x_out, b, L, p->query_dim, s);
+  }
+
+  if (pl.bf16core) {
+    // ---- bf16-MFMA core on the bf16 context images (inference only): q = LN(x) W_q^T, fold with W_k, core, merge
+    HN_REQUIRE(bc && bc->zb && bc->zT && bc->DV == pl.dp && o_save == nullptr, HN_E_SHAPE, "attn: bf16 context images missing");
+    GemmArgs gq = gemm_defaults();
+    gq.A = x_in; gq.lda = p->query_dim;
+    gq.W = p->w_q; gq.ldw = p->query_dim;
+    gq.M = b * L; gq.N = pl.inner; gq.K = p->query_dim;
+    if (p->norm_w) { gq.pro = PRO_LAYERNORM; gq.gamma = p->norm_w; gq.beta = p->norm_b; }
+    gq.C = pl.q; gq.ldc = pl.inner;
+    if ((rc = launch_gemm(gq, s)) != HN_OK) return rc;
+    uint16_t *qfb = (uint16_t *)pl.qf;
+    if ((rc = launch_qfold_bf16(pl.q, pl.inner, p->w_kv, pl.D, p->ctx_gamma, pl.cscale, qfb, b, p->heads, L, pl.Lp, pl.dh, s)) != HN_OK)
+      return rc;
+    AttnCoreBf16Args ca;
+    memset(&ca, 0, sizeof(ca));
+    ca.Qf = qfb; ca.zb = bc->zb; ca.zT = bc->zT; ca.mask = mask;
+    ca.Opart = pl.opart; ca.Mpart = pl.mpart; ca.Lpart = pl.lpart;
+    ca.b = b; ca.h = p->heads; ca.Lq = L; ca.Lp = pl.Lp; ca.N = pl.N; ca.Np = bc->Np; ca.DV = bc->DV;
+    ca.nsplit = pl.nsplit; ca.chunk = pl.chunk;
+    if (ev0) HN_HIP_CHECK(hipEventRecord(ev0, s));
+    if ((rc = launch_attn_core_bf16(ca, s)) != HN_OK) return rc;
+    if (ev1) HN_HIP_CHECK(hipEventRecord(ev1, s));
+    if ((rc = launch_merge_vproj(pl.opart, pl.mpart, pl.lpart, pl.nsplit, b, p->heads, L, pl.Lp, pl.dp, pl.D, p->ctx_gamma,
+                                 p->ctx_beta, p->w_kv + (long)pl.inner * pl.D, pl.dh, pl.obuf, pl.inner, stats, nullptr, s, 0)) != HN_OK)
+      return rc;
+    GemmArgs go = gemm_defaults();
+    go.A = pl.obuf; go.lda = pl.inner;
+    go.W = p->w_out; go.ldw = pl.inner;
+    go.M = b * L; go.N = p->query_dim; go.K = pl.inner;
+    go.bias = p->b_out; go.act = ACT_LEAKY;
+    if (residual) { go.R = x_in; go.ldr = p->query_dim; }
+    go.C = x_out; go.ldc = p->query_dim;
+    return launch_gemm(go, s);
   }
 
   AttnCoreArgs core;
@@ -596,12 +641,15 @@ struct FusionPlan {
   int ldz[16], N[16], D[16];
   bool ones[16];   // z carries the synthetic ones column (rank-D pitch with a free last column)
   int pack[16];    // ... and uses the packed channel layout with this many QK^T k-steps (0 = natural)
+  bool bf16[16];   // core_precision = bf16: z holds the bf16 images (zb, then zT) instead of the fp32 rows
+  int Np[16];
   void *op_ws;
   size_t op_ws_bytes, bytes;
   int dominant;   // modality with the most tokens among the present ones
 };
 
-static int plan_fusion(const hn_model *m, const hn_modality_input *in, int b, void *ws, size_t ws_bytes, FusionPlan *fp) {
+static int plan_fusion(const hn_model *m, const hn_modality_input *in, int b, void *ws, size_t ws_bytes, FusionPlan *fp,
+                       bool inference = false) {
   HN_REQUIRE(m && in, HN_E_NULL, "fusion: NULL model / inputs");
   HN_REQUIRE(m->n_modalities >= 1 && m->n_modalities <= 16, HN_E_UNSUPPORTED, "fusion: n_modalities=%d (1..16)", m->n_modalities);
   HN_REQUIRE(m->depth >= 1 && m->l_c >= 1 && m->l_d >= 1 && b >= 1, HN_E_SHAPE, "fusion: depth=%d l_c=%d l_d=%d b=%d",
@@ -631,14 +679,31 @@ static int plan_fusion(const hn_model *m, const hn_modality_input *in, int b, vo
     fp->ldz[i] = context_pitch(fp->D[i], ap->dim_head);
     fp->ones[i] = (fp->ldz[i] == 16 || fp->ldz[i] == 32) && fp->D[i] <= fp->ldz[i] - 1;
     fp->pack[i] = fp->ones[i] ? packed_steps(fp->D[i], fp->ldz[i]) : 0;
-    fp->z[i] = ar.take<float>((size_t)b * n * fp->ldz[i]);
+    // One workspace size serves the inference forward (which may use the bf16 core) and the training forward / backward
+    // (always fp32) of the same model: size for the larger of the two layouts.
+    const bool want_bf16 = m->core_precision == HN_CORE_BF16 && fp->ones[i] && n > 1;
+    HN_REQUIRE(in[i].dtype == HN_F32 || in[i].dtype == HN_BF16, HN_E_UNSUPPORTED, "fusion: modality %d dtype=%d", i, in[i].dtype);
+    fp->bf16[i] = want_bf16 && inference;
+    fp->Np[i] = (int)((n + 31) / 32 * 32);
+    if (fp->bf16[i]) fp->pack[i] = 0;
+    size_t zbytes = (size_t)b * n * fp->ldz[i] * sizeof(float);
+    if (want_bf16) {
+      const size_t zb16 = (size_t)b * fp->Np[i] * (32 + fp->ldz[i]) * sizeof(uint16_t);
+      if (zb16 > zbytes) zbytes = zb16;
+    }
+    fp->z[i] = (float *)ar.take<char>(zbytes);
     if (n > best) { best = n; fp->dominant = i; }
     for (int layer = 0; layer < m->depth; ++layer) {
       AttnPlan pl;
       int rc = plan_attn(&m->cross_attn[layer * m->n_modalities + i], true, fp->ldz[i], b, m->l_c, (int)n, fp->D[i], nullptr,
-                         0, &pl);
+                         0, &pl, false);
       if (rc != HN_OK) return rc;
       if (pl.bytes > op_max) op_max = pl.bytes;
+      if (want_bf16) {
+        if ((rc = plan_attn(&m->cross_attn[layer * m->n_modalities + i], true, fp->ldz[i], b, m->l_c, (int)n, fp->D[i], nullptr,
+                            0, &pl, true)) != HN_OK) return rc;
+        if (pl.bytes > op_max) op_max = pl.bytes;
+      }
     }
   }
   HN_REQUIRE(fp->dominant >= 0, HN_E_SHAPE, "fusion: every modality is missing");
@@ -777,13 +842,13 @@ int hn_context_pitch(int D, int dim_head) { return context_pitch(D, dim_head); }
 
 int hn_fourier_encode_concat(const float *data, int b, int n_axes, const int *spatial, int channels, int num_freq_bands,
                              float max_freq, int fourier, float *ctx, int ld_out, void *stream) {
-  return launch_encode(data, b, n_axes, spatial, channels, num_freq_bands, max_freq, fourier, 0, 0.0f, ctx, ld_out,
+  return launch_encode(data, HN_F32, b, n_axes, spatial, channels, num_freq_bands, max_freq, fourier, 0, 0.0f, ctx, ld_out,
                        (hipStream_t)stream);
 }
 
 int hn_encode_norm(const float *data, int b, int n_axes, const int *spatial, int channels, int num_freq_bands,
                    float max_freq, int fourier, float eps, float *z, int ld_out, void *stream) {
-  return launch_encode(data, b, n_axes, spatial, channels, num_freq_bands, max_freq, fourier, 1, eps, z, ld_out,
+  return launch_encode(data, HN_F32, b, n_axes, spatial, channels, num_freq_bands, max_freq, fourier, 1, eps, z, ld_out,
                        (hipStream_t)stream);
 }
 
@@ -886,7 +951,7 @@ int hn_head_bwd(const float *x, int b, int L, int d, const float *norm_w, const 
 
 size_t hn_fusion_workspace_bytes(const hn_model *model, const hn_modality_input *inputs, int b) {
   FusionPlan fp;
-  if (plan_fusion(model, inputs, b, nullptr, 0, &fp) != HN_OK) return 0;
+  if (plan_fusion(model, inputs, b, nullptr, 0, &fp, true) != HN_OK) return 0;
   return fp.bytes;
 }
 
@@ -896,10 +961,10 @@ int hn_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, con
   hipStream_t s = (hipStream_t)stream;
   HN_REQUIRE(out, HN_E_NULL, "fusion: out is NULL");
   FusionPlan fp;
-  int rc = plan_fusion(m, in, b, nullptr, 0, &fp);
+  int rc = plan_fusion(m, in, b, nullptr, 0, &fp, true);
   if (rc != HN_OK) return rc;
   if ((rc = check_ws(workspace, workspace_bytes, fp.bytes, "fusion")) != HN_OK) return rc;
-  if ((rc = plan_fusion(m, in, b, workspace, workspace_bytes, &fp)) != HN_OK) return rc;
+  if ((rc = plan_fusion(m, in, b, workspace, workspace_bytes, &fp, true)) != HN_OK) return rc;
   const int M = m->n_modalities, L = m->l_c, d = m->l_d;
   const size_t xbytes = (size_t)b * L * d * sizeof(float);
   if (prof) prof->n_recorded = 0;
@@ -907,10 +972,16 @@ int hn_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, con
   // K1 once per forward: the normalised context of every present modality (layer independent)
   for (int i = 0; i < M; ++i) {
     if (!in[i].data) continue;
-    if ((rc = launch_encode(in[i].data, b, m->num_spatial_axes[i], in[i].spatial, m->channel_dims[i], m->num_freq_bands,
-                            m->max_freq, m->fourier_encode_data, 1, 1e-5f, fp.z[i], fp.ldz[i], s, fp.ones[i] ? fp.ldz[i] - 1 : -1,
-                            fp.pack[i])) != HN_OK)
-      return rc;
+    if (fp.bf16[i]) {
+      uint16_t *zb = (uint16_t *)fp.z[i], *zT = zb + (size_t)b * fp.Np[i] * 32;
+      rc = launch_encode_bf16ctx(in[i].data, in[i].dtype, b, m->num_spatial_axes[i], in[i].spatial, m->channel_dims[i],
+                                 m->num_freq_bands, m->max_freq, m->fourier_encode_data, 1e-5f, zb, zT, fp.Np[i], fp.ldz[i], s);
+    } else {
+      rc = launch_encode(in[i].data, in[i].dtype, b, m->num_spatial_axes[i], in[i].spatial, m->channel_dims[i], m->num_freq_bands,
+                         m->max_freq, m->fourier_encode_data, 1, 1e-5f, fp.z[i], fp.ldz[i], s, fp.ones[i] ? fp.ldz[i] - 1 : -1,
+                         fp.pack[i]);
+    }
+    if (rc != HN_OK) return rc;
   }
   if ((rc = launch_broadcast_rows(m->latents, fp.x, (long)L * d, b, s)) != HN_OK) return rc;   // :225
 
@@ -929,9 +1000,11 @@ int hn_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, con
           e1 = (hipEvent_t)prof->ev_stop[prof->n_recorded];
           prof->n_recorded++;
         }
+        Bf16Context bc;
+        bc.zb = (const uint16_t *)fp.z[i]; bc.zT = bc.zb + (size_t)b * fp.Np[i] * 32; bc.Np = fp.Np[i]; bc.DV = fp.ldz[i];
         if ((rc = attn_fwd_impl(ap, fp.x, fp.x, 1, fp.z[i], fp.ldz[i], b, L, fp.N[i], fp.D[i], mask,
                                 attn_stats ? attn_stats[slot + i] : nullptr, fp.op_ws, fp.op_ws_bytes, s, e0, e1, nullptr,
-                                fp.ones[i], fp.pack[i])) != HN_OK)
+                                fp.ones[i], fp.pack[i], fp.bf16[i] ? &bc : nullptr)) != HN_OK)
           return rc;
         if ((rc = ff_fwd_impl(&m->cross_ff[layer * M + i], fp.x, fp.x, 1, b * L, fp.op_ws, fp.op_ws_bytes, s)) != HN_OK)
           return rc;
@@ -976,7 +1049,7 @@ int hn_fusion_forward_train(const hn_model *m, const hn_modality_input *in, int 
   const int M = m->n_modalities, L = m->l_c, d = m->l_d;
   for (int i = 0; i < M; ++i) {
     if (!in[i].data) continue;
-    if ((rc = launch_encode(in[i].data, b, m->num_spatial_axes[i], in[i].spatial, m->channel_dims[i], m->num_freq_bands,
+    if ((rc = launch_encode(in[i].data, in[i].dtype, b, m->num_spatial_axes[i], in[i].spatial, m->channel_dims[i], m->num_freq_bands,
                             m->max_freq, m->fourier_encode_data, 1, 1e-5f, fp.z[i], fp.ldz[i], s)) != HN_OK)
       return rc;
   }
@@ -1047,7 +1120,7 @@ int hn_fusion_backward(const hn_model *m, const hn_modality_input *in, int b, co
   const size_t xn = (size_t)b * L * d;
   for (int i = 0; i < M; ++i) {     // the normalised contexts are recomputed (one HBM pass) rather than kept on the tape
     if (!in[i].data) continue;
-    if ((rc = launch_encode(in[i].data, b, m->num_spatial_axes[i], in[i].spatial, m->channel_dims[i], m->num_freq_bands,
+    if ((rc = launch_encode(in[i].data, in[i].dtype, b, m->num_spatial_axes[i], in[i].spatial, m->channel_dims[i], m->num_freq_bands,
                             m->max_freq, m->fourier_encode_data, 1, 1e-5f, fp.z[i], fp.ldz[i], s)) != HN_OK)
       return rc;
   }

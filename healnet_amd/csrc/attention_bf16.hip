@@ -1,0 +1,268 @@
+// bf16-MFMA attention core for the shared-context (rank-D) binding: the image / volume cross-attention of
+// Attention.forward (healnet/models/healnet.py:400-426) when the model runs with core_precision = bf16
+// (BASELINE.json configs[2]: "3-modality ... 1 MI355X bf16").
+//
+// Same algorithm and partial-result format as attn_core_kernel<.., ONES> in attention.hip (split-KV flash
+// attention, scores in log2 units, -m delivered through the C operand of the QK^T MFMA, softmax denominator
+// accumulated by a ones row of V, lazy sum-guarded rescale); what changes is the matrix instruction and the
+// operand images it wants:
+//
+//   v_mfma_f32_16x16x32_bf16: A lane (g, j) = row j, k = 8 g .. 8 g + 7   (one 16-byte register quad)
+//                             B lane (g, j) = col j, k = 8 g .. 8 g + 7
+//                             C/D lane (g, j) = col j, rows 4 g + r        (as the fp32 16x16x4)
+//
+//   * QK^T contracts the channel slots: one MFMA covers 32 slots (D <= 32), two MFMAs (tiles X, Y) cover a
+//     32-token step.  A = context rows from the token-major image zb (Np, 32): row m of tile X is token
+//     t0 + 8 (m / 4) + m % 4, of tile Y that + 4, so that lane (g, q) ends up with the scores of the eight
+//     CONSECUTIVE tokens t0 + 8 g .. 8 g + 7 of its query q (X: regs 0-3, Y: regs 4-7).
+//   * P V contracts those tokens: the eight probabilities, converted pairwise with v_cvt_pk_bf16_f32, ARE the
+//     A operand (row q, k = 8 g + s) -- no shuffle, no LDS -- and B = eight consecutive tokens of one channel,
+//     one 16-byte load from the channel-major image zT (DV, Np).  Row DV - 1 of zT is 1.0 on valid tokens, so
+//     accumulator column DV - 1 is the softmax denominator of the SAME rounded probabilities the numerator used.
+//
+// Per 32-token step and 16-query tile: 2 + DV/16 MFMAs of 16 cycles (fp32 path: 14 .. 26 of 32 cycles), 8 v_exp,
+// 4 cvt_pk, 4 packed adds: the loop is bound by the exp / VALU rate, not by the matrix pipe.
+#include "common.h"
+
+namespace hn {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+__device__ __forceinline__ float fast_exp2_b(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+__device__ __forceinline__ bf16x8 as_bf16x8(const f32x4 &v) { return __builtin_bit_cast(bf16x8, v); }
+
+template <int DTV, int NQ>
+__global__ __launch_bounds__(256) void attn_core_bf16_kernel(AttnCoreBf16Args a, int ngroups, int gy, int waves_per_block) {
+  constexpr int DV = 16 * DTV;
+  const int L = a.Lq;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, j = lane & 15;
+
+  long total = (long)gridDim.x;
+  long id = blockIdx.x;
+  if ((total & 7) == 0) id = (id & 7) * (total >> 3) + (id >> 3);      // XCD-aware remap (see attention.hip)
+  const int split = (int)(id % a.nsplit);
+  const int yb = (int)((id / a.nsplit) % gy);
+  const int bh = (int)(id / ((long)a.nsplit * gy));
+  const int qg = yb * waves_per_block + wave;
+  if (qg >= ngroups) return;
+  const int bi = bh / a.h;
+
+  // ---- query fragments (B operand): lane (g, j) holds Qf[row = tile*16 + j][8 g .. 8 g + 7]
+  bf16x8 qf[NQ];
+  const uint16_t *qbase = a.Qf + (long)bh * a.Lp * 32;
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    const int row = (qg * NQ + i) * 16 + j;
+    f32x4 w = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (row < a.Lp) w = *(const f32x4 *)(qbase + (long)row * 32 + 8 * g);
+    qf[i] = as_bf16x8(w);
+  }
+
+  f32x4 O[NQ][DTV];
+  f32x4 negm[NQ];
+  float m[NQ];
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    negm[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    m[i] = 0.0f;
+#pragma unroll
+    for (int d = 0; d < DTV; ++d) O[i][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  bool unset = true;
+
+  const int t_begin = split * a.chunk;
+  const int t_end = min(a.N, t_begin + a.chunk);
+  const uint8_t *mrow = a.mask ? a.mask + (long)bi * a.N : nullptr;
+
+  const i32x4 krs = make_rsrc(a.zb + (long)bi * a.Np * 32, (unsigned)((long)a.Np * 64));
+  const i32x4 vrs = make_rsrc(a.zT + (long)bi * DV * a.Np, (unsigned)((long)DV * a.Np * 2));
+  const int koff = (8 * (j >> 2) + (j & 3)) * 64 + 16 * g;
+  int voff[DTV];
+#pragma unroll
+  for (int d = 0; d < DTV; ++d) voff[d] = ((16 * d + j) * a.Np + 8 * g) * 2;
+
+  auto load_kv = [&](int t0, f32x4 (&kf)[2], f32x4 (&vf)[DTV]) {
+    kf[0] = hn_buffer_load_x4(krs, koff, t0 * 64, 0);
+    kf[1] = hn_buffer_load_x4(krs, koff + 256, t0 * 64, 0);
+#pragma unroll
+    for (int d = 0; d < DTV; ++d) vf[d] = hn_buffer_load_x4(vrs, voff[d], t0 * 2, 0);
+  };
+
+  // one 32-token step on (kf, vf); prefetches the following step into (kn, vn)
+  auto step = [&](int t0, f32x4 (&kf)[2], f32x4 (&vf)[DTV], f32x4 (&kn)[2], f32x4 (&vn)[DTV]) {
+    if (t0 + 32 < t_end) load_kv(t0 + 32, kn, vn);
+
+    f32x4 S[NQ][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int i = 0; i < NQ; ++i)
+        S[i][x] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(kf[x]), qf[i], negm[i], 0, 0, 0);
+
+    // ---- mask / ragged tail: lane (g, j) holds tokens t0 + 8 g + 4 x + r
+    bool any_live = true;
+    if (mrow != nullptr || t0 + 32 > t_end) {
+      bool live = false;
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int tok = t0 + 8 * g + 4 * x + r;
+          bool ok = tok < t_end;
+          if (ok && mrow) ok = mrow[tok] != 0;
+          live |= ok;
+          if (!ok) {
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) S[i][x][r] = -__builtin_inff();
+          }
+        }
+      any_live = __any(live);
+    }
+
+    float ps0 = 0.0f, ps1 = 0.0f;
+    f32x4 P[NQ][2];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i)
+#pragma unroll
+      for (int x = 0; x < 2; ++x) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) P[i][x][r] = fast_exp2_b(S[i][x][r]);
+        ps0 += P[i][x][0] + P[i][x][2];
+        ps1 += P[i][x][1] + P[i][x][3];
+      }
+    const bool need = !(ps0 + ps1 <= 512.0f) || unset;
+    if (__any(need) && any_live) {
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) {
+        float tm = fmaxf(fmaxf(fmaxf(S[i][0][0], S[i][0][1]), fmaxf(S[i][0][2], S[i][0][3])),
+                         fmaxf(fmaxf(S[i][1][0], S[i][1][1]), fmaxf(S[i][1][2], S[i][1][3])));
+        tm = fmaxf(tm, __shfl_xor(tm, 16));
+        tm = fmaxf(tm, __shfl_xor(tm, 32));
+        float delta = unset ? tm : fmaxf(tm, 0.0f);
+        if (!(delta > -3.0e38f)) delta = 0.0f;          // row saw only -inf scores: keep the reference
+        const float alpha = unset ? 1.0f : fast_exp2_b(-delta);
+        m[i] += delta;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float ar = __shfl(alpha, 4 * g + r);    // accumulator reg r of lane (g, d) belongs to query row 4 g + r
+#pragma unroll
+          for (int d = 0; d < DTV; ++d) O[i][d][r] *= ar;
+        }
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) P[i][x][r] = fast_exp2_b(S[i][x][r] - delta);
+        negm[i] = (f32x4){-m[i], -m[i], -m[i], -m[i]};
+      }
+      unset = false;
+    }
+
+    // ---- O += P V: A = the eight probabilities of this lane's query, B = eight consecutive tokens of a channel
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      u32x4 pk;
+      pk.x = cvt_pk_bf16(P[i][0][0], P[i][0][1]);
+      pk.y = cvt_pk_bf16(P[i][0][2], P[i][0][3]);
+      pk.z = cvt_pk_bf16(P[i][1][0], P[i][1][1]);
+      pk.w = cvt_pk_bf16(P[i][1][2], P[i][1][3]);
+      const bf16x8 pa = __builtin_bit_cast(bf16x8, pk);
+#pragma unroll
+      for (int d = 0; d < DTV; ++d)
+        O[i][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, as_bf16x8(vf[d]), O[i][d], 0, 0, 0);
+    }
+  };
+
+  f32x4 kA[2], kB[2], vA[DTV], vB[DTV];
+  if (t_begin < t_end) load_kv(t_begin, kA, vA);
+  for (int t0 = t_begin; t0 < t_end; t0 += 64) {
+    step(t0, kA, vA, kB, vB);
+    if (t0 + 32 < t_end) step(t0 + 32, kB, vB, kA, vA);
+  }
+
+  // ---- partial (O, m, l) of this split; l sits in accumulator column DV-1
+  const long prow = ((long)bh * a.nsplit + split) * a.Lp;
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    const int tile = qg * NQ + i;
+    if (tile * 16 < a.Lp) {
+#pragma unroll
+      for (int d = 0; d < DTV; ++d)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          a.Opart[(prow + tile * 16 + 4 * g + r) * DV + 16 * d + j] = O[i][d][r];
+      if (g == 0) a.Mpart[prow + tile * 16 + j] = m[i];
+      if (j == 15) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a.Lpart[prow + tile * 16 + 4 * g + r] = O[i][DTV - 1][r];
+      }
+    }
+  }
+  (void)L;
+}
+
+int launch_attn_core_bf16(const AttnCoreBf16Args &a, hipStream_t s) {
+  HN_REQUIRE(a.DV == 16 || a.DV == 32, HN_E_UNSUPPORTED, "attn_core_bf16: DV=%d", a.DV);
+  HN_REQUIRE(a.Lp % 16 == 0 && a.chunk % 32 == 0 && a.nsplit >= 1 && a.Np % 32 == 0 && a.Np >= a.N, HN_E_SHAPE,
+             "attn_core_bf16: Lp=%d chunk=%d Np=%d", a.Lp, a.chunk, a.Np);
+  HN_REQUIRE((long)a.Np * 64 < (1L << 31), HN_E_UNSUPPORTED, "attn_core_bf16: one sample's context must span < 2 GiB (N=%d)", a.N);
+  constexpr int NQ = 4;
+  const int ngroups = ceil_div(a.Lp / 16, NQ);
+  const int wpb = ngroups < 4 ? ngroups : 4;
+  const int gy = ceil_div(ngroups, wpb);
+  const long blocks = (long)a.nsplit * gy * a.b * a.h;
+  HN_REQUIRE(blocks < (1L << 31), HN_E_UNSUPPORTED, "attn_core_bf16: grid too large");
+  dim3 grid((unsigned)blocks), block(64 * wpb);
+  if (a.DV == 16) hipLaunchKernelGGL((attn_core_bf16_kernel<1, NQ>), grid, block, 0, s, a, ngroups, gy, wpb);
+  else hipLaunchKernelGGL((attn_core_bf16_kernel<2, NQ>), grid, block, 0, s, a, ngroups, gy, wpb);
+  HN_LAUNCH_CHECK("attn_core_bf16");
+  return HN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// query side: Qf[b,h,q,c] = bf16( cscale * gamma[c] * sum_e Q[b,q,h*dh+e] * W_k[h*dh+e, c] ), 32 slots per row
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint16_t f2bf(float f) {       // round to nearest even
+  unsigned u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+__global__ __launch_bounds__(256) void qfold_bf16_kernel(const float *__restrict__ Q, int ldq_row, const float *__restrict__ w_k,
+                                                         int D, const float *__restrict__ gamma, float cscale,
+                                                         uint16_t *__restrict__ Qf, int h, int L, int Lp, int dh) {
+  extern __shared__ float wk[];  // [dh][32]
+  const int bh = blockIdx.x, bi = bh / h, hi = bh % h;
+  for (int idx = threadIdx.x; idx < dh * 32; idx += blockDim.x) {
+    const int e = idx >> 5, d = idx & 31;
+    wk[idx] = d < D ? w_k[(long)(hi * dh + e) * D + d] * (gamma ? gamma[d] : 1.0f) * cscale : 0.0f;
+  }
+  __syncthreads();
+  uint16_t *dst = Qf + (long)bh * Lp * 32;
+  for (int idx = threadIdx.x; idx < Lp * 32; idx += blockDim.x) {
+    const int q = idx >> 5, d = idx & 31;
+    float acc = 0.0f;
+    if (q < L && d < D) {
+      const float *qr = Q + ((long)bi * L + q) * ldq_row + hi * dh;
+      for (int e = 0; e < dh; ++e) acc = fmaf(qr[e], wk[e * 32 + d], acc);
+    }
+    dst[idx] = f2bf(acc);
+  }
+}
+
+int launch_qfold_bf16(const float *Q, int ldq_row, const float *w_k, int D, const float *gamma, float cscale, uint16_t *Qf,
+                      int b, int h, int L, int Lp, int dh, hipStream_t s) {
+  HN_REQUIRE(D <= 32, HN_E_SHAPE, "qfold_bf16: D=%d", D);
+  hipLaunchKernelGGL(qfold_bf16_kernel, dim3(b * h), dim3(256), (size_t)dh * 32 * sizeof(float), s, Q, ldq_row, w_k, D, gamma,
+                     cscale, Qf, h, L, Lp, dh);
+  HN_LAUNCH_CHECK("qfold_bf16");
+  return HN_OK;
+}
+
+}  // namespace hn

@@ -126,9 +126,11 @@ int launch_gemm(const GemmArgs &g, hipStream_t s);
 // ------------------------------------------------------------------------------------------------
 // encode
 // ------------------------------------------------------------------------------------------------
-int launch_encode(const float *data, int b, int n_axes, const int *spatial, int C, int F, float max_freq,
+int launch_encode(const void *data, int in_dtype, int b, int n_axes, const int *spatial, int C, int F, float max_freq,
                   int fourier, int normalize, float eps, float *out, int ld_out, hipStream_t s, int ones_col = -1,
                   int pack_ks = 0);
+int launch_encode_bf16ctx(const void *data, int in_dtype, int b, int n_axes, const int *spatial, int C, int F, float max_freq,
+                          int fourier, float eps, uint16_t *zb, uint16_t *zT, int Np, int DV, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
 // attention pieces
@@ -147,6 +149,18 @@ struct AttnCoreArgs {
   float *Ofinal; int ldo, dh; float *stats;     // nsplit == 1 only: write the normalised O (b*Lq, ldo) + stats directly (no merge kernel)
 };
 int launch_attn_core(const AttnCoreArgs &a, hipStream_t s);
+
+struct AttnCoreBf16Args {                        // bf16-MFMA core of the shared-context binding (attention_bf16.hip)
+  const uint16_t *Qf;                            // (b, h, Lp, 32) bf16 folded queries
+  const uint16_t *zb, *zT;                       // (b, Np, 32) token-major / (b, DV, Np) channel-major context images
+  const uint8_t *mask;                           // (b, N) or NULL
+  float *Opart, *Mpart, *Lpart;                  // (b, h, nsplit, Lp, DV), (b, h, nsplit, Lp) x2
+  int b, h, Lq, Lp, N, Np, DV;
+  int nsplit, chunk;                             // tokens per split (multiple of 32)
+};
+int launch_attn_core_bf16(const AttnCoreBf16Args &a, hipStream_t s);
+int launch_qfold_bf16(const float *Q, int ldq_row, const float *w_k, int D, const float *gamma, float cscale, uint16_t *Qf,
+                      int b, int h, int L, int Lp, int dh, hipStream_t s);
 void attn_core_geometry(int b, int h, int Lp, int N, int dp, int *nsplit, int *chunk);
 
 int launch_qfold(const float *Q, int ldq_row, const float *w_k, int D, const float *gamma, float cscale,

@@ -69,10 +69,19 @@ __device__ __forceinline__ float pos_feature(int j, const int *idx, const EncGeo
 
 constexpr int kMaxNarrow = 32;
 
+// modality elements: fp32 or bf16 (hn_modality_input.dtype); all arithmetic is fp32 either way
+__device__ __forceinline__ float in_at(const float *p, long i) { return p[i]; }
+__device__ __forceinline__ float in_at(const uint16_t *p, long i) { return __uint_as_float((unsigned)p[i] << 16); }
+__device__ __forceinline__ uint16_t to_bf16(float f) {     // round to nearest even
+  unsigned u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
 // PACK > 0: packed context layout (common.h): the D-1 kept channels go to packed_slot(c, PACK), the last channel is
 // dropped (it is minus the sum of the others after normalisation).
-template <int PACK>
-__global__ __launch_bounds__(256) void encode_token_kernel(const float *__restrict__ data, float *__restrict__ out,
+template <int PACK, typename IN>
+__global__ __launch_bounds__(256) void encode_token_kernel(const IN *__restrict__ data, float *__restrict__ out,
                                                            EncGeom g, long total) {
   long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= total) return;
@@ -80,11 +89,11 @@ __global__ __launch_bounds__(256) void encode_token_kernel(const float *__restri
   int idx[HN_MAX_AXES];
   token_coords(n, g, idx);
   float v[kMaxNarrow];
-  const float *src = data + gid * g.C;
+  const IN *src = data + gid * g.C;
 #pragma unroll
   for (int c = 0; c < kMaxNarrow; ++c) {
     float x = 0.0f;
-    if (c < g.C) x = src[c];
+    if (c < g.C) x = in_at(src, c);
     else if (c < g.D) x = pos_feature(c - g.C, idx, g);
     v[c] = x;
   }
@@ -134,7 +143,8 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-__global__ __launch_bounds__(256) void encode_wave_kernel(const float *__restrict__ data, float *__restrict__ out,
+template <typename IN>
+__global__ __launch_bounds__(256) void encode_wave_kernel(const IN *__restrict__ data, float *__restrict__ out,
                                                           EncGeom g, long total) {
   const int lane = threadIdx.x & 63;
   long tok = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -142,21 +152,21 @@ __global__ __launch_bounds__(256) void encode_wave_kernel(const float *__restric
   long n = tok % g.N;
   int idx[HN_MAX_AXES];
   token_coords(n, g, idx);
-  const float *src = data + tok * g.C;
+  const IN *src = data + tok * g.C;
   float *dst = out + tok * (long)g.ld_out;
   const int n_pos = g.D - g.C;
   float mean = 0.0f, rstd = 1.0f;
   if (g.normalize) {
     float s = 0.0f;
-    for (int c = lane; c < g.C; c += 64) s += src[c];
+    for (int c = lane; c < g.C; c += 64) s += in_at(src, c);
     for (int j = lane; j < n_pos; j += 64) s += pos_feature(j, idx, g);
     mean = wave_sum(s) / (float)g.D;
     float q = 0.0f;
-    for (int c = lane; c < g.C; c += 64) { float d = src[c] - mean; q += d * d; }
+    for (int c = lane; c < g.C; c += 64) { float d = in_at(src, c) - mean; q += d * d; }
     for (int j = lane; j < n_pos; j += 64) { float d = pos_feature(j, idx, g) - mean; q += d * d; }
     rstd = 1.0f / sqrtf(wave_sum(q) / (float)g.D + g.eps);
   }
-  for (int c = lane; c < g.C; c += 64) dst[c] = g.normalize ? (src[c] - mean) * rstd : src[c];
+  for (int c = lane; c < g.C; c += 64) dst[c] = g.normalize ? (in_at(src, c) - mean) * rstd : in_at(src, c);
   for (int j = lane; j < n_pos; j += 64) {
     float p = pos_feature(j, idx, g);
     dst[g.C + j] = g.normalize ? (p - mean) * rstd : p;
@@ -164,50 +174,142 @@ __global__ __launch_bounds__(256) void encode_wave_kernel(const float *__restric
   for (int c = g.D + lane; c < g.ld_out; c += 64) dst[c] = c == g.ones_col ? 1.0f : 0.0f;
 }
 
-int launch_encode(const float *data, int b, int n_axes, const int *spatial, int C, int F, float max_freq,
-                  int fourier, int normalize, float eps, float *out, int ld_out, hipStream_t s, int ones_col, int pack_ks) {
-  HN_REQUIRE(data && out && spatial, HN_E_NULL, "encode: NULL pointer");
+static int fill_geom(EncGeom *g, int b, int n_axes, const int *spatial, int C, int F, float max_freq, int fourier, int normalize,
+                     float eps) {
+  HN_REQUIRE(spatial, HN_E_NULL, "encode: NULL pointer");
   HN_REQUIRE(b > 0 && C > 0 && n_axes >= 1 && n_axes <= HN_MAX_AXES, HN_E_SHAPE,
              "encode: b=%d C=%d n_axes=%d (1..%d axes supported)", b, C, n_axes, HN_MAX_AXES);
   HN_REQUIRE(!fourier || F >= 1, HN_E_SHAPE, "encode: num_freq_bands=%d", F);
-  EncGeom g;
-  g.n_axes = n_axes;
-  g.N = 1;
+  g->n_axes = n_axes;
+  g->N = 1;
   for (int a = 0; a < HN_MAX_AXES; ++a) {
-    g.S[a] = a < n_axes ? spatial[a] : 1;
-    HN_REQUIRE(g.S[a] > 0, HN_E_SHAPE, "encode: spatial[%d]=%d", a, g.S[a]);
-    g.N *= g.S[a];
+    g->S[a] = a < n_axes ? spatial[a] : 1;
+    HN_REQUIRE(g->S[a] > 0, HN_E_SHAPE, "encode: spatial[%d]=%d", a, g->S[a]);
+    g->N *= g->S[a];
   }
-  g.C = C;
-  g.F = F;
-  g.D = C + (fourier ? n_axes * (2 * F + 1) : 0);
-  g.ld_out = ld_out;
-  g.max_freq = max_freq;
-  g.fourier = fourier;
-  g.normalize = normalize;
-  g.eps = eps;
-  g.ones_col = (ones_col >= g.D && ones_col < ld_out) ? ones_col : -1;
-  HN_REQUIRE(ld_out >= g.D, HN_E_SHAPE, "encode: ld_out=%d < D=%d", ld_out, g.D);
+  g->C = C;
+  g->F = F;
+  g->D = C + (fourier ? n_axes * (2 * F + 1) : 0);
+  g->max_freq = max_freq;
+  g->fourier = fourier;
+  g->normalize = normalize;
+  g->eps = eps;
+  g->ones_col = -1;
+  g->ld_out = 0;
+  return HN_OK;
+}
+
+template <typename IN>
+static int launch_encode_t(const IN *data, EncGeom g, int b, float *out, int ld_out, hipStream_t s, int pack_ks) {
   long total = (long)b * g.N;
   if (g.D <= kMaxNarrow && ld_out <= kMaxNarrow) {
     long blocks = ceil_div_ll(total, 256);
-    HN_REQUIRE(pack_ks == 0 || (normalize && pack_ks == packed_steps(g.D, ld_out)), HN_E_SHAPE, "encode: pack_ks=%d", pack_ks);
+    HN_REQUIRE(pack_ks == 0 || (g.normalize && pack_ks == packed_steps(g.D, ld_out)), HN_E_SHAPE, "encode: pack_ks=%d", pack_ks);
+#define HN_ENC(P_) hipLaunchKernelGGL((encode_token_kernel<P_, IN>), dim3((unsigned)blocks), dim3(256), 0, s, data, out, g, total)
     switch (pack_ks) {
-      case 1: hipLaunchKernelGGL(encode_token_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, data, out, g, total); break;
-      case 2: hipLaunchKernelGGL(encode_token_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, data, out, g, total); break;
-      case 3: hipLaunchKernelGGL(encode_token_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, s, data, out, g, total); break;
-      case 4: hipLaunchKernelGGL(encode_token_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, data, out, g, total); break;
-      case 5: hipLaunchKernelGGL(encode_token_kernel<5>, dim3((unsigned)blocks), dim3(256), 0, s, data, out, g, total); break;
-      case 6: hipLaunchKernelGGL(encode_token_kernel<6>, dim3((unsigned)blocks), dim3(256), 0, s, data, out, g, total); break;
-      case 7: hipLaunchKernelGGL(encode_token_kernel<7>, dim3((unsigned)blocks), dim3(256), 0, s, data, out, g, total); break;
-      default: hipLaunchKernelGGL(encode_token_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, s, data, out, g, total); break;
+      case 1: HN_ENC(1); break;
+      case 2: HN_ENC(2); break;
+      case 3: HN_ENC(3); break;
+      case 4: HN_ENC(4); break;
+      case 5: HN_ENC(5); break;
+      case 6: HN_ENC(6); break;
+      case 7: HN_ENC(7); break;
+      default: HN_ENC(0); break;
     }
+#undef HN_ENC
   } else {
     HN_REQUIRE(pack_ks == 0, HN_E_SHAPE, "encode: packed layout needs a narrow modality");
     long blocks = ceil_div_ll(total, 4);
-    hipLaunchKernelGGL(encode_wave_kernel, dim3((unsigned)blocks), dim3(256), 0, s, data, out, g, total);
+    hipLaunchKernelGGL((encode_wave_kernel<IN>), dim3((unsigned)blocks), dim3(256), 0, s, data, out, g, total);
   }
   HN_LAUNCH_CHECK("encode");
+  return HN_OK;
+}
+
+int launch_encode(const void *data, int in_dtype, int b, int n_axes, const int *spatial, int C, int F, float max_freq,
+                  int fourier, int normalize, float eps, float *out, int ld_out, hipStream_t s, int ones_col, int pack_ks) {
+  HN_REQUIRE(data && out, HN_E_NULL, "encode: NULL pointer");
+  HN_REQUIRE(in_dtype == HN_F32 || in_dtype == HN_BF16, HN_E_UNSUPPORTED, "encode: dtype=%d (0 = fp32, 1 = bf16)", in_dtype);
+  EncGeom g;
+  int rc = fill_geom(&g, b, n_axes, spatial, C, F, max_freq, fourier, normalize, eps);
+  if (rc != HN_OK) return rc;
+  g.ld_out = ld_out;
+  g.ones_col = (ones_col >= g.D && ones_col < ld_out) ? ones_col : -1;
+  HN_REQUIRE(ld_out >= g.D, HN_E_SHAPE, "encode: ld_out=%d < D=%d", ld_out, g.D);
+  return in_dtype == HN_BF16 ? launch_encode_t((const uint16_t *)data, g, b, out, ld_out, s, pack_ks)
+                             : launch_encode_t((const float *)data, g, b, out, ld_out, s, pack_ks);
+}
+
+// ------------------------------------------------------------------------------------------------
+// bf16 context images for attn_core_bf16_kernel (attention_bf16.hip): per sample
+//   zb (Np, 32)  token-major, channel c at slot c, zero beyond D, zero rows for the padding tokens n >= N
+//   zT (DV, Np)  channel-major, row DV-1 = 1.0 on valid tokens (softmax denominator), zero padding tokens
+// Always the affine-free LayerNorm of the encoded token, rounded to bf16 once.
+// ------------------------------------------------------------------------------------------------
+template <typename IN>
+__global__ __launch_bounds__(256) void encode_bf16ctx_kernel(const IN *__restrict__ data, uint16_t *__restrict__ zb,
+                                                             uint16_t *__restrict__ zT, EncGeom g, int Np, int DV, long total) {
+  long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= total) return;
+  const long bi = gid / Np;
+  const int n = (int)(gid % Np);
+  float v[kMaxNarrow];
+#pragma unroll
+  for (int c = 0; c < kMaxNarrow; ++c) v[c] = 0.0f;
+  const bool valid = n < g.N;
+  if (valid) {
+    int idx[HN_MAX_AXES];
+    token_coords(n, g, idx);
+    const IN *src = data + (bi * g.N + n) * g.C;
+#pragma unroll
+    for (int c = 0; c < kMaxNarrow; ++c) {
+      float x = 0.0f;
+      if (c < g.C) x = in_at(src, c);
+      else if (c < g.D) x = pos_feature(c - g.C, idx, g);
+      v[c] = x;
+    }
+    float sum = 0.0f;
+#pragma unroll
+    for (int c = 0; c < kMaxNarrow; ++c) sum += (c < g.D) ? v[c] : 0.0f;
+    const float mean = sum / (float)g.D;
+    float sq = 0.0f;
+#pragma unroll
+    for (int c = 0; c < kMaxNarrow; ++c) {
+      float d = (c < g.D) ? v[c] - mean : 0.0f;
+      sq += d * d;
+    }
+    const float rstd = 1.0f / sqrtf(sq / (float)g.D + g.eps);
+#pragma unroll
+    for (int c = 0; c < kMaxNarrow; ++c) v[c] = (c < g.D) ? (v[c] - mean) * rstd : 0.0f;
+  }
+  unsigned w[kMaxNarrow / 2];
+#pragma unroll
+  for (int c = 0; c < kMaxNarrow; c += 2) w[c / 2] = (unsigned)to_bf16(v[c]) | ((unsigned)to_bf16(v[c + 1]) << 16);
+  uint4 *dst = (uint4 *)(zb + gid * 32);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dst[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+  uint16_t *col = zT + bi * (long)DV * Np + n;
+#pragma unroll
+  for (int c = 0; c < kMaxNarrow; ++c)
+    if (c < DV) col[(long)c * Np] = c == DV - 1 ? (valid ? (uint16_t)0x3f80 : (uint16_t)0) : to_bf16(v[c]);
+}
+
+int launch_encode_bf16ctx(const void *data, int in_dtype, int b, int n_axes, const int *spatial, int C, int F, float max_freq,
+                          int fourier, float eps, uint16_t *zb, uint16_t *zT, int Np, int DV, hipStream_t s) {
+  HN_REQUIRE(data && zb && zT, HN_E_NULL, "encode_bf16ctx: NULL pointer");
+  HN_REQUIRE(in_dtype == HN_F32 || in_dtype == HN_BF16, HN_E_UNSUPPORTED, "encode: dtype=%d (0 = fp32, 1 = bf16)", in_dtype);
+  EncGeom g;
+  int rc = fill_geom(&g, b, n_axes, spatial, C, F, max_freq, fourier, 1, eps);
+  if (rc != HN_OK) return rc;
+  HN_REQUIRE(g.D <= DV - 1 && (DV == 16 || DV == 32) && Np % 32 == 0 && Np >= g.N, HN_E_SHAPE,
+             "encode_bf16ctx: D=%d DV=%d Np=%d N=%ld", g.D, DV, Np, g.N);
+  const long total = (long)b * Np;
+  const long blocks = ceil_div_ll(total, 256);
+  if (in_dtype == HN_BF16)
+    hipLaunchKernelGGL((encode_bf16ctx_kernel<uint16_t>), dim3((unsigned)blocks), dim3(256), 0, s, (const uint16_t *)data, zb, zT, g, Np, DV, total);
+  else
+    hipLaunchKernelGGL((encode_bf16ctx_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, s, (const float *)data, zb, zT, g, Np, DV, total);
+  HN_LAUNCH_CHECK("encode_bf16ctx");
   return HN_OK;
 }
 

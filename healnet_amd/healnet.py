@@ -361,8 +361,14 @@ class HealNet(nn.Module):
                  num_freq_bands: int = 2, max_freq: float = 10., l_c: int = 128, l_d: int = 128, x_heads: int = 8,
                  l_heads: int = 8, cross_dim_head: int = 64, latent_dim_head: int = 64, attn_dropout: float = 0.,
                  ff_dropout: float = 0., weight_tie_layers: bool = False, fourier_encode_data: bool = True,
-                 self_per_cross_attn: int = 1, final_classifier_head: bool = True, snn: bool = True):
+                 self_per_cross_attn: int = 1, final_classifier_head: bool = True, snn: bool = True,
+                 core_precision: str = "fp32"):
         super().__init__()
+        if core_precision not in ("fp32", "bf16"):
+            raise ValueError("core_precision must be 'fp32' or 'bf16'")
+        # Extension over the reference signature: matrix-instruction precision of the image / volume cross-attention
+        # core in the no-grad forward ('bf16' = BASELINE configs[2]; parameters, statistics and outputs stay fp32).
+        self.core_precision = core_precision
         assert len(channel_dims) == len(num_spatial_axes), 'input channels and input axis must be of the same length'
         assert len(num_spatial_axes) == n_modalities, 'input axis must be of the same length as the number of modalities'
 
@@ -443,7 +449,8 @@ class HealNet(nn.Module):
             head_norm_w=_ptr(self.to_logits[1].weight) if self.final_classifier_head else None,
             head_norm_b=_ptr(self.to_logits[1].bias) if self.final_classifier_head else None,
             head_w=_ptr(self.to_logits[2].weight) if self.final_classifier_head else None,
-            head_b=_ptr(self.to_logits[2].bias) if self.final_classifier_head else None)
+            head_b=_ptr(self.to_logits[2].bias) if self.final_classifier_head else None,
+            core_precision=_capi.HN_CORE_BF16 if self.core_precision == "bf16" else _capi.HN_CORE_F32)
         keep.extend([cross_attn, cross_ff, self_attn, self_ff, cd, ax])
         return model, keep
 
@@ -519,9 +526,11 @@ class HealNet(nn.Module):
                 b = bb
             elif bb != b:
                 raise ValueError("batch dim must be identical across modalities")
-            x = _f32c(data)
+            # bf16 tensors are read as they are (hn_modality_input.dtype); anything else is staged as fp32
+            x = data.contiguous() if data.dtype == torch.bfloat16 else _f32c(data)
             held[i] = x
             inputs[i].data = x.data_ptr()
+            inputs[i].dtype = _capi.HN_BF16 if x.dtype == torch.bfloat16 else _capi.HN_F32
             for a, s in enumerate(axis):
                 inputs[i].spatial[a] = int(s)
         if b is None:
@@ -583,7 +592,7 @@ class HealNet(nn.Module):
         if self.compat_mutate_inputs:
             for i in range(min(M, len(tensors))):
                 if held[i] is not None:
-                    tensors[i] = fourier_encode_concat(held[i], self.num_freq_bands, self.max_freq, self.fourier_encode_data)
+                    tensors[i] = fourier_encode_concat(_f32c(held[i]), self.num_freq_bands, self.max_freq, self.fourier_encode_data)
         return out
 
     # -- attention weights on demand ---------------------------------------------------------------
@@ -611,7 +620,7 @@ class HealNet(nn.Module):
                     dev = xin.device
                     if j < M:
                         if j not in zcache:
-                            data = last["inputs"][j]
+                            data = _f32c(last["inputs"][j])
                             n = data.numel() // (b * data.shape[-1])
                             d = self.context_dims[j]
                             ld = lib.hn_context_pitch(d, att.dim_head)

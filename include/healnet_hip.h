@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HN_ABI_VERSION 1
+#define HN_ABI_VERSION 2
 #define HN_MAX_AXES 4
 
 typedef enum hn_status {
@@ -41,6 +41,16 @@ typedef enum hn_status {
 
 /* Gate of the feed-forward block: SELU (healnet.py:328-331, snn=True) or GELU (:323-326). */
 typedef enum hn_gate { HN_GATE_SELU = 0, HN_GATE_GELU = 1 } hn_gate;
+
+/* Element type of a modality tensor handed to the fused forward (weights, latents and outputs are always fp32). */
+typedef enum hn_dtype { HN_F32 = 0, HN_BF16 = 1 } hn_dtype;
+
+/* Matrix-instruction precision of the shared-context (image / volume) cross-attention core of hn_fusion_forward:
+ * HN_CORE_F32  fp32 MFMA on the fp32 context (default; the <= 1e-3 parity configuration);
+ * HN_CORE_BF16 bf16 MFMA with fp32 accumulation: context, folded queries and probabilities rounded to bf16 once
+ *              (BASELINE configs[2], tolerance 2e-2 max-norm against the fp32 oracle).  Everything else -- LayerNorms,
+ *              projections, softmax statistics, feed-forward, head -- stays fp32.  Training always uses HN_CORE_F32. */
+typedef enum hn_core_precision { HN_CORE_F32 = 0, HN_CORE_BF16 = 1 } hn_core_precision;
 
 int hn_abi_version(void);
 const char *hn_last_error_string(void);
@@ -166,8 +176,9 @@ size_t hn_head_bwd_workspace_bytes(int b, int d, int out_dims);
  * Whole fusion forward                                 replaces HealNet.forward :190-250
  * ------------------------------------------------------------------------------------------- */
 typedef struct hn_modality_input {
-  const float *data;         /* (b, S_1..S_a, C) or NULL for a missing modality (Appendix B-1)   */
+  const void *data;          /* (b, S_1..S_a, C) or NULL for a missing modality (Appendix B-1)   */
   int spatial[HN_MAX_AXES];  /* S_1..S_a (a = num_spatial_axes[m])                               */
+  int dtype;                 /* hn_dtype of data: HN_F32 (0) or HN_BF16                          */
 } hn_modality_input;
 
 typedef struct hn_model {
@@ -186,6 +197,7 @@ typedef struct hn_model {
   const hn_attn_params *self_attn;  /* [depth]  (unused when self_per_cross_attn == 0)           */
   const hn_ff_params *self_ff;      /* [depth]                                                  */
   const float *head_norm_w, *head_norm_b, *head_w, *head_b;
+  int core_precision;            /* hn_core_precision (inference forward only)                  */
 } hn_model;
 
 /* Optional timing hooks: when non-NULL, hn_fusion_forward records ev_start[i] / ev_stop[i]

@@ -1,0 +1,123 @@
+"""GPU: the bf16 configuration of the fused forward (BASELINE.json configs[2]):
+bf16 modality tensors read in place, and core_precision='bf16' (bf16 MFMA in the image / volume cross-attention
+core).  Tolerance of the bf16 core against the fp32 reference: 2e-2 max-norm; bf16 *inputs* with the
+fp32 core must reproduce the fp32 path on the same (already rounded) values bit for bit."""
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+from oracle import healnet_cpu as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL_BF16 = 2e-2
+
+
+@pytest.fixture(scope="module")
+def hn():
+    import healnet_amd
+    return healnet_amd
+
+
+def _g5_model(hn, manifest, name, **extra):
+    g = load_golden("g5_" + name)
+    kw = dict(manifest["g5_" + name]["kwargs"])
+    model = hn.HealNet(**kw, **extra).eval()
+    model.load_state_dict({k[4:]: v for k, v in g.items() if k.startswith("sd::")}, strict=True)
+    ins = [g[f"in{i}"] for i in range(kw["n_modalities"])]
+    return model.to(DEV), ins, g
+
+
+@pytest.mark.parametrize("name", ["m2_d3", "m3_d3", "m2_d2_masked", "m2_d2_nofourier"])
+def test_bf16_tensors_are_read_in_place(hn, name, manifest):
+    model, ins, g = _g5_model(hn, manifest, name)
+    mask = g["mask"].to(DEV) if "mask" in g else None
+    lo = [t.to(torch.bfloat16).to(DEV) for t in ins]
+    want = model([t.float() for t in lo], mask=mask)
+    got = model(list(lo), mask=mask)
+    assert got.dtype == torch.float32
+    assert torch.equal(got, want)
+    # mixed list: one bf16, the rest fp32
+    mixed = [lo[0]] + [t.float() for t in lo[1:]]
+    assert torch.equal(model(mixed, mask=mask), want)
+
+
+@pytest.mark.parametrize("name", ["m1_d1", "m2_d3", "m3_d3", "m2_d3_tied", "m2_d2_noself", "m2_d2_gelu", "m2_d2_bands4",
+                                  "m2_d2_masked"])
+def test_bf16_core_tiny_models_vs_reference_fixtures(hn, name, manifest):
+    model, ins, g = _g5_model(hn, manifest, name, core_precision="bf16")
+    mask = g["mask"].to(DEV) if "mask" in g else None
+    y = model([t.to(DEV) for t in ins], mask=mask)
+    assert rel_err(y.cpu(), g["logits"]) <= TOL_BF16, name
+    if "emb" in g:
+        e = model([t.to(DEV) for t in ins], mask=mask, return_embeddings=True)
+        assert rel_err(e.cpu(), g["emb"]) <= TOL_BF16
+    if "logits_missing1" in g:
+        miss = [ins[0].to(DEV), None] + [t.to(DEV) for t in ins[2:]]
+        assert rel_err(model(miss).cpu(), g["logits_missing1"]) <= TOL_BF16
+
+
+@pytest.mark.parametrize("name", ["cfg1", "cfg3s"])
+def test_bf16_core_default_size_configs_vs_reference_fixtures(hn, name, manifest):
+    m = manifest["g6_" + name]
+    cfg = O.FusionConfig(**m["kwargs"])
+    model = hn.HealNet(**m["kwargs"], core_precision="bf16").eval()
+    model.load_state_dict(O.filler_state_dict(cfg, gain=m["gain"]), strict=True)
+    model.to(DEV)
+    ins = [O.filler_input(s, 20 + i).to(DEV) for i, s in enumerate(m["shapes"])]
+    g = load_golden("g6_" + name)
+    assert rel_err(model(list(ins)).cpu(), g["logits"]) <= TOL_BF16
+    assert rel_err(model(list(ins), return_embeddings=True).cpu(), g["emb"]) <= TOL_BF16
+    # the lazily recomputed attention rows are normalised with the core's bf16 statistics: ~1e-2 off, still rows of a softmax
+    big = int(g["attn_mean_index"])
+    model(list(ins))
+    p = model.layers[0][2 * big].fn.attn_weights
+    assert rel_err(p.mean(dim=1)[:, :4096].cpu(), g["attn_mean"]) <= 5e-2
+    assert (p.sum(-1) - 1).abs().max() < 5e-2
+
+
+def test_bf16_core_ragged_and_masked_contexts(hn):
+    """Token counts that are not multiples of the 32-token step, a key mask that kills whole steps, one sample fully
+    masked except a single token; bf16 core against the fp32 core of the same build (itself pinned to the oracle)."""
+    torch.manual_seed(3)
+    kw = dict(n_modalities=2, channel_dims=[5, 3], num_spatial_axes=[1, 2], out_dims=3, depth=2, l_c=24, l_d=32,
+              x_heads=2, l_heads=2, cross_dim_head=32, latent_dim_head=16)
+    ref = hn.HealNet(**kw).eval().to(DEV)
+    low = hn.HealNet(**kw, core_precision="bf16").eval().to(DEV)
+    low.load_state_dict(ref.state_dict())
+    for (h, w) in [(7, 11), (1, 33), (9, 31), (16, 16)]:
+        n = h * w
+        seq = torch.rand(3, n, 5, device=DEV)
+        img = torch.rand(3, h, w, 3, device=DEV)
+        assert rel_err(low([seq, img]), ref([seq, img])) <= TOL_BF16, (h, w)
+        mask = torch.rand(3, n, device=DEV) > 0.4
+        mask[1] = False
+        mask[1, n // 2] = True
+        mask[2, : min(n, 40)] = False
+        mask[2, -1] = True
+        assert rel_err(low([seq, img], mask=mask), ref([seq, img], mask=mask)) <= TOL_BF16, (h, w, "masked")
+
+
+def test_cfg3_full_size_bf16(hn):
+    """BASELINE configs[2]: tab + 224x224x3 image + 12x224x224x3 volume, b = 16, bf16 tensors, bf16 core.
+    Checked against the fp32 core on the same bf16-rounded inputs, plus batch-slice and permutation properties."""
+    torch.manual_seed(0)
+    kw = dict(n_modalities=3, channel_dims=[2000, 3, 3], num_spatial_axes=[1, 2, 3], out_dims=4)
+    ref = hn.HealNet(**kw).eval().to(DEV)
+    low = hn.HealNet(**kw, core_precision="bf16").eval().to(DEV)
+    low.load_state_dict(ref.state_dict())
+    gen = torch.Generator().manual_seed(1234)
+    b = 16
+    tab = torch.rand(b, 1, 2000, generator=gen).to(torch.bfloat16).to(DEV)
+    img = torch.rand(b, 224, 224, 3, generator=gen).to(torch.bfloat16).to(DEV)
+    vol = torch.rand(b, 12, 224, 224, 3, generator=gen).to(torch.bfloat16).to(DEV)
+    y = low([tab, img, vol])
+    assert torch.isfinite(y).all()
+    want = ref([tab[:4], img[:4], vol[:4]])
+    assert rel_err(y[:4], want) <= TOL_BF16
+    # samples are independent: a permuted batch gives permuted logits, bit for bit
+    perm = torch.randperm(b, generator=gen).to(DEV)
+    assert torch.equal(low([tab[perm], img[perm], vol[perm]]), y[perm])
+    # a missing volume falls back to the two remaining modalities
+    y2 = low([tab[:4], img[:4], None])
+    assert rel_err(y2, ref([tab[:4], img[:4], None])) <= TOL_BF16
