@@ -130,7 +130,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH, help="samples per GPU per step (headline config: 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--core-precision", choices=["fp32", "bf16"], default="fp32",
+    ap.add_argument("--core-precision", choices=["fp32", "bf16", "bf16x3"], default="fp32",
                     help="development switch: bf16 MFMA in the image cross-attention core (the headline is fp32)")
     args = ap.parse_args()
 
@@ -209,7 +209,7 @@ def main():
         total_samples = b * args.steps * world
         core_ms = events.elapsed_ms(recorded)
         avg_core_ms = sum(core_ms) / max(1, len(core_ms))
-        bf16_core = args.core_precision == "bf16"
+        bf16_core = args.core_precision != "fp32"
         # bf16 development switch: QK^T contracts 32 channel slots, P V 16 columns, on v_mfma_f32_16x16x32_bf16
         exec_flops = (2.0 * L_C * N_IMG * (32 + DP) * HEADS) if bf16_core else EXEC_FLOPS_CORE_PER_SAMPLE
         peak = 2500.0 if bf16_core else PEAK_FP32_MFMA_TFLOPS

@@ -32,7 +32,7 @@ static inline int round16(int v) { return (v + 15) / 16 * 16; }
 // ------------------------------------------------------------------------------------------------
 struct Bf16Context {              // bf16 images of one modality's normalised context (encode.hip)
   const uint16_t *zb, *zT;
-  int Np, DV;
+  int Np, DV, ns;
 };
 
 struct AttnPlan {
@@ -77,7 +77,7 @@ static int plan_attn(const hn_attn_params *p, bool has_ctx, int ld_ctx, int b, i
   pl->obuf = ar.take<float>(rows * pl->inner);
   if (pl->rank_d) {
     pl->q = ar.take<float>(rows * pl->inner);
-    pl->qf = ar.take<float>((size_t)b * p->heads * pl->Lp * pl->dp);
+    pl->qf = ar.take<float>((size_t)b * p->heads * pl->Lp * (pl->bf16core ? 48 : pl->dp));   // bf16 core: up to 96 bf16 slots per row
     pl->kv = nullptr;
   } else {
     pl->q = ar.take<float>(rows * p->heads * pl->dhp);
@@ -210,14 +210,14 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
     gq.C = pl.q; gq.ldc = pl.inner;
     if ((rc = launch_gemm(gq, s)) != HN_OK) return rc;
     uint16_t *qfb = (uint16_t *)pl.qf;
-    if ((rc = launch_qfold_bf16(pl.q, pl.inner, p->w_kv, pl.D, p->ctx_gamma, pl.cscale, qfb, b, p->heads, L, pl.Lp, pl.dh, s)) != HN_OK)
+    if ((rc = launch_qfold_bf16(pl.q, pl.inner, p->w_kv, pl.D, p->ctx_gamma, pl.cscale, qfb, b, p->heads, L, pl.Lp, pl.dh, bc->DV, bc->ns, s)) != HN_OK)
       return rc;
     AttnCoreBf16Args ca;
     memset(&ca, 0, sizeof(ca));
     ca.Qf = qfb; ca.zb = bc->zb; ca.zT = bc->zT; ca.mask = mask;
     ca.Opart = pl.opart; ca.Mpart = pl.mpart; ca.Lpart = pl.lpart;
     ca.b = b; ca.h = p->heads; ca.Lq = L; ca.Lp = pl.Lp; ca.N = pl.N; ca.Np = bc->Np; ca.DV = bc->DV;
-    ca.nsplit = pl.nsplit; ca.chunk = pl.chunk;
+    ca.nsplit = pl.nsplit; ca.chunk = pl.chunk; ca.ns = bc->ns;
     if (ev0) HN_HIP_CHECK(hipEventRecord(ev0, s));
     if ((rc = launch_attn_core_bf16(ca, s)) != HN_OK) return rc;
     if (ev1) HN_HIP_CHECK(hipEventRecord(ev1, s));
@@ -642,7 +642,7 @@ struct FusionPlan {
   bool ones[16];   // z carries the synthetic ones column (rank-D pitch with a free last column)
   int pack[16];    // ... and uses the packed channel layout with this many QK^T k-steps (0 = natural)
   bool bf16[16];   // core_precision = bf16: z holds the bf16 images (zb, then zT) instead of the fp32 rows
-  int Np[16];
+  int Np[16], ns[16];
   void *op_ws;
   size_t op_ws_bytes, bytes;
   int dominant;   // modality with the most tokens among the present ones
@@ -681,14 +681,16 @@ static int plan_fusion(const hn_model *m, const hn_modality_input *in, int b, vo
     fp->pack[i] = fp->ones[i] ? packed_steps(fp->D[i], fp->ldz[i]) : 0;
     // One workspace size serves the inference forward (which may use the bf16 core) and the training forward / backward
     // (always fp32) of the same model: size for the larger of the two layouts.
-    const bool want_bf16 = m->core_precision == HN_CORE_BF16 && fp->ones[i] && n > 1;
+    const bool want_bf16 = (m->core_precision == HN_CORE_BF16 || m->core_precision == HN_CORE_BF16X3) && fp->ones[i] && n > 1;
+    const int ns = m->core_precision == HN_CORE_BF16X3 ? 2 : 1;
+    fp->ns[i] = ns;
     HN_REQUIRE(in[i].dtype == HN_F32 || in[i].dtype == HN_BF16, HN_E_UNSUPPORTED, "fusion: modality %d dtype=%d", i, in[i].dtype);
     fp->bf16[i] = want_bf16 && inference;
     fp->Np[i] = (int)((n + 31) / 32 * 32);
     if (fp->bf16[i]) fp->pack[i] = 0;
     size_t zbytes = (size_t)b * n * fp->ldz[i] * sizeof(float);
     if (want_bf16) {
-      const size_t zb16 = (size_t)b * fp->Np[i] * (32 + fp->ldz[i]) * sizeof(uint16_t);
+      const size_t zb16 = (size_t)b * fp->Np[i] * (bf16_row_slots(fp->ldz[i], ns) + ns * fp->ldz[i]) * sizeof(uint16_t);
       if (zb16 > zbytes) zbytes = zb16;
     }
     fp->z[i] = (float *)ar.take<char>(zbytes);
@@ -973,9 +975,10 @@ int hn_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, con
   for (int i = 0; i < M; ++i) {
     if (!in[i].data) continue;
     if (fp.bf16[i]) {
-      uint16_t *zb = (uint16_t *)fp.z[i], *zT = zb + (size_t)b * fp.Np[i] * 32;
+      uint16_t *zb = (uint16_t *)fp.z[i], *zT = zb + (size_t)b * fp.Np[i] * bf16_row_slots(fp.ldz[i], fp.ns[i]);
       rc = launch_encode_bf16ctx(in[i].data, in[i].dtype, b, m->num_spatial_axes[i], in[i].spatial, m->channel_dims[i],
-                                 m->num_freq_bands, m->max_freq, m->fourier_encode_data, 1e-5f, zb, zT, fp.Np[i], fp.ldz[i], s);
+                                 m->num_freq_bands, m->max_freq, m->fourier_encode_data, 1e-5f, zb, zT, fp.Np[i], fp.ldz[i],
+                                 fp.ns[i], s);
     } else {
       rc = launch_encode(in[i].data, in[i].dtype, b, m->num_spatial_axes[i], in[i].spatial, m->channel_dims[i], m->num_freq_bands,
                          m->max_freq, m->fourier_encode_data, 1, 1e-5f, fp.z[i], fp.ldz[i], s, fp.ones[i] ? fp.ldz[i] - 1 : -1,
@@ -1001,7 +1004,8 @@ int hn_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, con
           prof->n_recorded++;
         }
         Bf16Context bc;
-        bc.zb = (const uint16_t *)fp.z[i]; bc.zT = bc.zb + (size_t)b * fp.Np[i] * 32; bc.Np = fp.Np[i]; bc.DV = fp.ldz[i];
+        bc.zb = (const uint16_t *)fp.z[i]; bc.zT = bc.zb + (size_t)b * fp.Np[i] * bf16_row_slots(fp.ldz[i], fp.ns[i]);
+        bc.Np = fp.Np[i]; bc.DV = fp.ldz[i]; bc.ns = fp.ns[i];
         if ((rc = attn_fwd_impl(ap, fp.x, fp.x, 1, fp.z[i], fp.ldz[i], b, L, fp.N[i], fp.D[i], mask,
                                 attn_stats ? attn_stats[slot + i] : nullptr, fp.op_ws, fp.op_ws_bytes, s, e0, e1, nullptr,
                                 fp.ones[i], fp.pack[i], fp.bf16[i] ? &bc : nullptr)) != HN_OK)

@@ -20,7 +20,15 @@
 //     one 16-byte load from the channel-major image zT (DV, Np).  Row DV - 1 of zT is 1.0 on valid tokens, so
 //     accumulator column DV - 1 is the softmax denominator of the SAME rounded probabilities the numerator used.
 //
-// Per 32-token step and 16-query tile: 2 + DV/16 MFMAs of 16 cycles (fp32 path: 14 .. 26 of 32 cycles), 8 v_exp,
+// NS = 2 ("bf16x3"): every operand is carried as a bf16 pair hi + lo (hi = bf16(v), lo = bf16(v - hi), 16 mantissa
+// bits together) and every product as hi*hi + hi*lo + lo*hi with fp32 accumulation in the MFMA -- fp32-class results
+// (operand error 2^-17, the dropped lo*lo term 2^-18) from the bf16 pipe.  QK^T: the three partial products are laid
+// side by side along the contraction index (NKQ 32-slot blocks: [zh | zl] . [qh | qh] and [zh | 0] . [ql | 0] for
+// D <= 16; [zh].[qh], [zl].[qh], [zh].[ql] for D <= 32).  P V: p is split in registers (cvt_pk, shift/mask, subtract,
+// cvt_pk), V comes as two channel-major planes; the ones row lives in the hi plane only, so the denominator is
+// sum(p_hi + p_lo).
+//
+// Per 32-token step and 16-query tile (NS = 1): 2 + DV/16 MFMAs of 16 cycles (fp32 path: 14 .. 26 of 32 cycles), 8 v_exp,
 // 4 cvt_pk, 4 packed adds: the loop is bound by the exp / VALU rate, not by the matrix pipe.
 #include "common.h"
 
@@ -36,9 +44,11 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
 }
 __device__ __forceinline__ bf16x8 as_bf16x8(const f32x4 &v) { return __builtin_bit_cast(bf16x8, v); }
 
-template <int DTV, int NQ>
+template <int DTV, int NQ, int NS>
 __global__ __launch_bounds__(256) void attn_core_bf16_kernel(AttnCoreBf16Args a, int ngroups, int gy, int waves_per_block) {
   constexpr int DV = 16 * DTV;
+  constexpr int NKQ = NS == 1 ? 1 : (DTV == 1 ? 2 : 3);      // 32-slot blocks of the QK^T contraction
+  constexpr int ZP = 32 * NKQ;                                // slots per context / query row
   const int L = a.Lq;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, j = lane & 15;
@@ -54,14 +64,17 @@ __global__ __launch_bounds__(256) void attn_core_bf16_kernel(AttnCoreBf16Args a,
   const int bi = bh / a.h;
 
   // ---- query fragments (B operand): lane (g, j) holds Qf[row = tile*16 + j][8 g .. 8 g + 7]
-  bf16x8 qf[NQ];
-  const uint16_t *qbase = a.Qf + (long)bh * a.Lp * 32;
+  bf16x8 qf[NQ][NKQ];
+  const uint16_t *qbase = a.Qf + (long)bh * a.Lp * ZP;
 #pragma unroll
   for (int i = 0; i < NQ; ++i) {
     const int row = (qg * NQ + i) * 16 + j;
-    f32x4 w = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (row < a.Lp) w = *(const f32x4 *)(qbase + (long)row * 32 + 8 * g);
-    qf[i] = as_bf16x8(w);
+#pragma unroll
+    for (int k = 0; k < NKQ; ++k) {
+      f32x4 w = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (row < a.Lp) w = *(const f32x4 *)(qbase + (long)row * ZP + 32 * k + 8 * g);
+      qf[i][k] = as_bf16x8(w);
+    }
   }
 
   f32x4 O[NQ][DTV];
@@ -80,30 +93,38 @@ __global__ __launch_bounds__(256) void attn_core_bf16_kernel(AttnCoreBf16Args a,
   const int t_end = min(a.N, t_begin + a.chunk);
   const uint8_t *mrow = a.mask ? a.mask + (long)bi * a.N : nullptr;
 
-  const i32x4 krs = make_rsrc(a.zb + (long)bi * a.Np * 32, (unsigned)((long)a.Np * 64));
-  const i32x4 vrs = make_rsrc(a.zT + (long)bi * DV * a.Np, (unsigned)((long)DV * a.Np * 2));
-  const int koff = (8 * (j >> 2) + (j & 3)) * 64 + 16 * g;
-  int voff[DTV];
+  const i32x4 krs = make_rsrc(a.zb + (long)bi * a.Np * ZP, (unsigned)((long)a.Np * ZP * 2));
+  const i32x4 vrs = make_rsrc(a.zT + (long)bi * NS * DV * a.Np, (unsigned)((long)NS * DV * a.Np * 2));
+  const int koff = (8 * (j >> 2) + (j & 3)) * (ZP * 2) + 16 * g;
+  int voff[NS][DTV];
 #pragma unroll
-  for (int d = 0; d < DTV; ++d) voff[d] = ((16 * d + j) * a.Np + 8 * g) * 2;
+  for (int p = 0; p < NS; ++p)
+#pragma unroll
+    for (int d = 0; d < DTV; ++d) voff[p][d] = (((p * DV + 16 * d + j)) * a.Np + 8 * g) * 2;
 
-  auto load_kv = [&](int t0, f32x4 (&kf)[2], f32x4 (&vf)[DTV]) {
-    kf[0] = hn_buffer_load_x4(krs, koff, t0 * 64, 0);
-    kf[1] = hn_buffer_load_x4(krs, koff + 256, t0 * 64, 0);
+  auto load_kv = [&](int t0, f32x4 (&kf)[2][NKQ], f32x4 (&vf)[NS][DTV]) {
 #pragma unroll
-    for (int d = 0; d < DTV; ++d) vf[d] = hn_buffer_load_x4(vrs, voff[d], t0 * 2, 0);
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int k = 0; k < NKQ; ++k) kf[x][k] = hn_buffer_load_x4(krs, koff + x * 4 * (ZP * 2) + 64 * k, t0 * (ZP * 2), 0);
+#pragma unroll
+    for (int p = 0; p < NS; ++p)
+#pragma unroll
+      for (int d = 0; d < DTV; ++d) vf[p][d] = hn_buffer_load_x4(vrs, voff[p][d], t0 * 2, 0);
   };
 
   // one 32-token step on (kf, vf); prefetches the following step into (kn, vn)
-  auto step = [&](int t0, f32x4 (&kf)[2], f32x4 (&vf)[DTV], f32x4 (&kn)[2], f32x4 (&vn)[DTV]) {
+  auto step = [&](int t0, f32x4 (&kf)[2][NKQ], f32x4 (&vf)[NS][DTV], f32x4 (&kn)[2][NKQ], f32x4 (&vn)[NS][DTV]) {
     if (t0 + 32 < t_end) load_kv(t0 + 32, kn, vn);
 
     f32x4 S[NQ][2];
 #pragma unroll
-    for (int x = 0; x < 2; ++x)
+    for (int k = 0; k < NKQ; ++k)
 #pragma unroll
-      for (int i = 0; i < NQ; ++i)
-        S[i][x] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(kf[x]), qf[i], negm[i], 0, 0, 0);
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int i = 0; i < NQ; ++i)
+          S[i][x] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(kf[x][k]), qf[i][k], k == 0 ? negm[i] : S[i][x], 0, 0, 0);
 
     // ---- mask / ragged tail: lane (g, j) holds tokens t0 + 8 g + 4 x + r
     bool any_live = true;
@@ -175,11 +196,28 @@ __global__ __launch_bounds__(256) void attn_core_bf16_kernel(AttnCoreBf16Args a,
       const bf16x8 pa = __builtin_bit_cast(bf16x8, pk);
 #pragma unroll
       for (int d = 0; d < DTV; ++d)
-        O[i][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, as_bf16x8(vf[d]), O[i][d], 0, 0, 0);
+        O[i][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, as_bf16x8(vf[0][d]), O[i][d], 0, 0, 0);
+      if (NS == 2) {
+        // residual plane: p_lo = bf16(p - p_hi); unpack p_hi from the packed pairs (low half << 16, high half masked)
+        u32x4 pl;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const unsigned u = pk[w];
+          const float h0 = __uint_as_float(u << 16), h1 = __uint_as_float(u & 0xffff0000u);
+          const int x = w >> 1, r = (w & 1) * 2;
+          pl[w] = cvt_pk_bf16(P[i][x][r] - h0, P[i][x][r + 1] - h1);
+        }
+        const bf16x8 pb = __builtin_bit_cast(bf16x8, pl);
+#pragma unroll
+        for (int d = 0; d < DTV; ++d) {
+          O[i][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, as_bf16x8(vf[1][d]), O[i][d], 0, 0, 0);
+          O[i][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pb, as_bf16x8(vf[0][d]), O[i][d], 0, 0, 0);
+        }
+      }
     }
   };
 
-  f32x4 kA[2], kB[2], vA[DTV], vB[DTV];
+  f32x4 kA[2][NKQ], kB[2][NKQ], vA[NS][DTV], vB[NS][DTV];
   if (t_begin < t_end) load_kv(t_begin, kA, vA);
   for (int t0 = t_begin; t0 < t_end; t0 += 64) {
     step(t0, kA, vA, kB, vB);
@@ -209,9 +247,11 @@ __global__ __launch_bounds__(256) void attn_core_bf16_kernel(AttnCoreBf16Args a,
 
 int launch_attn_core_bf16(const AttnCoreBf16Args &a, hipStream_t s) {
   HN_REQUIRE(a.DV == 16 || a.DV == 32, HN_E_UNSUPPORTED, "attn_core_bf16: DV=%d", a.DV);
+  HN_REQUIRE(a.ns == 1 || a.ns == 2, HN_E_UNSUPPORTED, "attn_core_bf16: ns=%d", a.ns);
   HN_REQUIRE(a.Lp % 16 == 0 && a.chunk % 32 == 0 && a.nsplit >= 1 && a.Np % 32 == 0 && a.Np >= a.N, HN_E_SHAPE,
              "attn_core_bf16: Lp=%d chunk=%d Np=%d", a.Lp, a.chunk, a.Np);
-  HN_REQUIRE((long)a.Np * 64 < (1L << 31), HN_E_UNSUPPORTED, "attn_core_bf16: one sample's context must span < 2 GiB (N=%d)", a.N);
+  HN_REQUIRE((long)a.Np * bf16_row_slots(a.DV, a.ns) * 2 < (1L << 31) && (long)a.ns * a.DV * a.Np * 2 < (1L << 31), HN_E_UNSUPPORTED,
+             "attn_core_bf16: one sample's context must span < 2 GiB (N=%d)", a.N);
   constexpr int NQ = 4;
   const int ngroups = ceil_div(a.Lp / 16, NQ);
   const int wpb = ngroups < 4 ? ngroups : 4;
@@ -219,8 +259,12 @@ int launch_attn_core_bf16(const AttnCoreBf16Args &a, hipStream_t s) {
   const long blocks = (long)a.nsplit * gy * a.b * a.h;
   HN_REQUIRE(blocks < (1L << 31), HN_E_UNSUPPORTED, "attn_core_bf16: grid too large");
   dim3 grid((unsigned)blocks), block(64 * wpb);
-  if (a.DV == 16) hipLaunchKernelGGL((attn_core_bf16_kernel<1, NQ>), grid, block, 0, s, a, ngroups, gy, wpb);
-  else hipLaunchKernelGGL((attn_core_bf16_kernel<2, NQ>), grid, block, 0, s, a, ngroups, gy, wpb);
+#define HN_CORE16(DT_, NS_) hipLaunchKernelGGL((attn_core_bf16_kernel<DT_, NQ, NS_>), grid, block, 0, s, a, ngroups, gy, wpb)
+  if (a.DV == 16 && a.ns == 1) HN_CORE16(1, 1);
+  else if (a.DV == 16) HN_CORE16(1, 2);
+  else if (a.ns == 1) HN_CORE16(2, 1);
+  else HN_CORE16(2, 2);
+#undef HN_CORE16
   HN_LAUNCH_CHECK("attn_core_bf16");
   return HN_OK;
 }
@@ -234,9 +278,13 @@ __device__ __forceinline__ uint16_t f2bf(float f) {       // round to nearest ev
   return (uint16_t)(u >> 16);
 }
 
+__device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float((unsigned)h << 16); }
+
+// q-side slot image (see the kernel header): ns == 1: [qh(32)];  ns == 2, DV == 16: [qh(16) qh(16)] [ql(16) 0];
+// ns == 2, DV == 32: [qh(32)] [qh(32)] [ql(32)]
 __global__ __launch_bounds__(256) void qfold_bf16_kernel(const float *__restrict__ Q, int ldq_row, const float *__restrict__ w_k,
                                                          int D, const float *__restrict__ gamma, float cscale,
-                                                         uint16_t *__restrict__ Qf, int h, int L, int Lp, int dh) {
+                                                         uint16_t *__restrict__ Qf, int h, int L, int Lp, int dh, int DV, int ns) {
   extern __shared__ float wk[];  // [dh][32]
   const int bh = blockIdx.x, bi = bh / h, hi = bh % h;
   for (int idx = threadIdx.x; idx < dh * 32; idx += blockDim.x) {
@@ -244,7 +292,8 @@ __global__ __launch_bounds__(256) void qfold_bf16_kernel(const float *__restrict
     wk[idx] = d < D ? w_k[(long)(hi * dh + e) * D + d] * (gamma ? gamma[d] : 1.0f) * cscale : 0.0f;
   }
   __syncthreads();
-  uint16_t *dst = Qf + (long)bh * Lp * 32;
+  const int zp = bf16_row_slots(DV, ns);
+  uint16_t *dst = Qf + (long)bh * Lp * zp;
   for (int idx = threadIdx.x; idx < Lp * 32; idx += blockDim.x) {
     const int q = idx >> 5, d = idx & 31;
     float acc = 0.0f;
@@ -252,15 +301,26 @@ __global__ __launch_bounds__(256) void qfold_bf16_kernel(const float *__restrict
       const float *qr = Q + ((long)bi * L + q) * ldq_row + hi * dh;
       for (int e = 0; e < dh; ++e) acc = fmaf(qr[e], wk[e * 32 + d], acc);
     }
-    dst[idx] = f2bf(acc);
+    const uint16_t hi16 = f2bf(acc);
+    uint16_t *row = dst + (long)q * zp;
+    if (ns == 1) {
+      row[d] = hi16;
+    } else {
+      const uint16_t lo16 = f2bf(acc - bf2f(hi16));
+      if (DV == 16) {
+        if (d < 16) { row[d] = hi16; row[16 + d] = hi16; row[32 + d] = lo16; row[48 + d] = 0; }
+      } else {
+        row[d] = hi16; row[32 + d] = hi16; row[64 + d] = lo16;
+      }
+    }
   }
 }
 
 int launch_qfold_bf16(const float *Q, int ldq_row, const float *w_k, int D, const float *gamma, float cscale, uint16_t *Qf,
-                      int b, int h, int L, int Lp, int dh, hipStream_t s) {
-  HN_REQUIRE(D <= 32, HN_E_SHAPE, "qfold_bf16: D=%d", D);
+                      int b, int h, int L, int Lp, int dh, int DV, int ns, hipStream_t s) {
+  HN_REQUIRE(D <= DV - 1 && (ns == 1 || ns == 2), HN_E_SHAPE, "qfold_bf16: D=%d DV=%d ns=%d", D, DV, ns);
   hipLaunchKernelGGL(qfold_bf16_kernel, dim3(b * h), dim3(256), (size_t)dh * 32 * sizeof(float), s, Q, ldq_row, w_k, D, gamma,
-                     cscale, Qf, h, L, Lp, dh);
+                     cscale, Qf, h, L, Lp, dh, DV, ns);
   HN_LAUNCH_CHECK("qfold_bf16");
   return HN_OK;
 }

@@ -130,7 +130,7 @@ int launch_encode(const void *data, int in_dtype, int b, int n_axes, const int *
                   int fourier, int normalize, float eps, float *out, int ld_out, hipStream_t s, int ones_col = -1,
                   int pack_ks = 0);
 int launch_encode_bf16ctx(const void *data, int in_dtype, int b, int n_axes, const int *spatial, int C, int F, float max_freq,
-                          int fourier, float eps, uint16_t *zb, uint16_t *zT, int Np, int DV, hipStream_t s);
+                          int fourier, float eps, uint16_t *zb, uint16_t *zT, int Np, int DV, int ns, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
 // attention pieces
@@ -157,10 +157,13 @@ struct AttnCoreBf16Args {                        // bf16-MFMA core of the shared
   float *Opart, *Mpart, *Lpart;                  // (b, h, nsplit, Lp, DV), (b, h, nsplit, Lp) x2
   int b, h, Lq, Lp, N, Np, DV;
   int nsplit, chunk;                             // tokens per split (multiple of 32)
+  int ns;                                        // operand planes: 1 = plain bf16, 2 = hi + lo pairs ("bf16x3")
 };
+// bf16 slots per context / query row of the QK^T contraction (see attention_bf16.hip)
+__host__ __device__ constexpr int bf16_row_slots(int DV, int ns) { return ns == 1 ? 32 : (DV == 16 ? 64 : 96); }
 int launch_attn_core_bf16(const AttnCoreBf16Args &a, hipStream_t s);
 int launch_qfold_bf16(const float *Q, int ldq_row, const float *w_k, int D, const float *gamma, float cscale, uint16_t *Qf,
-                      int b, int h, int L, int Lp, int dh, hipStream_t s);
+                      int b, int h, int L, int Lp, int dh, int DV, int ns, hipStream_t s);
 void attn_core_geometry(int b, int h, int Lp, int N, int dp, int *nsplit, int *chunk);
 
 int launch_qfold(const float *Q, int ldq_row, const float *w_k, int D, const float *gamma, float cscale,

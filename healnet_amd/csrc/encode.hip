@@ -242,11 +242,13 @@ int launch_encode(const void *data, int in_dtype, int b, int n_axes, const int *
 
 // ------------------------------------------------------------------------------------------------
 // bf16 context images for attn_core_bf16_kernel (attention_bf16.hip): per sample
-//   zb (Np, 32)  token-major, channel c at slot c, zero beyond D, zero rows for the padding tokens n >= N
-//   zT (DV, Np)  channel-major, row DV-1 = 1.0 on valid tokens (softmax denominator), zero padding tokens
-// Always the affine-free LayerNorm of the encoded token, rounded to bf16 once.
+//   zb (Np, ZP)      token-major QK^T operand, ZP = bf16_row_slots(DV, ns); zero rows for the padding tokens n >= N
+//                    ns == 1: [zh(32)]   ns == 2, DV == 16: [zh(16) zl(16)] [zh(16) 0]   ns == 2, DV == 32: [zh] [zl] [zh]
+//   zT (ns, DV, Np)  channel-major P V operand planes (hi, lo); row DV-1 of the hi plane = 1.0 on valid tokens
+//                    (softmax denominator), zero on padding tokens and in the lo plane
+// zh = bf16(z), zl = bf16(z - zh) of the affine-free LayerNorm z of the encoded token.
 // ------------------------------------------------------------------------------------------------
-template <typename IN>
+template <typename IN, int NS>
 __global__ __launch_bounds__(256) void encode_bf16ctx_kernel(const IN *__restrict__ data, uint16_t *__restrict__ zb,
                                                              uint16_t *__restrict__ zT, EncGeom g, int Np, int DV, long total) {
   long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -282,33 +284,56 @@ __global__ __launch_bounds__(256) void encode_bf16ctx_kernel(const IN *__restric
 #pragma unroll
     for (int c = 0; c < kMaxNarrow; ++c) v[c] = (c < g.D) ? (v[c] - mean) * rstd : 0.0f;
   }
-  unsigned w[kMaxNarrow / 2];
+  uint16_t hi[kMaxNarrow], lo[kMaxNarrow];
 #pragma unroll
-  for (int c = 0; c < kMaxNarrow; c += 2) w[c / 2] = (unsigned)to_bf16(v[c]) | ((unsigned)to_bf16(v[c + 1]) << 16);
-  uint4 *dst = (uint4 *)(zb + gid * 32);
+  for (int c = 0; c < kMaxNarrow; ++c) {
+    hi[c] = to_bf16(v[c]);
+    lo[c] = NS == 2 ? to_bf16(v[c] - __uint_as_float((unsigned)hi[c] << 16)) : (uint16_t)0;
+  }
+  // token-major row: slot s of the row image
+  const int zp = bf16_row_slots(DV, NS);
+  uint4 *dst = (uint4 *)(zb + gid * zp);
+  auto slot = [&](int s) -> unsigned {         // s is a compile-time constant after unrolling
+    if (NS == 1) return hi[s];
+    if (DV == 16) return s < 16 ? hi[s] : (s < 32 ? lo[s - 16] : (s < 48 ? hi[s - 32] : 0));
+    return s < 32 ? hi[s] : (s < 64 ? lo[s - 32] : hi[s - 64]);
+  };
+  if (NS == 1 || DV == 16) {
 #pragma unroll
-  for (int q = 0; q < 4; ++q) dst[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
-  uint16_t *col = zT + bi * (long)DV * Np + n;
+    for (int q = 0; q < (NS == 1 ? 4 : 8); ++q)
+      dst[q] = make_uint4(slot(8 * q) | (slot(8 * q + 1) << 16), slot(8 * q + 2) | (slot(8 * q + 3) << 16),
+                          slot(8 * q + 4) | (slot(8 * q + 5) << 16), slot(8 * q + 6) | (slot(8 * q + 7) << 16));
+  } else {
+#pragma unroll
+    for (int q = 0; q < 12; ++q)
+      dst[q] = make_uint4(slot(8 * q) | (slot(8 * q + 1) << 16), slot(8 * q + 2) | (slot(8 * q + 3) << 16),
+                          slot(8 * q + 4) | (slot(8 * q + 5) << 16), slot(8 * q + 6) | (slot(8 * q + 7) << 16));
+  }
+  uint16_t *col = zT + bi * (long)NS * DV * Np + n;
 #pragma unroll
   for (int c = 0; c < kMaxNarrow; ++c)
-    if (c < DV) col[(long)c * Np] = c == DV - 1 ? (valid ? (uint16_t)0x3f80 : (uint16_t)0) : to_bf16(v[c]);
+    if (c < DV) {
+      col[(long)c * Np] = c == DV - 1 ? (valid ? (uint16_t)0x3f80 : (uint16_t)0) : hi[c];
+      if (NS == 2) col[(long)(DV + c) * Np] = c == DV - 1 ? (uint16_t)0 : lo[c];
+    }
 }
 
 int launch_encode_bf16ctx(const void *data, int in_dtype, int b, int n_axes, const int *spatial, int C, int F, float max_freq,
-                          int fourier, float eps, uint16_t *zb, uint16_t *zT, int Np, int DV, hipStream_t s) {
+                          int fourier, float eps, uint16_t *zb, uint16_t *zT, int Np, int DV, int ns, hipStream_t s) {
   HN_REQUIRE(data && zb && zT, HN_E_NULL, "encode_bf16ctx: NULL pointer");
   HN_REQUIRE(in_dtype == HN_F32 || in_dtype == HN_BF16, HN_E_UNSUPPORTED, "encode: dtype=%d (0 = fp32, 1 = bf16)", in_dtype);
+  HN_REQUIRE(ns == 1 || ns == 2, HN_E_UNSUPPORTED, "encode_bf16ctx: ns=%d", ns);
   EncGeom g;
   int rc = fill_geom(&g, b, n_axes, spatial, C, F, max_freq, fourier, 1, eps);
   if (rc != HN_OK) return rc;
   HN_REQUIRE(g.D <= DV - 1 && (DV == 16 || DV == 32) && Np % 32 == 0 && Np >= g.N, HN_E_SHAPE,
              "encode_bf16ctx: D=%d DV=%d Np=%d N=%ld", g.D, DV, Np, g.N);
   const long total = (long)b * Np;
-  const long blocks = ceil_div_ll(total, 256);
-  if (in_dtype == HN_BF16)
-    hipLaunchKernelGGL((encode_bf16ctx_kernel<uint16_t>), dim3((unsigned)blocks), dim3(256), 0, s, (const uint16_t *)data, zb, zT, g, Np, DV, total);
-  else
-    hipLaunchKernelGGL((encode_bf16ctx_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, s, (const float *)data, zb, zT, g, Np, DV, total);
+  const dim3 grid((unsigned)ceil_div_ll(total, 256)), block(256);
+#define HN_ENC16(T_, NS_) hipLaunchKernelGGL((encode_bf16ctx_kernel<T_, NS_>), grid, block, 0, s, (const T_ *)data, zb, zT, g, Np, DV, total)
+  if (in_dtype == HN_BF16) { if (ns == 1) HN_ENC16(uint16_t, 1); else HN_ENC16(uint16_t, 2); }
+  else { if (ns == 1) HN_ENC16(float, 1); else HN_ENC16(float, 2); }
+#undef HN_ENC16
   HN_LAUNCH_CHECK("encode_bf16ctx");
   return HN_OK;
 }

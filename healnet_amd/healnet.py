@@ -364,10 +364,11 @@ class HealNet(nn.Module):
                  self_per_cross_attn: int = 1, final_classifier_head: bool = True, snn: bool = True,
                  core_precision: str = "fp32"):
         super().__init__()
-        if core_precision not in ("fp32", "bf16"):
-            raise ValueError("core_precision must be 'fp32' or 'bf16'")
+        if core_precision not in ("fp32", "bf16", "bf16x3"):
+            raise ValueError("core_precision must be 'fp32', 'bf16' or 'bf16x3'")
         # Extension over the reference signature: matrix-instruction precision of the image / volume cross-attention
-        # core in the no-grad forward ('bf16' = BASELINE configs[2]; parameters, statistics and outputs stay fp32).
+        # core in the no-grad forward ('bf16' = BASELINE configs[2]; 'bf16x3' = bf16 MFMA on hi+lo operand pairs, fp32-class
+        # results; parameters, statistics and outputs stay fp32).
         self.core_precision = core_precision
         assert len(channel_dims) == len(num_spatial_axes), 'input channels and input axis must be of the same length'
         assert len(num_spatial_axes) == n_modalities, 'input axis must be of the same length as the number of modalities'
@@ -450,7 +451,7 @@ class HealNet(nn.Module):
             head_norm_b=_ptr(self.to_logits[1].bias) if self.final_classifier_head else None,
             head_w=_ptr(self.to_logits[2].weight) if self.final_classifier_head else None,
             head_b=_ptr(self.to_logits[2].bias) if self.final_classifier_head else None,
-            core_precision=_capi.HN_CORE_BF16 if self.core_precision == "bf16" else _capi.HN_CORE_F32)
+            core_precision={"fp32": _capi.HN_CORE_F32, "bf16": _capi.HN_CORE_BF16, "bf16x3": _capi.HN_CORE_BF16X3}[self.core_precision])
         keep.extend([cross_attn, cross_ff, self_attn, self_ff, cd, ax])
         return model, keep
 

@@ -49,8 +49,11 @@ typedef enum hn_dtype { HN_F32 = 0, HN_BF16 = 1 } hn_dtype;
  * HN_CORE_F32  fp32 MFMA on the fp32 context (default; the <= 1e-3 parity configuration);
  * HN_CORE_BF16 bf16 MFMA with fp32 accumulation: context, folded queries and probabilities rounded to bf16 once
  *              (BASELINE configs[2], tolerance 2e-2 max-norm against the fp32 oracle).  Everything else -- LayerNorms,
- *              projections, softmax statistics, feed-forward, head -- stays fp32.  Training always uses HN_CORE_F32. */
-typedef enum hn_core_precision { HN_CORE_F32 = 0, HN_CORE_BF16 = 1 } hn_core_precision;
+ *              projections, softmax statistics, feed-forward, head -- stays fp32.  Training always uses HN_CORE_F32.
+ * HN_CORE_BF16X3 bf16 MFMA on hi + lo operand pairs (hi = bf16(v), lo = bf16(v - hi)), products hi*hi + hi*lo + lo*hi
+ *              accumulated in fp32: 16 operand mantissa bits, fp32-class results (same <= 1e-3 parity bound as
+ *              HN_CORE_F32; the tests run it against the same fixtures with the same tolerances). */
+typedef enum hn_core_precision { HN_CORE_F32 = 0, HN_CORE_BF16 = 1, HN_CORE_BF16X3 = 2 } hn_core_precision;
 
 int hn_abi_version(void);
 const char *hn_last_error_string(void);

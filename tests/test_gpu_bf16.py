@@ -121,3 +121,85 @@ def test_cfg3_full_size_bf16(hn):
     # a missing volume falls back to the two remaining modalities
     y2 = low([tab[:4], img[:4], None])
     assert rel_err(y2, ref([tab[:4], img[:4], None])) <= TOL_BF16
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# core_precision='bf16x3': bf16 MFMA on hi + lo operand pairs.  Held to the fp32 configuration's tolerances.
+# ---------------------------------------------------------------------------------------------------------------
+TOL = 1e-3
+
+
+@pytest.mark.parametrize("name", ["m1_d1", "m2_d3", "m3_d3", "m2_d3_tied", "m2_d2_noself", "m2_d2_nofourier", "m2_d2_gelu",
+                                  "m2_d2_nohead", "m2_d2_bands4", "m2_d2_masked"])
+def test_bf16x3_tiny_models_match_reference_fixtures(hn, name, manifest):
+    from conftest import assert_close
+    model, ins, g = _g5_model(hn, manifest, name, core_precision="bf16x3")
+    mask = g["mask"].to(DEV) if "mask" in g else None
+    ins = [t.to(DEV) for t in ins]
+    assert_close(model(list(ins), mask=mask).cpu(), g["logits"], rel=2e-4, what=name + ".logits")
+    if "emb" in g:
+        assert_close(model(list(ins), mask=mask, return_embeddings=True).cpu(), g["emb"], rel=2e-4, what=name + ".emb")
+    if "attn0" in g:
+        model(list(ins), mask=mask)
+        got = model.get_attention_weights()
+        i = 0
+        while f"attn{i}" in g:
+            assert_close(got[i].cpu(), g[f"attn{i}"], rel=5e-4, what=f"{name}.attn{i}")
+            i += 1
+    if "logits_missing1" in g:
+        miss = [ins[0], None] + ins[2:]
+        assert_close(model(list(miss)).cpu(), g["logits_missing1"], rel=2e-4, what=name + ".missing1")
+
+
+@pytest.mark.parametrize("name", ["cfg1", "cfg3s", "tuned"])
+def test_bf16x3_default_size_configs_match_reference_fixtures(hn, name, manifest):
+    from conftest import assert_close
+    m = manifest["g6_" + name]
+    cfg = O.FusionConfig(**m["kwargs"])
+    model = hn.HealNet(**m["kwargs"], core_precision="bf16x3").eval()
+    model.load_state_dict(O.filler_state_dict(cfg, gain=m["gain"]), strict=True)
+    model.to(DEV)
+    ins = [O.filler_input(s, 20 + i).to(DEV) for i, s in enumerate(m["shapes"])]
+    g = load_golden("g6_" + name)
+    assert_close(model(list(ins)).cpu(), g["logits"], rel=TOL, floor=0.0, abs_floor=1e-5, what=name + ".logits")
+    assert_close(model(list(ins), return_embeddings=True).cpu(), g["emb"], rel=TOL, what=name + ".emb")
+    big = int(g["attn_mean_index"])
+    model(list(ins))
+    p = model.layers[0][2 * big].fn.attn_weights
+    assert_close(p.mean(dim=1)[:, :4096].cpu(), g["attn_mean"], rel=TOL, floor=1e-3, what=name + ".attn_mean")
+
+
+def test_bf16x3_kat0_and_ragged(hn, manifest):
+    from conftest import assert_close
+    g = load_golden("kat0")
+    torch.manual_seed(0)
+    model = hn.HealNet(**manifest["kat0"]["kwargs"], core_precision="bf16x3").eval()
+    tab = torch.rand(4, 1, 2000)
+    img = torch.rand(4, 224, 224, 3)
+    model.to(DEV)
+    y = model([tab.to(DEV), img.to(DEV)]).cpu()
+    assert_close(y, g["logits"], rel=TOL, what="kat0.logits")
+    # ragged / masked contexts against the fp32 core
+    torch.manual_seed(3)
+    kw = dict(n_modalities=2, channel_dims=[5, 3], num_spatial_axes=[1, 2], out_dims=3, depth=2, l_c=24, l_d=32,
+              x_heads=2, l_heads=2, cross_dim_head=32, latent_dim_head=16)
+    ref = hn.HealNet(**kw).eval().to(DEV)
+    x3 = hn.HealNet(**kw, core_precision="bf16x3").eval().to(DEV)
+    x3.load_state_dict(ref.state_dict())
+    for (h, w) in [(7, 11), (1, 33), (9, 31)]:
+        n = h * w
+        seq = torch.rand(3, n, 5, device=DEV)
+        img = torch.rand(3, h, w, 3, device=DEV)
+        mask = torch.rand(3, n, device=DEV) > 0.4
+        mask[1] = False
+        mask[1, n // 2] = True
+        assert rel_err(x3([seq, img]), ref([seq, img])) <= 1e-4
+        assert rel_err(x3([seq, img], mask=mask), ref([seq, img], mask=mask)) <= 1e-4
+    # a volume (D = 18: the three-block contraction layout)
+    kw = dict(n_modalities=1, channel_dims=[3], num_spatial_axes=[3], out_dims=2, depth=1, l_c=16, l_d=32, x_heads=2,
+              cross_dim_head=32, latent_dim_head=16, l_heads=2)
+    ref = hn.HealNet(**kw).eval().to(DEV)
+    x3 = hn.HealNet(**kw, core_precision="bf16x3").eval().to(DEV)
+    x3.load_state_dict(ref.state_dict())
+    vol = torch.rand(2, 5, 9, 7, 3, device=DEV)
+    assert rel_err(x3([vol]), ref([vol])) <= 1e-4
