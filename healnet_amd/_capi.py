@@ -94,6 +94,8 @@ SIGNATURES = {
     "hn_attn_workspace_bytes": (C.c_size_t, [C.POINTER(AttnParams), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "hn_attn_probs": (C.c_int, [C.POINTER(AttnParams), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "hn_attn_importance": (C.c_int, [C.POINTER(AttnParams), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "hn_ff_fwd": (C.c_int, [C.POINTER(FFParams), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "hn_ff_workspace_bytes": (C.c_size_t, [C.POINTER(FFParams), C.c_int]),
     "hn_attn_saved_floats": (C.c_size_t, [C.POINTER(AttnParams)] + [C.c_int] * 7),

@@ -884,6 +884,23 @@ int hn_attn_probs(const hn_attn_params *p, const float *x_in, const float *ctx, 
                       mask, stats, probs, b, p->heads, L, pl.N, s);
 }
 
+int hn_attn_importance(const hn_attn_params *p, const float *x_in, const float *ctx, int ld_ctx, int b, int L, int N, int D,
+                       const uint8_t *mask, const float *stats, float *importance, void *workspace, size_t workspace_bytes,
+                       void *stream) {
+  HN_REQUIRE(p && x_in && stats && importance, HN_E_NULL, "attn_importance: NULL pointer");
+  hipStream_t s = (hipStream_t)stream;
+  AttnPlan pl;
+  int rc = plan_attn(p, ctx != nullptr, ld_ctx, b, L, N, D, nullptr, 0, &pl);
+  if (rc != HN_OK) return rc;
+  if ((rc = check_ws(workspace, workspace_bytes, pl.bytes, "attn_importance")) != HN_OK) return rc;
+  if ((rc = plan_attn(p, ctx != nullptr, ld_ctx, b, L, N, D, workspace, workspace_bytes, &pl)) != HN_OK) return rc;
+  if (ctx != nullptr && pl.N == 1 && mask == nullptr) return launch_fill(importance, 1.0f, (long)b * p->heads, s);
+  AttnCoreArgs core;
+  if ((rc = attn_prepare(p, pl, x_in, ctx, ld_ctx, b, L, s, &core)) != HN_OK) return rc;
+  return launch_importance(core.Q, core.q_b, core.q_h, core.ldq, pl.rank_d ? pl.D : pl.dh, core.Kp, core.k_b, core.k_h,
+                           core.ldk, mask, stats, importance, b, p->heads, L, pl.N, s);
+}
+
 size_t hn_attn_saved_floats(const hn_attn_params *p, int has_ctx, int ld_ctx, int b, int L, int N, int D, int masked) {
   AttnPlan pl;
   if (plan_attn(p, has_ctx != 0, ld_ctx, b, L, N, D, nullptr, 0, &pl) != HN_OK) return 0;

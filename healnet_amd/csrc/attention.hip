@@ -594,4 +594,51 @@ int launch_probs(const float *Q, long q_b, long q_h, int ldq, int dp, const floa
   return HN_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Reduced export for the explainer: every consumer of Attention.attn_weights in the reference
+// takes the mean over the latent rows first (healnet/models/explainer.py:161-164, :209-211: `torch.mean(w, dim=1)`),
+//   I[bh, t] = 1/L * sum_q P[bh, q, t]
+// so this kernel emits the (b*h, N) vector straight from the saved softmax statistics instead of the
+// (b*h, L, N) matrix (6.6 GB per image block at b = 32).  Same tiling as probs_kernel; the four row groups of a
+// workgroup are summed in a fixed order through LDS (deterministic).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void importance_kernel(const float *__restrict__ Q, long q_b, long q_h, int ldq, int dp,
+                                                         const float *__restrict__ Kp, long k_b, long k_h, int ldk,
+                                                         const uint8_t *__restrict__ mask, const float *__restrict__ stats,
+                                                         float *__restrict__ I, int h, int L, int N) {
+  extern __shared__ float ks[];  // [64][dp + 1] + [4][64]
+  float *part = ks + 64 * (dp + 1);
+  const int bh = blockIdx.y, bi = bh / h, hi = bh % h;
+  const int t0 = blockIdx.x * 64;
+  const float *kbase = Kp + (long)bi * k_b + (long)hi * k_h;
+  for (int idx = threadIdx.x; idx < 64 * dp; idx += blockDim.x) {
+    const int tt = idx / dp, d = idx % dp;
+    const int t = min(t0 + tt, N - 1);
+    ks[tt * (dp + 1) + d] = kbase[(long)t * ldk + d];
+  }
+  __syncthreads();
+  const int tt = threadIdx.x & 63, t = t0 + tt, grp = threadIdx.x >> 6;
+  const bool live = t < N && (!mask || mask[(long)bi * N + t] != 0);
+  const float *qb = Q + (long)bi * q_b + (long)hi * q_h;
+  float sum = 0.0f;
+  for (int q = grp; q < L; q += 4) {
+    float acc = 0.0f;
+    for (int d = 0; d < dp; ++d) acc = fmaf(qb[(long)q * ldq + d], ks[tt * (dp + 1) + d], acc);
+    const float M = stats[((long)bh * L + q) * 2 + 0], Ls = stats[((long)bh * L + q) * 2 + 1];
+    sum += live ? fast_exp2(acc - M) / Ls : 0.0f;
+  }
+  part[grp * 64 + tt] = sum;
+  __syncthreads();
+  if (grp == 0 && t < N) I[(long)bh * N + t] = (((part[tt] + part[64 + tt]) + part[128 + tt]) + part[192 + tt]) / (float)L;
+}
+
+int launch_importance(const float *Q, long q_b, long q_h, int ldq, int dp, const float *Kp, long k_b, long k_h, int ldk,
+                      const uint8_t *mask, const float *stats, float *I, int b, int h, int L, int N, hipStream_t s) {
+  size_t lds = ((size_t)64 * (dp + 1) + 256) * sizeof(float);
+  hipLaunchKernelGGL(importance_kernel, dim3(ceil_div(N, 64), b * h), dim3(256), lds, s, Q, q_b, q_h, ldq, dp, Kp, k_b, k_h,
+                     ldk, mask, stats, I, h, L, N);
+  HN_LAUNCH_CHECK("importance");
+  return HN_OK;
+}
+
 }  // namespace hn

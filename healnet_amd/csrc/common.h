@@ -175,6 +175,8 @@ int launch_merge_explicit(const float *Opart, const float *Mpart, const float *L
                           int L, int Lp, int dp, int dh, float *O, int ldo, float *stats, hipStream_t s);
 int launch_probs(const float *Q, long q_b, long q_h, int ldq, int dp, const float *Kp, long k_b, long k_h, int ldk,
                  const uint8_t *mask, const float *stats, float *P, int b, int h, int L, int N, hipStream_t s);
+int launch_importance(const float *Q, long q_b, long q_h, int ldq, int dp, const float *Kp, long k_b, long k_h, int ldk,
+                      const uint8_t *mask, const float *stats, float *I, int b, int h, int L, int N, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
 // backward building blocks (backward.hip)

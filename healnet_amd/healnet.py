@@ -142,6 +142,12 @@ class Attention(nn.Module):
     def attn_weights(self) -> Optional[torch.Tensor]:
         return None if self._probs_fn is None else self._probs_fn()
 
+    @property
+    def attn_importance(self) -> Optional[torch.Tensor]:
+        """``attn_weights.mean(dim=1)`` -- the (b*heads, N) row-mean every consumer in the reference's explainer takes
+        (explainer.py:161-164, :209-211) -- computed without materialising the (b*heads, L, N) matrix."""
+        return None if self._probs_fn is None else self._probs_fn(reduced=True)
+
     def _params(self, norm: Optional[nn.LayerNorm], norm_context: Optional[nn.LayerNorm]) -> _capi.AttnParams:
         return _capi.AttnParams(
             heads=self.heads, dim_head=self.dim_head, query_dim=self.query_dim,
@@ -199,13 +205,14 @@ class Attention(nn.Module):
                                     _ptr(mask_u8), stats.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(x.device)),
                     "hn_attn_fwd")
 
-        def probs() -> torch.Tensor:
-            pr = torch.empty(b * self.heads, L, N, dtype=torch.float32, device=x.device)
+        def probs(reduced: bool = False) -> torch.Tensor:
+            pr = torch.empty((b * self.heads, N) if reduced else (b * self.heads, L, N), dtype=torch.float32, device=x.device)
             pp = self._params(norm, norm_context)
             aux = _WS_AUX.get(x.device, need)
-            _capi.check(lib.hn_attn_probs(C.byref(pp), x.data_ptr(), _ptr(ctx_z), ld, b, L, N, D, _ptr(mask_u8),
-                                          stats.data_ptr(), pr.data_ptr(), aux.data_ptr(), aux.numel(),
-                                          _stream_ptr(x.device)), "hn_attn_probs")
+            fn = lib.hn_attn_importance if reduced else lib.hn_attn_probs
+            _capi.check(fn(C.byref(pp), x.data_ptr(), _ptr(ctx_z), ld, b, L, N, D, _ptr(mask_u8), stats.data_ptr(),
+                           pr.data_ptr(), aux.data_ptr(), aux.numel(), _stream_ptr(x.device)),
+                        "hn_attn_importance" if reduced else "hn_attn_probs")
             return pr
 
         self._probs_fn = probs
@@ -615,7 +622,7 @@ class HealNet(nn.Module):
                 blk = self.layers[layer][2 * j] if j < M else self.layers[layer][2 * M][0]
                 att: Attention = blk.fn
 
-                def probs(layer=layer, j=j, slot=slot, blk=blk, att=att):
+                def probs(reduced=False, layer=layer, j=j, slot=slot, blk=blk, att=att):
                     b, L = last["b"], self.l_c
                     xin, stats = last["trace"][slot], last["stats"][slot]
                     dev = xin.device
@@ -641,10 +648,11 @@ class HealNet(nn.Module):
                         msk = None
                     need = lib.hn_attn_workspace_bytes(C.byref(p), int(z is not None), ld, b, L, n, d)
                     aux = _WS_AUX.get(dev, need)
-                    pr = torch.empty(b * att.heads, L, n, dtype=torch.float32, device=dev)
-                    _capi.check(lib.hn_attn_probs(C.byref(p), xin.data_ptr(), _ptr(z), ld, b, L, n, d, _ptr(msk),
-                                                  stats.data_ptr(), pr.data_ptr(), aux.data_ptr(), aux.numel(),
-                                                  _stream_ptr(dev)), "hn_attn_probs")
+                    pr = torch.empty((b * att.heads, n) if reduced else (b * att.heads, L, n), dtype=torch.float32, device=dev)
+                    fn = lib.hn_attn_importance if reduced else lib.hn_attn_probs
+                    _capi.check(fn(C.byref(p), xin.data_ptr(), _ptr(z), ld, b, L, n, d, _ptr(msk), stats.data_ptr(),
+                                   pr.data_ptr(), aux.data_ptr(), aux.numel(), _stream_ptr(dev)),
+                                "hn_attn_importance" if reduced else "hn_attn_probs")
                     return pr
 
                 att._probs_fn = probs
@@ -653,3 +661,9 @@ class HealNet(nn.Module):
         """Every ``Attention.attn_weights`` in ``self.modules()`` order (healnet.py:252-262): per layer
         [cross_0 .. cross_{M-1}, self]; shape (b*heads, l_c, N) each, ``None`` for blocks that did not run."""
         return [mod.attn_weights for mod in self.modules() if isinstance(mod, Attention)]
+
+    def get_attention_importance(self) -> List[Optional[torch.Tensor]]:
+        """``[w.mean(dim=1) for w in get_attention_weights()]`` -- shape (b*heads, N) each -- without ever forming the
+        (b*heads, l_c, N) matrices: the reduction the reference's explainer applies to every entry (explainer.py:161-164,
+        :209-211).  Same order and ``None`` convention as ``get_attention_weights``."""
+        return [mod.attn_importance for mod in self.modules() if isinstance(mod, Attention)]

@@ -116,6 +116,13 @@ int hn_attn_probs(const hn_attn_params *p, const float *x_in, const float *ctx, 
                   int N, int D, const uint8_t *mask, const float *stats, float *probs, void *workspace,
                   size_t workspace_bytes, void *stream);
 
+/* Reduced export for the explainer: importance (b*heads, N) = mean over the L latent rows of
+ * Attention.attn_weights -- what healnet/models/explainer.py:161-164 and :209-211 compute from the full matrix
+ * (`torch.mean(w, dim=1)`) -- without materialising the (b*heads, L, N) tensor.  Same arguments as hn_attn_probs. */
+int hn_attn_importance(const hn_attn_params *p, const float *x_in, const float *ctx, int ld_ctx, int b, int L,
+                       int N, int D, const uint8_t *mask, const float *stats, float *importance, void *workspace,
+                       size_t workspace_bytes, void *stream);
+
 /* Training forward: identical to hn_attn_fwd but also keeps what hn_attn_bwd needs: `stats` (required) and `saved`
  * (hn_attn_saved_floats() floats: the normalised attention output O for the explicit binding, the normalised
  * context average P z for the rank-D binding, V for a one-token context). */

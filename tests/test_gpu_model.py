@@ -200,3 +200,42 @@ def test_cfg5_shape_depth8_properties(hn):
     assert_close(y2.cpu(), y.cpu(), rel=1e-4, what="cfg5 batch-slicing")
     perm = torch.tensor([2, 0, 3, 1], device=DEV)
     assert_close(model([t[perm] for t in ins]).cpu(), y[perm].cpu(), rel=1e-5, what="cfg5 permutation")
+
+
+@pytest.mark.parametrize("name", ["cfg1", "cfg4"])
+def test_attention_importance_matches_reference_row_means(hn, name, manifest):
+    """the (b*h, N) latent-row mean of attn_weights -- what the reference's explainer reduces every matrix
+    to -- straight from the softmax statistics; expected rows were produced by the reference (fixture attn_mean)."""
+    m = manifest["g6_" + name]
+    cfg = O.FusionConfig(**m["kwargs"])
+    model = hn.HealNet(**m["kwargs"]).eval()
+    model.load_state_dict(O.filler_state_dict(cfg, gain=m["gain"]), strict=True)
+    model.to(DEV)
+    ins = [O.filler_input(s, 20 + i).to(DEV) for i, s in enumerate(m["shapes"])]
+    g = load_golden("g6_" + name)
+    big = int(g["attn_mean_index"])
+    with torch.no_grad():
+        model(list(ins))
+    imp = model.get_attention_importance()
+    full = model.get_attention_weights()
+    assert len(imp) == len(full)
+    for a, w in zip(imp, full):
+        assert a.shape == (w.shape[0], w.shape[2])
+        assert_close(a, w.mean(dim=1), rel=1e-5, floor=1e-6, what="importance vs full matrix")
+    got = model.layers[0][2 * big].fn.attn_importance
+    assert_close(got[:, :4096].cpu(), g["attn_mean"], rel=TOL, floor=1e-3, what=name + ".attn_mean")
+
+
+def test_attention_importance_masked_and_standalone(hn):
+    torch.manual_seed(5)
+    att = hn.Attention(32, 7, heads=2, dim_head=16).to(DEV)
+    x = torch.randn(3, 10, 32, device=DEV)
+    ctx = torch.randn(3, 77, 7, device=DEV)
+    mask = torch.rand(3, 77, device=DEV) > 0.3
+    with torch.no_grad():
+        att(x, context=ctx, mask=mask)
+    w, a = att.attn_weights, att.attn_importance
+    assert a.shape == (6, 77)
+    assert_close(a, w.mean(dim=1), rel=1e-5, floor=1e-6, what="standalone importance")
+    assert float(a[~mask.repeat_interleave(2, dim=0)].abs().max()) == 0.0
+    assert_close(a.sum(-1), torch.ones(6, device=DEV), rel=1e-5, what="rows of a softmax average to a distribution")
