@@ -5,6 +5,7 @@ konst-int-i/healnet.  ``import healnet_amd as healnet`` keeps ``from healnet imp
 from .healnet import Attention, FeedForward, HealNet, PreNorm, fourier_encode_concat
 from .etl import MMDataset
 from . import ops as _ops  # noqa: F401  (registers torch.ops.healnet_hip.*)
+from . import train  # noqa: F401  (survival loss + fused L1/Adam step)
 
 __all__ = ["HealNet", "Attention", "PreNorm", "FeedForward", "MMDataset", "fourier_encode_concat"]
 __version__ = "0.1.0"

@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhealnet_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ["api.hip", "gemm.hip", "attention.hip", "attention_bf16.hip", "attention_bwd.hip", "encode.hip", "misc.hip",
-           "backward.hip"]
+           "backward.hip", "train.hip"]
 
 c_float_p = C.POINTER(C.c_float)
 
@@ -96,6 +96,11 @@ SIGNATURES = {
                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "hn_attn_importance": (C.c_int, [C.POINTER(AttnParams), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "hn_surv_nll": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
+                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hn_l1_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_double, C.c_double, C.c_double,
+                                  C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "hn_l1_adam_workspace_bytes": (C.c_size_t, []),
     "hn_ff_fwd": (C.c_int, [C.POINTER(FFParams), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "hn_ff_workspace_bytes": (C.c_size_t, [C.POINTER(FFParams), C.c_int]),
     "hn_attn_saved_floats": (C.c_size_t, [C.POINTER(AttnParams)] + [C.c_int] * 7),

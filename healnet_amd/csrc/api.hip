@@ -968,6 +968,24 @@ int hn_head_bwd(const float *x, int b, int L, int d, const float *norm_w, const 
                          (float *)workspace, (hipStream_t)stream);
 }
 
+int hn_surv_nll(const float *logits, const int64_t *y, const float *censorship, const float *class_weights, int b, int n_bins,
+                float alpha, float eps, float grad_scale, float *loss, float *dlogits, float *hazards, float *survival,
+                float *risk, void *stream) {
+  return launch_surv_nll(logits, (const long long *)y, censorship, class_weights, b, n_bins, alpha, eps, grad_scale, loss, dlogits,
+                         hazards, survival, risk, (hipStream_t)stream);
+}
+
+size_t hn_l1_adam_workspace_bytes(void) { return L1_ADAM_PARTIALS * sizeof(float); }
+
+int hn_l1_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, long n, double l1, double grad_scale,
+                    double lr, double beta1, double beta2, double eps, int step, float *reg_loss, void *workspace,
+                    size_t workspace_bytes, void *stream) {
+  int rc = check_ws(workspace, workspace_bytes, hn_l1_adam_workspace_bytes(), "l1_adam");
+  if (rc != HN_OK) return rc;
+  return launch_l1_adam(params, grads, exp_avg, exp_avg_sq, n, l1, grad_scale, lr, beta1, beta2, eps, step, reg_loss,
+                        (float *)workspace, (hipStream_t)stream);
+}
+
 size_t hn_fusion_workspace_bytes(const hn_model *model, const hn_modality_input *inputs, int b) {
   FusionPlan fp;
   if (plan_fusion(model, inputs, b, nullptr, 0, &fp, true) != HN_OK) return 0;

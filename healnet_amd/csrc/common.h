@@ -178,6 +178,14 @@ int launch_probs(const float *Q, long q_b, long q_h, int ldq, int dp, const floa
 int launch_importance(const float *Q, long q_b, long q_h, int ldq, int dp, const float *Kp, long k_b, long k_h, int ldk,
                       const uint8_t *mask, const float *stats, float *I, int b, int h, int L, int N, hipStream_t s);
 
+// training-step tail (train.hip)
+int launch_surv_nll(const float *logits, const long long *y, const float *cens, const float *weights, int b, int K, float alpha,
+                    float eps, float grad_scale, float *loss, float *dlogits, float *hazards, float *survival, float *risk,
+                    hipStream_t s);
+constexpr int L1_ADAM_PARTIALS = 1024;
+int launch_l1_adam(float *p, const float *g, float *m, float *v, long n, double l1, double grad_scale, double lr, double beta1,
+                   double beta2, double eps, int step, float *reg_loss, float *partial, hipStream_t s);
+
 // ------------------------------------------------------------------------------------------------
 // backward building blocks (backward.hip)
 // ------------------------------------------------------------------------------------------------

@@ -346,7 +346,18 @@ class _FusionFunction(torch.autograd.Function):
         module, params = ctx.module, ctx.params
         device = module.latents.device
         model, keep = module._descriptor()
-        gmap = {id(p): torch.zeros_like(p, dtype=torch.float32) for p in params if p.requires_grad}
+        # healnet_amd.train.flatten_parameters(): every p.grad is a view of one flat buffer -> the kernels accumulate
+        # straight into it (no per-parameter zero tensors, no AccumulateGrad add pass) and autograd gets None back.
+        flat = getattr(module, "_hn_flat", None)
+        direct = False
+        if flat is not None:
+            lo, hi = flat.grads.data_ptr(), flat.grads.data_ptr() + flat.grads.numel() * 4
+            direct = all((not p.requires_grad) or (p.grad is not None and p.grad.is_contiguous()
+                                                   and lo <= p.grad.data_ptr() < hi) for p in params)
+        if direct:
+            gmap = {id(p): p.grad for p in params if p.requires_grad}
+        else:
+            gmap = {id(p): torch.zeros_like(p, dtype=torch.float32) for p in params if p.requires_grad}
         grads, keep_g = module._grad_descriptor(gmap)
         masked = int(ctx.mask_u8 is not None)
         need = lib.hn_fusion_backward_workspace_bytes(C.byref(model), ctx.inputs, ctx.b, masked)
@@ -357,6 +368,8 @@ class _FusionFunction(torch.autograd.Function):
         _capi.check(lib.hn_fusion_backward(C.byref(model), ctx.inputs, ctx.b, _ptr(ctx.mask_u8), int(ctx.skip_self),
                                            int(ctx.embeddings), dout.data_ptr(), ctx.tape.data_ptr(), C.byref(grads),
                                            ws.data_ptr(), ws.numel(), _stream_ptr(device)), "hn_fusion_backward")
+        if direct:
+            return (None,) * (9 + len(params))
         return (None,) * 9 + tuple(gmap.get(id(p)) for p in params)
 
 

@@ -260,6 +260,28 @@ int hn_fusion_backward(const hn_model *model, const hn_modality_input *inputs, i
                        int skip_self_on_missing, int return_embeddings, const float *dout, const void *tape,
                        const hn_model_grads *grads, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Training-step tail                  replaces healnet/main.py:439-447 + :464-467
+ * ------------------------------------------------------------------------------------------- */
+/* hazards = sigmoid(logits), survival = cumprod(1 - hazards), risk = -sum(survival) (main.py:439-441), the discrete
+ * survival NLL `nll_loss(hazards, S, Y, c, weights, alpha, eps)` (healnet/models/survival_loss.py:9-43; batch mean) and
+ * grad_scale * d loss / d logits in one launch.
+ *   logits (b, n_bins); y (b) int64 bin index; censorship (b) float {0, 1}; class_weights (n_bins) or NULL;
+ *   loss (1); dlogits (b, n_bins) or NULL; hazards / survival (b, n_bins) or NULL; risk (b) or NULL. */
+int hn_surv_nll(const float *logits, const int64_t *y, const float *censorship, const float *class_weights, int b,
+                int n_bins, float alpha, float eps, float grad_scale, float *loss, float *dlogits, float *hazards,
+                float *survival, float *risk, void *stream);
+
+/* One fused pass over flat fp32 buffers of n elements: g = grad_scale * grads + l1 * sign(params) (the gradient of
+ * calc_reg_loss, healnet/utils/train_utils.py:5-14), then torch.optim.Adam's update (main.py:390; step >= 1 is the
+ * 1-based update count; lr / beta1 are per-call because OneCycleLR cycles both, main.py:391-394), and
+ * reg_loss[0] = l1 * sum |params| of the parameters BEFORE the update (the value main.py:449 logs); reg_loss may be
+ * NULL.  Buffers 16-byte aligned; workspace >= hn_l1_adam_workspace_bytes(). */
+int hn_l1_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, long n, double l1,
+                    double grad_scale, double lr, double beta1, double beta2, double eps, int step, float *reg_loss,
+                    void *workspace, size_t workspace_bytes, void *stream);
+size_t hn_l1_adam_workspace_bytes(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, rel_err
+from conftest import assert_close, load_golden, rel_err
 from oracle import healnet_cpu as O
 
 
@@ -117,3 +117,40 @@ def test_kat0_seed_route(manifest):
     assert torch.allclose(g["logits"][0], want_row0, atol=2e-6)
     assert torch.allclose(g["logits"][3], want_row3, atol=2e-6)
     assert abs(float(g["emb_mean"]) - 0.8022665) < 1e-5 and abs(float(g["emb_absmax"]) - 6.958313) < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# training-step tail: oracle/train_cpu.py against fixtures generated from the reference's
+# survival_loss.py / train_utils.py / torch.optim.Adam + OneCycleLR (tools/gen_goldens_train.py)
+# ---------------------------------------------------------------------------------------------------------------
+def test_train_oracle_surv_nll_matches_reference(manifest):
+    from oracle import train_cpu as T
+    g = load_golden("g7_surv_nll")
+    for case in manifest["g7_surv_nll"]["cases"]:
+        t = case["tag"]
+        w = g[t + "weights"] if case["weighted"] else None
+        loss, dl, hz, sv = T.surv_nll(g[t + "logits"], g[t + "y"], g[t + "c"], w, alpha=manifest["g7_surv_nll"]["alpha"],
+                                      eps=manifest["g7_surv_nll"]["eps"])
+        assert abs(float(loss) - float(g[t + "loss"])) <= 1e-6 * max(1.0, abs(float(g[t + "loss"]))), t
+        assert torch.equal(dl, g[t + "dlogits"]), t
+        assert torch.equal(hz, g[t + "hazards"]) and torch.equal(sv, g[t + "survival"]), t
+
+
+def test_train_oracle_l1_adam_matches_reference(manifest):
+    from oracle import train_cpu as T
+    g = load_golden("g7_l1_adam")
+    m = manifest["g7_l1_adam"]
+    ps = [g[f"p{i}_init"].clone() for i in range(len(m["shapes"]))]
+    ms = [torch.zeros_like(p) for p in ps]
+    vs = [torch.zeros_like(p) for p in ps]
+    for t in range(m["n_steps"]):
+        reg = 0.0
+        for i, p in enumerate(ps):
+            q = p.clone().requires_grad_(True)
+            c = g[f"coef{i}"]
+            loss = (((q * c).sum() ** 2 + (q * q * c).sum()) * (0.1 * (t + 1))) / m["gc"]
+            (gr,) = torch.autograd.grad(loss, q)
+            reg += T.l1_adam_step(p, gr, ms[i], vs[i], step=t + 1, l1=m["l1"], lr=float(g["lrs"][t]), beta1=float(g["beta1s"][t]))
+        assert abs(reg - float(g["reg_losses"][t])) <= 1e-5 * float(g["reg_losses"][t])
+        for i, p in enumerate(ps):
+            assert_close(p, g[f"p{i}_step{t}"], rel=2e-6, floor=1e-7, what=f"adam p{i} step{t}")
