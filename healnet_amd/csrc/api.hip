@@ -112,8 +112,16 @@ static GemmArgs gemm_defaults() {
 
 // Steps shared by hn_attn_fwd and hn_attn_probs: the scaled query operand of the attention core and
 // (explicit path) the projected keys / values.
+static float *saved_kv(const AttnPlan &pl, bool has_ctx, bool masked, int b, int L, float *saved) {
+  if (!saved || !has_ctx || pl.rank_d || (pl.N == 1 && !masked)) return nullptr;
+  return saved + align_up((size_t)b * L * pl.inner, 64);
+}
+
+// kv_tape (explicit cross binding, training): the projected K / V live in the tape instead of the workspace; the forward
+// writes them there, the backward (kv_ready) reads them back instead of re-running the K/V projection GEMM.
 static int attn_prepare(const hn_attn_params *p, const AttnPlan &pl, const float *x_in, const float *ctx, int ld_ctx,
-                        int b, int L, hipStream_t s, AttnCoreArgs *core, int pack_ks = 0) {
+                        int b, int L, hipStream_t s, AttnCoreArgs *core, int pack_ks = 0, float *kv_tape = nullptr,
+                        bool kv_ready = false) {
   const int rows = b * L;
   GemmArgs gq = gemm_defaults();
   gq.A = x_in; gq.lda = p->query_dim;
@@ -137,28 +145,31 @@ static int attn_prepare(const hn_attn_params *p, const AttnPlan &pl, const float
     core->ones_col = pl.ones ? 1 : 0;
   } else {
     const int qpitch = p->heads * pl.dhp, kvpitch = 2 * p->heads * pl.dhp;
+    float *kvbuf = kv_tape ? kv_tape : pl.kv;
     if (pl.dhp != pl.dh) {
       HN_HIP_CHECK(hipMemsetAsync(pl.q, 0, (size_t)rows * qpitch * sizeof(float), s));
-      HN_HIP_CHECK(hipMemsetAsync(pl.kv, 0, (size_t)b * pl.N * kvpitch * sizeof(float), s));
+      if (!kv_ready) HN_HIP_CHECK(hipMemsetAsync(kvbuf, 0, (size_t)b * pl.N * kvpitch * sizeof(float), s));
     }
     gq.C = pl.q; gq.ldc = qpitch; gq.alpha = pl.cscale;
     gq.col_group = pl.dh; gq.col_group_pitch = pl.dhp;
     if ((rc = launch_gemm(gq, s)) != HN_OK) return rc;
-    GemmArgs gk = gemm_defaults();
-    if (ctx) {
-      gk.A = ctx; gk.lda = ld_ctx; gk.M = b * pl.N; gk.K = pl.D;
-      if (p->ctx_gamma) { gk.pro = PRO_AFFINE; gk.gamma = p->ctx_gamma; gk.beta = p->ctx_beta; }
-    } else {   // self-attention: context = normalised x (healnet.py:404)
-      gk.A = x_in; gk.lda = p->query_dim; gk.M = rows; gk.K = p->query_dim;
-      if (p->norm_w) { gk.pro = PRO_LAYERNORM; gk.gamma = p->norm_w; gk.beta = p->norm_b; }
+    if (!kv_ready) {
+      GemmArgs gk = gemm_defaults();
+      if (ctx) {
+        gk.A = ctx; gk.lda = ld_ctx; gk.M = b * pl.N; gk.K = pl.D;
+        if (p->ctx_gamma) { gk.pro = PRO_AFFINE; gk.gamma = p->ctx_gamma; gk.beta = p->ctx_beta; }
+      } else {   // self-attention: context = normalised x (healnet.py:404)
+        gk.A = x_in; gk.lda = p->query_dim; gk.M = rows; gk.K = p->query_dim;
+        if (p->norm_w) { gk.pro = PRO_LAYERNORM; gk.gamma = p->norm_w; gk.beta = p->norm_b; }
+      }
+      gk.W = p->w_kv; gk.ldw = pl.D;
+      gk.N = 2 * pl.inner;
+      gk.C = kvbuf; gk.ldc = kvpitch; gk.col_group = pl.dh; gk.col_group_pitch = pl.dhp;
+      if ((rc = launch_gemm(gk, s)) != HN_OK) return rc;
     }
-    gk.W = p->w_kv; gk.ldw = pl.D;
-    gk.N = 2 * pl.inner;
-    gk.C = pl.kv; gk.ldc = kvpitch; gk.col_group = pl.dh; gk.col_group_pitch = pl.dhp;
-    if ((rc = launch_gemm(gk, s)) != HN_OK) return rc;
     core->Q = pl.q; core->q_b = (long)L * qpitch; core->q_h = pl.dhp; core->ldq = qpitch;
-    core->Kp = pl.kv; core->k_b = (long)pl.N * kvpitch; core->k_h = pl.dhp; core->ldk = kvpitch;
-    core->Vp = pl.kv + (long)p->heads * pl.dhp; core->v_b = core->k_b; core->v_h = pl.dhp; core->ldv = kvpitch;
+    core->Kp = kvbuf; core->k_b = (long)pl.N * kvpitch; core->k_h = pl.dhp; core->ldk = kvpitch;
+    core->Vp = kvbuf + (long)p->heads * pl.dhp; core->v_b = core->k_b; core->v_h = pl.dhp; core->ldv = kvpitch;
   }
   return HN_OK;
 }
@@ -236,7 +247,8 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
 
   AttnCoreArgs core;
   const int pack_ks = (pl.rank_d && pl.ones && ctx_has_ones && p->ctx_gamma) ? ctx_pack_ks : 0;
-  if ((rc = attn_prepare(p, pl, x_in, ctx, ld_ctx, b, L, s, &core, pack_ks)) != HN_OK) return rc;
+  if ((rc = attn_prepare(p, pl, x_in, ctx, ld_ctx, b, L, s, &core, pack_ks,
+                         saved_kv(pl, ctx != nullptr, mask != nullptr, b, L, o_save))) != HN_OK) return rc;
   core.mask = mask;
   core.ones_in_mem = (ctx_has_ones && pl.ones) ? 1 : 0;
   const bool direct = !pl.rank_d && pl.nsplit == 1;
@@ -276,7 +288,9 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
 static size_t attn_saved_floats(const AttnPlan &pl, bool has_ctx, bool masked, int b, int L) {
   if (has_ctx && pl.N == 1 && !masked) return (size_t)b * pl.inner;
   if (pl.rank_d) return (size_t)b * L * pl.heads * pl.dp;
-  return (size_t)b * L * pl.inner;
+  // explicit binding: O, and for a cross block also the projected K / V (288 GB of HBM: keeping 134 MB per WSI-bag block
+  // at cfg4 is cheaper than re-running its 52 GF projection in the backward)
+  return align_up((size_t)b * L * pl.inner, 64) + (has_ctx ? (size_t)b * pl.N * 2 * pl.heads * pl.dhp : 0);
 }
 
 struct AttnBwdPlan {
@@ -406,7 +420,8 @@ static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float
 
   // ---- recompute the operands of the core (scaled Q, and K/V or the folded queries)
   AttnCoreArgs core;
-  if ((rc = attn_prepare(p, pl, x_in, ctx, ld_ctx, b, L, s, &core)) != HN_OK) return rc;
+  float *kv_saved = saved_kv(pl, has_ctx, mask != nullptr, b, L, const_cast<float *>(saved));
+  if ((rc = attn_prepare(p, pl, x_in, ctx, ld_ctx, b, L, s, &core, 0, kv_saved, kv_saved != nullptr)) != HN_OK) return rc;
   const float *xhat = x_in;
   if (p->norm_w) {
     if ((rc = launch_ln_fwd(x_in, p->norm_w, p->norm_b, rows, qd, bp.xhat, s)) != HN_OK) return rc;
@@ -593,7 +608,7 @@ static int ff_bwd_impl(const hn_ff_params *p, const float *x_in, const float *dy
   GemmExArgs e = {};
   e.batch = 1; e.alpha = 1.0f;
   e.A = dy; e.a_rs = d; e.a_cs = 1; e.B = p->w2; e.b_rs = 1; e.b_cs = hid; e.C = pl.dh; e.ldc = hid; e.M = rows; e.N = hid; e.K = d;
-  if ((rc = launch_gemm_ex(e, s)) != HN_OK) return rc;
+  if ((rc = launch_gemm_ex(e, s, pl.red)) != HN_OK) return rc;
   // h = a * act(g);  u <- du
   if ((rc = launch_glu_bwd(pl.u, pl.dh, pl.h, rows, hid, p->gate == HN_GATE_GELU, s)) != HN_OK) return rc;
   if (g->w2) {   // dW2 += dy^T h
@@ -616,13 +631,13 @@ static int ff_bwd_impl(const hn_ff_params *p, const float *x_in, const float *dy
   x.A = pl.u; x.a_rs = 2 * hid; x.a_cs = 1; x.B = p->w1; x.b_rs = 1; x.b_cs = d; x.M = rows; x.N = d; x.K = 2 * hid;
   if (p->norm_w) {
     x.C = pl.dxhat; x.ldc = d;
-    if ((rc = launch_gemm_ex(x, s)) != HN_OK) return rc;
+    if ((rc = launch_gemm_ex(x, s, pl.red)) != HN_OK) return rc;
     if (residual) { if (dx != dy && (rc = launch_add_into(dy, dx, (long)rows * d, 0, s)) != HN_OK) return rc; }
     return launch_ln_bwd(x_in, pl.dxhat, p->norm_w, rows, d, dx, residual ? 1 : 0, g->norm_w, g->norm_b, pl.lns, s);
   }
   if (residual) { if (dx != dy && (rc = launch_add_into(dy, dx, (long)rows * d, 0, s)) != HN_OK) return rc; }
   x.C = dx; x.ldc = d; x.accumulate = residual ? 1 : 0;
-  return launch_gemm_ex(x, s);
+  return launch_gemm_ex(x, s, pl.red);
 }
 
 static int context_pitch(int D, int dim_head) {

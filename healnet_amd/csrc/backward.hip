@@ -102,12 +102,185 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
   }
 }
 
-// Weight-gradient shaped products (small M x N, very long contraction over the b*L or b*N rows) start only a
-// handful of 64x64 tiles; with `scratch` (GEMM_EX_SPLITS * M * N floats) the contraction is cut into GEMM_EX_SPLITS
-// slices that run as extra grid.z entries into scratch and are then summed in fixed order (deterministic).
+// ------------------------------------------------------------------------------------------------
+// TN product  C[m, n] (+)= alpha * sum_k A[k, m] * B[k, n]   (A: K x M, B: K x N, both row-major): every
+// weight gradient dW = dY^T X of the path and G = dKV^T z.  The contraction runs over the rows, which is exactly the
+// operand layout of v_mfma_f32_32x32x2_f32 (lane l <-> row/col l % 32, k = l / 32): a wave's A / B operand for a
+// k-pair is ONE coalesced dword load of two 128-byte row segments -- no LDS, no transposition, no barrier.
+// A wave owns a 64 x 64 tile (2 x 2 MFMA tiles, 4 loads per 4 MFMAs), a workgroup 128 x 128; the long contraction is
+// cut into grid.z slices that write partial tiles to scratch, summed in fixed order by splitk_reduce_kernel
+// (deterministic).  Ragged M / N / K go through the buffer descriptor's range check (invalid lanes get an
+// out-of-range offset, rows past the slice read 0): no predicate in the loop.
+// ------------------------------------------------------------------------------------------------
+struct GemmTnArgs {
+  const float *A; long lda;
+  const float *B; long ldb;
+  float *C; long ldc;          // nsplit == 1: the destination; else scratch (nsplit, M, N)
+  int M, N, K, kslice, nsplit;
+  float alpha; int accumulate;
+};
+
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs g) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m0 = blockIdx.x * 128 + (wave >> 1) * 64, n0 = blockIdx.y * 128 + (wave & 1) * 64, z = blockIdx.z;
+  if (m0 >= g.M || n0 >= g.N) return;
+  const int k_begin = z * g.kslice, k_end = min(g.K, k_begin + g.kslice);
+  const int rows = k_end - k_begin;                     // >= 1: nsplit = ceil(K / kslice)
+  const int half = lane >> 5, col = lane & 31;
+  const i32x4 ars = make_rsrc(g.A + (long)k_begin * g.lda, rows > 0 ? (unsigned)(((long)(rows - 1) * g.lda + g.M) * 4) : 0u);
+  const i32x4 brs = make_rsrc(g.B + (long)k_begin * g.ldb, rows > 0 ? (unsigned)(((long)(rows - 1) * g.ldb + g.N) * 4) : 0u);
+  int aoff[2], boff[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int m = m0 + 32 * c + col, n = n0 + 32 * c + col;
+    aoff[c] = m < g.M ? (int)(((long)half * g.lda + m) * 4) : 0x7ffffff0;
+    boff[c] = n < g.N ? (int)(((long)half * g.ldb + n) * 4) : 0x7ffffff0;
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+  constexpr int UN = 4;                      // k-pairs in flight
+  const int npairs = (rows + 1) / 2;
+  const int sa = (int)(2 * g.lda * 4), sb = (int)(2 * g.ldb * 4);
+  float a[UN][2], b[UN][2];
+  // The scalar offset must stay inside the descriptor's range (the range check subtracts it from num_records), so
+  // pairs past the end are not fetched at all (wave-uniform branch) instead of relying on the range check.
+  auto load = [&](int pair, float (&av)[2], float (&bv)[2]) {
+    if (pair < npairs) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        av[c] = hn_buffer_load_x1(ars, aoff[c], pair * sa, 0);
+        bv[c] = hn_buffer_load_x1(brs, boff[c], pair * sb, 0);
+      }
+    } else {
+      av[0] = av[1] = bv[0] = bv[1] = 0.0f;
+    }
+  };
+#pragma unroll
+  for (int u = 0; u < UN; ++u) load(u, a[u], b[u]);
+  for (int p0 = 0; p0 < npairs; p0 += UN) {
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      float ca[2] = {a[u][0], a[u][1]}, cb[2] = {b[u][0], b[u][1]};
+      load(p0 + UN + u, a[u], b[u]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[i], cb[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  float *C = g.C + (g.nsplit > 1 ? (long)z * g.M * g.ldc : 0);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + 32 * j + col;
+      if (n >= g.N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (m < g.M) {
+          float *dst = C + (long)m * g.ldc + n;
+          if (g.nsplit > 1) *dst = acc[i][j][r];
+          else { const float v = g.alpha * acc[i][j][r]; *dst = g.accumulate ? *dst + v : v; }
+        }
+      }
+    }
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_alpha_kernel(const float *__restrict__ part, int nsplit, long mn, int N,
+                                                                  float *__restrict__ C, long ldc, float alpha, int accumulate) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < mn; i += (long)gridDim.x * blockDim.x) {
+    float acc = 0.0f;
+    for (int k = 0; k < nsplit; ++k) acc += part[(long)k * mn + i];
+    float *dst = C + (i / N) * ldc + (i % N);
+    *dst = accumulate ? *dst + alpha * acc : alpha * acc;
+  }
+}
+
+static int launch_gemm_tn(const float *A, long lda, const float *B, long ldb, float *C, long ldc, int M, int N, int K, float alpha,
+                          int accumulate, float *scratch, hipStream_t s) {
+  const int tiles = ceil_div(M, 128) * ceil_div(N, 128);
+  int nsplit = 1;
+  if (scratch) {
+    nsplit = ceil_div(768, tiles);                              // ~3 workgroups per CU
+    const int max_by_k = ceil_div(K, 64);                       // at least 64 rows per slice
+    if (nsplit > max_by_k) nsplit = max_by_k;
+    if (nsplit > GEMM_EX_SPLITS) nsplit = GEMM_EX_SPLITS;
+    if (nsplit < 1) nsplit = 1;
+  }
+  GemmTnArgs g;
+  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb;
+  g.M = M; g.N = N; g.K = K;
+  g.kslice = ceil_div(ceil_div(K, nsplit), 2) * 2;
+  g.nsplit = ceil_div(K, g.kslice);
+  g.alpha = alpha; g.accumulate = accumulate;
+  if (g.nsplit > 1) { g.C = scratch; g.ldc = N; } else { g.C = C; g.ldc = ldc; }
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3(ceil_div(M, 128), ceil_div(N, 128), g.nsplit), dim3(256), 0, s, g);
+  HN_LAUNCH_CHECK("gemm_tn");
+  if (g.nsplit > 1) {
+    const long mn = (long)M * N;
+    long blocks = ceil_div_ll(mn, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(splitk_reduce_alpha_kernel, dim3((unsigned)blocks), dim3(256), 0, s, scratch, g.nsplit, mn, N, C, ldc, alpha, accumulate);
+    HN_LAUNCH_CHECK("splitk_reduce");
+  }
+  return HN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// NN product  C[m, n] (+)= sum_k A[m, k] * B[k, n]  (dX = dY W with W in nn.Linear layout): W is transposed into
+// scratch (a few hundred KB, one tiny launch) and the product runs on the forward path's tuned NT kernels
+// (gemm.hip) instead of the generic strided kernel: 2 launches of ~4 + ~12 us instead of one of 30-50 us.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict__ src, long ld, int rows, int cols,
+                                                        float *__restrict__ dst) {       // dst (cols, rows)
+  __shared__ float tile[32][33];
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    tile[ty + 8 * i][tx] = (r < rows && c < cols) ? src[(long)r * ld + c] : 0.0f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, r = r0 + tx;
+    if (c < cols && r < rows) dst[(long)c * rows + r] = tile[tx][ty + 8 * i];
+  }
+}
+
+static int launch_gemm_nn(const GemmExArgs &g, hipStream_t s, float *scratch) {
+  // B(j, c) = B + j + c * b_cs: a (K x N) row-major matrix of pitch b_cs
+  hipLaunchKernelGGL(transpose_kernel, dim3(ceil_div(g.N, 32), ceil_div(g.K, 32)), dim3(256), 0, s, g.B, g.b_cs, g.K, g.N, scratch);
+  HN_LAUNCH_CHECK("transpose");
+  GemmArgs f = {};
+  f.batch = 1; f.eps = 1e-5f;
+  f.A = g.A; f.lda = g.a_rs;
+  f.W = scratch; f.ldw = g.K;
+  f.C = g.C; f.ldc = g.ldc;
+  f.M = g.M; f.N = g.N; f.K = g.K;
+  f.alpha = g.alpha;
+  if (g.accumulate) { f.R = g.C; f.ldr = g.ldc; }
+  return launch_gemm(f, s);
+}
+
+// Other weight-gradient shaped products (head-batched, strided): small M x N, long contraction; with `scratch`
+// (GEMM_EX_SPLITS * M * N floats) the contraction is cut into slices that run as extra grid.z entries.
 int launch_gemm_ex(const GemmExArgs &g, hipStream_t s, float *scratch) {
   HN_REQUIRE(g.A && g.B && g.C, HN_E_NULL, "gemm_ex: NULL operand");
   HN_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.batch > 0, HN_E_SHAPE, "gemm_ex: M=%d N=%d K=%d", g.M, g.N, g.K);
+  // TN form (both operands contraction-major, unit stride along their own row index): the MFMA-native kernel
+  if (g.batch == 1 && g.a_rs == 1 && g.b_rs == 1 && g.k_total == 0 && (long)g.K * g.a_cs * 4 < (1L << 31) &&
+      (long)g.K * g.b_cs * 4 < (1L << 31))
+    return launch_gemm_tn(g.A, g.a_cs, g.B, g.b_cs, g.C, g.ldc, g.M, g.N, g.K, g.alpha, g.accumulate, scratch, s);
+  // NN form (A row-major over the contraction, B contraction-major): dX = dY W
+  if (scratch && g.batch == 1 && g.a_cs == 1 && g.b_rs == 1 && g.k_total == 0 && g.M >= 256 && (g.K & 3) == 0 && (g.a_rs & 3) == 0)
+    return launch_gemm_nn(g, s, scratch);
   const int tiles = ceil_div(g.M, XM) * ceil_div(g.N, XN) * g.batch;
   if (scratch && g.batch == 1 && g.K >= 2048 && tiles <= 128) {
     GemmExArgs p = g;
