@@ -13,7 +13,7 @@ from typing import Optional
 
 HN_MAX_AXES = 4
 HN_ABI_VERSION = 2
-HN_F32, HN_BF16 = 0, 1
+HN_F32, HN_BF16, HN_U8 = 0, 1, 2
 HN_CORE_F32, HN_CORE_BF16, HN_CORE_BF16X3 = 0, 1, 2
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhealnet_hip.so")

@@ -699,7 +699,8 @@ static int plan_fusion(const hn_model *m, const hn_modality_input *in, int b, vo
     const bool want_bf16 = (m->core_precision == HN_CORE_BF16 || m->core_precision == HN_CORE_BF16X3) && fp->ones[i] && n > 1;
     const int ns = m->core_precision == HN_CORE_BF16X3 ? 2 : 1;
     fp->ns[i] = ns;
-    HN_REQUIRE(in[i].dtype == HN_F32 || in[i].dtype == HN_BF16, HN_E_UNSUPPORTED, "fusion: modality %d dtype=%d", i, in[i].dtype);
+    HN_REQUIRE(in[i].dtype == HN_F32 || in[i].dtype == HN_BF16 || in[i].dtype == HN_U8, HN_E_UNSUPPORTED,
+               "fusion: modality %d dtype=%d", i, in[i].dtype);
     fp->bf16[i] = want_bf16 && inference;
     fp->Np[i] = (int)((n + 31) / 32 * 32);
     if (fp->bf16[i]) fp->pack[i] = 0;

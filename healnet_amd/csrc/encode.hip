@@ -72,6 +72,8 @@ constexpr int kMaxNarrow = 32;
 // modality elements: fp32 or bf16 (hn_modality_input.dtype); all arithmetic is fp32 either way
 __device__ __forceinline__ float in_at(const float *p, long i) { return p[i]; }
 __device__ __forceinline__ float in_at(const uint16_t *p, long i) { return __uint_as_float((unsigned)p[i] << 16); }
+// HN_U8: 8-bit image transport; the value is byte / 255 in fp32, bit-identical to torchvision's ToTensor (`.div(255)`)
+__device__ __forceinline__ float in_at(const uint8_t *p, long i) { return __fdiv_rn((float)p[i], 255.0f); }
 __device__ __forceinline__ uint16_t to_bf16(float f) {     // round to nearest even
   unsigned u = __float_as_uint(f);
   u += 0x7fffu + ((u >> 16) & 1u);
@@ -229,15 +231,17 @@ static int launch_encode_t(const IN *data, EncGeom g, int b, float *out, int ld_
 int launch_encode(const void *data, int in_dtype, int b, int n_axes, const int *spatial, int C, int F, float max_freq,
                   int fourier, int normalize, float eps, float *out, int ld_out, hipStream_t s, int ones_col, int pack_ks) {
   HN_REQUIRE(data && out, HN_E_NULL, "encode: NULL pointer");
-  HN_REQUIRE(in_dtype == HN_F32 || in_dtype == HN_BF16, HN_E_UNSUPPORTED, "encode: dtype=%d (0 = fp32, 1 = bf16)", in_dtype);
+  HN_REQUIRE(in_dtype == HN_F32 || in_dtype == HN_BF16 || in_dtype == HN_U8, HN_E_UNSUPPORTED,
+             "encode: dtype=%d (0 = fp32, 1 = bf16, 2 = uint8)", in_dtype);
   EncGeom g;
   int rc = fill_geom(&g, b, n_axes, spatial, C, F, max_freq, fourier, normalize, eps);
   if (rc != HN_OK) return rc;
   g.ld_out = ld_out;
   g.ones_col = (ones_col >= g.D && ones_col < ld_out) ? ones_col : -1;
   HN_REQUIRE(ld_out >= g.D, HN_E_SHAPE, "encode: ld_out=%d < D=%d", ld_out, g.D);
-  return in_dtype == HN_BF16 ? launch_encode_t((const uint16_t *)data, g, b, out, ld_out, s, pack_ks)
-                             : launch_encode_t((const float *)data, g, b, out, ld_out, s, pack_ks);
+  if (in_dtype == HN_BF16) return launch_encode_t((const uint16_t *)data, g, b, out, ld_out, s, pack_ks);
+  if (in_dtype == HN_U8) return launch_encode_t((const uint8_t *)data, g, b, out, ld_out, s, pack_ks);
+  return launch_encode_t((const float *)data, g, b, out, ld_out, s, pack_ks);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -321,7 +325,8 @@ __global__ __launch_bounds__(256) void encode_bf16ctx_kernel(const IN *__restric
 int launch_encode_bf16ctx(const void *data, int in_dtype, int b, int n_axes, const int *spatial, int C, int F, float max_freq,
                           int fourier, float eps, uint16_t *zb, uint16_t *zT, int Np, int DV, int ns, hipStream_t s) {
   HN_REQUIRE(data && zb && zT, HN_E_NULL, "encode_bf16ctx: NULL pointer");
-  HN_REQUIRE(in_dtype == HN_F32 || in_dtype == HN_BF16, HN_E_UNSUPPORTED, "encode: dtype=%d (0 = fp32, 1 = bf16)", in_dtype);
+  HN_REQUIRE(in_dtype == HN_F32 || in_dtype == HN_BF16 || in_dtype == HN_U8, HN_E_UNSUPPORTED,
+             "encode: dtype=%d (0 = fp32, 1 = bf16, 2 = uint8)", in_dtype);
   HN_REQUIRE(ns == 1 || ns == 2, HN_E_UNSUPPORTED, "encode_bf16ctx: ns=%d", ns);
   EncGeom g;
   int rc = fill_geom(&g, b, n_axes, spatial, C, F, max_freq, fourier, 1, eps);
@@ -332,6 +337,7 @@ int launch_encode_bf16ctx(const void *data, int in_dtype, int b, int n_axes, con
   const dim3 grid((unsigned)ceil_div_ll(total, 256)), block(256);
 #define HN_ENC16(T_, NS_) hipLaunchKernelGGL((encode_bf16ctx_kernel<T_, NS_>), grid, block, 0, s, (const T_ *)data, zb, zT, g, Np, DV, total)
   if (in_dtype == HN_BF16) { if (ns == 1) HN_ENC16(uint16_t, 1); else HN_ENC16(uint16_t, 2); }
+  else if (in_dtype == HN_U8) { if (ns == 1) HN_ENC16(uint8_t, 1); else HN_ENC16(uint8_t, 2); }
   else { if (ns == 1) HN_ENC16(float, 1); else HN_ENC16(float, 2); }
 #undef HN_ENC16
   HN_LAUNCH_CHECK("encode_bf16ctx");

@@ -46,8 +46,10 @@ def _require_gpu(t: torch.Tensor, what: str) -> None:
 
 
 def _f32c(t: torch.Tensor) -> torch.Tensor:
-    """fp32, contiguous view of an input (positions are always computed in fp32, Appendix B-8)."""
-    if t.dtype != torch.float32:
+    """fp32, contiguous view of an input (positions are always computed in fp32, Appendix B-8); uint8 means byte / 255."""
+    if t.dtype == torch.uint8:
+        t = t.float().div(255)
+    elif t.dtype != torch.float32:
         t = t.float()
     return t.contiguous()
 
@@ -547,11 +549,12 @@ class HealNet(nn.Module):
                 b = bb
             elif bb != b:
                 raise ValueError("batch dim must be identical across modalities")
-            # bf16 tensors are read as they are (hn_modality_input.dtype); anything else is staged as fp32
-            x = data.contiguous() if data.dtype == torch.bfloat16 else _f32c(data)
+            # bf16 tensors are read as they are, uint8 tensors as byte / 255 (8-bit image transport, == ToTensor);
+            # anything else is staged as fp32
+            x = data.contiguous() if data.dtype in (torch.bfloat16, torch.uint8) else _f32c(data)
             held[i] = x
             inputs[i].data = x.data_ptr()
-            inputs[i].dtype = _capi.HN_BF16 if x.dtype == torch.bfloat16 else _capi.HN_F32
+            inputs[i].dtype = {torch.bfloat16: _capi.HN_BF16, torch.uint8: _capi.HN_U8}.get(x.dtype, _capi.HN_F32)
             for a, s in enumerate(axis):
                 inputs[i].spatial[a] = int(s)
         if b is None:

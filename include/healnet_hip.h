@@ -42,8 +42,9 @@ typedef enum hn_status {
 /* Gate of the feed-forward block: SELU (healnet.py:328-331, snn=True) or GELU (:323-326). */
 typedef enum hn_gate { HN_GATE_SELU = 0, HN_GATE_GELU = 1 } hn_gate;
 
-/* Element type of a modality tensor handed to the fused forward (weights, latents and outputs are always fp32). */
-typedef enum hn_dtype { HN_F32 = 0, HN_BF16 = 1 } hn_dtype;
+/* Element type of a modality tensor handed to the fused forward (weights, latents and outputs are always fp32).
+ * HN_U8 is the 8-bit image transport: the value is byte / 255 in fp32, bit-identical to torchvision's ToTensor. */
+typedef enum hn_dtype { HN_F32 = 0, HN_BF16 = 1, HN_U8 = 2 } hn_dtype;
 
 /* Matrix-instruction precision of the shared-context (image / volume) cross-attention core of hn_fusion_forward:
  * HN_CORE_F32  fp32 MFMA on the fp32 context (default; the <= 1e-3 parity configuration);
@@ -188,7 +189,7 @@ size_t hn_head_bwd_workspace_bytes(int b, int d, int out_dims);
 typedef struct hn_modality_input {
   const void *data;          /* (b, S_1..S_a, C) or NULL for a missing modality (Appendix B-1)   */
   int spatial[HN_MAX_AXES];  /* S_1..S_a (a = num_spatial_axes[m])                               */
-  int dtype;                 /* hn_dtype of data: HN_F32 (0) or HN_BF16                          */
+  int dtype;                 /* hn_dtype of data: HN_F32 (0), HN_BF16 or HN_U8                   */
 } hn_modality_input;
 
 typedef struct hn_model {
