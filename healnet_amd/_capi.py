@@ -12,7 +12,7 @@ import sys
 from typing import Optional
 
 HN_MAX_AXES = 4
-HN_ABI_VERSION = 2
+HN_ABI_VERSION = 3
 HN_F32, HN_BF16, HN_U8 = 0, 1, 2
 HN_CORE_F32, HN_CORE_BF16, HN_CORE_BF16X3 = 0, 1, 2
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -24,12 +24,17 @@ SOURCES = ["api.hip", "gemm.hip", "attention.hip", "attention_bf16.hip", "attent
 c_float_p = C.POINTER(C.c_float)
 
 
+class Rng(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("offset", C.c_uint32), ("stream", C.c_uint32)]
+
+
 class AttnParams(C.Structure):
     _fields_ = [
         ("heads", C.c_int), ("dim_head", C.c_int), ("query_dim", C.c_int),
         ("norm_w", C.c_void_p), ("norm_b", C.c_void_p),
         ("ctx_gamma", C.c_void_p), ("ctx_beta", C.c_void_p),
         ("w_q", C.c_void_p), ("w_kv", C.c_void_p), ("w_out", C.c_void_p), ("b_out", C.c_void_p),
+        ("dropout", C.c_float), ("rng", Rng),
     ]
 
 
@@ -38,6 +43,7 @@ class FFParams(C.Structure):
         ("dim", C.c_int), ("gate", C.c_int),
         ("norm_w", C.c_void_p), ("norm_b", C.c_void_p),
         ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p),
+        ("dropout", C.c_float), ("rng", Rng),
     ]
 
 
@@ -65,7 +71,7 @@ class Model(C.Structure):
         ("cross_attn", C.POINTER(AttnParams)), ("cross_ff", C.POINTER(FFParams)),
         ("self_attn", C.POINTER(AttnParams)), ("self_ff", C.POINTER(FFParams)),
         ("head_norm_w", C.c_void_p), ("head_norm_b", C.c_void_p), ("head_w", C.c_void_p), ("head_b", C.c_void_p),
-        ("core_precision", C.c_int),
+        ("core_precision", C.c_int), ("rng", Rng),
     ]
 
 
@@ -96,6 +102,7 @@ SIGNATURES = {
                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "hn_attn_importance": (C.c_int, [C.POINTER(AttnParams), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "hn_dropout_mask": (C.c_int, [C.c_float, Rng, C.c_int, C.c_long, C.c_int, C.c_void_p, C.c_void_p]),
     "hn_surv_nll": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hn_l1_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_double, C.c_double, C.c_double,

@@ -24,6 +24,10 @@ int fail(int code, const char *fmt, ...) {
   return code;
 }
 
+static inline DropCfg drop_off() { return make_drop(0.0f, 0, 0, 0); }
+static inline DropCfg drop_of(float p, const hn_rng &r, bool ff) {
+  return p > 0.0f ? make_drop(p, r.seed, r.offset, ff ? (r.stream | DROP_SID_FF) : (r.stream & ~DROP_SID_FF)) : drop_off();
+}
 static inline int pad_head_dim(int dh) { return dh <= 16 ? 16 : dh <= 32 ? 32 : dh <= 64 ? 64 : dh <= 128 ? 128 : 0; }
 static inline int round16(int v) { return (v + 15) / 16 * 16; }
 
@@ -189,7 +193,11 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
   // ---- one-token context without a mask (tabular / omic modality): softmax over a single key is exactly 1, so the
   // block reduces to y = LeakyReLU(W_out (W_v c) + b_out) broadcast over the latent rows; Q and K are dead
   // (SURVEY.md Appendix A-7).  Two skinny GEMMs on b rows instead of the b*L-row pipeline.
-  if (ctx != nullptr && pl.N == 1 && mask == nullptr) {
+  // dropout on the probabilities: training entry points only (o_save != NULL); needs the general path (explicit
+  // denominator, no one-token shortcut)
+  const bool dropping = o_save != nullptr && p->dropout > 0.0f;
+  HN_REQUIRE(p->dropout >= 0.0f && p->dropout < 1.0f, HN_E_SHAPE, "attn: dropout=%g", (double)p->dropout);
+  if (ctx != nullptr && pl.N == 1 && mask == nullptr && !dropping) {
     float *vbuf = pl.q, *ybuf = pl.obuf;                   // (b, inner), (b, query_dim)
     GemmArgs gv = gemm_defaults();
     gv.A = ctx; gv.lda = ld_ctx; gv.M = b; gv.K = pl.D;
@@ -248,9 +256,13 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
   AttnCoreArgs core;
   const int pack_ks = (pl.rank_d && pl.ones && ctx_has_ones && p->ctx_gamma) ? ctx_pack_ks : 0;
   if ((rc = attn_prepare(p, pl, x_in, ctx, ld_ctx, b, L, s, &core, pack_ks,
-                         saved_kv(pl, ctx != nullptr, mask != nullptr, b, L, o_save))) != HN_OK) return rc;
+                         saved_kv(pl, ctx != nullptr, mask != nullptr || dropping, b, L, o_save))) != HN_OK) return rc;
   core.mask = mask;
   core.ones_in_mem = (ctx_has_ones && pl.ones) ? 1 : 0;
+  core.drop = drop_off();
+  const int srow = (dropping && pl.rank_d) ? 1 : 0;       // the thinned probabilities' row sum rides in column dp-1
+  HN_REQUIRE(!srow || pl.ones, HN_E_UNSUPPORTED, "attn: dropout on the shared-context binding needs a free column (D <= dp - 1)");
+  if (dropping) { core.ones_col = 0; core.ones_in_mem = 0; core.drop = drop_of(p->dropout, p->rng, false); core.drop_rowsum = srow; }
   const bool direct = !pl.rank_d && pl.nsplit == 1;
   if (direct) { core.Ofinal = pl.obuf; core.ldo = pl.inner; core.dh = pl.dh; core.stats = stats; }
   if (ev0) HN_HIP_CHECK(hipEventRecord(ev0, s));
@@ -258,7 +270,7 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
   if (ev1) HN_HIP_CHECK(hipEventRecord(ev1, s));
   if (pl.rank_d) {
     rc = launch_merge_vproj(pl.opart, pl.mpart, pl.lpart, pl.nsplit, b, p->heads, L, pl.Lp, pl.dp, pl.D, p->ctx_gamma,
-                            p->ctx_beta, p->w_kv + (long)pl.inner * pl.D, pl.dh, pl.obuf, pl.inner, stats, o_save, s, pack_ks);
+                            p->ctx_beta, p->w_kv + (long)pl.inner * pl.D, pl.dh, pl.obuf, pl.inner, stats, o_save, s, pack_ks, srow);
   } else if (!direct) {
     rc = launch_merge_explicit(pl.opart, pl.mpart, pl.lpart, pl.nsplit, b, p->heads, L, pl.Lp, pl.dp, pl.dh, pl.obuf,
                                pl.inner, stats, s);
@@ -360,13 +372,15 @@ static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float
   HN_REQUIRE(p && x_in && x_out && stats && saved && dy && dx && g, HN_E_NULL, "attn_bwd: NULL pointer");
   HN_REQUIRE(p->w_q && p->w_kv && p->w_out, HN_E_NULL, "attn_bwd: weight pointer is NULL");
   const bool has_ctx = ctx != nullptr;
+  const bool dropping = p->dropout > 0.0f;           // the forward that produced `saved` thinned its probabilities
+  const bool general = mask != nullptr || dropping;   // ... and therefore took the general (not the one-token) path
   AttnPlan pl;
   int rc = plan_attn(p, has_ctx, ld_ctx, b, L, N, D, nullptr, 0, &pl);
   if (rc != HN_OK) return rc;
   AttnBwdPlan bp;
-  if ((rc = plan_attn_bwd(p, pl, has_ctx, mask != nullptr, b, L, nullptr, 0, &bp)) != HN_OK) return rc;
+  if ((rc = plan_attn_bwd(p, pl, has_ctx, general, b, L, nullptr, 0, &bp)) != HN_OK) return rc;
   if ((rc = check_ws(ws, ws_bytes, bp.bytes, "attn_bwd")) != HN_OK) return rc;
-  if ((rc = plan_attn_bwd(p, pl, has_ctx, mask != nullptr, b, L, ws, ws_bytes, &bp)) != HN_OK) return rc;
+  if ((rc = plan_attn_bwd(p, pl, has_ctx, general, b, L, ws, ws_bytes, &bp)) != HN_OK) return rc;
   if ((rc = plan_attn(p, has_ctx, ld_ctx, b, L, N, D, bp.fwd_ws, bp.fwd_bytes, &pl)) != HN_OK) return rc;
 
   const int rows = b * L, qd = p->query_dim, inner = pl.inner, h = p->heads, dh = pl.dh;
@@ -374,7 +388,7 @@ static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float
   // dpre = dy * LeakyReLU'(pre); the sign of pre is the sign of y = x_out - x_in
   if ((rc = launch_leaky_bwd(dy, x_out, residual ? x_in : nullptr, bp.dpre, (long)rows * qd, s)) != HN_OK) return rc;
 
-  if (has_ctx && pl.N == 1 && mask == nullptr) {   // ---- one-token context: y_b = LeakyReLU(W_out V_b + b_out) for every row
+  if (has_ctx && pl.N == 1 && !general) {   // ---- one-token context: y_b = LeakyReLU(W_out V_b + b_out) for every row
     if ((rc = launch_segsum(bp.dpre, L, qd, b, bp.dyb, s)) != HN_OK) return rc;
     if (g->b_out && (rc = launch_colsum(bp.dyb, qd, b, qd, 1.0f, g->b_out, 1, s, bp.red)) != HN_OK) return rc;
     if (g->w_out) {   // dWo += dyb^T V
@@ -401,8 +415,10 @@ static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float
   // ---- output projection: dWo += dpre^T O, dbo += colsum(dpre), dO = dpre Wo
   const float *O = saved;
   if (pl.rank_d) {   // O = (P z * gamma + beta) W_v^T is recomputed from the saved P z
-    if ((rc = launch_head_affine(saved, h * pl.dp, pl.dp, nullptr, 0, 0, p->ctx_gamma, p->ctx_beta, 1.0f, h, pl.D, pl.dp,
-                                 h * pl.dp, rows, bp.Abuf, s)) != HN_OK) return rc;
+    if (dropping) rc = launch_srow_affine(saved, nullptr, p->ctx_gamma, p->ctx_beta, 0, h, pl.D, pl.dp, rows, bp.Abuf, s);
+    else rc = launch_head_affine(saved, h * pl.dp, pl.dp, nullptr, 0, 0, p->ctx_gamma, p->ctx_beta, 1.0f, h, pl.D, pl.dp,
+                                 h * pl.dp, rows, bp.Abuf, s);
+    if (rc != HN_OK) return rc;
     GemmExArgs e = gex(bp.Abuf, (long)h * pl.dp, 1, p->w_kv + (long)inner * pl.D, pl.D, 1, pl.obuf, inner, rows, dh, pl.D, 0);
     e.batch = h; e.strideA = pl.dp; e.strideB = (long)dh * pl.D; e.strideC = dh;
     if ((rc = launch_gemm_ex(e, s, bp.red)) != HN_OK) return rc;
@@ -420,7 +436,7 @@ static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float
 
   // ---- recompute the operands of the core (scaled Q, and K/V or the folded queries)
   AttnCoreArgs core;
-  float *kv_saved = saved_kv(pl, has_ctx, mask != nullptr, b, L, const_cast<float *>(saved));
+  float *kv_saved = saved_kv(pl, has_ctx, general, b, L, const_cast<float *>(saved));
   if ((rc = attn_prepare(p, pl, x_in, ctx, ld_ctx, b, L, s, &core, 0, kv_saved, kv_saved != nullptr)) != HN_OK) return rc;
   const float *xhat = x_in;
   if (p->norm_w) {
@@ -434,6 +450,9 @@ static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float
   ba.Vp = core.Vp; ba.v_b = core.v_b; ba.v_h = core.v_h; ba.ldv = core.ldv;
   ba.mask = mask; ba.stats = stats; ba.delta = bp.delta; ba.dQpart = bp.dQpart;
   ba.b = b; ba.h = h; ba.Lq = L; ba.Lp = pl.Lp; ba.N = pl.N; ba.dp = pl.dp; ba.nsplit = pl.nsplit; ba.chunk = pl.chunk;
+  ba.drop = dropping ? drop_of(p->dropout, p->rng, false) : drop_off();
+  const bool srow = dropping && pl.rank_d;
+  ba.drop_rowsum = srow ? 1 : 0;
 
   if (pl.rank_d) {
     const int hp = h * pl.dp;
@@ -454,11 +473,20 @@ static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float
     if (p->ctx_gamma) {   // dgamma += sum dA * (P z) ; dbeta += sum dA   (over rows and heads)
       if ((rc = launch_head_affine(bp.dA, hp, pl.dp, saved, hp, pl.dp, nullptr, nullptr, 1.0f, h, pl.D, pl.dp, hp, rows, bp.E, s)) != HN_OK) return rc;
       if (g->ctx_gamma && (rc = launch_colsum(bp.E, pl.dp, (long)rows * h, pl.D, 1.0f, g->ctx_gamma, 1, s, bp.red)) != HN_OK) return rc;
-      if (g->ctx_beta && (rc = launch_colsum(bp.dA, pl.dp, (long)rows * h, pl.D, 1.0f, g->ctx_beta, 1, s, bp.red)) != HN_OK) return rc;
+      if (g->ctx_beta) {
+        const float *src = bp.dA;
+        if (srow) {   // d beta_c = sum dA_c * s
+          if ((rc = launch_srow_affine(saved, bp.dA, nullptr, nullptr, 1, h, pl.D, pl.dp, rows, bp.E, s)) != HN_OK) return rc;
+          src = bp.E;
+        }
+        if ((rc = launch_colsum(src, pl.dp, (long)rows * h, pl.D, 1.0f, g->ctx_beta, 1, s, bp.red)) != HN_OK) return rc;
+      }
     }
-    // d(P z) = dA * gamma ;  delta = rowsum(d(P z) * P z)
-    if ((rc = launch_head_affine(bp.dA, hp, pl.dp, nullptr, 0, 0, p->ctx_gamma, nullptr, 1.0f, h, pl.D, pl.dp, hp, rows, bp.dOp, s)) != HN_OK) return rc;
-    if ((rc = launch_rowdot_heads(bp.dOp, hp, pl.dp, saved, hp, pl.dp, h, L, pl.D, rows, bp.delta, s)) != HN_OK) return rc;
+    // d(P z) = dA * gamma (+ the row-sum channel under dropout) ;  delta = rowsum(d(P z) * P z)
+    if (srow) rc = launch_srow_affine(saved, bp.dA, p->ctx_gamma, p->ctx_beta, 2, h, pl.D, pl.dp, rows, bp.dOp, s);
+    else rc = launch_head_affine(bp.dA, hp, pl.dp, nullptr, 0, 0, p->ctx_gamma, nullptr, 1.0f, h, pl.D, pl.dp, hp, rows, bp.dOp, s);
+    if (rc != HN_OK) return rc;
+    if ((rc = launch_rowdot_heads(bp.dOp, hp, pl.dp, saved, hp, pl.dp, h, L, srow ? pl.dp : pl.D, rows, bp.delta, s)) != HN_OK) return rc;
     ba.dO = bp.dOp; ba.do_b = (long)L * hp; ba.do_h = pl.dp; ba.lddo = hp;
     if ((rc = launch_attn_bwd_dq(ba, s)) != HN_OK) return rc;
     // dQacc (rows, h*dp) = sum over splits; folded-query chain  Qf = c * gamma * T,  T = Q_h W_k,h
@@ -533,15 +561,20 @@ static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float
 // ------------------------------------------------------------------------------------------------
 // feed-forward block
 // ------------------------------------------------------------------------------------------------
+static size_t ff_ws_bytes(const hn_ff_params *p, int rows) {     // hidden (rows, 4 dim) + the pre-dropout output (rows, dim)
+  return align_up((size_t)rows * 5 * p->dim * sizeof(float), 256);
+}
+
 static int ff_fwd_impl(const hn_ff_params *p, const float *x_in, float *x_out, int residual, int rows, void *ws,
-                       size_t ws_bytes, hipStream_t s) {
+                       size_t ws_bytes, hipStream_t s, bool training = false) {
   HN_REQUIRE(p && x_in && x_out, HN_E_NULL, "ff: NULL pointer");
   HN_REQUIRE(p->w1 && p->b1 && p->w2 && p->b2, HN_E_NULL, "ff: weight pointer is NULL");
   HN_REQUIRE(p->dim > 0 && rows > 0, HN_E_SHAPE, "ff: dim=%d rows=%d", p->dim, rows);
   HN_REQUIRE(p->gate == HN_GATE_SELU || p->gate == HN_GATE_GELU, HN_E_UNSUPPORTED, "ff: gate=%d", p->gate);
   const int hid = 4 * p->dim;
-  const size_t need = align_up((size_t)rows * hid * sizeof(float), 256);
-  int rc = check_ws(ws, ws_bytes, need, "ff");
+  HN_REQUIRE(p->dropout >= 0.0f && p->dropout < 1.0f, HN_E_SHAPE, "ff: dropout=%g", (double)p->dropout);
+  const bool dropping = training && p->dropout > 0.0f;
+  int rc = check_ws(ws, ws_bytes, ff_ws_bytes(p, rows), "ff");
   if (rc != HN_OK) return rc;
   float *hidden = (float *)ws;
   GemmArgs g1 = gemm_defaults();
@@ -560,6 +593,12 @@ static int ff_fwd_impl(const hn_ff_params *p, const float *x_in, float *x_out, i
   g2.C = x_out; g2.ldc = p->dim;
   g2.bias = p->b2;
   g2.M = rows; g2.N = p->dim; g2.K = hid;
+  if (dropping) {   // y = x + dropout(h W2^T + b2)   (nn.Dropout is the last module of the block, :347)
+    float *pre = hidden + (size_t)rows * hid;
+    g2.C = pre;
+    if ((rc = launch_gemm(g2, s)) != HN_OK) return rc;
+    return launch_dropout_apply(pre, residual ? x_in : nullptr, x_out, rows, p->dim, drop_of(p->dropout, p->rng, true), s);
+  }
   if (residual) { g2.R = x_in; g2.ldr = p->dim; }
   return launch_gemm(g2, s);
 }
@@ -567,7 +606,7 @@ static int ff_fwd_impl(const hn_ff_params *p, const float *x_in, float *x_out, i
 // ------------------------------------------------------------------------------------------------
 // feed-forward block, backward
 // ------------------------------------------------------------------------------------------------
-struct FFBwdPlan { float *u, *h, *dh, *xhat, *dxhat, *lns, *red; size_t bytes; };
+struct FFBwdPlan { float *u, *h, *dh, *xhat, *dxhat, *lns, *red, *dyd; size_t bytes; };
 
 static void plan_ff_bwd(const hn_ff_params *p, int rows, void *ws, size_t ws_bytes, FFBwdPlan *pl) {
   Arena ar(ws, ws_bytes);
@@ -579,6 +618,7 @@ static void plan_ff_bwd(const hn_ff_params *p, int rows, void *ws, size_t ws_byt
   pl->dxhat = ar.take<float>((size_t)rows * p->dim);
   pl->lns = ar.take<float>(ln_bwd_scratch_floats(rows, p->dim));
   pl->red = ar.take<float>(reduce_scratch_floats(8L * p->dim * p->dim, 8 * p->dim));
+  pl->dyd = ar.take<float>((size_t)rows * p->dim);          // dropout: the gradient that enters the block proper
   pl->bytes = ar.off;
 }
 
@@ -604,20 +644,26 @@ static int ff_bwd_impl(const hn_ff_params *p, const float *x_in, const float *dy
     if ((rc = launch_ln_fwd(x_in, p->norm_w, p->norm_b, rows, d, pl.xhat, s)) != HN_OK) return rc;
     xhat = pl.xhat;
   }
+  // dropout sits between the block and the residual add: the block proper sees dy * keepscale (the forward's mask)
+  const float *dyf = dy;
+  if (p->dropout > 0.0f) {
+    if ((rc = launch_dropout_apply(dy, nullptr, pl.dyd, rows, d, drop_of(p->dropout, p->rng, true), s)) != HN_OK) return rc;
+    dyf = pl.dyd;
+  }
   // dh = dy W2          (W2 is (d, hid): B(j = k, c = n) = W2[n, k])
   GemmExArgs e = {};
   e.batch = 1; e.alpha = 1.0f;
-  e.A = dy; e.a_rs = d; e.a_cs = 1; e.B = p->w2; e.b_rs = 1; e.b_cs = hid; e.C = pl.dh; e.ldc = hid; e.M = rows; e.N = hid; e.K = d;
+  e.A = dyf; e.a_rs = d; e.a_cs = 1; e.B = p->w2; e.b_rs = 1; e.b_cs = hid; e.C = pl.dh; e.ldc = hid; e.M = rows; e.N = hid; e.K = d;
   if ((rc = launch_gemm_ex(e, s, pl.red)) != HN_OK) return rc;
   // h = a * act(g);  u <- du
   if ((rc = launch_glu_bwd(pl.u, pl.dh, pl.h, rows, hid, p->gate == HN_GATE_GELU, s)) != HN_OK) return rc;
   if (g->w2) {   // dW2 += dy^T h
     GemmExArgs w = {};
     w.batch = 1; w.alpha = 1.0f; w.accumulate = 1;
-    w.A = dy; w.a_rs = 1; w.a_cs = d; w.B = pl.h; w.b_rs = 1; w.b_cs = hid; w.C = g->w2; w.ldc = hid; w.M = d; w.N = hid; w.K = rows;
+    w.A = dyf; w.a_rs = 1; w.a_cs = d; w.B = pl.h; w.b_rs = 1; w.b_cs = hid; w.C = g->w2; w.ldc = hid; w.M = d; w.N = hid; w.K = rows;
     if ((rc = launch_gemm_ex(w, s, pl.red)) != HN_OK) return rc;
   }
-  if (g->b2 && (rc = launch_colsum(dy, d, rows, d, 1.0f, g->b2, 1, s, pl.red)) != HN_OK) return rc;
+  if (g->b2 && (rc = launch_colsum(dyf, d, rows, d, 1.0f, g->b2, 1, s, pl.red)) != HN_OK) return rc;
   if (g->w1) {   // dW1 += du^T x_hat
     GemmExArgs w = {};
     w.batch = 1; w.alpha = 1.0f; w.accumulate = 1;
@@ -733,7 +779,7 @@ static int plan_fusion(const hn_model *m, const hn_modality_input *in, int b, vo
       if (pl.bytes > op_max) op_max = pl.bytes;
     }
   }
-  const size_t ffb = align_up((size_t)b * m->l_c * 4 * m->l_d * sizeof(float), 256);
+  const size_t ffb = align_up((size_t)b * m->l_c * 5 * m->l_d * sizeof(float), 256);
   if (ffb > op_max) op_max = ffb;
   fp->op_ws_bytes = op_max;
   fp->op_ws = ar.take<char>(op_max);
@@ -796,7 +842,7 @@ static int plan_tape(const hn_model *m, const hn_modality_input *in, int b, int 
                          nullptr, 0, &pl);
       if (rc != HN_OK) return rc;
       tp->stats_off[k] = off; off += align_up((size_t)b * ap->heads * m->l_c * 2, 64);
-      tp->saved_off[k] = off; off += align_up(attn_saved_floats(pl, cross, cross && masked, b, m->l_c), 64);
+      tp->saved_off[k] = off; off += align_up(attn_saved_floats(pl, cross, cross && (masked || ap->dropout > 0.0f), b, m->l_c), 64);
     }
   }
   tp->floats = off;
@@ -823,7 +869,7 @@ static int fusion_bwd_workspace(const hn_model *m, const hn_modality_input *in, 
       AttnPlan pl;
       if ((rc = plan_attn(ap, true, fp->ldz[i], b, m->l_c, fp->N[i], fp->D[i], nullptr, 0, &pl)) != HN_OK) return rc;
       AttnBwdPlan bp;
-      if ((rc = plan_attn_bwd(ap, pl, true, masked != 0, b, m->l_c, nullptr, 0, &bp)) != HN_OK) return rc;
+      if ((rc = plan_attn_bwd(ap, pl, true, masked != 0 || ap->dropout > 0.0f, b, m->l_c, nullptr, 0, &bp)) != HN_OK) return rc;
       if (bp.bytes > need) need = bp.bytes;
     }
     if (m->self_per_cross_attn > 0) {
@@ -920,7 +966,7 @@ int hn_attn_importance(const hn_attn_params *p, const float *x_in, const float *
 size_t hn_attn_saved_floats(const hn_attn_params *p, int has_ctx, int ld_ctx, int b, int L, int N, int D, int masked) {
   AttnPlan pl;
   if (plan_attn(p, has_ctx != 0, ld_ctx, b, L, N, D, nullptr, 0, &pl) != HN_OK) return 0;
-  return attn_saved_floats(pl, has_ctx != 0, masked != 0, b, L);
+  return attn_saved_floats(pl, has_ctx != 0, masked != 0 || p->dropout > 0.0f, b, L);
 }
 
 int hn_attn_fwd_train(const hn_attn_params *p, const float *x_in, float *x_out, int residual, const float *ctx, int ld_ctx,
@@ -935,7 +981,7 @@ size_t hn_attn_bwd_workspace_bytes(const hn_attn_params *p, int has_ctx, int ld_
   AttnPlan pl;
   if (plan_attn(p, has_ctx != 0, ld_ctx, b, L, N, D, nullptr, 0, &pl) != HN_OK) return 0;
   AttnBwdPlan bp;
-  if (plan_attn_bwd(p, pl, has_ctx != 0, masked != 0, b, L, nullptr, 0, &bp) != HN_OK) return 0;
+  if (plan_attn_bwd(p, pl, has_ctx != 0, masked != 0 || p->dropout > 0.0f, b, L, nullptr, 0, &bp) != HN_OK) return 0;
   return bp.bytes;
 }
 
@@ -948,12 +994,20 @@ int hn_attn_bwd(const hn_attn_params *p, const float *x_in, const float *x_out, 
 
 size_t hn_ff_workspace_bytes(const hn_ff_params *p, int rows) {
   if (!p || p->dim <= 0 || rows <= 0) return 0;
-  return align_up((size_t)rows * 4 * p->dim * sizeof(float), 256);
+  return ff_ws_bytes(p, rows);
 }
 
+// p->dropout > 0 applies the mask of p->rng (the caller passes 0 outside training, as nn.Dropout does in eval mode)
 int hn_ff_fwd(const hn_ff_params *p, const float *x_in, float *x_out, int residual, int rows, void *workspace,
               size_t workspace_bytes, void *stream) {
-  return ff_fwd_impl(p, x_in, x_out, residual, rows, workspace, workspace_bytes, (hipStream_t)stream);
+  return ff_fwd_impl(p, x_in, x_out, residual, rows, workspace, workspace_bytes, (hipStream_t)stream, true);
+}
+
+int hn_dropout_mask(float p, hn_rng rng, int is_ff, long rows, int cols, uint8_t *mask, void *stream) {
+  HN_REQUIRE(mask && rows > 0 && cols > 0 && p >= 0.0f && p < 1.0f, HN_E_SHAPE, "dropout_mask: p=%g rows=%ld cols=%d", (double)p, rows, cols);
+  DropCfg d = drop_of(p, rng, is_ff != 0);
+  if (d.thr == 0) { HN_HIP_CHECK(hipMemsetAsync(mask, 1, (size_t)rows * cols, (hipStream_t)stream)); return HN_OK; }
+  return launch_dropout_mask(mask, rows, cols, d, (hipStream_t)stream);
 }
 
 int hn_head_fwd(const float *x, int b, int L, int d, const float *norm_w, const float *norm_b, const float *w,
@@ -1113,21 +1167,29 @@ int hn_fusion_forward_train(const hn_model *m, const hn_modality_input *in, int 
     const Step &st = tp.steps[k];
     const float *xin = T + tp.x_off[k];
     float *xout = T + tp.x_off[k + 1];
+    // dropout: one generator state per forward (hn_model.rng), one stream id per executed block (its step index)
+    const hn_rng rng = {m->rng.seed, m->rng.offset, (uint32_t)k};
     switch (st.kind) {
-      case STEP_CROSS_ATTN:
-        rc = attn_fwd_impl(&m->cross_attn[st.layer * M + st.m], xin, xout, 1, fp.z[st.m], fp.ldz[st.m], b, L, fp.N[st.m], fp.D[st.m],
+      case STEP_CROSS_ATTN: {
+        hn_attn_params ap = m->cross_attn[st.layer * M + st.m];
+        ap.rng = rng;
+        rc = attn_fwd_impl(&ap, xin, xout, 1, fp.z[st.m], fp.ldz[st.m], b, L, fp.N[st.m], fp.D[st.m],
                            mask, T + tp.stats_off[k], fp.op_ws, fp.op_ws_bytes, s, nullptr, nullptr, T + tp.saved_off[k]);
         break;
-      case STEP_SELF_ATTN:
-        rc = attn_fwd_impl(&m->self_attn[st.layer], xin, xout, 1, nullptr, 0, b, L, L, d, nullptr, T + tp.stats_off[k], fp.op_ws,
+      }
+      case STEP_SELF_ATTN: {
+        hn_attn_params ap = m->self_attn[st.layer];
+        ap.rng = rng;
+        rc = attn_fwd_impl(&ap, xin, xout, 1, nullptr, 0, b, L, L, d, nullptr, T + tp.stats_off[k], fp.op_ws,
                            fp.op_ws_bytes, s, nullptr, nullptr, T + tp.saved_off[k]);
         break;
-      case STEP_CROSS_FF:
-        rc = ff_fwd_impl(&m->cross_ff[st.layer * M + st.m], xin, xout, 1, b * L, fp.op_ws, fp.op_ws_bytes, s);
+      }
+      default: {
+        hn_ff_params fpar = st.kind == STEP_CROSS_FF ? m->cross_ff[st.layer * M + st.m] : m->self_ff[st.layer];
+        fpar.rng = rng;
+        rc = ff_fwd_impl(&fpar, xin, xout, 1, b * L, fp.op_ws, fp.op_ws_bytes, s, true);
         break;
-      default:
-        rc = ff_fwd_impl(&m->self_ff[st.layer], xin, xout, 1, b * L, fp.op_ws, fp.op_ws_bytes, s);
-        break;
+      }
     }
     if (rc != HN_OK) return rc;
     if (st.kind == STEP_CROSS_ATTN || st.kind == STEP_SELF_ATTN) {     // optional copies for hn_attn_probs (same slots as hn_fusion_forward)
@@ -1191,23 +1253,35 @@ int hn_fusion_backward(const hn_model *m, const hn_modality_input *in, int b, co
   for (int k = tp.nsteps - 1; k >= 0; --k) {
     const Step &st = tp.steps[k];
     const float *xin = T + tp.x_off[k], *xout = T + tp.x_off[k + 1];
+    const hn_rng rng = {m->rng.seed, m->rng.offset, (uint32_t)k};      // the forward's generator state and stream id
     switch (st.kind) {
-      case STEP_CROSS_ATTN:
-        rc = attn_bwd_impl(&m->cross_attn[st.layer * M + st.m], xin, xout, 1, fp.z[st.m], fp.ldz[st.m], b, L, fp.N[st.m], fp.D[st.m],
+      case STEP_CROSS_ATTN: {
+        hn_attn_params ap = m->cross_attn[st.layer * M + st.m];
+        ap.rng = rng;
+        rc = attn_bwd_impl(&ap, xin, xout, 1, fp.z[st.m], fp.ldz[st.m], b, L, fp.N[st.m], fp.D[st.m],
                            mask, T + tp.stats_off[k], T + tp.saved_off[k], dX, dX, g->cross_attn ? &g->cross_attn[st.layer * M + st.m] : &no_attn,
                            op, opb, s);
         break;
-      case STEP_SELF_ATTN:
-        rc = attn_bwd_impl(&m->self_attn[st.layer], xin, xout, 1, nullptr, 0, b, L, L, d, nullptr, T + tp.stats_off[k],
+      }
+      case STEP_SELF_ATTN: {
+        hn_attn_params ap = m->self_attn[st.layer];
+        ap.rng = rng;
+        rc = attn_bwd_impl(&ap, xin, xout, 1, nullptr, 0, b, L, L, d, nullptr, T + tp.stats_off[k],
                            T + tp.saved_off[k], dX, dX, g->self_attn ? &g->self_attn[st.layer] : &no_attn, op, opb, s);
         break;
-      case STEP_CROSS_FF:
-        rc = ff_bwd_impl(&m->cross_ff[st.layer * M + st.m], xin, dX, dX, 1, b * L, g->cross_ff ? &g->cross_ff[st.layer * M + st.m] : &no_ff,
-                         op, opb, s);
+      }
+      case STEP_CROSS_FF: {
+        hn_ff_params fpar = m->cross_ff[st.layer * M + st.m];
+        fpar.rng = rng;
+        rc = ff_bwd_impl(&fpar, xin, dX, dX, 1, b * L, g->cross_ff ? &g->cross_ff[st.layer * M + st.m] : &no_ff, op, opb, s);
         break;
-      default:
-        rc = ff_bwd_impl(&m->self_ff[st.layer], xin, dX, dX, 1, b * L, g->self_ff ? &g->self_ff[st.layer] : &no_ff, op, opb, s);
+      }
+      default: {
+        hn_ff_params fpar = m->self_ff[st.layer];
+        fpar.rng = rng;
+        rc = ff_bwd_impl(&fpar, xin, dX, dX, 1, b * L, g->self_ff ? &g->self_ff[st.layer] : &no_ff, op, opb, s);
         break;
+      }
     }
     if (rc != HN_OK) return rc;
   }

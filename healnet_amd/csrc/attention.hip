@@ -56,7 +56,7 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 // KS = number of QK^T k-steps (4 per 16-column block); < 4*DT only with the packed context layout (common.h).
 __device__ __forceinline__ float f4c(const float4 &v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); }
 
-template <int DT, int NQ, bool ONES, int KS = 4 * DT>
+template <int DT, int NQ, bool ONES, int KS = 4 * DT, bool DROP = false>
 __global__ __launch_bounds__(256) void attn_core_kernel(AttnCoreArgs a, int ngroups, int gy, int waves_per_block) {
   constexpr int DP = 16 * DT;
   const int L = a.Lq;
@@ -135,6 +135,12 @@ __global__ __launch_bounds__(256) void attn_core_kernel(AttnCoreArgs a, int ngro
   // one 16-token step on the (kf, vf) fragments; prefetches the following tile into (kn, vn)
   auto step = [&](int t0, float4 (&kf)[DT], float (&vf)[DT][4], float4 (&kn)[DT], float (&vn)[DT][4]) {
     if (t0 + 16 < t_end) load_kv(t0 + 16, kn, vn);
+    if (DROP && a.drop_rowsum) {       // shared-context binding under dropout: accumulator column DP-1 = sum_t p'_t, the row sum
+      if (j == 15) {                    // of the THINNED probabilities (no longer 1), needed by the beta term of the values
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vf[DT - 1][r] = 1.0f;
+      }
+    }
     if (ONES && !a.ones_in_mem) {      // hn_fusion_forward has K1 write the ones column into z itself
       if (g == 3) kf[DT - 1].w = 1.0f;
       if (j == 15) {
@@ -240,6 +246,15 @@ __global__ __launch_bounds__(256) void attn_core_kernel(AttnCoreArgs a, int ngro
           const float p = fast_exp2(S[i][r] - m[i]);
           l[i] += p;
           P[i][r] = p;
+        }
+      }
+      if (DROP) {   // nn.Dropout on the NORMALISED probabilities (:421): l keeps the full sum, the P V operand is thinned
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+          float dm[4];
+          drop_quad(a.drop, (uint32_t)(t0 + 4 * g) >> 2, (uint32_t)(bh * L + (qg * NQ + i) * 16 + j), dm);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) P[i][r] *= dm[r];
         }
       }
     }
@@ -357,6 +372,7 @@ int launch_attn_core(const AttnCoreArgs &a, hipStream_t s) {
              "attn_core: one sample's K/V rows must span < 2 GiB (N=%d ld=%d)", a.N, a.ldk);
   HN_REQUIRE(a.Ofinal == nullptr || (a.nsplit == 1 && !a.ones_col), HN_E_SHAPE, "attn_core: direct output needs a single split");
   HN_REQUIRE(!a.ones_col || (a.dp <= 32 && a.Kp == a.Vp), HN_E_UNSUPPORTED, "attn_core: ones column needs the shared-context binding");
+  HN_REQUIRE(a.drop.thr == 0 || !a.ones_col, HN_E_SHAPE, "attn_core: dropout needs the explicit denominator (ones_col = 0)");
   const int dt = a.dp / 16, nq = nq_for(dt);
   const int ngroups = ceil_div(a.Lp / 16, nq);
   const int wpb = ngroups < 4 ? ngroups : 4;
@@ -374,6 +390,14 @@ int launch_attn_core(const AttnCoreArgs &a, hipStream_t s) {
     else if (ks == 2) HN_CORE(1, 4, true, 2);
     else if (ks == 3) HN_CORE(1, 4, true, 3);
     else HN_CORE(1, 4, true, 4);
+  } else if (a.drop.thr != 0) {
+#define HN_CORE_DROP(DT_, NQ_) hipLaunchKernelGGL((attn_core_kernel<DT_, NQ_, false, 4 * DT_, true>), grid, block, 0, s, a, ngroups, gy, wpb)
+    HN_REQUIRE(dt != 1 || nq == 4, HN_E_UNSUPPORTED, "attn_core: dropout variant is built for NQ = 4");
+    if (dt == 1) HN_CORE_DROP(1, 4);
+    else if (dt == 2) HN_CORE_DROP(2, 2);
+    else if (dt == 4) HN_CORE_DROP(4, 2);
+    else HN_CORE_DROP(8, 1);
+#undef HN_CORE_DROP
   } else if (dt == 1) {
     if (nq == 8) HN_CORE(1, 8, false, 4);
     else if (nq == 2) HN_CORE(1, 2, false, 4);
@@ -468,7 +492,7 @@ __global__ __launch_bounds__(256) void merge_vproj_kernel(const float *__restric
                                                           int dp, int D, const float *__restrict__ gamma,
                                                           const float *__restrict__ beta, const float *__restrict__ w_v,
                                                           int dh, float *__restrict__ O, int ldo, float *__restrict__ stats,
-                                                          float *__restrict__ oprime_save, int pack_ks) {
+                                                          float *__restrict__ oprime_save, int pack_ks, int srow) {
   extern __shared__ float sm[];
   float *oh = sm;                        // [MERGE_ROWS][dp + 1]
   float *wv = sm + MERGE_ROWS * (dp + 1);  // [dh][dp + 1]: gamma folded in; [dp] = the beta term
@@ -479,15 +503,15 @@ __global__ __launch_bounds__(256) void merge_vproj_kernel(const float *__restric
   for (int idx = threadIdx.x; idx < MERGE_ROWS * dp; idx += blockDim.x) {
     const int qq = idx / dp, d = idx % dp, q = q0 + qq;
     float v = 0.0f;
-    if (q < L && d < dlim) {
+    if (q < L && (d < dlim || (srow && d == dp - 1))) {      // srow: column dp-1 carries the dropped row sum (see attn_core)
       float M, Ls;
       v = merged_value(Opart, Mpart, Lpart, pbase, nsplit, Lp, dp, q, d, &M, &Ls);
-      if (oprime_save) oprime_save[((long)bi * L + q) * (h * dp) + hi * dp + d] = v;      // training: normalised P z
       if (stats && d == 0) {
         stats[((long)bh * L + q) * 2 + 0] = M;
         stats[((long)bh * L + q) * 2 + 1] = Ls;
       }
     }
+    if (oprime_save && q < L) oprime_save[((long)bi * L + q) * (h * dp) + hi * dp + d] = v;   // training: normalised P z, padding columns 0
     oh[qq * (dp + 1) + d] = v;
   }
   for (int idx = threadIdx.x; idx < dh * (dp + 1); idx += blockDim.x) {
@@ -509,7 +533,7 @@ __global__ __launch_bounds__(256) void merge_vproj_kernel(const float *__restric
   for (int idx = threadIdx.x; idx < MERGE_ROWS * dh; idx += blockDim.x) {
     const int qq = idx / dh, e = idx % dh, q = q0 + qq;
     if (q >= L) continue;
-    float acc = wv[e * (dp + 1) + dp];
+    float acc = wv[e * (dp + 1) + dp] * (srow ? oh[qq * (dp + 1) + dp - 1] : 1.0f);      // beta term * sum_t p'_t (1 without dropout)
     for (int d = 0; d < dlim; ++d) acc = fmaf(oh[qq * (dp + 1) + d], wv[e * (dp + 1) + d], acc);
     O[((long)bi * L + q) * ldo + hi * dh + e] = acc;
   }
@@ -517,11 +541,11 @@ __global__ __launch_bounds__(256) void merge_vproj_kernel(const float *__restric
 
 int launch_merge_vproj(const float *Opart, const float *Mpart, const float *Lpart, int nsplit, int b, int h, int L,
                        int Lp, int dp, int D, const float *gamma, const float *beta, const float *w_v, int dh,
-                       float *O, int ldo, float *stats, float *oprime_save, hipStream_t s, int pack_ks) {
+                       float *O, int ldo, float *stats, float *oprime_save, hipStream_t s, int pack_ks, int srow) {
   size_t lds = ((size_t)MERGE_ROWS * (dp + 1) + (size_t)dh * (dp + 1)) * sizeof(float);
   HN_REQUIRE(!(pack_ks && oprime_save), HN_E_SHAPE, "merge_vproj: the training tape keeps the natural channel layout");
   hipLaunchKernelGGL(merge_vproj_kernel, dim3(b * h, ceil_div(L, MERGE_ROWS)), dim3(256), lds, s, Opart, Mpart, Lpart,
-                     nsplit, h, L, Lp, dp, D, gamma, beta, w_v, dh, O, ldo, stats, oprime_save, pack_ks);
+                     nsplit, h, L, Lp, dp, D, gamma, beta, w_v, dh, O, ldo, stats, oprime_save, pack_ks, srow);
   HN_LAUNCH_CHECK("merge_vproj");
   return HN_OK;
 }

@@ -24,7 +24,7 @@ __device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(
 // scores of query row j for tokens 4 g + r;  dP^T = V dO^T has the same shape with the dO fragment in the place of
 // the Q fragment;  dQ += dS K uses dS straight from registers as the A operand and K rows 4 g + r as B.
 // ------------------------------------------------------------------------------------------------
-template <int DT, int NQ, bool SHARED_KV>
+template <int DT, int NQ, bool SHARED_KV, bool DROP = false>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a, int ngroups, int gy, int waves_per_block) {
   constexpr int DP = 16 * DT;
   const int L = a.Lq;
@@ -93,7 +93,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a, int ngr
     for (int i = 0; i < NQ; ++i) { S[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dP[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
     for (int s = 0; s < DT; ++s) {
-      const float4 vv = SHARED_KV ? kf[s] : vf[s];
+      float4 vv = SHARED_KV ? kf[s] : vf[s];
+      if (DROP && SHARED_KV && s == DT - 1 && a.drop_rowsum && g == 3) vv.w = 1.0f;      // the values' ones column dp-1 (row-sum channel)
 #pragma unroll
       for (int i = 0; i < NQ; ++i) {
         S[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].x, qf[i][s].x, S[i], 0, 0, 0);
@@ -123,6 +124,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a, int ngr
       float ok = tok < t_end ? 1.0f : 0.0f;
       if (mask) ok *= mask[min(tok, a.N - 1)] ? 1.0f : 0.0f;
       live[r] = ok;
+    }
+    if (DROP) {   // O = (P * d) V with the forward's keep/scale factors d:  dP <- d * (dO V^T)
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) {
+        float dm[4];
+        drop_quad(a.drop, (uint32_t)(t0 + 4 * g) >> 2, (uint32_t)(bh * L + (qg * NQ + i) * 16 + j), dm);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dP[i][r] *= dm[r];
+      }
     }
 #pragma unroll
     for (int i = 0; i < NQ; ++i)
@@ -165,9 +175,12 @@ int launch_attn_bwd_dq(const AttnBwdArgs &a, hipStream_t s) {
   HN_REQUIRE(blocks < (1L << 31), HN_E_UNSUPPORTED, "attn_bwd_dq: grid too large");
   dim3 grid((unsigned)blocks), block(64 * wpb);
   const bool shared = a.Kp == a.Vp;
-#define HN_DQ(DT_, NQ_)                                                                                          \
-  if (shared) hipLaunchKernelGGL((attn_bwd_dq_kernel<DT_, NQ_, true>), grid, block, 0, s, a, ngroups, gy, wpb);   \
-  else hipLaunchKernelGGL((attn_bwd_dq_kernel<DT_, NQ_, false>), grid, block, 0, s, a, ngroups, gy, wpb);
+  const bool drop = a.drop.thr != 0;
+#define HN_DQ(DT_, NQ_)                                                                                                          \
+  if (shared && drop) hipLaunchKernelGGL((attn_bwd_dq_kernel<DT_, NQ_, true, true>), grid, block, 0, s, a, ngroups, gy, wpb);     \
+  else if (shared) hipLaunchKernelGGL((attn_bwd_dq_kernel<DT_, NQ_, true, false>), grid, block, 0, s, a, ngroups, gy, wpb);      \
+  else if (drop) hipLaunchKernelGGL((attn_bwd_dq_kernel<DT_, NQ_, false, true>), grid, block, 0, s, a, ngroups, gy, wpb);        \
+  else hipLaunchKernelGGL((attn_bwd_dq_kernel<DT_, NQ_, false, false>), grid, block, 0, s, a, ngroups, gy, wpb);
   switch (dt) {
     case 1: HN_DQ(1, 4) break;
     case 2: HN_DQ(2, 2) break;
@@ -212,7 +225,7 @@ int launch_dq_reduce(const float *part, int nsplit, int b, int h, int L, int Lp,
 // (N = tokens) -- so lane (g, j) holds S[q = 4 g + r][t = j]: P^T and dS^T are then directly the A operands of
 // dV += P^T dO and dK += dS^T Q with k-chunk r = query rows {4 g + r}.
 // ------------------------------------------------------------------------------------------------
-template <int DT>
+template <int DT, bool DROP = false>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs a, int ntiles, int dh, int inner) {
   constexpr int DP = 16 * DT;
   const int L = a.Lq;
@@ -277,8 +290,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs a, int nt
     f32x4 P, dS;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      P[r] = fexp2(S[r] - mr[r]) * il[r] * live;
-      dS[r] = P[r] * (dP[r] - dl[r]);
+      const float pn = fexp2(S[r] - mr[r]) * il[r] * live;
+      float dmul = 1.0f;
+      if (DROP) dmul = drop_one(a.drop, (uint32_t)(t0 + j), (uint32_t)(bh * L + q0 + 4 * g + r));
+      dS[r] = pn * (dP[r] * dmul - dl[r]);
+      P[r] = pn * dmul;                                      // dV takes the thinned probabilities
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -307,12 +323,16 @@ int launch_attn_bwd_dkv(const AttnBwdArgs &a, int dh, int inner, hipStream_t s) 
   const int ntiles = ceil_div(a.N, 16);
   dim3 grid(ceil_div(ntiles, 4), a.b * a.h), block(256);
   HN_REQUIRE(grid.y <= 65535, HN_E_UNSUPPORTED, "attn_bwd_dkv: b*h too large");
+#define HN_DKV(DT_)                                                                                              \
+  if (a.drop.thr != 0) hipLaunchKernelGGL((attn_bwd_dkv_kernel<DT_, true>), grid, block, 0, s, a, ntiles, dh, inner); \
+  else hipLaunchKernelGGL((attn_bwd_dkv_kernel<DT_, false>), grid, block, 0, s, a, ntiles, dh, inner);
   switch (a.dp / 16) {
-    case 1: hipLaunchKernelGGL((attn_bwd_dkv_kernel<1>), grid, block, 0, s, a, ntiles, dh, inner); break;
-    case 2: hipLaunchKernelGGL((attn_bwd_dkv_kernel<2>), grid, block, 0, s, a, ntiles, dh, inner); break;
-    case 4: hipLaunchKernelGGL((attn_bwd_dkv_kernel<4>), grid, block, 0, s, a, ntiles, dh, inner); break;
-    default: hipLaunchKernelGGL((attn_bwd_dkv_kernel<8>), grid, block, 0, s, a, ntiles, dh, inner); break;
+    case 1: HN_DKV(1) break;
+    case 2: HN_DKV(2) break;
+    case 4: HN_DKV(4) break;
+    default: HN_DKV(8) break;
   }
+#undef HN_DKV
   HN_LAUNCH_CHECK("attn_bwd_dkv");
   return HN_OK;
 }
@@ -371,6 +391,45 @@ int launch_head_affine(const float *src, int lds, int spitch, const float *mul, 
   hipLaunchKernelGGL(head_affine_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, lds, spitch, mul, ldm, mpitch, colscale, coladd,
                      scale, h, width, dpitch, ldd, rows, dst);
   HN_LAUNCH_CHECK("head_affine");
+  return HN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Shared-context (rank-D) binding under dropout.  Without dropout sum_t p_t = 1 and the value bias folds to a constant:
+// A = (P z) gamma + beta.  With thinned probabilities p' the row sum s = sum_t p'_t is a random variable; the forward keeps
+// it in column dp-1 of the saved average (the values get a ones column), and
+//     A_c = o_c gamma_c + beta_c s        d o_c = dA_c gamma_c        d s = sum_c dA_c beta_c        d beta_c = sum dA_c s
+// mode 0: dst = A   mode 1: dst_c = dA_c * s (-> colsum = d beta)   mode 2: dst = d(saved): [dA gamma | 0 .. | sum dA beta]
+// Layout of every operand: (rows, h, dp) with D valid channels and the row-sum channel at dp-1.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void srow_affine_kernel(const float *__restrict__ saved, const float *__restrict__ dA,
+                                                          const float *__restrict__ gamma, const float *__restrict__ beta, int mode,
+                                                          int D, int dp, long total, float *__restrict__ dst) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % dp);
+    const long base = i - c;
+    float v = 0.0f;
+    if (mode == 0) {
+      if (c < D) v = saved[i] * (gamma ? gamma[c] : 1.0f) + (beta ? beta[c] : 0.0f) * saved[base + dp - 1];
+    } else if (mode == 1) {
+      if (c < D) v = dA[i] * saved[base + dp - 1];
+    } else {
+      if (c < D) v = dA[i] * (gamma ? gamma[c] : 1.0f);
+      else if (c == dp - 1 && beta) {
+        for (int k = 0; k < D; ++k) v = fmaf(dA[base + k], beta[k], v);
+      }
+    }
+    dst[i] = v;
+  }
+}
+
+int launch_srow_affine(const float *saved, const float *dA, const float *gamma, const float *beta, int mode, int h, int D, int dp,
+                       long rows, float *dst, hipStream_t s) {
+  const long total = rows * h * dp;
+  long blocks = ceil_div_ll(total, 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(srow_affine_kernel, dim3((unsigned)blocks), dim3(256), 0, s, saved, dA, gamma, beta, mode, D, dp, total, dst);
+  HN_LAUNCH_CHECK("srow_affine");
   return HN_OK;
 }
 

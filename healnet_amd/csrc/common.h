@@ -108,6 +108,57 @@ struct Arena {
 enum { PRO_NONE = 0, PRO_AFFINE = 1, PRO_LAYERNORM = 2 };
 enum { ACT_NONE = 0, ACT_LEAKY = 1, ACT_GLU_SELU = 2, ACT_GLU_GELU = 3 };
 
+// ------------------------------------------------------------------------------------------------
+// Dropout (nn.Dropout at healnet/models/healnet.py:381,421 on the attention probabilities and :347 on
+// the feed-forward output).  Counter-based: the keep decision of an element is a pure function of
+// (seed, offset, stream id of the block, row, column), so the forward core, both backward kernels and the mask export
+// used by the tests regenerate identical masks whatever their tiling.  Philox4x32-10; one call yields the four
+// decisions of an aligned column quad (row, 4 c .. 4 c + 3): keep iff word >= thr, P(keep) = 1 - p.
+// ------------------------------------------------------------------------------------------------
+struct DropCfg {
+  uint32_t thr;        // p * 2^32; 0 = dropout disabled
+  float scale;         // 1 / (1 - p)
+  uint32_t seed_lo, seed_hi, sid, offset;
+};
+static inline DropCfg make_drop(float p, uint64_t seed, uint32_t offset, uint32_t sid) {
+  DropCfg d;
+  d.thr = 0; d.scale = 1.0f; d.seed_lo = (uint32_t)seed; d.seed_hi = (uint32_t)(seed >> 32); d.sid = sid; d.offset = offset;
+  if (p > 0.0f) {
+    double t = (double)p * 4294967296.0;
+    d.thr = t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t;
+    if (d.thr == 0) d.thr = 1;
+    d.scale = (float)(1.0 / (1.0 - (double)p));
+  }
+  return d;
+}
+__device__ __forceinline__ void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+// multipliers (scale or 0) of the aligned quad (row, 4 * quad .. 4 * quad + 3)
+__device__ __forceinline__ void drop_quad(const DropCfg &d, uint32_t quad, uint32_t row, float (&m)[4]) {
+  uint32_t w[4];
+  philox4x32_10(d.seed_lo, d.seed_hi, quad, row, d.sid, d.offset, w);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) m[r] = w[r] >= d.thr ? d.scale : 0.0f;
+}
+__device__ __forceinline__ float drop_one(const DropCfg &d, uint32_t col, uint32_t row) {
+  uint32_t w[4];
+  philox4x32_10(d.seed_lo, d.seed_hi, col >> 2, row, d.sid, d.offset, w);
+  const uint32_t c = col & 3;
+  const uint32_t v = c == 0 ? w[0] : (c == 1 ? w[1] : (c == 2 ? w[2] : w[3]));
+  return v >= d.thr ? d.scale : 0.0f;
+}
+constexpr uint32_t DROP_SID_FF = 0x80000000u;      // stream ids of feed-forward blocks carry this bit
+
 struct GemmArgs {
   const float *A; long lda; long strideA;
   const float *W; long ldw; long strideW;      // W[n][k], NT
@@ -147,6 +198,8 @@ struct AttnCoreArgs {
   int ones_in_mem;                              // ... and the context rows already carry 1.0 there (written by K1)
   int qk_steps;                                 // packed context layout: QK^T k-steps to run (0 = all dp/4)
   float *Ofinal; int ldo, dh; float *stats;     // nsplit == 1 only: write the normalised O (b*Lq, ldo) + stats directly (no merge kernel)
+  DropCfg drop;                                 // training: dropout on the probabilities (thr == 0: off; needs ones_col == 0)
+  int drop_rowsum;                              // ... shared-context binding: also accumulate sum_t p'_t in column dp-1
 };
 int launch_attn_core(const AttnCoreArgs &a, hipStream_t s);
 
@@ -170,13 +223,17 @@ int launch_qfold(const float *Q, int ldq_row, const float *w_k, int D, const flo
                  float *Qf, int b, int h, int L, int Lp, int dh, int dp, hipStream_t s, int pack_ks = 0);
 int launch_merge_vproj(const float *Opart, const float *Mpart, const float *Lpart, int nsplit, int b, int h,
                        int L, int Lp, int dp, int D, const float *gamma, const float *beta, const float *w_v,
-                       int dh, float *O, int ldo, float *stats, float *oprime_save, hipStream_t s, int pack_ks = 0);
+                       int dh, float *O, int ldo, float *stats, float *oprime_save, hipStream_t s, int pack_ks = 0, int srow = 0);
 int launch_merge_explicit(const float *Opart, const float *Mpart, const float *Lpart, int nsplit, int b, int h,
                           int L, int Lp, int dp, int dh, float *O, int ldo, float *stats, hipStream_t s);
 int launch_probs(const float *Q, long q_b, long q_h, int ldq, int dp, const float *Kp, long k_b, long k_h, int ldk,
                  const uint8_t *mask, const float *stats, float *P, int b, int h, int L, int N, hipStream_t s);
 int launch_importance(const float *Q, long q_b, long q_h, int ldq, int dp, const float *Kp, long k_b, long k_h, int ldk,
                       const uint8_t *mask, const float *stats, float *I, int b, int h, int L, int N, hipStream_t s);
+
+
+int launch_dropout_apply(const float *src, const float *add, float *out, long rows, int cols, const DropCfg &d, hipStream_t s);
+int launch_dropout_mask(uint8_t *mask, long rows, int cols, const DropCfg &d, hipStream_t s);
 
 // training-step tail (train.hip)
 int launch_surv_nll(const float *logits, const long long *y, const float *cens, const float *weights, int b, int K, float alpha,
@@ -229,6 +286,8 @@ struct AttnBwdArgs {
   float *dQpart;                                 // (b, h, nsplit, Lp, dp)
   float *dKV; float dk_scale;                    // dkv kernel: compact (b*N, 2*inner) output
   int b, h, Lq, Lp, N, dp, nsplit, chunk;
+  DropCfg drop;                                  // the forward's dropout on the probabilities (thr == 0: off)
+  int drop_rowsum;                               // shared-context binding under dropout: V carries a ones column dp-1
 };
 int launch_attn_bwd_dq(const AttnBwdArgs &a, hipStream_t s);
 int launch_dq_reduce(const float *part, int nsplit, int b, int h, int L, int Lp, int dp, int width, float scale, float *out,
@@ -239,6 +298,9 @@ int launch_rowdot_heads(const float *X, int ldx, int xpitch, const float *Y, int
 int launch_head_affine(const float *src, int lds, int spitch, const float *mul, int ldm, int mpitch, const float *colscale,
                        const float *coladd, float scale, int h, int width, int dpitch, int ldd, long rows, float *dst,
                        hipStream_t s);
+// rank-D binding under dropout (row-sum channel dp-1 of the saved average, see attention_bwd.hip)
+int launch_srow_affine(const float *saved, const float *dA, const float *gamma, const float *beta, int mode, int h, int D, int dp,
+                       long rows, float *dst, hipStream_t s);
 int launch_kv_weight_grads(const float *G, const float *cs, const float *w, const float *gamma, const float *beta, int nrows, int D,
                            float *dw, float *dgamma, float *dbeta, hipStream_t s);
 int launch_segsum(const float *X, int seg, int cols, int nseg, float *out, hipStream_t s);

@@ -126,4 +126,50 @@ int launch_head(const float *x, int b, int L, int d, const float *nw, const floa
   return HN_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// dropout helpers (see DropCfg in common.h)
+// ------------------------------------------------------------------------------------------------
+// out[r, c] = (add ? add[r, c] : 0) + src[r, c] * keepscale(r, c)        (cols % 4 == 0)
+__global__ __launch_bounds__(256) void dropout_apply_kernel(const float *__restrict__ src, const float *add, float *out, long rows,
+                                                            int cols, DropCfg d) {
+  const int q4 = cols >> 2;
+  const long total = rows * q4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / q4;
+    const int q = (int)(i - r * q4);
+    float m[4];
+    drop_quad(d, (uint32_t)q, (uint32_t)r, m);
+    const float4 v = ((const float4 *)src)[i];
+    float4 o = make_float4(v.x * m[0], v.y * m[1], v.z * m[2], v.w * m[3]);
+    if (add) { const float4 a = ((const float4 *)add)[i]; o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w; }
+    ((float4 *)out)[i] = o;
+  }
+}
+
+int launch_dropout_apply(const float *src, const float *add, float *out, long rows, int cols, const DropCfg &d, hipStream_t s) {
+  HN_REQUIRE((cols & 3) == 0, HN_E_UNSUPPORTED, "dropout: the feature dimension (%d) must be a multiple of 4", cols);
+  long blocks = ceil_div_ll(rows * (cols >> 2), 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(dropout_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, add, out, rows, cols, d);
+  HN_LAUNCH_CHECK("dropout_apply");
+  return HN_OK;
+}
+
+__global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t *__restrict__ mask, long rows, int cols, DropCfg d) {
+  const long total = rows * cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / cols;
+    const int c = (int)(i - r * cols);
+    mask[i] = drop_one(d, (uint32_t)c, (uint32_t)r) != 0.0f ? 1 : 0;
+  }
+}
+
+int launch_dropout_mask(uint8_t *mask, long rows, int cols, const DropCfg &d, hipStream_t s) {
+  long blocks = ceil_div_ll(rows * cols, 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, s, mask, rows, cols, d);
+  HN_LAUNCH_CHECK("dropout_mask");
+  return HN_OK;
+}
+
 }  // namespace hn

@@ -150,8 +150,10 @@ class Attention(nn.Module):
         (explainer.py:161-164, :209-211) -- computed without materialising the (b*heads, L, N) matrix."""
         return None if self._probs_fn is None else self._probs_fn(reduced=True)
 
-    def _params(self, norm: Optional[nn.LayerNorm], norm_context: Optional[nn.LayerNorm]) -> _capi.AttnParams:
+    def _params(self, norm: Optional[nn.LayerNorm], norm_context: Optional[nn.LayerNorm],
+                dropout: float = 0.0) -> _capi.AttnParams:
         return _capi.AttnParams(
+            dropout=float(dropout),
             heads=self.heads, dim_head=self.dim_head, query_dim=self.query_dim,
             norm_w=_ptr(norm.weight) if norm is not None else None,
             norm_b=_ptr(norm.bias) if norm is not None else None,
@@ -170,8 +172,8 @@ class Attention(nn.Module):
 
     def _check_mode(self) -> None:
         if self.training and self.dropout_p > 0.0:
-            raise NotImplementedError("healnet_amd: attention dropout > 0 in training mode is not implemented "
-                                      "(SURVEY.md §8 f2); call .eval() or construct with attn_dropout=0")
+            raise NotImplementedError("healnet_amd: the stand-alone Attention / FeedForward modules are inference ops; dropout "
+                                      "(and autograd) run through HealNet's fused training path -- call .eval() here")
 
     def _run(self, x: torch.Tensor, context: Optional[torch.Tensor], mask: Optional[torch.Tensor],
              norm: Optional[nn.LayerNorm], norm_context: Optional[nn.LayerNorm], residual: bool) -> torch.Tensor:
@@ -237,8 +239,8 @@ class FeedForward(nn.Module):
         self.dropout_p = float(dropout)
         self.net = nn.Sequential(nn.Linear(dim, dim * mult * 2), nn.Identity(), nn.Linear(dim * mult, dim), nn.Identity())
 
-    def _params(self, norm: Optional[nn.LayerNorm]) -> _capi.FFParams:
-        return _capi.FFParams(dim=self.dim, gate=0 if self.snn else 1,
+    def _params(self, norm: Optional[nn.LayerNorm], dropout: float = 0.0) -> _capi.FFParams:
+        return _capi.FFParams(dropout=float(dropout), dim=self.dim, gate=0 if self.snn else 1,
                               norm_w=_ptr(norm.weight) if norm is not None else None,
                               norm_b=_ptr(norm.bias) if norm is not None else None,
                               w1=_ptr(self.net[0].weight), b1=_ptr(self.net[0].bias),
@@ -322,10 +324,11 @@ class _FusionFunction(torch.autograd.Function):
     gradient, as in the reference's training loop (healnet/main.py:432-465)."""
 
     @staticmethod
-    def forward(ctx, module, inputs, held, mask_u8, b, skip_self, embeddings, stats_ptrs, x_ptrs, *params):
+    def forward(ctx, module, inputs, held, mask_u8, b, skip_self, embeddings, stats_ptrs, x_ptrs, rng, *params):
         lib = _capi.lib()
         device = module.latents.device
-        model, keep = module._descriptor()
+        model, keep = module._descriptor(rng=rng)
+        ctx.rng = rng
         masked = int(mask_u8 is not None)
         tape_bytes = lib.hn_fusion_tape_bytes(C.byref(model), inputs, b, masked, int(skip_self))
         need = lib.hn_fusion_workspace_bytes(C.byref(model), inputs, b)
@@ -347,7 +350,7 @@ class _FusionFunction(torch.autograd.Function):
         lib = _capi.lib()
         module, params = ctx.module, ctx.params
         device = module.latents.device
-        model, keep = module._descriptor()
+        model, keep = module._descriptor(rng=ctx.rng)
         # healnet_amd.train.flatten_parameters(): every p.grad is a view of one flat buffer -> the kernels accumulate
         # straight into it (no per-parameter zero tensors, no AccumulateGrad add pass) and autograd gets None back.
         flat = getattr(module, "_hn_flat", None)
@@ -371,8 +374,8 @@ class _FusionFunction(torch.autograd.Function):
                                            int(ctx.embeddings), dout.data_ptr(), ctx.tape.data_ptr(), C.byref(grads),
                                            ws.data_ptr(), ws.numel(), _stream_ptr(device)), "hn_fusion_backward")
         if direct:
-            return (None,) * (9 + len(params))
-        return (None,) * 9 + tuple(gmap.get(id(p)) for p in params)
+            return (None,) * (10 + len(params))
+        return (None,) * 10 + tuple(gmap.get(id(p)) for p in params)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -444,8 +447,11 @@ class HealNet(nn.Module):
         self._last: Optional[dict] = None
 
     # -- C-ABI descriptor ------------------------------------------------------------------------
-    def _descriptor(self):
+    def _descriptor(self, rng=None):
+        """rng = (seed, offset) of a training forward / its backward: blocks then carry their dropout rates (Philox masks,
+        include/healnet_hip.h hn_rng); None = inference descriptor (no dropout)."""
         M, depth = self.modalities, self.depth
+        drop = (lambda mod: mod.dropout_p) if rng is not None else (lambda mod: 0.0)
         keep = []   # keep ctypes arrays alive for the duration of the call
         cross_attn = (_capi.AttnParams * (depth * M))()
         cross_ff = (_capi.FFParams * (depth * M))()
@@ -455,12 +461,12 @@ class HealNet(nn.Module):
             mods = self.layers[layer]
             for m in range(M):
                 blk, ffn = mods[2 * m], mods[2 * m + 1]
-                cross_attn[layer * M + m] = blk.fn._params(blk.norm, blk.norm_context)
-                cross_ff[layer * M + m] = ffn.fn._params(ffn.norm)
+                cross_attn[layer * M + m] = blk.fn._params(blk.norm, blk.norm_context, drop(blk.fn))
+                cross_ff[layer * M + m] = ffn.fn._params(ffn.norm, drop(ffn.fn))
             if self.self_per_cross_attn >= 1:
                 blk, ffn = mods[2 * M][0], mods[2 * M][1]
-                self_attn[layer] = blk.fn._params(blk.norm, None)
-                self_ff[layer] = ffn.fn._params(ffn.norm)
+                self_attn[layer] = blk.fn._params(blk.norm, None, drop(blk.fn))
+                self_ff[layer] = ffn.fn._params(ffn.norm, drop(ffn.fn))
         cd = (C.c_int * M)(*[int(c) for c in self.input_channels])
         ax = (C.c_int * M)(*[int(a) for a in self.input_axes])
         model = _capi.Model(
@@ -473,7 +479,9 @@ class HealNet(nn.Module):
             head_norm_b=_ptr(self.to_logits[1].bias) if self.final_classifier_head else None,
             head_w=_ptr(self.to_logits[2].weight) if self.final_classifier_head else None,
             head_b=_ptr(self.to_logits[2].bias) if self.final_classifier_head else None,
-            core_precision={"fp32": _capi.HN_CORE_F32, "bf16": _capi.HN_CORE_BF16, "bf16x3": _capi.HN_CORE_BF16X3}[self.core_precision])
+            core_precision={"fp32": _capi.HN_CORE_F32, "bf16": _capi.HN_CORE_BF16, "bf16x3": _capi.HN_CORE_BF16X3}[self.core_precision],
+            rng=_capi.Rng(seed=int(rng[0]) & 0xFFFFFFFFFFFFFFFF, offset=int(rng[1]) & 0xFFFFFFFF, stream=0) if rng is not None
+            else _capi.Rng(0, 0, 0))
         keep.extend([cross_attn, cross_ff, self_attn, self_ff, cd, ax])
         return model, keep
 
@@ -508,11 +516,10 @@ class HealNet(nn.Module):
         if self.self_per_cross_attn >= 2:
             raise ValueError("self_per_cross_attn >= 2 fails in the reference as well (healnet.py:242: "
                              "`self_attn, self_ff = layer[-1]`)")
-        if self.training:
-            for mod in self.modules():
-                if isinstance(mod, (Attention, FeedForward)) and mod.dropout_p > 0.0:
-                    raise NotImplementedError("healnet_amd: dropout > 0 in training mode is not implemented "
-                                              "(SURVEY.md §8 f2); call .eval()")
+
+    def _dropout_active(self) -> bool:
+        """nn.Dropout semantics: masks are drawn in training mode only (healnet.py:381,421 attention, :347 feed-forward)."""
+        return self.training and any(isinstance(mod, (Attention, FeedForward)) and mod.dropout_p > 0.0 for mod in self.modules())
 
     # -- forward ---------------------------------------------------------------------------------
     def forward(self, tensors: List[Optional[torch.Tensor]], mask: Optional[torch.Tensor] = None,
@@ -597,11 +604,19 @@ class HealNet(nn.Module):
                     stats_ptrs[layer * (M + 1) + j] = stats_t[layer * (M + 1) + j].data_ptr()
                     x_ptrs[layer * (M + 1) + j] = trace_t[layer * (M + 1) + j].data_ptr()
 
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            # autograd path (train or eval mode alike, as in PyTorch): tape-recording forward + hn_fusion_backward
+        dropping = self._dropout_active()
+        if dropping or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
+            # autograd path (train or eval mode alike, as in PyTorch): tape-recording forward + hn_fusion_backward.
+            # Dropout masks are drawn in training mode only, grad mode or not (nn.Dropout); every forward advances the
+            # Philox offset, the seed is torch's global seed (torch.manual_seed).
             if _profile is not None:
-                raise ValueError("profiling hooks are only available under torch.no_grad()")
-            out = _FusionFunction.apply(self, inputs, held, mask_u8, b, bool(verbose), embeddings, stats_ptrs, x_ptrs,
+                raise ValueError("profiling hooks are only available under torch.no_grad() in eval mode")
+            rng = None
+            if dropping:
+                self._rng_offset = (getattr(self, "_rng_offset", 0) + 1) & 0xFFFFFFFF
+                rng = (torch.initial_seed(), self._rng_offset)
+            self._last_rng = rng
+            out = _FusionFunction.apply(self, inputs, held, mask_u8, b, bool(verbose), embeddings, stats_ptrs, x_ptrs, rng,
                                         *list(self.parameters()))
         else:
             _capi.check(lib.hn_fusion_forward(C.byref(model), inputs, b, _ptr(mask_u8), int(bool(verbose)), int(embeddings),

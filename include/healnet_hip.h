@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HN_ABI_VERSION 2
+#define HN_ABI_VERSION 3
 #define HN_MAX_AXES 4
 
 typedef enum hn_status {
@@ -86,6 +86,18 @@ int hn_context_pitch(int D, int dim_head);
  * Attention block                                      replaces PreNorm.forward :313-321 +
  *                                                      Attention.forward :400-426 (+ residual :236/:244)
  * ------------------------------------------------------------------------------------------- */
+/* Counter-based dropout: whether element (row, col) of a block's mask is kept is a pure function of
+ * (seed, offset, stream, row, col) -- Philox4x32-10, one call per aligned column quad, keep iff word >= p * 2^32,
+ * kept values scaled by 1 / (1 - p).  `seed` is the generator seed, `offset` a per-forward counter (a fresh mask every
+ * iteration; the backward is called with the forward's value), `stream` tells the blocks of a model apart: the fused
+ * entry points use hn_model.rng and set stream = index of the block in execution order (feed-forward blocks have
+ * bit 31 set).  The masks are reproducible bit for bit by hn_dropout_mask. */
+typedef struct hn_rng {
+  uint64_t seed;
+  uint32_t offset;
+  uint32_t stream;
+} hn_rng;
+
 typedef struct hn_attn_params {
   int heads, dim_head;    /* inner = heads * dim_head                                          */
   int query_dim;          /* l_d                                                               */
@@ -97,6 +109,8 @@ typedef struct hn_attn_params {
   const float *w_kv;      /* to_kv.weight     (2*inner, D)   rows [0,inner) = K, rest = V      */
   const float *w_out;     /* to_out.0.weight  (query_dim, inner)                               */
   const float *b_out;     /* to_out.0.bias    (query_dim)                                      */
+  float dropout;          /* nn.Dropout on the attention probabilities (:381,:421); training entry points only,  */
+  hn_rng rng;             /* 0 = off.  rng: see hn_rng (the fused entry points override it per block)            */
 } hn_attn_params;
 
 /* y = LeakyReLU_0.01( concat_h( softmax(2 * dim_head^-1/2 * Q_h K_h^T) V_h ) W_out^T + b_out )  [+ x_in]
@@ -154,6 +168,8 @@ typedef struct hn_ff_params {
   const float *norm_w; /* NULL -> no LayerNorm (bare FeedForward)                               */
   const float *norm_b;
   const float *w1, *b1, *w2, *b2;
+  float dropout;       /* nn.Dropout on the block output before the residual (:347); 0 = off                    */
+  hn_rng rng;
 } hn_ff_params;
 
 int hn_ff_fwd(const hn_ff_params *p, const float *x_in, float *x_out, int residual, int rows,
@@ -209,6 +225,7 @@ typedef struct hn_model {
   const hn_ff_params *self_ff;      /* [depth]                                                  */
   const float *head_norm_w, *head_norm_b, *head_w, *head_b;
   int core_precision;            /* hn_core_precision (inference forward only)                  */
+  hn_rng rng;                    /* dropout generator state of hn_fusion_forward_train / _backward (stream unused) */
 } hn_model;
 
 /* Optional timing hooks: when non-NULL, hn_fusion_forward records ev_start[i] / ev_stop[i]
@@ -282,6 +299,10 @@ int hn_l1_adam_step(float *params, const float *grads, float *exp_avg, float *ex
                     double grad_scale, double lr, double beta1, double beta2, double eps, int step, float *reg_loss,
                     void *workspace, size_t workspace_bytes, void *stream);
 size_t hn_l1_adam_workspace_bytes(void);
+
+/* The dropout mask of one block as bytes (1 = kept): (rows, cols) = (b*heads*L, N) for an attention block,
+ * (b*L, dim) for a feed-forward block (pass is_ff != 0, which sets bit 31 of rng.stream).  Test / debugging aid. */
+int hn_dropout_mask(float p, hn_rng rng, int is_ff, long rows, int cols, uint8_t *mask, void *stream);
 
 #ifdef __cplusplus
 }

@@ -109,7 +109,7 @@ def layer_norm(x: Tensor, weight: Tensor, bias: Tensor, eps: float = 1e-5) -> Te
 # --------------------------------------------------------------------------------------
 def attention(x: Tensor, context: Optional[Tensor], w_q: Tensor, w_kv: Tensor, w_out: Tensor, b_out: Tensor,
               heads: int, mask: Optional[Tensor] = None, temperature: float = 0.5,
-              return_weights: bool = False):
+              return_weights: bool = False, drop_mult: Optional[Tensor] = None):
     """healnet.py:400-426.  x (b, L, dq) already normalised; context (b, N, D) already normalised
     (or None -> x).  Returns LeakyReLU_{0.01}(concat_heads(P V) W_out^T + b_out) and optionally P
     with shape (b*heads, L, N) (batch-major head index b*heads + h, :407)."""
@@ -133,7 +133,8 @@ def attention(x: Tensor, context: Optional[Tensor], w_q: Tensor, w_kv: Tensor, w
         keep = flat[:, None, None, :].expand(b, heads, 1, n).reshape(b * heads, 1, n)
         sim = sim.masked_fill(~keep, neg)
     attn = torch.softmax(sim / temperature, dim=-1)                                 # :419 / :364-365
-    out = torch.bmm(attn, vh)                                                       # :424
+    pv = attn if drop_mult is None else attn * drop_mult                            # :421 nn.Dropout with a GIVEN mask:
+    out = torch.bmm(pv, vh)                                                         # :424   drop_mult = keep / (1 - p)
     out = out.reshape(b, heads, L, e).permute(0, 2, 1, 3).reshape(b, L, inner)      # :425
     out = F.leaky_relu(out @ w_out.t() + b_out, negative_slope=1e-2)                # :383-386, :426
     return (out, attn) if return_weights else out
@@ -142,43 +143,46 @@ def attention(x: Tensor, context: Optional[Tensor], w_q: Tensor, w_kv: Tensor, w
 # --------------------------------------------------------------------------------------
 # a8: gated feed-forward
 # --------------------------------------------------------------------------------------
-def feed_forward(x: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, snn: bool = True) -> Tensor:
-    """healnet.py:339-351 with the SELU (:328-331) or GELU (:323-326) gate; x already normalised."""
+def feed_forward(x: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, snn: bool = True,
+                 drop_mult: Optional[Tensor] = None) -> Tensor:
+    """healnet.py:339-351 with the SELU (:328-331) or GELU (:323-326) gate; x already normalised.
+    drop_mult: the nn.Dropout of :347 with a given mask (keep / (1 - p), shape of the output)."""
     u = x @ w1.t() + b1
     half = u.shape[-1] // 2
     a, g = u[..., :half], u[..., half:]                                             # chunk(2): value first, gate second
     z = a * (F.selu(g) if snn else F.gelu(g))
-    return z @ w2.t() + b2
+    y = z @ w2.t() + b2
+    return y if drop_mult is None else y * drop_mult
 
 
 # --------------------------------------------------------------------------------------
 # a9/a10: the fusion loop over a reference-layout state_dict
 # --------------------------------------------------------------------------------------
-def _cross_block(sd: Dict[str, Tensor], pfx: str, x: Tensor, ctx: Tensor, heads: int, mask, keep: Optional[list]):
+def _cross_block(sd: Dict[str, Tensor], pfx: str, x: Tensor, ctx: Tensor, heads: int, mask, keep: Optional[list], dm=None):
     xn = layer_norm(x, sd[pfx + "norm.weight"], sd[pfx + "norm.bias"])                                  # :314
     cn = layer_norm(ctx, sd[pfx + "norm_context.weight"], sd[pfx + "norm_context.bias"])              # :316-319
     y, p = attention(xn, cn, sd[pfx + "fn.to_q.weight"], sd[pfx + "fn.to_kv.weight"],
                      sd[pfx + "fn.to_out.0.weight"], sd[pfx + "fn.to_out.0.bias"], heads, mask,
-                     return_weights=True)
+                     return_weights=True, drop_mult=dm)
     if keep is not None:
         keep.append(p)
     return y + x                                                                                         # :236 residual
 
 
-def _self_block(sd: Dict[str, Tensor], pfx: str, x: Tensor, heads: int, keep: Optional[list]):
+def _self_block(sd: Dict[str, Tensor], pfx: str, x: Tensor, heads: int, keep: Optional[list], dm=None):
     xn = layer_norm(x, sd[pfx + "norm.weight"], sd[pfx + "norm.bias"])
     y, p = attention(xn, None, sd[pfx + "fn.to_q.weight"], sd[pfx + "fn.to_kv.weight"],
                      sd[pfx + "fn.to_out.0.weight"], sd[pfx + "fn.to_out.0.bias"], heads, None,
-                     return_weights=True)
+                     return_weights=True, drop_mult=dm)
     if keep is not None:
         keep.append(p)
     return y + x                                                                                         # :244
 
 
-def _ff_block(sd: Dict[str, Tensor], pfx: str, x: Tensor, snn: bool):
+def _ff_block(sd: Dict[str, Tensor], pfx: str, x: Tensor, snn: bool, dm=None):
     xn = layer_norm(x, sd[pfx + "norm.weight"], sd[pfx + "norm.bias"])
     return feed_forward(xn, sd[pfx + "fn.net.0.weight"], sd[pfx + "fn.net.0.bias"],
-                        sd[pfx + "fn.net.2.weight"], sd[pfx + "fn.net.2.bias"], snn) + x                 # :237/:245
+                        sd[pfx + "fn.net.2.weight"], sd[pfx + "fn.net.2.bias"], snn, dm) + x             # :237/:245
 
 
 @dataclass
@@ -191,9 +195,13 @@ class FusionTrace:
 
 def fusion_forward(sd: Dict[str, Tensor], cfg: FusionConfig, tensors: Sequence[Optional[Tensor]],
                    mask: Optional[Tensor] = None, return_embeddings: bool = False, verbose: bool = False,
-                   trace: Optional[FusionTrace] = None) -> Tensor:
+                   trace: Optional[FusionTrace] = None, drop: Optional[Dict[int, Tensor]] = None) -> Tensor:
     """healnet.py:190-250 including its observable quirks:
 
+      * ``drop`` (training mode with dropout > 0): {index of the executed block, counted in execution order ->
+        multiplier tensor keep / (1 - p)} -- attention blocks (b*heads, L, N) on the probabilities (:421), feed-forward
+        blocks (b, L, d) on the block output (:347).  The masks are GIVEN (the tests export the build's own Philox masks),
+        so this restates nn.Dropout exactly for any mask;
       * a ``None`` modality skips its cross-attention + cross-FF, but the latent self block of that
         (layer, modality) iteration still runs (:235-245); with ``verbose=True`` the ``continue`` at
         :232 skips the self block too;
@@ -223,24 +231,30 @@ def fusion_forward(sd: Dict[str, Tensor], cfg: FusionConfig, tensors: Sequence[O
     x = sd["latents"].unsqueeze(0).expand(b, -1, -1)                                  # :225
     if cfg.self_per_cross_attn not in (0, 1):
         raise ValueError("self_per_cross_attn >= 2 fails in the reference (healnet.py:242)")
+    step = 0
+    dm = (lambda k: None) if drop is None else (lambda k: drop.get(k))
     for layer in range(cfg.depth):
         for m in range(M):
             if not present[m] and verbose:                                            # :229-232
                 continue
             if present[m]:
-                x = _cross_block(sd, f"layers.{layer}.{2 * m}.", x, ctxs[m], cfg.x_heads, mask, keep)
+                x = _cross_block(sd, f"layers.{layer}.{2 * m}.", x, ctxs[m], cfg.x_heads, mask, keep, dm(step))
+                step += 1
                 tags.append((layer, "cross", m))
                 if trace is not None:
                     trace.blocks.append(x)
-                x = _ff_block(sd, f"layers.{layer}.{2 * m + 1}.", x, cfg.snn)
+                x = _ff_block(sd, f"layers.{layer}.{2 * m + 1}.", x, cfg.snn, dm(step))
+                step += 1
                 if trace is not None:
                     trace.blocks.append(x)
             if cfg.self_per_cross_attn > 0:                                           # :241-245
-                x = _self_block(sd, f"layers.{layer}.{2 * M}.0.", x, cfg.l_heads, keep)
+                x = _self_block(sd, f"layers.{layer}.{2 * M}.0.", x, cfg.l_heads, keep, dm(step))
+                step += 1
                 tags.append((layer, "self", m))
                 if trace is not None:
                     trace.blocks.append(x)
-                x = _ff_block(sd, f"layers.{layer}.{2 * M}.1.", x, cfg.snn)
+                x = _ff_block(sd, f"layers.{layer}.{2 * M}.1.", x, cfg.snn, dm(step))
+                step += 1
                 if trace is not None:
                     trace.blocks.append(x)
     if return_embeddings or not cfg.final_classifier_head:                            # :247-250, :181-185

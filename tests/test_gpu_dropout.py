@@ -1,0 +1,158 @@
+"""GPU: dropout inside the path.  The masks are counter-based (Philox), so a test can export exactly the
+masks a training forward used (hn_dropout_mask) and hand them to the CPU oracle, which restates nn.Dropout for a GIVEN mask:
+forward and every parameter gradient are then compared like in the dropout-free tests; the statistics of the masks
+themselves (keep rate, independence across blocks / calls) are checked separately."""
+import ctypes as C
+
+import pytest
+import torch
+
+from conftest import assert_close, rel_err
+from oracle import healnet_cpu as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def hn():
+    import healnet_amd
+    return healnet_amd
+
+
+def _mask(hn, p, seed, offset, stream, is_ff, rows, cols):
+    from healnet_amd import _capi
+    out = torch.empty(rows, cols, dtype=torch.uint8, device=DEV)
+    rng = _capi.Rng(seed=seed & 0xFFFFFFFFFFFFFFFF, offset=offset, stream=stream)
+    _capi.check(_capi.lib().hn_dropout_mask(float(p), rng, int(is_ff), rows, cols, out.data_ptr(),
+                                            torch.cuda.current_stream().cuda_stream), "hn_dropout_mask")
+    return out
+
+
+def _oracle_masks(hn, model, kw, b, n_tokens, seed, offset, present):
+    """multipliers per executed block, numbered like build_schedule (api.hip) / oracle.fusion_forward"""
+    M, L, d = kw["n_modalities"], kw["l_c"], kw["l_d"]
+    pa, pf = kw.get("attn_dropout", 0.0), kw.get("ff_dropout", 0.0)
+    drop, k = {}, 0
+    for layer in range(kw["depth"]):
+        for m in range(M):
+            if present[m]:
+                h = kw["x_heads"]
+                if pa > 0:
+                    drop[k] = (_mask(hn, pa, seed, offset, k, False, b * h * L, n_tokens[m]).float() / (1 - pa)).reshape(b * h, L, n_tokens[m]).cpu()
+                k += 1
+                if pf > 0:
+                    drop[k] = (_mask(hn, pf, seed, offset, k, True, b * L, d).float() / (1 - pf)).reshape(b, L, d).cpu()
+                k += 1
+            if kw.get("self_per_cross_attn", 1) > 0:
+                h = kw["l_heads"]
+                if pa > 0:
+                    drop[k] = (_mask(hn, pa, seed, offset, k, False, b * h * L, L).float() / (1 - pa)).reshape(b * h, L, L).cpu()
+                k += 1
+                if pf > 0:
+                    drop[k] = (_mask(hn, pf, seed, offset, k, True, b * L, d).float() / (1 - pf)).reshape(b, L, d).cpu()
+                k += 1
+    return drop
+
+
+CASES = [
+    # tab (explicit binding, several tokens) + image (rank-D binding), both dropouts
+    dict(kw=dict(n_modalities=2, channel_dims=[40, 3], num_spatial_axes=[1, 2], out_dims=4, depth=2, l_c=16, l_d=32, x_heads=2,
+                 l_heads=2, cross_dim_head=16, latent_dim_head=16, attn_dropout=0.25, ff_dropout=0.1),
+         shapes=[(9, 40), (11, 13, 3)]),
+    # one-token tabular context (the shortcut path must be bypassed when dropping) + attention dropout only, GELU gate
+    dict(kw=dict(n_modalities=2, channel_dims=[50, 3], num_spatial_axes=[1, 2], out_dims=3, depth=1, l_c=8, l_d=16, x_heads=2,
+                 l_heads=2, cross_dim_head=8, latent_dim_head=8, attn_dropout=0.4, ff_dropout=0.0, snn=False),
+         shapes=[(1, 50), (6, 7, 3)]),
+    # feed-forward dropout only, no latent self blocks
+    dict(kw=dict(n_modalities=1, channel_dims=[3], num_spatial_axes=[2], out_dims=2, depth=2, l_c=8, l_d=16, x_heads=2,
+                 l_heads=2, cross_dim_head=8, latent_dim_head=8, attn_dropout=0.0, ff_dropout=0.3, self_per_cross_attn=0),
+         shapes=[(10, 9, 3)]),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_training_forward_and_gradients_under_the_exported_masks(hn, case):
+    kw, shapes = case["kw"], case["shapes"]
+    torch.manual_seed(21)
+    model = hn.HealNet(**kw).train()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    cfg = O.FusionConfig(**{k: v for k, v in kw.items()})
+    gen = torch.Generator().manual_seed(8)
+    b = 3
+    ins = [torch.rand(b, *s, generator=gen) for s in shapes]
+    n_tokens = [int(torch.tensor(s[:-1]).prod()) for s in shapes]
+    target = torch.randn(b, kw["out_dims"], generator=gen)
+    model.to(DEV)
+    y = model([t.to(DEV) for t in ins])
+    seed, offset = model._last_rng
+    loss = ((y - target.to(DEV)) ** 2).sum()
+    loss.backward()
+
+    drop = _oracle_masks(hn, model, kw, b, n_tokens, seed, offset, [True] * kw["n_modalities"])
+    cpu = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    yc = O.fusion_forward(cpu, cfg, ins, drop=drop)
+    assert_close(y.detach().cpu(), yc.detach(), rel=2e-4, what="logits under dropout")
+    ((yc - target) ** 2).sum().backward()
+    named = dict(model.named_parameters())
+    for k, v in cpu.items():
+        if v.grad is None:
+            continue
+        g = named[k].grad
+        assert g is not None, k
+        if float(v.grad.abs().max()) < 1e-12:       # exactly zero in exact arithmetic (queries / keys of a one-token softmax)
+            assert float(g.abs().max()) < 1e-5, k
+            continue
+        assert rel_err(g.cpu(), v.grad) <= 5e-4, (k, rel_err(g.cpu(), v.grad))
+
+    # a second forward draws fresh masks (offset advances); eval mode draws none and equals the dropout-free model
+    y2 = model([t.to(DEV) for t in ins])
+    assert model._last_rng[1] == offset + 1 and not torch.equal(y2, y)
+    model.eval()
+    with torch.no_grad():
+        ye = model([t.to(DEV) for t in ins])
+    assert_close(ye.cpu(), O.fusion_forward(sd, cfg, ins), rel=2e-4, what="eval mode: no dropout")
+
+
+def test_dropout_in_train_mode_applies_under_no_grad_too(hn):
+    kw = CASES[0]["kw"]
+    torch.manual_seed(3)
+    model = hn.HealNet(**kw).train().to(DEV)
+    ins = [torch.rand(2, *s, device=DEV) for s in CASES[0]["shapes"]]
+    with torch.no_grad():
+        a, b_ = model(list(ins)), model(list(ins))
+    assert not torch.equal(a, b_)                     # nn.Dropout is active in training mode whatever the grad mode
+
+
+def test_mask_statistics(hn):
+    p = 0.3
+    m0 = _mask(hn, p, 1234, 1, 5, False, 4096, 1000).float()
+    assert abs(float(m0.mean()) - (1 - p)) < 2e-3
+    # different stream / offset / seed / ff-bit -> different, uncorrelated masks
+    for (seed, off, sid, ff) in [(1234, 1, 6, False), (1234, 2, 5, False), (99, 1, 5, False), (1234, 1, 5, True)]:
+        m1 = _mask(hn, p, seed, off, sid, ff, 4096, 1000).float()
+        agree = float((m0 == m1).float().mean())
+        assert abs(agree - ((1 - p) ** 2 + p ** 2)) < 3e-3, (seed, off, sid, ff, agree)
+    # neighbouring rows / columns are uncorrelated
+    c = float(((m0[:, 1:] - (1 - p)) * (m0[:, :-1] - (1 - p))).mean())
+    r = float(((m0[1:] - (1 - p)) * (m0[:-1] - (1 - p))).mean())
+    assert abs(c) < 2e-3 and abs(r) < 2e-3
+    assert float(_mask(hn, 0.0, 1, 1, 1, False, 8, 8).float().mean()) == 1.0
+
+
+def test_expected_output_matches_the_dropout_free_model(hn):
+    """E[dropout(x)] = x: averaging training-mode outputs of a LINEAR probe of the masks (attention output before the
+    non-linearity is not observable through the ABI, so use a large sample and a loose bound on the logits)."""
+    kw = dict(n_modalities=1, channel_dims=[3], num_spatial_axes=[2], out_dims=4, depth=1, l_c=8, l_d=16, x_heads=2, l_heads=2,
+              cross_dim_head=8, latent_dim_head=8, attn_dropout=0.2, ff_dropout=0.0, self_per_cross_attn=0)
+    torch.manual_seed(5)
+    model = hn.HealNet(**kw).train().to(DEV)
+    img = torch.rand(4, 16, 16, 3, device=DEV)
+    with torch.no_grad():
+        acc = torch.zeros(4, 4, device=DEV)
+        n = 300
+        for _ in range(n):
+            acc += model([img])
+        model.eval()
+        ref = model([img])
+    assert rel_err(acc / n, ref) < 5e-2

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     lib = _capi.lib()                      # raises if the .so is missing: build() must have run
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.hn_abi_version() == _capi.HN_ABI_VERSION == 2
+    assert lib.hn_abi_version() == _capi.HN_ABI_VERSION == 3
     assert lib.hn_context_pitch(13, 64) == 16 and lib.hn_context_pitch(18, 64) == 32
     assert lib.hn_context_pitch(773, 64) == 776 and lib.hn_context_pitch(2005, 64) == 2008
     assert lib.hn_context_pitch(20, 16) == 20          # rank-D path would not pay: dp 32 > dim_head 16
@@ -35,7 +35,7 @@ def test_error_codes_without_gpu():
     need = lib.hn_attn_workspace_bytes(ctypes.byref(p), 1, 16, 32, 128, 50176, 13)
     assert 0 < need < 200 << 20
     f = _capi.FFParams(dim=128, gate=0)
-    assert lib.hn_ff_workspace_bytes(ctypes.byref(f), 4096) == 4096 * 512 * 4
+    assert lib.hn_ff_workspace_bytes(ctypes.byref(f), 4096) == 4096 * 640 * 4      # hidden (rows, 4 dim) + the pre-dropout output (rows, dim)
     # NULL pointers are reported, not dereferenced
     rc = lib.hn_head_fwd(None, 1, 1, 1, None, None, None, None, 1, None, None)
     assert rc == -5
@@ -109,11 +109,13 @@ def test_cpu_tensors_are_rejected_loudly():
 
 
 def test_unsupported_modes_raise():
+    # the stand-alone modules are inference ops: dropout in training mode goes through HealNet's fused training path
+    att = Attention(8, 5, heads=2, dim_head=4, dropout=0.1).train()
+    with pytest.raises(NotImplementedError):
+        att(torch.rand(1, 3, 8), context=torch.rand(1, 4, 5))
     m = HealNet(n_modalities=1, channel_dims=[4], num_spatial_axes=[1], out_dims=2, l_c=4, l_d=8, x_heads=1, l_heads=1,
                 cross_dim_head=4, latent_dim_head=4, attn_dropout=0.1)
-    m.train()
-    with pytest.raises(NotImplementedError):
-        m([torch.rand(2, 3, 4)])
+    assert m.train()._dropout_active() and not m.eval()._dropout_active()
     m2 = HealNet(n_modalities=1, channel_dims=[4], num_spatial_axes=[1], out_dims=2, l_c=4, l_d=8, x_heads=1, l_heads=1,
                  cross_dim_head=4, latent_dim_head=4, self_per_cross_attn=2).eval()
     with pytest.raises(ValueError):
