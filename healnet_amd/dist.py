@@ -73,6 +73,11 @@ def allreduce_mean_(tensors: Iterable[torch.Tensor], bucket_bytes: int = 32 << 2
         nonlocal bucket, size
         if not bucket:
             return
+        if len(bucket) == 1 and bucket[0].is_contiguous():     # already flat (healnet_amd.train.FlatParameters.grads): in place
+            dist.all_reduce(bucket[0], op=dist.ReduceOp.SUM)
+            bucket[0].div_(world)
+            bucket, size = [], 0
+            return
         flat = torch.cat([t.reshape(-1) for t in bucket])
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         flat.div_(world)

@@ -47,6 +47,16 @@ def _worker(rank, world, port, q):
             ref.append(acc / world)
         for a, b in zip(mine_g, ref):
             assert torch.allclose(a, b, atol=1e-6)
+        # 2b. one flat buffer larger than a bucket (healnet_amd.train.FlatParameters.grads): reduced in place, no staging copy
+        torch.manual_seed(200 + rank)
+        flat = torch.randn(5000)
+        ptr = flat.data_ptr()
+        hd.allreduce_mean_([flat], bucket_bytes=4096)
+        acc = torch.zeros(5000)
+        for rr in range(world):
+            torch.manual_seed(200 + rr)
+            acc += torch.randn(5000)
+        assert flat.data_ptr() == ptr and torch.allclose(flat, acc / world, atol=1e-6)
         # 3. timing contract
         assert hd.max_over_ranks(1.0 + rank) == float(world)
         q.put((rank, "ok"))
