@@ -9,6 +9,9 @@
 #include "../../include/healnet_hip.h"
 
 namespace hn {
+// development aid (HN_POISON_LDS=1): after every launch fill the LDS of every CU with NaNs on the same stream, so a kernel
+// that reads LDS it has not written fails deterministically instead of inheriting benign leftovers (misc.hip)
+void debug_after_launch(hipStream_t s);
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -27,6 +30,7 @@ int fail(int code, const char *fmt, ...);
   do {                                                                                           \
     hipError_t _e = hipGetLastError();                                                           \
     if (_e != hipSuccess) return ::hn::fail(HN_E_HIP, "launch of %s failed: %s", name, hipGetErrorString(_e)); \
+    ::hn::debug_after_launch(s);                                                                 \
   } while (0)
 
 #define HN_REQUIRE(cond, code, ...)                                                              \

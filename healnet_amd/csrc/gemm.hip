@@ -173,6 +173,109 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Large kernel: the context-side K/V projection of patch bags (M = b*N = 32 768 rows, N = 2*inner = 1024, K = D = 773
+// at cfg4: 52 GF per block of the model).  Same loader / fragment scheme as gemm_kernel (dword loads with lanes along
+// k: any alignment, affine prologue fused) on a 128 x 128 tile: a wave owns 64 x 64 (2 x 2 MFMA tiles), so every
+// ds_read_b128 feeds 8 MFMAs instead of 4 and the tile's arithmetic intensity against L2 doubles (32 FLOP/B).
+// Work-item order: the 8 column tiles that share one 128-row block of A run back to back on ONE XCD (workgroups are
+// dealt round-robin to the 8 XCDs, each with its own L2), so A (100 MB at cfg4) streams from HBM once.
+// ------------------------------------------------------------------------------------------------
+constexpr int GM = 128, GN = 128;
+
+__global__ __launch_bounds__(256) void gemm_big_kernel(GemmArgs g, int ntm, int ntn) {
+  __shared__ __attribute__((aligned(16))) float As[GM * LDS_PITCH];
+  __shared__ __attribute__((aligned(16))) float Bs[GN * LDS_PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int id = blockIdx.x, xcd = id & 7, seq = id >> 3;
+  const int n_tile = seq % ntn, m_tile = (seq / ntn) * 8 + xcd;
+  if (m_tile >= ntm) return;
+  const int m0 = m_tile * GM, n0 = n_tile * GN;
+  const float *__restrict__ A = g.A;
+  const float *__restrict__ W = g.W;
+  const i32x4 rsA = make_rsrc(A, rsrc_bytes(g.M, g.lda, g.K));
+  const i32x4 rsW = make_rsrc(W, rsrc_bytes(g.N, g.ldw, g.K));
+
+  const int lk = tid & 31, lr = tid >> 5;     // loader: lane runs along k, 8 row groups x 16 rows
+  float ra[16], rb[16];
+  auto load_tile = [&](int k0) {
+    const int k = k0 + lk;
+    const float km = k < g.K ? 1.0f : 0.0f;
+    const int kc = min(k, g.K - 1);
+    float gam = 1.0f, bet = 0.0f;
+    if (g.pro == PRO_AFFINE) { gam = g.gamma[kc]; bet = g.beta[kc]; }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int r = lr + 8 * j;
+      const float a = hn_buffer_load_x1(rsA, ((m0 + r) * (int)g.lda + kc) * 4, 0, 0);
+      ra[j] = (a * gam + bet) * km;
+      rb[j] = hn_buffer_load_x1(rsW, ((n0 + r) * (int)g.ldw + kc) * 4, 0, 0);
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int r = lr + 8 * j;
+      As[r * LDS_PITCH + lk] = ra[j];
+      Bs[r * LDS_PITCH + lk] = rb[j];
+    }
+  };
+
+  const int wm = wave >> 1, wn = wave & 1;
+  const int frow = lane & 31, fhalf = lane >> 5;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+  const int nk = (g.K + BK - 1) / BK;
+  load_tile(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    store_tile();
+    __syncthreads();
+    if (kt + 1 < nk) load_tile((kt + 1) * BK);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float4 a4[2], b4[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a4[i] = *(const float4 *)(As + (wm * 64 + 32 * i + frow) * LDS_PITCH + 16 * fhalf + 4 * q);
+        b4[i] = *(const float4 *)(Bs + (wn * 64 + 32 * i + frow) * LDS_PITCH + 16 * fhalf + 4 * q);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].x, b4[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].y, b4[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].z, b4[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].w, b4[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wn * 64 + 32 * j + frow;
+    if (n >= g.N) continue;
+    const float bv = g.bias ? g.bias[n] : 0.0f;
+    const long ocol = out_col(g, n);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+        if (m < g.M) {
+          float v = epilogue_value<false>(g, acc[i][j][r], 0.0f, bv, 0.0f);
+          if (g.R) v += g.R[(long)m * g.ldr + n];
+          g.C[(long)m * g.ldc + ocol] = v;
+        }
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Aligned kernels (16-byte aligned operands, K % 4 == 0).  32 x 64 output tile -> 256 workgroups even for
 // M = 4096, N = 128; operands move in full 128-byte lines (8 lanes x 16 B per row of a 32-wide k-tile) into an
 // XOR-swizzled LDS image (slot = c ^ (row & 7), pitch 32 floats, no padding): conflict free for the
@@ -539,6 +642,14 @@ int launch_gemm(const GemmArgs &g, hipStream_t s) {
   if (g.M <= 32 && !glu && g.pro != PRO_LAYERNORM && g.K >= 512) {
     hipLaunchKernelGGL(gemm_skinny_kernel, dim3(ceil_div(g.N, 4), 1, g.batch), dim3(256), 0, s, g);
     HN_LAUNCH_CHECK("gemm_skinny");
+    return HN_OK;
+  }
+  if (!glu && g.batch == 1 && g.pro != PRO_LAYERNORM && g.M >= 2048 && g.N >= 256 && g.K >= 256) {
+    const int ntm = ceil_div(g.M, GM), ntn = ceil_div(g.N, GN);
+    const long blocks = (long)ceil_div(ntm, 8) * 8 * ntn;
+    HN_REQUIRE(blocks < (1L << 31), HN_E_UNSUPPORTED, "gemm: grid too large");
+    hipLaunchKernelGGL(gemm_big_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g, ntm, ntn);
+    HN_LAUNCH_CHECK("gemm_big");
     return HN_OK;
   }
   if (aligned_eligible(g) && ceil_div(g.N, TN) <= 65535) {

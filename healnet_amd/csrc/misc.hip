@@ -1,5 +1,6 @@
 // Small support kernels: latent broadcast (healnet.py:225), classifier head (to_logits :181-185).
 #include "common.h"
+#include <stdlib.h>
 
 namespace hn {
 
@@ -170,6 +171,20 @@ int launch_dropout_mask(uint8_t *mask, long rows, int cols, const DropCfg &d, hi
   hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, s, mask, rows, cols, d);
   HN_LAUNCH_CHECK("dropout_mask");
   return HN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lds_poison_kernel(float *sink) {
+  __shared__ float buf[16000];                       // 62.5 KB: two such workgroups per CU touch 125 of the 160 KB
+  for (int i = threadIdx.x; i < 16000; i += 256) buf[i] = __uint_as_float(0x7fc00000u + i);
+  __syncthreads();
+  if (sink && buf[threadIdx.x] == 1.0f) sink[0] = 1.0f;   // keep the stores alive
+}
+
+void debug_after_launch(hipStream_t s) {
+  static int enabled = -1;
+  if (enabled < 0) { const char *e = getenv("HN_POISON_LDS"); enabled = (e && e[0] == '1') ? 1 : 0; }
+  if (enabled) hipLaunchKernelGGL(lds_poison_kernel, dim3(2048), dim3(256), 0, s, (float *)nullptr);
 }
 
 }  // namespace hn

@@ -22,6 +22,7 @@ Deliberate deviations from the reference (documented in DESIGN.md):
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Callable, Dict, List, Optional, Sequence
 
 import torch
@@ -58,6 +59,9 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+_POISON = os.environ.get("HN_POISON_WS", "0") == "1"
+
+
 class _Workspace:
     """One growing scratch allocation per device (the C ABI never allocates)."""
 
@@ -69,6 +73,8 @@ class _Workspace:
         if buf is None or buf.numel() < nbytes:
             buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
             self._buf[device] = buf
+        if _POISON:      # development aid (HN_POISON_WS=1): every call starts from an all-NaN workspace, so a kernel that
+            buf.fill_(0xFF)   # reads scratch it has not written shows up deterministically
         return buf
 
 

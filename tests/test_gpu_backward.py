@@ -18,7 +18,8 @@ def capi():
 
 
 def _ws(nbytes):
-    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=DEV)
+    # all-NaN scratch: a kernel that reads workspace it has not written fails deterministically instead of once in a while
+    return torch.full((max(int(nbytes), 256),), 0xFF, dtype=torch.uint8, device=DEV)
 
 
 def _stream():
@@ -49,7 +50,7 @@ def test_ff_backward(capi, dim, rows, snn, norm, residual):
     lib = capi.lib()
     ws = _ws(lib.hn_ff_bwd_workspace_bytes(C.byref(params), rows))
     xd, dyd = x.detach().to(DEV).contiguous(), dy.to(DEV).contiguous()
-    dx = torch.empty_like(xd)
+    dx = torch.full_like(xd, float("nan"))
     capi.check(lib.hn_ff_bwd(C.byref(params), xd.data_ptr(), dyd.data_ptr(), dx.data_ptr(), int(residual), rows, C.byref(grads),
                              ws.data_ptr(), ws.numel(), _stream()), "hn_ff_bwd")
     assert_close(dx.cpu(), x.grad, rel=2e-4, what="ff.dx")
@@ -72,7 +73,7 @@ def test_head_backward(capi, b, L, d, out):
     dl = torch.randn(b, out, generator=gen)
     (O.layer_norm(x.mean(1), nw, nb) @ w.t() + bias).backward(dl)
     dev = [t.detach().to(DEV).contiguous() for t in (x, nw, nb, w, bias, dl)]
-    dx = torch.empty_like(dev[0])
+    dx = torch.full_like(dev[0], float("nan"))
     g = [torch.zeros_like(t) for t in dev[1:5]]
     lib = capi.lib()
     ws = _ws(lib.hn_head_bwd_workspace_bytes(b, d, out))
@@ -130,17 +131,17 @@ def _attn_case(capi, b, L, N, D, heads, dh, qd, self_attn=False, masked=False, n
     m8 = None if mask is None else mask.to(DEV).to(torch.uint8).contiguous()
     Nn, Dd = (L, qd) if self_attn else (N, D)
     nsaved = lib.hn_attn_saved_floats(C.byref(params), has_ctx, ld, b, L, Nn, Dd, int(masked))
-    saved = torch.empty(nsaved, dtype=torch.float32, device=DEV)
-    stats = torch.empty(b, heads, L, 2, dtype=torch.float32, device=DEV)
+    saved = torch.full((nsaved,), float("nan"), dtype=torch.float32, device=DEV)
+    stats = torch.full((b, heads, L, 2), float("nan"), dtype=torch.float32, device=DEV)
     ws = _ws(max(lib.hn_attn_workspace_bytes(C.byref(params), has_ctx, ld, b, L, Nn, Dd),
                  lib.hn_attn_bwd_workspace_bytes(C.byref(params), has_ctx, ld, b, L, Nn, Dd, int(masked))))
-    xo = torch.empty_like(xd)
+    xo = torch.full_like(xd, float("nan"))
     zp = None if z is None else z.data_ptr()
     mp = None if m8 is None else m8.data_ptr()
     capi.check(lib.hn_attn_fwd_train(C.byref(params), xd.data_ptr(), xo.data_ptr(), int(residual), zp, ld, b, L, Nn, Dd, mp,
                                      stats.data_ptr(), saved.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "fwd_train")
     assert_close(xo.cpu(), y.detach(), rel=2e-4, what="attn.fwd_train")
-    dx = torch.empty_like(xd)
+    dx = torch.full_like(xd, float("nan"))
     capi.check(lib.hn_attn_bwd(C.byref(params), xd.data_ptr(), xo.data_ptr(), int(residual), zp, ld, b, L, Nn, Dd, mp,
                                stats.data_ptr(), saved.data_ptr(), dyd.data_ptr(), dx.data_ptr(), C.byref(grads), ws.data_ptr(),
                                ws.numel(), _stream()), "hn_attn_bwd")
