@@ -151,7 +151,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     # -amdgpu-mfma-vgpr-form: MFMA accumulators live in plain VGPRs (gfx950 has a unified register file), which
     # removes the per-iteration v_accvgpr_read/write shuffles hipcc otherwise emits around the softmax / epilogues.
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm", "-amdgpu-mfma-vgpr-form=1",
-           "-o", LIB_PATH] + srcs
+           "-o", LIB_PATH] + os.environ.get("HN_EXTRA_HIPCC_FLAGS", "").split() + srcs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True, cwd=CSRC)

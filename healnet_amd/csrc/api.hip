@@ -151,8 +151,8 @@ static int attn_prepare(const hn_attn_params *p, const AttnPlan &pl, const float
     const int qpitch = p->heads * pl.dhp, kvpitch = 2 * p->heads * pl.dhp;
     float *kvbuf = kv_tape ? kv_tape : pl.kv;
     if (pl.dhp != pl.dh) {
-      HN_HIP_CHECK(hipMemsetAsync(pl.q, 0, (size_t)rows * qpitch * sizeof(float), s));
-      if (!kv_ready) HN_HIP_CHECK(hipMemsetAsync(kvbuf, 0, (size_t)b * pl.N * kvpitch * sizeof(float), s));
+      { int rc_ = launch_fill(pl.q, 0.0f, (long)((size_t)rows * qpitch), s); if (rc_ != HN_OK) return rc_; }
+      if (!kv_ready) { int rc_ = launch_fill(kvbuf, 0.0f, (long)((size_t)b * pl.N * kvpitch), s); if (rc_ != HN_OK) return rc_; }
     }
     gq.C = pl.q; gq.ldc = qpitch; gq.alpha = pl.cscale;
     gq.col_group = pl.dh; gq.col_group_pitch = pl.dhp;
@@ -205,7 +205,7 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
     gv.W = p->w_kv + (long)pl.inner * pl.D; gv.ldw = pl.D; gv.N = pl.inner;
     gv.C = vbuf; gv.ldc = pl.inner;
     if ((rc = launch_gemm(gv, s)) != HN_OK) return rc;
-    if (o_save) HN_HIP_CHECK(hipMemcpyAsync(o_save, vbuf, (size_t)b * pl.inner * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (o_save) { int rc_ = launch_copy(o_save, vbuf, (long)((size_t)b * pl.inner), s); if (rc_ != HN_OK) return rc_; }
     GemmArgs gy = gemm_defaults();
     gy.A = vbuf; gy.lda = pl.inner; gy.M = b; gy.K = pl.inner;
     gy.W = p->w_out; gy.ldw = pl.inner; gy.N = p->query_dim;
@@ -277,7 +277,7 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
   }
   if (rc != HN_OK) return rc;
   if (o_save && !pl.rank_d)
-    HN_HIP_CHECK(hipMemcpyAsync(o_save, pl.obuf, (size_t)b * L * pl.inner * sizeof(float), hipMemcpyDeviceToDevice, s));
+    { int rc_ = launch_copy(o_save, pl.obuf, (long)((size_t)b * L * pl.inner), s); if (rc_ != HN_OK) return rc_; }
 
   GemmArgs go = gemm_defaults();
   go.A = pl.obuf; go.lda = pl.inner;
@@ -408,7 +408,7 @@ static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float
         return rc;
     }
     if (residual) { if (dx != dy) return launch_add_into(dy, dx, (long)rows * qd, 0, s); return HN_OK; }
-    HN_HIP_CHECK(hipMemsetAsync(dx, 0, (size_t)rows * qd * sizeof(float), s));
+    { int rc_ = launch_fill(dx, 0.0f, (long)((size_t)rows * qd), s); if (rc_ != HN_OK) return rc_; }
     return HN_OK;
   }
 
@@ -464,7 +464,7 @@ static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float
       e.batch = h; e.strideA = dh; e.strideB = pl.dp; e.strideC = (long)dh * pl.D;
       if ((rc = launch_gemm_ex(e, s, bp.red)) != HN_OK) return rc;
     }
-    HN_HIP_CHECK(hipMemsetAsync(bp.dA, 0, (size_t)rows * hp * sizeof(float), s));
+    { int rc_ = launch_fill(bp.dA, 0.0f, (long)((size_t)rows * hp), s); if (rc_ != HN_OK) return rc_; }
     {
       GemmExArgs e = gex(bp.dO, inner, 1, wv, 1, pl.D, bp.dA, hp, rows, pl.D, dh, 0);
       e.batch = h; e.strideA = dh; e.strideB = (long)dh * pl.D; e.strideC = pl.dp;
@@ -491,7 +491,7 @@ static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float
     if ((rc = launch_attn_bwd_dq(ba, s)) != HN_OK) return rc;
     // dQacc (rows, h*dp) = sum over splits; folded-query chain  Qf = c * gamma * T,  T = Q_h W_k,h
     if ((rc = launch_dq_reduce(bp.dQpart, pl.nsplit, b, h, L, pl.Lp, pl.dp, pl.dp, 1.0f, bp.E, hp, pl.dp, s)) != HN_OK) return rc;
-    HN_HIP_CHECK(hipMemsetAsync(bp.T, 0, (size_t)rows * hp * sizeof(float), s));
+    { int rc_ = launch_fill(bp.T, 0.0f, (long)((size_t)rows * hp), s); if (rc_ != HN_OK) return rc_; }
     {   // T = Qraw_h W_k,h   (Qraw = x_hat W_q^T lives in pl.q after attn_prepare)
       GemmExArgs e = gex(pl.q, inner, 1, wk, 1, pl.D, bp.T, hp, rows, pl.D, dh, 0);
       e.batch = h; e.strideA = dh; e.strideB = (long)dh * pl.D; e.strideC = pl.dp;
@@ -1006,7 +1006,7 @@ int hn_ff_fwd(const hn_ff_params *p, const float *x_in, float *x_out, int residu
 int hn_dropout_mask(float p, hn_rng rng, int is_ff, long rows, int cols, uint8_t *mask, void *stream) {
   HN_REQUIRE(mask && rows > 0 && cols > 0 && p >= 0.0f && p < 1.0f, HN_E_SHAPE, "dropout_mask: p=%g rows=%ld cols=%d", (double)p, rows, cols);
   DropCfg d = drop_of(p, rng, is_ff != 0);
-  if (d.thr == 0) { HN_HIP_CHECK(hipMemsetAsync(mask, 1, (size_t)rows * cols, (hipStream_t)stream)); return HN_OK; }
+  if (d.thr == 0) return launch_fill_bytes(mask, 1, rows * (long)cols, (hipStream_t)stream);
   return launch_dropout_mask(mask, rows, cols, d, (hipStream_t)stream);
 }
 
@@ -1101,7 +1101,7 @@ int hn_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, con
       const int slot = layer * (M + 1);
       if (present) {
         const hn_attn_params *ap = &m->cross_attn[layer * M + i];
-        if (x_trace && x_trace[slot + i]) HN_HIP_CHECK(hipMemcpyAsync(x_trace[slot + i], fp.x, xbytes, hipMemcpyDeviceToDevice, s));
+        if (x_trace && x_trace[slot + i]) { int rc_ = launch_copy(x_trace[slot + i], fp.x, (long)((xbytes) / sizeof(float)), s); if (rc_ != HN_OK) return rc_; }
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (prof && i == fp.dominant && prof->n_recorded < prof->n_events) {
           e0 = (hipEvent_t)prof->ev_start[prof->n_recorded];
@@ -1119,7 +1119,7 @@ int hn_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, con
           return rc;
       }
       if (m->self_per_cross_attn > 0) {                                                     // :241-245
-        if (x_trace && x_trace[slot + M]) HN_HIP_CHECK(hipMemcpyAsync(x_trace[slot + M], fp.x, xbytes, hipMemcpyDeviceToDevice, s));
+        if (x_trace && x_trace[slot + M]) { int rc_ = launch_copy(x_trace[slot + M], fp.x, (long)((xbytes) / sizeof(float)), s); if (rc_ != HN_OK) return rc_; }
         if ((rc = attn_fwd_impl(&m->self_attn[layer], fp.x, fp.x, 1, nullptr, 0, b, L, L, d, nullptr,
                                 attn_stats ? attn_stats[slot + M] : nullptr, fp.op_ws, fp.op_ws_bytes, s, nullptr, nullptr)) != HN_OK)
           return rc;
@@ -1128,7 +1128,7 @@ int hn_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, con
     }
   }
   if (head) return launch_head(fp.x, b, L, d, m->head_norm_w, m->head_norm_b, m->head_w, m->head_b, m->out_dims, out, s);
-  HN_HIP_CHECK(hipMemcpyAsync(out, fp.x, xbytes, hipMemcpyDeviceToDevice, s));
+  { int rc_ = launch_copy(out, fp.x, (long)((xbytes) / sizeof(float)), s); if (rc_ != HN_OK) return rc_; }
   return HN_OK;
 }
 
@@ -1196,15 +1196,15 @@ int hn_fusion_forward_train(const hn_model *m, const hn_modality_input *in, int 
       const int slot = st.layer * (M + 1) + (st.kind == STEP_CROSS_ATTN ? st.m : M);
       const int heads = st.kind == STEP_CROSS_ATTN ? m->cross_attn[st.layer * M + st.m].heads : m->self_attn[st.layer].heads;
       if (attn_stats && attn_stats[slot])
-        HN_HIP_CHECK(hipMemcpyAsync(attn_stats[slot], T + tp.stats_off[k], (size_t)b * heads * L * 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
+        { int rc_ = launch_copy(attn_stats[slot], T + tp.stats_off[k], (long)((size_t)b * heads * L * 2), s); if (rc_ != HN_OK) return rc_; }
       if (x_trace && x_trace[slot])
-        HN_HIP_CHECK(hipMemcpyAsync(x_trace[slot], xin, (size_t)b * L * d * sizeof(float), hipMemcpyDeviceToDevice, s));
+        { int rc_ = launch_copy(x_trace[slot], xin, (long)((size_t)b * L * d), s); if (rc_ != HN_OK) return rc_; }
     }
   }
   const float *xf = T + tp.x_off[tp.nsteps];
   if (m->final_classifier_head && !return_embeddings)
     return launch_head(xf, b, L, d, m->head_norm_w, m->head_norm_b, m->head_w, m->head_b, m->out_dims, out, s);
-  HN_HIP_CHECK(hipMemcpyAsync(out, xf, (size_t)b * L * d * sizeof(float), hipMemcpyDeviceToDevice, s));
+  { int rc_ = launch_copy(out, xf, (long)((size_t)b * L * d), s); if (rc_ != HN_OK) return rc_; }
   return HN_OK;
 }
 
@@ -1246,7 +1246,7 @@ int hn_fusion_backward(const hn_model *m, const hn_modality_input *in, int b, co
     if ((rc = launch_head_bwd(xf, b, L, d, m->head_norm_w, m->head_norm_b, m->head_w, m->out_dims, dout, dX, g->head_norm_w,
                               g->head_norm_b, g->head_w, g->head_b, hs, s)) != HN_OK) return rc;
   } else {
-    HN_HIP_CHECK(hipMemcpyAsync(dX, dout, xn * sizeof(float), hipMemcpyDeviceToDevice, s));
+    { int rc_ = launch_copy(dX, dout, (long)(xn), s); if (rc_ != HN_OK) return rc_; }
   }
   static const hn_attn_grads no_attn = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   static const hn_ff_grads no_ff = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};

@@ -8,6 +8,7 @@
 //   ln_bwd_kernel    LayerNorm backward (dx and per-block partials of dgamma / dbeta)
 //   leaky_bwd / glu_bwd / head_bwd   elementwise and head pieces
 #include "common.h"
+#include <stdlib.h>
 
 namespace hn {
 
@@ -274,12 +275,14 @@ static int launch_gemm_nn(const GemmExArgs &g, hipStream_t s, float *scratch) {
 int launch_gemm_ex(const GemmExArgs &g, hipStream_t s, float *scratch) {
   HN_REQUIRE(g.A && g.B && g.C, HN_E_NULL, "gemm_ex: NULL operand");
   HN_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.batch > 0, HN_E_SHAPE, "gemm_ex: M=%d N=%d K=%d", g.M, g.N, g.K);
+  static int no_tn = -1, no_nn = -1;      // development knobs (flakiness bisect)
+  if (no_tn < 0) { const char *e = getenv("HN_NO_TN"); no_tn = (e && e[0] == '1') ? 1 : 0; e = getenv("HN_NO_NN"); no_nn = (e && e[0] == '1') ? 1 : 0; }
   // TN form (both operands contraction-major, unit stride along their own row index): the MFMA-native kernel
-  if (g.batch == 1 && g.a_rs == 1 && g.b_rs == 1 && g.k_total == 0 && (long)g.K * g.a_cs * 4 < (1L << 31) &&
+  if (!no_tn && g.batch == 1 && g.a_rs == 1 && g.b_rs == 1 && g.k_total == 0 && (long)g.K * g.a_cs * 4 < (1L << 31) &&
       (long)g.K * g.b_cs * 4 < (1L << 31))
     return launch_gemm_tn(g.A, g.a_cs, g.B, g.b_cs, g.C, g.ldc, g.M, g.N, g.K, g.alpha, g.accumulate, scratch, s);
   // NN form (A row-major over the contraction, B contraction-major): dX = dY W
-  if (scratch && g.batch == 1 && g.a_cs == 1 && g.b_rs == 1 && g.k_total == 0 && g.M >= 256 && (g.K & 3) == 0 && (g.a_rs & 3) == 0)
+  if (!no_nn && scratch && g.batch == 1 && g.a_cs == 1 && g.b_rs == 1 && g.k_total == 0 && g.M >= 256 && (g.K & 3) == 0 && (g.a_rs & 3) == 0)
     return launch_gemm_nn(g, s, scratch);
   const int tiles = ceil_div(g.M, XM) * ceil_div(g.N, XN) * g.batch;
   if (scratch && g.batch == 1 && g.K >= 2048 && tiles <= 128) {

@@ -46,8 +46,17 @@ int fail(int code, const char *fmt, ...);
 // With a descriptor whose num_records ends at the last valid row, out-of-range rows simply read as 0 in
 // hardware: no predicate, no branch, all loads of a tile in flight together.
 typedef int i32x4 __attribute__((ext_vector_type(4)));
-__device__ f32x4 hn_buffer_load_x4(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
-__device__ float hn_buffer_load_x1(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
+__device__ f32x4 hn_buffer_load_x4_raw(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+__device__ float hn_buffer_load_x1_raw(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
+#ifndef HN_LOAD_AUX
+#define HN_LOAD_AUX 0      // cache-policy bits of every buffer load (development: -DHN_LOAD_AUX=17 = sc0 sc1, system scope)
+#endif
+__device__ __forceinline__ f32x4 hn_buffer_load_x4(i32x4 rsrc, int voffset, int soffset, int) {
+  return hn_buffer_load_x4_raw(rsrc, voffset, soffset, HN_LOAD_AUX);
+}
+__device__ __forceinline__ float hn_buffer_load_x1(i32x4 rsrc, int voffset, int soffset, int) {
+  return hn_buffer_load_x1_raw(rsrc, voffset, soffset, HN_LOAD_AUX);
+}
 __device__ __forceinline__ i32x4 make_rsrc(const void *base, unsigned bytes) {
   const unsigned long long a = (unsigned long long)base;
   i32x4 r;
@@ -236,6 +245,8 @@ int launch_importance(const float *Q, long q_b, long q_h, int ldq, int dp, const
                       const uint8_t *mask, const float *stats, float *I, int b, int h, int L, int N, hipStream_t s);
 
 
+int launch_copy(float *dst, const float *src, long n, hipStream_t s);
+int launch_fill_bytes(uint8_t *dst, uint8_t value, long n, hipStream_t s);
 int launch_dropout_apply(const float *src, const float *add, float *out, long rows, int cols, const DropCfg &d, hipStream_t s);
 int launch_dropout_mask(uint8_t *mask, long rows, int cols, const DropCfg &d, hipStream_t s);
 

@@ -69,6 +69,42 @@ int launch_fill(float *dst, float value, long n, hipStream_t s) {
   return HN_OK;
 }
 
+// Device-to-device copy as an ordinary kernel.  The library never uses hipMemcpyAsync / hipMemsetAsync between its kernels:
+// on this stack (ROCm 7.2, MI355X) results that depended on a D2D hipMemcpyAsync issued between two kernels of the same
+// stream were wrong in a few percent of fresh processes (tools/flake_probe.py); plain kernels are ordered like any other.
+__global__ __launch_bounds__(256) void copy_kernel(const float *__restrict__ src, float *__restrict__ dst, long n) {
+  const long n4 = n >> 2;
+  const bool al = ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0;
+  if (al) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x)
+      ((float4 *)dst)[i] = ((const float4 *)src)[i];
+    for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = src[i];
+  } else {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = src[i];
+  }
+}
+
+int launch_copy(float *dst, const float *src, long n, hipStream_t s) {
+  if (n <= 0 || dst == src) return HN_OK;
+  long blocks = ceil_div_ll((n + 3) / 4, 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(copy_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, n);
+  HN_LAUNCH_CHECK("copy");
+  return HN_OK;
+}
+
+__global__ __launch_bounds__(256) void fill_bytes_kernel(uint8_t *__restrict__ dst, uint8_t value, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = value;
+}
+
+int launch_fill_bytes(uint8_t *dst, uint8_t value, long n, hipStream_t s) {
+  long blocks = ceil_div_ll(n, 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(fill_bytes_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dst, value, n);
+  HN_LAUNCH_CHECK("fill_bytes");
+  return HN_OK;
+}
+
 // One workgroup per sample: column means over the L latent rows -> LayerNorm(d) -> Linear(d, out).
 __global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ x, int L, int d, const float *__restrict__ nw,
                                                    const float *__restrict__ nb, const float *__restrict__ w,

@@ -85,7 +85,7 @@ def test_head_backward(capi, b, L, d, out):
         assert_close(got.cpu(), want.grad, rel=2e-4, what="head." + nm)
 
 
-def _attn_case(capi, b, L, N, D, heads, dh, qd, self_attn=False, masked=False, norm=True, residual=True, seed=0):
+def _attn_case(capi, b, L, N, D, heads, dh, qd, self_attn=False, masked=False, norm=True, residual=True, seed=0, _depth=0):
     import healnet_amd.healnet as H
     gen = torch.Generator().manual_seed(seed)
     inner = heads * dh
@@ -104,7 +104,12 @@ def _attn_case(capi, b, L, N, D, heads, dh, qd, self_attn=False, masked=False, n
     dy = torch.randn(b, L, qd, generator=gen)
     xn = O.layer_norm(x, P["nw"], P["nb"]) if norm else x
     cn = None if self_attn else (O.layer_norm(ctx, P["cg"], P["cb"]) if norm else ctx)
-    y = O.attention(xn, cn, P["wq"], P["wkv"], P["wo"], P["bo"], heads, mask) + (x if residual else 0)
+    act = O.attention(xn, cn, P["wq"], P["wkv"], P["wo"], P["bo"], heads, mask)
+    # |pre| of the LeakyReLU from its output: act = pre (pre > 0) or 0.01 pre (pre < 0)
+    margin = float(torch.where(act > 0, act, act * 100).abs().min())
+    if margin < 1e-5 and _depth < 20:
+        return _attn_case(capi, b, L, N, D, heads, dh, qd, self_attn, masked, norm, residual, seed + 1, _depth + 1)
+    y = act + (x if residual else 0)
     y.backward(dy)
 
     d = {k: v.detach().to(DEV).contiguous() for k, v in P.items()}
@@ -152,7 +157,7 @@ def _attn_case(capi, b, L, N, D, heads, dh, qd, self_attn=False, masked=False, n
         assert_close(gr[k].cpu(), want, rel=5e-4, floor=2e-4, what="attn.d" + k)
 
 
-@pytest.mark.parametrize("kw", [
+ATTN_CASES = [
     dict(b=2, L=128, N=600, D=13, heads=8, dh=64, qd=128),                       # rank-D (image-like), several splits
     dict(b=2, L=25, N=77, D=18, heads=2, dh=63, qd=32),                          # rank-D dp=32, odd sizes
     dict(b=2, L=16, N=300, D=13, heads=2, dh=64, qd=32, masked=True),            # rank-D with a mask
@@ -162,9 +167,18 @@ def _attn_case(capi, b, L, N, D, heads, dh, qd, self_attn=False, masked=False, n
     dict(b=2, L=24, N=0, D=0, heads=2, dh=16, qd=32, self_attn=True, norm=False, residual=False),
     dict(b=4, L=128, N=1, D=2005, heads=8, dh=64, qd=128),                       # one-token (tabular) context
     dict(b=2, L=16, N=50, D=13, heads=2, dh=16, qd=32, norm=False),              # bare Attention, raw 13-wide context
-])
+]
+CASE_INDEX = {id(c): k for k, c in enumerate(ATTN_CASES)}
+
+
+@pytest.mark.parametrize("kw", ATTN_CASES)
 def test_attention_backward(capi, kw):
-    _attn_case(capi, seed=hash(tuple(sorted(kw.items()))) % 1000, **kw)
+    # Fixed seed per case (NOT hash(): str hashes are randomised per process, which made the inputs -- and, at the kink of
+    # LeakyReLU, the outcome -- differ from run to run).  LeakyReLU' jumps from 0.01 to 1 at pre = 0: when some
+    # pre-activation is within rounding distance of 0, two correct fp32 forwards can disagree on its sign and their
+    # gradients then differ by O(1) in that element (1-2 % of random inputs at these sizes have such an element:
+    # tools/seed_scan.py).  _attn_case therefore advances the seed until every |pre| clears 1e-5.
+    _attn_case(capi, seed=1000 + 17 * CASE_INDEX[id(kw)], **kw)
 
 
 # ------------------------------------------------------------------------------------------------
