@@ -2,10 +2,10 @@
 fusion stack, a drop-in for ``healnet.models.HealNet`` / ``healnet.models.Attention`` of
 konst-int-i/healnet.  ``import healnet_amd as healnet`` keeps ``from healnet import HealNet`` style code working.
 """
-from .healnet import Attention, FeedForward, HealNet, PreNorm, fourier_encode_concat
+from .healnet import Attention, FeedForward, HealNet, PreNorm, fourier_encode_concat, temperature_softmax
 from .etl import MMDataset
 from . import ops as _ops  # noqa: F401  (registers torch.ops.healnet_hip.*)
 from . import train  # noqa: F401  (survival loss + fused L1/Adam step, SURVEY.md 8 f1)
 
-__all__ = ["HealNet", "Attention", "PreNorm", "FeedForward", "MMDataset", "fourier_encode_concat"]
+__all__ = ["HealNet", "Attention", "PreNorm", "FeedForward", "MMDataset", "fourier_encode_concat", "temperature_softmax"]
 __version__ = "0.1.0"

@@ -1003,6 +1003,10 @@ int hn_ff_fwd(const hn_ff_params *p, const float *x_in, float *x_out, int residu
   return ff_fwd_impl(p, x_in, x_out, residual, rows, workspace, workspace_bytes, (hipStream_t)stream, true);
 }
 
+int hn_temperature_softmax(const float *logits, float *probs, long rows, int n, float temperature, void *stream) {
+  return launch_temperature_softmax(logits, probs, rows, n, temperature, (hipStream_t)stream);
+}
+
 int hn_dropout_mask(float p, hn_rng rng, int is_ff, long rows, int cols, uint8_t *mask, void *stream) {
   HN_REQUIRE(mask && rows > 0 && cols > 0 && p >= 0.0f && p < 1.0f, HN_E_SHAPE, "dropout_mask: p=%g rows=%ld cols=%d", (double)p, rows, cols);
   DropCfg d = drop_of(p, rng, is_ff != 0);

@@ -246,6 +246,7 @@ int launch_importance(const float *Q, long q_b, long q_h, int ldq, int dp, const
 
 
 int launch_copy(float *dst, const float *src, long n, hipStream_t s);
+int launch_temperature_softmax(const float *x, float *y, long rows, int n, float temperature, hipStream_t s);
 int launch_fill_bytes(uint8_t *dst, uint8_t value, long n, hipStream_t s);
 int launch_dropout_apply(const float *src, const float *add, float *out, long rows, int cols, const DropCfg &d, hipStream_t s);
 int launch_dropout_mask(uint8_t *mask, long rows, int cols, const DropCfg &d, hipStream_t s);

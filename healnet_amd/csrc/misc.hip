@@ -210,6 +210,36 @@ int launch_dropout_mask(uint8_t *mask, long rows, int cols, const DropCfg &d, hi
 }
 
 // ------------------------------------------------------------------------------------------------
+// temperature_softmax(logits, temperature, dim = -1) (healnet/models/healnet.py:354-365): F.softmax(logits / T) over the
+// contiguous last dimension, one wave per row (rows of any length; three passes over the row: max, sum, write).
+// Inside Attention.forward the same function is fused into the split-KV core; this entry point is the stand-alone op.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void temperature_softmax_kernel(const float *__restrict__ x, float *__restrict__ y, long rows,
+                                                                  int n, float inv_t) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float *xr = x + row * n;
+  float *yr = y + row * n;
+  float m = -__builtin_inff();
+  for (int i = lane; i < n; i += 64) m = fmaxf(m, xr[i] * inv_t);
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  float s = 0.0f;
+  for (int i = lane; i < n; i += 64) s += expf(xr[i] * inv_t - m);
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float inv = 1.0f / s;
+  for (int i = lane; i < n; i += 64) yr[i] = expf(xr[i] * inv_t - m) * inv;
+}
+
+int launch_temperature_softmax(const float *x, float *y, long rows, int n, float temperature, hipStream_t s) {
+  HN_REQUIRE(x && y, HN_E_NULL, "temperature_softmax: NULL pointer");
+  HN_REQUIRE(rows > 0 && n > 0 && temperature > 0.0f, HN_E_SHAPE, "temperature_softmax: rows=%ld n=%d T=%g", rows, n, (double)temperature);
+  hipLaunchKernelGGL(temperature_softmax_kernel, dim3((unsigned)ceil_div_ll(rows, 4)), dim3(256), 0, s, x, y, rows, n, 1.0f / temperature);
+  HN_LAUNCH_CHECK("temperature_softmax");
+  return HN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void lds_poison_kernel(float *sink) {
   __shared__ float buf[16000];                       // 62.5 KB: two such workgroups per CU touch 125 of the 160 KB
   for (int i = threadIdx.x; i < 16000; i += 256) buf[i] = __uint_as_float(0x7fc00000u + i);

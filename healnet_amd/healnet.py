@@ -111,6 +111,21 @@ def fourier_encode_concat(data: torch.Tensor, num_freq_bands: int = 2, max_freq:
     return out
 
 
+def temperature_softmax(logits: torch.Tensor, temperature: float = 1.0, dim: int = -1) -> torch.Tensor:
+    """``F.softmax(logits / temperature, dim)`` (healnet/models/healnet.py:354-365) on the GPU; ``Attention.forward`` uses
+    temperature 0.5 (:419), where the same function is fused into the attention core."""
+    _require_gpu(logits, "logits")
+    x = _f32c(logits)
+    moved = dim not in (-1, x.dim() - 1)
+    if moved:
+        x = x.movedim(dim, -1).contiguous()
+    y = torch.empty_like(x)
+    n = x.shape[-1]
+    _capi.check(_capi.lib().hn_temperature_softmax(x.data_ptr(), y.data_ptr(), x.numel() // n, n, float(temperature),
+                                                   _stream_ptr(x.device)), "hn_temperature_softmax")
+    return y.movedim(-1, dim) if moved else y
+
+
 def _normalise_context(ctx: torch.Tensor, pitch: int) -> torch.Tensor:
     """Affine-free LayerNorm over the last dim of an already encoded (b, N, D) context -> (b, N, pitch)."""
     b, n, d = ctx.shape

@@ -7,6 +7,7 @@ only: there is no CPU kernel, calling them with CPU tensors raises NotImplemente
                                     heads, residual) -> (b, L, query_dim)
     torch.ops.healnet_hip.feed_forward(x, norm_w?, norm_b?, w1, b1, w2, b2, gelu, residual) -> like x
     torch.ops.healnet_hip.head(x, norm_w, norm_b, w, bias) -> (b, out_dims)
+    torch.ops.healnet_hip.temperature_softmax(logits, temperature) -> like logits (softmax over the last dim)
 """
 from __future__ import annotations
 
@@ -16,7 +17,7 @@ from typing import Optional
 import torch
 
 from . import _capi
-from .healnet import _WS, _f32c, _ptr, _stream_ptr, fourier_encode_concat as _encode
+from .healnet import _WS, _f32c, _ptr, _stream_ptr, fourier_encode_concat as _encode, temperature_softmax as _tsoftmax
 
 _lib = torch.library.Library("healnet_hip", "DEF")
 _lib.define("fourier_encode_concat(Tensor data, int num_freq_bands, float max_freq, bool fourier_encode_data) -> Tensor")
@@ -26,6 +27,7 @@ _lib.define("attention(Tensor x, Tensor? context, Tensor? mask, Tensor? norm_w, 
 _lib.define("feed_forward(Tensor x, Tensor? norm_w, Tensor? norm_b, Tensor w1, Tensor b1, Tensor w2, Tensor b2, bool gelu, "
             "bool residual) -> Tensor")
 _lib.define("head(Tensor x, Tensor norm_w, Tensor norm_b, Tensor w, Tensor bias) -> Tensor")
+_lib.define("temperature_softmax(Tensor logits, float temperature) -> Tensor")
 
 
 def _fourier_encode_concat(data, num_freq_bands, max_freq, fourier_encode_data):
@@ -91,5 +93,6 @@ def _head(x, norm_w, norm_b, w, bias):
 
 
 for _name, _fn in (("fourier_encode_concat", _fourier_encode_concat), ("encode_norm", _encode_norm), ("attention", _attention),
-                   ("feed_forward", _feed_forward), ("head", _head)):
+                   ("feed_forward", _feed_forward), ("head", _head),
+                   ("temperature_softmax", lambda logits, temperature: _tsoftmax(logits, temperature, -1))):
     _lib.impl(_name, _fn, "CUDA")

@@ -126,6 +126,11 @@ int hn_attn_fwd(const hn_attn_params *p, const float *x_in, float *x_out, int re
                 float *stats, void *workspace, size_t workspace_bytes, void *stream);
 size_t hn_attn_workspace_bytes(const hn_attn_params *p, int has_ctx, int ld_ctx, int b, int L, int N, int D);
 
+/* temperature_softmax(logits, temperature, dim=-1) (healnet/models/healnet.py:354-365) as a stand-alone op: softmax of
+ * logits / temperature over the contiguous last dimension of a (rows, n) array.  Attention.forward calls it with
+ * temperature = 0.5 (:419); inside hn_attn_fwd it is fused into the attention core. */
+int hn_temperature_softmax(const float *logits, float *probs, long rows, int n, float temperature, void *stream);
+
 /* Attention.attn_weights (:420), shape (b*heads, L, N), recomputed from x_in (the block INPUT) and stats. */
 int hn_attn_probs(const hn_attn_params *p, const float *x_in, const float *ctx, int ld_ctx, int b, int L,
                   int N, int D, const uint8_t *mask, const float *stats, float *probs, void *workspace,

@@ -202,3 +202,16 @@ def test_one_token_context_paths_agree(hn):
     p_general = blk.fn.attn_weights
     assert_close(fast.cpu(), general.cpu(), rel=1e-5, what="one-token fast vs general")
     assert torch.equal(p_fast, torch.ones_like(p_fast)) and torch.allclose(p_general, p_fast, atol=1e-6)
+
+
+def test_temperature_softmax_matches_reference_function(hn):
+    """temperature_softmax(logits, temperature, dim) as a stand-alone op, against outputs of the reference's
+    own function (tests/golden/g8_temperature_softmax.npz)."""
+    g = load_golden("g8_temperature_softmax")
+    for i in range(4):
+        x, want, t = g[f"x{i}"].to(DEV), g[f"y{i}"], float(g[f"t{i}"])
+        got = hn.temperature_softmax(x, temperature=t)
+        assert_close(got.cpu(), want, rel=2e-6, floor=1e-7, what=f"temperature_softmax[{i}]")
+        assert_close(torch.ops.healnet_hip.temperature_softmax(x, t).cpu(), want, rel=2e-6, floor=1e-7, what="torch.ops")
+    got = hn.temperature_softmax(g["xd"].to(DEV), temperature=0.5, dim=1)
+    assert_close(got.cpu(), g["yd"], rel=2e-6, floor=1e-7, what="temperature_softmax dim=1")

@@ -154,3 +154,12 @@ def test_train_oracle_l1_adam_matches_reference(manifest):
         assert abs(reg - float(g["reg_losses"][t])) <= 1e-5 * float(g["reg_losses"][t])
         for i, p in enumerate(ps):
             assert_close(p, g[f"p{i}_step{t}"], rel=2e-6, floor=1e-7, what=f"adam p{i} step{t}")
+
+
+def test_temperature_softmax_restatement_matches_reference():
+    """a7: the oracle's attention() restates temperature_softmax as softmax(sim / temperature) (oracle/healnet_cpu.py);
+    pinned here against outputs of the reference's own function."""
+    g = load_golden("g8_temperature_softmax")
+    for i in range(4):
+        assert torch.equal(torch.softmax(g[f"x{i}"] / float(g[f"t{i}"]), dim=-1), g[f"y{i}"])
+    assert torch.equal(torch.softmax(g["xd"] / 0.5, dim=1), g["yd"])

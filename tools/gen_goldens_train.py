@@ -4,6 +4,7 @@
   g7_surv_nll   healnet/models/survival_loss.py::nll_loss exactly as healnet/main.py:441-447 calls it
                 (hazards = sigmoid(logits), S = cumprod(1 - hazards), optional class weights), with the gradient
                 d loss / d logits through the reference's own autograd graph
+  g8_temperature_softmax   healnet/models/healnet.py::temperature_softmax (:354-365)
   g7_l1_adam    healnet/utils/train_utils.py::calc_reg_loss (L1 over all parameters) added to a data loss, then
                 torch.optim.Adam + OneCycleLR exactly as healnet/main.py:390-394,464-467 drives them, 4 steps
 
@@ -112,5 +113,19 @@ def main():
     print("wrote g7_surv_nll, g7_l1_adam")
 
 
+def g8_temperature_softmax():
+    """tests/golden/g8_temperature_softmax.npz: the reference's temperature_softmax (healnet/models/healnet.py:354-365)."""
+    ref = load("/root/reference/healnet/models/healnet.py", "ref_healnet")
+    gen = torch.Generator().manual_seed(31)
+    arr = {}
+    for i, (shape, T) in enumerate([((16, 128, 77), 0.5), ((3, 5, 1), 0.5), ((7, 1000), 2.0), ((4, 6, 130), 1.0)]):
+        x = torch.randn(*shape, generator=gen) * 4
+        arr[f"x{i}"] = x.numpy(); arr[f"y{i}"] = ref.temperature_softmax(x, temperature=T).numpy(); arr[f"t{i}"] = np.float32(T)
+    x = torch.randn(5, 9, 11, generator=gen)
+    arr["xd"] = x.numpy(); arr["yd"] = ref.temperature_softmax(x, temperature=0.5, dim=1).numpy()
+    np.savez_compressed(os.path.join(GOLD, "g8_temperature_softmax.npz"), **arr)
+
+
 if __name__ == "__main__":
     main()
+    g8_temperature_softmax()
