@@ -102,6 +102,8 @@ SIGNATURES = {
                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "hn_attn_importance": (C.c_int, [C.POINTER(AttnParams), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "hn_fourier_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_float, C.c_void_p]),
+    "hn_glu_gate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p]),
     "hn_temperature_softmax": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_float, C.c_void_p]),
     "hn_dropout_mask": (C.c_int, [C.c_float, Rng, C.c_int, C.c_long, C.c_int, C.c_void_p, C.c_void_p]),
     "hn_surv_nll": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,

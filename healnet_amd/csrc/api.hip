@@ -1003,6 +1003,15 @@ int hn_ff_fwd(const hn_ff_params *p, const float *x_in, float *x_out, int residu
   return ff_fwd_impl(p, x_in, x_out, residual, rows, workspace, workspace_bytes, (hipStream_t)stream, true);
 }
 
+int hn_fourier_encode(const float *x, float *out, long n, int num_bands, float max_freq, void *stream) {
+  return launch_fourier_encode(x, out, n, num_bands, max_freq, (hipStream_t)stream);
+}
+
+int hn_glu_gate(const float *x, float *out, long rows, int hidden, int gate, void *stream) {
+  HN_REQUIRE(gate == HN_GATE_SELU || gate == HN_GATE_GELU, HN_E_UNSUPPORTED, "glu_gate: gate=%d", gate);
+  return launch_glu_gate(x, out, rows, hidden, gate == HN_GATE_GELU, (hipStream_t)stream);
+}
+
 int hn_temperature_softmax(const float *logits, float *probs, long rows, int n, float temperature, void *stream) {
   return launch_temperature_softmax(logits, probs, rows, n, temperature, (hipStream_t)stream);
 }

@@ -246,6 +246,8 @@ int launch_importance(const float *Q, long q_b, long q_h, int ldq, int dp, const
 
 
 int launch_copy(float *dst, const float *src, long n, hipStream_t s);
+int launch_fourier_encode(const float *x, float *out, long n, int F, float max_freq, hipStream_t s);
+int launch_glu_gate(const float *x, float *out, long rows, int hid, int gelu, hipStream_t s);
 int launch_temperature_softmax(const float *x, float *y, long rows, int n, float temperature, hipStream_t s);
 int launch_fill_bytes(uint8_t *dst, uint8_t value, long n, hipStream_t s);
 int launch_dropout_apply(const float *src, const float *add, float *out, long rows, int cols, const DropCfg &d, hipStream_t s);

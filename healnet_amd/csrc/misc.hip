@@ -210,6 +210,64 @@ int launch_dropout_mask(uint8_t *mask, long rows, int cols, const DropCfg &d, hi
 }
 
 // ------------------------------------------------------------------------------------------------
+// Stand-alone pieces of the reference's module surface (inside the fused path they live in K1 / the GEMM epilogues):
+//   fourier_encode(x, max_freq, num_bands)  healnet.py:292-302   out[i, :] = [sin(x s_f pi).., cos(x s_f pi).., x]
+//   GELU / SELU gate modules                healnet.py:323-331   out = a * act(g), (a | g) = chunk(x, 2, dim=-1)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fourier_encode_kernel(const float *__restrict__ x, float *__restrict__ out, long n, int F,
+                                                             float max_freq) {
+  const int per = 2 * F + 1;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n * per; i += (long)gridDim.x * blockDim.x) {
+    const long e = i / per;
+    const int w = (int)(i - e * per);
+    const float p = x[e];
+    float v = p;
+    if (w < 2 * F) {
+      const int f = w < F ? w : w - F;
+      const float end = max_freq * 0.5f;                   // torch.linspace(1, max_freq / 2, F)[f], ATen's symmetric form
+      float sc = 1.0f;
+      if (F > 1) {
+        const float step = __fdiv_rn(end - 1.0f, (float)(F - 1));
+        sc = f < F / 2 ? __fadd_rn(1.0f, __fmul_rn(step, (float)f)) : __fsub_rn(end, __fmul_rn(step, (float)(F - 1 - f)));
+      }
+      const float arg = __fmul_rn(__fmul_rn(p, sc), 3.14159265358979323846f);
+      v = w < F ? sinf(arg) : cosf(arg);
+    }
+    out[i] = v;
+  }
+}
+
+int launch_fourier_encode(const float *x, float *out, long n, int F, float max_freq, hipStream_t s) {
+  HN_REQUIRE(x && out && n > 0 && F >= 1, HN_E_SHAPE, "fourier_encode: n=%ld num_bands=%d", n, F);
+  long blocks = ceil_div_ll(n * (2 * F + 1), 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(fourier_encode_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, out, n, F, max_freq);
+  HN_LAUNCH_CHECK("fourier_encode");
+  return HN_OK;
+}
+
+__global__ __launch_bounds__(256) void glu_gate_kernel(const float *__restrict__ x, float *__restrict__ out, long rows, int hid, int gelu) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < rows * hid; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / hid;
+    const int c = (int)(i - r * hid);
+    const float a = x[r * 2 * hid + c], g = x[r * 2 * hid + hid + c];
+    float act;
+    if (gelu) act = 0.5f * g * (1.0f + erff(g * 0.70710678118654752440f));
+    else act = 1.0507009873554804934193349852946f * (g > 0.0f ? g : 1.6732632423543772848170429916717f * expm1f(g));
+    out[i] = a * act;
+  }
+}
+
+int launch_glu_gate(const float *x, float *out, long rows, int hid, int gelu, hipStream_t s) {
+  HN_REQUIRE(x && out && rows > 0 && hid > 0, HN_E_SHAPE, "glu_gate: rows=%ld hid=%d", rows, hid);
+  long blocks = ceil_div_ll(rows * hid, 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(glu_gate_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, out, rows, hid, gelu);
+  HN_LAUNCH_CHECK("glu_gate");
+  return HN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // temperature_softmax(logits, temperature, dim = -1) (healnet/models/healnet.py:354-365): F.softmax(logits / T) over the
 // contiguous last dimension, one wave per row (rows of any length; three passes over the row: max, sum, write).
 // Inside Attention.forward the same function is fused into the split-KV core; this entry point is the stand-alone op.

@@ -111,6 +111,64 @@ def fourier_encode_concat(data: torch.Tensor, num_freq_bands: int = 2, max_freq:
     return out
 
 
+def exists(val) -> bool:                     # healnet.py:270-271
+    return val is not None
+
+
+def default(val, d):                         # healnet.py:273-274
+    return val if exists(val) else d
+
+
+def cache_fn(f):
+    """healnet.py:276-290: memoise a factory by ``key`` while ``_cache`` is true -- how weight tying is implemented."""
+    import functools
+    cache: dict = {}
+
+    @functools.wraps(f)
+    def cached_fn(*args, _cache=True, key=None, **kwargs):
+        if not _cache:
+            return f(*args, **kwargs)
+        if key in cache:
+            return cache[key]
+        result = f(*args, **kwargs)
+        cache[key] = result
+        return result
+    return cached_fn
+
+
+def fourier_encode(x: torch.Tensor, max_freq: float, num_bands: int = 4) -> torch.Tensor:
+    """healnet.py:292-302: ``(*S) -> (*S, 2*num_bands+1)`` = [sin(x s pi), cos(x s pi), x], s = linspace(1, max_freq/2, num_bands)."""
+    _require_gpu(x, "x")
+    xf = _f32c(x)
+    out = torch.empty(*xf.shape, 2 * num_bands + 1, dtype=torch.float32, device=xf.device)
+    _capi.check(_capi.lib().hn_fourier_encode(xf.data_ptr(), out.data_ptr(), xf.numel(), int(num_bands), float(max_freq),
+                                              _stream_ptr(xf.device)), "hn_fourier_encode")
+    return out
+
+
+class _Gate(nn.Module):
+    _gate = 0
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        _require_gpu(x, "x")
+        xf = _f32c(x)
+        hid = xf.shape[-1] // 2
+        out = torch.empty(*xf.shape[:-1], hid, dtype=torch.float32, device=xf.device)
+        _capi.check(_capi.lib().hn_glu_gate(xf.data_ptr(), out.data_ptr(), xf.numel() // (2 * hid), hid, self._gate,
+                                            _stream_ptr(xf.device)), "hn_glu_gate")
+        return out
+
+
+class SELU(_Gate):
+    """``x, gates = x.chunk(2, -1); x * F.selu(gates)`` (healnet.py:328-331)."""
+    _gate = 0
+
+
+class GELU(_Gate):
+    """``x, gates = x.chunk(2, -1); x * F.gelu(gates)`` (healnet.py:323-326)."""
+    _gate = 1
+
+
 def temperature_softmax(logits: torch.Tensor, temperature: float = 1.0, dim: int = -1) -> torch.Tensor:
     """``F.softmax(logits / temperature, dim)`` (healnet/models/healnet.py:354-365) on the GPU; ``Attention.forward`` uses
     temperature 0.5 (:419), where the same function is fused into the attention core."""

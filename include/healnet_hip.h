@@ -126,6 +126,15 @@ int hn_attn_fwd(const hn_attn_params *p, const float *x_in, float *x_out, int re
                 float *stats, void *workspace, size_t workspace_bytes, void *stream);
 size_t hn_attn_workspace_bytes(const hn_attn_params *p, int has_ctx, int ld_ctx, int b, int L, int N, int D);
 
+/* fourier_encode(x, max_freq, num_bands) (healnet/models/healnet.py:292-302) on a flat array of n positions:
+ * out (n, 2*num_bands+1) = [sin(x s_f pi) .., cos(x s_f pi) .., x], s = linspace(1, max_freq/2, num_bands).
+ * (hn_fourier_encode_concat is the fused form the model uses: positions are generated from the token index.) */
+int hn_fourier_encode(const float *x, float *out, long n, int num_bands, float max_freq, void *stream);
+
+/* The GELU / SELU gate modules (:323-331): out (rows, hidden) = a * act(g) with x (rows, 2*hidden) = [a | g].
+ * Inside hn_ff_fwd the gate is the epilogue of the first GEMM. */
+int hn_glu_gate(const float *x, float *out, long rows, int hidden, int gate, void *stream);
+
 /* temperature_softmax(logits, temperature, dim=-1) (healnet/models/healnet.py:354-365) as a stand-alone op: softmax of
  * logits / temperature over the contiguous last dimension of a (rows, n) array.  Attention.forward calls it with
  * temperature = 0.5 (:419); inside hn_attn_fwd it is fused into the attention core. */

@@ -215,3 +215,23 @@ def test_temperature_softmax_matches_reference_function(hn):
         assert_close(torch.ops.healnet_hip.temperature_softmax(x, t).cpu(), want, rel=2e-6, floor=1e-7, what="torch.ops")
     got = hn.temperature_softmax(g["xd"].to(DEV), temperature=0.5, dim=1)
     assert_close(got.cpu(), g["yd"], rel=2e-6, floor=1e-7, what="temperature_softmax dim=1")
+
+
+def test_fourier_encode_function_matches_reference_fixtures(hn):
+    """a3 as a stand-alone function: every (S, max_freq, bands) fixture of tests/golden/g1_fourier.npz, bit for bit except
+    sin/cos at huge arguments (device sinf/cosf vs ATen: <= 2 ulp)."""
+    g = load_golden("g1_fourier")
+    for key, want in g.items():
+        S, mf, nb = key.split("_")
+        S, mf, nb = int(S[1:]), float(mf[2:]), int(nb[2:])
+        pos = torch.linspace(-1.0, 1.0, S)[:, None].to(DEV)
+        got = hn.fourier_encode(pos, mf, nb)
+        assert got.shape == want.shape
+        assert_close(got.cpu(), want, rel=2e-6, floor=2e-7, what="fourier_encode " + key)
+
+
+def test_gate_modules_match_torch(hn):
+    x = torch.randn(5, 7, 64, device=DEV) * 2
+    a, g_ = x.chunk(2, dim=-1)
+    assert_close(hn.SELU()(x).cpu(), (a * F.selu(g_)).cpu(), rel=2e-6, floor=1e-7, what="SELU gate")
+    assert_close(hn.GELU()(x).cpu(), (a * F.gelu(g_)).cpu(), rel=2e-6, floor=1e-7, what="GELU gate")

@@ -129,3 +129,15 @@ def test_mmdataset_semantics():
     ds2 = MMDataset([a, b_], target=torch.tensor([7, 8, 9]))
     sample, y = ds2[2]
     assert int(y) == 9 and torch.equal(sample[1], b_[2])
+
+
+def test_module_level_names_of_the_reference_exist():
+    """from healnet.models.healnet import ... keeps working after the import swap (healnet.py module surface)."""
+    import healnet_amd as h
+    for name in ["HealNet", "Attention", "PreNorm", "FeedForward", "GELU", "SELU", "fourier_encode", "temperature_softmax", "cache_fn",
+                 "exists", "default"]:
+        assert hasattr(h, name), name
+    assert h.exists(0) and not h.exists(None) and h.default(None, 3) == 3 and h.default(2, 3) == 2
+    calls = []
+    f = h.cache_fn(lambda: calls.append(1) or len(calls))
+    assert f(key="a") == 1 and f(key="a") == 1 and f(key="b") == 2 and f(_cache=False) == 3 and f(key="a") == 1
