@@ -45,7 +45,7 @@ struct AttnPlan {
   int nsplit, chunk;
   float cscale;
   // workspace carve
-  float *obuf, *q, *qf, *kv, *opart, *mpart, *lpart;
+  float *obuf, *q, *qf, *kv, *opart, *mpart, *lpart, *bound;
   size_t bytes;
 };
 
@@ -83,7 +83,9 @@ static int plan_attn(const hn_attn_params *p, bool has_ctx, int ld_ctx, int b, i
     pl->q = ar.take<float>(rows * pl->inner);
     pl->qf = ar.take<float>((size_t)b * p->heads * pl->Lp * (pl->bf16core ? 48 : pl->dp));   // bf16 core: up to 96 bf16 slots per row
     pl->kv = nullptr;
+    pl->bound = ar.take<float>((size_t)b * p->heads * pl->Lp + 64);      // per-row score bounds + the fallback flag
   } else {
+    pl->bound = nullptr;
     pl->q = ar.take<float>(rows * p->heads * pl->dhp);
     pl->qf = nullptr;
     pl->kv = ar.take<float>((size_t)b * pl->N * 2 * p->heads * pl->dhp);
@@ -125,7 +127,7 @@ static float *saved_kv(const AttnPlan &pl, bool has_ctx, bool masked, int b, int
 // writes them there, the backward (kv_ready) reads them back instead of re-running the K/V projection GEMM.
 static int attn_prepare(const hn_attn_params *p, const AttnPlan &pl, const float *x_in, const float *ctx, int ld_ctx,
                         int b, int L, hipStream_t s, AttnCoreArgs *core, int pack_ks = 0, float *kv_tape = nullptr,
-                        bool kv_ready = false) {
+                        bool kv_ready = false, bool use_bound = false) {
   const int rows = b * L;
   GemmArgs gq = gemm_defaults();
   gq.A = x_in; gq.lda = p->query_dim;
@@ -140,8 +142,13 @@ static int attn_prepare(const hn_attn_params *p, const AttnPlan &pl, const float
   if (pl.rank_d) {
     gq.C = pl.q; gq.ldc = pl.inner;
     if ((rc = launch_gemm(gq, s)) != HN_OK) return rc;
+    // score bounds need |z|^2 <= D, i.e. a context that went through the LayerNorm of PreNorm.norm_context (ctx_gamma set)
+    float *bound = (pl.ones && p->ctx_gamma && use_bound) ? pl.bound : nullptr;
+    int *bflag = bound ? (int *)(pl.bound + (size_t)b * p->heads * pl.Lp) : nullptr;
+    if (bound && (rc = launch_fill((float *)bflag, 0.0f, 1, s)) != HN_OK) return rc;
     if ((rc = launch_qfold(pl.q, pl.inner, p->w_kv, pl.D, p->ctx_gamma, pl.cscale, pl.qf, b, p->heads, L, pl.Lp, pl.dh,
-                           pl.dp, s, pack_ks)) != HN_OK) return rc;
+                           pl.dp, s, pack_ks, bound, bflag)) != HN_OK) return rc;
+    core->bound = bound; core->bound_flag = bflag;
     core->qk_steps = pack_ks;
     core->Q = pl.qf; core->q_b = (long)p->heads * pl.Lp * pl.dp; core->q_h = (long)pl.Lp * pl.dp; core->ldq = pl.dp;
     core->Kp = ctx; core->k_b = (long)pl.N * ld_ctx; core->k_h = 0; core->ldk = ld_ctx;
@@ -256,13 +263,13 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
   AttnCoreArgs core;
   const int pack_ks = (pl.rank_d && pl.ones && ctx_has_ones && p->ctx_gamma) ? ctx_pack_ks : 0;
   if ((rc = attn_prepare(p, pl, x_in, ctx, ld_ctx, b, L, s, &core, pack_ks,
-                         saved_kv(pl, ctx != nullptr, mask != nullptr || dropping, b, L, o_save))) != HN_OK) return rc;
+                         saved_kv(pl, ctx != nullptr, mask != nullptr || dropping, b, L, o_save), false, !dropping)) != HN_OK) return rc;
   core.mask = mask;
   core.ones_in_mem = (ctx_has_ones && pl.ones) ? 1 : 0;
   core.drop = drop_off();
   const int srow = (dropping && pl.rank_d) ? 1 : 0;       // the thinned probabilities' row sum rides in column dp-1
   HN_REQUIRE(!srow || pl.ones, HN_E_UNSUPPORTED, "attn: dropout on the shared-context binding needs a free column (D <= dp - 1)");
-  if (dropping) { core.ones_col = 0; core.ones_in_mem = 0; core.drop = drop_of(p->dropout, p->rng, false); core.drop_rowsum = srow; }
+  if (dropping) { core.ones_col = 0; core.ones_in_mem = 0; core.drop = drop_of(p->dropout, p->rng, false); core.drop_rowsum = srow; core.bound = nullptr; core.bound_flag = nullptr; }
   const bool direct = !pl.rank_d && pl.nsplit == 1;
   if (direct) { core.Ofinal = pl.obuf; core.ldo = pl.inner; core.dh = pl.dh; core.stats = stats; }
   if (ev0) HN_HIP_CHECK(hipEventRecord(ev0, s));

@@ -210,6 +210,8 @@ struct AttnCoreArgs {
   int ones_col;                                 // rank-D binding with D <= dp-1: synthetic ones column dp-1 (see attention.hip)
   int ones_in_mem;                              // ... and the context rows already carry 1.0 there (written by K1)
   int qk_steps;                                 // packed context layout: QK^T k-steps to run (0 = all dp/4)
+  const float *bound; const int *bound_flag;    // ONES + LayerNorm-ed context: per-row score bounds (b, h, Lp) and the
+                                                // device flag that disables them (see qfold_kernel); NULL = running max
   float *Ofinal; int ldo, dh; float *stats;     // nsplit == 1 only: write the normalised O (b*Lq, ldo) + stats directly (no merge kernel)
   DropCfg drop;                                 // training: dropout on the probabilities (thr == 0: off; needs ones_col == 0)
   int drop_rowsum;                              // ... shared-context binding: also accumulate sum_t p'_t in column dp-1
@@ -233,7 +235,8 @@ int launch_qfold_bf16(const float *Q, int ldq_row, const float *w_k, int D, cons
 void attn_core_geometry(int b, int h, int Lp, int N, int dp, int *nsplit, int *chunk);
 
 int launch_qfold(const float *Q, int ldq_row, const float *w_k, int D, const float *gamma, float cscale,
-                 float *Qf, int b, int h, int L, int Lp, int dh, int dp, hipStream_t s, int pack_ks = 0);
+                 float *Qf, int b, int h, int L, int Lp, int dh, int dp, hipStream_t s, int pack_ks = 0, float *bound = nullptr,
+                 int *bound_flag = nullptr);
 int launch_merge_vproj(const float *Opart, const float *Mpart, const float *Lpart, int nsplit, int b, int h,
                        int L, int Lp, int dp, int D, const float *gamma, const float *beta, const float *w_v,
                        int dh, float *O, int ldo, float *stats, float *oprime_save, hipStream_t s, int pack_ks = 0, int srow = 0);

@@ -235,3 +235,31 @@ def test_gate_modules_match_torch(hn):
     a, g_ = x.chunk(2, dim=-1)
     assert_close(hn.SELU()(x).cpu(), (a * F.selu(g_)).cpu(), rel=2e-6, floor=1e-7, what="SELU gate")
     assert_close(hn.GELU()(x).cpu(), (a * F.gelu(g_)).cpu(), rel=2e-6, floor=1e-7, what="GELU gate")
+
+
+@pytest.mark.parametrize("qscale", [1.0, 6.0, 60.0])
+def test_bounded_softmax_reference_and_its_fallback(hn, qscale):
+    """Shared-context binding with a LayerNorm-ed context: the core takes the Cauchy-Schwarz score bound |q| sqrt(D) of each
+    row as its softmax reference (no running max, no overflow guard).  qscale = 1 / 6 stays inside the usable range (bounds
+    of a few / a few dozen log2 units: probabilities as small as 2^-100 against the reference), qscale = 60 pushes rows
+    past the limit, which must flip the launch back to the running reference -- all against the oracle."""
+    gen = torch.Generator().manual_seed(17)
+    b, L, N, D, heads, dh, qd = 2, 48, 1500, 13, 4, 64, 64
+    blk = hn.PreNorm(qd, hn.Attention(qd, D, heads=heads, dim_head=dh), context_dim=D).eval().to(DEV)
+    with torch.no_grad():
+        blk.fn.to_q.weight.mul_(qscale)
+        blk.norm_context.weight.copy_(1 + 0.3 * torch.randn(D, generator=gen))
+        blk.norm_context.bias.copy_(0.2 * torch.randn(D, generator=gen))
+    x = torch.randn(b, L, qd, generator=gen)
+    ctx = torch.rand(b, N, D, generator=gen)
+    sd = {k: v.detach().cpu() for k, v in blk.state_dict().items()}
+    xn = O.layer_norm(x, sd["norm.weight"], sd["norm.bias"])
+    cn = O.layer_norm(ctx, sd["norm_context.weight"], sd["norm_context.bias"])
+    want, pw = O.attention(xn, cn, sd["fn.to_q.weight"], sd["fn.to_kv.weight"], sd["fn.to_out.0.weight"], sd["fn.to_out.0.bias"],
+                           heads, return_weights=True)
+    with torch.no_grad():
+        got = blk(x.to(DEV), context=ctx.to(DEV))
+    assert_close(got.cpu(), want, rel=3e-4, what=f"bounded softmax qscale={qscale}")
+    assert_close(blk.fn.attn_weights.cpu(), pw, rel=1e-3, floor=1e-5, what="attn_weights from the bound-referenced statistics")
+    if qscale >= 60:
+        assert pw.max() > 0.9          # genuinely saturated rows
