@@ -236,7 +236,11 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
     gq.C = pl.q; gq.ldc = pl.inner;
     if ((rc = launch_gemm(gq, s)) != HN_OK) return rc;
     uint16_t *qfb = (uint16_t *)pl.qf;
-    if ((rc = launch_qfold_bf16(pl.q, pl.inner, p->w_kv, pl.D, p->ctx_gamma, pl.cscale, qfb, b, p->heads, L, pl.Lp, pl.dh, bc->DV, bc->ns, s)) != HN_OK)
+    float *bound = p->ctx_gamma ? pl.bound : nullptr;
+    int *bflag = bound ? (int *)(pl.bound + (size_t)b * p->heads * pl.Lp) : nullptr;
+    if (bound && (rc = launch_fill((float *)bflag, 0.0f, 1, s)) != HN_OK) return rc;
+    if ((rc = launch_qfold_bf16(pl.q, pl.inner, p->w_kv, pl.D, p->ctx_gamma, pl.cscale, qfb, b, p->heads, L, pl.Lp, pl.dh, bc->DV, bc->ns, s,
+                                bound, bflag)) != HN_OK)
       return rc;
     AttnCoreBf16Args ca;
     memset(&ca, 0, sizeof(ca));
@@ -244,6 +248,7 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
     ca.Opart = pl.opart; ca.Mpart = pl.mpart; ca.Lpart = pl.lpart;
     ca.b = b; ca.h = p->heads; ca.Lq = L; ca.Lp = pl.Lp; ca.N = pl.N; ca.Np = bc->Np; ca.DV = bc->DV;
     ca.nsplit = pl.nsplit; ca.chunk = pl.chunk; ca.ns = bc->ns;
+    ca.bound = bound; ca.bound_flag = bflag;
     if (ev0) HN_HIP_CHECK(hipEventRecord(ev0, s));
     if ((rc = launch_attn_core_bf16(ca, s)) != HN_OK) return rc;
     if (ev1) HN_HIP_CHECK(hipEventRecord(ev1, s));

@@ -88,6 +88,16 @@ __global__ __launch_bounds__(256) void attn_core_bf16_kernel(AttnCoreBf16Args a,
     for (int d = 0; d < DTV; ++d) O[i][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
   bool unset = true;
+  const bool bounded = a.bound != nullptr && *a.bound_flag == 0;      // fixed Cauchy-Schwarz reference (see attention.hip)
+  if (bounded) {
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int row = min((qg * NQ + i) * 16 + j, a.Lp - 1);
+      m[i] = a.bound[(long)bh * a.Lp + row];
+      negm[i] = (f32x4){-m[i], -m[i], -m[i], -m[i]};
+    }
+    unset = false;
+  }
 
   const int t_begin = split * a.chunk;
   const int t_end = min(a.N, t_begin + a.chunk);
@@ -154,10 +164,12 @@ __global__ __launch_bounds__(256) void attn_core_bf16_kernel(AttnCoreBf16Args a,
       for (int x = 0; x < 2; ++x) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) P[i][x][r] = fast_exp2_b(S[i][x][r]);
-        ps0 += P[i][x][0] + P[i][x][2];
-        ps1 += P[i][x][1] + P[i][x][3];
+        if (!bounded) {
+          ps0 += P[i][x][0] + P[i][x][2];
+          ps1 += P[i][x][1] + P[i][x][3];
+        }
       }
-    const bool need = !(ps0 + ps1 <= 512.0f) || unset;
+    const bool need = !bounded && (!(ps0 + ps1 <= 512.0f) || unset);
     if (__any(need) && any_live) {
 #pragma unroll
       for (int i = 0; i < NQ; ++i) {
@@ -284,8 +296,9 @@ __device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float((unsi
 // ns == 2, DV == 32: [qh(32)] [qh(32)] [ql(32)]
 __global__ __launch_bounds__(256) void qfold_bf16_kernel(const float *__restrict__ Q, int ldq_row, const float *__restrict__ w_k,
                                                          int D, const float *__restrict__ gamma, float cscale,
-                                                         uint16_t *__restrict__ Qf, int h, int L, int Lp, int dh, int DV, int ns) {
-  extern __shared__ float wk[];  // [dh][32]
+                                                         uint16_t *__restrict__ Qf, int h, int L, int Lp, int dh, int DV, int ns,
+                                                         float *__restrict__ bound, int *__restrict__ bound_flag) {
+  extern __shared__ float wk[];  // [dh][32] + [Lp] row sums of squares
   const int bh = blockIdx.x, bi = bh / h, hi = bh % h;
   for (int idx = threadIdx.x; idx < dh * 32; idx += blockDim.x) {
     const int e = idx >> 5, d = idx & 31;
@@ -294,12 +307,21 @@ __global__ __launch_bounds__(256) void qfold_bf16_kernel(const float *__restrict
   __syncthreads();
   const int zp = bf16_row_slots(DV, ns);
   uint16_t *dst = Qf + (long)bh * Lp * zp;
+  float *ssq = wk + dh * 32;
+  for (int q = threadIdx.x; q < Lp; q += blockDim.x) ssq[q] = 0.0f;
+  __syncthreads();
   for (int idx = threadIdx.x; idx < Lp * 32; idx += blockDim.x) {
     const int q = idx >> 5, d = idx & 31;
     float acc = 0.0f;
     if (q < L && d < D) {
       const float *qr = Q + ((long)bi * L + q) * ldq_row + hi * dh;
       for (int e = 0; e < dh; ++e) acc = fmaf(qr[e], wk[e * 32 + d], acc);
+    }
+    if (bound != nullptr) {      // row sum of squares: the 32 lanes of a row are one half-wave
+      float sq = acc * acc;
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+      if (d == 0) ssq[q] = sq;
     }
     const uint16_t hi16 = f2bf(acc);
     uint16_t *row = dst + (long)q * zp;
@@ -314,13 +336,21 @@ __global__ __launch_bounds__(256) void qfold_bf16_kernel(const float *__restrict
       }
     }
   }
+  if (bound != nullptr) {        // Cauchy-Schwarz score bound (see qfold_kernel); 1 % slack covers the bf16 rounding of q and z
+    __syncthreads();
+    for (int q = threadIdx.x; q < Lp; q += blockDim.x) {
+      const float bq = sqrtf(ssq[q] * (float)D) * 1.01f + 1e-6f;
+      bound[(long)bh * Lp + q] = bq;
+      if (bq > 60.0f) atomicOr(bound_flag, 1);
+    }
+  }
 }
 
 int launch_qfold_bf16(const float *Q, int ldq_row, const float *w_k, int D, const float *gamma, float cscale, uint16_t *Qf,
-                      int b, int h, int L, int Lp, int dh, int DV, int ns, hipStream_t s) {
+                      int b, int h, int L, int Lp, int dh, int DV, int ns, hipStream_t s, float *bound, int *bound_flag) {
   HN_REQUIRE(D <= DV - 1 && (ns == 1 || ns == 2), HN_E_SHAPE, "qfold_bf16: D=%d DV=%d ns=%d", D, DV, ns);
-  hipLaunchKernelGGL(qfold_bf16_kernel, dim3(b * h), dim3(256), (size_t)dh * 32 * sizeof(float), s, Q, ldq_row, w_k, D, gamma,
-                     cscale, Qf, h, L, Lp, dh, DV, ns);
+  hipLaunchKernelGGL(qfold_bf16_kernel, dim3(b * h), dim3(256), ((size_t)dh * 32 + Lp) * sizeof(float), s, Q, ldq_row, w_k, D, gamma,
+                     cscale, Qf, h, L, Lp, dh, DV, ns, bound, bound_flag);
   HN_LAUNCH_CHECK("qfold_bf16");
   return HN_OK;
 }

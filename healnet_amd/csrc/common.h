@@ -226,12 +226,13 @@ struct AttnCoreBf16Args {                        // bf16-MFMA core of the shared
   int b, h, Lq, Lp, N, Np, DV;
   int nsplit, chunk;                             // tokens per split (multiple of 32)
   int ns;                                        // operand planes: 1 = plain bf16, 2 = hi + lo pairs ("bf16x3")
+  const float *bound; const int *bound_flag;     // per-row score bounds + fallback flag (qfold_bf16_kernel), or NULL
 };
 // bf16 slots per context / query row of the QK^T contraction (see attention_bf16.hip)
 __host__ __device__ constexpr int bf16_row_slots(int DV, int ns) { return ns == 1 ? 32 : (DV == 16 ? 64 : 96); }
 int launch_attn_core_bf16(const AttnCoreBf16Args &a, hipStream_t s);
 int launch_qfold_bf16(const float *Q, int ldq_row, const float *w_k, int D, const float *gamma, float cscale, uint16_t *Qf,
-                      int b, int h, int L, int Lp, int dh, int DV, int ns, hipStream_t s);
+                      int b, int h, int L, int Lp, int dh, int DV, int ns, hipStream_t s, float *bound = nullptr, int *bound_flag = nullptr);
 void attn_core_geometry(int b, int h, int Lp, int N, int dp, int *nsplit, int *chunk);
 
 int launch_qfold(const float *Q, int ldq_row, const float *w_k, int D, const float *gamma, float cscale,
