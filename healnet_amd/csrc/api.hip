@@ -43,6 +43,7 @@ struct AttnPlan {
   int heads, dh, inner, dhp, Lp, N, D, dp;
   bool rank_d, self_attn, ones, bf16core;
   int nsplit, chunk;
+  int nsplit_bwd, chunk_bwd;      // token split of attn_bwd_dq_kernel (≈150 VGPRs: 3 waves per SIMD)
   float cscale;
   // workspace carve
   float *obuf, *q, *qf, *kv, *opart, *mpart, *lpart, *bound;
@@ -50,7 +51,7 @@ struct AttnPlan {
 };
 
 static int plan_attn(const hn_attn_params *p, bool has_ctx, int ld_ctx, int b, int L, int N, int D, void *ws,
-                     size_t ws_bytes, AttnPlan *pl, bool bf16core = false) {
+                     size_t ws_bytes, AttnPlan *pl, int bf16core = 0 /* 0: fp32 core, else the number of bf16 operand planes */) {
   HN_REQUIRE(p, HN_E_NULL, "attn: params NULL");
   HN_REQUIRE(p->heads > 0 && p->dim_head > 0 && p->query_dim > 0 && b > 0 && L > 0, HN_E_SHAPE,
              "attn: heads=%d dim_head=%d query_dim=%d b=%d L=%d", p->heads, p->dim_head, p->query_dim, b, L);
@@ -70,8 +71,12 @@ static int plan_attn(const hn_attn_params *p, bool has_ctx, int ld_ctx, int b, i
   pl->dp = pl->rank_d ? ld_ctx : pl->dhp;
   pl->cscale = 2.0f * (1.0f / sqrtf((float)p->dim_head)) * 1.44269504088896340736f;  // (1/0.5) * dh^-1/2 * log2(e)
   attn_core_geometry(b, p->heads, pl->Lp, pl->N, pl->dp, &pl->nsplit, &pl->chunk);
-  pl->bf16core = bf16core && pl->ones && pl->N > 1;
-  if (pl->bf16core) {                     // the bf16 core walks 32-token steps
+  attn_core_geometry(b, p->heads, pl->Lp, pl->N, pl->dp, &pl->nsplit_bwd, &pl->chunk_bwd, 3);
+  pl->bf16core = bf16core != 0 && pl->ones && pl->N > 1;
+  if (pl->bf16core) {
+    // the plain dp = 16 bf16 core holds 161 VGPRs = 3 resident waves per SIMD: size the split for 3 (a split sized for 4 runs
+    // a second, mostly idle round).  The larger variants measured faster with the default split (cfg3: 7.6 vs 11.2 ms).
+    if (pl->dp == 16 && bf16core == 1) attn_core_geometry(b, p->heads, pl->Lp, pl->N, pl->dp, &pl->nsplit, &pl->chunk, 3);
     pl->chunk = (pl->chunk + 31) / 32 * 32;
     pl->nsplit = (pl->N + pl->chunk - 1) / pl->chunk;
   }
@@ -192,10 +197,10 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
   HN_REQUIRE(x_in && x_out, HN_E_NULL, "attn: x is NULL");
   HN_REQUIRE(p && p->w_q && p->w_kv && p->w_out, HN_E_NULL, "attn: weight pointer is NULL");
   AttnPlan pl;
-  int rc = plan_attn(p, ctx != nullptr, ld_ctx, b, L, N, D, nullptr, 0, &pl, bc != nullptr);
+  int rc = plan_attn(p, ctx != nullptr, ld_ctx, b, L, N, D, nullptr, 0, &pl, bc ? bc->ns : 0);
   if (rc != HN_OK) return rc;
   if ((rc = check_ws(ws, ws_bytes, pl.bytes, "attn")) != HN_OK) return rc;
-  if ((rc = plan_attn(p, ctx != nullptr, ld_ctx, b, L, N, D, ws, ws_bytes, &pl, bc != nullptr)) != HN_OK) return rc;
+  if ((rc = plan_attn(p, ctx != nullptr, ld_ctx, b, L, N, D, ws, ws_bytes, &pl, bc ? bc->ns : 0)) != HN_OK) return rc;
 
   // ---- one-token context without a mask (tabular / omic modality): softmax over a single key is exactly 1, so the
   // block reduces to y = LeakyReLU(W_out (W_v c) + b_out) broadcast over the latent rows; Q and K are dead
@@ -345,7 +350,7 @@ static int plan_attn_bwd(const hn_attn_params *p, const AttnPlan &pl, bool has_c
     bp->dxhat = ar.take<float>(rows * qd);
     bp->lns = ar.take<float>(ln_bwd_scratch_floats(rows, (int)qd));
     bp->delta = ar.take<float>((size_t)b * h * L);
-    bp->dQpart = ar.take<float>((size_t)b * h * pl.nsplit * pl.Lp * pl.dp);
+    bp->dQpart = ar.take<float>((size_t)b * h * pl.nsplit_bwd * pl.Lp * pl.dp);
     bp->dQ = ar.take<float>(rows * inner);
     if (pl.rank_d) {
       const size_t hp = rows * h * pl.dp;
@@ -461,7 +466,7 @@ static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float
   ba.Kp = core.Kp; ba.k_b = core.k_b; ba.k_h = core.k_h; ba.ldk = core.ldk;
   ba.Vp = core.Vp; ba.v_b = core.v_b; ba.v_h = core.v_h; ba.ldv = core.ldv;
   ba.mask = mask; ba.stats = stats; ba.delta = bp.delta; ba.dQpart = bp.dQpart;
-  ba.b = b; ba.h = h; ba.Lq = L; ba.Lp = pl.Lp; ba.N = pl.N; ba.dp = pl.dp; ba.nsplit = pl.nsplit; ba.chunk = pl.chunk;
+  ba.b = b; ba.h = h; ba.Lq = L; ba.Lp = pl.Lp; ba.N = pl.N; ba.dp = pl.dp; ba.nsplit = pl.nsplit_bwd; ba.chunk = pl.chunk_bwd;
   ba.drop = dropping ? drop_of(p->dropout, p->rng, false) : drop_off();
   const bool srow = dropping && pl.rank_d;
   ba.drop_rowsum = srow ? 1 : 0;
@@ -502,7 +507,7 @@ static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float
     ba.dO = bp.dOp; ba.do_b = (long)L * hp; ba.do_h = pl.dp; ba.lddo = hp;
     if ((rc = launch_attn_bwd_dq(ba, s)) != HN_OK) return rc;
     // dQacc (rows, h*dp) = sum over splits; folded-query chain  Qf = c * gamma * T,  T = Q_h W_k,h
-    if ((rc = launch_dq_reduce(bp.dQpart, pl.nsplit, b, h, L, pl.Lp, pl.dp, pl.dp, 1.0f, bp.E, hp, pl.dp, s)) != HN_OK) return rc;
+    if ((rc = launch_dq_reduce(bp.dQpart, pl.nsplit_bwd, b, h, L, pl.Lp, pl.dp, pl.dp, 1.0f, bp.E, hp, pl.dp, s)) != HN_OK) return rc;
     { int rc_ = launch_fill(bp.T, 0.0f, (long)((size_t)rows * hp), s); if (rc_ != HN_OK) return rc_; }
     {   // T = Qraw_h W_k,h   (Qraw = x_hat W_q^T lives in pl.q after attn_prepare)
       GemmExArgs e = gex(pl.q, inner, 1, wk, 1, pl.D, bp.T, hp, rows, pl.D, dh, 0);
@@ -531,7 +536,7 @@ static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float
     if ((rc = launch_head_affine(bp.dO, inner, dh, nullptr, 0, 0, nullptr, nullptr, 1.0f, h, dh, pl.dhp, qp, rows, bp.dOp, s)) != HN_OK) return rc;
     ba.dO = bp.dOp; ba.do_b = (long)L * qp; ba.do_h = pl.dhp; ba.lddo = qp;
     if ((rc = launch_attn_bwd_dq(ba, s)) != HN_OK) return rc;
-    if ((rc = launch_dq_reduce(bp.dQpart, pl.nsplit, b, h, L, pl.Lp, pl.dp, dh, two_scale, bp.dQ, inner, dh, s)) != HN_OK) return rc;
+    if ((rc = launch_dq_reduce(bp.dQpart, pl.nsplit_bwd, b, h, L, pl.Lp, pl.dp, dh, two_scale, bp.dQ, inner, dh, s)) != HN_OK) return rc;
     ba.dKV = bp.dKV; ba.dk_scale = 0.69314718055994530942f;
     if ((rc = launch_attn_bwd_dkv(ba, dh, inner, s)) != HN_OK) return rc;
     const long krows = (long)b * pl.N;
@@ -772,12 +777,12 @@ static int plan_fusion(const hn_model *m, const hn_modality_input *in, int b, vo
     for (int layer = 0; layer < m->depth; ++layer) {
       AttnPlan pl;
       int rc = plan_attn(&m->cross_attn[layer * m->n_modalities + i], true, fp->ldz[i], b, m->l_c, (int)n, fp->D[i], nullptr,
-                         0, &pl, false);
+                         0, &pl, 0);
       if (rc != HN_OK) return rc;
       if (pl.bytes > op_max) op_max = pl.bytes;
       if (want_bf16) {
         if ((rc = plan_attn(&m->cross_attn[layer * m->n_modalities + i], true, fp->ldz[i], b, m->l_c, (int)n, fp->D[i], nullptr,
-                            0, &pl, true)) != HN_OK) return rc;
+                            0, &pl, ns)) != HN_OK) return rc;
         if (pl.bytes > op_max) op_max = pl.bytes;
       }
     }

@@ -365,12 +365,13 @@ static int nq_dt1() {
 }
 static int nq_for(int dt) { return dt == 1 ? nq_dt1() : (dt == 2 ? 2 : (dt == 4 ? 2 : 1)); }
 
-void attn_core_geometry(int b, int h, int Lp, int N, int dp, int *nsplit, int *chunk) {
+void attn_core_geometry(int b, int h, int Lp, int N, int dp, int *nsplit, int *chunk, int waves_per_simd) {
   const int dt = dp / 16;
   const int ngroups = ceil_div(Lp / 16, nq_for(dt));
   static long target_waves = 0;   // development knob HN_CORE_WAVES: resident waves the token split aims for
   if (target_waves == 0) { const char *e = getenv("HN_CORE_WAVES"); target_waves = e ? atol(e) : 256L * 4 * 4; if (target_waves < 64) target_waves = 4096; }
-  long want = ceil_div_ll(target_waves, (long)b * h * ngroups);
+  const long tw = waves_per_simd > 0 ? 256L * 4 * waves_per_simd : target_waves;
+  long want = ceil_div_ll(tw, (long)b * h * ngroups);
   long max_splits = N / 128;
   if (max_splits < 1) max_splits = 1;
   if (want > max_splits) want = max_splits;

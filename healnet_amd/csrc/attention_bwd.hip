@@ -57,11 +57,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a, int ngr
     drow[i] = a.delta[(long)bh * L + rc];
   }
 
-  f32x4 dQ[NQ][DT];
+  f32x4 dQ[NQ][DT], negm[NQ], negd[NQ];
 #pragma unroll
-  for (int i = 0; i < NQ; ++i)
+  for (int i = 0; i < NQ; ++i) {
+    negm[i] = (f32x4){-mrow[i], -mrow[i], -mrow[i], -mrow[i]};
+    negd[i] = (f32x4){-drow[i], -drow[i], -drow[i], -drow[i]};
 #pragma unroll
     for (int d = 0; d < DT; ++d) dQ[i][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
 
   const int t_begin = split * a.chunk;
   const int t_end = min(a.N, t_begin + a.chunk);
@@ -88,9 +91,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a, int ngr
 #pragma unroll
       for (int d = 0; d < DT; ++d) kr[d][r] = hn_buffer_load_x1(krs, kroff[r] + 64 * d, ks, 0);
 
+    // S and dP start from -m and -D (persistent register quads) as the C operands of their MFMA chains, so the chains deliver
+    // s - m and dP - D directly; 1/l is applied once to the finished dQ rows.  (With dropout dP must be thinned BEFORE D is
+    // subtracted, so that variant starts dP from 0.)
     f32x4 S[NQ], dP[NQ];
 #pragma unroll
-    for (int i = 0; i < NQ; ++i) { S[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dP[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    for (int i = 0; i < NQ; ++i) { S[i] = negm[i]; dP[i] = DROP ? (f32x4){0.f, 0.f, 0.f, 0.f} : negd[i]; }
 #pragma unroll
     for (int s = 0; s < DT; ++s) {
       float4 vv = SHARED_KV ? kf[s] : vf[s];
@@ -116,31 +122,32 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a, int ngr
         dP[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.w, gf[i][s].w, dP[i], 0, 0, 0);
       }
     }
-    // token validity of lane (g, j): tokens t0 + 4 g + r
-    float live[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int tok = t0 + 4 * g + r;
-      float ok = tok < t_end ? 1.0f : 0.0f;
-      if (mask) ok *= mask[min(tok, a.N - 1)] ? 1.0f : 0.0f;
-      live[r] = ok;
-    }
-    if (DROP) {   // O = (P * d) V with the forward's keep/scale factors d:  dP <- d * (dO V^T)
+    if (DROP) {   // O = (P * d) V with the forward's keep/scale factors d:  dP <- d * (dO V^T) - D
 #pragma unroll
       for (int i = 0; i < NQ; ++i) {
         float dm[4];
         drop_quad(a.drop, (uint32_t)(t0 + 4 * g) >> 2, (uint32_t)(bh * L + (qg * NQ + i) * 16 + j), dm);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dP[i][r] *= dm[r];
+        for (int r = 0; r < 4; ++r) dP[i][r] = dP[i][r] * dm[r] - drow[i];
+      }
+    }
+    // token validity of lane (g, j): tokens t0 + 4 g + r -- only the ragged tail / masked launches pay for it
+    if (mask != nullptr || t0 + 16 > t_end) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int tok = t0 + 4 * g + r;
+        bool ok = tok < t_end;
+        if (ok && mask) ok = mask[tok] != 0;
+        if (!ok) {
+#pragma unroll
+          for (int i = 0; i < NQ; ++i) S[i][r] = -__builtin_inff();
+        }
       }
     }
 #pragma unroll
     for (int i = 0; i < NQ; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float p = fexp2(S[i][r] - mrow[i]) * invl[i] * live[r];
-        S[i][r] = p * (dP[i][r] - drow[i]);                  // dS
-      }
+      for (int r = 0; r < 4; ++r) S[i][r] = fexp2(S[i][r]) * dP[i][r];       // l * dS  (2^-inf = 0 kills invalid tokens)
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -158,7 +165,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a, int ngr
 #pragma unroll
       for (int d = 0; d < DT; ++d)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) a.dQpart[(prow + tile * 16 + 4 * g + r) * DP + 16 * d + j] = dQ[i][d][r];
+        for (int r = 0; r < 4; ++r)     // accumulator reg r of lane (g, d) belongs to query row 4 g + r, whose 1/l lives in lane 4 g + r
+          a.dQpart[(prow + tile * 16 + 4 * g + r) * DP + 16 * d + j] = dQ[i][d][r] * __shfl(invl[i], 4 * g + r);
     }
   }
 }

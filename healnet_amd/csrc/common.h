@@ -233,7 +233,9 @@ __host__ __device__ constexpr int bf16_row_slots(int DV, int ns) { return ns == 
 int launch_attn_core_bf16(const AttnCoreBf16Args &a, hipStream_t s);
 int launch_qfold_bf16(const float *Q, int ldq_row, const float *w_k, int D, const float *gamma, float cscale, uint16_t *Qf,
                       int b, int h, int L, int Lp, int dh, int DV, int ns, hipStream_t s, float *bound = nullptr, int *bound_flag = nullptr);
-void attn_core_geometry(int b, int h, int Lp, int N, int dp, int *nsplit, int *chunk);
+// waves_per_simd > 0: size the token split for that many resident waves per SIMD (kernels with more than 128 VGPRs hold 3:
+// a split sized for 4 would run a second, mostly idle round)
+void attn_core_geometry(int b, int h, int Lp, int N, int dp, int *nsplit, int *chunk, int waves_per_simd = 0);
 
 int launch_qfold(const float *Q, int ldq_row, const float *w_k, int D, const float *gamma, float cscale,
                  float *Qf, int b, int h, int L, int Lp, int dh, int dp, hipStream_t s, int pack_ks = 0, float *bound = nullptr,
