@@ -441,11 +441,11 @@ static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float
     if ((rc = launch_gemm_ex(e, s, bp.red)) != HN_OK) return rc;
     O = pl.obuf;
   }
-  if (g->w_out) {
+  if (g->w_out) {      // dWo += dpre^T O, and db_out += colsum(dpre) from the same pass over dpre
     GemmExArgs e = gex(bp.dpre, 1, qd, O, 1, inner, g->w_out, inner, qd, inner, rows, 1);
+    e.colsum = g->b_out; e.colsum_accumulate = 1;
     if ((rc = launch_gemm_ex(e, s, bp.red)) != HN_OK) return rc;
-  }
-  if (g->b_out && (rc = launch_colsum(bp.dpre, qd, rows, qd, 1.0f, g->b_out, 1, s, bp.red)) != HN_OK) return rc;
+  } else if (g->b_out && (rc = launch_colsum(bp.dpre, qd, rows, qd, 1.0f, g->b_out, 1, s, bp.red)) != HN_OK) return rc;
   {
     GemmExArgs e = gex(bp.dpre, qd, 1, p->w_out, 1, inner, bp.dO, inner, rows, inner, qd, 0);
     if ((rc = launch_gemm_ex(e, s, bp.red)) != HN_OK) return rc;
@@ -542,8 +542,8 @@ static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float
     const long krows = (long)b * pl.N;
     if (has_ctx) {   // gradients of to_kv and of the context LayerNorm affine from G = dKV^T z and colsum(dKV)
       GemmExArgs e = gex(bp.dKV, 1, 2 * inner, ctx, 1, ld_ctx, bp.G, pl.D, 2 * inner, pl.D, (int)krows, 0);
+      e.colsum = bp.cs; e.colsum_accumulate = 0;          // colsum(dKV) rides on the same pass
       if ((rc = launch_gemm_ex(e, s, bp.red)) != HN_OK) return rc;
-      if ((rc = launch_colsum(bp.dKV, 2 * inner, krows, 2 * inner, 1.0f, bp.cs, 0, s, bp.red)) != HN_OK) return rc;
       if ((rc = launch_kv_weight_grads(bp.G, bp.cs, p->w_kv, p->ctx_gamma, p->ctx_beta, 2 * inner, pl.D, g->w_kv, g->ctx_gamma,
                                        g->ctx_beta, s)) != HN_OK) return rc;
     } else if (g->w_kv) {   // self-attention: K, V come from x_hat
@@ -678,16 +678,16 @@ static int ff_bwd_impl(const hn_ff_params *p, const float *x_in, const float *dy
     GemmExArgs w = {};
     w.batch = 1; w.alpha = 1.0f; w.accumulate = 1;
     w.A = dyf; w.a_rs = 1; w.a_cs = d; w.B = pl.h; w.b_rs = 1; w.b_cs = hid; w.C = g->w2; w.ldc = hid; w.M = d; w.N = hid; w.K = rows;
+    w.colsum = g->b2; w.colsum_accumulate = 1;          // db2 += colsum(dy) from the same pass
     if ((rc = launch_gemm_ex(w, s, pl.red)) != HN_OK) return rc;
-  }
-  if (g->b2 && (rc = launch_colsum(dyf, d, rows, d, 1.0f, g->b2, 1, s, pl.red)) != HN_OK) return rc;
+  } else if (g->b2 && (rc = launch_colsum(dyf, d, rows, d, 1.0f, g->b2, 1, s, pl.red)) != HN_OK) return rc;
   if (g->w1) {   // dW1 += du^T x_hat
     GemmExArgs w = {};
     w.batch = 1; w.alpha = 1.0f; w.accumulate = 1;
     w.A = pl.u; w.a_rs = 1; w.a_cs = 2 * hid; w.B = xhat; w.b_rs = 1; w.b_cs = d; w.C = g->w1; w.ldc = d; w.M = 2 * hid; w.N = d; w.K = rows;
+    w.colsum = g->b1; w.colsum_accumulate = 1;          // db1 += colsum(du) from the same pass
     if ((rc = launch_gemm_ex(w, s, pl.red)) != HN_OK) return rc;
-  }
-  if (g->b1 && (rc = launch_colsum(pl.u, 2 * hid, rows, 2 * hid, 1.0f, g->b1, 1, s, pl.red)) != HN_OK) return rc;
+  } else if (g->b1 && (rc = launch_colsum(pl.u, 2 * hid, rows, 2 * hid, 1.0f, g->b1, 1, s, pl.red)) != HN_OK) return rc;
   // dx_hat = du W1      (W1 is (2 hid, d): B(j = k, c = n) = W1[n, k])
   GemmExArgs x = {};
   x.batch = 1; x.alpha = 1.0f;

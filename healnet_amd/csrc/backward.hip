@@ -119,6 +119,7 @@ struct GemmTnArgs {
   float *C; long ldc;          // nsplit == 1: the destination; else scratch (nsplit, M, N)
   int M, N, K, kslice, nsplit;
   float alpha; int accumulate;
+  float *colsum; int colsum_accumulate;      // optional: sum_k A[k, m] (bias gradient); nsplit > 1: partials (nsplit, M) in scratch
 };
 
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs g) {
@@ -142,6 +143,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs g) {
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // bias gradient for free: the waves of the first column tile also contract A with a vector of ones (every column of that
+  // accumulator is sum_k A[k, m]); +2 MFMAs per k-pair for 1 wave in 2 * ntn, no extra memory traffic, no colsum launch
+  const bool do_colsum = g.colsum != nullptr && n0 == 0;
+  f32x16 accs[2];
+  accs[0] = accs[1] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
   constexpr int UN = 4;                      // k-pairs in flight
   const int npairs = (rows + 1) / 2;
@@ -171,7 +177,24 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs g) {
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[i], cb[j], acc[i][j], 0, 0, 0);
+      if (do_colsum) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) accs[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[i], 1.0f, accs[i], 0, 0, 0);
+      }
     }
+  }
+  if (do_colsum && col == 0) {               // column 0 of the ones-accumulator: lanes 0 and 32 hold its 32 rows
+    float *cs = g.colsum + (g.nsplit > 1 ? (long)z * g.M : 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (m < g.M) {
+          if (g.nsplit > 1) cs[m] = accs[i][r];
+          else cs[m] = g.colsum_accumulate ? cs[m] + accs[i][r] : accs[i][r];
+        }
+      }
   }
   float *C = g.C + (g.nsplit > 1 ? (long)z * g.M * g.ldc : 0);
 #pragma unroll
@@ -202,8 +225,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_alpha_kernel(const float *_
   }
 }
 
+__global__ __launch_bounds__(256) void splitk_colsum_reduce_kernel(const float *__restrict__ part, int nsplit, int M, float *__restrict__ out,
+                                                                   int accumulate) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  float acc = 0.0f;
+  for (int k = 0; k < nsplit; ++k) acc += part[(long)k * M + m];
+  out[m] = accumulate ? out[m] + acc : acc;
+}
+
 static int launch_gemm_tn(const float *A, long lda, const float *B, long ldb, float *C, long ldc, int M, int N, int K, float alpha,
-                          int accumulate, float *scratch, hipStream_t s) {
+                          int accumulate, float *scratch, hipStream_t s, float *colsum = nullptr, int colsum_accumulate = 0) {
   const int tiles = ceil_div(M, 128) * ceil_div(N, 128);
   int nsplit = 1;
   if (scratch) {
@@ -219,7 +251,8 @@ static int launch_gemm_tn(const float *A, long lda, const float *B, long ldb, fl
   g.kslice = ceil_div(ceil_div(K, nsplit), 2) * 2;
   g.nsplit = ceil_div(K, g.kslice);
   g.alpha = alpha; g.accumulate = accumulate;
-  if (g.nsplit > 1) { g.C = scratch; g.ldc = N; } else { g.C = C; g.ldc = ldc; }
+  g.colsum = colsum; g.colsum_accumulate = colsum_accumulate;
+  if (g.nsplit > 1) { g.C = scratch; g.ldc = N; if (colsum) g.colsum = scratch + (size_t)g.nsplit * M * N; } else { g.C = C; g.ldc = ldc; }
   hipLaunchKernelGGL(gemm_tn_kernel, dim3(ceil_div(M, 128), ceil_div(N, 128), g.nsplit), dim3(256), 0, s, g);
   HN_LAUNCH_CHECK("gemm_tn");
   if (g.nsplit > 1) {
@@ -228,6 +261,10 @@ static int launch_gemm_tn(const float *A, long lda, const float *B, long ldb, fl
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(splitk_reduce_alpha_kernel, dim3((unsigned)blocks), dim3(256), 0, s, scratch, g.nsplit, mn, N, C, ldc, alpha, accumulate);
     HN_LAUNCH_CHECK("splitk_reduce");
+    if (colsum) {
+      hipLaunchKernelGGL(splitk_colsum_reduce_kernel, dim3(ceil_div(M, 256)), dim3(256), 0, s, g.colsum, g.nsplit, M, colsum, colsum_accumulate);
+      HN_LAUNCH_CHECK("splitk_colsum_reduce");
+    }
   }
   return HN_OK;
 }
@@ -280,7 +317,11 @@ int launch_gemm_ex(const GemmExArgs &g, hipStream_t s, float *scratch) {
   // TN form (both operands contraction-major, unit stride along their own row index): the MFMA-native kernel
   if (!no_tn && g.batch == 1 && g.a_rs == 1 && g.b_rs == 1 && g.k_total == 0 && (long)g.K * g.a_cs * 4 < (1L << 31) &&
       (long)g.K * g.b_cs * 4 < (1L << 31))
-    return launch_gemm_tn(g.A, g.a_cs, g.B, g.b_cs, g.C, g.ldc, g.M, g.N, g.K, g.alpha, g.accumulate, scratch, s);
+    return launch_gemm_tn(g.A, g.a_cs, g.B, g.b_cs, g.C, g.ldc, g.M, g.N, g.K, g.alpha, g.accumulate, scratch, s, g.colsum, g.colsum_accumulate);
+  if (g.colsum) {      // not the TN route: the caller's column sum still has to happen
+    int rc = launch_colsum(g.A, g.a_cs, g.K, g.M, 1.0f, g.colsum, g.colsum_accumulate, s, scratch);
+    if (rc != HN_OK) return rc;
+  }
   // NN form (A row-major over the contraction, B contraction-major): dX = dY W
   if (!no_nn && scratch && g.batch == 1 && g.a_cs == 1 && g.b_rs == 1 && g.k_total == 0 && g.M >= 256 && (g.K & 3) == 0 && (g.a_rs & 3) == 0)
     return launch_gemm_nn(g, s, scratch);
@@ -354,7 +395,7 @@ int launch_colsum(const float *X, long ld, long rows, int cols, float scale, flo
 }
 
 size_t reduce_scratch_floats(long max_mn, int max_cols) {
-  const size_t a = (size_t)GEMM_EX_SPLITS * max_mn, c = (size_t)COLSUM_CHUNKS * max_cols;
+  const size_t a = (size_t)GEMM_EX_SPLITS * (max_mn + max_cols), c = (size_t)COLSUM_CHUNKS * max_cols;   // split-k partials (+ colsum partials)
   return a > c ? a : c;
 }
 

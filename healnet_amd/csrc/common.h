@@ -278,6 +278,7 @@ struct GemmExArgs {                              // C[i,j] (+)= alpha * sum_c A(
   float alpha;
   int accumulate;
   int k_total;                                   // internal (split-k launches): full contraction length, 0 otherwise
+  float *colsum; int colsum_accumulate;          // TN form only: also colsum[i] (+)= sum_c A(i, c) (the bias gradient of dW = dY^T X)
 };
 constexpr int GEMM_EX_SPLITS = 32;
 int launch_gemm_ex(const GemmExArgs &g, hipStream_t s, float *scratch = nullptr);
