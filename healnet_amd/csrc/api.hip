@@ -421,7 +421,7 @@ static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float
       if ((rc = launch_gemm_ex(e, s, bp.red)) != HN_OK) return rc;
       if ((rc = launch_colsum(bp.dV, inner, b, inner, 1.0f, bp.cs, 0, s, bp.red)) != HN_OK) return rc;
       if ((rc = launch_kv_weight_grads(bp.G, bp.cs, p->w_kv + (long)inner * pl.D, p->ctx_gamma, p->ctx_beta, inner, pl.D,
-                                       g->w_kv ? g->w_kv + (long)inner * pl.D : nullptr, g->ctx_gamma, g->ctx_beta, s)) != HN_OK)
+                                       g->w_kv ? g->w_kv + (long)inner * pl.D : nullptr, g->ctx_gamma, g->ctx_beta, s, bp.red)) != HN_OK)
         return rc;
     }
     if (residual) { if (dx != dy) return launch_add_into(dy, dx, (long)rows * qd, 0, s); return HN_OK; }
@@ -545,7 +545,7 @@ static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float
       e.colsum = bp.cs; e.colsum_accumulate = 0;          // colsum(dKV) rides on the same pass
       if ((rc = launch_gemm_ex(e, s, bp.red)) != HN_OK) return rc;
       if ((rc = launch_kv_weight_grads(bp.G, bp.cs, p->w_kv, p->ctx_gamma, p->ctx_beta, 2 * inner, pl.D, g->w_kv, g->ctx_gamma,
-                                       g->ctx_beta, s)) != HN_OK) return rc;
+                                       g->ctx_beta, s, bp.red)) != HN_OK) return rc;
     } else if (g->w_kv) {   // self-attention: K, V come from x_hat
       GemmExArgs e = gex(bp.dKV, 1, 2 * inner, xhat, 1, qd, g->w_kv, qd, 2 * inner, qd, rows, 1);
       if ((rc = launch_gemm_ex(e, s, bp.red)) != HN_OK) return rc;

@@ -396,6 +396,7 @@ int launch_colsum(const float *X, long ld, long rows, int cols, float scale, flo
 
 size_t reduce_scratch_floats(long max_mn, int max_cols) {
   const size_t a = (size_t)GEMM_EX_SPLITS * (max_mn + max_cols), c = (size_t)COLSUM_CHUNKS * max_cols;   // split-k partials (+ colsum partials)
+  // (kv_weight_grads needs 2 * KVG_CHUNKS * D floats: covered by a, since max_mn >= 2 * inner * D)
   return a > c ? a : c;
 }
 
@@ -498,15 +499,19 @@ int launch_ln_bwd(const float *x, const float *dy, const float *gamma, long rows
 //   G = dKV^T z  (nrows, D)   and   cs = colsum(dKV)  (nrows):
 //   dW[n, d] += G[n, d] * gamma[d] + cs[n] * beta[d];  dgamma[d] += sum_n W[n, d] G[n, d];  dbeta[d] += sum_n W[n, d] cs[n]
 // (c_hat and its gradient are never materialised).  gamma == NULL: plain dW += G.
+constexpr int KVG_CHUNKS = 32;
+
 __global__ __launch_bounds__(256) void kv_weight_grads_kernel(const float *__restrict__ G, const float *__restrict__ cs,
                                                               const float *__restrict__ w, const float *gamma, const float *beta,
-                                                              int nrows, int D, float *dw, float *dgamma, float *dbeta) {
+                                                              int nrows, int D, float *dw, float *__restrict__ partial) {
   __shared__ float pg[4][64], pb[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), wv = threadIdx.x >> 6;
+  const int chunk = (nrows + gridDim.y - 1) / gridDim.y;
+  const int n0 = blockIdx.y * chunk, n1 = min(nrows, n0 + chunk);
   float sg = 0.0f, sb = 0.0f;
   if (c < D) {
     const float gm = gamma ? gamma[c] : 1.0f, bt = beta ? beta[c] : 0.0f;
-    for (int n = wv; n < nrows; n += 4) {
+    for (int n = n0 + wv; n < n1; n += 4) {
       const float gv = G[(long)n * D + c], wv_ = w[(long)n * D + c], csn = cs[n];
       if (dw) dw[(long)n * D + c] += gv * gm + csn * bt;
       sg += wv_ * gv;
@@ -516,16 +521,32 @@ __global__ __launch_bounds__(256) void kv_weight_grads_kernel(const float *__res
   pg[wv][threadIdx.x & 63] = sg;
   pb[wv][threadIdx.x & 63] = sb;
   __syncthreads();
-  if (wv == 0 && c < D && gamma) {
-    if (dgamma) dgamma[c] += pg[0][threadIdx.x] + pg[1][threadIdx.x] + pg[2][threadIdx.x] + pg[3][threadIdx.x];
-    if (dbeta) dbeta[c] += pb[0][threadIdx.x] + pb[1][threadIdx.x] + pb[2][threadIdx.x] + pb[3][threadIdx.x];
+  if (wv == 0 && c < D && partial) {      // row-chunk partials of (dgamma, dbeta), summed in fixed order by the reduce kernel
+    partial[((long)blockIdx.y * 2 + 0) * D + c] = pg[0][threadIdx.x] + pg[1][threadIdx.x] + pg[2][threadIdx.x] + pg[3][threadIdx.x];
+    partial[((long)blockIdx.y * 2 + 1) * D + c] = pb[0][threadIdx.x] + pb[1][threadIdx.x] + pb[2][threadIdx.x] + pb[3][threadIdx.x];
   }
 }
 
+__global__ __launch_bounds__(256) void kv_affine_reduce_kernel(const float *__restrict__ partial, int nchunks, int D, float *dgamma, float *dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= D) return;
+  float sg = 0.0f, sb = 0.0f;
+  for (int k = 0; k < nchunks; ++k) { sg += partial[((long)k * 2 + 0) * D + c]; sb += partial[((long)k * 2 + 1) * D + c]; }
+  if (dgamma) dgamma[c] += sg;
+  if (dbeta) dbeta[c] += sb;
+}
+
 int launch_kv_weight_grads(const float *G, const float *cs, const float *w, const float *gamma, const float *beta, int nrows, int D,
-                           float *dw, float *dgamma, float *dbeta, hipStream_t s) {
-  hipLaunchKernelGGL(kv_weight_grads_kernel, dim3(ceil_div(D, 64)), dim3(256), 0, s, G, cs, w, gamma, beta, nrows, D, dw, dgamma, dbeta);
+                           float *dw, float *dgamma, float *dbeta, hipStream_t s, float *scratch) {
+  HN_REQUIRE(scratch != nullptr, HN_E_NULL, "kv_weight_grads: scratch is NULL");
+  const bool affine = gamma != nullptr && (dgamma != nullptr || dbeta != nullptr);
+  hipLaunchKernelGGL(kv_weight_grads_kernel, dim3(ceil_div(D, 64), KVG_CHUNKS), dim3(256), 0, s, G, cs, w, gamma, beta, nrows, D, dw,
+                     affine ? scratch : nullptr);
   HN_LAUNCH_CHECK("kv_weight_grads");
+  if (affine) {
+    hipLaunchKernelGGL(kv_affine_reduce_kernel, dim3(ceil_div(D, 256)), dim3(256), 0, s, scratch, KVG_CHUNKS, D, dgamma, dbeta);
+    HN_LAUNCH_CHECK("kv_affine_reduce");
+  }
   return HN_OK;
 }
 

@@ -327,7 +327,7 @@ int launch_head_affine(const float *src, int lds, int spitch, const float *mul, 
 int launch_srow_affine(const float *saved, const float *dA, const float *gamma, const float *beta, int mode, int h, int D, int dp,
                        long rows, float *dst, hipStream_t s);
 int launch_kv_weight_grads(const float *G, const float *cs, const float *w, const float *gamma, const float *beta, int nrows, int D,
-                           float *dw, float *dgamma, float *dbeta, hipStream_t s);
+                           float *dw, float *dgamma, float *dbeta, hipStream_t s, float *scratch);
 int launch_segsum(const float *X, int seg, int cols, int nseg, float *out, hipStream_t s);
 
 // misc
