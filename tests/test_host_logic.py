@@ -141,3 +141,19 @@ def test_module_level_names_of_the_reference_exist():
     calls = []
     f = h.cache_fn(lambda: calls.append(1) or len(calls))
     assert f(key="a") == 1 and f(key="a") == 1 and f(key="b") == 2 and f(_cache=False) == 3 and f(key="a") == 1
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    """No CPU fallback: without libhealnet_hip.so every product entry point raises (the oracle is never consulted)."""
+    monkeypatch.setattr(_capi, "_lib", None)
+    monkeypatch.setattr(_capi, "LIB_PATH", str(tmp_path / "libhealnet_hip.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _capi.lib()
+    import sys
+    assert not any(name.startswith("oracle") for name in sys.modules if "healnet_amd" in (getattr(sys.modules[name], "__file__", "") or "")), \
+        "the product package must not import the oracle"
+    import healnet_amd
+    import healnet_amd.dist, healnet_amd.etl, healnet_amd.ops, healnet_amd.train      # noqa: F401
+    src = "".join(open(getattr(m, "__file__")).read() for m in (healnet_amd, healnet_amd.healnet, healnet_amd.train, healnet_amd.etl,
+                                                                healnet_amd.dist, healnet_amd.ops, healnet_amd._capi))
+    assert "import oracle" not in src and "from oracle" not in src
