@@ -132,7 +132,7 @@ static float *saved_kv(const AttnPlan &pl, bool has_ctx, bool masked, int b, int
 // writes them there, the backward (kv_ready) reads them back instead of re-running the K/V projection GEMM.
 static int attn_prepare(const hn_attn_params *p, const AttnPlan &pl, const float *x_in, const float *ctx, int ld_ctx,
                         int b, int L, hipStream_t s, AttnCoreArgs *core, int pack_ks = 0, float *kv_tape = nullptr,
-                        bool kv_ready = false, bool use_bound = false) {
+                        bool kv_ready = false, bool use_bound = false, int *ext_flag = nullptr) {
   const int rows = b * L;
   GemmArgs gq = gemm_defaults();
   gq.A = x_in; gq.lda = p->query_dim;
@@ -149,8 +149,9 @@ static int attn_prepare(const hn_attn_params *p, const AttnPlan &pl, const float
     if ((rc = launch_gemm(gq, s)) != HN_OK) return rc;
     // score bounds need |z|^2 <= D, i.e. a context that went through the LayerNorm of PreNorm.norm_context (ctx_gamma set)
     float *bound = (pl.ones && p->ctx_gamma && use_bound) ? pl.bound : nullptr;
-    int *bflag = bound ? (int *)(pl.bound + (size_t)b * p->heads * pl.Lp) : nullptr;
-    if (bound && (rc = launch_fill((float *)bflag, 0.0f, 1, s)) != HN_OK) return rc;
+    // the fallback flag: the caller's pre-zeroed one (hn_fusion_forward zeroes all of a forward's flags in one launch) or ours
+    int *bflag = bound ? (ext_flag ? ext_flag : (int *)(pl.bound + (size_t)b * p->heads * pl.Lp)) : nullptr;
+    if (bound && !ext_flag && (rc = launch_fill((float *)bflag, 0.0f, 1, s)) != HN_OK) return rc;
     if ((rc = launch_qfold(pl.q, pl.inner, p->w_kv, pl.D, p->ctx_gamma, pl.cscale, pl.qf, b, p->heads, L, pl.Lp, pl.dh,
                            pl.dp, s, pack_ks, bound, bflag)) != HN_OK) return rc;
     core->bound = bound; core->bound_flag = bflag;
@@ -193,7 +194,7 @@ static int attn_prepare(const hn_attn_params *p, const AttnPlan &pl, const float
 static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_out, int residual, const float *ctx,
                          int ld_ctx, int b, int L, int N, int D, const uint8_t *mask, float *stats, void *ws,
                          size_t ws_bytes, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, float *o_save = nullptr,
-                         bool ctx_has_ones = false, int ctx_pack_ks = 0, const Bf16Context *bc = nullptr) {
+                         bool ctx_has_ones = false, int ctx_pack_ks = 0, const Bf16Context *bc = nullptr, int *bound_flag = nullptr) {
   HN_REQUIRE(x_in && x_out, HN_E_NULL, "attn: x is NULL");
   HN_REQUIRE(p && p->w_q && p->w_kv && p->w_out, HN_E_NULL, "attn: weight pointer is NULL");
   AttnPlan pl;
@@ -242,8 +243,8 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
     if ((rc = launch_gemm(gq, s)) != HN_OK) return rc;
     uint16_t *qfb = (uint16_t *)pl.qf;
     float *bound = p->ctx_gamma ? pl.bound : nullptr;
-    int *bflag = bound ? (int *)(pl.bound + (size_t)b * p->heads * pl.Lp) : nullptr;
-    if (bound && (rc = launch_fill((float *)bflag, 0.0f, 1, s)) != HN_OK) return rc;
+    int *bflag = bound ? (bound_flag ? bound_flag : (int *)(pl.bound + (size_t)b * p->heads * pl.Lp)) : nullptr;
+    if (bound && !bound_flag && (rc = launch_fill((float *)bflag, 0.0f, 1, s)) != HN_OK) return rc;
     if ((rc = launch_qfold_bf16(pl.q, pl.inner, p->w_kv, pl.D, p->ctx_gamma, pl.cscale, qfb, b, p->heads, L, pl.Lp, pl.dh, bc->DV, bc->ns, s,
                                 bound, bflag)) != HN_OK)
       return rc;
@@ -273,7 +274,7 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
   AttnCoreArgs core;
   const int pack_ks = (pl.rank_d && pl.ones && ctx_has_ones && p->ctx_gamma) ? ctx_pack_ks : 0;
   if ((rc = attn_prepare(p, pl, x_in, ctx, ld_ctx, b, L, s, &core, pack_ks,
-                         saved_kv(pl, ctx != nullptr, mask != nullptr || dropping, b, L, o_save), false, !dropping)) != HN_OK) return rc;
+                         saved_kv(pl, ctx != nullptr, mask != nullptr || dropping, b, L, o_save), false, !dropping, bound_flag)) != HN_OK) return rc;
   core.mask = mask;
   core.ones_in_mem = (ctx_has_ones && pl.ones) ? 1 : 0;
   core.drop = drop_off();
@@ -721,6 +722,7 @@ struct FusionPlan {
   int pack[16];    // ... and uses the packed channel layout with this many QK^T k-steps (0 = natural)
   bool bf16[16];   // core_precision = bf16: z holds the bf16 images (zb, then zT) instead of the fp32 rows
   int Np[16], ns[16];
+  int *flags;      // one pre-zeroed fallback flag of the score-bound softmax per (layer, modality)
   void *op_ws;
   size_t op_ws_bytes, bytes;
   int dominant;   // modality with the most tokens among the present ones
@@ -798,6 +800,7 @@ static int plan_fusion(const hn_model *m, const hn_modality_input *in, int b, vo
   }
   const size_t ffb = align_up((size_t)b * m->l_c * 5 * m->l_d * sizeof(float), 256);
   if (ffb > op_max) op_max = ffb;
+  fp->flags = ar.take<int>((size_t)m->depth * m->n_modalities);
   fp->op_ws_bytes = op_max;
   fp->op_ws = ar.take<char>(op_max);
   fp->bytes = ar.off;
@@ -1122,6 +1125,7 @@ int hn_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, con
     if (rc != HN_OK) return rc;
   }
   if ((rc = launch_broadcast_rows(m->latents, fp.x, (long)L * d, b, s)) != HN_OK) return rc;   // :225
+  if ((rc = launch_fill((float *)fp.flags, 0.0f, (long)m->depth * M, s)) != HN_OK) return rc;
 
   const bool head = m->final_classifier_head && !return_embeddings;
   for (int layer = 0; layer < m->depth; ++layer) {
@@ -1143,7 +1147,7 @@ int hn_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, con
         bc.Np = fp.Np[i]; bc.DV = fp.ldz[i]; bc.ns = fp.ns[i];
         if ((rc = attn_fwd_impl(ap, fp.x, fp.x, 1, fp.z[i], fp.ldz[i], b, L, fp.N[i], fp.D[i], mask,
                                 attn_stats ? attn_stats[slot + i] : nullptr, fp.op_ws, fp.op_ws_bytes, s, e0, e1, nullptr,
-                                fp.ones[i], fp.pack[i], fp.bf16[i] ? &bc : nullptr)) != HN_OK)
+                                fp.ones[i], fp.pack[i], fp.bf16[i] ? &bc : nullptr, fp.flags + layer * M + i)) != HN_OK)
           return rc;
         if ((rc = ff_fwd_impl(&m->cross_ff[layer * M + i], fp.x, fp.x, 1, b * L, fp.op_ws, fp.op_ws_bytes, s)) != HN_OK)
           return rc;

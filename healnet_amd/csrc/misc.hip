@@ -115,16 +115,38 @@ __global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ x, 
   float *part = sm + d + 8;
   const int bi = blockIdx.x, tid = threadIdx.x;
   const float *xb = x + (long)bi * L * d;
-  {   // column means: the four waves take rows w, w+4, ...; lanes run along the columns (coalesced rows)
+  if ((d & 3) == 0 && d <= 256) {
+    // column means, 16-byte loads: d/4 column quads x (256 / (d/4)) row groups, four independent accumulations in flight
+    const int nq = d >> 2, groups = 256 / nq;
+    const int cq = tid % nq, gr = tid / nq;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+    if (gr < groups) {
+      int r = gr;
+      for (; r + groups < L; r += 2 * groups) {
+        const float4 v0 = *(const float4 *)(xb + (long)r * d + 4 * cq), v1 = *(const float4 *)(xb + (long)(r + groups) * d + 4 * cq);
+        a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+        a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+      }
+      if (r < L) { const float4 v0 = *(const float4 *)(xb + (long)r * d + 4 * cq); a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w; }
+      float *dst = part + (long)gr * d + 4 * cq;        // groups * d <= 1024 floats (launch_head sizes the LDS for it)
+      dst[0] = a0.x + a1.x; dst[1] = a0.y + a1.y; dst[2] = a0.z + a1.z; dst[3] = a0.w + a1.w;
+    }
+    __syncthreads();
+    for (int c = tid; c < d; c += blockDim.x) {
+      float sacc = 0.0f;
+      for (int k = 0; k < groups; ++k) sacc += part[(long)k * d + c];
+      pooled[c] = sacc / (float)L;
+    }
+  } else {   // column means: the four waves take rows w, w+4, ...; lanes run along the columns (coalesced rows)
     const int w = tid >> 6, ln = tid & 63;
     for (int c = ln; c < d; c += 64) {
       float s = 0.0f;
       for (int r = w; r < L; r += 4) s += xb[(long)r * d + c];
       part[w * d + c] = s;
     }
+    __syncthreads();
+    for (int c = tid; c < d; c += blockDim.x) pooled[c] = (part[c] + part[d + c] + part[2 * d + c] + part[3 * d + c]) / (float)L;
   }
-  __syncthreads();
-  for (int c = tid; c < d; c += blockDim.x) pooled[c] = (part[c] + part[d + c] + part[2 * d + c] + part[3 * d + c]) / (float)L;
   __syncthreads();
   // mean
   float s = 0.0f;
@@ -156,7 +178,7 @@ int launch_head(const float *x, int b, int L, int d, const float *nw, const floa
                 int out_dims, float *logits, hipStream_t s) {
   HN_REQUIRE(x && nw && nb && w && logits, HN_E_NULL, "head: NULL pointer");
   HN_REQUIRE(b > 0 && L > 0 && d > 0 && out_dims > 0, HN_E_SHAPE, "head: b=%d L=%d d=%d out=%d", b, L, d, out_dims);
-  size_t lds = (size_t)(5 * d + 8) * sizeof(float);
+  size_t lds = (size_t)(d + 8 + (4 * d > 1024 ? 4 * d : 1024)) * sizeof(float);     // pooled + scratch + row-group partials
   HN_REQUIRE(lds <= 64 * 1024, HN_E_UNSUPPORTED, "head: l_d=%d too large", d);
   hipLaunchKernelGGL(head_kernel, dim3(b), dim3(256), lds, s, x, L, d, nw, nb, w, bias, out_dims, logits);
   HN_LAUNCH_CHECK("head");
