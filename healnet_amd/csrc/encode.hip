@@ -176,6 +176,46 @@ __global__ __launch_bounds__(256) void encode_wave_kernel(const IN *__restrict__
   for (int c = g.D + lane; c < g.ld_out; c += 64) dst[c] = c == g.ones_col ? 1.0f : 0.0f;
 }
 
+// Few, wide tokens (the tabular / omic modality: b tokens of 2005 channels): one 256-thread workgroup per token instead of
+// one wave, so the three passes over the row (sum, variance, write) run 4x wider; workgroup sums through LDS.
+__device__ __forceinline__ float block_sum(float v, float *red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+template <typename IN>
+__global__ __launch_bounds__(256) void encode_block_kernel(const IN *__restrict__ data, float *__restrict__ out, EncGeom g) {
+  __shared__ float red[4];
+  const long tok = blockIdx.x;
+  const int tid = threadIdx.x;
+  long n = tok % g.N;
+  int idx[HN_MAX_AXES];
+  token_coords(n, g, idx);
+  const IN *src = data + tok * g.C;
+  float *dst = out + tok * (long)g.ld_out;
+  const int n_pos = g.D - g.C;
+  float mean = 0.0f, rstd = 1.0f;
+  if (g.normalize) {
+    float s = 0.0f;
+    for (int c = tid; c < g.C; c += 256) s += in_at(src, c);
+    for (int j = tid; j < n_pos; j += 256) s += pos_feature(j, idx, g);
+    mean = block_sum(s, red) / (float)g.D;
+    float q = 0.0f;
+    for (int c = tid; c < g.C; c += 256) { float d = in_at(src, c) - mean; q += d * d; }
+    for (int j = tid; j < n_pos; j += 256) { float d = pos_feature(j, idx, g) - mean; q += d * d; }
+    rstd = 1.0f / sqrtf(block_sum(q, red) / (float)g.D + g.eps);
+  }
+  for (int c = tid; c < g.C; c += 256) dst[c] = g.normalize ? (in_at(src, c) - mean) * rstd : in_at(src, c);
+  for (int j = tid; j < n_pos; j += 256) {
+    float p = pos_feature(j, idx, g);
+    dst[g.C + j] = g.normalize ? (p - mean) * rstd : p;
+  }
+  for (int c = g.D + tid; c < g.ld_out; c += 256) dst[c] = c == g.ones_col ? 1.0f : 0.0f;
+}
+
 static int fill_geom(EncGeom *g, int b, int n_axes, const int *spatial, int C, int F, float max_freq, int fourier, int normalize,
                      float eps) {
   HN_REQUIRE(spatial, HN_E_NULL, "encode: NULL pointer");
@@ -221,8 +261,12 @@ static int launch_encode_t(const IN *data, EncGeom g, int b, float *out, int ld_
 #undef HN_ENC
   } else {
     HN_REQUIRE(pack_ks == 0, HN_E_SHAPE, "encode: packed layout needs a narrow modality");
-    long blocks = ceil_div_ll(total, 4);
-    hipLaunchKernelGGL((encode_wave_kernel<IN>), dim3((unsigned)blocks), dim3(256), 0, s, data, out, g, total);
+    if (total <= 2048 && g.D >= 512) {      // few wide tokens: a workgroup per token
+      hipLaunchKernelGGL((encode_block_kernel<IN>), dim3((unsigned)total), dim3(256), 0, s, data, out, g);
+    } else {
+      long blocks = ceil_div_ll(total, 4);
+      hipLaunchKernelGGL((encode_wave_kernel<IN>), dim3((unsigned)blocks), dim3(256), 0, s, data, out, g, total);
+    }
   }
   HN_LAUNCH_CHECK("encode");
   return HN_OK;
