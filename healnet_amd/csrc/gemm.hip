@@ -197,6 +197,15 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(GemmArgs g, int ntm, int 
 
   const int lk = tid & 31, lr = tid >> 5;     // loader: lane runs along k, 8 row groups x 16 rows
   float ra[16], rb[16];
+  // per-lane byte offsets are loop invariant (row * pitch + lane's k); the k-tile base advances in an SGPR.  Columns past K
+  // read the next row (rows past the end read 0 through the descriptor): A is masked with km, so whatever W holds there
+  // is multiplied by 0 (weights are finite).
+  int offA[16], offW[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    offA[j] = ((m0 + lr + 8 * j) * (int)g.lda + lk) * 4;
+    offW[j] = ((n0 + lr + 8 * j) * (int)g.ldw + lk) * 4;
+  }
   auto load_tile = [&](int k0) {
     const int k = k0 + lk;
     const float km = k < g.K ? 1.0f : 0.0f;
@@ -205,10 +214,9 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(GemmArgs g, int ntm, int 
     if (g.pro == PRO_AFFINE) { gam = g.gamma[kc]; bet = g.beta[kc]; }
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      const int r = lr + 8 * j;
-      const float a = hn_buffer_load_x1(rsA, ((m0 + r) * (int)g.lda + kc) * 4, 0, 0);
+      const float a = hn_buffer_load_x1(rsA, offA[j], k0 * 4, 0);
       ra[j] = (a * gam + bet) * km;
-      rb[j] = hn_buffer_load_x1(rsW, ((n0 + r) * (int)g.ldw + kc) * 4, 0, 0);
+      rb[j] = hn_buffer_load_x1(rsW, offW[j], k0 * 4, 0);
     }
   };
   auto store_tile = [&]() {
