@@ -508,19 +508,45 @@ int launch_qfold(const float *Q, int ldq_row, const float *w_k, int D, const flo
 // ------------------------------------------------------------------------------------------------
 constexpr int MERGE_ROWS = 32;
 
-__device__ __forceinline__ float merged_value(const float *Opart, const float *Mpart, const float *Lpart, long pbase,
-                                              int nsplit, int Lp, int dp, int q, int d, float *Mout, float *Lout) {
+// Split merge in two phases: 8 lanes per latent row first turn the per-split (m, l) pairs into weights
+// w_s = 2^(m_s - M) and the merged (M, l) (staged in LDS), then every output element is one pass of nsplit
+// independent coalesced loads.  (The one-phase form re-read m and l for every element: 4 * nsplit dependent loads.)
+constexpr int MERGE_MAXS = 64;
+struct MergeWeights {
+  float w[MERGE_ROWS][MERGE_MAXS + 1];
+  float M[MERGE_ROWS], invl[MERGE_ROWS], l[MERGE_ROWS];
+};
+
+__device__ __forceinline__ void merge_row_weights(MergeWeights &mw, const float *Mpart, const float *Lpart, long pbase,
+                                                  int nsplit, int Lp, int q0, int L) {
+  const int qq = threadIdx.x >> 3, j = threadIdx.x & 7, q = q0 + qq;     // 256 threads = 32 rows x 8 lanes
+  const bool live = q < L;
   float M = kNegBig;
-  for (int s = 0; s < nsplit; ++s) M = fmaxf(M, Mpart[pbase + (long)s * Lp + q]);
-  float acc = 0.0f, lsum = 0.0f;
-  for (int s = 0; s < nsplit; ++s) {
+  if (live) for (int s = j; s < nsplit; s += 8) M = fmaxf(M, Mpart[pbase + (long)s * Lp + q]);
+  M = fmaxf(M, __shfl_xor(M, 1));
+  M = fmaxf(M, __shfl_xor(M, 2));
+  M = fmaxf(M, __shfl_xor(M, 4));
+  float lsum = 0.0f;
+  if (live) for (int s = j; s < nsplit; s += 8) {
     const float w = fast_exp2(Mpart[pbase + (long)s * Lp + q] - M);
     lsum = fmaf(w, Lpart[pbase + (long)s * Lp + q], lsum);
-    acc = fmaf(w, Opart[(pbase + (long)s * Lp + q) * dp + d], acc);
+    if (s < MERGE_MAXS) mw.w[qq][s] = w;
   }
-  *Mout = M;
-  *Lout = lsum;
-  return acc / lsum;
+  lsum += __shfl_xor(lsum, 1);
+  lsum += __shfl_xor(lsum, 2);
+  lsum += __shfl_xor(lsum, 4);
+  if (j == 0) { mw.M[qq] = M; mw.l[qq] = lsum; mw.invl[qq] = 1.0f / lsum; }
+}
+
+__device__ __forceinline__ float merged_value(const MergeWeights &mw, const float *Opart, const float *Mpart, long pbase,
+                                              int nsplit, int Lp,
+                                              int dp, int qq, int q, int d) {
+  float acc = 0.0f;
+  const int ns = nsplit < MERGE_MAXS ? nsplit : MERGE_MAXS;
+  for (int s = 0; s < ns; ++s) acc = fmaf(mw.w[qq][s], Opart[(pbase + (long)s * Lp + q) * dp + d], acc);
+  for (int s = MERGE_MAXS; s < nsplit; ++s)       // tiny batches only (b * h * row groups < 64): weights past the staged 64 on the fly
+    acc = fmaf(fast_exp2(Mpart[pbase + (long)s * Lp + q] - mw.M[qq]), Opart[(pbase + (long)s * Lp + q) * dp + d], acc);
+  return acc * mw.invl[qq];
 }
 
 __global__ __launch_bounds__(256) void merge_vproj_kernel(const float *__restrict__ Opart, const float *__restrict__ Mpart,
@@ -536,17 +562,18 @@ __global__ __launch_bounds__(256) void merge_vproj_kernel(const float *__restric
   const int q0 = blockIdx.y * MERGE_ROWS;
   const long pbase = (long)bh * nsplit * Lp;
   const int dlim = pack_ks ? dp : D;
+  __shared__ MergeWeights mw;
+  merge_row_weights(mw, Mpart, Lpart, pbase, nsplit, Lp, q0, L);
+  __syncthreads();
+  if (stats && threadIdx.x < MERGE_ROWS && q0 + threadIdx.x < L) {
+    stats[((long)bh * L + q0 + threadIdx.x) * 2 + 0] = mw.M[threadIdx.x];
+    stats[((long)bh * L + q0 + threadIdx.x) * 2 + 1] = mw.l[threadIdx.x];
+  }
   for (int idx = threadIdx.x; idx < MERGE_ROWS * dp; idx += blockDim.x) {
     const int qq = idx / dp, d = idx % dp, q = q0 + qq;
     float v = 0.0f;
-    if (q < L && (d < dlim || (srow && d == dp - 1))) {      // srow: column dp-1 carries the dropped row sum (see attn_core)
-      float M, Ls;
-      v = merged_value(Opart, Mpart, Lpart, pbase, nsplit, Lp, dp, q, d, &M, &Ls);
-      if (stats && d == 0) {
-        stats[((long)bh * L + q) * 2 + 0] = M;
-        stats[((long)bh * L + q) * 2 + 1] = Ls;
-      }
-    }
+    if (q < L && (d < dlim || (srow && d == dp - 1)))        // srow: column dp-1 carries the dropped row sum (see attn_core)
+      v = merged_value(mw, Opart, Mpart, pbase, nsplit, Lp, dp, qq, q, d);
     if (oprime_save && q < L) oprime_save[((long)bi * L + q) * (h * dp) + hi * dp + d] = v;   // training: normalised P z, padding columns 0
     oh[qq * (dp + 1) + d] = v;
   }
@@ -593,16 +620,17 @@ __global__ __launch_bounds__(256) void merge_explicit_kernel(const float *__rest
   const int bh = blockIdx.x, bi = bh / h, hi = bh % h;
   const int q0 = blockIdx.y * MERGE_ROWS;
   const long pbase = (long)bh * nsplit * Lp;
+  __shared__ MergeWeights mw;
+  merge_row_weights(mw, Mpart, Lpart, pbase, nsplit, Lp, q0, L);
+  __syncthreads();
+  if (stats && threadIdx.x < MERGE_ROWS && q0 + threadIdx.x < L) {
+    stats[((long)bh * L + q0 + threadIdx.x) * 2 + 0] = mw.M[threadIdx.x];
+    stats[((long)bh * L + q0 + threadIdx.x) * 2 + 1] = mw.l[threadIdx.x];
+  }
   for (int idx = threadIdx.x; idx < MERGE_ROWS * dh; idx += blockDim.x) {
     const int qq = idx / dh, e = idx % dh, q = q0 + qq;
     if (q >= L) continue;
-    float M, Ls;
-    const float v = merged_value(Opart, Mpart, Lpart, pbase, nsplit, Lp, dp, q, e, &M, &Ls);
-    O[((long)bi * L + q) * ldo + hi * dh + e] = v;
-    if (stats && e == 0) {
-      stats[((long)bh * L + q) * 2 + 0] = M;
-      stats[((long)bh * L + q) * 2 + 1] = Ls;
-    }
+    O[((long)bi * L + q) * ldo + hi * dh + e] = merged_value(mw, Opart, Mpart, pbase, nsplit, Lp, dp, qq, q, e);
   }
 }
 

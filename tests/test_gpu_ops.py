@@ -75,7 +75,8 @@ def test_attention_matches_reference_fixtures(hn, manifest):
 
 @pytest.mark.parametrize("b,L,N,D,heads,dh", [(2, 128, 5000, 13, 8, 64), (1, 128, 777, 18, 8, 64), (2, 25, 300, 96, 1, 63),
                                               (2, 17, 65, 40, 4, 27), (1, 128, 4096, 773, 8, 64), (3, 128, 1, 2005, 8, 64),
-                                              (2, 16, 33, 12, 2, 103), (2, 256, 1, 2189, 8, 64)])
+                                              (2, 16, 33, 12, 2, 103), (2, 256, 1, 2189, 8, 64),
+                                              (1, 25, 9000, 13, 1, 63), (1, 25, 9100, 96, 1, 63)])   # > 64 token splits
 def test_prenorm_cross_attention_vs_oracle(hn, b, L, N, D, heads, dh):
     gen = torch.Generator().manual_seed(b * 1000 + N)
     qd = 128 if L == 128 else 32
