@@ -120,12 +120,16 @@ struct GemmTnArgs {
   int M, N, K, kslice, nsplit;
   float alpha; int accumulate;
   float *colsum; int colsum_accumulate;      // optional: sum_k A[k, m] (bias gradient); nsplit > 1: partials (nsplit, M) in scratch
+  int batch; long strideA, strideB, strideC; // independent products (per-head weight gradients); grid.z = batch * nsplit
 };
 
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs g) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int m0 = blockIdx.x * 128 + (wave >> 1) * 64, n0 = blockIdx.y * 128 + (wave & 1) * 64, z = blockIdx.z;
+  const int m0 = blockIdx.x * 128 + (wave >> 1) * 64, n0 = blockIdx.y * 128 + (wave & 1) * 64;
+  const int z = blockIdx.z % g.nsplit, bt = blockIdx.z / g.nsplit;
   if (m0 >= g.M || n0 >= g.N) return;
+  g.A += bt * g.strideA;
+  g.B += bt * g.strideB;
   const int k_begin = z * g.kslice, k_end = min(g.K, k_begin + g.kslice);
   const int rows = k_end - k_begin;                     // >= 1: nsplit = ceil(K / kslice)
   const int half = lane >> 5, col = lane & 31;
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs g) {
         }
       }
   }
-  float *C = g.C + (g.nsplit > 1 ? (long)z * g.M * g.ldc : 0);
+  float *C = g.C + (g.nsplit > 1 ? ((long)bt * g.nsplit + z) * g.M * g.ldc : bt * g.strideC);
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -216,7 +220,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs g) {
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_alpha_kernel(const float *__restrict__ part, int nsplit, long mn, int N,
-                                                                  float *__restrict__ C, long ldc, float alpha, int accumulate) {
+                                                                  float *__restrict__ C, long ldc, float alpha, int accumulate,
+                                                                  long strideC) {
+  part += (long)blockIdx.y * nsplit * mn;          // blockIdx.y: batch entry
+  C += blockIdx.y * strideC;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < mn; i += (long)gridDim.x * blockDim.x) {
     float acc = 0.0f;
     for (int k = 0; k < nsplit; ++k) acc += part[(long)k * mn + i];
@@ -235,8 +242,10 @@ __global__ __launch_bounds__(256) void splitk_colsum_reduce_kernel(const float *
 }
 
 static int launch_gemm_tn(const float *A, long lda, const float *B, long ldb, float *C, long ldc, int M, int N, int K, float alpha,
-                          int accumulate, float *scratch, hipStream_t s, float *colsum = nullptr, int colsum_accumulate = 0) {
-  const int tiles = ceil_div(M, 128) * ceil_div(N, 128);
+                          int accumulate, float *scratch, hipStream_t s, float *colsum = nullptr, int colsum_accumulate = 0,
+                          int batch = 1, long strideA = 0, long strideB = 0, long strideC = 0) {
+  HN_REQUIRE(batch == 1 || colsum == nullptr, HN_E_UNSUPPORTED, "gemm_tn: the fused column sum is not batched");
+  const int tiles = ceil_div(M, 128) * ceil_div(N, 128) * batch;
   int nsplit = 1;
   if (scratch) {
     nsplit = ceil_div(768, tiles);                              // ~3 workgroups per CU
@@ -252,14 +261,17 @@ static int launch_gemm_tn(const float *A, long lda, const float *B, long ldb, fl
   g.nsplit = ceil_div(K, g.kslice);
   g.alpha = alpha; g.accumulate = accumulate;
   g.colsum = colsum; g.colsum_accumulate = colsum_accumulate;
+  g.batch = batch; g.strideA = strideA; g.strideB = strideB; g.strideC = strideC;
+  HN_REQUIRE((long)g.nsplit * batch <= 65535, HN_E_UNSUPPORTED, "gemm_tn: batch=%d", batch);
   if (g.nsplit > 1) { g.C = scratch; g.ldc = N; if (colsum) g.colsum = scratch + (size_t)g.nsplit * M * N; } else { g.C = C; g.ldc = ldc; }
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3(ceil_div(M, 128), ceil_div(N, 128), g.nsplit), dim3(256), 0, s, g);
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3(ceil_div(M, 128), ceil_div(N, 128), g.nsplit * batch), dim3(256), 0, s, g);
   HN_LAUNCH_CHECK("gemm_tn");
   if (g.nsplit > 1) {
     const long mn = (long)M * N;
     long blocks = ceil_div_ll(mn, 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(splitk_reduce_alpha_kernel, dim3((unsigned)blocks), dim3(256), 0, s, scratch, g.nsplit, mn, N, C, ldc, alpha, accumulate);
+    hipLaunchKernelGGL(splitk_reduce_alpha_kernel, dim3((unsigned)blocks, batch), dim3(256), 0, s, scratch, g.nsplit, mn, N, C, ldc, alpha,
+                       accumulate, strideC);
     HN_LAUNCH_CHECK("splitk_reduce");
     if (colsum) {
       hipLaunchKernelGGL(splitk_colsum_reduce_kernel, dim3(ceil_div(M, 256)), dim3(256), 0, s, g.colsum, g.nsplit, M, colsum, colsum_accumulate);
@@ -315,9 +327,10 @@ int launch_gemm_ex(const GemmExArgs &g, hipStream_t s, float *scratch) {
   static int no_tn = -1, no_nn = -1;      // development knobs (flakiness bisect)
   if (no_tn < 0) { const char *e = getenv("HN_NO_TN"); no_tn = (e && e[0] == '1') ? 1 : 0; e = getenv("HN_NO_NN"); no_nn = (e && e[0] == '1') ? 1 : 0; }
   // TN form (both operands contraction-major, unit stride along their own row index): the MFMA-native kernel
-  if (!no_tn && g.batch == 1 && g.a_rs == 1 && g.b_rs == 1 && g.k_total == 0 && (long)g.K * g.a_cs * 4 < (1L << 31) &&
-      (long)g.K * g.b_cs * 4 < (1L << 31))
-    return launch_gemm_tn(g.A, g.a_cs, g.B, g.b_cs, g.C, g.ldc, g.M, g.N, g.K, g.alpha, g.accumulate, scratch, s, g.colsum, g.colsum_accumulate);
+  if (!no_tn && (g.batch == 1 || (!g.colsum && scratch)) && g.a_rs == 1 && g.b_rs == 1 && g.k_total == 0 &&
+      (long)g.K * g.a_cs * 4 < (1L << 31) && (long)g.K * g.b_cs * 4 < (1L << 31))
+    return launch_gemm_tn(g.A, g.a_cs, g.B, g.b_cs, g.C, g.ldc, g.M, g.N, g.K, g.alpha, g.accumulate, scratch, s, g.colsum, g.colsum_accumulate,
+                          g.batch, g.strideA, g.strideB, g.strideC);
   if (g.colsum) {      // not the TN route: the caller's column sum still has to happen
     int rc = launch_colsum(g.A, g.a_cs, g.K, g.M, 1.0f, g.colsum, g.colsum_accumulate, s, scratch);
     if (rc != HN_OK) return rc;
