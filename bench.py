@@ -152,7 +152,8 @@ def main():
     from healnet_amd import _capi
     torch.manual_seed(0)                                   # every replica holds the same seed-0 default-init model
     model = healnet_amd.HealNet(**KW, core_precision=args.core_precision).eval().to(dev)
-    model.keep_attention_stats = False
+    # keep_attention_stats stays at its default (True): every attention block's softmax statistics and input are kept so
+    # that Attention.attn_weights (healnet.py:420) can be rebuilt on demand -- zero-copy, the blocks write them in place
     gen = torch.Generator().manual_seed(1234 + rank)       # SURVEY.md §8d synthetic inputs, U[0,1)
     b = args.batch
     tab = torch.rand(b, *TAB, generator=gen).to(dev)

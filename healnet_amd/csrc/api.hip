@@ -1124,18 +1124,30 @@ int hn_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, con
     }
     if (rc != HN_OK) return rc;
   }
-  if ((rc = launch_broadcast_rows(m->latents, fp.x, (long)L * d, b, s)) != HN_OK) return rc;   // :225
   if ((rc = launch_fill((float *)fp.flags, 0.0f, (long)m->depth * M, s)) != HN_OK) return rc;
 
+  // The latent array moves through a chain of buffers instead of being updated in place: the block in front of an
+  // attention block writes straight into that block's x_trace slot (the input hn_attn_probs re-reads later), so
+  // keeping the trace costs no copy.  Without trace slots every block works in place on fp.x as before.
+  static thread_local Step steps[kMaxSteps];
+  const int nsteps = build_schedule(m, in, skip_self_on_missing, steps, kMaxSteps);
+  HN_REQUIRE(nsteps >= 0, HN_E_UNSUPPORTED, "fusion: more than %d blocks", kMaxSteps);
+  auto slot_of = [&](const Step &st) { return st.layer * (M + 1) + (st.kind == STEP_CROSS_ATTN ? st.m : M); };
+  auto input_buffer = [&](int k) -> float * {      // where step k wants to find x
+    if (k < nsteps && x_trace && (steps[k].kind == STEP_CROSS_ATTN || steps[k].kind == STEP_SELF_ATTN) && x_trace[slot_of(steps[k])])
+      return x_trace[slot_of(steps[k])];
+    return fp.x;
+  };
+  float *cur = input_buffer(0);
+  if ((rc = launch_broadcast_rows(m->latents, cur, (long)L * d, b, s)) != HN_OK) return rc;   // :225
   const bool head = m->final_classifier_head && !return_embeddings;
-  for (int layer = 0; layer < m->depth; ++layer) {
-    for (int i = 0; i < M; ++i) {
-      const bool present = in[i].data != nullptr;
-      if (!present && skip_self_on_missing) continue;                                       // verbose quirk :229-232
-      const int slot = layer * (M + 1);
-      if (present) {
+  for (int k = 0; k < nsteps; ++k) {
+    const Step &st = steps[k];
+    const int layer = st.layer, i = st.m;
+    float *dst = input_buffer(k + 1);
+    switch (st.kind) {
+      case STEP_CROSS_ATTN: {
         const hn_attn_params *ap = &m->cross_attn[layer * M + i];
-        if (x_trace && x_trace[slot + i]) { int rc_ = launch_copy(x_trace[slot + i], fp.x, (long)((xbytes) / sizeof(float)), s); if (rc_ != HN_OK) return rc_; }
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (prof && i == fp.dominant && prof->n_recorded < prof->n_events) {
           e0 = (hipEvent_t)prof->ev_start[prof->n_recorded];
@@ -1145,24 +1157,27 @@ int hn_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, con
         Bf16Context bc;
         bc.zb = (const uint16_t *)fp.z[i]; bc.zT = bc.zb + (size_t)b * fp.Np[i] * bf16_row_slots(fp.ldz[i], fp.ns[i]);
         bc.Np = fp.Np[i]; bc.DV = fp.ldz[i]; bc.ns = fp.ns[i];
-        if ((rc = attn_fwd_impl(ap, fp.x, fp.x, 1, fp.z[i], fp.ldz[i], b, L, fp.N[i], fp.D[i], mask,
-                                attn_stats ? attn_stats[slot + i] : nullptr, fp.op_ws, fp.op_ws_bytes, s, e0, e1, nullptr,
-                                fp.ones[i], fp.pack[i], fp.bf16[i] ? &bc : nullptr, fp.flags + layer * M + i)) != HN_OK)
-          return rc;
-        if ((rc = ff_fwd_impl(&m->cross_ff[layer * M + i], fp.x, fp.x, 1, b * L, fp.op_ws, fp.op_ws_bytes, s)) != HN_OK)
-          return rc;
+        rc = attn_fwd_impl(ap, cur, dst, 1, fp.z[i], fp.ldz[i], b, L, fp.N[i], fp.D[i], mask,
+                           attn_stats ? attn_stats[slot_of(st)] : nullptr, fp.op_ws, fp.op_ws_bytes, s, e0, e1, nullptr,
+                           fp.ones[i], fp.pack[i], fp.bf16[i] ? &bc : nullptr, fp.flags + layer * M + i);
+        break;
       }
-      if (m->self_per_cross_attn > 0) {                                                     // :241-245
-        if (x_trace && x_trace[slot + M]) { int rc_ = launch_copy(x_trace[slot + M], fp.x, (long)((xbytes) / sizeof(float)), s); if (rc_ != HN_OK) return rc_; }
-        if ((rc = attn_fwd_impl(&m->self_attn[layer], fp.x, fp.x, 1, nullptr, 0, b, L, L, d, nullptr,
-                                attn_stats ? attn_stats[slot + M] : nullptr, fp.op_ws, fp.op_ws_bytes, s, nullptr, nullptr)) != HN_OK)
-          return rc;
-        if ((rc = ff_fwd_impl(&m->self_ff[layer], fp.x, fp.x, 1, b * L, fp.op_ws, fp.op_ws_bytes, s)) != HN_OK) return rc;
-      }
+      case STEP_CROSS_FF:
+        rc = ff_fwd_impl(&m->cross_ff[layer * M + i], cur, dst, 1, b * L, fp.op_ws, fp.op_ws_bytes, s);
+        break;
+      case STEP_SELF_ATTN:                                                                  // :241-245
+        rc = attn_fwd_impl(&m->self_attn[layer], cur, dst, 1, nullptr, 0, b, L, L, d, nullptr,
+                           attn_stats ? attn_stats[slot_of(st)] : nullptr, fp.op_ws, fp.op_ws_bytes, s, nullptr, nullptr);
+        break;
+      default:
+        rc = ff_fwd_impl(&m->self_ff[layer], cur, dst, 1, b * L, fp.op_ws, fp.op_ws_bytes, s);
+        break;
     }
+    if (rc != HN_OK) return rc;
+    cur = dst;
   }
-  if (head) return launch_head(fp.x, b, L, d, m->head_norm_w, m->head_norm_b, m->head_w, m->head_b, m->out_dims, out, s);
-  { int rc_ = launch_copy(out, fp.x, (long)((xbytes) / sizeof(float)), s); if (rc_ != HN_OK) return rc_; }
+  if (head) return launch_head(cur, b, L, d, m->head_norm_w, m->head_norm_b, m->head_w, m->head_b, m->out_dims, out, s);
+  { int rc_ = launch_copy(out, cur, (long)((xbytes) / sizeof(float)), s); if (rc_ != HN_OK) return rc_; }
   return HN_OK;
 }
 
@@ -1172,6 +1187,26 @@ size_t hn_fusion_tape_bytes(const hn_model *m, const hn_modality_input *in, int 
   static thread_local TapePlan tp;
   if (plan_tape(m, in, b, masked, skip_self_on_missing, fp, &tp) != HN_OK) return 0;
   return align_up(tp.floats * sizeof(float), 256);
+}
+
+int hn_fusion_tape_layout(const hn_model *m, const hn_modality_input *in, int b, int masked, int skip_self_on_missing,
+                          size_t *stats_off, size_t *x_off) {
+  HN_REQUIRE(stats_off && x_off, HN_E_NULL, "fusion_tape_layout: NULL output");
+  FusionPlan fp;
+  int rc = plan_fusion(m, in, b, nullptr, 0, &fp);
+  if (rc != HN_OK) return rc;
+  static thread_local TapePlan tp;
+  if ((rc = plan_tape(m, in, b, masked, skip_self_on_missing, fp, &tp)) != HN_OK) return rc;
+  const int M = m->n_modalities;
+  for (int i = 0; i < m->depth * (M + 1); ++i) stats_off[i] = x_off[i] = (size_t)-1;
+  for (int k = 0; k < tp.nsteps; ++k) {        // a slot executed twice (the self-attention of a layer) reports its last run
+    const Step &st = tp.steps[k];
+    if (st.kind != STEP_CROSS_ATTN && st.kind != STEP_SELF_ATTN) continue;
+    const int slot = st.layer * (M + 1) + (st.kind == STEP_CROSS_ATTN ? st.m : M);
+    stats_off[slot] = tp.stats_off[k];
+    x_off[slot] = tp.x_off[k];
+  }
+  return HN_OK;
 }
 
 int hn_fusion_forward_train(const hn_model *m, const hn_modality_input *in, int b, const uint8_t *mask, int skip_self_on_missing,

@@ -419,48 +419,53 @@ size_t reduce_scratch_floats(long max_mn, int max_cols) {
 //   partial[block, 0:d] = sum_rows dy * xn ;  partial[block, d:2d] = sum_rows dy     (reduced by colsum)
 // One wave per row (lanes along d), LN_ROWS rows per workgroup.
 // ------------------------------------------------------------------------------------------------
-constexpr int LN_ROWS = 32, LN_MAXC = 16;   // d <= 64 * LN_MAXC
+constexpr int LN_ROWS = 16, LN_MAXC = 16;   // d <= 64 * LN_MAXC
 
+template <int MAXC>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dy,
                                                      const float *__restrict__ gamma, float eps, long rows, int d,
                                                      float *__restrict__ dx, int dx_accumulate, float *__restrict__ partial) {
   extern __shared__ float red[];   // [4 waves][2 d]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float gsum[LN_MAXC], bsum[LN_MAXC];
+  float gsum[MAXC], bsum[MAXC], gam[MAXC];
 #pragma unroll
-  for (int k = 0; k < LN_MAXC; ++k) { gsum[k] = 0.0f; bsum[k] = 0.0f; }
+  for (int k = 0; k < MAXC; ++k) {
+    gsum[k] = 0.0f; bsum[k] = 0.0f;
+    gam[k] = lane + 64 * k < d ? gamma[lane + 64 * k] : 0.0f;
+  }
   const long r0 = (long)blockIdx.x * LN_ROWS;
+  const float invd = 1.0f / (float)d;
   for (int rr = wave; rr < LN_ROWS; rr += 4) {
     const long r = r0 + rr;
     if (r >= rows) break;
     const float *xr = x + r * d, *dyr = dy + r * d;
-    float xv[LN_MAXC], dv[LN_MAXC];
+    float xv[MAXC], dv[MAXC];
     float s = 0.0f;
 #pragma unroll
-    for (int k = 0; k < LN_MAXC; ++k) {
+    for (int k = 0; k < MAXC; ++k) {
       const int c = lane + 64 * k;
       xv[k] = c < d ? xr[c] : 0.0f;
       dv[k] = c < d ? dyr[c] : 0.0f;
       s += xv[k];
     }
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    const float mu = s / (float)d;
+    const float mu = s * invd;
     float q = 0.0f;
 #pragma unroll
-    for (int k = 0; k < LN_MAXC; ++k) {
+    for (int k = 0; k < MAXC; ++k) {
       const int c = lane + 64 * k;
       const float t = c < d ? xv[k] - mu : 0.0f;
       q += t * t;
     }
     for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
-    const float rs = 1.0f / sqrtf(q / (float)d + eps);
+    const float rs = 1.0f / sqrtf(q * invd + eps);
     float m1 = 0.0f, m2 = 0.0f;
 #pragma unroll
-    for (int k = 0; k < LN_MAXC; ++k) {
+    for (int k = 0; k < MAXC; ++k) {
       const int c = lane + 64 * k;
       if (c < d) {
         const float xn = (xv[k] - mu) * rs;
-        const float dyg = dv[k] * gamma[c];
+        const float dyg = dv[k] * gam[k];
         gsum[k] += dv[k] * xn;
         bsum[k] += dv[k];
         m1 += dyg;
@@ -470,10 +475,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ x
       }
     }
     for (int o = 32; o > 0; o >>= 1) { m1 += __shfl_xor(m1, o); m2 += __shfl_xor(m2, o); }
-    m1 /= (float)d;
-    m2 /= (float)d;
+    m1 *= invd;
+    m2 *= invd;
 #pragma unroll
-    for (int k = 0; k < LN_MAXC; ++k) {
+    for (int k = 0; k < MAXC; ++k) {
       const int c = lane + 64 * k;
       if (c < d) {
         const float v = rs * (dv[k] - m1 - xv[k] * m2);
@@ -482,13 +487,30 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ x
     }
   }
 #pragma unroll
-  for (int k = 0; k < LN_MAXC; ++k) {
+  for (int k = 0; k < MAXC; ++k) {
     const int c = lane + 64 * k;
     if (c < d) { red[wave * 2 * d + c] = gsum[k]; red[wave * 2 * d + d + c] = bsum[k]; }
   }
   __syncthreads();
   for (int c = threadIdx.x; c < 2 * d; c += blockDim.x)
     partial[(long)blockIdx.x * 2 * d + c] = red[c] + red[2 * d + c] + red[4 * d + c] + red[6 * d + c];
+}
+
+// dgamma[c] += sum_blocks partial[., c] ; dbeta[c] += sum_blocks partial[., d + c]  -- one launch for both (fixed order)
+__global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float *__restrict__ partial, int blocks, int d,
+                                                              float *__restrict__ dgamma, float *__restrict__ dbeta) {
+  __shared__ float part[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+  float s = 0.0f;
+  if (c < 2 * d)
+    for (int r = w; r < blocks; r += 4) s += partial[(long)r * 2 * d + c];
+  part[w][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (w == 0 && c < 2 * d) {
+    const float v = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+    if (c < d) { if (dgamma) dgamma[c] += v; }
+    else if (dbeta) dbeta[c - d] += v;
+  }
 }
 
 // dgamma / dbeta accumulate into their gradient buffers; `scratch` needs ln_bwd_scratch_floats(rows, d) floats
@@ -499,12 +521,18 @@ int launch_ln_bwd(const float *x, const float *dy, const float *gamma, long rows
   HN_REQUIRE(x && dy && gamma && dx && scratch, HN_E_NULL, "ln_bwd: NULL pointer");
   HN_REQUIRE(d > 0 && d <= 64 * LN_MAXC, HN_E_UNSUPPORTED, "ln_bwd: d=%d (<= %d supported)", d, 64 * LN_MAXC);
   const int blocks = (int)ceil_div_ll(rows, LN_ROWS);
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), (size_t)8 * d * sizeof(float), s, x, dy, gamma, 1e-5f, rows, d, dx,
-                     dx_accumulate, scratch);
+  const size_t lds = (size_t)8 * d * sizeof(float);
+#define HN_LN_BWD(C_) hipLaunchKernelGGL(ln_bwd_kernel<C_>, dim3(blocks), dim3(256), lds, s, x, dy, gamma, 1e-5f, rows, d, dx, dx_accumulate, scratch)
+  if (d <= 128) HN_LN_BWD(2);
+  else if (d <= 256) HN_LN_BWD(4);
+  else if (d <= 512) HN_LN_BWD(8);
+  else HN_LN_BWD(LN_MAXC);
+#undef HN_LN_BWD
   HN_LAUNCH_CHECK("ln_bwd");
-  int rc;
-  if (dgamma && (rc = launch_colsum(scratch, 2 * d, blocks, d, 1.0f, dgamma, 1, s)) != HN_OK) return rc;
-  if (dbeta && (rc = launch_colsum(scratch + d, 2 * d, blocks, d, 1.0f, dbeta, 1, s)) != HN_OK) return rc;
+  if (dgamma || dbeta) {
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(ceil_div(2 * d, 64)), dim3(256), 0, s, scratch, blocks, d, dgamma, dbeta);
+    HN_LAUNCH_CHECK("ln_param_reduce");
+  }
   return HN_OK;
 }
 

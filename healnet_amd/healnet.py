@@ -422,6 +422,7 @@ class _FusionFunction(torch.autograd.Function):
                                                 ws.numel(), _stream_ptr(device)), "hn_fusion_forward_train")
         ctx.module, ctx.inputs, ctx.held, ctx.mask_u8 = module, inputs, held, mask_u8
         ctx.b, ctx.skip_self, ctx.embeddings, ctx.tape, ctx.params = b, skip_self, embeddings, tape, params
+        module._last_tape = (tape, masked, int(skip_self))      # forward() views the statistics / block inputs in place
         return out
 
     @staticmethod
@@ -669,7 +670,9 @@ class HealNet(nn.Module):
         stats_ptrs = x_ptrs = None
         stats_t: List[Optional[torch.Tensor]] = [None] * n_slots
         trace_t: List[Optional[torch.Tensor]] = [None] * n_slots
-        if self.keep_attention_stats:
+        dropping = self._dropout_active()
+        taping = dropping or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()))
+        if self.keep_attention_stats and not taping:
             stats_ptrs = (C.c_void_p * n_slots)()
             x_ptrs = (C.c_void_p * n_slots)()
             for layer in range(self.depth):
@@ -683,8 +686,7 @@ class HealNet(nn.Module):
                     stats_ptrs[layer * (M + 1) + j] = stats_t[layer * (M + 1) + j].data_ptr()
                     x_ptrs[layer * (M + 1) + j] = trace_t[layer * (M + 1) + j].data_ptr()
 
-        dropping = self._dropout_active()
-        if dropping or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
+        if taping:
             # autograd path (train or eval mode alike, as in PyTorch): tape-recording forward + hn_fusion_backward.
             # Dropout masks are drawn in training mode only, grad mode or not (nn.Dropout); every forward advances the
             # Philox offset, the seed is torch's global seed (torch.manual_seed).
@@ -695,8 +697,22 @@ class HealNet(nn.Module):
                 self._rng_offset = (getattr(self, "_rng_offset", 0) + 1) & 0xFFFFFFFF
                 rng = (torch.initial_seed(), self._rng_offset)
             self._last_rng = rng
-            out = _FusionFunction.apply(self, inputs, held, mask_u8, b, bool(verbose), embeddings, stats_ptrs, x_ptrs, rng,
+            out = _FusionFunction.apply(self, inputs, held, mask_u8, b, bool(verbose), embeddings, None, None, rng,
                                         *list(self.parameters()))
+            if self.keep_attention_stats:
+                # the tape already holds every block's softmax statistics and input: view them, no copies
+                tape, masked, skip = self._last_tape
+                so, xo = (C.c_size_t * n_slots)(), (C.c_size_t * n_slots)()
+                _capi.check(lib.hn_fusion_tape_layout(C.byref(model), inputs, b, masked, skip, so, xo), "hn_fusion_tape_layout")
+                tf = tape.view(torch.float32)
+                for slot in range(n_slots):
+                    if so[slot] == C.c_size_t(-1).value:
+                        continue
+                    j = slot % (M + 1)
+                    heads = self.layers[slot // (M + 1)][2 * j].fn.heads if j < M else self.layers[slot // (M + 1)][2 * M][0].fn.heads
+                    stats_t[slot] = tf[so[slot]:so[slot] + b * heads * self.l_c * 2].view(b, heads, self.l_c, 2)
+                    trace_t[slot] = tf[xo[slot]:xo[slot] + b * self.l_c * self.l_d].view(b, self.l_c, self.l_d)
+            self._last_tape = None
         else:
             _capi.check(lib.hn_fusion_forward(C.byref(model), inputs, b, _ptr(mask_u8), int(bool(verbose)), int(embeddings),
                                               out.data_ptr(), stats_ptrs, x_ptrs, ws.data_ptr(), ws.numel(),

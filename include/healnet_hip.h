@@ -283,6 +283,13 @@ typedef struct hn_model_grads {
 } hn_model_grads;
 
 size_t hn_fusion_tape_bytes(const hn_model *model, const hn_modality_input *inputs, int b, int masked, int skip_self_on_missing);
+/* Where the tape of hn_fusion_forward_train keeps what hn_attn_probs needs, as FLOAT offsets from the tape base, one
+ * entry per attention slot (layer * (M + 1) + modality, M = the layer's latent self-attention; (size_t)-1: block not
+ * executed): stats_off -> the (b, heads, l_c, 2) softmax statistics, x_off -> the (b, l_c, l_d) latent array the block
+ * read.  Lets a host expose Attention.attn_weights (healnet.py:420) after a training forward without copying either
+ * out (pass attn_stats = x_trace = NULL to hn_fusion_forward_train). */
+int hn_fusion_tape_layout(const hn_model *model, const hn_modality_input *inputs, int b, int masked, int skip_self_on_missing,
+                          size_t *stats_off, size_t *x_off);
 int hn_fusion_forward_train(const hn_model *model, const hn_modality_input *inputs, int b, const uint8_t *mask,
                             int skip_self_on_missing, int return_embeddings, float *out, float **attn_stats,
                             float **x_trace, void *tape, size_t tape_bytes, void *workspace, size_t workspace_bytes,
