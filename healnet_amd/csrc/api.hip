@@ -386,7 +386,8 @@ static GemmExArgs gex(const float *A, long a_rs, long a_cs, const float *B, long
 
 static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float *x_out, int residual, const float *ctx,
                          int ld_ctx, int b, int L, int N, int D, const uint8_t *mask, const float *stats, const float *saved,
-                         const float *dy, float *dx, const hn_attn_grads *g, void *ws, size_t ws_bytes, hipStream_t s) {
+                         const float *dy, float *dx, const hn_attn_grads *g, void *ws, size_t ws_bytes, hipStream_t s,
+                         int ctx_pack_ks = 0) {
   HN_REQUIRE(p && x_in && x_out && stats && saved && dy && dx && g, HN_E_NULL, "attn_bwd: NULL pointer");
   HN_REQUIRE(p->w_q && p->w_kv && p->w_out, HN_E_NULL, "attn_bwd: weight pointer is NULL");
   const bool has_ctx = ctx != nullptr;
@@ -455,7 +456,9 @@ static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float
   // ---- recompute the operands of the core (scaled Q, and K/V or the folded queries)
   AttnCoreArgs core;
   float *kv_saved = saved_kv(pl, has_ctx, general, b, L, const_cast<float *>(saved));
-  if ((rc = attn_prepare(p, pl, x_in, ctx, ld_ctx, b, L, s, &core, 0, kv_saved, kv_saved != nullptr)) != HN_OK) return rc;
+  // packed shared context (the training forward's layout when nothing is dropped): folded queries, dO' and dQ'' in slot order
+  const int pack_ks = (pl.rank_d && pl.ones && p->ctx_gamma && !dropping) ? ctx_pack_ks : 0;
+  if ((rc = attn_prepare(p, pl, x_in, ctx, ld_ctx, b, L, s, &core, pack_ks, kv_saved, kv_saved != nullptr)) != HN_OK) return rc;
   const float *xhat = x_in;
   if (p->norm_w) {
     if ((rc = launch_ln_fwd(x_in, p->norm_w, p->norm_b, rows, qd, bp.xhat, s)) != HN_OK) return rc;
@@ -506,9 +509,12 @@ static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float
     if (rc != HN_OK) return rc;
     if ((rc = launch_rowdot_heads(bp.dOp, hp, pl.dp, saved, hp, pl.dp, h, L, srow ? pl.dp : pl.D, rows, bp.delta, s)) != HN_OK) return rc;
     ba.dO = bp.dOp; ba.do_b = (long)L * hp; ba.do_h = pl.dp; ba.lddo = hp;
+    ba.qk_steps = pack_ks;
+    if (pack_ks && (rc = launch_pack_fold(bp.dOp, hp, h, pl.D, pl.dp, pack_ks, 0, rows, s)) != HN_OK) return rc;
     if ((rc = launch_attn_bwd_dq(ba, s)) != HN_OK) return rc;
     // dQacc (rows, h*dp) = sum over splits; folded-query chain  Qf = c * gamma * T,  T = Q_h W_k,h
     if ((rc = launch_dq_reduce(bp.dQpart, pl.nsplit_bwd, b, h, L, pl.Lp, pl.dp, pl.dp, 1.0f, bp.E, hp, pl.dp, s)) != HN_OK) return rc;
+    if (pack_ks && (rc = launch_pack_fold(bp.E, hp, h, pl.D, pl.dp, pack_ks, 1, rows, s)) != HN_OK) return rc;
     { int rc_ = launch_fill(bp.T, 0.0f, (long)((size_t)rows * hp), s); if (rc_ != HN_OK) return rc_; }
     {   // T = Qraw_h W_k,h   (Qraw = x_hat W_q^T lives in pl.q after attn_prepare)
       GemmExArgs e = gex(pl.q, inner, 1, wk, 1, pl.D, bp.T, hp, rows, pl.D, dh, 0);
@@ -757,7 +763,17 @@ static int plan_fusion(const hn_model *m, const hn_modality_input *in, int b, vo
     fp->D[i] = m->channel_dims[i] + (m->fourier_encode_data ? axes * (2 * m->num_freq_bands + 1) : 0);
     const hn_attn_params *ap = &m->cross_attn[i];
     fp->ldz[i] = context_pitch(fp->D[i], ap->dim_head);
-    fp->ones[i] = (fp->ldz[i] == 16 || fp->ldz[i] == 32) && fp->D[i] <= fp->ldz[i] - 1;
+    // ones column / packed channel order: only for the shared-context (rank-D) binding, where the core reads z itself; the
+    // explicit binding projects z through to_kv and needs the natural layout (the pitch alone does not tell: D = 29 with
+    // dim_head = 4 gets pitch 32 from the 4-float rounding)
+    // (and never for a one-token context: its shortcut runs z through the value projection in natural order)
+    fp->ones[i] = n > 1 && (fp->ldz[i] == 16 || fp->ldz[i] == 32) && fp->D[i] <= fp->ldz[i] - 1;
+    for (int layer = 0; layer < m->depth && fp->ones[i]; ++layer) {
+      AttnPlan pl;
+      int rc = plan_attn(&m->cross_attn[layer * m->n_modalities + i], true, fp->ldz[i], b, m->l_c, (int)n, fp->D[i], nullptr, 0, &pl, 0);
+      if (rc != HN_OK) return rc;
+      fp->ones[i] = pl.rank_d && pl.ones;
+    }
     fp->pack[i] = fp->ones[i] ? packed_steps(fp->D[i], fp->ldz[i]) : 0;
     // One workspace size serves the inference forward (which may use the bf16 core) and the training forward / backward
     // (always fp32) of the same model: size for the larger of the two layouts.
@@ -1189,6 +1205,26 @@ size_t hn_fusion_tape_bytes(const hn_model *m, const hn_modality_input *in, int 
   return align_up(tp.floats * sizeof(float), 256);
 }
 
+}  // extern "C"
+
+// Context layout of the training forward / backward: the ones column and the packed channel order of the inference forward
+// whenever none of the modality's cross-attention blocks drops probabilities (dropout needs column dp-1 for the row-sum
+// channel and the explicit denominator).
+static void train_context_layout(const hn_model *m, const FusionPlan &fp, bool *ones, int *pack) {
+  for (int i = 0; i < m->n_modalities; ++i) {
+    bool dropping = false, affine = true;
+    for (int layer = 0; layer < m->depth; ++layer) {
+      const hn_attn_params &ap = m->cross_attn[layer * m->n_modalities + i];
+      dropping = dropping || ap.dropout > 0.0f;
+      affine = affine && ap.ctx_gamma != nullptr;
+    }
+    ones[i] = fp.z[i] != nullptr && fp.ones[i] && !dropping && affine;
+    pack[i] = ones[i] ? fp.pack[i] : 0;
+  }
+}
+
+extern "C" {
+
 int hn_fusion_tape_layout(const hn_model *m, const hn_modality_input *in, int b, int masked, int skip_self_on_missing,
                           size_t *stats_off, size_t *x_off) {
   HN_REQUIRE(stats_off && x_off, HN_E_NULL, "fusion_tape_layout: NULL output");
@@ -1225,10 +1261,13 @@ int hn_fusion_forward_train(const hn_model *m, const hn_modality_input *in, int 
              "fusion_forward_train: tape %zu bytes < required %zu (256-byte aligned)", tape_bytes, tp.floats * sizeof(float));
   float *T = (float *)tape;
   const int M = m->n_modalities, L = m->l_c, d = m->l_d;
+  bool tones[16]; int tpack[16];
+  train_context_layout(m, fp, tones, tpack);
   for (int i = 0; i < M; ++i) {
     if (!in[i].data) continue;
     if ((rc = launch_encode(in[i].data, in[i].dtype, b, m->num_spatial_axes[i], in[i].spatial, m->channel_dims[i], m->num_freq_bands,
-                            m->max_freq, m->fourier_encode_data, 1, 1e-5f, fp.z[i], fp.ldz[i], s)) != HN_OK)
+                            m->max_freq, m->fourier_encode_data, 1, 1e-5f, fp.z[i], fp.ldz[i], s, tones[i] ? fp.ldz[i] - 1 : -1,
+                            tpack[i])) != HN_OK)
       return rc;
   }
   if ((rc = launch_broadcast_rows(m->latents, T + tp.x_off[0], (long)L * d, b, s)) != HN_OK) return rc;
@@ -1243,7 +1282,8 @@ int hn_fusion_forward_train(const hn_model *m, const hn_modality_input *in, int 
         hn_attn_params ap = m->cross_attn[st.layer * M + st.m];
         ap.rng = rng;
         rc = attn_fwd_impl(&ap, xin, xout, 1, fp.z[st.m], fp.ldz[st.m], b, L, fp.N[st.m], fp.D[st.m],
-                           mask, T + tp.stats_off[k], fp.op_ws, fp.op_ws_bytes, s, nullptr, nullptr, T + tp.saved_off[k]);
+                           mask, T + tp.stats_off[k], fp.op_ws, fp.op_ws_bytes, s, nullptr, nullptr, T + tp.saved_off[k],
+                           tones[st.m], tpack[st.m]);
         break;
       }
       case STEP_SELF_ATTN: {
@@ -1304,10 +1344,13 @@ int hn_fusion_backward(const hn_model *m, const hn_modality_input *in, int b, co
   const float *T = (const float *)tape;
   const int M = m->n_modalities, L = m->l_c, d = m->l_d;
   const size_t xn = (size_t)b * L * d;
+  bool tones[16]; int tpack[16];
+  train_context_layout(m, fp, tones, tpack);
   for (int i = 0; i < M; ++i) {     // the normalised contexts are recomputed (one HBM pass) rather than kept on the tape
     if (!in[i].data) continue;
     if ((rc = launch_encode(in[i].data, in[i].dtype, b, m->num_spatial_axes[i], in[i].spatial, m->channel_dims[i], m->num_freq_bands,
-                            m->max_freq, m->fourier_encode_data, 1, 1e-5f, fp.z[i], fp.ldz[i], s)) != HN_OK)
+                            m->max_freq, m->fourier_encode_data, 1, 1e-5f, fp.z[i], fp.ldz[i], s, tones[i] ? fp.ldz[i] - 1 : -1,
+                            tpack[i])) != HN_OK)
       return rc;
   }
   const float *xf = T + tp.x_off[tp.nsteps];
@@ -1329,7 +1372,7 @@ int hn_fusion_backward(const hn_model *m, const hn_modality_input *in, int b, co
         ap.rng = rng;
         rc = attn_bwd_impl(&ap, xin, xout, 1, fp.z[st.m], fp.ldz[st.m], b, L, fp.N[st.m], fp.D[st.m],
                            mask, T + tp.stats_off[k], T + tp.saved_off[k], dX, dX, g->cross_attn ? &g->cross_attn[st.layer * M + st.m] : &no_attn,
-                           op, opb, s);
+                           op, opb, s, tpack[st.m]);
         break;
       }
       case STEP_SELF_ATTN: {

@@ -574,7 +574,7 @@ __global__ __launch_bounds__(256) void merge_vproj_kernel(const float *__restric
     float v = 0.0f;
     if (q < L && (d < dlim || (srow && d == dp - 1)))        // srow: column dp-1 carries the dropped row sum (see attn_core)
       v = merged_value(mw, Opart, Mpart, pbase, nsplit, Lp, dp, qq, q, d);
-    if (oprime_save && q < L) oprime_save[((long)bi * L + q) * (h * dp) + hi * dp + d] = v;   // training: normalised P z, padding columns 0
+    if (oprime_save && !pack_ks && q < L) oprime_save[((long)bi * L + q) * (h * dp) + hi * dp + d] = v;   // training: normalised P z, padding columns 0
     oh[qq * (dp + 1) + d] = v;
   }
   for (int idx = threadIdx.x; idx < dh * (dp + 1); idx += blockDim.x) {
@@ -593,6 +593,18 @@ __global__ __launch_bounds__(256) void merge_vproj_kernel(const float *__restric
     wv[idx] = w;
   }
   __syncthreads();
+  if (oprime_save && pack_ks) {     // the tape keeps the natural channel layout: kept channels from their slots, the dropped one = -sum
+    for (int idx = threadIdx.x; idx < MERGE_ROWS * dp; idx += blockDim.x) {
+      const int qq = idx / dp, c = idx % dp, q = q0 + qq;
+      if (q >= L) continue;
+      float v = 0.0f;
+      if (c < D - 1) v = oh[qq * (dp + 1) + packed_slot(c, pack_ks)];
+      else if (c == D - 1) {
+        for (int k = 0; k < D - 1; ++k) v -= oh[qq * (dp + 1) + packed_slot(k, pack_ks)];
+      }
+      oprime_save[((long)bi * L + q) * (h * dp) + hi * dp + c] = v;
+    }
+  }
   for (int idx = threadIdx.x; idx < MERGE_ROWS * dh; idx += blockDim.x) {
     const int qq = idx / dh, e = idx % dh, q = q0 + qq;
     if (q >= L) continue;
@@ -606,7 +618,7 @@ int launch_merge_vproj(const float *Opart, const float *Mpart, const float *Lpar
                        int Lp, int dp, int D, const float *gamma, const float *beta, const float *w_v, int dh,
                        float *O, int ldo, float *stats, float *oprime_save, hipStream_t s, int pack_ks, int srow) {
   size_t lds = ((size_t)MERGE_ROWS * (dp + 1) + (size_t)dh * (dp + 1)) * sizeof(float);
-  HN_REQUIRE(!(pack_ks && oprime_save), HN_E_SHAPE, "merge_vproj: the training tape keeps the natural channel layout");
+  HN_REQUIRE(!(pack_ks && srow), HN_E_SHAPE, "merge_vproj: the row-sum channel needs the natural channel layout");
   hipLaunchKernelGGL(merge_vproj_kernel, dim3(b * h, ceil_div(L, MERGE_ROWS)), dim3(256), lds, s, Opart, Mpart, Lpart,
                      nsplit, h, L, Lp, dp, D, gamma, beta, w_v, dh, O, ldo, stats, oprime_save, pack_ks, srow);
   HN_LAUNCH_CHECK("merge_vproj");

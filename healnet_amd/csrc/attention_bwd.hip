@@ -24,9 +24,12 @@ __device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(
 // scores of query row j for tokens 4 g + r;  dP^T = V dO^T has the same shape with the dO fragment in the place of
 // the Q fragment;  dQ += dS K uses dS straight from registers as the A operand and K rows 4 g + r as B.
 // ------------------------------------------------------------------------------------------------
-template <int DT, int NQ, bool SHARED_KV, bool DROP = false>
+// KS > 0: packed context (common.h packed_slot) -- the channel contractions of S and dP run KS steps instead of 4 DT, the last
+// 16-column block only its first KS - 4 (DT - 1) k-steps (the skipped ones hold unused columns and the ones column).
+template <int DT, int NQ, bool SHARED_KV, bool DROP = false, int KS = 0>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a, int ngroups, int gy, int waves_per_block) {
   constexpr int DP = 16 * DT;
+  constexpr int LAST = KS > 0 ? KS - 4 * (DT - 1) : 4;     // k-steps of the last 16-column block
   const int L = a.Lq;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, j = lane & 15;
@@ -101,25 +104,32 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a, int ngr
     for (int s = 0; s < DT; ++s) {
       float4 vv = SHARED_KV ? kf[s] : vf[s];
       if (DROP && SHARED_KV && s == DT - 1 && a.drop_rowsum && g == 3) vv.w = 1.0f;      // the values' ones column dp-1 (row-sum channel)
+      const int steps = s == DT - 1 ? LAST : 4;
 #pragma unroll
       for (int i = 0; i < NQ; ++i) {
         S[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].x, qf[i][s].x, S[i], 0, 0, 0);
         dP[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.x, gf[i][s].x, dP[i], 0, 0, 0);
       }
+      if (steps > 1) {
 #pragma unroll
-      for (int i = 0; i < NQ; ++i) {
-        S[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].y, qf[i][s].y, S[i], 0, 0, 0);
-        dP[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.y, gf[i][s].y, dP[i], 0, 0, 0);
+        for (int i = 0; i < NQ; ++i) {
+          S[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].y, qf[i][s].y, S[i], 0, 0, 0);
+          dP[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.y, gf[i][s].y, dP[i], 0, 0, 0);
+        }
       }
+      if (steps > 2) {
 #pragma unroll
-      for (int i = 0; i < NQ; ++i) {
-        S[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].z, qf[i][s].z, S[i], 0, 0, 0);
-        dP[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.z, gf[i][s].z, dP[i], 0, 0, 0);
+        for (int i = 0; i < NQ; ++i) {
+          S[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].z, qf[i][s].z, S[i], 0, 0, 0);
+          dP[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.z, gf[i][s].z, dP[i], 0, 0, 0);
+        }
       }
+      if (steps > 3) {
 #pragma unroll
-      for (int i = 0; i < NQ; ++i) {
-        S[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].w, qf[i][s].w, S[i], 0, 0, 0);
-        dP[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.w, gf[i][s].w, dP[i], 0, 0, 0);
+        for (int i = 0; i < NQ; ++i) {
+          S[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].w, qf[i][s].w, S[i], 0, 0, 0);
+          dP[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.w, gf[i][s].w, dP[i], 0, 0, 0);
+        }
       }
     }
     if (DROP) {   // O = (P * d) V with the forward's keep/scale factors d:  dP <- d * (dO V^T) - D
@@ -189,12 +199,28 @@ int launch_attn_bwd_dq(const AttnBwdArgs &a, hipStream_t s) {
   else if (shared) hipLaunchKernelGGL((attn_bwd_dq_kernel<DT_, NQ_, true, false>), grid, block, 0, s, a, ngroups, gy, wpb);      \
   else if (drop) hipLaunchKernelGGL((attn_bwd_dq_kernel<DT_, NQ_, false, true>), grid, block, 0, s, a, ngroups, gy, wpb);        \
   else hipLaunchKernelGGL((attn_bwd_dq_kernel<DT_, NQ_, false, false>), grid, block, 0, s, a, ngroups, gy, wpb);
+#define HN_DQ_PACKED(DT_, NQ_, KS_) hipLaunchKernelGGL((attn_bwd_dq_kernel<DT_, NQ_, true, false, KS_>), grid, block, 0, s, a, ngroups, gy, wpb)
+  if (a.qk_steps > 0) {     // packed shared context (rank-D binding without dropout)
+    HN_REQUIRE(shared && !drop && (dt == 1 || dt == 2) && a.qk_steps > 4 * (dt - 1) && a.qk_steps < 4 * dt, HN_E_SHAPE,
+               "attn_bwd_dq: qk_steps=%d dp=%d", a.qk_steps, a.dp);
+    switch (a.qk_steps) {
+      case 1: HN_DQ_PACKED(1, 4, 1); break;
+      case 2: HN_DQ_PACKED(1, 4, 2); break;
+      case 3: HN_DQ_PACKED(1, 4, 3); break;
+      case 5: HN_DQ_PACKED(2, 2, 5); break;
+      case 6: HN_DQ_PACKED(2, 2, 6); break;
+      default: HN_DQ_PACKED(2, 2, 7); break;
+    }
+    HN_LAUNCH_CHECK("attn_bwd_dq(packed)");
+    return HN_OK;
+  }
   switch (dt) {
     case 1: HN_DQ(1, 4) break;
     case 2: HN_DQ(2, 2) break;
     case 4: HN_DQ(4, 2) break;
     default: HN_DQ(8, 1) break;
   }
+#undef HN_DQ_PACKED
 #undef HN_DQ
   HN_LAUNCH_CHECK("attn_bwd_dq");
   return HN_OK;
@@ -399,6 +425,45 @@ int launch_head_affine(const float *src, int lds, int spitch, const float *mul, 
   hipLaunchKernelGGL(head_affine_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, lds, spitch, mul, ldm, mpitch, colscale, coladd,
                      scale, h, width, dpitch, ldd, rows, dst);
   HN_LAUNCH_CHECK("head_affine");
+  return HN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Packed shared context (common.h packed_slot): the token side stores D - 1 channels, the dropped one being minus their sum
+// (LayerNorm rows sum to zero).  For any row vector u contracted with a context row z:
+//     u . z = sum_{c < D-1} (u_c - u_{D-1}) z_c                       -> fold (mode 0): natural -> packed operand
+// and a gradient w.r.t. the packed operand goes back to the natural one as
+//     du_c = dup_{slot(c)}  (c < D-1),   du_{D-1} = - sum_c dup_{slot(c)}   -> unfold (mode 1): packed -> natural
+// One thread per (row, head), in place, (rows, h, dp) head-pitched.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_fold_kernel(float *__restrict__ x, int ld, int h, int D, int dp, int ks, int mode, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  float *row = x + (i / h) * ld + (i % h) * dp;
+  float v[32];                      // dp <= 32 on this path
+  for (int c = 0; c < dp; ++c) v[c] = row[c];
+  if (mode == 0) {
+    const float last = v[D - 1];
+    for (int sl = 0; sl < dp; ++sl) {
+      const int c = packed_chan(sl, ks);
+      row[sl] = (c >= 0 && c < D - 1) ? v[c] - last : 0.0f;
+    }
+  } else {
+    float sum = 0.0f;
+    for (int c = 0; c < dp; ++c) {   // channels in order: every kept one is in `sum` when c reaches D - 1
+      float o = 0.0f;
+      if (c < D - 1) { o = v[packed_slot(c, ks)]; sum += o; }
+      else if (c == D - 1) o = -sum;
+      row[c] = o;
+    }
+  }
+}
+
+int launch_pack_fold(float *x, int ld, int h, int D, int dp, int ks, int mode, long rows, hipStream_t s) {
+  HN_REQUIRE(dp <= 32 && ks > 0 && D >= 2 && D <= dp - 1, HN_E_SHAPE, "pack_fold: D=%d dp=%d ks=%d", D, dp, ks);
+  const long total = rows * h;
+  hipLaunchKernelGGL(pack_fold_kernel, dim3((unsigned)ceil_div_ll(total, 256)), dim3(256), 0, s, x, ld, h, D, dp, ks, mode, total);
+  HN_LAUNCH_CHECK("pack_fold");
   return HN_OK;
 }
 

@@ -313,7 +313,9 @@ struct AttnBwdArgs {
   int b, h, Lq, Lp, N, dp, nsplit, chunk;
   DropCfg drop;                                  // the forward's dropout on the probabilities (thr == 0: off)
   int drop_rowsum;                               // shared-context binding under dropout: V carries a ones column dp-1
+  int qk_steps;                                  // > 0: packed shared context, k-steps of the channel contractions (see attn_core)
 };
+int launch_pack_fold(float *x, int ld, int h, int D, int dp, int ks, int mode, long rows, hipStream_t s);
 int launch_attn_bwd_dq(const AttnBwdArgs &a, hipStream_t s);
 int launch_dq_reduce(const float *part, int nsplit, int b, int h, int L, int Lp, int dp, int width, float scale, float *out,
                      int ld_out, int head_pitch, hipStream_t s);

@@ -212,11 +212,26 @@ def manifest_():
         return json.load(f)
 
 
-@pytest.mark.parametrize("cfg", ["cfg1_b2", "cfg4_b2", "missing"])
+PACKED = {   # packed shared-context layouts of the training path: (channels, spatial shape, cross_dim_head) -> D, k-steps
+    "packed_ks1": (4, (9,), 16, dict(fourier_encode_data=False)),   # D = 4 -> ks = 1
+    "packed_ks2": (2, (40,), 64),         # D = 7  -> ks = 2
+    "packed_ks5": (3, (3, 4, 5), 32),     # D = 18 -> dp = 32, ks = 5 (the volume modality)
+    "packed_ks6": (9, (4, 3, 2), 32),     # D = 24 -> ks = 6
+    "packed_ks7": (22, (11,), 32),        # D = 27 -> ks = 7
+    "natural_d16": (11, (6,), 16),        # D = 16 == dp: no free column, natural layout, synthetic ones column
+}
+
+
+@pytest.mark.parametrize("cfg", ["cfg1_b2", "cfg4_b2", "missing"] + sorted(PACKED))
 def test_model_gradients_vs_oracle_autograd(cfg):
     import healnet_amd as hn
     gen = torch.Generator().manual_seed(31)
-    if cfg == "cfg1_b2":
+    if cfg in PACKED:
+        chan, shape, dh = PACKED[cfg][:3]
+        kw = dict(n_modalities=2, channel_dims=[5, chan], num_spatial_axes=[1, len(shape)], out_dims=3, depth=2, l_c=24, l_d=32,
+                  x_heads=2, l_heads=2, cross_dim_head=dh, latent_dim_head=8, **(PACKED[cfg][3] if len(PACKED[cfg]) > 3 else {}))
+        ins = [torch.rand(3, 2, 5, generator=gen), torch.rand(3, *shape, chan, generator=gen)]
+    elif cfg == "cfg1_b2":
         kw = dict(n_modalities=2, channel_dims=[2000, 3], num_spatial_axes=[1, 2], out_dims=4, depth=2)
         ins = [torch.rand(2, 1, 2000, generator=gen), torch.rand(2, 48, 40, 3, generator=gen)]
     elif cfg == "cfg4_b2":

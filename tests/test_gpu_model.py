@@ -17,6 +17,15 @@ def hn():
     return healnet_amd
 
 
+@pytest.fixture(autouse=True, params=["inference", "taping"])
+def forward_path(request):
+    """Every test of this module runs twice: under torch.no_grad() -> hn_fusion_forward (the inference forward bench.py
+    measures: ones column, packed context, score-bound softmax, chained trace buffers) and with grad mode on ->
+    hn_fusion_forward_train (the tape-recording forward autograd uses, parameters require grad)."""
+    with torch.set_grad_enabled(request.param == "taping"):
+        yield request.param
+
+
 G5 = ["m1_d1", "m2_d3", "m3_d3", "m2_d3_tied", "m2_d2_noself", "m2_d2_nofourier", "m2_d2_gelu", "m2_d2_nohead",
       "m2_d2_bands4", "m2_d2_masked"]
 
@@ -239,3 +248,28 @@ def test_attention_importance_masked_and_standalone(hn):
     assert_close(a, w.mean(dim=1), rel=1e-5, floor=1e-6, what="standalone importance")
     assert float(a[~mask.repeat_interleave(2, dim=0)].abs().max()) == 0.0
     assert_close(a.sum(-1), torch.ones(6, device=DEV), rel=1e-5, what="rows of a softmax average to a distribution")
+
+
+@pytest.mark.parametrize("chan,axes_shape,dim_head", [
+    (6, (1,), 8),        # one-token context with D = 11 <= 15: rank-D pitch 16, but the one-token shortcut (natural channel order)
+    (6, (3,), 8),        # same D with 3 tokens: packed rank-D core
+    (20, (1,), 4),       # D = 29 -> pitch 32 from the 4-float rounding with dim_head 4: explicit binding, natural order
+    (20, (5,), 4),
+    (3, (6, 5), 4),      # D = 13, dim_head 4 (padded to 16): rank-D with dp == padded head dim
+    (3, (6, 5), 64),     # the default image block at a tiny size
+    (9, (4, 3, 2), 16),  # volume, D = 9 + 15 = 24 -> dp = 32 > padded head 16: explicit
+    (9, (4, 3, 2), 32),  # ... and the packed dp = 32 rank-D core (ks = 6)
+    (1, (7,), 64),       # D = 6: ks = 2
+    (2, (40,), 64),      # D = 7: ks = 2
+])
+def test_context_layout_corner_cases_vs_oracle(hn, chan, axes_shape, dim_head):
+    """Which context layout a modality gets (ones column, packed channels, natural) depends on D, the head dim and the
+    token count; every combination must give the oracle's logits on BOTH forwards (see forward_path)."""
+    kw = dict(n_modalities=2, channel_dims=[5, chan], num_spatial_axes=[1, len(axes_shape)], out_dims=3, depth=2, l_c=8, l_d=16,
+              x_heads=2, l_heads=2, cross_dim_head=dim_head, latent_dim_head=8)
+    torch.manual_seed(chan * 100 + dim_head)
+    model = hn.HealNet(**kw).eval().to(DEV)
+    gen = torch.Generator().manual_seed(9)
+    ins = [torch.rand(3, 2, 5, generator=gen).to(DEV), torch.rand(3, *axes_shape, chan, generator=gen).to(DEV)]
+    y = model(list(ins))
+    assert_close(y.cpu(), _oracle_logits(model, kw, ins), rel=2e-4, what=f"layout chan={chan} axes={axes_shape} dh={dim_head}")
