@@ -96,8 +96,14 @@ __global__ __launch_bounds__(256) void gemm_ex_kernel(GemmExArgs g) {
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ part, int nsplit, long mn, int N, float *__restrict__ C,
                                                             long ldc, int accumulate) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < mn; i += (long)gridDim.x * blockDim.x) {
-    float acc = 0.0f;
-    for (int k = 0; k < nsplit; ++k) acc += part[(long)k * mn + i];
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;     // four independent chains (loads in flight), fixed order -> deterministic
+    int k = 0;
+    for (; k + 4 <= nsplit; k += 4) {
+      a0 += part[(long)k * mn + i]; a1 += part[(long)(k + 1) * mn + i];
+      a2 += part[(long)(k + 2) * mn + i]; a3 += part[(long)(k + 3) * mn + i];
+    }
+    for (; k < nsplit; ++k) a0 += part[(long)k * mn + i];
+    const float acc = (a0 + a1) + (a2 + a3);
     float *dst = C + (i / N) * ldc + (i % N);
     *dst = accumulate ? *dst + acc : acc;
   }
@@ -123,6 +129,7 @@ struct GemmTnArgs {
   int batch; long strideA, strideB, strideC; // independent products (per-head weight gradients); grid.z = batch * nsplit
 };
 
+template <int UN>      // k-pairs in flight: 16 for short slices (latency decides), 4 for long ones (occupancy decides)
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs g) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m0 = blockIdx.x * 128 + (wave >> 1) * 64, n0 = blockIdx.y * 128 + (wave & 1) * 64;
@@ -153,7 +160,6 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs g) {
   f32x16 accs[2];
   accs[0] = accs[1] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
-  constexpr int UN = 4;                      // k-pairs in flight
   const int npairs = (rows + 1) / 2;
   const int sa = (int)(2 * g.lda * 4), sb = (int)(2 * g.ldb * 4);
   float a[UN][2], b[UN][2];
@@ -225,8 +231,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_alpha_kernel(const float *_
   part += (long)blockIdx.y * nsplit * mn;          // blockIdx.y: batch entry
   C += blockIdx.y * strideC;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < mn; i += (long)gridDim.x * blockDim.x) {
-    float acc = 0.0f;
-    for (int k = 0; k < nsplit; ++k) acc += part[(long)k * mn + i];
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;     // four independent chains (loads in flight), fixed order -> deterministic
+    int k = 0;
+    for (; k + 4 <= nsplit; k += 4) {
+      a0 += part[(long)k * mn + i]; a1 += part[(long)(k + 1) * mn + i];
+      a2 += part[(long)(k + 2) * mn + i]; a3 += part[(long)(k + 3) * mn + i];
+    }
+    for (; k < nsplit; ++k) a0 += part[(long)k * mn + i];
+    const float acc = (a0 + a1) + (a2 + a3);
     float *dst = C + (i / N) * ldc + (i % N);
     *dst = accumulate ? *dst + alpha * acc : alpha * acc;
   }
@@ -264,7 +276,8 @@ static int launch_gemm_tn(const float *A, long lda, const float *B, long ldb, fl
   g.batch = batch; g.strideA = strideA; g.strideB = strideB; g.strideC = strideC;
   HN_REQUIRE((long)g.nsplit * batch <= 65535, HN_E_UNSUPPORTED, "gemm_tn: batch=%d", batch);
   if (g.nsplit > 1) { g.C = scratch; g.ldc = N; if (colsum) g.colsum = scratch + (size_t)g.nsplit * M * N; } else { g.C = C; g.ldc = ldc; }
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3(ceil_div(M, 128), ceil_div(N, 128), g.nsplit * batch), dim3(256), 0, s, g);
+  if (g.kslice <= 512) hipLaunchKernelGGL(gemm_tn_kernel<16>, dim3(ceil_div(M, 128), ceil_div(N, 128), g.nsplit * batch), dim3(256), 0, s, g);
+  else hipLaunchKernelGGL(gemm_tn_kernel<4>, dim3(ceil_div(M, 128), ceil_div(N, 128), g.nsplit * batch), dim3(256), 0, s, g);
   HN_LAUNCH_CHECK("gemm_tn");
   if (g.nsplit > 1) {
     const long mn = (long)M * N;
@@ -497,17 +510,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ x
 }
 
 // dgamma[c] += sum_blocks partial[., c] ; dbeta[c] += sum_blocks partial[., d + c]  -- one launch for both (fixed order)
-__global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float *__restrict__ partial, int blocks, int d,
+__global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float *__restrict__ partial, int blocks, int d,
                                                               float *__restrict__ dgamma, float *__restrict__ dbeta) {
-  __shared__ float part[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+  __shared__ float part[16][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;      // 16 waves share the partial rows
   float s = 0.0f;
-  if (c < 2 * d)
-    for (int r = w; r < blocks; r += 4) s += partial[(long)r * 2 * d + c];
+  if (c < 2 * d) {
+#pragma unroll 4
+    for (int r = w; r < blocks; r += 16) s += partial[(long)r * 2 * d + c];
+  }
   part[w][threadIdx.x & 63] = s;
   __syncthreads();
   if (w == 0 && c < 2 * d) {
-    const float v = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+    float v = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v += part[k][threadIdx.x];
     if (c < d) { if (dgamma) dgamma[c] += v; }
     else if (dbeta) dbeta[c - d] += v;
   }
@@ -530,7 +547,7 @@ int launch_ln_bwd(const float *x, const float *dy, const float *gamma, long rows
 #undef HN_LN_BWD
   HN_LAUNCH_CHECK("ln_bwd");
   if (dgamma || dbeta) {
-    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(ceil_div(2 * d, 64)), dim3(256), 0, s, scratch, blocks, d, dgamma, dbeta);
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(ceil_div(2 * d, 64)), dim3(1024), 0, s, scratch, blocks, d, dgamma, dbeta);
     HN_LAUNCH_CHECK("ln_param_reduce");
   }
   return HN_OK;
