@@ -63,16 +63,19 @@ _POISON = os.environ.get("HN_POISON_WS", "0") == "1"
 
 
 class _Workspace:
-    """One growing scratch allocation per device (the C ABI never allocates)."""
+    """One growing scratch allocation per (device, stream) (the C ABI never allocates).  Per stream, because calls on
+    different streams of one device may run concurrently (two micro-batches, a serving thread per stream) and must not
+    share scratch; calls on one stream are ordered, so they can."""
 
     def __init__(self) -> None:
-        self._buf: Dict[torch.device, torch.Tensor] = {}
+        self._buf: Dict[tuple, torch.Tensor] = {}
 
     def get(self, device: torch.device, nbytes: int) -> torch.Tensor:
-        buf = self._buf.get(device)
+        key = (device, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
+        buf = self._buf.get(key)
         if buf is None or buf.numel() < nbytes:
             buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
-            self._buf[device] = buf
+            self._buf[key] = buf
         if _POISON:      # development aid (HN_POISON_WS=1): every call starts from an all-NaN workspace, so a kernel that
             buf.fill_(0xFF)   # reads scratch it has not written shows up deterministically
         return buf
