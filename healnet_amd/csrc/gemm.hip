@@ -581,7 +581,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
   constexpr int SN = 4, SM = 32;
   __shared__ float part[4][SM * SN];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n0 = blockIdx.x * SN, z = blockIdx.z;
+  const int n0 = blockIdx.x * SN, z = blockIdx.z, m0 = blockIdx.y * SM;      // blockIdx.y: 32-row chunk (batches above 32 samples)
   const i32x4 rsA = make_rsrc(g.A + (long)z * g.strideA, rsrc_bytes(g.M, g.lda, g.K));
   const i32x4 rsW = make_rsrc(g.W + (long)z * g.strideW, rsrc_bytes(g.N, g.ldw, g.K));
   float acc[SM * SN];
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < SN; ++j) w[j] = hn_buffer_load_x1(rsW, ((n0 + j) * (int)g.ldw + kc) * 4, 0, 0);
 #pragma unroll
-    for (int m = 0; m < SM; ++m) av[m] = hn_buffer_load_x1(rsA, (m * (int)g.lda + kc) * 4, 0, 0);
+    for (int m = 0; m < SM; ++m) av[m] = hn_buffer_load_x1(rsA, ((m0 + m) * (int)g.lda + kc) * 4, 0, 0);
     float gam = 1.0f, bet = 0.0f;
     if (g.pro == PRO_AFFINE) { gam = g.gamma[kc]; bet = g.beta[kc]; }
     gam *= km;
@@ -617,7 +617,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
   part[wave][2 * lane + 1] = acc[1];
   __syncthreads();
   if (threadIdx.x < SM * SN) {
-    const int idx = threadIdx.x, m = idx / SN, n = n0 + idx % SN;
+    const int idx = threadIdx.x, m = m0 + idx / SN, n = n0 + idx % SN;
     if (m < g.M && n < g.N) {
       float v = g.alpha * (part[0][idx] + part[1][idx] + part[2][idx] + part[3][idx]);
       if (g.bias) v += g.bias[(long)z * g.strideBias + n];
@@ -647,8 +647,10 @@ int launch_gemm(const GemmArgs &g, hipStream_t s) {
   const long a_span = ((long)(g.M + 64) * g.lda) * 4, w_span = ((long)(g.N + (glu ? g.glu_offset : 0) + 64) * g.ldw) * 4;
   HN_REQUIRE(a_span < (1L << 31) && w_span < (1L << 31) && (long)(g.M + 64) * g.ldr * 4 < (1L << 31), HN_E_UNSUPPORTED,
              "gemm: an operand spans more than 2 GiB (M=%d lda=%ld N=%d ldw=%ld)", g.M, g.lda, g.N, g.ldw);
-  if (g.M <= 32 && !glu && g.pro != PRO_LAYERNORM && g.K >= 512) {
-    hipLaunchKernelGGL(gemm_skinny_kernel, dim3(ceil_div(g.N, 4), 1, g.batch), dim3(256), 0, s, g);
+  // M <= 32 always; up to 512 rows (32-row chunks re-stream the weight from L2) when the operands are not 16-byte aligned
+  // (K = 2005: the tile kernels do not apply and the generic one runs 8 workgroups -- 265 us at b = 64 against 2 x 9)
+  if ((g.M <= 32 || (g.M <= 512 && !aligned_eligible(g))) && !glu && g.pro != PRO_LAYERNORM && g.K >= 512) {
+    hipLaunchKernelGGL(gemm_skinny_kernel, dim3(ceil_div(g.N, 4), ceil_div(g.M, 32), g.batch), dim3(256), 0, s, g);
     HN_LAUNCH_CHECK("gemm_skinny");
     return HN_OK;
   }

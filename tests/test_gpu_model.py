@@ -273,3 +273,16 @@ def test_context_layout_corner_cases_vs_oracle(hn, chan, axes_shape, dim_head):
     ins = [torch.rand(3, 2, 5, generator=gen).to(DEV), torch.rand(3, *axes_shape, chan, generator=gen).to(DEV)]
     y = model(list(ins))
     assert_close(y.cpu(), _oracle_logits(model, kw, ins), rel=2e-4, what=f"layout chan={chan} axes={axes_shape} dh={dim_head}")
+
+
+def test_one_token_route_above_32_samples(hn):
+    """b > 32 takes the row-chunked form of the weight-streaming GEMV (the tabular K/V projection has K = 2005, which
+    no tile kernel accepts): every sample must equal its logits from a batch of 8."""
+    torch.manual_seed(6)
+    model = hn.HealNet(n_modalities=2, channel_dims=[2000, 3], num_spatial_axes=[1, 2], out_dims=4, depth=1).eval().to(DEV)
+    gen = torch.Generator().manual_seed(80)
+    for b in (33, 72):
+        tab, img = torch.rand(b, 1, 2000, generator=gen).to(DEV), torch.rand(b, 8, 8, 3, generator=gen).to(DEV)
+        y = model([tab, img])
+        y8 = torch.cat([model([tab[i:i + 8], img[i:i + 8]]) for i in range(0, b, 8)])
+        assert_close(y.detach().cpu(), y8.detach().cpu(), rel=1e-5, what=f"b={b} vs batches of 8")
