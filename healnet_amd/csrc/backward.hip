@@ -225,6 +225,126 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs g) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Long-slice form of the same product (the patch-bag G = dKV^T z: 1024 x 773, K = 32 768 rows per call): the direct kernel above
+// is bound by what a wave can keep in flight (4 dword loads per 4 MFMAs, no sharing between the 4 waves of a tile).  Here a
+// workgroup stages 16-row slabs of both operands through LDS with 16-byte loads (each element fetched once per tile instead
+// of twice), double-buffered, one barrier per slab (32 MFMAs per wave between barriers).  LDS pitch 160 floats: the two
+// half-waves of a 32x32x2 operand read rows k and k + 1, 160 mod 64 = 32 puts them on disjoint banks.
+// Needs 16-byte aligned operands (lda, ldb multiples of 4 floats).
+// ------------------------------------------------------------------------------------------------
+constexpr int TNL_BK = 16, TNL_PITCH = 160;
+
+__global__ __launch_bounds__(256) void gemm_tn_lds_kernel(GemmTnArgs g) {
+  __shared__ __attribute__((aligned(16))) float As[2][TNL_BK * TNL_PITCH];
+  __shared__ __attribute__((aligned(16))) float Bs[2][TNL_BK * TNL_PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bm0 = blockIdx.x * 128, bn0 = blockIdx.y * 128;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int z = blockIdx.z % g.nsplit, bt = blockIdx.z / g.nsplit;
+  g.A += bt * g.strideA;
+  g.B += bt * g.strideB;
+  const int k_begin = z * g.kslice, k_end = min(g.K, k_begin + g.kslice);
+  const int rows = k_end - k_begin;
+  const int half = lane >> 5, col = lane & 31;
+  const i32x4 ars = make_rsrc(g.A + (long)k_begin * g.lda, rows > 0 ? (unsigned)(((long)(rows - 1) * g.lda + g.M) * 4) : 0u);
+  const i32x4 brs = make_rsrc(g.B + (long)k_begin * g.ldb, rows > 0 ? (unsigned)(((long)(rows - 1) * g.ldb + g.N) * 4) : 0u);
+  // loader: thread -> slab rows lr and lr + 8, 4 consecutive columns lc .. lc + 3
+  const int lr = tid >> 5, lc = (tid & 31) * 4;
+  const int am = bm0 + lc, bn = bn0 + lc;
+  const int aoff = (int)(((long)lr * g.lda + am) * 4), boff = (int)(((long)lr * g.ldb + bn) * 4);
+  const int astep = (int)(8 * g.lda * 4), bstep = (int)(8 * g.ldb * 4);
+  const int aslab = (int)(TNL_BK * g.lda * 4), bslab = (int)(TNL_BK * g.ldb * 4);
+  // columns past M / N inside a row would read the next row: masked in registers (whole-float4 granularity is not enough)
+  const float am0 = am + 0 < g.M ? 1.f : 0.f, am1 = am + 1 < g.M ? 1.f : 0.f, am2 = am + 2 < g.M ? 1.f : 0.f, am3 = am + 3 < g.M ? 1.f : 0.f;
+  const float bn0m = bn + 0 < g.N ? 1.f : 0.f, bn1m = bn + 1 < g.N ? 1.f : 0.f, bn2m = bn + 2 < g.N ? 1.f : 0.f, bn3m = bn + 3 < g.N ? 1.f : 0.f;
+  const int nslabs = (rows + TNL_BK - 1) / TNL_BK;
+
+  f32x4 ra[2], rb[2];
+  auto load = [&](int slab) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      // rows past the slice: the descriptor's range check returns 0 (offsets stay below 2^31: checked by the launcher)
+      ra[h] = am < g.M ? hn_buffer_load_x4(ars, aoff + h * astep + slab * aslab, 0, 0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      rb[h] = bn < g.N ? hn_buffer_load_x4(brs, boff + h * bstep + slab * bslab, 0, 0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  // bias gradient sum_k A[k, m]: the loader threads of the first column tile add up what they stage (8 VALU adds per slab) --
+  // ones-vector MFMAs in one wave of the tile would make that wave, and through the barrier the whole workgroup, 1.5x slower
+  const bool do_colsum = g.colsum != nullptr && bn0 == 0;
+  f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+  auto store = [&](int buf) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const f32x4 av = (f32x4){ra[h][0] * am0, ra[h][1] * am1, ra[h][2] * am2, ra[h][3] * am3};
+      if (do_colsum) csum += av;
+      *(f32x4 *)&As[buf][(lr + 8 * h) * TNL_PITCH + lc] = av;
+      *(f32x4 *)&Bs[buf][(lr + 8 * h) * TNL_PITCH + lc] = (f32x4){rb[h][0] * bn0m, rb[h][1] * bn1m, rb[h][2] * bn2m, rb[h][3] * bn3m};
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const bool wave_live = bm0 + wm < g.M && bn0 + wn < g.N;
+
+  if (nslabs > 0) { load(0); store(0); }
+  __syncthreads();
+  for (int sl = 0; sl < nslabs; ++sl) {
+    const int buf = sl & 1;
+    if (sl + 1 < nslabs) load(sl + 1);
+    if (wave_live) {
+      const float *ap = &As[buf][half * TNL_PITCH + wm + col], *bp = &Bs[buf][half * TNL_PITCH + wn + col];
+#pragma unroll
+      for (int kk = 0; kk < TNL_BK; kk += 2) {
+        const float a0 = ap[kk * TNL_PITCH], a1 = ap[kk * TNL_PITCH + 32];
+        const float b0 = bp[kk * TNL_PITCH], b1 = bp[kk * TNL_PITCH + 32];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      }
+    }
+    if (sl + 1 < nslabs) store(buf ^ 1);
+    __syncthreads();
+  }
+  if (do_colsum) {     // 8 loader rows x 128 columns of partial sums -> LDS (the slab buffers are free after the last barrier)
+    *(f32x4 *)&As[0][lr * TNL_PITCH + lc] = csum;
+    __syncthreads();
+    if (tid < 128 && bm0 + tid < g.M) {
+      float v = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v += As[0][r * TNL_PITCH + tid];
+      float *cs = g.colsum + (g.nsplit > 1 ? (long)z * g.M : 0);
+      const int m = bm0 + tid;
+      if (g.nsplit > 1) cs[m] = v;
+      else cs[m] = g.colsum_accumulate ? cs[m] + v : v;
+    }
+  }
+  if (!wave_live) return;
+
+  const int m0 = bm0 + wm, n0 = bn0 + wn;
+  float *C = g.C + (g.nsplit > 1 ? ((long)bt * g.nsplit + z) * g.M * g.ldc : bt * g.strideC);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + 32 * j + col;
+      if (n >= g.N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (m < g.M) {
+          float *dst = C + (long)m * g.ldc + n;
+          if (g.nsplit > 1) *dst = acc[i][j][r];
+          else { const float v = g.alpha * acc[i][j][r]; *dst = g.accumulate ? *dst + v : v; }
+        }
+      }
+    }
+}
+
 __global__ __launch_bounds__(256) void splitk_reduce_alpha_kernel(const float *__restrict__ part, int nsplit, long mn, int N,
                                                                   float *__restrict__ C, long ldc, float alpha, int accumulate,
                                                                   long strideC) {
@@ -260,7 +380,8 @@ static int launch_gemm_tn(const float *A, long lda, const float *B, long ldb, fl
   const int tiles = ceil_div(M, 128) * ceil_div(N, 128) * batch;
   int nsplit = 1;
   if (scratch) {
-    nsplit = ceil_div(768, tiles);                              // ~3 workgroups per CU
+    nsplit = 768 / tiles;                                       // 3 workgroups per CU resident (150 VGPRs): one full round,
+                                                                // never a few leftovers in a second one (784 of 768 cost 40 %)
     const int max_by_k = ceil_div(K, 64);                       // at least 64 rows per slice
     if (nsplit > max_by_k) nsplit = max_by_k;
     if (nsplit > GEMM_EX_SPLITS) nsplit = GEMM_EX_SPLITS;
@@ -276,7 +397,11 @@ static int launch_gemm_tn(const float *A, long lda, const float *B, long ldb, fl
   g.batch = batch; g.strideA = strideA; g.strideB = strideB; g.strideC = strideC;
   HN_REQUIRE((long)g.nsplit * batch <= 65535, HN_E_UNSUPPORTED, "gemm_tn: batch=%d", batch);
   if (g.nsplit > 1) { g.C = scratch; g.ldc = N; if (colsum) g.colsum = scratch + (size_t)g.nsplit * M * N; } else { g.C = C; g.ldc = ldc; }
-  if (g.kslice <= 512) hipLaunchKernelGGL(gemm_tn_kernel<16>, dim3(ceil_div(M, 128), ceil_div(N, 128), g.nsplit * batch), dim3(256), 0, s, g);
+  const bool aligned = (lda & 3) == 0 && (ldb & 3) == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 && (strideA & 3) == 0 &&
+                       (strideB & 3) == 0;
+  if (g.kslice > 512 && aligned && M >= 128 && N >= 128)
+    hipLaunchKernelGGL(gemm_tn_lds_kernel, dim3(ceil_div(M, 128), ceil_div(N, 128), g.nsplit * batch), dim3(256), 0, s, g);
+  else if (g.kslice <= 512) hipLaunchKernelGGL(gemm_tn_kernel<16>, dim3(ceil_div(M, 128), ceil_div(N, 128), g.nsplit * batch), dim3(256), 0, s, g);
   else hipLaunchKernelGGL(gemm_tn_kernel<4>, dim3(ceil_div(M, 128), ceil_div(N, 128), g.nsplit * batch), dim3(256), 0, s, g);
   HN_LAUNCH_CHECK("gemm_tn");
   if (g.nsplit > 1) {

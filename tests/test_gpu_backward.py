@@ -167,6 +167,8 @@ ATTN_CASES = [
     dict(b=2, L=24, N=0, D=0, heads=2, dh=16, qd=32, self_attn=True, norm=False, residual=False),
     dict(b=4, L=128, N=1, D=2005, heads=8, dh=64, qd=128),                       # one-token (tabular) context
     dict(b=2, L=16, N=50, D=13, heads=2, dh=16, qd=32, norm=False),              # bare Attention, raw 13-wide context
+    dict(b=2, L=128, N=9000, D=200, heads=8, dh=64, qd=128),                     # explicit cross, 18 000-row contraction: LDS-staged
+                                                                                 # weight-gradient GEMM with a ragged column tile
 ]
 CASE_INDEX = {id(c): k for k, c in enumerate(ATTN_CASES)}
 
