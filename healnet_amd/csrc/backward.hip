@@ -129,7 +129,7 @@ struct GemmTnArgs {
   int batch; long strideA, strideB, strideC; // independent products (per-head weight gradients); grid.z = batch * nsplit
 };
 
-template <int UN>      // k-pairs in flight: 16 for short slices (latency decides), 4 for long ones (occupancy decides)
+template <int UN>      // k-pairs in flight: 8 for short slices (latency decides; 16 costs 272 VGPRs for nothing), 4 for long ones
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs g) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m0 = blockIdx.x * 128 + (wave >> 1) * 64, n0 = blockIdx.y * 128 + (wave & 1) * 64;
@@ -401,7 +401,7 @@ static int launch_gemm_tn(const float *A, long lda, const float *B, long ldb, fl
                        (strideB & 3) == 0;
   if (g.kslice > 512 && aligned && M >= 128 && N >= 128)
     hipLaunchKernelGGL(gemm_tn_lds_kernel, dim3(ceil_div(M, 128), ceil_div(N, 128), g.nsplit * batch), dim3(256), 0, s, g);
-  else if (g.kslice <= 512) hipLaunchKernelGGL(gemm_tn_kernel<16>, dim3(ceil_div(M, 128), ceil_div(N, 128), g.nsplit * batch), dim3(256), 0, s, g);
+  else if (g.kslice <= 512) hipLaunchKernelGGL(gemm_tn_kernel<8>, dim3(ceil_div(M, 128), ceil_div(N, 128), g.nsplit * batch), dim3(256), 0, s, g);
   else hipLaunchKernelGGL(gemm_tn_kernel<4>, dim3(ceil_div(M, 128), ceil_div(N, 128), g.nsplit * batch), dim3(256), 0, s, g);
   HN_LAUNCH_CHECK("gemm_tn");
   if (g.nsplit > 1) {
