@@ -154,11 +154,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs g) {
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  // bias gradient for free: the waves of the first column tile also contract A with a vector of ones (every column of that
-  // accumulator is sum_k A[k, m]); +2 MFMAs per k-pair for 1 wave in 2 * ntn, no extra memory traffic, no colsum launch
+  // bias gradient for free: the waves of the first column tile also add up their A operands (lane (half, col) sees
+  // A[2p + half, m] of every k-pair: 2 VALU adds per pair, the two halves meet in one shuffle at the end); no extra memory
+  // traffic, no colsum launch.  (Ones-vector MFMAs did the same at +50 % matrix work for exactly those waves.)
   const bool do_colsum = g.colsum != nullptr && n0 == 0;
-  f32x16 accs[2];
-  accs[0] = accs[1] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  float csum[2] = {0.0f, 0.0f};
 
   const int npairs = (rows + 1) / 2;
   const int sa = (int)(2 * g.lda * 4), sb = (int)(2 * g.ldb * 4);
@@ -187,24 +187,20 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs g) {
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[i], cb[j], acc[i][j], 0, 0, 0);
-      if (do_colsum) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) accs[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[i], 1.0f, accs[i], 0, 0, 0);
-      }
+      if (do_colsum) { csum[0] += ca[0]; csum[1] += ca[1]; }
     }
   }
-  if (do_colsum && col == 0) {               // column 0 of the ones-accumulator: lanes 0 and 32 hold its 32 rows
+  if (do_colsum) {
     float *cs = g.colsum + (g.nsplit > 1 ? (long)z * g.M : 0);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (m < g.M) {
-          if (g.nsplit > 1) cs[m] = accs[i][r];
-          else cs[m] = g.colsum_accumulate ? cs[m] + accs[i][r] : accs[i][r];
-        }
+    for (int i = 0; i < 2; ++i) {
+      const float v = csum[i] + __shfl_xor(csum[i], 32);
+      const int m = m0 + 32 * i + col;
+      if (half == 0 && m < g.M) {
+        if (g.nsplit > 1) cs[m] = v;
+        else cs[m] = g.colsum_accumulate ? cs[m] + v : v;
       }
+    }
   }
   float *C = g.C + (g.nsplit > 1 ? ((long)bt * g.nsplit + z) * g.M * g.ldc : bt * g.strideC);
 #pragma unroll
