@@ -371,7 +371,10 @@ void attn_core_geometry(int b, int h, int Lp, int N, int dp, int *nsplit, int *c
   static long target_waves = 0;   // development knob HN_CORE_WAVES: resident waves the token split aims for
   if (target_waves == 0) { const char *e = getenv("HN_CORE_WAVES"); target_waves = e ? atol(e) : 256L * 4 * 4; if (target_waves < 64) target_waves = 4096; }
   const long tw = waves_per_simd > 0 ? 256L * 4 * waves_per_simd : target_waves;
-  long want = ceil_div_ll(tw, (long)b * h * ngroups);
+  static int geom_floor = -1;      // development knob HN_GEOM_CEIL=1: the old rounding
+  if (geom_floor < 0) { const char *e = getenv("HN_GEOM_CEIL"); geom_floor = (e && e[0] == '1') ? 0 : 1; }
+  // floor: all waves resident in ONE round (a ceil that overshoots the slots by a few waves costs a whole second round)
+  long want = geom_floor ? tw / ((long)b * h * ngroups) : ceil_div_ll(tw, (long)b * h * ngroups);
   long max_splits = N / 128;
   if (max_splits < 1) max_splits = 1;
   if (want > max_splits) want = max_splits;
