@@ -343,10 +343,20 @@ __global__ __launch_bounds__(256) void gemm_tn_lds_kernel(GemmTnArgs g) {
 
 __global__ __launch_bounds__(256) void splitk_reduce_alpha_kernel(const float *__restrict__ part, int nsplit, long mn, int N,
                                                                   float *__restrict__ C, long ldc, float alpha, int accumulate,
-                                                                  long strideC) {
+                                                                  long strideC, const float *__restrict__ cs_part, int M,
+                                                                  float *__restrict__ cs_out, int cs_accumulate) {
   part += (long)blockIdx.y * nsplit * mn;          // blockIdx.y: batch entry
   C += blockIdx.y * strideC;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < mn; i += (long)gridDim.x * blockDim.x) {
+  // the fused column-sum partials (nsplit, M) are folded by the same launch: elements mn .. mn + M - 1 of the index space
+  const long total = mn + (cs_part ? M : 0);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    if (i >= mn) {
+      const int m = (int)(i - mn);
+      float acc = 0.0f;
+      for (int k = 0; k < nsplit; ++k) acc += cs_part[(long)k * M + m];
+      cs_out[m] = cs_accumulate ? cs_out[m] + acc : acc;
+      continue;
+    }
     float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;     // four independent chains (loads in flight), fixed order -> deterministic
     int k = 0;
     for (; k + 4 <= nsplit; k += 4) {
@@ -358,15 +368,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_alpha_kernel(const float *_
     float *dst = C + (i / N) * ldc + (i % N);
     *dst = accumulate ? *dst + alpha * acc : alpha * acc;
   }
-}
-
-__global__ __launch_bounds__(256) void splitk_colsum_reduce_kernel(const float *__restrict__ part, int nsplit, int M, float *__restrict__ out,
-                                                                   int accumulate) {
-  const int m = blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= M) return;
-  float acc = 0.0f;
-  for (int k = 0; k < nsplit; ++k) acc += part[(long)k * M + m];
-  out[m] = accumulate ? out[m] + acc : acc;
 }
 
 static int launch_gemm_tn(const float *A, long lda, const float *B, long ldb, float *C, long ldc, int M, int N, int K, float alpha,
@@ -402,15 +403,11 @@ static int launch_gemm_tn(const float *A, long lda, const float *B, long ldb, fl
   HN_LAUNCH_CHECK("gemm_tn");
   if (g.nsplit > 1) {
     const long mn = (long)M * N;
-    long blocks = ceil_div_ll(mn, 256);
+    long blocks = ceil_div_ll(mn + (colsum ? M : 0), 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(splitk_reduce_alpha_kernel, dim3((unsigned)blocks, batch), dim3(256), 0, s, scratch, g.nsplit, mn, N, C, ldc, alpha,
-                       accumulate, strideC);
+                       accumulate, strideC, colsum ? g.colsum : nullptr, M, colsum, colsum_accumulate);
     HN_LAUNCH_CHECK("splitk_reduce");
-    if (colsum) {
-      hipLaunchKernelGGL(splitk_colsum_reduce_kernel, dim3(ceil_div(M, 256)), dim3(256), 0, s, g.colsum, g.nsplit, M, colsum, colsum_accumulate);
-      HN_LAUNCH_CHECK("splitk_colsum_reduce");
-    }
   }
   return HN_OK;
 }
