@@ -21,6 +21,7 @@ gen = torch.Generator().manual_seed(1234)
 b = args.batch
 pool = [([torch.rand(b, 1, 2000, generator=gen), torch.rand(b, 224, 224, 3, generator=gen)],) for _ in range(4)]
 pool8 = [([p[0][0], (p[0][1] * 255).round().to(torch.uint8)],) for p in pool]
+pool16 = [([t.to(torch.bfloat16) for t in p[0]],) for p in pool]      # a dataset that is stored in bf16
 
 
 def run(batches, transport, staged=True):
@@ -46,7 +47,8 @@ with torch.no_grad():
     torch.cuda.synchronize(); res["resident"] = round(b * args.steps / (time.perf_counter() - t0), 1)
 res["blocking_to_device_fp32"] = round(run(pool, None, staged=False), 1)
 res["device_loader_fp32"] = round(run(pool, None), 1)
-res["device_loader_bf16"] = round(run(pool, "bf16"), 1)
+res["device_loader_bf16_stored"] = round(run(pool16, None), 1)           # half the PCIe bytes, K1 reads bf16 in place
+res["device_loader_bf16_cast_on_host"] = round(run(pool, "bf16"), 1)     # fp32 dataset cast per batch by the producer thread: host-bound
 res["device_loader_uint8_image"] = round(run(pool8, None), 1)
 res["unit"] = "samples/s, cfg2 b=%d, 1 GPU" % b
 print(json.dumps(res))
