@@ -49,7 +49,10 @@ class DeviceLoader:
 
     ``transport`` narrows floating-point modality tensors on the HOST before the copy:
       None / "fp32"  as produced by the dataset
-      "bf16"         fp32 -> bf16 through a pinned buffer (half the PCIe bytes); the model reads bf16 tensors in place
+      "bf16"         fp32 -> bf16 through a pinned buffer (half the PCIe bytes); the model reads bf16 tensors in place.
+                     The cast runs on the producer thread and is slower than the PCIe time it saves on a 64 GB/s link
+                     (tools/bench_staging.py: 1.6k instead of 9.5k samples/s at cfg2) -- only for links that are the
+                     bottleneck; a dataset that is already stored in bf16 needs no option and costs nothing.
     uint8 tensors (8-bit images) are always shipped as they are (a quarter of the bytes) and decoded as byte / 255 by the
     encode kernel.  Integer / bool tensors (labels, censorship) are copied unchanged."""
 
