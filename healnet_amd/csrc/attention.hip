@@ -511,45 +511,65 @@ int launch_qfold(const float *Q, int ldq_row, const float *w_k, int D, const flo
 // ------------------------------------------------------------------------------------------------
 constexpr int MERGE_ROWS = 32;
 
-// Split merge in two phases: 8 lanes per latent row first turn the per-split (m, l) pairs into weights
-// w_s = 2^(m_s - M) and the merged (M, l) (staged in LDS), then every output element is one pass of nsplit
-// independent coalesced loads.  (The one-phase form re-read m and l for every element: 4 * nsplit dependent loads.)
+// Split merge in two phases per chunk of MERGE_MAXS splits: 8 lanes per latent row turn the per-split (m, l) pairs into
+// weights w_s = 2^(m_s - M) (staged in LDS) and the merged (M, l), then every output element is one pass of independent
+// coalesced loads over the chunk.  (The one-phase form re-read m and l for every element: 4 * nsplit dependent loads.)
+// R rows per workgroup: 32, or 8 when that would leave most of the chip idle (small batches: few (b, h) pairs, hundreds of
+// splits -- at b = 1 the merge of 256 splits took 121 us per image block, a third of the forward).
 constexpr int MERGE_MAXS = 64;
 struct MergeWeights {
   float w[MERGE_ROWS][MERGE_MAXS + 1];
   float M[MERGE_ROWS], invl[MERGE_ROWS], l[MERGE_ROWS];
 };
 
-__device__ __forceinline__ void merge_row_weights(MergeWeights &mw, const float *Mpart, const float *Lpart, long pbase,
-                                                  int nsplit, int Lp, int q0, int L) {
-  const int qq = threadIdx.x >> 3, j = threadIdx.x & 7, q = q0 + qq;     // 256 threads = 32 rows x 8 lanes
-  const bool live = q < L;
+// Accumulates acc[k] (element idx = tid + 256 k of the R x width block; element (qq, d) is taken when keep(d)) over all
+// splits, unnormalised; leaves M / l / 1/l of the block's rows in mw.  All 256 threads must call it.
+template <int EPT, typename Keep>
+__device__ __forceinline__ void merge_splits(MergeWeights &mw, const float *Opart, const float *Mpart, const float *Lpart,
+                                             long pbase, int nsplit, int Lp, int dp, int q0, int L, int R, int width, Keep keep,
+                                             float (&acc)[EPT]) {
+  const int tid = threadIdx.x;
+  const int wq = tid >> 3, j = tid & 7;                  // weight phase: 8 lanes per row, rows 0 .. R-1
+  const bool wlive = wq < R && q0 + wq < L;
   float M = kNegBig;
-  if (live) for (int s = j; s < nsplit; s += 8) M = fmaxf(M, Mpart[pbase + (long)s * Lp + q]);
+  if (wlive) for (int s = j; s < nsplit; s += 8) M = fmaxf(M, Mpart[pbase + (long)s * Lp + q0 + wq]);
   M = fmaxf(M, __shfl_xor(M, 1));
   M = fmaxf(M, __shfl_xor(M, 2));
   M = fmaxf(M, __shfl_xor(M, 4));
   float lsum = 0.0f;
-  if (live) for (int s = j; s < nsplit; s += 8) {
-    const float w = fast_exp2(Mpart[pbase + (long)s * Lp + q] - M);
-    lsum = fmaf(w, Lpart[pbase + (long)s * Lp + q], lsum);
-    if (s < MERGE_MAXS) mw.w[qq][s] = w;
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) acc[k] = 0.0f;
+  for (int s0 = 0; s0 < nsplit; s0 += MERGE_MAXS) {
+    const int s1 = min(nsplit, s0 + MERGE_MAXS);
+    if (wlive) for (int s = s0 + j; s < s1; s += 8) {
+      const float w = fast_exp2(Mpart[pbase + (long)s * Lp + q0 + wq] - M);
+      lsum = fmaf(w, Lpart[pbase + (long)s * Lp + q0 + wq], lsum);
+      mw.w[wq][s - s0] = w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const int idx = tid + 256 * k;
+      if (idx < R * width) {
+        const int qq = idx / width, d = idx % width, q = q0 + qq;
+        if (q < L && keep(d)) {
+          float a = acc[k];
+          for (int s = s0; s < s1; ++s) a = fmaf(mw.w[qq][s - s0], Opart[(pbase + (long)s * Lp + q) * dp + d], a);
+          acc[k] = a;
+        }
+      }
+    }
+    __syncthreads();
   }
   lsum += __shfl_xor(lsum, 1);
   lsum += __shfl_xor(lsum, 2);
   lsum += __shfl_xor(lsum, 4);
-  if (j == 0) { mw.M[qq] = M; mw.l[qq] = lsum; mw.invl[qq] = 1.0f / lsum; }
+  if (wq < R && j == 0) { mw.M[wq] = M; mw.l[wq] = lsum; mw.invl[wq] = 1.0f / lsum; }
+  __syncthreads();
 }
 
-__device__ __forceinline__ float merged_value(const MergeWeights &mw, const float *Opart, const float *Mpart, long pbase,
-                                              int nsplit, int Lp,
-                                              int dp, int qq, int q, int d) {
-  float acc = 0.0f;
-  const int ns = nsplit < MERGE_MAXS ? nsplit : MERGE_MAXS;
-  for (int s = 0; s < ns; ++s) acc = fmaf(mw.w[qq][s], Opart[(pbase + (long)s * Lp + q) * dp + d], acc);
-  for (int s = MERGE_MAXS; s < nsplit; ++s)       // tiny batches only (b * h * row groups < 64): weights past the staged 64 on the fly
-    acc = fmaf(fast_exp2(Mpart[pbase + (long)s * Lp + q] - mw.M[qq]), Opart[(pbase + (long)s * Lp + q) * dp + d], acc);
-  return acc * mw.invl[qq];
+static int merge_rows_per_block(int b, int h, int L) {       // 32 rows, or 8 while 32 would give fewer workgroups than CUs
+  return (long)b * h * ceil_div(L, MERGE_ROWS) >= 256 ? MERGE_ROWS : 8;
 }
 
 __global__ __launch_bounds__(256) void merge_vproj_kernel(const float *__restrict__ Opart, const float *__restrict__ Mpart,
@@ -557,28 +577,33 @@ __global__ __launch_bounds__(256) void merge_vproj_kernel(const float *__restric
                                                           int dp, int D, const float *__restrict__ gamma,
                                                           const float *__restrict__ beta, const float *__restrict__ w_v,
                                                           int dh, float *__restrict__ O, int ldo, float *__restrict__ stats,
-                                                          float *__restrict__ oprime_save, int pack_ks, int srow) {
+                                                          float *__restrict__ oprime_save, int pack_ks, int srow, int R) {
   extern __shared__ float sm[];
   float *oh = sm;                        // [MERGE_ROWS][dp + 1]
   float *wv = sm + MERGE_ROWS * (dp + 1);  // [dh][dp + 1]: gamma folded in; [dp] = the beta term
   const int bh = blockIdx.x, bi = bh / h, hi = bh % h;
-  const int q0 = blockIdx.y * MERGE_ROWS;
+  const int q0 = blockIdx.y * R;
   const long pbase = (long)bh * nsplit * Lp;
   const int dlim = pack_ks ? dp : D;
   __shared__ MergeWeights mw;
-  merge_row_weights(mw, Mpart, Lpart, pbase, nsplit, Lp, q0, L);
-  __syncthreads();
-  if (stats && threadIdx.x < MERGE_ROWS && q0 + threadIdx.x < L) {
+  float acc[4];                          // R * dp <= 32 * 32 elements
+  // srow: column dp-1 carries the dropped row sum (see attn_core)
+  merge_splits<4>(mw, Opart, Mpart, Lpart, pbase, nsplit, Lp, dp, q0, L, R, dp,
+                  [&](int d) { return d < dlim || (srow && d == dp - 1); }, acc);
+  if (stats && threadIdx.x < R && q0 + threadIdx.x < L) {
     stats[((long)bh * L + q0 + threadIdx.x) * 2 + 0] = mw.M[threadIdx.x];
     stats[((long)bh * L + q0 + threadIdx.x) * 2 + 1] = mw.l[threadIdx.x];
   }
-  for (int idx = threadIdx.x; idx < MERGE_ROWS * dp; idx += blockDim.x) {
-    const int qq = idx / dp, d = idx % dp, q = q0 + qq;
-    float v = 0.0f;
-    if (q < L && (d < dlim || (srow && d == dp - 1)))        // srow: column dp-1 carries the dropped row sum (see attn_core)
-      v = merged_value(mw, Opart, Mpart, pbase, nsplit, Lp, dp, qq, q, d);
-    if (oprime_save && !pack_ks && q < L) oprime_save[((long)bi * L + q) * (h * dp) + hi * dp + d] = v;   // training: normalised P z, padding columns 0
-    oh[qq * (dp + 1) + d] = v;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int idx = threadIdx.x + 256 * k;
+    if (idx < R * dp) {
+      const int qq = idx / dp, d = idx % dp, q = q0 + qq;
+      const bool kept = q < L && (d < dlim || (srow && d == dp - 1));
+      const float v = kept ? acc[k] * mw.invl[qq] : 0.0f;
+      if (oprime_save && !pack_ks && q < L) oprime_save[((long)bi * L + q) * (h * dp) + hi * dp + d] = v;   // training: normalised P z, padding columns 0
+      oh[qq * (dp + 1) + d] = v;
+    }
   }
   for (int idx = threadIdx.x; idx < dh * (dp + 1); idx += blockDim.x) {
     const int e = idx / (dp + 1), d = idx % (dp + 1);
@@ -597,7 +622,7 @@ __global__ __launch_bounds__(256) void merge_vproj_kernel(const float *__restric
   }
   __syncthreads();
   if (oprime_save && pack_ks) {     // the tape keeps the natural channel layout: kept channels from their slots, the dropped one = -sum
-    for (int idx = threadIdx.x; idx < MERGE_ROWS * dp; idx += blockDim.x) {
+    for (int idx = threadIdx.x; idx < R * dp; idx += blockDim.x) {
       const int qq = idx / dp, c = idx % dp, q = q0 + qq;
       if (q >= L) continue;
       float v = 0.0f;
@@ -608,12 +633,12 @@ __global__ __launch_bounds__(256) void merge_vproj_kernel(const float *__restric
       oprime_save[((long)bi * L + q) * (h * dp) + hi * dp + c] = v;
     }
   }
-  for (int idx = threadIdx.x; idx < MERGE_ROWS * dh; idx += blockDim.x) {
+  for (int idx = threadIdx.x; idx < R * dh; idx += blockDim.x) {
     const int qq = idx / dh, e = idx % dh, q = q0 + qq;
     if (q >= L) continue;
-    float acc = wv[e * (dp + 1) + dp] * (srow ? oh[qq * (dp + 1) + dp - 1] : 1.0f);      // beta term * sum_t p'_t (1 without dropout)
-    for (int d = 0; d < dlim; ++d) acc = fmaf(oh[qq * (dp + 1) + d], wv[e * (dp + 1) + d], acc);
-    O[((long)bi * L + q) * ldo + hi * dh + e] = acc;
+    float a = wv[e * (dp + 1) + dp] * (srow ? oh[qq * (dp + 1) + dp - 1] : 1.0f);      // beta term * sum_t p'_t (1 without dropout)
+    for (int d = 0; d < dlim; ++d) a = fmaf(oh[qq * (dp + 1) + d], wv[e * (dp + 1) + d], a);
+    O[((long)bi * L + q) * ldo + hi * dh + e] = a;
   }
 }
 
@@ -622,8 +647,10 @@ int launch_merge_vproj(const float *Opart, const float *Mpart, const float *Lpar
                        float *O, int ldo, float *stats, float *oprime_save, hipStream_t s, int pack_ks, int srow) {
   size_t lds = ((size_t)MERGE_ROWS * (dp + 1) + (size_t)dh * (dp + 1)) * sizeof(float);
   HN_REQUIRE(!(pack_ks && srow), HN_E_SHAPE, "merge_vproj: the row-sum channel needs the natural channel layout");
-  hipLaunchKernelGGL(merge_vproj_kernel, dim3(b * h, ceil_div(L, MERGE_ROWS)), dim3(256), lds, s, Opart, Mpart, Lpart,
-                     nsplit, h, L, Lp, dp, D, gamma, beta, w_v, dh, O, ldo, stats, oprime_save, pack_ks, srow);
+  HN_REQUIRE(dp <= 32, HN_E_UNSUPPORTED, "merge_vproj: dp=%d", dp);
+  const int R = merge_rows_per_block(b, h, L);
+  hipLaunchKernelGGL(merge_vproj_kernel, dim3(b * h, ceil_div(L, R)), dim3(256), lds, s, Opart, Mpart, Lpart,
+                     nsplit, h, L, Lp, dp, D, gamma, beta, w_v, dh, O, ldo, stats, oprime_save, pack_ks, srow, R);
   HN_LAUNCH_CHECK("merge_vproj");
   return HN_OK;
 }
@@ -631,28 +658,33 @@ int launch_merge_vproj(const float *Opart, const float *Mpart, const float *Lpar
 __global__ __launch_bounds__(256) void merge_explicit_kernel(const float *__restrict__ Opart, const float *__restrict__ Mpart,
                                                              const float *__restrict__ Lpart, int nsplit, int h, int L,
                                                              int Lp, int dp, int dh, float *__restrict__ O, int ldo,
-                                                             float *__restrict__ stats) {
+                                                             float *__restrict__ stats, int R) {
   const int bh = blockIdx.x, bi = bh / h, hi = bh % h;
-  const int q0 = blockIdx.y * MERGE_ROWS;
+  const int q0 = blockIdx.y * R;
   const long pbase = (long)bh * nsplit * Lp;
   __shared__ MergeWeights mw;
-  merge_row_weights(mw, Mpart, Lpart, pbase, nsplit, Lp, q0, L);
-  __syncthreads();
-  if (stats && threadIdx.x < MERGE_ROWS && q0 + threadIdx.x < L) {
+  float acc[16];                         // R * dh <= 32 * 128 elements
+  merge_splits<16>(mw, Opart, Mpart, Lpart, pbase, nsplit, Lp, dp, q0, L, R, dh, [](int) { return true; }, acc);
+  if (stats && threadIdx.x < R && q0 + threadIdx.x < L) {
     stats[((long)bh * L + q0 + threadIdx.x) * 2 + 0] = mw.M[threadIdx.x];
     stats[((long)bh * L + q0 + threadIdx.x) * 2 + 1] = mw.l[threadIdx.x];
   }
-  for (int idx = threadIdx.x; idx < MERGE_ROWS * dh; idx += blockDim.x) {
-    const int qq = idx / dh, e = idx % dh, q = q0 + qq;
-    if (q >= L) continue;
-    O[((long)bi * L + q) * ldo + hi * dh + e] = merged_value(mw, Opart, Mpart, pbase, nsplit, Lp, dp, qq, q, e);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int idx = threadIdx.x + 256 * k;
+    if (idx < R * dh) {
+      const int qq = idx / dh, e = idx % dh, q = q0 + qq;
+      if (q < L) O[((long)bi * L + q) * ldo + hi * dh + e] = acc[k] * mw.invl[qq];
+    }
   }
 }
 
 int launch_merge_explicit(const float *Opart, const float *Mpart, const float *Lpart, int nsplit, int b, int h, int L,
                           int Lp, int dp, int dh, float *O, int ldo, float *stats, hipStream_t s) {
-  hipLaunchKernelGGL(merge_explicit_kernel, dim3(b * h, ceil_div(L, MERGE_ROWS)), dim3(256), 0, s, Opart, Mpart, Lpart,
-                     nsplit, h, L, Lp, dp, dh, O, ldo, stats);
+  HN_REQUIRE(dh <= 128, HN_E_UNSUPPORTED, "merge_explicit: dh=%d", dh);
+  const int R = merge_rows_per_block(b, h, L);
+  hipLaunchKernelGGL(merge_explicit_kernel, dim3(b * h, ceil_div(L, R)), dim3(256), 0, s, Opart, Mpart, Lpart,
+                     nsplit, h, L, Lp, dp, dh, O, ldo, stats, R);
   HN_LAUNCH_CHECK("merge_explicit");
   return HN_OK;
 }
