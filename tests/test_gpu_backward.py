@@ -221,6 +221,7 @@ PACKED = {   # packed shared-context layouts of the training path: (channels, sp
     "packed_ks6": (9, (4, 3, 2), 32),     # D = 24 -> ks = 6
     "packed_ks7": (22, (11,), 32),        # D = 27 -> ks = 7
     "natural_d16": (11, (6,), 16),        # D = 16 == dp: no free column, natural layout, synthetic ones column
+    "packed_masked": (3, (6, 5), 64, dict(), True),                 # image-like D = 13 (ks = 3) with a key mask
 }
 
 
@@ -233,6 +234,13 @@ def test_model_gradients_vs_oracle_autograd(cfg):
         kw = dict(n_modalities=2, channel_dims=[5, chan], num_spatial_axes=[1, len(shape)], out_dims=3, depth=2, l_c=24, l_d=32,
                   x_heads=2, l_heads=2, cross_dim_head=dh, latent_dim_head=8, **(PACKED[cfg][3] if len(PACKED[cfg]) > 3 else {}))
         ins = [torch.rand(3, 2, 5, generator=gen), torch.rand(3, *shape, chan, generator=gen)]
+        if len(PACKED[cfg]) > 4:      # one mask for every modality (Appendix B-5): both need the same token count
+            n = 1
+            for s_ in shape:
+                n *= s_
+            ins[0] = torch.rand(3, n, 5, generator=gen)
+            mask = torch.rand(3, n, generator=gen) > 0.3
+            mask[:, 0] = True
     elif cfg == "cfg1_b2":
         kw = dict(n_modalities=2, channel_dims=[2000, 3], num_spatial_axes=[1, 2], out_dims=4, depth=2)
         ins = [torch.rand(2, 1, 2000, generator=gen), torch.rand(2, 48, 40, 3, generator=gen)]
@@ -246,11 +254,12 @@ def test_model_gradients_vs_oracle_autograd(cfg):
     torch.manual_seed(11)
     model = hn.HealNet(**kw).train()
     sd = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
-    want = O.fusion_forward(sd, O.FusionConfig(**kw), ins)
+    mask = locals().get("mask")
+    want = O.fusion_forward(sd, O.FusionConfig(**kw), ins, mask=mask)
     dl = torch.randn(want.shape, generator=gen)
     (want * dl).sum().backward()
     model.to(DEV)
-    got = model([None if t is None else t.to(DEV) for t in ins])
+    got = model([None if t is None else t.to(DEV) for t in ins], mask=None if mask is None else mask.to(DEV))
     assert_close(got.detach().cpu(), want.detach(), rel=1e-3, what=cfg + ".fwd_train")
     (got * dl.to(DEV)).sum().backward()
     for k, p in model.named_parameters():

@@ -286,3 +286,20 @@ def test_one_token_route_above_32_samples(hn):
         y = model([tab, img])
         y8 = torch.cat([model([tab[i:i + 8], img[i:i + 8]]) for i in range(0, b, 8)])
         assert_close(y.detach().cpu(), y8.detach().cpu(), rel=1e-5, what=f"b={b} vs batches of 8")
+
+
+def test_narrow_input_dtypes_on_both_forwards(hn):
+    """bf16 tensors are read in place and uint8 images as byte / 255 by the encode kernel: on the inference AND the
+    tape-recording forward the result must equal the fp32 path on the same (already rounded) values, bit for bit."""
+    torch.manual_seed(8)
+    model = hn.HealNet(n_modalities=2, channel_dims=[30, 3], num_spatial_axes=[1, 2], out_dims=3, depth=2, l_c=16, l_d=32,
+                       x_heads=2, l_heads=2, cross_dim_head=16, latent_dim_head=8).eval().to(DEV)
+    gen = torch.Generator().manual_seed(81)
+    tab = torch.rand(3, 4, 30, generator=gen).to(DEV)
+    img8 = torch.randint(0, 256, (3, 9, 7, 3), generator=gen, dtype=torch.uint8).to(DEV)
+    img_f = img8.cpu().float().div(255).to(DEV)      # on the CPU: torch's GPU division by a scalar multiplies by 1/255 (1 ulp off)
+    want8 = model([tab, img_f])
+    assert torch.equal(model([tab, img8]).detach(), want8.detach())
+    tab16, img16 = tab.to(torch.bfloat16), img_f.to(torch.bfloat16)
+    want16 = model([tab16.float(), img16.float()])
+    assert torch.equal(model([tab16, img16]).detach(), want16.detach())
