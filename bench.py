@@ -74,7 +74,7 @@ class HipEvents:
 def pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/): counters cannot be
     collected from inside this process.  (2*FETCH_SIZE + WRITE_SIZE) KiB, per MI355X_MICROARCH.md's gfx950 note."""
-    path = os.path.join(ROOT, "profiles", "r01_i_pmc_cfg2_b32.json")
+    path = os.path.join(ROOT, "profiles", "r01_l_pmc_cfg2_b32.json")
     try:
         with open(path) as f:
             return float(json.load(f)["dominant_kernel_traffic_bytes_per_launch"]["fetch_doubled"])
