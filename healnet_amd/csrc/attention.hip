@@ -622,10 +622,17 @@ __device__ __forceinline__ void merge_splits(MergeWeights &mw, const float *Opar
   for (int k = 0; k < EPT; ++k) acc[k] = 0.0f;
   for (int s0 = 0; s0 < nsplit; s0 += MERGE_MAXS) {
     const int s1 = min(nsplit, s0 + MERGE_MAXS);
+    const bool last = s1 == nsplit;
     if (wlive) for (int s = s0 + j; s < s1; s += 8) {
       const float w = fast_exp2(Mpart[pbase + (long)s * Lp + q0 + wq] - M);
       lsum = fmaf(w, Lpart[pbase + (long)s * Lp + q0 + wq], lsum);
       mw.w[wq][s - s0] = w;
+    }
+    if (last) {           // the merged (M, l) ride on the barrier the last chunk needs anyway: one barrier in all for <= 64 splits
+      lsum += __shfl_xor(lsum, 1);
+      lsum += __shfl_xor(lsum, 2);
+      lsum += __shfl_xor(lsum, 4);
+      if (wq < R && j == 0) { mw.M[wq] = M; mw.l[wq] = lsum; mw.invl[wq] = 1.0f / lsum; }
     }
     __syncthreads();
 #pragma unroll
@@ -640,13 +647,8 @@ __device__ __forceinline__ void merge_splits(MergeWeights &mw, const float *Opar
         }
       }
     }
-    __syncthreads();
+    if (!last) __syncthreads();      // the next chunk overwrites the staged weights
   }
-  lsum += __shfl_xor(lsum, 1);
-  lsum += __shfl_xor(lsum, 2);
-  lsum += __shfl_xor(lsum, 4);
-  if (wq < R && j == 0) { mw.M[wq] = M; mw.l[wq] = lsum; mw.invl[wq] = 1.0f / lsum; }
-  __syncthreads();
 }
 
 static int merge_rows_per_block(int b, int h, int L) {       // 32 rows, or 8 while 32 would give fewer workgroups than CUs
