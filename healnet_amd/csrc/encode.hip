@@ -82,7 +82,8 @@ __device__ __forceinline__ uint16_t to_bf16(float f) {     // round to nearest e
 
 // PACK > 0: packed context layout (common.h): the D-1 kept channels go to packed_slot(c, PACK), the last channel is
 // dropped (it is minus the sum of the others after normalisation).
-template <int PACK, typename IN>
+// LD: compile-time bound of the output row (16 or 32 columns): every loop below runs over LD candidate channels
+template <int PACK, typename IN, int LD>
 __global__ __launch_bounds__(256) void encode_token_kernel(const IN *__restrict__ data, float *__restrict__ out,
                                                            EncGeom g, long total) {
   long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -90,10 +91,10 @@ __global__ __launch_bounds__(256) void encode_token_kernel(const IN *__restrict_
   long n = gid % g.N;
   int idx[HN_MAX_AXES];
   token_coords(n, g, idx);
-  float v[kMaxNarrow];
+  float v[LD];
   const IN *src = data + gid * g.C;
 #pragma unroll
-  for (int c = 0; c < kMaxNarrow; ++c) {
+  for (int c = 0; c < LD; ++c) {
     float x = 0.0f;
     if (c < g.C) x = in_at(src, c);
     else if (c < g.D) x = pos_feature(c - g.C, idx, g);
@@ -102,39 +103,39 @@ __global__ __launch_bounds__(256) void encode_token_kernel(const IN *__restrict_
   if (g.normalize) {
     float sum = 0.0f;
 #pragma unroll
-    for (int c = 0; c < kMaxNarrow; ++c) sum += (c < g.D) ? v[c] : 0.0f;
+    for (int c = 0; c < LD; ++c) sum += (c < g.D) ? v[c] : 0.0f;
     float mean = sum / (float)g.D;
     float sq = 0.0f;
 #pragma unroll
-    for (int c = 0; c < kMaxNarrow; ++c) {
+    for (int c = 0; c < LD; ++c) {
       float d = (c < g.D) ? v[c] - mean : 0.0f;
       sq += d * d;
     }
     float rstd = 1.0f / sqrtf(sq / (float)g.D + g.eps);
 #pragma unroll
-    for (int c = 0; c < kMaxNarrow; ++c) v[c] = (c < g.D) ? (v[c] - mean) * rstd : 0.0f;
+    for (int c = 0; c < LD; ++c) v[c] = (c < g.D) ? (v[c] - mean) * rstd : 0.0f;
   }
   if (PACK > 0) {
-    float o[kMaxNarrow];
+    float o[LD];
 #pragma unroll
-    for (int c = 0; c < kMaxNarrow; ++c) o[c] = 0.0f;
+    for (int c = 0; c < LD; ++c) o[c] = 0.0f;
 #pragma unroll
     for (int c = 0; c < (PACK <= 4 ? 4 * PACK : 16 + 4 * (PACK - 4)); ++c)
       if (c < g.D - 1) o[packed_slot(c, PACK)] = v[c];
 #pragma unroll
-    for (int c = 0; c < kMaxNarrow; ++c) v[c] = o[c];
+    for (int c = 0; c < LD; ++c) v[c] = o[c];
   }
 #pragma unroll
-  for (int c = 0; c < kMaxNarrow; ++c)
+  for (int c = 0; c < LD; ++c)
     if (c == g.ones_col) v[c] = 1.0f;
   float *dst = out + gid * (long)g.ld_out;
   if ((g.ld_out & 3) == 0) {
 #pragma unroll
-    for (int c = 0; c < kMaxNarrow; c += 4)
+    for (int c = 0; c < LD; c += 4)
       if (c < g.ld_out) *(float4 *)(dst + c) = make_float4(v[c], v[c + 1], v[c + 2], v[c + 3]);
   } else {
 #pragma unroll
-    for (int c = 0; c < kMaxNarrow; ++c)
+    for (int c = 0; c < LD; ++c)
       if (c < g.ld_out) dst[c] = v[c];
   }
 }
@@ -247,16 +248,17 @@ static int launch_encode_t(const IN *data, EncGeom g, int b, float *out, int ld_
   if (g.D <= kMaxNarrow && ld_out <= kMaxNarrow) {
     long blocks = ceil_div_ll(total, 256);
     HN_REQUIRE(pack_ks == 0 || (g.normalize && pack_ks == packed_steps(g.D, ld_out)), HN_E_SHAPE, "encode: pack_ks=%d", pack_ks);
-#define HN_ENC(P_) hipLaunchKernelGGL((encode_token_kernel<P_, IN>), dim3((unsigned)blocks), dim3(256), 0, s, data, out, g, total)
+#define HN_ENC(P_, LD_) hipLaunchKernelGGL((encode_token_kernel<P_, IN, LD_>), dim3((unsigned)blocks), dim3(256), 0, s, data, out, g, total)
+    const bool narrow16 = g.D <= 16 && ld_out <= 16;
     switch (pack_ks) {
-      case 1: HN_ENC(1); break;
-      case 2: HN_ENC(2); break;
-      case 3: HN_ENC(3); break;
-      case 4: HN_ENC(4); break;
-      case 5: HN_ENC(5); break;
-      case 6: HN_ENC(6); break;
-      case 7: HN_ENC(7); break;
-      default: HN_ENC(0); break;
+      case 1: HN_ENC(1, 16); break;
+      case 2: HN_ENC(2, 16); break;
+      case 3: HN_ENC(3, 16); break;
+      case 4: HN_ENC(4, 32); break;      // D = 16 / 17 on a 32-column row
+      case 5: HN_ENC(5, 32); break;
+      case 6: HN_ENC(6, 32); break;
+      case 7: HN_ENC(7, 32); break;
+      default: if (narrow16) HN_ENC(0, 16); else HN_ENC(0, 32); break;
     }
 #undef HN_ENC
   } else {
