@@ -169,8 +169,14 @@ static int attn_prepare(const hn_attn_params *p, const AttnPlan &pl, const float
     }
     gq.C = pl.q; gq.ldc = qpitch; gq.alpha = pl.cscale;
     gq.col_group = pl.dh; gq.col_group_pitch = pl.dhp;
+    // latent self-attention: the K/V projection reads the same LayerNorm-ed x as the query projection -> one launch for both
+    const bool fused_kv = !ctx && !kv_ready;
+    if (fused_kv) {
+      gq.W2 = p->w_kv; gq.C2 = kvbuf; gq.ldc2 = kvpitch; gq.N2 = 2 * pl.inner; gq.alpha2 = 1.0f;
+      gq.col_group2 = pl.dh; gq.col_group_pitch2 = pl.dhp;
+    }
     if ((rc = launch_gemm(gq, s)) != HN_OK) return rc;
-    if (!kv_ready) {
+    if (!kv_ready && !fused_kv) {
       GemmArgs gk = gemm_defaults();
       if (ctx) {
         gk.A = ctx; gk.lda = ld_ctx; gk.M = b * pl.N; gk.K = pl.D;

@@ -184,6 +184,9 @@ struct GemmArgs {
   int act;
   int glu_offset;                              // row offset of the gate half in W / bias (GLU acts)
   int col_group, col_group_pitch;              // out col = (n / col_group) * col_group_pitch + n % col_group (0 = identity)
+  // optional SECOND product on the same (prologued) A in the same launch: C2 = alpha2 * pro(A) W2^T (no bias / act / residual;
+  // same K and ldw; N a multiple of 64).  The Q and K/V projections of a latent self-attention block share their input.
+  const float *W2; float *C2; long ldc2; int N2; float alpha2; int col_group2, col_group_pitch2;
 };
 int launch_gemm(const GemmArgs &g, hipStream_t s);
 

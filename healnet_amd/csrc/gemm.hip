@@ -471,7 +471,13 @@ __global__ __launch_bounds__(256) void gemm_t32a_kernel(GemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int fg = lane >> 4, fi = lane & 15;
-  const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN, z = blockIdx.z;
+  const int m0 = blockIdx.x * TM, z = blockIdx.z;
+  int n0 = blockIdx.y * TN;
+  if (!GLU && g.W2 != nullptr && n0 >= g.N) {     // column tiles past N belong to the second product (workgroup-uniform)
+    n0 -= g.N;
+    g.W = g.W2; g.C = g.C2; g.ldc = g.ldc2; g.N = g.N2; g.alpha = g.alpha2;
+    g.col_group = g.col_group2; g.col_group_pitch = g.col_group_pitch2;
+  }
   const float *__restrict__ A = g.A + (long)z * g.strideA;
   const float *__restrict__ W = g.W + (long)z * g.strideW;
   float *__restrict__ C = g.C + (long)z * g.strideC;
@@ -637,7 +643,26 @@ static bool aligned_eligible(const GemmArgs &g) {
   return true;
 }
 
-int launch_gemm(const GemmArgs &g, hipStream_t s) {
+int launch_gemm(const GemmArgs &g_in, hipStream_t s) {
+  if (g_in.W2 != nullptr) {
+    // two products on one A: a single launch on the resident-A tile kernel when it applies, two launches otherwise
+    const GemmArgs &d = g_in;
+    const bool plain = d.act == ACT_NONE && !d.bias && !d.R && d.batch == 1 && d.N % 64 == 0 && d.K <= 128;
+    if (!(plain && aligned_eligible(d) && ((uintptr_t)d.W2 & 15) == 0 && !(d.M <= 32 && d.K >= 512))) {
+      GemmArgs a = d, b2 = d;
+      a.W2 = nullptr;
+      b2.W2 = nullptr; b2.W = d.W2; b2.C = d.C2; b2.ldc = d.ldc2; b2.N = d.N2; b2.alpha = d.alpha2;
+      b2.col_group = d.col_group2; b2.col_group_pitch = d.col_group_pitch2;
+      const int rc = launch_gemm(a, s);
+      return rc != HN_OK ? rc : launch_gemm(b2, s);
+    }
+    HN_REQUIRE(d.A && d.W && d.C && d.C2, HN_E_NULL, "gemm: NULL operand");
+    dim3 grid(ceil_div(d.M, TM), ceil_div(d.N, TN) + ceil_div(d.N2, TN), 1);
+    hipLaunchKernelGGL((gemm_t32a_kernel<false, 4>), grid, dim3(256), 0, s, d);
+    HN_LAUNCH_CHECK("gemm_t32a(dual)");
+    return HN_OK;
+  }
+  const GemmArgs &g = g_in;
   HN_REQUIRE(g.A && g.W && g.C, HN_E_NULL, "gemm: NULL operand");
   HN_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.batch > 0, HN_E_SHAPE, "gemm: M=%d N=%d K=%d batch=%d", g.M, g.N,
              g.K, g.batch);
