@@ -565,6 +565,123 @@ __global__ __launch_bounds__(256) void gemm_t32a_kernel(GemmArgs g) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// gemm_t32a2_kernel: the K = 256 .. 512 latent GEMMs (attention out-projection, second feed-forward layer: N = 128, so only
+// 2 x M/32 = 256 workgroups at cfg2 -- one wave per SIMD, every barrier and LDS round trip of 16 sequential k-tiles exposed).
+// Same tile, same resident A block, but 8 waves: the second group of four walks the upper half of K on the same output tile
+// with its own W pipeline, so the workgroup goes through K/64 stages instead of K/32; the two partial tiles meet in LDS.
+// ------------------------------------------------------------------------------------------------
+template <int KT>
+__global__ __launch_bounds__(512) void gemm_t32a2_kernel(GemmArgs g) {
+  constexpr int KH = KT / 2;                       // k-tiles per half
+  __shared__ __attribute__((aligned(16))) float As[KT * TM * TK];
+  __shared__ __attribute__((aligned(16))) float Bs[2][2][TN * TK];
+  __shared__ float rstat[2][3][TM];                // per half: sum, sum of squares, (half 0) first element of the row
+
+  const int tid = threadIdx.x, half = tid >> 8, t = tid & 255, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fg = lane >> 4, fi = lane & 15;
+  const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
+  const float *__restrict__ A = g.A;
+  float *__restrict__ C = g.C;
+  const float *bias = g.bias;
+  const float *R = g.R;
+  const i32x4 rsA = make_rsrc(A, rsrc_bytes(g.M, g.lda, g.K));
+  const i32x4 rsW = make_rsrc(g.W, rsrc_bytes(g.N, g.ldw, g.K));
+  const int lr = t >> 3, lc = t & 7;
+  const int nk = (g.K + TK - 1) / TK;              // even, <= KT (launcher)
+  const int nh = nk / 2, kt0 = half * nh;          // this half's k-tiles: kt0 .. kt0 + nh - 1
+  const int sw = (lc ^ (lr & 7)) * 4;
+
+  // ---- far loads first: this half's part of the A block, the residual values (half 0), W tiles 0 / 1 of the half
+  float4 av[KH];
+  const int arowb = (m0 + lr) * (int)g.lda * 4;
+#pragma unroll
+  for (int i = 0; i < KH; ++i) av[i] = buf4(rsA, arowb + min((kt0 + i) * TK + lc * 4, g.K - 4) * 4);
+  float res0[4] = {0.f, 0.f, 0.f, 0.f}, res1[4] = {0.f, 0.f, 0.f, 0.f};
+  if (R && half == 0) {
+    const i32x4 rsR = make_rsrc(R, rsrc_bytes(g.M, g.ldr, g.N));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int off = ((m0 + wm * 16 + 4 * fg + r) * (int)g.ldr + n0 + wn * 32 + fi) * 4;
+      res0[r] = hn_buffer_load_x1(rsR, off, 0, 0);
+      res1[r] = hn_buffer_load_x1(rsR, off + 64, 0, 0);
+    }
+  }
+  WStage wa, wb;
+  load_w_stage<false>(g, rsW, n0, lr, lc, kt0, wa);
+  if (nh > 1) load_w_stage<false>(g, rsW, n0, lr, lc, kt0 + 1, wb);
+
+  // ---- prologue: LayerNorm moments need the whole row = both halves
+  float mu = 0.0f, rs = 1.0f;
+  if (g.pro == PRO_LAYERNORM) {
+    if (half == 0 && lc == 0) rstat[0][2][lr] = av[0].x;
+    __syncthreads();
+    const float x0 = rstat[0][2][lr];
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < KH; ++i) {
+      if (i < nh) {
+        const float km = ((kt0 + i) * TK + lc * 4) < g.K ? 1.0f : 0.0f;
+        const float dx = av[i].x - x0, dy = av[i].y - x0, dz = av[i].z - x0, dw = av[i].w - x0;
+        s1 += km * ((dx + dy) + (dz + dw));
+        s2 += km * ((dx * dx + dy * dy) + (dz * dz + dw * dw));
+      }
+    }
+    s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2); s1 += __shfl_xor(s1, 4);
+    s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2); s2 += __shfl_xor(s2, 4);
+    if (lc == 0) { rstat[half][0][lr] = s1; rstat[half][1][lr] = s2; }
+    __syncthreads();
+    s1 = rstat[0][0][lr] + rstat[1][0][lr];
+    s2 = rstat[0][1][lr] + rstat[1][1][lr];
+    const float inv_k = 1.0f / (float)g.K, dm = s1 * inv_k;
+    mu = x0 + dm;
+    rs = 1.0f / sqrtf(fmaxf(s2 * inv_k - dm * dm, 0.0f) + g.eps);
+  }
+#pragma unroll
+  for (int i = 0; i < KH; ++i) {
+    if (i < nh) {
+      const int k = (kt0 + i) * TK + lc * 4;
+      float4 v = av[i];
+      if (g.pro != PRO_NONE) {
+        const int kc = min(k, g.K - 4);
+        const float4 gm = *(const float4 *)(g.gamma + kc);
+        const float4 bt = *(const float4 *)(g.beta + kc);
+        v.x = (v.x - mu) * rs * gm.x + bt.x; v.y = (v.y - mu) * rs * gm.y + bt.y;
+        v.z = (v.z - mu) * rs * gm.z + bt.z; v.w = (v.w - mu) * rs * gm.w + bt.w;
+      }
+      const float km = k < g.K ? 1.0f : 0.0f;
+      *(float4 *)&As[(kt0 + i) * TM * TK + lr * TK + sw] = make_float4(v.x * km, v.y * km, v.z * km, v.w * km);
+    }
+  }
+  store_w_stage<false>(Bs[half][0], lr, sw, wa);
+  __syncthreads();
+
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, accg0 = {0.f, 0.f, 0.f, 0.f}, accg1 = {0.f, 0.f, 0.f, 0.f};
+  const int arow = wm * 16 + fi, br0 = wn * 32 + fi;
+  for (int i = 0; i < nh; i += 2) {
+    if (i + 2 < nh) load_w_stage<false>(g, rsW, n0, lr, lc, kt0 + i + 2, wa);
+    tile_mfma<false>(As + (kt0 + i) * TM * TK, Bs[half][0], arow, br0, fg, acc0, acc1, accg0, accg1);
+    if (i + 1 < nh) store_w_stage<false>(Bs[half][1], lr, sw, wb);
+    __syncthreads();
+    if (i + 1 >= nh) break;
+    if (i + 3 < nh) load_w_stage<false>(g, rsW, n0, lr, lc, kt0 + i + 3, wb);
+    tile_mfma<false>(As + (kt0 + i + 1) * TM * TK, Bs[half][1], arow, br0, fg, acc0, acc1, accg0, accg1);
+    if (i + 2 < nh) store_w_stage<false>(Bs[half][0], lr, sw, wa);
+    __syncthreads();
+  }
+
+  // ---- the upper half hands its partial tile over through LDS (the W buffers are free after the last barrier)
+  f32x4 *hand = (f32x4 *)&Bs[0][0][0];             // 256 threads x 2 quads = 8 KB
+  if (half == 1) { hand[2 * t] = acc0; hand[2 * t + 1] = acc1; }
+  __syncthreads();
+  if (half == 1) return;
+  acc0 += hand[2 * t];
+  acc1 += hand[2 * t + 1];
+  tile_store<false, true>(g, acc0, accg0, m0 + wm * 16 + 4 * fg, n0 + wn * 32 + fi, bias, R, C, res0);
+  tile_store<false, true>(g, acc1, accg1, m0 + wm * 16 + 4 * fg, n0 + wn * 32 + 16 + fi, bias, R, C, res1);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Skinny variant for M <= 32 rows (the tabular / omic modality: one context token per sample, so the
 // K/V projection is b rows x 2005 features against an 8.2 MB weight -- a weight-streaming, HBM-bound
 // GEMV batch, not MFMA work).  One workgroup produces 4 output columns for all rows: lanes run
@@ -692,6 +809,9 @@ int launch_gemm(const GemmArgs &g_in, hipStream_t s) {
     if (g.K <= 128) {
       if (glu) hipLaunchKernelGGL((gemm_t32a_kernel<true, 4>), grid32, dim3(256), 0, s, g);
       else hipLaunchKernelGGL((gemm_t32a_kernel<false, 4>), grid32, dim3(256), 0, s, g);
+    } else if (g.K <= 512 && !glu && g.batch == 1 && g.K % 64 == 0 && g.K >= 256 && (long)grid32.x * grid32.y <= 1024) {
+      // few workgroups (N = 128 latent GEMMs): the 8-wave split-K form; larger grids keep the 4-wave kernel (more of them per CU)
+      hipLaunchKernelGGL((gemm_t32a2_kernel<16>), grid32, dim3(512), 0, s, g);
     } else if (g.K <= 512 && !glu) {
       hipLaunchKernelGGL((gemm_t32a_kernel<false, 16>), grid32, dim3(256), 0, s, g);
     } else if (glu) {
