@@ -570,12 +570,12 @@ __global__ __launch_bounds__(256) void gemm_t32a_kernel(GemmArgs g) {
 // Same tile, same resident A block, but 8 waves: the second group of four walks the upper half of K on the same output tile
 // with its own W pipeline, so the workgroup goes through K/64 stages instead of K/32; the two partial tiles meet in LDS.
 // ------------------------------------------------------------------------------------------------
-template <int KT>
-__global__ __launch_bounds__(512) void gemm_t32a2_kernel(GemmArgs g) {
-  constexpr int KH = KT / 2;                       // k-tiles per half
+template <int KT, int SPLIT>       // SPLIT groups of four waves, each on its own 1/SPLIT of K
+__global__ __launch_bounds__(256 * SPLIT) void gemm_t32a2_kernel(GemmArgs g) {
+  constexpr int KH = KT / SPLIT;                   // k-tiles per group
   __shared__ __attribute__((aligned(16))) float As[KT * TM * TK];
-  __shared__ __attribute__((aligned(16))) float Bs[2][2][TN * TK];
-  __shared__ float rstat[2][3][TM];                // per half: sum, sum of squares, (half 0) first element of the row
+  __shared__ __attribute__((aligned(16))) float Bs[SPLIT][2][TN * TK];
+  __shared__ float rstat[SPLIT][3][TM];                // per half: sum, sum of squares, (half 0) first element of the row
 
   const int tid = threadIdx.x, half = tid >> 8, t = tid & 255, lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(512) void gemm_t32a2_kernel(GemmArgs g) {
   const i32x4 rsW = make_rsrc(g.W, rsrc_bytes(g.N, g.ldw, g.K));
   const int lr = t >> 3, lc = t & 7;
   const int nk = (g.K + TK - 1) / TK;              // even, <= KT (launcher)
-  const int nh = nk / 2, kt0 = half * nh;          // this half's k-tiles: kt0 .. kt0 + nh - 1
+  const int nh = nk / SPLIT, kt0 = half * nh;      // this group's k-tiles: kt0 .. kt0 + nh - 1
   const int sw = (lc ^ (lr & 7)) * 4;
 
   // ---- far loads first: this half's part of the A block, the residual values (half 0), W tiles 0 / 1 of the half
@@ -631,8 +631,9 @@ __global__ __launch_bounds__(512) void gemm_t32a2_kernel(GemmArgs g) {
     s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2); s2 += __shfl_xor(s2, 4);
     if (lc == 0) { rstat[half][0][lr] = s1; rstat[half][1][lr] = s2; }
     __syncthreads();
-    s1 = rstat[0][0][lr] + rstat[1][0][lr];
-    s2 = rstat[0][1][lr] + rstat[1][1][lr];
+    s1 = 0.0f; s2 = 0.0f;
+#pragma unroll
+    for (int h = 0; h < SPLIT; ++h) { s1 += rstat[h][0][lr]; s2 += rstat[h][1][lr]; }
     const float inv_k = 1.0f / (float)g.K, dm = s1 * inv_k;
     mu = x0 + dm;
     rs = 1.0f / sqrtf(fmaxf(s2 * inv_k - dm * dm, 0.0f) + g.eps);
@@ -671,12 +672,12 @@ __global__ __launch_bounds__(512) void gemm_t32a2_kernel(GemmArgs g) {
   }
 
   // ---- the upper half hands its partial tile over through LDS (the W buffers are free after the last barrier)
-  f32x4 *hand = (f32x4 *)&Bs[0][0][0];             // 256 threads x 2 quads = 8 KB
-  if (half == 1) { hand[2 * t] = acc0; hand[2 * t + 1] = acc1; }
+  f32x4 *hand = (f32x4 *)&Bs[0][0][0];             // (SPLIT - 1) x 256 threads x 2 quads = 8 KB per group
+  if (half > 0) { hand[(half - 1) * 512 + 2 * t] = acc0; hand[(half - 1) * 512 + 2 * t + 1] = acc1; }
   __syncthreads();
-  if (half == 1) return;
-  acc0 += hand[2 * t];
-  acc1 += hand[2 * t + 1];
+  if (half > 0) return;
+#pragma unroll
+  for (int h = 0; h < SPLIT - 1; ++h) { acc0 += hand[h * 512 + 2 * t]; acc1 += hand[h * 512 + 2 * t + 1]; }
   tile_store<false, true>(g, acc0, accg0, m0 + wm * 16 + 4 * fg, n0 + wn * 32 + fi, bias, R, C, res0);
   tile_store<false, true>(g, acc1, accg1, m0 + wm * 16 + 4 * fg, n0 + wn * 32 + 16 + fi, bias, R, C, res1);
 }
@@ -811,7 +812,7 @@ int launch_gemm(const GemmArgs &g_in, hipStream_t s) {
       else hipLaunchKernelGGL((gemm_t32a_kernel<false, 4>), grid32, dim3(256), 0, s, g);
     } else if (g.K <= 512 && !glu && g.batch == 1 && g.K % 64 == 0 && g.K >= 256 && (long)grid32.x * grid32.y <= 1024) {
       // few workgroups (N = 128 latent GEMMs): the 8-wave split-K form; larger grids keep the 4-wave kernel (more of them per CU)
-      hipLaunchKernelGGL((gemm_t32a2_kernel<16>), grid32, dim3(512), 0, s, g);
+      hipLaunchKernelGGL((gemm_t32a2_kernel<16, 2>), grid32, dim3(512), 0, s, g);      // (a 4-way split measured the same)
     } else if (g.K <= 512 && !glu) {
       hipLaunchKernelGGL((gemm_t32a_kernel<false, 16>), grid32, dim3(256), 0, s, g);
     } else if (glu) {
