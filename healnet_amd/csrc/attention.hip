@@ -394,7 +394,11 @@ int launch_attn_core(const AttnCoreArgs &a, hipStream_t s) {
   HN_REQUIRE(a.Ofinal == nullptr || (a.nsplit == 1 && !a.ones_col), HN_E_SHAPE, "attn_core: direct output needs a single split");
   HN_REQUIRE(!a.ones_col || (a.dp <= 32 && a.Kp == a.Vp), HN_E_UNSUPPORTED, "attn_core: ones column needs the shared-context binding");
   HN_REQUIRE(a.drop.thr == 0 || !a.ones_col, HN_E_SHAPE, "attn_core: dropout needs the explicit denominator (ones_col = 0)");
-  const int dt = a.dp / 16, nq = nq_for(dt);
+  const int dt = a.dp / 16;
+  int nq = nq_for(dt);
+  // latent self-attention (dp = 64, one split) at small batches: fewer than one wave per two SIMDs with 2 tiles per wave;
+  // one tile per wave doubles the resident waves (b = 1: 0.92 -> 0.90 ms per forward; no gain from b = 32 on)
+  if (dt == 4 && a.nsplit == 1 && !a.ones_col && a.drop.thr == 0 && (long)a.b * a.h * ceil_div(a.Lp / 16, 2) <= 512) nq = 1;
   const int ngroups = ceil_div(a.Lp / 16, nq);
   const int wpb = ngroups < 4 ? ngroups : 4;
   const int gy = ceil_div(ngroups, wpb);
@@ -432,7 +436,8 @@ int launch_attn_core(const AttnCoreArgs &a, hipStream_t s) {
   } else if (dt == 2) {
     HN_CORE(2, 2, false, 8);
   } else if (dt == 4) {
-    HN_CORE(4, 2, false, 16);
+    if (nq == 1) HN_CORE(4, 1, false, 16);
+    else HN_CORE(4, 2, false, 16);
   } else {
     HN_CORE(8, 1, false, 32);
   }
