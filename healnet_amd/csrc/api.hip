@@ -231,9 +231,8 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
     gy.bias = p->b_out; gy.act = ACT_LEAKY;
     gy.C = ybuf; gy.ldc = p->query_dim;
     if ((rc = launch_gemm(gy, s)) != HN_OK) return rc;
-    if (stats) {   // p == 1: any (max, sum) pair with sum 1 and max == the score reproduces it; hn_attn_probs special-cases N == 1
-      if ((rc = launch_fill(stats, 1.0f, (long)b * p->heads * L * 2, s)) != HN_OK) return rc;
-    }
+    // (`stats` is not written on this path: p == 1 for every row, and hn_attn_probs / hn_attn_importance / the backward
+    // special-case a one-token context without a mask instead of reading it)
     return launch_add_row_broadcast(ybuf, residual ? x_in : nullptr, x_out, b, L, p->query_dim, s);
   }
 
@@ -1146,8 +1145,6 @@ int hn_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, con
     }
     if (rc != HN_OK) return rc;
   }
-  if ((rc = launch_fill((float *)fp.flags, 0.0f, (long)m->depth * M, s)) != HN_OK) return rc;
-
   // The latent array moves through a chain of buffers instead of being updated in place: the block in front of an
   // attention block writes straight into that block's x_trace slot (the input hn_attn_probs re-reads later), so
   // keeping the trace costs no copy.  Without trace slots every block works in place on fp.x as before.
@@ -1161,7 +1158,7 @@ int hn_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, con
     return fp.x;
   };
   float *cur = input_buffer(0);
-  if ((rc = launch_broadcast_rows(m->latents, cur, (long)L * d, b, s)) != HN_OK) return rc;   // :225
+  if ((rc = launch_broadcast_rows(m->latents, cur, (long)L * d, b, s, fp.flags, m->depth * M)) != HN_OK) return rc;   // :225 (+ the bound flags)
   const bool head = m->final_classifier_head && !return_embeddings;
   for (int k = 0; k < nsteps; ++k) {
     const Step &st = steps[k];

@@ -336,7 +336,7 @@ int launch_kv_weight_grads(const float *G, const float *cs, const float *w, cons
 int launch_segsum(const float *X, int seg, int cols, int nseg, float *out, hipStream_t s);
 
 // misc
-int launch_broadcast_rows(const float *src, float *dst, long n_per, int b, hipStream_t s);
+int launch_broadcast_rows(const float *src, float *dst, long n_per, int b, hipStream_t s, int *zero = nullptr, int nzero = 0);
 int launch_head(const float *x, int b, int L, int d, const float *nw, const float *nb, const float *w,
                 const float *bias, int out_dims, float *logits, hipStream_t s);
 int launch_pad_rows(const float *src, int ld_src, float *dst, int ld_dst, long rows, int cols, hipStream_t s);

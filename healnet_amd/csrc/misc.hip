@@ -4,17 +4,20 @@
 
 namespace hn {
 
+// (also clears `nzero` ints at `zero`: the score-bound fallback flags of a forward ride on this launch)
 __global__ __launch_bounds__(256) void broadcast_rows_kernel(const float *__restrict__ src, float *__restrict__ dst,
-                                                             long n_per, long total) {
+                                                             long n_per, long total, int *__restrict__ zero, int nzero) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
     dst[i] = src[i % n_per];
+  if (blockIdx.x == 0)
+    for (int i = threadIdx.x; i < nzero; i += blockDim.x) zero[i] = 0;
 }
 
-int launch_broadcast_rows(const float *src, float *dst, long n_per, int b, hipStream_t s) {
+int launch_broadcast_rows(const float *src, float *dst, long n_per, int b, hipStream_t s, int *zero, int nzero) {
   long total = n_per * b;
   long blocks = ceil_div_ll(total, 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(broadcast_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, n_per, total);
+  hipLaunchKernelGGL(broadcast_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, n_per, total, zero, zero ? nzero : 0);
   HN_LAUNCH_CHECK("broadcast_rows");
   return HN_OK;
 }

@@ -117,7 +117,8 @@ typedef struct hn_attn_params {
  *   x_in  (b, L, query_dim); x_out may alias x_in;  residual != 0 adds the un-normalised x_in (:236).
  *   ctx   (b, N, ld_ctx) with D valid columns, or NULL for self-attention (context = normalised x, :404).
  *   mask  (b, N) bytes, 0 = masked out (sim <- -FLT_MAX, :411-415), or NULL.
- *   stats optional (b, heads, L, 2): per row {max of scaled logits in log2 units, sum of 2^(s-max)};
+ *   stats optional (b, heads, L, 2): per row {max of scaled logits in log2 units, sum of 2^(s-max)} (left untouched for a
+ *         one-token context without a mask: every probability is 1 and nothing reads it there);
  *         with it hn_attn_probs re-creates Attention.attn_weights (:420) on demand.
  * The kernels pick the rank-D reassociated path when ld_ctx is a hn_context_pitch() pitch of 16/32
  * and D < dim_head, and the explicit K/V path otherwise. */
