@@ -734,6 +734,8 @@ struct FusionPlan {
   bool bf16[16];   // core_precision = bf16: z holds the bf16 images (zb, then zT) instead of the fp32 rows
   int Np[16], ns[16];
   int *flags;      // one pre-zeroed fallback flag of the score-bound softmax per (layer, modality)
+  float *tabv[16], *taby[16];   // one-token modalities (inference): V (depth, b, inner) and block outputs (depth, b, query_dim) of ALL layers
+  bool tab_ahead[16];           // ... computed ahead of the layer loop in two batched launches
   void *op_ws;
   size_t op_ws_bytes, bytes;
   int dominant;   // modality with the most tokens among the present ones
@@ -796,6 +798,24 @@ static int plan_fusion(const hn_model *m, const hn_modality_input *in, int b, vo
       if (zb16 > zbytes) zbytes = zb16;
     }
     fp->z[i] = (float *)ar.take<char>(zbytes);
+    // one-token context (tabular / omic): y_l = LeakyReLU(W_out,l (W_v,l c_hat_l) + b_out,l) does not depend on the latent array,
+    // so the inference forward evaluates all layers' vectors up front (weight-streaming GEMV shapes only, equal heads / dims)
+    fp->tab_ahead[i] = false;
+    fp->tabv[i] = fp->taby[i] = nullptr;
+    if (inference && n == 1 && m->depth <= HN_SKINNY_MAXZ && fp->D[i] >= 512 && b <= 512) {
+      bool same = true;
+      for (int layer = 1; layer < m->depth; ++layer) {
+        const hn_attn_params &a0 = m->cross_attn[i], &al = m->cross_attn[layer * m->n_modalities + i];
+        same = same && al.heads == a0.heads && al.dim_head == a0.dim_head && al.query_dim == a0.query_dim &&
+               (al.ctx_gamma != nullptr) == (a0.ctx_gamma != nullptr);
+      }
+      const int inner0 = ap->heads * ap->dim_head;
+      if (same && inner0 >= 512) {
+        fp->tab_ahead[i] = true;
+        fp->tabv[i] = ar.take<float>((size_t)m->depth * b * inner0);
+        fp->taby[i] = ar.take<float>((size_t)m->depth * b * ap->query_dim);
+      }
+    }
     if (n > best) { best = n; fp->dominant = i; }
     for (int layer = 0; layer < m->depth; ++layer) {
       AttnPlan pl;
@@ -1145,6 +1165,34 @@ int hn_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, con
     }
     if (rc != HN_OK) return rc;
   }
+  // one-token modalities: all layers' block outputs in two batched launches (a key mask routes them through the general path)
+  bool tab_ready[16];
+  for (int i = 0; i < M; ++i) {
+    tab_ready[i] = false;
+    if (!in[i].data || !fp.tab_ahead[i] || mask != nullptr) continue;
+    const hn_attn_params &a0 = m->cross_attn[i];
+    const int inner = a0.heads * a0.dim_head;
+    GemmSkinnyMulti gv, gy;
+    memset(&gv, 0, sizeof(gv));
+    memset(&gy, 0, sizeof(gy));
+    gv.nz = gy.nz = m->depth;
+    gv.lda = fp.ldz[i]; gv.ldw = fp.D[i]; gv.ldc = inner; gv.M = b; gv.N = inner; gv.K = fp.D[i];
+    gv.pro = a0.ctx_gamma ? PRO_AFFINE : PRO_NONE; gv.act = ACT_NONE;
+    gy.lda = inner; gy.ldw = inner; gy.ldc = a0.query_dim; gy.M = b; gy.N = a0.query_dim; gy.K = inner;
+    gy.pro = PRO_NONE; gy.act = ACT_LEAKY;
+    for (int layer = 0; layer < m->depth; ++layer) {
+      const hn_attn_params &al = m->cross_attn[layer * M + i];
+      HN_REQUIRE(al.w_kv && al.w_out, HN_E_NULL, "attn: weight pointer is NULL");
+      gv.A[layer] = fp.z[i]; gv.W[layer] = al.w_kv + (long)inner * fp.D[i]; gv.gamma[layer] = al.ctx_gamma; gv.beta[layer] = al.ctx_beta;
+      gv.C[layer] = fp.tabv[i] + (size_t)layer * b * inner;
+      gy.A[layer] = gv.C[layer]; gy.W[layer] = al.w_out; gy.bias[layer] = al.b_out;
+      gy.C[layer] = fp.taby[i] + (size_t)layer * b * a0.query_dim;
+    }
+    if ((rc = launch_gemm_skinny_multi(gv, s)) != HN_OK) return rc;
+    if ((rc = launch_gemm_skinny_multi(gy, s)) != HN_OK) return rc;
+    tab_ready[i] = true;
+  }
+
   // The latent array moves through a chain of buffers instead of being updated in place: the block in front of an
   // attention block writes straight into that block's x_trace slot (the input hn_attn_probs re-reads later), so
   // keeping the trace costs no copy.  Without trace slots every block works in place on fp.x as before.
@@ -1167,6 +1215,10 @@ int hn_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, con
     switch (st.kind) {
       case STEP_CROSS_ATTN: {
         const hn_attn_params *ap = &m->cross_attn[layer * M + i];
+        if (tab_ready[i]) {     // x <- x + y_layer broadcast over the latent rows (healnet.py:236 with softmax == 1)
+          rc = launch_add_row_broadcast(fp.taby[i] + (size_t)layer * b * ap->query_dim, cur, dst, b, L, ap->query_dim, s);
+          break;
+        }
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (prof && i == fp.dominant && prof->n_recorded < prof->n_events) {
           e0 = (hipEvent_t)prof->ev_start[prof->n_recorded];

@@ -190,6 +190,20 @@ struct GemmArgs {
 };
 int launch_gemm(const GemmArgs &g, hipStream_t s);
 
+// Several skinny products of one shape in ONE launch, operands given per entry (the one-token projections of all layers of a
+// forward: they do not depend on the latent array, and each is a ~9 us latency-bound launch on its own)
+constexpr int HN_SKINNY_MAXZ = 16;
+struct GemmSkinnyMulti {
+  int nz;
+  const float *A[HN_SKINNY_MAXZ]; long lda;
+  const float *W[HN_SKINNY_MAXZ]; long ldw;
+  const float *gamma[HN_SKINNY_MAXZ], *beta[HN_SKINNY_MAXZ];     // PRO_AFFINE operands (pro != PRO_NONE)
+  const float *bias[HN_SKINNY_MAXZ];                              // may hold NULLs
+  float *C[HN_SKINNY_MAXZ]; long ldc;
+  int M, N, K, pro, act;
+};
+int launch_gemm_skinny_multi(const GemmSkinnyMulti &g, hipStream_t s);
+
 // ------------------------------------------------------------------------------------------------
 // encode
 // ------------------------------------------------------------------------------------------------

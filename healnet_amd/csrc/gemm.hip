@@ -752,6 +752,69 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
   }
 }
 
+// gemm_skinny_kernel with per-entry operands (blockIdx.z): see GemmSkinnyMulti
+__global__ __launch_bounds__(256) void gemm_skinny_multi_kernel(GemmSkinnyMulti g) {
+  constexpr int SN = 4, SM = 32;
+  __shared__ float part[4][SM * SN];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n0 = blockIdx.x * SN, z = blockIdx.z, m0 = blockIdx.y * SM;
+  const float *gam_p = g.gamma[z], *bet_p = g.beta[z], *bias = g.bias[z];
+  float *C = g.C[z];
+  const i32x4 rsA = make_rsrc(g.A[z], rsrc_bytes(g.M, g.lda, g.K));
+  const i32x4 rsW = make_rsrc(g.W[z], rsrc_bytes(g.N, g.ldw, g.K));
+  float acc[SM * SN];
+#pragma unroll
+  for (int i = 0; i < SM * SN; ++i) acc[i] = 0.0f;
+  for (int k0 = wave * 64; k0 < g.K; k0 += 256) {
+    const int k = k0 + lane;
+    const float km = k < g.K ? 1.0f : 0.0f;
+    const int kc = min(k, g.K - 1);
+    float w[SN], av[SM];
+#pragma unroll
+    for (int j = 0; j < SN; ++j) w[j] = hn_buffer_load_x1(rsW, ((n0 + j) * (int)g.ldw + kc) * 4, 0, 0);
+#pragma unroll
+    for (int m = 0; m < SM; ++m) av[m] = hn_buffer_load_x1(rsA, ((m0 + m) * (int)g.lda + kc) * 4, 0, 0);
+    float gam = 1.0f, bet = 0.0f;
+    if (g.pro == PRO_AFFINE) { gam = gam_p[kc]; bet = bet_p[kc]; }
+    gam *= km;
+    bet *= km;
+#pragma unroll
+    for (int m = 0; m < SM; ++m) {
+      const float a = av[m] * gam + bet;
+#pragma unroll
+      for (int j = 0; j < SN; ++j) acc[m * SN + j] = fmaf(a, w[j], acc[m * SN + j]);
+    }
+  }
+  fold_half<64>(acc, lane, 32);
+  fold_half<32>(acc, lane, 16);
+  fold_half<16>(acc, lane, 8);
+  fold_half<8>(acc, lane, 4);
+  fold_half<4>(acc, lane, 2);
+  fold_half<2>(acc, lane, 1);
+  part[wave][2 * lane] = acc[0];
+  part[wave][2 * lane + 1] = acc[1];
+  __syncthreads();
+  if (threadIdx.x < SM * SN) {
+    const int idx = threadIdx.x, m = m0 + idx / SN, n = n0 + idx % SN;
+    if (m < g.M && n < g.N) {
+      float v = part[0][idx] + part[1][idx] + part[2][idx] + part[3][idx];
+      if (bias) v += bias[n];
+      if (g.act == ACT_LEAKY) v = v > 0.0f ? v : 0.01f * v;
+      C[(long)m * g.ldc + n] = v;
+    }
+  }
+}
+
+int launch_gemm_skinny_multi(const GemmSkinnyMulti &g, hipStream_t s) {
+  HN_REQUIRE(g.nz >= 1 && g.nz <= HN_SKINNY_MAXZ && g.M > 0 && g.N > 0 && g.K > 0, HN_E_SHAPE, "gemm_skinny_multi: nz=%d M=%d N=%d K=%d",
+             g.nz, g.M, g.N, g.K);
+  HN_REQUIRE(((long)(g.M + 64) * g.lda) * 4 < (1L << 31) && ((long)(g.N + 64) * g.ldw) * 4 < (1L << 31), HN_E_UNSUPPORTED,
+             "gemm_skinny_multi: an operand spans more than 2 GiB");
+  hipLaunchKernelGGL(gemm_skinny_multi_kernel, dim3(ceil_div(g.N, 4), ceil_div(g.M, 32), g.nz), dim3(256), 0, s, g);
+  HN_LAUNCH_CHECK("gemm_skinny_multi");
+  return HN_OK;
+}
+
 static bool aligned_eligible(const GemmArgs &g) {
   auto al16 = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
   if (g.K % 4 != 0 || g.lda % 4 != 0 || g.ldw % 4 != 0) return false;
