@@ -674,6 +674,13 @@ __global__ __launch_bounds__(256) void merge_vproj_kernel(const float *__restric
   const long pbase = (long)bh * nsplit * Lp;
   const int dlim = pack_ks ? dp : D;
   __shared__ MergeWeights mw;
+  // the head's W_v block (dh x D, contiguous) and the affine vectors come in with coalesced loads FIRST -- they overlap the split
+  // merge -- and the folded projection image is built from LDS afterwards (a per-element loop over D with dependent global
+  // loads used to be this kernel's longest chain)
+  float *raw = wv + dh * (dp + 1);       // [dh][D]
+  float *gb = raw + dh * D;              // gamma[D], beta[D]
+  for (int idx = threadIdx.x; idx < dh * D; idx += blockDim.x) raw[idx] = w_v[(long)hi * dh * D + idx];
+  for (int idx = threadIdx.x; idx < D; idx += blockDim.x) { gb[idx] = gamma ? gamma[idx] : 1.0f; gb[D + idx] = beta ? beta[idx] : 0.0f; }
   float acc[4];                          // R * dp <= 32 * 32 elements
   // srow: column dp-1 carries the dropped row sum (see attn_core)
   merge_splits<4>(mw, Opart, Mpart, Lpart, pbase, nsplit, Lp, dp, q0, L, R, dp,
@@ -695,16 +702,16 @@ __global__ __launch_bounds__(256) void merge_vproj_kernel(const float *__restric
   }
   for (int idx = threadIdx.x; idx < dh * (dp + 1); idx += blockDim.x) {
     const int e = idx / (dp + 1), d = idx % (dp + 1);
-    const float *wr = w_v + (long)(hi * dh + e) * D;
+    const float *wr = raw + e * D;
     float w = 0.0f;
     if (d == dp) {
-      if (beta) for (int c = 0; c < D; ++c) w = fmaf(beta[c], wr[c], w);
+      for (int c = 0; c < D; ++c) w = fmaf(gb[D + c], wr[c], w);
     } else if (pack_ks == 0) {
-      if (d < D) w = wr[d] * (gamma ? gamma[d] : 1.0f);
+      if (d < D) w = wr[d] * gb[d];
     } else {
       // packed layout: the dropped channel of the averaged row is minus the sum of the kept ones
       const int c = packed_chan(d, pack_ks);
-      if (c >= 0 && c < D - 1) w = wr[c] * (gamma ? gamma[c] : 1.0f) - wr[D - 1] * (gamma ? gamma[D - 1] : 1.0f);
+      if (c >= 0 && c < D - 1) w = wr[c] * gb[c] - wr[D - 1] * gb[D - 1];
     }
     wv[idx] = w;
   }
@@ -733,7 +740,7 @@ __global__ __launch_bounds__(256) void merge_vproj_kernel(const float *__restric
 int launch_merge_vproj(const float *Opart, const float *Mpart, const float *Lpart, int nsplit, int b, int h, int L,
                        int Lp, int dp, int D, const float *gamma, const float *beta, const float *w_v, int dh,
                        float *O, int ldo, float *stats, float *oprime_save, hipStream_t s, int pack_ks, int srow) {
-  size_t lds = ((size_t)MERGE_ROWS * (dp + 1) + (size_t)dh * (dp + 1)) * sizeof(float);
+  size_t lds = ((size_t)MERGE_ROWS * (dp + 1) + (size_t)dh * (dp + 1) + (size_t)dh * D + 2 * (size_t)D) * sizeof(float);
   HN_REQUIRE(!(pack_ks && srow), HN_E_SHAPE, "merge_vproj: the row-sum channel needs the natural channel layout");
   HN_REQUIRE(dp <= 32, HN_E_UNSUPPORTED, "merge_vproj: dp=%d", dp);
   const int R = merge_rows_per_block(b, h, L);
