@@ -83,9 +83,12 @@ __device__ __forceinline__ uint16_t to_bf16(float f) {     // round to nearest e
 // PACK > 0: packed context layout (common.h): the D-1 kept channels go to packed_slot(c, PACK), the last channel is
 // dropped (it is minus the sum of the others after normalisation).
 // LD: compile-time bound of the output row (16 or 32 columns): every loop below runs over LD candidate channels
-template <int PACK, typename IN, int LD>
+// SC / SA / SF > 0: channel count, axes and frequency bands known at compile time (RGB image: 3, 2, 2; RGB volume: 3, 3, 2) --
+// every predicate and index computation of the generic formulation folds away
+template <int PACK, typename IN, int LD, int SC = 0, int SA = 0, int SF = 0>
 __global__ __launch_bounds__(256) void encode_token_kernel(const IN *__restrict__ data, float *__restrict__ out,
                                                            EncGeom g, long total) {
+  if (SC > 0) { g.C = SC; g.n_axes = SA; g.F = SF; g.D = SC + SA * (2 * SF + 1); }
   long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= total) return;
   long n = gid % g.N;
@@ -250,6 +253,19 @@ static int launch_encode_t(const IN *data, EncGeom g, int b, float *out, int ld_
     HN_REQUIRE(pack_ks == 0 || (g.normalize && pack_ks == packed_steps(g.D, ld_out)), HN_E_SHAPE, "encode: pack_ks=%d", pack_ks);
 #define HN_ENC(P_, LD_) hipLaunchKernelGGL((encode_token_kernel<P_, IN, LD_>), dim3((unsigned)blocks), dim3(256), 0, s, data, out, g, total)
     const bool narrow16 = g.D <= 16 && ld_out <= 16;
+    // the two shapes of the BASELINE configs get fully static kernels
+#define HN_ENC_S(P_, LD_, C_, A_, F_) hipLaunchKernelGGL((encode_token_kernel<P_, IN, LD_, C_, A_, F_>), dim3((unsigned)blocks), dim3(256), 0, s, data, out, g, total)
+    if (g.fourier && g.C == 3 && g.F == 2 && g.n_axes == 2 && ld_out == 16 && (pack_ks == 0 || pack_ks == 3)) {
+      if (pack_ks == 3) HN_ENC_S(3, 16, 3, 2, 2); else HN_ENC_S(0, 16, 3, 2, 2);
+      HN_LAUNCH_CHECK("encode(static image)");
+      return HN_OK;
+    }
+    if (g.fourier && g.C == 3 && g.F == 2 && g.n_axes == 3 && ld_out == 32 && (pack_ks == 0 || pack_ks == 5)) {
+      if (pack_ks == 5) HN_ENC_S(5, 32, 3, 3, 2); else HN_ENC_S(0, 32, 3, 3, 2);
+      HN_LAUNCH_CHECK("encode(static volume)");
+      return HN_OK;
+    }
+#undef HN_ENC_S
     switch (pack_ks) {
       case 1: HN_ENC(1, 16); break;
       case 2: HN_ENC(2, 16); break;
