@@ -728,16 +728,28 @@ int launch_kv_weight_grads(const float *G, const float *cs, const float *w, cons
 
 // out[seg, c] = sum of `seg` consecutive rows of X (nseg segments): per-sample sums over the latent rows
 __global__ __launch_bounds__(256) void segsum_kernel(const float *__restrict__ X, int seg, int cols, float *__restrict__ out) {
+  // 64 columns per workgroup, the 4 waves split the segment's rows (4 independent chains each), fixed-order LDS reduce
+  __shared__ float part[4][64];
   const int sidx = blockIdx.y;
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= cols) return;
-  float s = 0.0f;
-  for (int r = 0; r < seg; ++r) s += X[((long)sidx * seg + r) * cols + c];
-  out[(long)sidx * cols + c] = s;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+  if (c < cols) {
+    const float *base = X + (long)sidx * seg * cols + c;
+    int r = w;
+    for (; r + 12 < seg; r += 16) {
+      s0 += base[(long)r * cols]; s1 += base[(long)(r + 4) * cols];
+      s2 += base[(long)(r + 8) * cols]; s3 += base[(long)(r + 12) * cols];
+    }
+    for (; r < seg; r += 4) s0 += base[(long)r * cols];
+  }
+  part[w][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (w == 0 && c < cols) out[(long)sidx * cols + c] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 
 int launch_segsum(const float *X, int seg, int cols, int nseg, float *out, hipStream_t s) {
-  hipLaunchKernelGGL(segsum_kernel, dim3(ceil_div(cols, 256), nseg), dim3(256), 0, s, X, seg, cols, out);
+  hipLaunchKernelGGL(segsum_kernel, dim3(ceil_div(cols, 64), nseg), dim3(256), 0, s, X, seg, cols, out);
   HN_LAUNCH_CHECK("segsum");
   return HN_OK;
 }
