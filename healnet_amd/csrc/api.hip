@@ -1274,7 +1274,9 @@ static void train_context_layout(const hn_model *m, const FusionPlan &fp, bool *
       affine = affine && ap.ctx_gamma != nullptr;
     }
     ones[i] = fp.z[i] != nullptr && fp.ones[i] && !dropping && affine;
-    pack[i] = ones[i] ? fp.pack[i] : 0;
+    // (the backward's dq kernel has no variant whose last 16-column block contributes zero k-steps: D = 16 / 17 on a 32-column
+    // row packs into exactly 4 steps -- that shape trains on the natural layout)
+    pack[i] = (ones[i] && fp.pack[i] % 4 != 0) ? fp.pack[i] : 0;
   }
 }
 

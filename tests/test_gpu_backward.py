@@ -221,6 +221,8 @@ PACKED = {   # packed shared-context layouts of the training path: (channels, sp
     "packed_ks6": (9, (4, 3, 2), 32),     # D = 24 -> ks = 6
     "packed_ks7": (22, (11,), 32),        # D = 27 -> ks = 7
     "natural_d16": (11, (6,), 16),        # D = 16 == dp: no free column, natural layout, synthetic ones column
+    "ks4_dp32": (11, (6,), 32),           # D = 16 on a 32-column row: packs into exactly 4 k-steps at inference, natural in training
+    "ks4_dp32_d17": (12, (6,), 32),       # D = 17: same
     "packed_masked": (3, (6, 5), 64, dict(), True),                 # image-like D = 13 (ks = 3) with a key mask
 }
 

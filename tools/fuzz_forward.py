@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""Randomised whole-model parity: random modality mixes (axes, channels, token counts), head counts / dims, latent sizes,
+batch sizes, key masks, missing modalities, on BOTH forwards (inference under no_grad, tape-recording with grad mode on) and
+the backward, against the CPU oracle.  Every fast path has entry conditions on these shapes; the BASELINE configs only
+exercise a few of them.
+
+    python tools/fuzz_forward.py [--n 60] [--seed 0] [--backward]
+"""
+import argparse, os, random, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import healnet_amd as hn
+from oracle import healnet_cpu as O
+
+DEV = "cuda:0"
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def random_case(rng):
+    M = rng.choice([1, 2, 2, 3])
+    chans, axes, shapes = [], [], []
+    masked = rng.random() < 0.25
+    n_tokens = None
+    for _ in range(M):
+        kind = rng.choice(["tab", "tab_wide", "seq", "img", "vol", "bag"])
+        if masked:       # one mask for every modality: equal token counts
+            kind = rng.choice(["seq", "bag"])
+        if kind == "tab":
+            c, sh = rng.choice([3, 6, 20, 40]), (1,)
+        elif kind == "tab_wide":
+            c, sh = rng.choice([600, 2000]), (1,)
+        elif kind == "seq":
+            c, sh = rng.choice([1, 2, 5, 9, 24]), (rng.choice([2, 7, 33, 200]),)
+        elif kind == "img":
+            c, sh = rng.choice([1, 3, 4]), (rng.choice([3, 9, 17]), rng.choice([4, 8, 21]))
+        elif kind == "vol":
+            c, sh = rng.choice([1, 3]), (rng.choice([2, 3]), rng.choice([3, 5]), rng.choice([4, 6]))
+        else:
+            c, sh = rng.choice([70, 96, 130]), (rng.choice([5, 64, 300]),)
+        if masked:
+            if n_tokens is None:
+                n_tokens = sh[0]
+            sh = (n_tokens,)
+        chans.append(c); axes.append(len(sh)); shapes.append(sh)
+    l_d = rng.choice([16, 32, 64, 128])
+    heads = rng.choice([1, 2, 4, 8])
+    kw = dict(n_modalities=M, channel_dims=chans, num_spatial_axes=axes, out_dims=rng.choice([2, 4]), depth=rng.choice([1, 2, 3]),
+              l_c=rng.choice([4, 16, 24, 128]), l_d=l_d, x_heads=heads, l_heads=rng.choice([1, 2, 4]),
+              cross_dim_head=rng.choice([4, 8, 16, 32, 64]), latent_dim_head=rng.choice([8, 16, 64]),
+              num_freq_bands=rng.choice([1, 2, 2, 4]), max_freq=rng.choice([2.0, 10.0]), snn=rng.random() < 0.7,
+              weight_tie_layers=rng.random() < 0.2, self_per_cross_attn=rng.choice([0, 1, 1, 1]),
+              fourier_encode_data=rng.random() < 0.85, final_classifier_head=rng.random() < 0.85)
+    b = rng.choice([1, 2, 3, 5, 33, 40])
+    if max(max(s) for s in shapes) >= 200 or max(chans) >= 600:
+        b = min(b, 5)
+    return kw, shapes, b, masked
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=60)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--backward", action="store_true")
+    ap.add_argument("--data-seed", type=int, default=0, help="offset of the input / weight seeds (same configurations, other numbers)")
+    ap.add_argument("--only", type=int, nargs="*", default=None, help="case indices to run (the others are generated and skipped)")
+    args = ap.parse_args(argv)
+    rng = random.Random(args.seed)
+    worst = 0.0
+    bad = 0
+    for case in range(args.n):
+        kw, shapes, b, masked = random_case(rng)
+        missing_draw = rng.random(), rng.random()      # drawn for every case so that --only reproduces the same sequence
+        if args.only is not None and case not in args.only:
+            continue
+        torch.manual_seed(1000 + case + 7919 * args.data_seed)
+        try:
+            model = hn.HealNet(**kw).eval()
+        except Exception as e:      # invalid combination for the reference constructor as well
+            print(f"[{case}] skipped at construction: {type(e).__name__}: {e}")
+            continue
+        gen = torch.Generator().manual_seed(case + 104729 * args.data_seed)
+        ins = [torch.rand(b, *s, c, generator=gen) for s, c in zip(shapes, kw["channel_dims"])]
+        missing = None
+        if kw["n_modalities"] > 1 and missing_draw[0] < 0.2:
+            missing = int(missing_draw[1] * kw["n_modalities"])
+            ins[missing] = None
+        mask = None
+        if masked and ins[0] is not None:
+            n = ins[0].shape[1]
+            mask = torch.rand(b, n, generator=gen) > 0.3
+            mask[:, 0] = True
+        # tied parameters (weight_tie_layers) stay ONE leaf tensor under all their keys, as in the reference's module tree
+        leaves = {}
+        sd = {}
+        for k, v in model.state_dict().items():
+            if v.data_ptr() not in leaves:
+                leaves[v.data_ptr()] = v.detach().clone().requires_grad_(args.backward)
+            sd[k] = leaves[v.data_ptr()]
+        cfg = O.FusionConfig(**kw)
+        # smallest |pre-activation| over every LeakyReLU of the oracle forward: below ~1e-5 two correct fp32 forwards can
+        # disagree on its sign and the gradients through that element differ by O(1) -- such cases are
+        # reported as "kink", not as failures
+        margins = []
+        orig_leaky = O.F.leaky_relu
+        def recording_leaky(x, *a, **k):
+            margins.append(float(x.detach().abs().min()))
+            return orig_leaky(x, *a, **k)
+        O.F.leaky_relu = recording_leaky
+        try:
+            with torch.set_grad_enabled(args.backward):
+                want = O.fusion_forward(sd, cfg, ins, mask=mask)
+        finally:
+            O.F.leaky_relu = orig_leaky
+        margin = min(margins) if margins else 1.0
+        model.to(DEV)
+        dins = [None if t is None else t.to(DEV) for t in ins]
+        dmask = None if mask is None else mask.to(DEV)
+        with torch.no_grad():
+            e_inf = rel(model(list(dins), mask=dmask), want.detach())
+        got = model(list(dins), mask=dmask)
+        e_tape = rel(got.detach(), want.detach())
+        e_grad = 0.0
+        if args.backward:
+            dl = torch.randn(want.shape, generator=gen)
+            (want * dl).sum().backward()
+            (got * dl.to(DEV)).sum().backward()
+            refs = {k: (sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])) for k, _ in model.named_parameters()}
+            gmax = max(float(r.abs().max()) for r in refs.values())
+            for k, p in model.named_parameters():       # (named_parameters lists a tied parameter once, under its first key)
+                ref = refs[k]
+                # per-parameter max-norm error; gradients that vanish analytically (|ref| ~ 1e-6 of the largest one) are
+                # measured against the model's gradient scale, not against their own rounding noise
+                scale = max(float(ref.abs().max()), 1e-3 * gmax, 1e-12)
+                e_k = float((p.grad.cpu().double() - ref.double()).abs().max()) / scale
+                if args.only is not None and e_k > 5e-3:
+                    print(f"      {k}: rel err {e_k:.2e} (|ref| max {float(ref.abs().max()):.2e}, model max {gmax:.2e})")
+                e_grad = max(e_grad, e_k)
+        fwd_ok = max(e_inf, e_tape) <= 2e-4
+        flag = "" if fwd_ok and e_grad <= 5e-3 else ("   (kink: min |pre| %.1e)" % margin if fwd_ok and margin < 2e-5 else "   <<<<<< FAIL")
+        bad += flag.endswith("FAIL")
+        worst = max(worst, e_inf, e_tape)
+        print(f"[{case}] M={kw['n_modalities']} ch={kw['channel_dims']} shapes={shapes} b={b} l=({kw['l_c']},{kw['l_d']}) h={kw['x_heads']}x{kw['cross_dim_head']} "
+              f"depth={kw['depth']} tie={int(kw['weight_tie_layers'])} self={kw['self_per_cross_attn']} bands={kw['num_freq_bands']} mask={masked} missing={missing}: inference {e_inf:.1e} taping {e_tape:.1e}"
+              + (f" grad {e_grad:.1e}" if args.backward else "") + flag, flush=True)
+    print(f"worst forward error {worst:.2e}; {bad} failing case(s)")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
