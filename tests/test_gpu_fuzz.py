@@ -26,3 +26,9 @@ def test_random_configurations_forward_and_backward(seed):
 
 def test_random_configurations_forward_only_wider_sweep():
     assert _fuzz().main(["--n", "60", "--seed", "7"]) == 0
+
+
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+def test_random_configurations_reduced_precision_cores(precision):
+    """Inference forward with the bf16 / bf16x3 attention core (tolerances 2e-2 / 1e-3); the taping forward stays fp32."""
+    assert _fuzz().main(["--n", "40", "--seed", "11", "--core-precision", precision]) == 0
