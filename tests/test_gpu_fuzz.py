@@ -32,3 +32,10 @@ def test_random_configurations_forward_only_wider_sweep():
 def test_random_configurations_reduced_precision_cores(precision):
     """Inference forward with the bf16 / bf16x3 attention core (tolerances 2e-2 / 1e-3); the taping forward stays fp32."""
     assert _fuzz().main(["--n", "40", "--seed", "11", "--core-precision", precision]) == 0
+
+
+def test_random_medium_size_configurations():
+    """Larger shapes, so that the size-gated routes run: 128x128 GEMM of the patch-bag projection, split-K latent GEMMs, Q + K/V in
+    one launch, one-token look-ahead, many-split merges, row-chunked GEMV above 32 samples."""
+    assert _fuzz().main(["--n", "16", "--seed", "0", "--scale", "medium"]) == 0
+    assert _fuzz().main(["--n", "6", "--seed", "4", "--scale", "medium", "--backward"]) == 0

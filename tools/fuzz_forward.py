@@ -20,6 +20,34 @@ def rel(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
+def random_case_medium(rng):
+    """Larger shapes: the size-gated routes (128x128 GEMM of the patch-bag projection, split-K latent GEMMs, Q+KV in one launch,
+    one-token look-ahead, many-split merges, row-chunked GEMV above 32 samples)."""
+    M = rng.choice([1, 2, 2, 3])
+    chans, axes, shapes = [], [], []
+    for _ in range(M):
+        kind = rng.choice(["tab_wide", "img", "vol", "bag", "seq"])
+        if kind == "tab_wide":
+            c, sh = rng.choice([600, 2000]), (1,)
+        elif kind == "img":
+            c, sh = rng.choice([1, 3]), (rng.choice([24, 40, 64]), rng.choice([24, 56]))
+        elif kind == "vol":
+            c, sh = rng.choice([1, 3]), (rng.choice([4, 6]), rng.choice([12, 16]), rng.choice([12, 16]))
+        elif kind == "bag":
+            c, sh = rng.choice([300, 768]), (rng.choice([300, 512, 1200]),)
+        else:
+            c, sh = rng.choice([5, 24]), (rng.choice([700, 2500]),)
+        chans.append(c); axes.append(len(sh)); shapes.append(sh)
+    kw = dict(n_modalities=M, channel_dims=chans, num_spatial_axes=axes, out_dims=4, depth=rng.choice([1, 2]),
+              l_c=rng.choice([64, 128, 256]), l_d=rng.choice([64, 128]), x_heads=8, l_heads=rng.choice([4, 8]),
+              cross_dim_head=64, latent_dim_head=rng.choice([32, 64]), num_freq_bands=2, max_freq=10.0, snn=True,
+              weight_tie_layers=False, self_per_cross_attn=1, fourier_encode_data=True, final_classifier_head=True)
+    b = rng.choice([4, 9, 20, 33, 48])
+    if any(s[0] >= 1200 for s in shapes if len(s) == 1) or any(c >= 768 for c in chans):
+        b = min(b, 9)
+    return kw, shapes, b, False
+
+
 def random_case(rng):
     M = rng.choice([1, 2, 2, 3])
     chans, axes, shapes = [], [], []
@@ -66,6 +94,7 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--backward", action="store_true")
     ap.add_argument("--data-seed", type=int, default=0, help="offset of the input / weight seeds (same configurations, other numbers)")
+    ap.add_argument("--scale", default="small", choices=["small", "medium"])
     ap.add_argument("--core-precision", default="fp32", choices=["fp32", "bf16", "bf16x3"], help="attention core of the inference forward")
     ap.add_argument("--only", type=int, nargs="*", default=None, help="case indices to run (the others are generated and skipped)")
     args = ap.parse_args(argv)
@@ -73,7 +102,7 @@ def main(argv=None):
     worst = 0.0
     bad = 0
     for case in range(args.n):
-        kw, shapes, b, masked = random_case(rng)
+        kw, shapes, b, masked = random_case_medium(rng) if args.scale == "medium" else random_case(rng)
         missing_draw = rng.random(), rng.random()      # drawn for every case so that --only reproduces the same sequence
         if args.only is not None and case not in args.only:
             continue
