@@ -910,8 +910,51 @@ static int plan_tape(const hn_model *m, const hn_modality_input *in, int b, int 
   return HN_OK;
 }
 
+// Registers, in the transposed-weight cache (backward.hip), every weight the dX products of a backward pass read in NN form.
+// `steps == nullptr`: the full schedule (an upper bound, for the workspace size).
+static void register_transposes(const hn_model *m, const hn_modality_input *in, int b, int masked, const Step *steps, int nsteps) {
+  transpose_cache_begin();
+  const int M = m->n_modalities, d = m->l_d;
+  if ((long)b * m->l_c < 256) return;                     // the NN route needs >= 256 rows (launch_gemm_ex)
+  auto add_attn = [&](const hn_attn_params &ap, bool self) {
+    const int inner = ap.heads * ap.dim_head, qd = ap.query_dim;
+    transpose_cache_add(ap.w_out, inner, qd, inner);      // dO = dpre W_out
+    transpose_cache_add(ap.w_q, qd, inner, qd);           // dx_hat = dQ W_q
+    if (self) transpose_cache_add(ap.w_kv, qd, 2 * inner, qd);   // ... + dKV W_kv
+  };
+  auto add_ff = [&](const hn_ff_params &fp) {
+    transpose_cache_add(fp.w2, 4 * fp.dim, fp.dim, 4 * fp.dim);   // dh = dy W2
+    transpose_cache_add(fp.w1, fp.dim, 8 * fp.dim, fp.dim);       // dx_hat = du W1
+  };
+  auto one_token_shortcut = [&](const hn_attn_params &ap, int i) {
+    long n = 1;
+    for (int a = 0; a < m->num_spatial_axes[i]; ++a) n *= in[i].spatial[a];
+    return n == 1 && !masked && !(ap.dropout > 0.0f);
+  };
+  if (steps == nullptr) {
+    for (int layer = 0; layer < m->depth; ++layer) {
+      for (int i = 0; i < M; ++i) {
+        if (!in[i].data) continue;
+        if (!one_token_shortcut(m->cross_attn[layer * M + i], i)) add_attn(m->cross_attn[layer * M + i], false);
+        add_ff(m->cross_ff[layer * M + i]);
+      }
+      if (m->self_per_cross_attn > 0) { add_attn(m->self_attn[layer], true); add_ff(m->self_ff[layer]); }
+    }
+    return;
+  }
+  for (int k = 0; k < nsteps; ++k) {
+    const Step &st = steps[k];
+    if (st.kind == STEP_CROSS_ATTN) { if (!one_token_shortcut(m->cross_attn[st.layer * M + st.m], st.m)) add_attn(m->cross_attn[st.layer * M + st.m], false); }
+    else if (st.kind == STEP_SELF_ATTN) add_attn(m->self_attn[st.layer], true);
+    else if (st.kind == STEP_CROSS_FF) add_ff(m->cross_ff[st.layer * M + st.m]);
+    else add_ff(m->self_ff[st.layer]);
+  }
+  (void)d;
+}
+
 static int fusion_bwd_workspace(const hn_model *m, const hn_modality_input *in, int b, int masked, void *ws, size_t ws_bytes,
-                                FusionPlan *fp, float **dX, float **head_scratch, void **op_ws, size_t *op_bytes, size_t *total) {
+                                FusionPlan *fp, float **dX, float **head_scratch, void **op_ws, size_t *op_bytes, size_t *total,
+                                float **tbuf = nullptr, size_t *tfloats = nullptr) {
   // same z / x carve as the forward (x is unused), then the backward scratch
   int rc = plan_fusion(m, in, b, nullptr, 0, fp);
   if (rc != HN_OK) return rc;
@@ -949,6 +992,12 @@ static int fusion_bwd_workspace(const hn_model *m, const hn_modality_input *in, 
   if (fb.bytes > need) need = fb.bytes;
   *op_bytes = need;
   *op_ws = ar.take<char>(need);
+  register_transposes(m, in, b, masked, nullptr, 0);          // upper bound of the transposed-weight cache
+  const size_t tf = transpose_cache_floats();
+  transpose_cache_end();
+  float *tb = ar.take<float>(tf);
+  if (tbuf) *tbuf = tb;
+  if (tfloats) *tfloats = tf;
   *total = ar.off;
   if (ws != nullptr && ar.overflow) return fail(HN_E_WORKSPACE, "fusion_backward: workspace %zu bytes < required %zu", ws_bytes, ar.off);
   return HN_OK;
@@ -1395,9 +1444,15 @@ int hn_fusion_backward(const hn_model *m, const hn_modality_input *in, int b, co
   int rc = fusion_bwd_workspace(m, in, b, mask != nullptr, nullptr, 0, &fp, &dX, &hs, &op, &opb, &total);
   if (rc != HN_OK) return rc;
   if ((rc = check_ws(workspace, workspace_bytes, total, "fusion_backward")) != HN_OK) return rc;
-  if ((rc = fusion_bwd_workspace(m, in, b, mask != nullptr, workspace, workspace_bytes, &fp, &dX, &hs, &op, &opb, &total)) != HN_OK) return rc;
+  float *tbuf = nullptr;
+  size_t tfloats = 0;
+  if ((rc = fusion_bwd_workspace(m, in, b, mask != nullptr, workspace, workspace_bytes, &fp, &dX, &hs, &op, &opb, &total, &tbuf, &tfloats)) != HN_OK) return rc;
   static thread_local TapePlan tp;
   if ((rc = plan_tape(m, in, b, mask != nullptr, skip_self_on_missing, fp, &tp)) != HN_OK) return rc;
+  // every weight the dX products read transposed, in ONE batched launch per 16 instead of a launch in front of each product
+  register_transposes(m, in, b, mask != nullptr, tp.steps, tp.nsteps);
+  struct CacheGuard { ~CacheGuard() { transpose_cache_end(); } } cache_guard;      // the cache lives for this call only
+  if ((rc = transpose_cache_run(tbuf, tfloats, s)) != HN_OK) return rc;
   const float *T = (const float *)tape;
   const int M = m->n_modalities, L = m->l_c, d = m->l_d;
   const size_t xn = (size_t)b * L * d;

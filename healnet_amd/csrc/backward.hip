@@ -435,14 +435,84 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict_
   }
 }
 
+// ---- transposed-weight cache of one backward pass: hn_fusion_backward registers every weight its dX products will need, ONE
+// batched launch per 16 of them transposes them all up front, launch_gemm_nn then finds them here instead of running a
+// transpose launch in front of every product (48 per step at cfg2).  Thread-local, valid between begin and end only.
+constexpr int TC_MAX = 512, TC_BATCH = 16;
+struct TransposeEntry { const float *src; long ld; int rows, cols; float *dst; };
+struct TransposeBatch { int n; TransposeEntry e[TC_BATCH]; };
+struct TransposeCache { int n; bool ready; TransposeEntry e[TC_MAX]; };
+static thread_local TransposeCache g_tc = {0, false, {}};
+
+void transpose_cache_begin() { g_tc.n = 0; g_tc.ready = false; }
+void transpose_cache_end() { g_tc.n = 0; g_tc.ready = false; }
+void transpose_cache_add(const float *src, long ld, int rows, int cols) {
+  if (!src || g_tc.n >= TC_MAX) return;
+  for (int i = 0; i < g_tc.n; ++i)
+    if (g_tc.e[i].src == src && g_tc.e[i].ld == ld && g_tc.e[i].rows == rows && g_tc.e[i].cols == cols) return;   // tied weights
+  g_tc.e[g_tc.n++] = {src, ld, rows, cols, nullptr};
+}
+size_t transpose_cache_floats() {
+  size_t n = 0;
+  for (int i = 0; i < g_tc.n; ++i) n += align_up((size_t)g_tc.e[i].rows * g_tc.e[i].cols, 64);
+  return n;
+}
+
+__global__ __launch_bounds__(256) void transpose_multi_kernel(TransposeBatch tb) {
+  const TransposeEntry &t = tb.e[blockIdx.z];
+  __shared__ float tile[32][33];
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  if (r0 >= t.rows || c0 >= t.cols) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    tile[ty + 8 * i][tx] = (r < t.rows && c < t.cols) ? t.src[(long)r * t.ld + c] : 0.0f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, r = r0 + tx;
+    if (c < t.cols && r < t.rows) t.dst[(long)c * t.rows + r] = tile[tx][ty + 8 * i];
+  }
+}
+
+int transpose_cache_run(float *buf, size_t buf_floats, hipStream_t s) {
+  HN_REQUIRE(buf_floats >= transpose_cache_floats(), HN_E_WORKSPACE, "transpose cache: buffer too small");
+  size_t off = 0;
+  for (int i = 0; i < g_tc.n; ++i) { g_tc.e[i].dst = buf + off; off += align_up((size_t)g_tc.e[i].rows * g_tc.e[i].cols, 64); }
+  for (int i0 = 0; i0 < g_tc.n; i0 += TC_BATCH) {
+    TransposeBatch tb;
+    tb.n = min(TC_BATCH, g_tc.n - i0);
+    int maxr = 1, maxc = 1;
+    for (int i = 0; i < tb.n; ++i) { tb.e[i] = g_tc.e[i0 + i]; maxr = max(maxr, tb.e[i].rows); maxc = max(maxc, tb.e[i].cols); }
+    for (int i = tb.n; i < TC_BATCH; ++i) tb.e[i] = {nullptr, 0, 0, 0, nullptr};
+    hipLaunchKernelGGL(transpose_multi_kernel, dim3(ceil_div(maxc, 32), ceil_div(maxr, 32), tb.n), dim3(256), 0, s, tb);
+    HN_LAUNCH_CHECK("transpose_multi");
+  }
+  g_tc.ready = true;
+  return HN_OK;
+}
+
+static const float *transpose_cache_lookup(const float *src, long ld, int rows, int cols) {
+  if (!g_tc.ready) return nullptr;
+  for (int i = 0; i < g_tc.n; ++i)
+    if (g_tc.e[i].src == src && g_tc.e[i].ld == ld && g_tc.e[i].rows == rows && g_tc.e[i].cols == cols) return g_tc.e[i].dst;
+  return nullptr;
+}
+
 static int launch_gemm_nn(const GemmExArgs &g, hipStream_t s, float *scratch) {
   // B(j, c) = B + j + c * b_cs: a (K x N) row-major matrix of pitch b_cs
-  hipLaunchKernelGGL(transpose_kernel, dim3(ceil_div(g.N, 32), ceil_div(g.K, 32)), dim3(256), 0, s, g.B, g.b_cs, g.K, g.N, scratch);
-  HN_LAUNCH_CHECK("transpose");
+  const float *wt = transpose_cache_lookup(g.B, g.b_cs, g.K, g.N);
+  if (wt == nullptr) {
+    hipLaunchKernelGGL(transpose_kernel, dim3(ceil_div(g.N, 32), ceil_div(g.K, 32)), dim3(256), 0, s, g.B, g.b_cs, g.K, g.N, scratch);
+    HN_LAUNCH_CHECK("transpose");
+    wt = scratch;
+  }
   GemmArgs f = {};
   f.batch = 1; f.eps = 1e-5f;
   f.A = g.A; f.lda = g.a_rs;
-  f.W = scratch; f.ldw = g.K;
+  f.W = wt; f.ldw = g.K;
   f.C = g.C; f.ldc = g.ldc;
   f.M = g.M; f.N = g.N; f.K = g.K;
   f.alpha = g.alpha;

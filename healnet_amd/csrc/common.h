@@ -303,6 +303,12 @@ int launch_colsum(const float *X, long ld, long rows, int cols, float scale, flo
                   float *scratch = nullptr);
 size_t reduce_scratch_floats(long max_mn, int max_cols);
 size_t ln_bwd_scratch_floats(long rows, int d);
+// transposed-weight cache of one backward pass (backward.hip)
+void transpose_cache_begin();
+void transpose_cache_end();
+void transpose_cache_add(const float *src, long ld, int rows, int cols);
+size_t transpose_cache_floats();
+int transpose_cache_run(float *buf, size_t buf_floats, hipStream_t s);
 int launch_ln_bwd(const float *x, const float *dy, const float *gamma, long rows, int d, float *dx, int dx_accumulate,
                   float *dgamma, float *dbeta, float *scratch, hipStream_t s);
 int launch_ln_fwd(const float *x, const float *gamma, const float *beta, long rows, int d, float *y, hipStream_t s);
