@@ -114,10 +114,22 @@ def main(argv=None):
             continue
         gen = torch.Generator().manual_seed(case + 104729 * args.data_seed)
         ins = [torch.rand(b, *s, c, generator=gen) for s, c in zip(shapes, kw["channel_dims"])]
+        # narrow transports: some modalities arrive as bf16 (read in place) or uint8 (byte / 255 in the encode kernel); the
+        # oracle gets the same values widened to fp32
+        dev_ins = list(ins)
+        for i in range(len(ins)):
+            u = rng.random()
+            if u < 0.12:
+                dev_ins[i] = ins[i].to(torch.bfloat16)
+                ins[i] = dev_ins[i].float()
+            elif u < 0.20:
+                dev_ins[i] = (ins[i] * 255).round().to(torch.uint8)
+                ins[i] = dev_ins[i].float().div(255)
         missing = None
         if kw["n_modalities"] > 1 and missing_draw[0] < 0.2:
             missing = int(missing_draw[1] * kw["n_modalities"])
             ins[missing] = None
+            dev_ins[missing] = None
         mask = None
         if masked and ins[0] is not None:
             n = ins[0].shape[1]
@@ -147,7 +159,7 @@ def main(argv=None):
             O.F.leaky_relu = orig_leaky
         margin = min(margins) if margins else 1.0
         model.to(DEV)
-        dins = [None if t is None else t.to(DEV) for t in ins]
+        dins = [None if t is None else t.to(DEV) for t in dev_ins]
         dmask = None if mask is None else mask.to(DEV)
         with torch.no_grad():
             e_inf = rel(model(list(dins), mask=dmask), want.detach())
