@@ -286,6 +286,7 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
   const int srow = (dropping && pl.rank_d) ? 1 : 0;       // the thinned probabilities' row sum rides in column dp-1
   HN_REQUIRE(!srow || pl.ones, HN_E_UNSUPPORTED, "attn: dropout on the shared-context binding needs a free column (D <= dp - 1)");
   if (dropping) { core.ones_col = 0; core.ones_in_mem = 0; core.drop = drop_of(p->dropout, p->rng, false); core.drop_rowsum = srow; core.bound = nullptr; core.bound_flag = nullptr; }
+  if (o_save && !pl.rank_d) pl.obuf = o_save;      // training, explicit binding: the merged O is produced straight in its tape slot
   const bool direct = !pl.rank_d && pl.nsplit == 1;
   if (direct) { core.Ofinal = pl.obuf; core.ldo = pl.inner; core.dh = pl.dh; core.stats = stats; }
   if (ev0) HN_HIP_CHECK(hipEventRecord(ev0, s));
@@ -299,8 +300,6 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
                                pl.inner, stats, s);
   }
   if (rc != HN_OK) return rc;
-  if (o_save && !pl.rank_d)
-    { int rc_ = launch_copy(o_save, pl.obuf, (long)((size_t)b * L * pl.inner), s); if (rc_ != HN_OK) return rc_; }
 
   GemmArgs go = gemm_defaults();
   go.A = pl.obuf; go.lda = pl.inner;
