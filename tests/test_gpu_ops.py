@@ -264,3 +264,25 @@ def test_bounded_softmax_reference_and_its_fallback(hn, qscale):
     assert_close(blk.fn.attn_weights.cpu(), pw, rel=1e-3, floor=1e-5, what="attn_weights from the bound-referenced statistics")
     if qscale >= 60:
         assert pw.max() > 0.9          # genuinely saturated rows
+
+
+def test_integration_md_ctypes_stub_is_valid(hn):
+    """The ctypes binding INTEGRATION.md shows a reference maintainer (struct mirror + hn_attn_fwd call) is executed as
+    written and must reproduce the package's own Attention.forward."""
+    import os, re, types
+    from healnet_amd import _capi
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(import ctypes as C, torch\n.*?)```", text, re.S).group(1)
+    code = code.replace('C.CDLL("libhealnet_hip.so")', f'C.CDLL({_capi.LIB_PATH!r})')
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    torch.manual_seed(12)
+    att = hn.Attention(32, 13, heads=2, dim_head=16).to(DEV)
+    x, ctx = torch.randn(3, 8, 32, device=DEV), torch.rand(3, 50, 13, device=DEV)
+    with torch.no_grad():
+        want = att(x, context=ctx)
+        got = types.MethodType(ns["forward"], att)(x, context=ctx)
+        assert_close(got.cpu(), want.cpu(), rel=1e-6, what="INTEGRATION.md stub (cross)")
+        assert_close(types.MethodType(ns["forward"], att.__class__(32, heads=2, dim_head=16).to(DEV))(x).cpu().isfinite().float(),
+                     torch.ones(3, 8, 32), rel=0, what="INTEGRATION.md stub (self) finite")
