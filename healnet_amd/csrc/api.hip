@@ -769,6 +769,14 @@ static int plan_fusion(const hn_model *m, const hn_modality_input *in, int b, vo
     fp->D[i] = m->channel_dims[i] + (m->fourier_encode_data ? axes * (2 * m->num_freq_bands + 1) : 0);
     const hn_attn_params *ap = &m->cross_attn[i];
     fp->ldz[i] = context_pitch(fp->D[i], ap->dim_head);
+    // Dropout on the probabilities of the shared-context (rank-D) binding keeps the thinned row sum in a spare column of the
+    // context row; D == 16 / 32 exactly has none, so such a modality takes the explicit K/V binding (pitch D + 4) when any of
+    // its blocks drops.
+    if ((fp->ldz[i] == 16 || fp->ldz[i] == 32) && fp->D[i] == fp->ldz[i]) {
+      bool drops = false;
+      for (int layer = 0; layer < m->depth; ++layer) drops = drops || m->cross_attn[layer * m->n_modalities + i].dropout > 0.0f;
+      if (drops) fp->ldz[i] += 4;
+    }
     // ones column / packed channel order: only for the shared-context (rank-D) binding, where the core reads z itself; the
     // explicit binding projects z through to_kv and needs the natural layout (the pitch alone does not tell: D = 29 with
     // dim_head = 4 gets pitch 32 from the 4-float rounding)

@@ -64,6 +64,10 @@ CASES = [
     dict(kw=dict(n_modalities=2, channel_dims=[50, 3], num_spatial_axes=[1, 2], out_dims=3, depth=1, l_c=8, l_d=16, x_heads=2,
                  l_heads=2, cross_dim_head=8, latent_dim_head=8, attn_dropout=0.4, ff_dropout=0.0, snn=False),
          shapes=[(1, 50), (6, 7, 3)]),
+    # D = 16 exactly on a 16-column row (no spare column for the thinned row sum): the modality takes the explicit binding
+    dict(kw=dict(n_modalities=1, channel_dims=[11], num_spatial_axes=[1], out_dims=3, depth=2, l_c=8, l_d=16, x_heads=2,
+                 l_heads=2, cross_dim_head=16, latent_dim_head=8, attn_dropout=0.3, ff_dropout=0.1),
+         shapes=[(6, 11)]),
     # feed-forward dropout only, no latent self blocks
     dict(kw=dict(n_modalities=1, channel_dims=[3], num_spatial_axes=[2], out_dims=2, depth=2, l_c=8, l_d=16, x_heads=2,
                  l_heads=2, cross_dim_head=8, latent_dim_head=8, attn_dropout=0.0, ff_dropout=0.3, self_per_cross_attn=0),

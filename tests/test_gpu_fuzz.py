@@ -39,3 +39,9 @@ def test_random_medium_size_configurations():
     one launch, one-token look-ahead, many-split merges, row-chunked GEMV above 32 samples."""
     assert _fuzz().main(["--n", "16", "--seed", "0", "--scale", "medium"]) == 0
     assert _fuzz().main(["--n", "6", "--seed", "4", "--scale", "medium", "--backward"]) == 0
+
+
+def test_random_configurations_under_dropout():
+    """Training mode with random attention / feed-forward dropout: the oracle replays the masks the build exports
+    (hn_dropout_mask).  (Found in round 1: dropout on a modality with D == 16 / 32 exactly had no binding to run on.)"""
+    assert _fuzz().main(["--n", "30", "--seed", "41", "--backward", "--dropout"]) == 0

@@ -94,6 +94,7 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--backward", action="store_true")
     ap.add_argument("--data-seed", type=int, default=0, help="offset of the input / weight seeds (same configurations, other numbers)")
+    ap.add_argument("--dropout", action="store_true", help="training mode with random attention / feed-forward dropout; the oracle replays the build's exported Philox masks")
     ap.add_argument("--scale", default="small", choices=["small", "medium"])
     ap.add_argument("--core-precision", default="fp32", choices=["fp32", "bf16", "bf16x3"], help="attention core of the inference forward")
     ap.add_argument("--only", type=int, nargs="*", default=None, help="case indices to run (the others are generated and skipped)")
@@ -103,6 +104,9 @@ def main(argv=None):
     bad = 0
     for case in range(args.n):
         kw, shapes, b, masked = random_case_medium(rng) if args.scale == "medium" else random_case(rng)
+        if args.dropout:
+            kw["attn_dropout"] = rng.choice([0.0, 0.1, 0.3])
+            kw["ff_dropout"] = rng.choice([0.0, 0.2]) if kw["attn_dropout"] > 0 else 0.2
         missing_draw = rng.random(), rng.random()      # drawn for every case so that --only reproduces the same sequence
         if args.only is not None and case not in args.only:
             continue
@@ -161,10 +165,24 @@ def main(argv=None):
         model.to(DEV)
         dins = [None if t is None else t.to(DEV) for t in dev_ins]
         dmask = None if mask is None else mask.to(DEV)
-        with torch.no_grad():
-            e_inf = rel(model(list(dins), mask=dmask), want.detach())
-        got = model(list(dins), mask=dmask)
-        e_tape = rel(got.detach(), want.detach())
+        if args.dropout:
+            # training mode: draw masks on the device, export them, replay them in the oracle
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("tgd", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "test_gpu_dropout.py"))
+            tgd = importlib.util.module_from_spec(spec); sys.path.insert(0, os.path.dirname(spec.origin)); spec.loader.exec_module(tgd)
+            model.train()
+            got = model(list(dins), mask=dmask)
+            seed_, offset_ = model._last_rng
+            n_tok = [1 if t is None else int(t.numel() // (t.shape[0] * t.shape[-1])) for t in ins]
+            drop = tgd._oracle_masks(hn, model, kw, b, n_tok, seed_, offset_, [t is not None for t in ins])
+            with torch.set_grad_enabled(args.backward):
+                want = O.fusion_forward(sd, cfg, ins, mask=mask, drop=drop)
+            e_inf = e_tape = rel(got.detach(), want.detach())
+        else:
+            with torch.no_grad():
+                e_inf = rel(model(list(dins), mask=dmask), want.detach())
+            got = model(list(dins), mask=dmask)
+            e_tape = rel(got.detach(), want.detach())
         e_grad = 0.0
         if args.backward:
             dl = torch.randn(want.shape, generator=gen)
