@@ -45,3 +45,9 @@ def test_random_configurations_under_dropout():
     """Training mode with random attention / feed-forward dropout: the oracle replays the masks the build exports
     (hn_dropout_mask).  (Found in round 1: dropout on a modality with D == 16 / 32 exactly had no binding to run on.)"""
     assert _fuzz().main(["--n", "30", "--seed", "41", "--backward", "--dropout"]) == 0
+
+
+def test_random_configurations_attention_export():
+    """get_attention_weights() / get_attention_importance() after the inference forward (statistics + chained trace slots)
+    and after the taping forward (views of the tape), against the oracle's probabilities."""
+    assert _fuzz().main(["--n", "40", "--seed", "61", "--attn"]) == 0

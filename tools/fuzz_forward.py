@@ -95,6 +95,7 @@ def main(argv=None):
     ap.add_argument("--backward", action="store_true")
     ap.add_argument("--data-seed", type=int, default=0, help="offset of the input / weight seeds (same configurations, other numbers)")
     ap.add_argument("--dropout", action="store_true", help="training mode with random attention / feed-forward dropout; the oracle replays the build's exported Philox masks")
+    ap.add_argument("--attn", action="store_true", help="also compare get_attention_weights() / get_attention_importance() of the inference forward (untied weights, nothing missing)")
     ap.add_argument("--scale", default="small", choices=["small", "medium"])
     ap.add_argument("--core-precision", default="fp32", choices=["fp32", "bf16", "bf16x3"], help="attention core of the inference forward")
     ap.add_argument("--only", type=int, nargs="*", default=None, help="case indices to run (the others are generated and skipped)")
@@ -181,8 +182,31 @@ def main(argv=None):
         else:
             with torch.no_grad():
                 e_inf = rel(model(list(dins), mask=dmask), want.detach())
+                check_attn = args.attn and missing is None and not kw["weight_tie_layers"]
+                ref_p = None
+                if check_attn:
+                    tr = O.FusionTrace()
+                    O.fusion_forward({k: v.detach() for k, v in sd.items()}, cfg, ins, mask=mask, trace=tr)
+                    ref_p = O.attention_weights_in_module_order(tr, cfg)
+
+                def attn_error():
+                    got_p = [p for p in model.get_attention_weights() if p is not None]
+                    got_i = [p for p in model.get_attention_importance() if p is not None]
+                    assert len(ref_p) == len(got_p) == len(got_i), (len(ref_p), len(got_p), len(got_i))
+                    e = 0.0
+                    for rp, gp, gi in zip(ref_p, got_p, got_i):
+                        ok_rows = torch.isfinite(rp).all(dim=-1, keepdim=True)       # fully masked rows are NaN on both sides
+                        e = max(e, rel(torch.where(ok_rows.to(gp.device), gp, torch.zeros_like(gp)), torch.where(ok_rows, rp, torch.zeros_like(rp))))
+                        e = max(e, rel(torch.nan_to_num(gi), torch.nan_to_num(rp).mean(dim=1)))
+                    return 0.4 * e        # tolerance 5e-4 on the probabilities against 2e-4 on the logits
+
+                if check_attn:
+                    e_inf = max(e_inf, attn_error())
             got = model(list(dins), mask=dmask)
             e_tape = rel(got.detach(), want.detach())
+            if check_attn:
+                with torch.no_grad():
+                    e_tape = max(e_tape, attn_error())      # after a taping forward: views of the tape
         e_grad = 0.0
         if args.backward:
             dl = torch.randn(want.shape, generator=gen)
