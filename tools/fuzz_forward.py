@@ -108,7 +108,9 @@ def main(argv=None):
         if args.dropout:
             kw["attn_dropout"] = rng.choice([0.0, 0.1, 0.3])
             kw["ff_dropout"] = rng.choice([0.0, 0.2]) if kw["attn_dropout"] > 0 else 0.2
-        missing_draw = rng.random(), rng.random()      # drawn for every case so that --only reproduces the same sequence
+        missing_draw = rng.random(), rng.random()
+        verbose = rng.random() < 0.15                  # the reference's `continue` quirk: skipped modalities also skip the self block
+        embeddings = rng.random() < 0.15      # drawn for every case so that --only reproduces the same sequence
         if args.only is not None and case not in args.only:
             continue
         torch.manual_seed(1000 + case + 7919 * args.data_seed)
@@ -159,7 +161,7 @@ def main(argv=None):
         O.F.leaky_relu = recording_leaky
         try:
             with torch.set_grad_enabled(args.backward):
-                want = O.fusion_forward(sd, cfg, ins, mask=mask)
+                want = O.fusion_forward(sd, cfg, ins, mask=mask, verbose=verbose, return_embeddings=embeddings)
         finally:
             O.F.leaky_relu = orig_leaky
         margin = min(margins) if margins else 1.0
@@ -172,21 +174,21 @@ def main(argv=None):
             spec = importlib.util.spec_from_file_location("tgd", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "test_gpu_dropout.py"))
             tgd = importlib.util.module_from_spec(spec); sys.path.insert(0, os.path.dirname(spec.origin)); spec.loader.exec_module(tgd)
             model.train()
-            got = model(list(dins), mask=dmask)
+            got = model(list(dins), mask=dmask, verbose=verbose, return_embeddings=embeddings)
             seed_, offset_ = model._last_rng
             n_tok = [1 if t is None else int(t.numel() // (t.shape[0] * t.shape[-1])) for t in ins]
             drop = tgd._oracle_masks(hn, model, kw, b, n_tok, seed_, offset_, [t is not None for t in ins])
             with torch.set_grad_enabled(args.backward):
-                want = O.fusion_forward(sd, cfg, ins, mask=mask, drop=drop)
+                want = O.fusion_forward(sd, cfg, ins, mask=mask, drop=drop, verbose=verbose, return_embeddings=embeddings)
             e_inf = e_tape = rel(got.detach(), want.detach())
         else:
             with torch.no_grad():
-                e_inf = rel(model(list(dins), mask=dmask), want.detach())
-                check_attn = args.attn and missing is None and not kw["weight_tie_layers"]
+                e_inf = rel(model(list(dins), mask=dmask, verbose=verbose, return_embeddings=embeddings), want.detach())
+                check_attn = args.attn and missing is None and not kw["weight_tie_layers"] and not verbose
                 ref_p = None
                 if check_attn:
                     tr = O.FusionTrace()
-                    O.fusion_forward({k: v.detach() for k, v in sd.items()}, cfg, ins, mask=mask, trace=tr)
+                    O.fusion_forward({k: v.detach() for k, v in sd.items()}, cfg, ins, mask=mask, trace=tr, return_embeddings=embeddings)
                     ref_p = O.attention_weights_in_module_order(tr, cfg)
 
                 def attn_error():
@@ -202,7 +204,7 @@ def main(argv=None):
 
                 if check_attn:
                     e_inf = max(e_inf, attn_error())
-            got = model(list(dins), mask=dmask)
+            got = model(list(dins), mask=dmask, verbose=verbose, return_embeddings=embeddings)
             e_tape = rel(got.detach(), want.detach())
             if check_attn:
                 with torch.no_grad():
@@ -229,7 +231,7 @@ def main(argv=None):
         bad += flag.endswith("FAIL")
         worst = max(worst, e_inf, e_tape)
         print(f"[{case}] M={kw['n_modalities']} ch={kw['channel_dims']} shapes={shapes} b={b} l=({kw['l_c']},{kw['l_d']}) h={kw['x_heads']}x{kw['cross_dim_head']} "
-              f"depth={kw['depth']} tie={int(kw['weight_tie_layers'])} self={kw['self_per_cross_attn']} bands={kw['num_freq_bands']} mask={masked} missing={missing}: inference {e_inf:.1e} taping {e_tape:.1e}"
+              f"depth={kw['depth']} tie={int(kw['weight_tie_layers'])} self={kw['self_per_cross_attn']} bands={kw['num_freq_bands']} mask={masked} missing={missing} verbose={int(verbose)} emb={int(embeddings)}: inference {e_inf:.1e} taping {e_tape:.1e}"
               + (f" grad {e_grad:.1e}" if args.backward else "") + flag, flush=True)
     print(f"worst forward error {worst:.2e}; {bad} failing case(s)")
     return 1 if bad else 0
