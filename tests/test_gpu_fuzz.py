@@ -51,3 +51,13 @@ def test_random_configurations_attention_export():
     """get_attention_weights() / get_attention_importance() after the inference forward (statistics + chained trace slots)
     and after the taping forward (views of the tape), against the oracle's probabilities."""
     assert _fuzz().main(["--n", "40", "--seed", "61", "--attn"]) == 0
+
+
+def test_random_op_level_blocks():
+    """tools/fuzz_ops.py: PreNorm(Attention) (cross / self, masks, odd head and context widths, attn_weights on demand) and
+    PreNorm(FeedForward) through the granular C-ABI entry points."""
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_ops.py")
+    spec = importlib.util.spec_from_file_location("fuzz_ops", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main(["--n", "150", "--seed", "0"]) == 0
