@@ -62,6 +62,14 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 _POISON = os.environ.get("HN_POISON_WS", "0") == "1"
 
 
+def _reject_autograd_inputs(what: str, *tensors: Optional[torch.Tensor]) -> None:
+    """The stand-alone blocks are forward-only ops: an input that requires grad means the caller expects gradients to
+    flow through them, which would silently not happen -- refuse instead (training runs through HealNet.forward)."""
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
+        raise RuntimeError(f"healnet_amd: the stand-alone {what} block is a forward-only op (no autograd); an input requires grad. "
+                           "Train through HealNet.forward (fused tape + backward), or detach the input / use torch.no_grad().")
+
+
 class _Workspace:
     """One growing scratch allocation per (device, stream) (the C ABI never allocates).  Per stream, because calls on
     different streams of one device may run concurrently (two micro-batches, a serving thread per stream) and must not
@@ -260,6 +268,7 @@ class Attention(nn.Module):
     def _run(self, x: torch.Tensor, context: Optional[torch.Tensor], mask: Optional[torch.Tensor],
              norm: Optional[nn.LayerNorm], norm_context: Optional[nn.LayerNorm], residual: bool) -> torch.Tensor:
         self._check_mode()
+        _reject_autograd_inputs("Attention", x, context)
         _require_gpu(x, "x")
         _require_gpu(self.to_q.weight, "Attention parameters")
         x = _f32c(x)
@@ -335,7 +344,9 @@ class FeedForward(nn.Module):
 
     def _run(self, x: torch.Tensor, norm: Optional[nn.LayerNorm], residual: bool) -> torch.Tensor:
         if self.training and self.dropout_p > 0.0:
-            raise NotImplementedError("healnet_amd: ff_dropout > 0 in training mode is not implemented (SURVEY.md §8 f2)")
+            raise NotImplementedError("healnet_amd: the stand-alone FeedForward module is an inference op; dropout (and autograd) run "
+                                      "through HealNet's fused training path -- call .eval() here")
+        _reject_autograd_inputs("FeedForward", x)
         _require_gpu(x, "x")
         x = _f32c(x)
         if x.shape[-1] != self.dim:

@@ -157,3 +157,16 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     src = "".join(open(getattr(m, "__file__")).read() for m in (healnet_amd, healnet_amd.healnet, healnet_amd.train, healnet_amd.etl,
                                                                 healnet_amd.dist, healnet_amd.ops, healnet_amd._capi))
     assert "import oracle" not in src and "from oracle" not in src
+
+
+def test_standalone_blocks_refuse_inputs_that_require_grad():
+    """The stand-alone Attention / FeedForward modules are forward-only ops: an input that requires grad must raise (a
+    silently non-differentiable output would train nothing) -- checked before any device work, so it runs on the CPU."""
+    import healnet_amd as hn
+    x = torch.randn(2, 4, 16, requires_grad=True)
+    with pytest.raises(RuntimeError, match="forward-only"):
+        hn.Attention(16, heads=2, dim_head=8)(x)
+    with pytest.raises(RuntimeError, match="forward-only"):
+        hn.PreNorm(16, hn.FeedForward(16))(x)
+    with pytest.raises(RuntimeError, match="forward-only"):
+        hn.PreNorm(16, hn.Attention(16, 5, heads=2, dim_head=8), context_dim=5)(x.detach(), context=torch.randn(2, 3, 5, requires_grad=True))
