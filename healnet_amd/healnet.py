@@ -56,7 +56,16 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
-    return None if t is None else t.data_ptr()
+    """Device address of a parameter / auxiliary tensor handed to the C ABI, which reads fp32, dense, row-major memory:
+    anything else (model.half() / .bfloat16() / .double(), a transposed view) would be read as garbage -- refuse it."""
+    if t is None:
+        return None
+    if t.is_floating_point() and t.dtype != torch.float32:
+        raise TypeError(f"healnet_amd: parameters must be float32 (got {t.dtype}); the kernels read fp32 memory -- keep the module in "
+                        "fp32 (bf16 modality TENSORS are fine: pass them to forward as they are)")
+    if not t.is_contiguous():
+        raise ValueError("healnet_amd: parameters / auxiliary tensors must be contiguous")
+    return t.data_ptr()
 
 
 _POISON = os.environ.get("HN_POISON_WS", "0") == "1"

@@ -170,3 +170,14 @@ def test_standalone_blocks_refuse_inputs_that_require_grad():
         hn.PreNorm(16, hn.FeedForward(16))(x)
     with pytest.raises(RuntimeError, match="forward-only"):
         hn.PreNorm(16, hn.Attention(16, 5, heads=2, dim_head=8), context_dim=5)(x.detach(), context=torch.randn(2, 3, 5, requires_grad=True))
+
+
+def test_non_fp32_parameters_are_refused():
+    """model.half() / .bfloat16() / .double() would make the kernels read the wrong bytes: the descriptor refuses."""
+    model = HealNet(n_modalities=1, channel_dims=[3], num_spatial_axes=[2], out_dims=2, depth=1, l_c=4, l_d=8, x_heads=1,
+                    l_heads=1, cross_dim_head=8, latent_dim_head=8)
+    model._descriptor()                                   # fp32: fine (pointer marshalling only, no device needed)
+    for cast in ("bfloat16", "half", "double"):
+        with pytest.raises(TypeError, match="float32"):
+            getattr(HealNet(n_modalities=1, channel_dims=[3], num_spatial_axes=[2], out_dims=2, depth=1, l_c=4, l_d=8, x_heads=1,
+                            l_heads=1, cross_dim_head=8, latent_dim_head=8), cast)()._descriptor()
