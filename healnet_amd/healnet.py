@@ -649,6 +649,8 @@ class HealNet(nn.Module):
                 continue
             data = tensors[i]
             _require_gpu(data, f"modality {i + 1}")
+            if data.device != device:
+                raise RuntimeError(f"healnet_amd: modality {i + 1} lives on {data.device}, the model on {device}")
             bb, *axis, ch = data.shape
             if ch != self.input_channels[i]:
                 raise ValueError(f"modality {i + 1}: expected {self.input_channels[i]} channels, got {ch} (the reference "
