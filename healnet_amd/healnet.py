@@ -627,6 +627,14 @@ class HealNet(nn.Module):
     # -- forward ---------------------------------------------------------------------------------
     def forward(self, tensors: List[Optional[torch.Tensor]], mask: Optional[torch.Tensor] = None,
                 return_embeddings: bool = False, verbose: bool = False, _profile=None):
+        # kernels are launched on the CURRENT device of the calling thread: make that the model's device for the call
+        # (a model on cuda:1 called while cuda:0 is current would otherwise launch on the wrong GPU)
+        if self.latents.is_cuda and torch.cuda.current_device() != self.latents.device.index:
+            with torch.cuda.device(self.latents.device):
+                return self._forward(tensors, mask, return_embeddings, verbose, _profile)
+        return self._forward(tensors, mask, return_embeddings, verbose, _profile)
+
+    def _forward(self, tensors, mask, return_embeddings, verbose, _profile):
         self._check_mode()
         M = self.modalities
         if len(tensors) > M:
