@@ -106,8 +106,10 @@ class FlatParameters:
         self.params = torch.zeros(total, dtype=torch.float32, device=dev)
         self.grads = torch.zeros(total, dtype=torch.float32, device=dev)
         self.views: List[torch.nn.Parameter] = ps
+        self.offsets: List[int] = []
         off = 0
         for p, n in zip(ps, sizes):
+            self.offsets.append(off)
             if p.dtype != torch.float32 or p.device != dev:
                 raise ValueError("all parameters must be fp32 on one device")
             flat = self.params[off:off + p.numel()].view_as(p)
@@ -120,6 +122,24 @@ class FlatParameters:
 
     def zero_grad(self) -> None:
         self.grads.zero_()
+
+    def relink(self) -> None:
+        """Called by the optimizer before every step: the flat layout only works while every parameter and gradient is still
+        a view of the two buffers.  ``model.zero_grad()`` (set_to_none) or an autograd fallback leaves ``.grad`` elsewhere:
+        such gradients are copied into their slot and re-pointed; a re-allocated parameter (``model.to(...)``,
+        ``load_state_dict(assign=True)``) cannot be repaired silently and raises."""
+        base_p, base_g = self.params.data_ptr(), self.grads.data_ptr()
+        for p, off in zip(self.views, self.offsets):
+            if p.data_ptr() != base_p + 4 * off:
+                raise RuntimeError("healnet_amd: a parameter no longer lives in the flat buffer (model.to(...) / assign-loading after "
+                                   "flatten_parameters?) -- call flatten_parameters(model) again and rebuild the optimizer")
+            slot = self.grads[off:off + p.numel()].view_as(p)
+            if p.grad is None:                    # set_to_none zeroing and no gradient arrived since: the slot may be stale
+                slot.zero_()
+                p.grad = slot
+            elif p.grad.data_ptr() != base_g + 4 * off:
+                slot.copy_(p.grad)
+                p.grad = slot
 
 
 def flatten_parameters(model: torch.nn.Module) -> FlatParameters:
@@ -156,6 +176,7 @@ class FusedL1Adam(torch.optim.Optimizer):
         g = self.param_groups[0]
         self._steps += 1
         f = self.flat
+        f.relink()
         _capi.check(_capi.lib().hn_l1_adam_step(f.params.data_ptr(), f.grads.data_ptr(), self.exp_avg.data_ptr(),
                                                 self.exp_avg_sq.data_ptr(), f.numel, float(g["l1"]), float(g["grad_scale"]),
                                                 float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),

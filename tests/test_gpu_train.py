@@ -134,3 +134,29 @@ def test_whole_training_step_vs_reference_equivalent_cpu(hn):
         # Adam normalises the step: tiny gradient differences can flip early updates of near-zero-gradient entries,
         # so compare against the update size (3 steps of <= lr each) rather than the parameter magnitude
         assert float((got[k].cpu() - v.detach()).abs().max()) <= 0.05 * 3 * lr, k
+
+
+def test_flat_layout_survives_model_zero_grad_and_detects_reallocation(hn):
+    """model.zero_grad() sets .grad to None (torch >= 2.0): the next backward then returns ordinary gradient tensors; the
+    optimizer must fold them back into the flat buffer instead of stepping on zeros.  A re-allocated parameter raises."""
+    torch.manual_seed(3)
+    kw = dict(n_modalities=1, channel_dims=[3], num_spatial_axes=[2], out_dims=2, depth=1, l_c=8, l_d=16, x_heads=2, l_heads=2,
+              cross_dim_head=8, latent_dim_head=8)
+    ref = hn.HealNet(**kw).train().to(DEV)
+    model = hn.HealNet(**kw).train().to(DEV)
+    model.load_state_dict(ref.state_dict())
+    x = torch.rand(4, 5, 6, 3, device=DEV)
+    flat_r, flat_m = hn.train.flatten_parameters(ref), hn.train.flatten_parameters(model)
+    opt_r, opt_m = hn.train.FusedL1Adam(flat_r, lr=1e-2), hn.train.FusedL1Adam(flat_m, lr=1e-2)
+    for step in range(3):
+        opt_r.zero_grad()
+        ref([x]).square().sum().backward()
+        opt_r.step()
+        model.zero_grad()                                   # the "wrong" call: .grad becomes None
+        model([x]).square().sum().backward()
+        opt_m.step()
+    for a, b_ in zip(ref.parameters(), model.parameters()):
+        assert torch.allclose(a, b_, rtol=1e-6, atol=1e-7)
+    model.latents.data = model.latents.data.clone()         # re-allocation behind the flat buffer's back
+    with pytest.raises(RuntimeError, match="flat buffer"):
+        opt_m.step()
