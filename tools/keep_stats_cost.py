@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Cost of keep_attention_stats (softmax statistics + block inputs kept for Attention.attn_weights): forward time at cfg2 b=32
+with the flag off / on, alternating.  Measured: 3.365 vs 3.373 ms (the blocks write both in place, no copies)."""
 import sys, time, torch
 sys.path.insert(0, '.')
 import healnet_amd as hn
