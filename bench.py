@@ -10,13 +10,20 @@ already reside in HBM, eval mode, no autograd (BASELINE.json configs[1], SURVEY.
 no cross-sample coupling, so N GPUs run N independent replicas on their own batch shard with no
 collective in the data path ("weak" scaling); timing = barrier + synchronize on both sides, max over ranks.
 
+`python bench.py --gpus N` with N > 1 and no torchrun environment re-executes itself under `python -m torch.distributed.run`
+(one rank per GPU, 127.0.0.1 rendezvous), so the plain command works as well as the explicit launcher line above.
+
 Rank 0 prints ONE JSON line.  Besides the driver's contract it carries
   roofline     : the dominant kernel (split-KV attention core of the image cross-attention), timed with HIP
                  events recorded on the launch stream inside hn_fusion_forward in an instrumented replay of the
                  same K steps right after the timed region (recording events between kernels costs ~1 ms per
                  forward on this runtime, so it stays out of the region `value` comes from);
   cpu_baseline : oracle/healnet_cpu.py (the op-for-op CPU restatement of the reference) timed on this
-                 box's host cores on a bounded sample (b=4 of the same workload), rank 0 at N=1 only.
+                 box's host cores on a bounded sample (b=4 of the same workload; 1 warm-up + median of 3 runs), rank 0 at N=1 only;
+  train_step   : SURVEY.md 8(d)'s second figure -- the training step of BASELINE configs[3] (TCGA-BRCA shape: omic 1x2000 + WSI bag
+                 4096x768, b=8 per GPU): forward with tape, survival NLL, fused backward, gradient all-reduce over RCCL
+                 (overlapped with the backward through hn_grad_ready, healnet_amd.dist.GradReadyAllReduce) and the fused
+                 L1 + Adam step, timed after the forward region with the same barrier / max-over-ranks rule.
 """
 import argparse
 import ctypes
@@ -71,21 +78,40 @@ class HipEvents:
         return out
 
 
+def _sha256(path):
+    import hashlib
+    with open(path, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
 def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/): counters cannot be
-    collected from inside this process.  (2*FETCH_SIZE + WRITE_SIZE) KiB, per MI355X_MICROARCH.md's gfx950 note."""
-    path = os.path.join(ROOT, "profiles", "r01_l_pmc_cfg2_b32.json")
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC passes (profiles/rNN_*_pmc_cfg2_b32.json,
+    tools/pmc_collect.py): counters cannot be collected from inside this process.  (2*FETCH_SIZE + WRITE_SIZE) KiB, per
+    MI355X_MICROARCH.md's gfx950 note.  The profile records the SHA-256 of the kernel source it was taken from; when
+    attention.hip has changed since, the figure is stale and is dropped (traffic = null) instead of being reported."""
+    import glob
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_cfg2_b32.json")) if "bf16core" not in f)
+    if not files:
+        return None, {"source": None, "reason": "no PMC profile committed"}
+    path = files[-1]
     try:
         with open(path) as f:
-            return float(json.load(f)["dominant_kernel_traffic_bytes_per_launch"]["fetch_doubled"])
-    except Exception:
-        return None
+            doc = json.load(f)
+        now = _sha256(os.path.join(ROOT, "healnet_amd", "csrc", "attention.hip"))
+        then = (doc.get("source_sha256") or {}).get("attention.hip")
+        label = {"source": os.path.relpath(path, ROOT), "attention_hip_sha256": then, "collected_at_commit": doc.get("git_head")}
+        if then != now:
+            label["reason"] = "attention.hip changed since the PMC passes were collected (sha256 mismatch): stale, dropped"
+            return None, label
+        return float(doc["dominant_kernel_traffic_bytes_per_launch"]["fetch_doubled"]), label
+    except Exception as e:      # noqa: BLE001
+        return None, {"source": os.path.relpath(path, ROOT), "reason": f"unreadable: {e}"}
 
 
 def cpu_baseline(budget_s=30.0):
-    """Oracle forward on the host cores, bounded to ~30 s: the thread count is calibrated on one sample
-    (a 256-core box runs this small-GEMM / elementwise mix far slower with every core than with a few
-    dozen), then b=4 of the same workload (BASELINE.json configs[0]) is timed 1-3 times."""
+    """Oracle forward on the host cores (BASELINE.md §3 protocol): the thread count is calibrated on one sample (a 256-core box
+    runs this small-GEMM / elementwise mix far slower with every core than with a few dozen), then b=4 of the same workload
+    (BASELINE.json configs[0]) runs once untimed (warm-up) and 3 times timed; the median is reported."""
     from oracle import healnet_cpu as O
     import healnet_amd
     torch.manual_seed(0)
@@ -97,7 +123,7 @@ def cpu_baseline(budget_s=30.0):
     tab, img = torch.rand(b, *TAB, generator=gen), torch.rand(b, *IMG, generator=gen)
     ncpu = os.cpu_count() or 1
     t_all = time.time()
-    best_threads, best_t = 1, float("inf")
+    calib = {}
     with torch.no_grad():
         for threads in sorted({t for t in (8, 16, 32, 64, ncpu) if t <= ncpu}):
             if time.time() - t_all > budget_s / 3:
@@ -106,30 +132,127 @@ def cpu_baseline(budget_s=30.0):
             O.fusion_forward(sd, cfg, [tab[:1], img[:1]])      # warm-up at this thread count
             t0 = time.time()
             O.fusion_forward(sd, cfg, [tab[:1], img[:1]])
-            dt = time.time() - t0
-            if dt < best_t:
-                best_threads, best_t = threads, dt
+            calib[threads] = time.time() - t0
+        best_threads = min(calib, key=calib.get)
         torch.set_num_threads(best_threads)
+        O.fusion_forward(sd, cfg, [tab, img])                  # warm-up of the timed shape
         times = []
-        while len(times) < 3 and (not times or time.time() - t_all + times[-1] < budget_s):
+        for _ in range(3):
             t0 = time.time()
             O.fusion_forward(sd, cfg, [tab, img])
             times.append(time.time() - t0)
     times.sort()
     med = times[len(times) // 2]
-    return {"value": round(b / med, 3), "unit": "samples/s", "cores": best_threads, "kind": "port",
-            "sample": f"oracle/healnet_cpu.py fusion_forward, b={b} of the same 2-modality workload, fp32, "
-                      f"torch {torch.__version__} CPU, median of {len(times)} run(s); {best_threads} threads picked by a "
-                      f"one-sample calibration out of {ncpu} host cores"}
+    return {"value": round(b / med, 3), "unit": "samples/s", "cores": best_threads, "kind": "port", "host_cores": ncpu,
+            "runs_s": [round(t, 3) for t in times], "calibration_s_per_sample": {str(k): round(v, 3) for k, v in calib.items()},
+            "sample": f"oracle/healnet_cpu.py fusion_forward, b={b} of the same 2-modality workload, fp32, torch {torch.__version__} "
+                      f"CPU, 1 warm-up + median of {len(times)} runs; {best_threads} threads (fastest of {sorted(calib)} on one "
+                      f"sample) out of {ncpu} host cores"}
+
+
+# BASELINE.json configs[3]: TCGA-BRCA-shaped training step, per-GPU batch 8
+TRAIN_KW = dict(n_modalities=2, channel_dims=[2000, 768], num_spatial_axes=[1, 1], out_dims=4)
+TRAIN_SHAPES = [(1, 2000), (4096, 768)]
+TRAIN_BATCH = 8
+
+
+def train_step_record(dev, rank, world, distributed, barrier, steps, warmup):
+    """fwd + bwd + gradient all-reduce + fused L1/Adam step at cfg4, b=8 per GPU (the reference's loop body, main.py:425-467)."""
+    import healnet_amd as hn
+    from healnet_amd import dist as hdist
+    import torch.distributed as dist
+    torch.manual_seed(0)
+    model = hn.HealNet(**TRAIN_KW).train().to(dev)
+    gen = torch.Generator().manual_seed(4321 + rank)
+    b = TRAIN_BATCH
+    ins = [torch.rand(b, *s, generator=gen).to(dev) for s in TRAIN_SHAPES]
+    y = torch.randint(0, TRAIN_KW["out_dims"], (b,), generator=gen).to(dev)
+    c = torch.randint(0, 2, (b,), generator=gen).to(dev)
+    flat = hn.train.flatten_parameters(model)
+    opt = hn.train.FusedL1Adam(flat, lr=1e-4, l1=1e-4)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=1e-3, total_steps=2 * (steps + warmup) + 4)
+    sync = hdist.GradReadyAllReduce(model, flat)
+
+    def step(overlap):
+        opt.zero_grad()
+        out = hn.train.surv_nll_loss(model(list(ins)), y, c)
+        if overlap:
+            out.loss.backward()                 # the all-reduces are released from inside hn_fusion_backward
+            sync.wait()
+        else:
+            sync.close()
+            out.loss.backward()
+            hdist.allreduce_mean_([flat.grads])
+            hn.ops.register_backward_hook(flat.grads, sync)
+        opt.step()
+        sched.step()
+        return out.loss
+
+    def timed(overlap):
+        for _ in range(warmup):
+            step(overlap)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step(overlap)
+        barrier()
+        dt = time.perf_counter() - t0
+        return (hdist.max_over_ranks(dt, dev) if distributed else dt), float(loss)
+
+    dt, loss = timed(True)
+    rec = {"config": "cfg4 (BASELINE configs[3]): HealNet(2,[2000,768],[1,1],4) default hyper-parameters, omic (b,1,2000) + WSI bag "
+                     "(b,4096,768), fp32, train mode, survival NLL + L1 + Adam under OneCycleLR",
+           "batch_per_gpu": b, "global_batch": b * world, "steps": steps, "warmup": warmup,
+           "ms_per_step": round(dt / steps * 1e3, 4), "value": round(b * world * steps / dt, 2), "unit": "samples/s",
+           "world_size": world, "backend": (dist.get_backend() if distributed else None),
+           "allreduce": "healnet_amd.dist.GradReadyAllReduce: flat gradient buffer, one bucket per layer released by hn_grad_ready "
+                        "signals on a side stream while the lower layers run their backward",
+           "allreduce_buckets_floats": [hi - lo for _, lo, hi in sync.launched], "gradient_floats": int(flat.numel),
+           "final_loss": loss}
+    if distributed:
+        dt2, _ = timed(False)
+        rec["ms_per_step_blocking_allreduce"] = round(dt2 / steps * 1e3, 4)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            hdist.allreduce_mean_([flat.grads])
+        barrier()
+        rec["allreduce_alone_ms"] = round((time.perf_counter() - t0) / 10 * 1e3, 4)
+    # forward (tape-recording) share of the step
+    with torch.enable_grad():
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            model(list(ins))
+        barrier()
+    rec["forward_train_ms"] = round((time.perf_counter() - t0) / steps * 1e3, 4)
+    sync.close()
+    return rec
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` outside torchrun: start N ranks of this script under torch.distributed.run."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=BATCH, help="samples per GPU per step (headline config: 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-step", action="store_true", help="skip the cfg4 training-step record")
+    ap.add_argument("--train-steps", type=int, default=30)
     ap.add_argument("--core-precision", choices=["fp32", "bf16", "bf16x3"], default="fp32",
                     help="development switch: bf16 MFMA in the image cross-attention core (the headline is fp32)")
     args = ap.parse_args()
@@ -138,15 +261,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)                                  # does not return
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # HN_BENCH_SHARED_GPU=1 (tests on a 1-GPU box only): every rank uses cuda:0 and the ranks talk over gloo -- exercises the
+    # launcher and the distributed code paths; RCCL needs one device per rank, which is what the real runs use
+    shared = os.environ.get("HN_BENCH_SHARED_GPU", "0") == "1"
+    if shared:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:
         import torch.distributed as dist
         from healnet_amd import dist as hdist
-        hdist.init_from_env("nccl")                       # RCCL; one process per GPU
+        hdist.init_from_env("gloo" if shared else "nccl")  # nccl = RCCL; one process per GPU
 
     import healnet_amd
     from healnet_amd import _capi
@@ -216,6 +345,8 @@ def main():
         peak = 2500.0 if bf16_core else PEAK_FP32_MFMA_TFLOPS
         exec_tf = exec_flops * b / (avg_core_ms * 1e-3) / 1e12 if core_ms else None
         algo_tf = ALGO_FLOPS_CORE_PER_SAMPLE * b / (avg_core_ms * 1e-3) / 1e12 if core_ms else None
+        useful_tf = 2.0 * L_C * N_IMG * (QK_DIM + 13) * HEADS * b / (avg_core_ms * 1e-3) / 1e12 if core_ms else None
+        traffic, traffic_label = (None, {"reason": "bf16 development switch"}) if bf16_core else pmc_traffic()
         result = {
             "metric": "fusion-forward samples/sec (2-modality, b=32)",
             "value": round(total_samples / elapsed, 2),
@@ -242,7 +373,9 @@ def main():
                 "peak": peak,
                 "unit": "TFLOP/s",
                 "frac": None if exec_tf is None else round(exec_tf / peak, 4),
-                "traffic": None if bf16_core else pmc_traffic(),
+                "frac_useful": None if (useful_tf is None or bf16_core) else round(useful_tf / peak, 4),
+                "traffic": traffic,
+                "traffic_source": traffic_label,
                 "avg_launch_ms": round(avg_core_ms, 4),
                 "timing": "hipEvent pairs on the launch stream around each of the 3 launches per forward, recorded in an "
                           "instrumented replay of the same K steps right after the timed region",
@@ -253,10 +386,19 @@ def main():
                 "effective_algorithmic_tflops": None if algo_tf is None else round(algo_tf, 2),
                 "note": "achieved/frac use EXECUTED fp32-MFMA FLOPs (rank-D reassociation + packed context: QK^T contracts 12 "
                         "channels and P V 16 columns instead of dim_head 64 each, 4.6x fewer than the reference formulation, "
-                        "SURVEY.md §8d); effective_algorithmic_tflops "
+                        "SURVEY.md §8d); frac_useful prices only the useful P V columns (12 channels + the softmax-denominator ones "
+                        "column = 13 of the 16 MFMA columns; 3 are idle padding); effective_algorithmic_tflops "
                         "prices the same launch at the reference formulation's 13.15 GF/sample",
             },
         }
+    train_rec = None
+    if not args.no_train_step:
+        del model, tab, img
+        torch.cuda.empty_cache()
+        train_rec = train_step_record(dev, rank, world, distributed, barrier, args.train_steps, 5)
+    if rank == 0:
+        if train_rec is not None:
+            result["train_step"] = train_rec
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline()
         print(json.dumps(result))

@@ -12,7 +12,7 @@ import sys
 from typing import Optional
 
 HN_MAX_AXES = 4
-HN_ABI_VERSION = 3
+HN_ABI_VERSION = 4
 HN_F32, HN_BF16, HN_U8 = 0, 1, 2
 HN_CORE_F32, HN_CORE_BF16, HN_CORE_BF16X3 = 0, 1, 2
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -86,6 +86,13 @@ class Profile(C.Structure):
                 ("n_events", C.c_int), ("n_recorded", C.c_int)]
 
 
+READY_FN = C.CFUNCTYPE(None, C.c_int, C.c_void_p)
+
+
+class GradReady(C.Structure):
+    _fields_ = [("events", C.POINTER(C.c_void_p)), ("notify", READY_FN), ("user", C.c_void_p)]
+
+
 # every symbol include/healnet_hip.h declares: name -> (restype, argtypes)
 SIGNATURES = {
     "hn_abi_version": (C.c_int, []),
@@ -139,7 +146,8 @@ SIGNATURES = {
                                           C.c_void_p, C.c_size_t, C.c_void_p]),
     "hn_fusion_backward_workspace_bytes": (C.c_size_t, [C.POINTER(Model), C.POINTER(ModalityInput), C.c_int, C.c_int]),
     "hn_fusion_backward": (C.c_int, [C.POINTER(Model), C.POINTER(ModalityInput), C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
-                                     C.c_void_p, C.POINTER(ModelGrads), C.c_void_p, C.c_size_t, C.c_void_p]),
+                                     C.c_void_p, C.POINTER(ModelGrads), C.c_void_p, C.c_size_t, C.c_void_p,
+                                     C.POINTER(GradReady)]),
     "hn_fusion_workspace_bytes": (C.c_size_t, [C.POINTER(Model), C.POINTER(ModalityInput), C.c_int]),
 }
 
@@ -147,19 +155,50 @@ _lib: Optional[C.CDLL] = None
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP translation unit for gfx950 into healnet_amd/libhealnet_hip.so (in-tree)."""
-    srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(_HERE, "..", "include", "healnet_hip.h")]
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
-        return LIB_PATH
+    """Compile every HIP translation unit for gfx950 into healnet_amd/libhealnet_hip.so (in-tree).  One hipcc process per
+    translation unit, in parallel, objects under healnet_amd/build/ (git-ignored); a unit is recompiled when it, common.h or
+    the public header is newer than its object.  ``force`` (or HN_FORCE_REBUILD=1) rebuilds everything from a clean slate."""
+    from concurrent.futures import ThreadPoolExecutor
+    force = force or os.environ.get("HN_FORCE_REBUILD", "0") == "1"
+    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(_HERE, "..", "include", "healnet_hip.h")]
+    objdir = os.path.join(_HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # -amdgpu-mfma-vgpr-form: MFMA accumulators live in plain VGPRs (gfx950 has a unified register file), which
     # removes the per-iteration v_accvgpr_read/write shuffles hipcc otherwise emits around the softmax / epilogues.
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm", "-amdgpu-mfma-vgpr-form=1",
-           "-o", LIB_PATH] + os.environ.get("HN_EXTRA_HIPCC_FLAGS", "").split() + srcs
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form=1"] + \
+        os.environ.get("HN_EXTRA_HIPCC_FLAGS", "").split()
+    stamp = os.path.join(objdir, "flags.txt")
+    flag_text = " ".join([hipcc] + flags)
+    if not os.path.exists(stamp) or open(stamp).read() != flag_text:
+        force = True
+    hdr_time = max(os.path.getmtime(h) for h in hdrs)
+    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(
+            [hdr_time] + [os.path.getmtime(os.path.join(CSRC, src)) for src in SOURCES]):
+        return LIB_PATH          # up to date (also the case on a GPU box that received the prebuilt library without objects)
+    jobs = []
+    for src in SOURCES:
+        path, obj = os.path.join(CSRC, src), os.path.join(objdir, src + ".o")
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(path), hdr_time):
+            jobs.append((path, obj))
+    objs = [os.path.join(objdir, src + ".o") for src in SOURCES]
+    if not jobs and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(o) for o in objs):
+        return LIB_PATH
+
+    def compile_one(job):
+        cmd = [hipcc] + flags + ["-c", job[0], "-o", job[1]]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True, cwd=CSRC)
+
+    with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as pool:
+        list(pool.map(compile_one, jobs))
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
     if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True, cwd=CSRC)
+        print(" ".join(link), file=sys.stderr)
+    subprocess.run(link, check=True, cwd=CSRC)
+    with open(stamp, "w") as f:
+        f.write(flag_text)
     return LIB_PATH
 
 

@@ -868,7 +868,7 @@ static int build_schedule(const hn_model *m, const hn_modality_input *in, int sk
   for (int layer = 0; layer < m->depth; ++layer)
     for (int i = 0; i < m->n_modalities; ++i) {
       const bool present = in[i].data != nullptr;
-      if (!present && skip_self_on_missing) continue;
+      if (!present && ((skip_self_on_missing >> i) & 1)) continue;   // bit i: the verbose=True `continue` quirk for modality i
       if (present) {
         if (n + 2 > cap) return -1;
         steps[n++] = {STEP_CROSS_ATTN, layer, i};
@@ -1441,7 +1441,7 @@ size_t hn_fusion_backward_workspace_bytes(const hn_model *m, const hn_modality_i
 
 int hn_fusion_backward(const hn_model *m, const hn_modality_input *in, int b, const uint8_t *mask, int skip_self_on_missing,
                        int return_embeddings, const float *dout, const void *tape, const hn_model_grads *g, void *workspace,
-                       size_t workspace_bytes, void *stream) {
+                       size_t workspace_bytes, void *stream, const hn_grad_ready *ready) {
   hipStream_t s = (hipStream_t)stream;
   HN_REQUIRE(dout && tape && g, HN_E_NULL, "fusion_backward: NULL pointer");
   FusionPlan fp;
@@ -1479,6 +1479,16 @@ int hn_fusion_backward(const hn_model *m, const hn_modality_input *in, int b, co
   } else {
     { int rc_ = launch_copy(dX, dout, (long)(xn), s); if (rc_ != HN_OK) return rc_; }
   }
+  // grad_ready[depth]: the head's parameter gradients are final; grad_ready[l]: every block of layers >= l has run its
+  // backward, so every gradient range only those layers accumulate into is final (layers finish in reverse order)
+  auto signal = [&](int idx) -> int {
+    if (!ready) return HN_OK;
+    if (ready->events && ready->events[idx]) HN_HIP_CHECK(hipEventRecord((hipEvent_t)ready->events[idx], s));
+    if (ready->notify) ready->notify(idx, ready->user);
+    return HN_OK;
+  };
+  if ((rc = signal(m->depth)) != HN_OK) return rc;
+  int next_layer_event = m->depth - 1;     // highest layer whose event has not been recorded yet
   static const hn_attn_grads no_attn = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   static const hn_ff_grads no_ff = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   for (int k = tp.nsteps - 1; k >= 0; --k) {
@@ -1515,7 +1525,14 @@ int hn_fusion_backward(const hn_model *m, const hn_modality_input *in, int b, co
       }
     }
     if (rc != HN_OK) return rc;
+    if (ready) {
+      const int done_above = k > 0 ? tp.steps[k - 1].layer : -1;   // layers > done_above have no block left
+      for (; next_layer_event > done_above; --next_layer_event)
+        if ((rc = signal(next_layer_event)) != HN_OK) return rc;
+    }
   }
+  for (; ready && next_layer_event >= 0; --next_layer_event)
+    if ((rc = signal(next_layer_event)) != HN_OK) return rc;
   if (g->latents) return launch_colsum(dX, (long)L * d, b, L * d, 1.0f, g->latents, 1, s);   // x0 = latents broadcast over the batch
   return HN_OK;
 }

@@ -33,7 +33,11 @@ __global__ __launch_bounds__(256) void surv_nll_kernel(const float *__restrict__
   float acc = 0.0f;
   for (int i = threadIdx.x; i < b; i += blockDim.x) {
     const float *l = logits + (long)i * K;
-    const int yi = (int)y[i];
+    const long long yraw = y[i];
+    // a label outside [0, K) makes the reference's torch.gather raise (survival_loss.py:27-31); a kernel cannot raise, so the
+    // sample poisons the loss and its gradient row with NaN instead of reading weights[] / S_pad[] out of bounds
+    const bool bad_label = yraw < 0 || yraw >= K;
+    const int yi = bad_label ? 0 : (int)yraw;
     const float c = cens[i];
     float S = 1.0f, A = 1.0f, B = 1.0f, H = 0.0f, rsum = 0.0f;
     for (int k = 0; k < K; ++k) {
@@ -50,7 +54,7 @@ __global__ __launch_bounds__(256) void surv_nll_kernel(const float *__restrict__
     const float unc = -(1.0f - c) * (logf(fmaxf(A, eps)) + logf(fmaxf(H, eps)));
     const float cen = -c * logf(fmaxf(B, eps));
     const float neg = (cen + unc) * w;
-    acc += (1.0f - alpha) * neg + alpha * unc;
+    acc += bad_label ? __int_as_float(0x7fc00000) : (1.0f - alpha) * neg + alpha * unc;
     if (dlogits) {
       const float a_c = (1.0f - alpha) * w * c * (B >= eps ? 1.0f : 0.0f);
       const float a_u = ((1.0f - alpha) * w + alpha) * (1.0f - c);
@@ -62,7 +66,7 @@ __global__ __launch_bounds__(256) void surv_nll_kernel(const float *__restrict__
         if (k <= yi) g += a_c * h;                  // d(-log S_pad[y+1]) / dl_k = h_k, k <= y
         if (k < yi) g += a_u * gA * h;              // d(-log S_pad[y])   / dl_k = h_k, k <  y
         if (k == yi) g -= a_u * gH * (1.0f - h);    // d(-log h_y)        / dl_y = -(1 - h_y)
-        dlogits[(long)i * K + k] = g * sc;
+        dlogits[(long)i * K + k] = bad_label ? __int_as_float(0x7fc00000) : g * sc;
       }
     }
   }

@@ -97,6 +97,130 @@ def allreduce_mean_(tensors: Iterable[torch.Tensor], bucket_bytes: int = 32 << 2
     flush()
 
 
+def shard_loss_scale(n_local: int, n_total: int, world: int) -> float:
+    """Factor for a rank's LOCAL mean loss so that the rank-averaged gradient equals the gradient of the GLOBAL batch mean
+    also with ragged shards: (1/world) * sum_r scale_r * grad(mean_r) = sum_r (n_r / n) * grad(mean_r)."""
+    return float(n_local) * world / float(n_total)
+
+
+def grad_ready_buckets(model, views, offsets):
+    """{signal index -> [(lo, hi) float ranges of the flat gradient buffer]} for GradReadyAllReduce: a parameter is released by the
+    hn_grad_ready signal of the LOWEST layer that uses it (a tied block belongs to layer 1); the head rides with the top layer's
+    signal (it is final even earlier), layer 0 and the latent array with the end of the call (index -1).  Adjacent parameters
+    released by the same signal merge into one range: with flatten_parameters' layout every bucket is one contiguous range."""
+    depth = int(model.depth)
+    owner = {}
+    for l in range(depth):
+        for p in model.layers[l].parameters():
+            owner.setdefault(id(p), l)
+    head_ids = {id(p) for p in model.to_logits.parameters()}
+    top = max(owner.values()) if owner else -1     # the highest layer that owns parameters (1 with weight tying)
+    per_param = []
+    for p, off in zip(views, offsets):
+        if id(p) in head_ids:
+            idx = top
+        else:
+            idx = owner.get(id(p), -1)            # not in any layer: the latent array
+        if idx <= 0:
+            idx = -1
+        per_param.append((off, (p.numel() + 3) // 4 * 4, idx))
+    per_param.sort()
+    buckets = {}
+    for off, n, idx in per_param:
+        ranges = buckets.setdefault(idx, [])
+        if ranges and ranges[-1][1] == off:
+            ranges[-1] = (ranges[-1][0], off + n)
+        else:
+            ranges.append((off, off + n))
+    return buckets
+
+
+class GradReadyAllReduce:
+    """The gradient average of a training step, overlapped with the backward (serves healnet/main.py:464-465).
+
+    ``hn_fusion_backward`` finishes the layers in reverse order and signals, per layer, the moment nothing accumulates into
+    that layer's parameter gradients any more (``hn_grad_ready``: an event on the compute stream + a host callback).  With the
+    flat layout of ``healnet_amd.train.flatten_parameters`` a layer's gradients are ONE contiguous range of ``flat.grads``, so
+    each signal releases one large all-reduce on a side stream (RCCL over xGMI: a few multi-MB messages, not 125 small
+    ones) while the lower layers are still running their backward:
+
+        bucket [layer depth-1 + head]  released by signal depth-1
+        bucket [layer l]               released by signal l          (l = depth-2 .. 1)
+        bucket [latents + layer 0]     released when the backward has been enqueued completely
+
+        flat = healnet_amd.train.flatten_parameters(model)
+        sync = healnet_amd.dist.GradReadyAllReduce(model, flat)       # registers itself with the fused backward
+        ...
+        loss.backward()          # all-reduces are enqueued from inside hn_fusion_backward
+        sync.wait()              # the compute stream waits for the side stream; then opt.step()
+
+    ``reduce_fn(view)`` replaces the collective (default: in-place mean over the default process group; a no-op group of one
+    still exercises the whole signalling path)."""
+
+    def __init__(self, model, flat, reduce_fn=None):
+        from . import _capi, ops
+        self.flat = flat
+        self.device = flat.grads.device
+        depth = int(model.depth)
+        self.buckets = grad_ready_buckets(model, flat.views, flat.offsets)
+        self.depth = depth
+        self.reduce_fn = reduce_fn or self._allreduce_mean
+        self.side = torch.cuda.Stream(self.device)
+        self.events = [torch.cuda.Event() for _ in range(depth + 1)]
+        for ev in self.events:                               # torch creates the hipEvent_t lazily at the first record
+            ev.record(torch.cuda.current_stream(self.device))
+        self._ev_arr = (_capi.C.c_void_p * (depth + 1))(*[ev.cuda_event for ev in self.events])
+        self._cb = _capi.READY_FN(self._notify)
+        self.ready = _capi.GradReady(events=self._ev_arr, notify=self._cb, user=None)
+        self._error = None
+        self.launched = []                                   # (signal index, lo, hi) in launch order, for tests / logging
+        ops.register_backward_hook(flat.grads, self)
+
+    def close(self) -> None:
+        from . import ops
+        ops.unregister_backward_hook(self.flat.grads)
+
+    def _allreduce_mean(self, view: torch.Tensor) -> None:
+        if not dist.is_initialized() or dist.get_world_size() == 1:
+            return
+        if dist.get_backend() == "nccl":
+            dist.all_reduce(view, op=dist.ReduceOp.AVG)
+        else:
+            dist.all_reduce(view, op=dist.ReduceOp.SUM)
+            view.div_(dist.get_world_size())
+
+    def _release(self, idx: int) -> None:
+        for lo, hi in self.buckets.get(idx, []):
+            with torch.cuda.stream(self.side):
+                self.reduce_fn(self.flat.grads[lo:hi])
+            self.launched.append((idx, lo, hi))
+
+    # -- called by torch.ops.healnet_hip.fusion_backward around / from inside hn_fusion_backward -------------------
+    def begin(self, stream_ptr: int) -> None:
+        self._error = None
+        self.launched = []
+
+    def _notify(self, idx, user) -> None:                    # host callback: events[idx] has just been recorded
+        try:
+            if idx in self.buckets and idx >= 1:
+                self.side.wait_event(self.events[idx])
+                self._release(idx)
+        except BaseException as e:                           # exceptions cannot cross the C frame
+            self._error = e
+
+    def end(self, stream_ptr: int) -> None:
+        if self._error is not None:
+            raise self._error
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(self.device))
+        self.side.wait_event(done)
+        self._release(-1)
+
+    def wait(self) -> None:
+        """Make the current stream wait for every all-reduce released by the last backward."""
+        torch.cuda.current_stream(self.device).wait_stream(self.side)
+
+
 def max_over_ranks(value: float, device: Optional[torch.device] = None) -> float:
     """bench.py timing contract: the slowest rank defines the step time."""
     if not dist.is_initialized() or dist.get_world_size() == 1:

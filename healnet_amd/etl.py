@@ -119,6 +119,12 @@ class DeviceLoader:
         stop = threading.Event()
         self._cv = threading.Condition()
         self._consumed = {}
+        # The slot ring is reused across epochs: kernels of the previous epoch's last batches (the backward re-reads the
+        # inputs to recompute the contexts) may still be in flight on the consumer's stream when batch 0 of this epoch is
+        # copied into slot 0 -- order the copy stream behind everything the consumer has enqueued so far.
+        epoch_start = torch.cuda.Event()
+        epoch_start.record(torch.cuda.current_stream(self.device))
+        self._stream.wait_event(epoch_start)
 
         def produce():
             torch.cuda.set_device(self.device)

@@ -17,12 +17,14 @@ Deliberate deviations from the reference (documented in DESIGN.md):
   * the caller's list is not overwritten with the encoded context (:222) unless
     ``compat_mutate_inputs=True``;
   * ``attn_weights`` (:420) is materialised lazily on request instead of being kept for every block;
-  * dropout > 0 in training mode is not implemented yet (raises); autograd runs through hn_fusion_backward.
+  * autograd: every forward is ONE torch.ops.healnet_hip.* call (ops.py); the backward is registered on the operator and runs
+    hn_fusion_backward / hn_attn_bwd / hn_ff_bwd.  No gradient flows to modality inputs / attention contexts.
 """
 from __future__ import annotations
 
 import ctypes as C
-import os
+import json
+import weakref
 from typing import Callable, Dict, List, Optional, Sequence
 
 import torch
@@ -34,101 +36,20 @@ __all__ = ["HealNet", "Attention", "PreNorm", "FeedForward", "fourier_encode_con
 
 
 # ------------------------------------------------------------------------------------------------
-# helpers
+# helpers (shared with ops.py)
 # ------------------------------------------------------------------------------------------------
-def _stream_ptr(device: torch.device) -> int:
-    return torch.cuda.current_stream(device).cuda_stream
+from ._rt import WS as _WS, WS_AUX as _WS_AUX, f32c as _f32c, mask_bytes as _mask_bytes, ptr as _ptr  # noqa: E402
+from ._rt import require_gpu as _require_gpu, stream_ptr as _stream_ptr  # noqa: E402
+from . import ops as _ops  # noqa: E402  (registers torch.ops.healnet_hip.*; every forward below dispatches through them)
 
-
-def _require_gpu(t: torch.Tensor, what: str) -> None:
-    if not t.is_cuda:
-        raise RuntimeError(f"healnet_amd: {what} must live on a HIP device (got {t.device}); "
-                           "the MI355X path has no CPU fallback")
-
-
-def _f32c(t: torch.Tensor) -> torch.Tensor:
-    """fp32, contiguous view of an input (positions are always computed in fp32, Appendix B-8); uint8 means byte / 255."""
-    if t.dtype == torch.uint8:
-        t = t.float().div(255)
-    elif t.dtype != torch.float32:
-        t = t.float()
-    return t.contiguous()
-
-
-def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
-    """Device address of a parameter / auxiliary tensor handed to the C ABI, which reads fp32, dense, row-major memory:
-    anything else (model.half() / .bfloat16() / .double(), a transposed view) would be read as garbage -- refuse it."""
-    if t is None:
-        return None
-    if t.is_floating_point() and t.dtype != torch.float32:
-        raise TypeError(f"healnet_amd: parameters must be float32 (got {t.dtype}); the kernels read fp32 memory -- keep the module in "
-                        "fp32 (bf16 modality TENSORS are fine: pass them to forward as they are)")
-    if not t.is_contiguous():
-        raise ValueError("healnet_amd: parameters / auxiliary tensors must be contiguous")
-    return t.data_ptr()
-
-
-_POISON = os.environ.get("HN_POISON_WS", "0") == "1"
-
-
-def _reject_autograd_inputs(what: str, *tensors: Optional[torch.Tensor]) -> None:
-    """The stand-alone blocks are forward-only ops: an input that requires grad means the caller expects gradients to
-    flow through them, which would silently not happen -- refuse instead (training runs through HealNet.forward)."""
-    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
-        raise RuntimeError(f"healnet_amd: the stand-alone {what} block is a forward-only op (no autograd); an input requires grad. "
-                           "Train through HealNet.forward (fused tape + backward), or detach the input / use torch.no_grad().")
-
-
-class _Workspace:
-    """One growing scratch allocation per (device, stream) (the C ABI never allocates).  Per stream, because calls on
-    different streams of one device may run concurrently (two micro-batches, a serving thread per stream) and must not
-    share scratch; calls on one stream are ordered, so they can."""
-
-    def __init__(self) -> None:
-        self._buf: Dict[tuple, torch.Tensor] = {}
-
-    def get(self, device: torch.device, nbytes: int) -> torch.Tensor:
-        key = (device, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
-        buf = self._buf.get(key)
-        if buf is None or buf.numel() < nbytes:
-            buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
-            self._buf[key] = buf
-        if _POISON:      # development aid (HN_POISON_WS=1): every call starts from an all-NaN workspace, so a kernel that
-            buf.fill_(0xFF)   # reads scratch it has not written shows up deterministically
-        return buf
-
-
-_WS = _Workspace()
-_WS_AUX = _Workspace()   # for on-demand attention-weight export (must not clobber the forward scratch)
-
-
-def _mask_bytes(mask: Optional[torch.Tensor], b: int, n: int) -> Optional[torch.Tensor]:
-    if mask is None:
-        return None
-    flat = mask.reshape(mask.shape[0], -1)
-    if flat.shape[0] != b or flat.shape[1] != n:
-        raise ValueError(f"mask of shape {tuple(mask.shape)} does not match context tokens (b={b}, N={n})")
-    return flat.to(torch.uint8).contiguous()
+_hip = torch.ops.healnet_hip
 
 
 def fourier_encode_concat(data: torch.Tensor, num_freq_bands: int = 2, max_freq: float = 10.0,
                           fourier_encode_data: bool = True) -> torch.Tensor:
     """(b, *S, C) -> (b, prod S, C + axes*(2F+1)); HIP restatement of healnet.py:204-222 / :292-302."""
     _require_gpu(data, "modality tensor")
-    x = _f32c(data)
-    b, spatial, ch = x.shape[0], list(x.shape[1:-1]), x.shape[-1]
-    if not 1 <= len(spatial) <= _capi.HN_MAX_AXES:
-        raise ValueError(f"1..{_capi.HN_MAX_AXES} spatial axes supported, got {len(spatial)}")
-    n = 1
-    for s in spatial:
-        n *= s
-    d = ch + (len(spatial) * (2 * num_freq_bands + 1) if fourier_encode_data else 0)
-    out = torch.empty(b, n, d, dtype=torch.float32, device=x.device)
-    sp = (C.c_int * len(spatial))(*spatial)
-    _capi.check(_capi.lib().hn_fourier_encode_concat(x.data_ptr(), b, len(spatial), sp, ch, num_freq_bands, float(max_freq),
-                                                     int(fourier_encode_data), out.data_ptr(), d, _stream_ptr(x.device)),
-                "hn_fourier_encode_concat")
-    return out
+    return _hip.fourier_encode_concat(data, int(num_freq_bands), float(max_freq), bool(fourier_encode_data))
 
 
 def exists(val) -> bool:                     # healnet.py:270-271
@@ -237,17 +158,33 @@ class Attention(nn.Module):
         self.to_kv = nn.Linear(self.context_dim, inner * 2, bias=False)
         self.to_out = nn.Sequential(nn.Linear(inner, query_dim), nn.LeakyReLU(negative_slope=1e-2))
         self._probs_fn: Optional[Callable[[], torch.Tensor]] = None
+        self._probs_owner_last = None      # the owner's `_last` record at the time of the last stand-alone call
+        self._hn_owner = None              # weakref to the HealNet that runs this block (set by HealNet._bind_owner)
+        self._hn_slots: List[int] = []     # its attention slots there, layer order (a tied block serves several layers)
+
+    def __getstate__(self):                # weak references / closures do not pickle (torch.save(model), copy.deepcopy)
+        state = dict(self.__dict__)
+        state["_probs_fn"] = state["_probs_owner_last"] = state["_hn_owner"] = None
+        return state
 
     # -- lazy Attention.attn_weights (:420) ------------------------------------------------------
+    def _lazy(self, reduced: bool) -> Optional[torch.Tensor]:
+        owner = self._hn_owner() if self._hn_owner is not None else None
+        if self._probs_fn is not None and (owner is None or owner._last is self._probs_owner_last):
+            return self._probs_fn(reduced=reduced)            # the stand-alone call is the most recent use of this module
+        if owner is not None:
+            return owner._block_probs(self, reduced)
+        return None
+
     @property
     def attn_weights(self) -> Optional[torch.Tensor]:
-        return None if self._probs_fn is None else self._probs_fn()
+        return self._lazy(False)
 
     @property
     def attn_importance(self) -> Optional[torch.Tensor]:
         """``attn_weights.mean(dim=1)`` -- the (b*heads, N) row-mean every consumer in the reference's explainer takes
         (explainer.py:161-164, :209-211) -- computed without materialising the (b*heads, L, N) matrix."""
-        return None if self._probs_fn is None else self._probs_fn(reduced=True)
+        return self._lazy(True)
 
     def _params(self, norm: Optional[nn.LayerNorm], norm_context: Optional[nn.LayerNorm],
                 dropout: float = 0.0) -> _capi.AttnParams:
@@ -261,65 +198,59 @@ class Attention(nn.Module):
             w_q=_ptr(self.to_q.weight), w_kv=_ptr(self.to_kv.weight),
             w_out=_ptr(self.to_out[0].weight), b_out=_ptr(self.to_out[0].bias))
 
-    def _grads(self, norm: Optional[nn.LayerNorm], norm_context: Optional[nn.LayerNorm], gmap) -> _capi.AttnGrads:
-        gp = lambda t: None if t is None or id(t) not in gmap else gmap[id(t)].data_ptr()   # noqa: E731
-        return _capi.AttnGrads(
-            norm_w=gp(norm.weight) if norm is not None else None, norm_b=gp(norm.bias) if norm is not None else None,
-            ctx_gamma=gp(norm_context.weight) if norm_context is not None else None,
-            ctx_beta=gp(norm_context.bias) if norm_context is not None else None,
-            w_q=gp(self.to_q.weight), w_kv=gp(self.to_kv.weight), w_out=gp(self.to_out[0].weight), b_out=gp(self.to_out[0].bias))
-
     def _check_mode(self) -> None:
         if self.training and self.dropout_p > 0.0:
-            raise NotImplementedError("healnet_amd: the stand-alone Attention / FeedForward modules are inference ops; dropout "
-                                      "(and autograd) run through HealNet's fused training path -- call .eval() here")
+            raise NotImplementedError("healnet_amd: the stand-alone Attention / FeedForward modules run without dropout; dropout "
+                                      "runs through HealNet's fused training path -- call .eval() here")
 
     def _run(self, x: torch.Tensor, context: Optional[torch.Tensor], mask: Optional[torch.Tensor],
              norm: Optional[nn.LayerNorm], norm_context: Optional[nn.LayerNorm], residual: bool) -> torch.Tensor:
+        """torch.ops.healnet_hip.attention_fwd (hn_attn_fwd / hn_attn_fwd_train): differentiable w.r.t. x and the parameters
+        (hn_attn_bwd); the context gets no gradient -- a context that requires grad is refused."""
         self._check_mode()
-        _reject_autograd_inputs("Attention", x, context)
+        if torch.is_grad_enabled() and context is not None and context.requires_grad:
+            raise RuntimeError("healnet_amd: no gradient flows to the context of an Attention block (hn_attn_bwd; HEALNet's contexts "
+                               "are encoded modality inputs) -- detach it")
         _require_gpu(x, "x")
         _require_gpu(self.to_q.weight, "Attention parameters")
-        x = _f32c(x)
         if x.dim() != 3 or x.shape[-1] != self.query_dim:
             raise ValueError(f"x must be (b, n, {self.query_dim}), got {tuple(x.shape)}")
         b, L, _ = x.shape
-        lib = _capi.lib()
         ctx_z, ld, N, D = None, 0, L, self.query_dim
         if context is not None:
             _require_gpu(context, "context")
-            ctx = _f32c(context)
-            if ctx.dim() != 3 or ctx.shape[0] != b or ctx.shape[-1] != self.context_dim:
-                raise ValueError(f"context must be (b={b}, N, {self.context_dim}), got {tuple(ctx.shape)}")
-            N, D = ctx.shape[1], ctx.shape[2]
+            if context.dim() != 3 or context.shape[0] != b or context.shape[-1] != self.context_dim:
+                raise ValueError(f"context must be (b={b}, N, {self.context_dim}), got {tuple(context.shape)}")
+            N, D = context.shape[1], context.shape[2]
             if norm_context is not None:
-                ld = lib.hn_context_pitch(D, self.dim_head)
-                ctx_z = _normalise_context(ctx, ld)
+                ld = _capi.lib().hn_context_pitch(D, self.dim_head)
+                ctx_z = _normalise_context(_f32c(context.detach()), ld)
             else:
-                ctx_z, ld = ctx, D
+                ctx_z, ld = _f32c(context.detach()), D
         mask_u8 = _mask_bytes(mask, b, N)
-        p = self._params(norm, norm_context)
-        need = lib.hn_attn_workspace_bytes(C.byref(p), int(ctx_z is not None), ld, b, L, N, D)
-        if need == 0:
-            _capi.check(-1, "hn_attn_workspace_bytes")
-        ws = _WS.get(x.device, need)
-        out = torch.empty_like(x)
-        stats = torch.empty(b, self.heads, L, 2, dtype=torch.float32, device=x.device)
-        _capi.check(lib.hn_attn_fwd(C.byref(p), x.data_ptr(), out.data_ptr(), int(residual), _ptr(ctx_z), ld, b, L, N, D,
-                                    _ptr(mask_u8), stats.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(x.device)),
-                    "hn_attn_fwd")
+        opt = lambda m_, name: getattr(m_, name) if m_ is not None else None      # noqa: E731
+        args = (opt(norm, "weight"), opt(norm, "bias"), opt(norm_context, "weight"), opt(norm_context, "bias"),
+                self.to_q.weight, self.to_kv.weight, self.to_out[0].weight, self.to_out[0].bias)
+        train = torch.is_grad_enabled() and (x.requires_grad or any(t is not None and t.requires_grad for t in args))
+        out, stats, _ = _hip.attention_fwd(x, ctx_z, mask_u8, *args, self.heads, bool(residual), train)
+        xin = x.detach()
 
         def probs(reduced: bool = False) -> torch.Tensor:
-            pr = torch.empty((b * self.heads, N) if reduced else (b * self.heads, L, N), dtype=torch.float32, device=x.device)
+            lib = _capi.lib()
+            xf = _f32c(xin)
+            pr = torch.empty((b * self.heads, N) if reduced else (b * self.heads, L, N), dtype=torch.float32, device=xf.device)
             pp = self._params(norm, norm_context)
-            aux = _WS_AUX.get(x.device, need)
+            need = lib.hn_attn_workspace_bytes(C.byref(pp), int(ctx_z is not None), ld, b, L, N, D)
+            aux = _WS_AUX.get(xf.device, need)
             fn = lib.hn_attn_importance if reduced else lib.hn_attn_probs
-            _capi.check(fn(C.byref(pp), x.data_ptr(), _ptr(ctx_z), ld, b, L, N, D, _ptr(mask_u8), stats.data_ptr(),
-                           pr.data_ptr(), aux.data_ptr(), aux.numel(), _stream_ptr(x.device)),
+            _capi.check(fn(C.byref(pp), xf.data_ptr(), _ptr(ctx_z), ld, b, L, N, D, _ptr(mask_u8), stats.data_ptr(),
+                           pr.data_ptr(), aux.data_ptr(), aux.numel(), _stream_ptr(xf.device)),
                         "hn_attn_importance" if reduced else "hn_attn_probs")
             return pr
 
         self._probs_fn = probs
+        owner = self._hn_owner() if self._hn_owner is not None else None
+        self._probs_owner_last = owner._last if owner is not None else None
         return out
 
     def forward(self, x: torch.Tensor, context: Optional[torch.Tensor] = None,
@@ -346,28 +277,17 @@ class FeedForward(nn.Module):
                               w1=_ptr(self.net[0].weight), b1=_ptr(self.net[0].bias),
                               w2=_ptr(self.net[2].weight), b2=_ptr(self.net[2].bias))
 
-    def _grads(self, norm: Optional[nn.LayerNorm], gmap) -> _capi.FFGrads:
-        gp = lambda t: None if t is None or id(t) not in gmap else gmap[id(t)].data_ptr()   # noqa: E731
-        return _capi.FFGrads(norm_w=gp(norm.weight) if norm is not None else None, norm_b=gp(norm.bias) if norm is not None else None,
-                             w1=gp(self.net[0].weight), b1=gp(self.net[0].bias), w2=gp(self.net[2].weight), b2=gp(self.net[2].bias))
-
     def _run(self, x: torch.Tensor, norm: Optional[nn.LayerNorm], residual: bool) -> torch.Tensor:
+        """torch.ops.healnet_hip.feed_forward (hn_ff_fwd, autograd through hn_ff_bwd)."""
         if self.training and self.dropout_p > 0.0:
-            raise NotImplementedError("healnet_amd: the stand-alone FeedForward module is an inference op; dropout (and autograd) run "
+            raise NotImplementedError("healnet_amd: the stand-alone FeedForward module runs without dropout; dropout runs "
                                       "through HealNet's fused training path -- call .eval() here")
-        _reject_autograd_inputs("FeedForward", x)
         _require_gpu(x, "x")
-        x = _f32c(x)
         if x.shape[-1] != self.dim:
             raise ValueError(f"last dim must be {self.dim}, got {tuple(x.shape)}")
-        rows = x.numel() // self.dim
-        lib = _capi.lib()
-        p = self._params(norm)
-        ws = _WS.get(x.device, lib.hn_ff_workspace_bytes(C.byref(p), rows))
-        out = torch.empty_like(x)
-        _capi.check(lib.hn_ff_fwd(C.byref(p), x.data_ptr(), out.data_ptr(), int(residual), rows, ws.data_ptr(), ws.numel(),
-                                  _stream_ptr(x.device)), "hn_ff_fwd")
-        return out
+        return _hip.feed_forward(x, norm.weight if norm is not None else None, norm.bias if norm is not None else None,
+                                 self.net[0].weight, self.net[0].bias, self.net[2].weight, self.net[2].bias, not self.snn,
+                                 bool(residual))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return self._run(x, None, residual=False)
@@ -392,6 +312,12 @@ class PreNorm(nn.Module):
         if isinstance(self.fn, FeedForward):
             return self.fn._run(x, self.norm, residual=False)
         raise TypeError(f"PreNorm cannot wrap {type(self.fn).__name__}")
+
+
+def _wrap64(seed: int) -> int:
+    """torch.initial_seed() is an unsigned 64-bit value; int64 tensors carry it two's-complement."""
+    seed &= 0xFFFFFFFFFFFFFFFF
+    return seed - (1 << 64) if seed >= (1 << 63) else seed
 
 
 class _MeanPool(nn.Module):
@@ -419,69 +345,6 @@ class _Memo:
 
 
 # ------------------------------------------------------------------------------------------------
-# autograd: one Function for the whole fusion stack (hn_fusion_forward_train / hn_fusion_backward)
-# ------------------------------------------------------------------------------------------------
-class _FusionFunction(torch.autograd.Function):
-    """Differentiable w.r.t. every parameter of the model (incl. the latent array); the modality inputs get no
-    gradient, as in the reference's training loop (healnet/main.py:432-465)."""
-
-    @staticmethod
-    def forward(ctx, module, inputs, held, mask_u8, b, skip_self, embeddings, stats_ptrs, x_ptrs, rng, *params):
-        lib = _capi.lib()
-        device = module.latents.device
-        model, keep = module._descriptor(rng=rng)
-        ctx.rng = rng
-        masked = int(mask_u8 is not None)
-        tape_bytes = lib.hn_fusion_tape_bytes(C.byref(model), inputs, b, masked, int(skip_self))
-        need = lib.hn_fusion_workspace_bytes(C.byref(model), inputs, b)
-        if tape_bytes == 0 or need == 0:
-            _capi.check(-1, "hn_fusion_tape_bytes")
-        tape = torch.empty(tape_bytes, dtype=torch.uint8, device=device)
-        ws = _WS.get(device, need)
-        out = torch.empty((b, module.l_c, module.l_d) if embeddings else (b, module.out_dims), dtype=torch.float32,
-                          device=device)
-        _capi.check(lib.hn_fusion_forward_train(C.byref(model), inputs, b, _ptr(mask_u8), int(skip_self), int(embeddings),
-                                                out.data_ptr(), stats_ptrs, x_ptrs, tape.data_ptr(), tape.numel(), ws.data_ptr(),
-                                                ws.numel(), _stream_ptr(device)), "hn_fusion_forward_train")
-        ctx.module, ctx.inputs, ctx.held, ctx.mask_u8 = module, inputs, held, mask_u8
-        ctx.b, ctx.skip_self, ctx.embeddings, ctx.tape, ctx.params = b, skip_self, embeddings, tape, params
-        module._last_tape = (tape, masked, int(skip_self))      # forward() views the statistics / block inputs in place
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        lib = _capi.lib()
-        module, params = ctx.module, ctx.params
-        device = module.latents.device
-        model, keep = module._descriptor(rng=ctx.rng)
-        # healnet_amd.train.flatten_parameters(): every p.grad is a view of one flat buffer -> the kernels accumulate
-        # straight into it (no per-parameter zero tensors, no AccumulateGrad add pass) and autograd gets None back.
-        flat = getattr(module, "_hn_flat", None)
-        direct = False
-        if flat is not None:
-            lo, hi = flat.grads.data_ptr(), flat.grads.data_ptr() + flat.grads.numel() * 4
-            direct = all((not p.requires_grad) or (p.grad is not None and p.grad.is_contiguous()
-                                                   and lo <= p.grad.data_ptr() < hi) for p in params)
-        if direct:
-            gmap = {id(p): p.grad for p in params if p.requires_grad}
-        else:
-            gmap = {id(p): torch.zeros_like(p, dtype=torch.float32) for p in params if p.requires_grad}
-        grads, keep_g = module._grad_descriptor(gmap)
-        masked = int(ctx.mask_u8 is not None)
-        need = lib.hn_fusion_backward_workspace_bytes(C.byref(model), ctx.inputs, ctx.b, masked)
-        if need == 0:
-            _capi.check(-1, "hn_fusion_backward_workspace_bytes")
-        ws = _WS.get(device, need)
-        dout = dout.contiguous().float()
-        _capi.check(lib.hn_fusion_backward(C.byref(model), ctx.inputs, ctx.b, _ptr(ctx.mask_u8), int(ctx.skip_self),
-                                           int(ctx.embeddings), dout.data_ptr(), ctx.tape.data_ptr(), C.byref(grads),
-                                           ws.data_ptr(), ws.numel(), _stream_ptr(device)), "hn_fusion_backward")
-        if direct:
-            return (None,) * (10 + len(params))
-        return (None,) * 10 + tuple(gmap.get(id(p)) for p in params)
-
-
-# ------------------------------------------------------------------------------------------------
 # the model
 # ------------------------------------------------------------------------------------------------
 class HealNet(nn.Module):
@@ -497,7 +360,7 @@ class HealNet(nn.Module):
         # Extension over the reference signature: matrix-instruction precision of the image / volume cross-attention
         # core in the no-grad forward ('bf16' = BASELINE configs[2]; 'bf16x3' = bf16 MFMA on hi+lo operand pairs, fp32-class
         # results; parameters, statistics and outputs stay fp32).
-        self.core_precision = core_precision
+        self._core_precision = core_precision
         assert len(channel_dims) == len(num_spatial_axes), 'input channels and input axis must be of the same length'
         assert len(num_spatial_axes) == n_modalities, 'input axis must be of the same length as the number of modalities'
 
@@ -548,72 +411,94 @@ class HealNet(nn.Module):
             if final_classifier_head else nn.Identity()
 
         self._last: Optional[dict] = None
+        self._any_dropout = attn_dropout > 0.0 or ff_dropout > 0.0
+        self._rng_offset = 0
+        self._last_rng = None
+        self._bind_owner()
+        self._spec_text = self._build_spec()
 
-    # -- C-ABI descriptor ------------------------------------------------------------------------
-    def _descriptor(self, rng=None):
-        """rng = (seed, offset) of a training forward / its backward: blocks then carry their dropout rates (Philox masks,
-        include/healnet_hip.h hn_rng); None = inference descriptor (no dropout)."""
+    # -- structure description handed to torch.ops.healnet_hip.fusion_* ---------------------------------
+    @property
+    def core_precision(self) -> str:
+        return self._core_precision
+
+    @core_precision.setter
+    def core_precision(self, value: str) -> None:
+        if value not in ("fp32", "bf16", "bf16x3"):
+            raise ValueError("core_precision must be 'fp32', 'bf16' or 'bf16x3'")
+        self._core_precision = value
+        if "_spec_text" in self.__dict__:
+            self._spec_text = self._build_spec()
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._bind_owner()                 # weak back-references do not survive pickling / deepcopy (Attention.__getstate__)
+
+    def _bind_owner(self) -> None:
+        """Every Attention block learns which model runs it and in which attention slots (layer * (M + 1) + modality, M = the
+        latent self-attention), so that ``Attention.attn_weights`` (:420) can be served lazily from the last forward."""
+        M = self.modalities
+        for mod in self.modules():
+            if isinstance(mod, Attention):
+                mod._hn_slots = []
+        ref = weakref.ref(self)
+        for layer in range(self.depth):
+            mods = self.layers[layer]
+            owned = [mods[2 * m].fn for m in range(M)] + ([mods[2 * M][0].fn] if self.self_per_cross_attn >= 1 else [])
+            for j, att in enumerate(owned):
+                att._hn_owner = ref
+                att._hn_slots.append(layer * (M + 1) + (j if j < M else M))
+
+    def _build_spec(self) -> str:
+        """JSON description of the module structure for the fusion operators (ops.Spec): sizes plus, for every pointer field of
+        hn_model, the position of its tensor in ``list(self.parameters())`` (tied blocks repeat positions)."""
+        index = {id(p): i for i, p in enumerate(self.parameters())}
+        ix = lambda t: -1 if t is None else index[id(t)]      # noqa: E731
         M, depth = self.modalities, self.depth
-        drop = (lambda mod: mod.dropout_p) if rng is not None else (lambda mod: 0.0)
-        keep = []   # keep ctypes arrays alive for the duration of the call
-        cross_attn = (_capi.AttnParams * (depth * M))()
-        cross_ff = (_capi.FFParams * (depth * M))()
-        self_attn = (_capi.AttnParams * depth)()
-        self_ff = (_capi.FFParams * depth)()
+
+        def attn(blk, cross):
+            a = blk.fn
+            nc = blk.norm_context if cross else None
+            return dict(heads=a.heads, dim_head=a.dim_head, query_dim=a.query_dim, dropout=a.dropout_p,
+                        p=[ix(blk.norm.weight), ix(blk.norm.bias), ix(nc.weight if nc is not None else None),
+                           ix(nc.bias if nc is not None else None), ix(a.to_q.weight), ix(a.to_kv.weight), ix(a.to_out[0].weight),
+                           ix(a.to_out[0].bias)])
+
+        def ff(blk):
+            f = blk.fn
+            return dict(dim=f.dim, gate=0 if f.snn else 1, dropout=f.dropout_p,
+                        p=[ix(blk.norm.weight), ix(blk.norm.bias), ix(f.net[0].weight), ix(f.net[0].bias), ix(f.net[2].weight),
+                           ix(f.net[2].bias)])
+
+        cross_attn, cross_ff, self_attn, self_ff = [], [], [], []
         for layer in range(depth):
             mods = self.layers[layer]
             for m in range(M):
-                blk, ffn = mods[2 * m], mods[2 * m + 1]
-                cross_attn[layer * M + m] = blk.fn._params(blk.norm, blk.norm_context, drop(blk.fn))
-                cross_ff[layer * M + m] = ffn.fn._params(ffn.norm, drop(ffn.fn))
+                cross_attn.append(attn(mods[2 * m], True))
+                cross_ff.append(ff(mods[2 * m + 1]))
             if self.self_per_cross_attn >= 1:
-                blk, ffn = mods[2 * M][0], mods[2 * M][1]
-                self_attn[layer] = blk.fn._params(blk.norm, None, drop(blk.fn))
-                self_ff[layer] = ffn.fn._params(ffn.norm, drop(ffn.fn))
-        cd = (C.c_int * M)(*[int(c) for c in self.input_channels])
-        ax = (C.c_int * M)(*[int(a) for a in self.input_axes])
-        model = _capi.Model(
-            n_modalities=M, depth=depth, l_c=self.l_c, l_d=self.l_d, self_per_cross_attn=self.self_per_cross_attn,
-            final_classifier_head=int(self.final_classifier_head), out_dims=self.out_dims,
-            num_freq_bands=self.num_freq_bands, max_freq=float(self.max_freq),
-            fourier_encode_data=int(self.fourier_encode_data), channel_dims=cd, num_spatial_axes=ax,
-            latents=_ptr(self.latents), cross_attn=cross_attn, cross_ff=cross_ff, self_attn=self_attn, self_ff=self_ff,
-            head_norm_w=_ptr(self.to_logits[1].weight) if self.final_classifier_head else None,
-            head_norm_b=_ptr(self.to_logits[1].bias) if self.final_classifier_head else None,
-            head_w=_ptr(self.to_logits[2].weight) if self.final_classifier_head else None,
-            head_b=_ptr(self.to_logits[2].bias) if self.final_classifier_head else None,
-            core_precision={"fp32": _capi.HN_CORE_F32, "bf16": _capi.HN_CORE_BF16, "bf16x3": _capi.HN_CORE_BF16X3}[self.core_precision],
-            rng=_capi.Rng(seed=int(rng[0]) & 0xFFFFFFFFFFFFFFFF, offset=int(rng[1]) & 0xFFFFFFFF, stream=0) if rng is not None
-            else _capi.Rng(0, 0, 0))
-        keep.extend([cross_attn, cross_ff, self_attn, self_ff, cd, ax])
-        return model, keep
-
-    def _grad_descriptor(self, gmap):
-        """hn_model_grads whose entries point into the per-parameter gradient buffers of ``gmap`` (id(param) -> tensor);
-        tied parameters share one buffer, into which the backward accumulates."""
-        M, depth = self.modalities, self.depth
-        cross_attn = (_capi.AttnGrads * (depth * M))()
-        cross_ff = (_capi.FFGrads * (depth * M))()
-        self_attn = (_capi.AttnGrads * depth)()
-        self_ff = (_capi.FFGrads * depth)()
-        for layer in range(depth):
-            mods = self.layers[layer]
-            for m in range(M):
-                blk, ffn = mods[2 * m], mods[2 * m + 1]
-                cross_attn[layer * M + m] = blk.fn._grads(blk.norm, blk.norm_context, gmap)
-                cross_ff[layer * M + m] = ffn.fn._grads(ffn.norm, gmap)
-            if self.self_per_cross_attn >= 1:
-                blk, ffn = mods[2 * M][0], mods[2 * M][1]
-                self_attn[layer] = blk.fn._grads(blk.norm, None, gmap)
-                self_ff[layer] = ffn.fn._grads(ffn.norm, gmap)
-        gp = lambda t: None if id(t) not in gmap else gmap[id(t)].data_ptr()   # noqa: E731
+                self_attn.append(attn(mods[2 * M][0], False))
+                self_ff.append(ff(mods[2 * M][1]))
+            else:   # never executed; keeps the arrays depth long
+                self_attn.append(dict(heads=1, dim_head=1, query_dim=self.l_d, dropout=0.0, p=[-1] * 8))
+                self_ff.append(dict(dim=self.l_d, gate=0, dropout=0.0, p=[-1] * 6))
         head = self.final_classifier_head
-        grads = _capi.ModelGrads(latents=gp(self.latents), cross_attn=cross_attn, cross_ff=cross_ff, self_attn=self_attn,
-                                 self_ff=self_ff, head_norm_w=gp(self.to_logits[1].weight) if head else None,
-                                 head_norm_b=gp(self.to_logits[1].bias) if head else None,
-                                 head_w=gp(self.to_logits[2].weight) if head else None,
-                                 head_b=gp(self.to_logits[2].bias) if head else None)
-        return grads, [cross_attn, cross_ff, self_attn, self_ff]
+        return json.dumps(dict(
+            M=M, depth=depth, l_c=self.l_c, l_d=self.l_d, self_per_cross_attn=self.self_per_cross_attn, head=int(head),
+            out_dims=self.out_dims, num_freq_bands=self.num_freq_bands, max_freq=float(self.max_freq),
+            fourier=int(self.fourier_encode_data), channels=[int(c) for c in self.input_channels],
+            axes=[int(a) for a in self.input_axes], latents=ix(self.latents), cross_attn=cross_attn, cross_ff=cross_ff,
+            self_attn=self_attn, self_ff=self_ff,
+            head_p=[ix(self.to_logits[1].weight), ix(self.to_logits[1].bias), ix(self.to_logits[2].weight),
+                    ix(self.to_logits[2].bias)] if head else None,
+            core_precision={"fp32": _capi.HN_CORE_F32, "bf16": _capi.HN_CORE_BF16, "bf16x3": _capi.HN_CORE_BF16X3}[self.core_precision]),
+            sort_keys=True)
+
+    def _descriptor(self, rng=None):
+        """(hn_model, keep-alive) for this module's parameters; rng = (seed, offset) of a training forward: blocks then carry
+        their dropout rates (include/healnet_hip.h hn_rng); None = inference descriptor."""
+        r = None if rng is None else torch.tensor([_wrap64(rng[0]), int(rng[1])], dtype=torch.int64)
+        return _ops.spec_of(self._spec_text).model(list(self.parameters()), r)
 
     def _check_mode(self) -> None:
         if self.self_per_cross_attn >= 2:
@@ -622,48 +507,44 @@ class HealNet(nn.Module):
 
     def _dropout_active(self) -> bool:
         """nn.Dropout semantics: masks are drawn in training mode only (healnet.py:381,421 attention, :347 feed-forward)."""
-        return self.training and any(isinstance(mod, (Attention, FeedForward)) and mod.dropout_p > 0.0 for mod in self.modules())
+        return self.training and self._any_dropout
 
     # -- forward ---------------------------------------------------------------------------------
     def forward(self, tensors: List[Optional[torch.Tensor]], mask: Optional[torch.Tensor] = None,
                 return_embeddings: bool = False, verbose: bool = False, _profile=None):
-        # kernels are launched on the CURRENT device of the calling thread: make that the model's device for the call
-        # (a model on cuda:1 called while cuda:0 is current would otherwise launch on the wrong GPU)
-        if self.latents.is_cuda and torch.cuda.current_device() != self.latents.device.index:
-            with torch.cuda.device(self.latents.device):
-                return self._forward(tensors, mask, return_embeddings, verbose, _profile)
-        return self._forward(tensors, mask, return_embeddings, verbose, _profile)
-
-    def _forward(self, tensors, mask, return_embeddings, verbose, _profile):
+        """One operator call: torch.ops.healnet_hip.fusion_forward (no autograd) or fusion_forward_train (tape + registered
+        backward) -- healnet.py:190-250 of the reference."""
         self._check_mode()
         M = self.modalities
         if len(tensors) > M:
             raise ValueError(f"{len(tensors)} tensors passed to a model with {M} modalities")
-        missing_idx = [i for i in range(M) if i >= len(tensors) or tensors[i] is None]
+        n_given = len(tensors)
+        # the reference's missing_idx holds the None entries INSIDE the list (:193); a modality beyond a shorter list fails in
+        # the bare try/except (:238) instead -- it is skipped too, but the verbose=True `continue` quirk never applies to it
+        none_idx = [i for i in range(n_given) if tensors[i] is None]
+        missing_idx = none_idx + list(range(n_given, M))
         if verbose:
-            print(f"Missing modalities indices: {[i for i in missing_idx if i < len(tensors)]}")
+            print(f"Missing modalities indices: {none_idx}")
         _require_gpu(self.latents, "HealNet parameters")
         device = self.latents.device
-        inputs = (_capi.ModalityInput * M)()
         held: List[Optional[torch.Tensor]] = [None] * M
         b = None
-        for i in range(M):                    # the reference's sanity check (:206-208), all modalities first
-            if i in missing_idx:
-                continue
-            assert tensors[i].dim() - 2 == self.input_axes[i], (f'input data for modality {i + 1} must hav'
-                                                                f' the same number of axis as the input axis parameter')
-        for i in range(M):
-            if i in missing_idx:
-                continue
+        for i in range(n_given):              # the reference's sanity check (:206-208), all modalities first
+            if tensors[i] is not None:
+                assert tensors[i].dim() - 2 == self.input_axes[i], (f'input data for modality {i + 1} must hav'
+                                                                    f' the same number of axis as the input axis parameter')
+        for i in range(n_given):
             data = tensors[i]
+            if data is None:
+                continue
             _require_gpu(data, f"modality {i + 1}")
             if data.device != device:
                 raise RuntimeError(f"healnet_amd: modality {i + 1} lives on {data.device}, the model on {device}")
-            bb, *axis, ch = data.shape
+            bb, ch = data.shape[0], data.shape[-1]
             if ch != self.input_channels[i]:
                 raise ValueError(f"modality {i + 1}: expected {self.input_channels[i]} channels, got {ch} (the reference "
                                  "would silently skip every block of this modality, Appendix B-7)")
-            if len(axis) > _capi.HN_MAX_AXES:
+            if data.dim() - 2 > _capi.HN_MAX_AXES:
                 raise NotImplementedError(f"at most {_capi.HN_MAX_AXES} spatial axes are supported")
             if b is None:
                 b = bb
@@ -671,12 +552,7 @@ class HealNet(nn.Module):
                 raise ValueError("batch dim must be identical across modalities")
             # bf16 tensors are read as they are, uint8 tensors as byte / 255 (8-bit image transport, == ToTensor);
             # anything else is staged as fp32
-            x = data.contiguous() if data.dtype in (torch.bfloat16, torch.uint8) else _f32c(data)
-            held[i] = x
-            inputs[i].data = x.data_ptr()
-            inputs[i].dtype = {torch.bfloat16: _capi.HN_BF16, torch.uint8: _capi.HN_U8}.get(x.dtype, _capi.HN_F32)
-            for a, s in enumerate(axis):
-                inputs[i].spatial[a] = int(s)
+            held[i] = data.contiguous() if data.dtype in (torch.bfloat16, torch.uint8) else _f32c(data)
         if b is None:
             raise ValueError("at least one modality must be present")
         mask_u8 = None
@@ -690,131 +566,108 @@ class HealNet(nn.Module):
                                          "the mask is applied to every modality's cross-attention (Appendix B-5)")
             mask_u8 = flat.to(device=device, dtype=torch.uint8).contiguous()
 
-        lib = _capi.lib()
-        model, keep = self._descriptor()
-        need = lib.hn_fusion_workspace_bytes(C.byref(model), inputs, b)
-        if need == 0:
-            _capi.check(-1, "hn_fusion_workspace_bytes")
-        ws = _WS.get(device, need)
-        embeddings = return_embeddings or not self.final_classifier_head
-        out = torch.empty((b, self.l_c, self.l_d) if embeddings else (b, self.out_dims), dtype=torch.float32, device=device)
-
-        n_slots = self.depth * (M + 1)
-        stats_ptrs = x_ptrs = None
-        stats_t: List[Optional[torch.Tensor]] = [None] * n_slots
-        trace_t: List[Optional[torch.Tensor]] = [None] * n_slots
+        params = list(self.parameters())
+        embeddings = bool(return_embeddings) or not self.final_classifier_head
+        skip_bits = sum(1 << i for i in none_idx) if verbose else 0
         dropping = self._dropout_active()
-        taping = dropping or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()))
-        if self.keep_attention_stats and not taping:
-            stats_ptrs = (C.c_void_p * n_slots)()
-            x_ptrs = (C.c_void_p * n_slots)()
-            for layer in range(self.depth):
-                for j in range(M + 1):
-                    live = (j < M and held[j] is not None) or (j == M and self.self_per_cross_attn > 0)
-                    if not live:
-                        continue
-                    heads = self.layers[layer][2 * j].fn.heads if j < M else self.layers[layer][2 * M][0].fn.heads
-                    stats_t[layer * (M + 1) + j] = torch.empty(b, heads, self.l_c, 2, dtype=torch.float32, device=device)
-                    trace_t[layer * (M + 1) + j] = torch.empty(b, self.l_c, self.l_d, dtype=torch.float32, device=device)
-                    stats_ptrs[layer * (M + 1) + j] = stats_t[layer * (M + 1) + j].data_ptr()
-                    x_ptrs[layer * (M + 1) + j] = trace_t[layer * (M + 1) + j].data_ptr()
-
+        taping = dropping or (torch.is_grad_enabled() and any(p.requires_grad for p in params))
         if taping:
-            # autograd path (train or eval mode alike, as in PyTorch): tape-recording forward + hn_fusion_backward.
+            # autograd route (train or eval mode alike, as in PyTorch): tape-recording forward, backward registered on the op.
             # Dropout masks are drawn in training mode only, grad mode or not (nn.Dropout); every forward advances the
             # Philox offset, the seed is torch's global seed (torch.manual_seed).
             if _profile is not None:
                 raise ValueError("profiling hooks are only available under torch.no_grad() in eval mode")
-            rng = None
+            rng, rng_t = None, None
             if dropping:
-                self._rng_offset = (getattr(self, "_rng_offset", 0) + 1) & 0xFFFFFFFF
+                self._rng_offset = (self._rng_offset + 1) & 0xFFFFFFFF
                 rng = (torch.initial_seed(), self._rng_offset)
+                rng_t = torch.tensor([_wrap64(rng[0]), rng[1]], dtype=torch.int64)
             self._last_rng = rng
-            out = _FusionFunction.apply(self, inputs, held, mask_u8, b, bool(verbose), embeddings, None, None, rng,
-                                        *list(self.parameters()))
-            if self.keep_attention_stats:
-                # the tape already holds every block's softmax statistics and input: view them, no copies
-                tape, masked, skip = self._last_tape
-                so, xo = (C.c_size_t * n_slots)(), (C.c_size_t * n_slots)()
-                _capi.check(lib.hn_fusion_tape_layout(C.byref(model), inputs, b, masked, skip, so, xo), "hn_fusion_tape_layout")
-                tf = tape.view(torch.float32)
-                for slot in range(n_slots):
-                    if so[slot] == C.c_size_t(-1).value:
-                        continue
-                    j = slot % (M + 1)
-                    heads = self.layers[slot // (M + 1)][2 * j].fn.heads if j < M else self.layers[slot // (M + 1)][2 * M][0].fn.heads
-                    stats_t[slot] = tf[so[slot]:so[slot] + b * heads * self.l_c * 2].view(b, heads, self.l_c, 2)
-                    trace_t[slot] = tf[xo[slot]:xo[slot] + b * self.l_c * self.l_d].view(b, self.l_c, self.l_d)
-            self._last_tape = None
+            # healnet_amd.train.flatten_parameters(): every p.grad is a view of one flat buffer -> the backward accumulates
+            # straight into it (no per-parameter zero tensors, no AccumulateGrad pass) and autograd gets None back
+            gbuf, goffs = None, []
+            flatp = self.__dict__.get("_hn_flat")
+            if flatp is not None and not torch.compiler.is_compiling():
+                goffs = flatp.direct_offsets(params)
+                gbuf = flatp.grads if goffs else None
+            out, tape, layout = _hip.fusion_forward_train(held, mask_u8, params, self._spec_text, skip_bits, embeddings, rng_t, gbuf,
+                                                          goffs or [])
+            self._last = dict(tape=tape, layout=layout, inputs=held, mask=mask_u8, b=b) if self.keep_attention_stats else None
         else:
-            _capi.check(lib.hn_fusion_forward(C.byref(model), inputs, b, _ptr(mask_u8), int(bool(verbose)), int(embeddings),
-                                              out.data_ptr(), stats_ptrs, x_ptrs, ws.data_ptr(), ws.numel(),
-                                              _stream_ptr(device), _profile), "hn_fusion_forward")
+            if _profile is not None:
+                _ops.set_profile(_profile)
+            out, stats, trace = _hip.fusion_forward(held, mask_u8, params, self._spec_text, skip_bits, embeddings,
+                                                    bool(self.keep_attention_stats))
+            self._last = dict(stats=stats, trace=trace, inputs=held, mask=mask_u8, b=b) if self.keep_attention_stats else None
         if verbose:
             for layer in range(self.depth):
-                for i in missing_idx:
+                for i in none_idx:
                     print(f"Skipping update in fusion layer {layer + 1} for missing modality {i + 1}")
-        self._last = dict(inputs=held, mask=mask_u8, stats=stats_t, trace=trace_t, b=b, skipped_self=bool(verbose) and bool(missing_idx))
-        self._bind_lazy_probs()
         if self.compat_mutate_inputs:
-            for i in range(min(M, len(tensors))):
+            for i in range(n_given):
                 if held[i] is not None:
                     tensors[i] = fourier_encode_concat(_f32c(held[i]), self.num_freq_bands, self.max_freq, self.fourier_encode_data)
         return out
 
     # -- attention weights on demand ---------------------------------------------------------------
-    def _bind_lazy_probs(self) -> None:
+    def _slot_buffers(self, slot: int):
+        """(stats (b, heads, l_c, 2), block input (b, l_c, l_d)) of an attention slot of the last forward, or None."""
         last = self._last
+        if last is None:
+            return None
+        M, b = self.modalities, last["b"]
+        layer, j = divmod(slot, M + 1)
+        heads = self.layers[layer][2 * j].fn.heads if j < M else self.layers[layer][2 * M][0].fn.heads
+        n_stats, n_x = b * heads * self.l_c * 2, b * self.l_c * self.l_d
+        if "tape" in last:
+            n_slots = self.depth * (M + 1)
+            so, xo = int(last["layout"][slot]), int(last["layout"][n_slots + slot])
+            if so < 0:
+                return None
+            tf = last["tape"].view(torch.float32)
+            return tf[so:so + n_stats].view(b, heads, self.l_c, 2), tf[xo:xo + n_x].view(b, self.l_c, self.l_d)
+        live = (j < M and last["inputs"][j] is not None) or (j == M and self.self_per_cross_attn > 0)
+        if not live:
+            return None
+        return last["stats"][slot, :n_stats].view(b, heads, self.l_c, 2), last["trace"][slot]
+
+    def _block_probs(self, att: "Attention", reduced: bool) -> Optional[torch.Tensor]:
+        """``att.attn_weights`` (or its latent-row mean) from the last forward: the most recent slot the block ran in."""
+        last = self._last
+        if last is None:
+            return None
         M = self.modalities
-        for mod in self.modules():
-            if isinstance(mod, Attention):
-                mod._probs_fn = None
-        if last is None or not self.keep_attention_stats:
-            return
-        lib = _capi.lib()
-        zcache: Dict[int, tuple] = {}
-        for layer in range(self.depth):
-            for j in range(M + 1):
-                slot = layer * (M + 1) + j
-                if last["stats"][slot] is None:
-                    continue
-                blk = self.layers[layer][2 * j] if j < M else self.layers[layer][2 * M][0]
-                att: Attention = blk.fn
-
-                def probs(reduced=False, layer=layer, j=j, slot=slot, blk=blk, att=att):
-                    b, L = last["b"], self.l_c
-                    xin, stats = last["trace"][slot], last["stats"][slot]
-                    dev = xin.device
-                    if j < M:
-                        if j not in zcache:
-                            data = _f32c(last["inputs"][j])
-                            n = data.numel() // (b * data.shape[-1])
-                            d = self.context_dims[j]
-                            ld = lib.hn_context_pitch(d, att.dim_head)
-                            z = torch.empty(b, n, ld, dtype=torch.float32, device=dev)
-                            sp = (C.c_int * len(data.shape[1:-1]))(*data.shape[1:-1])
-                            _capi.check(lib.hn_encode_norm(data.data_ptr(), b, len(data.shape) - 2, sp, data.shape[-1],
-                                                           self.num_freq_bands, float(self.max_freq),
-                                                           int(self.fourier_encode_data), 1e-5, z.data_ptr(), ld,
-                                                           _stream_ptr(dev)), "hn_encode_norm")
-                            zcache[j] = (z, ld, n, d)
-                        z, ld, n, d = zcache[j]
-                        p = att._params(blk.norm, blk.norm_context)
-                        msk = last["mask"]
-                    else:
-                        z, ld, n, d = None, 0, L, self.l_d
-                        p = att._params(blk.norm, None)
-                        msk = None
-                    need = lib.hn_attn_workspace_bytes(C.byref(p), int(z is not None), ld, b, L, n, d)
-                    aux = _WS_AUX.get(dev, need)
-                    pr = torch.empty((b * att.heads, n) if reduced else (b * att.heads, L, n), dtype=torch.float32, device=dev)
-                    fn = lib.hn_attn_importance if reduced else lib.hn_attn_probs
-                    _capi.check(fn(C.byref(p), xin.data_ptr(), _ptr(z), ld, b, L, n, d, _ptr(msk), stats.data_ptr(),
-                                   pr.data_ptr(), aux.data_ptr(), aux.numel(), _stream_ptr(dev)),
-                                "hn_attn_importance" if reduced else "hn_attn_probs")
-                    return pr
-
-                att._probs_fn = probs
+        for slot in reversed(att._hn_slots):
+            bufs = self._slot_buffers(slot)
+            if bufs is None:
+                continue
+            stats, xin = bufs
+            layer, j = divmod(slot, M + 1)
+            blk = self.layers[layer][2 * j] if j < M else self.layers[layer][2 * M][0]
+            lib = _capi.lib()
+            b, L, dev = last["b"], self.l_c, xin.device
+            with torch.cuda.device(dev):
+                if j < M:
+                    zc = last.setdefault("zcache", {})
+                    if j not in zc:
+                        d = self.context_dims[j]
+                        ld = lib.hn_context_pitch(d, att.dim_head)
+                        z = _hip.encode_norm(_f32c(last["inputs"][j]), self.num_freq_bands, float(self.max_freq),
+                                             bool(self.fourier_encode_data), ld)
+                        zc[j] = (z, ld, z.shape[1], d)
+                    z, ld, n, d = zc[j]
+                    p, msk = att._params(blk.norm, blk.norm_context), last["mask"]
+                else:
+                    z, ld, n, d = None, 0, L, self.l_d
+                    p, msk = att._params(blk.norm, None), None
+                need = lib.hn_attn_workspace_bytes(C.byref(p), int(z is not None), ld, b, L, n, d)
+                aux = _WS_AUX.get(dev, need)
+                pr = torch.empty((b * att.heads, n) if reduced else (b * att.heads, L, n), dtype=torch.float32, device=dev)
+                fn = lib.hn_attn_importance if reduced else lib.hn_attn_probs
+                _capi.check(fn(C.byref(p), xin.data_ptr(), _ptr(z), ld, b, L, n, d, _ptr(msk), stats.data_ptr(), pr.data_ptr(),
+                               aux.data_ptr(), aux.numel(), _stream_ptr(dev)), "hn_attn_importance" if reduced else "hn_attn_probs")
+            return pr
+        return None
 
     def get_attention_weights(self) -> List[Optional[torch.Tensor]]:
         """Every ``Attention.attn_weights`` in ``self.modules()`` order (healnet.py:252-262): per layer

@@ -1,45 +1,252 @@
-"""``torch.ops.healnet_hip.*`` -- the C-ABI entry points registered as PyTorch operators (CUDA/HIP dispatch key
-only: there is no CPU kernel, calling them with CPU tensors raises NotImplementedError from the dispatcher).
+"""``torch.ops.healnet_hip.*`` -- the C-ABI entry points registered as PyTorch operators.  This is THE route of the package:
+``HealNet.forward`` / ``Attention.forward`` / ``FeedForward.forward`` dispatch through these ops (healnet/models/healnet.py:190-195,
+:400, :349 of the reference are the call sites they serve), autograd is attached with ``torch.library.register_autograd``, shape
+inference with ``torch.library.register_fake`` (so ``torch.compile`` traces a model into one opaque node per call).
 
-    torch.ops.healnet_hip.fourier_encode_concat(data, num_freq_bands, max_freq, fourier_encode_data) -> (b, N, D)
-    torch.ops.healnet_hip.encode_norm(data, num_freq_bands, max_freq, fourier_encode_data, pitch)    -> (b, N, pitch)
-    torch.ops.healnet_hip.attention(x, context?, mask?, norm_w?, norm_b?, ctx_gamma?, ctx_beta?, w_q, w_kv, w_out, b_out,
-                                    heads, residual) -> (b, L, query_dim)
-    torch.ops.healnet_hip.feed_forward(x, norm_w?, norm_b?, w1, b1, w2, b2, gelu, residual) -> like x
-    torch.ops.healnet_hip.head(x, norm_w, norm_b, w, bias) -> (b, out_dims)
-    torch.ops.healnet_hip.temperature_softmax(logits, temperature) -> like logits (softmax over the last dim)
+CUDA/HIP dispatch key only: there is no CPU kernel, calling an op with CPU tensors raises NotImplementedError from the dispatcher.
+
+Whole fusion stack (``spec`` = JSON description of the module structure, see ``HealNet._spec``; ``params`` = ``list(model.parameters())``):
+    fusion_forward(tensors, mask?, params, spec, skip_self, embeddings, keep_stats) -> (out, stats, trace)       hn_fusion_forward
+    fusion_forward_train(tensors, mask?, params, spec, skip_self, embeddings, rng?, grad_buffer?, grad_offsets)
+                                                                                   -> (out, tape, layout)       hn_fusion_forward_train
+    fusion_backward(dout, tape, tensors, mask?, params, spec, skip_self, embeddings, rng?, grad_buffer?, grad_offsets,
+                    needs_grad) -> Tensor[]                                                                      hn_fusion_backward
+Blocks (differentiable w.r.t. x and the parameters; no gradient flows to the context, as in the C ABI):
+    attention(x, context?, mask?, norm_w?, norm_b?, ctx_gamma?, ctx_beta?, w_q, w_kv, w_out, b_out, heads, residual) -> (b, L, query_dim)
+    attention_fwd(..., train) -> (out, stats, saved)       attention_bwd(dy, x, out, ..., stats, saved) -> Tensor[9]
+    feed_forward(x, norm_w?, norm_b?, w1, b1, w2, b2, gelu, residual) -> like x        feed_forward_bwd(...) -> Tensor[7]
+    head(x, norm_w, norm_b, w, bias) -> (b, out_dims)                                   head_bwd(...) -> Tensor[5]
+Elementwise / encode helpers (forward only):
+    fourier_encode_concat(data, num_freq_bands, max_freq, fourier_encode_data) -> (b, N, D)
+    encode_norm(data, num_freq_bands, max_freq, fourier_encode_data, pitch) -> (b, N, pitch)
+    temperature_softmax(logits, temperature) -> like logits
 """
 from __future__ import annotations
 
 import ctypes as C
-from typing import Optional
+import functools
+import json
+import threading
+from typing import Dict, List, Optional, Sequence
 
 import torch
 
 from . import _capi
-from .healnet import _WS, _f32c, _ptr, _stream_ptr, fourier_encode_concat as _encode, temperature_softmax as _tsoftmax
+from ._rt import WS, f32c as _f32c, ptr as _ptr, stream_ptr as _stream_ptr
 
 _lib = torch.library.Library("healnet_hip", "DEF")
 _lib.define("fourier_encode_concat(Tensor data, int num_freq_bands, float max_freq, bool fourier_encode_data) -> Tensor")
 _lib.define("encode_norm(Tensor data, int num_freq_bands, float max_freq, bool fourier_encode_data, int pitch) -> Tensor")
-_lib.define("attention(Tensor x, Tensor? context, Tensor? mask, Tensor? norm_w, Tensor? norm_b, Tensor? ctx_gamma, "
-            "Tensor? ctx_beta, Tensor w_q, Tensor w_kv, Tensor w_out, Tensor b_out, int heads, bool residual) -> Tensor")
-_lib.define("feed_forward(Tensor x, Tensor? norm_w, Tensor? norm_b, Tensor w1, Tensor b1, Tensor w2, Tensor b2, bool gelu, "
-            "bool residual) -> Tensor")
+_ATTN_ARGS = ("Tensor x, Tensor? context, Tensor? mask, Tensor? norm_w, Tensor? norm_b, Tensor? ctx_gamma, Tensor? ctx_beta, "
+              "Tensor w_q, Tensor w_kv, Tensor w_out, Tensor b_out, int heads, bool residual")
+_lib.define(f"attention({_ATTN_ARGS}) -> Tensor")
+_lib.define(f"attention_fwd({_ATTN_ARGS}, bool train) -> (Tensor, Tensor, Tensor)")
+_lib.define("attention_bwd(Tensor dy, Tensor x, Tensor out, Tensor? context, Tensor? mask, Tensor? norm_w, Tensor? norm_b, "
+            "Tensor? ctx_gamma, Tensor? ctx_beta, Tensor w_q, Tensor w_kv, Tensor w_out, Tensor b_out, int heads, bool residual, "
+            "Tensor stats, Tensor saved) -> Tensor[]")
+_FF_ARGS = "Tensor x, Tensor? norm_w, Tensor? norm_b, Tensor w1, Tensor b1, Tensor w2, Tensor b2, bool gelu, bool residual"
+_lib.define(f"feed_forward({_FF_ARGS}) -> Tensor")
+_lib.define(f"feed_forward_bwd(Tensor dy, {_FF_ARGS}) -> Tensor[]")
 _lib.define("head(Tensor x, Tensor norm_w, Tensor norm_b, Tensor w, Tensor bias) -> Tensor")
+_lib.define("head_bwd(Tensor dlogits, Tensor x, Tensor norm_w, Tensor norm_b, Tensor w) -> Tensor[]")
 _lib.define("temperature_softmax(Tensor logits, float temperature) -> Tensor")
+_lib.define("fusion_forward(Tensor?[] tensors, Tensor? mask, Tensor[] params, str spec, int skip_self, bool embeddings, "
+            "bool keep_stats) -> (Tensor, Tensor, Tensor)")
+_lib.define("fusion_forward_train(Tensor?[] tensors, Tensor? mask, Tensor[] params, str spec, int skip_self, bool embeddings, "
+            "Tensor? rng, Tensor? grad_buffer, int[] grad_offsets) -> (Tensor, Tensor, Tensor)")
+_lib.define("fusion_backward(Tensor dout, Tensor tape, Tensor?[] tensors, Tensor? mask, Tensor[] params, str spec, int skip_self, "
+            "bool embeddings, Tensor? rng, Tensor(a!)? grad_buffer, int[] grad_offsets, bool[] needs_grad) -> Tensor[]")
+
+_FAKE_PTR = 256          # stands in for device addresses while tracing with FakeTensors (size queries only, nothing is launched)
+
+
+# ------------------------------------------------------------------------------------------------
+# model structure <-> C descriptors
+# ------------------------------------------------------------------------------------------------
+class Spec:
+    """Parsed ``spec`` string of the fusion ops: the structure of a HealNet (sizes, per-block head counts / dropout rates, and
+    for every pointer field of hn_model the index of the tensor in ``params`` that backs it -- tied blocks simply repeat
+    indices).  Builds the ctypes descriptors of include/healnet_hip.h from a parameter list."""
+
+    ATTN_FIELDS = ("norm_w", "norm_b", "ctx_gamma", "ctx_beta", "w_q", "w_kv", "w_out", "b_out")
+    FF_FIELDS = ("norm_w", "norm_b", "w1", "b1", "w2", "b2")
+    HEAD_FIELDS = ("head_norm_w", "head_norm_b", "head_w", "head_b")
+
+    def __init__(self, text: str):
+        d = json.loads(text)
+        self.d = d
+        self.M, self.depth, self.l_c, self.l_d = d["M"], d["depth"], d["l_c"], d["l_d"]
+        self.spca = d["self_per_cross_attn"]
+        self.head = bool(d["head"])
+        self.out_dims = d["out_dims"]
+        self.n_slots = self.depth * (self.M + 1)
+        self.max_heads = max([a["heads"] for a in d["cross_attn"]] + [a["heads"] for a in d["self_attn"]] + [1])
+
+    def slot_heads(self, slot: int) -> int:
+        layer, j = divmod(slot, self.M + 1)
+        return self.d["cross_attn"][layer * self.M + j]["heads"] if j < self.M else self.d["self_attn"][layer]["heads"]
+
+    def model(self, params: Optional[Sequence[torch.Tensor]], rng: Optional[torch.Tensor] = None):
+        """(hn_model, keep-alive list).  ``params`` None -> placeholder addresses (fake-tensor tracing).  ``rng`` = CPU int64
+        tensor (seed, offset) of a training forward / its backward: blocks then carry their dropout rates."""
+        d = self.d
+        if params is None:
+            P = lambda i: None if i is None or i < 0 else _FAKE_PTR      # noqa: E731
+        else:
+            P = lambda i: None if i is None or i < 0 else _ptr(params[i])  # noqa: E731
+        dropping = rng is not None
+        M, depth = self.M, self.depth
+        ca = (_capi.AttnParams * max(1, depth * M))()
+        cf = (_capi.FFParams * max(1, depth * M))()
+        sa = (_capi.AttnParams * depth)()
+        sf = (_capi.FFParams * depth)()
+
+        def attn(dst, a):
+            dst.heads, dst.dim_head, dst.query_dim = a["heads"], a["dim_head"], a["query_dim"]
+            for f, i in zip(self.ATTN_FIELDS, a["p"]):
+                setattr(dst, f, P(i))
+            dst.dropout = float(a["dropout"]) if dropping else 0.0
+
+        def ff(dst, a):
+            dst.dim, dst.gate = a["dim"], a["gate"]
+            for f, i in zip(self.FF_FIELDS, a["p"]):
+                setattr(dst, f, P(i))
+            dst.dropout = float(a["dropout"]) if dropping else 0.0
+
+        for k, a in enumerate(d["cross_attn"]):
+            attn(ca[k], a)
+        for k, a in enumerate(d["cross_ff"]):
+            ff(cf[k], a)
+        for k, a in enumerate(d["self_attn"]):
+            attn(sa[k], a)
+        for k, a in enumerate(d["self_ff"]):
+            ff(sf[k], a)
+        cd = (C.c_int * M)(*d["channels"])
+        ax = (C.c_int * M)(*d["axes"])
+        hp = d["head_p"] if self.head else [None] * 4
+        if rng is not None:
+            seed, offset = int(rng[0]) & 0xFFFFFFFFFFFFFFFF, int(rng[1]) & 0xFFFFFFFF
+            r = _capi.Rng(seed=seed, offset=offset, stream=0)
+        else:
+            r = _capi.Rng(0, 0, 0)
+        model = _capi.Model(
+            n_modalities=M, depth=depth, l_c=self.l_c, l_d=self.l_d, self_per_cross_attn=self.spca,
+            final_classifier_head=int(self.head), out_dims=self.out_dims, num_freq_bands=d["num_freq_bands"],
+            max_freq=float(d["max_freq"]), fourier_encode_data=int(d["fourier"]), channel_dims=cd, num_spatial_axes=ax,
+            latents=P(d["latents"]), cross_attn=ca, cross_ff=cf, self_attn=sa, self_ff=sf,
+            head_norm_w=P(hp[0]), head_norm_b=P(hp[1]), head_w=P(hp[2]), head_b=P(hp[3]),
+            core_precision=d["core_precision"], rng=r)
+        return model, [ca, cf, sa, sf, cd, ax]
+
+    def grads(self, gptr: Sequence[Optional[int]]):
+        """hn_model_grads whose entries are the addresses ``gptr[param index]`` (None = no gradient wanted)."""
+        d = self.d
+        G = lambda i: None if i is None or i < 0 else gptr[i]      # noqa: E731
+        M, depth = self.M, self.depth
+        ca = (_capi.AttnGrads * max(1, depth * M))()
+        cf = (_capi.FFGrads * max(1, depth * M))()
+        sa = (_capi.AttnGrads * depth)()
+        sf = (_capi.FFGrads * depth)()
+        for arr, blocks, fields in ((ca, d["cross_attn"], self.ATTN_FIELDS), (cf, d["cross_ff"], self.FF_FIELDS),
+                                    (sa, d["self_attn"], self.ATTN_FIELDS), (sf, d["self_ff"], self.FF_FIELDS)):
+            for k, a in enumerate(blocks):
+                for f, i in zip(fields, a["p"]):
+                    setattr(arr[k], f, G(i))
+        hp = d["head_p"] if self.head else [None] * 4
+        g = _capi.ModelGrads(latents=G(d["latents"]), cross_attn=ca, cross_ff=cf, self_attn=sa, self_ff=sf,
+                             head_norm_w=G(hp[0]), head_norm_b=G(hp[1]), head_w=G(hp[2]), head_b=G(hp[3]))
+        return g, [ca, cf, sa, sf]
+
+    def inputs(self, tensors: Sequence[Optional[torch.Tensor]], fake: bool = False):
+        """(hn_modality_input[M], held tensors, b).  Entries beyond a shorter list / None = missing modality."""
+        M = self.M
+        inp = (_capi.ModalityInput * M)()
+        held: List[Optional[torch.Tensor]] = [None] * M
+        b = None
+        for i in range(min(M, len(tensors))):
+            t = tensors[i]
+            if t is None:
+                continue
+            if not fake:
+                t = t.contiguous() if t.dtype in (torch.bfloat16, torch.uint8) else _f32c(t)
+            held[i] = t
+            inp[i].data = _FAKE_PTR if fake else t.data_ptr()
+            inp[i].dtype = {torch.bfloat16: _capi.HN_BF16, torch.uint8: _capi.HN_U8}.get(t.dtype, _capi.HN_F32)
+            axes = list(t.shape[1:-1])
+            if len(axes) > _capi.HN_MAX_AXES:
+                raise NotImplementedError(f"at most {_capi.HN_MAX_AXES} spatial axes are supported")
+            for a, s in enumerate(axes):
+                inp[i].spatial[a] = int(s)
+            b = int(t.shape[0]) if b is None else b
+        if b is None:
+            raise ValueError("at least one modality must be present")
+        return inp, held, b
+
+
+@functools.lru_cache(maxsize=64)
+def spec_of(text: str) -> Spec:
+    return Spec(text)
+
+
+# Side channels of the fusion ops (host-only objects that cannot travel through an operator schema):
+#   profile hook  : bench.py's hipEvent pairs around the dominant kernel (hn_profile), consumed by the next fusion_forward call
+#   backward hooks: gradient-readiness callbacks of the overlapped data-parallel all-reduce (healnet_amd.dist), keyed by the
+#                   address of the flat gradient buffer the backward accumulates into
+_tls = threading.local()
+_BACKWARD_HOOKS: Dict[int, object] = {}
+
+
+def set_profile(profile) -> None:
+    """``profile``: ctypes pointer to a _capi.Profile (or None) handed to the NEXT hn_fusion_forward on this thread."""
+    _tls.profile = profile
+
+
+def register_backward_hook(grad_buffer: torch.Tensor, hook) -> None:
+    """``hook.ready`` must be a _capi.GradReady (kept alive by the hook); ``hook.begin()`` / ``hook.end()`` bracket the call."""
+    _BACKWARD_HOOKS[grad_buffer.data_ptr()] = hook
+
+
+def unregister_backward_hook(grad_buffer: torch.Tensor) -> None:
+    _BACKWARD_HOOKS.pop(grad_buffer.data_ptr(), None)
+
+
+# ------------------------------------------------------------------------------------------------
+# encode / elementwise helpers
+# ------------------------------------------------------------------------------------------------
+def _spatial(x):
+    spatial = list(x.shape[1:-1])
+    if not 1 <= len(spatial) <= _capi.HN_MAX_AXES:
+        raise ValueError(f"1..{_capi.HN_MAX_AXES} spatial axes supported, got {len(spatial)}")
+    n = 1
+    for s in spatial:
+        n *= s
+    return spatial, n
 
 
 def _fourier_encode_concat(data, num_freq_bands, max_freq, fourier_encode_data):
-    return _encode(data, num_freq_bands, max_freq, fourier_encode_data)
+    x = _f32c(data)
+    spatial, n = _spatial(x)
+    b, ch = x.shape[0], x.shape[-1]
+    d = ch + (len(spatial) * (2 * num_freq_bands + 1) if fourier_encode_data else 0)
+    out = torch.empty(b, n, d, dtype=torch.float32, device=x.device)
+    sp = (C.c_int * len(spatial))(*spatial)
+    _capi.check(_capi.lib().hn_fourier_encode_concat(x.data_ptr(), b, len(spatial), sp, ch, num_freq_bands, float(max_freq),
+                                                     int(fourier_encode_data), out.data_ptr(), d, _stream_ptr(x.device)),
+                "hn_fourier_encode_concat")
+    return out
+
+
+@torch.library.register_fake("healnet_hip::fourier_encode_concat")
+def _(data, num_freq_bands, max_freq, fourier_encode_data):
+    spatial, n = _spatial(data)
+    d = data.shape[-1] + (len(spatial) * (2 * num_freq_bands + 1) if fourier_encode_data else 0)
+    return data.new_empty((data.shape[0], n, d), dtype=torch.float32)
 
 
 def _encode_norm(data, num_freq_bands, max_freq, fourier_encode_data, pitch):
     x = _f32c(data)
-    b, spatial, ch = x.shape[0], list(x.shape[1:-1]), x.shape[-1]
-    n = 1
-    for s in spatial:
-        n *= s
+    spatial, n = _spatial(x)
+    b, ch = x.shape[0], x.shape[-1]
     z = torch.empty(b, n, pitch, dtype=torch.float32, device=x.device)
     sp = (C.c_int * len(spatial))(*spatial)
     _capi.check(_capi.lib().hn_encode_norm(x.data_ptr(), b, len(spatial), sp, ch, num_freq_bands, float(max_freq),
@@ -48,39 +255,215 @@ def _encode_norm(data, num_freq_bands, max_freq, fourier_encode_data, pitch):
     return z
 
 
-def _attention(x, context, mask, norm_w, norm_b, ctx_gamma, ctx_beta, w_q, w_kv, w_out, b_out, heads, residual):
-    lib = _capi.lib()
-    x = _f32c(x)
+@torch.library.register_fake("healnet_hip::encode_norm")
+def _(data, num_freq_bands, max_freq, fourier_encode_data, pitch):
+    _, n = _spatial(data)
+    return data.new_empty((data.shape[0], n, pitch), dtype=torch.float32)
+
+
+def _temperature_softmax(logits, temperature):
+    x = _f32c(logits)
+    y = torch.empty_like(x)
+    n = x.shape[-1]
+    _capi.check(_capi.lib().hn_temperature_softmax(x.data_ptr(), y.data_ptr(), x.numel() // n, n, float(temperature),
+                                                   _stream_ptr(x.device)), "hn_temperature_softmax")
+    return y
+
+
+@torch.library.register_fake("healnet_hip::temperature_softmax")
+def _(logits, temperature):
+    return torch.empty_like(logits, dtype=torch.float32, memory_format=torch.contiguous_format)
+
+
+# ------------------------------------------------------------------------------------------------
+# attention block
+# ------------------------------------------------------------------------------------------------
+def _attn_params(x, context, norm_w, norm_b, ctx_gamma, ctx_beta, w_q, w_kv, w_out, b_out, heads, fake=False):
     b, L, qd = x.shape
     inner = w_q.shape[0]
+    if context is None:
+        N, D, ld = L, qd, 0
+    else:
+        N, D, ld = context.shape[1], w_kv.shape[1], context.shape[2]
+    pf = (lambda t: None if t is None else _FAKE_PTR) if fake else _ptr
+    p = _capi.AttnParams(heads=heads, dim_head=inner // heads, query_dim=qd, norm_w=pf(norm_w), norm_b=pf(norm_b),
+                         ctx_gamma=pf(ctx_gamma), ctx_beta=pf(ctx_beta), w_q=pf(w_q), w_kv=pf(w_kv), w_out=pf(w_out),
+                         b_out=pf(b_out))
+    return p, (int(b), int(L), int(N), int(D), int(ld))
+
+
+def _mask_u8(mask, b):
+    return None if mask is None else mask.reshape(b, -1).to(torch.uint8).contiguous()
+
+
+def _attention_fwd(x, context, mask, norm_w, norm_b, ctx_gamma, ctx_beta, w_q, w_kv, w_out, b_out, heads, residual, train):
+    lib = _capi.lib()
+    x = _f32c(x)
     ctx = None if context is None else _f32c(context)
-    N, D, ld = (L, qd, 0) if ctx is None else (ctx.shape[1], w_kv.shape[1], ctx.shape[2])
-    p = _capi.AttnParams(heads=heads, dim_head=inner // heads, query_dim=qd, norm_w=_ptr(norm_w), norm_b=_ptr(norm_b),
-                         ctx_gamma=_ptr(ctx_gamma), ctx_beta=_ptr(ctx_beta), w_q=_ptr(w_q), w_kv=_ptr(w_kv),
-                         w_out=_ptr(w_out), b_out=_ptr(b_out))
-    m = None if mask is None else mask.reshape(b, -1).to(torch.uint8).contiguous()
-    need = lib.hn_attn_workspace_bytes(C.byref(p), int(ctx is not None), ld, b, L, N, D)
+    p, (b, L, N, D, ld) = _attn_params(x, ctx, norm_w, norm_b, ctx_gamma, ctx_beta, w_q, w_kv, w_out, b_out, heads)
+    m = _mask_u8(mask, b)
+    has_ctx = int(ctx is not None)
+    need = lib.hn_attn_workspace_bytes(C.byref(p), has_ctx, ld, b, L, N, D)
     if need == 0:
         _capi.check(-1, "hn_attn_workspace_bytes")
-    ws = _WS.get(x.device, need)
+    ws = WS.get(x.device, need)
     out = torch.empty_like(x)
-    _capi.check(lib.hn_attn_fwd(C.byref(p), x.data_ptr(), out.data_ptr(), int(residual), _ptr(ctx), ld, b, L, N, D, _ptr(m),
-                                None, ws.data_ptr(), ws.numel(), _stream_ptr(x.device)), "hn_attn_fwd")
-    return out
+    stats = torch.empty(b, heads, L, 2, dtype=torch.float32, device=x.device)
+    if train:
+        saved = torch.empty(lib.hn_attn_saved_floats(C.byref(p), has_ctx, ld, b, L, N, D, int(m is not None)),
+                            dtype=torch.float32, device=x.device)
+        _capi.check(lib.hn_attn_fwd_train(C.byref(p), x.data_ptr(), out.data_ptr(), int(residual), _ptr(ctx), ld, b, L, N, D,
+                                          _ptr(m), stats.data_ptr(), saved.data_ptr(), ws.data_ptr(), ws.numel(),
+                                          _stream_ptr(x.device)), "hn_attn_fwd_train")
+    else:
+        saved = torch.empty(0, dtype=torch.float32, device=x.device)
+        _capi.check(lib.hn_attn_fwd(C.byref(p), x.data_ptr(), out.data_ptr(), int(residual), _ptr(ctx), ld, b, L, N, D, _ptr(m),
+                                    stats.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(x.device)), "hn_attn_fwd")
+    return out, stats, saved
+
+
+@torch.library.register_fake("healnet_hip::attention_fwd")
+def _(x, context, mask, norm_w, norm_b, ctx_gamma, ctx_beta, w_q, w_kv, w_out, b_out, heads, residual, train):
+    p, (b, L, N, D, ld) = _attn_params(x, context, norm_w, norm_b, ctx_gamma, ctx_beta, w_q, w_kv, w_out, b_out, heads, fake=True)
+    n_saved = 0
+    if train:
+        n_saved = _capi.lib().hn_attn_saved_floats(C.byref(p), int(context is not None), ld, b, L, N, D, int(mask is not None))
+    return (x.new_empty(x.shape, dtype=torch.float32), x.new_empty((b, heads, L, 2), dtype=torch.float32),
+            x.new_empty((n_saved,), dtype=torch.float32))
+
+
+def _opt_out(t: Optional[torch.Tensor], like: Optional[torch.Tensor]):
+    """Gradient buffer for an optional parameter: zeros like it, or an empty placeholder when the parameter is absent."""
+    return torch.zeros_like(like) if like is not None else t
+
+
+def _attention_bwd(dy, x, out, context, mask, norm_w, norm_b, ctx_gamma, ctx_beta, w_q, w_kv, w_out, b_out, heads, residual,
+                   stats, saved):
+    lib = _capi.lib()
+    x, dy, out = _f32c(x), _f32c(dy), _f32c(out)
+    ctx = None if context is None else _f32c(context)
+    p, (b, L, N, D, ld) = _attn_params(x, ctx, norm_w, norm_b, ctx_gamma, ctx_beta, w_q, w_kv, w_out, b_out, heads)
+    m = _mask_u8(mask, b)
+    has_ctx = int(ctx is not None)
+    need = lib.hn_attn_bwd_workspace_bytes(C.byref(p), has_ctx, ld, b, L, N, D, int(m is not None))
+    if need == 0:
+        _capi.check(-1, "hn_attn_bwd_workspace_bytes")
+    ws = WS.get(x.device, need)
+    empty = torch.empty(0, dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    g = [_opt_out(empty, t) for t in (norm_w, norm_b, ctx_gamma, ctx_beta, w_q, w_kv, w_out, b_out)]
+    gp = lambda t: t.data_ptr() if t.numel() else None      # noqa: E731
+    grads = _capi.AttnGrads(norm_w=gp(g[0]), norm_b=gp(g[1]), ctx_gamma=gp(g[2]), ctx_beta=gp(g[3]), w_q=gp(g[4]), w_kv=gp(g[5]),
+                            w_out=gp(g[6]), b_out=gp(g[7]))
+    _capi.check(lib.hn_attn_bwd(C.byref(p), x.data_ptr(), out.data_ptr(), int(residual), _ptr(ctx), ld, b, L, N, D, _ptr(m),
+                                stats.data_ptr(), saved.data_ptr(), dy.data_ptr(), dx.data_ptr(), C.byref(grads), ws.data_ptr(),
+                                ws.numel(), _stream_ptr(x.device)), "hn_attn_bwd")
+    return [dx] + g
+
+
+@torch.library.register_fake("healnet_hip::attention_bwd")
+def _(dy, x, out, context, mask, norm_w, norm_b, ctx_gamma, ctx_beta, w_q, w_kv, w_out, b_out, heads, residual, stats, saved):
+    empty = x.new_empty((0,), dtype=torch.float32)
+    return [torch.empty_like(x)] + [empty if t is None else torch.empty_like(t)
+                                    for t in (norm_w, norm_b, ctx_gamma, ctx_beta, w_q, w_kv, w_out, b_out)]
+
+
+def _attn_setup(ctx, inputs, output):
+    (x, context, mask, norm_w, norm_b, ctx_gamma, ctx_beta, w_q, w_kv, w_out, b_out, heads, residual, train) = inputs
+    out, stats, saved = output
+    if not train:
+        raise RuntimeError("healnet_hip::attention_fwd was called with train=False on inputs that require grad")
+    if context is not None and context.requires_grad:
+        raise RuntimeError("healnet_hip::attention: no gradient flows to the context (include/healnet_hip.h hn_attn_bwd); "
+                           "detach it -- HEALNet's contexts are encoded modality inputs, not activations")
+    ctx.heads, ctx.residual = heads, residual
+    ctx.opt = [t is not None for t in (context, mask, norm_w, norm_b, ctx_gamma, ctx_beta)]
+    ctx.save_for_backward(x, out, stats, saved, w_q, w_kv, w_out, b_out,
+                          *[t for t in (context, mask, norm_w, norm_b, ctx_gamma, ctx_beta) if t is not None])
+
+
+def _attn_backward(ctx, dout, dstats, dsaved):
+    x, out, stats, saved, w_q, w_kv, w_out, b_out, *rest = ctx.saved_tensors
+    it = iter(rest)
+    context, mask, norm_w, norm_b, ctx_gamma, ctx_beta = [next(it) if have else None for have in ctx.opt]
+    g = torch.ops.healnet_hip.attention_bwd(dout.contiguous(), x, out, context, mask, norm_w, norm_b, ctx_gamma, ctx_beta, w_q, w_kv,
+                                            w_out, b_out, ctx.heads, ctx.residual, stats, saved)
+    opt = lambda t, have: t if have else None      # noqa: E731
+    return (g[0], None, None, opt(g[1], ctx.opt[2]), opt(g[2], ctx.opt[3]), opt(g[3], ctx.opt[4]), opt(g[4], ctx.opt[5]),
+            g[5], g[6], g[7], g[8], None, None, None)
+
+
+torch.library.register_autograd("healnet_hip::attention_fwd", _attn_backward, setup_context=_attn_setup)
+
+
+def _attention(x, context, mask, norm_w, norm_b, ctx_gamma, ctx_beta, w_q, w_kv, w_out, b_out, heads, residual):
+    """CompositeImplicitAutograd: attention_fwd with the tape only when something requires grad."""
+    train = torch.is_grad_enabled() and any(t is not None and t.requires_grad
+                                            for t in (x, norm_w, norm_b, ctx_gamma, ctx_beta, w_q, w_kv, w_out, b_out))
+    return torch.ops.healnet_hip.attention_fwd(x, context, mask, norm_w, norm_b, ctx_gamma, ctx_beta, w_q, w_kv, w_out, b_out, heads,
+                                               residual, train)[0]
+
+
+# ------------------------------------------------------------------------------------------------
+# feed-forward block, head
+# ------------------------------------------------------------------------------------------------
+def _ff_params(x, norm_w, norm_b, w1, b1, w2, b2, gelu):
+    dim = x.shape[-1]
+    return _capi.FFParams(dim=dim, gate=1 if gelu else 0, norm_w=_ptr(norm_w), norm_b=_ptr(norm_b), w1=_ptr(w1), b1=_ptr(b1),
+                          w2=_ptr(w2), b2=_ptr(b2)), x.numel() // dim
 
 
 def _feed_forward(x, norm_w, norm_b, w1, b1, w2, b2, gelu, residual):
     lib = _capi.lib()
     x = _f32c(x)
-    dim = x.shape[-1]
-    rows = x.numel() // dim
-    p = _capi.FFParams(dim=dim, gate=1 if gelu else 0, norm_w=_ptr(norm_w), norm_b=_ptr(norm_b), w1=_ptr(w1), b1=_ptr(b1),
-                       w2=_ptr(w2), b2=_ptr(b2))
-    ws = _WS.get(x.device, lib.hn_ff_workspace_bytes(C.byref(p), rows))
+    p, rows = _ff_params(x, norm_w, norm_b, w1, b1, w2, b2, gelu)
+    ws = WS.get(x.device, lib.hn_ff_workspace_bytes(C.byref(p), rows))
     out = torch.empty_like(x)
     _capi.check(lib.hn_ff_fwd(C.byref(p), x.data_ptr(), out.data_ptr(), int(residual), rows, ws.data_ptr(), ws.numel(),
                               _stream_ptr(x.device)), "hn_ff_fwd")
     return out
+
+
+@torch.library.register_fake("healnet_hip::feed_forward")
+def _(x, norm_w, norm_b, w1, b1, w2, b2, gelu, residual):
+    return x.new_empty(x.shape, dtype=torch.float32)
+
+
+def _feed_forward_bwd(dy, x, norm_w, norm_b, w1, b1, w2, b2, gelu, residual):
+    lib = _capi.lib()
+    x, dy = _f32c(x), _f32c(dy)
+    p, rows = _ff_params(x, norm_w, norm_b, w1, b1, w2, b2, gelu)
+    ws = WS.get(x.device, lib.hn_ff_bwd_workspace_bytes(C.byref(p), rows))
+    empty = torch.empty(0, dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    g = [_opt_out(empty, t) for t in (norm_w, norm_b, w1, b1, w2, b2)]
+    gp = lambda t: t.data_ptr() if t.numel() else None      # noqa: E731
+    grads = _capi.FFGrads(norm_w=gp(g[0]), norm_b=gp(g[1]), w1=gp(g[2]), b1=gp(g[3]), w2=gp(g[4]), b2=gp(g[5]))
+    _capi.check(lib.hn_ff_bwd(C.byref(p), x.data_ptr(), dy.data_ptr(), dx.data_ptr(), int(residual), rows, C.byref(grads),
+                              ws.data_ptr(), ws.numel(), _stream_ptr(x.device)), "hn_ff_bwd")
+    return [dx] + g
+
+
+@torch.library.register_fake("healnet_hip::feed_forward_bwd")
+def _(dy, x, norm_w, norm_b, w1, b1, w2, b2, gelu, residual):
+    empty = x.new_empty((0,), dtype=torch.float32)
+    return [torch.empty_like(x)] + [empty if t is None else torch.empty_like(t) for t in (norm_w, norm_b, w1, b1, w2, b2)]
+
+
+def _ff_setup(ctx, inputs, output):
+    x, norm_w, norm_b, w1, b1, w2, b2, gelu, residual = inputs
+    ctx.gelu, ctx.residual, ctx.has_norm = gelu, residual, norm_w is not None
+    ctx.save_for_backward(x, w1, b1, w2, b2, *([norm_w, norm_b] if norm_w is not None else []))
+
+
+def _ff_backward(ctx, dout):
+    x, w1, b1, w2, b2, *norm = ctx.saved_tensors
+    norm_w, norm_b = norm if ctx.has_norm else (None, None)
+    g = torch.ops.healnet_hip.feed_forward_bwd(dout.contiguous(), x, norm_w, norm_b, w1, b1, w2, b2, ctx.gelu, ctx.residual)
+    return (g[0], g[1] if ctx.has_norm else None, g[2] if ctx.has_norm else None, g[3], g[4], g[5], g[6], None, None)
+
+
+torch.library.register_autograd("healnet_hip::feed_forward", _ff_backward, setup_context=_ff_setup)
 
 
 def _head(x, norm_w, norm_b, w, bias):
@@ -92,7 +475,231 @@ def _head(x, norm_w, norm_b, w, bias):
     return out
 
 
-for _name, _fn in (("fourier_encode_concat", _fourier_encode_concat), ("encode_norm", _encode_norm), ("attention", _attention),
-                   ("feed_forward", _feed_forward), ("head", _head),
-                   ("temperature_softmax", lambda logits, temperature: _tsoftmax(logits, temperature, -1))):
+@torch.library.register_fake("healnet_hip::head")
+def _(x, norm_w, norm_b, w, bias):
+    return x.new_empty((x.shape[0], w.shape[0]), dtype=torch.float32)
+
+
+def _head_bwd(dlogits, x, norm_w, norm_b, w):
+    lib = _capi.lib()
+    x, dl = _f32c(x), _f32c(dlogits)
+    b, L, d = x.shape
+    out_dims = w.shape[0]
+    dx = torch.empty_like(x)
+    g = [torch.zeros_like(norm_w), torch.zeros_like(norm_b), torch.zeros_like(w), torch.zeros(out_dims, dtype=torch.float32, device=x.device)]
+    ws = WS.get(x.device, lib.hn_head_bwd_workspace_bytes(b, d, out_dims))
+    _capi.check(lib.hn_head_bwd(x.data_ptr(), b, L, d, _ptr(norm_w), _ptr(norm_b), _ptr(w), out_dims, dl.data_ptr(), dx.data_ptr(),
+                                g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(), g[3].data_ptr(), ws.data_ptr(), ws.numel(),
+                                _stream_ptr(x.device)), "hn_head_bwd")
+    return [dx] + g
+
+
+@torch.library.register_fake("healnet_hip::head_bwd")
+def _(dlogits, x, norm_w, norm_b, w):
+    return [torch.empty_like(x), torch.empty_like(norm_w), torch.empty_like(norm_b), torch.empty_like(w),
+            x.new_empty((w.shape[0],), dtype=torch.float32)]
+
+
+def _head_setup(ctx, inputs, output):
+    x, norm_w, norm_b, w, bias = inputs
+    ctx.save_for_backward(x, norm_w, norm_b, w)
+
+
+def _head_backward(ctx, dout):
+    g = torch.ops.healnet_hip.head_bwd(dout.contiguous(), *ctx.saved_tensors)
+    return tuple(g)
+
+
+torch.library.register_autograd("healnet_hip::head", _head_backward, setup_context=_head_setup)
+
+
+# ------------------------------------------------------------------------------------------------
+# whole fusion stack
+# ------------------------------------------------------------------------------------------------
+def _out_shape(spec: Spec, b: int, embeddings: bool):
+    return (b, spec.l_c, spec.l_d) if (embeddings or not spec.head) else (b, spec.out_dims)
+
+
+def _fusion_forward(tensors, mask, params, spec, skip_self, embeddings, keep_stats):
+    lib = _capi.lib()
+    sp = spec_of(spec)
+    device = params[0].device
+    with torch.cuda.device(device):        # kernels are launched on the CURRENT device of the calling thread
+        model, keep = sp.model(params)
+        inp, held, b = sp.inputs(tensors)
+        need = lib.hn_fusion_workspace_bytes(C.byref(model), inp, b)
+        if need == 0:
+            _capi.check(-1, "hn_fusion_workspace_bytes")
+        ws = WS.get(device, need)
+        out = torch.empty(_out_shape(sp, b, embeddings), dtype=torch.float32, device=device)
+        stats_ptrs = x_ptrs = None
+        if keep_stats:
+            # every attention block's softmax statistics and input, one row per slot (layer-major: cross_0..cross_{M-1}, self);
+            # the blocks write them in place (hn_fusion_forward chains the latent array through the trace slots: no copies)
+            stats = torch.empty(sp.n_slots, b * sp.max_heads * sp.l_c * 2, dtype=torch.float32, device=device)
+            trace = torch.empty(sp.n_slots, b, sp.l_c, sp.l_d, dtype=torch.float32, device=device)
+            stats_ptrs = (C.c_void_p * sp.n_slots)()
+            x_ptrs = (C.c_void_p * sp.n_slots)()
+            for slot in range(sp.n_slots):
+                j = slot % (sp.M + 1)
+                if (j < sp.M and held[j] is not None) or (j == sp.M and sp.spca > 0):
+                    stats_ptrs[slot] = stats[slot].data_ptr()
+                    x_ptrs[slot] = trace[slot].data_ptr()
+        else:
+            stats = torch.empty(0, dtype=torch.float32, device=device)
+            trace = torch.empty(0, dtype=torch.float32, device=device)
+        profile = getattr(_tls, "profile", None)
+        _tls.profile = None
+        _capi.check(lib.hn_fusion_forward(C.byref(model), inp, b, _ptr(mask), int(skip_self), int(embeddings), out.data_ptr(),
+                                          stats_ptrs, x_ptrs, ws.data_ptr(), ws.numel(), _stream_ptr(device), profile),
+                    "hn_fusion_forward")
+    return out, stats, trace
+
+
+def _batch_of(tensors):
+    for t in tensors:
+        if t is not None:
+            return int(t.shape[0])
+    raise ValueError("at least one modality must be present")
+
+
+@torch.library.register_fake("healnet_hip::fusion_forward")
+def _(tensors, mask, params, spec, skip_self, embeddings, keep_stats):
+    sp = spec_of(spec)
+    b = _batch_of(tensors)
+    like = params[0]
+    out = like.new_empty(_out_shape(sp, b, embeddings), dtype=torch.float32)
+    if keep_stats:
+        return (out, like.new_empty((sp.n_slots, b * sp.max_heads * sp.l_c * 2), dtype=torch.float32),
+                like.new_empty((sp.n_slots, b, sp.l_c, sp.l_d), dtype=torch.float32))
+    return out, like.new_empty((0,), dtype=torch.float32), like.new_empty((0,), dtype=torch.float32)
+
+
+def _fusion_forward_train(tensors, mask, params, spec, skip_self, embeddings, rng, grad_buffer, grad_offsets):
+    lib = _capi.lib()
+    sp = spec_of(spec)
+    device = params[0].device
+    with torch.cuda.device(device):
+        model, keep = sp.model(params, rng)
+        inp, held, b = sp.inputs(tensors)
+        masked = int(mask is not None)
+        tape_bytes = lib.hn_fusion_tape_bytes(C.byref(model), inp, b, masked, int(skip_self))
+        need = lib.hn_fusion_workspace_bytes(C.byref(model), inp, b)
+        if tape_bytes == 0 or need == 0:
+            _capi.check(-1, "hn_fusion_tape_bytes")
+        tape = torch.empty(tape_bytes, dtype=torch.uint8, device=device)
+        ws = WS.get(device, need)
+        out = torch.empty(_out_shape(sp, b, embeddings), dtype=torch.float32, device=device)
+        _capi.check(lib.hn_fusion_forward_train(C.byref(model), inp, b, _ptr(mask), int(skip_self), int(embeddings), out.data_ptr(),
+                                                None, None, tape.data_ptr(), tape.numel(), ws.data_ptr(), ws.numel(),
+                                                _stream_ptr(device)), "hn_fusion_forward_train")
+        # where the tape keeps every attention block's softmax statistics / input (float offsets; -1 = block not executed):
+        # the host views them in place for Attention.attn_weights -- laid out with THIS call's descriptor (dropout included)
+        so, xo = (C.c_size_t * sp.n_slots)(), (C.c_size_t * sp.n_slots)()
+        _capi.check(lib.hn_fusion_tape_layout(C.byref(model), inp, b, masked, int(skip_self), so, xo), "hn_fusion_tape_layout")
+        none = C.c_size_t(-1).value
+        layout = torch.tensor([-1 if v == none else int(v) for v in list(so) + list(xo)], dtype=torch.int64)
+    return out, tape, layout
+
+
+@torch.library.register_fake("healnet_hip::fusion_forward_train")
+def _(tensors, mask, params, spec, skip_self, embeddings, rng, grad_buffer, grad_offsets):
+    sp = spec_of(spec)
+    b = _batch_of(tensors)
+    rng_fake = None if rng is None else torch.zeros(2, dtype=torch.int64)   # sizes depend on WHETHER blocks drop, not on the seed
+    model, keep = sp.model(None, rng_fake)
+    inp, _, _ = sp.inputs(tensors, fake=True)
+    tape_bytes = _capi.lib().hn_fusion_tape_bytes(C.byref(model), inp, b, int(mask is not None), int(skip_self))
+    like = params[0]
+    return (like.new_empty(_out_shape(sp, b, embeddings), dtype=torch.float32), like.new_empty((tape_bytes,), dtype=torch.uint8),
+            torch.empty((2 * sp.n_slots,), dtype=torch.int64, device="cpu"))
+
+
+def _fusion_backward(dout, tape, tensors, mask, params, spec, skip_self, embeddings, rng, grad_buffer, grad_offsets, needs_grad):
+    lib = _capi.lib()
+    sp = spec_of(spec)
+    device = params[0].device
+    with torch.cuda.device(device):
+        model, keep = sp.model(params, rng)
+        inp, held, b = sp.inputs(tensors)
+        # gradient destinations: a slice of the caller's flat buffer (healnet_amd.train.FlatParameters: the kernels accumulate
+        # straight into it, nothing is returned for that parameter) or a fresh zero tensor that goes back to autograd
+        out: List[torch.Tensor] = []
+        gptr: List[Optional[int]] = []
+        empty = torch.empty(0, dtype=torch.float32, device=device)
+        base = grad_buffer.data_ptr() if grad_buffer is not None else 0
+        for i, p in enumerate(params):
+            off = grad_offsets[i] if (grad_buffer is not None and i < len(grad_offsets)) else -1
+            if off >= 0:
+                gptr.append(base + 4 * off)
+                out.append(empty)
+            elif needs_grad[i]:
+                g = torch.zeros_like(p, dtype=torch.float32)
+                gptr.append(g.data_ptr())
+                out.append(g)
+            else:
+                gptr.append(None)
+                out.append(empty)
+        grads, keep_g = sp.grads(gptr)
+        masked = int(mask is not None)
+        need = lib.hn_fusion_backward_workspace_bytes(C.byref(model), inp, b, masked)
+        if need == 0:
+            _capi.check(-1, "hn_fusion_backward_workspace_bytes")
+        ws = WS.get(device, need)
+        dout = dout.contiguous().float()
+        hook = _BACKWARD_HOOKS.get(base) if grad_buffer is not None else None
+        ready = None
+        if hook is not None:
+            hook.begin(_stream_ptr(device))
+            ready = C.byref(hook.ready)
+        _capi.check(lib.hn_fusion_backward(C.byref(model), inp, b, _ptr(mask), int(skip_self), int(embeddings), dout.data_ptr(),
+                                           tape.data_ptr(), C.byref(grads), ws.data_ptr(), ws.numel(), _stream_ptr(device), ready),
+                    "hn_fusion_backward")
+        if hook is not None:
+            hook.end(_stream_ptr(device))
+    return out
+
+
+@torch.library.register_fake("healnet_hip::fusion_backward")
+def _(dout, tape, tensors, mask, params, spec, skip_self, embeddings, rng, grad_buffer, grad_offsets, needs_grad):
+    out = []
+    for i, p in enumerate(params):
+        direct = grad_buffer is not None and i < len(grad_offsets) and grad_offsets[i] >= 0
+        out.append(torch.empty_like(p) if (needs_grad[i] and not direct) else p.new_empty((0,)))
+    return out
+
+
+def _fusion_setup(ctx, inputs, output):
+    tensors, mask, params, spec, skip_self, embeddings, rng, grad_buffer, grad_offsets = inputs
+    out, tape, layout = output
+    ctx.spec, ctx.skip_self, ctx.embeddings, ctx.grad_offsets = spec, skip_self, embeddings, list(grad_offsets)
+    ctx.present = [t is not None for t in tensors]
+    ctx.n_params = len(params)
+    ctx.flags = (mask is not None, rng is not None, grad_buffer is not None)
+    ctx.needs = [bool(p.requires_grad) for p in params]
+    extra = [t for t in (mask, rng, grad_buffer) if t is not None]
+    ctx.save_for_backward(tape, *params, *[t for t in tensors if t is not None], *extra)
+
+
+def _fusion_backward_formula(ctx, dout, dtape, dlayout):
+    saved = list(ctx.saved_tensors)
+    tape, params = saved[0], saved[1:1 + ctx.n_params]
+    it = iter(saved[1 + ctx.n_params:])
+    tensors = [next(it) if have else None for have in ctx.present]
+    mask, rng, grad_buffer = [next(it) if have else None for have in ctx.flags]
+    g = torch.ops.healnet_hip.fusion_backward(dout.contiguous(), tape, tensors, mask, params, ctx.spec, ctx.skip_self, ctx.embeddings,
+                                              rng, grad_buffer, ctx.grad_offsets, ctx.needs)
+    grads = [gi if (need and gi.numel() == p.numel() and p.numel() > 0) else None for gi, need, p in zip(g, ctx.needs, params)]
+    return None, None, grads, None, None, None, None, None, None
+
+
+torch.library.register_autograd("healnet_hip::fusion_forward_train", _fusion_backward_formula, setup_context=_fusion_setup)
+
+
+for _name, _fn in (("fourier_encode_concat", _fourier_encode_concat), ("encode_norm", _encode_norm), ("attention_fwd", _attention_fwd),
+                   ("attention_bwd", _attention_bwd), ("feed_forward", _feed_forward), ("feed_forward_bwd", _feed_forward_bwd),
+                   ("head", _head), ("head_bwd", _head_bwd), ("temperature_softmax", _temperature_softmax),
+                   ("fusion_forward", _fusion_forward), ("fusion_forward_train", _fusion_forward_train),
+                   ("fusion_backward", _fusion_backward)):
     _lib.impl(_name, _fn, "CUDA")
+_lib.impl("attention", _attention, "CompositeImplicitAutograd")

@@ -123,6 +123,27 @@ class FlatParameters:
     def zero_grad(self) -> None:
         self.grads.zero_()
 
+    def direct_offsets(self, params) -> Optional[List[int]]:
+        """For the fused backward (torch.ops.healnet_hip.fusion_backward): the float offset of every tensor of ``params`` in
+        ``grads`` (-1: not trainable), or None when some trainable parameter's ``.grad`` is not its slot of the flat buffer
+        (set_to_none zeroing, a foreign ``.grad``) -- the backward then returns ordinary gradients to autograd and
+        ``relink()`` repairs the layout before the next optimizer step."""
+        slot = {id(p): off for p, off in zip(self.views, self.offsets)}
+        base = self.grads.data_ptr()
+        out = []
+        for p in params:
+            off = slot.get(id(p), -1)
+            if off < 0:
+                if p.requires_grad:
+                    return None
+                out.append(-1)
+                continue
+            g = p.grad
+            if not p.requires_grad or g is None or not g.is_contiguous() or g.data_ptr() != base + 4 * off:
+                return None
+            out.append(off)
+        return out
+
     def relink(self) -> None:
         """Called by the optimizer before every step: the flat layout only works while every parameter and gradient is still
         a view of the two buffers.  ``model.zero_grad()`` (set_to_none) or an autograd fallback leaves ``.grad`` elsewhere:
@@ -158,11 +179,34 @@ class FusedL1Adam(torch.optim.Optimizer):
         self.flat = flat
         super().__init__([{"params": flat.views}], dict(lr=lr, betas=betas, eps=eps, l1=l1, grad_scale=grad_scale))
         dev = flat.params.device
-        self.exp_avg = torch.zeros_like(flat.params)
-        self.exp_avg_sq = torch.zeros_like(flat.params)
+        # Adam moments and the update count live in Optimizer.state (keyed by the first parameter, as flat tensors over the
+        # whole buffer) so that optimizer.state_dict() / load_state_dict() checkpoint and resume them like torch.optim.Adam's
+        self.state[flat.views[0]] = {"step": 0, "exp_avg": torch.zeros_like(flat.params), "exp_avg_sq": torch.zeros_like(flat.params)}
         self.reg_loss = torch.zeros((), dtype=torch.float32, device=dev)
         self._ws = torch.empty(_capi.lib().hn_l1_adam_workspace_bytes(), dtype=torch.uint8, device=dev)
-        self._steps = 0
+
+    def _flat_state(self) -> dict:
+        st = self.state[self.flat.views[0]]
+        n = self.flat.numel
+        for k in ("exp_avg", "exp_avg_sq"):      # load_state_dict casts / moves state like the parameter it is keyed by
+            t = st[k]
+            if t.numel() != n or t.dtype != torch.float32 or t.device != self.flat.params.device or not t.is_contiguous():
+                if t.numel() != n:
+                    raise RuntimeError(f"FusedL1Adam: checkpointed {k} has {t.numel()} elements, the flat buffer {n}")
+                st[k] = t.to(device=self.flat.params.device, dtype=torch.float32).contiguous().reshape(-1)
+        return st
+
+    @property
+    def exp_avg(self) -> torch.Tensor:
+        return self._flat_state()["exp_avg"]
+
+    @property
+    def exp_avg_sq(self) -> torch.Tensor:
+        return self._flat_state()["exp_avg_sq"]
+
+    @property
+    def _steps(self) -> int:
+        return int(self._flat_state()["step"])
 
     def zero_grad(self, set_to_none: bool = False) -> None:   # gradients stay views of the flat buffer
         self.flat.zero_grad()
@@ -174,12 +218,13 @@ class FusedL1Adam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         g = self.param_groups[0]
-        self._steps += 1
+        st = self._flat_state()
+        st["step"] = int(st["step"]) + 1
         f = self.flat
         f.relink()
-        _capi.check(_capi.lib().hn_l1_adam_step(f.params.data_ptr(), f.grads.data_ptr(), self.exp_avg.data_ptr(),
-                                                self.exp_avg_sq.data_ptr(), f.numel, float(g["l1"]), float(g["grad_scale"]),
+        _capi.check(_capi.lib().hn_l1_adam_step(f.params.data_ptr(), f.grads.data_ptr(), st["exp_avg"].data_ptr(),
+                                                st["exp_avg_sq"].data_ptr(), f.numel, float(g["l1"]), float(g["grad_scale"]),
                                                 float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
-                                                self._steps, self.reg_loss.data_ptr(), self._ws.data_ptr(), self._ws.numel(),
+                                                st["step"], self.reg_loss.data_ptr(), self._ws.data_ptr(), self._ws.numel(),
                                                 _stream(f.params.device)), "hn_l1_adam_step")
         return loss

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HN_ABI_VERSION 3
+#define HN_ABI_VERSION 4
 #define HN_MAX_AXES 4
 
 typedef enum hn_status {
@@ -255,8 +255,10 @@ typedef struct hn_profile {
 } hn_profile;
 
 /* out: (b, out_dims) logits, or (b, l_c, l_d) when return_embeddings != 0 or the model has no head.
- * skip_self_on_missing reproduces the reference's verbose=True quirk (:229-232): a missing
- * modality then also skips that iteration's latent self block.
+ * skip_self_on_missing reproduces the reference's verbose=True quirk (:229-232): bit i set -> when modality i is
+ * missing, that iteration's latent self block is skipped as well (the `continue` under `if verbose`).  The reference
+ * only takes that branch for a None entry INSIDE the tensor list; a modality beyond a shorter list fails in the bare
+ * try/except (:238) and still runs the self block, so a host sets bit i only for the former (0 = never, -1 = all).
  * attn_stats: optional array of depth*(M+1) pointers (layer-major: cross_0..cross_{M-1}, self), each
  *             NULL or a (b, heads, l_c, 2) buffer receiving that block's softmax statistics.
  * x_trace:    optional; receives the latent array (b, l_c, l_d) fed INTO every attention block
@@ -296,9 +298,25 @@ int hn_fusion_forward_train(const hn_model *model, const hn_modality_input *inpu
                             float **x_trace, void *tape, size_t tape_bytes, void *workspace, size_t workspace_bytes,
                             void *stream);
 size_t hn_fusion_backward_workspace_bytes(const hn_model *model, const hn_modality_input *inputs, int b, int masked);
+/* Gradient-readiness signals of hn_fusion_backward (the data-parallel gradient exchange overlapped with the
+ * backward; healnet/main.py:464-465 is the call site it serves).  Index depth = the head's parameter gradients are final;
+ * index l < depth = every block of layers >= l has run its backward, so nothing accumulates any more into the gradients of
+ * parameters used only by layers >= l (layers finish in reverse order; with weight tying the shared blocks belong to
+ * layer 1).  For each index, in that order while the backward is being enqueued:
+ *   events[idx] (hipEvent_t created by the caller, NULL entries skipped) is recorded on `stream`, then
+ *   notify(idx, user) is called on the calling host thread (may enqueue work on other streams, e.g. an all-reduce that
+ *   waits on the event; must not synchronise `stream`).
+ * The latent array's gradient is final when the call's last kernel has run (stream order). */
+typedef struct hn_grad_ready {
+  void **events;                          /* [depth + 1] or NULL */
+  void (*notify)(int index, void *user);  /* or NULL */
+  void *user;
+} hn_grad_ready;
+
 int hn_fusion_backward(const hn_model *model, const hn_modality_input *inputs, int b, const uint8_t *mask,
                        int skip_self_on_missing, int return_embeddings, const float *dout, const void *tape,
-                       const hn_model_grads *grads, void *workspace, size_t workspace_bytes, void *stream);
+                       const hn_model_grads *grads, void *workspace, size_t workspace_bytes, void *stream,
+                       const hn_grad_ready *ready);
 
 /* ---------------------------------------------------------------------------------------------
  * Training-step tail                  replaces healnet/main.py:439-447 + :464-467
@@ -306,7 +324,9 @@ int hn_fusion_backward(const hn_model *model, const hn_modality_input *inputs, i
 /* hazards = sigmoid(logits), survival = cumprod(1 - hazards), risk = -sum(survival) (main.py:439-441), the discrete
  * survival NLL `nll_loss(hazards, S, Y, c, weights, alpha, eps)` (healnet/models/survival_loss.py:9-43; batch mean) and
  * grad_scale * d loss / d logits in one launch.
- *   logits (b, n_bins); y (b) int64 bin index; censorship (b) float {0, 1}; class_weights (n_bins) or NULL;
+ *   logits (b, n_bins); y (b) int64 bin index in [0, n_bins) -- a label outside that range (torch.gather raises in the
+ *   reference) turns the loss and that sample's dlogits row into NaN, nothing is read out of bounds;
+ *   censorship (b) float {0, 1}; class_weights (n_bins) or NULL;
  *   loss (1); dlogits (b, n_bins) or NULL; hazards / survival (b, n_bins) or NULL; risk (b) or NULL. */
 int hn_surv_nll(const float *logits, const int64_t *y, const float *censorship, const float *class_weights, int b,
                 int n_bins, float alpha, float eps, float grad_scale, float *loss, float *dlogits, float *hazards,

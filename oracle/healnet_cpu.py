@@ -205,7 +205,9 @@ def fusion_forward(sd: Dict[str, Tensor], cfg: FusionConfig, tensors: Sequence[O
       * a ``None`` modality skips its cross-attention + cross-FF, but the latent self block of that
         (layer, modality) iteration still runs (:235-245); with ``verbose=True`` the ``continue`` at
         :232 skips the self block too;
-      * a list shorter than ``n_modalities`` behaves like trailing ``None`` entries;
+      * a list shorter than ``n_modalities`` behaves like trailing ``None`` entries -- except under ``verbose=True``: the
+        reference's ``missing_idx`` (:193) only holds the ``None`` entries INSIDE the list, so a modality beyond a shorter
+        list fails in the bare try/except (:238) and still runs its latent self block (fixture g9_verbose_shortlist);
       * ``self_per_cross_attn == 0`` -> no latent blocks; ``>= 2`` is a ValueError in the reference.
     The bare ``except`` of :238 is NOT restated: real shape errors raise here.
     """
@@ -235,7 +237,7 @@ def fusion_forward(sd: Dict[str, Tensor], cfg: FusionConfig, tensors: Sequence[O
     dm = (lambda k: None) if drop is None else (lambda k: drop.get(k))
     for layer in range(cfg.depth):
         for m in range(M):
-            if not present[m] and verbose:                                            # :229-232
+            if not present[m] and verbose and m < len(tensors):                       # :229-232 (missing_idx, :193)
                 continue
             if present[m]:
                 x = _cross_block(sd, f"layers.{layer}.{2 * m}.", x, ctxs[m], cfg.x_heads, mask, keep, dm(step))

@@ -85,3 +85,34 @@ def test_shard_bounds_cover_everything():
             spans = [hd.shard_bounds(n, r, world) for r in range(world)]
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+
+
+@pytest.mark.parametrize("tie", [False, True])
+def test_grad_ready_bucket_plan_covers_the_flat_buffer(tie):
+    """The overlapped all-reduce releases one contiguous range of the flat gradient buffer per hn_grad_ready signal; together
+    the ranges must cover every parameter exactly once, and a parameter may only be released by a signal that fires after the
+    last layer using it has run its backward (lowest user layer; tied blocks -> layer 1; layer 0 / latents -> end of call)."""
+    from healnet_amd import HealNet
+    model = HealNet(n_modalities=2, channel_dims=[7, 3], num_spatial_axes=[1, 2], out_dims=3, depth=4, l_c=8, l_d=16, x_heads=2,
+                    l_heads=2, cross_dim_head=8, latent_dim_head=8, weight_tie_layers=tie)
+    views = [p for p in model.parameters()]
+    offsets, off = [], 0
+    for p in views:
+        offsets.append(off)
+        off += (p.numel() + 3) // 4 * 4
+    buckets = hd.grad_ready_buckets(model, views, offsets)
+    spans = sorted(r for rs in buckets.values() for r in rs)
+    assert spans[0][0] == 0 and spans[-1][1] == off and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    assert all(len(rs) == 1 for rs in buckets.values()), buckets          # one message per signal
+    assert set(buckets) == ({-1, 1} if tie else {-1, 1, 2, 3})
+    where = {}
+    for idx, rs in buckets.items():
+        for lo, hi in rs:
+            for p, o in zip(views, offsets):
+                if lo <= o < hi:
+                    where[id(p)] = idx
+    for layer in range(model.depth):
+        for p in model.layers[layer].parameters():
+            assert where[id(p)] <= layer, "released before a layer that still accumulates into it has finished"
+    assert where[id(model.latents)] == -1
+    assert hd.shard_loss_scale(4, 7, 2) + hd.shard_loss_scale(3, 7, 2) == pytest.approx(2.0)

@@ -12,8 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_bench_prints_one_contract_line():
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu-baseline"],
-                         cwd=ROOT, capture_output=True, text=True, timeout=600, check=True).stdout
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu-baseline",
+                          "--train-steps", "3"], cwd=ROOT, capture_output=True, text=True, timeout=600, check=True).stdout
     lines = [l for l in out.splitlines() if l.strip().startswith("{")]
     assert len(lines) == 1, out
     j = json.loads(lines[0])
@@ -27,3 +27,29 @@ def test_bench_prints_one_contract_line():
     r = j["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
     assert 0.3 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert 0.3 < r["frac_useful"] < r["frac"]
+    assert r["traffic"] is None or r["traffic_source"]["source"].startswith("profiles/")
+    t = j["train_step"]                                   # fwd + bwd + all-reduce + optimizer step at cfg4, b=8 / GPU
+    assert t["batch_per_gpu"] == 8 and t["world_size"] == 1 and t["unit"] == "samples/s" and t["steps"] == 3
+    assert abs(t["value"] - 8 * 1000.0 / t["ms_per_step"]) <= 1e-3 * t["value"] and t["final_loss"] == t["final_loss"]
+    assert sum(t["allreduce_buckets_floats"]) == t["gradient_floats"]
+
+
+def test_plain_gpus_n_command_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no torchrun environment (the shape of the driver's command) must start 2 ranks itself.
+    On this 1-GPU box both ranks share cuda:0 and talk over gloo (HN_BENCH_SHARED_GPU=1, a test-only switch); the launcher,
+    the barrier / max-over-ranks timing and the 2-rank training step with the overlapped all-reduce are the real code."""
+    env = dict(os.environ, HN_BENCH_SHARED_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+                          "--train-steps", "3"], cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 64 and "cpu_baseline" not in j
+    assert abs(j["value"] - 64 * 1000.0 / j["ms_per_step"]) <= 1e-3 * j["value"]
+    t = j["train_step"]
+    assert t["world_size"] == 2 and t["global_batch"] == 16 and t["backend"] == "gloo"
+    assert "ms_per_step_blocking_allreduce" in t and "allreduce_alone_ms" in t

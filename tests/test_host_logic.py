@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     lib = _capi.lib()                      # raises if the .so is missing: build() must have run
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.hn_abi_version() == _capi.HN_ABI_VERSION == 3
+    assert lib.hn_abi_version() == _capi.HN_ABI_VERSION == 4
     assert lib.hn_context_pitch(13, 64) == 16 and lib.hn_context_pitch(18, 64) == 32
     assert lib.hn_context_pitch(773, 64) == 776 and lib.hn_context_pitch(2005, 64) == 2008
     assert lib.hn_context_pitch(20, 16) == 20          # rank-D path would not pay: dp 32 > dim_head 16
@@ -159,17 +159,64 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     assert "import oracle" not in src and "from oracle" not in src
 
 
-def test_standalone_blocks_refuse_inputs_that_require_grad():
-    """The stand-alone Attention / FeedForward modules are forward-only ops: an input that requires grad must raise (a
-    silently non-differentiable output would train nothing) -- checked before any device work, so it runs on the CPU."""
+def test_standalone_blocks_refuse_a_context_that_requires_grad():
+    """The stand-alone Attention is differentiable w.r.t. x and its parameters (torch.ops.healnet_hip.attention_fwd + the
+    registered backward); NO gradient flows to the context (hn_attn_bwd), so a context that requires grad must raise rather
+    than silently train nothing -- checked before any device work, so it runs on the CPU."""
     import healnet_amd as hn
-    x = torch.randn(2, 4, 16, requires_grad=True)
-    with pytest.raises(RuntimeError, match="forward-only"):
-        hn.Attention(16, heads=2, dim_head=8)(x)
-    with pytest.raises(RuntimeError, match="forward-only"):
-        hn.PreNorm(16, hn.FeedForward(16))(x)
-    with pytest.raises(RuntimeError, match="forward-only"):
-        hn.PreNorm(16, hn.Attention(16, 5, heads=2, dim_head=8), context_dim=5)(x.detach(), context=torch.randn(2, 3, 5, requires_grad=True))
+    with pytest.raises(RuntimeError, match="no gradient flows to the context"):
+        hn.PreNorm(16, hn.Attention(16, 5, heads=2, dim_head=8), context_dim=5)(torch.randn(2, 4, 16), context=torch.randn(2, 3, 5, requires_grad=True))
+    with pytest.raises(RuntimeError, match="no gradient flows to the context"):
+        hn.Attention(16, 5, heads=2, dim_head=8)(torch.randn(2, 4, 16), context=torch.randn(2, 3, 5, requires_grad=True))
+
+
+def test_operator_schemas_and_fake_kernels():
+    """torch.ops.healnet_hip.* is the route of the package: every operator is registered, has a fake (meta) kernel for
+    tracing, and the fusion operators' fake kernels size their outputs from the C library's own planning functions."""
+    import healnet_amd as hn
+    ops = torch.ops.healnet_hip
+    for name in ["fusion_forward", "fusion_forward_train", "fusion_backward", "attention", "attention_fwd", "attention_bwd",
+                 "feed_forward", "feed_forward_bwd", "head", "head_bwd", "fourier_encode_concat", "encode_norm", "temperature_softmax"]:
+        assert hasattr(ops, name), name
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    model = hn.HealNet(n_modalities=2, channel_dims=[7, 3], num_spatial_axes=[1, 2], out_dims=3, depth=2, l_c=8, l_d=16, x_heads=2,
+                       l_heads=2, cross_dim_head=8, latent_dim_head=8)
+    spec = model._spec_text
+    with FakeTensorMode(allow_non_fake_inputs=True) as mode:
+        params = [mode.from_tensor(p.detach()) for p in model.parameters()]
+        tab, img = mode.from_tensor(torch.rand(5, 1, 7)), mode.from_tensor(torch.rand(5, 6, 4, 3))
+        out, stats, trace = ops.fusion_forward([tab, img], None, params, spec, 0, False, True)
+        assert out.shape == (5, 3) and trace.shape == (2 * 3, 5, 8, 16) and stats.shape == (6, 5 * 2 * 8 * 2)
+        out, tape, layout = ops.fusion_forward_train([tab, None], None, params, spec, 0, True, None, None, [])
+        assert out.shape == (5, 8, 16) and tape.dtype == torch.uint8 and tape.numel() > 0 and layout.shape == (12,)
+        y, st, saved = ops.attention_fwd(mode.from_tensor(torch.rand(2, 8, 16)), None, None, None, None, None, None, params[4], params[5],
+                                         params[6], params[7], 2, True, True)
+        assert y.shape == (2, 8, 16) and st.shape == (2, 2, 8, 2) and saved.numel() > 0
+
+
+def test_fused_adam_state_is_checkpointed():
+    """the Adam moments and the update count live in Optimizer.state, so state_dict() / load_state_dict() resume them
+    (structure only here -- the arithmetic is covered by the GPU fixtures)."""
+    import healnet_amd as hn
+
+    class _Flat:          # FlatParameters without a device
+        def __init__(self):
+            self.params = torch.zeros(8)
+            self.grads = torch.zeros(8)
+            self.views = [torch.nn.Parameter(self.params[:8].view(2, 4))]
+            self.offsets = [0]
+            self.numel = 8
+    import unittest.mock as mock
+    with mock.patch.object(hn.train._capi, "lib") as lib:
+        lib.return_value.hn_l1_adam_workspace_bytes.return_value = 256
+        opt = hn.train.FusedL1Adam(_Flat(), lr=1e-3)
+        opt.state[opt.flat.views[0]]["step"] = 7
+        opt.exp_avg.fill_(0.5)
+        sd = opt.state_dict()
+        assert sd["state"][0]["step"] == 7 and float(sd["state"][0]["exp_avg"].sum()) == 4.0
+        opt2 = hn.train.FusedL1Adam(_Flat(), lr=1e-3)
+        opt2.load_state_dict(sd)
+        assert opt2._steps == 7 and float(opt2.exp_avg.sum()) == 4.0 and opt2.exp_avg.shape == (8,)
 
 
 def test_non_fp32_parameters_are_refused():

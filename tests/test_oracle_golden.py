@@ -163,3 +163,20 @@ def test_temperature_softmax_restatement_matches_reference():
     for i in range(4):
         assert torch.equal(torch.softmax(g[f"x{i}"] / float(g[f"t{i}"]), dim=-1), g[f"y{i}"])
     assert torch.equal(torch.softmax(g["xd"] / 0.5, dim=1), g["yd"])
+
+
+def test_verbose_quirk_with_short_tensor_lists(manifest):
+    """g9 (tools/gen_goldens_quirks.py, outputs of the reference itself): `verbose=True` skips the latent self block only for
+    None entries INSIDE the tensor list (healnet.py:193, :229-232); a modality beyond a shorter list still runs it (:238)."""
+    g = load_golden("g9_verbose_shortlist")
+    m = manifest["g9_verbose_shortlist"]
+    cfg = O.FusionConfig(**m["kwargs"])
+    sd = {k[4:]: v for k, v in g.items() if k.startswith("sd::")}
+    ins = [g[f"in{i}"] for i in range(3)]
+    for name, idx in m["cases"].items():
+        lst = [None if i == "None" else ins[i] for i in idx]
+        for mode in ("quiet", "verbose"):
+            got = O.fusion_forward(sd, cfg, lst, verbose=(mode == "verbose"))
+            assert rel_err(got, g[f"logits::{name}::{mode}"]) < 1e-5, (name, mode)
+    assert torch.equal(g["logits::short1::verbose"], g["logits::short1::quiet"])
+    assert not torch.equal(g["logits::none_tail::verbose"], g["logits::none_tail::quiet"])

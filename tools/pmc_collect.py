@@ -59,7 +59,13 @@ def main():
             row["hbm_bytes_fetch_doubled"] = (2 * row["FETCH_SIZE_avg"] + row["WRITE_SIZE_avg"]) * 1024.0
         kernels[name] = row
     dom = max(kernels, key=lambda k: kernels[k].get("avg_duration_ns_under_pmc", 0.0) * kernels[k]["launches_sampled"])
+    import hashlib
+    def sha(rel):
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            return hashlib.sha256(f.read()).hexdigest()
     doc = {
+        "source_sha256": {"attention.hip": sha("healnet_amd/csrc/attention.hip")},     # bench.py drops the traffic figure when this no longer matches
+        "git_head": os.environ.get("HN_GIT_HEAD"),
         "command": "python tools/pmc_collect.py (three rocprofv3 --kernel-trace --pmc passes over tools/quick_cfg2.py 32 3: "
                    + " | ".join(PASSES.values()) + ")",
         "core_precision": args.core_precision,
