@@ -690,7 +690,10 @@ def _fusion_backward_formula(ctx, dout, dtape, dlayout):
     g = torch.ops.healnet_hip.fusion_backward(dout.contiguous(), tape, tensors, mask, params, ctx.spec, ctx.skip_self, ctx.embeddings,
                                               rng, grad_buffer, ctx.grad_offsets, ctx.needs)
     grads = [gi if (need and gi.numel() == p.numel() and p.numel() > 0) else None for gi, need, p in zip(g, ctx.needs, params)]
-    return None, None, grads, None, None, None, None, None, None
+    # torch.library wants the structure of the inputs back: a list that held only tensors is a list of (optional) gradients,
+    # a list with a None entry / of ints is a single leaf
+    d_tensors = [None] * len(ctx.present) if all(ctx.present) else None
+    return d_tensors, None, grads, None, None, None, None, None, ([] if not ctx.grad_offsets else None)
 
 
 torch.library.register_autograd("healnet_hip::fusion_forward_train", _fusion_backward_formula, setup_context=_fusion_setup)
