@@ -9,8 +9,9 @@ Whole fusion stack (``spec`` = JSON description of the module structure, see ``H
     fusion_forward(tensors, mask?, params, spec, skip_self, embeddings, keep_stats) -> (out, stats, trace)       hn_fusion_forward
     fusion_forward_train(tensors, mask?, params, spec, skip_self, embeddings, rng?, grad_buffer?, grad_offsets)
                                                                                    -> (out, tape, layout)       hn_fusion_forward_train
-    fusion_backward(dout, tape, tensors, mask?, params, spec, skip_self, embeddings, rng?, grad_buffer?, grad_offsets,
-                    needs_grad) -> Tensor[]                                                                      hn_fusion_backward
+    fusion_backward(dout, tape, tensors, mask?, params, spec, skip_self, embeddings, rng?, needs_grad) -> Tensor[]   hn_fusion_backward
+    fusion_backward_into(dout, tape, tensors, mask?, params, spec, skip_self, embeddings, rng?, grad_buffer!, grad_offsets) -> ()
+                    (the same backward ACCUMULATING into a flat gradient buffer: healnet_amd.train.FlatParameters)
 Blocks (differentiable w.r.t. x and the parameters; no gradient flows to the context, as in the C ABI):
     attention(x, context?, mask?, norm_w?, norm_b?, ctx_gamma?, ctx_beta?, w_q, w_kv, w_out, b_out, heads, residual) -> (b, L, query_dim)
     attention_fwd(..., train) -> (out, stats, saved)       attention_bwd(dy, x, out, ..., stats, saved) -> Tensor[9]
@@ -55,7 +56,9 @@ _lib.define("fusion_forward(Tensor?[] tensors, Tensor? mask, Tensor[] params, st
 _lib.define("fusion_forward_train(Tensor?[] tensors, Tensor? mask, Tensor[] params, str spec, int skip_self, bool embeddings, "
             "Tensor? rng, Tensor? grad_buffer, int[] grad_offsets) -> (Tensor, Tensor, Tensor)")
 _lib.define("fusion_backward(Tensor dout, Tensor tape, Tensor?[] tensors, Tensor? mask, Tensor[] params, str spec, int skip_self, "
-            "bool embeddings, Tensor? rng, Tensor(a!)? grad_buffer, int[] grad_offsets, bool[] needs_grad) -> Tensor[]")
+            "bool embeddings, Tensor? rng, bool[] needs_grad) -> Tensor[]")
+_lib.define("fusion_backward_into(Tensor dout, Tensor tape, Tensor?[] tensors, Tensor? mask, Tensor[] params, str spec, "
+            "int skip_self, bool embeddings, Tensor? rng, Tensor(a!) grad_buffer, int[] grad_offsets) -> ()")
 
 _FAKE_PTR = 256          # stands in for device addresses while tracing with FakeTensors (size queries only, nothing is launched)
 
@@ -615,58 +618,60 @@ def _(tensors, mask, params, spec, skip_self, embeddings, rng, grad_buffer, grad
             torch.empty((2 * sp.n_slots,), dtype=torch.int64, device="cpu"))
 
 
-def _fusion_backward(dout, tape, tensors, mask, params, spec, skip_self, embeddings, rng, grad_buffer, grad_offsets, needs_grad):
+def _run_fusion_backward(dout, tape, tensors, mask, params, spec, skip_self, embeddings, rng, gptr, hook):
     lib = _capi.lib()
     sp = spec_of(spec)
     device = params[0].device
+    model, keep = sp.model(params, rng)
+    inp, held, b = sp.inputs(tensors)
+    grads, keep_g = sp.grads(gptr)
+    masked = int(mask is not None)
+    need = lib.hn_fusion_backward_workspace_bytes(C.byref(model), inp, b, masked)
+    if need == 0:
+        _capi.check(-1, "hn_fusion_backward_workspace_bytes")
+    ws = WS.get(device, need)
+    dout = dout.contiguous().float()
+    ready = None
+    if hook is not None:
+        hook.begin(_stream_ptr(device))
+        ready = C.byref(hook.ready)
+    _capi.check(lib.hn_fusion_backward(C.byref(model), inp, b, _ptr(mask), int(skip_self), int(embeddings), dout.data_ptr(),
+                                       tape.data_ptr(), C.byref(grads), ws.data_ptr(), ws.numel(), _stream_ptr(device), ready),
+                "hn_fusion_backward")
+    if hook is not None:
+        hook.end(_stream_ptr(device))
+
+
+def _fusion_backward(dout, tape, tensors, mask, params, spec, skip_self, embeddings, rng, needs_grad):
+    """Gradients as fresh tensors (zero-initialised, the kernels accumulate), an empty tensor for parameters without one."""
+    device = params[0].device
     with torch.cuda.device(device):
-        model, keep = sp.model(params, rng)
-        inp, held, b = sp.inputs(tensors)
-        # gradient destinations: a slice of the caller's flat buffer (healnet_amd.train.FlatParameters: the kernels accumulate
-        # straight into it, nothing is returned for that parameter) or a fresh zero tensor that goes back to autograd
-        out: List[torch.Tensor] = []
-        gptr: List[Optional[int]] = []
         empty = torch.empty(0, dtype=torch.float32, device=device)
-        base = grad_buffer.data_ptr() if grad_buffer is not None else 0
-        for i, p in enumerate(params):
-            off = grad_offsets[i] if (grad_buffer is not None and i < len(grad_offsets)) else -1
-            if off >= 0:
-                gptr.append(base + 4 * off)
-                out.append(empty)
-            elif needs_grad[i]:
-                g = torch.zeros_like(p, dtype=torch.float32)
-                gptr.append(g.data_ptr())
-                out.append(g)
-            else:
-                gptr.append(None)
-                out.append(empty)
-        grads, keep_g = sp.grads(gptr)
-        masked = int(mask is not None)
-        need = lib.hn_fusion_backward_workspace_bytes(C.byref(model), inp, b, masked)
-        if need == 0:
-            _capi.check(-1, "hn_fusion_backward_workspace_bytes")
-        ws = WS.get(device, need)
-        dout = dout.contiguous().float()
-        hook = _BACKWARD_HOOKS.get(base) if grad_buffer is not None else None
-        ready = None
-        if hook is not None:
-            hook.begin(_stream_ptr(device))
-            ready = C.byref(hook.ready)
-        _capi.check(lib.hn_fusion_backward(C.byref(model), inp, b, _ptr(mask), int(skip_self), int(embeddings), dout.data_ptr(),
-                                           tape.data_ptr(), C.byref(grads), ws.data_ptr(), ws.numel(), _stream_ptr(device), ready),
-                    "hn_fusion_backward")
-        if hook is not None:
-            hook.end(_stream_ptr(device))
+        out = [torch.zeros_like(p, dtype=torch.float32) if need else empty for p, need in zip(params, needs_grad)]
+        gptr = [g.data_ptr() if need else None for g, need in zip(out, needs_grad)]
+        _run_fusion_backward(dout, tape, tensors, mask, params, spec, skip_self, embeddings, rng, gptr, None)
     return out
 
 
 @torch.library.register_fake("healnet_hip::fusion_backward")
-def _(dout, tape, tensors, mask, params, spec, skip_self, embeddings, rng, grad_buffer, grad_offsets, needs_grad):
-    out = []
-    for i, p in enumerate(params):
-        direct = grad_buffer is not None and i < len(grad_offsets) and grad_offsets[i] >= 0
-        out.append(torch.empty_like(p) if (needs_grad[i] and not direct) else p.new_empty((0,)))
-    return out
+def _(dout, tape, tensors, mask, params, spec, skip_self, embeddings, rng, needs_grad):
+    return [torch.empty_like(p) if need else p.new_empty((0,)) for p, need in zip(params, needs_grad)]
+
+
+def _fusion_backward_into(dout, tape, tensors, mask, params, spec, skip_self, embeddings, rng, grad_buffer, grad_offsets):
+    """The kernels accumulate straight into ``grad_buffer[grad_offsets[i] : ...]`` (float offsets, -1 = no gradient for that
+    parameter): no per-parameter zero tensors, no AccumulateGrad pass.  A gradient-readiness hook registered for the buffer
+    (healnet_amd.dist.GradReadyAllReduce) is driven from inside hn_fusion_backward."""
+    device = params[0].device
+    with torch.cuda.device(device):
+        base = grad_buffer.data_ptr()
+        gptr = [base + 4 * off if off >= 0 else None for off in grad_offsets]
+        _run_fusion_backward(dout, tape, tensors, mask, params, spec, skip_self, embeddings, rng, gptr, _BACKWARD_HOOKS.get(base))
+
+
+@torch.library.register_fake("healnet_hip::fusion_backward_into")
+def _(dout, tape, tensors, mask, params, spec, skip_self, embeddings, rng, grad_buffer, grad_offsets):
+    return None
 
 
 def _fusion_setup(ctx, inputs, output):
@@ -687,9 +692,14 @@ def _fusion_backward_formula(ctx, dout, dtape, dlayout):
     it = iter(saved[1 + ctx.n_params:])
     tensors = [next(it) if have else None for have in ctx.present]
     mask, rng, grad_buffer = [next(it) if have else None for have in ctx.flags]
-    g = torch.ops.healnet_hip.fusion_backward(dout.contiguous(), tape, tensors, mask, params, ctx.spec, ctx.skip_self, ctx.embeddings,
-                                              rng, grad_buffer, ctx.grad_offsets, ctx.needs)
-    grads = [gi if (need and gi.numel() == p.numel() and p.numel() > 0) else None for gi, need, p in zip(g, ctx.needs, params)]
+    if grad_buffer is not None:
+        torch.ops.healnet_hip.fusion_backward_into(dout.contiguous(), tape, tensors, mask, params, ctx.spec, ctx.skip_self,
+                                                   ctx.embeddings, rng, grad_buffer, ctx.grad_offsets)
+        grads = [None] * len(params)
+    else:
+        g = torch.ops.healnet_hip.fusion_backward(dout.contiguous(), tape, tensors, mask, params, ctx.spec, ctx.skip_self,
+                                                  ctx.embeddings, rng, ctx.needs)
+        grads = [gi if need else None for gi, need in zip(g, ctx.needs)]
     # torch.library wants the structure of the inputs back: a list that held only tensors is a list of (optional) gradients,
     # a list with a None entry / of ints is a single leaf
     d_tensors = [None] * len(ctx.present) if all(ctx.present) else None
@@ -703,6 +713,6 @@ for _name, _fn in (("fourier_encode_concat", _fourier_encode_concat), ("encode_n
                    ("attention_bwd", _attention_bwd), ("feed_forward", _feed_forward), ("feed_forward_bwd", _feed_forward_bwd),
                    ("head", _head), ("head_bwd", _head_bwd), ("temperature_softmax", _temperature_softmax),
                    ("fusion_forward", _fusion_forward), ("fusion_forward_train", _fusion_forward_train),
-                   ("fusion_backward", _fusion_backward)):
+                   ("fusion_backward", _fusion_backward), ("fusion_backward_into", _fusion_backward_into)):
     _lib.impl(_name, _fn, "CUDA")
 _lib.impl("attention", _attention, "CompositeImplicitAutograd")

@@ -113,7 +113,7 @@ def _dp_worker(rank, world, port, n_total, overlapped, q):
         if overlapped:
             assert [i for i, _, _ in sync.launched] == [2, 1, -1], sync.launched
         torch.cuda.synchronize()
-        q.put((rank, "ok", g.cpu(), flat.params.detach().cpu().clone()))
+        q.put((rank, "ok", g.cpu().numpy(), flat.params.detach().cpu().numpy()))      # numpy: pickled by value (no fd passing)
     except Exception as e:  # pragma: no cover
         import traceback
         q.put((rank, "".join(traceback.format_exception(type(e), e, e.__traceback__)), None, None))
@@ -143,8 +143,15 @@ def test_two_rank_step_equals_the_full_batch_step(n_total, overlapped):
     opt = hn.train.FusedL1Adam(flat, lr=1e-3, l1=1e-4)
     ins, y, c = _inputs(n_total, 17)
     g = _step(model, flat, opt, [t.to(DEV) for t in ins], y.to(DEV), c.to(DEV), 1.0, lambda: None)
+    import numpy as np
+    p_ref = flat.params.detach().cpu()
     for rank, _, g_dp, p_dp in results:
-        assert_close(g_dp, g.cpu(), rel=2e-5, floor=2e-6, what=f"rank {rank}: averaged flat gradient vs the full-batch gradient")
-        # Adam's first step moves every parameter by ~lr * sign(g): compare the UPDATE, not the parameter
-        assert_close(p_dp, flat.params.detach().cpu(), rel=1e-5, floor=1e-6, what=f"rank {rank}: parameters after FusedL1Adam")
-    assert torch.equal(results[0][2], results[1][2]) and torch.equal(results[0][3], results[1][3]), "ranks diverged"
+        assert_close(torch.from_numpy(g_dp), g.cpu(), rel=2e-5, floor=2e-6,
+                     what=f"rank {rank}: averaged flat gradient vs the full-batch gradient")
+        # Adam's first step moves a parameter by lr * g / (|g| + eps) ~ lr * sign(g): where the total gradient (data term +
+        # l1 * sign(p)) nearly cancels, fp32 summation order decides the size of the move -- bounded by a fraction of lr there,
+        # and everything else must agree to fp32 noise
+        diff = (torch.from_numpy(p_dp) - p_ref).abs()
+        assert float(diff.max()) <= 0.2 * 1e-3, float(diff.max())
+        assert float((diff > 1e-6).float().mean()) < 1e-4, float((diff > 1e-6).float().mean())
+    assert np.array_equal(results[0][2], results[1][2]) and np.array_equal(results[0][3], results[1][3]), "ranks diverged"

@@ -37,12 +37,27 @@ def _grad_parity(hn, kw, ins, seed, what, mask=None):
     got = model([None if t is None else t.to(DEV) for t in ins], mask=None if mask is None else mask.to(DEV))
     assert_close(got.detach().cpu(), want.detach(), rel=TOL, floor=0.0, abs_floor=1e-5, what=what + ".fwd_train")
     (got * dl.to(DEV)).sum().backward()
-    n = 0
+    # At these sizes ~10^6 LeakyReLU / SELU pre-activations exist per block, so a few lie within fp32 rounding of the kink
+    # and two correct forwards disagree on their side: such a flip perturbs a handful of gradient elements by
+    # O(1e-3) of the tensor's scale.  Hence two criteria per parameter: every element within 5e-3 of the scale (a kink flip
+    # passes, a wrong kernel route does not), and the relative L2 error <= 3e-4 (isolated flips vanish in it, a systematic
+    # error -- a dropped split, a mis-scaled partial -- does not).
+    n, worst = 0, []
     for k, p in model.named_parameters():
         ref = sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])
         assert p.grad is not None, k
-        assert_close(p.grad.cpu(), ref, rel=2e-3, floor=1e-3, what=f"{what}.grad[{k}]")
+        got = p.grad.double().cpu()
+        scale = float(ref.abs().max().clamp_min(1e-30))
+        linf = float((got - ref.double()).abs().max()) / scale
+        l2 = float((got - ref.double()).norm() / ref.double().norm().clamp_min(1e-30))
+        outliers = int(((got - ref.double()).abs() > 5e-4 * scale).sum())
+        worst.append((linf, l2, k, outliers, p.numel()))
         n += p.numel()
+    bad = [w for w in worst if w[0] > 5e-3 or w[1] > 3e-4]
+    top = sorted(worst, reverse=True)[:3]
+    print(f"{what}: worst max-norm {top[0][0]:.2e} ({top[0][2]}: {top[0][3]} of {top[0][4]} elements beyond 5e-4 of the scale), "
+          f"worst L2 {max(w[1] for w in worst):.2e}; next: {[(f'{w[0]:.1e}', w[2], w[3]) for w in top[1:]]}")
+    assert not bad, f"{what}: {len(bad)} parameter gradients off: {sorted(bad, reverse=True)[:5]}"
     return n
 
 
