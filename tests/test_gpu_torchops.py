@@ -59,8 +59,11 @@ def test_opcheck_fusion(hn):
     tab, img = torch.rand(3, 1, 7, device=DEV), torch.rand(3, 6, 5, 3, device=DEV)
     torch.library.opcheck(ops.fusion_forward.default, ([tab, img], None, [p.detach() for p in params], model._spec_text, 0, False, True),
                           test_utils=("test_schema", "test_faketensor"))
+    # (no test_aot_dispatch_static here: it compares ALL outputs of two runs bit for bit, and the tape output has alignment gaps
+    # nothing writes; AOT tracing of the op is covered by test_torch_compile_traces_the_model_without_graph_breaks, which
+    # compares logits and gradients)
     torch.library.opcheck(ops.fusion_forward_train.default, ([tab, None], None, params, model._spec_text, 0, False, None, None, []),
-                          test_utils=("test_schema", "test_autograd_registration", "test_faketensor", "test_aot_dispatch_static"))
+                          test_utils=("test_schema", "test_autograd_registration", "test_faketensor"))
 
 
 @pytest.mark.parametrize("cross", [True, False], ids=["cross", "self"])
