@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhealnet_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ["api.hip", "gemm.hip", "attention.hip", "attention_bf16.hip", "attention_bwd.hip", "encode.hip", "misc.hip",
-           "backward.hip", "train.hip"]
+           "backward.hip", "train.hip", "chain.hip"]
 
 c_float_p = C.POINTER(C.c_float)
 
@@ -149,6 +149,13 @@ SIGNATURES = {
                                      C.c_void_p, C.POINTER(ModelGrads), C.c_void_p, C.c_size_t, C.c_void_p,
                                      C.POINTER(GradReady)]),
     "hn_fusion_workspace_bytes": (C.c_size_t, [C.POINTER(Model), C.POINTER(ModalityInput), C.c_int]),
+    "hn_latent_block_fwd": (C.c_int, [C.POINTER(AttnParams), C.POINTER(FFParams), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "hn_latent_block_workspace_bytes": (C.c_size_t, [C.POINTER(AttnParams), C.POINTER(FFParams), C.c_int, C.c_int]),
+    "hn_latent_block_bwd": (C.c_int, [C.POINTER(AttnParams), C.POINTER(FFParams), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(AttnGrads), C.POINTER(FFGrads), C.c_void_p,
+                                      C.c_size_t, C.c_void_p]),
+    "hn_latent_block_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(AttnParams), C.POINTER(FFParams), C.c_int, C.c_int]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -3,6 +3,7 @@
 #include "common.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 namespace hn {
@@ -105,6 +106,16 @@ static int plan_attn(const hn_attn_params *p, bool has_ctx, int ld_ctx, int b, i
   return HN_OK;
 }
 
+// Hooks of the fused latent chain (chain.hip) into an attention block: the block's projections were already produced by the
+// chain in front of it (q / kv given, *_done), and / or its out-projection + residual is left to the chain behind it
+// (defer_out: the merged attention output stays in the block's O buffer, reported through o_out / ldo_out).
+struct AttnExt {
+  float *q, *kv;          // external projection buffers (NULL: the plan's own)
+  bool q_done, kv_done;
+  bool defer_out;
+  const float *o_out; int ldo_out;
+};
+
 static int check_ws(void *ws, size_t ws_bytes, size_t need, const char *who) {
   HN_REQUIRE(ws != nullptr, HN_E_WORKSPACE, "%s: workspace is NULL (need %zu bytes)", who, need);
   HN_REQUIRE(((uintptr_t)ws & 255) == 0, HN_E_WORKSPACE, "%s: workspace must be 256-byte aligned", who);
@@ -132,8 +143,10 @@ static float *saved_kv(const AttnPlan &pl, bool has_ctx, bool masked, int b, int
 // writes them there, the backward (kv_ready) reads them back instead of re-running the K/V projection GEMM.
 static int attn_prepare(const hn_attn_params *p, const AttnPlan &pl, const float *x_in, const float *ctx, int ld_ctx,
                         int b, int L, hipStream_t s, AttnCoreArgs *core, int pack_ks = 0, float *kv_tape = nullptr,
-                        bool kv_ready = false, bool use_bound = false, int *ext_flag = nullptr) {
+                        bool kv_ready = false, bool use_bound = false, int *ext_flag = nullptr, const AttnExt *ext = nullptr) {
   const int rows = b * L;
+  float *qbuf = (ext && ext->q) ? ext->q : pl.q;
+  const bool q_done = ext && ext->q_done;
   GemmArgs gq = gemm_defaults();
   gq.A = x_in; gq.lda = p->query_dim;
   gq.W = p->w_q; gq.ldw = p->query_dim;
@@ -145,14 +158,14 @@ static int attn_prepare(const hn_attn_params *p, const AttnPlan &pl, const float
   core->Opart = pl.opart; core->Mpart = pl.mpart; core->Lpart = pl.lpart;
   int rc;
   if (pl.rank_d) {
-    gq.C = pl.q; gq.ldc = pl.inner;
-    if ((rc = launch_gemm(gq, s)) != HN_OK) return rc;
+    gq.C = qbuf; gq.ldc = pl.inner;
+    if (!q_done && (rc = launch_gemm(gq, s)) != HN_OK) return rc;
     // score bounds need |z|^2 <= D, i.e. a context that went through the LayerNorm of PreNorm.norm_context (ctx_gamma set)
     float *bound = (pl.ones && p->ctx_gamma && use_bound) ? pl.bound : nullptr;
     // the fallback flag: the caller's pre-zeroed one (hn_fusion_forward zeroes all of a forward's flags in one launch) or ours
     int *bflag = bound ? (ext_flag ? ext_flag : (int *)(pl.bound + (size_t)b * p->heads * pl.Lp)) : nullptr;
     if (bound && !ext_flag && (rc = launch_fill((float *)bflag, 0.0f, 1, s)) != HN_OK) return rc;
-    if ((rc = launch_qfold(pl.q, pl.inner, p->w_kv, pl.D, p->ctx_gamma, pl.cscale, pl.qf, b, p->heads, L, pl.Lp, pl.dh,
+    if ((rc = launch_qfold(qbuf, pl.inner, p->w_kv, pl.D, p->ctx_gamma, pl.cscale, pl.qf, b, p->heads, L, pl.Lp, pl.dh,
                            pl.dp, s, pack_ks, bound, bflag)) != HN_OK) return rc;
     core->bound = bound; core->bound_flag = bflag;
     core->qk_steps = pack_ks;
@@ -162,20 +175,22 @@ static int attn_prepare(const hn_attn_params *p, const AttnPlan &pl, const float
     core->ones_col = pl.ones ? 1 : 0;
   } else {
     const int qpitch = p->heads * pl.dhp, kvpitch = 2 * p->heads * pl.dhp;
-    float *kvbuf = kv_tape ? kv_tape : pl.kv;
+    float *kvbuf = kv_tape ? kv_tape : ((ext && ext->kv) ? ext->kv : pl.kv);
+    if (ext && ext->kv_done) kv_ready = true;
     if (pl.dhp != pl.dh) {
+      HN_REQUIRE(!q_done, HN_E_SHAPE, "attn: external projections need dim_head in {16, 32, 64, 128}");
       { int rc_ = launch_fill(pl.q, 0.0f, (long)((size_t)rows * qpitch), s); if (rc_ != HN_OK) return rc_; }
       if (!kv_ready) { int rc_ = launch_fill(kvbuf, 0.0f, (long)((size_t)b * pl.N * kvpitch), s); if (rc_ != HN_OK) return rc_; }
     }
-    gq.C = pl.q; gq.ldc = qpitch; gq.alpha = pl.cscale;
+    gq.C = qbuf; gq.ldc = qpitch; gq.alpha = pl.cscale;
     gq.col_group = pl.dh; gq.col_group_pitch = pl.dhp;
     // latent self-attention: the K/V projection reads the same LayerNorm-ed x as the query projection -> one launch for both
-    const bool fused_kv = !ctx && !kv_ready;
+    const bool fused_kv = !ctx && !kv_ready && !q_done;
     if (fused_kv) {
       gq.W2 = p->w_kv; gq.C2 = kvbuf; gq.ldc2 = kvpitch; gq.N2 = 2 * pl.inner; gq.alpha2 = 1.0f;
       gq.col_group2 = pl.dh; gq.col_group_pitch2 = pl.dhp;
     }
-    if ((rc = launch_gemm(gq, s)) != HN_OK) return rc;
+    if (!q_done && (rc = launch_gemm(gq, s)) != HN_OK) return rc;
     if (!kv_ready && !fused_kv) {
       GemmArgs gk = gemm_defaults();
       if (ctx) {
@@ -190,7 +205,7 @@ static int attn_prepare(const hn_attn_params *p, const AttnPlan &pl, const float
       gk.C = kvbuf; gk.ldc = kvpitch; gk.col_group = pl.dh; gk.col_group_pitch = pl.dhp;
       if ((rc = launch_gemm(gk, s)) != HN_OK) return rc;
     }
-    core->Q = pl.q; core->q_b = (long)L * qpitch; core->q_h = pl.dhp; core->ldq = qpitch;
+    core->Q = qbuf; core->q_b = (long)L * qpitch; core->q_h = pl.dhp; core->ldq = qpitch;
     core->Kp = kvbuf; core->k_b = (long)pl.N * kvpitch; core->k_h = pl.dhp; core->ldk = kvpitch;
     core->Vp = kvbuf + (long)p->heads * pl.dhp; core->v_b = core->k_b; core->v_h = pl.dhp; core->ldv = kvpitch;
   }
@@ -200,8 +215,9 @@ static int attn_prepare(const hn_attn_params *p, const AttnPlan &pl, const float
 static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_out, int residual, const float *ctx,
                          int ld_ctx, int b, int L, int N, int D, const uint8_t *mask, float *stats, void *ws,
                          size_t ws_bytes, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, float *o_save = nullptr,
-                         bool ctx_has_ones = false, int ctx_pack_ks = 0, const Bf16Context *bc = nullptr, int *bound_flag = nullptr) {
-  HN_REQUIRE(x_in && x_out, HN_E_NULL, "attn: x is NULL");
+                         bool ctx_has_ones = false, int ctx_pack_ks = 0, const Bf16Context *bc = nullptr, int *bound_flag = nullptr,
+                         AttnExt *ext = nullptr) {
+  HN_REQUIRE(x_in && (x_out || (ext && ext->defer_out)), HN_E_NULL, "attn: x is NULL");
   HN_REQUIRE(p && p->w_q && p->w_kv && p->w_out, HN_E_NULL, "attn: weight pointer is NULL");
   AttnPlan pl;
   int rc = plan_attn(p, ctx != nullptr, ld_ctx, b, L, N, D, nullptr, 0, &pl, bc ? bc->ns : 0);
@@ -244,13 +260,14 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
     gq.W = p->w_q; gq.ldw = p->query_dim;
     gq.M = b * L; gq.N = pl.inner; gq.K = p->query_dim;
     if (p->norm_w) { gq.pro = PRO_LAYERNORM; gq.gamma = p->norm_w; gq.beta = p->norm_b; }
-    gq.C = pl.q; gq.ldc = pl.inner;
-    if ((rc = launch_gemm(gq, s)) != HN_OK) return rc;
+    float *qraw = (ext && ext->q) ? ext->q : pl.q;
+    gq.C = qraw; gq.ldc = pl.inner;
+    if (!(ext && ext->q_done) && (rc = launch_gemm(gq, s)) != HN_OK) return rc;
     uint16_t *qfb = (uint16_t *)pl.qf;
     float *bound = p->ctx_gamma ? pl.bound : nullptr;
     int *bflag = bound ? (bound_flag ? bound_flag : (int *)(pl.bound + (size_t)b * p->heads * pl.Lp)) : nullptr;
     if (bound && !bound_flag && (rc = launch_fill((float *)bflag, 0.0f, 1, s)) != HN_OK) return rc;
-    if ((rc = launch_qfold_bf16(pl.q, pl.inner, p->w_kv, pl.D, p->ctx_gamma, pl.cscale, qfb, b, p->heads, L, pl.Lp, pl.dh, bc->DV, bc->ns, s,
+    if ((rc = launch_qfold_bf16(qraw, pl.inner, p->w_kv, pl.D, p->ctx_gamma, pl.cscale, qfb, b, p->heads, L, pl.Lp, pl.dh, bc->DV, bc->ns, s,
                                 bound, bflag)) != HN_OK)
       return rc;
     AttnCoreBf16Args ca;
@@ -266,6 +283,7 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
     if ((rc = launch_merge_vproj(pl.opart, pl.mpart, pl.lpart, pl.nsplit, b, p->heads, L, pl.Lp, pl.dp, pl.D, p->ctx_gamma,
                                  p->ctx_beta, p->w_kv + (long)pl.inner * pl.D, pl.dh, pl.obuf, pl.inner, stats, nullptr, s, 0)) != HN_OK)
       return rc;
+    if (ext && ext->defer_out) { ext->o_out = pl.obuf; ext->ldo_out = pl.inner; return HN_OK; }
     GemmArgs go = gemm_defaults();
     go.A = pl.obuf; go.lda = pl.inner;
     go.W = p->w_out; go.ldw = pl.inner;
@@ -279,7 +297,7 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
   AttnCoreArgs core;
   const int pack_ks = (pl.rank_d && pl.ones && ctx_has_ones && p->ctx_gamma) ? ctx_pack_ks : 0;
   if ((rc = attn_prepare(p, pl, x_in, ctx, ld_ctx, b, L, s, &core, pack_ks,
-                         saved_kv(pl, ctx != nullptr, mask != nullptr || dropping, b, L, o_save), false, !dropping, bound_flag)) != HN_OK) return rc;
+                         saved_kv(pl, ctx != nullptr, mask != nullptr || dropping, b, L, o_save), false, !dropping, bound_flag, ext)) != HN_OK) return rc;
   core.mask = mask;
   core.ones_in_mem = (ctx_has_ones && pl.ones) ? 1 : 0;
   core.drop = drop_off();
@@ -300,6 +318,7 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
                                pl.inner, stats, s);
   }
   if (rc != HN_OK) return rc;
+  if (ext && ext->defer_out) { ext->o_out = pl.obuf; ext->ldo_out = pl.inner; return HN_OK; }
 
   GemmArgs go = gemm_defaults();
   go.A = pl.obuf; go.lda = pl.inner;
@@ -738,6 +757,8 @@ struct FusionPlan {
   void *op_ws;
   size_t op_ws_bytes, bytes;
   int dominant;   // modality with the most tokens among the present ones
+  bool chain;     // the latent side runs on latent_chain_kernel (chain.hip): l_d = 128, l_c % 16 == 0
+  float *cq, *ckv;   // ... which writes the NEXT attention block's projections here (outside op_ws: the block in front still owns it)
 };
 
 static int plan_fusion(const hn_model *m, const hn_modality_input *in, int b, void *ws, size_t ws_bytes, FusionPlan *fp,
@@ -849,6 +870,19 @@ static int plan_fusion(const hn_model *m, const hn_modality_input *in, int b, vo
   const size_t ffb = align_up((size_t)b * m->l_c * 5 * m->l_d * sizeof(float), 256);
   if (ffb > op_max) op_max = ffb;
   fp->flags = ar.take<int>((size_t)m->depth * m->n_modalities);
+  {
+    int max_inner = 0, max_inner_self = 0;
+    for (int k = 0; k < m->depth * m->n_modalities; ++k) max_inner = max_inner > m->cross_attn[k].heads * pad_head_dim(m->cross_attn[k].dim_head) ? max_inner : m->cross_attn[k].heads * pad_head_dim(m->cross_attn[k].dim_head);
+    if (m->self_per_cross_attn > 0)
+      for (int k = 0; k < m->depth; ++k) max_inner_self = max_inner_self > m->self_attn[k].heads * pad_head_dim(m->self_attn[k].dim_head) ? max_inner_self : m->self_attn[k].heads * pad_head_dim(m->self_attn[k].dim_head);
+    if (max_inner_self > max_inner) max_inner = max_inner_self;
+    fp->chain = inference && latent_chain_supported(b * m->l_c, m->l_d, 4 * m->l_d) && m->l_c % 16 == 0;
+    fp->cq = fp->ckv = nullptr;
+    if (fp->chain) {
+      fp->cq = ar.take<float>((size_t)b * m->l_c * max_inner);
+      fp->ckv = ar.take<float>((size_t)b * m->l_c * 2 * (max_inner_self > 0 ? max_inner_self : 1));
+    }
+  }
   fp->op_ws_bytes = op_max;
   fp->op_ws = ar.take<char>(op_max);
   fp->bytes = ar.off;
@@ -1264,44 +1298,96 @@ int hn_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, con
   float *cur = input_buffer(0);
   if ((rc = launch_broadcast_rows(m->latents, cur, (long)L * d, b, s, fp.flags, m->depth * M)) != HN_OK) return rc;   // :225 (+ the bound flags)
   const bool head = m->final_classifier_head && !return_embeddings;
-  for (int k = 0; k < nsteps; ++k) {
-    const Step &st = steps[k];
+  static const bool chain_off = getenv("HN_NO_CHAIN") != nullptr;      // development switch: the unfused launch sequence
+  const bool use_chain = fp.chain && !chain_off;
+
+  auto run_attn = [&](const Step &st, const float *xin, float *xout, AttnExt *ext) -> int {
     const int layer = st.layer, i = st.m;
-    float *dst = input_buffer(k + 1);
-    switch (st.kind) {
-      case STEP_CROSS_ATTN: {
-        const hn_attn_params *ap = &m->cross_attn[layer * M + i];
-        if (tab_ready[i]) {     // x <- x + y_layer broadcast over the latent rows (healnet.py:236 with softmax == 1)
-          rc = launch_add_row_broadcast(fp.taby[i] + (size_t)layer * b * ap->query_dim, cur, dst, b, L, ap->query_dim, s);
-          break;
-        }
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (prof && i == fp.dominant && prof->n_recorded < prof->n_events) {
-          e0 = (hipEvent_t)prof->ev_start[prof->n_recorded];
-          e1 = (hipEvent_t)prof->ev_stop[prof->n_recorded];
-          prof->n_recorded++;
-        }
-        Bf16Context bc;
-        bc.zb = (const uint16_t *)fp.z[i]; bc.zT = bc.zb + (size_t)b * fp.Np[i] * bf16_row_slots(fp.ldz[i], fp.ns[i]);
-        bc.Np = fp.Np[i]; bc.DV = fp.ldz[i]; bc.ns = fp.ns[i];
-        rc = attn_fwd_impl(ap, cur, dst, 1, fp.z[i], fp.ldz[i], b, L, fp.N[i], fp.D[i], mask,
-                           attn_stats ? attn_stats[slot_of(st)] : nullptr, fp.op_ws, fp.op_ws_bytes, s, e0, e1, nullptr,
-                           fp.ones[i], fp.pack[i], fp.bf16[i] ? &bc : nullptr, fp.flags + layer * M + i);
-        break;
-      }
-      case STEP_CROSS_FF:
-        rc = ff_fwd_impl(&m->cross_ff[layer * M + i], cur, dst, 1, b * L, fp.op_ws, fp.op_ws_bytes, s);
-        break;
-      case STEP_SELF_ATTN:                                                                  // :241-245
-        rc = attn_fwd_impl(&m->self_attn[layer], cur, dst, 1, nullptr, 0, b, L, L, d, nullptr,
-                           attn_stats ? attn_stats[slot_of(st)] : nullptr, fp.op_ws, fp.op_ws_bytes, s, nullptr, nullptr);
-        break;
-      default:
-        rc = ff_fwd_impl(&m->self_ff[layer], cur, dst, 1, b * L, fp.op_ws, fp.op_ws_bytes, s);
-        break;
+    if (st.kind == STEP_SELF_ATTN)                                                              // :241-245
+      return attn_fwd_impl(&m->self_attn[layer], xin, xout, 1, nullptr, 0, b, L, L, d, nullptr,
+                           attn_stats ? attn_stats[slot_of(st)] : nullptr, fp.op_ws, fp.op_ws_bytes, s, nullptr, nullptr, nullptr, false, 0,
+                           nullptr, nullptr, ext);
+    const hn_attn_params *ap = &m->cross_attn[layer * M + i];
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (prof && i == fp.dominant && prof->n_recorded < prof->n_events) {
+      e0 = (hipEvent_t)prof->ev_start[prof->n_recorded];
+      e1 = (hipEvent_t)prof->ev_stop[prof->n_recorded];
+      prof->n_recorded++;
     }
-    if (rc != HN_OK) return rc;
-    cur = dst;
+    Bf16Context bc;
+    bc.zb = (const uint16_t *)fp.z[i]; bc.zT = bc.zb + (size_t)b * fp.Np[i] * bf16_row_slots(fp.ldz[i], fp.ns[i]);
+    bc.Np = fp.Np[i]; bc.DV = fp.ldz[i]; bc.ns = fp.ns[i];
+    return attn_fwd_impl(ap, xin, xout, 1, fp.z[i], fp.ldz[i], b, L, fp.N[i], fp.D[i], mask,
+                         attn_stats ? attn_stats[slot_of(st)] : nullptr, fp.op_ws, fp.op_ws_bytes, s, e0, e1, nullptr,
+                         fp.ones[i], fp.pack[i], fp.bf16[i] ? &bc : nullptr, fp.flags + layer * M + i, ext);
+  };
+  auto ff_of = [&](const Step &st) { return st.kind == STEP_CROSS_FF ? &m->cross_ff[st.layer * M + st.m] : &m->self_ff[st.layer]; };
+  auto is_attn = [](const Step &st) { return st.kind == STEP_CROSS_ATTN || st.kind == STEP_SELF_ATTN; };
+  // one-token cross block whose output vectors were computed ahead of the layer loop
+  auto is_tab = [&](const Step &st) { return st.kind == STEP_CROSS_ATTN && tab_ready[st.m]; };
+
+  bool q_done = false, kv_done = false;      // projections of the attention block at `k` already produced by the chain in front of it
+  for (int k = 0; k < nsteps;) {
+    const Step &st = steps[k];
+    if (!is_attn(st)) {                      // a feed-forward block not absorbed by a chain
+      float *dst = input_buffer(k + 1);
+      if ((rc = ff_fwd_impl(ff_of(st), cur, dst, 1, b * L, fp.op_ws, fp.op_ws_bytes, s)) != HN_OK) return rc;
+      cur = dst; ++k;
+      continue;
+    }
+    const hn_attn_params *ap = st.kind == STEP_SELF_ATTN ? &m->self_attn[st.layer] : &m->cross_attn[st.layer * M + st.m];
+    const int inner = ap->heads * ap->dim_head;
+    // The chain behind this block: its out-projection (or the one-token broadcast add), the feed-forward block that follows
+    // (healnet.py:237 / :245) and the projections of the attention block after that.
+    const bool ff_next = k + 1 < nsteps && !is_attn(steps[k + 1]);
+    bool fuse = use_chain && ff_next && ff_of(steps[k + 1])->dim == d && ff_of(steps[k + 1])->dropout == 0.0f;
+    if (fuse && !is_tab(st)) fuse = ap->query_dim == d && inner % 64 == 0 && inner <= 512 && !(st.kind == STEP_CROSS_ATTN && fp.N[st.m] == 1 && mask == nullptr);
+    if (!fuse) {
+      float *dst = input_buffer(k + 1);
+      if (is_tab(st)) rc = launch_add_row_broadcast(fp.taby[st.m] + (size_t)st.layer * b * ap->query_dim, cur, dst, b, L, ap->query_dim, s);
+      else {
+        AttnExt ext = {fp.cq, fp.ckv, q_done, kv_done, false, nullptr, 0};
+        rc = run_attn(st, cur, dst, (q_done || kv_done) ? &ext : nullptr);
+      }
+      if (rc != HN_OK) return rc;
+      cur = dst; ++k; q_done = kv_done = false;
+      continue;
+    }
+    ChainArgs ca;
+    memset(&ca, 0, sizeof(ca));
+    ca.rows = b * L; ca.L = L; ca.x_in = cur;
+    if (is_tab(st)) {
+      ca.head = 2; ca.y = fp.taby[st.m] + (size_t)st.layer * b * ap->query_dim;
+    } else {
+      AttnExt ext = {fp.cq, fp.ckv, q_done, kv_done, true, nullptr, 0};
+      if ((rc = run_attn(st, cur, nullptr, &ext)) != HN_OK) return rc;
+      ca.head = 1; ca.O = ext.o_out; ca.ldo = ext.ldo_out; ca.inner_o = inner; ca.w_out = ap->w_out; ca.b_out = ap->b_out;
+    }
+    const hn_ff_params *fpar = ff_of(steps[k + 1]);
+    HN_REQUIRE(fpar->w1 && fpar->b1 && fpar->w2 && fpar->b2, HN_E_NULL, "ff: weight pointer is NULL");
+    ca.has_ff = 1; ca.gate = fpar->gate; ca.f_nw = fpar->norm_w; ca.f_nb = fpar->norm_b;
+    ca.w1 = fpar->w1; ca.b1 = fpar->b1; ca.w2 = fpar->w2; ca.b2 = fpar->b2;
+    // projections of the attention block after the feed-forward block
+    q_done = kv_done = false;
+    if (k + 2 < nsteps && is_attn(steps[k + 2]) && !is_tab(steps[k + 2])) {
+      const Step &sn = steps[k + 2];
+      const bool self = sn.kind == STEP_SELF_ATTN;
+      const hn_attn_params *an = self ? &m->self_attn[sn.layer] : &m->cross_attn[sn.layer * M + sn.m];
+      AttnPlan pn;
+      if ((rc = plan_attn(an, !self, self ? 0 : fp.ldz[sn.m], b, L, self ? L : fp.N[sn.m], self ? d : fp.D[sn.m], nullptr, 0, &pn)) != HN_OK) return rc;
+      const bool one_token = !self && fp.N[sn.m] == 1 && mask == nullptr;
+      if (!one_token && pn.dh == pn.dhp && pn.inner % 128 == 0 && an->query_dim == d && an->w_q && an->w_kv) {
+        ca.p_nw = an->norm_w; ca.p_nb = an->norm_b;
+        ca.nq = pn.inner; ca.wq = an->w_q; ca.Q = fp.cq; ca.ldq = pn.inner;
+        ca.alpha_q = pn.rank_d ? 1.0f : pn.cscale;       // the rank-D binding scales in its query fold
+        q_done = true;
+        if (self) { ca.nkv = 2 * pn.inner; ca.wkv = an->w_kv; ca.KV = fp.ckv; ca.ldkv = 2 * pn.inner; kv_done = true; }
+      }
+    }
+    float *dst = input_buffer(k + 2);
+    ca.x_out = dst;
+    if ((rc = launch_latent_chain(ca, s)) != HN_OK) return rc;
+    cur = dst; k += 2;
   }
   if (head) return launch_head(cur, b, L, d, m->head_norm_w, m->head_norm_b, m->head_w, m->head_b, m->out_dims, out, s);
   { int rc_ = launch_copy(out, cur, (long)((xbytes) / sizeof(float)), s); if (rc_ != HN_OK) return rc_; }
@@ -1535,6 +1621,105 @@ int hn_fusion_backward(const hn_model *m, const hn_modality_input *in, int b, co
     if ((rc = signal(next_layer_event)) != HN_OK) return rc;
   if (g->latents) return launch_colsum(dX, (long)L * d, b, L * d, 1.0f, g->latents, 1, s);   // x0 = latents broadcast over the batch
   return HN_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// latent block = latent self-attention + feed-forward (healnet.py:241-245), SURVEY.md 8(b) hn_latent_block_fwd / _bwd
+// ------------------------------------------------------------------------------------------------
+struct LatentBlockPlan { float *q, *kv, *xmid; void *op; size_t op_bytes, bytes; bool chain; };
+
+static int plan_latent_block(const hn_attn_params *ap, const hn_ff_params *fp, int b, int L, void *ws, size_t ws_bytes, LatentBlockPlan *lp) {
+  HN_REQUIRE(ap && fp, HN_E_NULL, "latent_block: params NULL");
+  HN_REQUIRE(fp->dim == ap->query_dim, HN_E_SHAPE, "latent_block: attention width %d != feed-forward width %d", ap->query_dim, fp->dim);
+  AttnPlan pl;
+  int rc = plan_attn(ap, false, 0, b, L, L, ap->query_dim, nullptr, 0, &pl);
+  if (rc != HN_OK) return rc;
+  Arena ar(ws, ws_bytes);
+  const size_t rows = (size_t)b * L;
+  lp->chain = latent_chain_supported((int)rows, ap->query_dim, 4 * fp->dim) && pl.dh == pl.dhp && pl.inner % 128 == 0 && pl.inner <= 512 &&
+              fp->dropout == 0.0f && ap->dropout == 0.0f && getenv("HN_NO_CHAIN") == nullptr;
+  lp->q = ar.take<float>(rows * pl.heads * pl.dhp);
+  lp->kv = ar.take<float>(rows * 2 * pl.heads * pl.dhp);
+  lp->xmid = ar.take<float>(rows * ap->query_dim);
+  const size_t ffb = ff_ws_bytes(fp, (int)rows);
+  lp->op_bytes = pl.bytes > ffb ? pl.bytes : ffb;
+  lp->op = ar.take<char>(lp->op_bytes);
+  lp->bytes = ar.off;
+  if (ws != nullptr && ar.overflow) return fail(HN_E_WORKSPACE, "latent_block: workspace %zu bytes < required %zu", ws_bytes, ar.off);
+  return HN_OK;
+}
+
+extern "C" {
+
+size_t hn_latent_block_workspace_bytes(const hn_attn_params *attn, const hn_ff_params *ff, int b, int L) {
+  LatentBlockPlan lp;
+  if (plan_latent_block(attn, ff, b, L, nullptr, 0, &lp) != HN_OK) return 0;
+  return lp.bytes;
+}
+
+int hn_latent_block_fwd(const hn_attn_params *attn, const hn_ff_params *ff, const float *x_in, float *x_out, int b, int L,
+                        float *x_mid, float *stats, float *saved, void *workspace, size_t workspace_bytes, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  HN_REQUIRE(x_in && x_out, HN_E_NULL, "latent_block: x is NULL");
+  LatentBlockPlan lp;
+  int rc = plan_latent_block(attn, ff, b, L, nullptr, 0, &lp);
+  if (rc != HN_OK) return rc;
+  if ((rc = check_ws(workspace, workspace_bytes, lp.bytes, "latent_block")) != HN_OK) return rc;
+  if ((rc = plan_latent_block(attn, ff, b, L, workspace, workspace_bytes, &lp)) != HN_OK) return rc;
+  const int d = attn->query_dim;
+  const bool training = saved != nullptr;        // the training form keeps x_mid / stats / saved for hn_latent_block_bwd
+  HN_REQUIRE(!training || (x_mid && stats), HN_E_NULL, "latent_block: the training form needs x_mid and stats");
+  if (!lp.chain || training) {                   // unfused: the two blocks back to back (any shape; dropout; tape)
+    float *mid = x_mid ? x_mid : lp.xmid;
+    if ((rc = attn_fwd_impl(attn, x_in, mid, 1, nullptr, 0, b, L, L, d, nullptr, stats, lp.op, lp.op_bytes, s, nullptr, nullptr, saved)) != HN_OK)
+      return rc;
+    return ff_fwd_impl(ff, mid, x_out, 1, b * L, lp.op, lp.op_bytes, s, training);
+  }
+  AttnPlan pl;
+  if ((rc = plan_attn(attn, false, 0, b, L, L, d, nullptr, 0, &pl)) != HN_OK) return rc;
+  HN_REQUIRE(attn->w_q && attn->w_kv && attn->w_out && attn->b_out, HN_E_NULL, "attn: weight pointer is NULL");
+  ChainArgs c1;                                   // Q | KV = LN(x) W^T
+  memset(&c1, 0, sizeof(c1));
+  c1.rows = b * L; c1.L = L; c1.x_in = x_in;
+  c1.p_nw = attn->norm_w; c1.p_nb = attn->norm_b;
+  c1.nq = pl.inner; c1.wq = attn->w_q; c1.Q = lp.q; c1.ldq = pl.inner; c1.alpha_q = pl.cscale;
+  c1.nkv = 2 * pl.inner; c1.wkv = attn->w_kv; c1.KV = lp.kv; c1.ldkv = 2 * pl.inner;
+  if ((rc = launch_latent_chain(c1, s)) != HN_OK) return rc;
+  AttnExt ext = {lp.q, lp.kv, true, true, true, nullptr, 0};
+  if ((rc = attn_fwd_impl(attn, x_in, nullptr, 1, nullptr, 0, b, L, L, d, nullptr, stats, lp.op, lp.op_bytes, s, nullptr, nullptr, nullptr,
+                          false, 0, nullptr, nullptr, &ext)) != HN_OK) return rc;
+  ChainArgs c2;                                   // x_out = x1 + FF(LN x1), x1 = x + LeakyReLU(O W_out^T + b_out)
+  memset(&c2, 0, sizeof(c2));
+  c2.rows = b * L; c2.L = L; c2.x_in = x_in; c2.x_out = x_out;
+  c2.head = 1; c2.O = ext.o_out; c2.ldo = ext.ldo_out; c2.inner_o = pl.inner; c2.w_out = attn->w_out; c2.b_out = attn->b_out;
+  HN_REQUIRE(ff->w1 && ff->b1 && ff->w2 && ff->b2, HN_E_NULL, "ff: weight pointer is NULL");
+  c2.has_ff = 1; c2.gate = ff->gate; c2.f_nw = ff->norm_w; c2.f_nb = ff->norm_b; c2.w1 = ff->w1; c2.b1 = ff->b1; c2.w2 = ff->w2; c2.b2 = ff->b2;
+  return launch_latent_chain(c2, s);
+}
+
+size_t hn_latent_block_bwd_workspace_bytes(const hn_attn_params *attn, const hn_ff_params *ff, int b, int L) {
+  if (!attn || !ff) return 0;
+  const size_t a = hn_attn_bwd_workspace_bytes(attn, 0, 0, b, L, L, attn->query_dim, 0), f = hn_ff_bwd_workspace_bytes(ff, b * L);
+  if (a == 0 || f == 0) return 0;
+  return (a > f ? a : f) + align_up((size_t)b * L * attn->query_dim * sizeof(float), 256);
+}
+
+int hn_latent_block_bwd(const hn_attn_params *attn, const hn_ff_params *ff, const float *x_in, const float *x_mid, int b, int L,
+                        const float *stats, const float *saved, const float *dy, float *dx, const hn_attn_grads *attn_grads,
+                        const hn_ff_grads *ff_grads, void *workspace, size_t workspace_bytes, void *stream) {
+  HN_REQUIRE(attn && ff && x_in && x_mid && stats && saved && dy && dx && attn_grads && ff_grads, HN_E_NULL, "latent_block_bwd: NULL pointer");
+  const size_t need = hn_latent_block_bwd_workspace_bytes(attn, ff, b, L);
+  int rc = check_ws(workspace, workspace_bytes, need, "latent_block_bwd");
+  if (rc != HN_OK) return rc;
+  const size_t dmid_bytes = align_up((size_t)b * L * attn->query_dim * sizeof(float), 256);
+  float *dmid = (float *)workspace;
+  void *op = (char *)workspace + dmid_bytes;
+  // x_out = x_mid + FF(LN x_mid);  x_mid = x_in + Attn(LN x_in): the two block backwards in reverse order
+  if ((rc = ff_bwd_impl(ff, x_mid, dy, dmid, 1, b * L, ff_grads, op, workspace_bytes - dmid_bytes, (hipStream_t)stream)) != HN_OK) return rc;
+  return attn_bwd_impl(attn, x_in, x_mid, 1, nullptr, 0, b, L, L, attn->query_dim, nullptr, stats, saved, dmid, dx, attn_grads, op,
+                       workspace_bytes - dmid_bytes, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -205,6 +205,26 @@ struct GemmSkinnyMulti {
 int launch_gemm_skinny_multi(const GemmSkinnyMulti &g, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
+// latent chain (chain.hip): out-projection / broadcast add -> feed-forward block -> next block's projections, one launch
+// ------------------------------------------------------------------------------------------------
+struct ChainArgs {
+  int rows, L;                          // b * l_c rows of width 128 (16 per workgroup); l_c rows per sample
+  const float *x_in; float *x_out;      // (rows, 128); x_out may be NULL or alias x_in
+  int head;                             // 0: x = x_in; 1: x = x_in + LeakyReLU(O W_out^T + b_out); 2: x = x_in + y[row / L]
+  const float *O; int ldo, inner_o;     // head 1: merged attention output (rows, inner_o), inner_o a multiple of 32, <= 512
+  const float *w_out, *b_out;           //         to_out.0.weight (128, inner_o), to_out.0.bias
+  const float *y;                       // head 2: (b, 128) block output of a one-token cross-attention
+  int has_ff, gate;                     // feed-forward block (hn_gate)
+  const float *f_nw, *f_nb, *w1, *b1, *w2, *b2;
+  int nq, nkv;                          // widths of the next attention block's projections (multiples of 128; 0 = none)
+  const float *p_nw, *p_nb;             // that block's LayerNorm on x (NULL: none)
+  const float *wq; float *Q; int ldq; float alpha_q;
+  const float *wkv; float *KV; int ldkv;
+};
+bool latent_chain_supported(int rows, int d, int hidden);
+int launch_latent_chain(const ChainArgs &a, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
 // encode
 // ------------------------------------------------------------------------------------------------
 int launch_encode(const void *data, int in_dtype, int b, int n_axes, const int *spatial, int C, int F, float max_freq,

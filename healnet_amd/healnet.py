@@ -32,7 +32,7 @@ from torch import nn
 
 from . import _capi
 
-__all__ = ["HealNet", "Attention", "PreNorm", "FeedForward", "fourier_encode_concat"]
+__all__ = ["HealNet", "Attention", "PreNorm", "FeedForward", "fourier_encode_concat", "latent_block"]
 
 
 # ------------------------------------------------------------------------------------------------
@@ -318,6 +318,21 @@ def _wrap64(seed: int) -> int:
     """torch.initial_seed() is an unsigned 64-bit value; int64 tensors carry it two's-complement."""
     seed &= 0xFFFFFFFFFFFFFFFF
     return seed - (1 << 64) if seed >= (1 << 63) else seed
+
+
+def latent_block(self_attn: "PreNorm", self_ff: "PreNorm", x: torch.Tensor) -> torch.Tensor:
+    """One latent self block of the fusion loop, ``x = self_attn(x) + x; x = self_ff(x) + x`` (healnet.py:241-245), as ONE
+    operator: torch.ops.healnet_hip.latent_block -> hn_latent_block_fwd (the fused latent chain for l_d = 128; differentiable
+    through hn_latent_block_bwd).  ``self_attn`` / ``self_ff`` are the PreNorm-wrapped blocks, e.g. ``model.layers[l][-1]``."""
+    att, ff = self_attn.fn, self_ff.fn
+    if not isinstance(att, Attention) or not isinstance(ff, FeedForward) or self_attn.norm_context is not None:
+        raise TypeError("latent_block takes PreNorm(Attention without context) and PreNorm(FeedForward)")
+    _require_gpu(x, "x")
+    if (att.training and att.dropout_p > 0.0) or (ff.training and ff.dropout_p > 0.0):
+        raise NotImplementedError("healnet_amd: latent_block runs without dropout; dropout runs through HealNet's fused training path")
+    return _hip.latent_block(x, self_attn.norm.weight, self_attn.norm.bias, att.to_q.weight, att.to_kv.weight, att.to_out[0].weight,
+                             att.to_out[0].bias, att.heads, self_ff.norm.weight, self_ff.norm.bias, ff.net[0].weight, ff.net[0].bias,
+                             ff.net[2].weight, ff.net[2].bias, not ff.snn)
 
 
 class _MeanPool(nn.Module):

@@ -15,6 +15,9 @@ Whole fusion stack (``spec`` = JSON description of the module structure, see ``H
 Blocks (differentiable w.r.t. x and the parameters; no gradient flows to the context, as in the C ABI):
     attention(x, context?, mask?, norm_w?, norm_b?, ctx_gamma?, ctx_beta?, w_q, w_kv, w_out, b_out, heads, residual) -> (b, L, query_dim)
     attention_fwd(..., train) -> (out, stats, saved)       attention_bwd(dy, x, out, ..., stats, saved) -> Tensor[9]
+    latent_block(x, a_norm_w?, a_norm_b?, w_q, w_kv, w_out, b_out, heads, f_norm_w?, f_norm_b?, w1, b1, w2, b2, gelu) -> like x
+                 (latent self-attention + feed-forward of one fusion iteration, hn_latent_block_fwd: the fused latent chain)
+    latent_block_fwd(..., train) -> (out, x_mid, stats, saved)      latent_block_bwd(dy, x_mid, stats, saved, ...) -> Tensor[13]
     feed_forward(x, norm_w?, norm_b?, w1, b1, w2, b2, gelu, residual) -> like x        feed_forward_bwd(...) -> Tensor[7]
     head(x, norm_w, norm_b, w, bias) -> (b, out_dims)                                   head_bwd(...) -> Tensor[5]
 Elementwise / encode helpers (forward only):
@@ -48,6 +51,11 @@ _lib.define("attention_bwd(Tensor dy, Tensor x, Tensor out, Tensor? context, Ten
 _FF_ARGS = "Tensor x, Tensor? norm_w, Tensor? norm_b, Tensor w1, Tensor b1, Tensor w2, Tensor b2, bool gelu, bool residual"
 _lib.define(f"feed_forward({_FF_ARGS}) -> Tensor")
 _lib.define(f"feed_forward_bwd(Tensor dy, {_FF_ARGS}) -> Tensor[]")
+_LB_ARGS = ("Tensor x, Tensor? a_norm_w, Tensor? a_norm_b, Tensor w_q, Tensor w_kv, Tensor w_out, Tensor b_out, int heads, "
+            "Tensor? f_norm_w, Tensor? f_norm_b, Tensor w1, Tensor b1, Tensor w2, Tensor b2, bool gelu")
+_lib.define(f"latent_block({_LB_ARGS}) -> Tensor")
+_lib.define(f"latent_block_fwd({_LB_ARGS}, bool train) -> (Tensor, Tensor, Tensor, Tensor)")
+_lib.define(f"latent_block_bwd(Tensor dy, Tensor x_mid, Tensor stats, Tensor saved, {_LB_ARGS}) -> Tensor[]")
 _lib.define("head(Tensor x, Tensor norm_w, Tensor norm_b, Tensor w, Tensor bias) -> Tensor")
 _lib.define("head_bwd(Tensor dlogits, Tensor x, Tensor norm_w, Tensor norm_b, Tensor w) -> Tensor[]")
 _lib.define("temperature_softmax(Tensor logits, float temperature) -> Tensor")
@@ -469,6 +477,110 @@ def _ff_backward(ctx, dout):
 torch.library.register_autograd("healnet_hip::feed_forward", _ff_backward, setup_context=_ff_setup)
 
 
+# ------------------------------------------------------------------------------------------------
+# latent block (self-attention + feed-forward)
+# ------------------------------------------------------------------------------------------------
+def _lb_params(x, a_norm_w, a_norm_b, w_q, w_kv, w_out, b_out, heads, f_norm_w, f_norm_b, w1, b1, w2, b2, gelu, fake=False):
+    b, L, d = x.shape
+    pf = (lambda t: None if t is None else _FAKE_PTR) if fake else _ptr
+    ap = _capi.AttnParams(heads=heads, dim_head=w_q.shape[0] // heads, query_dim=d, norm_w=pf(a_norm_w), norm_b=pf(a_norm_b),
+                          w_q=pf(w_q), w_kv=pf(w_kv), w_out=pf(w_out), b_out=pf(b_out))
+    fp = _capi.FFParams(dim=d, gate=1 if gelu else 0, norm_w=pf(f_norm_w), norm_b=pf(f_norm_b), w1=pf(w1), b1=pf(b1), w2=pf(w2),
+                        b2=pf(b2))
+    return ap, fp, int(b), int(L), int(d)
+
+
+def _latent_block_fwd(x, a_norm_w, a_norm_b, w_q, w_kv, w_out, b_out, heads, f_norm_w, f_norm_b, w1, b1, w2, b2, gelu, train):
+    lib = _capi.lib()
+    x = _f32c(x)
+    ap, fp, b, L, d = _lb_params(x, a_norm_w, a_norm_b, w_q, w_kv, w_out, b_out, heads, f_norm_w, f_norm_b, w1, b1, w2, b2, gelu)
+    need = lib.hn_latent_block_workspace_bytes(C.byref(ap), C.byref(fp), b, L)
+    if need == 0:
+        _capi.check(-1, "hn_latent_block_workspace_bytes")
+    ws = WS.get(x.device, need)
+    out = torch.empty_like(x)
+    stats = torch.empty(b, heads, L, 2, dtype=torch.float32, device=x.device)
+    if train:
+        x_mid = torch.empty_like(x)
+        saved = torch.empty(lib.hn_attn_saved_floats(C.byref(ap), 0, 0, b, L, L, d, 0), dtype=torch.float32, device=x.device)
+    else:
+        x_mid = saved = torch.empty(0, dtype=torch.float32, device=x.device)
+    _capi.check(lib.hn_latent_block_fwd(C.byref(ap), C.byref(fp), x.data_ptr(), out.data_ptr(), b, L,
+                                        x_mid.data_ptr() if train else None, stats.data_ptr(), saved.data_ptr() if train else None,
+                                        ws.data_ptr(), ws.numel(), _stream_ptr(x.device)), "hn_latent_block_fwd")
+    return out, x_mid, stats, saved
+
+
+@torch.library.register_fake("healnet_hip::latent_block_fwd")
+def _(x, a_norm_w, a_norm_b, w_q, w_kv, w_out, b_out, heads, f_norm_w, f_norm_b, w1, b1, w2, b2, gelu, train):
+    ap, fp, b, L, d = _lb_params(x, a_norm_w, a_norm_b, w_q, w_kv, w_out, b_out, heads, f_norm_w, f_norm_b, w1, b1, w2, b2, gelu, fake=True)
+    n_saved = _capi.lib().hn_attn_saved_floats(C.byref(ap), 0, 0, b, L, L, d, 0) if train else 0
+    e = x.new_empty
+    return (e(x.shape, dtype=torch.float32), e(x.shape if train else (0,), dtype=torch.float32), e((b, heads, L, 2), dtype=torch.float32),
+            e((n_saved,), dtype=torch.float32))
+
+
+def _latent_block_bwd(dy, x_mid, stats, saved, x, a_norm_w, a_norm_b, w_q, w_kv, w_out, b_out, heads, f_norm_w, f_norm_b, w1, b1, w2, b2,
+                      gelu):
+    lib = _capi.lib()
+    x, dy = _f32c(x), _f32c(dy)
+    ap, fp, b, L, d = _lb_params(x, a_norm_w, a_norm_b, w_q, w_kv, w_out, b_out, heads, f_norm_w, f_norm_b, w1, b1, w2, b2, gelu)
+    need = lib.hn_latent_block_bwd_workspace_bytes(C.byref(ap), C.byref(fp), b, L)
+    if need == 0:
+        _capi.check(-1, "hn_latent_block_bwd_workspace_bytes")
+    ws = WS.get(x.device, need)
+    empty = torch.empty(0, dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    ga = [_opt_out(empty, t) for t in (a_norm_w, a_norm_b, w_q, w_kv, w_out, b_out)]
+    gf = [_opt_out(empty, t) for t in (f_norm_w, f_norm_b, w1, b1, w2, b2)]
+    gp = lambda t: t.data_ptr() if t.numel() else None      # noqa: E731
+    agr = _capi.AttnGrads(norm_w=gp(ga[0]), norm_b=gp(ga[1]), w_q=gp(ga[2]), w_kv=gp(ga[3]), w_out=gp(ga[4]), b_out=gp(ga[5]))
+    fgr = _capi.FFGrads(norm_w=gp(gf[0]), norm_b=gp(gf[1]), w1=gp(gf[2]), b1=gp(gf[3]), w2=gp(gf[4]), b2=gp(gf[5]))
+    _capi.check(lib.hn_latent_block_bwd(C.byref(ap), C.byref(fp), x.data_ptr(), x_mid.data_ptr(), b, L, stats.data_ptr(),
+                                        saved.data_ptr(), dy.data_ptr(), dx.data_ptr(), C.byref(agr), C.byref(fgr), ws.data_ptr(),
+                                        ws.numel(), _stream_ptr(x.device)), "hn_latent_block_bwd")
+    return [dx] + ga + gf
+
+
+@torch.library.register_fake("healnet_hip::latent_block_bwd")
+def _(dy, x_mid, stats, saved, x, a_norm_w, a_norm_b, w_q, w_kv, w_out, b_out, heads, f_norm_w, f_norm_b, w1, b1, w2, b2, gelu):
+    empty = x.new_empty((0,), dtype=torch.float32)
+    return [torch.empty_like(x)] + [empty if t is None else torch.empty_like(t)
+                                    for t in (a_norm_w, a_norm_b, w_q, w_kv, w_out, b_out, f_norm_w, f_norm_b, w1, b1, w2, b2)]
+
+
+def _lb_setup(ctx, inputs, output):
+    (x, a_norm_w, a_norm_b, w_q, w_kv, w_out, b_out, heads, f_norm_w, f_norm_b, w1, b1, w2, b2, gelu, train) = inputs
+    out, x_mid, stats, saved = output
+    if not train:
+        raise RuntimeError("healnet_hip::latent_block_fwd was called with train=False on inputs that require grad")
+    ctx.heads, ctx.gelu = heads, gelu
+    ctx.opt = [t is not None for t in (a_norm_w, a_norm_b, f_norm_w, f_norm_b)]
+    ctx.save_for_backward(x, x_mid, stats, saved, w_q, w_kv, w_out, b_out, w1, b1, w2, b2,
+                          *[t for t in (a_norm_w, a_norm_b, f_norm_w, f_norm_b) if t is not None])
+
+
+def _lb_backward(ctx, dout, dmid, dstats, dsaved):
+    x, x_mid, stats, saved, w_q, w_kv, w_out, b_out, w1, b1, w2, b2, *rest = ctx.saved_tensors
+    it = iter(rest)
+    a_nw, a_nb, f_nw, f_nb = [next(it) if have else None for have in ctx.opt]
+    g = torch.ops.healnet_hip.latent_block_bwd(dout.contiguous(), x_mid, stats, saved, x, a_nw, a_nb, w_q, w_kv, w_out, b_out, ctx.heads,
+                                               f_nw, f_nb, w1, b1, w2, b2, ctx.gelu)
+    o = ctx.opt
+    return (g[0], g[1] if o[0] else None, g[2] if o[1] else None, g[3], g[4], g[5], g[6], None,
+            g[7] if o[2] else None, g[8] if o[3] else None, g[9], g[10], g[11], g[12], None, None)
+
+
+torch.library.register_autograd("healnet_hip::latent_block_fwd", _lb_backward, setup_context=_lb_setup)
+
+
+def _latent_block(x, a_norm_w, a_norm_b, w_q, w_kv, w_out, b_out, heads, f_norm_w, f_norm_b, w1, b1, w2, b2, gelu):
+    ts = (x, a_norm_w, a_norm_b, w_q, w_kv, w_out, b_out, f_norm_w, f_norm_b, w1, b1, w2, b2)
+    train = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts)
+    return torch.ops.healnet_hip.latent_block_fwd(x, a_norm_w, a_norm_b, w_q, w_kv, w_out, b_out, heads, f_norm_w, f_norm_b, w1, b1, w2, b2,
+                                                  gelu, train)[0]
+
+
 def _head(x, norm_w, norm_b, w, bias):
     x = _f32c(x)
     b, L, d = x.shape
@@ -712,7 +824,9 @@ torch.library.register_autograd("healnet_hip::fusion_forward_train", _fusion_bac
 for _name, _fn in (("fourier_encode_concat", _fourier_encode_concat), ("encode_norm", _encode_norm), ("attention_fwd", _attention_fwd),
                    ("attention_bwd", _attention_bwd), ("feed_forward", _feed_forward), ("feed_forward_bwd", _feed_forward_bwd),
                    ("head", _head), ("head_bwd", _head_bwd), ("temperature_softmax", _temperature_softmax),
+                   ("latent_block_fwd", _latent_block_fwd), ("latent_block_bwd", _latent_block_bwd),
                    ("fusion_forward", _fusion_forward), ("fusion_forward_train", _fusion_forward_train),
                    ("fusion_backward", _fusion_backward), ("fusion_backward_into", _fusion_backward_into)):
     _lib.impl(_name, _fn, "CUDA")
 _lib.impl("attention", _attention, "CompositeImplicitAutograd")
+_lib.impl("latent_block", _latent_block, "CompositeImplicitAutograd")

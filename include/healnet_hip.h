@@ -202,6 +202,29 @@ int hn_ff_bwd(const hn_ff_params *p, const float *x_in, const float *dy, float *
 size_t hn_ff_bwd_workspace_bytes(const hn_ff_params *p, int rows);
 
 /* ---------------------------------------------------------------------------------------------
+ * Latent block                                         replaces the latent self block of one fusion iteration, :241-245:
+ *                                                      x_mid = self_attn(x) + x ;  x_out = self_ff(x_mid) + x_mid
+ * `attn` without a context (latent self-attention), `ff` of the same width.  With l_d = 128, l_c % 16 == 0, dim_head in
+ * {16, 32, 64, 128} and heads * dim_head a multiple of 128 (<= 512) the block runs as three launches: one pass of the fused
+ * latent chain (LayerNorm + Q / K / V projections), the attention core, one pass of the chain (out-projection + LeakyReLU +
+ * residual + LayerNorm + gated feed-forward + residual, every intermediate in LDS); other shapes run hn_attn_fwd + hn_ff_fwd.
+ * The same chain kernel carries the latent side of hn_fusion_forward (there it also absorbs the neighbouring cross blocks'
+ * out-projection / query projection).
+ *   x_mid, stats, saved: NULL for inference.  The training form (saved != NULL, then x_mid (b, L, d) and stats (b, heads, L, 2)
+ *   are required; saved has hn_attn_saved_floats(attn, 0, 0, b, L, L, d, 0) floats) keeps what hn_latent_block_bwd needs
+ *   and applies the blocks' dropout.  stats alone (inference) serves hn_attn_probs.
+ * The backward is the two block backwards in reverse order (hn_ff_bwd, then hn_attn_bwd): the dQ / dK / dV cores and the
+ * weight-gradient GEMMs dominate there, a fused chain would save launches only.
+ * ------------------------------------------------------------------------------------------- */
+int hn_latent_block_fwd(const hn_attn_params *attn, const hn_ff_params *ff, const float *x_in, float *x_out, int b, int L,
+                        float *x_mid, float *stats, float *saved, void *workspace, size_t workspace_bytes, void *stream);
+size_t hn_latent_block_workspace_bytes(const hn_attn_params *attn, const hn_ff_params *ff, int b, int L);
+int hn_latent_block_bwd(const hn_attn_params *attn, const hn_ff_params *ff, const float *x_in, const float *x_mid, int b, int L,
+                        const float *stats, const float *saved, const float *dy, float *dx, const hn_attn_grads *attn_grads,
+                        const hn_ff_grads *ff_grads, void *workspace, size_t workspace_bytes, void *stream);
+size_t hn_latent_block_bwd_workspace_bytes(const hn_attn_params *attn, const hn_ff_params *ff, int b, int L);
+
+/* ---------------------------------------------------------------------------------------------
  * Head                                                 replaces to_logits :181-185
  * logits = LN(mean_n x) W^T + bias ;  x (b, L, d) -> (b, out_dims)
  * ------------------------------------------------------------------------------------------- */

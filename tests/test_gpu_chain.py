@@ -1,0 +1,136 @@
+"""GPU: the fused latent chain (chain.hip; SURVEY.md 8(b) hn_latent_block_fwd / _bwd).
+
+  * hn_latent_block_fwd (chain: LN + Q|K|V -> attention core -> chain: out-projection + LeakyReLU + residual + LN + gated FF +
+    residual) against the oracle's _self_block + _ff_block (healnet.py:241-245), SELU and GELU gates, several head shapes,
+    incl. shapes that fall back to the unfused launches;
+  * its registered backward (hn_latent_block_bwd) against oracle autograd;
+  * the whole model with the chain vs the unfused launch sequence (HN_NO_CHAIN=1 in a subprocess): same logits to fp32 noise,
+    same attention weights -- the chain also absorbs the cross blocks' out-projection / query projection and the one-token
+    broadcast add there.
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from conftest import assert_close
+from oracle import healnet_cpu as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def hn():
+    import healnet_amd
+    return healnet_amd
+
+
+def _blocks(hn, d, heads, dh, snn, seed):
+    torch.manual_seed(seed)
+    att = hn.PreNorm(d, hn.Attention(d, heads=heads, dim_head=dh))
+    ff = hn.PreNorm(d, hn.FeedForward(d, snn=snn))
+    with torch.no_grad():
+        for blk in (att, ff):
+            blk.norm.weight.add_(0.2 * torch.randn(d))
+            blk.norm.bias.add_(0.2 * torch.randn(d))
+    return att, ff
+
+
+def _oracle_block(att, ff, x, heads, snn):
+    sa = {k: v for k, v in att.state_dict().items()}
+    sf = {k: v for k, v in ff.state_dict().items()}
+    return _oracle_block_sd(sa, sf, x, heads, snn)
+
+
+def _oracle_block_sd(sa, sf, x, heads, snn):
+    xn = O.layer_norm(x, sa["norm.weight"], sa["norm.bias"])
+    x1 = O.attention(xn, None, sa["fn.to_q.weight"], sa["fn.to_kv.weight"], sa["fn.to_out.0.weight"], sa["fn.to_out.0.bias"], heads) + x
+    h = O.feed_forward(O.layer_norm(x1, sf["norm.weight"], sf["norm.bias"]), sf["fn.net.0.weight"], sf["fn.net.0.bias"],
+                       sf["fn.net.2.weight"], sf["fn.net.2.bias"], snn=snn)
+    return h + x1
+
+
+@pytest.mark.parametrize("d,heads,dh,b,L,snn", [
+    (128, 8, 64, 4, 128, True),      # the default latent block: fused chain
+    (128, 8, 64, 3, 48, False),      # GELU gate, l_c = 48 (3 row tiles per sample)
+    (128, 4, 32, 2, 128, True),      # inner = 128
+    (128, 2, 128, 2, 64, True),      # dim_head 128
+    (128, 8, 16, 5, 16, True),       # inner = 128 with 8 heads of 16, one tile per sample
+    (128, 3, 64, 2, 128, True),      # inner = 192: not a multiple of 128 -> unfused fallback
+    (128, 8, 64, 2, 40, True),       # l_c = 40: rows not a multiple of 16 per sample but b*L is -> still row tiles of 16
+    (64, 4, 16, 2, 32, True),        # l_d = 64 -> unfused fallback
+])
+def test_latent_block_forward_vs_oracle(hn, d, heads, dh, b, L, snn):
+    att, ff = _blocks(hn, d, heads, dh, snn, seed=d + heads + dh)
+    gen = torch.Generator().manual_seed(7)
+    x = torch.randn(b, L, d, generator=gen) * 1.2
+    with torch.no_grad():
+        want = _oracle_block(att, ff, x, heads, snn)
+        got = hn.latent_block(att.to(DEV), ff.to(DEV), x.to(DEV))
+    assert_close(got.cpu(), want, rel=3e-4, floor=2e-5, what=f"latent block d={d} h={heads} dh={dh} b={b} L={L}")
+
+
+@pytest.mark.parametrize("heads,dh,snn", [(8, 64, True), (4, 32, False)])
+def test_latent_block_backward_vs_oracle_autograd(hn, heads, dh, snn):
+    d, b, L = 128, 3, 32
+    att, ff = _blocks(hn, d, heads, dh, snn, seed=77)
+    gen = torch.Generator().manual_seed(8)
+    x = torch.randn(b, L, d, generator=gen)
+    dy = torch.randn(b, L, d, generator=gen)
+    sa = {k: v.detach().clone().requires_grad_(True) for k, v in att.state_dict().items()}
+    sf = {k: v.detach().clone().requires_grad_(True) for k, v in ff.state_dict().items()}
+    xr = x.clone().requires_grad_(True)
+    want = _oracle_block_sd(sa, sf, xr, heads, snn)
+    want.backward(dy)
+    att.to(DEV), ff.to(DEV)
+    xd = x.to(DEV).requires_grad_(True)
+    got = hn.latent_block(att, ff, xd)
+    assert_close(got.detach().cpu(), want.detach(), rel=3e-4, floor=2e-5, what="latent block (training form)")
+    got.backward(dy.to(DEV))
+    assert_close(xd.grad.cpu(), xr.grad, rel=2e-3, floor=1e-3, what="dx")
+    for blk, sd, nm in ((att, sa, "attn"), (ff, sf, "ff")):
+        for k, p in blk.named_parameters():
+            assert p.grad is not None, k
+            assert_close(p.grad.cpu(), sd[k].grad, rel=2e-3, floor=1e-3, what=f"{nm}.{k}")
+
+
+_SCRIPT = r"""
+import sys, torch
+sys.path.insert(0, {root!r})
+import healnet_amd as hn
+kw = dict(n_modalities=3, channel_dims=[2000, 3, 96], num_spatial_axes=[1, 2, 1], out_dims=4, depth=2)
+torch.manual_seed(5)
+model = hn.HealNet(**kw).eval().to("cuda:0")
+gen = torch.Generator().manual_seed(6)
+ins = [torch.rand(3, 1, 2000, generator=gen).cuda(), torch.rand(3, 40, 36, 3, generator=gen).cuda(), torch.rand(3, 200, 96, generator=gen).cuda()]
+with torch.no_grad():
+    outs = [model(list(ins)), model([ins[0], None, ins[2]]), model(list(ins), return_embeddings=True)]
+    model(list(ins))
+    w = model.get_attention_weights()
+torch.save([o.cpu() for o in outs] + [t.cpu() for t in w], sys.argv[1])
+"""
+
+
+def test_whole_model_chain_vs_unfused_launches(hn, tmp_path):
+    """tab (one-token look-ahead -> broadcast-add head) + image (rank-D binding: Q-only projection) + patch bag (explicit
+    binding: scaled Q projection), default width: the chain route and the HN_NO_CHAIN=1 route must agree."""
+    script = tmp_path / "run.py"
+    script.write_text(_SCRIPT.format(root=ROOT))
+    res = {}
+    for tag, env in (("chain", {}), ("plain", {"HN_NO_CHAIN": "1"})):
+        out = tmp_path / f"{tag}.pt"
+        e = dict(os.environ, **env)
+        e.pop("HN_NO_CHAIN", None) if tag == "chain" else None
+        r = subprocess.run([sys.executable, str(script), str(out)], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = torch.load(out)
+    assert len(res["chain"]) == len(res["plain"]) == 3 + 2 * 4
+    diffs = []
+    for i, (a, b_) in enumerate(zip(res["chain"], res["plain"])):
+        assert_close(a, b_, rel=2e-5, floor=2e-6, what=f"output {i}: chain vs unfused")
+        diffs.append(float((a - b_).abs().max()))
+    assert max(diffs) > 0.0, "both runs took the same route (HN_NO_CHAIN had no effect)"
