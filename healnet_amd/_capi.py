@@ -16,7 +16,7 @@ HN_ABI_VERSION = 4
 HN_F32, HN_BF16, HN_U8 = 0, 1, 2
 HN_CORE_F32, HN_CORE_BF16, HN_CORE_BF16X3 = 0, 1, 2
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhealnet_hip.so")
+LIB_PATH = os.environ.get("HN_LIB_PATH") or os.path.join(_HERE, "libhealnet_hip.so")   # HN_LIB_PATH: kernel experiments (tools/)
 CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ["api.hip", "gemm.hip", "attention.hip", "attention_bf16.hip", "attention_bwd.hip", "encode.hip", "misc.hip",
            "backward.hip", "train.hip", "chain.hip"]

@@ -1341,7 +1341,7 @@ int hn_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, con
     // (healnet.py:237 / :245) and the projections of the attention block after that.
     const bool ff_next = k + 1 < nsteps && !is_attn(steps[k + 1]);
     bool fuse = use_chain && ff_next && ff_of(steps[k + 1])->dim == d && ff_of(steps[k + 1])->dropout == 0.0f;
-    if (fuse && !is_tab(st)) fuse = ap->query_dim == d && inner % 64 == 0 && inner <= 512 && !(st.kind == STEP_CROSS_ATTN && fp.N[st.m] == 1 && mask == nullptr);
+    if (fuse && !is_tab(st)) fuse = ap->query_dim == d && inner % 128 == 0 && inner <= 512 && !(st.kind == STEP_CROSS_ATTN && fp.N[st.m] == 1 && mask == nullptr);
     if (!fuse) {
       float *dst = input_buffer(k + 1);
       if (is_tab(st)) rc = launch_add_row_broadcast(fp.taby[st.m] + (size_t)st.layer * b * ap->query_dim, cur, dst, b, L, ap->query_dim, s);
