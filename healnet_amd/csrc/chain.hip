@@ -8,22 +8,23 @@
 //
 // Every step is local to a latent row, so a workgroup owns 16 rows (b * l_c / 16 workgroups: 256 at cfg2 b = 32, one per CU)
 // and walks the whole chain with its rows in LDS: the x tile, its LayerNorm-ed image, the 16 x 512 feed-forward hidden tile.
-// What streams is the WEIGHTS, and they never touch LDS: eight waves split each 128-column chunk of a GEMM (16 columns per
-// wave), and every wave fetches its own B fragments -- 16 weight rows x 64 bytes per buffer load, already in the MFMA's
-// operand layout -- straight into a four-deep register ring that runs ahead across chunk and stage boundaries (one flat block
-// order for the whole chain).  No barrier inside a GEMM; waves only meet where a stage hands its tile to the next.
-//   (First version: weights staged through a three-buffer LDS ring with one barrier per 16 KB block.  At 16 rows per
-//   workgroup every weight byte feeds only 16 FMAs, so that ring moved 16 KB in and 16 KB out of LDS per 512 MFMA cycles:
-//   the ds_write path alone (~75 B/clk/CU) ate 40 % of a step, a step took 2.1x its MFMA time, 8 waves instead of 4 changed
-//   nothing -- measured with the NOLOAD / NOLDSW / NOMFMA variants of tools/bench_chain.py.)
+// What streams is the WEIGHTS.  Eight waves split each 128-column chunk of a GEMM (16 columns = 16 weight rows per wave), and
+// every wave moves ITS 16 rows x 32 k of each block with two global_load_lds_dwordx4 (full 128-byte lines, 1 KB per
+// instruction, no VGPRs, no ds_write) into a private six-slot LDS ring that runs five blocks ahead across chunk and stage
+// boundaries (one flat block order for the whole chain), and reads its MFMA B fragments back with ds_read_b128.  A wave only
+// ever reads what it loaded itself, so there is NO barrier inside a GEMM -- a counted s_waitcnt vmcnt (inline asm: the loads
+// are invisible to the compiler, which would otherwise drain the whole ring at every use) is all the synchronisation the
+// weight stream needs; waves meet only where a stage hands its tile to the next.
+//   History (tools/bench_chain.py, cfg2 b = 32, 12 chains per forward):
+//   v1  weights staged global -> VGPR -> one shared LDS ring, barrier per block, 4 or 8 waves: 52.6 us per chain.  A block
+//       took 2.1x its MFMA time; removing the ds_writes alone saved 36 % of it (16 KB per 512 MFMA cycles through the
+//       ~75 B/clk ds_write path), removing the global loads almost nothing.
+//   v2  B fragments straight from global memory into a register ring (16 rows x 64 B per load, the attention core's
+//       pattern), no LDS, no barrier: 49 us.  Now the loads were the cost (0.46 us per block against 0.22 us of MFMAs;
+//       15 B/clk/CU at a 92 % L2 hit rate, 20 % more L2 requests than bytes needed: half-line requests).  Neither an L2
+//       warm-up pass nor rotating the chunk order between the workgroups of an XCD changed it.
+//   v3  this version: full-line direct-to-LDS loads.
 //
-// Bound (measured, cfg2 b = 32, tools/bench_chain.py variants): the L2 -> L1 fill rate.  With the loads removed a 128 x 32
-// weight block costs 518 cycles per workgroup (8 MFMAs per wave x two waves per SIMD = 512: the matrix work is AT its bound);
-// with them 1100 cycles = 15 B/clk/CU, 9 TB/s over the chip, at a 92 % L2 hit rate (TCC_HIT / TCC_REQ) -- the same 6-9 TB/s
-// the 2-D tiled latent GEMMs reach.  Every CU has to pull ALL weights of the chain (1.1-2 MB) through its L1, so a chain
-// costs about weights / 38 GB/s + 13 us whatever the tile height up to 256 workgroups; neither an L2 warm-up pass, nor
-// rotating the chunk order between the workgroups of an XCD, nor eight instead of four waves changed that.  Larger batches
-// (more rows per CU) move the same kernel towards the MFMA bound.
 // Shapes: l_d = 128, hidden 512, K a multiple of 128, N a multiple of 128, rows % 16 == 0.
 #include "common.h"
 
@@ -38,7 +39,10 @@ constexpr int WN = 128, WK = 32;        // weight block: 128 output columns x 32
 constexpr int WBLK = WN * WK;           // floats per block (16 KB)
 constexpr int ATILE = CR * WK;          // floats per A k-tile (16 rows x 32 k, 16-byte slots XOR-swizzled by row & 7)
 constexpr int XP = 132;                 // pitch of the x tile
-constexpr int LDS_FLOATS = 16 * ATILE + 4 * ATILE + CR * XP;       // 48.25 KB
+constexpr int NB = 6, PD = 5;           // slots of a wave's weight ring / how many blocks the loads run ahead (NB = PD + 1)
+constexpr int WSLOT = 16 * WK;          // floats per wave and block: 16 weight rows x 32 k (2 KB = two wave-wide 16-byte loads)
+constexpr int PRM = 128 + 2 * CHID + 128 + 4 * 128;      // b_out | b1 | b2 | ff gamma, beta | projection gamma, beta
+constexpr int LDS_FLOATS = 8 * NB * WSLOT + 16 * ATILE + 4 * ATILE + CR * XP + PRM;       // 151.25 KB
 enum { CS_OUT = 0, CS_FF1 = 1, CS_FF2 = 2, CS_Q = 3, CS_KV = 4, CS_END = 5 };
 
 // Pointers that arrive inside the argument struct are generic: hipcc emits flat_load / flat_store for them, and with flat
@@ -69,6 +73,16 @@ __device__ __forceinline__ void lst4(lf32 *base, int off, const float4 &v) {
   *(lf32x4 *)(base + off) = t;
 }
 
+// One wave-wide direct-to-LDS load: lane l fetches 16 bytes at sbase + voff and they land at LDS byte address m0v + 16 l.
+// Issued from inline asm on purpose: the compiler does not see a memory operation, so it inserts no wait of its own; every
+// wait on these loads is a counted vmcnt below.
+__device__ __forceinline__ void glds16(const void *sbase, int voff, unsigned m0v) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(m0v), "s"(sbase) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
 __device__ __forceinline__ float selu_f(float x) {
   const float alpha = 1.6732632423543772848170429916717f, scale = 1.0507009873554804934193349852946f;
   return scale * (x > 0.0f ? x : alpha * expm1f(x));
@@ -83,23 +97,17 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
   // turns "select among pointers" into loads from a selected scratch address followed by flat accesses.
   const gf32 *const a_x_in = (const gf32 *)args.x_in;
   const gf32 *const a_O = (const gf32 *)args.O;
-  const gf32 *const a_w_out = (const gf32 *)args.w_out;
   const gf32 *const a_b_out = (const gf32 *)args.b_out;
   const gf32 *const a_y = (const gf32 *)args.y;
   const gf32 *const a_f_nw = (const gf32 *)args.f_nw;
   const gf32 *const a_f_nb = (const gf32 *)args.f_nb;
-  const gf32 *const a_w1 = (const gf32 *)args.w1;
   const gf32 *const a_b1 = (const gf32 *)args.b1;
-  const gf32 *const a_w2 = (const gf32 *)args.w2;
   const gf32 *const a_b2 = (const gf32 *)args.b2;
   const gf32 *const a_p_nw = (const gf32 *)args.p_nw;
   const gf32 *const a_p_nb = (const gf32 *)args.p_nb;
-  const gf32 *const a_wq = (const gf32 *)args.wq;
-  const gf32 *const a_wkv = (const gf32 *)args.wkv;
   gf32 *const a_x_out = (gf32 *)args.x_out;
   gf32 *const a_Q = (gf32 *)args.Q;
   gf32 *const a_KV = (gf32 *)args.KV;
-  const int a_rows = args.rows;
   const int a_L = args.L;
   const int a_head = args.head;
   const int a_ldo = args.ldo;
@@ -111,19 +119,24 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
   const int a_ldq = args.ldq;
   const int a_ldkv = args.ldkv;
   const float a_alpha_q = args.alpha_q;
-  __shared__ __attribute__((aligned(16))) float lds_raw[LDS_FLOATS];
+  extern __shared__ __attribute__((aligned(16))) float lds_raw[];
   lf32 *lds = (lf32 *)lds_raw;              // float offsets into the one LDS allocation:
-  constexpr int Abig = 0;                   // [16][ATILE]  attention output tile (A of the out-projection), then the FF hidden tile
+  constexpr int Wr = 0;                     // [8 waves][NB][WSLOT]  per-wave weight rings
+  constexpr int Abig = Wr + 8 * NB * WSLOT; // [16][ATILE]  attention output tile (A of the out-projection), then the FF hidden tile,
+                                            //              then (projections) the per-wave output staging tiles
   constexpr int Ahat = Abig + 16 * ATILE;   // [4][ATILE]   LayerNorm-ed x (A of FF1 / of the projections)
   constexpr int xs = Ahat + 4 * ATILE;      // [CR][XP]     the x tile
+  constexpr int prm = xs + CR * XP;         // small parameters: no global load may sit between the steps (see wait_vm)
+  constexpr int p_bout = prm, p_b1 = p_bout + 128, p_b2 = p_b1 + 2 * CHID, p_fnw = p_b2 + 128, p_fnb = p_fnw + 128,
+                p_pnw = p_fnb + 128, p_pnb = p_pnw + 128;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fg = lane >> 4, fi = lane & 15;
   const int m0 = blockIdx.x * CR;
 
   // ---- the block stream: stage -> n-chunk -> k-chunk, identical for the loader and the consumer.  The loader addresses
-  // block number `lb` of the whole chain with branch-free scalar arithmetic (a branchy iterator breaks the step into many
-  // basic blocks and the compiler then waits for ALL outstanding loads in front of every LDS store).
+  // block number `lb` of the whole chain with branch-free scalar arithmetic.
   const int nk_out = a_head == 1 ? a_inner_o / WK : 0;           // out-projection: ONE 128-column chunk of nk_out k-chunks
   const int nq_ch = a_nq / WN, nkv_ch = a_nkv / WN;
   const int e0 = nk_out;                                         // first block of FF1
@@ -131,26 +144,25 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
   const int e2 = e1 + (a_has_ff ? CHID / WK : 0);                //                Q
   const int e3 = e2 + nq_ch * (CD / WK);                         //                KV
   const int nblocks = e3 + nkv_ch * (CD / WK);
-  // (the descriptor words pass through readfirstlane HERE: as plain loads of the by-value argument struct the compiler turns the
-  // per-block "select among five descriptors" into a load from a selected address of a scratch copy of the struct)
-  auto pinned = [](const gf32 *base, unsigned bytes) {
-    i32x4 r = make_rsrc((const void *)(unsigned long long)base, bytes);
-    r.x = __builtin_amdgcn_readfirstlane(r.x); r.y = __builtin_amdgcn_readfirstlane(r.y); r.z = __builtin_amdgcn_readfirstlane(r.z);
-    return r;
-  };
-  const i32x4 rs_out = pinned(a_w_out, a_head == 1 ? (unsigned)((long)CD * a_inner_o * 4) : 0u);
-  const i32x4 rs_w1 = pinned(a_w1, a_has_ff ? (unsigned)(2 * CHID * CD * 4) : 0u);
-  const i32x4 rs_w2 = pinned(a_w2, a_has_ff ? (unsigned)(CD * CHID * 4) : 0u);
-  const i32x4 rs_q = pinned(a_wq, (unsigned)((long)a_nq * CD * 4));
-  const i32x4 rs_kv = pinned(a_wkv, (unsigned)((long)a_nkv * CD * 4));
+  // the five weight base addresses as pinned scalars (readfirstlane keeps the compiler from turning the per-block select
+  // into a lookup table in scratch)
+  auto lo32 = [](const void *p) { return __builtin_amdgcn_readfirstlane((int)((unsigned long long)p & 0xffffffffu)); };
+  auto hi32 = [](const void *p) { return __builtin_amdgcn_readfirstlane((int)((unsigned long long)p >> 32)); };
+  const int wo_lo = lo32(args.w_out), wo_hi = hi32(args.w_out), w1_lo = lo32(args.w1), w1_hi = hi32(args.w1);
+  const int w2_lo = lo32(args.w2), w2_hi = hi32(args.w2), wq_lo = lo32(args.wq), wq_hi = hi32(args.wq);
+  const int wk_lo = lo32(args.wkv), wk_hi = hi32(args.wkv);
   const int inner_o = __builtin_amdgcn_readfirstlane(a_inner_o);
+  const unsigned ring_byte = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds + (unsigned)((Wr + wave * NB * WSLOT) * 4));
+  const int r8 = lane >> 3, pos = lane & 7;                      // loader lane: row r8 (and r8 + 8) of the wave's 16, 16-byte position
+  const int lane_k = ((pos ^ (r8 & 7)) * 4) * 4;                 // ... which holds chunk pos ^ (row & 7) of the 128-byte row
   int lb = 0;                               // next block to request
+  int wslot = 0;                            // ... and the ring slot it goes to
 
-  auto issue = [&](float4 (&r)[2]) {        // global loads of block lb (past the end: the last block again, never consumed)
+  auto issue = [&]() {                      // this wave's 2 KB of block lb (past the end: the last block again, never consumed)
     const int bi = min(lb, nblocks - 1);
     ++lb;
-    // stage of the block as 0 / -1 masks, everything selected with AND / OR: a chain of ?: keyed by the stage is recognised as
-    // a switch and lowered to lookup tables IN SCRATCH (the five descriptors, the stage offsets), read back through flat loads
+    // stage of the block as 0 / -1 masks, everything selected with AND / OR (a chain of ?: keyed by the stage is lowered to
+    // lookup tables in scratch)
     const int m_out = -(int)(bi < e0), m_ff1 = -(int)(bi >= e0 && bi < e1), m_ff2 = -(int)(bi >= e1 && bi < e2);
     const int m_q = -(int)(bi >= e2 && bi < e3), m_kv = -(int)(bi >= e3);
     const int local = bi - ((e0 & m_ff1) | (e1 & m_ff2) | (e2 & m_q) | (e3 & m_kv));
@@ -159,28 +171,32 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
     const int k = (local & one_chunk) | (local & 3 & ~one_chunk);
     const int ldw = (inner_o & m_out) | (CHID & m_ff2) | (CD & ~(m_out | m_ff2));
     const int rb = ((((j & 1) * CHID + (j >> 1) * WN) & m_ff1) | ((j * WN) & ~m_ff1));   // FF1: value chunk, then its gate chunk
-    i32x4 rs;
-    rs.x = __builtin_amdgcn_readfirstlane((rs_out.x & m_out) | (rs_w1.x & m_ff1) | (rs_w2.x & m_ff2) | (rs_q.x & m_q) | (rs_kv.x & m_kv));
-    rs.y = __builtin_amdgcn_readfirstlane((rs_out.y & m_out) | (rs_w1.y & m_ff1) | (rs_w2.y & m_ff2) | (rs_q.y & m_q) | (rs_kv.y & m_kv));
-    rs.z = __builtin_amdgcn_readfirstlane((rs_out.z & m_out) | (rs_w1.z & m_ff1) | (rs_w2.z & m_ff2) | (rs_q.z & m_q) | (rs_kv.z & m_kv));
-    rs.w = 0x00020000;
-    // this wave's B fragments of the block: weight row 16 wave + fi of the chunk, k = 16 s2 + 4 fg .. + 3 (component s of the
-    // 16 bytes feeds MFMA k-step s: the A fragments in LDS use the same permutation of the contraction index)
-    const int off = ((wave * 16 + fi) * ldw + 4 * fg) * 4;
-    const int soff = __builtin_amdgcn_readfirstlane((rb * ldw + k * WK) * 4);      // block part (scalar)
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      const f32x4 v = hn_buffer_load_x4(rs, off + s2 * 64, soff, 0);
-      r[s2] = make_float4(v.x, v.y, v.z, v.w);
-    }
+    const unsigned blo = (unsigned)((wo_lo & m_out) | (w1_lo & m_ff1) | (w2_lo & m_ff2) | (wq_lo & m_q) | (wk_lo & m_kv));
+    const unsigned bhi = (unsigned)((wo_hi & m_out) | (w1_hi & m_ff1) | (w2_hi & m_ff2) | (wq_hi & m_q) | (wk_hi & m_kv));
+    const unsigned long long base = (((unsigned long long)bhi << 32) | blo) + (unsigned long long)(((rb + wave * 16) * ldw + k * WK) * 4);
+    const void *sbase = (const void *)base;
+    const int voff = r8 * ldw * 4 + lane_k;
+    const unsigned dst = ring_byte + (unsigned)(wslot * WSLOT * 4);
+    glds16(sbase, voff, dst);                                    // rows 0..7 of the wave's 16
+    glds16(sbase, voff + 8 * ldw * 4, dst + 1024);               // rows 8..15
+    wslot = wslot + 1 == NB ? 0 : wslot + 1;
   };
 
-  // ---- far loads first: four weight blocks per wave, the x tile, the attention-output tile
-  float4 B0[2], B1[2], B2[2], B3[2];
-  issue(B0);
-  issue(B1);
-  issue(B2);
-  issue(B3);
+  // ---- far loads first: PD weight blocks per wave, then the small parameters, the x tile, the attention-output tile
+#pragma unroll
+  for (int i = 0; i < PD; ++i) issue();
+  if (tid < PRM / 4) {                      // 448 threads, one 16-byte piece each
+    const int q = tid;
+    const gf32 *src = nullptr;
+    if (q < 32) src = a_b_out ? a_b_out + 4 * q : nullptr;
+    else if (q < 288) src = a_b1 ? a_b1 + 4 * (q - 32) : nullptr;
+    else if (q < 320) src = a_b2 ? a_b2 + 4 * (q - 288) : nullptr;
+    else if (q < 352) src = a_f_nw ? a_f_nw + 4 * (q - 320) : nullptr;
+    else if (q < 384) src = a_f_nb ? a_f_nb + 4 * (q - 352) : nullptr;
+    else if (q < 416) src = a_p_nw ? a_p_nw + 4 * (q - 384) : nullptr;
+    else src = a_p_nb ? a_p_nb + 4 * (q - 416) : nullptr;
+    if (src) lst4(lds, prm + 4 * q, gld4(src));
+  }
   {
     const int row = tid >> 5, l32 = tid & 31;           // 32 lanes per row, one 16-byte chunk each
     float4 v0 = gld4(a_x_in + (long)(m0 + row) * CD + 4 * l32);
@@ -197,57 +213,58 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
       }
     }
   }
+  wait_vm<0>();                             // (the compiler's own waits on the loads above may count short: it cannot see the ring's)
   __syncthreads();
 
-  // ---- consumer state: A fragments of the even / odd block of a pair (slots s2 = 0 / 1)
-  float4 fa0[2], fa1[2];
+  // ---- consumer state: fragments of the even / odd block of a pair (slots s2 = 0 / 1): A from the shared tiles, B from the
+  // wave's ring (row fi of its 16, same XOR swizzle on both sides)
+  float4 fa0[2], fa1[2], fb0[2], fb1[2];
+  int rslot = 0;                            // ring slot of the block whose fragments are read next
   auto read_a = [&](float4 (&f)[2], int A, int kt) {
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) f[s2] = lld4(lds, A + kt * ATILE + fi * WK + (((4 * s2 + fg) ^ (fi & 7)) * 4));
   };
-
-  // One block: the A fragments of the next block, the 8 MFMAs of this one, then the register slot is re-used for the request
-  // of block t + 4.  Straight-line code, no barrier.
-  auto step = [&](float4 (&Bq)[2], const float4 (&fa)[2], float4 (&fan)[2], int A, int kt_next, f32x4 &c0, f32x4 &c1) {
-    read_a(fan, A, kt_next);
-#ifdef CHAIN_EXP_NOMFMA
-    c0.x += fa[0].x + Bq[0].x + fa[1].y + Bq[1].x;
-#else
-    // two accumulators (k-slots 0 and 1) so that consecutive MFMAs never depend on each other; they are summed in the epilogue
-    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0].x, Bq[0].x, c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1].x, Bq[1].x, c1, 0, 0, 0);
-    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0].y, Bq[0].y, c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1].y, Bq[1].y, c1, 0, 0, 0);
-    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0].z, Bq[0].z, c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1].z, Bq[1].z, c1, 0, 0, 0);
-    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0].w, Bq[0].w, c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1].w, Bq[1].w, c1, 0, 0, 0);
-#endif
-#ifndef CHAIN_EXP_NOLOAD
-    issue(Bq);
-#endif
+  auto read_b = [&](float4 (&f)[2]) {
+    const int B = Wr + (wave * NB + rslot) * WSLOT;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) f[s2] = lld4(lds, B + fi * WK + (((4 * s2 + fg) ^ (fi & 7)) * 4));
+    rslot = rslot + 1 == NB ? 0 : rslot + 1;
   };
-  // the k loop of one 128-column chunk, four blocks per iteration (nk is a multiple of 4): register slots and A fragment
-  // sets alternate, nothing is copied.  The A fragments requested by the last step (k-tile 0 again) serve the next chunk of
-  // the same stage.
+  read_b(fb0);                              // block 0 has landed (wait_vm<0> above)
+
+  // One block: wait until block t+1 has landed (blocks t+2 .. t+PD-1 may still be in flight: 2 loads each), fetch its
+  // fragments, issue the 8 MFMAs of block t, request block t+PD into the slot block t-1 occupied.  Straight-line, no barrier.
+  auto step = [&](const float4 (&fa)[2], const float4 (&fb)[2], float4 (&fan)[2], float4 (&fbn)[2], int A, int kt_next,
+                  f32x4 &c0, f32x4 &c1) {
+    wait_vm<2 * (PD - 2)>();
+    read_b(fbn);
+    read_a(fan, A, kt_next);
+    // two accumulators (k-slots 0 and 1) so that consecutive MFMAs never depend on each other; they are summed in the epilogue
+    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0].x, fb[0].x, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1].x, fb[1].x, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0].y, fb[0].y, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1].y, fb[1].y, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0].z, fb[0].z, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1].z, fb[1].z, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0].w, fb[0].w, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1].w, fb[1].w, c1, 0, 0, 0);
+    issue();
+  };
+  // the k loop of one 128-column chunk, two blocks per iteration (nk is even): the fragment sets alternate, nothing is copied.
+  // The A fragments requested by the last step (k-tile 0 again) serve the next chunk of the same stage.
   auto run_chunk = [&](int A, int nk, f32x4 &c0, f32x4 &c1) {
-#ifdef CHAIN_EXP_NOSTEP
-    nk = 0;
-#endif
-    for (int kc = 0; kc < nk; kc += 4) {
-      step(B0, fa0, fa1, A, kc + 1, c0, c1);
-      step(B1, fa1, fa0, A, kc + 2, c0, c1);
-      step(B2, fa0, fa1, A, kc + 3, c0, c1);
-      step(B3, fa1, fa0, A, kc + 4 == nk ? 0 : kc + 4, c0, c1);
+    for (int kc = 0; kc < nk; kc += 2) {
+      step(fa0, fb0, fa1, fb1, A, kc + 1, c0, c1);
+      step(fa1, fb1, fa0, fb0, A, kc + 2 == nk ? 0 : kc + 2, c0, c1);
     }
   };
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 
-  // LayerNorm of the x tile -> Ahat (A layout); gamma == NULL: the rows as they are
-  auto layer_norm = [&](const gf32 *gamma, const gf32 *beta) {
+  // LayerNorm of the x tile -> Ahat (A layout); no affine: the rows as they are
+  auto layer_norm = [&](bool affine, int gamma, int beta) {
     const int row = tid >> 5, l32 = tid & 31;
     float4 v = lld4(lds, xs + row * XP + 4 * l32);
-    if (gamma) {
+    if (affine) {
       float sm = (v.x + v.y) + (v.z + v.w);
       sm += __shfl_xor(sm, 1); sm += __shfl_xor(sm, 2); sm += __shfl_xor(sm, 4); sm += __shfl_xor(sm, 8); sm += __shfl_xor(sm, 16);
       const float mu = sm * (1.0f / CD);
@@ -255,7 +272,7 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
       float q = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
       q += __shfl_xor(q, 1); q += __shfl_xor(q, 2); q += __shfl_xor(q, 4); q += __shfl_xor(q, 8); q += __shfl_xor(q, 16);
       const float rs = 1.0f / sqrtf(q * (1.0f / CD) + 1e-5f);
-      const float4 g0 = gld4(gamma + 4 * l32), b0 = gld4(beta + 4 * l32);
+      const float4 g0 = lld4(lds, gamma + 4 * l32), b0 = lld4(lds, beta + 4 * l32);
       v.x = v.x * rs * g0.x + b0.x; v.y = v.y * rs * g0.y + b0.y; v.z = v.z * rs * g0.z + b0.z; v.w = v.w * rs * g0.w + b0.w;
     }
     lst4(lds, Ahat + (l32 >> 3) * ATILE + row * WK + (((l32 & 7) ^ (row & 7)) * 4), v);   // k = 4 l32: k-tile l32 >> 3, slot l32 & 7
@@ -268,7 +285,7 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
     f32x4 c0 = zero, c1 = zero;
     read_a(fa0, Abig, 0);
     run_chunk(Abig, nk_out, c0, c1);
-    const float bv = gld1(a_b_out + ncol);
+    const float bv = lds[p_bout + ncol];
     const float v[4] = {c0.x + c1.x, c0.y + c1.y, c0.z + c1.z, c0.w + c1.w};
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -281,7 +298,7 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
 
   // ================= stages FF1 / FF2: x += (a * gate(g)) W2^T + b2,  [a | g] = LN(x) W1^T + b1 =================
   if (a_has_ff) {
-    layer_norm(a_f_nw, a_f_nb);
+    layer_norm(a_f_nw != nullptr, p_fnw, p_fnb);
     __syncthreads();
     read_a(fa0, Ahat, 0);
     for (int hc = 0; hc < 4; ++hc) {
@@ -289,7 +306,7 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
       run_chunk(Ahat, CD / WK, a0, a1);
       run_chunk(Ahat, CD / WK, g0, g1);
       const int h0 = hc * WN + ncol;
-      const float ba = gld1(a_b1 + h0), bg = gld1(a_b1 + CHID + h0);
+      const float ba = lds[p_b1 + h0], bg = lds[p_b1 + CHID + h0];
       const float va[4] = {a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w};
       const float vg[4] = {g0.x + g1.x, g0.y + g1.y, g0.z + g1.z, g0.w + g1.w};
 #pragma unroll
@@ -305,7 +322,7 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
       f32x4 c0 = zero, c1 = zero;
       read_a(fa0, Abig, 0);
       run_chunk(Abig, CHID / WK, c0, c1);
-      const float bv = gld1(a_b2 + ncol);
+      const float bv = lds[p_b2 + ncol];
       const float v[4] = {c0.x + c1.x, c0.y + c1.y, c0.z + c1.z, c0.w + c1.w};
 #pragma unroll
       for (int r = 0; r < 4; ++r) lds[xs + (4 * fg + r) * XP + ncol] += v[r] + bv;
@@ -321,9 +338,10 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
 
   // ================= stages Q / KV: the next attention block's projections of LN'(x) =================
   if (nq_ch + nkv_ch > 0) {
-    layer_norm(a_p_nw, a_p_nb);
+    layer_norm(a_p_nw != nullptr, p_pnw, p_pnb);
     __syncthreads();
     read_a(fa0, Ahat, 0);
+    const int stg = Abig + wave * 256;       // this wave's 16 x 16 output tile (the hidden tile is dead by now)
     for (int pj = 0; pj < nq_ch + nkv_ch; ++pj) {
       const bool isq = pj < nq_ch;
       const int j = isq ? pj : pj - nq_ch;
@@ -333,16 +351,15 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
       const long ldc = isq ? a_ldq : a_ldkv;
       const float al = isq ? a_alpha_q : 1.0f;
       const float v[4] = {c0.x + c1.x, c0.y + c1.y, c0.z + c1.z, c0.w + c1.w};
+      // through LDS to ONE 16-byte store per lane (16 rows x 64 contiguous bytes per wave) instead of four 4-byte ones: a store
+      // counts against vmcnt like a load, so every outstanding store shortens the weight ring's lead
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-#ifndef CHAIN_EXP_NOSTORE
-        gst1(C + (long)(m0 + 4 * fg + r) * ldc + j * WN + ncol, al * v[r]);
-#else
-        if (al * v[r] == 1.2345f) gst1(C, 0.f);
-#endif
-      }
+      for (int r = 0; r < 4; ++r) lds[stg + (4 * fg + r) * 16 + fi] = al * v[r];
+      const int srow = lane >> 2, c4 = lane & 3;
+      gst4(C + (long)(m0 + srow) * ldc + j * WN + wave * 16 + 4 * c4, lld4(lds, stg + srow * 16 + 4 * c4));
     }
   }
+  wait_vm<0>();                             // direct-to-LDS loads must not outlive the workgroup's LDS allocation
 }
 
 bool latent_chain_supported(int rows, int d, int hidden) { return d == CD && hidden == CHID && rows > 0 && rows % CR == 0; }
@@ -367,7 +384,16 @@ int launch_latent_chain(const ChainArgs &a, hipStream_t s) {
   HN_REQUIRE(a.nkv == 0 || (a.wkv && a.KV && al16(a.wkv)), HN_E_NULL, "latent_chain: KV projection operand is NULL");
   HN_REQUIRE(al16(a.x_in) && (!a.x_out || al16(a.x_out)) && (!a.p_nw || (al16(a.p_nw) && al16(a.p_nb))), HN_E_SHAPE,
              "latent_chain: unaligned operand");
-  hipLaunchKernelGGL(latent_chain_kernel, dim3(a.rows / CR), dim3(512), 0, s, a);
+  // one-time opt-in per device to > 64 KB of dynamic LDS (a function attribute; setting it twice is harmless, so no lock)
+  static bool configured[64] = {};
+  const int lds_bytes = LDS_FLOATS * (int)sizeof(float);
+  int dev = 0;
+  HN_HIP_CHECK(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64 || !configured[dev]) {
+    HN_HIP_CHECK(hipFuncSetAttribute((const void *)latent_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    if (dev >= 0 && dev < 64) configured[dev] = true;
+  }
+  hipLaunchKernelGGL(latent_chain_kernel, dim3(a.rows / CR), dim3(512), lds_bytes, s, a);
   HN_LAUNCH_CHECK("latent_chain");
   return HN_OK;
 }
