@@ -191,28 +191,40 @@ int launch_head(const float *x, int b, int L, int d, const float *nw, const floa
 // ------------------------------------------------------------------------------------------------
 // dropout helpers (see DropCfg in common.h)
 // ------------------------------------------------------------------------------------------------
-// out[r, c] = (add ? add[r, c] : 0) + src[r, c] * keepscale(r, c)        (cols % 4 == 0)
+// out[r, c] = (add ? add[r, c] : 0) + src[r, c] * keepscale(r, c).  One thread per aligned column quad (the unit of one Philox
+// call); VEC: cols % 4 == 0, 16-byte accesses.  Otherwise (the reference's tuned widths: l_d = 119, 126, 62, 65) rows are not
+// 16-byte aligned and the last quad is partial: scalar accesses, same masks.
+template <bool VEC>
 __global__ __launch_bounds__(256) void dropout_apply_kernel(const float *__restrict__ src, const float *add, float *out, long rows,
                                                             int cols, DropCfg d) {
-  const int q4 = cols >> 2;
+  const int q4 = (cols + 3) >> 2;
   const long total = rows * q4;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long r = i / q4;
     const int q = (int)(i - r * q4);
     float m[4];
     drop_quad(d, (uint32_t)q, (uint32_t)r, m);
-    const float4 v = ((const float4 *)src)[i];
-    float4 o = make_float4(v.x * m[0], v.y * m[1], v.z * m[2], v.w * m[3]);
-    if (add) { const float4 a = ((const float4 *)add)[i]; o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w; }
-    ((float4 *)out)[i] = o;
+    if (VEC) {
+      const float4 v = ((const float4 *)src)[i];
+      float4 o = make_float4(v.x * m[0], v.y * m[1], v.z * m[2], v.w * m[3]);
+      if (add) { const float4 a = ((const float4 *)add)[i]; o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w; }
+      ((float4 *)out)[i] = o;
+    } else {
+      const long base = r * cols + 4 * q;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (4 * q + e < cols) out[base + e] = (add ? add[base + e] : 0.0f) + src[base + e] * m[e];
+    }
   }
 }
 
 int launch_dropout_apply(const float *src, const float *add, float *out, long rows, int cols, const DropCfg &d, hipStream_t s) {
-  HN_REQUIRE((cols & 3) == 0, HN_E_UNSUPPORTED, "dropout: the feature dimension (%d) must be a multiple of 4", cols);
-  long blocks = ceil_div_ll(rows * (cols >> 2), 256);
+  HN_REQUIRE(cols > 0 && rows > 0, HN_E_SHAPE, "dropout: rows=%ld cols=%d", rows, cols);
+  long blocks = ceil_div_ll(rows * ((cols + 3) >> 2), 256);
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(dropout_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, add, out, rows, cols, d);
+  const bool vec = (cols & 3) == 0 && (((uintptr_t)src | (uintptr_t)out | (uintptr_t)add) & 15) == 0;
+  if (vec) hipLaunchKernelGGL(dropout_apply_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, src, add, out, rows, cols, d);
+  else hipLaunchKernelGGL(dropout_apply_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, src, add, out, rows, cols, d);
   HN_LAUNCH_CHECK("dropout_apply");
   return HN_OK;
 }

@@ -72,6 +72,14 @@ CASES = [
     dict(kw=dict(n_modalities=1, channel_dims=[3], num_spatial_axes=[2], out_dims=2, depth=2, l_c=8, l_d=16, x_heads=2,
                  l_heads=2, cross_dim_head=8, latent_dim_head=8, attn_dropout=0.0, ff_dropout=0.3, self_per_cross_attn=0),
          shapes=[(10, 9, 3)]),
+    # the reference's tuned TCGA shape class (config/best_hyperparams.yml: odd latent width, ONE cross head of an odd dim, no
+    # latent self-attention, both dropouts): l_d = 30 is not a multiple of 4 -> the feed-forward mask's last column quad is partial
+    dict(kw=dict(n_modalities=2, channel_dims=[37, 21], num_spatial_axes=[1, 1], out_dims=4, depth=2, l_c=17, l_d=30, x_heads=1,
+                 l_heads=8, cross_dim_head=27, latent_dim_head=11, attn_dropout=0.3, ff_dropout=0.25, self_per_cross_attn=0),
+         shapes=[(1, 37), (50, 21)]),
+    dict(kw=dict(n_modalities=1, channel_dims=[21], num_spatial_axes=[1], out_dims=4, depth=1, l_c=16, l_d=65, x_heads=1,
+                 l_heads=8, cross_dim_head=103, latent_dim_head=51, attn_dropout=0.25, ff_dropout=0.06, self_per_cross_attn=0),
+         shapes=[(33, 21)]),
 ]
 
 

@@ -2,7 +2,17 @@
 import pytest
 import torch
 
-from conftest import rel_err
+from conftest import assert_close, rel_err
+from oracle import healnet_cpu as O
+
+KW = dict(n_modalities=2, channel_dims=[40, 3], num_spatial_axes=[1, 2], out_dims=4, depth=1, l_c=8, l_d=16, x_heads=2, l_heads=2,
+          cross_dim_head=8, latent_dim_head=8)
+
+
+def _oracle(model, kw, feats):
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        return O.fusion_forward(sd, O.FusionConfig(**kw), [f.float().cpu() for f in feats])
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -36,6 +46,7 @@ def test_device_loader_yields_the_reference_batch_structure_in_order(hn):
         assert len(got) == 5
         for y, (features, c, t, yd) in zip(got, batches):
             assert torch.equal(y, model([f.to(DEV) for f in features]))       # same data, same order, no torn copies
+            assert_close(y.cpu(), _oracle(model, KW, features), rel=2e-4, what="staged batch vs oracle")
 
 
 def test_bf16_transport_equals_host_side_rounding(hn):
@@ -49,6 +60,8 @@ def test_bf16_transport_equals_host_side_rounding(hn):
             assert c.dtype == torch.int64 and t.dtype == torch.float32       # labels / times untouched
             want = model([f.to(torch.bfloat16).float().to(DEV) for f in f0])
             assert torch.equal(model(features), want)
+            # ... and the oracle on the same bf16-rounded values (the reference would see exactly these after a host-side cast)
+            assert_close(want.cpu(), _oracle(model, KW, [f.to(torch.bfloat16) for f in f0]), rel=2e-4, what="bf16 transport vs oracle")
 
 
 def test_uint8_image_transport_is_totensor_exact(hn):
@@ -61,6 +74,8 @@ def test_uint8_image_transport_is_totensor_exact(hn):
     with torch.no_grad():
         want = model([tab, img8.float().div(255).to(DEV)])      # what ToTensor hands the reference
         assert torch.equal(model([tab, img8.to(DEV)]), want)
+        kw2 = dict(KW, depth=2)
+        assert_close(want.cpu(), _oracle(model, kw2, [tab, img8.float().div(255)]), rel=2e-4, what="uint8 transport vs oracle")
         low = hn.HealNet(n_modalities=2, channel_dims=[40, 3], num_spatial_axes=[1, 2], out_dims=4, depth=2, l_c=8, l_d=16,
                          x_heads=2, l_heads=2, cross_dim_head=8, latent_dim_head=8, core_precision="bf16").eval().to(DEV)
         low.load_state_dict(model.state_dict())
