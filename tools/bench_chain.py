@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Times hn.latent_block (chain -> self-attention core -> chain) and the cfg2 forward; HN_LIB_PATH selects a library variant."""
+"""Times hn.latent_block (chain -> self-attention core -> chain; host-bound when called in a loop) and the cfg2 forward.  HN_LIB_PATH
+selects another build of the library: this is how the variants in the header of healnet_amd/csrc/chain.hip were compared (e.g. a copy
+of chain.hip with the weight loads / the LDS stores / the MFMAs compiled out, linked against the other objects under healnet_amd/build/)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
