@@ -48,6 +48,24 @@ def random_case_medium(rng):
     return kw, shapes, b, False
 
 
+def random_case_chain(rng):
+    """Shapes the fused latent chain (chain.hip) accepts -- l_d = 128, l_c a multiple of 16, heads * dim_head a multiple of 128
+    with dim_head in {16, 32, 64, 128} -- mixed with ones it must leave to the per-block launches, over every head kind of a
+    chain (attention out-projection, one-token broadcast add) and projection kind (rank-D: Q only; explicit / self: scaled Q
+    (+ K|V); nothing in front of a one-token block), with key masks, GELU / SELU, missing modalities, no self block."""
+    small = random_case(rng)
+    kw, shapes, b, masked = small
+    inner = rng.choice([128, 256, 512])
+    dh = rng.choice([16, 32, 64, 128])
+    li = rng.choice([128, 256, 384, 512])
+    ldh = rng.choice([32, 64, 128])
+    kw.update(l_d=128, l_c=rng.choice([16, 32, 48, 128]), x_heads=max(1, inner // dh), cross_dim_head=dh,
+              l_heads=max(1, li // ldh), latent_dim_head=ldh)
+    if rng.random() < 0.2:      # not eligible: odd head dim -> the unfused route inside an otherwise eligible model
+        kw.update(cross_dim_head=24, x_heads=4)
+    return kw, shapes, min(b, 9), masked
+
+
 def random_case(rng):
     M = rng.choice([1, 2, 2, 3])
     chans, axes, shapes = [], [], []
@@ -96,7 +114,7 @@ def main(argv=None):
     ap.add_argument("--data-seed", type=int, default=0, help="offset of the input / weight seeds (same configurations, other numbers)")
     ap.add_argument("--dropout", action="store_true", help="training mode with random attention / feed-forward dropout; the oracle replays the build's exported Philox masks")
     ap.add_argument("--attn", action="store_true", help="also compare get_attention_weights() / get_attention_importance() of the inference forward (untied weights, nothing missing)")
-    ap.add_argument("--scale", default="small", choices=["small", "medium"])
+    ap.add_argument("--scale", default="small", choices=["small", "medium", "chain"])
     ap.add_argument("--core-precision", default="fp32", choices=["fp32", "bf16", "bf16x3"], help="attention core of the inference forward")
     ap.add_argument("--only", type=int, nargs="*", default=None, help="case indices to run (the others are generated and skipped)")
     args = ap.parse_args(argv)
@@ -104,7 +122,8 @@ def main(argv=None):
     worst = 0.0
     bad = 0
     for case in range(args.n):
-        kw, shapes, b, masked = random_case_medium(rng) if args.scale == "medium" else random_case(rng)
+        kw, shapes, b, masked = (random_case_medium(rng) if args.scale == "medium" else random_case_chain(rng) if args.scale == "chain"
+                                 else random_case(rng))
         if args.dropout:
             kw["attn_dropout"] = rng.choice([0.0, 0.1, 0.3])
             kw["ff_dropout"] = rng.choice([0.0, 0.2]) if kw["attn_dropout"] > 0 else 0.2
