@@ -876,7 +876,14 @@ static int plan_fusion(const hn_model *m, const hn_modality_input *in, int b, vo
     if (m->self_per_cross_attn > 0)
       for (int k = 0; k < m->depth; ++k) max_inner_self = max_inner_self > m->self_attn[k].heads * pad_head_dim(m->self_attn[k].dim_head) ? max_inner_self : m->self_attn[k].heads * pad_head_dim(m->self_attn[k].dim_head);
     if (max_inner_self > max_inner) max_inner = max_inner_self;
-    fp->chain = inference && latent_chain_supported(b * m->l_c, m->l_d, 4 * m->l_d) && m->l_c % 16 == 0;
+    // The chain pays when its b * l_c / 16 workgroups fill the chip in whole rounds: every workgroup streams ALL weights of the
+    // chain through its CU in ~47 us however few rows there are, while the 2-D tiled per-block GEMMs shrink with the row count.
+    // Measured at cfg2 (l_c = 128), chain vs per-block launches: b = 8 1.40 vs 1.22 ms, 16: 1.96 / 1.85, 24: 2.67 / 2.62,
+    // 28: 2.91 / 2.94, 32: 3.15 / 3.22, 40: 4.54 / 4.28, 48: 5.21 / 5.02, 64: 6.26 / 6.31, 128: 12.31 / 12.28.
+    const int chain_wgs = b * m->l_c / 16, chain_rem = chain_wgs % 256;
+    const bool chain_pays = chain_wgs >= 224 && (chain_rem == 0 || chain_rem >= 224);
+    fp->chain = inference && latent_chain_supported(b * m->l_c, m->l_d, 4 * m->l_d) && m->l_c % 16 == 0 &&
+                (chain_pays || getenv("HN_FORCE_CHAIN") != nullptr);
     fp->cq = fp->ckv = nullptr;
     if (fp->chain) {
       fp->cq = ar.take<float>((size_t)b * m->l_c * max_inner);
