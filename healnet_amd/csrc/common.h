@@ -125,8 +125,10 @@ enum { ACT_NONE = 0, ACT_LEAKY = 1, ACT_GLU_SELU = 2, ACT_GLU_GELU = 3 };
 // Dropout (nn.Dropout at healnet/models/healnet.py:381,421 on the attention probabilities and :347 on
 // the feed-forward output).  Counter-based: the keep decision of an element is a pure function of
 // (seed, offset, stream id of the block, row, column), so the forward core, both backward kernels and the mask export
-// used by the tests regenerate identical masks whatever their tiling.  Philox4x32-10; one call yields the four
-// decisions of an aligned column quad (row, 4 c .. 4 c + 3): keep iff word >= thr, P(keep) = 1 - p.
+// used by the tests regenerate identical masks whatever their tiling.  Philox4x32 with 7 rounds (the shortest variant that
+// passes BigCrush in Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11 -- 10 is the library default's safety
+// margin, and inside the attention core every round is paid per score quad); one call yields the four decisions of an aligned
+// column quad (row, 4 c .. 4 c + 3): keep iff word >= thr, P(keep) = 1 - p.
 // ------------------------------------------------------------------------------------------------
 struct DropCfg {
   uint32_t thr;        // p * 2^32; 0 = dropout disabled
@@ -144,10 +146,11 @@ static inline DropCfg make_drop(float p, uint64_t seed, uint32_t offset, uint32_
   }
   return d;
 }
-__device__ __forceinline__ void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                              uint32_t (&out)[4]) {
+constexpr int PHILOX_ROUNDS = 7;
+__device__ __forceinline__ void philox4x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                           uint32_t (&out)[4]) {
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < PHILOX_ROUNDS; ++r) {
     const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
     const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
     const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
@@ -159,16 +162,35 @@ __device__ __forceinline__ void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t
 // multipliers (scale or 0) of the aligned quad (row, 4 * quad .. 4 * quad + 3)
 __device__ __forceinline__ void drop_quad(const DropCfg &d, uint32_t quad, uint32_t row, float (&m)[4]) {
   uint32_t w[4];
-  philox4x32_10(d.seed_lo, d.seed_hi, quad, row, d.sid, d.offset, w);
+  philox4x32(d.seed_lo, d.seed_hi, quad, row, d.sid, d.offset, w);
 #pragma unroll
   for (int r = 0; r < 4; ++r) m[r] = w[r] >= d.thr ? d.scale : 0.0f;
 }
 __device__ __forceinline__ float drop_one(const DropCfg &d, uint32_t col, uint32_t row) {
   uint32_t w[4];
-  philox4x32_10(d.seed_lo, d.seed_hi, col >> 2, row, d.sid, d.offset, w);
+  philox4x32(d.seed_lo, d.seed_hi, col >> 2, row, d.sid, d.offset, w);
   const uint32_t c = col & 3;
   const uint32_t v = c == 0 ? w[0] : (c == 1 ? w[1] : (c == 2 ? w[2] : w[3]));
   return v >= d.thr ? d.scale : 0.0f;
+}
+// Four lanes that are adjacent in a wave (a DPP quad) and hold the SAME column quad of four different rows -- the layout of
+// attn_bwd_dkv_kernel: lane e of the quad has column 4 c + e of rows row0 .. row0 + 3 -- need 4 calls, not 16: lane e runs the
+// call of row row0 + e, then word e of every call is fetched from the lane that ran it (quad_perm broadcasts, one VALU move each).
+// m[r] = multiplier of (row0 + r, 4 quad + e).
+__device__ __forceinline__ void drop_quad_transposed(const DropCfg &d, uint32_t quad, uint32_t row0, uint32_t e, float (&m)[4]) {
+  uint32_t w[4];
+  philox4x32(d.seed_lo, d.seed_hi, quad, row0 + e, d.sid, d.offset, w);
+#define HN_QUAD_BCAST(v, r) (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (r) * 0x55, 0xf, 0xf, true)
+#define HN_QUAD_WORD(r)                                                                                          \
+  {                                                                                                              \
+    const uint32_t t0_ = HN_QUAD_BCAST(w[0], r), t1_ = HN_QUAD_BCAST(w[1], r), t2_ = HN_QUAD_BCAST(w[2], r),     \
+                   t3_ = HN_QUAD_BCAST(w[3], r);                                                                 \
+    const uint32_t v_ = e == 0 ? t0_ : (e == 1 ? t1_ : (e == 2 ? t2_ : t3_));                                    \
+    m[r] = v_ >= d.thr ? d.scale : 0.0f;                                                                         \
+  }
+  HN_QUAD_WORD(0) HN_QUAD_WORD(1) HN_QUAD_WORD(2) HN_QUAD_WORD(3)
+#undef HN_QUAD_WORD
+#undef HN_QUAD_BCAST
 }
 constexpr uint32_t DROP_SID_FF = 0x80000000u;      // stream ids of feed-forward blocks carry this bit
 

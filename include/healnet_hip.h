@@ -87,7 +87,7 @@ int hn_context_pitch(int D, int dim_head);
  *                                                      Attention.forward :400-426 (+ residual :236/:244)
  * ------------------------------------------------------------------------------------------- */
 /* Counter-based dropout: whether element (row, col) of a block's mask is kept is a pure function of
- * (seed, offset, stream, row, col) -- Philox4x32-10, one call per aligned column quad, keep iff word >= p * 2^32,
+ * (seed, offset, stream, row, col) -- Philox4x32 with 7 rounds, one call per aligned column quad, keep iff word >= p * 2^32,
  * kept values scaled by 1 / (1 - p).  `seed` is the generator seed, `offset` a per-forward counter (a fresh mask every
  * iteration; the backward is called with the forward's value), `stream` tells the blocks of a model apart: the fused
  * entry points use hn_model.rng and set stream = index of the block in execution order (feed-forward blocks have
