@@ -9,21 +9,28 @@
 // Every step is local to a latent row, so a workgroup owns 16 rows (b * l_c / 16 workgroups: 256 at cfg2 b = 32, one per CU)
 // and walks the whole chain with its rows in LDS: the x tile, its LayerNorm-ed image, the 16 x 512 feed-forward hidden tile.
 // What streams is the WEIGHTS.  Eight waves split each 128-column chunk of a GEMM (16 columns = 16 weight rows per wave), and
-// every wave moves ITS 16 rows x 32 k of each block with two global_load_lds_dwordx4 (full 128-byte lines, 1 KB per
-// instruction, no VGPRs, no ds_write) into a private six-slot LDS ring that runs five blocks ahead across chunk and stage
-// boundaries (one flat block order for the whole chain), and reads its MFMA B fragments back with ds_read_b128.  A wave only
-// ever reads what it loaded itself, so there is NO barrier inside a GEMM -- a counted s_waitcnt vmcnt (inline asm: the loads
-// are invisible to the compiler, which would otherwise drain the whole ring at every use) is all the synchronisation the
-// weight stream needs; waves meet only where a stage hands its tile to the next.
-//   History (tools/bench_chain.py, cfg2 b = 32, 12 chains per forward):
-//   v1  weights staged global -> VGPR -> one shared LDS ring, barrier per block, 4 or 8 waves: 52.6 us per chain.  A block
-//       took 2.1x its MFMA time; removing the ds_writes alone saved 36 % of it (16 KB per 512 MFMA cycles through the
-//       ~75 B/clk ds_write path), removing the global loads almost nothing.
-//   v2  B fragments straight from global memory into a register ring (16 rows x 64 B per load, the attention core's
-//       pattern), no LDS, no barrier: 49 us.  Now the loads were the cost (0.46 us per block against 0.22 us of MFMAs;
-//       15 B/clk/CU at a 92 % L2 hit rate, 20 % more L2 requests than bytes needed: half-line requests).  Neither an L2
-//       warm-up pass nor rotating the chunk order between the workgroups of an XCD changed it.
-//   v3  this version: full-line direct-to-LDS loads.
+// every wave moves ITS 16 rows x 32 k of each block: two 16-byte buffer loads per lane in FULL 128-byte lines (8 lanes per row)
+// into a four-deep register ring that runs across chunk and stage boundaries (one flat block order for the whole chain), then
+// two ds_write_b128 into the wave's private 2 KB LDS slot (XOR-swizzled), from where the MFMA B fragments are read back with
+// ds_read_b128.  A wave only ever reads what it wrote itself, so there is NO barrier inside a GEMM; waves meet only where a
+// stage hands its tile to the next.
+//   History (tools/bench_chain.py and tools/ubench/l2_fill.hip; cfg2 b = 32, 12 chains per forward):
+//   v1  weights staged global -> VGPR -> one SHARED 3-buffer LDS ring, barrier per block, 4 or 8 waves: 52.6 us per chain.  A
+//       block took 2.1x its MFMA time; removing the ds_writes alone saved 36 % of it, removing the global loads almost nothing.
+//   v2  B fragments straight from global memory into a register ring in the MFMA operand layout (16 rows x 64 B per load, the
+//       attention core's pattern), no LDS, no barrier: 49 us.  With the loads removed a block costs 0.216 us (= 8 MFMAs per wave
+//       on two waves per SIMD: the matrix work is AT its bound), with them 0.46 us: 38 GB/s per CU.
+//   v3  per-wave LDS rings filled by global_load_lds_dwordx4 (full lines, counted vmcnt from inline asm): 49 us again.
+//   The micro-benchmark then separated pattern from path -- all 256 CUs streaming the same L2-resident 2 MB: 117-124 GB/s per
+//   CU with full-line loads into registers, 81 GB/s through global_load_lds, and exactly the chain's 38 GB/s with the 16 x 64 B
+//   fragment pattern (K = 128 or 512 alike; neither an L2 warm-up pass nor rotating the chunk order had changed anything).
+//   v4  this version: full-line register loads + a private LDS transpose per wave: 47 us -- and the loads were still not the
+//       limit: with every address replaced by a constant the forward dropped by 0.19 ms.  What each wave paid per block was the
+//       SCALAR work of finding it (stage -> weight pointer / leading dimension / chunk / k offset: ~45 SALU instructions and a
+//       handful of v_readfirstlane on the critical path of the issue).  The block order of a chain is known at kernel start, so
+//       512 threads now write it ONCE as a table in LDS (64-bit byte address of the block's first row, ldw/128 - 1 in the two
+//       low bits) and a wave fetches the entry of the NEXT block with one broadcast ds_read_b64 a step ahead: 40 us per chain,
+//       forward 3.224 -> 3.036 ms at cfg2 b = 32.  (An L2 warm-up pass was re-tried on top of this: no change.)
 //
 // Shapes: l_d = 128, hidden 512, K a multiple of 128, N a multiple of 128, rows % 16 == 0.
 #include "common.h"
@@ -39,10 +46,10 @@ constexpr int WN = 128, WK = 32;        // weight block: 128 output columns x 32
 constexpr int WBLK = WN * WK;           // floats per block (16 KB)
 constexpr int ATILE = CR * WK;          // floats per A k-tile (16 rows x 32 k, 16-byte slots XOR-swizzled by row & 7)
 constexpr int XP = 132;                 // pitch of the x tile
-constexpr int NB = 6, PD = 5;           // slots of a wave's weight ring / how many blocks the loads run ahead (NB = PD + 1)
 constexpr int WSLOT = 16 * WK;          // floats per wave and block: 16 weight rows x 32 k (2 KB = two wave-wide 16-byte loads)
 constexpr int PRM = 128 + 2 * CHID + 128 + 4 * 128;      // b_out | b1 | b2 | ff gamma, beta | projection gamma, beta
-constexpr int LDS_FLOATS = 8 * NB * WSLOT + 16 * ATILE + 4 * ATILE + CR * XP + PRM;       // 151.25 KB
+constexpr int MAXBLK = 128;             // blocks of a chain: <= 16 (out) + 32 + 16 (ff) + 16 (q) + 32 (kv) = 112
+constexpr int LDS_FLOATS = 8 * WSLOT + 16 * ATILE + 4 * ATILE + CR * XP + PRM + 2 * MAXBLK;       // 72.25 KB
 enum { CS_OUT = 0, CS_FF1 = 1, CS_FF2 = 2, CS_Q = 3, CS_KV = 4, CS_END = 5 };
 
 // Pointers that arrive inside the argument struct are generic: hipcc emits flat_load / flat_store for them, and with flat
@@ -72,16 +79,6 @@ __device__ __forceinline__ void lst4(lf32 *base, int off, const float4 &v) {
   f32x4 t = {v.x, v.y, v.z, v.w};
   *(lf32x4 *)(base + off) = t;
 }
-
-// One wave-wide direct-to-LDS load: lane l fetches 16 bytes at sbase + voff and they land at LDS byte address m0v + 16 l.
-// Issued from inline asm on purpose: the compiler does not see a memory operation, so it inserts no wait of its own; every
-// wait on these loads is a counted vmcnt below.
-__device__ __forceinline__ void glds16(const void *sbase, int voff, unsigned m0v) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(voff), "s"(m0v), "s"(sbase) : "memory");
-}
-template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
 __device__ __forceinline__ float selu_f(float x) {
   const float alpha = 1.6732632423543772848170429916717f, scale = 1.0507009873554804934193349852946f;
@@ -121,12 +118,13 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
   const float a_alpha_q = args.alpha_q;
   extern __shared__ __attribute__((aligned(16))) float lds_raw[];
   lf32 *lds = (lf32 *)lds_raw;              // float offsets into the one LDS allocation:
-  constexpr int Wr = 0;                     // [8 waves][NB][WSLOT]  per-wave weight rings
-  constexpr int Abig = Wr + 8 * NB * WSLOT; // [16][ATILE]  attention output tile (A of the out-projection), then the FF hidden tile,
+  constexpr int Wr = 0;                     // [8 waves][WSLOT]  per-wave transpose slot of the weight stream
+  constexpr int Abig = Wr + 8 * WSLOT;      // [16][ATILE]  attention output tile (A of the out-projection), then the FF hidden tile,
                                             //              then (projections) the per-wave output staging tiles
   constexpr int Ahat = Abig + 16 * ATILE;   // [4][ATILE]   LayerNorm-ed x (A of FF1 / of the projections)
   constexpr int xs = Ahat + 4 * ATILE;      // [CR][XP]     the x tile
-  constexpr int prm = xs + CR * XP;         // small parameters: no global load may sit between the steps (see wait_vm)
+  constexpr int prm = xs + CR * XP;         // small parameters (no global load sits between the steps: the weight ring owns the memory queue)
+  constexpr int tbl = prm + PRM;            // [MAXBLK] byte address of every block of the chain (64 bit; bits 0-1: row length / 128 - 1)
   constexpr int p_bout = prm, p_b1 = p_bout + 128, p_b2 = p_b1 + 2 * CHID, p_fnw = p_b2 + 128, p_fnb = p_fnw + 128,
                 p_pnw = p_fnb + 128, p_pnb = p_pnw + 128;
 
@@ -144,47 +142,58 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
   const int e2 = e1 + (a_has_ff ? CHID / WK : 0);                //                Q
   const int e3 = e2 + nq_ch * (CD / WK);                         //                KV
   const int nblocks = e3 + nkv_ch * (CD / WK);
-  // the five weight base addresses as pinned scalars (readfirstlane keeps the compiler from turning the per-block select
-  // into a lookup table in scratch)
-  auto lo32 = [](const void *p) { return __builtin_amdgcn_readfirstlane((int)((unsigned long long)p & 0xffffffffu)); };
-  auto hi32 = [](const void *p) { return __builtin_amdgcn_readfirstlane((int)((unsigned long long)p >> 32)); };
-  const int wo_lo = lo32(args.w_out), wo_hi = hi32(args.w_out), w1_lo = lo32(args.w1), w1_hi = hi32(args.w1);
-  const int w2_lo = lo32(args.w2), w2_hi = hi32(args.w2), wq_lo = lo32(args.wq), wq_hi = hi32(args.wq);
-  const int wk_lo = lo32(args.wkv), wk_hi = hi32(args.wkv);
-  const int inner_o = __builtin_amdgcn_readfirstlane(a_inner_o);
-  const unsigned ring_byte = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds + (unsigned)((Wr + wave * NB * WSLOT) * 4));
-  const int r8 = lane >> 3, pos = lane & 7;                      // loader lane: row r8 (and r8 + 8) of the wave's 16, 16-byte position
-  const int lane_k = ((pos ^ (r8 & 7)) * 4) * 4;                 // ... which holds chunk pos ^ (row & 7) of the 128-byte row
+  // ---- the address of every block, once: thread bi works out (stage, chunk, k-chunk) of block bi and leaves the byte address of
+  // its first row in an LDS table.  Doing this arithmetic in the loader -- ~45 scalar instructions and four readfirstlanes per
+  // block and wave -- was what kept the weight stream from overlapping with the MFMAs (0.42 us per block against 0.24 without
+  // loads; 0.25 with a constant-stride dummy address): a table entry costs one broadcast ds_read_b64, fetched a step ahead.
+  if (tid < MAXBLK) {
+    const int bi = min(tid, nblocks - 1);
+    const int s_out = bi < e0, s_ff1 = bi >= e0 && bi < e1, s_ff2 = bi >= e1 && bi < e2, s_q = bi >= e2 && bi < e3;
+    const int local = bi - (s_out ? 0 : s_ff1 ? e0 : s_ff2 ? e1 : s_q ? e2 : e3);
+    const bool one_chunk = s_out || s_ff2;                       // stages with a single 128-column chunk: k = local
+    const int j = one_chunk ? 0 : local >> 2, k = one_chunk ? local : local & 3;
+    const int ldw = s_out ? a_inner_o : s_ff2 ? CHID : CD;
+    const int rb = s_ff1 ? (j & 1) * CHID + (j >> 1) * WN : j * WN;               // FF1: value chunk, then its gate chunk
+    const float *W = s_out ? args.w_out : s_ff1 ? args.w1 : s_ff2 ? args.w2 : s_q ? args.wq : args.wkv;
+    const unsigned long long addr = (unsigned long long)(W + (long)rb * ldw + k * WK) | (unsigned long long)(ldw / CD - 1);
+    *(__attribute__((address_space(3))) unsigned long long *)(lds + tbl + 2 * tid) = addr;
+  }
+  const int r8 = lane >> 3, pos = lane & 7;                      // loader lane: row r8 (and r8 + 8) of the wave's 16, 16-byte piece pos
+  const int wslot = Wr + wave * WSLOT + r8 * WK + ((pos ^ (r8 & 7)) * 4);   // ... parked at slot pos ^ (row & 7) of its LDS row
+  const int row512 = (wave * 16 + r8) * (CD * 4), pos16 = pos * 16;      // byte offset of the lane's row at K = 128, of its piece
   int lb = 0;                               // next block to request
-  int wslot = 0;                            // ... and the ring slot it goes to
+  unsigned long long ent = 0;               // its table entry (fetched a step ahead)
+  auto fetch_entry = [&]() { ent = *(const __attribute__((address_space(3))) unsigned long long *)(lds + tbl + 2 * min(lb, MAXBLK - 1)); };
 
-  auto issue = [&]() {                      // this wave's 2 KB of block lb (past the end: the last block again, never consumed)
-    const int bi = min(lb, nblocks - 1);
+  // this wave's 2 KB of block lb (past the end: the last block again, never consumed): rows 16 wave + r8 and + 8 of the chunk
+  // as FULL 128-byte lines (8 lanes per row) -- 16 rows x 64 B per load, the MFMA fragment layout, runs at a third of the rate
+  // (tools/ubench/l2_fill.hip: 38 against 117 GB/s per CU when all CUs stream the same L2-resident weights)
+  auto issue = [&](float4 (&r)[2]) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)ent), hi = __builtin_amdgcn_readfirstlane((unsigned)(ent >> 32));
+    const int kq = (int)(lo & 3u) + 1;                           // row length in units of 128 floats
+    const __attribute__((address_space(1))) char *base = (const __attribute__((address_space(1))) char *)(((unsigned long long)hi << 32) | (lo & ~3u));
+    const gf32 *p0 = (const gf32 *)(base + (row512 * kq + pos16));
+    r[0] = gld4(p0);
+    r[1] = gld4(p0 + 8 * CD * kq);
     ++lb;
-    // stage of the block as 0 / -1 masks, everything selected with AND / OR (a chain of ?: keyed by the stage is lowered to
-    // lookup tables in scratch)
-    const int m_out = -(int)(bi < e0), m_ff1 = -(int)(bi >= e0 && bi < e1), m_ff2 = -(int)(bi >= e1 && bi < e2);
-    const int m_q = -(int)(bi >= e2 && bi < e3), m_kv = -(int)(bi >= e3);
-    const int local = bi - ((e0 & m_ff1) | (e1 & m_ff2) | (e2 & m_q) | (e3 & m_kv));
-    const int one_chunk = m_out | m_ff2;                         // stages with a single 128-column chunk: k = local
-    const int j = (local >> 2) & ~one_chunk;                     // chunk within the stage (4 k-chunks per chunk at K = 128)
-    const int k = (local & one_chunk) | (local & 3 & ~one_chunk);
-    const int ldw = (inner_o & m_out) | (CHID & m_ff2) | (CD & ~(m_out | m_ff2));
-    const int rb = ((((j & 1) * CHID + (j >> 1) * WN) & m_ff1) | ((j * WN) & ~m_ff1));   // FF1: value chunk, then its gate chunk
-    const unsigned blo = (unsigned)((wo_lo & m_out) | (w1_lo & m_ff1) | (w2_lo & m_ff2) | (wq_lo & m_q) | (wk_lo & m_kv));
-    const unsigned bhi = (unsigned)((wo_hi & m_out) | (w1_hi & m_ff1) | (w2_hi & m_ff2) | (wq_hi & m_q) | (wk_hi & m_kv));
-    const unsigned long long base = (((unsigned long long)bhi << 32) | blo) + (unsigned long long)(((rb + wave * 16) * ldw + k * WK) * 4);
-    const void *sbase = (const void *)base;
-    const int voff = r8 * ldw * 4 + lane_k;
-    const unsigned dst = ring_byte + (unsigned)(wslot * WSLOT * 4);
-    glds16(sbase, voff, dst);                                    // rows 0..7 of the wave's 16
-    glds16(sbase, voff + 8 * ldw * 4, dst + 1024);               // rows 8..15
-    wslot = wslot + 1 == NB ? 0 : wslot + 1;
+    fetch_entry();
+  };
+  // ... and into the wave's LDS slot, from where the MFMA fragments are read back (a wave only reads what it wrote: no barrier)
+  auto park = [&](const float4 (&r)[2]) {
+    lst4(lds, wslot, r[0]);
+    lst4(lds, wslot + 8 * WK, r[1]);
   };
 
-  // ---- far loads first: PD weight blocks per wave, then the small parameters, the x tile, the attention-output tile
-#pragma unroll
-  for (int i = 0; i < PD; ++i) issue();
+  // ---- far loads first: five weight blocks per wave (block 0, then the 4-deep register ring: blocks 1..4), then the small
+  // parameters, the x tile, the attention-output tile
+  __syncthreads();                           // the block table
+  fetch_entry();
+  float4 Bp[2], B0[2], B1[2], B2[2], B3[2];
+  issue(Bp);
+  issue(B0);
+  issue(B1);
+  issue(B2);
+  issue(B3);
   if (tid < PRM / 4) {                      // 448 threads, one 16-byte piece each
     const int q = tid;
     const gf32 *src = nullptr;
@@ -213,30 +222,29 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
       }
     }
   }
-  wait_vm<0>();                             // (the compiler's own waits on the loads above may count short: it cannot see the ring's)
+  park(Bp);                                 // block 0
   __syncthreads();
 
   // ---- consumer state: fragments of the even / odd block of a pair (slots s2 = 0 / 1): A from the shared tiles, B from the
-  // wave's ring (row fi of its 16, same XOR swizzle on both sides)
+  // wave's slot (row fi of its 16, same XOR swizzle on both sides)
   float4 fa0[2], fa1[2], fb0[2], fb1[2];
-  int rslot = 0;                            // ring slot of the block whose fragments are read next
   auto read_a = [&](float4 (&f)[2], int A, int kt) {
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) f[s2] = lld4(lds, A + kt * ATILE + fi * WK + (((4 * s2 + fg) ^ (fi & 7)) * 4));
   };
   auto read_b = [&](float4 (&f)[2]) {
-    const int B = Wr + (wave * NB + rslot) * WSLOT;
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) f[s2] = lld4(lds, B + fi * WK + (((4 * s2 + fg) ^ (fi & 7)) * 4));
-    rslot = rslot + 1 == NB ? 0 : rslot + 1;
+    for (int s2 = 0; s2 < 2; ++s2) f[s2] = lld4(lds, Wr + wave * WSLOT + fi * WK + (((4 * s2 + fg) ^ (fi & 7)) * 4));
   };
-  read_b(fb0);                              // block 0 has landed (wait_vm<0> above)
+  read_b(fb0);                              // block 0
 
-  // One block: wait until block t+1 has landed (blocks t+2 .. t+PD-1 may still be in flight: 2 loads each), fetch its
-  // fragments, issue the 8 MFMAs of block t, request block t+PD into the slot block t-1 occupied.  Straight-line, no barrier.
-  auto step = [&](const float4 (&fa)[2], const float4 (&fb)[2], float4 (&fan)[2], float4 (&fbn)[2], int A, int kt_next,
+  // One block.  `Bq` holds block t+1 (requested four steps ago): park it in the wave's LDS slot (the fragments of block t
+  // left it a step ago), re-use the registers for the request of block t+5, read the fragments of block t+1 back, and issue
+  // the 8 MFMAs of block t.  Straight-line code, no barrier; the compiler counts vmcnt (6 younger loads stay in flight).
+  auto step = [&](float4 (&Bq)[2], const float4 (&fa)[2], const float4 (&fb)[2], float4 (&fan)[2], float4 (&fbn)[2], int A, int kt_next,
                   f32x4 &c0, f32x4 &c1) {
-    wait_vm<2 * (PD - 2)>();
+    park(Bq);
+    issue(Bq);
     read_b(fbn);
     read_a(fan, A, kt_next);
     // two accumulators (k-slots 0 and 1) so that consecutive MFMAs never depend on each other; they are summed in the epilogue
@@ -248,14 +256,16 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
     c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1].z, fb[1].z, c1, 0, 0, 0);
     c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0].w, fb[0].w, c0, 0, 0, 0);
     c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1].w, fb[1].w, c1, 0, 0, 0);
-    issue();
   };
-  // the k loop of one 128-column chunk, two blocks per iteration (nk is even): the fragment sets alternate, nothing is copied.
-  // The A fragments requested by the last step (k-tile 0 again) serve the next chunk of the same stage.
+  // the k loop of one 128-column chunk, four blocks per iteration (nk is a multiple of 4): the register slots and the fragment
+  // sets alternate, nothing is copied.  The A fragments requested by the last step (k-tile 0 again) serve the next chunk of
+  // the same stage.
   auto run_chunk = [&](int A, int nk, f32x4 &c0, f32x4 &c1) {
-    for (int kc = 0; kc < nk; kc += 2) {
-      step(fa0, fb0, fa1, fb1, A, kc + 1, c0, c1);
-      step(fa1, fb1, fa0, fb0, A, kc + 2 == nk ? 0 : kc + 2, c0, c1);
+    for (int kc = 0; kc < nk; kc += 4) {
+      step(B0, fa0, fb0, fa1, fb1, A, kc + 1, c0, c1);
+      step(B1, fa1, fb1, fa0, fb0, A, kc + 2, c0, c1);
+      step(B2, fa0, fb0, fa1, fb1, A, kc + 3, c0, c1);
+      step(B3, fa1, fb1, fa0, fb0, A, kc + 4 == nk ? 0 : kc + 4, c0, c1);
     }
   };
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -359,7 +369,6 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
       gst4(C + (long)(m0 + srow) * ldc + j * WN + wave * 16 + 4 * c4, lld4(lds, stg + srow * 16 + 4 * c4));
     }
   }
-  wait_vm<0>();                             // direct-to-LDS loads must not outlive the workgroup's LDS allocation
 }
 
 bool latent_chain_supported(int rows, int d, int hidden) { return d == CD && hidden == CHID && rows > 0 && rows % CR == 0; }
