@@ -876,12 +876,12 @@ static int plan_fusion(const hn_model *m, const hn_modality_input *in, int b, vo
     if (m->self_per_cross_attn > 0)
       for (int k = 0; k < m->depth; ++k) max_inner_self = max_inner_self > m->self_attn[k].heads * pad_head_dim(m->self_attn[k].dim_head) ? max_inner_self : m->self_attn[k].heads * pad_head_dim(m->self_attn[k].dim_head);
     if (max_inner_self > max_inner) max_inner = max_inner_self;
-    // The chain pays when its b * l_c / 16 workgroups fill the chip in whole rounds: every workgroup streams ALL weights of the
-    // chain through its CU in ~47 us however few rows there are, while the 2-D tiled per-block GEMMs shrink with the row count.
-    // Measured at cfg2 (l_c = 128), chain vs per-block launches: b = 8 1.40 vs 1.22 ms, 16: 1.96 / 1.85, 24: 2.67 / 2.62,
-    // 28: 2.91 / 2.94, 32: 3.15 / 3.22, 40: 4.54 / 4.28, 48: 5.21 / 5.02, 64: 6.26 / 6.31, 128: 12.31 / 12.28.
-    const int chain_wgs = b * m->l_c / 16, chain_rem = chain_wgs % 256;
-    const bool chain_pays = chain_wgs >= 224 && (chain_rem == 0 || chain_rem >= 224);
+    // Every workgroup of the chain streams ALL weights of the chain through its CU in ~40 us however few rows there are, while
+    // the 2-D tiled per-block GEMMs shrink with the row count: the chain pays from ~160 workgroups (of 256 CUs) on.
+    // Measured at cfg2 (l_c = 128), chain vs per-block launches (ms per forward, profiles/r02_e_chain_sweep.txt): b = 8 1.30 vs
+    // 1.21, 16: 1.86 / 1.84, 20: 2.27 / 2.30, 24: 2.57 / 2.62, 32: 3.06 / 3.23, 36: 3.71 / 3.82, 40: 4.14 / 4.27,
+    // 48: 4.79 / 5.00, 64: 5.86 / 6.32, 96: 10.88 / 11.46, 128: 11.52 / 12.24 -- partial rounds no longer lose.
+    const bool chain_pays = b * m->l_c / 16 >= 160;
     fp->chain = inference && latent_chain_supported(b * m->l_c, m->l_d, 4 * m->l_d) && m->l_c % 16 == 0 &&
                 (chain_pays || getenv("HN_FORCE_CHAIN") != nullptr);
     fp->cq = fp->ckv = nullptr;
