@@ -86,6 +86,20 @@ __device__ __forceinline__ float selu_f(float x) {
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
+#ifdef CHAIN_PROFILE
+// development only (tools/chain_profile.py builds a private library with -DCHAIN_PROFILE): cycle stamps of one workgroup at the
+// stage boundaries of the last 16 launches
+__device__ unsigned long long g_chain_prof[16 * 16];
+__device__ int g_chain_seq;
+#define CHAIN_PROF(i)                                                                                          \
+  do {                                                                                                         \
+    if (blockIdx.x == 100 % gridDim.x && threadIdx.x == 0)                                                     \
+      g_chain_prof[(g_chain_seq & 15) * 16 + (i)] = (i) >= 14 ? __builtin_amdgcn_s_memrealtime() : __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define CHAIN_PROF(i)
+#endif
+
 }  // namespace
 
 __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args) {
@@ -116,6 +130,8 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
   const int a_ldq = args.ldq;
   const int a_ldkv = args.ldkv;
   const float a_alpha_q = args.alpha_q;
+  CHAIN_PROF(14);
+  CHAIN_PROF(0);
   extern __shared__ __attribute__((aligned(16))) float lds_raw[];
   lf32 *lds = (lf32 *)lds_raw;              // float offsets into the one LDS allocation:
   constexpr int Wr = 0;                     // [8 waves][WSLOT]  per-wave transpose slot of the weight stream
@@ -187,6 +203,7 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
   // ---- far loads first: five weight blocks per wave (block 0, then the 4-deep register ring: blocks 1..4), then the small
   // parameters, the x tile, the attention-output tile
   __syncthreads();                           // the block table
+  CHAIN_PROF(1);
   fetch_entry();
   float4 Bp[2], B0[2], B1[2], B2[2], B3[2];
   issue(Bp);
@@ -224,6 +241,7 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
   }
   park(Bp);                                 // block 0
   __syncthreads();
+  CHAIN_PROF(2);
 
   // ---- consumer state: fragments of the even / odd block of a pair (slots s2 = 0 / 1): A from the shared tiles, B from the
   // wave's slot (row fi of its 16, same XOR swizzle on both sides)
@@ -243,19 +261,34 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
   // the 8 MFMAs of block t.  Straight-line code, no barrier; the compiler counts vmcnt (6 younger loads stay in flight).
   auto step = [&](float4 (&Bq)[2], const float4 (&fa)[2], const float4 (&fb)[2], float4 (&fan)[2], float4 (&fbn)[2], int A, int kt_next,
                   f32x4 &c0, f32x4 &c1) {
-    park(Bq);
-    issue(Bq);
-    read_b(fbn);
-    read_a(fan, A, kt_next);
-    // two accumulators (k-slots 0 and 1) so that consecutive MFMAs never depend on each other; they are summed in the epilogue
-    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0].x, fb[0].x, c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1].x, fb[1].x, c1, 0, 0, 0);
-    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0].y, fb[0].y, c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1].y, fb[1].y, c1, 0, 0, 0);
-    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0].z, fb[0].z, c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1].z, fb[1].z, c1, 0, 0, 0);
-    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0].w, fb[0].w, c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1].w, fb[1].w, c1, 0, 0, 0);
+    // The order below is pinned slot by slot (sched_barrier(0): nothing crosses).  A wave issues in order and there are only two
+    // waves per SIMD, so every memory instruction sits BEHIND an MFMA of the same wave that keeps the matrix pipe busy (32 cycles)
+    // while the memory instruction waits for its queue; left to itself the scheduler puts the two ds_writes, the address
+    // arithmetic and the two global loads in front of the first MFMA of a step (~200 idle cycles per block), and in the unrolled
+    // feed-forward stages it even sank every global load to just in front of its ds_write (s_waitcnt vmcnt(0) per block).
+    // Two accumulators (k-slots 0 and 1) so that consecutive MFMAs never depend on each other; they are summed in the epilogue.
+#define CH_SB __builtin_amdgcn_sched_barrier(0)
+    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0].x, fb[0].x, c0, 0, 0, 0); CH_SB;
+    lst4(lds, wslot, Bq[0]); CH_SB;                                        // park block t+1, first half
+    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1].x, fb[1].x, c1, 0, 0, 0); CH_SB;
+    lst4(lds, wslot + 8 * WK, Bq[1]); CH_SB;                               //                 second half
+    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0].y, fb[0].y, c0, 0, 0, 0); CH_SB;
+    read_b(fbn); CH_SB;                                                    // its fragments back
+    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1].y, fb[1].y, c1, 0, 0, 0); CH_SB;
+    read_a(fan, A, kt_next); CH_SB;
+    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0].z, fb[0].z, c0, 0, 0, 0); CH_SB;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)ent), hi = __builtin_amdgcn_readfirstlane((unsigned)(ent >> 32));
+    const int kq = (int)(lo & 3u) + 1;
+    const __attribute__((address_space(1))) char *base = (const __attribute__((address_space(1))) char *)(((unsigned long long)hi << 32) | (lo & ~3u));
+    const gf32 *p0 = (const gf32 *)(base + (row512 * kq + pos16));
+    Bq[0] = gld4(p0); CH_SB;                                               // request block t+5 into the registers just parked
+    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1].z, fb[1].z, c1, 0, 0, 0); CH_SB;
+    Bq[1] = gld4(p0 + 8 * CD * kq);
+    ++lb;
+    fetch_entry(); CH_SB;
+    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0].w, fb[0].w, c0, 0, 0, 0); CH_SB;
+    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1].w, fb[1].w, c1, 0, 0, 0); CH_SB;
+#undef CH_SB
   };
   // the k loop of one 128-column chunk, four blocks per iteration (nk is a multiple of 4): the register slots and the fragment
   // sets alternate, nothing is copied.  The A fragments requested by the last step (k-tile 0 again) serve the next chunk of
@@ -305,11 +338,13 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
     }
     __syncthreads();
   }
+  CHAIN_PROF(3);
 
   // ================= stages FF1 / FF2: x += (a * gate(g)) W2^T + b2,  [a | g] = LN(x) W1^T + b1 =================
   if (a_has_ff) {
     layer_norm(a_f_nw != nullptr, p_fnw, p_fnb);
     __syncthreads();
+    CHAIN_PROF(4);
     read_a(fa0, Ahat, 0);
     for (int hc = 0; hc < 4; ++hc) {
       f32x4 a0 = zero, a1 = zero, g0 = zero, g1 = zero;
@@ -328,6 +363,7 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
       }
     }
     __syncthreads();
+    CHAIN_PROF(5);
     {
       f32x4 c0 = zero, c1 = zero;
       read_a(fa0, Abig, 0);
@@ -340,6 +376,7 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
     __syncthreads();
   }
 
+  CHAIN_PROF(6);
   // ---- x is final: hand it to the next attention block (its input / residual, and the trace slot of hn_attn_probs)
   if (a_x_out) {
     const int row = tid >> 5, l32 = tid & 31;
@@ -350,6 +387,7 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
   if (nq_ch + nkv_ch > 0) {
     layer_norm(a_p_nw != nullptr, p_pnw, p_pnb);
     __syncthreads();
+    CHAIN_PROF(7);
     read_a(fa0, Ahat, 0);
     const int stg = Abig + wave * 256;       // this wave's 16 x 16 output tile (the hidden tile is dead by now)
     for (int pj = 0; pj < nq_ch + nkv_ch; ++pj) {
@@ -367,9 +405,27 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
       for (int r = 0; r < 4; ++r) lds[stg + (4 * fg + r) * 16 + fi] = al * v[r];
       const int srow = lane >> 2, c4 = lane & 3;
       gst4(C + (long)(m0 + srow) * ldc + j * WN + wave * 16 + 4 * c4, lld4(lds, stg + srow * 16 + 4 * c4));
+      if (pj + 1 == nq_ch) CHAIN_PROF(8);
     }
   }
+  CHAIN_PROF(9);
+  CHAIN_PROF(15);
+#ifdef CHAIN_PROFILE
+  if (blockIdx.x == 100 % gridDim.x && threadIdx.x == 0) {
+    g_chain_prof[(g_chain_seq & 15) * 16 + 10] = (unsigned long long)nblocks | ((unsigned long long)nk_out << 16) | ((unsigned long long)nq_ch << 32) | ((unsigned long long)nkv_ch << 48);
+    __threadfence();
+    g_chain_seq = g_chain_seq + 1;
+  }
+#endif
 }
+
+#ifdef CHAIN_PROFILE
+extern "C" __attribute__((visibility("default"))) int hn_debug_chain_prof(unsigned long long *out, int *seq) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chain_prof), sizeof(unsigned long long) * 256) != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(seq, HIP_SYMBOL(g_chain_seq), sizeof(int)) != hipSuccess) return -1;
+  return 0;
+}
+#endif
 
 bool latent_chain_supported(int rows, int d, int hidden) { return d == CD && hidden == CHID && rows > 0 && rows % CR == 0; }
 
