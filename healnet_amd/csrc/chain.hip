@@ -31,6 +31,18 @@
 //       512 threads now write it ONCE as a table in LDS (64-bit byte address of the block's first row, ldw/128 - 1 in the two
 //       low bits) and a wave fetches the entry of the NEXT block with one broadcast ds_read_b64 a step ahead: 40 us per chain,
 //       forward 3.224 -> 3.036 ms at cfg2 b = 32.  (An L2 warm-up pass was re-tried on top of this: no change.)
+//   v5  stage cycle stamps (tools/chain_profile.py, -DCHAIN_PROFILE) then showed 740-925 cycles per block against the 512 of its
+//       MFMAs, and the ISA why: in the unrolled feed-forward stages the scheduler had sunk every global load to just in front of
+//       its ds_write (s_waitcnt vmcnt(0) per block), and everywhere it grouped the ds_writes, the address arithmetic and the
+//       loads in front of the first MFMA of a step.  The step is now pinned slot by slot (one memory instruction behind each
+//       MFMA): 700-870 cycles per block, forward 2.99 ms.  Streaming (nt) stores for x / Q / KV -- the end-of-kernel write-back
+//       of 24 MB dirty lines cost 4-8 us per chain -- 2.975 ms; a split expm1 in the SELU epilogue and DPP row sums in LayerNorm
+//       (two ds_bpermute chains of 5) another ~1 us per chain.
+//       Ablations on v5 (cycles per block, OUT / FF2 / KV): as is 774 / 722 / 728; no global loads 700 / 654 / 664; loads kept
+//       but consumed straight from registers (no LDS transpose: what weights pre-tiled in MFMA order would buy) 830 / 710 / 790
+//       -- NO gain, so the LDS path is not the cost; neither loads nor B-side LDS 582 / 546 / 595; a ring twice as deep 830 /
+//       838 / 762 (worse: not latency).  What is left is what two waves per SIMD cannot overlap of ~30 non-MFMA instructions
+//       per block; the micro-benchmark (mfma_stream.hip) sits at the same 690 cycles.
 //
 // Shapes: l_d = 128, hidden 512, K a multiple of 128, N a multiple of 128, rows % 16 == 0.
 #include "common.h"
@@ -70,11 +82,7 @@ __device__ __forceinline__ void gst1(gf32 *p, float v) { *p = v; }
 // streaming store: written through instead of staying dirty in this XCD's L2 until the end-of-kernel write-back
 __device__ __forceinline__ void gst4_nt(gf32 *p, const float4 &v) {
   f32x4 t = {v.x, v.y, v.z, v.w};
-#ifndef X_NONT
   __builtin_nontemporal_store(t, (gf32x4 *)p);
-#else
-  *(gf32x4 *)p = t;
-#endif
 }
 // ... and every LDS access through address space 3 with integer offsets (a generic pointer that the compiler cannot trace back
 // to the LDS symbol becomes a flat access, which counts against BOTH wait counters)
@@ -300,39 +308,21 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
     // Two accumulators (k-slots 0 and 1) so that consecutive MFMAs never depend on each other; they are summed in the epilogue.
 #define CH_SB __builtin_amdgcn_sched_barrier(0)
     c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0].x, fb[0].x, c0, 0, 0, 0); CH_SB;
-#ifndef X_NOPARK
     lst4(lds, wslot, Bq[0]); CH_SB;                                        // park block t+1, first half
-#endif
     c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1].x, fb[1].x, c1, 0, 0, 0); CH_SB;
-#ifndef X_NOPARK
     lst4(lds, wslot + 8 * WK, Bq[1]); CH_SB;                               //                 second half
-#endif
     c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0].y, fb[0].y, c0, 0, 0, 0); CH_SB;
-#ifndef X_NOREADB
     read_b(fbn); CH_SB;                                                    // its fragments back
-#else
-    fbn[0] = fb[0]; fbn[1] = fb[1];
-#endif
     c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1].y, fb[1].y, c1, 0, 0, 0); CH_SB;
-#ifndef X_NOREADA
     read_a(fan, A, kt_next); CH_SB;
-#else
-    fan[0] = fa[0]; fan[1] = fa[1];
-#endif
     c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0].z, fb[0].z, c0, 0, 0, 0); CH_SB;
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)ent), hi = __builtin_amdgcn_readfirstlane((unsigned)(ent >> 32));
     const int kq = (int)(lo & 3u) + 1;
     const __attribute__((address_space(1))) char *base = (const __attribute__((address_space(1))) char *)(((unsigned long long)hi << 32) | (lo & ~3u));
     const gf32 *p0 = (const gf32 *)(base + (row512 * kq + pos16));
-#ifndef X_NOISSUE
     Bq[0] = gld4(p0); CH_SB;                                               // request block t+5 into the registers just parked
-#else
-    Bq[0].x = __int_as_float((int)(long)p0);
-#endif
     c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1].z, fb[1].z, c1, 0, 0, 0); CH_SB;
-#ifndef X_NOISSUE
     Bq[1] = gld4(p0 + 8 * CD * kq);
-#endif
     ++lb;
     fetch_entry(); CH_SB;
     c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0].w, fb[0].w, c0, 0, 0, 0); CH_SB;

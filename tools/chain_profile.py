@@ -8,14 +8,13 @@ workgroup), runs cfg2 forwards through it and prints, per chain of one forward, 
 import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-VAR = os.environ.get("CHAIN_VARIANT", "")
-lib = os.path.join(ROOT, "healnet_amd", f"libhealnet_prof{VAR}.so")
+lib = os.path.join(ROOT, "healnet_amd", "libhealnet_prof.so")
 if not os.path.exists(lib):
     src = os.path.join(ROOT, "healnet_amd", "csrc")
     objs = [os.path.join(ROOT, "healnet_amd", "build", f) for f in os.listdir(os.path.join(ROOT, "healnet_amd", "build")) if f.endswith(".hip.o") and not f.startswith("chain")]
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-DCHAIN_PROFILE"] + [f"-DX_{v}" for v in VAR.split("_") if v] + [
-                           "-c", os.path.join(src, "chain.hip"), "-o", f"/tmp/chain_prof{VAR}.o"])
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + [f"/tmp/chain_prof{VAR}.o"])
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-DCHAIN_PROFILE",
+                           "-c", os.path.join(src, "chain.hip"), "-o", "/tmp/chain_prof.o"])
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["/tmp/chain_prof.o"])
 if len(sys.argv) > 1 and sys.argv[1] == "--build-only":
     sys.exit(0)
 os.environ["HN_LIB_PATH"] = lib
