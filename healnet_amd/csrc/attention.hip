@@ -394,6 +394,7 @@ int launch_attn_core(const AttnCoreArgs &a, hipStream_t s) {
   HN_REQUIRE(a.Ofinal == nullptr || (a.nsplit == 1 && !a.ones_col), HN_E_SHAPE, "attn_core: direct output needs a single split");
   HN_REQUIRE(!a.ones_col || (a.dp <= 32 && a.Kp == a.Vp), HN_E_UNSUPPORTED, "attn_core: ones column needs the shared-context binding");
   HN_REQUIRE(a.drop.thr == 0 || !a.ones_col, HN_E_SHAPE, "attn_core: dropout needs the explicit denominator (ones_col = 0)");
+  if (self_core_lds_eligible(a)) return launch_self_core_lds(a, s);
   const int dt = a.dp / 16;
   int nq = nq_for(dt);
   // latent self-attention (dp = 64, one split) at small batches: fewer than one wave per two SIMDs with 2 tiles per wave;

@@ -276,6 +276,9 @@ struct AttnCoreArgs {
   int drop_rowsum;                              // ... shared-context binding: also accumulate sum_t p'_t in column dp-1
 };
 int launch_attn_core(const AttnCoreArgs &a, hipStream_t s);
+// one workgroup per (sample, head) with K / V in LDS: the latent self-attention shape (self_attention.hip)
+bool self_core_lds_eligible(const AttnCoreArgs &a);
+int launch_self_core_lds(const AttnCoreArgs &a, hipStream_t s);
 
 struct AttnCoreBf16Args {                        // bf16-MFMA core of the shared-context binding (attention_bf16.hip)
   const uint16_t *Qf;                            // (b, h, Lp, 32) bf16 folded queries

@@ -122,15 +122,24 @@ def test_forced_softmax_rescale_branch(hn):
     assert_close(got.cpu(), want, rel=2e-4, what="spike.y")
 
 
-def test_self_attention_block_vs_oracle(hn):
-    gen = torch.Generator().manual_seed(5)
-    blk = hn.PreNorm(128, hn.Attention(128, heads=8, dim_head=64)).to(DEV)
-    x = torch.randn(4, 128, 128, generator=gen) * 1.5
+@pytest.mark.parametrize("b,L,heads,dh", [(4, 128, 8, 64), (3, 40, 2, 64), (2, 100, 5, 64), (1, 16, 1, 64), (2, 1, 3, 64),
+                                          (2, 160, 2, 64), (2, 48, 4, 32)])
+def test_self_attention_block_vs_oracle(hn, b, L, heads, dh, monkeypatch):
+    """Latent self-attention (healnet.py:241-245).  dim_head 64 with L <= 128 runs on self_core_lds_kernel (one workgroup per
+    (sample, head), K / V in LDS): full and ragged row counts (40, 100: masked token tail + idle waves), a single row, one
+    head; L = 160 and dim_head 32 stay on the split-KV core.  Output and the probabilities hn_attn_probs rebuilds from the
+    kernel's (max, sum) statistics.  (The kernel is only chosen from 192 (sample, head) pairs on: forced here.)"""
+    monkeypatch.setenv("HN_FORCE_SELF_LDS", "1")
+    gen = torch.Generator().manual_seed(5 + L)
+    blk = hn.PreNorm(128, hn.Attention(128, heads=heads, dim_head=dh)).to(DEV)
+    x = torch.randn(b, L, 128, generator=gen) * 1.5
     sd = {k: v.detach().cpu() for k, v in blk.state_dict().items()}
     xn = O.layer_norm(x, sd["norm.weight"], sd["norm.bias"])
-    want = O.attention(xn, None, sd["fn.to_q.weight"], sd["fn.to_kv.weight"], sd["fn.to_out.0.weight"], sd["fn.to_out.0.bias"], 8)
+    want, pw = O.attention(xn, None, sd["fn.to_q.weight"], sd["fn.to_kv.weight"], sd["fn.to_out.0.weight"], sd["fn.to_out.0.bias"],
+                           heads, return_weights=True)
     got = blk(x.to(DEV))
     assert_close(got.cpu(), want, rel=2e-4, what="self.y")
+    assert_close(blk.fn.attn_weights.cpu(), pw, rel=5e-4, what="self.p")
 
 
 def test_fully_masked_row_is_nan_like_reference(hn):
