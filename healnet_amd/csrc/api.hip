@@ -876,14 +876,12 @@ static int plan_fusion(const hn_model *m, const hn_modality_input *in, int b, vo
     if (m->self_per_cross_attn > 0)
       for (int k = 0; k < m->depth; ++k) max_inner_self = max_inner_self > m->self_attn[k].heads * pad_head_dim(m->self_attn[k].dim_head) ? max_inner_self : m->self_attn[k].heads * pad_head_dim(m->self_attn[k].dim_head);
     if (max_inner_self > max_inner) max_inner = max_inner_self;
-    // Every workgroup of the chain streams ALL weights of the chain through its CU in ~40 us however few rows there are, while
-    // the 2-D tiled per-block GEMMs shrink with the row count: the chain pays from ~160 workgroups (of 256 CUs) on.
-    // Measured at cfg2 (l_c = 128), chain vs per-block launches (ms per forward, profiles/r02_e_chain_sweep.txt): b = 8 1.30 vs
-    // 1.21, 16: 1.86 / 1.84, 20: 2.27 / 2.30, 24: 2.57 / 2.62, 32: 3.06 / 3.23, 36: 3.71 / 3.82, 40: 4.14 / 4.27,
-    // 48: 4.79 / 5.00, 64: 5.86 / 6.32, 96: 10.88 / 11.46, 128: 11.52 / 12.24 -- partial rounds no longer lose.
-    const bool chain_pays = b * m->l_c / 16 >= 160;
-    fp->chain = inference && latent_chain_supported(b * m->l_c, m->l_d, 4 * m->l_d) && m->l_c % 16 == 0 &&
-                (chain_pays || getenv("HN_FORCE_CHAIN") != nullptr);
+    // Every workgroup of the chain streams ALL weights of the chain through its CU however few rows there are, while the 2-D tiled
+    // per-block GEMMs shrink with the row count; until the loader lost its vector address arithmetic (chain.hip, v6) that made the
+    // per-block launches faster below ~160 workgroups.  Measured at cfg2 (l_c = 128) since, chain vs per-block launches, ms per
+    // forward: b = 1 0.851 / 0.848, 2: 0.820 / 0.822, 4: 0.908 / 0.915, 8: 1.193 / 1.212, 16: 1.740 / 1.830, 24: 2.435 / 2.605,
+    // 32: 2.911 / 3.205 -- no crossover left, the chain is the route whenever its shapes apply (HN_NO_CHAIN=1: development switch).
+    fp->chain = inference && latent_chain_supported(b * m->l_c, m->l_d, 4 * m->l_d) && m->l_c % 16 == 0;
     fp->cq = fp->ckv = nullptr;
     if (fp->chain) {
       fp->cq = ar.take<float>((size_t)b * m->l_c * max_inner);

@@ -43,6 +43,12 @@
 //       -- NO gain, so the LDS path is not the cost; neither loads nor B-side LDS 582 / 546 / 595; a ring twice as deep 830 /
 //       838 / 762 (worse: not latency).  What is left is what two waves per SIMD cannot overlap of ~30 non-MFMA instructions
 //       per block; the micro-benchmark (mfma_stream.hip) sits at the same 690 cycles.
+//   v6  ... and the micro-benchmark then named the instructions: the fp32 MFMA shares the SIMD's issue with the VALU, and the
+//       64-bit per-lane addresses of global_load cost five vector instructions per block (v_mul_lo_u32, v_or, v_ashr, two
+//       v_lshl_add_u64).  With buffer loads -- base and row pitch of the block in the SGPR descriptor (the table entry IS words
+//       0-1 of it), row index and piece offset in loop-invariant VGPRs -- the same stream costs 0.241 us per block instead of
+//       0.307 (MFMAs alone: 0.225): 590-730 cycles per block in the chain, 30.4 us per launch, forward 2.92 ms, and the chain now
+//       beats the per-block launches at every batch size (profiles/r02_g_chain_sweep.txt).
 //
 // Shapes: l_d = 128, hidden 512, K a multiple of 128, N a multiple of 128, rows % 16 == 0.
 #include "common.h"
@@ -67,6 +73,8 @@ enum { CS_OUT = 0, CS_FF1 = 1, CS_FF2 = 2, CS_Q = 3, CS_KV = 4, CS_END = 5 };
 // Pointers that arrive inside the argument struct are generic: hipcc emits flat_load / flat_store for them, and with flat
 // operations in flight its wait-count insertion falls back to "wait for everything" in front of every use of a prefetched
 // register.  Everything outside the weight stream therefore goes through explicit global-address-space accesses.
+// buffer_load_dwordx4 ... idxen offen: address = base + vindex * stride + voffset, base and stride in the SGPR descriptor
+__device__ f32x4 hn_sbuffer_load_x4(i32x4 rsrc, int vindex, int voffset, int soffset, int aux) __asm("llvm.amdgcn.struct.buffer.load.v4f32");
 typedef float __attribute__((address_space(1))) gf32;
 typedef f32x4 __attribute__((address_space(1))) gf32x4;
 __device__ __forceinline__ float4 gld4(const gf32 *p) {
@@ -210,26 +218,38 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
     const int ldw = s_out ? a_inner_o : s_ff2 ? CHID : CD;
     const int rb = s_ff1 ? (j & 1) * CHID + (j >> 1) * WN : j * WN;               // FF1: value chunk, then its gate chunk
     const float *W = s_out ? args.w_out : s_ff1 ? args.w1 : s_ff2 ? args.w2 : s_q ? args.wq : args.wkv;
-    const unsigned long long addr = (unsigned long long)(W + (long)rb * ldw + k * WK) | (unsigned long long)(ldw / CD - 1);
-    *(__attribute__((address_space(3))) unsigned long long *)(lds + tbl + 2 * tid) = addr;
+    // words 0 and 1 of the block's buffer descriptor: base = its first row at k, stride = the row pitch in bytes
+    const unsigned long long addr = (unsigned long long)(W + (long)rb * ldw + k * WK);
+    const unsigned long long desc = (addr & 0x0000ffffffffffffull) | ((unsigned long long)(ldw * 4) << 48);
+    *(__attribute__((address_space(3))) unsigned long long *)(lds + tbl + 2 * tid) = desc;
   }
   const int r8 = lane >> 3, pos = lane & 7;                      // loader lane: row r8 (and r8 + 8) of the wave's 16, 16-byte piece pos
   const int wslot = Wr + wave * WSLOT + r8 * WK + ((pos ^ (r8 & 7)) * 4);   // ... parked at slot pos ^ (row & 7) of its LDS row
-  const int row512 = (wave * 16 + r8) * (CD * 4), pos16 = pos * 16;      // byte offset of the lane's row at K = 128, of its piece
+  const int vrow = wave * 16 + r8, pos16 = pos * 16;             // the lane's row of the 128-row block (index), byte offset of its piece
   int lb = 0;                               // next block to request
   unsigned long long ent = 0;               // its table entry (fetched a step ahead)
-  auto fetch_entry = [&]() { ent = *(const __attribute__((address_space(3))) unsigned long long *)(lds + tbl + 2 * min(lb, MAXBLK - 1)); };
+  auto fetch_entry = [&]() { ent = *(const __attribute__((address_space(3))) unsigned long long *)(lds + tbl + 2 * lb); };   // lb <= nblocks + 4 < MAXBLK
 
   // this wave's 2 KB of block lb (past the end: the last block again, never consumed): rows 16 wave + r8 and + 8 of the chunk
   // as FULL 128-byte lines (8 lanes per row) -- 16 rows x 64 B per load, the MFMA fragment layout, runs at a third of the rate
   // (tools/ubench/l2_fill.hip: 38 against 117 GB/s per CU when all CUs stream the same L2-resident weights)
+  // The loads are BUFFER loads with the block's base and row pitch in the SGPR descriptor and loop-invariant VGPR operands (row
+  // index, piece offset): no vector instruction computes an address.  The fp32 MFMA shares the SIMD's issue with the VALU --
+  // every VALU instruction in the step is matrix time lost -- and the 64-bit per-lane addresses of global_load (v_mul_lo,
+  // two v_lshl_add_u64, ...) were most of what kept a block at 1.45x its MFMA time (tools/ubench/mfma_stream.hip: 8 MFMAs
+  // + 2 loads per wave and block 0.307 us with global loads, 0.241 us with buffer loads, 0.225 us without loads).
+  auto load2 = [&](float4 (&r)[2]) {
+    i32x4 rs;
+    rs.x = (int)__builtin_amdgcn_readfirstlane((unsigned)ent);
+    rs.y = (int)__builtin_amdgcn_readfirstlane((unsigned)(ent >> 32));
+    rs.z = WN;                              // 128 records (rows)
+    rs.w = 0x00020000;
+    const f32x4 v0 = hn_sbuffer_load_x4(rs, vrow, pos16, 0, 0), v1 = hn_sbuffer_load_x4(rs, vrow + 8, pos16, 0, 0);
+    r[0] = make_float4(v0.x, v0.y, v0.z, v0.w);
+    r[1] = make_float4(v1.x, v1.y, v1.z, v1.w);
+  };
   auto issue = [&](float4 (&r)[2]) {
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)ent), hi = __builtin_amdgcn_readfirstlane((unsigned)(ent >> 32));
-    const int kq = (int)(lo & 3u) + 1;                           // row length in units of 128 floats
-    const __attribute__((address_space(1))) char *base = (const __attribute__((address_space(1))) char *)(((unsigned long long)hi << 32) | (lo & ~3u));
-    const gf32 *p0 = (const gf32 *)(base + (row512 * kq + pos16));
-    r[0] = gld4(p0);
-    r[1] = gld4(p0 + 8 * CD * kq);
+    load2(r);
     ++lb;
     fetch_entry();
   };
@@ -316,13 +336,21 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
     c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1].y, fb[1].y, c1, 0, 0, 0); CH_SB;
     read_a(fan, A, kt_next); CH_SB;
     c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0].z, fb[0].z, c0, 0, 0, 0); CH_SB;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)ent), hi = __builtin_amdgcn_readfirstlane((unsigned)(ent >> 32));
-    const int kq = (int)(lo & 3u) + 1;
-    const __attribute__((address_space(1))) char *base = (const __attribute__((address_space(1))) char *)(((unsigned long long)hi << 32) | (lo & ~3u));
-    const gf32 *p0 = (const gf32 *)(base + (row512 * kq + pos16));
-    Bq[0] = gld4(p0); CH_SB;                                               // request block t+5 into the registers just parked
+    i32x4 rs;
+    rs.x = (int)__builtin_amdgcn_readfirstlane((unsigned)ent);
+    rs.y = (int)__builtin_amdgcn_readfirstlane((unsigned)(ent >> 32));
+    rs.z = WN;
+    rs.w = 0x00020000;
+    {
+      const f32x4 v0 = hn_sbuffer_load_x4(rs, vrow, pos16, 0, 0);            // request block t+5 into the registers just parked
+      Bq[0] = make_float4(v0.x, v0.y, v0.z, v0.w);
+    }
+    CH_SB;
     c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1].z, fb[1].z, c1, 0, 0, 0); CH_SB;
-    Bq[1] = gld4(p0 + 8 * CD * kq);
+    {
+      const f32x4 v1 = hn_sbuffer_load_x4(rs, vrow + 8, pos16, 0, 0);
+      Bq[1] = make_float4(v1.x, v1.y, v1.z, v1.w);
+    }
     ++lb;
     fetch_entry(); CH_SB;
     c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0].w, fb[0].w, c0, 0, 0, 0); CH_SB;

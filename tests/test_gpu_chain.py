@@ -121,12 +121,11 @@ def test_whole_model_chain_vs_unfused_launches(hn, tmp_path):
     script = tmp_path / "run.py"
     script.write_text(_SCRIPT.format(root=ROOT))
     res = {}
-    # (HN_FORCE_CHAIN: at this batch size the forward would pick the per-block launches on its own -- the chain only pays
-    # when its workgroups fill the chip in whole rounds)
-    for tag, env in (("chain", {"HN_FORCE_CHAIN": "1"}), ("plain", {"HN_NO_CHAIN": "1"})):
+    for tag, env in (("chain", {}), ("plain", {"HN_NO_CHAIN": "1"})):
         out = tmp_path / f"{tag}.pt"
         e = dict(os.environ, **env)
-        e.pop("HN_NO_CHAIN", None) if tag == "chain" else e.pop("HN_FORCE_CHAIN", None)
+        if tag == "chain":
+            e.pop("HN_NO_CHAIN", None)
         r = subprocess.run([sys.executable, str(script), str(out)], env=e, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         res[tag] = torch.load(out)

@@ -41,11 +41,9 @@ def test_random_medium_size_configurations():
     assert _fuzz().main(["--n", "6", "--seed", "4", "--scale", "medium", "--backward"]) == 0
 
 
-def test_random_configurations_on_the_latent_chain(monkeypatch):
+def test_random_configurations_on_the_latent_chain():
     """l_d = 128 models whose latent side runs on the fused chain kernel (all head / projection kinds, masks, missing
-    modalities, the verbose quirk, embeddings), plus the attention export through the chain's trace slots.  HN_FORCE_CHAIN:
-    at these small batches the forward would otherwise choose the per-block launches."""
-    monkeypatch.setenv("HN_FORCE_CHAIN", "1")
+    modalities, the verbose quirk, embeddings), plus the attention export through the chain's trace slots."""
     assert _fuzz().main(["--n", "50", "--seed", "21", "--scale", "chain"]) == 0
     assert _fuzz().main(["--n", "25", "--seed", "22", "--scale", "chain", "--attn"]) == 0
     assert _fuzz().main(["--n", "10", "--seed", "23", "--scale", "chain", "--backward"]) == 0

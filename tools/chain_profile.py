@@ -18,7 +18,6 @@ if not os.path.exists(lib):
 if len(sys.argv) > 1 and sys.argv[1] == "--build-only":
     sys.exit(0)
 os.environ["HN_LIB_PATH"] = lib
-os.environ.setdefault("HN_FORCE_CHAIN", "1")
 import torch
 import healnet_amd as hn
 from healnet_amd import _capi
