@@ -611,27 +611,58 @@ struct MergeWeights {
 
 // Accumulates acc[k] (element idx = tid + 256 k of the R x width block; element (qq, d) is taken when keep(d)) over all
 // splits, unnormalised; leaves M / l / 1/l of the block's rows in mw.  All 256 threads must call it.
+// Every load is unconditional on a clamped address (rows up to Lp exist in the partials) and issued in groups of PF that are in
+// flight together; the first group leaves BEFORE the weight phase.  The partials were written by the core on other XCDs, so each
+// load is an HBM / Infinity-Cache round trip: the per-split loop with one dependent load per iteration this replaces spent
+// nsplit + 4 of them in sequence (merge_vproj 19.5 us at 9 splits, merge_explicit 42 us at cfg4).
 template <int EPT, typename Keep>
 __device__ __forceinline__ void merge_splits(MergeWeights &mw, const float *Opart, const float *Mpart, const float *Lpart,
                                              long pbase, int nsplit, int Lp, int dp, int q0, int L, int R, int width, Keep keep,
                                              float (&acc)[EPT]) {
+  constexpr int PF = EPT <= 4 ? 8 : 4;                   // splits per group (EPT * PF values in registers)
   const int tid = threadIdx.x;
+  const long sstride = (long)Lp * dp;
+  long eoff[EPT];
+  int eq[EPT];
+  bool live[EPT];
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const int idx = tid + 256 * k;
+    const bool inb = idx < R * width;
+    const int qq = inb ? idx / width : 0, d = inb ? idx % width : 0;
+    eq[k] = qq;
+    live[k] = inb && q0 + qq < L && keep(d);
+    eoff[k] = (pbase + min(q0 + qq, Lp - 1)) * dp + d;
+    acc[k] = 0.0f;
+  }
+  float pre[EPT][PF];
+  auto request = [&](int s) {                            // splits s .. s + PF - 1 (past the end: the last one again, weight 0)
+#pragma unroll
+    for (int k = 0; k < EPT; ++k)
+#pragma unroll
+      for (int u = 0; u < PF; ++u) pre[k][u] = Opart[eoff[k] + (long)min(s + u, nsplit - 1) * sstride];
+  };
+  request(0);
+
   const int wq = tid >> 3, j = tid & 7;                  // weight phase: 8 lanes per row, rows 0 .. R-1
   const bool wlive = wq < R && q0 + wq < L;
+  const long wrow = pbase + min(q0 + wq, Lp - 1);
   float M = kNegBig;
-  if (wlive) for (int s = j; s < nsplit; s += 8) M = fmaxf(M, Mpart[pbase + (long)s * Lp + q0 + wq]);
+  if (wlive) for (int s = j; s < nsplit; s += 8) M = fmaxf(M, Mpart[wrow + (long)s * Lp]);
   M = fmaxf(M, __shfl_xor(M, 1));
   M = fmaxf(M, __shfl_xor(M, 2));
   M = fmaxf(M, __shfl_xor(M, 4));
   float lsum = 0.0f;
-#pragma unroll
-  for (int k = 0; k < EPT; ++k) acc[k] = 0.0f;
   for (int s0 = 0; s0 < nsplit; s0 += MERGE_MAXS) {
     const int s1 = min(nsplit, s0 + MERGE_MAXS);
+    const int s1p = min(s0 + MERGE_MAXS, (s1 + PF - 1) / PF * PF);       // weights up to the end of the last group: 0
     const bool last = s1 == nsplit;
-    if (wlive) for (int s = s0 + j; s < s1; s += 8) {
-      const float w = fast_exp2(Mpart[pbase + (long)s * Lp + q0 + wq] - M);
-      lsum = fmaf(w, Lpart[pbase + (long)s * Lp + q0 + wq], lsum);
+    if (wq < R) for (int s = s0 + j; s < s1p; s += 8) {
+      float w = 0.0f;
+      if (wlive && s < s1) {
+        w = fast_exp2(Mpart[wrow + (long)s * Lp] - M);
+        lsum = fmaf(w, Lpart[wrow + (long)s * Lp], lsum);
+      }
       mw.w[wq][s - s0] = w;
     }
     if (last) {           // the merged (M, l) ride on the barrier the last chunk needs anyway: one barrier in all for <= 64 splits
@@ -641,20 +672,17 @@ __device__ __forceinline__ void merge_splits(MergeWeights &mw, const float *Opar
       if (wq < R && j == 0) { mw.M[wq] = M; mw.l[wq] = lsum; mw.invl[wq] = 1.0f / lsum; }
     }
     __syncthreads();
+    for (int s = s0; s < s1; s += PF) {
+      if (s != 0) request(s);
 #pragma unroll
-    for (int k = 0; k < EPT; ++k) {
-      const int idx = tid + 256 * k;
-      if (idx < R * width) {
-        const int qq = idx / width, d = idx % width, q = q0 + qq;
-        if (q < L && keep(d)) {
-          float a = acc[k];
-          for (int s = s0; s < s1; ++s) a = fmaf(mw.w[qq][s - s0], Opart[(pbase + (long)s * Lp + q) * dp + d], a);
-          acc[k] = a;
-        }
-      }
+      for (int k = 0; k < EPT; ++k)
+#pragma unroll
+        for (int u = 0; u < PF; ++u) acc[k] = fmaf(mw.w[eq[k]][s + u - s0], pre[k][u], acc[k]);
     }
     if (!last) __syncthreads();      // the next chunk overwrites the staged weights
   }
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) acc[k] = live[k] ? acc[k] : 0.0f;
 }
 
 static int merge_rows_per_block(int b, int h, int L) {       // 32 rows, or 8 while 32 would give fewer workgroups than CUs

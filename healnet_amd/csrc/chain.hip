@@ -226,9 +226,15 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
   const int r8 = lane >> 3, pos = lane & 7;                      // loader lane: row r8 (and r8 + 8) of the wave's 16, 16-byte piece pos
   const int wslot = Wr + wave * WSLOT + r8 * WK + ((pos ^ (r8 & 7)) * 4);   // ... parked at slot pos ^ (row & 7) of its LDS row
   const int vrow = wave * 16 + r8, pos16 = pos * 16;             // the lane's row of the 128-row block (index), byte offset of its piece
-  int lb = 0;                               // next block to request
-  unsigned long long ent = 0;               // its table entry (fetched a step ahead)
-  auto fetch_entry = [&]() { ent = *(const __attribute__((address_space(3))) unsigned long long *)(lds + tbl + 2 * lb); };   // lb <= nblocks + 4 < MAXBLK
+  unsigned long long ent = 0;               // table entry of the next block to request (fetched a step ahead)
+  // the table pointer lives in a VGPR (opaque to the compiler: as a scalar it is copied into one with a v_mov per fetch) and
+  // advances by one entry per fetch: immediate offsets inside the unrolled groups of four steps, one v_add per group
+  int tp = tbl;
+  asm volatile("" : "+v"(tp));
+  auto fetch_entry = [&]() {                // at most nblocks + 4 < MAXBLK fetches
+    ent = *(const __attribute__((address_space(3))) unsigned long long *)(lds + tp);
+    tp += 2;
+  };
 
   // this wave's 2 KB of block lb (past the end: the last block again, never consumed): rows 16 wave + r8 and + 8 of the chunk
   // as FULL 128-byte lines (8 lanes per row) -- 16 rows x 64 B per load, the MFMA fragment layout, runs at a third of the rate
@@ -250,7 +256,6 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
   };
   auto issue = [&](float4 (&r)[2]) {
     load2(r);
-    ++lb;
     fetch_entry();
   };
   // ... and into the wave's LDS slot, from where the MFMA fragments are read back (a wave only reads what it wrote: no barrier)
@@ -351,7 +356,6 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
       const f32x4 v1 = hn_sbuffer_load_x4(rs, vrow + 8, pos16, 0, 0);
       Bq[1] = make_float4(v1.x, v1.y, v1.z, v1.w);
     }
-    ++lb;
     fetch_entry(); CH_SB;
     c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0].w, fb[0].w, c0, 0, 0, 0); CH_SB;
     c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1].w, fb[1].w, c1, 0, 0, 0); CH_SB;
@@ -360,13 +364,21 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
   // the k loop of one 128-column chunk, four blocks per iteration (nk is a multiple of 4): the register slots and the fragment
   // sets alternate, nothing is copied.  The A fragments requested by the last step (k-tile 0 again) serve the next chunk of
   // the same stage.
-  auto run_chunk = [&](int A, int nk, f32x4 &c0, f32x4 &c1) {
-    for (int kc = 0; kc < nk; kc += 4) {
-      step(B0, fa0, fb0, fa1, fb1, A, kc + 1, c0, c1);
-      step(B1, fa1, fb1, fa0, fb0, A, kc + 2, c0, c1);
-      step(B2, fa0, fb0, fa1, fb1, A, kc + 3, c0, c1);
-      step(B3, fa1, fb1, fa0, fb0, A, kc + 4 == nk ? 0 : kc + 4, c0, c1);
-    }
+  auto run4 = [&](int A, int kc, int nk, f32x4 &c0, f32x4 &c1) {
+    step(B0, fa0, fb0, fa1, fb1, A, kc + 1, c0, c1);
+    step(B1, fa1, fb1, fa0, fb0, A, kc + 2, c0, c1);
+    step(B2, fa0, fb0, fa1, fb1, A, kc + 3, c0, c1);
+    step(B3, fa1, fb1, fa0, fb0, A, kc + 4 == nk ? 0 : kc + 4, c0, c1);
+  };
+  // K = 128 and K = 512 with the k-tile a compile-time constant: the A-fragment addresses are immediates (with a run-time k-tile
+  // the compiler adds the scalar tile offset to the lane's VGPR offset with a v_add per fragment read -- VALU time the MFMAs lose)
+  auto run_chunk_k128 = [&](int A, f32x4 &c0, f32x4 &c1) { run4(A, 0, 4, c0, c1); };
+  auto run_chunk_k512 = [&](int A, f32x4 &c0, f32x4 &c1) {
+#pragma unroll
+    for (int kc = 0; kc < 16; kc += 4) run4(A, kc, 16, c0, c1);
+  };
+  auto run_chunk = [&](int A, int nk, f32x4 &c0, f32x4 &c1) {       // run-time K (the out-projection: inner_o / 32 k-tiles)
+    for (int kc = 0; kc < nk; kc += 4) run4(A, kc, nk, c0, c1);
   };
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 
@@ -412,8 +424,8 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
     read_a(fa0, Ahat, 0);
     for (int hc = 0; hc < 4; ++hc) {
       f32x4 a0 = zero, a1 = zero, g0 = zero, g1 = zero;
-      run_chunk(Ahat, CD / WK, a0, a1);
-      run_chunk(Ahat, CD / WK, g0, g1);
+      run_chunk_k128(Ahat, a0, a1);
+      run_chunk_k128(Ahat, g0, g1);
       const int h0 = hc * WN + ncol;
       const float ba = lds[p_b1 + h0], bg = lds[p_b1 + CHID + h0];
       const float va[4] = {a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w};
@@ -431,7 +443,7 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
     {
       f32x4 c0 = zero, c1 = zero;
       read_a(fa0, Abig, 0);
-      run_chunk(Abig, CHID / WK, c0, c1);
+      run_chunk_k512(Abig, c0, c1);
       const float bv = lds[p_b2 + ncol];
       const float v[4] = {c0.x + c1.x, c0.y + c1.y, c0.z + c1.z, c0.w + c1.w};
 #pragma unroll
@@ -458,7 +470,7 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
       const bool isq = pj < nq_ch;
       const int j = isq ? pj : pj - nq_ch;
       f32x4 c0 = zero, c1 = zero;
-      run_chunk(Ahat, CD / WK, c0, c1);
+      run_chunk_k128(Ahat, c0, c1);
       gf32 *C = isq ? a_Q : a_KV;
       const long ldc = isq ? a_ldq : a_ldkv;
       const float al = isq ? a_alpha_q : 1.0f;
