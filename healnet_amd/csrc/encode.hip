@@ -96,12 +96,32 @@ __global__ __launch_bounds__(256) void encode_token_kernel(const IN *__restrict_
   token_coords(n, g, idx);
   float v[LD];
   const IN *src = data + gid * g.C;
+  if (SC > 0) {
+    // static shapes: one sincosf per (axis, band) -- the argument reduction is shared -- instead of a sinf and a cosf of the same
+    // argument through pos_feature (whose per-column selects hide the pairing from the compiler)
 #pragma unroll
-  for (int c = 0; c < LD; ++c) {
-    float x = 0.0f;
-    if (c < g.C) x = in_at(src, c);
-    else if (c < g.D) x = pos_feature(c - g.C, idx, g);
-    v[c] = x;
+    for (int c = 0; c < LD; ++c) v[c] = c < SC ? in_at(src, c) : 0.0f;
+#pragma unroll
+    for (int a = 0; a < SA; ++a) {
+      const float p = axis_pos(idx[a], g.S[a]);
+#pragma unroll
+      for (int f = 0; f < SF; ++f) {
+        const float arg = __fmul_rn(__fmul_rn(p, band_scale(f, SF, g.max_freq)), 3.14159265358979323846f);  // (p*s)*pi, :299
+        float sn, cs;
+        sincosf(arg, &sn, &cs);
+        v[SC + a * (2 * SF + 1) + f] = sn;
+        v[SC + a * (2 * SF + 1) + SF + f] = cs;
+      }
+      v[SC + a * (2 * SF + 1) + 2 * SF] = p;
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < LD; ++c) {
+      float x = 0.0f;
+      if (c < g.C) x = in_at(src, c);
+      else if (c < g.D) x = pos_feature(c - g.C, idx, g);
+      v[c] = x;
+    }
   }
   if (g.normalize) {
     float sum = 0.0f;
