@@ -146,7 +146,10 @@ __global__ __launch_bounds__(256) void attn_core_kernel(AttnCoreArgs a, int ngro
 
   // one 16-token step on the (kf, vf) fragments; prefetches the following tile into (kn, vn)
   auto step = [&](int t0, float4 (&kf)[DT], float (&vf)[DT][4], float4 (&kn)[DT], float (&vn)[DT][4]) {
-    if (t0 + 16 < t_end) load_kv(t0 + 16, kn, vn);
+    // Unconditional: past the split the rows belong to the next split (read and never used), past the context they read 0
+    // through the descriptor.  Behind a branch the request count differs between the two paths into the join, and the
+    // compiler then waits vmcnt(0) -- for the prefetch it has just issued -- in front of the tile's first MFMA.
+    load_kv(t0 + 16, kn, vn);
     if (DROP && a.drop_rowsum) {       // shared-context binding under dropout: accumulator column DP-1 = sum_t p'_t, the row sum
       if (j == 15) {                    // of the THINNED probabilities (no longer 1), needed by the beta term of the values
 #pragma unroll
