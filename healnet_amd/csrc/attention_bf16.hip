@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void attn_core_bf16_kernel(AttnCoreBf16Args a,
 
   // one 32-token step on (kf, vf); prefetches the following step into (kn, vn)
   auto step = [&](int t0, f32x4 (&kf)[2][NKQ], f32x4 (&vf)[NS][DTV], f32x4 (&kn)[2][NKQ], f32x4 (&vn)[NS][DTV]) {
-    if (t0 + 32 < t_end) load_kv(t0 + 32, kn, vn);
+    load_kv(t0 + 32, kn, vn);     // unconditional (see attention.hip: behind a branch the compiler waits vmcnt(0) for it at once); rows past the end read 0
 
     f32x4 S[NQ][2];
 #pragma unroll
