@@ -102,7 +102,10 @@ __global__ __launch_bounds__(256) void attn_core_kernel(AttnCoreArgs a, int ngro
   bool unset = true;      // ONES: no unmasked token seen yet (wave-uniform)
   // ONES with a LayerNorm-ed context: the reference of every row is its Cauchy-Schwarz score bound (qfold_kernel), fixed for
   // the whole launch: no running max, no overflow guard, no rescale (wave-uniform switch; the flag is set on the device).
-  const bool bounded = ONES && a.bound != nullptr && *a.bound_flag == 0;
+  // kept as a scalar INTEGER: a bool carried into the loop comes back as v_cndmask / v_cmp pairs (i1 copies through a VGPR) in
+  // front of every branch on it -- VALU instructions in a loop where every VALU cycle is MFMA time lost
+  const int unbounded = (ONES && a.bound != nullptr) ? __builtin_amdgcn_readfirstlane(*a.bound_flag) : 1;
+  const bool bounded = unbounded == 0;
   if (bounded) {
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
@@ -203,15 +206,19 @@ __global__ __launch_bounds__(256) void attn_core_kernel(AttnCoreArgs a, int ngro
 #pragma unroll
         for (int r = 0; r < 4; ++r) P[i][r] = fast_exp2(S[i][r]);
       }
-      if (!bounded) {
+      // (one scalar branch on `bounded`: folded into the per-lane `need` it came back as v_cndmask / v_cmp pairs in front of two
+      // branches -- four VALU instructions per step in a loop where every VALU cycle is MFMA time lost)
+      bool rescale = false;
+      if (unbounded != 0) {
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
           ps0 += P[i][0] + P[i][2];
           ps1 += P[i][1] + P[i][3];
         }
+        const bool need = !(ps0 + ps1 <= 256.0f) || unset;
+        rescale = __any(need) && any_live;
       }
-      const bool need = !bounded && (!(ps0 + ps1 <= 256.0f) || unset);
-      if (__any(need) && any_live) {
+      if (rescale) {
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
           float tm = fmaxf(fmaxf(S[i][0], S[i][1]), fmaxf(S[i][2], S[i][3]));
