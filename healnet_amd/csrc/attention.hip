@@ -160,6 +160,7 @@ __global__ __launch_bounds__(256) void attn_core_kernel(AttnCoreArgs a, int ngro
       }
     }
     if (ONES && !a.ones_in_mem) {      // hn_fusion_forward has K1 write the ones column into z itself
+      asm volatile("" ::: "memory");   // keeps this a scalar BRANCH: if-converted it is five v_cndmask per step for every caller
       if (g == 3) kf[DT - 1].w = 1.0f;
       if (j == 15) {
 #pragma unroll
