@@ -80,10 +80,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a, int ngr
 #pragma unroll
   for (int r = 0; r < 4; ++r) kroff[r] = ((4 * g + r) * a.ldk + j) * 4;
 
-  for (int t0 = t_begin; t0 < t_end; t0 += 16) {
-    const int ks = t0 * a.ldk * 4, vs = t0 * a.ldv * 4;
-    float4 kf[DT], vf[DT];
-    float kr[DT][4];
+  // fragments of one 16-token tile: K (and V) rows j as A operands of the S / dP chains, K rows 4 g + r as the B operand of dQ.
+  // Rows past the context read 0 through the descriptors, so a request needs no guard.
+  // Narrow rows (dp <= 32: the shared-context image / volume bindings, 8-16 fragment registers per tile) keep TWO fragment sets:
+  // the next tile is requested -- unconditionally: a guarded request makes the compiler wait vmcnt(0) for it at once -- before
+  // the current one is multiplied.  Wider rows keep one set and rely on the resident waves (150 VGPRs already).
+  constexpr int NSET = DT <= 2 ? 2 : 1;
+  float4 kfs[NSET][DT], vfs[NSET][DT];
+  float krs_[NSET][DT][4];
+  auto load_frags = [&](int t, float4 (&kf)[DT], float4 (&vf)[DT], float (&kr)[DT][4]) {
+    const int ks = t * a.ldk * 4, vs = t * a.ldv * 4;
 #pragma unroll
     for (int s = 0; s < DT; ++s) {
       kf[s] = buf4s(krs, koff + 64 * s, ks);
@@ -93,6 +99,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a, int ngr
     for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int d = 0; d < DT; ++d) kr[d][r] = hn_buffer_load_x1(krs, kroff[r] + 64 * d, ks, 0);
+  };
+  if (NSET == 2) load_frags(t_begin, kfs[0], vfs[0], krs_[0]);
+  for (int tb = t_begin; tb < t_end; tb += 16 * NSET) {
+#pragma unroll
+  for (int ps = 0; ps < NSET; ++ps) {
+    const int t0 = tb + 16 * ps;
+    if (t0 >= t_end) break;
+    if (NSET == 2) load_frags(t0 + 16, kfs[ps ^ 1], vfs[ps ^ 1], krs_[ps ^ 1]);
+    else load_frags(t0, kfs[0], vfs[0], krs_[0]);
+    float4 (&kf)[DT] = kfs[ps];
+    float4 (&vf)[DT] = vfs[ps];
+    float (&kr)[DT][4] = krs_[ps];
 
     // S and dP start from -m and -D (persistent register quads) as the C operands of their MFMA chains, so the chains deliver
     // s - m and dP - D directly; 1/l is applied once to the finished dQ rows.  (With dropout dP must be thinned BEFORE D is
@@ -165,6 +183,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a, int ngr
 #pragma unroll
         for (int i = 0; i < NQ; ++i)
           dQ[i][d] = __builtin_amdgcn_mfma_f32_16x16x4f32(S[i][r], kr[d][r], dQ[i][d], 0, 0, 0);
+  }
   }
 
   const long prow = ((long)bh * a.nsplit + split) * a.Lp;
