@@ -105,20 +105,14 @@ __device__ __forceinline__ void lst4(lf32 *base, int off, const float4 &v) {
   *(lf32x4 *)(base + off) = t;
 }
 
-// SELU with expm1 split at -0.25: exp(x) - 1 below it (no cancellation there: exp(x) < 0.78, v_exp_f32), a degree-7 Taylor polynomial
-// above (remainder x^8 / 40320 < 4e-10 |x|); ocml's expm1f is ~4x the instructions and sat in the FF1 epilogue of every chunk.
+// SELU with expm1(x) as exp(x) - 1 (v_exp_f32): the absolute error is half an ulp of 1 (6e-8) for any x <= 0 -- what matters
+// here, since the result scales a value of O(1) that is summed into 512-term dot products; the RELATIVE accuracy that expm1
+// buys for |x| << 1 is below the rounding of those sums.  ocml's expm1f is ~40 instructions, a split polynomial form ~16; this
+// is 6, in an epilogue that runs once per 8 blocks on the VALU the MFMAs share.
 __device__ __forceinline__ float selu_f(float x) {
   const float alpha = 1.6732632423543772848170429916717f, scale = 1.0507009873554804934193349852946f;
-  const float xm = fminf(x, 0.0f);
-  const float e = __expf(xm) - 1.0f;
-  float p = fmaf(xm, 1.0f / 5040.0f, 1.0f / 720.0f);
-  p = fmaf(p, xm, 1.0f / 120.0f);
-  p = fmaf(p, xm, 1.0f / 24.0f);
-  p = fmaf(p, xm, 1.0f / 6.0f);
-  p = fmaf(p, xm, 0.5f);
-  p = fmaf(p, xm, 1.0f);
-  p *= xm;
-  return scale * (x > 0.0f ? x : alpha * (xm > -0.25f ? p : e));
+  const float e = __expf(fminf(x, 0.0f)) - 1.0f;
+  return scale * (x > 0.0f ? x : alpha * e);
 }
 // sum over the 32 lanes that share a row of the x tile (one half of a wave), delivered to all of them: four DPP steps inside each
 // row of 16 lanes and one swizzle across the two rows (__shfl_xor is a ds_bpermute each: ten of them sat in every LayerNorm)
