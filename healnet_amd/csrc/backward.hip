@@ -261,21 +261,40 @@ __global__ __launch_bounds__(256) void gemm_tn_lds_kernel(GemmTnArgs g) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       // rows past the slice: the descriptor's range check returns 0 (offsets stay below 2^31: checked by the launcher)
-      ra[h] = am < g.M ? hn_buffer_load_x4(ars, aoff + h * astep + slab * aslab, 0, 0) : (f32x4){0.f, 0.f, 0.f, 0.f};
-      rb[h] = bn < g.N ? hn_buffer_load_x4(brs, boff + h * bstep + slab * bslab, 0, 0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      // unconditional: a piece past M / N reads the next row (or 0 past the slice) and is zeroed by the edge masks below; a
+      // per-lane "load or 0" becomes a branch around every load with a full wait behind it
+      ra[h] = hn_buffer_load_x4(ars, aoff + h * astep + slab * aslab, 0, 0);
+      rb[h] = hn_buffer_load_x4(brs, boff + h * bstep + slab * bslab, 0, 0);
     }
   };
   // bias gradient sum_k A[k, m]: the loader threads of the first column tile add up what they stage (8 VALU adds per slab) --
   // ones-vector MFMAs in one wave of the tile would make that wave, and through the barrier the whole workgroup, 1.5x slower
   const bool do_colsum = g.colsum != nullptr && bn0 == 0;
   f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+  // The masks only matter in the last row / column tile, the column sum only in the first column tile: each behind a scalar
+  // branch (kept one by the empty asm), so that the interior tiles store what they loaded -- vector instructions in this loop
+  // are matrix time lost (the fp32 MFMA shares the SIMD's issue with the VALU)
+  const bool edge_a = bm0 + 128 > g.M, edge_b = bn0 + 128 > g.N;
   auto store = [&](int buf) {
+    if (edge_a) {
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int h = 0; h < 2; ++h) ra[h] = (f32x4){ra[h][0] * am0, ra[h][1] * am1, ra[h][2] * am2, ra[h][3] * am3};
+    }
+    if (edge_b) {
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int h = 0; h < 2; ++h) rb[h] = (f32x4){rb[h][0] * bn0m, rb[h][1] * bn1m, rb[h][2] * bn2m, rb[h][3] * bn3m};
+    }
+    if (do_colsum) {
+      asm volatile("" ::: "memory");
+      csum += ra[0];
+      csum += ra[1];
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const f32x4 av = (f32x4){ra[h][0] * am0, ra[h][1] * am1, ra[h][2] * am2, ra[h][3] * am3};
-      if (do_colsum) csum += av;
-      *(f32x4 *)&As[buf][(lr + 8 * h) * TNL_PITCH + lc] = av;
-      *(f32x4 *)&Bs[buf][(lr + 8 * h) * TNL_PITCH + lc] = (f32x4){rb[h][0] * bn0m, rb[h][1] * bn1m, rb[h][2] * bn2m, rb[h][3] * bn3m};
+      *(f32x4 *)&As[buf][(lr + 8 * h) * TNL_PITCH + lc] = ra[h];
+      *(f32x4 *)&Bs[buf][(lr + 8 * h) * TNL_PITCH + lc] = rb[h];
     }
   };
 
@@ -285,6 +304,7 @@ __global__ __launch_bounds__(256) void gemm_tn_lds_kernel(GemmTnArgs g) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   const bool wave_live = bm0 + wm < g.M && bn0 + wn < g.N;
+  const bool col1_live = bn0 + wn + 32 < g.N;
 
   if (nslabs > 0) { load(0); store(0); }
   __syncthreads();
@@ -293,14 +313,24 @@ __global__ __launch_bounds__(256) void gemm_tn_lds_kernel(GemmTnArgs g) {
     if (sl + 1 < nslabs) load(sl + 1);
     if (wave_live) {
       const float *ap = &As[buf][half * TNL_PITCH + wm + col], *bp = &Bs[buf][half * TNL_PITCH + wn + col];
+      // two fragment sets: the operands of k-pair kk + 2 are requested before the four MFMAs of pair kk (pinned: left alone
+      // the reads sit right in front of their MFMAs and every group of four starts with an exposed LDS round trip)
+      float fa[2][2], fb[2][2];
+      fa[0][0] = ap[0]; fa[0][1] = ap[32]; fb[0][0] = bp[0]; fb[0][1] = bp[32];
 #pragma unroll
       for (int kk = 0; kk < TNL_BK; kk += 2) {
-        const float a0 = ap[kk * TNL_PITCH], a1 = ap[kk * TNL_PITCH + 32];
-        const float b0 = bp[kk * TNL_PITCH], b1 = bp[kk * TNL_PITCH + 32];
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        const int cur = (kk >> 1) & 1, nxt = cur ^ 1;
+        if (kk + 2 < TNL_BK) {
+          fa[nxt][0] = ap[(kk + 2) * TNL_PITCH]; fa[nxt][1] = ap[(kk + 2) * TNL_PITCH + 32];
+          fb[nxt][0] = bp[(kk + 2) * TNL_PITCH]; fb[nxt][1] = bp[(kk + 2) * TNL_PITCH + 32];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][0], fb[cur][0], acc[0][0], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][1], fb[cur][0], acc[1][0], 0, 0, 0);
+        if (col1_live) {                      // wave-uniform: the second 32 columns of a ragged last column tile (773 = 6 * 128 + 5) are empty
+          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][0], fb[cur][1], acc[0][1], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][1], fb[cur][1], acc[1][1], 0, 0, 0);
+        }
       }
     }
     if (sl + 1 < nslabs) store(buf ^ 1);
