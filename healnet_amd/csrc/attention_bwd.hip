@@ -306,27 +306,45 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs a, int nt
 #pragma unroll
   for (int d = 0; d < DT; ++d) { dK[d] = (f32x4){0.f, 0.f, 0.f, 0.f}; dV[d] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
+  // Per-lane byte offsets of every fragment are loop invariant; the query tile advances in the SGPR offset of the buffer loads
+  // and the row statistics come through descriptors too (rows past L read 0): no vector instruction computes an address in
+  // the loop, and 1 / l is a v_rcp_f32 (1 ulp) instead of a division (ten instructions), masked only in a ragged last tile.
+  // Every vector instruction here is matrix time lost (the fp32 MFMA shares the SIMD's issue with the VALU).
+  const int qa_off = (j * a.ldq + 4 * g) * 4, ga_off = (j * a.lddo + 4 * g) * 4;
+  int qb_off[4], gb_off[4], st_off[4], dl_off[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    qb_off[r] = ((4 * g + r) * a.ldq + j) * 4;
+    gb_off[r] = ((4 * g + r) * a.lddo + j) * 4;
+    st_off[r] = (4 * g + r) * 8;
+    dl_off[r] = (4 * g + r) * 4;
+  }
+  const i32x4 rsS = make_rsrc(a.stats + (long)bh * L * 2, (unsigned)L * 8u);
+  const i32x4 rsD = make_rsrc(a.delta + (long)bh * L, (unsigned)L * 4u);
   for (int q0 = 0; q0 < L; q0 += 16) {
     float4 qa[DT], ga[DT];                       // A operands: lane (g, i = q) holds Q[q][16 s + 4 g ..]
     float qb[DT][4], gb[DT][4];                  // B operands of the second products: rows 4 g + r, column 16 d + j
+    const int qs = q0 * a.ldq * 4, gs = q0 * a.lddo * 4;
 #pragma unroll
     for (int s = 0; s < DT; ++s) {
-      qa[s] = buf4(rsQ, ((q0 + j) * a.ldq + 16 * s + 4 * g) * 4);
-      ga[s] = buf4(rsG, ((q0 + j) * a.lddo + 16 * s + 4 * g) * 4);
+      qa[s] = buf4s(rsQ, qa_off + 64 * s, qs);
+      ga[s] = buf4s(rsG, ga_off + 64 * s, gs);
     }
     float mr[4], il[4], dl[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int q = q0 + 4 * g + r;
 #pragma unroll
       for (int d = 0; d < DT; ++d) {
-        qb[d][r] = hn_buffer_load_x1(rsQ, (q * a.ldq + 16 * d + j) * 4, 0, 0);
-        gb[d][r] = hn_buffer_load_x1(rsG, (q * a.lddo + 16 * d + j) * 4, 0, 0);
+        qb[d][r] = hn_buffer_load_x1(rsQ, qb_off[r] + 64 * d, qs, 0);
+        gb[d][r] = hn_buffer_load_x1(rsG, gb_off[r] + 64 * d, gs, 0);
       }
-      const int qc = min(q, L - 1);
-      mr[r] = a.stats[((long)bh * L + qc) * 2 + 0];
-      il[r] = q < L ? 1.0f / a.stats[((long)bh * L + qc) * 2 + 1] : 0.0f;      // rows past L contribute nothing
-      dl[r] = a.delta[(long)bh * L + qc];
+      mr[r] = hn_buffer_load_x1(rsS, st_off[r], q0 * 8, 0);
+      il[r] = __builtin_amdgcn_rcpf(hn_buffer_load_x1(rsS, st_off[r] + 4, q0 * 8, 0));
+      dl[r] = hn_buffer_load_x1(rsD, dl_off[r], q0 * 4, 0);
+    }
+    if (q0 + 16 > L) {                           // ragged last tile (wave-uniform): rows past L contribute nothing (their l read 0)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) il[r] = q0 + 4 * g + r < L ? il[r] : 0.0f;
     }
     f32x4 S = {0.f, 0.f, 0.f, 0.f}, dP = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
