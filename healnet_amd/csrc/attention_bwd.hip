@@ -82,10 +82,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a, int ngr
 
   // fragments of one 16-token tile: K (and V) rows j as A operands of the S / dP chains, K rows 4 g + r as the B operand of dQ.
   // Rows past the context read 0 through the descriptors, so a request needs no guard.
-  // Narrow rows (dp <= 32: the shared-context image / volume bindings, 8-16 fragment registers per tile) keep TWO fragment sets:
-  // the next tile is requested -- unconditionally: a guarded request makes the compiler wait vmcnt(0) for it at once -- before
-  // the current one is multiplied.  Wider rows keep one set and rely on the resident waves (150 VGPRs already).
-  constexpr int NSET = DT <= 2 ? 2 : 1;
+  // TWO fragment sets: the next tile is requested -- unconditionally: a guarded request makes the compiler wait vmcnt(0) for it at
+  // once -- before the current one is multiplied.  Measured per launch: dp = 16 (cfg2 image, N = 50 176) 1143 -> 1073 us;
+  // dp = 64 (cfg4 patch bag, N = 4096: 48 more VGPRs, three -> two resident waves) 184 -> 132 us.
+  constexpr int NSET = 2;
   float4 kfs[NSET][DT], vfs[NSET][DT];
   float krs_[NSET][DT][4];
   auto load_frags = [&](int t, float4 (&kf)[DT], float4 (&vf)[DT], float (&kr)[DT][4]) {
