@@ -173,9 +173,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a, int ngr
       }
     }
 #pragma unroll
-    for (int i = 0; i < NQ; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) S[i][r] = fexp2(S[i][r]) * dP[i][r];       // l * dS  (2^-inf = 0 kills invalid tokens)
+    for (int i = 0; i < NQ; ++i) {          // l * dS  (2^-inf = 0 kills invalid tokens); the product as a vector op: two v_pk_mul_f32
+      const f32x4 e = {fexp2(S[i][0]), fexp2(S[i][1]), fexp2(S[i][2]), fexp2(S[i][3])};
+      S[i] = e * dP[i];
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
