@@ -881,7 +881,7 @@ static int plan_fusion(const hn_model *m, const hn_modality_input *in, int b, vo
     // per-block launches faster below ~160 workgroups.  Measured at cfg2 (l_c = 128) since, chain vs per-block launches, ms per
     // forward: b = 1 0.851 / 0.848, 2: 0.820 / 0.822, 4: 0.908 / 0.915, 8: 1.193 / 1.212, 16: 1.740 / 1.830, 24: 2.435 / 2.605,
     // 32: 2.911 / 3.205 -- no crossover left, the chain is the route whenever its shapes apply (HN_NO_CHAIN=1: development switch).
-    fp->chain = inference && latent_chain_supported(b * m->l_c, m->l_d, 4 * m->l_d) && m->l_c % 16 == 0;
+    fp->chain = latent_chain_supported(b * m->l_c, m->l_d, 4 * m->l_d) && m->l_c % 16 == 0;      // both forwards (the training one keeps x_mid)
     fp->cq = fp->ckv = nullptr;
     if (fp->chain) {
       fp->cq = ar.take<float>((size_t)b * m->l_c * max_inner);
@@ -1475,26 +1475,101 @@ int hn_fusion_forward_train(const hn_model *m, const hn_modality_input *in, int 
       return rc;
   }
   if ((rc = launch_broadcast_rows(m->latents, T + tp.x_off[0], (long)L * d, b, s)) != HN_OK) return rc;
-  for (int k = 0; k < tp.nsteps; ++k) {
+  static const bool chain_off_t = getenv("HN_NO_CHAIN") != nullptr;
+  const bool use_chain = fp.chain && !chain_off_t;
+  auto is_attn_t = [](const Step &q) { return q.kind == STEP_CROSS_ATTN || q.kind == STEP_SELF_ATTN; };
+  auto trace_copies = [&](int k) -> int {       // optional copies for hn_attn_probs (same slots as hn_fusion_forward)
+    const Step &st = tp.steps[k];
+    const int slot = st.layer * (M + 1) + (st.kind == STEP_CROSS_ATTN ? st.m : M);
+    const int heads = st.kind == STEP_CROSS_ATTN ? m->cross_attn[st.layer * M + st.m].heads : m->self_attn[st.layer].heads;
+    if (attn_stats && attn_stats[slot])
+      { int rc_ = launch_copy(attn_stats[slot], T + tp.stats_off[k], (long)((size_t)b * heads * L * 2), s); if (rc_ != HN_OK) return rc_; }
+    if (x_trace && x_trace[slot])
+      { int rc_ = launch_copy(x_trace[slot], T + tp.x_off[k], (long)((size_t)b * L * d), s); if (rc_ != HN_OK) return rc_; }
+    return HN_OK;
+  };
+  bool q_done = false, kv_done = false;          // projections of the attention block at `k` already produced by the chain in front of it
+  for (int k = 0; k < tp.nsteps;) {
     const Step &st = tp.steps[k];
     const float *xin = T + tp.x_off[k];
     float *xout = T + tp.x_off[k + 1];
     // dropout: one generator state per forward (hn_model.rng), one stream id per executed block (its step index)
     const hn_rng rng = {m->rng.seed, m->rng.offset, (uint32_t)k};
+    // The latent chain behind an attention block, as in hn_fusion_forward (out-projection + residual, the feed-forward block,
+    // the projections of the attention block after it), with the feed-forward block's input kept on the tape (x_mid): the
+    // backward recomputes everything else of these blocks from the tape as before.  Not with feed-forward dropout, not behind
+    // the one-token shortcut.
+    bool fuse = false;
+    if (use_chain && is_attn_t(st) && k + 1 < tp.nsteps && !is_attn_t(tp.steps[k + 1])) {
+      const Step &sf = tp.steps[k + 1];
+      const hn_ff_params &fq = sf.kind == STEP_CROSS_FF ? m->cross_ff[sf.layer * M + sf.m] : m->self_ff[sf.layer];
+      const hn_attn_params &aq = st.kind == STEP_SELF_ATTN ? m->self_attn[st.layer] : m->cross_attn[st.layer * M + st.m];
+      const int inner = aq.heads * aq.dim_head;
+      fuse = fq.dim == d && fq.dropout == 0.0f && aq.query_dim == d && inner % 128 == 0 && inner <= 512 &&
+             !(st.kind == STEP_CROSS_ATTN && fp.N[st.m] == 1 && mask == nullptr);
+    }
+    if (fuse) {
+      const bool self = st.kind == STEP_SELF_ATTN;
+      hn_attn_params ap = self ? m->self_attn[st.layer] : m->cross_attn[st.layer * M + st.m];
+      ap.rng = rng;
+      AttnExt ext = {fp.cq, fp.ckv, q_done, kv_done, true, nullptr, 0};
+      if (self)
+        rc = attn_fwd_impl(&ap, xin, nullptr, 1, nullptr, 0, b, L, L, d, nullptr, T + tp.stats_off[k], fp.op_ws, fp.op_ws_bytes, s,
+                           nullptr, nullptr, T + tp.saved_off[k], false, 0, nullptr, nullptr, &ext);
+      else
+        rc = attn_fwd_impl(&ap, xin, nullptr, 1, fp.z[st.m], fp.ldz[st.m], b, L, fp.N[st.m], fp.D[st.m], mask, T + tp.stats_off[k],
+                           fp.op_ws, fp.op_ws_bytes, s, nullptr, nullptr, T + tp.saved_off[k], tones[st.m], tpack[st.m], nullptr, nullptr,
+                           &ext);
+      if (rc != HN_OK) return rc;
+      HN_REQUIRE(ext.o_out != nullptr, HN_E_UNSUPPORTED, "fusion_forward_train: attention block did not defer its out-projection");
+      const Step &sf = tp.steps[k + 1];
+      const hn_ff_params &fq = sf.kind == STEP_CROSS_FF ? m->cross_ff[sf.layer * M + sf.m] : m->self_ff[sf.layer];
+      HN_REQUIRE(fq.w1 && fq.b1 && fq.w2 && fq.b2, HN_E_NULL, "ff: weight pointer is NULL");
+      ChainArgs ca;
+      memset(&ca, 0, sizeof(ca));
+      ca.rows = b * L; ca.L = L; ca.x_in = xin;
+      ca.head = 1; ca.O = ext.o_out; ca.ldo = ext.ldo_out; ca.inner_o = ap.heads * ap.dim_head; ca.w_out = ap.w_out; ca.b_out = ap.b_out;
+      ca.has_ff = 1; ca.gate = fq.gate; ca.f_nw = fq.norm_w; ca.f_nb = fq.norm_b;
+      ca.w1 = fq.w1; ca.b1 = fq.b1; ca.w2 = fq.w2; ca.b2 = fq.b2;
+      ca.x_mid = xout;
+      ca.x_out = T + tp.x_off[k + 2];
+      q_done = kv_done = false;
+      if (k + 2 < tp.nsteps && is_attn_t(tp.steps[k + 2])) {
+        const Step &sn = tp.steps[k + 2];
+        const bool nself = sn.kind == STEP_SELF_ATTN;
+        const hn_attn_params *an = nself ? &m->self_attn[sn.layer] : &m->cross_attn[sn.layer * M + sn.m];
+        AttnPlan pn;
+        if ((rc = plan_attn(an, !nself, nself ? 0 : fp.ldz[sn.m], b, L, nself ? L : fp.N[sn.m], nself ? d : fp.D[sn.m], nullptr, 0, &pn)) != HN_OK) return rc;
+        const bool one_token = !nself && fp.N[sn.m] == 1 && mask == nullptr && !(an->dropout > 0.0f);
+        if (!one_token && pn.dh == pn.dhp && pn.inner % 128 == 0 && an->query_dim == d && an->w_q && an->w_kv) {
+          ca.p_nw = an->norm_w; ca.p_nb = an->norm_b;
+          ca.nq = pn.inner; ca.wq = an->w_q; ca.Q = fp.cq; ca.ldq = pn.inner;
+          ca.alpha_q = pn.rank_d ? 1.0f : pn.cscale;
+          q_done = true;
+          if (nself) { ca.nkv = 2 * pn.inner; ca.wkv = an->w_kv; ca.KV = fp.ckv; ca.ldkv = 2 * pn.inner; kv_done = true; }
+        }
+      }
+      if ((rc = launch_latent_chain(ca, s)) != HN_OK) return rc;
+      if ((rc = trace_copies(k)) != HN_OK) return rc;
+      k += 2;
+      continue;
+    }
+    AttnExt ext = {fp.cq, fp.ckv, q_done, kv_done, false, nullptr, 0};
+    AttnExt *extp = (q_done || kv_done) ? &ext : nullptr;
     switch (st.kind) {
       case STEP_CROSS_ATTN: {
         hn_attn_params ap = m->cross_attn[st.layer * M + st.m];
         ap.rng = rng;
         rc = attn_fwd_impl(&ap, xin, xout, 1, fp.z[st.m], fp.ldz[st.m], b, L, fp.N[st.m], fp.D[st.m],
                            mask, T + tp.stats_off[k], fp.op_ws, fp.op_ws_bytes, s, nullptr, nullptr, T + tp.saved_off[k],
-                           tones[st.m], tpack[st.m]);
+                           tones[st.m], tpack[st.m], nullptr, nullptr, extp);
         break;
       }
       case STEP_SELF_ATTN: {
         hn_attn_params ap = m->self_attn[st.layer];
         ap.rng = rng;
         rc = attn_fwd_impl(&ap, xin, xout, 1, nullptr, 0, b, L, L, d, nullptr, T + tp.stats_off[k], fp.op_ws,
-                           fp.op_ws_bytes, s, nullptr, nullptr, T + tp.saved_off[k]);
+                           fp.op_ws_bytes, s, nullptr, nullptr, T + tp.saved_off[k], false, 0, nullptr, nullptr, extp);
         break;
       }
       default: {
@@ -1505,14 +1580,11 @@ int hn_fusion_forward_train(const hn_model *m, const hn_modality_input *in, int 
       }
     }
     if (rc != HN_OK) return rc;
-    if (st.kind == STEP_CROSS_ATTN || st.kind == STEP_SELF_ATTN) {     // optional copies for hn_attn_probs (same slots as hn_fusion_forward)
-      const int slot = st.layer * (M + 1) + (st.kind == STEP_CROSS_ATTN ? st.m : M);
-      const int heads = st.kind == STEP_CROSS_ATTN ? m->cross_attn[st.layer * M + st.m].heads : m->self_attn[st.layer].heads;
-      if (attn_stats && attn_stats[slot])
-        { int rc_ = launch_copy(attn_stats[slot], T + tp.stats_off[k], (long)((size_t)b * heads * L * 2), s); if (rc_ != HN_OK) return rc_; }
-      if (x_trace && x_trace[slot])
-        { int rc_ = launch_copy(x_trace[slot], xin, (long)((size_t)b * L * d), s); if (rc_ != HN_OK) return rc_; }
+    if (is_attn_t(st)) {
+      if ((rc = trace_copies(k)) != HN_OK) return rc;
+      q_done = kv_done = false;
     }
+    ++k;
   }
   const float *xf = T + tp.x_off[tp.nsteps];
   if (m->final_classifier_head && !return_embeddings)

@@ -158,6 +158,7 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
   const gf32 *const a_p_nw = (const gf32 *)args.p_nw;
   const gf32 *const a_p_nb = (const gf32 *)args.p_nb;
   gf32 *const a_x_out = (gf32 *)args.x_out;
+  gf32 *const a_x_mid = (gf32 *)args.x_mid;
   gf32 *const a_Q = (gf32 *)args.Q;
   gf32 *const a_KV = (gf32 *)args.KV;
   const int a_L = args.L;
@@ -410,6 +411,12 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
   }
   CHAIN_PROF(3);
 
+  // ---- training: the feed-forward block's input goes to the tape (the backward recomputes the block from it)
+  if (a_x_mid) {
+    const int row = tid >> 5, l32 = tid & 31;
+    gst4_nt(a_x_mid + (long)(m0 + row) * CD + 4 * l32, lld4(lds, xs + row * XP + 4 * l32));
+  }
+
   // ================= stages FF1 / FF2: x += (a * gate(g)) W2^T + b2,  [a | g] = LN(x) W1^T + b1 =================
   if (a_has_ff) {
     layer_norm(a_f_nw != nullptr, p_fnw, p_fnb);
@@ -517,7 +524,7 @@ int launch_latent_chain(const ChainArgs &a, hipStream_t s) {
   HN_REQUIRE(a.nq >= 0 && a.nkv >= 0 && a.nq % WN == 0 && a.nkv % WN == 0, HN_E_SHAPE, "latent_chain: nq=%d nkv=%d", a.nq, a.nkv);
   HN_REQUIRE(a.nq == 0 || (a.wq && a.Q && al16(a.wq)), HN_E_NULL, "latent_chain: Q projection operand is NULL");
   HN_REQUIRE(a.nkv == 0 || (a.wkv && a.KV && al16(a.wkv)), HN_E_NULL, "latent_chain: KV projection operand is NULL");
-  HN_REQUIRE(al16(a.x_in) && (!a.x_out || al16(a.x_out)) && (!a.p_nw || (al16(a.p_nw) && al16(a.p_nb))), HN_E_SHAPE,
+  HN_REQUIRE(al16(a.x_in) && (!a.x_out || al16(a.x_out)) && (!a.x_mid || al16(a.x_mid)) && (!a.p_nw || (al16(a.p_nw) && al16(a.p_nb))), HN_E_SHAPE,
              "latent_chain: unaligned operand");
   // one-time opt-in per device to > 64 KB of dynamic LDS (a function attribute; setting it twice is harmless, so no lock)
   static bool configured[64] = {};

@@ -232,6 +232,7 @@ int launch_gemm_skinny_multi(const GemmSkinnyMulti &g, hipStream_t s);
 struct ChainArgs {
   int rows, L;                          // b * l_c rows of width 128 (16 per workgroup); l_c rows per sample
   const float *x_in; float *x_out;      // (rows, 128); x_out may be NULL or alias x_in
+  float *x_mid;                         // training: x after the head stage (the feed-forward block's input) is kept on the tape; NULL otherwise
   int head;                             // 0: x = x_in; 1: x = x_in + LeakyReLU(O W_out^T + b_out); 2: x = x_in + y[row / L]
   const float *O; int ldo, inner_o;     // head 1: merged attention output (rows, inner_o), inner_o a multiple of 32, <= 512
   const float *w_out, *b_out;           //         to_out.0.weight (128, inner_o), to_out.0.bias
