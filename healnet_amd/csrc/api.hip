@@ -1748,7 +1748,8 @@ int hn_latent_block_fwd(const hn_attn_params *attn, const hn_ff_params *ff, cons
   const int d = attn->query_dim;
   const bool training = saved != nullptr;        // the training form keeps x_mid / stats / saved for hn_latent_block_bwd
   HN_REQUIRE(!training || (x_mid && stats), HN_E_NULL, "latent_block: the training form needs x_mid and stats");
-  if (!lp.chain || training) {                   // unfused: the two blocks back to back (any shape; dropout; tape)
+  const bool drops = training && (attn->dropout > 0.0f || ff->dropout > 0.0f);
+  if (!lp.chain || drops) {                      // unfused: the two blocks back to back (any shape; dropout)
     float *mid = x_mid ? x_mid : lp.xmid;
     if ((rc = attn_fwd_impl(attn, x_in, mid, 1, nullptr, 0, b, L, L, d, nullptr, stats, lp.op, lp.op_bytes, s, nullptr, nullptr, saved)) != HN_OK)
       return rc;
@@ -1765,11 +1766,12 @@ int hn_latent_block_fwd(const hn_attn_params *attn, const hn_ff_params *ff, cons
   c1.nkv = 2 * pl.inner; c1.wkv = attn->w_kv; c1.KV = lp.kv; c1.ldkv = 2 * pl.inner;
   if ((rc = launch_latent_chain(c1, s)) != HN_OK) return rc;
   AttnExt ext = {lp.q, lp.kv, true, true, true, nullptr, 0};
-  if ((rc = attn_fwd_impl(attn, x_in, nullptr, 1, nullptr, 0, b, L, L, d, nullptr, stats, lp.op, lp.op_bytes, s, nullptr, nullptr, nullptr,
+  // (training: O is produced in `saved`, the feed-forward block's input is written to x_mid by the second chain)
+  if ((rc = attn_fwd_impl(attn, x_in, nullptr, 1, nullptr, 0, b, L, L, d, nullptr, stats, lp.op, lp.op_bytes, s, nullptr, nullptr, saved,
                           false, 0, nullptr, nullptr, &ext)) != HN_OK) return rc;
   ChainArgs c2;                                   // x_out = x1 + FF(LN x1), x1 = x + LeakyReLU(O W_out^T + b_out)
   memset(&c2, 0, sizeof(c2));
-  c2.rows = b * L; c2.L = L; c2.x_in = x_in; c2.x_out = x_out;
+  c2.rows = b * L; c2.L = L; c2.x_in = x_in; c2.x_out = x_out; c2.x_mid = x_mid;
   c2.head = 1; c2.O = ext.o_out; c2.ldo = ext.ldo_out; c2.inner_o = pl.inner; c2.w_out = attn->w_out; c2.b_out = attn->b_out;
   HN_REQUIRE(ff->w1 && ff->b1 && ff->w2 && ff->b2, HN_E_NULL, "ff: weight pointer is NULL");
   c2.has_ff = 1; c2.gate = ff->gate; c2.f_nw = ff->norm_w; c2.f_nb = ff->norm_b; c2.w1 = ff->w1; c2.b1 = ff->b1; c2.w2 = ff->w2; c2.b2 = ff->b2;
