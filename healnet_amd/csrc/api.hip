@@ -114,6 +114,12 @@ struct AttnExt {
   bool q_done, kv_done;
   bool defer_out;
   const float *o_out; int ldo_out;
+  // shared-context (rank-D) block in front of a chain that can merge the split partials itself (ChainArgs.head == 3): the
+  // block stops behind its core and reports the partials instead of running merge_vproj_kernel
+  bool allow_defer_merge;
+  bool merge_deferred;
+  const float *opart, *mpart, *lpart;
+  int nsplit, Lp, dp;
 };
 
 static int check_ws(void *ws, size_t ws_bytes, size_t need, const char *who) {
@@ -310,6 +316,13 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
   if (ev0) HN_HIP_CHECK(hipEventRecord(ev0, s));
   if ((rc = launch_attn_core(core, s)) != HN_OK) return rc;
   if (ev1) HN_HIP_CHECK(hipEventRecord(ev1, s));
+  if (pl.rank_d && ext && ext->defer_out && ext->allow_defer_merge && !o_save && !dropping && pl.ones && pl.dp == 16 &&
+      pl.nsplit <= CHAIN_MERGE_MAX_SPLITS && p->heads <= 8 && (pl.dh == 16 || pl.dh == 32 || pl.dh == 64) && L % 16 == 0) {
+    ext->merge_deferred = true;
+    ext->opart = pl.opart; ext->mpart = pl.mpart; ext->lpart = pl.lpart;
+    ext->nsplit = pl.nsplit; ext->Lp = pl.Lp; ext->dp = pl.dp;
+    return HN_OK;
+  }
   if (pl.rank_d) {
     rc = launch_merge_vproj(pl.opart, pl.mpart, pl.lpart, pl.nsplit, b, p->heads, L, pl.Lp, pl.dp, pl.D, p->ctx_gamma,
                             p->ctx_beta, p->w_kv + (long)pl.inner * pl.D, pl.dh, pl.obuf, pl.inner, stats, o_save, s, pack_ks, srow);
@@ -748,6 +761,7 @@ struct FusionPlan {
   float *z[16];
   int ldz[16], N[16], D[16];
   bool ones[16];   // z carries the synthetic ones column (rank-D pitch with a free last column)
+  float *wvf[16];  // inference: folded value projections of all layers (depth, inner, 16) for the chain's merge head, or NULL
   int pack[16];    // ... and uses the packed channel layout with this many QK^T k-steps (0 = natural)
   bool bf16[16];   // core_precision = bf16: z holds the bf16 images (zb, then zT) instead of the fp32 rows
   int Np[16], ns[16];
@@ -810,6 +824,18 @@ static int plan_fusion(const hn_model *m, const hn_modality_input *in, int b, vo
       fp->ones[i] = pl.rank_d && pl.ones;
     }
     fp->pack[i] = fp->ones[i] ? packed_steps(fp->D[i], fp->ldz[i]) : 0;
+    // the chain behind a shared-context block can merge its split partials itself when the folded value projections of the
+    // modality's layers are staged up front (one launch per forward): dp = 16, equal heads / dim_head over the layers
+    fp->wvf[i] = nullptr;
+    if (inference && fp->ones[i] && fp->ldz[i] == 16 && m->depth <= HN_SKINNY_MAXZ) {
+      const hn_attn_params &a0 = m->cross_attn[i];
+      bool ok = a0.heads <= 8 && (a0.dim_head == 16 || a0.dim_head == 32 || a0.dim_head == 64) && a0.ctx_gamma != nullptr;
+      for (int layer = 1; layer < m->depth && ok; ++layer) {
+        const hn_attn_params &al = m->cross_attn[layer * m->n_modalities + i];
+        ok = al.heads == a0.heads && al.dim_head == a0.dim_head && al.ctx_gamma != nullptr;
+      }
+      if (ok) fp->wvf[i] = ar.take<float>((size_t)m->depth * a0.heads * a0.dim_head * 16);
+    }
     // One workspace size serves the inference forward (which may use the bf16 core) and the training forward / backward
     // (always fp32) of the same model: size for the larger of the two layouts.
     const bool want_bf16 = (m->core_precision == HN_CORE_BF16 || m->core_precision == HN_CORE_BF16X3) && fp->ones[i] && n > 1;
@@ -819,7 +845,7 @@ static int plan_fusion(const hn_model *m, const hn_modality_input *in, int b, vo
                "fusion: modality %d dtype=%d", i, in[i].dtype);
     fp->bf16[i] = want_bf16 && inference;
     fp->Np[i] = (int)((n + 31) / 32 * 32);
-    if (fp->bf16[i]) fp->pack[i] = 0;
+    if (fp->bf16[i]) { fp->pack[i] = 0; fp->wvf[i] = nullptr; }
     size_t zbytes = (size_t)b * n * fp->ldz[i] * sizeof(float);
     if (want_bf16) {
       const size_t zb16 = (size_t)b * fp->Np[i] * (bf16_row_slots(fp->ldz[i], ns) + ns * fp->ldz[i]) * sizeof(uint16_t);
@@ -1288,6 +1314,27 @@ int hn_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, con
     tab_ready[i] = true;
   }
 
+  // folded value projections for the chains that merge the split partials of a shared-context block themselves (one launch per
+  // modality and forward; only when the chain is the route)
+  static const bool merge_chain_off = getenv("HN_NO_MERGE_CHAIN") != nullptr;      // development switch: merge_vproj_kernel instead
+  bool vmerge[16];
+  for (int i = 0; i < M; ++i) {
+    vmerge[i] = false;
+    if (!in[i].data || !fp.wvf[i] || !fp.chain || merge_chain_off || getenv("HN_NO_CHAIN") != nullptr) continue;
+    VfoldMulti vf;
+    memset(&vf, 0, sizeof(vf));
+    const hn_attn_params &a0 = m->cross_attn[i];
+    vf.n = m->depth; vf.D = fp.D[i]; vf.heads = a0.heads; vf.dh = a0.dim_head; vf.pack_ks = fp.pack[i];
+    vf.out = fp.wvf[i]; vf.out_stride = (long)a0.heads * a0.dim_head * 16;
+    for (int layer = 0; layer < m->depth; ++layer) {
+      const hn_attn_params &al = m->cross_attn[layer * M + i];
+      HN_REQUIRE(al.w_kv, HN_E_NULL, "attn: weight pointer is NULL");
+      vf.w_v[layer] = al.w_kv + (long)al.heads * al.dim_head * fp.D[i]; vf.gamma[layer] = al.ctx_gamma; vf.beta[layer] = al.ctx_beta;
+    }
+    if ((rc = launch_vfold(vf, s)) != HN_OK) return rc;
+    vmerge[i] = true;
+  }
+
   // The latent array moves through a chain of buffers instead of being updated in place: the block in front of an
   // attention block writes straight into that block's x_trace slot (the input hn_attn_probs re-reads later), so
   // keeping the trace costs no copy.  Without trace slots every block works in place on fp.x as before.
@@ -1351,7 +1398,7 @@ int hn_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, con
       float *dst = input_buffer(k + 1);
       if (is_tab(st)) rc = launch_add_row_broadcast(fp.taby[st.m] + (size_t)st.layer * b * ap->query_dim, cur, dst, b, L, ap->query_dim, s);
       else {
-        AttnExt ext = {fp.cq, fp.ckv, q_done, kv_done, false, nullptr, 0};
+        AttnExt ext = {fp.cq, fp.ckv, q_done, kv_done, false, nullptr, 0, false, false, nullptr, nullptr, nullptr, 0, 0, 0};
         rc = run_attn(st, cur, dst, (q_done || kv_done) ? &ext : nullptr);
       }
       if (rc != HN_OK) return rc;
@@ -1364,9 +1411,18 @@ int hn_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, con
     if (is_tab(st)) {
       ca.head = 2; ca.y = fp.taby[st.m] + (size_t)st.layer * b * ap->query_dim;
     } else {
-      AttnExt ext = {fp.cq, fp.ckv, q_done, kv_done, true, nullptr, 0};
+      AttnExt ext = {fp.cq, fp.ckv, q_done, kv_done, true, nullptr, 0, false, false, nullptr, nullptr, nullptr, 0, 0, 0};
+      ext.allow_defer_merge = st.kind == STEP_CROSS_ATTN && vmerge[st.m];
       if ((rc = run_attn(st, cur, nullptr, &ext)) != HN_OK) return rc;
-      ca.head = 1; ca.O = ext.o_out; ca.ldo = ext.ldo_out; ca.inner_o = inner; ca.w_out = ap->w_out; ca.b_out = ap->b_out;
+      ca.inner_o = inner; ca.w_out = ap->w_out; ca.b_out = ap->b_out;
+      if (ext.merge_deferred) {              // the chain merges the core's split partials and applies the value projection itself
+        ca.head = 3; ca.Opart = ext.opart; ca.Mpart = ext.mpart; ca.Lpart = ext.lpart;
+        ca.nsplit = ext.nsplit; ca.Lp = ext.Lp; ca.dp = ext.dp; ca.heads = ap->heads; ca.dh = ap->dim_head;
+        ca.wvf = fp.wvf[st.m] + (size_t)st.layer * ap->heads * ap->dim_head * 16;
+        ca.stats = attn_stats ? attn_stats[slot_of(st)] : nullptr;
+      } else {
+        ca.head = 1; ca.O = ext.o_out; ca.ldo = ext.ldo_out;
+      }
     }
     const hn_ff_params *fpar = ff_of(steps[k + 1]);
     HN_REQUIRE(fpar->w1 && fpar->b1 && fpar->w2 && fpar->b2, HN_E_NULL, "ff: weight pointer is NULL");
@@ -1512,7 +1568,7 @@ int hn_fusion_forward_train(const hn_model *m, const hn_modality_input *in, int 
       const bool self = st.kind == STEP_SELF_ATTN;
       hn_attn_params ap = self ? m->self_attn[st.layer] : m->cross_attn[st.layer * M + st.m];
       ap.rng = rng;
-      AttnExt ext = {fp.cq, fp.ckv, q_done, kv_done, true, nullptr, 0};
+      AttnExt ext = {fp.cq, fp.ckv, q_done, kv_done, true, nullptr, 0, false, false, nullptr, nullptr, nullptr, 0, 0, 0};
       if (self)
         rc = attn_fwd_impl(&ap, xin, nullptr, 1, nullptr, 0, b, L, L, d, nullptr, T + tp.stats_off[k], fp.op_ws, fp.op_ws_bytes, s,
                            nullptr, nullptr, T + tp.saved_off[k], false, 0, nullptr, nullptr, &ext);
@@ -1554,7 +1610,7 @@ int hn_fusion_forward_train(const hn_model *m, const hn_modality_input *in, int 
       k += 2;
       continue;
     }
-    AttnExt ext = {fp.cq, fp.ckv, q_done, kv_done, false, nullptr, 0};
+    AttnExt ext = {fp.cq, fp.ckv, q_done, kv_done, false, nullptr, 0, false, false, nullptr, nullptr, nullptr, 0, 0, 0};
     AttnExt *extp = (q_done || kv_done) ? &ext : nullptr;
     switch (st.kind) {
       case STEP_CROSS_ATTN: {
@@ -1765,7 +1821,7 @@ int hn_latent_block_fwd(const hn_attn_params *attn, const hn_ff_params *ff, cons
   c1.nq = pl.inner; c1.wq = attn->w_q; c1.Q = lp.q; c1.ldq = pl.inner; c1.alpha_q = pl.cscale;
   c1.nkv = 2 * pl.inner; c1.wkv = attn->w_kv; c1.KV = lp.kv; c1.ldkv = 2 * pl.inner;
   if ((rc = launch_latent_chain(c1, s)) != HN_OK) return rc;
-  AttnExt ext = {lp.q, lp.kv, true, true, true, nullptr, 0};
+  AttnExt ext = {lp.q, lp.kv, true, true, true, nullptr, 0, false, false, nullptr, nullptr, nullptr, 0, 0, 0};
   // (training: O is produced in `saved`, the feed-forward block's input is written to x_mid by the second chain)
   if ((rc = attn_fwd_impl(attn, x_in, nullptr, 1, nullptr, 0, b, L, L, d, nullptr, stats, lp.op, lp.op_bytes, s, nullptr, nullptr, saved,
                           false, 0, nullptr, nullptr, &ext)) != HN_OK) return rc;

@@ -49,6 +49,9 @@
 //       0-1 of it), row index and piece offset in loop-invariant VGPRs -- the same stream costs 0.241 us per block instead of
 //       0.307 (MFMAs alone: 0.225): 590-730 cycles per block in the chain, 30.4 us per launch, forward 2.92 ms, and the chain now
 //       beats the per-block launches at every batch size (profiles/r02_g_chain_sweep.txt).
+//   head 3  behind a shared-context (image) block the chain also merges the core's split partials and applies the folded value
+//       projection (vfold_kernel stages it once per forward): merge_vproj_kernel's launch (17 us) disappears, the chain's
+//       prologue grows by one round trip: forward 2.773 -> 2.742 ms.
 //
 // Shapes: l_d = 128, hidden 512, K a multiple of 128, N a multiple of 128, rows % 16 == 0.
 #include "common.h"
@@ -151,6 +154,12 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
   const gf32 *const a_O = (const gf32 *)args.O;
   const gf32 *const a_b_out = (const gf32 *)args.b_out;
   const gf32 *const a_y = (const gf32 *)args.y;
+  const gf32 *const a_Opart = (const gf32 *)args.Opart;
+  const gf32 *const a_Mpart = (const gf32 *)args.Mpart;
+  const gf32 *const a_Lpart = (const gf32 *)args.Lpart;
+  const gf32 *const a_wvf = (const gf32 *)args.wvf;
+  gf32 *const a_stats = (gf32 *)args.stats;
+  const int a_nsplit = args.nsplit, a_Lp = args.Lp, a_heads = args.heads, a_dh = args.dh;
   const gf32 *const a_f_nw = (const gf32 *)args.f_nw;
   const gf32 *const a_f_nb = (const gf32 *)args.f_nb;
   const gf32 *const a_b1 = (const gf32 *)args.b1;
@@ -193,7 +202,7 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
 
   // ---- the block stream: stage -> n-chunk -> k-chunk, identical for the loader and the consumer.  The loader addresses
   // block number `lb` of the whole chain with branch-free scalar arithmetic.
-  const int nk_out = a_head == 1 ? a_inner_o / WK : 0;           // out-projection: ONE 128-column chunk of nk_out k-chunks
+  const int nk_out = (a_head == 1 || a_head == 3) ? a_inner_o / WK : 0;      // out-projection: ONE 128-column chunk of nk_out k-chunks
   const int nq_ch = a_nq / WN, nkv_ch = a_nkv / WN;
   const int e0 = nk_out;                                         // first block of FF1
   const int e1 = e0 + (a_has_ff ? 8 * (CD / WK) : 0);            //                FF2
@@ -259,6 +268,61 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
     lst4(lds, wslot + 8 * WK, r[1]);
   };
 
+  // ---- head 3: the attention-output tile is built HERE from the split partials of the shared-context core (what
+  // merge_vproj_kernel did in a launch of its own: 17 us between the core and this chain).  Wave w = head w; lane (g, i):
+  // row i of the tile, 16-byte piece g of the 16-wide merged row (dp = 16: the image binding).  Merge over the splits (weights 2^(M_s - M), sum
+  // l = sum w_s l_s), normalise, then the folded value projection on the matrix cores: the lane's four floats ARE the A
+  // It runs BEFORE the weight ring starts: its 72 landing registers and the ring's 40 are then never live together (the kernel
+  // stays within 128 VGPRs, two workgroups per CU at b >= 64), at the price of one serial round trip.  The lane's four floats: the A
+  // operands of the four k-steps (k = 4 g + s: the contraction order is free), B = wvf rows (column dp-1 of the merged row is
+  // exactly 1 -- the ones column -- and carries the beta term).  The 16 x dh result goes into the A tile of the out-projection.
+  if (a_head == 3 && wave < a_heads) {
+    const int i = lane & 15, gq = lane >> 4;
+    const int bi = m0 / a_L, q = m0 - bi * a_L + i;                       // L % 16 == 0: a tile never straddles two samples
+    const long prow = ((long)(bi * a_heads + wave) * a_nsplit) * a_Lp + q;      // + s * Lp
+    float mv[CHAIN_MERGE_MAX_SPLITS], lv[CHAIN_MERGE_MAX_SPLITS];
+    float4 ov[CHAIN_MERGE_MAX_SPLITS];
+#pragma unroll
+    for (int s = 0; s < CHAIN_MERGE_MAX_SPLITS; ++s) {                    // every request up front (clamped: weight 0 past nsplit)
+      const long pr = prow + (long)min(s, a_nsplit - 1) * a_Lp;
+      mv[s] = gld1(a_Mpart + pr);
+      lv[s] = gld1(a_Lpart + pr);
+      ov[s] = gld4(a_Opart + pr * 16 + 4 * gq);
+    }
+    float M = -3.0e38f;
+#pragma unroll
+    for (int s = 0; s < CHAIN_MERGE_MAX_SPLITS; ++s) M = fmaxf(M, s < a_nsplit ? mv[s] : -3.0e38f);
+    float l = 0.0f;
+    float4 o0 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int s = 0; s < CHAIN_MERGE_MAX_SPLITS; ++s) {
+      const float w = s < a_nsplit ? __builtin_amdgcn_exp2f(mv[s] - M) : 0.0f;
+      l = fmaf(w, lv[s], l);
+      o0.x = fmaf(w, ov[s].x, o0.x); o0.y = fmaf(w, ov[s].y, o0.y); o0.z = fmaf(w, ov[s].z, o0.z); o0.w = fmaf(w, ov[s].w, o0.w);
+    }
+    const float inv = 1.0f / l;
+    o0.x *= inv; o0.y *= inv; o0.z *= inv; o0.w *= inv;
+    if (a_stats && gq == 0) {
+      gf32 *st = a_stats + ((long)(bi * a_heads + wave) * a_L + q) * 2;
+      gst1(st, M);
+      gst1(st + 1, l);
+    }
+    for (int ct = 0; ct < (a_dh >> 4); ++ct) {                            // 16 output columns of the head at a time
+      const gf32 *wrow = a_wvf + ((long)(wave * a_dh + 16 * ct + i) * 16 + 4 * gq);
+      const float4 b0 = gld4(wrow);
+      f32x4 c = {0.f, 0.f, 0.f, 0.f};
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(o0.x, b0.x, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(o0.y, b0.y, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(o0.z, b0.z, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(o0.w, b0.w, c, 0, 0, 0);
+      const int col = wave * a_dh + 16 * ct + i;                          // accumulator register r: row 4 gq + r, column col
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 4 * gq + r;
+        lds[Abig + (col >> 5) * ATILE + row * WK + ((((col & 31) >> 2) ^ (row & 7)) * 4) + (col & 3)] = c[r];
+      }
+    }
+  }
   // ---- far loads first: five weight blocks per wave (block 0, then the 4-deep register ring: blocks 1..4), then the small
   // parameters, the x tile, the attention-output tile
   __syncthreads();                           // the block table
@@ -504,6 +568,36 @@ extern "C" __attribute__((visibility("default"))) int hn_debug_chain_prof(unsign
 }
 #endif
 
+// Folded value projection of a shared-context (rank-D) block, (heads * dh, dp): column d of row (h, e) multiplies slot d of the
+// merged context average -- gamma folded in, the packed channel order of the context (common.h), and in column dp-1 (the ones
+// column of the average) the beta term.  What merge_vproj_kernel builds per workgroup, once per forward here.
+__global__ __launch_bounds__(256) void vfold_kernel(VfoldMulti v) {
+  const int hi = blockIdx.x, z = blockIdx.y, dp = 16;
+  const float *w_v = v.w_v[z], *gamma = v.gamma[z], *beta = v.beta[z];
+  float *out = v.out + (long)z * v.out_stride;
+  for (int idx = threadIdx.x; idx < v.dh * dp; idx += blockDim.x) {
+    const int e = idx / dp, d = idx % dp;
+    const float *wr = w_v + (long)(hi * v.dh + e) * v.D;
+    float w = 0.0f;
+    if (d == dp - 1) {
+      for (int c = 0; c < v.D; ++c) w = fmaf(beta ? beta[c] : 0.0f, wr[c], w);
+    } else if (v.pack_ks == 0) {
+      if (d < v.D) w = wr[d] * (gamma ? gamma[d] : 1.0f);
+    } else {
+      const int c = packed_chan(d, v.pack_ks);
+      if (c >= 0 && c < v.D - 1) w = wr[c] * (gamma ? gamma[c] : 1.0f) - wr[v.D - 1] * (gamma ? gamma[v.D - 1] : 1.0f);
+    }
+    out[(long)(hi * v.dh + e) * dp + d] = w;
+  }
+}
+
+int launch_vfold(const VfoldMulti &v, hipStream_t s) {
+  HN_REQUIRE(v.n >= 1 && v.n <= 16 && v.out && v.D >= 1 && v.D <= 15 && v.heads >= 1, HN_E_SHAPE, "vfold: n=%d D=%d heads=%d", v.n, v.D, v.heads);
+  hipLaunchKernelGGL(vfold_kernel, dim3(v.heads, v.n), dim3(256), 0, s, v);
+  HN_LAUNCH_CHECK("vfold");
+  return HN_OK;
+}
+
 bool latent_chain_supported(int rows, int d, int hidden) { return d == CD && hidden == CHID && rows > 0 && rows % CR == 0; }
 
 int launch_latent_chain(const ChainArgs &a, hipStream_t s) {
@@ -516,6 +610,12 @@ int launch_latent_chain(const ChainArgs &a, hipStream_t s) {
                "latent_chain: inner=%d ldo=%d", a.inner_o, a.ldo);
   } else if (a.head == 2) {
     HN_REQUIRE(a.y && al16(a.y), HN_E_NULL, "latent_chain: y is NULL / unaligned");
+  } else if (a.head == 3) {
+    HN_REQUIRE(a.Opart && a.Mpart && a.Lpart && a.wvf && a.w_out && a.b_out, HN_E_NULL, "latent_chain: merge operand is NULL");
+    HN_REQUIRE(a.dp == 16 && a.heads >= 1 && a.heads <= 8 && (a.dh == 16 || a.dh == 32 || a.dh == 64) &&
+                   a.inner_o == a.heads * a.dh && a.inner_o % (4 * WK) == 0 && a.inner_o <= 16 * WK && a.nsplit >= 1 &&
+                   a.nsplit <= CHAIN_MERGE_MAX_SPLITS && a.L % CR == 0 && a.Lp >= a.L && al16(a.Opart) && al16(a.wvf) && al16(a.w_out),
+               HN_E_SHAPE, "latent_chain: merge head dp=%d heads=%d dh=%d nsplit=%d L=%d", a.dp, a.heads, a.dh, a.nsplit, a.L);
   }
   if (a.has_ff) {
     HN_REQUIRE(a.w1 && a.b1 && a.w2 && a.b2, HN_E_NULL, "latent_chain: feed-forward operand is NULL");

@@ -233,7 +233,13 @@ struct ChainArgs {
   int rows, L;                          // b * l_c rows of width 128 (16 per workgroup); l_c rows per sample
   const float *x_in; float *x_out;      // (rows, 128); x_out may be NULL or alias x_in
   float *x_mid;                         // training: x after the head stage (the feed-forward block's input) is kept on the tape; NULL otherwise
-  int head;                             // 0: x = x_in; 1: x = x_in + LeakyReLU(O W_out^T + b_out); 2: x = x_in + y[row / L]
+  int head;                             // 0: x = x_in; 1: x = x_in + LeakyReLU(O W_out^T + b_out); 2: x = x_in + y[row / L];
+                                        // 3: as 1, with O built here from the split partials of a shared-context (rank-D) core:
+                                        //    merged over the splits, normalised, run through the folded value projection
+  const float *Opart, *Mpart, *Lpart;   // head 3: (b, heads, nsplit, Lp, dp), (b, heads, nsplit, Lp) x 2 (attention.hip)
+  int nsplit, Lp, dp, heads, dh;        //         dp in {16, 32}, heads <= 8, dh in {16, 32, 64}, inner_o = heads * dh
+  const float *wvf;                     //         (heads * dh, dp) folded value projection (vfold_kernel), row dp-1 = the beta term
+  float *stats;                         //         (b, heads, L, 2) merged (max, sum) per row for hn_attn_probs, or NULL
   const float *O; int ldo, inner_o;     // head 1: merged attention output (rows, inner_o), inner_o a multiple of 32, <= 512
   const float *w_out, *b_out;           //         to_out.0.weight (128, inner_o), to_out.0.bias
   const float *y;                       // head 2: (b, 128) block output of a one-token cross-attention
@@ -246,6 +252,15 @@ struct ChainArgs {
 };
 bool latent_chain_supported(int rows, int d, int hidden);
 int launch_latent_chain(const ChainArgs &a, hipStream_t s);
+constexpr int CHAIN_MERGE_MAX_SPLITS = 12;   // head 3 merges at most this many splits (more: merge_vproj_kernel)
+// folded value projection of a shared-context block for ChainArgs.wvf (the image merge_vproj_kernel builds per workgroup)
+struct VfoldMulti {                    // one entry per layer of a modality (<= HN_SKINNY_MAXZ): value half of to_kv, context LayerNorm affine
+  int n;
+  const float *w_v[16], *gamma[16], *beta[16];
+  float *out; long out_stride;         // entry z writes out + z * out_stride, (heads * dh, 16)
+  int D, heads, dh, pack_ks;
+};
+int launch_vfold(const VfoldMulti &v, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
 // encode
