@@ -580,7 +580,15 @@ __global__ __launch_bounds__(256) void vfold_kernel(VfoldMulti v) {
     const float *wr = w_v + (long)(hi * v.dh + e) * v.D;
     float w = 0.0f;
     if (d == dp - 1) {
-      for (int c = 0; c < v.D; ++c) w = fmaf(beta ? beta[c] : 0.0f, wr[c], w);
+      float bc[15], wc[15];                   // all requests first (D <= 15): one round trip instead of D
+#pragma unroll
+      for (int c = 0; c < 15; ++c) {
+        const int cc = c < v.D ? c : 0;
+        bc[c] = beta ? beta[cc] : 0.0f;
+        wc[c] = wr[cc];
+      }
+#pragma unroll
+      for (int c = 0; c < 15; ++c) w = c < v.D ? fmaf(bc[c], wc[c], w) : w;
     } else if (v.pack_ks == 0) {
       if (d < v.D) w = wr[d] * (gamma ? gamma[d] : 1.0f);
     } else {
