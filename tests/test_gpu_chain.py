@@ -135,3 +135,27 @@ def test_whole_model_chain_vs_unfused_launches(hn, tmp_path):
         assert_close(a, b_, rel=2e-5, floor=2e-6, what=f"output {i}: chain vs unfused")
         diffs.append(float((a - b_).abs().max()))
     assert max(diffs) > 0.0, "both runs took the same route (HN_NO_CHAIN had no effect)"
+
+
+@pytest.mark.parametrize("grad_mode", [False, True], ids=["inference", "taping"])
+def test_whole_model_without_attention_trace_vs_oracle(hn, grad_mode):
+    """keep_attention_stats=False: no statistics / trace slots are handed to the forward, the latent array then lives in the
+    workspace (every chain runs in place, the merge head gets no statistics pointer).  Same three-modality model as above
+    (one-token look-ahead head, merge head behind the image block, plain out-projection head behind the patch bag and the
+    self-attention), against the oracle and against the default mode."""
+    kw = dict(n_modalities=3, channel_dims=[2000, 3, 96], num_spatial_axes=[1, 2, 1], out_dims=4, depth=2)
+    torch.manual_seed(15)
+    model = hn.HealNet(**kw).eval().to(DEV)
+    gen = torch.Generator().manual_seed(16)
+    ins = [torch.rand(3, 1, 2000, generator=gen), torch.rand(3, 40, 36, 3, generator=gen), torch.rand(3, 200, 96, generator=gen)]
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        want = O.fusion_forward(sd, O.FusionConfig(**kw), [t.clone() for t in ins])
+    with torch.set_grad_enabled(grad_mode):
+        kept = model([t.to(DEV) for t in ins]).detach().cpu()
+        model.keep_attention_stats = False
+        bare = model([t.to(DEV) for t in ins]).detach().cpu()
+        bare2 = model([t.to(DEV) for t in ins]).detach().cpu()
+    assert_close(bare, want, rel=1e-3, floor=0.0, abs_floor=1e-5, what="no-trace forward vs oracle")
+    assert torch.equal(bare, bare2), "no-trace forward is not deterministic"
+    assert_close(bare, kept, rel=1e-6, floor=0.0, abs_floor=1e-6, what="no-trace vs default mode")
