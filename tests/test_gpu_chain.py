@@ -159,3 +159,28 @@ def test_whole_model_without_attention_trace_vs_oracle(hn, grad_mode):
     assert_close(bare, want, rel=1e-3, floor=0.0, abs_floor=1e-5, what="no-trace forward vs oracle")
     assert torch.equal(bare, bare2), "no-trace forward is not deterministic"
     assert_close(bare, kept, rel=1e-6, floor=0.0, abs_floor=1e-6, what="no-trace vs default mode")
+
+
+@pytest.mark.parametrize("x_heads,cross_dim_head,shape", [(8, 64, (40, 36)), (4, 32, (24, 20)), (2, 64, (16, 48)), (8, 16, (30, 30)),
+                                                          (3, 64, (20, 20))])
+def test_merge_head_shapes_vs_oracle(hn, x_heads, cross_dim_head, shape):
+    """The chain's merge head (split partials of the image block -> normalised average -> folded value projection, chain.hip
+    head == 3) at other head counts / head widths than the default 8 x 64: 4 x 32 and 2 x 64 (inner = 128: waves 2..7 idle in
+    the merge), 8 x 16; 3 x 64 (inner = 192, not a multiple of 128) stays on merge_vproj_kernel + the unfused out-projection."""
+    kw = dict(n_modalities=2, channel_dims=[2000, 3], num_spatial_axes=[1, 2], out_dims=4, depth=2, x_heads=x_heads,
+              cross_dim_head=cross_dim_head)
+    torch.manual_seed(31 + x_heads)
+    model = hn.HealNet(**kw).eval().to(DEV)
+    gen = torch.Generator().manual_seed(32)
+    ins = [torch.rand(5, 1, 2000, generator=gen), torch.rand(5, *shape, 3, generator=gen)]
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        want = O.fusion_forward(sd, O.FusionConfig(**kw), [t.clone() for t in ins])
+        got = model([t.to(DEV) for t in ins]).cpu()
+    assert_close(got, want, rel=1e-3, floor=0.0, abs_floor=1e-5, what=f"merge head {x_heads}x{cross_dim_head}")
+    # the statistics the merge head writes feed the attention-weight export: compare the image block's probabilities
+    with torch.no_grad():
+        probs = model.get_attention_weights()
+    assert all(torch.isfinite(p).all() for p in probs)
+    row_sums = probs[1].float().sum(-1)            # layer 0, image block: (b * heads, l_c, N) -> rows sum to 1
+    assert_close(row_sums.cpu(), torch.ones_like(row_sums).cpu(), rel=1e-4, floor=0.0, abs_floor=1e-4, what="image block probabilities")
