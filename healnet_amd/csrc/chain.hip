@@ -487,6 +487,12 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
     __syncthreads();
     CHAIN_PROF(4);
     read_a(fa0, Ahat, 0);
+    int hid_at[4];                          // hidden-tile element (row 4 fg + r, column ncol of chunk 0): A layout, 16-byte slots XOR-swizzled
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * fg + r;
+      hid_at[r] = Abig + (ncol >> 5) * ATILE + row * WK + ((((ncol & 31) >> 2) ^ (row & 7)) * 4) + (ncol & 3);
+    }
     for (int hc = 0; hc < 4; ++hc) {
       f32x4 a0 = zero, a1 = zero, g0 = zero, g1 = zero;
       run_chunk_k128(Ahat, a0, a1);
@@ -495,13 +501,20 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
       const float ba = lds[p_b1 + h0], bg = lds[p_b1 + CHID + h0];
       const float va[4] = {a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w};
       const float vg[4] = {g0.x + g1.x, g0.y + g1.y, g0.z + g1.z, g0.w + g1.w};
+      // one gate, behind a scalar branch (a select between the two evaluates both on the VALU the MFMAs share), and the four
+      // hidden-tile addresses of the lane precomputed: only the chunk offset is added here
+      float gate[4];
+      if (a_gate == HN_GATE_SELU) {
+        asm volatile("" ::: "memory");
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 4 * fg + r;
-        const float gt = vg[r] + bg;
-        const float hv = (va[r] + ba) * (a_gate == HN_GATE_SELU ? selu_f(gt) : gelu_erf(gt));
-        lds[Abig + (h0 >> 5) * ATILE + row * WK + ((((h0 & 31) >> 2) ^ (row & 7)) * 4) + (h0 & 3)] = hv;
+        for (int r = 0; r < 4; ++r) gate[r] = selu_f(vg[r] + bg);
+      } else {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gate[r] = gelu_erf(vg[r] + bg);
       }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) lds[hid_at[r] + hc * 4 * ATILE] = (va[r] + ba) * gate[r];
     }
     __syncthreads();
     CHAIN_PROF(5);
