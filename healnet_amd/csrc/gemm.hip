@@ -34,7 +34,14 @@ __device__ __forceinline__ float epilogue_value(const GemmArgs &g, float acc, fl
   float v = g.alpha * acc + bv;
   if (GLU) {
     const float gate = g.alpha * accg + bgv;
-    v *= (g.act == ACT_GLU_SELU) ? selu_exact(gate) : gelu_f(gate);
+    // a scalar branch (kept one by the empty asm): as a select BOTH gates are evaluated for every element
+    if (g.act == ACT_GLU_SELU) {
+      asm volatile("" ::: "memory");
+      v *= selu_exact(gate);
+    } else {
+      asm volatile("" ::: "memory");
+      v *= gelu_f(gate);
+    }
   } else if (g.act == ACT_LEAKY) {
     v = v > 0.0f ? v : 0.01f * v;
   }
