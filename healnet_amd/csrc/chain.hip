@@ -52,6 +52,9 @@
 //   head 3  behind a shared-context (image) block the chain also merges the core's split partials and applies the folded value
 //       projection (vfold_kernel stages it once per forward): merge_vproj_kernel's launch (17 us) disappears, the chain's
 //       prologue grows by one round trip: forward 2.773 -> 2.742 ms.
+//   ... and one more vector-instruction item: `gate == SELU ? selu(g) : gelu(g)` in the FF1 epilogue was a select, so BOTH gates
+//       (erff among them) were evaluated for every hidden element; behind a scalar branch, with the lane's four hidden-tile
+//       addresses precomputed: 2.747 -> 2.724 ms.
 //
 // Shapes: l_d = 128, hidden 512, K a multiple of 128, N a multiple of 128, rows % 16 == 0.
 #include "common.h"
