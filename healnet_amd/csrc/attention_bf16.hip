@@ -88,7 +88,9 @@ __global__ __launch_bounds__(256) void attn_core_bf16_kernel(AttnCoreBf16Args a,
     for (int d = 0; d < DTV; ++d) O[i][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
   bool unset = true;
-  const bool bounded = a.bound != nullptr && *a.bound_flag == 0;      // fixed Cauchy-Schwarz reference (see attention.hip)
+  // fixed Cauchy-Schwarz reference (see attention.hip); a scalar INTEGER: a bool carried into the loop costs VALU copies there
+  const int unbounded = a.bound != nullptr ? __builtin_amdgcn_readfirstlane(*a.bound_flag) : 1;
+  const bool bounded = unbounded == 0;
   if (bounded) {
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
@@ -164,13 +166,17 @@ __global__ __launch_bounds__(256) void attn_core_bf16_kernel(AttnCoreBf16Args a,
       for (int x = 0; x < 2; ++x) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) P[i][x][r] = fast_exp2_b(S[i][x][r]);
-        if (!bounded) {
+        if (unbounded != 0) {
           ps0 += P[i][x][0] + P[i][x][2];
           ps1 += P[i][x][1] + P[i][x][3];
         }
       }
-    const bool need = !bounded && (!(ps0 + ps1 <= 512.0f) || unset);
-    if (__any(need) && any_live) {
+    bool rescale = false;
+    if (unbounded != 0) {
+      const bool need = !(ps0 + ps1 <= 512.0f) || unset;
+      rescale = __any(need) && any_live;
+    }
+    if (rescale) {
 #pragma unroll
       for (int i = 0; i < NQ; ++i) {
         float tm = fmaxf(fmaxf(fmaxf(S[i][0][0], S[i][0][1]), fmaxf(S[i][0][2], S[i][0][3])),
