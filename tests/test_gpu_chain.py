@@ -184,3 +184,23 @@ def test_merge_head_shapes_vs_oracle(hn, x_heads, cross_dim_head, shape):
     assert all(torch.isfinite(p).all() for p in probs)
     row_sums = probs[1].float().sum(-1)            # layer 0, image block: (b * heads, l_c, N) -> rows sum to 1
     assert_close(row_sums.cpu(), torch.ones_like(row_sums).cpu(), rel=1e-4, floor=0.0, abs_floor=1e-4, what="image block probabilities")
+
+
+@pytest.mark.parametrize("grad_mode", [False, True], ids=["inference", "taping"])
+def test_masked_image_model_on_the_chain_vs_oracle(hn, grad_mode):
+    """One image modality with a key mask at the default widths: the masked split-KV core feeds the chain's merge head (splits
+    whose tokens are all masked carry weight 0), the self-attention blocks take the LDS core / the chain as usual."""
+    kw = dict(n_modalities=1, channel_dims=[3], num_spatial_axes=[2], out_dims=4, depth=2)
+    torch.manual_seed(41)
+    model = hn.HealNet(**kw).eval().to(DEV)
+    gen = torch.Generator().manual_seed(42)
+    img = torch.rand(4, 48, 40, 3, generator=gen)
+    mask = torch.rand(4, 48 * 40, generator=gen) > 0.4
+    mask[:, 0] = True
+    mask[1, 600:] = False                      # a sample whose later splits are masked out entirely
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        want = O.fusion_forward(sd, O.FusionConfig(**kw), [img.clone()], mask=mask)
+    with torch.set_grad_enabled(grad_mode):
+        got = model([img.to(DEV)], mask=mask.to(DEV)).detach().cpu()
+    assert_close(got, want, rel=1e-3, floor=0.0, abs_floor=1e-5, what="masked image model")
