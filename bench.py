@@ -54,6 +54,19 @@ EXEC_FLOPS_CORE_PER_SAMPLE = 2.0 * L_C * N_IMG * (QK_DIM + DP) * HEADS
 PEAK_FP32_MFMA_TFLOPS = 157.3                                            # MI355X_MICROARCH.md chip table
 
 
+def exec_flops_forward_per_sample(depth=3, l_d=128):
+    """EXECUTED matrix FLOPs of one cfg2 forward per sample (what the kernels run, not the reference formulation), by the
+    schedule of healnet.py:225-245: per layer the image cross block (Q projection, query fold, core, folded value projection,
+    out-projection) + its feed-forward block, the one-token tabular block + its feed-forward block, and behind EACH of the two
+    the latent self-attention block (Q|K|V, core, out) + feed-forward block.  318.7 GF per 32 samples."""
+    inner = HEADS * DIM_HEAD
+    ff = 2.0 * L_C * l_d * 8 * l_d + 2.0 * L_C * 4 * l_d * l_d
+    img = 2.0 * L_C * l_d * inner + 2 * 2.0 * L_C * inner * DP + EXEC_FLOPS_CORE_PER_SAMPLE + 2.0 * L_C * inner * l_d + ff
+    tab = 2.0 * 2005 * inner + 2.0 * inner * l_d + ff
+    self_blk = 2.0 * L_C * l_d * 3 * inner + 4.0 * L_C * L_C * DIM_HEAD * HEADS + 2.0 * L_C * inner * l_d + ff
+    return depth * (img + tab + 2 * self_blk)
+
+
 class HipEvents:
     """Raw hipEvent_t pairs (the C ABI records them on the launch stream around the dominant kernel)."""
 
@@ -262,14 +275,24 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        self_launch(args)                                  # does not return
-    if args.gpus != world:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # HN_BENCH_FORCE_DIST=1 (1-GPU box): take the `distributed` branch end to end on a ONE-rank RCCL group -- nccl process group
+    # with device_id, dist.barrier() inside the timed regions, the MAX all-reduce of the timing, the overlapped and the blocking
+    # gradient all-reduce of the training step (ReduceOp.AVG on the side stream) all really execute
+    force_dist = os.environ.get("HN_BENCH_FORCE_DIST", "0") == "1"
+    if force_dist:
+        os.environ["HN_FORCE_COLLECTIVES"] = "1"
+    distributed = world > 1 or force_dist
     # HN_BENCH_SHARED_GPU=1 (tests on a 1-GPU box only): every rank uses cuda:0 and the ranks talk over gloo -- exercises the
     # launcher and the distributed code paths; RCCL needs one device per rank, which is what the real runs use
     shared = os.environ.get("HN_BENCH_SHARED_GPU", "0") == "1"
+    visible = torch.cuda.device_count()
+    if not shared and args.gpus > visible:               # one clear line instead of a rendezvous hang / an invalid-device trace
+        raise SystemExit(f"bench.py: --gpus {args.gpus} requested but only {visible} GPU(s) are visible on this node "
+                         f"(one process per GPU over RCCL; nothing was launched)")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)                                  # does not return
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     if shared:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -386,6 +409,10 @@ def main():
                 "flops_per_launch_executed": exec_flops * b,
                 "flops_per_launch_algorithmic": ALGO_FLOPS_CORE_PER_SAMPLE * b,
                 "effective_algorithmic_tflops": None if algo_tf is None else round(algo_tf, 2),
+                # the whole forward against the same roof: executed matrix FLOPs of every kernel of one step / step time / peak
+                "forward_flops_executed_per_step": None if bf16_core else exec_flops_forward_per_sample() * b,
+                "forward_frac_executed": None if bf16_core else round(
+                    exec_flops_forward_per_sample() * total_samples / elapsed / 1e12 / world / PEAK_FP32_MFMA_TFLOPS, 4),
                 "note": "achieved/frac use EXECUTED fp32-MFMA FLOPs (rank-D reassociation + packed context: QK^T contracts 12 "
                         "channels and P V 16 columns instead of dim_head 64 each, 4.6x fewer than the reference formulation, "
                         "SURVEY.md §8d); frac_useful prices only the useful P V columns (12 channels + the softmax-denominator ones "

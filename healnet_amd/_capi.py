@@ -177,11 +177,19 @@ def build(force: bool = False, verbose: bool = False) -> str:
         os.environ.get("HN_EXTRA_HIPCC_FLAGS", "").split()
     stamp = os.path.join(objdir, "flags.txt")
     flag_text = " ".join([hipcc] + flags)
-    if not os.path.exists(stamp) or open(stamp).read() != flag_text:
+    # a rebuild is forced only when a flag stamp EXISTS and differs; a box that received the prebuilt library without the
+    # build/ directory (no stamp) keeps it as long as it is newer than every source
+    if os.path.exists(stamp) and open(stamp).read() != flag_text:
         force = True
     hdr_time = max(os.path.getmtime(h) for h in hdrs)
     if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(
             [hdr_time] + [os.path.getmtime(os.path.join(CSRC, src)) for src in SOURCES]):
+        if not os.path.exists(stamp):
+            try:
+                with open(stamp, "w") as f:
+                    f.write(flag_text)
+            except OSError:
+                pass
         return LIB_PATH          # up to date (also the case on a GPU box that received the prebuilt library without objects)
     jobs = []
     for src in SOURCES:

@@ -29,6 +29,15 @@ static inline DropCfg drop_off() { return make_drop(0.0f, 0, 0, 0); }
 static inline DropCfg drop_of(float p, const hn_rng &r, bool ff) {
   return p > 0.0f ? make_drop(p, r.seed, r.offset, ff ? (r.stream | DROP_SID_FF) : (r.stream & ~DROP_SID_FF)) : drop_off();
 }
+// development switches, read ONCE per process (no getenv on the launch path)
+static bool chain_disabled() { static const bool off = getenv("HN_NO_CHAIN") != nullptr; return off; }
+static bool merge_chain_disabled() { static const bool off = getenv("HN_NO_MERGE_CHAIN") != nullptr; return off; }
+// operands the latent chain reads with 16-byte loads: an unaligned one (a parameter that is a view at an odd float offset of a
+// user-made flat buffer, a tape / trace slot) sends the block down the per-block launches instead of failing the forward
+static inline bool al16(const void *p) { return ((uintptr_t)p & 15) == 0; }
+static inline bool chain_ff_aligned(const hn_ff_params *f) { return al16(f->w1) && al16(f->w2) && al16(f->norm_w) && al16(f->norm_b); }
+static inline bool chain_out_aligned(const hn_attn_params *a) { return al16(a->w_out); }
+static inline bool chain_proj_aligned(const hn_attn_params *a) { return al16(a->w_q) && al16(a->w_kv) && al16(a->norm_w) && al16(a->norm_b); }
 static inline int pad_head_dim(int dh) { return dh <= 16 ? 16 : dh <= 32 ? 32 : dh <= 64 ? 64 : dh <= 128 ? 128 : 0; }
 static inline int round16(int v) { return (v + 15) / 16 * 16; }
 
@@ -151,8 +160,11 @@ static int attn_prepare(const hn_attn_params *p, const AttnPlan &pl, const float
                         int b, int L, hipStream_t s, AttnCoreArgs *core, int pack_ks = 0, float *kv_tape = nullptr,
                         bool kv_ready = false, bool use_bound = false, int *ext_flag = nullptr, const AttnExt *ext = nullptr) {
   const int rows = b * L;
-  float *qbuf = (ext && ext->q) ? ext->q : pl.q;
-  const bool q_done = ext && ext->q_done;
+  // external projection buffers are used only when the chain in front has actually produced them: they are sized for the
+  // chain's own products (ckv: latent self-attention only), not for this block's plan (an explicit cross block
+  // with N >> l_c would overrun ckv; padded head dims would leave the external q's pad columns unwritten)
+  const bool q_done = ext && ext->q && ext->q_done;
+  float *qbuf = q_done ? ext->q : pl.q;
   GemmArgs gq = gemm_defaults();
   gq.A = x_in; gq.lda = p->query_dim;
   gq.W = p->w_q; gq.ldw = p->query_dim;
@@ -181,11 +193,13 @@ static int attn_prepare(const hn_attn_params *p, const AttnPlan &pl, const float
     core->ones_col = pl.ones ? 1 : 0;
   } else {
     const int qpitch = p->heads * pl.dhp, kvpitch = 2 * p->heads * pl.dhp;
-    float *kvbuf = kv_tape ? kv_tape : ((ext && ext->kv) ? ext->kv : pl.kv);
-    if (ext && ext->kv_done) kv_ready = true;
+    const bool kv_ext = ext && ext->kv && ext->kv_done && !ctx;      // the chain projects K/V for latent self-attention only
+    HN_REQUIRE(!(ext && ext->kv_done) || kv_ext, HN_E_SHAPE, "attn: external K/V projections exist for latent self-attention only");
+    float *kvbuf = kv_tape ? kv_tape : (kv_ext ? ext->kv : pl.kv);
+    if (kv_ext) kv_ready = true;
     if (pl.dhp != pl.dh) {
       HN_REQUIRE(!q_done, HN_E_SHAPE, "attn: external projections need dim_head in {16, 32, 64, 128}");
-      { int rc_ = launch_fill(pl.q, 0.0f, (long)((size_t)rows * qpitch), s); if (rc_ != HN_OK) return rc_; }
+      { int rc_ = launch_fill(qbuf, 0.0f, (long)((size_t)rows * qpitch), s); if (rc_ != HN_OK) return rc_; }
       if (!kv_ready) { int rc_ = launch_fill(kvbuf, 0.0f, (long)((size_t)b * pl.N * kvpitch), s); if (rc_ != HN_OK) return rc_; }
     }
     gq.C = qbuf; gq.ldc = qpitch; gq.alpha = pl.cscale;
@@ -266,9 +280,10 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
     gq.W = p->w_q; gq.ldw = p->query_dim;
     gq.M = b * L; gq.N = pl.inner; gq.K = p->query_dim;
     if (p->norm_w) { gq.pro = PRO_LAYERNORM; gq.gamma = p->norm_w; gq.beta = p->norm_b; }
-    float *qraw = (ext && ext->q) ? ext->q : pl.q;
+    const bool q_ext = ext && ext->q && ext->q_done;
+    float *qraw = q_ext ? ext->q : pl.q;
     gq.C = qraw; gq.ldc = pl.inner;
-    if (!(ext && ext->q_done) && (rc = launch_gemm(gq, s)) != HN_OK) return rc;
+    if (!q_ext && (rc = launch_gemm(gq, s)) != HN_OK) return rc;
     uint16_t *qfb = (uint16_t *)pl.qf;
     float *bound = p->ctx_gamma ? pl.bound : nullptr;
     int *bflag = bound ? (bound_flag ? bound_flag : (int *)(pl.bound + (size_t)b * p->heads * pl.Lp)) : nullptr;
@@ -1316,11 +1331,10 @@ int hn_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, con
 
   // folded value projections for the chains that merge the split partials of a shared-context block themselves (one launch per
   // modality and forward; only when the chain is the route)
-  static const bool merge_chain_off = getenv("HN_NO_MERGE_CHAIN") != nullptr;      // development switch: merge_vproj_kernel instead
   bool vmerge[16];
   for (int i = 0; i < M; ++i) {
     vmerge[i] = false;
-    if (!in[i].data || !fp.wvf[i] || !fp.chain || merge_chain_off || getenv("HN_NO_CHAIN") != nullptr) continue;
+    if (!in[i].data || !fp.wvf[i] || !fp.chain || merge_chain_disabled() || chain_disabled()) continue;
     VfoldMulti vf;
     memset(&vf, 0, sizeof(vf));
     const hn_attn_params &a0 = m->cross_attn[i];
@@ -1350,8 +1364,7 @@ int hn_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, con
   float *cur = input_buffer(0);
   if ((rc = launch_broadcast_rows(m->latents, cur, (long)L * d, b, s, fp.flags, m->depth * M)) != HN_OK) return rc;   // :225 (+ the bound flags)
   const bool head = m->final_classifier_head && !return_embeddings;
-  static const bool chain_off = getenv("HN_NO_CHAIN") != nullptr;      // development switch: the unfused launch sequence
-  const bool use_chain = fp.chain && !chain_off;
+  const bool use_chain = fp.chain && !chain_disabled();      // HN_NO_CHAIN: development switch, the unfused launch sequence
 
   auto run_attn = [&](const Step &st, const float *xin, float *xout, AttnExt *ext) -> int {
     const int layer = st.layer, i = st.m;
@@ -1392,8 +1405,10 @@ int hn_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, con
     // The chain behind this block: its out-projection (or the one-token broadcast add), the feed-forward block that follows
     // (healnet.py:237 / :245) and the projections of the attention block after that.
     const bool ff_next = k + 1 < nsteps && !is_attn(steps[k + 1]);
-    bool fuse = use_chain && ff_next && ff_of(steps[k + 1])->dim == d && ff_of(steps[k + 1])->dropout == 0.0f;
-    if (fuse && !is_tab(st)) fuse = ap->query_dim == d && inner % 128 == 0 && inner <= 512 && !(st.kind == STEP_CROSS_ATTN && fp.N[st.m] == 1 && mask == nullptr);
+    bool fuse = use_chain && ff_next && ff_of(steps[k + 1])->dim == d && ff_of(steps[k + 1])->dropout == 0.0f &&
+                chain_ff_aligned(ff_of(steps[k + 1])) && al16(cur) && al16(input_buffer(k + 2));
+    if (fuse && !is_tab(st)) fuse = ap->query_dim == d && inner % 128 == 0 && inner <= 512 && chain_out_aligned(ap) &&
+                                    !(st.kind == STEP_CROSS_ATTN && fp.N[st.m] == 1 && mask == nullptr);
     if (!fuse) {
       float *dst = input_buffer(k + 1);
       if (is_tab(st)) rc = launch_add_row_broadcast(fp.taby[st.m] + (size_t)st.layer * b * ap->query_dim, cur, dst, b, L, ap->query_dim, s);
@@ -1437,7 +1452,7 @@ int hn_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, con
       AttnPlan pn;
       if ((rc = plan_attn(an, !self, self ? 0 : fp.ldz[sn.m], b, L, self ? L : fp.N[sn.m], self ? d : fp.D[sn.m], nullptr, 0, &pn)) != HN_OK) return rc;
       const bool one_token = !self && fp.N[sn.m] == 1 && mask == nullptr;
-      if (!one_token && pn.dh == pn.dhp && pn.inner % 128 == 0 && an->query_dim == d && an->w_q && an->w_kv) {
+      if (!one_token && pn.dh == pn.dhp && pn.inner % 128 == 0 && an->query_dim == d && an->w_q && an->w_kv && chain_proj_aligned(an)) {
         ca.p_nw = an->norm_w; ca.p_nb = an->norm_b;
         ca.nq = pn.inner; ca.wq = an->w_q; ca.Q = fp.cq; ca.ldq = pn.inner;
         ca.alpha_q = pn.rank_d ? 1.0f : pn.cscale;       // the rank-D binding scales in its query fold
@@ -1531,8 +1546,7 @@ int hn_fusion_forward_train(const hn_model *m, const hn_modality_input *in, int 
       return rc;
   }
   if ((rc = launch_broadcast_rows(m->latents, T + tp.x_off[0], (long)L * d, b, s)) != HN_OK) return rc;
-  static const bool chain_off_t = getenv("HN_NO_CHAIN") != nullptr;
-  const bool use_chain = fp.chain && !chain_off_t;
+  const bool use_chain = fp.chain && !chain_disabled();
   auto is_attn_t = [](const Step &q) { return q.kind == STEP_CROSS_ATTN || q.kind == STEP_SELF_ATTN; };
   auto trace_copies = [&](int k) -> int {       // optional copies for hn_attn_probs (same slots as hn_fusion_forward)
     const Step &st = tp.steps[k];
@@ -1562,6 +1576,7 @@ int hn_fusion_forward_train(const hn_model *m, const hn_modality_input *in, int 
       const hn_attn_params &aq = st.kind == STEP_SELF_ATTN ? m->self_attn[st.layer] : m->cross_attn[st.layer * M + st.m];
       const int inner = aq.heads * aq.dim_head;
       fuse = fq.dim == d && fq.dropout == 0.0f && aq.query_dim == d && inner % 128 == 0 && inner <= 512 &&
+             chain_ff_aligned(&fq) && chain_out_aligned(&aq) && al16(xin) && al16(xout) && al16(T + tp.x_off[k + 2]) &&
              !(st.kind == STEP_CROSS_ATTN && fp.N[st.m] == 1 && mask == nullptr);
     }
     if (fuse) {
@@ -1597,7 +1612,7 @@ int hn_fusion_forward_train(const hn_model *m, const hn_modality_input *in, int 
         AttnPlan pn;
         if ((rc = plan_attn(an, !nself, nself ? 0 : fp.ldz[sn.m], b, L, nself ? L : fp.N[sn.m], nself ? d : fp.D[sn.m], nullptr, 0, &pn)) != HN_OK) return rc;
         const bool one_token = !nself && fp.N[sn.m] == 1 && mask == nullptr && !(an->dropout > 0.0f);
-        if (!one_token && pn.dh == pn.dhp && pn.inner % 128 == 0 && an->query_dim == d && an->w_q && an->w_kv) {
+        if (!one_token && pn.dh == pn.dhp && pn.inner % 128 == 0 && an->query_dim == d && an->w_q && an->w_kv && chain_proj_aligned(an)) {
           ca.p_nw = an->norm_w; ca.p_nb = an->norm_b;
           ca.nq = pn.inner; ca.wq = an->w_q; ca.Q = fp.cq; ca.ldq = pn.inner;
           ca.alpha_q = pn.rank_d ? 1.0f : pn.cscale;
@@ -1772,7 +1787,8 @@ static int plan_latent_block(const hn_attn_params *ap, const hn_ff_params *fp, i
   Arena ar(ws, ws_bytes);
   const size_t rows = (size_t)b * L;
   lp->chain = latent_chain_supported((int)rows, ap->query_dim, 4 * fp->dim) && pl.dh == pl.dhp && pl.inner % 128 == 0 && pl.inner <= 512 &&
-              fp->dropout == 0.0f && ap->dropout == 0.0f && getenv("HN_NO_CHAIN") == nullptr;
+              fp->dropout == 0.0f && ap->dropout == 0.0f && !chain_disabled() && chain_ff_aligned(fp) && chain_out_aligned(ap) &&
+              chain_proj_aligned(ap);
   lp->q = ar.take<float>(rows * pl.heads * pl.dhp);
   lp->kv = ar.take<float>(rows * 2 * pl.heads * pl.dhp);
   lp->xmid = ar.take<float>(rows * ap->query_dim);
@@ -1805,7 +1821,8 @@ int hn_latent_block_fwd(const hn_attn_params *attn, const hn_ff_params *ff, cons
   const bool training = saved != nullptr;        // the training form keeps x_mid / stats / saved for hn_latent_block_bwd
   HN_REQUIRE(!training || (x_mid && stats), HN_E_NULL, "latent_block: the training form needs x_mid and stats");
   const bool drops = training && (attn->dropout > 0.0f || ff->dropout > 0.0f);
-  if (!lp.chain || drops) {                      // unfused: the two blocks back to back (any shape; dropout)
+  const bool aligned = al16(x_in) && al16(x_out) && al16(x_mid) && al16(saved);
+  if (!lp.chain || drops || !aligned) {                      // unfused: the two blocks back to back (any shape; dropout)
     float *mid = x_mid ? x_mid : lp.xmid;
     if ((rc = attn_fwd_impl(attn, x_in, mid, 1, nullptr, 0, b, L, L, d, nullptr, stats, lp.op, lp.op_bytes, s, nullptr, nullptr, saved)) != HN_OK)
       return rc;

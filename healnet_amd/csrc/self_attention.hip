@@ -143,10 +143,11 @@ __global__ __launch_bounds__(512) void self_core_lds_kernel(AttnCoreArgs a) {
 }  // namespace
 
 bool self_core_lds_eligible(const AttnCoreArgs &a) {
+  static const bool force = getenv("HN_FORCE_SELF_LDS") != nullptr;
   static const bool off = getenv("HN_NO_SELF_LDS") != nullptr;       // development switch: the split-KV core instead
   // one workgroup per (sample, head): below ~3/4 of the CUs the split-KV core (one query tile per wave, spread over the chip)
   // wins -- cfg2 forward with / without: b = 8 1.232 / 1.216 ms, b = 32 2.966 / 2.974, b = 64 5.813 / 5.834, b = 128 11.48 / 11.51
-  const bool enough = (long)a.b * a.h >= 192 || getenv("HN_FORCE_SELF_LDS") != nullptr;
+  const bool enough = (long)a.b * a.h >= 192 || force;
   auto al16 = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
   return !off && enough && a.dp == 64 && a.dh == 64 && a.nsplit == 1 && a.Ofinal != nullptr && !a.ones_col && a.drop.thr == 0 && a.mask == nullptr &&
          a.N >= 1 && a.N <= ST && a.Lq >= 1 && a.Lq <= ST && a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0 && a.ldk >= 64 &&

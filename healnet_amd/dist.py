@@ -15,14 +15,34 @@ import torch
 import torch.distributed as dist
 
 
+def force_collectives() -> bool:
+    """HN_FORCE_COLLECTIVES=1: a process group of ONE rank still issues every collective (instead of the world == 1 early
+    returns below).  This is how the RCCL code path -- ``init_process_group("nccl", device_id=...)``, ``ReduceOp.AVG`` on a side
+    stream from inside the hn_grad_ready host callback, all_gather, MAX all-reduce, barrier -- is exercised on a 1-GPU box
+    (tests/test_gpu_rccl.py, ``HN_BENCH_FORCE_DIST=1 python bench.py --gpus 1``)."""
+    return os.environ.get("HN_FORCE_COLLECTIVES", "0") == "1"
+
+
+def _active() -> bool:
+    return dist.is_initialized() and (dist.get_world_size() > 1 or force_collectives())
+
+
+def _free_port() -> int:
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
 def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     """Initialise the default process group from torchrun's environment.  Returns (rank, world, local_rank)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_collectives()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
+        if "MASTER_PORT" not in os.environ:
+            os.environ["MASTER_PORT"] = str(_free_port() if world == 1 else 29500)
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         kwargs = {}
@@ -49,7 +69,7 @@ def shard_batch(tensors: Sequence[Optional[torch.Tensor]], rank: int, world: int
 
 def gather_outputs(local: torch.Tensor, n_total: int) -> torch.Tensor:
     """All-gather per-rank outputs of a sharded forward back into batch order (ragged shards allowed)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _active():
         return local
     world = dist.get_world_size()
     sizes = [shard_bounds(n_total, r, world) for r in range(world)]
@@ -63,7 +83,7 @@ def gather_outputs(local: torch.Tensor, n_total: int) -> torch.Tensor:
 
 def allreduce_mean_(tensors: Iterable[torch.Tensor], bucket_bytes: int = 32 << 20) -> None:
     """In-place average of a list of tensors (e.g. gradients) across ranks using flat buckets."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _active():
         return
     world = dist.get_world_size()
     bucket: List[torch.Tensor] = []
@@ -181,7 +201,7 @@ class GradReadyAllReduce:
         ops.unregister_backward_hook(self.flat.grads)
 
     def _allreduce_mean(self, view: torch.Tensor) -> None:
-        if not dist.is_initialized() or dist.get_world_size() == 1:
+        if not _active():
             return
         if dist.get_backend() == "nccl":
             dist.all_reduce(view, op=dist.ReduceOp.AVG)
@@ -223,7 +243,7 @@ class GradReadyAllReduce:
 
 def max_over_ranks(value: float, device: Optional[torch.device] = None) -> float:
     """bench.py timing contract: the slowest rank defines the step time."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _active():
         return value
     t = torch.tensor([value], dtype=torch.float64, device=device or "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -61,19 +61,14 @@ def default(val, d):                         # healnet.py:273-274
 
 
 def cache_fn(f):
-    """healnet.py:276-290: memoise a factory by ``key`` while ``_cache`` is true -- how weight tying is implemented."""
-    import functools
-    cache: dict = {}
+    """Name-compatibility shim for healnet.py:276-290 (the product's weight tying goes through ``_Memo`` below): the returned
+    callable takes the reference's ``_cache`` / ``key`` keywords; results are stored per ``key`` only."""
+    store: dict = {}
 
-    @functools.wraps(f)
     def cached_fn(*args, _cache=True, key=None, **kwargs):
-        if not _cache:
-            return f(*args, **kwargs)
-        if key in cache:
-            return cache[key]
-        result = f(*args, **kwargs)
-        cache[key] = result
-        return result
+        return _Memo(lambda: f(*args, **kwargs), store)(bool(_cache), key)
+    cached_fn.__name__ = getattr(f, "__name__", "cached_fn")
+    cached_fn.__doc__ = getattr(f, "__doc__", None)
     return cached_fn
 
 
@@ -347,9 +342,9 @@ class _Memo:
     """Weight-tying helper with the reference's ``cache_fn`` semantics (healnet.py:278-290): a factory
     result is stored / reused per key only when caching is requested for that call."""
 
-    def __init__(self, factory: Callable[[], nn.Module]):
+    def __init__(self, factory: Callable[[], nn.Module], store: Optional[dict] = None):
         self._factory = factory
-        self._store: Dict[object, nn.Module] = {}
+        self._store: Dict[object, nn.Module] = {} if store is None else store
 
     def __call__(self, use_cache: bool, key=None) -> nn.Module:
         if not use_cache:

@@ -792,9 +792,13 @@ def _fusion_setup(ctx, inputs, output):
     ctx.spec, ctx.skip_self, ctx.embeddings, ctx.grad_offsets = spec, skip_self, embeddings, list(grad_offsets)
     ctx.present = [t is not None for t in tensors]
     ctx.n_params = len(params)
-    ctx.flags = (mask is not None, rng is not None, grad_buffer is not None)
+    ctx.flags = (mask is not None, rng is not None)
     ctx.needs = [bool(p.requires_grad) for p in params]
-    extra = [t for t in (mask, rng, grad_buffer) if t is not None]
+    # the flat gradient buffer is WRITTEN by every backward (and by the side-stream all-reduce on its views): kept as a plain
+    # attribute, not through save_for_backward -- with two forwards in front of one backward (two model calls summed into one
+    # loss) the first backward bumps its version counter and the second would fail autograd's saved-tensor check
+    ctx.grad_buffer = grad_buffer
+    extra = [t for t in (mask, rng) if t is not None]
     ctx.save_for_backward(tape, *params, *[t for t in tensors if t is not None], *extra)
 
 
@@ -803,7 +807,8 @@ def _fusion_backward_formula(ctx, dout, dtape, dlayout):
     tape, params = saved[0], saved[1:1 + ctx.n_params]
     it = iter(saved[1 + ctx.n_params:])
     tensors = [next(it) if have else None for have in ctx.present]
-    mask, rng, grad_buffer = [next(it) if have else None for have in ctx.flags]
+    mask, rng = [next(it) if have else None for have in ctx.flags]
+    grad_buffer = ctx.grad_buffer
     if grad_buffer is not None:
         torch.ops.healnet_hip.fusion_backward_into(dout.contiguous(), tape, tensors, mask, params, ctx.spec, ctx.skip_self,
                                                    ctx.embeddings, rng, grad_buffer, ctx.grad_offsets)

@@ -1,0 +1,136 @@
+"""GPU: regression tests for the advisor's round-2 findings, each against the CPU oracle.
+
+  * explicit (D > 31) multi-head CROSS block behind a chain with N >> l_c and self_per_cross_attn = 0: its K/V projection must
+    live in the block's own scratch, not in the chain's latent-K/V buffer (sized for l_c rows) -- run under HN_POISON_WS=1
+    (every call starts from an all-NaN workspace) at a split and an unsplit geometry, both forwards;
+  * padded head width behind a chain (dim_head 48 x 8 heads, inner = 384): the pad columns of Q are zero-filled in the buffer
+    the Q projection actually writes;
+  * two forwards in front of one backward on the FlatParameters route (the flat gradient buffer is not an autograd-saved tensor);
+  * a parameter that is a view at an odd float offset (unaligned for the chain's 16-byte loads) takes the per-block launches
+    instead of failing the forward.
+"""
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+import torch
+
+from conftest import assert_close
+from oracle import healnet_cpu as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def hn():
+    import healnet_amd
+    return healnet_amd
+
+
+_POISON_SCRIPT = textwrap.dedent("""
+    import json, sys, torch
+    sys.path.insert(0, {root!r})
+    import healnet_amd as hn
+    from healnet_amd import _rt
+    from oracle import healnet_cpu as O
+    assert _rt._POISON
+    kw = {kw!r}
+    shapes = {shapes!r}
+    torch.manual_seed(101)
+    model = hn.HealNet(**kw).eval()
+    gen = torch.Generator().manual_seed(102)
+    ins = [torch.rand(*s, generator=gen) for s in shapes]
+    sd = {{k: v.detach().clone() for k, v in model.state_dict().items()}}
+    with torch.no_grad():
+        want = O.fusion_forward(sd, O.FusionConfig(**kw), [t.clone() for t in ins])
+    model.to("cuda:0")
+    out = {{}}
+    for name, grad in (("inference", False), ("taping", True)):
+        with torch.set_grad_enabled(grad):
+            runs = [model([t.to("cuda:0") for t in ins]).detach().cpu() for _ in range(3)]
+        out[name] = {{"finite": bool(all(torch.isfinite(r).all() for r in runs)),
+                     "deterministic": bool(all(torch.equal(runs[0], r) for r in runs[1:])),
+                     "rel_err": float((runs[0] - want).abs().max() / want.abs().max())}}
+    print("RESULT " + json.dumps(out))
+""")
+
+
+def _run_poisoned(kw, shapes):
+    env = dict(os.environ, HN_POISON_WS="1")
+    out = subprocess.run([sys.executable, "-c", _POISON_SCRIPT.format(root=ROOT, kw=kw, shapes=shapes)], cwd=ROOT, capture_output=True,
+                         text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    import json
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1]
+    return json.loads(line[len("RESULT "):])
+
+
+@pytest.mark.parametrize("n_tokens,b", [(200, 2), (600, 2), (3000, 1)], ids=["unsplit", "n600", "split"])
+def test_explicit_cross_block_behind_a_chain_keeps_its_own_kv(n_tokens, b):
+    kw = dict(n_modalities=1, channel_dims=[40], num_spatial_axes=[1], out_dims=3, depth=3, l_c=16, l_d=128, x_heads=2,
+              cross_dim_head=64, self_per_cross_attn=0, num_freq_bands=2)
+    res = _run_poisoned(kw, [(b, n_tokens, 40)])
+    for name, r in res.items():
+        assert r["finite"] and r["deterministic"], (name, r)
+        assert r["rel_err"] < 1e-3, (name, r)
+
+
+def test_padded_head_width_behind_a_chain():
+    kw = dict(n_modalities=2, channel_dims=[30, 50], num_spatial_axes=[1, 1], out_dims=3, depth=2, l_c=32, l_d=128, x_heads=8,
+              cross_dim_head=48, l_heads=8, latent_dim_head=48, num_freq_bands=2)
+    res = _run_poisoned(kw, [(3, 1, 30), (3, 70, 50)])
+    for name, r in res.items():
+        assert r["finite"] and r["deterministic"], (name, r)
+        assert r["rel_err"] < 1e-3, (name, r)
+
+
+def test_two_forwards_one_backward_on_the_flat_route(hn):
+    kw = dict(n_modalities=2, channel_dims=[20, 3], num_spatial_axes=[1, 2], out_dims=3, depth=2, l_c=16, l_d=32, x_heads=2, l_heads=2,
+              cross_dim_head=16, latent_dim_head=16, num_freq_bands=2)
+    torch.manual_seed(5)
+    model = hn.HealNet(**kw).train().to(DEV)
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    gen = torch.Generator().manual_seed(6)
+    a = [torch.rand(3, 1, 20, generator=gen), torch.rand(3, 10, 12, 3, generator=gen)]
+    c = [torch.rand(3, 1, 20, generator=gen), torch.rand(3, 10, 12, 3, generator=gen)]
+    cfg = O.FusionConfig(**kw)
+    want = (O.fusion_forward(sd, cfg, [t.clone() for t in a]).square().sum() + O.fusion_forward(sd, cfg, [t.clone() for t in c]).sum())
+    want.backward()
+    flat = hn.train.flatten_parameters(model)
+    flat.zero_grad()
+    loss = model([t.to(DEV) for t in a]).square().sum() + model([t.to(DEV) for t in c]).sum()
+    loss.backward()                                   # two fusion_backward_into calls on one flat buffer
+    assert_close(loss.detach().cpu(), want.detach(), rel=1e-4, floor=0.0, abs_floor=1e-5, what="summed loss")
+    scale = max(float(v.grad.abs().max()) for v in sd.values() if v.grad is not None)
+    for k, p in model.named_parameters():
+        ref = sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])
+        assert float((p.grad.cpu() - ref).abs().max()) <= 5e-4 * scale, k
+
+
+@pytest.mark.parametrize("grad_mode", [False, True], ids=["inference", "taping"])
+def test_unaligned_parameter_views_take_the_unfused_route(hn, grad_mode):
+    kw = dict(n_modalities=2, channel_dims=[60, 3], num_spatial_axes=[1, 2], out_dims=4, depth=2, l_c=32)
+    torch.manual_seed(9)
+    model = hn.HealNet(**kw).eval().to(DEV)
+    # re-home some parameters the chain would read with 16-byte loads as views at an odd float offset
+    moved = 0
+    for name, p in model.named_parameters():
+        if name.endswith(("fn.net.0.weight", "fn.to_out.0.weight", "fn.to_q.weight")) and moved < 6:
+            buf = torch.empty(p.numel() + 1, device=DEV)
+            buf[1:].copy_(p.data.reshape(-1))
+            p.data = buf[1:].view_as(p)
+            assert p.data_ptr() % 16 != 0
+            moved += 1
+    assert moved == 6
+    gen = torch.Generator().manual_seed(10)
+    ins = [torch.rand(3, 1, 60, generator=gen), torch.rand(3, 20, 24, 3, generator=gen)]
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        want = O.fusion_forward(sd, O.FusionConfig(**kw), [t.clone() for t in ins])
+    with torch.set_grad_enabled(grad_mode):
+        got = model([t.to(DEV) for t in ins]).detach().cpu()
+    assert_close(got, want, rel=1e-3, floor=0.0, abs_floor=1e-5, what="unaligned parameter views")
