@@ -149,6 +149,22 @@ class Spec:
             core_precision=d["core_precision"], rng=r)
         return model, [ca, cf, sa, sf, cd, ax]
 
+    def model_cached(self, params: Sequence[torch.Tensor]):
+        """Inference descriptor of ``params``, memoised on the parameters' addresses: rebuilding the ~125 pointer fields through
+        ctypes costs a large part of the ~0.8 ms a forward spends on the host, which is what bounds the path at b <= 4 (VERDICT
+        r2).  The descriptor only holds addresses, so it stays valid exactly as long as the key (a re-homed parameter changes
+        the key; a handful of entries are kept: the fp32 model, its flat-parameter twin, ...)."""
+        key = tuple(p.data_ptr() for p in params)
+        cache = self.__dict__.setdefault("_model_cache", {})
+        hit = cache.get(key)
+        if hit is None:
+            if len(cache) >= 8:
+                cache.clear()
+            for p in params:
+                _ptr(p)                                  # the dtype / contiguity checks of the uncached route
+            hit = cache[key] = self.model(params)
+        return hit
+
     def grads(self, gptr: Sequence[Optional[int]]):
         """hn_model_grads whose entries are the addresses ``gptr[param index]`` (None = no gradient wanted)."""
         d = self.d
@@ -640,7 +656,7 @@ def _fusion_forward(tensors, mask, params, spec, skip_self, embeddings, keep_sta
     sp = spec_of(spec)
     device = params[0].device
     with torch.cuda.device(device):        # kernels are launched on the CURRENT device of the calling thread
-        model, keep = sp.model(params)
+        model, keep = sp.model_cached(params)
         inp, held, b = sp.inputs(tensors)
         need = lib.hn_fusion_workspace_bytes(C.byref(model), inp, b)
         if need == 0:

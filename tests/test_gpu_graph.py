@@ -1,0 +1,123 @@
+"""GPU: the small-batch latency path (Next 4): ``HealNet.capture`` -- one inference forward as a HIP graph owned by
+the model (static workspace / statistics / input buffers), replayed with one host call.  README.md:96-110 of the reference
+calls the model at b = 1; BASELINE configs[0] is b = 4.
+
+  * replay == eager forward bit for bit, == the CPU oracle within the fp32 tolerance, on new input VALUES of the captured shapes
+    (3-modality README shape at reduced volume, cfg1 at its full image size, b = 1 and 4);
+  * attention weights exported after a replay belong to the replayed inputs;
+  * shape / missing-modality changes are refused loudly; masks and `return_embeddings` are part of the capture;
+  * the cached inference descriptor (ops.Spec.model_cached) follows re-homed parameters.
+"""
+import pytest
+import torch
+
+from conftest import assert_close
+from oracle import healnet_cpu as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def hn():
+    import healnet_amd
+    return healnet_amd
+
+
+def _oracle(model, kw, ins, **extra):
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        return O.fusion_forward(sd, O.FusionConfig(**kw), [None if t is None else t.clone() for t in ins], **extra)
+
+
+@pytest.mark.parametrize("b", [1, 4])
+@pytest.mark.parametrize("case", ["cfg1", "readme3"])
+def test_graph_replay_equals_eager_and_oracle(hn, case, b):
+    if case == "cfg1":
+        kw = dict(n_modalities=2, channel_dims=[2000, 3], num_spatial_axes=[1, 2], out_dims=4)
+        shapes = [(1, 2000), (224, 224, 3)]
+    else:
+        kw = dict(n_modalities=3, channel_dims=[2000, 3, 3], num_spatial_axes=[1, 2, 3], out_dims=4)
+        shapes = [(1, 2000), (64, 48, 3), (3, 40, 36, 3)]
+    torch.manual_seed(21)
+    model = hn.HealNet(**kw).eval().to(DEV)
+    gen = torch.Generator().manual_seed(22)
+    first = [torch.rand(b, *s, generator=gen) for s in shapes]
+    graph = model.capture([t.to(DEV) for t in first])
+    for trial in range(3):                                   # new VALUES of the captured shapes
+        ins = [torch.rand(b, *s, generator=gen) for s in shapes]
+        with torch.no_grad():
+            got = graph([t.to(DEV) for t in ins]).clone()
+            eager = model([t.to(DEV) for t in ins])
+        assert torch.equal(got, eager), f"trial {trial}: graph replay differs from the eager forward"
+        if case == "readme3" or trial == 0:
+            assert_close(got.cpu(), _oracle(model, kw, ins), rel=1e-3, floor=0.0, abs_floor=1e-5, what=f"{case} b={b} graph replay vs oracle")
+    # the statistics / trace buffers are static: attention weights after a replay belong to the replayed inputs
+    ins = [torch.rand(b, *s, generator=gen) for s in shapes]
+    with torch.no_grad():
+        graph([t.to(DEV) for t in ins])
+        w_graph = [None if w is None else w.clone() for w in model.get_attention_weights()]
+        model([t.to(DEV) for t in ins])
+        w_eager = model.get_attention_weights()
+    assert len(w_graph) == len(w_eager)
+    for a, e in zip(w_graph, w_eager):
+        assert (a is None) == (e is None)
+        if a is not None:
+            assert torch.equal(a, e)
+    # in-place weight updates are seen by the next replay (parameters are read in place)
+    with torch.no_grad():
+        model.to_logits[2].bias.add_(0.5)
+        got = graph([t.to(DEV) for t in ins]).clone()
+        assert torch.equal(got, model([t.to(DEV) for t in ins]))
+
+
+def test_graph_refuses_other_shapes_and_keeps_mask_and_embeddings(hn):
+    kw = dict(n_modalities=2, channel_dims=[30, 3], num_spatial_axes=[1, 2], out_dims=3, depth=2, l_c=16, l_d=32, x_heads=2, l_heads=2,
+              cross_dim_head=16, latent_dim_head=16)
+    torch.manual_seed(31)
+    model = hn.HealNet(**kw).eval().to(DEV)
+    gen = torch.Generator().manual_seed(32)
+    seq = torch.rand(2, 40, 30, generator=gen)
+    img = torch.rand(2, 8, 5, 3, generator=gen)
+    mask = torch.rand(2, 40, generator=gen) > 0.3
+    mask[:, 0] = True
+    g = model.capture([seq.to(DEV), None], mask=mask.to(DEV), return_embeddings=True)
+    seq2 = torch.rand(2, 40, 30, generator=gen)
+    mask2 = torch.rand(2, 40, generator=gen) > 0.5
+    mask2[:, 1] = True
+    got = g([seq2.to(DEV), None], mask=mask2.to(DEV)).clone()
+    want = _oracle(model, kw, [seq2, None], mask=mask2, return_embeddings=True)
+    assert got.shape == (2, 16, 32)
+    assert_close(got.cpu(), want, rel=1e-3, floor=0.0, abs_floor=1e-5, what="masked graph replay, embeddings")
+    with pytest.raises(ValueError):
+        g([seq2.to(DEV)[:1], None])
+    with pytest.raises(ValueError):
+        g([seq2.to(DEV), img.to(DEV)])
+    model.train()
+    model2 = hn.HealNet(**kw, attn_dropout=0.1).train().to(DEV)
+    with pytest.raises(RuntimeError):
+        model2.capture([seq.to(DEV), None])
+
+
+def test_cached_descriptor_follows_rehomed_parameters(hn):
+    kw = dict(n_modalities=2, channel_dims=[30, 3], num_spatial_axes=[1, 2], out_dims=3, depth=2, l_c=16, l_d=32, x_heads=2, l_heads=2,
+              cross_dim_head=16, latent_dim_head=16)
+    torch.manual_seed(41)
+    model = hn.HealNet(**kw).eval().to(DEV)
+    gen = torch.Generator().manual_seed(42)
+    ins = [torch.rand(3, 1, 30, generator=gen), torch.rand(3, 8, 6, 3, generator=gen)]
+    with torch.no_grad():
+        a = model([t.to(DEV) for t in ins]).clone()
+        a2 = model([t.to(DEV) for t in ins])
+        assert torch.equal(a, a2)
+        # re-home every parameter (new storage, new values): the memoised descriptor must not be reused
+        for p in model.parameters():
+            p.data = (p.data * 1.5).clone()
+        b_ = model([t.to(DEV) for t in ins])
+    assert_close(b_.cpu(), _oracle(model, kw, ins), rel=1e-3, floor=0.0, abs_floor=1e-5, what="after re-homing the parameters")
+    assert not torch.equal(a, b_)
+    flat = hn.train.flatten_parameters(model)                # re-homes everything once more
+    with torch.no_grad():
+        c = model([t.to(DEV) for t in ins])
+    assert torch.equal(c, b_)
+    assert flat.numel > 0
