@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HN_LIB_PATH") or os.path.join(_HERE, "libhealnet_hip.so")   # HN_LIB_PATH: kernel experiments (tools/)
 CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ["api.hip", "gemm.hip", "attention.hip", "attention_bf16.hip", "attention_bwd.hip", "encode.hip", "misc.hip",
-           "backward.hip", "train.hip", "chain.hip", "self_attention.hip"]
+           "backward.hip", "train.hip", "chain.hip", "self_attention.hip", "bchain.hip"]
 
 c_float_p = C.POINTER(C.c_float)
 
@@ -167,7 +167,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     the public header is newer than its object.  ``force`` (or HN_FORCE_REBUILD=1) rebuilds everything from a clean slate."""
     from concurrent.futures import ThreadPoolExecutor
     force = force or os.environ.get("HN_FORCE_REBUILD", "0") == "1"
-    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(_HERE, "..", "include", "healnet_hip.h")]
+    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "chain_common.h"), os.path.join(_HERE, "..", "include", "healnet_hip.h")]
     objdir = os.path.join(_HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

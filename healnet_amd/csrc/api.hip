@@ -31,6 +31,7 @@ static inline DropCfg drop_of(float p, const hn_rng &r, bool ff) {
 }
 // development switches, read ONCE per process (no getenv on the launch path)
 static bool chain_disabled() { static const bool off = getenv("HN_NO_CHAIN") != nullptr; return off; }
+static bool bchain_disabled() { static const bool off = getenv("HN_NO_BCHAIN") != nullptr; return off; }
 static bool merge_chain_disabled() { static const bool off = getenv("HN_NO_MERGE_CHAIN") != nullptr; return off; }
 // operands the latent chain reads with 16-byte loads: an unaligned one (a parameter that is a view at an odd float offset of a
 // user-made flat buffer, a tape / trace slot) sends the block down the per-block launches instead of failing the forward
@@ -435,10 +436,22 @@ static GemmExArgs gex(const float *A, long a_rs, long a_cs, const float *B, long
   return e;
 }
 
+// Hooks of the fused latent backward (bchain.hip) into an attention block's backward: the chain behind the block (in backward
+// order: in front of it) has already produced dpre = dy * LeakyReLU'(.) and dO = dpre W_out, and / or the chain in front of it
+// will run the projection backward (dx_hat = dQ W_q + dKV W_kv, LayerNorm backward, residual) and the batched weight-gradient
+// launch takes dW_q / dW_kv (and dW_out when the block's O is on the tape).
+struct AttnBwdExt {
+  const float *dpre, *dO;    // given (rows, query_dim) / (rows, inner): the LeakyReLU backward and the dO product are skipped
+  bool skip_wout;            // dW_out / db_out are left to the caller's batched launch (O = the tape's, explicit bindings only)
+  bool defer_proj;           // stop behind the core: no dW_q / dW_kv, no dx; dQ / dKV / xhat are reported instead
+  const float *dQ, *dKV, *xhat;   // out (defer_proj): (rows, inner) scaled, (rows, 2 inner) or NULL (cross blocks), LN(x_in) (rows, query_dim)
+  const float *O;            // out: the block's attention output (rows, inner) -- the tape's or the recomputed one
+};
+
 static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float *x_out, int residual, const float *ctx,
                          int ld_ctx, int b, int L, int N, int D, const uint8_t *mask, const float *stats, const float *saved,
                          const float *dy, float *dx, const hn_attn_grads *g, void *ws, size_t ws_bytes, hipStream_t s,
-                         int ctx_pack_ks = 0) {
+                         int ctx_pack_ks = 0, AttnBwdExt *ext = nullptr) {
   HN_REQUIRE(p && x_in && x_out && stats && saved && dy && dx && g, HN_E_NULL, "attn_bwd: NULL pointer");
   HN_REQUIRE(p->w_q && p->w_kv && p->w_out, HN_E_NULL, "attn_bwd: weight pointer is NULL");
   const bool has_ctx = ctx != nullptr;
@@ -456,9 +469,12 @@ static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float
   const int rows = b * L, qd = p->query_dim, inner = pl.inner, h = p->heads, dh = pl.dh;
   const float two_scale = 2.0f / sqrtf((float)dh);
   // dpre = dy * LeakyReLU'(pre); the sign of pre is the sign of y = x_out - x_in
-  if ((rc = launch_leaky_bwd(dy, x_out, residual ? x_in : nullptr, bp.dpre, (long)rows * qd, s)) != HN_OK) return rc;
+  const float *dpre = bp.dpre;
+  if (ext && ext->dpre) dpre = ext->dpre;
+  else if ((rc = launch_leaky_bwd(dy, x_out, residual ? x_in : nullptr, bp.dpre, (long)rows * qd, s)) != HN_OK) return rc;
 
-  if (has_ctx && pl.N == 1 && !general) {   // ---- one-token context: y_b = LeakyReLU(W_out V_b + b_out) for every row
+  if (has_ctx && pl.N == 1 && !general) {
+    HN_REQUIRE(!ext, HN_E_UNSUPPORTED, "attn_bwd: the one-token shortcut takes no chain hooks");   // ---- one-token context: y_b = LeakyReLU(W_out V_b + b_out) for every row
     if ((rc = launch_segsum(bp.dpre, L, qd, b, bp.dyb, s)) != HN_OK) return rc;
     if (g->b_out && (rc = launch_colsum(bp.dyb, qd, b, qd, 1.0f, g->b_out, 1, s, bp.red)) != HN_OK) return rc;
     if (g->w_out) {   // dWo += dyb^T V
@@ -494,13 +510,18 @@ static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float
     if ((rc = launch_gemm_ex(e, s, bp.red)) != HN_OK) return rc;
     O = pl.obuf;
   }
-  if (g->w_out) {      // dWo += dpre^T O, and db_out += colsum(dpre) from the same pass over dpre
-    GemmExArgs e = gex(bp.dpre, 1, qd, O, 1, inner, g->w_out, inner, qd, inner, rows, 1);
+  if (ext) ext->O = O;
+  if (ext && ext->skip_wout) {
+    // dW_out / db_out: the caller's batched weight-gradient launch
+  } else if (g->w_out) {      // dWo += dpre^T O, and db_out += colsum(dpre) from the same pass over dpre
+    GemmExArgs e = gex(dpre, 1, qd, O, 1, inner, g->w_out, inner, qd, inner, rows, 1);
     e.colsum = g->b_out; e.colsum_accumulate = 1;
     if ((rc = launch_gemm_ex(e, s, bp.red)) != HN_OK) return rc;
-  } else if (g->b_out && (rc = launch_colsum(bp.dpre, qd, rows, qd, 1.0f, g->b_out, 1, s, bp.red)) != HN_OK) return rc;
-  {
-    GemmExArgs e = gex(bp.dpre, qd, 1, p->w_out, 1, inner, bp.dO, inner, rows, inner, qd, 0);
+  } else if (g->b_out && (rc = launch_colsum(dpre, qd, rows, qd, 1.0f, g->b_out, 1, s, bp.red)) != HN_OK) return rc;
+  const float *dO = bp.dO;
+  if (ext && ext->dO) dO = ext->dO;
+  else {
+    GemmExArgs e = gex(dpre, qd, 1, p->w_out, 1, inner, bp.dO, inner, rows, inner, qd, 0);
     if ((rc = launch_gemm_ex(e, s, bp.red)) != HN_OK) return rc;
   }
 
@@ -532,13 +553,13 @@ static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float
     float *dwv = g->w_kv ? g->w_kv + (long)inner * pl.D : nullptr, *dwk = g->w_kv;
     // O_h = A_h W_v,h^T with A = P z * gamma + beta:  dW_v,h += dO_h^T A_h ;  dA_h = dO_h W_v,h
     if (dwv) {
-      GemmExArgs e = gex(bp.dO, 1, inner, bp.Abuf, 1, hp, dwv, pl.D, dh, pl.D, rows, 1);
+      GemmExArgs e = gex(dO, 1, inner, bp.Abuf, 1, hp, dwv, pl.D, dh, pl.D, rows, 1);
       e.batch = h; e.strideA = dh; e.strideB = pl.dp; e.strideC = (long)dh * pl.D;
       if ((rc = launch_gemm_ex(e, s, bp.red)) != HN_OK) return rc;
     }
     { int rc_ = launch_fill(bp.dA, 0.0f, (long)((size_t)rows * hp), s); if (rc_ != HN_OK) return rc_; }
     {
-      GemmExArgs e = gex(bp.dO, inner, 1, wv, 1, pl.D, bp.dA, hp, rows, pl.D, dh, 0);
+      GemmExArgs e = gex(dO, inner, 1, wv, 1, pl.D, bp.dA, hp, rows, pl.D, dh, 0);
       e.batch = h; e.strideA = dh; e.strideB = (long)dh * pl.D; e.strideC = pl.dp;
       if ((rc = launch_gemm_ex(e, s, bp.red)) != HN_OK) return rc;
     }
@@ -590,9 +611,13 @@ static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float
     }
   } else {
     const int qp = h * pl.dhp;
-    if ((rc = launch_rowdot_heads(bp.dO, inner, dh, O, inner, dh, h, L, dh, rows, bp.delta, s)) != HN_OK) return rc;
-    if ((rc = launch_head_affine(bp.dO, inner, dh, nullptr, 0, 0, nullptr, nullptr, 1.0f, h, dh, pl.dhp, qp, rows, bp.dOp, s)) != HN_OK) return rc;
-    ba.dO = bp.dOp; ba.do_b = (long)L * qp; ba.do_h = pl.dhp; ba.lddo = qp;
+    if ((rc = launch_rowdot_heads(dO, inner, dh, O, inner, dh, h, L, dh, rows, bp.delta, s)) != HN_OK) return rc;
+    if (pl.dhp == dh) {          // no head padding: the core reads dO where it is (the padding copy is the identity)
+      ba.dO = dO; ba.do_b = (long)L * inner; ba.do_h = dh; ba.lddo = inner;
+    } else {
+      if ((rc = launch_head_affine(dO, inner, dh, nullptr, 0, 0, nullptr, nullptr, 1.0f, h, dh, pl.dhp, qp, rows, bp.dOp, s)) != HN_OK) return rc;
+      ba.dO = bp.dOp; ba.do_b = (long)L * qp; ba.do_h = pl.dhp; ba.lddo = qp;
+    }
     if ((rc = launch_attn_bwd_dq(ba, s)) != HN_OK) return rc;
     if ((rc = launch_dq_reduce(bp.dQpart, pl.nsplit_bwd, b, h, L, pl.Lp, pl.dp, dh, two_scale, bp.dQ, inner, dh, s)) != HN_OK) return rc;
     ba.dKV = bp.dKV; ba.dk_scale = 0.69314718055994530942f;
@@ -604,12 +629,18 @@ static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float
       if ((rc = launch_gemm_ex(e, s, bp.red)) != HN_OK) return rc;
       if ((rc = launch_kv_weight_grads(bp.G, bp.cs, p->w_kv, p->ctx_gamma, p->ctx_beta, 2 * inner, pl.D, g->w_kv, g->ctx_gamma,
                                        g->ctx_beta, s, bp.red)) != HN_OK) return rc;
-    } else if (g->w_kv) {   // self-attention: K, V come from x_hat
+    } else if (g->w_kv && !(ext && ext->defer_proj)) {   // self-attention: K, V come from x_hat
       GemmExArgs e = gex(bp.dKV, 1, 2 * inner, xhat, 1, qd, g->w_kv, qd, 2 * inner, qd, rows, 1);
       if ((rc = launch_gemm_ex(e, s, bp.red)) != HN_OK) return rc;
     }
   }
 
+  if (ext && ext->defer_proj) {      // the chain in front of this block runs the projection backward; its batched launch dW_q / dW_kv
+    ext->dQ = bp.dQ;
+    ext->dKV = has_ctx ? nullptr : bp.dKV;
+    ext->xhat = xhat;
+    return HN_OK;
+  }
   // ---- query projection: dWq += dQ^T x_hat ; dx_hat = dQ Wq (+ dKV Wkv for self-attention)
   if (g->w_q) {
     GemmExArgs e = gex(bp.dQ, 1, inner, xhat, 1, qd, g->w_q, qd, inner, qd, rows, 1);
@@ -1002,7 +1033,8 @@ static int plan_tape(const hn_model *m, const hn_modality_input *in, int b, int 
 static void register_transposes(const hn_model *m, const hn_modality_input *in, int b, int masked, const Step *steps, int nsteps) {
   transpose_cache_begin();
   const int M = m->n_modalities, d = m->l_d;
-  if ((long)b * m->l_c < 256) return;                     // the NN route needs >= 256 rows (launch_gemm_ex)
+  // the NN route needs >= 256 rows (launch_gemm_ex); the fused latent backward (bchain.hip) reads the transposes at any row count
+  if ((long)b * m->l_c < 256 && !latent_bchain_supported(b * m->l_c, m->l_d, 4 * m->l_d)) return;
   auto add_attn = [&](const hn_attn_params &ap, bool self) {
     const int inner = ap.heads * ap.dim_head, qd = ap.query_dim;
     transpose_cache_add(ap.w_out, inner, qd, inner);      // dO = dpre W_out
@@ -1039,9 +1071,22 @@ static void register_transposes(const hn_model *m, const hn_modality_input *in, 
   (void)d;
 }
 
+// buffers of the fused latent backward (bchain.hip): what a chain hands to the batched weight-gradient launch and to the
+// attention core backward in front of it
+struct BChainBufs { float *H, *dU, *Xhat, *dYff, *dPre, *dO, *lnpart, *tn; size_t tn_floats; bool ok; };
+
+static size_t bchain_tn_scratch_floats(int rows) {      // the largest product set of a chain: dW1, dW2, dW_out, dW_q, dW_kv at inner = 512
+  GemmTnMulti mm;
+  memset(&mm, 0, sizeof(mm));
+  const int MN[5][2] = {{1024, 128}, {128, 512}, {128, 512}, {512, 128}, {1024, 128}};
+  mm.n = 5; mm.K = rows;
+  for (int i = 0; i < 5; ++i) { mm.p[i].M = MN[i][0]; mm.p[i].N = MN[i][1]; mm.p[i].colsum = (float *)(uintptr_t)(i < 3 ? 16 : 0); }
+  return gemm_tn_multi_scratch_floats(mm);
+}
+
 static int fusion_bwd_workspace(const hn_model *m, const hn_modality_input *in, int b, int masked, void *ws, size_t ws_bytes,
                                 FusionPlan *fp, float **dX, float **head_scratch, void **op_ws, size_t *op_bytes, size_t *total,
-                                float **tbuf = nullptr, size_t *tfloats = nullptr) {
+                                float **tbuf = nullptr, size_t *tfloats = nullptr, BChainBufs *bb = nullptr) {
   // same z / x carve as the forward (x is unused), then the backward scratch
   int rc = plan_fusion(m, in, b, nullptr, 0, fp);
   if (rc != HN_OK) return rc;
@@ -1085,6 +1130,22 @@ static int fusion_bwd_workspace(const hn_model *m, const hn_modality_input *in, 
   float *tb = ar.take<float>(tf);
   if (tbuf) *tbuf = tb;
   if (tfloats) *tfloats = tf;
+  BChainBufs cb;
+  memset(&cb, 0, sizeof(cb));
+  const int rows = b * m->l_c;
+  cb.ok = latent_bchain_supported(rows, m->l_d, 4 * m->l_d);
+  if (cb.ok) {
+    cb.H = ar.take<float>((size_t)rows * 512);
+    cb.dU = ar.take<float>((size_t)rows * 1024);
+    cb.Xhat = ar.take<float>((size_t)rows * 128);
+    cb.dYff = ar.take<float>((size_t)rows * 128);
+    cb.dPre = ar.take<float>((size_t)rows * 128);
+    cb.dO = ar.take<float>((size_t)rows * 512);
+    cb.lnpart = ar.take<float>((size_t)(rows / 16) * 4 * 128);
+    cb.tn_floats = bchain_tn_scratch_floats(rows);
+    cb.tn = ar.take<float>(cb.tn_floats);
+  }
+  if (bb) *bb = cb;
   *total = ar.off;
   if (ws != nullptr && ar.overflow) return fail(HN_E_WORKSPACE, "fusion_backward: workspace %zu bytes < required %zu", ws_bytes, ar.off);
   return HN_OK;
@@ -1687,7 +1748,8 @@ int hn_fusion_backward(const hn_model *m, const hn_modality_input *in, int b, co
   if ((rc = check_ws(workspace, workspace_bytes, total, "fusion_backward")) != HN_OK) return rc;
   float *tbuf = nullptr;
   size_t tfloats = 0;
-  if ((rc = fusion_bwd_workspace(m, in, b, mask != nullptr, workspace, workspace_bytes, &fp, &dX, &hs, &op, &opb, &total, &tbuf, &tfloats)) != HN_OK) return rc;
+  BChainBufs cb;
+  if ((rc = fusion_bwd_workspace(m, in, b, mask != nullptr, workspace, workspace_bytes, &fp, &dX, &hs, &op, &opb, &total, &tbuf, &tfloats, &cb)) != HN_OK) return rc;
   static thread_local TapePlan tp;
   if ((rc = plan_tape(m, in, b, mask != nullptr, skip_self_on_missing, fp, &tp)) != HN_OK) return rc;
   // every weight the dX products read transposed, in ONE batched launch per 16 instead of a launch in front of each product
@@ -1725,46 +1787,171 @@ int hn_fusion_backward(const hn_model *m, const hn_modality_input *in, int b, co
   int next_layer_event = m->depth - 1;     // highest layer whose event has not been recorded yet
   static const hn_attn_grads no_attn = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   static const hn_ff_grads no_ff = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  for (int k = tp.nsteps - 1; k >= 0; --k) {
-    const Step &st = tp.steps[k];
-    const float *xin = T + tp.x_off[k], *xout = T + tp.x_off[k + 1];
-    const hn_rng rng = {m->rng.seed, m->rng.offset, (uint32_t)k};      // the forward's generator state and stream id
-    switch (st.kind) {
-      case STEP_CROSS_ATTN: {
-        hn_attn_params ap = m->cross_attn[st.layer * M + st.m];
-        ap.rng = rng;
-        rc = attn_bwd_impl(&ap, xin, xout, 1, fp.z[st.m], fp.ldz[st.m], b, L, fp.N[st.m], fp.D[st.m],
-                           mask, T + tp.stats_off[k], T + tp.saved_off[k], dX, dX, g->cross_attn ? &g->cross_attn[st.layer * M + st.m] : &no_attn,
-                           op, opb, s, tpack[st.m]);
-        break;
+  // ---- the fused latent backward (bchain.hip): a feed-forward block's backward runs in ONE launch together with the projection
+  // backward of the attention block behind it (whose core backward has just run: `pend`) and the out-projection backward of the
+  // attention block in front of it; the weight gradients of the chain follow in one batched launch + one reduce.
+  const int rows = b * L;
+  const bool use_bchain = cb.ok && fp.chain && !bchain_disabled() && !chain_disabled();
+  struct Pending { bool valid; int layer; hn_attn_params ap; const hn_attn_grads *ag; const float *x_in, *dQ, *dKV, *xhat; } pend;
+  memset(&pend, 0, sizeof(pend));
+  auto is_attn_b = [](const Step &q) { return q.kind == STEP_CROSS_ATTN || q.kind == STEP_SELF_ATTN; };
+  auto attn_of = [&](const Step &q) { return q.kind == STEP_SELF_ATTN ? m->self_attn[q.layer] : m->cross_attn[q.layer * M + q.m]; };
+  auto attn_grads_of = [&](const Step &q) -> const hn_attn_grads * {
+    if (q.kind == STEP_SELF_ATTN) return g->self_attn ? &g->self_attn[q.layer] : &no_attn;
+    return g->cross_attn ? &g->cross_attn[q.layer * M + q.m] : &no_attn;
+  };
+  auto ff_of_b = [&](const Step &q) { return q.kind == STEP_CROSS_FF ? m->cross_ff[q.layer * M + q.m] : m->self_ff[q.layer]; };
+  auto ff_grads_of = [&](const Step &q) -> const hn_ff_grads * {
+    if (q.kind == STEP_CROSS_FF) return g->cross_ff ? &g->cross_ff[q.layer * M + q.m] : &no_ff;
+    return g->self_ff ? &g->self_ff[q.layer] : &no_ff;
+  };
+  auto one_token = [&](const Step &q, const hn_attn_params &ap) {
+    return q.kind == STEP_CROSS_ATTN && fp.N[q.m] == 1 && mask == nullptr && !(ap.dropout > 0.0f);
+  };
+  // an attention block whose row-local backward (out-projection in front of the core, projections behind it) can ride on chains
+  auto attn_chainable = [&](const Step &q, const hn_attn_params &ap) {
+    const int inner = ap.heads * ap.dim_head;
+    return use_bchain && is_attn_b(q) && !one_token(q, ap) && ap.dropout == 0.0f && ap.query_dim == d && inner % 128 == 0 && inner <= 512 &&
+           ap.w_q && ap.w_kv && ap.w_out && transpose_cache_lookup(ap.w_out, inner, d, inner) && transpose_cache_lookup(ap.w_q, d, inner, d) &&
+           (q.kind != STEP_SELF_ATTN || transpose_cache_lookup(ap.w_kv, d, 2 * inner, d)) && al16(ap.norm_w);
+  };
+  auto ff_chainable = [&](const hn_ff_params &f, const float *x) {
+    return use_bchain && f.dim == d && f.dropout == 0.0f && f.w1 && f.b1 && f.w2 && f.b2 && al16(f.w1) && al16(f.b1) && al16(f.norm_w) &&
+           al16(f.norm_b) && (f.norm_w != nullptr || f.norm_b == nullptr) && al16(x) && transpose_cache_lookup(f.w2, 4 * d, d, 4 * d) &&
+           transpose_cache_lookup(f.w1, d, 8 * d, d);
+  };
+  // one chain launch + its batched weight-gradient launch.  ff_k < 0: projection backward of `pend` only.
+  auto run_bchain = [&](int ff_k, bool has_out, const AttnBwdExt *out_ext_in, const float **o_saved) -> int {
+    (void)out_ext_in;
+    BChainArgs ca;
+    memset(&ca, 0, sizeof(ca));
+    GemmTnMulti mm;
+    memset(&mm, 0, sizeof(mm));
+    mm.K = rows;
+    int rc2 = HN_OK;
+    auto add_product = [&](const float *A, long lda, int Mm, const float *B, long ldb, int Nn, float *C, long ldc, float *cs) {
+      if (!C) {
+        if (cs && rc2 == HN_OK) rc2 = launch_colsum(A, lda, rows, Mm, 1.0f, cs, 1, s);
+        return;
       }
-      case STEP_SELF_ATTN: {
-        hn_attn_params ap = m->self_attn[st.layer];
-        ap.rng = rng;
-        rc = attn_bwd_impl(&ap, xin, xout, 1, nullptr, 0, b, L, L, d, nullptr, T + tp.stats_off[k],
-                           T + tp.saved_off[k], dX, dX, g->self_attn ? &g->self_attn[st.layer] : &no_attn, op, opb, s);
-        break;
-      }
-      case STEP_CROSS_FF: {
-        hn_ff_params fpar = m->cross_ff[st.layer * M + st.m];
-        fpar.rng = rng;
-        rc = ff_bwd_impl(&fpar, xin, dX, dX, 1, b * L, g->cross_ff ? &g->cross_ff[st.layer * M + st.m] : &no_ff, op, opb, s);
-        break;
-      }
-      default: {
-        hn_ff_params fpar = m->self_ff[st.layer];
-        fpar.rng = rng;
-        rc = ff_bwd_impl(&fpar, xin, dX, dX, 1, b * L, g->self_ff ? &g->self_ff[st.layer] : &no_ff, op, opb, s);
-        break;
+      TnProduct &pr = mm.p[mm.n++];
+      pr.A = A; pr.lda = lda; pr.B = B; pr.ldb = ldb; pr.C = C; pr.ldc = ldc; pr.M = Mm; pr.N = Nn; pr.colsum = cs;
+    };
+    auto add_ln = [&](int slot, float *out) {
+      if (!out) return;
+      LnPartial &lp = mm.ln[mm.n_ln++];
+      lp.part = cb.lnpart + (size_t)slot * 128; lp.nwg = rows / 16; lp.width = 128; lp.stride = 4 * 128; lp.out = out;
+    };
+    ca.rows = rows; ca.L = L; ca.dy = dX; ca.dx_out = dX; ca.lnpart = cb.lnpart;
+    if (pend.valid) {
+      const int inner = pend.ap.heads * pend.ap.dim_head;
+      ca.has_p = 1; ca.dQ = pend.dQ; ca.lddq = inner; ca.nq = inner;
+      ca.wqT = transpose_cache_lookup(pend.ap.w_q, d, inner, d);
+      if (pend.dKV) { ca.dKV = pend.dKV; ca.lddkv = 2 * inner; ca.nkv = 2 * inner; ca.wkvT = transpose_cache_lookup(pend.ap.w_kv, d, 2 * inner, d); }
+      ca.p_x = pend.x_in; ca.p_nw = pend.ap.norm_w;
+      add_product(pend.dQ, inner, inner, pend.xhat, d, d, pend.ag->w_q, d, nullptr);
+      if (pend.dKV) add_product(pend.dKV, 2 * inner, 2 * inner, pend.xhat, d, d, pend.ag->w_kv, d, nullptr);
+      if (pend.ap.norm_w) { add_ln(0, pend.ag->norm_w); add_ln(1, pend.ag->norm_b); }
+    }
+    if (ff_k >= 0) {
+      const Step &sf = tp.steps[ff_k];
+      const hn_ff_params f = ff_of_b(sf);
+      const hn_ff_grads *fg = ff_grads_of(sf);
+      ca.has_ff = 1; ca.gate = f.gate; ca.f_x = T + tp.x_off[ff_k];
+      ca.f_nw = f.norm_w; ca.f_nb = f.norm_b; ca.w1 = f.w1; ca.b1 = f.b1;
+      ca.w2T = transpose_cache_lookup(f.w2, 4 * d, d, 4 * d); ca.w1T = transpose_cache_lookup(f.w1, d, 8 * d, d);
+      ca.H = cb.H; ca.dU = cb.dU; ca.Xhat = cb.Xhat; ca.dYff = cb.dYff;
+      add_product(cb.dU, 8 * d, 8 * d, cb.Xhat, d, d, fg->w1, d, fg->b1);
+      add_product(cb.dYff, d, d, cb.H, 4 * d, 4 * d, fg->w2, 4 * d, fg->b2);
+      if (f.norm_w) { add_ln(2, fg->norm_w); add_ln(3, fg->norm_b); }
+      if (has_out) {
+        const Step &sa = tp.steps[ff_k - 1];
+        const hn_attn_params oa = attn_of(sa);
+        const int inner = oa.heads * oa.dim_head;
+        ca.has_out = 1; ca.inner_o = inner; ca.o_x = T + tp.x_off[ff_k - 1];
+        ca.woT = transpose_cache_lookup(oa.w_out, inner, d, inner);
+        ca.dPre = cb.dPre; ca.dO = cb.dO; ca.lddo = inner;
+        if (o_saved && *o_saved) add_product(cb.dPre, d, d, *o_saved, inner, inner, attn_grads_of(sa)->w_out, inner, attn_grads_of(sa)->b_out);
       }
     }
-    if (rc != HN_OK) return rc;
+    if ((rc2 = (rc2 != HN_OK ? rc2 : launch_latent_bchain(ca, s))) != HN_OK) return rc2;
+    pend.valid = false;
+    return launch_gemm_tn_multi(mm, cb.tn, cb.tn_floats, s);
+  };
+  // backward of an attention block with the chain hooks; `dpre` / `dO` non-NULL: its out-projection already ran in a chain
+  auto run_attn = [&](int k, const float *dpre, const float *dO_in, bool skip_wout) -> int {
+    const Step &st = tp.steps[k];
+    hn_attn_params ap = attn_of(st);
+    const hn_rng rng = {m->rng.seed, m->rng.offset, (uint32_t)k};      // the forward's generator state and stream id
+    ap.rng = rng;
+    const bool defer = attn_chainable(st, ap) && al16(T + tp.x_off[k]);
+    AttnBwdExt ext;
+    memset(&ext, 0, sizeof(ext));
+    ext.dpre = dpre; ext.dO = dO_in; ext.skip_wout = skip_wout; ext.defer_proj = defer;
+    AttnBwdExt *extp = (dpre || defer) ? &ext : nullptr;
+    const float *xin = T + tp.x_off[k], *xout = T + tp.x_off[k + 1];
+    int rc2;
+    if (st.kind == STEP_CROSS_ATTN)
+      rc2 = attn_bwd_impl(&ap, xin, xout, 1, fp.z[st.m], fp.ldz[st.m], b, L, fp.N[st.m], fp.D[st.m], mask, T + tp.stats_off[k],
+                          T + tp.saved_off[k], dX, dX, attn_grads_of(st), op, opb, s, tpack[st.m], extp);
+    else
+      rc2 = attn_bwd_impl(&ap, xin, xout, 1, nullptr, 0, b, L, L, d, nullptr, T + tp.stats_off[k], T + tp.saved_off[k], dX, dX,
+                          attn_grads_of(st), op, opb, s, 0, extp);
+    if (rc2 != HN_OK) return rc2;
+    if (defer) {
+      pend.valid = true; pend.layer = st.layer; pend.ap = ap; pend.ag = attn_grads_of(st); pend.x_in = xin;
+      pend.dQ = ext.dQ; pend.dKV = ext.dKV; pend.xhat = ext.xhat;
+    }
+    return HN_OK;
+  };
+  for (int k = tp.nsteps - 1; k >= 0;) {
+    const Step &st = tp.steps[k];
+    const float *xin = T + tp.x_off[k];
+    const hn_rng rng = {m->rng.seed, m->rng.offset, (uint32_t)k};      // the forward's generator state and stream id
+    if (!is_attn_b(st) && ff_chainable(ff_of_b(st), xin)) {
+      bool has_out = false, o_on_tape = false;
+      const float *o_saved = nullptr;
+      if (k >= 1 && is_attn_b(tp.steps[k - 1])) {
+        const Step &sa = tp.steps[k - 1];
+        const hn_attn_params oa = attn_of(sa);
+        has_out = attn_chainable(sa, oa) && al16(T + tp.x_off[k - 1]);
+        if (has_out) {
+          // explicit K/V bindings keep O on the tape: dW_out rides on the chain's batched launch; the shared-context (rank-D)
+          // binding recomputes O inside its backward and keeps dW_out there
+          AttnPlan pa;
+          const bool self = sa.kind == STEP_SELF_ATTN;
+          if ((rc = plan_attn(&oa, !self, self ? 0 : fp.ldz[sa.m], b, L, self ? L : fp.N[sa.m], self ? d : fp.D[sa.m], nullptr, 0, &pa)) != HN_OK) return rc;
+          o_on_tape = !pa.rank_d;
+          if (o_on_tape) o_saved = T + tp.saved_off[k - 1];
+        }
+      }
+      if ((rc = run_bchain(k, has_out, nullptr, &o_saved)) != HN_OK) return rc;
+      if (has_out) {
+        if ((rc = run_attn(k - 1, cb.dPre, cb.dO, o_on_tape)) != HN_OK) return rc;
+        k -= 2;
+      } else {
+        k -= 1;
+      }
+    } else {
+      if (pend.valid && (rc = run_bchain(-1, false, nullptr, nullptr)) != HN_OK) return rc;
+      if (is_attn_b(st)) {
+        rc = run_attn(k, nullptr, nullptr, false);
+      } else {
+        hn_ff_params fpar = ff_of_b(st);
+        fpar.rng = rng;
+        rc = ff_bwd_impl(&fpar, xin, dX, dX, 1, b * L, ff_grads_of(st), op, opb, s);
+      }
+      if (rc != HN_OK) return rc;
+      k -= 1;
+    }
     if (ready) {
-      const int done_above = k > 0 ? tp.steps[k - 1].layer : -1;   // layers > done_above have no block left
+      int done_above = k >= 0 ? tp.steps[k].layer : -1;   // layers > done_above have no block left ...
+      if (pend.valid && pend.layer > done_above) done_above = pend.layer;      // ... and no projection backward pending in a chain
       for (; next_layer_event > done_above; --next_layer_event)
         if ((rc = signal(next_layer_event)) != HN_OK) return rc;
     }
   }
+  if (pend.valid && (rc = run_bchain(-1, false, nullptr, nullptr)) != HN_OK) return rc;
   for (; ready && next_layer_event >= 0; --next_layer_event)
     if ((rc = signal(next_layer_event)) != HN_OK) return rc;
   if (g->latents) return launch_colsum(dX, (long)L * d, b, L * d, 1.0f, g->latents, 1, s);   // x0 = latents broadcast over the batch

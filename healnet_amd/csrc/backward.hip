@@ -231,13 +231,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs g) {
 // ------------------------------------------------------------------------------------------------
 constexpr int TNL_BK = 16, TNL_PITCH = 160;
 
-__global__ __launch_bounds__(256) void gemm_tn_lds_kernel(GemmTnArgs g) {
-  __shared__ __attribute__((aligned(16))) float As[2][TNL_BK * TNL_PITCH];
-  __shared__ __attribute__((aligned(16))) float Bs[2][TNL_BK * TNL_PITCH];
+typedef float TnlSlab[TNL_BK * TNL_PITCH];
+__device__ __forceinline__ void gemm_tn_lds_body(GemmTnArgs g, int bx, int by, int bz, TnlSlab *As, TnlSlab *Bs) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int bm0 = blockIdx.x * 128, bn0 = blockIdx.y * 128;
+  const int bm0 = bx * 128, bn0 = by * 128;
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-  const int z = blockIdx.z % g.nsplit, bt = blockIdx.z / g.nsplit;
+  const int z = bz % g.nsplit, bt = bz / g.nsplit;
   g.A += bt * g.strideA;
   g.B += bt * g.strideB;
   const int k_begin = z * g.kslice, k_end = min(g.K, k_begin + g.kslice);
@@ -371,6 +370,75 @@ __global__ __launch_bounds__(256) void gemm_tn_lds_kernel(GemmTnArgs g) {
     }
 }
 
+__global__ __launch_bounds__(256) void gemm_tn_lds_kernel(GemmTnArgs g) {
+  __shared__ __attribute__((aligned(16))) float As[2][TNL_BK * TNL_PITCH];
+  __shared__ __attribute__((aligned(16))) float Bs[2][TNL_BK * TNL_PITCH];
+  gemm_tn_lds_body(g, blockIdx.x, blockIdx.y, blockIdx.z, As, Bs);
+}
+
+// Several weight-gradient products of ONE contraction length in one launch (the fused latent backward, bchain.hip: dW1, dW2,
+// dW_out, dW_q, dW_kv of a chain all contract over the same b * l_c rows): blockIdx.x walks the 128 x 128 tiles of all products,
+// blockIdx.y the k-slices.  Partials (and the fused column-sum partials) go to scratch; splitk_reduce_multi_kernel folds them in
+// a fixed order (bitwise reproducible).
+__global__ __launch_bounds__(256) void gemm_tn_lds_multi_kernel(GemmTnMulti mm) {
+  __shared__ __attribute__((aligned(16))) float As[2][TNL_BK * TNL_PITCH];
+  __shared__ __attribute__((aligned(16))) float Bs[2][TNL_BK * TNL_PITCH];
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < TN_MULTI_MAX; ++i) pi += (i < mm.n && (int)blockIdx.x >= mm.tile0[i]) ? 1 : 0;
+  const TnProduct &pr = mm.p[pi];
+  const int t = blockIdx.x - mm.tile0[pi], tm = (pr.M + 127) / 128;
+  GemmTnArgs g;
+  g.A = pr.A; g.lda = pr.lda; g.B = pr.B; g.ldb = pr.ldb;
+  g.C = mm.scratch + pr.part_off; g.ldc = pr.N;
+  g.M = pr.M; g.N = pr.N; g.K = mm.K; g.kslice = mm.kslice; g.nsplit = mm.nsplit;
+  g.alpha = 1.0f; g.accumulate = 0;
+  g.colsum = pr.colsum ? mm.scratch + pr.cs_off : nullptr; g.colsum_accumulate = 0;
+  g.batch = 1; g.strideA = g.strideB = g.strideC = 0;
+  gemm_tn_lds_body(g, t % tm, t / tm, blockIdx.y, As, Bs);
+}
+
+// blockIdx.y: product (entries n .. n + n_ln - 1: LayerNorm partial sums (nwg, width) -> out[width], same launch)
+__global__ __launch_bounds__(256) void splitk_reduce_multi_kernel(GemmTnMulti mm) {
+  const int pi = blockIdx.y;
+  if (pi >= mm.n) {                                     // column sums of per-workgroup LayerNorm partials
+    const LnPartial &lp = mm.ln[pi - mm.n];
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < lp.width; c += gridDim.x * blockDim.x) {
+      float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+      int k = 0;
+      for (; k + 4 <= lp.nwg; k += 4) {
+        a0 += lp.part[(long)k * lp.stride + c]; a1 += lp.part[(long)(k + 1) * lp.stride + c];
+        a2 += lp.part[(long)(k + 2) * lp.stride + c]; a3 += lp.part[(long)(k + 3) * lp.stride + c];
+      }
+      for (; k < lp.nwg; ++k) a0 += lp.part[(long)k * lp.stride + c];
+      lp.out[c] += (a0 + a1) + (a2 + a3);
+    }
+    return;
+  }
+  const TnProduct &pr = mm.p[pi];
+  const float *part = mm.scratch + pr.part_off, *cs_part = pr.colsum ? mm.scratch + pr.cs_off : nullptr;
+  const long mn = (long)pr.M * pr.N, total = mn + (cs_part ? pr.M : 0);
+  const int nsplit = mm.nsplit;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    if (i >= mn) {
+      const int m = (int)(i - mn);
+      float acc = 0.0f;
+      for (int k = 0; k < nsplit; ++k) acc += cs_part[(long)k * pr.M + m];
+      pr.colsum[m] += acc;
+      continue;
+    }
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    int k = 0;
+    for (; k + 4 <= nsplit; k += 4) {
+      a0 += part[(long)k * mn + i]; a1 += part[(long)(k + 1) * mn + i];
+      a2 += part[(long)(k + 2) * mn + i]; a3 += part[(long)(k + 3) * mn + i];
+    }
+    for (; k < nsplit; ++k) a0 += part[(long)k * mn + i];
+    float *dst = pr.C + (i / pr.N) * pr.ldc + (i % pr.N);
+    *dst += (a0 + a1) + (a2 + a3);
+  }
+}
+
 __global__ __launch_bounds__(256) void splitk_reduce_alpha_kernel(const float *__restrict__ part, int nsplit, long mn, int N,
                                                                   float *__restrict__ C, long ldc, float alpha, int accumulate,
                                                                   long strideC, const float *__restrict__ cs_part, int M,
@@ -438,6 +506,68 @@ static int launch_gemm_tn(const float *A, long lda, const float *B, long ldb, fl
     hipLaunchKernelGGL(splitk_reduce_alpha_kernel, dim3((unsigned)blocks, batch), dim3(256), 0, s, scratch, g.nsplit, mn, N, C, ldc, alpha,
                        accumulate, strideC, colsum ? g.colsum : nullptr, M, colsum, colsum_accumulate);
     HN_LAUNCH_CHECK("splitk_reduce");
+  }
+  return HN_OK;
+}
+
+// Plans the shared split of a multi-product launch (one full round of resident workgroups, >= 64 rows per slice) and the scratch
+// layout of the partials.
+static void plan_tn_multi(GemmTnMulti &m) {
+  int tiles = 0;
+  for (int i = 0; i < m.n; ++i) { m.tile0[i] = tiles; tiles += ceil_div(m.p[i].M, 128) * ceil_div(m.p[i].N, 128); }
+  m.tile0[m.n] = tiles;
+  int nsplit = tiles > 0 ? 768 / tiles : 1;
+  const int max_by_k = ceil_div(m.K, 64);
+  if (nsplit > max_by_k) nsplit = max_by_k;
+  if (nsplit > GEMM_EX_SPLITS) nsplit = GEMM_EX_SPLITS;
+  if (nsplit < 1) nsplit = 1;
+  m.kslice = ceil_div(ceil_div(m.K, nsplit), 2) * 2;
+  m.nsplit = ceil_div(m.K, m.kslice);
+  long off = 0;
+  for (int i = 0; i < m.n; ++i) {
+    m.p[i].part_off = off; off += (long)m.nsplit * m.p[i].M * m.p[i].N;
+    m.p[i].cs_off = off; if (m.p[i].colsum) off += (long)m.nsplit * m.p[i].M;
+    off = (off + 63) / 64 * 64;
+  }
+  m.scratch = nullptr;
+  m.p[0].part_off += 0;
+  m.tile0[m.n] = tiles;
+  (void)off;
+}
+
+size_t gemm_tn_multi_scratch_floats(const GemmTnMulti &mm) {
+  GemmTnMulti m = mm;
+  plan_tn_multi(m);
+  long off = 0;
+  for (int i = 0; i < m.n; ++i) {
+    off = m.p[i].cs_off + (m.p[i].colsum ? (long)m.nsplit * m.p[i].M : 0);
+    off = (off + 63) / 64 * 64;
+  }
+  return (size_t)off;
+}
+
+int launch_gemm_tn_multi(GemmTnMulti &m, float *scratch, size_t scratch_floats, hipStream_t s) {
+  HN_REQUIRE(m.n >= 0 && m.n <= TN_MULTI_MAX && m.n_ln >= 0 && m.n_ln <= 4 && m.K > 0, HN_E_SHAPE, "gemm_tn_multi: n=%d n_ln=%d K=%d", m.n, m.n_ln, m.K);
+  for (int i = 0; i < m.n; ++i) {
+    const TnProduct &p = m.p[i];
+    HN_REQUIRE(p.A && p.B && p.C && p.M >= 128 && p.N >= 128 && (p.lda & 3) == 0 && (p.ldb & 3) == 0 && ((uintptr_t)p.A & 15) == 0 &&
+                   ((uintptr_t)p.B & 15) == 0, HN_E_SHAPE, "gemm_tn_multi: product %d M=%d N=%d", i, p.M, p.N);
+    HN_REQUIRE(((long)m.K * p.lda + p.M) * 4 < (1L << 31) && ((long)m.K * p.ldb + p.N) * 4 < (1L << 31), HN_E_UNSUPPORTED, "gemm_tn_multi: operand too large");
+  }
+  if (m.n > 0) {
+    plan_tn_multi(m);
+    HN_REQUIRE(scratch && scratch_floats >= gemm_tn_multi_scratch_floats(m), HN_E_WORKSPACE, "gemm_tn_multi: scratch too small");
+    m.scratch = scratch;
+    hipLaunchKernelGGL(gemm_tn_lds_multi_kernel, dim3(m.tile0[m.n], m.nsplit), dim3(256), 0, s, m);
+    HN_LAUNCH_CHECK("gemm_tn_multi");
+  }
+  if (m.n + m.n_ln > 0) {
+    long biggest = 128;
+    for (int i = 0; i < m.n; ++i) { const long e = (long)m.p[i].M * m.p[i].N + m.p[i].M; if (e > biggest) biggest = e; }
+    long blocks = ceil_div_ll(biggest, 256);
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(splitk_reduce_multi_kernel, dim3((unsigned)blocks, m.n + m.n_ln), dim3(256), 0, s, m);
+    HN_LAUNCH_CHECK("splitk_reduce_multi");
   }
   return HN_OK;
 }
@@ -524,7 +654,7 @@ int transpose_cache_run(float *buf, size_t buf_floats, hipStream_t s) {
   return HN_OK;
 }
 
-static const float *transpose_cache_lookup(const float *src, long ld, int rows, int cols) {
+const float *transpose_cache_lookup(const float *src, long ld, int rows, int cols) {
   if (!g_tc.ready) return nullptr;
   for (int i = 0; i < g_tc.n; ++i)
     if (g_tc.e[i].src == src && g_tc.e[i].ld == ld && g_tc.e[i].rows == rows && g_tc.e[i].cols == cols) return g_tc.e[i].dst;

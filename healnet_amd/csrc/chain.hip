@@ -63,75 +63,11 @@ namespace hn {
 
 namespace {
 
-constexpr int CR = 16;                  // rows per workgroup
-constexpr int CD = 128;                 // latent width
-constexpr int CHID = 512;               // feed-forward hidden width (4 * CD)
-constexpr int WN = 128, WK = 32;        // weight block: 128 output columns x 32 k
-constexpr int WBLK = WN * WK;           // floats per block (16 KB)
-constexpr int ATILE = CR * WK;          // floats per A k-tile (16 rows x 32 k, 16-byte slots XOR-swizzled by row & 7)
-constexpr int XP = 132;                 // pitch of the x tile
-constexpr int WSLOT = 16 * WK;          // floats per wave and block: 16 weight rows x 32 k (2 KB = two wave-wide 16-byte loads)
+#include "chain_common.h"
 constexpr int PRM = 128 + 2 * CHID + 128 + 4 * 128;      // b_out | b1 | b2 | ff gamma, beta | projection gamma, beta
 constexpr int MAXBLK = 128;             // blocks of a chain: <= 16 (out) + 32 + 16 (ff) + 16 (q) + 32 (kv) = 112
 constexpr int LDS_FLOATS = 8 * WSLOT + 16 * ATILE + 4 * ATILE + CR * XP + PRM + 2 * MAXBLK;       // 72.25 KB
 enum { CS_OUT = 0, CS_FF1 = 1, CS_FF2 = 2, CS_Q = 3, CS_KV = 4, CS_END = 5 };
-
-// Pointers that arrive inside the argument struct are generic: hipcc emits flat_load / flat_store for them, and with flat
-// operations in flight its wait-count insertion falls back to "wait for everything" in front of every use of a prefetched
-// register.  Everything outside the weight stream therefore goes through explicit global-address-space accesses.
-// buffer_load_dwordx4 ... idxen offen: address = base + vindex * stride + voffset, base and stride in the SGPR descriptor
-__device__ f32x4 hn_sbuffer_load_x4(i32x4 rsrc, int vindex, int voffset, int soffset, int aux) __asm("llvm.amdgcn.struct.buffer.load.v4f32");
-typedef float __attribute__((address_space(1))) gf32;
-typedef f32x4 __attribute__((address_space(1))) gf32x4;
-__device__ __forceinline__ float4 gld4(const gf32 *p) {
-  const f32x4 v = *(const gf32x4 *)p;
-  return make_float4(v.x, v.y, v.z, v.w);
-}
-__device__ __forceinline__ float gld1(const gf32 *p) { return *p; }
-__device__ __forceinline__ void gst4(gf32 *p, const float4 &v) {
-  f32x4 t = {v.x, v.y, v.z, v.w};
-  *(gf32x4 *)p = t;
-}
-__device__ __forceinline__ void gst1(gf32 *p, float v) { *p = v; }
-// streaming store: written through instead of staying dirty in this XCD's L2 until the end-of-kernel write-back
-__device__ __forceinline__ void gst4_nt(gf32 *p, const float4 &v) {
-  f32x4 t = {v.x, v.y, v.z, v.w};
-  __builtin_nontemporal_store(t, (gf32x4 *)p);
-}
-// ... and every LDS access through address space 3 with integer offsets (a generic pointer that the compiler cannot trace back
-// to the LDS symbol becomes a flat access, which counts against BOTH wait counters)
-typedef float __attribute__((address_space(3))) lf32;
-typedef f32x4 __attribute__((address_space(3))) lf32x4;
-__device__ __forceinline__ float4 lld4(const lf32 *base, int off) {
-  const f32x4 v = *(const lf32x4 *)(base + off);
-  return make_float4(v.x, v.y, v.z, v.w);
-}
-__device__ __forceinline__ void lst4(lf32 *base, int off, const float4 &v) {
-  f32x4 t = {v.x, v.y, v.z, v.w};
-  *(lf32x4 *)(base + off) = t;
-}
-
-// SELU with expm1(x) as exp(x) - 1 (v_exp_f32): the absolute error is half an ulp of 1 (6e-8) for any x <= 0 -- what matters
-// here, since the result scales a value of O(1) that is summed into 512-term dot products; the RELATIVE accuracy that expm1
-// buys for |x| << 1 is below the rounding of those sums.  ocml's expm1f is ~40 instructions, a split polynomial form ~16; this
-// is 6, in an epilogue that runs once per 8 blocks on the VALU the MFMAs share.
-__device__ __forceinline__ float selu_f(float x) {
-  const float alpha = 1.6732632423543772848170429916717f, scale = 1.0507009873554804934193349852946f;
-  const float e = __expf(fminf(x, 0.0f)) - 1.0f;
-  return scale * (x > 0.0f ? x : alpha * e);
-}
-// sum over the 32 lanes that share a row of the x tile (one half of a wave), delivered to all of them: four DPP steps inside each
-// row of 16 lanes and one swizzle across the two rows (__shfl_xor is a ds_bpermute each: ten of them sat in every LayerNorm)
-#define CH_DPP(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), 0xf, 0xf, true))
-__device__ __forceinline__ float half_wave_sum(float v) {
-  v += CH_DPP(v, 0xB1);                       // quad_perm [1,0,3,2]
-  v += CH_DPP(v, 0x4E);                       // quad_perm [2,3,0,1]
-  v += CH_DPP(v, 0x141);                      // row_half_mirror
-  v += CH_DPP(v, 0x140);                      // row_mirror
-  v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));      // lane ^ 16 (bit mode: and 0x1f, xor 0x10)
-  return v;
-}
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 #ifdef CHAIN_PROFILE
 // development only (tools/chain_profile.py builds a private library with -DCHAIN_PROFILE): cycle stamps of one workgroup at the

@@ -252,6 +252,51 @@ struct ChainArgs {
 };
 bool latent_chain_supported(int rows, int d, int hidden);
 int launch_latent_chain(const ChainArgs &a, hipStream_t s);
+// backward of the latent chain (bchain.hip): projection backward of an attention block -> feed-forward block backward -> the
+// out-projection backward of the attention block in front of it, one launch; weight gradients by launch_gemm_tn_multi
+struct BChainArgs {
+  int rows, L;
+  const float *dy;                     // (rows, 128) gradient entering the chain (w.r.t. the output of its last block in forward order)
+  float *dx_out;                       // (rows, 128) gradient leaving: w.r.t. the input of the feed-forward block (of the P block without one)
+  int has_p;                           // ---- P: dxh = dQ W_q + dKV W_kv ; G = LN'(dxh; p_x, p_nw) + dy
+  const float *dQ; int lddq, nq;       // (rows, nq), scaled as the q projection's output
+  const float *dKV; int lddkv, nkv;    // (rows, nkv) or nkv = 0 (cross blocks: the context carries no gradient)
+  const float *wqT, *wkvT;             // transposed projection weights (128, nq), (128, nkv)
+  const float *p_x, *p_nw;             // the attention block's input (tape) and its LayerNorm weight (NULL: no LayerNorm)
+  int has_ff, gate;                    // ---- FF
+  const float *f_x;                    // the feed-forward block's input (tape)
+  const float *f_nw, *f_nb, *w1, *b1;  // LayerNorm affine, first layer (1024, 128) + bias
+  const float *w2T, *w1T;              // transposes: (512, 128) of net.2.weight, (128, 1024) of net.0.weight
+  float *H, *dU, *Xhat, *dYff;         // out: h (rows, 512), dU (rows, 1024), LN(f_x) (rows, 128), G entering the block (rows, 128)
+  int has_out, inner_o;                // ---- OUT: dpre = G * LeakyReLU'(f_x - o_x) ; dO = dpre W_out
+  const float *o_x, *woT;              // the attention block's input (tape), W_out^T (inner_o, 128)
+  float *dPre, *dO; int lddo;          // out: (rows, 128), (rows, inner_o)
+  float *lnpart;                       // out: (rows / 16, 4, 128) per-workgroup partial [dgamma_p, dbeta_p, dgamma_f, dbeta_f]
+};
+bool latent_bchain_supported(int rows, int d, int hidden);
+int launch_latent_bchain(const BChainArgs &a, hipStream_t s);
+// several TN products C_i += A_i^T B_i (+ colsum_i += column sums of A_i) over ONE contraction length K in one launch + one reduce
+constexpr int TN_MULTI_MAX = 6;
+struct TnProduct {
+  const float *A; long lda;            // (K, M)
+  const float *B; long ldb;            // (K, N)
+  float *C; long ldc;                  // (M, N), accumulated into
+  int M, N;
+  float *colsum;                       // (M) accumulated into, or NULL
+  long part_off, cs_off;               // internal: scratch offsets of the split partials
+};
+struct LnPartial { const float *part; int nwg, width; long stride; float *out; };     // out[c] += sum_w part[w * stride + c]
+struct GemmTnMulti {
+  int n, n_ln;
+  TnProduct p[TN_MULTI_MAX];
+  LnPartial ln[4];
+  int tile0[TN_MULTI_MAX + 1];         // internal
+  int K, kslice, nsplit;
+  float *scratch;
+};
+size_t gemm_tn_multi_scratch_floats(const GemmTnMulti &m);
+int launch_gemm_tn_multi(GemmTnMulti &m, float *scratch, size_t scratch_floats, hipStream_t s);
+const float *transpose_cache_lookup(const float *src, long ld, int rows, int cols);
 constexpr int CHAIN_MERGE_MAX_SPLITS = 12;   // head 3 merges at most this many splits (more: merge_vproj_kernel)
 // folded value projection of a shared-context block for ChainArgs.wvf (the image merge_vproj_kernel builds per workgroup)
 struct VfoldMulti {                    // one entry per layer of a modality (<= HN_SKINNY_MAXZ): value half of to_kv, context LayerNorm affine
