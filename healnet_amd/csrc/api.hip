@@ -54,6 +54,7 @@ struct AttnPlan {
   int heads, dh, inner, dhp, Lp, N, D, dp;
   bool rank_d, self_attn, ones, bf16core;
   int nsplit, chunk;
+  int nq;                         // query tiles per wave the forward split was planned for (0: the kernel's default)
   int nsplit_bwd, chunk_bwd;      // token split of attn_bwd_dq_kernel (≈150 VGPRs: 3 waves per SIMD)
   float cscale;
   // workspace carve
@@ -81,9 +82,10 @@ static int plan_attn(const hn_attn_params *p, bool has_ctx, int ld_ctx, int b, i
   pl->ones = pl->rank_d && D <= ld_ctx - 1;
   pl->dp = pl->rank_d ? ld_ctx : pl->dhp;
   pl->cscale = 2.0f * (1.0f / sqrtf((float)p->dim_head)) * 1.44269504088896340736f;  // (1/0.5) * dh^-1/2 * log2(e)
-  attn_core_geometry(b, p->heads, pl->Lp, pl->N, pl->dp, &pl->nsplit, &pl->chunk);
-  attn_core_geometry(b, p->heads, pl->Lp, pl->N, pl->dp, &pl->nsplit_bwd, &pl->chunk_bwd, 3);
   pl->bf16core = bf16core != 0 && pl->ones && pl->N > 1;
+  pl->nq = (pl->rank_d && !pl->bf16core && p->dropout == 0.0f) ? attn_core_nq_small_batch(pl->dp, b, p->heads, pl->Lp) : 0;
+  attn_core_geometry(b, p->heads, pl->Lp, pl->N, pl->dp, &pl->nsplit, &pl->chunk, 0, pl->nq);
+  attn_core_geometry(b, p->heads, pl->Lp, pl->N, pl->dp, &pl->nsplit_bwd, &pl->chunk_bwd, 3);
   if (pl->bf16core) {
     // the plain dp = 16 bf16 core holds 161 VGPRs = 3 resident waves per SIMD: size the split for 3 (a split sized for 4 runs
     // a second, mostly idle round).  The larger variants measured faster with the default split (cfg3: 7.6 vs 11.2 ms).
@@ -173,7 +175,7 @@ static int attn_prepare(const hn_attn_params *p, const AttnPlan &pl, const float
   if (p->norm_w) { gq.pro = PRO_LAYERNORM; gq.gamma = p->norm_w; gq.beta = p->norm_b; }
   memset(core, 0, sizeof(*core));
   core->b = b; core->h = p->heads; core->Lq = L; core->Lp = pl.Lp; core->N = pl.N; core->dp = pl.dp;
-  core->nsplit = pl.nsplit; core->chunk = pl.chunk;
+  core->nsplit = pl.nsplit; core->chunk = pl.chunk; core->nq = pl.nq;
   core->Opart = pl.opart; core->Mpart = pl.mpart; core->Lpart = pl.lpart;
   int rc;
   if (pl.rank_d) {
@@ -1075,13 +1077,14 @@ static void register_transposes(const hn_model *m, const hn_modality_input *in, 
 // attention core backward in front of it
 struct BChainBufs { float *H, *dU, *Xhat, *dYff, *dPre, *dO, *lnpart, *tn; size_t tn_floats; bool ok; };
 
-static size_t bchain_tn_scratch_floats(int rows) {      // the largest product set of a chain: dW1, dW2, dW_out, dW_q, dW_kv at inner = 512
-  GemmTnMulti mm;
-  memset(&mm, 0, sizeof(mm));
-  const int MN[5][2] = {{1024, 128}, {128, 512}, {128, 512}, {512, 128}, {1024, 128}};
-  mm.n = 5; mm.K = rows;
-  for (int i = 0; i < 5; ++i) { mm.p[i].M = MN[i][0]; mm.p[i].N = MN[i][1]; mm.p[i].colsum = (float *)(uintptr_t)(i < 3 ? 16 : 0); }
-  return gemm_tn_multi_scratch_floats(mm);
+static size_t bchain_tn_scratch_floats(int rows) {
+  // upper bound over every product subset a chain can batch (dW1, dW2, dW_out, dW_q, dW_kv at inner = 512): fewer products means
+  // fewer tiles and therefore MORE k-slices (up to GEMM_EX_SPLITS), so the bound is the split cap times all partial sizes
+  (void)rows;
+  const long MN[5][2] = {{1024, 128}, {128, 512}, {128, 512}, {512, 128}, {1024, 128}};
+  size_t n = 0;
+  for (int i = 0; i < 5; ++i) n += (size_t)GEMM_EX_SPLITS * (MN[i][0] * MN[i][1] + MN[i][0]) + 128;
+  return n;
 }
 
 static int fusion_bwd_workspace(const hn_model *m, const hn_modality_input *in, int b, int masked, void *ws, size_t ws_bytes,

@@ -376,9 +376,23 @@ static int nq_dt1() {
 }
 static int nq_for(int dt) { return dt == 1 ? nq_dt1() : (dt == 2 ? 2 : (dt == 4 ? 2 : 1)); }
 
-void attn_core_geometry(int b, int h, int Lp, int N, int dp, int *nsplit, int *chunk, int waves_per_simd) {
+// Forward fp32 core, dp = 16: the default of 4 query tiles per wave leaves b * h * ceil(tiles / 4) work items -- 16 at b = 1 --
+// and the token split then has to make up the waves: 242 splits at b = 1, 64 at b = 4, whose merge costs more than the core
+// (profiles/r03_c: merge_vproj_kernel 49 us against 34 us for the core at b = 1).  With 2 or 1 tiles per wave the same waves come
+// from 12 splits or fewer, which the chain behind the block merges itself.  0 = keep the default.
+int attn_core_nq_small_batch(int dp, int b, int h, int Lp) {
+  static const bool off = getenv("HN_CORE_NQ") != nullptr || getenv("HN_NO_SMALL_BATCH_GEOMETRY") != nullptr;
+  if (off || dp != 16) return 0;
+  const int tiles = Lp / 16;
+  const int cand[3] = {4, 2, 1};
+  for (int i = 0; i < 3; ++i)
+    if ((long)b * h * ceil_div(tiles, cand[i]) * 12 >= 3072) return cand[i] == 4 ? 0 : cand[i];
+  return (long)b * h * tiles * 12 >= 512 ? 1 : 0;
+}
+
+void attn_core_geometry(int b, int h, int Lp, int N, int dp, int *nsplit, int *chunk, int waves_per_simd, int nq) {
   const int dt = dp / 16;
-  const int ngroups = ceil_div(Lp / 16, nq_for(dt));
+  const int ngroups = ceil_div(Lp / 16, nq > 0 ? nq : nq_for(dt));
   static long target_waves = 0;   // development knob HN_CORE_WAVES: resident waves the token split aims for
   if (target_waves == 0) { const char *e = getenv("HN_CORE_WAVES"); target_waves = e ? atol(e) : 256L * 4 * 4; if (target_waves < 64) target_waves = 4096; }
   const long tw = waves_per_simd > 0 ? 256L * 4 * waves_per_simd : target_waves;
@@ -388,6 +402,7 @@ void attn_core_geometry(int b, int h, int Lp, int N, int dp, int *nsplit, int *c
   long want = geom_floor ? tw / ((long)b * h * ngroups) : ceil_div_ll(tw, (long)b * h * ngroups);
   long max_splits = N / 128;
   if (max_splits < 1) max_splits = 1;
+  if (nq > 0 && want > 12) want = 12;          // planned for the chain's merge head (attn_core_nq_small_batch)
   if (want > max_splits) want = max_splits;
   if (want < 1) want = 1;
   int c = (int)ceil_div_ll(N, want);
@@ -407,7 +422,7 @@ int launch_attn_core(const AttnCoreArgs &a, hipStream_t s) {
   HN_REQUIRE(a.drop.thr == 0 || !a.ones_col, HN_E_SHAPE, "attn_core: dropout needs the explicit denominator (ones_col = 0)");
   if (self_core_lds_eligible(a)) return launch_self_core_lds(a, s);
   const int dt = a.dp / 16;
-  int nq = nq_for(dt);
+  int nq = a.nq > 0 ? a.nq : nq_for(dt);
   // latent self-attention (dp = 64, one split) at small batches: fewer than one wave per two SIMDs with 2 tiles per wave;
   // one tile per wave doubles the resident waves (b = 1: 0.92 -> 0.90 ms per forward; no gain from b = 32 on)
   if (dt == 4 && a.nsplit == 1 && !a.ones_col && a.drop.thr == 0 && (long)a.b * a.h * ceil_div(a.Lp / 16, 2) <= 512) nq = 1;
@@ -420,9 +435,14 @@ int launch_attn_core(const AttnCoreArgs &a, hipStream_t s) {
   const int ks = a.qk_steps > 0 ? a.qk_steps : 4 * dt;
   HN_REQUIRE(ks >= 1 && ks <= 4 * dt && (ks == 4 * dt || (a.ones_col && a.ones_in_mem)), HN_E_SHAPE, "attn_core: qk_steps=%d", a.qk_steps);
 #define HN_CORE(DT_, NQ_, ONES_, KS_) hipLaunchKernelGGL((attn_core_kernel<DT_, NQ_, ONES_, KS_>), grid, block, 0, s, a, ngroups, gy, wpb)
-  if (dt == 1 && a.ones_col) {
+  if (dt == 1 && a.ones_col && (nq == 2 || nq == 1) && ks != 4) {
+    HN_REQUIRE(ks >= 1 && ks <= 3, HN_E_SHAPE, "attn_core: qk_steps=%d", ks);
+    if (nq == 2) { if (ks == 1) HN_CORE(1, 2, true, 1); else if (ks == 2) HN_CORE(1, 2, true, 2); else HN_CORE(1, 2, true, 3); }
+    else { if (ks == 1) HN_CORE(1, 1, true, 1); else if (ks == 2) HN_CORE(1, 1, true, 2); else HN_CORE(1, 1, true, 3); }
+  } else if (dt == 1 && a.ones_col) {
     if (nq == 8) HN_CORE(1, 8, true, 4);
     else if (nq == 2) HN_CORE(1, 2, true, 4);
+    else if (nq == 1) HN_CORE(1, 1, true, 4);
     else if (ks == 1) HN_CORE(1, 4, true, 1);
     else if (ks == 2) HN_CORE(1, 4, true, 2);
     else if (ks == 3) HN_CORE(1, 4, true, 3);
@@ -438,6 +458,7 @@ int launch_attn_core(const AttnCoreArgs &a, hipStream_t s) {
   } else if (dt == 1) {
     if (nq == 8) HN_CORE(1, 8, false, 4);
     else if (nq == 2) HN_CORE(1, 2, false, 4);
+    else if (nq == 1) HN_CORE(1, 1, false, 4);
     else HN_CORE(1, 4, false, 4);
   } else if (dt == 2 && a.ones_col) {
     if (ks == 4) HN_CORE(2, 2, true, 4);

@@ -335,8 +335,12 @@ struct AttnCoreArgs {
   float *Ofinal; int ldo, dh; float *stats;     // nsplit == 1 only: write the normalised O (b*Lq, ldo) + stats directly (no merge kernel)
   DropCfg drop;                                 // training: dropout on the probabilities (thr == 0: off; needs ones_col == 0)
   int drop_rowsum;                              // ... shared-context binding: also accumulate sum_t p'_t in column dp-1
+  int nq;                                       // query tiles per wave the token split was planned for (0: the kernel's default)
 };
 int launch_attn_core(const AttnCoreArgs &a, hipStream_t s);
+// small batches of the dp = 16 shared-context binding: fewer query tiles per wave (more work items) and at most 12 splits, so that
+// the chain behind the block can merge them itself (chain.hip head 3) instead of a merge launch over up to 256 splits
+int attn_core_nq_small_batch(int dp, int b, int h, int Lp);
 // one workgroup per (sample, head) with K / V in LDS: the latent self-attention shape (self_attention.hip)
 bool self_core_lds_eligible(const AttnCoreArgs &a);
 int launch_self_core_lds(const AttnCoreArgs &a, hipStream_t s);
@@ -358,7 +362,7 @@ int launch_qfold_bf16(const float *Q, int ldq_row, const float *w_k, int D, cons
                       int b, int h, int L, int Lp, int dh, int DV, int ns, hipStream_t s, float *bound = nullptr, int *bound_flag = nullptr);
 // waves_per_simd > 0: size the token split for that many resident waves per SIMD (kernels with more than 128 VGPRs hold 3:
 // a split sized for 4 would run a second, mostly idle round)
-void attn_core_geometry(int b, int h, int Lp, int N, int dp, int *nsplit, int *chunk, int waves_per_simd = 0);
+void attn_core_geometry(int b, int h, int Lp, int N, int dp, int *nsplit, int *chunk, int waves_per_simd = 0, int nq = 0);
 
 int launch_qfold(const float *Q, int ldq_row, const float *w_k, int D, const float *gamma, float cscale,
                  float *Qf, int b, int h, int L, int Lp, int dh, int dp, hipStream_t s, int pack_ks = 0, float *bound = nullptr,
