@@ -89,7 +89,8 @@ static int plan_attn(const hn_attn_params *p, bool has_ctx, int ld_ctx, int b, i
   if (pl->bf16core) {
     // the plain dp = 16 bf16 core holds 161 VGPRs = 3 resident waves per SIMD: size the split for 3 (a split sized for 4 runs
     // a second, mostly idle round).  The larger variants measured faster with the default split (cfg3: 7.6 vs 11.2 ms).
-    if (pl->dp == 16 && bf16core == 1) attn_core_geometry(b, p->heads, pl->Lp, pl->N, pl->dp, &pl->nsplit, &pl->chunk, 3);
+    static const int w16 = getenv("HN_BF16_WAVES16") ? atoi(getenv("HN_BF16_WAVES16")) : 3;      // development knob
+    if (pl->dp == 16 && bf16core == 1) attn_core_geometry(b, p->heads, pl->Lp, pl->N, pl->dp, &pl->nsplit, &pl->chunk, w16);
     pl->chunk = (pl->chunk + 31) / 32 * 32;
     pl->nsplit = (pl->N + pl->chunk - 1) / pl->chunk;
   }

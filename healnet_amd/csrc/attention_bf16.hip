@@ -17,7 +17,8 @@
 //     CONSECUTIVE tokens t0 + 8 g .. 8 g + 7 of its query q (X: regs 0-3, Y: regs 4-7).
 //   * P V contracts those tokens: the eight probabilities, converted pairwise with v_cvt_pk_bf16_f32, ARE the
 //     A operand (row q, k = 8 g + s) -- no shuffle, no LDS -- and B = eight consecutive tokens of one channel,
-//     one 16-byte load from the channel-major image zT (DV, Np).  Row DV - 1 of zT is 1.0 on valid tokens, so
+//     one 16-byte load from the fragment-major image zT (Np / 32, DV / 16, 4, 16, 8): a wave's load is one contiguous
+//     1 KB tile.  Channel DV - 1 of zT is 1.0 on valid tokens, so
 //     accumulator column DV - 1 is the softmax denominator of the SAME rounded probabilities the numerator used.
 //
 // NS = 2 ("bf16x3"): every operand is carried as a bf16 pair hi + lo (hi = bf16(v), lo = bf16(v - hi), 16 mantissa
@@ -31,6 +32,7 @@
 // Per 32-token step and 16-query tile (NS = 1): 2 + DV/16 MFMAs of 16 cycles (fp32 path: 14 .. 26 of 32 cycles), 8 v_exp,
 // 4 cvt_pk, 4 packed adds: the loop is bound by the exp / VALU rate, not by the matrix pipe.
 #include "common.h"
+#include <stdlib.h>
 
 namespace hn {
 
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(256) void attn_core_bf16_kernel(AttnCoreBf16Args a,
 #pragma unroll
   for (int p = 0; p < NS; ++p)
 #pragma unroll
-    for (int d = 0; d < DTV; ++d) voff[p][d] = (((p * DV + 16 * d + j)) * a.Np + 8 * g) * 2;
+    for (int d = 0; d < DTV; ++d) voff[p][d] = (p * DV * a.Np + (d * 64 + g * 16 + j) * 8) * 2;      // fragment-major tiles (encode.hip)
 
   auto load_kv = [&](int t0, f32x4 (&kf)[2][NKQ], f32x4 (&vf)[NS][DTV]) {
 #pragma unroll
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(256) void attn_core_bf16_kernel(AttnCoreBf16Args a,
 #pragma unroll
     for (int p = 0; p < NS; ++p)
 #pragma unroll
-      for (int d = 0; d < DTV; ++d) vf[p][d] = hn_buffer_load_x4(vrs, voff[p][d], t0 * 2, 0);
+      for (int d = 0; d < DTV; ++d) vf[p][d] = hn_buffer_load_x4(vrs, voff[p][d], t0 * (DTV * 32), 0);      // 32 tokens = DTV tiles of 1 KB
   };
 
   // one 32-token step on (kf, vf); prefetches the following step into (kn, vn)
@@ -236,10 +238,77 @@ __global__ __launch_bounds__(256) void attn_core_bf16_kernel(AttnCoreBf16Args a,
   };
 
   f32x4 kA[2][NKQ], kB[2][NKQ], vA[NS][DTV], vB[NS][DTV];
-  if (t_begin < t_end) load_kv(t_begin, kA, vA);
-  for (int t0 = t_begin; t0 < t_end; t0 += 64) {
-    step(t0, kA, vA, kB, vB);
-    if (t0 + 32 < t_end) step(t0 + 32, kB, vB, kA, vA);
+  if (NS == 1 && bounded && mrow == nullptr && !a.no_pipeline) {
+    // ---- software-pipelined loop for the bounded reference without a key mask (the inference forward of BASELINE configs[2]).
+    // tools/ubench/mfma_valu_overlap.hip: on gfx950 a block of v_mfma_f32_16x16x32_bf16 and a block of v_exp_f32 of the waves
+    // of one SIMD do NOT overlap (both = 0.92 x the sum), but with the exponentials PINNED between the MFMAs of the same wave
+    // a quarter of the vector time hides (4 waves per SIMD: 495 -> 396 ns per 8 MFMAs + 16 exp + 16 mul; the fp32 16x16x4
+    // MFMA shows no such effect: 781 -> 816).  So the QK^T MFMAs of step t + 1 are issued one by one with the four
+    // exponentials of a score quad of step t behind each; the probabilities overwrite their scores, the next step's scores
+    // land in the other register set (same register count as the S / P pair of the general loop).  No tail masking is needed:
+    // splits end on multiples of 32 tokens and the rows of zT past N (ones row included) are zero, so tokens past the end add
+    // nothing to O or to the denominator.
+    auto load_k = [&](int t0, f32x4 (&kf)[2][NKQ]) {
+#pragma unroll
+      for (int x = 0; x < 2; ++x) kf[x][0] = hn_buffer_load_x4(krs, koff + x * 4 * (ZP * 2), t0 * (ZP * 2), 0);
+    };
+    auto load_v = [&](int t0, f32x4 (&vf)[NS][DTV]) {
+#pragma unroll
+      for (int d = 0; d < DTV; ++d) vf[0][d] = hn_buffer_load_x4(vrs, voff[0][d], t0 * (DTV * 32), 0);
+    };
+    f32x4 S0[NQ][2], S1[NQ][2];
+    auto pstep = [&](f32x4 (&Sc)[NQ][2], f32x4 (&Sn)[NQ][2], const f32x4 (&kn)[2][NKQ], const f32x4 (&vf)[NS][DTV]) {
+#define BF_SB __builtin_amdgcn_sched_barrier(0)
+#pragma unroll
+      for (int i = 0; i < NQ; ++i)
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+          Sn[i][x] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(kn[x][0]), qf[i][0], negm[i], 0, 0, 0); BF_SB;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Sc[i][x][r] = fast_exp2_b(Sc[i][x][r]);
+          BF_SB;
+        }
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 pk;
+        pk.x = cvt_pk_bf16(Sc[i][0][0], Sc[i][0][1]);
+        pk.y = cvt_pk_bf16(Sc[i][0][2], Sc[i][0][3]);
+        pk.z = cvt_pk_bf16(Sc[i][1][0], Sc[i][1][1]);
+        pk.w = cvt_pk_bf16(Sc[i][1][2], Sc[i][1][3]);
+        const bf16x8 pa = __builtin_bit_cast(bf16x8, pk);
+#pragma unroll
+        for (int d = 0; d < DTV; ++d)
+          O[i][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, as_bf16x8(vf[0][d]), O[i][d], 0, 0, 0);
+      }
+#undef BF_SB
+    };
+    if (t_begin < t_end) {
+      load_k(t_begin, kA);
+      load_v(t_begin, vA);
+      load_k(t_begin + 32, kB);
+#pragma unroll
+      for (int i = 0; i < NQ; ++i)
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+          S0[i][x] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(kA[x][0]), qf[i][0], negm[i], 0, 0, 0);
+    }
+    for (int t0 = t_begin; t0 < t_end; t0 += 64) {
+      load_k(t0 + 64, kA);                    // unconditional prefetches: rows past the end read 0
+      load_v(t0 + 32, vB);
+      pstep(S0, S1, kB, vA);
+      if (t0 + 32 < t_end) {
+        load_k(t0 + 96, kB);
+        load_v(t0 + 64, vA);
+        pstep(S1, S0, kA, vB);
+      }
+    }
+  } else {
+    if (t_begin < t_end) load_kv(t_begin, kA, vA);
+    for (int t0 = t_begin; t0 < t_end; t0 += 64) {
+      step(t0, kA, vA, kB, vB);
+      if (t0 + 32 < t_end) step(t0 + 32, kB, vB, kA, vA);
+    }
   }
 
   // ---- partial (O, m, l) of this split; l sits in accumulator column DV-1
@@ -277,7 +346,10 @@ int launch_attn_core_bf16(const AttnCoreBf16Args &a, hipStream_t s) {
   const long blocks = (long)a.nsplit * gy * a.b * a.h;
   HN_REQUIRE(blocks < (1L << 31), HN_E_UNSUPPORTED, "attn_core_bf16: grid too large");
   dim3 grid((unsigned)blocks), block(64 * wpb);
-#define HN_CORE16(DT_, NS_) hipLaunchKernelGGL((attn_core_bf16_kernel<DT_, NQ, NS_>), grid, block, 0, s, a, ngroups, gy, wpb)
+  static const bool no_pipeline = getenv("HN_BF16_NO_PIPELINE") != nullptr;
+  AttnCoreBf16Args ap = a;
+  ap.no_pipeline = no_pipeline ? 1 : 0;
+#define HN_CORE16(DT_, NS_) hipLaunchKernelGGL((attn_core_bf16_kernel<DT_, NQ, NS_>), grid, block, 0, s, ap, ngroups, gy, wpb)
   if (a.DV == 16 && a.ns == 1) HN_CORE16(1, 1);
   else if (a.DV == 16) HN_CORE16(1, 2);
   else if (a.ns == 1) HN_CORE16(2, 1);

@@ -353,6 +353,7 @@ struct AttnCoreBf16Args {                        // bf16-MFMA core of the shared
   int b, h, Lq, Lp, N, Np, DV;
   int nsplit, chunk;                             // tokens per split (multiple of 32)
   int ns;                                        // operand planes: 1 = plain bf16, 2 = hi + lo pairs ("bf16x3")
+  int no_pipeline;                               // development knob HN_BF16_NO_PIPELINE: the general loop also for the bounded, unmasked case
   const float *bound; const int *bound_flag;     // per-row score bounds + fallback flag (qfold_bf16_kernel), or NULL
 };
 // bf16 slots per context / query row of the QK^T contraction (see attention_bf16.hip)

@@ -330,7 +330,7 @@ int launch_encode(const void *data, int in_dtype, int b, int n_axes, const int *
 // bf16 context images for attn_core_bf16_kernel (attention_bf16.hip): per sample
 //   zb (Np, ZP)      token-major QK^T operand, ZP = bf16_row_slots(DV, ns); zero rows for the padding tokens n >= N
 //                    ns == 1: [zh(32)]   ns == 2, DV == 16: [zh(16) zl(16)] [zh(16) 0]   ns == 2, DV == 32: [zh] [zl] [zh]
-//   zT (ns, DV, Np)  channel-major P V operand planes (hi, lo); row DV-1 of the hi plane = 1.0 on valid tokens
+//   zT (ns, Np / 32, DV / 16, 4, 16, 8)  fragment-major P V operand planes (hi, lo); channel DV-1 of the hi plane = 1.0 on valid tokens
 //                    (softmax denominator), zero on padding tokens and in the lo plane
 // zh = bf16(z), zl = bf16(z - zh) of the affine-free LayerNorm z of the encoded token.
 // ------------------------------------------------------------------------------------------------
@@ -395,12 +395,18 @@ __global__ __launch_bounds__(256) void encode_bf16ctx_kernel(const IN *__restric
       dst[q] = make_uint4(slot(8 * q) | (slot(8 * q + 1) << 16), slot(8 * q + 2) | (slot(8 * q + 3) << 16),
                           slot(8 * q + 4) | (slot(8 * q + 5) << 16), slot(8 * q + 6) | (slot(8 * q + 7) << 16));
   }
-  uint16_t *col = zT + bi * (long)NS * DV * Np + n;
+  // P V operand planes in FRAGMENT-MAJOR tiles: per 32-token block and 16-channel group one contiguous 1 KB tile laid out as the
+  // MFMA B fragment reads it -- [g = token / 8][j = channel % 16][8 tokens] -- so that a wave's operand load is eight full
+  // 128-byte lines.  (Channel-major rows (DV, Np) made every load touch 16 lines 1.2 MB apart, half of each used: the slow
+  // "16 rows x 64 B" pattern of DESIGN 4.7, and this kernel's own stores 32 scattered 2-byte writes per token.)
+  const int blk = n >> 5, tg = (n >> 3) & 3, te = n & 7, DTV = DV >> 4;
+  uint16_t *plane = zT + bi * (long)NS * DV * Np;
 #pragma unroll
   for (int c = 0; c < kMaxNarrow; ++c)
     if (c < DV) {
-      col[(long)c * Np] = c == DV - 1 ? (valid ? (uint16_t)0x3f80 : (uint16_t)0) : hi[c];
-      if (NS == 2) col[(long)(DV + c) * Np] = c == DV - 1 ? (uint16_t)0 : lo[c];
+      const long at = ((((long)blk * DTV + (c >> 4)) * 4 + tg) * 16 + (c & 15)) * 8 + te;
+      plane[at] = c == DV - 1 ? (valid ? (uint16_t)0x3f80 : (uint16_t)0) : hi[c];
+      if (NS == 2) plane[(long)DV * Np + at] = c == DV - 1 ? (uint16_t)0 : lo[c];
     }
 }
 
