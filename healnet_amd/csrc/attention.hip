@@ -537,7 +537,9 @@ __global__ __launch_bounds__(256) void qfold_kernel(const float *__restrict__ Q,
 // head) a (Lp x dh) . (dh x dp) product -- 128 MFMAs instead of 2048 x 64 scalar FMAs fed by uncoalesced global reads
 // (17 -> ~6 us at cfg2).  Contraction order permuted like the attention core's (step (c, r) <-> channel 16 c + 4 g + r), so
 // every A fragment is one 16-byte load; B comes from the staged weight image; the row bound falls out of the accumulators.
-template <int CT>      // 16-column tiles of the folded query (dp = 16 CT)
+// BF16: the folded queries leave as bf16 (round to nearest even) for the bf16 core -- 32 slots per row, natural channel order --
+// with the 1 % slack on the row bound that covers the bf16 rounding of q and z (attention_bf16.hip).
+template <int CT, bool BF16 = false>      // 16-column tiles of the folded query (dp = 16 CT)
 __global__ __launch_bounds__(256) void qfold_mfma_kernel(const float *__restrict__ Q, int ldq_row, const float *__restrict__ w_k,
                                                          int D, const float *__restrict__ gamma, float cscale,
                                                          float *__restrict__ Qf, int h, int L, int Lp, int dh, int pack_ks,
@@ -587,7 +589,13 @@ __global__ __launch_bounds__(256) void qfold_mfma_kernel(const float *__restrict
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int orow = tile * 16 + 4 * g + r;
-        if (orow < Lp) dst[(long)orow * dp + 16 * t + j] = acc[t][r];
+        if (BF16) {
+          unsigned u = __float_as_uint(acc[t][r]);
+          u += 0x7fffu + ((u >> 16) & 1u);
+          if (orow < Lp) ((uint16_t *)Qf)[((long)bh * Lp + orow) * dp + 16 * t + j] = (uint16_t)(u >> 16);
+        } else if (orow < Lp) {
+          dst[(long)orow * dp + 16 * t + j] = acc[t][r];
+        }
         ss[r] = fmaf(acc[t][r], acc[t][r], ss[r]);
       }
     if (bound != nullptr) {
@@ -597,13 +605,22 @@ __global__ __launch_bounds__(256) void qfold_mfma_kernel(const float *__restrict
         v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
         const int orow = tile * 16 + 4 * g + r;
         if (j == 0 && orow < Lp) {
-          const float bq = sqrtf(v * (float)D) * 1.00002f + 1e-6f;
+          const float bq = sqrtf(v * (float)D) * (BF16 ? 1.01f : 1.00002f) + 1e-6f;
           bound[(long)bh * Lp + orow] = bq;
           if (bq > 60.0f) atomicOr(bound_flag, 1);
         }
       }
     }
   }
+}
+
+// bf16 folded queries on the matrix cores (plain bf16 core, one operand plane): false when the shape needs qfold_bf16_kernel
+bool launch_qfold_mfma_bf16(const float *Q, int ldq_row, const float *w_k, int D, const float *gamma, float cscale, uint16_t *Qf,
+                            int b, int h, int L, int Lp, int dh, hipStream_t s, float *bound, int *bound_flag) {
+  if (!(dh % 16 == 0 && (ldq_row & 3) == 0 && ((uintptr_t)Q & 15) == 0 && D <= 32)) return false;
+  hipLaunchKernelGGL((qfold_mfma_kernel<2, true>), dim3(b * h), dim3(256), (size_t)dh * 32 * sizeof(float), s, Q, ldq_row, w_k, D, gamma, cscale,
+                     (float *)Qf, h, L, Lp, dh, 0, bound, bound_flag);
+  return true;
 }
 
 int launch_qfold(const float *Q, int ldq_row, const float *w_k, int D, const float *gamma, float cscale, float *Qf,

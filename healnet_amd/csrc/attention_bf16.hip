@@ -427,6 +427,11 @@ __global__ __launch_bounds__(256) void qfold_bf16_kernel(const float *__restrict
 int launch_qfold_bf16(const float *Q, int ldq_row, const float *w_k, int D, const float *gamma, float cscale, uint16_t *Qf,
                       int b, int h, int L, int Lp, int dh, int DV, int ns, hipStream_t s, float *bound, int *bound_flag) {
   HN_REQUIRE(D <= DV - 1 && (ns == 1 || ns == 2), HN_E_SHAPE, "qfold_bf16: D=%d DV=%d ns=%d", D, DV, ns);
+  // one operand plane: the fold runs on the matrix cores (33 -> ~9 us per call at cfg3: 6 calls per forward)
+  if (ns == 1 && launch_qfold_mfma_bf16(Q, ldq_row, w_k, D, gamma, cscale, Qf, b, h, L, Lp, dh, s, bound, bound_flag)) {
+    HN_LAUNCH_CHECK("qfold_mfma_bf16");
+    return HN_OK;
+  }
   hipLaunchKernelGGL(qfold_bf16_kernel, dim3(b * h), dim3(256), ((size_t)dh * 32 + Lp) * sizeof(float), s, Q, ldq_row, w_k, D, gamma,
                      cscale, Qf, h, L, Lp, dh, DV, ns, bound, bound_flag);
   HN_LAUNCH_CHECK("qfold_bf16");

@@ -338,6 +338,8 @@ struct AttnCoreArgs {
   int nq;                                       // query tiles per wave the token split was planned for (0: the kernel's default)
 };
 int launch_attn_core(const AttnCoreArgs &a, hipStream_t s);
+bool launch_qfold_mfma_bf16(const float *Q, int ldq_row, const float *w_k, int D, const float *gamma, float cscale, uint16_t *Qf,
+                            int b, int h, int L, int Lp, int dh, hipStream_t s, float *bound, int *bound_flag);
 // small batches of the dp = 16 shared-context binding: fewer query tiles per wave (more work items) and at most 12 splits, so that
 // the chain behind the block can merge them itself (chain.hip head 3) instead of a merge launch over up to 256 splits
 int attn_core_nq_small_batch(int dp, int b, int h, int Lp);

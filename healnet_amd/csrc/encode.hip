@@ -334,11 +334,16 @@ int launch_encode(const void *data, int in_dtype, int b, int n_axes, const int *
 //                    (softmax denominator), zero on padding tokens and in the lo plane
 // zh = bf16(z), zl = bf16(z - zh) of the affine-free LayerNorm z of the encoded token.
 // ------------------------------------------------------------------------------------------------
-template <typename IN, int NS>
+// SC / SA / SF > 0 and SDV: channel count, axes, frequency bands and row width known at compile time (RGB image: 3, 2, 2, 16;
+// RGB volume: 3, 3, 2, 32), as in encode_token_kernel: one sincosf per (axis, band), every predicate folds away.
+template <typename IN, int NS, int SC = 0, int SA = 0, int SF = 0, int SDV = 0>
 __global__ __launch_bounds__(256) void encode_bf16ctx_kernel(const IN *__restrict__ data, uint16_t *__restrict__ zb,
                                                              uint16_t *__restrict__ zT, EncGeom g, int Np, int DV, long total) {
-  long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= total) return;
+  if (SC > 0) { g.C = SC; g.n_axes = SA; g.F = SF; g.D = SC + SA * (2 * SF + 1); DV = SDV; }
+  // (total = b * Np is a multiple of 32: the last workgroup may be partly idle, but every 32-token block is whole)
+  const long gid_raw = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = gid_raw < total;
+  const long gid = active ? gid_raw : total - 1;
   const long bi = gid / Np;
   const int n = (int)(gid % Np);
   float v[kMaxNarrow];
@@ -349,12 +354,30 @@ __global__ __launch_bounds__(256) void encode_bf16ctx_kernel(const IN *__restric
     int idx[HN_MAX_AXES];
     token_coords(n, g, idx);
     const IN *src = data + (bi * g.N + n) * g.C;
+    if (SC > 0) {
 #pragma unroll
-    for (int c = 0; c < kMaxNarrow; ++c) {
-      float x = 0.0f;
-      if (c < g.C) x = in_at(src, c);
-      else if (c < g.D) x = pos_feature(c - g.C, idx, g);
-      v[c] = x;
+      for (int c = 0; c < SC; ++c) v[c] = in_at(src, c);
+#pragma unroll
+      for (int a = 0; a < SA; ++a) {
+        const float p = axis_pos(idx[a], g.S[a]);
+#pragma unroll
+        for (int f = 0; f < SF; ++f) {
+          const float arg = __fmul_rn(__fmul_rn(p, band_scale(f, SF, g.max_freq)), 3.14159265358979323846f);  // (p*s)*pi, :299
+          float sn, cs;
+          sincosf(arg, &sn, &cs);
+          v[SC + a * (2 * SF + 1) + f] = sn;
+          v[SC + a * (2 * SF + 1) + SF + f] = cs;
+        }
+        v[SC + a * (2 * SF + 1) + 2 * SF] = p;
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < kMaxNarrow; ++c) {
+        float x = 0.0f;
+        if (c < g.C) x = in_at(src, c);
+        else if (c < g.D) x = pos_feature(c - g.C, idx, g);
+        v[c] = x;
+      }
     }
     float sum = 0.0f;
 #pragma unroll
@@ -384,29 +407,48 @@ __global__ __launch_bounds__(256) void encode_bf16ctx_kernel(const IN *__restric
     if (DV == 16) return s < 16 ? hi[s] : (s < 32 ? lo[s - 16] : (s < 48 ? hi[s - 32] : 0));
     return s < 32 ? hi[s] : (s < 64 ? lo[s - 32] : hi[s - 64]);
   };
-  if (NS == 1 || DV == 16) {
+  if (active) {
+    if (NS == 1 || DV == 16) {
 #pragma unroll
-    for (int q = 0; q < (NS == 1 ? 4 : 8); ++q)
-      dst[q] = make_uint4(slot(8 * q) | (slot(8 * q + 1) << 16), slot(8 * q + 2) | (slot(8 * q + 3) << 16),
-                          slot(8 * q + 4) | (slot(8 * q + 5) << 16), slot(8 * q + 6) | (slot(8 * q + 7) << 16));
-  } else {
+      for (int q = 0; q < (NS == 1 ? 4 : 8); ++q)
+        dst[q] = make_uint4(slot(8 * q) | (slot(8 * q + 1) << 16), slot(8 * q + 2) | (slot(8 * q + 3) << 16),
+                            slot(8 * q + 4) | (slot(8 * q + 5) << 16), slot(8 * q + 6) | (slot(8 * q + 7) << 16));
+    } else {
 #pragma unroll
-    for (int q = 0; q < 12; ++q)
-      dst[q] = make_uint4(slot(8 * q) | (slot(8 * q + 1) << 16), slot(8 * q + 2) | (slot(8 * q + 3) << 16),
-                          slot(8 * q + 4) | (slot(8 * q + 5) << 16), slot(8 * q + 6) | (slot(8 * q + 7) << 16));
+      for (int q = 0; q < 12; ++q)
+        dst[q] = make_uint4(slot(8 * q) | (slot(8 * q + 1) << 16), slot(8 * q + 2) | (slot(8 * q + 3) << 16),
+                            slot(8 * q + 4) | (slot(8 * q + 5) << 16), slot(8 * q + 6) | (slot(8 * q + 7) << 16));
+    }
   }
   // P V operand planes in FRAGMENT-MAJOR tiles: per 32-token block and 16-channel group one contiguous 1 KB tile laid out as the
   // MFMA B fragment reads it -- [g = token / 8][j = channel % 16][8 tokens] -- so that a wave's operand load is eight full
   // 128-byte lines.  (Channel-major rows (DV, Np) made every load touch 16 lines 1.2 MB apart, half of each used: the slow
-  // "16 rows x 64 B" pattern of DESIGN 4.7, and this kernel's own stores 32 scattered 2-byte writes per token.)
-  const int blk = n >> 5, tg = (n >> 3) & 3, te = n & 7, DTV = DV >> 4;
-  uint16_t *plane = zT + bi * (long)NS * DV * Np;
+  // "16 rows x 64 B" pattern of DESIGN 4.7.)  The tiles are written in 16-byte pieces (8 consecutive tokens of one channel)
+  // after a transpose through LDS: per-token 2-byte stores made this kernel 267 us at cfg3 (9.6 M tokens x 32 channels).
+  __shared__ uint16_t tr[NS][256][kMaxNarrow + 2];
+  {
 #pragma unroll
-  for (int c = 0; c < kMaxNarrow; ++c)
-    if (c < DV) {
-      const long at = ((((long)blk * DTV + (c >> 4)) * 4 + tg) * 16 + (c & 15)) * 8 + te;
-      plane[at] = c == DV - 1 ? (valid ? (uint16_t)0x3f80 : (uint16_t)0) : hi[c];
-      if (NS == 2) plane[(long)DV * Np + at] = c == DV - 1 ? (uint16_t)0 : lo[c];
+    for (int c = 0; c < kMaxNarrow; ++c)
+      if (c < DV) {
+        tr[0][threadIdx.x][c] = c == DV - 1 ? (valid ? (uint16_t)0x3f80 : (uint16_t)0) : hi[c];
+        if (NS == 2) tr[NS - 1][threadIdx.x][c] = c == DV - 1 ? (uint16_t)0 : lo[c];
+      }
+  }
+  __syncthreads();
+  const int DTV = DV >> 4;
+  const int pieces = 8 * DTV * 64;             // 8 token blocks of 32 per workgroup x DTV channel groups x 64 fragment slots
+  for (int p = 0; p < NS; ++p)
+    for (int q = threadIdx.x; q < pieces; q += 256) {
+      const int tb = q / (DTV * 64), rem = q - tb * (DTV * 64), dg = rem >> 6, sl = rem & 63, fg = sl >> 4, fj = sl & 15;
+      const long gid0 = (long)blockIdx.x * 256 + tb * 32;
+      if (gid0 >= total) continue;
+      const long sb = gid0 / Np;
+      const int blk = (int)(gid0 - sb * Np) >> 5, c = dg * 16 + fj, tl = tb * 32 + fg * 8;
+      unsigned w[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[e] = (unsigned)tr[p][tl + 2 * e][c] | ((unsigned)tr[p][tl + 2 * e + 1][c] << 16);
+      uint16_t *plane = zT + (sb * NS + p) * (long)DV * Np;
+      *(uint4 *)(plane + ((((long)blk * DTV + dg) * 4 + fg) * 16 + fj) * 8) = make_uint4(w[0], w[1], w[2], w[3]);
     }
 }
 
@@ -424,10 +466,19 @@ int launch_encode_bf16ctx(const void *data, int in_dtype, int b, int n_axes, con
   const long total = (long)b * Np;
   const dim3 grid((unsigned)ceil_div_ll(total, 256)), block(256);
 #define HN_ENC16(T_, NS_) hipLaunchKernelGGL((encode_bf16ctx_kernel<T_, NS_>), grid, block, 0, s, (const T_ *)data, zb, zT, g, Np, DV, total)
+#define HN_ENC16_S(T_, A_, DV_) hipLaunchKernelGGL((encode_bf16ctx_kernel<T_, 1, 3, A_, 2, DV_>), grid, block, 0, s, (const T_ *)data, zb, zT, g, Np, DV, total)
+  // static variants for the two BASELINE shapes (plain bf16 plane): RGB image (2 axes, 2 bands, 16-wide row), RGB volume (3 axes, 32-wide)
+  const bool rgb = g.fourier && g.C == 3 && g.F == 2 && ns == 1;
+  if (rgb && g.n_axes == 2 && DV == 16 && (in_dtype == HN_BF16 || in_dtype == HN_F32)) {
+    if (in_dtype == HN_BF16) HN_ENC16_S(uint16_t, 2, 16); else HN_ENC16_S(float, 2, 16);
+  } else if (rgb && g.n_axes == 3 && DV == 32 && (in_dtype == HN_BF16 || in_dtype == HN_F32)) {
+    if (in_dtype == HN_BF16) HN_ENC16_S(uint16_t, 3, 32); else HN_ENC16_S(float, 3, 32);
+  } else
   if (in_dtype == HN_BF16) { if (ns == 1) HN_ENC16(uint16_t, 1); else HN_ENC16(uint16_t, 2); }
   else if (in_dtype == HN_U8) { if (ns == 1) HN_ENC16(uint8_t, 1); else HN_ENC16(uint8_t, 2); }
   else { if (ns == 1) HN_ENC16(float, 1); else HN_ENC16(float, 2); }
 #undef HN_ENC16
+#undef HN_ENC16_S
   HN_LAUNCH_CHECK("encode_bf16ctx");
   return HN_OK;
 }
