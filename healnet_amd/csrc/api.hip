@@ -814,7 +814,8 @@ struct FusionPlan {
   int pack[16];    // ... and uses the packed channel layout with this many QK^T k-steps (0 = natural)
   bool bf16[16];   // core_precision = bf16: z holds the bf16 images (zb, then zT) instead of the fp32 rows
   int Np[16], ns[16];
-  int *flags;      // one pre-zeroed fallback flag of the score-bound softmax per (layer, modality)
+  int *flags;      // one pre-zeroed fallback flag of the score-bound softmax per (layer, modality), then the chain cluster flags
+  float *xchg;     // exchange buffer of the latent chain's cluster mode (small batches)
   float *tabv[16], *taby[16];   // one-token modalities (inference): V (depth, b, inner) and block outputs (depth, b, query_dim) of ALL layers
   bool tab_ahead[16];           // ... computed ahead of the layer loop in two batched launches
   void *op_ws;
@@ -944,7 +945,8 @@ static int plan_fusion(const hn_model *m, const hn_modality_input *in, int b, vo
   }
   const size_t ffb = align_up((size_t)b * m->l_c * 5 * m->l_d * sizeof(float), 256);
   if (ffb > op_max) op_max = ffb;
-  fp->flags = ar.take<int>((size_t)m->depth * m->n_modalities);
+  fp->flags = ar.take<int>((size_t)m->depth * m->n_modalities + CHAIN_XCHG_FLAGS);
+  fp->xchg = ar.take<float>(CHAIN_XCHG_FLOATS);
   {
     int max_inner = 0, max_inner_self = 0;
     for (int k = 0; k < m->depth * m->n_modalities; ++k) max_inner = max_inner > m->cross_attn[k].heads * pad_head_dim(m->cross_attn[k].dim_head) ? max_inner : m->cross_attn[k].heads * pad_head_dim(m->cross_attn[k].dim_head);
@@ -1427,7 +1429,8 @@ int hn_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, con
     return fp.x;
   };
   float *cur = input_buffer(0);
-  if ((rc = launch_broadcast_rows(m->latents, cur, (long)L * d, b, s, fp.flags, m->depth * M)) != HN_OK) return rc;   // :225 (+ the bound flags)
+  if ((rc = launch_broadcast_rows(m->latents, cur, (long)L * d, b, s, fp.flags, m->depth * M + CHAIN_XCHG_FLAGS)) != HN_OK) return rc;   // :225 (+ the bound / cluster flags)
+  int chain_seq = 0;
   const bool head = m->final_classifier_head && !return_embeddings;
   const bool use_chain = fp.chain && !chain_disabled();      // HN_NO_CHAIN: development switch, the unfused launch sequence
 
@@ -1527,6 +1530,7 @@ int hn_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, con
     }
     float *dst = input_buffer(k + 2);
     ca.x_out = dst;
+    ca.xchg = fp.xchg; ca.xflags = fp.flags + m->depth * M; ca.seq = ++chain_seq;
     if ((rc = launch_latent_chain(ca, s)) != HN_OK) return rc;
     cur = dst; k += 2;
   }

@@ -58,6 +58,7 @@
 //
 // Shapes: l_d = 128, hidden 512, K a multiple of 128, N a multiple of 128, rows % 16 == 0.
 #include "common.h"
+#include <stdlib.h>
 
 namespace hn {
 
@@ -137,29 +138,42 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fg = lane >> 4, fi = lane & 15;
-  const int m0 = blockIdx.x * CR;
+  // Small batches (rows / 16 <= 64 workgroups would leave most of the chip idle while each pulls the whole weight stream through
+  // one CU): a CLUSTER of C = 2 or 4 workgroups shares a row tile.  Every member runs the head stage (it needs the whole x tile for
+  // the LayerNorm anyway), then only ITS hidden chunks of the feed-forward block (FF1 columns and the matching k-tiles of FF2: a
+  // partial x tile), the members exchange the partials ONCE through global memory (fixed summation order: all members hold the
+  // same bits afterwards), and each computes its share of the projection chunks.  Members of a tile sit `ntiles` workgroups
+  // apart: with ntiles a multiple of 8 they share an XCD (its L2).
+  const int a_C = args.cluster > 1 ? args.cluster : 1;
+  const int ntiles = gridDim.x / a_C;
+  const int member = __builtin_amdgcn_readfirstlane((int)blockIdx.x / ntiles), tile = blockIdx.x - member * ntiles;
+  const int my_chunks = 4 / a_C;             // hidden chunks (128 columns) of this member: member, member + C, ...
+  const int m0 = tile * CR;
 
   // ---- the block stream: stage -> n-chunk -> k-chunk, identical for the loader and the consumer.  The loader addresses
   // block number `lb` of the whole chain with branch-free scalar arithmetic.
   const int nk_out = (a_head == 1 || a_head == 3) ? a_inner_o / WK : 0;      // out-projection: ONE 128-column chunk of nk_out k-chunks
   const int nq_ch = a_nq / WN, nkv_ch = a_nkv / WN;
+  const int my_proj = (nq_ch + nkv_ch - member + a_C - 1) / a_C;            // projection chunks pj = member, member + C, ...
   const int e0 = nk_out;                                         // first block of FF1
-  const int e1 = e0 + (a_has_ff ? 8 * (CD / WK) : 0);            //                FF2
-  const int e2 = e1 + (a_has_ff ? CHID / WK : 0);                //                Q
-  const int e3 = e2 + nq_ch * (CD / WK);                         //                KV
-  const int nblocks = e3 + nkv_ch * (CD / WK);
+  const int e1 = e0 + (a_has_ff ? 2 * my_chunks * (CD / WK) : 0);           //                FF2
+  const int e2 = e1 + (a_has_ff ? my_chunks * (CD / WK) : 0);    //                Q / KV
+  const int nblocks = max(1, e2 + my_proj * (CD / WK));
   // ---- the address of every block, once: thread bi works out (stage, chunk, k-chunk) of block bi and leaves the byte address of
   // its first row in an LDS table.  Doing this arithmetic in the loader -- ~45 scalar instructions and four readfirstlanes per
   // block and wave -- was what kept the weight stream from overlapping with the MFMAs (0.42 us per block against 0.24 without
   // loads; 0.25 with a constant-stride dummy address): a table entry costs one broadcast ds_read_b64, fetched a step ahead.
   if (tid < MAXBLK) {
     const int bi = min(tid, nblocks - 1);
-    const int s_out = bi < e0, s_ff1 = bi >= e0 && bi < e1, s_ff2 = bi >= e1 && bi < e2, s_q = bi >= e2 && bi < e3;
-    const int local = bi - (s_out ? 0 : s_ff1 ? e0 : s_ff2 ? e1 : s_q ? e2 : e3);
-    const bool one_chunk = s_out || s_ff2;                       // stages with a single 128-column chunk: k = local
-    const int j = one_chunk ? 0 : local >> 2, k = one_chunk ? local : local & 3;
+    const int s_out = bi < e0, s_ff1 = bi >= e0 && bi < e1, s_ff2 = bi >= e1 && bi < e2;
+    const int local = bi - (s_out ? 0 : s_ff1 ? e0 : s_ff2 ? e1 : e2);
+    // FF1: per own hidden chunk hc its value rows, then its gate rows (4 k-blocks each); FF2: the k-tiles of the own chunks;
+    // projections: chunks pj = member + ci * C of the [Q | KV] column range
+    const int hc1 = member + (local >> 3) * a_C, hc2 = member + (local >> 2) * a_C, pj = member + (local >> 2) * a_C;
+    const int s_q = !s_out && !s_ff1 && !s_ff2 && pj < nq_ch;
+    const int k = s_out ? local : s_ff2 ? 4 * hc2 + (local & 3) : local & 3;
     const int ldw = s_out ? a_inner_o : s_ff2 ? CHID : CD;
-    const int rb = s_ff1 ? (j & 1) * CHID + (j >> 1) * WN : j * WN;               // FF1: value chunk, then its gate chunk
+    const int rb = s_out || s_ff2 ? 0 : s_ff1 ? ((local >> 2) & 1) * CHID + hc1 * WN : (s_q ? pj : pj - nq_ch) * WN;
     const float *W = s_out ? args.w_out : s_ff1 ? args.w1 : s_ff2 ? args.w2 : s_q ? args.wq : args.wkv;
     // words 0 and 1 of the block's buffer descriptor: base = its first row at k, stride = the row pitch in bytes
     const unsigned long long addr = (unsigned long long)(W + (long)rb * ldw + k * WK);
@@ -241,7 +255,7 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
     }
     const float inv = 1.0f / l;
     o0.x *= inv; o0.y *= inv; o0.z *= inv; o0.w *= inv;
-    if (a_stats && gq == 0) {
+    if (a_stats && gq == 0 && member == 0) {
       gf32 *st = a_stats + ((long)(bi * a_heads + wave) * a_L + q) * 2;
       gst1(st, M);
       gst1(st + 1, l);
@@ -368,6 +382,12 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
     step(B2, fa0, fb0, fa1, fb1, A, kc + 3, c0, c1);
     step(B3, fa1, fb1, fa0, fb0, A, kc + 4 == nk ? 0 : kc + 4, c0, c1);
   };
+  auto run4n = [&](int A, int kc, int ktn, f32x4 &c0, f32x4 &c1) {      // ... with the k-tile the last step prefetches given
+    step(B0, fa0, fb0, fa1, fb1, A, kc + 1, c0, c1);
+    step(B1, fa1, fb1, fa0, fb0, A, kc + 2, c0, c1);
+    step(B2, fa0, fb0, fa1, fb1, A, kc + 3, c0, c1);
+    step(B3, fa1, fb1, fa0, fb0, A, ktn, c0, c1);
+  };
   // K = 128 and K = 512 with the k-tile a compile-time constant: the A-fragment addresses are immediates (with a run-time k-tile
   // the compiler adds the scalar tile offset to the lane's VGPR offset with a v_add per fragment read -- VALU time the MFMAs lose)
   auto run_chunk_k128 = [&](int A, f32x4 &c0, f32x4 &c1) { run4(A, 0, 4, c0, c1); };
@@ -415,7 +435,7 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
   CHAIN_PROF(3);
 
   // ---- training: the feed-forward block's input goes to the tape (the backward recomputes the block from it)
-  if (a_x_mid) {
+  if (a_x_mid && member == 0) {
     const int row = tid >> 5, l32 = tid & 31;
     gst4_nt(a_x_mid + (long)(m0 + row) * CD + 4 * l32, lld4(lds, xs + row * XP + 4 * l32));
   }
@@ -432,7 +452,8 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
       const int row = 4 * fg + r;
       hid_at[r] = Abig + (ncol >> 5) * ATILE + row * WK + ((((ncol & 31) >> 2) ^ (row & 7)) * 4) + (ncol & 3);
     }
-    for (int hc = 0; hc < 4; ++hc) {
+    for (int hci = 0; hci < my_chunks; ++hci) {
+      const int hc = member + hci * a_C;
       f32x4 a0 = zero, a1 = zero, g0 = zero, g1 = zero;
       run_chunk_k128(Ahat, a0, a1);
       run_chunk_k128(Ahat, g0, g1);
@@ -457,7 +478,7 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
     }
     __syncthreads();
     CHAIN_PROF(5);
-    {
+    if (a_C == 1) {
       f32x4 c0 = zero, c1 = zero;
       read_a(fa0, Abig, 0);
       run_chunk_k512(Abig, c0, c1);
@@ -465,25 +486,66 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
       const float v[4] = {c0.x + c1.x, c0.y + c1.y, c0.z + c1.z, c0.w + c1.w};
 #pragma unroll
       for (int r = 0; r < 4; ++r) lds[xs + (4 * fg + r) * XP + ncol] += v[r] + bv;
+    } else {
+      // cluster: the k-tiles of the own hidden chunks only -> a partial tile; exchange with the other members
+      f32x4 c0 = zero, c1 = zero;
+      read_a(fa0, Abig, 4 * member);
+      for (int hci = 0; hci < my_chunks; ++hci) {
+        const int hc = member + hci * a_C;
+        run4n(Abig, 4 * hc, hci + 1 < my_chunks ? 4 * (hc + a_C) : 0, c0, c1);
+      }
+      const float v[4] = {c0.x + c1.x, c0.y + c1.y, c0.z + c1.z, c0.w + c1.w};
+      // The members of a tile share an XCD (launcher: ntiles % 8 == 0), i.e. one L2: partials and flags move as RELAXED agent-scope
+      // atomics, which are performed at the L2 -- no release fence (a device-scope release writes back the XCD's whole L2:
+      // measured 12 us per exchange, more than the cluster saved from b = 2 on), no stale L1 lines on the reading side.
+      float *mine = args.xchg + ((long)tile * a_C + member) * (CR * CD);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) __hip_atomic_store(mine + (4 * fg + r) * CD + ncol, v[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the stores have reached the L2 ...
+      __syncthreads();
+      if (tid == 0)                          // ... before the member's flag goes up
+        __hip_atomic_store(args.xflags + tile * a_C + member, args.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid < a_C) {                       // one lane per member flag; bounded spin (a lost member must not hang the device)
+        int spins = 0;
+        while (__hip_atomic_load(args.xflags + tile * a_C + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < args.seq) {
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > (1 << 22)) { args.xflags[ntiles * a_C] = 1; break; }      // error marker (members not co-resident): no hang
+        }
+      }
+      __syncthreads();
+      {
+        const int row = tid >> 5, l32 = tid & 31;
+        float4 x = lld4(lds, xs + row * XP + 4 * l32);
+        const float4 bb = lld4(lds, p_b2 + 4 * l32);
+        x.x += bb.x; x.y += bb.y; x.z += bb.z; x.w += bb.w;
+        for (int c = 0; c < a_C; ++c) {      // fixed order: every member ends with the same bits
+          const float *pp = args.xchg + ((long)tile * a_C + c) * (CR * CD) + row * CD + 4 * l32;
+          x.x += __hip_atomic_load(pp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          x.y += __hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          x.z += __hip_atomic_load(pp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          x.w += __hip_atomic_load(pp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        lst4(lds, xs + row * XP + 4 * l32, x);
+      }
     }
     __syncthreads();
   }
 
   CHAIN_PROF(6);
   // ---- x is final: hand it to the next attention block (its input / residual, and the trace slot of hn_attn_probs)
-  if (a_x_out) {
+  if (a_x_out && member == 0) {
     const int row = tid >> 5, l32 = tid & 31;
     gst4_nt(a_x_out + (long)(m0 + row) * CD + 4 * l32, lld4(lds, xs + row * XP + 4 * l32));
   }
 
   // ================= stages Q / KV: the next attention block's projections of LN'(x) =================
-  if (nq_ch + nkv_ch > 0) {
+  if (my_proj > 0) {
     layer_norm(a_p_nw != nullptr, p_pnw, p_pnb);
     __syncthreads();
     CHAIN_PROF(7);
     read_a(fa0, Ahat, 0);
     const int stg = Abig + wave * 256;       // this wave's 16 x 16 output tile (the hidden tile is dead by now)
-    for (int pj = 0; pj < nq_ch + nkv_ch; ++pj) {
+    for (int pj = member; pj < nq_ch + nkv_ch; pj += a_C) {
       const bool isq = pj < nq_ch;
       const int j = isq ? pj : pj - nq_ch;
       f32x4 c0 = zero, c1 = zero;
@@ -595,7 +657,15 @@ int launch_latent_chain(const ChainArgs &a, hipStream_t s) {
     HN_HIP_CHECK(hipFuncSetAttribute((const void *)latent_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     if (dev >= 0 && dev < 64) configured[dev] = true;
   }
-  hipLaunchKernelGGL(latent_chain_kernel, dim3(a.rows / CR), dim3(512), lds_bytes, s, a);
+  // cluster mode for small batches (see the kernel): 4 workgroups per row tile up to 64 tiles, 2 up to 128 -- at most 256
+  // workgroups, all resident (the exchange spins on the other members' flags)
+  static const bool no_cluster = getenv("HN_NO_CHAIN_CLUSTER") != nullptr;
+  static const int max_tiles = getenv("HN_CHAIN_CLUSTER_TILES") ? atoi(getenv("HN_CHAIN_CLUSTER_TILES")) : 128;      // development knob
+  ChainArgs ac = a;
+  const int tiles = a.rows / CR;
+  ac.cluster = 1;
+  if (!no_cluster && a.xchg && a.xflags && a.seq > 0 && a.has_ff && !a.x_mid && tiles <= max_tiles && tiles % 8 == 0 && al16(a.xchg)) ac.cluster = tiles <= 64 ? 4 : 2;
+  hipLaunchKernelGGL(latent_chain_kernel, dim3(tiles * ac.cluster), dim3(512), lds_bytes, s, ac);
   HN_LAUNCH_CHECK("latent_chain");
   return HN_OK;
 }

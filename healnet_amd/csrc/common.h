@@ -249,7 +249,13 @@ struct ChainArgs {
   const float *p_nw, *p_nb;             // that block's LayerNorm on x (NULL: none)
   const float *wq; float *Q; int ldq; float alpha_q;
   const float *wkv; float *KV; int ldkv;
+  // cluster mode (small batches; inference forward): exchange buffer (rows / 16 * 4 tiles of 16 x 128 floats), one flag per (tile,
+  // member) + one error marker, zeroed at the start of the forward, and this chain's 1-based sequence number within the forward
+  float *xchg; int *xflags; int seq;
+  int cluster;                          // internal: members per row tile (launch_latent_chain decides)
 };
+constexpr int CHAIN_XCHG_FLOATS = 256 * 16 * 128;      // <= 256 workgroups x one partial tile
+constexpr int CHAIN_XCHG_FLAGS = 256 + 1;
 bool latent_chain_supported(int rows, int d, int hidden);
 int launch_latent_chain(const ChainArgs &a, hipStream_t s);
 // backward of the latent chain (bchain.hip): projection backward of an attention block -> feed-forward block backward -> the
