@@ -133,6 +133,9 @@ struct AttnExt {
   bool merge_deferred;
   const float *opart, *mpart, *lpart;
   int nsplit, Lp, dp;
+  // training: the block's projections live in the tape (sized from THIS block's plan) -- produced there by the chain in front
+  // (q / kv above point at the same slots) or by the block's own GEMMs -- so that the backward does not recompute them
+  float *q_home, *kv_home;
 };
 
 static int check_ws(void *ws, size_t ws_bytes, size_t need, const char *who) {
@@ -168,7 +171,7 @@ static int attn_prepare(const hn_attn_params *p, const AttnPlan &pl, const float
   // chain's own products (ckv: latent self-attention only), not for this block's plan (an explicit cross block
   // with N >> l_c would overrun ckv; padded head dims would leave the external q's pad columns unwritten)
   const bool q_done = ext && ext->q && ext->q_done;
-  float *qbuf = q_done ? ext->q : pl.q;
+  float *qbuf = q_done ? ext->q : ((ext && ext->q_home) ? ext->q_home : pl.q);
   GemmArgs gq = gemm_defaults();
   gq.A = x_in; gq.lda = p->query_dim;
   gq.W = p->w_q; gq.ldw = p->query_dim;
@@ -199,11 +202,12 @@ static int attn_prepare(const hn_attn_params *p, const AttnPlan &pl, const float
     const int qpitch = p->heads * pl.dhp, kvpitch = 2 * p->heads * pl.dhp;
     const bool kv_ext = ext && ext->kv && ext->kv_done && !ctx;      // the chain projects K/V for latent self-attention only
     HN_REQUIRE(!(ext && ext->kv_done) || kv_ext, HN_E_SHAPE, "attn: external K/V projections exist for latent self-attention only");
-    float *kvbuf = kv_tape ? kv_tape : (kv_ext ? ext->kv : pl.kv);
+    float *kvbuf = kv_tape ? kv_tape : (kv_ext ? ext->kv : ((ext && ext->kv_home && !ctx) ? ext->kv_home : pl.kv));
     if (kv_ext) kv_ready = true;
     if (pl.dhp != pl.dh) {
-      HN_REQUIRE(!q_done, HN_E_SHAPE, "attn: external projections need dim_head in {16, 32, 64, 128}");
-      { int rc_ = launch_fill(qbuf, 0.0f, (long)((size_t)rows * qpitch), s); if (rc_ != HN_OK) return rc_; }
+      // (projections found ready with a padded head width were written by this block's own forward into its tape slot, pad
+      // columns included: the chain only projects for dim_head in {16, 32, 64, 128})
+      if (!q_done) { int rc_ = launch_fill(qbuf, 0.0f, (long)((size_t)rows * qpitch), s); if (rc_ != HN_OK) return rc_; }
       if (!kv_ready) { int rc_ = launch_fill(kvbuf, 0.0f, (long)((size_t)b * pl.N * kvpitch), s); if (rc_ != HN_OK) return rc_; }
     }
     gq.C = qbuf; gq.ldc = qpitch; gq.alpha = pl.cscale;
@@ -449,6 +453,7 @@ struct AttnBwdExt {
   bool defer_proj;           // stop behind the core: no dW_q / dW_kv, no dx; dQ / dKV / xhat are reported instead
   const float *dQ, *dKV, *xhat;   // out (defer_proj): (rows, inner) scaled, (rows, 2 inner) or NULL (cross blocks), LN(x_in) (rows, query_dim)
   const float *O;            // out: the block's attention output (rows, inner) -- the tape's or the recomputed one
+  const float *q_taped, *kv_taped;      // in: the forward's projections from the tape (NULL: recomputed here)
 };
 
 static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float *x_out, int residual, const float *ctx,
@@ -533,7 +538,13 @@ static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float
   float *kv_saved = saved_kv(pl, has_ctx, general, b, L, const_cast<float *>(saved));
   // packed shared context (the training forward's layout when nothing is dropped): folded queries, dO' and dQ'' in slot order
   const int pack_ks = (pl.rank_d && pl.ones && p->ctx_gamma && !dropping) ? ctx_pack_ks : 0;
-  if ((rc = attn_prepare(p, pl, x_in, ctx, ld_ctx, b, L, s, &core, pack_ks, kv_saved, kv_saved != nullptr)) != HN_OK) return rc;
+  float *kv_from = kv_saved ? kv_saved : ((ext && ext->kv_taped && !has_ctx) ? const_cast<float *>(ext->kv_taped) : nullptr);
+  AttnExt pe;
+  memset(&pe, 0, sizeof(pe));
+  if (ext && ext->q_taped) { pe.q = const_cast<float *>(ext->q_taped); pe.q_done = true; }
+  const float *qraw = (ext && ext->q_taped) ? ext->q_taped : pl.q;      // rank-D binding: Q before the fold
+  if ((rc = attn_prepare(p, pl, x_in, ctx, ld_ctx, b, L, s, &core, pack_ks, kv_from, kv_from != nullptr, false, nullptr,
+                         (ext && ext->q_taped) ? &pe : nullptr)) != HN_OK) return rc;
   const float *xhat = x_in;
   if (p->norm_w) {
     if ((rc = launch_ln_fwd(x_in, p->norm_w, p->norm_b, rows, qd, bp.xhat, s)) != HN_OK) return rc;
@@ -592,7 +603,7 @@ static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float
     if (pack_ks && (rc = launch_pack_fold(bp.E, hp, h, pl.D, pl.dp, pack_ks, 1, rows, s)) != HN_OK) return rc;
     { int rc_ = launch_fill(bp.T, 0.0f, (long)((size_t)rows * hp), s); if (rc_ != HN_OK) return rc_; }
     {   // T = Qraw_h W_k,h   (Qraw = x_hat W_q^T lives in pl.q after attn_prepare)
-      GemmExArgs e = gex(pl.q, inner, 1, wk, 1, pl.D, bp.T, hp, rows, pl.D, dh, 0);
+      GemmExArgs e = gex(qraw, inner, 1, wk, 1, pl.D, bp.T, hp, rows, pl.D, dh, 0);
       e.batch = h; e.strideA = dh; e.strideB = (long)dh * pl.D; e.strideC = pl.dp;
       if ((rc = launch_gemm_ex(e, s, bp.red)) != HN_OK) return rc;
     }
@@ -603,7 +614,7 @@ static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float
     // dT = 2 scale * gamma * dQacc
     if ((rc = launch_head_affine(bp.E, hp, pl.dp, nullptr, 0, 0, p->ctx_gamma, nullptr, two_scale, h, pl.D, pl.dp, hp, rows, bp.dT, s)) != HN_OK) return rc;
     if (dwk) {   // dW_k,h += Qraw_h^T dT_h
-      GemmExArgs e = gex(pl.q, 1, inner, bp.dT, 1, hp, dwk, pl.D, dh, pl.D, rows, 1);
+      GemmExArgs e = gex(qraw, 1, inner, bp.dT, 1, hp, dwk, pl.D, dh, pl.D, rows, 1);
       e.batch = h; e.strideA = dh; e.strideB = pl.dp; e.strideC = (long)dh * pl.D;
       if ((rc = launch_gemm_ex(e, s, bp.red)) != HN_OK) return rc;
     }
@@ -1006,8 +1017,10 @@ struct TapePlan {
   Step steps[kMaxSteps];
   size_t x_off[kMaxSteps + 1];       // float offsets of the latent array before step k (x_off[nsteps] = final)
   size_t stats_off[kMaxSteps], saved_off[kMaxSteps];
+  size_t q_off[kMaxSteps], kv_off[kMaxSteps];      // projections of the attention block at step k kept for the backward (kNoSlot: none)
   size_t floats;
 };
+constexpr size_t kNoSlot = (size_t)-1;
 
 static int plan_tape(const hn_model *m, const hn_modality_input *in, int b, int masked, int skip_self, const FusionPlan &fp, TapePlan *tp) {
   tp->nsteps = build_schedule(m, in, skip_self, tp->steps, kMaxSteps);
@@ -1018,6 +1031,7 @@ static int plan_tape(const hn_model *m, const hn_modality_input *in, int b, int 
   for (int k = 0; k < tp->nsteps; ++k) {
     const Step &st = tp->steps[k];
     tp->stats_off[k] = tp->saved_off[k] = 0;
+    tp->q_off[k] = tp->kv_off[k] = kNoSlot;
     if (st.kind == STEP_CROSS_ATTN || st.kind == STEP_SELF_ATTN) {
       const bool cross = st.kind == STEP_CROSS_ATTN;
       const hn_attn_params *ap = cross ? &m->cross_attn[st.layer * m->n_modalities + st.m] : &m->self_attn[st.layer];
@@ -1027,6 +1041,14 @@ static int plan_tape(const hn_model *m, const hn_modality_input *in, int b, int 
       if (rc != HN_OK) return rc;
       tp->stats_off[k] = off; off += align_up((size_t)b * ap->heads * m->l_c * 2, 64);
       tp->saved_off[k] = off; off += align_up(attn_saved_floats(pl, cross, cross && (masked || ap->dropout > 0.0f), b, m->l_c), 64);
+      // the q (and, for the latent self-attention, k / v) projections: 25 MB per self block at cfg2 b = 32 against a 10-27 us
+      // recompute launch in front of every attention core backward (not for the one-token shortcut, which has no q / k)
+      const bool one_token = cross && pl.N == 1 && !masked && !(ap->dropout > 0.0f);
+      if (!one_token) {
+        const size_t rows = (size_t)b * m->l_c;
+        tp->q_off[k] = off; off += align_up(rows * (pl.rank_d ? pl.inner : pl.heads * pl.dhp), 64);
+        if (!cross) { tp->kv_off[k] = off; off += align_up(rows * 2 * pl.heads * pl.dhp, 64); }
+      }
     }
   }
   tp->floats = off;
@@ -1614,7 +1636,9 @@ int hn_fusion_forward_train(const hn_model *m, const hn_modality_input *in, int 
                             tpack[i])) != HN_OK)
       return rc;
   }
-  if ((rc = launch_broadcast_rows(m->latents, T + tp.x_off[0], (long)L * d, b, s)) != HN_OK) return rc;
+  // (the launch also zeroes the cluster flags of the latent chains: small batches run them as clusters, chain.hip)
+  if ((rc = launch_broadcast_rows(m->latents, T + tp.x_off[0], (long)L * d, b, s, fp.flags + m->depth * M, CHAIN_XCHG_FLAGS)) != HN_OK) return rc;
+  int chain_seq = 0;
   const bool use_chain = fp.chain && !chain_disabled();
   auto is_attn_t = [](const Step &q) { return q.kind == STEP_CROSS_ATTN || q.kind == STEP_SELF_ATTN; };
   auto trace_copies = [&](int k) -> int {       // optional copies for hn_attn_probs (same slots as hn_fusion_forward)
@@ -1628,6 +1652,14 @@ int hn_fusion_forward_train(const hn_model *m, const hn_modality_input *in, int 
     return HN_OK;
   };
   bool q_done = false, kv_done = false;          // projections of the attention block at `k` already produced by the chain in front of it
+  // the projections of the attention block at step k live in its tape slots: what the chain in front wrote there is found there
+  // (q / kv), what the block projects itself goes there (q_home / kv_home)
+  auto tape_homes = [&](int k, AttnExt *e) -> bool {
+    bool any = false;
+    if (tp.q_off[k] != kNoSlot) { e->q = e->q_home = T + tp.q_off[k]; any = true; }
+    if (tp.kv_off[k] != kNoSlot) { e->kv = e->kv_home = T + tp.kv_off[k]; any = true; }
+    return any;
+  };
   for (int k = 0; k < tp.nsteps;) {
     const Step &st = tp.steps[k];
     const float *xin = T + tp.x_off[k];
@@ -1653,6 +1685,7 @@ int hn_fusion_forward_train(const hn_model *m, const hn_modality_input *in, int 
       hn_attn_params ap = self ? m->self_attn[st.layer] : m->cross_attn[st.layer * M + st.m];
       ap.rng = rng;
       AttnExt ext = {fp.cq, fp.ckv, q_done, kv_done, true, nullptr, 0, false, false, nullptr, nullptr, nullptr, 0, 0, 0};
+      tape_homes(k, &ext);
       if (self)
         rc = attn_fwd_impl(&ap, xin, nullptr, 1, nullptr, 0, b, L, L, d, nullptr, T + tp.stats_off[k], fp.op_ws, fp.op_ws_bytes, s,
                            nullptr, nullptr, T + tp.saved_off[k], false, 0, nullptr, nullptr, &ext);
@@ -1683,12 +1716,17 @@ int hn_fusion_forward_train(const hn_model *m, const hn_modality_input *in, int 
         const bool one_token = !nself && fp.N[sn.m] == 1 && mask == nullptr && !(an->dropout > 0.0f);
         if (!one_token && pn.dh == pn.dhp && pn.inner % 128 == 0 && an->query_dim == d && an->w_q && an->w_kv && chain_proj_aligned(an)) {
           ca.p_nw = an->norm_w; ca.p_nb = an->norm_b;
-          ca.nq = pn.inner; ca.wq = an->w_q; ca.Q = fp.cq; ca.ldq = pn.inner;
+          ca.nq = pn.inner; ca.wq = an->w_q; ca.ldq = pn.inner;
+          ca.Q = tp.q_off[k + 2] != kNoSlot ? T + tp.q_off[k + 2] : fp.cq;      // straight into the next block's tape slot
           ca.alpha_q = pn.rank_d ? 1.0f : pn.cscale;
           q_done = true;
-          if (nself) { ca.nkv = 2 * pn.inner; ca.wkv = an->w_kv; ca.KV = fp.ckv; ca.ldkv = 2 * pn.inner; kv_done = true; }
+          if (nself) {
+            ca.nkv = 2 * pn.inner; ca.wkv = an->w_kv; ca.ldkv = 2 * pn.inner; kv_done = true;
+            ca.KV = tp.kv_off[k + 2] != kNoSlot ? T + tp.kv_off[k + 2] : fp.ckv;
+          }
         }
       }
+      ca.xchg = fp.xchg; ca.xflags = fp.flags + m->depth * M; ca.seq = ++chain_seq;
       if ((rc = launch_latent_chain(ca, s)) != HN_OK) return rc;
       if ((rc = trace_copies(k)) != HN_OK) return rc;
       k += 2;
@@ -1696,6 +1734,7 @@ int hn_fusion_forward_train(const hn_model *m, const hn_modality_input *in, int 
     }
     AttnExt ext = {fp.cq, fp.ckv, q_done, kv_done, false, nullptr, 0, false, false, nullptr, nullptr, nullptr, 0, 0, 0};
     AttnExt *extp = (q_done || kv_done) ? &ext : nullptr;
+    if (is_attn_t(st) && tape_homes(k, &ext)) extp = &ext;
     switch (st.kind) {
       case STEP_CROSS_ATTN: {
         hn_attn_params ap = m->cross_attn[st.layer * M + st.m];
@@ -1896,7 +1935,9 @@ int hn_fusion_backward(const hn_model *m, const hn_modality_input *in, int b, co
     AttnBwdExt ext;
     memset(&ext, 0, sizeof(ext));
     ext.dpre = dpre; ext.dO = dO_in; ext.skip_wout = skip_wout; ext.defer_proj = defer;
-    AttnBwdExt *extp = (dpre || defer) ? &ext : nullptr;
+    if (tp.q_off[k] != kNoSlot) ext.q_taped = T + tp.q_off[k];
+    if (tp.kv_off[k] != kNoSlot) ext.kv_taped = T + tp.kv_off[k];
+    AttnBwdExt *extp = (dpre || defer || ext.q_taped) ? &ext : nullptr;
     const float *xin = T + tp.x_off[k], *xout = T + tp.x_off[k + 1];
     int rc2;
     if (st.kind == STEP_CROSS_ATTN)

@@ -501,7 +501,11 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
       float *mine = args.xchg + ((long)tile * a_C + member) * (CR * CD);
 #pragma unroll
       for (int r = 0; r < 4; ++r) __hip_atomic_store(mine + (4 * fg + r) * CD + ncol, v[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the stores have reached the L2 ...
+      // ... but ORDER still has to be made: a workgroup-scope fence emits no wait at all here (the waves of a workgroup share the
+      // CU's L1), and stores to different L2 channels are not ordered among themselves -- the flag could overtake a partial.
+      // Every wave waits until ITS stores have been acknowledged by the L2 (vmcnt counts stores on gfx9), then the barrier, then
+      // the flag.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0)                          // ... before the member's flag goes up
         __hip_atomic_store(args.xflags + tile * a_C + member, args.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -664,7 +668,7 @@ int launch_latent_chain(const ChainArgs &a, hipStream_t s) {
   ChainArgs ac = a;
   const int tiles = a.rows / CR;
   ac.cluster = 1;
-  if (!no_cluster && a.xchg && a.xflags && a.seq > 0 && a.has_ff && !a.x_mid && tiles <= max_tiles && tiles % 8 == 0 && al16(a.xchg)) ac.cluster = tiles <= 64 ? 4 : 2;
+  if (!no_cluster && a.xchg && a.xflags && a.seq > 0 && a.has_ff && tiles <= max_tiles && tiles % 8 == 0 && al16(a.xchg)) ac.cluster = tiles <= 64 ? 4 : 2;
   hipLaunchKernelGGL(latent_chain_kernel, dim3(tiles * ac.cluster), dim3(512), lds_bytes, s, ac);
   HN_LAUNCH_CHECK("latent_chain");
   return HN_OK;

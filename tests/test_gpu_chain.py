@@ -204,3 +204,58 @@ def test_masked_image_model_on_the_chain_vs_oracle(hn, grad_mode):
     with torch.set_grad_enabled(grad_mode):
         got = model([img.to(DEV)], mask=mask.to(DEV)).detach().cpu()
     assert_close(got, want, rel=1e-3, floor=0.0, abs_floor=1e-5, what="masked image model")
+
+
+@pytest.mark.parametrize("b", [1, 2, 4, 8, 16])
+def test_cluster_chain_small_batches_deterministic_and_vs_oracle(hn, b):
+    """Round 3: up to 128 row tiles the chain runs as a CLUSTER (4 or 2 workgroups per 16-row tile, one exchange of FF2 partials
+    per chain through the shared L2).  The exchange must be ordered (every partial before its member's flag): 40 repetitions
+    of the inference forward and of the taping forward are bitwise identical, and agree with the oracle."""
+    kw = dict(n_modalities=2, channel_dims=[2000, 3], num_spatial_axes=[1, 2], out_dims=4, depth=2)
+    torch.manual_seed(71)
+    model = hn.HealNet(**kw).eval().to(DEV)
+    gen = torch.Generator().manual_seed(72 + b)
+    ins = [torch.rand(b, 1, 2000, generator=gen), torch.rand(b, 56, 40, 3, generator=gen)]
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        want = O.fusion_forward(sd, O.FusionConfig(**kw), [t.clone() for t in ins])
+    dins = [t.to(DEV) for t in ins]
+    for grad_mode in (False, True):
+        with torch.set_grad_enabled(grad_mode):
+            first = model(list(dins)).detach().clone()
+            for rep in range(40):
+                again = model(list(dins)).detach()
+                assert torch.equal(first, again), f"b={b} grad_mode={grad_mode}: repetition {rep} differs (unordered exchange?)"
+        assert_close(first.cpu(), want, rel=1e-3, floor=0.0, abs_floor=1e-5, what=f"cluster chain b={b} grad_mode={grad_mode}")
+
+
+def test_cluster_chain_equals_one_workgroup_per_tile():
+    """Same model, cluster mode on / off (HN_NO_CHAIN_CLUSTER=1 in a subprocess): logits equal to fp32 summation noise (the FF2
+    contraction is summed per hidden chunk in cluster mode), and the cluster really ran (the bits differ)."""
+    script = textwrap_dedent("""
+        import sys, torch
+        sys.path.insert(0, {root!r})
+        import healnet_amd as hn
+        torch.manual_seed(81)
+        m = hn.HealNet(n_modalities=2, channel_dims=[2000, 3], num_spatial_axes=[1, 2], out_dims=4).eval().to("cuda:0")
+        g = torch.Generator().manual_seed(82)
+        ins = [torch.rand(4, 1, 2000, generator=g).cuda(), torch.rand(4, 64, 48, 3, generator=g).cuda()]
+        with torch.no_grad():
+            torch.save(m(ins).cpu(), {dst!r})
+    """)
+    import tempfile
+    outs = {}
+    with tempfile.TemporaryDirectory() as d:
+        for tag, env in (("cluster", {}), ("single", {"HN_NO_CHAIN_CLUSTER": "1"})):
+            dst = os.path.join(d, tag + ".pt")
+            r = subprocess.run([sys.executable, "-c", script.format(root=ROOT, dst=dst)], cwd=ROOT, capture_output=True, text=True, timeout=600,
+                               env=dict(os.environ, **env))
+            assert r.returncode == 0, r.stderr[-3000:]
+            outs[tag] = torch.load(dst)
+    assert_close(outs["cluster"], outs["single"], rel=1e-5, floor=0.0, abs_floor=1e-6, what="cluster vs one workgroup per tile")
+    assert not torch.equal(outs["cluster"], outs["single"]), "HN_NO_CHAIN_CLUSTER did not change the route?"
+
+
+def textwrap_dedent(s):
+    import textwrap
+    return textwrap.dedent(s)
