@@ -380,14 +380,24 @@ static int nq_for(int dt) { return dt == 1 ? nq_dt1() : (dt == 2 ? 2 : (dt == 4 
 // and the token split then has to make up the waves: 242 splits at b = 1, 64 at b = 4, whose merge costs more than the core
 // (profiles/r03_c: merge_vproj_kernel 49 us against 34 us for the core at b = 1).  With 2 or 1 tiles per wave the same waves come
 // from 12 splits or fewer, which the chain behind the block merges itself.  0 = keep the default.
+static int sb_env(const char *name) { const char *e = getenv(name); return e ? atoi(e) : 0; }
 int attn_core_nq_small_batch(int dp, int b, int h, int Lp) {
   static const bool off = getenv("HN_CORE_NQ") != nullptr || getenv("HN_NO_SMALL_BATCH_GEOMETRY") != nullptr;
+  static const int force_nq = sb_env("HN_SB_NQ");       // development knobs: fixed tiles per wave / split cap of the small-batch plan
   if (off || dp != 16) return 0;
+  if (force_nq > 0) return force_nq;
   const int tiles = Lp / 16;
   const int cand[3] = {4, 2, 1};
+  // measured (cfg1, b = 1 .. 16, every (tiles per wave, split cap) pair: gpurun_out/r03u): the fastest plan has >= 128 work items
+  // (b * h * query-tile groups) in front of the token split -- 1 tile per wave at b <= 2, 2 at b = 4, the default 4 from b = 8 on --
+  // and as many splits (<= 48, folded by the chain's merge head in groups of 12) as fill the wave slots
   for (int i = 0; i < 3; ++i)
-    if ((long)b * h * ceil_div(tiles, cand[i]) * 12 >= 3072) return cand[i] == 4 ? 0 : cand[i];
-  return (long)b * h * tiles * 12 >= 512 ? 1 : 0;
+    if ((long)b * h * ceil_div(tiles, cand[i]) >= 128) return cand[i];
+  return (long)b * h * tiles * CHAIN_MERGE_MAX_SPLITS >= 512 ? 1 : 0;
+}
+int attn_core_small_batch_split_cap() {
+  static const int cap = sb_env("HN_SB_SPLITS");
+  return cap > 0 && cap <= CHAIN_MERGE_MAX_SPLITS ? cap : CHAIN_MERGE_MAX_SPLITS;
 }
 
 void attn_core_geometry(int b, int h, int Lp, int N, int dp, int *nsplit, int *chunk, int waves_per_simd, int nq) {
@@ -402,7 +412,7 @@ void attn_core_geometry(int b, int h, int Lp, int N, int dp, int *nsplit, int *c
   long want = geom_floor ? tw / ((long)b * h * ngroups) : ceil_div_ll(tw, (long)b * h * ngroups);
   long max_splits = N / 128;
   if (max_splits < 1) max_splits = 1;
-  if (nq > 0 && want > 12) want = 12;          // planned for the chain's merge head (attn_core_nq_small_batch)
+  if (nq > 0 && want > attn_core_small_batch_split_cap()) want = attn_core_small_batch_split_cap();      // planned for the chain's merge head (attn_core_nq_small_batch)
   if (want > max_splits) want = max_splits;
   if (want < 1) want = 1;
   int c = (int)ceil_div_ll(N, want);

@@ -233,25 +233,33 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
     const int i = lane & 15, gq = lane >> 4;
     const int bi = m0 / a_L, q = m0 - bi * a_L + i;                       // L % 16 == 0: a tile never straddles two samples
     const long prow = ((long)(bi * a_heads + wave) * a_nsplit) * a_Lp + q;      // + s * Lp
-    float mv[CHAIN_MERGE_MAX_SPLITS], lv[CHAIN_MERGE_MAX_SPLITS];
-    float4 ov[CHAIN_MERGE_MAX_SPLITS];
-#pragma unroll
-    for (int s = 0; s < CHAIN_MERGE_MAX_SPLITS; ++s) {                    // every request up front (clamped: weight 0 past nsplit)
-      const long pr = prow + (long)min(s, a_nsplit - 1) * a_Lp;
-      mv[s] = gld1(a_Mpart + pr);
-      lv[s] = gld1(a_Lpart + pr);
-      ov[s] = gld4(a_Opart + pr * 16 + 4 * gq);
-    }
-    float M = -3.0e38f;
-#pragma unroll
-    for (int s = 0; s < CHAIN_MERGE_MAX_SPLITS; ++s) M = fmaxf(M, s < a_nsplit ? mv[s] : -3.0e38f);
-    float l = 0.0f;
+    // groups of CHAIN_MERGE_GROUP splits (all requests of a group in flight together), folded into a running (M, l, o) in split
+    // order: one group for the usual 8-12 splits, up to four when a small batch needs more splits to fill the wave slots
+    float M = -3.0e38f, l = 0.0f;
     float4 o0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s0 = 0; s0 < a_nsplit; s0 += CHAIN_MERGE_GROUP) {
+      float mv[CHAIN_MERGE_GROUP], lv[CHAIN_MERGE_GROUP];
+      float4 ov[CHAIN_MERGE_GROUP];
 #pragma unroll
-    for (int s = 0; s < CHAIN_MERGE_MAX_SPLITS; ++s) {
-      const float w = s < a_nsplit ? __builtin_amdgcn_exp2f(mv[s] - M) : 0.0f;
-      l = fmaf(w, lv[s], l);
-      o0.x = fmaf(w, ov[s].x, o0.x); o0.y = fmaf(w, ov[s].y, o0.y); o0.z = fmaf(w, ov[s].z, o0.z); o0.w = fmaf(w, ov[s].w, o0.w);
+      for (int s = 0; s < CHAIN_MERGE_GROUP; ++s) {                       // clamped: weight 0 past nsplit
+        const long pr = prow + (long)min(s0 + s, a_nsplit - 1) * a_Lp;
+        mv[s] = gld1(a_Mpart + pr);
+        lv[s] = gld1(a_Lpart + pr);
+        ov[s] = gld4(a_Opart + pr * 16 + 4 * gq);
+      }
+      float Mn = M;
+#pragma unroll
+      for (int s = 0; s < CHAIN_MERGE_GROUP; ++s) Mn = fmaxf(Mn, s0 + s < a_nsplit ? mv[s] : -3.0e38f);
+      const float sc = __builtin_amdgcn_exp2f(M - Mn);                    // first group: 2^(-3e38 - Mn) = 0 on an all-zero state
+      l *= sc;
+      o0.x *= sc; o0.y *= sc; o0.z *= sc; o0.w *= sc;
+#pragma unroll
+      for (int s = 0; s < CHAIN_MERGE_GROUP; ++s) {
+        const float w = s0 + s < a_nsplit ? __builtin_amdgcn_exp2f(mv[s] - Mn) : 0.0f;
+        l = fmaf(w, lv[s], l);
+        o0.x = fmaf(w, ov[s].x, o0.x); o0.y = fmaf(w, ov[s].y, o0.y); o0.z = fmaf(w, ov[s].z, o0.z); o0.w = fmaf(w, ov[s].w, o0.w);
+      }
+      M = Mn;
     }
     const float inv = 1.0f / l;
     o0.x *= inv; o0.y *= inv; o0.z *= inv; o0.w *= inv;

@@ -303,7 +303,8 @@ struct GemmTnMulti {
 size_t gemm_tn_multi_scratch_floats(const GemmTnMulti &m);
 int launch_gemm_tn_multi(GemmTnMulti &m, float *scratch, size_t scratch_floats, hipStream_t s);
 const float *transpose_cache_lookup(const float *src, long ld, int rows, int cols);
-constexpr int CHAIN_MERGE_MAX_SPLITS = 12;   // head 3 merges at most this many splits (more: merge_vproj_kernel)
+constexpr int CHAIN_MERGE_GROUP = 12;        // head 3 folds the splits in groups of this many (registers)
+constexpr int CHAIN_MERGE_MAX_SPLITS = 48;   // ... and at most this many in all (more: merge_vproj_kernel)
 // folded value projection of a shared-context block for ChainArgs.wvf (the image merge_vproj_kernel builds per workgroup)
 struct VfoldMulti {                    // one entry per layer of a modality (<= HN_SKINNY_MAXZ): value half of to_kv, context LayerNorm affine
   int n;
