@@ -20,6 +20,7 @@
 // All operand loads are raw buffer loads (see common.h): rows past the end read as 0 in hardware, so the loaders
 // carry no per-lane predicates (hipcc turns "load or 0" into branch + load + s_waitcnt vmcnt(0) per element).
 #include "common.h"
+#include <stdlib.h>
 
 namespace hn {
 
@@ -867,7 +868,8 @@ int launch_gemm(const GemmArgs &g_in, hipStream_t s) {
     HN_LAUNCH_CHECK("gemm_skinny");
     return HN_OK;
   }
-  if (!glu && g.batch == 1 && g.pro != PRO_LAYERNORM && g.M >= 2048 && g.N >= 256 && g.K >= 256) {
+  static const int big_min_n = getenv("HN_GEMM_BIG_MIN_N") ? atoi(getenv("HN_GEMM_BIG_MIN_N")) : 256;      // development knob
+  if (!glu && g.batch == 1 && g.pro != PRO_LAYERNORM && g.M >= 2048 && g.N >= big_min_n && g.K >= 256) {
     const int ntm = ceil_div(g.M, GM), ntn = ceil_div(g.N, GN);
     const long blocks = (long)ceil_div(ntm, 8) * 8 * ntn;
     HN_REQUIRE(blocks < (1L << 31), HN_E_UNSUPPORTED, "gemm: grid too large");

@@ -19,6 +19,8 @@ TUNED = {   # dataset: depth, num_latents, latent_dim, cross_dim_head, latent_di
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--json", default="")
+ap.add_argument("--per-param-grads", action="store_true", help="the reference loop's `p.grad = None` per step (one zero tensor per parameter "
+                "per backward) instead of healnet_amd.train.flatten_parameters (gradients accumulate into one flat buffer)")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 b = args.batch
@@ -46,13 +48,17 @@ for name, kw in list(TUNED.items()) + [("default", dict())]:
     with torch.no_grad():
         t_fwd = timeit(lambda: model(list(ins)))
     model.train()
+    flat = None if args.per_param_grads else hn.train.flatten_parameters(model)
 
     def step():
-        for p in model.parameters():
-            p.grad = None
+        if flat is None:
+            for p in model.parameters():
+                p.grad = None
+        else:
+            flat.zero_grad()
         model(list(ins)).sum().backward()
     t_train = timeit(step, n=15, warm=3)
-    rows.append(dict(config=name, batch=b, forward_ms=round(t_fwd, 3), fwd_bwd_ms=round(t_train, 3),
+    rows.append(dict(config=name, batch=b, grads="per-parameter" if flat is None else "flat buffer", forward_ms=round(t_fwd, 3), fwd_bwd_ms=round(t_train, 3),
                      params=sum(p.numel() for p in model.parameters())))
     print(rows[-1], flush=True)
 if args.json:
