@@ -494,8 +494,9 @@ static int launch_gemm_tn(const float *A, long lda, const float *B, long ldb, fl
   if (g.nsplit > 1) { g.C = scratch; g.ldc = N; if (colsum) g.colsum = scratch + (size_t)g.nsplit * M * N; } else { g.C = C; g.ldc = ldc; }
   const bool aligned = (lda & 3) == 0 && (ldb & 3) == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 && (strideA & 3) == 0 &&
                        (strideB & 3) == 0;
-  static const int lds_min = getenv("HN_TN_LDS_MIN") ? atoi(getenv("HN_TN_LDS_MIN")) : 128;      // development knob
-  if (g.kslice >= 64 && aligned && M >= lds_min && N >= lds_min)
+  // (from 32 x 32 outputs: the LDS-staged kernel masks its ragged tiles; G = dKV^T z of a single 16 .. 103-wide head ran 142 us on
+  // the direct kernel)
+  if (g.kslice >= 64 && aligned && M >= 32 && N >= 32)
     hipLaunchKernelGGL(gemm_tn_lds_kernel, dim3(ceil_div(M, 128), ceil_div(N, 128), g.nsplit * batch), dim3(256), 0, s, g);
   else if (g.kslice <= 512) hipLaunchKernelGGL(gemm_tn_kernel<8>, dim3(ceil_div(M, 128), ceil_div(N, 128), g.nsplit * batch), dim3(256), 0, s, g);
   else hipLaunchKernelGGL(gemm_tn_kernel<4>, dim3(ceil_div(M, 128), ceil_div(N, 128), g.nsplit * batch), dim3(256), 0, s, g);

@@ -868,8 +868,9 @@ int launch_gemm(const GemmArgs &g_in, hipStream_t s) {
     HN_LAUNCH_CHECK("gemm_skinny");
     return HN_OK;
   }
-  static const int big_min_n = getenv("HN_GEMM_BIG_MIN_N") ? atoi(getenv("HN_GEMM_BIG_MIN_N")) : 256;      // development knob
-  if (!glu && g.batch == 1 && g.pro != PRO_LAYERNORM && g.M >= 2048 && g.N >= big_min_n && g.K >= 256) {
+  // (N >= 256, or from 32 columns when the operands are not 16-byte aligned -- one cross head of 16 .. 103 on a 773-channel patch
+  // bag, the reference's tuned configs: the alternative there is the 64 x 64 dword-load kernel at a third of this one's rate)
+  if (!glu && g.batch == 1 && g.pro != PRO_LAYERNORM && g.M >= 2048 && g.K >= 256 && (g.N >= 256 || (g.N >= 32 && !aligned_eligible(g)))) {
     const int ntm = ceil_div(g.M, GM), ntn = ceil_div(g.N, GN);
     const long blocks = (long)ceil_div(ntm, 8) * 8 * ntn;
     HN_REQUIRE(blocks < (1L << 31), HN_E_UNSUPPORTED, "gemm: grid too large");

@@ -134,3 +134,33 @@ def test_unaligned_parameter_views_take_the_unfused_route(hn, grad_mode):
     with torch.set_grad_enabled(grad_mode):
         got = model([t.to(DEV) for t in ins]).detach().cpu()
     assert_close(got, want, rel=1e-3, floor=0.0, abs_floor=1e-5, what="unaligned parameter views")
+
+
+@pytest.mark.parametrize("dh,l_d,l_c", [(16, 119, 25), (63, 126, 17), (27, 62, 17), (103, 65, 16)], ids=["blca", "brca", "kirp", "ucec"])
+def test_tuned_shapes_on_the_large_tile_routes_vs_oracle(hn, dh, l_d, l_c):
+    """The reference's tuned TCGA shapes (config/best_hyperparams.yml: one cross head of 16 / 63 / 27 / 103, odd latent widths,
+    no latent self-attention) on a patch bag large enough (b * N >= 2048 rows) for the routes round 3 opened to them: the
+    128 x 128 gemm_big_kernel for the unaligned K/V projection (N = 2 dh >= 32 columns) and the LDS-staged weight-gradient
+    kernel from 32 x 32 outputs (G = dKV^T z).  Logits on both forwards and every gradient vs the oracle."""
+    kw = dict(n_modalities=2, channel_dims=[2000, 768], num_spatial_axes=[1, 1], out_dims=4, depth=2, l_c=l_c, l_d=l_d, x_heads=1,
+              cross_dim_head=dh, l_heads=8, latent_dim_head=20, self_per_cross_attn=0, num_freq_bands=2, max_freq=2.0)
+    torch.manual_seed(500 + dh)
+    model = hn.HealNet(**kw).train()
+    gen = torch.Generator().manual_seed(600 + dh)
+    ins = [torch.rand(3, 1, 2000, generator=gen), torch.rand(3, 1024, 768, generator=gen)]
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    want = O.fusion_forward(sd, O.FusionConfig(**kw), [t.clone() for t in ins])
+    dl = torch.randn(want.shape, generator=gen)
+    (want * dl).sum().backward()
+    model.to(DEV)
+    dins = [t.to(DEV) for t in ins]
+    with torch.no_grad():
+        inf = model(list(dins)).cpu()
+    assert_close(inf, want.detach(), rel=1e-3, floor=0.0, abs_floor=1e-5, what="tuned shape, inference forward")
+    got = model(list(dins))
+    assert_close(got.detach().cpu(), want.detach(), rel=1e-3, floor=0.0, abs_floor=1e-5, what="tuned shape, taping forward")
+    (got * dl.to(DEV)).sum().backward()
+    scale = max(float(v.grad.abs().max()) for v in sd.values() if v.grad is not None)
+    for k, p in model.named_parameters():
+        ref = sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])
+        assert_close(p.grad.cpu(), ref, rel=2e-3, floor=1e-3, abs_floor=1e-5 * scale, what=f"tuned shape grad[{k}]")

@@ -19,6 +19,7 @@ TUNED = {   # dataset: depth, num_latents, latent_dim, cross_dim_head, latent_di
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--json", default="")
+ap.add_argument("--configs", nargs="*", default=None, help="subset of blca brca kirp ucec default")
 ap.add_argument("--per-param-grads", action="store_true", help="the reference loop's `p.grad = None` per step (one zero tensor per parameter "
                 "per backward) instead of healnet_amd.train.flatten_parameters (gradients accumulate into one flat buffer)")
 args = ap.parse_args()
@@ -40,7 +41,7 @@ def timeit(fn, n=30, warm=5):
 
 
 rows = []
-for name, kw in list(TUNED.items()) + [("default", dict())]:
+for name, kw in [(n, k) for n, k in list(TUNED.items()) + [("default", dict())] if args.configs is None or n in args.configs]:
     torch.manual_seed(0)
     extra = dict(x_heads=1, l_heads=8, self_per_cross_attn=0, num_freq_bands=2, max_freq=2.0) if kw else {}
     model = hn.HealNet(n_modalities=2, channel_dims=[2000, 768], num_spatial_axes=[1, 1], out_dims=4, **kw, **extra).to(dev)
