@@ -1100,7 +1100,8 @@ static void register_transposes(const hn_model *m, const hn_modality_input *in, 
 
 // buffers of the fused latent backward (bchain.hip): what a chain hands to the batched weight-gradient launch and to the
 // attention core backward in front of it
-struct BChainBufs { float *H, *dU, *Xhat, *dYff, *dPre, *dO, *lnpart, *tn; size_t tn_floats; bool ok; };
+struct BChainBufs { float *H, *dU, *Xhat, *dYff, *dPre, *dO, *lnpart, *tn, *xchg; int *xflags; size_t tn_floats; bool ok; };
+constexpr int BCHAIN_XFLAGS = 2 * 256 + 1;
 
 static size_t bchain_tn_scratch_floats(int rows) {
   // upper bound over every product subset a chain can batch (dW1, dW2, dW_out, dW_q, dW_kv at inner = 512): fewer products means
@@ -1172,6 +1173,8 @@ static int fusion_bwd_workspace(const hn_model *m, const hn_modality_input *in, 
     cb.lnpart = ar.take<float>((size_t)(rows / 16) * 4 * 128);
     cb.tn_floats = bchain_tn_scratch_floats(rows);
     cb.tn = ar.take<float>(cb.tn_floats);
+    cb.xchg = ar.take<float>((size_t)2 * 256 * 16 * 128);      // cluster mode: two exchanges x <= 256 workgroups x one partial tile
+    cb.xflags = ar.take<int>(BCHAIN_XFLAGS);
   }
   if (bb) *bb = cb;
   *total = ar.off;
@@ -1839,6 +1842,8 @@ int hn_fusion_backward(const hn_model *m, const hn_modality_input *in, int b, co
   // attention block in front of it; the weight gradients of the chain follow in one batched launch + one reduce.
   const int rows = b * L;
   const bool use_bchain = cb.ok && fp.chain && !bchain_disabled() && !chain_disabled();
+  int bchain_seq = 0;
+  if (use_bchain && (rc = launch_fill((float *)cb.xflags, 0.0f, BCHAIN_XFLAGS, s)) != HN_OK) return rc;      // cluster flags (bchain.hip)
   struct Pending { bool valid; int layer; hn_attn_params ap; const hn_attn_grads *ag; const float *x_in, *dQ, *dKV, *xhat; } pend;
   memset(&pend, 0, sizeof(pend));
   auto is_attn_b = [](const Step &q) { return q.kind == STEP_CROSS_ATTN || q.kind == STEP_SELF_ATTN; };
@@ -1890,6 +1895,7 @@ int hn_fusion_backward(const hn_model *m, const hn_modality_input *in, int b, co
       lp.part = cb.lnpart + (size_t)slot * 128; lp.nwg = rows / 16; lp.width = 128; lp.stride = 4 * 128; lp.out = out;
     };
     ca.rows = rows; ca.L = L; ca.dy = dX; ca.dx_out = dX; ca.lnpart = cb.lnpart;
+    ca.xchg = cb.xchg; ca.xflags = cb.xflags; ca.seq = ++bchain_seq;
     if (pend.valid) {
       const int inner = pend.ap.heads * pend.ap.dim_head;
       ca.has_p = 1; ca.dQ = pend.dQ; ca.lddq = inner; ca.nq = inner;

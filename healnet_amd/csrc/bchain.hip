@@ -22,6 +22,7 @@
 //
 // Shapes: l_d = 128, hidden 512, nq / nkv / inner_o multiples of 128 (nq + nkv <= 1536), rows % 16 == 0.
 #include "common.h"
+#include <stdlib.h>
 
 namespace hn {
 
@@ -77,35 +78,50 @@ __global__ __launch_bounds__(512) void latent_bchain_kernel(const BChainArgs arg
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fg = lane >> 4, fi = lane & 15;
-  const int m0 = blockIdx.x * CR;
+  // Cluster mode (<= 128 row tiles; see chain.hip): C = 4 or 2 workgroups share a row tile.  P: each member contracts ITS quarter
+  // of the dQ | dKV columns (partial dx_hat, exchange 1); FF: its hidden chunks -- a, g, dz, the matching h / dU columns, and the
+  // matching k-tiles of dx_hat = dU W1 (partial, exchange 2); OUT: its share of the dO chunks.  Partials are summed in member
+  // order by every member (identical bits everywhere); member 0 writes what is per row tile.
+  const int a_C = args.cluster > 1 ? args.cluster : 1;
+  const int ntiles = gridDim.x / a_C;
+  const int member = __builtin_amdgcn_readfirstlane((int)blockIdx.x / ntiles), tile = blockIdx.x - member * ntiles;
+  const int my_chunks = 4 / a_C;
+  const int m0 = tile * CR;
   const int row = tid >> 5, l32 = tid & 31;                  // row layout: 32 lanes per row, one 16-byte chunk each
   const long grow = (long)(m0 + row) * CD + 4 * l32;         // this thread's chunk of a (rows, 128) tensor
 
   // ---- the block stream of the chain
   const int ptot = a_has_p ? a_nq + a_nkv : 0;               // contraction length of P, in two segments of <= 1024 columns
-  const int pseg1 = min(ptot, 1024), pseg2 = ptot - pseg1;
+  // (cluster: the member's contiguous share of the columns, one segment)
+  const int pc0 = a_C > 1 ? member * (ptot / a_C) : 0;
+  const int pmine = a_C > 1 ? ptot / a_C : ptot;
+  const int pseg1 = min(pmine, 1024), pseg2 = pmine - pseg1;
   const int nk1 = pseg1 / WK, nk2 = pseg2 / WK;
+  const int my_out = a_has_out ? (a_inner_o / WN - member + a_C - 1) / a_C : 0;      // dO chunks j = member, member + C, ...
   const int eP = nk1 + nk2;
-  const int eF1 = eP + (a_has_ff ? 48 : 0);                  // per hidden chunk: a, g (W1), dz (W2^T), 4 k-blocks each
-  const int eF2 = eF1 + (a_has_ff ? 32 : 0);                 // dxh = dU W1: W1^T (128, 1024)
-  const int nblocks = eF2 + (a_has_out ? a_inner_o / WK : 0);   // dO = dpre W_out: W_out^T (inner_o, 128)
+  const int eF1 = eP + (a_has_ff ? 12 * my_chunks : 0);      // per own hidden chunk: a, g (W1), dz (W2^T), 4 k-blocks each
+  const int eF2 = eF1 + (a_has_ff ? 8 * my_chunks : 0);      // dxh = dU W1: W1^T (128, 1024), the k-tiles of the own chunks
+  const int nblocks = max(1, eF2 + my_out * (CD / WK));      // dO = dpre W_out: W_out^T (inner_o, 128)
   if (tid < BMAXBLK) {
     const int bi = min(tid, nblocks - 1);
     const float *W;
     int ldw;
     if (bi < eP) {
-      const int c0 = bi * WK;
+      const int c0 = pc0 + bi * WK;
       if (c0 < a_nq) { W = args.wqT + c0; ldw = a_nq; } else { W = args.wkvT + (c0 - a_nq); ldw = a_nkv; }
     } else if (bi < eF1) {
-      const int local = bi - eP, hc = local / 12, t = local - hc * 12, which = t >> 2, k = t & 3;
+      const int local = bi - eP, hci = local / 12, hc = member + hci * a_C, t = local - hci * 12, which = t >> 2, k = t & 3;
       ldw = CD;
       if (which == 0) W = args.w1 + (long)(hc * WN) * CD + k * WK;
       else if (which == 1) W = args.w1 + (long)(CHID + hc * WN) * CD + k * WK;
       else W = args.w2T + (long)(hc * WN) * CD + k * WK;
     } else if (bi < eF2) {
-      W = args.w1T + (bi - eF1) * WK; ldw = 2 * CHID;
+      // k-tiles of the own chunks: the da columns of chunk hc (tiles 4 hc .. 4 hc + 3), then its dg columns (16 + 4 hc ..)
+      const int local = bi - eF1, hci = local >> 3, hc = member + hci * a_C, r = local & 7;
+      const int kt = a_C == 1 ? local : (r < 4 ? 4 * hc + r : 16 + 4 * hc + (r - 4));      // one workgroup per tile: all 32 in order
+      W = args.w1T + kt * WK; ldw = 2 * CHID;
     } else {
-      const int local = bi - eF2, j = local >> 2, k = local & 3;
+      const int local = bi - eF2, j = member + (local >> 2) * a_C, k = local & 3;
       W = args.woT + (long)(j * WN) * CD + k * WK; ldw = CD;
     }
     const unsigned long long addr = (unsigned long long)W;
@@ -163,7 +179,7 @@ __global__ __launch_bounds__(512) void latent_bchain_kernel(const BChainArgs arg
         float4 seg1[8];                      // all requests first (<= 8 passes of 128 columns), then the LDS stores
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          const int c = min(128 * i, pseg1 - 128) + 4 * l32;       // passes beyond the segment re-read its last one (not stored)
+          const int c = pc0 + min(128 * i, pseg1 - 128) + 4 * l32; // passes beyond the segment re-read its last one (not stored)
           const gf32 *src = c < a_nq ? a_dQ + (long)(m0 + row) * a_lddq + c : a_dKV + (long)(m0 + row) * a_lddkv + (c - a_nq);
           seg1[i] = gld4(src);
         }
@@ -173,9 +189,9 @@ __global__ __launch_bounds__(512) void latent_bchain_kernel(const BChainArgs arg
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int c = pseg1 + 128 * i + 4 * l32;
+        const int c = pc0 + pseg1 + 128 * i + 4 * l32;
         seg2[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c < ptot) seg2[i] = gld4(a_dKV + (long)(m0 + row) * a_lddkv + (c - a_nq));
+        if (pseg2 > 0 && c < ptot) seg2[i] = gld4(a_dKV + (long)(m0 + row) * a_lddkv + (c - a_nq));
       }
       if (a_p_nw) lst4(lds, B_gp + 4 * l32, gld4(a_p_nw + 4 * l32));    // (16 rows write the same 128 floats)
       if (a_has_ff) xm_pre = gld4(a_f_x + grow);
@@ -254,6 +270,37 @@ __global__ __launch_bounds__(512) void latent_bchain_kernel(const BChainArgs arg
     gst4_nt(C + (long)(m0 + srow) * ldc + col0 + wave * 16 + 4 * c4, lld4(lds, stg + srow * 16 + 4 * c4));
   };
 
+  // cluster exchange `which` (0: P, 1: FF) of this launch: the member's partial 16 x 128 tile (accumulator layout v) goes to its
+  // slot, the members' partials are summed in member order into B_ts.  Relaxed agent-scope atomics at the shared XCD's L2, the
+  // stores acknowledged before the flag (chain.hip explains both).
+  auto exchange_into_ts = [&](const float (&v)[4], int which) {
+    float *slot = args.xchg + (((long)which * ntiles + tile) * a_C) * (CR * CD);
+    int *flags = args.xflags + ((long)which * ntiles + tile) * a_C;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      __hip_atomic_store(slot + (long)member * (CR * CD) + (4 * fg + r) * CD + ncol, v[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(flags + member, args.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < a_C) {
+      int spins = 0;
+      while (__hip_atomic_load(flags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < args.seq) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1 << 22)) { args.xflags[2 * ntiles * a_C] = 1; break; }      // error marker instead of a hang
+      }
+    }
+    __syncthreads();
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c = 0; c < a_C; ++c) {
+      const float *pp = slot + (long)c * (CR * CD) + row * CD + 4 * l32;
+      acc.x += __hip_atomic_load(pp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      acc.y += __hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      acc.z += __hip_atomic_load(pp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      acc.w += __hip_atomic_load(pp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    lst4(lds, B_ts + row * XP + 4 * l32, acc);
+  };
+
   // LayerNorm statistics of the tile in B_xs: normalised rows -> B_xn, rstd -> B_rs; optionally the affine image in the A layout
   // (and to HBM for the weight-gradient product)
   auto ln_stats = [&](bool normalise, bool emit_hat, int gamma, int beta, bool has_beta) {
@@ -275,7 +322,7 @@ __global__ __launch_bounds__(512) void latent_bchain_kernel(const BChainArgs arg
     }
     if (emit_hat) {
       lst4(lds, a_at(B_Ahat, row, l32), v);
-      gst4_nt(a_Xhat + grow, v);
+      if (member == 0) gst4_nt(a_Xhat + grow, v);
     }
   };
   // G <- LayerNorm'(dxh in B_ts; B_xn, B_rs, gamma) + G ; per-workgroup column sums of dxh * xn (dgamma) and dxh (dbeta) -> lnpart
@@ -294,12 +341,12 @@ __global__ __launch_bounds__(512) void latent_bchain_kernel(const BChainArgs arg
       // column sums over the 16 rows: contributions to two scratch tiles (B_ts holds dxh already; B_xs <- dxh * xn)
       lst4(lds, B_xs + row * XP + 4 * l32, make_float4(dv.x * xn.x, dv.y * xn.y, dv.z * xn.z, dv.w * xn.w));
       __syncthreads();
-      if (tid < 256) {
+      if (tid < 256 && member == 0) {
         const int c = tid & 127, src = tid < 128 ? B_xs : B_ts;
         float acc = 0.0f;
 #pragma unroll
         for (int r = 0; r < CR; ++r) acc += lds[src + r * XP + c];
-        gst1(a_lnpart + ((long)blockIdx.x * 4 + slot + (tid >> 7)) * CD + c, acc);
+        gst1(a_lnpart + ((long)tile * 4 + slot + (tid >> 7)) * CD + c, acc);
       }
     } else {
       G.x += dv.x; G.y += dv.y; G.z += dv.z; G.w += dv.w;
@@ -324,8 +371,12 @@ __global__ __launch_bounds__(512) void latent_bchain_kernel(const BChainArgs arg
       for (int kc = 0; kc < nk2; kc += 4) run4(B_Abig, kc, B_Abig, kc + 4 == nk2 ? 0 : kc + 4, c0, c1);
     }
     const float v[4] = {c0.x + c1.x, c0.y + c1.y, c0.z + c1.z, c0.w + c1.w};
+    if (a_C > 1) {
+      exchange_into_ts(v, 0);
+    } else {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) lds[B_ts + (4 * fg + r) * XP + ncol] = v[r];
+      for (int r = 0; r < 4; ++r) lds[B_ts + (4 * fg + r) * XP + ncol] = v[r];
+    }
     __syncthreads();
     ln_bwd(a_p_nw != nullptr, B_gp, 0);
     if (a_has_ff) lst4(lds, B_xs + row * XP + 4 * l32, xm_pre);
@@ -344,7 +395,7 @@ __global__ __launch_bounds__(512) void latent_bchain_kernel(const BChainArgs arg
     {
       const float4 G = lld4(lds, B_gs + row * XP + 4 * l32);
       lst4(lds, a_at(B_Adz, row, l32), G);
-      gst4_nt(a_dYff + grow, G);                              // the gradient that entered the block (dW2 = G^T h, db2)
+      if (member == 0) gst4_nt(a_dYff + grow, G);             // the gradient that entered the block (dW2 = G^T h, db2)
     }
     __syncthreads();
     read_a(fa0, B_Ahat, 0);
@@ -354,7 +405,8 @@ __global__ __launch_bounds__(512) void latent_bchain_kernel(const BChainArgs arg
       const int rr = 4 * fg + r;
       du_at[r] = B_Abig + (ncol >> 5) * ATILE + rr * WK + ((((ncol & 31) >> 2) ^ (rr & 7)) * 4) + (ncol & 3);
     }
-    for (int hc = 0; hc < 4; ++hc) {
+    for (int hci = 0; hci < my_chunks; ++hci) {
+      const int hc = member + hci * a_C;
       f32x4 a0 = zero, a1 = zero, g0 = zero, g1 = zero, z0 = zero, z1 = zero;
       run4(B_Ahat, 0, B_Ahat, 0, a0, a1);
       run4(B_Ahat, 0, B_Adz, 0, g0, g1);
@@ -394,12 +446,12 @@ __global__ __launch_bounds__(512) void latent_bchain_kernel(const BChainArgs arg
     }
     __syncthreads();
     // the dU tile to HBM for dW1 = dU^T xhat / db1 (16 rows x 4 KB, 16-byte pieces: 8 per thread)
+    if (a_C == 1) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int q = l32 + 32 * i;
-      gst4_nt(a_dU + (long)(m0 + row) * (2 * CHID) + 4 * q, lld4(lds, a_at(B_Abig, row, q)));
-    }
-    {
+      for (int i = 0; i < 8; ++i) {
+        const int q = l32 + 32 * i;
+        gst4_nt(a_dU + (long)(m0 + row) * (2 * CHID) + 4 * q, lld4(lds, a_at(B_Abig, row, q)));
+      }
       f32x4 c0 = zero, c1 = zero;
       read_a(fa0, B_Abig, 0);
 #pragma unroll
@@ -407,6 +459,25 @@ __global__ __launch_bounds__(512) void latent_bchain_kernel(const BChainArgs arg
       const float v[4] = {c0.x + c1.x, c0.y + c1.y, c0.z + c1.z, c0.w + c1.w};
 #pragma unroll
       for (int r = 0; r < 4; ++r) lds[B_ts + (4 * fg + r) * XP + ncol] = v[r];
+    } else {
+      // cluster: the own chunks' dU columns to HBM, the own k-tiles of dx_hat = dU W1 (partial), exchange 2
+      for (int hci = 0; hci < my_chunks; ++hci) {
+        const int hc = member + hci * a_C;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int q = half * 128 + hc * 32 + l32;        // 16-byte chunk of the row: da columns, then dg columns of the chunk
+          gst4_nt(a_dU + (long)(m0 + row) * (2 * CHID) + 4 * q, lld4(lds, a_at(B_Abig, row, q)));
+        }
+      }
+      f32x4 c0 = zero, c1 = zero;
+      read_a(fa0, B_Abig, 4 * member);
+      for (int hci = 0; hci < my_chunks; ++hci) {
+        const int hc = member + hci * a_C;
+        run4(B_Abig, 4 * hc, B_Abig, 16 + 4 * hc, c0, c1);
+        run4(B_Abig, 16 + 4 * hc, B_Abig, hci + 1 < my_chunks ? 4 * (hc + a_C) : 0, c0, c1);
+      }
+      const float v[4] = {c0.x + c1.x, c0.y + c1.y, c0.z + c1.z, c0.w + c1.w};
+      exchange_into_ts(v, 1);
     }
     __syncthreads();
     ln_bwd(a_f_nw != nullptr, B_gf, 2);
@@ -415,10 +486,10 @@ __global__ __launch_bounds__(512) void latent_bchain_kernel(const BChainArgs arg
   // ---- G is the gradient w.r.t. the input of the feed-forward block (= the output of the attention block in front of it)
   {
     const float4 G = lld4(lds, B_gs + row * XP + 4 * l32);
-    gst4_nt(a_dx_out + grow, G);
+    if (member == 0) gst4_nt(a_dx_out + grow, G);
     if (a_has_out) {
       const float4 dp = make_float4(G.x * lmask.x, G.y * lmask.y, G.z * lmask.z, G.w * lmask.w);
-      gst4_nt(a_dPre + grow, dp);
+      if (member == 0) gst4_nt(a_dPre + grow, dp);
       lst4(lds, a_at(B_Adz, row, l32), dp);
     }
   }
@@ -427,7 +498,7 @@ __global__ __launch_bounds__(512) void latent_bchain_kernel(const BChainArgs arg
   if (a_has_out) {
     __syncthreads();
     read_a(fa0, B_Adz, 0);
-    for (int j = 0; j < a_inner_o / WN; ++j) {
+    for (int j = member; j < a_inner_o / WN; j += a_C) {
       f32x4 c0 = zero, c1 = zero;
       run4(B_Adz, 0, B_Adz, 0, c0, c1);
       const float v[4] = {c0.x + c1.x, c0.y + c1.y, c0.z + c1.z, c0.w + c1.w};
@@ -471,7 +542,16 @@ int launch_latent_bchain(const BChainArgs &a, hipStream_t s) {
     HN_HIP_CHECK(hipFuncSetAttribute((const void *)latent_bchain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     if (dev >= 0 && dev < 64) configured[dev] = true;
   }
-  hipLaunchKernelGGL(latent_bchain_kernel, dim3(a.rows / CR), dim3(512), lds_bytes, s, a);
+  static const bool no_cluster = getenv("HN_NO_CHAIN_CLUSTER") != nullptr;
+  BChainArgs ac = a;
+  const int tiles = a.rows / CR;
+  ac.cluster = 1;
+  if (!no_cluster && a.xchg && a.xflags && a.seq > 0 && a.has_ff && tiles <= 128 && tiles % 8 == 0 && al16(a.xchg)) {
+    const int C = tiles <= 64 ? 4 : 2;
+    // the member's share of the P contraction must be whole 128-column groups
+    if (!a.has_p || ((a.nq + a.nkv) / C) % WN == 0) ac.cluster = C;
+  }
+  hipLaunchKernelGGL(latent_bchain_kernel, dim3(tiles * ac.cluster), dim3(512), lds_bytes, s, ac);
   HN_LAUNCH_CHECK("latent_bchain");
   return HN_OK;
 }

@@ -278,6 +278,10 @@ struct BChainArgs {
   const float *o_x, *woT;              // the attention block's input (tape), W_out^T (inner_o, 128)
   float *dPre, *dO; int lddo;          // out: (rows, 128), (rows, inner_o)
   float *lnpart;                       // out: (rows / 16, 4, 128) per-workgroup partial [dgamma_p, dbeta_p, dgamma_f, dbeta_f]
+  // cluster mode (<= 128 row tiles): two exchange buffers of (tiles * C) partial tiles, two flag sets + an error marker (zeroed at
+  // the start of the backward), this chain's 1-based sequence number within the backward
+  float *xchg; int *xflags; int seq;
+  int cluster;                         // internal
 };
 bool latent_bchain_supported(int rows, int d, int hidden);
 int launch_latent_bchain(const BChainArgs &a, hipStream_t s);

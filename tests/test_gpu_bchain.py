@@ -135,3 +135,38 @@ def test_fused_backward_equals_the_per_block_launches(name, tmp_path):
         assert float((got - ref).abs().max()) <= 2e-5 * scale + 1e-4 * float(ref.abs().max()), k
         differ += int(not torch.equal(got, ref))
     assert differ > 0, "the fused route produced bit-identical gradients: HN_NO_BCHAIN did not change the route?"
+
+
+@pytest.mark.parametrize("b,l_c", [(8, 128), (16, 128), (4, 32)], ids=["64tiles_c4", "128tiles_c2", "8tiles_c4"])
+def test_cluster_mode_gradients_bitwise_reproducible_and_vs_oracle(b, l_c):
+    """Row-tile counts that run the forward AND backward chains as clusters (4 workgroups per tile up to 64 tiles, 2 up to 128; two
+    exchanges per backward chain): ten repetitions of the step give bitwise identical gradients (ordered exchanges, fixed
+    summation order), and they agree with oracle autograd."""
+    import healnet_amd as hn
+    kw = dict(n_modalities=2, channel_dims=[300, 64], num_spatial_axes=[1, 1], out_dims=4, depth=2, l_c=l_c)
+    torch.manual_seed(401)
+    model = hn.HealNet(**kw).train()
+    gen = torch.Generator().manual_seed(402)
+    ins = [torch.rand(b, 1, 300, generator=gen), torch.rand(b, 40, 64, generator=gen)]
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    want = O.fusion_forward(sd, O.FusionConfig(**kw), [t.clone() for t in ins])
+    dl = torch.randn(want.shape, generator=gen)
+    (want * dl).sum().backward()
+    model.to(DEV)
+    dins = [t.to(DEV) for t in ins]
+    first = None
+    for rep in range(10):
+        model.zero_grad(set_to_none=True)
+        out = model(list(dins))
+        (out * dl.to(DEV)).sum().backward()
+        grads = {k: p.grad.clone() for k, p in model.named_parameters()}
+        if first is None:
+            first = grads
+            assert_close(out.detach().cpu(), want.detach(), rel=1e-3, what="cluster mode forward")
+        else:
+            for k in grads:
+                assert torch.equal(grads[k], first[k]), f"repetition {rep}: gradient of {k} differs"
+    scale = max(float(v.grad.abs().max()) for v in sd.values() if v.grad is not None)
+    for k, g in first.items():
+        ref = sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])
+        assert_close(g.cpu(), ref, rel=2e-3, floor=1e-3, abs_floor=1e-5 * scale, what=f"cluster mode grad[{k}]")
