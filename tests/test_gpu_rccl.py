@@ -205,3 +205,18 @@ def test_bench_more_gpus_than_visible_exits_with_one_clear_line():
                          timeout=300, env=dict(_clean_env(), RANK="0", WORLD_SIZE=str(n), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                                                MASTER_PORT=str(_free_port())))
     assert out.returncode != 0 and "visible" in out.stderr
+
+
+def test_bench_under_the_drivers_launcher_line_on_rccl():
+    """The driver's N > 1 command shape -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` -- with N = 1 and HN_BENCH_FORCE_DIST=1: rendezvous environment from the launcher,
+    nccl process group, barriers inside the timed regions, rank 0 prints ONE JSON line."""
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                          "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1",
+                          "--no-cpu-baseline", "--train-steps", "3"], cwd=ROOT, capture_output=True, text=True, timeout=900,
+                         env=_clean_env(HN_BENCH_FORCE_DIST="1"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["train_step"]["backend"] == "nccl" and j["scaling"] == "weak"
