@@ -548,8 +548,16 @@ int launch_latent_bchain(const BChainArgs &a, hipStream_t s) {
   ac.cluster = 1;
   if (!no_cluster && a.xchg && a.xflags && a.seq > 0 && a.has_ff && tiles <= 128 && tiles % 8 == 0 && al16(a.xchg)) {
     const int C = tiles <= 64 ? 4 : 2;
+    // every member of every tile must be resident at once (the exchanges spin): ONE 135 KB workgroup fits a CU
+    static int cu_count[64] = {};
+    if (dev >= 0 && dev < 64 && cu_count[dev] == 0) {
+      int n = 0;
+      if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 1;
+      cu_count[dev] = n;
+    }
+    const int cus = (dev >= 0 && dev < 64) ? cu_count[dev] : 1;
     // the member's share of the P contraction must be whole 128-column groups
-    if (!a.has_p || ((a.nq + a.nkv) / C) % WN == 0) ac.cluster = C;
+    if (tiles * C <= cus && (!a.has_p || ((a.nq + a.nkv) / C) % WN == 0)) ac.cluster = C;
   }
   hipLaunchKernelGGL(latent_bchain_kernel, dim3(tiles * ac.cluster), dim3(512), lds_bytes, s, ac);
   HN_LAUNCH_CHECK("latent_bchain");

@@ -676,7 +676,17 @@ int launch_latent_chain(const ChainArgs &a, hipStream_t s) {
   ChainArgs ac = a;
   const int tiles = a.rows / CR;
   ac.cluster = 1;
-  if (!no_cluster && a.xchg && a.xflags && a.seq > 0 && a.has_ff && tiles <= max_tiles && tiles % 8 == 0 && al16(a.xchg)) ac.cluster = tiles <= 64 ? 4 : 2;
+  if (!no_cluster && a.xchg && a.xflags && a.seq > 0 && a.has_ff && tiles <= max_tiles && tiles % 8 == 0 && al16(a.xchg)) {
+    // every member of every tile must be resident at once (the exchange spins): two 72 KB workgroups fit a CU
+    static int cu_count[64] = {};
+    if (dev >= 0 && dev < 64 && cu_count[dev] == 0) {
+      int n = 0;
+      if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 1;
+      cu_count[dev] = n;
+    }
+    const int cus = (dev >= 0 && dev < 64) ? cu_count[dev] : 1, C = tiles <= 64 ? 4 : 2;
+    if (tiles * C <= 2 * cus) ac.cluster = C;
+  }
   hipLaunchKernelGGL(latent_chain_kernel, dim3(tiles * ac.cluster), dim3(512), lds_bytes, s, ac);
   HN_LAUNCH_CHECK("latent_chain");
   return HN_OK;

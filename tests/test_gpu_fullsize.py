@@ -85,6 +85,47 @@ def test_cfg2_full_size_gradients_vs_oracle_autograd(hn):
     _grad_parity(hn, kw, ins, seed=42, what="cfg2_b2_224")
 
 
+def test_cfg2_b32_full_size_training_step_vs_oracle_autograd(hn):
+    """The headline batch itself: cfg2 at b = 32 on the full 224x224x3 image -- the split geometry, the 256-workgroup chains
+    (one per row tile, no cluster), the batched weight-gradient launches over 4096 rows that only this size runs.  The oracle's
+    materialised scores are 0.6 GB per sample and layer, so its gradient is accumulated sample by sample (the model couples no
+    two samples: per-token LayerNorm, per-row softmax, per-sample mean)."""
+    kw = dict(n_modalities=2, channel_dims=[2000, 3], num_spatial_axes=[1, 2], out_dims=4)
+    gen = torch.Generator().manual_seed(4132)
+    b = 32
+    ins = [torch.rand(b, 1, 2000, generator=gen), torch.rand(b, 224, 224, 3, generator=gen)]
+    torch.manual_seed(43)
+    model = hn.HealNet(**kw).train()
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    dl = torch.randn(b, 4, generator=gen)
+    logits = []
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(32, threads))                # (a 256-core host runs this small-GEMM mix far slower with every core)
+    try:
+        for i in range(b):
+            out = O.fusion_forward(sd, O.FusionConfig(**kw), [t[i:i + 1] for t in ins])
+            (out * dl[i:i + 1]).sum().backward()           # accumulates into sd[k].grad
+            logits.append(out.detach())
+    finally:
+        torch.set_num_threads(threads)
+    want = torch.cat(logits)
+    model.to(DEV)
+    got = model([t.to(DEV) for t in ins])
+    assert_close(got.detach().cpu(), want, rel=TOL, floor=0.0, abs_floor=1e-5, what="cfg2_b32.fwd_train")
+    (got * dl.to(DEV)).sum().backward()
+    n_out, n = 0, 0
+    for k, p in model.named_parameters():
+        ref = sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])
+        g = p.grad.double().cpu()
+        scale = float(ref.abs().max().clamp_min(1e-30))
+        linf = float((g - ref.double()).abs().max()) / scale
+        l2 = float((g - ref.double()).norm() / ref.double().norm().clamp_min(1e-30))
+        assert linf <= 5e-3 and l2 <= 3e-4, f"cfg2_b32 grad[{k}]: max-norm {linf:.2e}, L2 {l2:.2e}"
+        n_out += int(((g - ref.double()).abs() > 5e-4 * scale).sum())
+        n += p.numel()
+    assert n_out <= max(64, int(1e-4 * n)), f"cfg2_b32: {n_out} of {n} gradient elements beyond 5e-4 of their tensor's scale"
+
+
 def _oracle_logits(model, kw, ins, **kwargs):
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     with torch.no_grad():
