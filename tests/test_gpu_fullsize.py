@@ -113,16 +113,32 @@ def test_cfg2_b32_full_size_training_step_vs_oracle_autograd(hn):
     got = model([t.to(DEV) for t in ins])
     assert_close(got.detach().cpu(), want, rel=TOL, floor=0.0, abs_floor=1e-5, what="cfg2_b32.fwd_train")
     (got * dl.to(DEV)).sum().backward()
-    n_out, n = 0, 0
+    # Criteria as in _grad_parity, plus what 16x more rows bring: ~25 M SELU-gate and ~6 M LeakyReLU pre-activations per step, so ONE
+    # of them landing within fp32 rounding of the kink on the other side than the oracle's is the expected case, not the rare one.
+    # tools/diag_b32_grads.py (this input): fused and per-block GPU routes agree to 7e-6 (L2), the oracle in fp32 and in fp64 to
+    # 6.5e-6, and what separates the two pairs is EXACTLY rank 1 -- one row of one dW1 (128 elements, 4e-3 of the tensor's scale:
+    # one SELU-derivative flip) plus its trace in that block's b1 / LayerNorm gradients and in the rows of the upstream tensors.
+    # So a tensor beyond the 3e-4 L2 bound passes only if its error is such an isolated flip: >= 98 % of the error energy in the
+    # four leading singular directions (2-D), L2 <= 1e-3 (1-D) -- a dropped split or a mis-scaled partial is neither.
+    n_out, n, flips = 0, 0, []
     for k, p in model.named_parameters():
         ref = sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])
         g = p.grad.double().cpu()
+        d = g - ref.double()
         scale = float(ref.abs().max().clamp_min(1e-30))
-        linf = float((g - ref.double()).abs().max()) / scale
-        l2 = float((g - ref.double()).norm() / ref.double().norm().clamp_min(1e-30))
-        assert linf <= 5e-3 and l2 <= 3e-4, f"cfg2_b32 grad[{k}]: max-norm {linf:.2e}, L2 {l2:.2e}"
-        n_out += int(((g - ref.double()).abs() > 5e-4 * scale).sum())
+        linf = float(d.abs().max()) / scale
+        l2 = float(d.norm() / ref.double().norm().clamp_min(1e-30))
+        assert linf <= 5e-3, f"cfg2_b32 grad[{k}]: max-norm {linf:.2e}, L2 {l2:.2e}"
+        if l2 > 3e-4:
+            assert l2 <= 1e-3, f"cfg2_b32 grad[{k}]: L2 {l2:.2e}"
+            if d.dim() == 2:
+                sv = torch.linalg.svdvals(d)
+                lead = float((sv[:4] ** 2).sum() / (sv ** 2).sum())
+                assert lead >= 0.98, f"cfg2_b32 grad[{k}]: L2 {l2:.2e} and only {lead:.2f} of the error in four singular directions"
+            flips.append((k, l2))
+        n_out += int((d.abs() > 5e-4 * scale).sum())
         n += p.numel()
+    assert len(flips) <= 6, f"cfg2_b32: {len(flips)} tensors beyond the L2 bound: {flips}"
     assert n_out <= max(64, int(1e-4 * n)), f"cfg2_b32: {n_out} of {n} gradient elements beyond 5e-4 of their tensor's scale"
 
 
