@@ -35,6 +35,7 @@ class AttnParams(C.Structure):
         ("ctx_gamma", C.c_void_p), ("ctx_beta", C.c_void_p),
         ("w_q", C.c_void_p), ("w_kv", C.c_void_p), ("w_out", C.c_void_p), ("b_out", C.c_void_p),
         ("dropout", C.c_float), ("rng", Rng),
+        ("dim_head_valid", C.c_int), ("query_dim_valid", C.c_int),        # staged layout (0 = off; include/healnet_hip.h)
     ]
 
 
@@ -44,6 +45,7 @@ class FFParams(C.Structure):
         ("norm_w", C.c_void_p), ("norm_b", C.c_void_p),
         ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p),
         ("dropout", C.c_float), ("rng", Rng),
+        ("dim_valid", C.c_int),
     ]
 
 
@@ -72,6 +74,7 @@ class Model(C.Structure):
         ("self_attn", C.POINTER(AttnParams)), ("self_ff", C.POINTER(FFParams)),
         ("head_norm_w", C.c_void_p), ("head_norm_b", C.c_void_p), ("head_w", C.c_void_p), ("head_b", C.c_void_p),
         ("core_precision", C.c_int), ("rng", Rng),
+        ("l_d_valid", C.c_int),
     ]
 
 

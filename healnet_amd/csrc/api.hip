@@ -41,6 +41,17 @@ static inline bool chain_out_aligned(const hn_attn_params *a) { return al16(a->w
 static inline bool chain_proj_aligned(const hn_attn_params *a) { return al16(a->w_q) && al16(a->w_kv) && al16(a->norm_w) && al16(a->norm_b); }
 static inline int pad_head_dim(int dh) { return dh <= 16 ? 16 : dh <= 32 ? 32 : dh <= 64 ? 64 : dh <= 128 ? 128 : 0; }
 static inline int round16(int v) { return (v + 15) / 16 * 16; }
+static inline int up128(int v) { return (v + 127) / 128 * 128; }
+// the latent chains work on 16-row tiles: every (b * l_c, .) buffer they touch is allocated for the row count rounded up to 16
+static inline size_t rows16(size_t rows) { return (rows + 15) / 16 * 16; }
+// Staged layout (include/healnet_hip.h): zero-padded images of a narrower block.  The softmax scale and the LayerNorm statistics
+// come from the valid widths; a staged block's w_out rows have the padded pitch (w_q / w_kv only gain zero rows at the end).
+static inline bool staged_attn(const hn_attn_params *p) { return p->query_dim_valid > 0; }
+static inline int dh_valid(const hn_attn_params *p) { return p->dim_head_valid > 0 ? p->dim_head_valid : p->dim_head; }
+static inline int wo_ld(const hn_attn_params *p) { const int inner = p->heads * p->dim_head; return staged_attn(p) ? up128(inner) : inner; }
+// a LayerNorm over fewer columns than the operand has exists in the chain kernels, ln_fwd and the head only
+static inline bool narrow_ln(const hn_attn_params *p) { return p->query_dim_valid > 0 && p->query_dim_valid < p->query_dim; }
+static inline bool narrow_ln(const hn_ff_params *p) { return p->dim_valid > 0 && p->dim_valid < p->dim; }
 
 // ------------------------------------------------------------------------------------------------
 // attention block
@@ -81,7 +92,9 @@ static int plan_attn(const hn_attn_params *p, bool has_ctx, int ld_ctx, int b, i
   pl->rank_d = has_ctx && (ld_ctx == 16 || ld_ctx == 32) && D <= ld_ctx && ld_ctx <= pl->dhp;
   pl->ones = pl->rank_d && D <= ld_ctx - 1;
   pl->dp = pl->rank_d ? ld_ctx : pl->dhp;
-  pl->cscale = 2.0f * (1.0f / sqrtf((float)p->dim_head)) * 1.44269504088896340736f;  // (1/0.5) * dh^-1/2 * log2(e)
+  HN_REQUIRE(p->dim_head_valid >= 0 && p->dim_head_valid <= p->dim_head && p->query_dim_valid >= 0 && p->query_dim_valid <= p->query_dim,
+             HN_E_SHAPE, "attn: staged widths dim_head_valid=%d query_dim_valid=%d", p->dim_head_valid, p->query_dim_valid);
+  pl->cscale = 2.0f * (1.0f / sqrtf((float)dh_valid(p))) * 1.44269504088896340736f;  // (1/0.5) * dh^-1/2 * log2(e)
   pl->bf16core = bf16core != 0 && pl->ones && pl->N > 1;
   pl->nq = (pl->rank_d && !pl->bf16core && p->dropout == 0.0f) ? attn_core_nq_small_batch(pl->dp, b, p->heads, pl->Lp) : 0;
   attn_core_geometry(b, p->heads, pl->Lp, pl->N, pl->dp, &pl->nsplit, &pl->chunk, 0, pl->nq);
@@ -96,7 +109,7 @@ static int plan_attn(const hn_attn_params *p, bool has_ctx, int ld_ctx, int b, i
   }
 
   Arena ar(ws, ws_bytes);
-  const size_t rows = (size_t)b * L;
+  const size_t rows = rows16((size_t)b * L);
   pl->obuf = ar.take<float>(rows * pl->inner);
   if (pl->rank_d) {
     pl->q = ar.take<float>(rows * pl->inner);
@@ -158,7 +171,7 @@ static GemmArgs gemm_defaults() {
 // (explicit path) the projected keys / values.
 static float *saved_kv(const AttnPlan &pl, bool has_ctx, bool masked, int b, int L, float *saved) {
   if (!saved || !has_ctx || pl.rank_d || (pl.N == 1 && !masked)) return nullptr;
-  return saved + align_up((size_t)b * L * pl.inner, 64);
+  return saved + align_up(rows16((size_t)b * L) * pl.inner, 64);
 }
 
 // kv_tape (explicit cross binding, training): the projected K / V live in the tape instead of the workspace; the forward
@@ -177,6 +190,9 @@ static int attn_prepare(const hn_attn_params *p, const AttnPlan &pl, const float
   gq.W = p->w_q; gq.ldw = p->query_dim;
   gq.M = rows; gq.N = pl.inner; gq.K = p->query_dim;
   if (p->norm_w) { gq.pro = PRO_LAYERNORM; gq.gamma = p->norm_w; gq.beta = p->norm_b; }
+  // (a staged block's projections come from the latent chain, whose LayerNorm knows the valid width; the GEMM prologue does not)
+  HN_REQUIRE(!narrow_ln(p) || (q_done && (ctx != nullptr || kv_ready || (ext && ext->kv && ext->kv_done))), HN_E_UNSUPPORTED,
+             "attn: a staged block (query_dim_valid=%d of %d) takes its projections from the latent chain", p->query_dim_valid, p->query_dim);
   memset(core, 0, sizeof(*core));
   core->b = b; core->h = p->heads; core->Lq = L; core->Lp = pl.Lp; core->N = pl.N; core->dp = pl.dp;
   core->nsplit = pl.nsplit; core->chunk = pl.chunk; core->nq = pl.nq;
@@ -271,7 +287,7 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
     if (o_save) { int rc_ = launch_copy(o_save, vbuf, (long)((size_t)b * pl.inner), s); if (rc_ != HN_OK) return rc_; }
     GemmArgs gy = gemm_defaults();
     gy.A = vbuf; gy.lda = pl.inner; gy.M = b; gy.K = pl.inner;
-    gy.W = p->w_out; gy.ldw = pl.inner; gy.N = p->query_dim;
+    gy.W = p->w_out; gy.ldw = wo_ld(p); gy.N = p->query_dim;
     gy.bias = p->b_out; gy.act = ACT_LEAKY;
     gy.C = ybuf; gy.ldc = p->query_dim;
     if ((rc = launch_gemm(gy, s)) != HN_OK) return rc;
@@ -315,7 +331,7 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
     if (ext && ext->defer_out) { ext->o_out = pl.obuf; ext->ldo_out = pl.inner; return HN_OK; }
     GemmArgs go = gemm_defaults();
     go.A = pl.obuf; go.lda = pl.inner;
-    go.W = p->w_out; go.ldw = pl.inner;
+    go.W = p->w_out; go.ldw = wo_ld(p);
     go.M = b * L; go.N = p->query_dim; go.K = pl.inner;
     go.bias = p->b_out; go.act = ACT_LEAKY;
     if (residual) { go.R = x_in; go.ldr = p->query_dim; }
@@ -358,7 +374,7 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
 
   GemmArgs go = gemm_defaults();
   go.A = pl.obuf; go.lda = pl.inner;
-  go.W = p->w_out; go.ldw = pl.inner;
+  go.W = p->w_out; go.ldw = wo_ld(p);
   go.C = x_out; go.ldc = p->query_dim;
   go.bias = p->b_out;
   go.M = b * L; go.N = p->query_dim; go.K = pl.inner;
@@ -379,7 +395,7 @@ static size_t attn_saved_floats(const AttnPlan &pl, bool has_ctx, bool masked, i
   if (pl.rank_d) return (size_t)b * L * pl.heads * pl.dp;
   // explicit binding: O, and for a cross block also the projected K / V (288 GB of HBM: keeping 134 MB per WSI-bag block
   // at cfg4 is cheaper than re-running its 52 GF projection in the backward)
-  return align_up((size_t)b * L * pl.inner, 64) + (has_ctx ? (size_t)b * pl.N * 2 * pl.heads * pl.dhp : 0);
+  return align_up(rows16((size_t)b * L) * pl.inner, 64) + (has_ctx ? (size_t)b * pl.N * 2 * pl.heads * pl.dhp : 0);
 }
 
 struct AttnBwdPlan {
@@ -390,7 +406,7 @@ struct AttnBwdPlan {
 static int plan_attn_bwd(const hn_attn_params *p, const AttnPlan &pl, bool has_ctx, bool masked, int b, int L, void *ws,
                          size_t ws_bytes, AttnBwdPlan *bp) {
   Arena ar(ws, ws_bytes);
-  const size_t rows = (size_t)b * L, qd = p->query_dim, inner = pl.inner, h = p->heads;
+  const size_t rows = rows16((size_t)b * L), qd = p->query_dim, inner = pl.inner, h = p->heads;
   memset(bp, 0, sizeof(*bp));
   bp->fwd_bytes = pl.bytes;
   bp->fwd_ws = ar.take<char>(pl.bytes);
@@ -475,7 +491,7 @@ static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float
   if ((rc = plan_attn(p, has_ctx, ld_ctx, b, L, N, D, bp.fwd_ws, bp.fwd_bytes, &pl)) != HN_OK) return rc;
 
   const int rows = b * L, qd = p->query_dim, inner = pl.inner, h = p->heads, dh = pl.dh;
-  const float two_scale = 2.0f / sqrtf((float)dh);
+  const float two_scale = 2.0f / sqrtf((float)dh_valid(p));
   // dpre = dy * LeakyReLU'(pre); the sign of pre is the sign of y = x_out - x_in
   const float *dpre = bp.dpre;
   if (ext && ext->dpre) dpre = ext->dpre;
@@ -486,11 +502,11 @@ static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float
     if ((rc = launch_segsum(bp.dpre, L, qd, b, bp.dyb, s)) != HN_OK) return rc;
     if (g->b_out && (rc = launch_colsum(bp.dyb, qd, b, qd, 1.0f, g->b_out, 1, s, bp.red)) != HN_OK) return rc;
     if (g->w_out) {   // dWo += dyb^T V
-      GemmExArgs e = gex(bp.dyb, 1, qd, saved, 1, inner, g->w_out, inner, qd, inner, b, 1);
+      GemmExArgs e = gex(bp.dyb, 1, qd, saved, 1, inner, g->w_out, wo_ld(p), qd, inner, b, 1);
       if ((rc = launch_gemm_ex(e, s, bp.red)) != HN_OK) return rc;
     }
     {   // dV = dyb Wo
-      GemmExArgs e = gex(bp.dyb, qd, 1, p->w_out, 1, inner, bp.dV, inner, b, inner, qd, 0);
+      GemmExArgs e = gex(bp.dyb, qd, 1, p->w_out, 1, wo_ld(p), bp.dV, inner, b, inner, qd, 0);
       if ((rc = launch_gemm_ex(e, s, bp.red)) != HN_OK) return rc;
     }
     {   // G = dV^T z, cs = colsum(dV)  -> gradients of the V half of to_kv and of the context LayerNorm affine
@@ -522,14 +538,14 @@ static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float
   if (ext && ext->skip_wout) {
     // dW_out / db_out: the caller's batched weight-gradient launch
   } else if (g->w_out) {      // dWo += dpre^T O, and db_out += colsum(dpre) from the same pass over dpre
-    GemmExArgs e = gex(dpre, 1, qd, O, 1, inner, g->w_out, inner, qd, inner, rows, 1);
+    GemmExArgs e = gex(dpre, 1, qd, O, 1, inner, g->w_out, wo_ld(p), qd, inner, rows, 1);
     e.colsum = g->b_out; e.colsum_accumulate = 1;
     if ((rc = launch_gemm_ex(e, s, bp.red)) != HN_OK) return rc;
   } else if (g->b_out && (rc = launch_colsum(dpre, qd, rows, qd, 1.0f, g->b_out, 1, s, bp.red)) != HN_OK) return rc;
   const float *dO = bp.dO;
   if (ext && ext->dO) dO = ext->dO;
   else {
-    GemmExArgs e = gex(dpre, qd, 1, p->w_out, 1, inner, bp.dO, inner, rows, inner, qd, 0);
+    GemmExArgs e = gex(dpre, qd, 1, p->w_out, 1, wo_ld(p), bp.dO, inner, rows, inner, qd, 0);
     if ((rc = launch_gemm_ex(e, s, bp.red)) != HN_OK) return rc;
   }
 
@@ -547,7 +563,7 @@ static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float
                          (ext && ext->q_taped) ? &pe : nullptr)) != HN_OK) return rc;
   const float *xhat = x_in;
   if (p->norm_w) {
-    if ((rc = launch_ln_fwd(x_in, p->norm_w, p->norm_b, rows, qd, bp.xhat, s)) != HN_OK) return rc;
+    if ((rc = launch_ln_fwd(x_in, p->norm_w, p->norm_b, rows, qd, bp.xhat, s, p->query_dim_valid)) != HN_OK) return rc;
     xhat = bp.xhat;
   }
   AttnBwdArgs ba;
@@ -656,6 +672,7 @@ static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float
     return HN_OK;
   }
   // ---- query projection: dWq += dQ^T x_hat ; dx_hat = dQ Wq (+ dKV Wkv for self-attention)
+  HN_REQUIRE(!narrow_ln(p), HN_E_UNSUPPORTED, "attn_bwd: a staged block's projection backward runs in the latent chain");
   if (g->w_q) {
     GemmExArgs e = gex(bp.dQ, 1, inner, xhat, 1, qd, g->w_q, qd, inner, qd, rows, 1);
     if ((rc = launch_gemm_ex(e, s, bp.red)) != HN_OK) return rc;
@@ -694,6 +711,7 @@ static int ff_fwd_impl(const hn_ff_params *p, const float *x_in, float *x_out, i
   const int hid = 4 * p->dim;
   HN_REQUIRE(p->dropout >= 0.0f && p->dropout < 1.0f, HN_E_SHAPE, "ff: dropout=%g", (double)p->dropout);
   const bool dropping = training && p->dropout > 0.0f;
+  HN_REQUIRE(!narrow_ln(p), HN_E_UNSUPPORTED, "ff: a staged block (dim_valid=%d of %d) runs in the latent chain", p->dim_valid, p->dim);
   int rc = check_ws(ws, ws_bytes, ff_ws_bytes(p, rows), "ff");
   if (rc != HN_OK) return rc;
   float *hidden = (float *)ws;
@@ -747,6 +765,7 @@ static int ff_bwd_impl(const hn_ff_params *p, const float *x_in, const float *dy
   HN_REQUIRE(p && x_in && dy && dx && g, HN_E_NULL, "ff_bwd: NULL pointer");
   HN_REQUIRE(p->w1 && p->b1 && p->w2 && p->b2, HN_E_NULL, "ff_bwd: weight pointer is NULL");
   HN_REQUIRE(p->dim > 0 && rows > 0, HN_E_SHAPE, "ff_bwd: dim=%d rows=%d", p->dim, rows);
+  HN_REQUIRE(!narrow_ln(p), HN_E_UNSUPPORTED, "ff_bwd: a staged block (dim_valid=%d of %d) runs in the latent chain", p->dim_valid, p->dim);
   FFBwdPlan pl;
   plan_ff_bwd(p, rows, nullptr, 0, &pl);
   int rc = check_ws(ws, ws_bytes, pl.bytes, "ff_bwd");
@@ -845,7 +864,7 @@ static int plan_fusion(const hn_model *m, const hn_modality_input *in, int b, vo
   HN_REQUIRE(m->self_per_cross_attn == 0 || m->self_per_cross_attn == 1, HN_E_UNSUPPORTED,
              "fusion: self_per_cross_attn=%d (the reference only runs 0 or 1, healnet.py:242)", m->self_per_cross_attn);
   Arena ar(ws, ws_bytes);
-  fp->x = ar.take<float>((size_t)b * m->l_c * m->l_d);
+  fp->x = ar.take<float>(rows16((size_t)b * m->l_c) * m->l_d);
   size_t op_max = 0;
   fp->dominant = -1;
   long best = -1;
@@ -969,11 +988,13 @@ static int plan_fusion(const hn_model *m, const hn_modality_input *in, int b, vo
     // per-block launches faster below ~160 workgroups.  Measured at cfg2 (l_c = 128) since, chain vs per-block launches, ms per
     // forward: b = 1 0.851 / 0.848, 2: 0.820 / 0.822, 4: 0.908 / 0.915, 8: 1.193 / 1.212, 16: 1.740 / 1.830, 24: 2.435 / 2.605,
     // 32: 2.911 / 3.205 -- no crossover left, the chain is the route whenever its shapes apply (HN_NO_CHAIN=1: development switch).
-    fp->chain = latent_chain_supported(b * m->l_c, m->l_d, 4 * m->l_d) && m->l_c % 16 == 0;      // both forwards (the training one keeps x_mid)
+    // both forwards (the training one keeps x_mid).  Host-owned trace / output buffers hold exactly b * l_c rows, so a row count
+    // that is not a multiple of 16 needs the staged route (internal, row-padded buffers).
+    fp->chain = m->l_d == 128 && (m->l_c % 16 == 0 || m->l_d_valid > 0);
     fp->cq = fp->ckv = nullptr;
     if (fp->chain) {
-      fp->cq = ar.take<float>((size_t)b * m->l_c * max_inner);
-      fp->ckv = ar.take<float>((size_t)b * m->l_c * 2 * (max_inner_self > 0 ? max_inner_self : 1));
+      fp->cq = ar.take<float>(rows16((size_t)b * m->l_c) * max_inner);
+      fp->ckv = ar.take<float>(rows16((size_t)b * m->l_c) * 2 * (max_inner_self > 0 ? max_inner_self : 1));
     }
   }
   fp->op_ws_bytes = op_max;
@@ -1025,7 +1046,7 @@ constexpr size_t kNoSlot = (size_t)-1;
 static int plan_tape(const hn_model *m, const hn_modality_input *in, int b, int masked, int skip_self, const FusionPlan &fp, TapePlan *tp) {
   tp->nsteps = build_schedule(m, in, skip_self, tp->steps, kMaxSteps);
   HN_REQUIRE(tp->nsteps >= 0, HN_E_UNSUPPORTED, "fusion: more than %d blocks", kMaxSteps);
-  const size_t xn = (size_t)b * m->l_c * m->l_d;
+  const size_t xn = rows16((size_t)b * m->l_c) * m->l_d;
   size_t off = 0;
   for (int k = 0; k <= tp->nsteps; ++k) { tp->x_off[k] = off; off += align_up(xn, 64); }
   for (int k = 0; k < tp->nsteps; ++k) {
@@ -1045,7 +1066,7 @@ static int plan_tape(const hn_model *m, const hn_modality_input *in, int b, int 
       // recompute launch in front of every attention core backward (not for the one-token shortcut, which has no q / k)
       const bool one_token = cross && pl.N == 1 && !masked && !(ap->dropout > 0.0f);
       if (!one_token) {
-        const size_t rows = (size_t)b * m->l_c;
+        const size_t rows = rows16((size_t)b * m->l_c);
         tp->q_off[k] = off; off += align_up(rows * (pl.rank_d ? pl.inner : pl.heads * pl.dhp), 64);
         if (!cross) { tp->kv_off[k] = off; off += align_up(rows * 2 * pl.heads * pl.dhp, 64); }
       }
@@ -1064,9 +1085,11 @@ static void register_transposes(const hn_model *m, const hn_modality_input *in, 
   if ((long)b * m->l_c < 256 && !latent_bchain_supported(b * m->l_c, m->l_d, 4 * m->l_d)) return;
   auto add_attn = [&](const hn_attn_params &ap, bool self) {
     const int inner = ap.heads * ap.dim_head, qd = ap.query_dim;
-    transpose_cache_add(ap.w_out, inner, qd, inner);      // dO = dpre W_out
-    transpose_cache_add(ap.w_q, qd, inner, qd);           // dx_hat = dQ W_q
-    if (self) transpose_cache_add(ap.w_kv, qd, 2 * inner, qd);   // ... + dKV W_kv
+    // (staged blocks: the padded allocation -- w_out rows of pitch wo_ld, w_q / w_kv with zero rows up to a multiple of 128)
+    const bool st = staged_attn(&ap);
+    transpose_cache_add(ap.w_out, wo_ld(&ap), qd, wo_ld(&ap));      // dO = dpre W_out
+    transpose_cache_add(ap.w_q, qd, st ? up128(inner) : inner, qd);           // dx_hat = dQ W_q
+    if (self) transpose_cache_add(ap.w_kv, qd, st ? up128(2 * inner) : 2 * inner, qd);   // ... + dKV W_kv
   };
   auto add_ff = [&](const hn_ff_params &fp) {
     transpose_cache_add(fp.w2, 4 * fp.dim, fp.dim, 4 * fp.dim);   // dh = dy W2
@@ -1124,7 +1147,7 @@ static int fusion_bwd_workspace(const hn_model *m, const hn_modality_input *in, 
     fp->z[i] = nullptr;
     if (in[i].data) fp->z[i] = ar.take<float>((size_t)b * fp->N[i] * fp->ldz[i]);
   }
-  *dX = ar.take<float>((size_t)b * m->l_c * m->l_d);
+  *dX = ar.take<float>(rows16((size_t)b * m->l_c) * m->l_d);
   *head_scratch = ar.take<float>(head_bwd_scratch_floats(b, m->l_d, m->out_dims > 0 ? m->out_dims : 1));
   size_t need = 0;
   for (int layer = 0; layer < m->depth; ++layer) {
@@ -1161,16 +1184,16 @@ static int fusion_bwd_workspace(const hn_model *m, const hn_modality_input *in, 
   if (tfloats) *tfloats = tf;
   BChainBufs cb;
   memset(&cb, 0, sizeof(cb));
-  const int rows = b * m->l_c;
-  cb.ok = latent_bchain_supported(rows, m->l_d, 4 * m->l_d);
+  const size_t rows = rows16((size_t)b * m->l_c);
+  cb.ok = latent_bchain_supported(b * m->l_c, m->l_d, 4 * m->l_d);
   if (cb.ok) {
-    cb.H = ar.take<float>((size_t)rows * 512);
-    cb.dU = ar.take<float>((size_t)rows * 1024);
-    cb.Xhat = ar.take<float>((size_t)rows * 128);
-    cb.dYff = ar.take<float>((size_t)rows * 128);
-    cb.dPre = ar.take<float>((size_t)rows * 128);
-    cb.dO = ar.take<float>((size_t)rows * 512);
-    cb.lnpart = ar.take<float>((size_t)(rows / 16) * 4 * 128);
+    cb.H = ar.take<float>(rows * 512);
+    cb.dU = ar.take<float>(rows * 1024);
+    cb.Xhat = ar.take<float>(rows * 128);
+    cb.dYff = ar.take<float>(rows * 128);
+    cb.dPre = ar.take<float>(rows * 128);
+    cb.dO = ar.take<float>(rows * 512);
+    cb.lnpart = ar.take<float>((rows / 16) * 4 * 128);
     cb.tn_floats = bchain_tn_scratch_floats(rows);
     cb.tn = ar.take<float>(cb.tn_floats);
     cb.xchg = ar.take<float>((size_t)2 * 256 * 16 * 128);      // cluster mode: two exchanges x <= 256 workgroups x one partial tile
@@ -1358,13 +1381,13 @@ int hn_l1_adam_step(float *params, const float *grads, float *exp_avg, float *ex
                         (float *)workspace, (hipStream_t)stream);
 }
 
-size_t hn_fusion_workspace_bytes(const hn_model *model, const hn_modality_input *inputs, int b) {
+static size_t impl_fusion_workspace_bytes(const hn_model *model, const hn_modality_input *inputs, int b) {
   FusionPlan fp;
   if (plan_fusion(model, inputs, b, nullptr, 0, &fp, true) != HN_OK) return 0;
   return fp.bytes;
 }
 
-int hn_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, const uint8_t *mask, int skip_self_on_missing,
+static int impl_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, const uint8_t *mask, int skip_self_on_missing,
                       int return_embeddings, float *out, float **attn_stats, float **x_trace, void *workspace,
                       size_t workspace_bytes, void *stream, hn_profile *prof) {
   hipStream_t s = (hipStream_t)stream;
@@ -1485,10 +1508,56 @@ int hn_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, con
   auto is_tab = [&](const Step &st) { return st.kind == STEP_CROSS_ATTN && tab_ready[st.m]; };
 
   bool q_done = false, kv_done = false;      // projections of the attention block at `k` already produced by the chain in front of it
+  const bool staged = m->l_d_valid > 0;      // staged model: every LayerNorm of the latent side runs inside a chain (valid width)
+  // projections of the attention block at step kn (if it is one that needs them) as the last stages of chain `ca`
+  auto add_next_proj = [&](ChainArgs &ca, int kn) -> int {
+    q_done = kv_done = false;
+    if (!(kn < nsteps && is_attn(steps[kn]) && !is_tab(steps[kn]))) return HN_OK;
+    const Step &sn = steps[kn];
+    const bool self = sn.kind == STEP_SELF_ATTN;
+    const hn_attn_params *an = self ? &m->self_attn[sn.layer] : &m->cross_attn[sn.layer * M + sn.m];
+    AttnPlan pn;
+    int rc2 = plan_attn(an, !self, self ? 0 : fp.ldz[sn.m], b, L, self ? L : fp.N[sn.m], self ? d : fp.D[sn.m], nullptr, 0, &pn);
+    if (rc2 != HN_OK) return rc2;
+    const bool one_token = !self && fp.N[sn.m] == 1 && mask == nullptr;
+    if (!one_token && pn.dh == pn.dhp && (pn.inner % 128 == 0 || staged_attn(an)) && pn.inner % 16 == 0 && pn.inner <= 512 &&
+        an->query_dim == d && an->w_q && an->w_kv && chain_proj_aligned(an)) {
+      ca.p_nw = an->norm_w; ca.p_nb = an->norm_b;
+      ca.nq = up128(pn.inner); ca.q_cols = pn.inner; ca.wq = an->w_q; ca.Q = fp.cq; ca.ldq = pn.inner;
+      ca.alpha_q = pn.rank_d ? 1.0f : pn.cscale;       // the rank-D binding scales in its query fold
+      q_done = true;
+      if (self) { ca.nkv = up128(2 * pn.inner); ca.kv_cols = 2 * pn.inner; ca.wkv = an->w_kv; ca.KV = fp.ckv; ca.ldkv = 2 * pn.inner; kv_done = true; }
+    }
+    return HN_OK;
+  };
+  auto launch_chain = [&](ChainArgs &ca) -> int {
+    ca.rows = b * L; ca.L = L; ca.dv = m->l_d_valid;
+    ca.xchg = fp.xchg; ca.xflags = fp.flags + m->depth * M; ca.seq = ++chain_seq;
+    return launch_latent_chain(ca, s);
+  };
+  if (staged && use_chain && nsteps > 0 && is_attn(steps[0]) && !is_tab(steps[0])) {      // the first block's projections: a chain of their own
+    ChainArgs ca;
+    memset(&ca, 0, sizeof(ca));
+    ca.x_in = cur;
+    if ((rc = add_next_proj(ca, 0)) != HN_OK) return rc;
+    if (q_done && (rc = launch_chain(ca)) != HN_OK) return rc;
+  }
   for (int k = 0; k < nsteps;) {
     const Step &st = steps[k];
     if (!is_attn(st)) {                      // a feed-forward block not absorbed by a chain
       float *dst = input_buffer(k + 1);
+      if (staged && use_chain && chain_ff_aligned(ff_of(st)) && al16(cur) && al16(dst)) {      // ... is a chain without a head
+        const hn_ff_params *fpar = ff_of(st);
+        ChainArgs ca;
+        memset(&ca, 0, sizeof(ca));
+        ca.x_in = cur; ca.x_out = dst; ca.head = 0;
+        ca.has_ff = 1; ca.gate = fpar->gate; ca.f_nw = fpar->norm_w; ca.f_nb = fpar->norm_b;
+        ca.w1 = fpar->w1; ca.b1 = fpar->b1; ca.w2 = fpar->w2; ca.b2 = fpar->b2;
+        if ((rc = add_next_proj(ca, k + 1)) != HN_OK) return rc;
+        if ((rc = launch_chain(ca)) != HN_OK) return rc;
+        cur = dst; ++k;
+        continue;
+      }
       if ((rc = ff_fwd_impl(ff_of(st), cur, dst, 1, b * L, fp.op_ws, fp.op_ws_bytes, s)) != HN_OK) return rc;
       cur = dst; ++k;
       continue;
@@ -1498,10 +1567,11 @@ int hn_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, con
     // The chain behind this block: its out-projection (or the one-token broadcast add), the feed-forward block that follows
     // (healnet.py:237 / :245) and the projections of the attention block after that.
     const bool ff_next = k + 1 < nsteps && !is_attn(steps[k + 1]);
-    bool fuse = use_chain && ff_next && ff_of(steps[k + 1])->dim == d && ff_of(steps[k + 1])->dropout == 0.0f &&
+    // (a model configured with dropout runs the same chain: nothing is dropped on this entry point)
+    bool fuse = use_chain && ff_next && ff_of(steps[k + 1])->dim == d &&
                 chain_ff_aligned(ff_of(steps[k + 1])) && al16(cur) && al16(input_buffer(k + 2));
-    if (fuse && !is_tab(st)) fuse = ap->query_dim == d && inner % 128 == 0 && inner <= 512 && chain_out_aligned(ap) &&
-                                    !(st.kind == STEP_CROSS_ATTN && fp.N[st.m] == 1 && mask == nullptr);
+    if (fuse && !is_tab(st)) fuse = ap->query_dim == d && (inner % 128 == 0 || staged_attn(ap)) && inner % 16 == 0 && inner <= 512 &&
+                                    chain_out_aligned(ap) && !(st.kind == STEP_CROSS_ATTN && fp.N[st.m] == 1 && mask == nullptr);
     if (!fuse) {
       float *dst = input_buffer(k + 1);
       if (is_tab(st)) rc = launch_add_row_broadcast(fp.taby[st.m] + (size_t)st.layer * b * ap->query_dim, cur, dst, b, L, ap->query_dim, s);
@@ -1515,14 +1585,14 @@ int hn_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, con
     }
     ChainArgs ca;
     memset(&ca, 0, sizeof(ca));
-    ca.rows = b * L; ca.L = L; ca.x_in = cur;
+    ca.x_in = cur;
     if (is_tab(st)) {
       ca.head = 2; ca.y = fp.taby[st.m] + (size_t)st.layer * b * ap->query_dim;
     } else {
       AttnExt ext = {fp.cq, fp.ckv, q_done, kv_done, true, nullptr, 0, false, false, nullptr, nullptr, nullptr, 0, 0, 0};
-      ext.allow_defer_merge = st.kind == STEP_CROSS_ATTN && vmerge[st.m];
+      ext.allow_defer_merge = st.kind == STEP_CROSS_ATTN && vmerge[st.m] && inner % 128 == 0;
       if ((rc = run_attn(st, cur, nullptr, &ext)) != HN_OK) return rc;
-      ca.inner_o = inner; ca.w_out = ap->w_out; ca.b_out = ap->b_out;
+      ca.inner_o = up128(inner); ca.o_cols = inner; ca.w_out = ap->w_out; ca.b_out = ap->b_out;
       if (ext.merge_deferred) {              // the chain merges the core's split partials and applies the value projection itself
         ca.head = 3; ca.Opart = ext.opart; ca.Mpart = ext.mpart; ca.Lpart = ext.lpart;
         ca.nsplit = ext.nsplit; ca.Lp = ext.Lp; ca.dp = ext.dp; ca.heads = ap->heads; ca.dh = ap->dim_head;
@@ -1537,34 +1607,18 @@ int hn_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, con
     ca.has_ff = 1; ca.gate = fpar->gate; ca.f_nw = fpar->norm_w; ca.f_nb = fpar->norm_b;
     ca.w1 = fpar->w1; ca.b1 = fpar->b1; ca.w2 = fpar->w2; ca.b2 = fpar->b2;
     // projections of the attention block after the feed-forward block
-    q_done = kv_done = false;
-    if (k + 2 < nsteps && is_attn(steps[k + 2]) && !is_tab(steps[k + 2])) {
-      const Step &sn = steps[k + 2];
-      const bool self = sn.kind == STEP_SELF_ATTN;
-      const hn_attn_params *an = self ? &m->self_attn[sn.layer] : &m->cross_attn[sn.layer * M + sn.m];
-      AttnPlan pn;
-      if ((rc = plan_attn(an, !self, self ? 0 : fp.ldz[sn.m], b, L, self ? L : fp.N[sn.m], self ? d : fp.D[sn.m], nullptr, 0, &pn)) != HN_OK) return rc;
-      const bool one_token = !self && fp.N[sn.m] == 1 && mask == nullptr;
-      if (!one_token && pn.dh == pn.dhp && pn.inner % 128 == 0 && an->query_dim == d && an->w_q && an->w_kv && chain_proj_aligned(an)) {
-        ca.p_nw = an->norm_w; ca.p_nb = an->norm_b;
-        ca.nq = pn.inner; ca.wq = an->w_q; ca.Q = fp.cq; ca.ldq = pn.inner;
-        ca.alpha_q = pn.rank_d ? 1.0f : pn.cscale;       // the rank-D binding scales in its query fold
-        q_done = true;
-        if (self) { ca.nkv = 2 * pn.inner; ca.wkv = an->w_kv; ca.KV = fp.ckv; ca.ldkv = 2 * pn.inner; kv_done = true; }
-      }
-    }
+    if ((rc = add_next_proj(ca, k + 2)) != HN_OK) return rc;
     float *dst = input_buffer(k + 2);
     ca.x_out = dst;
-    ca.xchg = fp.xchg; ca.xflags = fp.flags + m->depth * M; ca.seq = ++chain_seq;
-    if ((rc = launch_latent_chain(ca, s)) != HN_OK) return rc;
+    if ((rc = launch_chain(ca)) != HN_OK) return rc;
     cur = dst; k += 2;
   }
-  if (head) return launch_head(cur, b, L, d, m->head_norm_w, m->head_norm_b, m->head_w, m->head_b, m->out_dims, out, s);
+  if (head) return launch_head(cur, b, L, d, m->head_norm_w, m->head_norm_b, m->head_w, m->head_b, m->out_dims, out, s, m->l_d_valid);
   { int rc_ = launch_copy(out, cur, (long)((xbytes) / sizeof(float)), s); if (rc_ != HN_OK) return rc_; }
   return HN_OK;
 }
 
-size_t hn_fusion_tape_bytes(const hn_model *m, const hn_modality_input *in, int b, int masked, int skip_self_on_missing) {
+static size_t impl_fusion_tape_bytes(const hn_model *m, const hn_modality_input *in, int b, int masked, int skip_self_on_missing) {
   FusionPlan fp;
   if (plan_fusion(m, in, b, nullptr, 0, &fp) != HN_OK) return 0;
   static thread_local TapePlan tp;
@@ -1594,7 +1648,7 @@ static void train_context_layout(const hn_model *m, const FusionPlan &fp, bool *
 
 extern "C" {
 
-int hn_fusion_tape_layout(const hn_model *m, const hn_modality_input *in, int b, int masked, int skip_self_on_missing,
+static int impl_fusion_tape_layout(const hn_model *m, const hn_modality_input *in, int b, int masked, int skip_self_on_missing,
                           size_t *stats_off, size_t *x_off) {
   HN_REQUIRE(stats_off && x_off, HN_E_NULL, "fusion_tape_layout: NULL output");
   FusionPlan fp;
@@ -1614,7 +1668,7 @@ int hn_fusion_tape_layout(const hn_model *m, const hn_modality_input *in, int b,
   return HN_OK;
 }
 
-int hn_fusion_forward_train(const hn_model *m, const hn_modality_input *in, int b, const uint8_t *mask, int skip_self_on_missing,
+static int impl_fusion_forward_train(const hn_model *m, const hn_modality_input *in, int b, const uint8_t *mask, int skip_self_on_missing,
                             int return_embeddings, float *out, float **attn_stats, float **x_trace, void *tape,
                             size_t tape_bytes, void *workspace, size_t workspace_bytes, void *stream) {
   hipStream_t s = (hipStream_t)stream;
@@ -1663,25 +1717,80 @@ int hn_fusion_forward_train(const hn_model *m, const hn_modality_input *in, int 
     if (tp.kv_off[k] != kNoSlot) { e->kv = e->kv_home = T + tp.kv_off[k]; any = true; }
     return any;
   };
+  const bool staged = m->l_d_valid > 0;          // staged model: every LayerNorm of the latent side runs inside a chain (valid width)
+  // projections of the attention block at step kn (if it is one that needs them) as the last stages of chain `ca`, straight into
+  // that block's tape slots
+  auto add_next_proj = [&](ChainArgs &ca, int kn) -> int {
+    q_done = kv_done = false;
+    if (!(kn < tp.nsteps && is_attn_t(tp.steps[kn]))) return HN_OK;
+    const Step &sn = tp.steps[kn];
+    const bool nself = sn.kind == STEP_SELF_ATTN;
+    const hn_attn_params *an = nself ? &m->self_attn[sn.layer] : &m->cross_attn[sn.layer * M + sn.m];
+    AttnPlan pn;
+    int rc2 = plan_attn(an, !nself, nself ? 0 : fp.ldz[sn.m], b, L, nself ? L : fp.N[sn.m], nself ? d : fp.D[sn.m], nullptr, 0, &pn);
+    if (rc2 != HN_OK) return rc2;
+    const bool one_token = !nself && fp.N[sn.m] == 1 && mask == nullptr && !(an->dropout > 0.0f);
+    if (!one_token && pn.dh == pn.dhp && (pn.inner % 128 == 0 || staged_attn(an)) && pn.inner % 16 == 0 && pn.inner <= 512 &&
+        an->query_dim == d && an->w_q && an->w_kv && chain_proj_aligned(an)) {
+      ca.p_nw = an->norm_w; ca.p_nb = an->norm_b;
+      ca.nq = up128(pn.inner); ca.q_cols = pn.inner; ca.wq = an->w_q; ca.ldq = pn.inner;
+      ca.Q = tp.q_off[kn] != kNoSlot ? T + tp.q_off[kn] : fp.cq;      // straight into the next block's tape slot
+      ca.alpha_q = pn.rank_d ? 1.0f : pn.cscale;
+      q_done = true;
+      if (nself) {
+        ca.nkv = up128(2 * pn.inner); ca.kv_cols = 2 * pn.inner; ca.wkv = an->w_kv; ca.ldkv = 2 * pn.inner; kv_done = true;
+        ca.KV = tp.kv_off[kn] != kNoSlot ? T + tp.kv_off[kn] : fp.ckv;
+      }
+    }
+    return HN_OK;
+  };
+  auto launch_chain = [&](ChainArgs &ca) -> int {
+    ca.rows = b * L; ca.L = L; ca.dv = m->l_d_valid;
+    ca.xchg = fp.xchg; ca.xflags = fp.flags + m->depth * M; ca.seq = ++chain_seq;
+    return launch_latent_chain(ca, s);
+  };
+  if (staged && use_chain && tp.nsteps > 0 && is_attn_t(tp.steps[0])) {      // the first block's projections: a chain of their own
+    ChainArgs ca;
+    memset(&ca, 0, sizeof(ca));
+    ca.x_in = T + tp.x_off[0];
+    if ((rc = add_next_proj(ca, 0)) != HN_OK) return rc;
+    if (q_done && (rc = launch_chain(ca)) != HN_OK) return rc;
+  }
   for (int k = 0; k < tp.nsteps;) {
     const Step &st = tp.steps[k];
     const float *xin = T + tp.x_off[k];
     float *xout = T + tp.x_off[k + 1];
     // dropout: one generator state per forward (hn_model.rng), one stream id per executed block (its step index)
     const hn_rng rng = {m->rng.seed, m->rng.offset, (uint32_t)k};
+    if (staged && use_chain && !is_attn_t(st)) {       // a feed-forward block not absorbed by the chain of an attention block: a chain without a head
+      const hn_ff_params &fq = st.kind == STEP_CROSS_FF ? m->cross_ff[st.layer * M + st.m] : m->self_ff[st.layer];
+      if (chain_ff_aligned(&fq) && al16(xin) && al16(xout) && fq.w1 && fq.b1 && fq.w2 && fq.b2) {
+        ChainArgs ca;
+        memset(&ca, 0, sizeof(ca));
+        ca.x_in = xin; ca.x_out = xout; ca.head = 0;
+        ca.has_ff = 1; ca.gate = fq.gate; ca.f_nw = fq.norm_w; ca.f_nb = fq.norm_b;
+        ca.w1 = fq.w1; ca.b1 = fq.b1; ca.w2 = fq.w2; ca.b2 = fq.b2;
+        ca.ff_drop = drop_of(fq.dropout, rng, true);
+        if ((rc = add_next_proj(ca, k + 1)) != HN_OK) return rc;
+        if ((rc = launch_chain(ca)) != HN_OK) return rc;
+        ++k;
+        continue;
+      }
+    }
     // The latent chain behind an attention block, as in hn_fusion_forward (out-projection + residual, the feed-forward block,
     // the projections of the attention block after it), with the feed-forward block's input kept on the tape (x_mid): the
-    // backward recomputes everything else of these blocks from the tape as before.  Not with feed-forward dropout, not behind
-    // the one-token shortcut.
+    // backward recomputes everything else of these blocks from the tape as before.  The feed-forward block's dropout is applied
+    // inside the chain (same generator, same stream id as the per-block route).  Not behind the one-token shortcut.
     bool fuse = false;
     if (use_chain && is_attn_t(st) && k + 1 < tp.nsteps && !is_attn_t(tp.steps[k + 1])) {
       const Step &sf = tp.steps[k + 1];
       const hn_ff_params &fq = sf.kind == STEP_CROSS_FF ? m->cross_ff[sf.layer * M + sf.m] : m->self_ff[sf.layer];
       const hn_attn_params &aq = st.kind == STEP_SELF_ATTN ? m->self_attn[st.layer] : m->cross_attn[st.layer * M + st.m];
       const int inner = aq.heads * aq.dim_head;
-      fuse = fq.dim == d && fq.dropout == 0.0f && aq.query_dim == d && inner % 128 == 0 && inner <= 512 &&
+      fuse = fq.dim == d && fq.dropout >= 0.0f && fq.dropout < 1.0f && aq.query_dim == d && (inner % 128 == 0 || staged_attn(&aq)) &&
+             inner % 16 == 0 && inner <= 512 &&
              chain_ff_aligned(&fq) && chain_out_aligned(&aq) && al16(xin) && al16(xout) && al16(T + tp.x_off[k + 2]) &&
-             !(st.kind == STEP_CROSS_ATTN && fp.N[st.m] == 1 && mask == nullptr);
+             !(st.kind == STEP_CROSS_ATTN && fp.N[st.m] == 1 && mask == nullptr && !(aq.dropout > 0.0f));
     }
     if (fuse) {
       const bool self = st.kind == STEP_SELF_ATTN;
@@ -1703,34 +1812,19 @@ int hn_fusion_forward_train(const hn_model *m, const hn_modality_input *in, int 
       HN_REQUIRE(fq.w1 && fq.b1 && fq.w2 && fq.b2, HN_E_NULL, "ff: weight pointer is NULL");
       ChainArgs ca;
       memset(&ca, 0, sizeof(ca));
-      ca.rows = b * L; ca.L = L; ca.x_in = xin;
-      ca.head = 1; ca.O = ext.o_out; ca.ldo = ext.ldo_out; ca.inner_o = ap.heads * ap.dim_head; ca.w_out = ap.w_out; ca.b_out = ap.b_out;
+      ca.x_in = xin;
+      ca.head = 1; ca.O = ext.o_out; ca.ldo = ext.ldo_out; ca.inner_o = up128(ap.heads * ap.dim_head); ca.o_cols = ap.heads * ap.dim_head;
+      ca.w_out = ap.w_out; ca.b_out = ap.b_out;
       ca.has_ff = 1; ca.gate = fq.gate; ca.f_nw = fq.norm_w; ca.f_nb = fq.norm_b;
       ca.w1 = fq.w1; ca.b1 = fq.b1; ca.w2 = fq.w2; ca.b2 = fq.b2;
+      {
+        const hn_rng rng_ff = {m->rng.seed, m->rng.offset, (uint32_t)(k + 1)};     // the feed-forward block's stream id: its step index
+        ca.ff_drop = drop_of(fq.dropout, rng_ff, true);
+      }
       ca.x_mid = xout;
       ca.x_out = T + tp.x_off[k + 2];
-      q_done = kv_done = false;
-      if (k + 2 < tp.nsteps && is_attn_t(tp.steps[k + 2])) {
-        const Step &sn = tp.steps[k + 2];
-        const bool nself = sn.kind == STEP_SELF_ATTN;
-        const hn_attn_params *an = nself ? &m->self_attn[sn.layer] : &m->cross_attn[sn.layer * M + sn.m];
-        AttnPlan pn;
-        if ((rc = plan_attn(an, !nself, nself ? 0 : fp.ldz[sn.m], b, L, nself ? L : fp.N[sn.m], nself ? d : fp.D[sn.m], nullptr, 0, &pn)) != HN_OK) return rc;
-        const bool one_token = !nself && fp.N[sn.m] == 1 && mask == nullptr && !(an->dropout > 0.0f);
-        if (!one_token && pn.dh == pn.dhp && pn.inner % 128 == 0 && an->query_dim == d && an->w_q && an->w_kv && chain_proj_aligned(an)) {
-          ca.p_nw = an->norm_w; ca.p_nb = an->norm_b;
-          ca.nq = pn.inner; ca.wq = an->w_q; ca.ldq = pn.inner;
-          ca.Q = tp.q_off[k + 2] != kNoSlot ? T + tp.q_off[k + 2] : fp.cq;      // straight into the next block's tape slot
-          ca.alpha_q = pn.rank_d ? 1.0f : pn.cscale;
-          q_done = true;
-          if (nself) {
-            ca.nkv = 2 * pn.inner; ca.wkv = an->w_kv; ca.ldkv = 2 * pn.inner; kv_done = true;
-            ca.KV = tp.kv_off[k + 2] != kNoSlot ? T + tp.kv_off[k + 2] : fp.ckv;
-          }
-        }
-      }
-      ca.xchg = fp.xchg; ca.xflags = fp.flags + m->depth * M; ca.seq = ++chain_seq;
-      if ((rc = launch_latent_chain(ca, s)) != HN_OK) return rc;
+      if ((rc = add_next_proj(ca, k + 2)) != HN_OK) return rc;
+      if ((rc = launch_chain(ca)) != HN_OK) return rc;
       if ((rc = trace_copies(k)) != HN_OK) return rc;
       k += 2;
       continue;
@@ -1770,12 +1864,12 @@ int hn_fusion_forward_train(const hn_model *m, const hn_modality_input *in, int 
   }
   const float *xf = T + tp.x_off[tp.nsteps];
   if (m->final_classifier_head && !return_embeddings)
-    return launch_head(xf, b, L, d, m->head_norm_w, m->head_norm_b, m->head_w, m->head_b, m->out_dims, out, s);
+    return launch_head(xf, b, L, d, m->head_norm_w, m->head_norm_b, m->head_w, m->head_b, m->out_dims, out, s, m->l_d_valid);
   { int rc_ = launch_copy(out, xf, (long)((size_t)b * L * d), s); if (rc_ != HN_OK) return rc_; }
   return HN_OK;
 }
 
-size_t hn_fusion_backward_workspace_bytes(const hn_model *m, const hn_modality_input *in, int b, int masked) {
+static size_t impl_fusion_backward_workspace_bytes(const hn_model *m, const hn_modality_input *in, int b, int masked) {
   FusionPlan fp;
   float *dX, *hs;
   void *op;
@@ -1784,7 +1878,7 @@ size_t hn_fusion_backward_workspace_bytes(const hn_model *m, const hn_modality_i
   return total;
 }
 
-int hn_fusion_backward(const hn_model *m, const hn_modality_input *in, int b, const uint8_t *mask, int skip_self_on_missing,
+static int impl_fusion_backward(const hn_model *m, const hn_modality_input *in, int b, const uint8_t *mask, int skip_self_on_missing,
                        int return_embeddings, const float *dout, const void *tape, const hn_model_grads *g, void *workspace,
                        size_t workspace_bytes, void *stream, const hn_grad_ready *ready) {
   hipStream_t s = (hipStream_t)stream;
@@ -1821,7 +1915,7 @@ int hn_fusion_backward(const hn_model *m, const hn_modality_input *in, int b, co
   const float *xf = T + tp.x_off[tp.nsteps];
   if (m->final_classifier_head && !return_embeddings) {
     if ((rc = launch_head_bwd(xf, b, L, d, m->head_norm_w, m->head_norm_b, m->head_w, m->out_dims, dout, dX, g->head_norm_w,
-                              g->head_norm_b, g->head_w, g->head_b, hs, s)) != HN_OK) return rc;
+                              g->head_norm_b, g->head_w, g->head_b, hs, s, m->l_d_valid)) != HN_OK) return rc;
   } else {
     { int rc_ = launch_copy(dX, dout, (long)(xn), s); if (rc_ != HN_OK) return rc_; }
   }
@@ -1863,12 +1957,14 @@ int hn_fusion_backward(const hn_model *m, const hn_modality_input *in, int b, co
   // an attention block whose row-local backward (out-projection in front of the core, projections behind it) can ride on chains
   auto attn_chainable = [&](const Step &q, const hn_attn_params &ap) {
     const int inner = ap.heads * ap.dim_head;
-    return use_bchain && is_attn_b(q) && !one_token(q, ap) && ap.dropout == 0.0f && ap.query_dim == d && inner % 128 == 0 && inner <= 512 &&
-           ap.w_q && ap.w_kv && ap.w_out && transpose_cache_lookup(ap.w_out, inner, d, inner) && transpose_cache_lookup(ap.w_q, d, inner, d) &&
-           (q.kind != STEP_SELF_ATTN || transpose_cache_lookup(ap.w_kv, d, 2 * inner, d)) && al16(ap.norm_w);
+    const bool sg = staged_attn(&ap);
+    return use_bchain && is_attn_b(q) && !one_token(q, ap) && ap.query_dim == d && (inner % 128 == 0 || sg) && inner % 16 == 0 && inner <= 512 &&
+           ap.w_q && ap.w_kv && ap.w_out && transpose_cache_lookup(ap.w_out, wo_ld(&ap), d, wo_ld(&ap)) &&
+           transpose_cache_lookup(ap.w_q, d, sg ? up128(inner) : inner, d) &&
+           (q.kind != STEP_SELF_ATTN || transpose_cache_lookup(ap.w_kv, d, sg ? up128(2 * inner) : 2 * inner, d)) && al16(ap.norm_w);
   };
   auto ff_chainable = [&](const hn_ff_params &f, const float *x) {
-    return use_bchain && f.dim == d && f.dropout == 0.0f && f.w1 && f.b1 && f.w2 && f.b2 && al16(f.w1) && al16(f.b1) && al16(f.norm_w) &&
+    return use_bchain && f.dim == d && f.dropout >= 0.0f && f.dropout < 1.0f && f.w1 && f.b1 && f.w2 && f.b2 && al16(f.w1) && al16(f.b1) && al16(f.norm_w) &&
            al16(f.norm_b) && (f.norm_w != nullptr || f.norm_b == nullptr) && al16(x) && transpose_cache_lookup(f.w2, 4 * d, d, 4 * d) &&
            transpose_cache_lookup(f.w1, d, 8 * d, d);
   };
@@ -1892,15 +1988,19 @@ int hn_fusion_backward(const hn_model *m, const hn_modality_input *in, int b, co
     auto add_ln = [&](int slot, float *out) {
       if (!out) return;
       LnPartial &lp = mm.ln[mm.n_ln++];
-      lp.part = cb.lnpart + (size_t)slot * 128; lp.nwg = rows / 16; lp.width = 128; lp.stride = 4 * 128; lp.out = out;
+      lp.part = cb.lnpart + (size_t)slot * 128; lp.nwg = (rows + 15) / 16; lp.width = 128; lp.stride = 4 * 128; lp.out = out;
     };
-    ca.rows = rows; ca.L = L; ca.dy = dX; ca.dx_out = dX; ca.lnpart = cb.lnpart;
+    ca.rows = rows; ca.L = L; ca.dy = dX; ca.dx_out = dX; ca.lnpart = cb.lnpart; ca.dv = m->l_d_valid;
     ca.xchg = cb.xchg; ca.xflags = cb.xflags; ca.seq = ++bchain_seq;
     if (pend.valid) {
       const int inner = pend.ap.heads * pend.ap.dim_head;
-      ca.has_p = 1; ca.dQ = pend.dQ; ca.lddq = inner; ca.nq = inner;
-      ca.wqT = transpose_cache_lookup(pend.ap.w_q, d, inner, d);
-      if (pend.dKV) { ca.dKV = pend.dKV; ca.lddkv = 2 * inner; ca.nkv = 2 * inner; ca.wkvT = transpose_cache_lookup(pend.ap.w_kv, d, 2 * inner, d); }
+      const bool sg = staged_attn(&pend.ap);
+      ca.has_p = 1; ca.dQ = pend.dQ; ca.lddq = inner; ca.nq = up128(inner); ca.q_cols = inner;
+      ca.wqT = transpose_cache_lookup(pend.ap.w_q, d, sg ? up128(inner) : inner, d);
+      if (pend.dKV) {
+        ca.dKV = pend.dKV; ca.lddkv = 2 * inner; ca.nkv = up128(2 * inner); ca.kv_cols = 2 * inner;
+        ca.wkvT = transpose_cache_lookup(pend.ap.w_kv, d, sg ? up128(2 * inner) : 2 * inner, d);
+      }
       ca.p_x = pend.x_in; ca.p_nw = pend.ap.norm_w;
       add_product(pend.dQ, inner, inner, pend.xhat, d, d, pend.ag->w_q, d, nullptr);
       if (pend.dKV) add_product(pend.dKV, 2 * inner, 2 * inner, pend.xhat, d, d, pend.ag->w_kv, d, nullptr);
@@ -1914,6 +2014,10 @@ int hn_fusion_backward(const hn_model *m, const hn_modality_input *in, int b, co
       ca.f_nw = f.norm_w; ca.f_nb = f.norm_b; ca.w1 = f.w1; ca.b1 = f.b1;
       ca.w2T = transpose_cache_lookup(f.w2, 4 * d, d, 4 * d); ca.w1T = transpose_cache_lookup(f.w1, d, 8 * d, d);
       ca.H = cb.H; ca.dU = cb.dU; ca.Xhat = cb.Xhat; ca.dYff = cb.dYff;
+      {
+        const hn_rng rng_ff = {m->rng.seed, m->rng.offset, (uint32_t)ff_k};      // the forward's generator state and stream id
+        ca.ff_drop = drop_of(f.dropout, rng_ff, true);
+      }
       add_product(cb.dU, 8 * d, 8 * d, cb.Xhat, d, d, fg->w1, d, fg->b1);
       add_product(cb.dYff, d, d, cb.H, 4 * d, 4 * d, fg->w2, 4 * d, fg->b2);
       if (f.norm_w) { add_ln(2, fg->norm_w); add_ln(3, fg->norm_b); }
@@ -1921,10 +2025,10 @@ int hn_fusion_backward(const hn_model *m, const hn_modality_input *in, int b, co
         const Step &sa = tp.steps[ff_k - 1];
         const hn_attn_params oa = attn_of(sa);
         const int inner = oa.heads * oa.dim_head;
-        ca.has_out = 1; ca.inner_o = inner; ca.o_x = T + tp.x_off[ff_k - 1];
-        ca.woT = transpose_cache_lookup(oa.w_out, inner, d, inner);
+        ca.has_out = 1; ca.inner_o = up128(inner); ca.o_cols = inner; ca.o_x = T + tp.x_off[ff_k - 1];
+        ca.woT = transpose_cache_lookup(oa.w_out, wo_ld(&oa), d, wo_ld(&oa));
         ca.dPre = cb.dPre; ca.dO = cb.dO; ca.lddo = inner;
-        if (o_saved && *o_saved) add_product(cb.dPre, d, d, *o_saved, inner, inner, attn_grads_of(sa)->w_out, inner, attn_grads_of(sa)->b_out);
+        if (o_saved && *o_saved) add_product(cb.dPre, d, d, *o_saved, inner, inner, attn_grads_of(sa)->w_out, wo_ld(&oa), attn_grads_of(sa)->b_out);
       }
     }
     if ((rc2 = (rc2 != HN_OK ? rc2 : launch_latent_bchain(ca, s))) != HN_OK) return rc2;
@@ -2114,6 +2218,421 @@ int hn_latent_block_bwd(const hn_attn_params *attn, const hn_ff_params *ff, cons
   if ((rc = ff_bwd_impl(ff, x_mid, dy, dmid, 1, b * L, ff_grads, op, workspace_bytes - dmid_bytes, (hipStream_t)stream)) != HN_OK) return rc;
   return attn_bwd_impl(attn, x_in, x_mid, 1, nullptr, 0, b, L, L, attn->query_dim, nullptr, stats, saved, dmid, dx, attn_grads, op,
                        workspace_bytes - dmid_bytes, (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// Staged models (SURVEY.md 8 "next": the reference's tuned shapes, config/best_hyperparams.yml: l_d = 119 / 126 / 62 / 65, ONE
+// cross head of 16 / 63 / 27 / 103, 25 / 17 / 17 / 16 latents, dropout on).  The latent chains (chain.hip / bchain.hip) are built
+// for l_d = 128, head widths of 16 / 32 / 64 / 128 and 16-row tiles.  A model outside those shapes that FITS them after zero
+// padding is run as its padded image: once per forward one table-driven launch (stage_kernel) copies every latent-side weight
+// into a zero-padded shadow (l_d -> 128, dim_head -> 16 / 32 / 64 / 128 per head, projection rows -> a multiple of 128), the
+// shadow model -- hn_model with the staged-layout fields set: LayerNorm statistics over the valid width, softmax scale of the
+// valid head width -- runs the fast path on row-padded internal buffers, and the results are un-padded on the way out
+// (embeddings, trace slots; in the backward the padded gradients are accumulated onto the real ones by the same kernel).
+// Exact: every pad entry is zero and stays zero (zero weight rows / columns, gamma = beta = 0 beyond the valid width), the
+// gradients of pad entries are never read.  A training forward keeps the staged weights on the tape for its backward.
+// HN_NO_STAGING=1: development switch (the generic per-block route these shapes took before).
+// ------------------------------------------------------------------------------------------------
+#include <vector>
+#include <unordered_map>
+
+namespace hn {
+namespace {
+
+static bool staging_disabled() { static const bool off = getenv("HN_NO_STAGING") != nullptr; return off; }
+
+struct Stager {
+  hn_model sm;                                   // the shadow descriptor
+  std::vector<hn_attn_params> ca, sa;
+  std::vector<hn_ff_params> cf, sf;
+  hn_model_grads sg;                             // shadow gradients (same layout as the shadow weights)
+  std::vector<hn_attn_grads> gca, gsa;
+  std::vector<hn_ff_grads> gcf, gsf;
+  std::vector<StagePiece> fwd, bwd;              // real weight -> shadow ; shadow gradient -> real gradient (accumulated)
+  std::unordered_map<const float *, size_t> seen;  // tied weights share one shadow (and one shadow gradient)
+  size_t floats;                                 // shadow region, in floats
+  float *wbase, *gbase;
+  int ld;                                        // the real latent width
+
+  size_t take(size_t n) { const size_t o = floats; floats += align_up(n, 64); return o; }
+  // one matrix: real (rows_r, cols_r) of pitch ld_r at `real` -> shadow rectangle (rows_s, cols_s) of pitch ld_s at slot offset
+  // `at` of a shadow slot starting at `slot`; the gradient travels the other way.  greal == NULL: no gradient wanted.
+  void piece(size_t slot, size_t at, const float *real, float *greal, int rows_r, int cols_r, int ld_r, int rows_s, int cols_s, int ld_s,
+             bool want_grads) {
+    if (wbase) fwd.push_back({real, wbase + slot + at, rows_r, cols_r, ld_r, rows_s, cols_s, ld_s});
+    if (want_grads && greal && gbase) bwd.push_back({gbase + slot + at, greal, rows_r, cols_r, ld_s, rows_r, cols_r, ld_r});
+  }
+  // a whole parameter in `n` pieces; returns the shadow pointer (NULL for a NULL parameter) and the shadow gradient pointer
+  struct Slot { size_t off; bool fresh; };
+  Slot slot_for(const float *real, size_t n) {
+    const size_t off = take(n);                  // the layout never depends on pointer values (size queries see fake ones)
+    auto it = seen.find(real);
+    if (it != seen.end()) return {it->second, false};
+    seen[real] = off;
+    return {off, true};
+  }
+  const float *wptr(const float *real, size_t off) const { return real ? (wbase ? wbase : (float *)256) + off : nullptr; }
+  float *gptr(const float *greal, size_t off) const { return (greal && gbase) ? gbase + off : nullptr; }
+  // a vector of the latent width (LayerNorm affine, biases, ...): (1, n_r) -> (1, n_s)
+  void vec(const float *real, float *greal, int n_r, int n_s, const float **w_out, float **g_out, bool grads) {
+    if (!real) { *w_out = nullptr; if (g_out) *g_out = nullptr; take(n_s); return; }
+    const Slot sl = slot_for(real, n_s);
+    if (sl.fresh) piece(sl.off, 0, real, greal, 1, n_r, n_r, 1, n_s, n_s, grads);
+    *w_out = wptr(real, sl.off);
+    if (g_out) *g_out = gptr(greal, sl.off);
+  }
+
+  void attn(const hn_attn_params &p, const hn_attn_grads *g, bool cross, int D, hn_attn_params *q, hn_attn_grads *qg, bool grads) {
+    *q = p;
+    const int H = p.heads, dh = p.dim_head, dhp = pad_head_dim(dh), inner_r = H * dh, inner_s = H * dhp, ip = up128(inner_s);
+    q->dim_head = dhp; q->dim_head_valid = dh; q->query_dim = 128; q->query_dim_valid = ld;
+    hn_attn_grads zero;
+    memset(&zero, 0, sizeof(zero));
+    const hn_attn_grads &gr = g ? *g : zero;
+    if (qg) *qg = gr;                            // (the context-side entries stay the real ones)
+    vec(p.norm_w, gr.norm_w, ld, 128, &q->norm_w, qg ? &qg->norm_w : nullptr, grads);
+    vec(p.norm_b, gr.norm_b, ld, 128, &q->norm_b, qg ? &qg->norm_b : nullptr, grads);
+    vec(p.b_out, gr.b_out, ld, 128, &q->b_out, qg ? &qg->b_out : nullptr, grads);
+    {   // w_q (H dh, l_d) -> (ip, 128): head h at rows h dhp; the last head's rectangle runs to row ip
+      const Slot sl = slot_for(p.w_q, (size_t)ip * 128);
+      if (p.w_q && sl.fresh)
+        for (int h = 0; h < H; ++h)
+          piece(sl.off, (size_t)h * dhp * 128, p.w_q + (size_t)h * dh * ld, gr.w_q ? gr.w_q + (size_t)h * dh * ld : nullptr, dh, ld, ld,
+                h == H - 1 ? dhp + ip - inner_s : dhp, 128, 128, grads);
+      q->w_q = wptr(p.w_q, sl.off);
+      if (qg) qg->w_q = gptr(gr.w_q, sl.off);
+    }
+    {   // w_out (l_d, H dh) -> (128, ip): head h at columns h dhp; the last head's rectangle runs to column ip
+      const Slot sl = slot_for(p.w_out, (size_t)128 * ip);
+      if (p.w_out && sl.fresh)
+        for (int h = 0; h < H; ++h)
+          piece(sl.off, (size_t)h * dhp, p.w_out + (size_t)h * dh, gr.w_out ? gr.w_out + (size_t)h * dh : nullptr, ld, dh, inner_r, 128,
+                h == H - 1 ? dhp + ip - inner_s : dhp, ip, grads);
+      q->w_out = wptr(p.w_out, sl.off);
+      if (qg) qg->w_out = gptr(gr.w_out, sl.off);
+    }
+    if (cross) {   // to_kv reads the CONTEXT (D columns, unchanged): only the head rows move, and only when the head width is padded
+      if (dh == dhp) { take((size_t)2 * inner_s * D); return; }
+      const Slot sl = slot_for(p.w_kv, (size_t)2 * inner_s * D);
+      if (p.w_kv && sl.fresh)
+        for (int j = 0; j < 2 * H; ++j)
+          piece(sl.off, (size_t)j * dhp * D, p.w_kv + (size_t)j * dh * D, gr.w_kv ? gr.w_kv + (size_t)j * dh * D : nullptr, dh, D, D, dhp, D, D, grads);
+      q->w_kv = wptr(p.w_kv, sl.off);
+      if (qg) qg->w_kv = gptr(gr.w_kv, sl.off);
+    } else {       // latent self-attention: (2 H dh, l_d) -> (2 H dhp rounded up to 128, 128)
+      const int kvp = up128(2 * inner_s);
+      const Slot sl = slot_for(p.w_kv, (size_t)kvp * 128);
+      if (p.w_kv && sl.fresh)
+        for (int j = 0; j < 2 * H; ++j)
+          piece(sl.off, (size_t)j * dhp * 128, p.w_kv + (size_t)j * dh * ld, gr.w_kv ? gr.w_kv + (size_t)j * dh * ld : nullptr, dh, ld, ld,
+                j == 2 * H - 1 ? dhp + kvp - 2 * inner_s : dhp, 128, 128, grads);
+      q->w_kv = wptr(p.w_kv, sl.off);
+      if (qg) qg->w_kv = gptr(gr.w_kv, sl.off);
+    }
+  }
+
+  void ff(const hn_ff_params &p, const hn_ff_grads *g, hn_ff_params *q, hn_ff_grads *qg, bool grads) {
+    *q = p;
+    q->dim = 128; q->dim_valid = ld;
+    hn_ff_grads zero;
+    memset(&zero, 0, sizeof(zero));
+    const hn_ff_grads &gr = g ? *g : zero;
+    if (qg) *qg = gr;
+    const int hid = 4 * ld;
+    vec(p.norm_w, gr.norm_w, ld, 128, &q->norm_w, qg ? &qg->norm_w : nullptr, grads);
+    vec(p.norm_b, gr.norm_b, ld, 128, &q->norm_b, qg ? &qg->norm_b : nullptr, grads);
+    vec(p.b2, gr.b2, ld, 128, &q->b2, qg ? &qg->b2 : nullptr, grads);
+    {   // net.0.weight (8 l_d, l_d) -> (1024, 128): value rows at 0, gate rows at 512
+      const Slot sl = slot_for(p.w1, (size_t)1024 * 128);
+      if (p.w1 && sl.fresh) {
+        piece(sl.off, 0, p.w1, gr.w1, hid, ld, ld, 512, 128, 128, grads);
+        piece(sl.off, (size_t)512 * 128, p.w1 + (size_t)hid * ld, gr.w1 ? gr.w1 + (size_t)hid * ld : nullptr, hid, ld, ld, 512, 128, 128, grads);
+      }
+      q->w1 = wptr(p.w1, sl.off);
+      if (qg) qg->w1 = gptr(gr.w1, sl.off);
+    }
+    {   // net.0.bias (8 l_d) -> (1024)
+      const Slot sl = slot_for(p.b1, 1024);
+      if (p.b1 && sl.fresh) {
+        piece(sl.off, 0, p.b1, gr.b1, 1, hid, hid, 1, 512, 512, grads);
+        piece(sl.off, 512, p.b1 + hid, gr.b1 ? gr.b1 + hid : nullptr, 1, hid, hid, 1, 512, 512, grads);
+      }
+      q->b1 = wptr(p.b1, sl.off);
+      if (qg) qg->b1 = gptr(gr.b1, sl.off);
+    }
+    {   // net.2.weight (l_d, 4 l_d) -> (128, 512)
+      const Slot sl = slot_for(p.w2, (size_t)128 * 512);
+      if (p.w2 && sl.fresh) piece(sl.off, 0, p.w2, gr.w2, ld, hid, hid, 128, 512, 512, grads);
+      q->w2 = wptr(p.w2, sl.off);
+      if (qg) qg->w2 = gptr(gr.w2, sl.off);
+    }
+  }
+
+  // wb / gb: where the shadow weights / shadow gradients live (NULL: layout only -- a size query); g: the caller's gradients
+  void build(const hn_model *m, const hn_model_grads *g, float *wb, float *gb) {
+    const int M = m->n_modalities, depth = m->depth;
+    const bool grads = g != nullptr;
+    ld = m->l_d; floats = 0; wbase = wb; gbase = gb;
+    fwd.clear(); bwd.clear(); seen.clear();
+    ca.assign((size_t)depth * M, hn_attn_params()); cf.assign((size_t)depth * M, hn_ff_params());
+    sa.assign((size_t)depth, hn_attn_params()); sf.assign((size_t)depth, hn_ff_params());
+    gca.assign((size_t)depth * M, hn_attn_grads()); gcf.assign((size_t)depth * M, hn_ff_grads());
+    gsa.assign((size_t)depth, hn_attn_grads()); gsf.assign((size_t)depth, hn_ff_grads());
+    sm = *m;
+    sm.l_d = 128; sm.l_d_valid = ld;
+    memset(&sg, 0, sizeof(sg));
+    for (int k = 0; k < depth * M; ++k) {
+      const int i = k % M;
+      const int D = m->channel_dims[i] + (m->fourier_encode_data ? m->num_spatial_axes[i] * (2 * m->num_freq_bands + 1) : 0);
+      attn(m->cross_attn[k], (g && g->cross_attn) ? &g->cross_attn[k] : nullptr, true, D, &ca[k], &gca[k], grads);
+      ff(m->cross_ff[k], (g && g->cross_ff) ? &g->cross_ff[k] : nullptr, &cf[k], &gcf[k], grads);
+    }
+    if (m->self_per_cross_attn > 0)
+      for (int k = 0; k < depth; ++k) {
+        attn(m->self_attn[k], (g && g->self_attn) ? &g->self_attn[k] : nullptr, false, 0, &sa[k], &gsa[k], grads);
+        ff(m->self_ff[k], (g && g->self_ff) ? &g->self_ff[k] : nullptr, &sf[k], &gsf[k], grads);
+      }
+    sm.cross_attn = ca.data(); sm.cross_ff = cf.data(); sm.self_attn = sa.data(); sm.self_ff = sf.data();
+    {   // latents (l_c, l_d) -> (l_c, 128)
+      const Slot sl = slot_for(m->latents, (size_t)m->l_c * 128);
+      if (m->latents && sl.fresh) piece(sl.off, 0, m->latents, g ? g->latents : nullptr, m->l_c, ld, ld, m->l_c, 128, 128, grads);
+      sm.latents = wptr(m->latents, sl.off);
+      sg.latents = gptr(g ? g->latents : nullptr, sl.off);
+    }
+    vec(m->head_norm_w, g ? g->head_norm_w : nullptr, ld, 128, &sm.head_norm_w, &sg.head_norm_w, grads);
+    vec(m->head_norm_b, g ? g->head_norm_b : nullptr, ld, 128, &sm.head_norm_b, &sg.head_norm_b, grads);
+    {   // to_logits weight (out_dims, l_d) -> (out_dims, 128)
+      const int od = m->out_dims > 0 ? m->out_dims : 1;
+      const Slot sl = slot_for(m->head_w, (size_t)od * 128);
+      if (m->head_w && sl.fresh) piece(sl.off, 0, m->head_w, g ? g->head_w : nullptr, od, ld, ld, od, 128, 128, grads);
+      sm.head_w = wptr(m->head_w, sl.off);
+      sg.head_w = gptr(g ? g->head_w : nullptr, sl.off);
+    }
+    sg.head_b = g ? g->head_b : nullptr;
+    sg.cross_attn = gca.data(); sg.cross_ff = gcf.data(); sg.self_attn = gsa.data(); sg.self_ff = gsf.data();
+  }
+
+  int run(const std::vector<StagePiece> &pieces, int accumulate, hipStream_t s) const {
+    StageTable t;
+    for (size_t i = 0; i < pieces.size(); i += STAGE_MAX) {
+      t.n = (int)((pieces.size() - i) < (size_t)STAGE_MAX ? pieces.size() - i : (size_t)STAGE_MAX);
+      t.accumulate = accumulate;
+      memcpy(t.p, pieces.data() + i, (size_t)t.n * sizeof(StagePiece));
+      int rc = launch_stage(t, s);
+      if (rc != HN_OK) return rc;
+    }
+    return HN_OK;
+  }
+};
+
+// Does this model run as its padded image?  Yes when it is NOT already one of the chain's shapes but fits them after padding.
+static bool stage_wanted(const hn_model *m) {
+  if (!m || staging_disabled() || chain_disabled() || m->l_d_valid > 0) return false;
+  if (m->l_d < 1 || m->l_d > 128 || m->l_c < 1 || m->depth < 1 || m->n_modalities < 1 || m->n_modalities > 16) return false;
+  if (!m->cross_attn || !m->cross_ff || !m->channel_dims || !m->num_spatial_axes) return false;
+  if (m->self_per_cross_attn < 0 || m->self_per_cross_attn > 1) return false;
+  bool need = m->l_d != 128 || m->l_c % 16 != 0;
+  auto fits = [&](const hn_attn_params &a, const hn_ff_params &f) {
+    if (a.query_dim != m->l_d || f.dim != m->l_d || a.heads < 1 || a.dim_head < 1 || a.query_dim_valid > 0 || f.dim_valid > 0) return false;
+    const int dhp = pad_head_dim(a.dim_head);
+    if (dhp == 0 || a.heads * dhp > 512) return false;
+    if (dhp != a.dim_head || (a.heads * dhp) % 128 != 0) need = true;
+    return true;
+  };
+  for (int k = 0; k < m->depth * m->n_modalities; ++k)
+    if (!fits(m->cross_attn[k], m->cross_ff[k])) return false;
+  if (m->self_per_cross_attn > 0) {
+    if (!m->self_attn || !m->self_ff) return false;
+    for (int k = 0; k < m->depth; ++k)
+      if (!fits(m->self_attn[k], m->self_ff[k])) return false;
+  }
+  return need;
+}
+
+static thread_local Stager g_stager;
+
+}  // namespace
+}  // namespace hn
+
+extern "C" {
+
+size_t hn_fusion_workspace_bytes(const hn_model *m, const hn_modality_input *in, int b) {
+  if (!stage_wanted(m)) return impl_fusion_workspace_bytes(m, in, b);
+  Stager &st = g_stager;
+  st.build(m, nullptr, nullptr, nullptr);
+  const size_t inner = impl_fusion_workspace_bytes(&st.sm, in, b);
+  if (inner == 0) return 0;
+  const size_t xn = align_up(rows16((size_t)b * m->l_c) * 128 * sizeof(float), 256);
+  const size_t n_slots = (size_t)m->depth * (m->n_modalities + 1);
+  return align_up(st.floats * sizeof(float), 256) + (n_slots + 1) * xn + inner;      // shadow weights | trace slots | output | inner
+}
+
+int hn_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, const uint8_t *mask, int skip_self_on_missing,
+                      int return_embeddings, float *out, float **attn_stats, float **x_trace, void *workspace,
+                      size_t workspace_bytes, void *stream, hn_profile *prof) {
+  if (!stage_wanted(m))
+    return impl_fusion_forward(m, in, b, mask, skip_self_on_missing, return_embeddings, out, attn_stats, x_trace, workspace, workspace_bytes,
+                               stream, prof);
+  hipStream_t s = (hipStream_t)stream;
+  HN_REQUIRE(out && in, HN_E_NULL, "fusion: NULL pointer");
+  Stager &st = g_stager;
+  st.build(m, nullptr, nullptr, nullptr);
+  const size_t wbytes = align_up(st.floats * sizeof(float), 256);
+  const size_t xn = align_up(rows16((size_t)b * m->l_c) * 128 * sizeof(float), 256);
+  const int n_slots = m->depth * (m->n_modalities + 1);
+  const size_t head = wbytes + ((size_t)n_slots + 1) * xn;
+  int rc = check_ws(workspace, workspace_bytes, head + 256, "fusion");
+  if (rc != HN_OK) return rc;
+  char *base = (char *)workspace;
+  st.build(m, nullptr, (float *)base, nullptr);
+  if ((rc = st.run(st.fwd, 0, s)) != HN_OK) return rc;
+  const bool emb = return_embeddings || !m->final_classifier_head;
+  float *out_pad = (float *)(base + wbytes + (size_t)n_slots * xn);
+  static thread_local std::vector<float *> xt;
+  xt.assign((size_t)n_slots, nullptr);
+  if (x_trace)
+    for (int i = 0; i < n_slots; ++i)
+      if (x_trace[i]) xt[i] = (float *)(base + wbytes + (size_t)i * xn);
+  rc = impl_fusion_forward(&st.sm, in, b, mask, skip_self_on_missing, return_embeddings, emb ? out_pad : out, attn_stats,
+                           x_trace ? xt.data() : nullptr, base + head, workspace_bytes - head, stream, prof);
+  if (rc != HN_OK) return rc;
+  // un-pad what leaves: the embeddings and the trace slots, (b l_c, 128) -> (b l_c, l_d), one launch
+  std::vector<StagePiece> outp;
+  const int rows = b * m->l_c;
+  if (emb) outp.push_back({out_pad, out, rows, m->l_d, 128, rows, m->l_d, m->l_d});
+  if (x_trace)
+    for (int i = 0; i < n_slots; ++i)
+      if (x_trace[i]) outp.push_back({xt[i], x_trace[i], rows, m->l_d, 128, rows, m->l_d, m->l_d});
+  return st.run(outp, 0, s);
+}
+
+size_t hn_fusion_tape_bytes(const hn_model *m, const hn_modality_input *in, int b, int masked, int skip_self_on_missing) {
+  if (!stage_wanted(m)) return impl_fusion_tape_bytes(m, in, b, masked, skip_self_on_missing);
+  Stager &st = g_stager;
+  st.build(m, nullptr, nullptr, nullptr);
+  const size_t inner = impl_fusion_tape_bytes(&st.sm, in, b, masked, skip_self_on_missing);
+  if (inner == 0) return 0;
+  const size_t n_slots = (size_t)m->depth * (m->n_modalities + 1);
+  // staged weights (the backward reads them back) | the shadow model's tape | the attention blocks' inputs un-padded (hn_attn_probs)
+  return align_up(st.floats * sizeof(float), 256) + inner + n_slots * align_up((size_t)b * m->l_c * m->l_d * sizeof(float), 256);
+}
+
+int hn_fusion_tape_layout(const hn_model *m, const hn_modality_input *in, int b, int masked, int skip_self_on_missing,
+                          size_t *stats_off, size_t *x_off) {
+  if (!stage_wanted(m)) return impl_fusion_tape_layout(m, in, b, masked, skip_self_on_missing, stats_off, x_off);
+  Stager &st = g_stager;
+  st.build(m, nullptr, nullptr, nullptr);
+  int rc = impl_fusion_tape_layout(&st.sm, in, b, masked, skip_self_on_missing, stats_off, x_off);
+  if (rc != HN_OK) return rc;
+  const size_t inner = impl_fusion_tape_bytes(&st.sm, in, b, masked, skip_self_on_missing);
+  HN_REQUIRE(inner != 0, HN_E_SHAPE, "fusion_tape_layout: tape size");
+  const size_t wfloats = align_up(st.floats * sizeof(float), 256) / sizeof(float);
+  const size_t xreal = wfloats + inner / sizeof(float), xstride = align_up((size_t)b * m->l_c * m->l_d * sizeof(float), 256) / sizeof(float);
+  const int n_slots = m->depth * (m->n_modalities + 1);
+  for (int i = 0; i < n_slots; ++i) {
+    if (stats_off[i] == (size_t)-1) continue;
+    stats_off[i] += wfloats;
+    x_off[i] = xreal + (size_t)i * xstride;
+  }
+  return HN_OK;
+}
+
+int hn_fusion_forward_train(const hn_model *m, const hn_modality_input *in, int b, const uint8_t *mask, int skip_self_on_missing,
+                            int return_embeddings, float *out, float **attn_stats, float **x_trace, void *tape,
+                            size_t tape_bytes, void *workspace, size_t workspace_bytes, void *stream) {
+  if (!stage_wanted(m))
+    return impl_fusion_forward_train(m, in, b, mask, skip_self_on_missing, return_embeddings, out, attn_stats, x_trace, tape, tape_bytes,
+                                     workspace, workspace_bytes, stream);
+  hipStream_t s = (hipStream_t)stream;
+  HN_REQUIRE(out && tape && in, HN_E_NULL, "fusion_forward_train: NULL pointer");
+  HN_REQUIRE(((uintptr_t)tape & 255) == 0, HN_E_WORKSPACE, "fusion_forward_train: tape must be 256-byte aligned");
+  Stager &st = g_stager;
+  st.build(m, nullptr, (float *)tape, nullptr);
+  const size_t wbytes = align_up(st.floats * sizeof(float), 256);
+  const size_t inner = impl_fusion_tape_bytes(&st.sm, in, b, mask != nullptr, skip_self_on_missing);
+  HN_REQUIRE(inner != 0, HN_E_SHAPE, "fusion_forward_train: tape size");
+  const int n_slots = m->depth * (m->n_modalities + 1);
+  const size_t xstride = align_up((size_t)b * m->l_c * m->l_d * sizeof(float), 256);
+  HN_REQUIRE(tape_bytes >= wbytes + inner + (size_t)n_slots * xstride, HN_E_WORKSPACE, "fusion_forward_train: tape %zu bytes < required %zu",
+             tape_bytes, wbytes + inner + (size_t)n_slots * xstride);
+  int rc = st.run(st.fwd, 0, s);
+  if (rc != HN_OK) return rc;
+  // (the output leaves through the padded slot at the head of the workspace, the inner call gets the rest)
+  const bool emb = return_embeddings || !m->final_classifier_head;
+  const size_t xn = align_up(rows16((size_t)b * m->l_c) * 128 * sizeof(float), 256);
+  const size_t head = emb ? xn : 0;
+  if ((rc = check_ws(workspace, workspace_bytes, head + 256, "fusion_forward_train")) != HN_OK) return rc;
+  float *out_pad = (float *)workspace;
+  char *itape = (char *)tape + wbytes;
+  rc = impl_fusion_forward_train(&st.sm, in, b, mask, skip_self_on_missing, return_embeddings, emb ? out_pad : out, attn_stats, nullptr, itape,
+                                 inner, (char *)workspace + head, workspace_bytes - head, stream);
+  if (rc != HN_OK) return rc;
+  static thread_local std::vector<size_t> so, xo;
+  so.assign((size_t)n_slots, 0); xo.assign((size_t)n_slots, 0);
+  if ((rc = impl_fusion_tape_layout(&st.sm, in, b, mask != nullptr, skip_self_on_missing, so.data(), xo.data())) != HN_OK) return rc;
+  std::vector<StagePiece> outp;
+  const int rows = b * m->l_c;
+  if (emb) outp.push_back({out_pad, out, rows, m->l_d, 128, rows, m->l_d, m->l_d});
+  for (int i = 0; i < n_slots; ++i) {
+    if (xo[i] == (size_t)-1) continue;
+    const float *src = (const float *)itape + xo[i];
+    outp.push_back({src, (float *)(itape + inner + (size_t)i * xstride), rows, m->l_d, 128, rows, m->l_d, m->l_d});
+    if (x_trace && x_trace[i]) outp.push_back({src, x_trace[i], rows, m->l_d, 128, rows, m->l_d, m->l_d});
+  }
+  return st.run(outp, 0, s);
+}
+
+size_t hn_fusion_backward_workspace_bytes(const hn_model *m, const hn_modality_input *in, int b, int masked) {
+  if (!stage_wanted(m)) return impl_fusion_backward_workspace_bytes(m, in, b, masked);
+  Stager &st = g_stager;
+  st.build(m, nullptr, nullptr, nullptr);
+  const size_t inner = impl_fusion_backward_workspace_bytes(&st.sm, in, b, masked);
+  if (inner == 0) return 0;
+  // shadow gradients | the padded output gradient | inner
+  return align_up(st.floats * sizeof(float), 256) + align_up(rows16((size_t)b * m->l_c) * 128 * sizeof(float), 256) + inner;
+}
+
+int hn_fusion_backward(const hn_model *m, const hn_modality_input *in, int b, const uint8_t *mask, int skip_self_on_missing,
+                       int return_embeddings, const float *dout, const void *tape, const hn_model_grads *g, void *workspace,
+                       size_t workspace_bytes, void *stream, const hn_grad_ready *ready) {
+  if (!stage_wanted(m))
+    return impl_fusion_backward(m, in, b, mask, skip_self_on_missing, return_embeddings, dout, tape, g, workspace, workspace_bytes, stream, ready);
+  hipStream_t s = (hipStream_t)stream;
+  HN_REQUIRE(dout && tape && g && in, HN_E_NULL, "fusion_backward: NULL pointer");
+  Stager &st = g_stager;
+  st.build(m, nullptr, nullptr, nullptr);
+  const size_t wbytes = align_up(st.floats * sizeof(float), 256);
+  const size_t xn = align_up(rows16((size_t)b * m->l_c) * 128 * sizeof(float), 256);
+  const size_t head = wbytes + xn;
+  int rc = check_ws(workspace, workspace_bytes, head + 256, "fusion_backward");
+  if (rc != HN_OK) return rc;
+  // the staged weights are the forward's (on the tape); the shadow gradients start at zero in the workspace
+  st.build(m, g, (float *)const_cast<void *>(tape), (float *)workspace);
+  if ((rc = launch_fill((float *)workspace, 0.0f, (long)(wbytes / sizeof(float)), s)) != HN_OK) return rc;
+  const bool emb = return_embeddings || !m->final_classifier_head;
+  const float *dout_in = dout;
+  if (emb) {     // (b l_c, l_d) -> (b l_c, 128), zero pad columns
+    float *dpad = (float *)((char *)workspace + wbytes);
+    std::vector<StagePiece> pp;
+    pp.push_back({dout, dpad, b * m->l_c, m->l_d, m->l_d, b * m->l_c, 128, 128});
+    if ((rc = st.run(pp, 0, s)) != HN_OK) return rc;
+    dout_in = dpad;
+  }
+  const size_t inner_tape = impl_fusion_tape_bytes(&st.sm, in, b, mask != nullptr, skip_self_on_missing);
+  HN_REQUIRE(inner_tape != 0, HN_E_SHAPE, "fusion_backward: tape size");
+  // gradient-readiness signals: the real gradients are complete only after the un-staging launch at the end
+  rc = impl_fusion_backward(&st.sm, in, b, mask, skip_self_on_missing, return_embeddings, dout_in, (const char *)tape + wbytes, &st.sg,
+                            (char *)workspace + head, workspace_bytes - head, stream, nullptr);
+  if (rc != HN_OK) return rc;
+  if ((rc = st.run(st.bwd, 1, s)) != HN_OK) return rc;
+  if (ready)
+    for (int idx = m->depth; idx >= 0; --idx) {
+      if (ready->events && ready->events[idx]) HN_HIP_CHECK(hipEventRecord((hipEvent_t)ready->events[idx], s));
+      if (ready->notify) ready->notify(idx, ready->user);
+    }
+  return HN_OK;
 }
 
 }  // extern "C"

@@ -553,7 +553,7 @@ int launch_gemm_tn_multi(GemmTnMulti &m, float *scratch, size_t scratch_floats, 
   HN_REQUIRE(m.n >= 0 && m.n <= TN_MULTI_MAX && m.n_ln >= 0 && m.n_ln <= 4 && m.K > 0, HN_E_SHAPE, "gemm_tn_multi: n=%d n_ln=%d K=%d", m.n, m.n_ln, m.K);
   for (int i = 0; i < m.n; ++i) {
     const TnProduct &p = m.p[i];
-    HN_REQUIRE(p.A && p.B && p.C && p.M >= 128 && p.N >= 128 && (p.lda & 3) == 0 && (p.ldb & 3) == 0 && ((uintptr_t)p.A & 15) == 0 &&
+    HN_REQUIRE(p.A && p.B && p.C && p.M >= 16 && p.N >= 16 && (p.lda & 3) == 0 && (p.ldb & 3) == 0 && ((uintptr_t)p.A & 15) == 0 &&
                    ((uintptr_t)p.B & 15) == 0, HN_E_SHAPE, "gemm_tn_multi: product %d M=%d N=%d", i, p.M, p.N);
     HN_REQUIRE(((long)m.K * p.lda + p.M) * 4 < (1L << 31) && ((long)m.K * p.ldb + p.N) * 4 < (1L << 31), HN_E_UNSUPPORTED, "gemm_tn_multi: operand too large");
   }
@@ -988,9 +988,10 @@ int launch_segsum(const float *X, int seg, int cols, int nseg, float *out, hipSt
 }
 
 // y = LayerNorm(x) * gamma + beta materialised (the backward needs the normalised operand of dW = dY^T x_hat)
+// dv: statistics over the first dv columns (staged models: the pad columns of x, gamma, beta are zero and stay zero in y)
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
                                                      const float *__restrict__ beta, float eps, long rows, int d,
-                                                     float *__restrict__ y) {
+                                                     float *__restrict__ y, int dv) {
   const int lane = threadIdx.x & 63;
   const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
@@ -998,16 +999,17 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float *__restrict__ x
   float s = 0.0f;
   for (int c = lane; c < d; c += 64) s += xr[c];
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-  const float mu = s / (float)d;
+  const float mu = s / (float)dv;
   float q = 0.0f;
-  for (int c = lane; c < d; c += 64) { const float t = xr[c] - mu; q += t * t; }
+  for (int c = lane; c < dv; c += 64) { const float t = xr[c] - mu; q += t * t; }
   for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
-  const float rs = 1.0f / sqrtf(q / (float)d + eps);
-  for (int c = lane; c < d; c += 64) y[r * d + c] = (xr[c] - mu) * rs * gamma[c] + beta[c];
+  const float rs = 1.0f / sqrtf(q / (float)dv + eps);
+  for (int c = lane; c < d; c += 64) y[r * d + c] = c < dv ? (xr[c] - mu) * rs * gamma[c] + beta[c] : 0.0f;
 }
 
-int launch_ln_fwd(const float *x, const float *gamma, const float *beta, long rows, int d, float *y, hipStream_t s) {
-  hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)ceil_div_ll(rows, 4)), dim3(256), 0, s, x, gamma, beta, 1e-5f, rows, d, y);
+int launch_ln_fwd(const float *x, const float *gamma, const float *beta, long rows, int d, float *y, hipStream_t s, int dv) {
+  if (dv <= 0 || dv > d) dv = d;
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)ceil_div_ll(rows, 4)), dim3(256), 0, s, x, gamma, beta, 1e-5f, rows, d, y, dv);
   HN_LAUNCH_CHECK("ln_fwd");
   return HN_OK;
 }
@@ -1091,7 +1093,8 @@ int launch_add_into(const float *src, float *dst, long n, int accumulate, hipStr
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float *__restrict__ x, int L, int d, const float *__restrict__ nw,
                                                        const float *__restrict__ nb, const float *__restrict__ w, int out_dims,
                                                        const float *__restrict__ dlogits, float *__restrict__ dx,
-                                                       float *__restrict__ partial) {
+                                                       float *__restrict__ partial, int dv) {
+  // dv: LayerNorm over the first dv columns (staged models; the pad columns carry no gradient)
   extern __shared__ float sm[];
   float *pooled = sm, *xn = sm + d, *dyn = sm + 2 * d, *red = sm + 3 * d, *part = sm + 3 * d + 8;   // part[4][d]
   const int tid = threadIdx.x, bi = blockIdx.x;
@@ -1113,18 +1116,18 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float *__restrict__
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
   if ((tid & 63) == 0) red[tid >> 6] = s;
   __syncthreads();
-  const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)d;
+  const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)dv;
   __syncthreads();
   float q = 0.0f;
-  for (int c = tid; c < d; c += blockDim.x) { const float t = pooled[c] - mean; q += t * t; }
+  for (int c = tid; c < dv; c += blockDim.x) { const float t = pooled[c] - mean; q += t * t; }
   for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
   if ((tid & 63) == 0) red[tid >> 6] = q;
   __syncthreads();
-  const float rstd = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)d + 1e-5f);
+  const float rstd = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)dv + 1e-5f);
   __syncthreads();
   float m1 = 0.0f, m2 = 0.0f;
   for (int c = tid; c < d; c += blockDim.x) {
-    const float n = (pooled[c] - mean) * rstd;
+    const float n = c < dv ? (pooled[c] - mean) * rstd : 0.0f;
     const float yh = n * nw[c] + nb[c];
     float dyh = 0.0f;
     for (int o = 0; o < out_dims; ++o) {
@@ -1144,8 +1147,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float *__restrict__
   for (int o = 32; o > 0; o >>= 1) { m1 += __shfl_xor(m1, o); m2 += __shfl_xor(m2, o); }
   if ((tid & 63) == 0) { red[tid >> 6] = m1; red[4 + (tid >> 6)] = m2; }
   __syncthreads();
-  const float mm1 = (red[0] + red[1] + red[2] + red[3]) / (float)d, mm2 = (red[4] + red[5] + red[6] + red[7]) / (float)d;
-  for (int c = tid; c < d; c += blockDim.x) pooled[c] = rstd * (dyn[c] - mm1 - xn[c] * mm2) / (float)L;   // d pooled / L
+  const float mm1 = (red[0] + red[1] + red[2] + red[3]) / (float)dv, mm2 = (red[4] + red[5] + red[6] + red[7]) / (float)dv;
+  for (int c = tid; c < d; c += blockDim.x) pooled[c] = c < dv ? rstd * (dyn[c] - mm1 - xn[c] * mm2) / (float)L : 0.0f;   // d pooled / L
   __syncthreads();
   float *dxb = dx + (long)bi * L * d;
   for (long i = tid; i < (long)L * d; i += blockDim.x) dxb[i] = pooled[i % d];
@@ -1155,12 +1158,14 @@ size_t head_bwd_scratch_floats(int b, int d, int out_dims) { return (size_t)b * 
 
 int launch_head_bwd(const float *x, int b, int L, int d, const float *nw, const float *nb, const float *w, int out_dims,
                     const float *dlogits, float *dx, float *dnw, float *dnb, float *dw, float *dbias, float *scratch,
-                    hipStream_t s) {
+                    hipStream_t s, int dv) {
   HN_REQUIRE(x && nw && nb && w && dlogits && dx && scratch, HN_E_NULL, "head_bwd: NULL pointer");
+  HN_REQUIRE(dv >= 0 && dv <= d, HN_E_SHAPE, "head_bwd: valid=%d of d=%d", dv, d);
+  if (dv == 0) dv = d;
   HN_REQUIRE(out_dims <= 256, HN_E_UNSUPPORTED, "head_bwd: out_dims=%d (<= 256)", out_dims);
   const size_t lds = (size_t)(7 * d + 8) * sizeof(float);
   HN_REQUIRE(lds <= 64 * 1024, HN_E_UNSUPPORTED, "head_bwd: l_d=%d too large", d);
-  hipLaunchKernelGGL(head_bwd_kernel, dim3(b), dim3(256), lds, s, x, L, d, nw, nb, w, out_dims, dlogits, dx, scratch);
+  hipLaunchKernelGGL(head_bwd_kernel, dim3(b), dim3(256), lds, s, x, L, d, nw, nb, w, out_dims, dlogits, dx, scratch, dv);
   HN_LAUNCH_CHECK("head_bwd");
   const long pitch = (long)out_dims * d + 2 * d + out_dims;
   int rc;

@@ -48,6 +48,8 @@ constexpr int B_LDS_FLOATS = B_tbl + 2 * BMAXBLK;          // 34 560 floats = 13
 
 }  // namespace
 
+// EXT: as in chain.hip (false = the default model's shapes exactly; true adds valid widths, ragged rows, idle cluster workgroups, dropout)
+template <bool EXT>
 __global__ __launch_bounds__(512) void latent_bchain_kernel(const BChainArgs args) {
   // every field unpacked once into locals (see chain.hip: capturing the struct keeps a scratch copy and turns pointer selects
   // into flat accesses)
@@ -72,6 +74,13 @@ __global__ __launch_bounds__(512) void latent_bchain_kernel(const BChainArgs arg
   gf32 *const a_dPre = (gf32 *)args.dPre;
   gf32 *const a_dO = (gf32 *)args.dO;
   gf32 *const a_lnpart = (gf32 *)args.lnpart;
+  // staged (padded) models: valid widths (common.h)
+  const int a_rows = args.rows;
+  const int a_dv = EXT && args.dv > 0 ? args.dv : CD;
+  const float inv_dv = 1.0f / (float)a_dv;
+  const int a_q_cols = EXT && args.q_cols > 0 ? args.q_cols : args.nq;
+  const int a_kv_cols = EXT && args.kv_cols > 0 ? args.kv_cols : args.nkv;
+  const uint32_t d_thr = EXT ? args.ff_drop.thr : 0u;   // (the rest of the generator state is read from the argument segment where it is used)
 
   extern __shared__ __attribute__((aligned(16))) float lds_raw[];
   lf32 *lds = (lf32 *)lds_raw;
@@ -85,6 +94,7 @@ __global__ __launch_bounds__(512) void latent_bchain_kernel(const BChainArgs arg
   const int a_C = args.cluster > 1 ? args.cluster : 1;
   const int ntiles = gridDim.x / a_C;
   const int member = __builtin_amdgcn_readfirstlane((int)blockIdx.x / ntiles), tile = blockIdx.x - member * ntiles;
+  if (EXT && tile >= args.tiles) return;            // (cluster grids are rounded up to 8 tiles per member row: idle workgroups)
   const int my_chunks = 4 / a_C;
   const int m0 = tile * CR;
   const int row = tid >> 5, l32 = tid & 31;                  // row layout: 32 lanes per row, one 16-byte chunk each
@@ -93,8 +103,11 @@ __global__ __launch_bounds__(512) void latent_bchain_kernel(const BChainArgs arg
   // ---- the block stream of the chain
   const int ptot = a_has_p ? a_nq + a_nkv : 0;               // contraction length of P, in two segments of <= 1024 columns
   // (cluster: the member's contiguous share of the columns, one segment)
-  const int pc0 = a_C > 1 ? member * (ptot / a_C) : 0;
-  const int pmine = a_C > 1 ? ptot / a_C : ptot;
+  // -- when the shares are whole 128-column groups; a short contraction (staged one-head models: 128 columns) is run in full by
+  // every member instead, without an exchange
+  const bool p_split = a_C > 1 && ptot % (a_C * WN) == 0;
+  const int pc0 = p_split ? member * (ptot / a_C) : 0;
+  const int pmine = p_split ? ptot / a_C : ptot;
   const int pseg1 = min(pmine, 1024), pseg2 = pmine - pseg1;
   const int nk1 = pseg1 / WK, nk2 = pseg2 / WK;
   const int my_out = a_has_out ? (a_inner_o / WN - member + a_C - 1) / a_C : 0;      // dO chunks j = member, member + C, ...
@@ -181,7 +194,8 @@ __global__ __launch_bounds__(512) void latent_bchain_kernel(const BChainArgs arg
         for (int i = 0; i < 8; ++i) {
           const int c = pc0 + min(128 * i, pseg1 - 128) + 4 * l32; // passes beyond the segment re-read its last one (not stored)
           const gf32 *src = c < a_nq ? a_dQ + (long)(m0 + row) * a_lddq + c : a_dKV + (long)(m0 + row) * a_lddkv + (c - a_nq);
-          seg1[i] = gld4(src);
+          seg1[i] = make_float4(0.f, 0.f, 0.f, 0.f);               // (staged models: the contraction beyond the operand's columns is zero)
+          if (!EXT || (c < a_nq ? c < a_q_cols : c - a_nq < a_kv_cols)) seg1[i] = gld4(src);
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -191,7 +205,7 @@ __global__ __launch_bounds__(512) void latent_bchain_kernel(const BChainArgs arg
       for (int i = 0; i < 4; ++i) {
         const int c = pc0 + pseg1 + 128 * i + 4 * l32;
         seg2[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (pseg2 > 0 && c < ptot) seg2[i] = gld4(a_dKV + (long)(m0 + row) * a_lddkv + (c - a_nq));
+        if (pseg2 > 0 && c < ptot && (!EXT || c - a_nq < a_kv_cols)) seg2[i] = gld4(a_dKV + (long)(m0 + row) * a_lddkv + (c - a_nq));
       }
       if (a_p_nw) lst4(lds, B_gp + 4 * l32, gld4(a_p_nw + 4 * l32));    // (16 rows write the same 128 floats)
       if (a_has_ff) xm_pre = gld4(a_f_x + grow);
@@ -306,10 +320,14 @@ __global__ __launch_bounds__(512) void latent_bchain_kernel(const BChainArgs arg
   auto ln_stats = [&](bool normalise, bool emit_hat, int gamma, int beta, bool has_beta) {
     float4 v = lld4(lds, B_xs + row * XP + 4 * l32);
     if (normalise) {
-      const float mu = half_wave_sum((v.x + v.y) + (v.z + v.w)) * (1.0f / CD);
+      const float mu = half_wave_sum((v.x + v.y) + (v.z + v.w)) * inv_dv;      // (pad columns of x are zero)
       v.x -= mu; v.y -= mu; v.z -= mu; v.w -= mu;
+      if (EXT && a_dv < CD) {                // ... and stay out of the variance (and of the normalised image)
+        const int c = 4 * l32;
+        v.x = c < a_dv ? v.x : 0.0f; v.y = c + 1 < a_dv ? v.y : 0.0f; v.z = c + 2 < a_dv ? v.z : 0.0f; v.w = c + 3 < a_dv ? v.w : 0.0f;
+      }
       const float q = half_wave_sum((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w));
-      const float rs = 1.0f / sqrtf(q * (1.0f / CD) + 1e-5f);
+      const float rs = 1.0f / sqrtf(q * inv_dv + 1e-5f);
       v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs;
       if (l32 == 0) lds[B_rs + row] = rs;
       lst4(lds, B_xn + row * XP + 4 * l32, v);
@@ -333,10 +351,15 @@ __global__ __launch_bounds__(512) void latent_bchain_kernel(const BChainArgs arg
       const float4 xn = lld4(lds, B_xn + row * XP + 4 * l32), g0 = lld4(lds, gamma + 4 * l32);
       const float rs = lds[B_rs + row];
       const float4 gg = make_float4(dv.x * g0.x, dv.y * g0.y, dv.z * g0.z, dv.w * g0.w);
-      const float m1 = half_wave_sum((gg.x + gg.y) + (gg.z + gg.w)) * (1.0f / CD);
-      const float m2 = half_wave_sum((gg.x * xn.x + gg.y * xn.y) + (gg.z * xn.z + gg.w * xn.w)) * (1.0f / CD);
-      G.x += rs * (gg.x - m1 - xn.x * m2); G.y += rs * (gg.y - m1 - xn.y * m2);
-      G.z += rs * (gg.z - m1 - xn.z * m2); G.w += rs * (gg.w - m1 - xn.w * m2);
+      const float m1 = half_wave_sum((gg.x + gg.y) + (gg.z + gg.w)) * inv_dv;           // (gamma, xn are zero in the pad columns)
+      const float m2 = half_wave_sum((gg.x * xn.x + gg.y * xn.y) + (gg.z * xn.z + gg.w * xn.w)) * inv_dv;
+      float4 dxv = make_float4(rs * (gg.x - m1 - xn.x * m2), rs * (gg.y - m1 - xn.y * m2), rs * (gg.z - m1 - xn.z * m2),
+                               rs * (gg.w - m1 - xn.w * m2));
+      if (EXT && a_dv < CD) {                // no gradient into the pad columns
+        const int c = 4 * l32;
+        dxv.x = c < a_dv ? dxv.x : 0.0f; dxv.y = c + 1 < a_dv ? dxv.y : 0.0f; dxv.z = c + 2 < a_dv ? dxv.z : 0.0f; dxv.w = c + 3 < a_dv ? dxv.w : 0.0f;
+      }
+      G.x += dxv.x; G.y += dxv.y; G.z += dxv.z; G.w += dxv.w;
       lst4(lds, B_gs + row * XP + 4 * l32, G);
       // column sums over the 16 rows: contributions to two scratch tiles (B_ts holds dxh already; B_xs <- dxh * xn)
       lst4(lds, B_xs + row * XP + 4 * l32, make_float4(dv.x * xn.x, dv.y * xn.y, dv.z * xn.z, dv.w * xn.w));
@@ -345,7 +368,7 @@ __global__ __launch_bounds__(512) void latent_bchain_kernel(const BChainArgs arg
         const int c = tid & 127, src = tid < 128 ? B_xs : B_ts;
         float acc = 0.0f;
 #pragma unroll
-        for (int r = 0; r < CR; ++r) acc += lds[src + r * XP + c];
+        for (int r = 0; r < CR; ++r) acc += !EXT || m0 + r < a_rows ? lds[src + r * XP + c] : 0.0f;      // (tail rows of a ragged last tile: nothing)
         gst1(a_lnpart + ((long)tile * 4 + slot + (tid >> 7)) * CD + c, acc);
       }
     } else {
@@ -371,7 +394,7 @@ __global__ __launch_bounds__(512) void latent_bchain_kernel(const BChainArgs arg
       for (int kc = 0; kc < nk2; kc += 4) run4(B_Abig, kc, B_Abig, kc + 4 == nk2 ? 0 : kc + 4, c0, c1);
     }
     const float v[4] = {c0.x + c1.x, c0.y + c1.y, c0.z + c1.z, c0.w + c1.w};
-    if (a_C > 1) {
+    if (p_split) {
       exchange_into_ts(v, 0);
     } else {
 #pragma unroll
@@ -393,7 +416,14 @@ __global__ __launch_bounds__(512) void latent_bchain_kernel(const BChainArgs arg
     }
     ln_stats(a_f_nw != nullptr, true, B_gf, B_gf + 128, a_f_nb != nullptr);
     {
-      const float4 G = lld4(lds, B_gs + row * XP + 4 * l32);
+      float4 G = lld4(lds, B_gs + row * XP + 4 * l32);
+      if (d_thr != 0) {                      // the forward's dropout on the block output: the block proper sees G * keep / (1 - p)
+        uint32_t w[4];
+        philox4x32(args.ff_drop.seed_lo, args.ff_drop.seed_hi, (uint32_t)l32, (uint32_t)(m0 + row), args.ff_drop.sid, args.ff_drop.offset, w);
+        const float d_scale = args.ff_drop.scale;
+        G.x = w[0] >= d_thr ? G.x * d_scale : 0.0f; G.y = w[1] >= d_thr ? G.y * d_scale : 0.0f;
+        G.z = w[2] >= d_thr ? G.z * d_scale : 0.0f; G.w = w[3] >= d_thr ? G.w * d_scale : 0.0f;
+      }
       lst4(lds, a_at(B_Adz, row, l32), G);
       if (member == 0) gst4_nt(a_dYff + grow, G);             // the gradient that entered the block (dW2 = G^T h, db2)
     }
@@ -498,20 +528,26 @@ __global__ __launch_bounds__(512) void latent_bchain_kernel(const BChainArgs arg
   if (a_has_out) {
     __syncthreads();
     read_a(fa0, B_Adz, 0);
+    const int a_o_cols = EXT && args.o_cols > 0 ? args.o_cols : a_inner_o;
     for (int j = member; j < a_inner_o / WN; j += a_C) {
       f32x4 c0 = zero, c1 = zero;
       run4(B_Adz, 0, B_Adz, 0, c0, c1);
       const float v[4] = {c0.x + c1.x, c0.y + c1.y, c0.z + c1.z, c0.w + c1.w};
-      store_tile(a_dO, a_lddo, j * WN, v);
+      if (!EXT || j * WN + wave * 16 < a_o_cols) store_tile(a_dO, a_lddo, j * WN, v);      // (staged models keep the leading columns only)
     }
   }
 }
 
-bool latent_bchain_supported(int rows, int d, int hidden) { return d == CD && hidden == CHID && rows > 0 && rows % CR == 0; }
+// (any row count: the callers allocate every (rows, .) operand for the count rounded up to 16, api.hip rows16)
+bool latent_bchain_supported(int rows, int d, int hidden) { return d == CD && hidden == CHID && rows > 0; }
 
 int launch_latent_bchain(const BChainArgs &a, hipStream_t s) {
   auto al16 = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
-  HN_REQUIRE(a.rows > 0 && a.rows % CR == 0, HN_E_SHAPE, "latent_bchain: rows=%d", a.rows);
+  HN_REQUIRE(a.rows > 0, HN_E_SHAPE, "latent_bchain: rows=%d", a.rows);
+  HN_REQUIRE(a.dv >= 0 && a.dv <= CD && a.q_cols >= 0 && a.q_cols <= a.nq && a.q_cols % 4 == 0 && a.kv_cols >= 0 && a.kv_cols <= a.nkv &&
+                 a.kv_cols % 4 == 0 && a.o_cols >= 0 && a.o_cols <= a.inner_o && a.o_cols % 16 == 0,
+             HN_E_SHAPE, "latent_bchain: valid widths dv=%d q_cols=%d kv_cols=%d o_cols=%d", a.dv, a.q_cols, a.kv_cols, a.o_cols);
+  HN_REQUIRE(a.ff_drop.thr == 0 || a.has_ff, HN_E_SHAPE, "latent_bchain: dropout without a feed-forward stage");
   HN_REQUIRE(a.dy && a.dx_out && al16(a.dy) && al16(a.dx_out), HN_E_NULL, "latent_bchain: dy / dx_out NULL or unaligned");
   HN_REQUIRE(a.has_p || a.has_ff, HN_E_SHAPE, "latent_bchain: empty chain");
   HN_REQUIRE(!a.has_out || a.has_ff, HN_E_UNSUPPORTED, "latent_bchain: the out-projection stage follows a feed-forward stage");
@@ -539,15 +575,18 @@ int launch_latent_bchain(const BChainArgs &a, hipStream_t s) {
   int dev = 0;
   HN_HIP_CHECK(hipGetDevice(&dev));
   if (dev < 0 || dev >= 64 || !configured[dev]) {
-    HN_HIP_CHECK(hipFuncSetAttribute((const void *)latent_bchain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    HN_HIP_CHECK(hipFuncSetAttribute((const void *)latent_bchain_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    HN_HIP_CHECK(hipFuncSetAttribute((const void *)latent_bchain_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     if (dev >= 0 && dev < 64) configured[dev] = true;
   }
   static const bool no_cluster = getenv("HN_NO_CHAIN_CLUSTER") != nullptr;
   BChainArgs ac = a;
-  const int tiles = a.rows / CR;
+  const int tiles = (a.rows + CR - 1) / CR;
+  const int gtiles = (tiles + 7) / 8 * 8;    // member rows of a cluster grid: a multiple of 8 tiles (members of a tile share an XCD)
   ac.cluster = 1;
-  if (!no_cluster && a.xchg && a.xflags && a.seq > 0 && a.has_ff && tiles <= 128 && tiles % 8 == 0 && al16(a.xchg)) {
-    const int C = tiles <= 64 ? 4 : 2;
+  ac.tiles = tiles;
+  if (!no_cluster && a.xchg && a.xflags && a.seq > 0 && a.has_ff && gtiles <= 128 && al16(a.xchg)) {
+    const int C = gtiles <= 64 ? 4 : 2;
     // every member of every tile must be resident at once (the exchanges spin): ONE 135 KB workgroup fits a CU
     static int cu_count[64] = {};
     if (dev >= 0 && dev < 64 && cu_count[dev] == 0) {
@@ -556,10 +595,14 @@ int launch_latent_bchain(const BChainArgs &a, hipStream_t s) {
       cu_count[dev] = n;
     }
     const int cus = (dev >= 0 && dev < 64) ? cu_count[dev] : 1;
-    // the member's share of the P contraction must be whole 128-column groups
-    if (tiles * C <= cus && (!a.has_p || ((a.nq + a.nkv) / C) % WN == 0)) ac.cluster = C;
+    if (gtiles * C <= cus) ac.cluster = C;
   }
-  hipLaunchKernelGGL(latent_bchain_kernel, dim3(tiles * ac.cluster), dim3(512), lds_bytes, s, ac);
+  const bool ext = a.rows % CR != 0 || (a.dv > 0 && a.dv < CD) || a.ff_drop.thr != 0 || (a.has_p && a.q_cols > 0 && a.q_cols < a.nq) ||
+                   (a.has_p && a.kv_cols > 0 && a.kv_cols < a.nkv) || (a.has_out && a.o_cols > 0 && a.o_cols < a.inner_o) ||
+                   (ac.cluster > 1 && gtiles != tiles);
+  const dim3 grid(ac.cluster > 1 ? gtiles * ac.cluster : tiles);
+  if (ext) hipLaunchKernelGGL(latent_bchain_kernel<true>, grid, dim3(512), lds_bytes, s, ac);
+  else hipLaunchKernelGGL(latent_bchain_kernel<false>, grid, dim3(512), lds_bytes, s, ac);
   HN_LAUNCH_CHECK("latent_bchain");
   return HN_OK;
 }

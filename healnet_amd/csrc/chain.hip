@@ -86,6 +86,10 @@ __device__ int g_chain_seq;
 
 }  // namespace
 
+// EXT = false: the shapes of the default model exactly (rows % 16 == 0, l_d = 128, no dropout, whole operands); EXT = true adds
+// the valid widths of staged models, ragged row counts, idle workgroups of rounded-up cluster grids and the feed-forward dropout
+// -- a second instantiation so that none of it costs the first a register (13 spilled SGPRs when it was one kernel).
+template <bool EXT>
 __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args) {
   // Every field of the by-value argument struct is unpacked ONCE into a local (pointers as global-address-space pointers): the
   // lambdas below capture locals only.  Capturing the struct itself keeps a copy of it in scratch, and the compiler then
@@ -121,6 +125,11 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
   const int a_ldq = args.ldq;
   const int a_ldkv = args.ldkv;
   const float a_alpha_q = args.alpha_q;
+  // staged (padded) models: valid widths (common.h)
+  const int a_rows = args.rows;
+  const int a_dv = EXT && args.dv > 0 ? args.dv : CD;
+  const float inv_dv = 1.0f / (float)a_dv;
+  const uint32_t d_thr = EXT ? args.ff_drop.thr : 0u;   // (the rest of the generator state is read from the argument segment where it is used)
   CHAIN_PROF(14);
   CHAIN_PROF(0);
   extern __shared__ __attribute__((aligned(16))) float lds_raw[];
@@ -147,6 +156,7 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
   const int a_C = args.cluster > 1 ? args.cluster : 1;
   const int ntiles = gridDim.x / a_C;
   const int member = __builtin_amdgcn_readfirstlane((int)blockIdx.x / ntiles), tile = blockIdx.x - member * ntiles;
+  if (EXT && tile >= args.tiles) return;            // cluster grids are rounded up to 8 tiles per member row (XCD alignment): idle workgroups
   const int my_chunks = 4 / a_C;             // hidden chunks (128 columns) of this member: member, member + C, ...
   const int m0 = tile * CR;
 
@@ -311,14 +321,16 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
     const int row = tid >> 5, l32 = tid & 31;           // 32 lanes per row, one 16-byte chunk each
     float4 v0 = gld4(a_x_in + (long)(m0 + row) * CD + 4 * l32);
     if (a_head == 2) {                      // one-token cross block: the same output row for every latent row of a sample
-      const float4 y0 = gld4(a_y + (long)((m0 + row) / a_L) * CD + 4 * l32);
+      const float4 y0 = gld4(a_y + (long)((EXT ? min(m0 + row, a_rows - 1) : m0 + row) / a_L) * CD + 4 * l32);
       v0.x += y0.x; v0.y += y0.y; v0.z += y0.z; v0.w += y0.w;
     }
     lst4(lds, xs + row * XP + 4 * l32, v0);
     if (a_head == 1) {
       const gf32 *orow = a_O + (long)(m0 + row) * a_ldo;
+      const int a_o_cols = EXT && args.o_cols > 0 ? args.o_cols : a_inner_o;
       for (int q = l32; q < a_inner_o / 4; q += 32) {       // 16-byte chunk q of the row: k-tile q >> 3, slot q & 7
-        const float4 o = gld4(orow + 4 * q);
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);         // (staged models: the contraction beyond O's own columns is zero)
+        if (4 * q < a_o_cols) o = gld4(orow + 4 * q);
         lst4(lds, Abig + (q >> 3) * ATILE + row * WK + (((q & 7) ^ (row & 7)) * 4), o);
       }
     }
@@ -413,10 +425,14 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
     const int row = tid >> 5, l32 = tid & 31;
     float4 v = lld4(lds, xs + row * XP + 4 * l32);
     if (affine) {
-      const float mu = half_wave_sum((v.x + v.y) + (v.z + v.w)) * (1.0f / CD);
+      const float mu = half_wave_sum((v.x + v.y) + (v.z + v.w)) * inv_dv;      // (pad columns of x are zero)
       v.x -= mu; v.y -= mu; v.z -= mu; v.w -= mu;
+      if (EXT && a_dv < CD) {                // ... and stay out of the variance
+        const int c = 4 * l32;
+        v.x = c < a_dv ? v.x : 0.0f; v.y = c + 1 < a_dv ? v.y : 0.0f; v.z = c + 2 < a_dv ? v.z : 0.0f; v.w = c + 3 < a_dv ? v.w : 0.0f;
+      }
       const float q = half_wave_sum((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w));
-      const float rs = 1.0f / sqrtf(q * (1.0f / CD) + 1e-5f);
+      const float rs = 1.0f / sqrtf(q * inv_dv + 1e-5f);
       const float4 g0 = lld4(lds, gamma + 4 * l32), b0 = lld4(lds, beta + 4 * l32);
       v.x = v.x * rs * g0.x + b0.x; v.y = v.y * rs * g0.y + b0.y; v.z = v.z * rs * g0.z + b0.z; v.w = v.w * rs * g0.w + b0.w;
     }
@@ -492,8 +508,25 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
       run_chunk_k512(Abig, c0, c1);
       const float bv = lds[p_b2 + ncol];
       const float v[4] = {c0.x + c1.x, c0.y + c1.y, c0.z + c1.z, c0.w + c1.w};
+      if (d_thr == 0) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) lds[xs + (4 * fg + r) * XP + ncol] += v[r] + bv;
+        for (int r = 0; r < 4; ++r) lds[xs + (4 * fg + r) * XP + ncol] += v[r] + bv;
+      } else {
+        // dropout on the block output (:347): through the (dead) LN tile into the row layout, where a thread holds one aligned
+        // column quad -- one generator call (common.h: the mask is a function of (row, quad) of the (rows, l_d) output)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lds[Ahat + (4 * fg + r) * CD + ncol] = v[r] + bv;
+        __syncthreads();
+        const int row = tid >> 5, l32 = tid & 31;
+        const float4 f = lld4(lds, Ahat + row * CD + 4 * l32);
+        float4 x = lld4(lds, xs + row * XP + 4 * l32);
+        uint32_t w[4];
+        philox4x32(args.ff_drop.seed_lo, args.ff_drop.seed_hi, (uint32_t)l32, (uint32_t)(m0 + row), args.ff_drop.sid, args.ff_drop.offset, w);
+        const float d_scale = args.ff_drop.scale;
+        x.x += w[0] >= d_thr ? f.x * d_scale : 0.0f; x.y += w[1] >= d_thr ? f.y * d_scale : 0.0f;
+        x.z += w[2] >= d_thr ? f.z * d_scale : 0.0f; x.w += w[3] >= d_thr ? f.w * d_scale : 0.0f;
+        lst4(lds, xs + row * XP + 4 * l32, x);
+      }
     } else {
       // cluster: the k-tiles of the own hidden chunks only -> a partial tile; exchange with the other members
       f32x4 c0 = zero, c1 = zero;
@@ -528,14 +561,25 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
       {
         const int row = tid >> 5, l32 = tid & 31;
         float4 x = lld4(lds, xs + row * XP + 4 * l32);
+        // fixed order: every member ends with the same bits.  Without dropout the partials are added onto x + b2 one by one;
+        // with it they are summed first (f = b2 + sum of the partials is what the mask thins)
         const float4 bb = lld4(lds, p_b2 + 4 * l32);
-        x.x += bb.x; x.y += bb.y; x.z += bb.z; x.w += bb.w;
-        for (int c = 0; c < a_C; ++c) {      // fixed order: every member ends with the same bits
+        float4 f = d_thr != 0 ? bb : make_float4(x.x + bb.x, x.y + bb.y, x.z + bb.z, x.w + bb.w);
+        for (int c = 0; c < a_C; ++c) {
           const float *pp = args.xchg + ((long)tile * a_C + c) * (CR * CD) + row * CD + 4 * l32;
-          x.x += __hip_atomic_load(pp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          x.y += __hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          x.z += __hip_atomic_load(pp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          x.w += __hip_atomic_load(pp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          f.x += __hip_atomic_load(pp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          f.y += __hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          f.z += __hip_atomic_load(pp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          f.w += __hip_atomic_load(pp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (d_thr != 0) {                    // dropout on the block output: every member draws the same mask
+          uint32_t w[4];
+          philox4x32(args.ff_drop.seed_lo, args.ff_drop.seed_hi, (uint32_t)l32, (uint32_t)(m0 + row), args.ff_drop.sid, args.ff_drop.offset, w);
+          const float d_scale = args.ff_drop.scale;
+          x.x += w[0] >= d_thr ? f.x * d_scale : 0.0f; x.y += w[1] >= d_thr ? f.y * d_scale : 0.0f;
+          x.z += w[2] >= d_thr ? f.z * d_scale : 0.0f; x.w += w[3] >= d_thr ? f.w * d_scale : 0.0f;
+        } else {
+          x = f;
         }
         lst4(lds, xs + row * XP + 4 * l32, x);
       }
@@ -557,6 +601,7 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
     CHAIN_PROF(7);
     read_a(fa0, Ahat, 0);
     const int stg = Abig + wave * 256;       // this wave's 16 x 16 output tile (the hidden tile is dead by now)
+    const int a_q_cols = EXT && args.q_cols > 0 ? args.q_cols : a_nq, a_kv_cols = EXT && args.kv_cols > 0 ? args.kv_cols : a_nkv;
     for (int pj = member; pj < nq_ch + nkv_ch; pj += a_C) {
       const bool isq = pj < nq_ch;
       const int j = isq ? pj : pj - nq_ch;
@@ -571,7 +616,8 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
 #pragma unroll
       for (int r = 0; r < 4; ++r) lds[stg + (4 * fg + r) * 16 + fi] = al * v[r];
       const int srow = lane >> 2, c4 = lane & 3;
-      gst4_nt(C + (long)(m0 + srow) * ldc + j * WN + wave * 16 + 4 * c4, lld4(lds, stg + srow * 16 + 4 * c4));
+      if (!EXT || j * WN + wave * 16 < (isq ? a_q_cols : a_kv_cols)) // (staged models keep the leading columns only)
+        gst4_nt(C + (long)(m0 + srow) * ldc + j * WN + wave * 16 + 4 * c4, lld4(lds, stg + srow * 16 + 4 * c4));
       if (pj + 1 == nq_ch) CHAIN_PROF(8);
     }
   }
@@ -635,7 +681,11 @@ int launch_vfold(const VfoldMulti &v, hipStream_t s) {
 bool latent_chain_supported(int rows, int d, int hidden) { return d == CD && hidden == CHID && rows > 0 && rows % CR == 0; }
 
 int launch_latent_chain(const ChainArgs &a, hipStream_t s) {
-  HN_REQUIRE(a.rows > 0 && a.rows % CR == 0 && a.L > 0, HN_E_SHAPE, "latent_chain: rows=%d L=%d", a.rows, a.L);
+  HN_REQUIRE(a.rows > 0 && a.L > 0, HN_E_SHAPE, "latent_chain: rows=%d L=%d", a.rows, a.L);
+  HN_REQUIRE(a.dv >= 0 && a.dv <= CD && a.o_cols >= 0 && a.o_cols <= a.inner_o && a.o_cols % 4 == 0 && a.q_cols >= 0 && a.q_cols <= a.nq &&
+                 a.q_cols % 16 == 0 && a.kv_cols >= 0 && a.kv_cols <= a.nkv && a.kv_cols % 16 == 0,
+             HN_E_SHAPE, "latent_chain: valid widths dv=%d o_cols=%d q_cols=%d kv_cols=%d", a.dv, a.o_cols, a.q_cols, a.kv_cols);
+  HN_REQUIRE(a.ff_drop.thr == 0 || a.has_ff, HN_E_SHAPE, "latent_chain: dropout without a feed-forward block");
   HN_REQUIRE(a.x_in, HN_E_NULL, "latent_chain: x_in is NULL");
   auto al16 = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
   if (a.head == 1) {
@@ -666,7 +716,8 @@ int launch_latent_chain(const ChainArgs &a, hipStream_t s) {
   int dev = 0;
   HN_HIP_CHECK(hipGetDevice(&dev));
   if (dev < 0 || dev >= 64 || !configured[dev]) {
-    HN_HIP_CHECK(hipFuncSetAttribute((const void *)latent_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    HN_HIP_CHECK(hipFuncSetAttribute((const void *)latent_chain_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    HN_HIP_CHECK(hipFuncSetAttribute((const void *)latent_chain_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     if (dev >= 0 && dev < 64) configured[dev] = true;
   }
   // cluster mode for small batches (see the kernel): 4 workgroups per row tile up to 64 tiles, 2 up to 128 -- at most 256
@@ -674,9 +725,13 @@ int launch_latent_chain(const ChainArgs &a, hipStream_t s) {
   static const bool no_cluster = getenv("HN_NO_CHAIN_CLUSTER") != nullptr;
   static const int max_tiles = getenv("HN_CHAIN_CLUSTER_TILES") ? atoi(getenv("HN_CHAIN_CLUSTER_TILES")) : 128;      // development knob
   ChainArgs ac = a;
-  const int tiles = a.rows / CR;
+  const int tiles = (a.rows + CR - 1) / CR;
+  // members of a tile sit `gtiles` workgroups apart and must share an XCD (workgroups are dealt round-robin over the 8 XCDs):
+  // the member rows of the grid are rounded up to a multiple of 8 tiles, the workgroups beyond `tiles` return at once
+  const int gtiles = (tiles + 7) / 8 * 8;
   ac.cluster = 1;
-  if (!no_cluster && a.xchg && a.xflags && a.seq > 0 && a.has_ff && tiles <= max_tiles && tiles % 8 == 0 && al16(a.xchg)) {
+  ac.tiles = tiles;
+  if (!no_cluster && a.xchg && a.xflags && a.seq > 0 && a.has_ff && gtiles <= max_tiles && al16(a.xchg)) {
     // every member of every tile must be resident at once (the exchange spins): two 72 KB workgroups fit a CU
     static int cu_count[64] = {};
     if (dev >= 0 && dev < 64 && cu_count[dev] == 0) {
@@ -684,10 +739,14 @@ int launch_latent_chain(const ChainArgs &a, hipStream_t s) {
       if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 1;
       cu_count[dev] = n;
     }
-    const int cus = (dev >= 0 && dev < 64) ? cu_count[dev] : 1, C = tiles <= 64 ? 4 : 2;
-    if (tiles * C <= 2 * cus) ac.cluster = C;
+    const int cus = (dev >= 0 && dev < 64) ? cu_count[dev] : 1, C = gtiles <= 64 ? 4 : 2;
+    if (gtiles * C <= 2 * cus && gtiles * C <= CHAIN_XCHG_FLAGS - 1) ac.cluster = C;
   }
-  hipLaunchKernelGGL(latent_chain_kernel, dim3(tiles * ac.cluster), dim3(512), lds_bytes, s, ac);
+  const bool ext = a.rows % CR != 0 || (a.dv > 0 && a.dv < CD) || a.ff_drop.thr != 0 || (a.o_cols > 0 && a.o_cols < a.inner_o) ||
+                   (a.q_cols > 0 && a.q_cols < a.nq) || (a.kv_cols > 0 && a.kv_cols < a.nkv) || (ac.cluster > 1 && gtiles != tiles);
+  const dim3 grid(ac.cluster > 1 ? gtiles * ac.cluster : tiles);
+  if (ext) hipLaunchKernelGGL(latent_chain_kernel<true>, grid, dim3(512), lds_bytes, s, ac);
+  else hipLaunchKernelGGL(latent_chain_kernel<false>, grid, dim3(512), lds_bytes, s, ac);
   HN_LAUNCH_CHECK("latent_chain");
   return HN_OK;
 }

@@ -252,7 +252,16 @@ struct ChainArgs {
   // cluster mode (small batches; inference forward): exchange buffer (rows / 16 * 4 tiles of 16 x 128 floats), one flag per (tile,
   // member) + one error marker, zeroed at the start of the forward, and this chain's 1-based sequence number within the forward
   float *xchg; int *xflags; int seq;
+  // Models staged into padded images (l_d < 128, odd head widths): the operands keep the shapes above, and
+  //   dv      LayerNorm statistics over the first dv columns only (0 = 128; the pad columns of x, gamma, beta, weights are zero)
+  //   o_cols  head 1: O has o_cols valid columns (multiple of 4, <= inner_o), the rest of the contraction reads as zero (0 = inner_o)
+  //   q_cols / kv_cols  Q / KV keep their first q_cols / kv_cols columns (multiples of 16; 0 = nq / nkv): pitch ldq / ldkv
+  // rows need not be a multiple of 16: every (rows, .) operand is then ALLOCATED for rows rounded up to 16 (the tail rows are
+  // computed and stored like any other; nothing reads them).
+  int dv, o_cols, q_cols, kv_cols;
+  DropCfg ff_drop;                      // training: nn.Dropout on the feed-forward output (:347); thr == 0: off
   int cluster;                          // internal: members per row tile (launch_latent_chain decides)
+  int tiles;                            // internal: row tiles (the grid may hold idle workgroups beyond them in cluster mode)
 };
 constexpr int CHAIN_XCHG_FLOATS = 256 * 16 * 128;      // <= 256 workgroups x one partial tile
 constexpr int CHAIN_XCHG_FLAGS = 256 + 1;
@@ -281,7 +290,14 @@ struct BChainArgs {
   // cluster mode (<= 128 row tiles): two exchange buffers of (tiles * C) partial tiles, two flag sets + an error marker (zeroed at
   // the start of the backward), this chain's 1-based sequence number within the backward
   float *xchg; int *xflags; int seq;
+  // staged (padded) models, as in ChainArgs: LayerNorm over the first dv columns (0 = 128); dQ / dKV have q_cols / kv_cols valid
+  // columns (multiples of 4; 0 = nq / nkv; the rest of the contraction reads as zero), dO keeps its first o_cols columns
+  // (multiple of 16; 0 = inner_o).  rows need not be a multiple of 16 (operands allocated for the rounded-up count; the
+  // LayerNorm partial sums skip the tail rows, the weight-gradient products contract over `rows` only).
+  int dv, q_cols, kv_cols, o_cols;
+  DropCfg ff_drop;                     // the forward's dropout on the feed-forward output (thr == 0: off)
   int cluster;                         // internal
+  int tiles;                           // internal
 };
 bool latent_bchain_supported(int rows, int d, int hidden);
 int launch_latent_bchain(const BChainArgs &a, hipStream_t s);
@@ -435,14 +451,14 @@ size_t transpose_cache_floats();
 int transpose_cache_run(float *buf, size_t buf_floats, hipStream_t s);
 int launch_ln_bwd(const float *x, const float *dy, const float *gamma, long rows, int d, float *dx, int dx_accumulate,
                   float *dgamma, float *dbeta, float *scratch, hipStream_t s);
-int launch_ln_fwd(const float *x, const float *gamma, const float *beta, long rows, int d, float *y, hipStream_t s);
+int launch_ln_fwd(const float *x, const float *gamma, const float *beta, long rows, int d, float *y, hipStream_t s, int dv = 0);
 int launch_leaky_bwd(const float *dy, const float *x_out, const float *x_in, float *dpre, long n, hipStream_t s);
 int launch_glu_bwd(float *u, const float *dh, float *h_out, long rows, int hid, int gelu, hipStream_t s);
 int launch_add_into(const float *src, float *dst, long n, int accumulate, hipStream_t s);
 size_t head_bwd_scratch_floats(int b, int d, int out_dims);
 int launch_head_bwd(const float *x, int b, int L, int d, const float *nw, const float *nb, const float *w, int out_dims,
                     const float *dlogits, float *dx, float *dnw, float *dnb, float *dw, float *dbias, float *scratch,
-                    hipStream_t s);
+                    hipStream_t s, int dv = 0);
 
 // ------------------------------------------------------------------------------------------------
 // attention backward (attention_bwd.hip)
@@ -482,8 +498,14 @@ int launch_segsum(const float *X, int seg, int cols, int nseg, float *out, hipSt
 // misc
 int launch_broadcast_rows(const float *src, float *dst, long n_per, int b, hipStream_t s, int *zero = nullptr, int nzero = 0);
 int launch_head(const float *x, int b, int L, int d, const float *nw, const float *nb, const float *w,
-                const float *bias, int out_dims, float *logits, hipStream_t s);
+                const float *bias, int out_dims, float *logits, hipStream_t s, int dv = 0);
 int launch_pad_rows(const float *src, int ld_src, float *dst, int ld_dst, long rows, int cols, hipStream_t s);
+// Staged models (api.hip): a table of 2-D pieces in ONE launch -- dst[r, c] (+)= r < rows_src && c < cols_src ? src[r, c] : 0 over
+// the piece's (rows_dst, cols_dst) rectangle.  Weights into their zero-padded images, padded gradients back onto the real ones.
+struct StagePiece { const float *src; float *dst; int rows_src, cols_src, ld_src, rows_dst, cols_dst, ld_dst; };
+constexpr int STAGE_MAX = 84;
+struct StageTable { int n, accumulate; StagePiece p[STAGE_MAX]; };
+int launch_stage(const StageTable &t, hipStream_t s);
 int launch_add_row_broadcast(const float *y, const float *x_in, float *x_out, int b, int L, int d, hipStream_t s);
 int launch_fill(float *dst, float value, long n, hipStream_t s);
 

@@ -40,6 +40,34 @@ int launch_pad_rows(const float *src, int ld_src, float *dst, int ld_dst, long r
   return HN_OK;
 }
 
+// blockIdx.y = piece; the piece's destination rectangle in 256-thread strides (common.h: StageTable)
+__global__ __launch_bounds__(256) void stage_kernel(const StageTable t) {
+  const StagePiece &p = t.p[blockIdx.y];
+  const long total = (long)p.rows_dst * p.cols_dst;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / p.cols_dst), c = (int)(i - (long)r * p.cols_dst);
+    const float v = (r < p.rows_src && c < p.cols_src) ? p.src[(long)r * p.ld_src + c] : 0.0f;
+    float *d = p.dst + (long)r * p.ld_dst + c;
+    *d = t.accumulate ? *d + v : v;
+  }
+}
+
+int launch_stage(const StageTable &t, hipStream_t s) {
+  HN_REQUIRE(t.n >= 0 && t.n <= STAGE_MAX, HN_E_SHAPE, "stage: %d pieces", t.n);
+  if (t.n == 0) return HN_OK;
+  long biggest = 1;
+  for (int i = 0; i < t.n; ++i) {
+    const long e = (long)t.p[i].rows_dst * t.p[i].cols_dst;
+    if (e > biggest) biggest = e;
+  }
+  long blocks = ceil_div_ll(biggest, 1024);
+  if (blocks > 64) blocks = 64;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(stage_kernel, dim3((unsigned)blocks, t.n), dim3(256), 0, s, t);
+  HN_LAUNCH_CHECK("stage");
+  return HN_OK;
+}
+
 // x_out[b, l, :] = y[b, :] (+ x_in[b, l, :]) -- epilogue of the one-token attention path
 __global__ __launch_bounds__(256) void add_row_broadcast_kernel(const float *__restrict__ y, const float *x_in,
                                                                 float *x_out, int L, int d, long total) {
@@ -111,7 +139,8 @@ int launch_fill_bytes(uint8_t *dst, uint8_t value, long n, hipStream_t s) {
 // One workgroup per sample: column means over the L latent rows -> LayerNorm(d) -> Linear(d, out).
 __global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ x, int L, int d, const float *__restrict__ nw,
                                                    const float *__restrict__ nb, const float *__restrict__ w,
-                                                   const float *__restrict__ bias, int out_dims, float *__restrict__ logits) {
+                                                   const float *__restrict__ bias, int out_dims, float *__restrict__ logits, int dv) {
+  // dv: LayerNorm statistics over the first dv columns (staged models: the pad columns of x, gamma, beta, w are zero)
   extern __shared__ float sm[];  // pooled[d] + 8 scratch + 4 x d partial column sums
   float *pooled = sm;
   float *red = sm + d;
@@ -157,16 +186,16 @@ __global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ x, 
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
   if ((tid & 63) == 0) red[tid >> 6] = s;
   __syncthreads();
-  const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)d;
+  const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)dv;
   __syncthreads();
   float q = 0.0f;
-  for (int c = tid; c < d; c += blockDim.x) { float t = pooled[c] - mean; q += t * t; }
+  for (int c = tid; c < dv; c += blockDim.x) { float t = pooled[c] - mean; q += t * t; }
   for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
   if ((tid & 63) == 0) red[tid >> 6] = q;
   __syncthreads();
-  const float rstd = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)d + 1e-5f);
+  const float rstd = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)dv + 1e-5f);
   __syncthreads();
-  for (int c = tid; c < d; c += blockDim.x) pooled[c] = (pooled[c] - mean) * rstd * nw[c] + nb[c];
+  for (int c = tid; c < d; c += blockDim.x) pooled[c] = c < dv ? (pooled[c] - mean) * rstd * nw[c] + nb[c] : 0.0f;
   __syncthreads();
   const int wave = tid >> 6, lane = tid & 63;
   for (int o = wave; o < out_dims; o += 4) {
@@ -178,12 +207,13 @@ __global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ x, 
 }
 
 int launch_head(const float *x, int b, int L, int d, const float *nw, const float *nb, const float *w, const float *bias,
-                int out_dims, float *logits, hipStream_t s) {
+                int out_dims, float *logits, hipStream_t s, int dv) {
   HN_REQUIRE(x && nw && nb && w && logits, HN_E_NULL, "head: NULL pointer");
-  HN_REQUIRE(b > 0 && L > 0 && d > 0 && out_dims > 0, HN_E_SHAPE, "head: b=%d L=%d d=%d out=%d", b, L, d, out_dims);
+  HN_REQUIRE(b > 0 && L > 0 && d > 0 && out_dims > 0 && dv >= 0 && dv <= d, HN_E_SHAPE, "head: b=%d L=%d d=%d out=%d valid=%d", b, L, d, out_dims, dv);
+  if (dv == 0) dv = d;
   size_t lds = (size_t)(d + 8 + (4 * d > 1024 ? 4 * d : 1024)) * sizeof(float);     // pooled + scratch + row-group partials
   HN_REQUIRE(lds <= 64 * 1024, HN_E_UNSUPPORTED, "head: l_d=%d too large", d);
-  hipLaunchKernelGGL(head_kernel, dim3(b), dim3(256), lds, s, x, L, d, nw, nb, w, bias, out_dims, logits);
+  hipLaunchKernelGGL(head_kernel, dim3(b), dim3(256), lds, s, x, L, d, nw, nb, w, bias, out_dims, logits, dv);
   HN_LAUNCH_CHECK("head");
   return HN_OK;
 }

@@ -111,6 +111,11 @@ typedef struct hn_attn_params {
   const float *b_out;     /* to_out.0.bias    (query_dim)                                      */
   float dropout;          /* nn.Dropout on the attention probabilities (:381,:421); training entry points only,  */
   hn_rng rng;             /* 0 = off.  rng: see hn_rng (the fused entry points override it per block)            */
+  /* STAGED layout (0 = off; see "Staged models" below): the block's weights are zero-padded images of a narrower block -- */
+  int dim_head_valid;     /* the softmax scale is dim_head_valid^-1/2; columns [dim_head_valid, dim_head) of every head are zero  */
+  int query_dim_valid;    /* LayerNorm statistics over the first query_dim_valid columns of x; != 0 also promises the padded
+                           * allocation: with ip = heads*dim_head rounded up to 128, w_q has ip rows, w_out row pitch ip, a
+                           * latent self-attention's w_kv 2*heads*dim_head rounded up to 128 rows (the pad entries zero)   */
 } hn_attn_params;
 
 /* y = LeakyReLU_0.01( concat_h( softmax(2 * dim_head^-1/2 * Q_h K_h^T) V_h ) W_out^T + b_out )  [+ x_in]
@@ -185,6 +190,7 @@ typedef struct hn_ff_params {
   const float *w1, *b1, *w2, *b2;
   float dropout;       /* nn.Dropout on the block output before the residual (:347); 0 = off                    */
   hn_rng rng;
+  int dim_valid;       /* staged layout (0 = off): LayerNorm statistics over the first dim_valid columns                 */
 } hn_ff_params;
 
 int hn_ff_fwd(const hn_ff_params *p, const float *x_in, float *x_out, int residual, int rows,
@@ -264,6 +270,7 @@ typedef struct hn_model {
   const float *head_norm_w, *head_norm_b, *head_w, *head_b;
   int core_precision;            /* hn_core_precision (inference forward only)                  */
   hn_rng rng;                    /* dropout generator state of hn_fusion_forward_train / _backward (stream unused) */
+  int l_d_valid;                 /* staged layout (0 = off): the head's LayerNorm covers the first l_d_valid columns  */
 } hn_model;
 
 /* Optional timing hooks: when non-NULL, hn_fusion_forward records ev_start[i] / ev_stop[i]
