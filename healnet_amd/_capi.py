@@ -141,6 +141,7 @@ SIGNATURES = {
     "hn_fusion_forward": (C.c_int, [C.POINTER(Model), C.POINTER(ModalityInput), C.c_int, C.c_void_p, C.c_int, C.c_int,
                                     C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p, C.c_size_t,
                                     C.c_void_p, C.POINTER(Profile)]),
+    "hn_fusion_is_staged": (C.c_int, [C.POINTER(Model)]),
     "hn_fusion_tape_bytes": (C.c_size_t, [C.POINTER(Model), C.POINTER(ModalityInput), C.c_int, C.c_int, C.c_int]),
     "hn_fusion_tape_layout": (C.c_int, [C.POINTER(Model), C.POINTER(ModalityInput), C.c_int, C.c_int, C.c_int,
                                         C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),

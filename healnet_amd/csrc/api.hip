@@ -2458,6 +2458,8 @@ static thread_local Stager g_stager;
 
 extern "C" {
 
+int hn_fusion_is_staged(const hn_model *m) { return stage_wanted(m) ? 1 : 0; }
+
 size_t hn_fusion_workspace_bytes(const hn_model *m, const hn_modality_input *in, int b) {
   if (!stage_wanted(m)) return impl_fusion_workspace_bytes(m, in, b);
   Stager &st = g_stager;

@@ -527,6 +527,12 @@ class HealNet(nn.Module):
         r = None if rng is None else torch.tensor([_wrap64(rng[0]), int(rng[1])], dtype=torch.int64)
         return _ops.spec_of(self._spec_text).model(list(self.parameters()), r)
 
+    def runs_staged(self) -> bool:
+        """True when the fused entry points run this model as its zero-padded image (include/healnet_hip.h "Staged models": the
+        reference's tuned shapes -- odd latent widths, one narrow cross head, a latent count that is not a multiple of 16)."""
+        model, keep = self._descriptor()
+        return bool(_capi.lib().hn_fusion_is_staged(C.byref(model)))
+
     def _check_mode(self) -> None:
         if self.self_per_cross_attn >= 2:
             raise ValueError("self_per_cross_attn >= 2 fails in the reference as well (healnet.py:242: "

@@ -299,6 +299,21 @@ int hn_fusion_forward(const hn_model *model, const hn_modality_input *inputs, in
                       hn_profile *profile);
 size_t hn_fusion_workspace_bytes(const hn_model *model, const hn_modality_input *inputs, int b);
 
+/* Staged models.  The fused latent side (chain.hip / bchain.hip) is built for l_d = 128, head widths of 16 / 32 / 64 / 128, inner
+ * widths that are multiples of 128 and 16-row tiles.  A model outside those shapes that fits them after ZERO PADDING -- l_d <= 128,
+ * every head width <= 128 with heads * padded width <= 512 (the reference's tuned TCGA shapes: config/best_hyperparams.yml) -- is
+ * run by hn_fusion_forward / _forward_train / _backward as its padded image: one launch per forward copies the latent-side weights
+ * into a zero-padded shadow inside the workspace (a training forward: on the tape, for its backward), the shadow model runs the
+ * fast path with its LayerNorms over the valid width and the softmax scale of the valid head width, and embeddings / trace
+ * slots / gradients come back in the model's own shapes (the padded gradients are accumulated onto the real ones at the end of the
+ * backward; gradient-readiness signals then fire after that launch).  Exact: pad entries are zero and stay zero.  The
+ * workspace / tape size queries account for it.  hn_fusion_is_staged tells which route a descriptor takes (1 / 0).
+ * A host that keeps padded weights itself can skip the per-forward copy by passing the padded descriptor directly: l_d = 128 with
+ * hn_model.l_d_valid, hn_attn_params.dim_head_valid / query_dim_valid, hn_ff_params.dim_valid set (layout: see those fields;
+ * w1 rows [0, 4 l_d) -> [0, 512) and [4 l_d, 8 l_d) -> [512, 1024), every buffer of b * l_c rows allocated for the count rounded up
+ * to 16).  HN_NO_STAGING=1 (environment, development): the generic per-block route instead. */
+int hn_fusion_is_staged(const hn_model *model);
+
 /* ---------------------------------------------------------------------------------------------
  * Training: forward that records a tape, and the matching backward   (autograd of HealNet.forward :190-250, driven by
  * surv_loss.backward() at healnet/main.py:464).  The tape holds the latent array before every executed block, the
