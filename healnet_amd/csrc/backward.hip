@@ -468,6 +468,41 @@ __global__ __launch_bounds__(256) void splitk_reduce_alpha_kernel(const float *_
   }
 }
 
+constexpr long TN_SCRATCH_MIN_FLOATS = 4L << 20;      // 16 MB: floor of every split-k scratch buffer (reduce_scratch_floats)
+// Many slices of a small output (launch_gemm_tn: up to 128): one thread per element walking all slices is a chain of ~30 dependent
+// loads on a hundred workgroups.  Here a workgroup takes 64 elements and its four waves a quarter of the slices each (two
+// independent chains per wave), folded through LDS in a fixed order: deterministic, 4x the loads in flight.
+__global__ __launch_bounds__(256) void splitk_reduce_wide_kernel(const float *__restrict__ part, int nsplit, long mn, int N,
+                                                                 float *__restrict__ C, long ldc, float alpha, int accumulate,
+                                                                 const float *__restrict__ cs_part, int M, float *__restrict__ cs_out,
+                                                                 int cs_accumulate) {
+  __shared__ float red[4][64];
+  const int li = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long total = mn + (cs_part ? M : 0);
+  const long i = (long)blockIdx.x * 64 + li;
+  float c0 = 0.0f, c1 = 0.0f;
+  if (i < total) {
+    const bool is_cs = i >= mn;
+    const float *src = is_cs ? cs_part + (i - mn) : part + i;
+    const long stride = is_cs ? M : mn;
+    int k = w;
+    for (; k + 4 < nsplit; k += 8) { c0 += src[(long)k * stride]; c1 += src[(long)(k + 4) * stride]; }
+    if (k < nsplit) c0 += src[(long)k * stride];
+  }
+  red[w][li] = c0 + c1;
+  __syncthreads();
+  if (w == 0 && i < total) {
+    const float acc = (red[0][li] + red[1][li]) + (red[2][li] + red[3][li]);
+    if (i >= mn) {
+      const int m = (int)(i - mn);
+      cs_out[m] = cs_accumulate ? cs_out[m] + acc : acc;
+    } else {
+      float *dst = C + (i / N) * ldc + (i % N);
+      *dst = accumulate ? *dst + alpha * acc : alpha * acc;
+    }
+  }
+}
+
 static int launch_gemm_tn(const float *A, long lda, const float *B, long ldb, float *C, long ldc, int M, int N, int K, float alpha,
                           int accumulate, float *scratch, hipStream_t s, float *colsum = nullptr, int colsum_accumulate = 0,
                           int batch = 1, long strideA = 0, long strideB = 0, long strideC = 0) {
@@ -479,7 +514,14 @@ static int launch_gemm_tn(const float *A, long lda, const float *B, long ldb, fl
                                                                 // never a few leftovers in a second one (784 of 768 cost 40 %)
     const int max_by_k = ceil_div(K, 64);                       // at least 64 rows per slice
     if (nsplit > max_by_k) nsplit = max_by_k;
-    if (nsplit > GEMM_EX_SPLITS) nsplit = GEMM_EX_SPLITS;
+    // Small outputs over a long contraction (G = dKV^T z of ONE 16 .. 64-wide head over 32 768 patch rows: 32 x 773) have few tiles:
+    // with 32 slices 224 workgroups stream the 101 MB operand at 1.2 TB/s (89 us).  Every scratch buffer holds at least
+    // TN_SCRATCH_MIN_FLOATS (reduce_scratch_floats), so such a product may take up to 128 slices -- a full round of workgroups.
+    int cap = GEMM_EX_SPLITS;
+    const long per = ((long)M * N + (colsum ? M : 0)) * batch;
+    if (batch == 1 && per * GEMM_EX_SPLITS < TN_SCRATCH_MIN_FLOATS) { const long c2 = TN_SCRATCH_MIN_FLOATS / per; cap = (int)(c2 < 128 ? c2 : 128); }
+    if (cap < GEMM_EX_SPLITS) cap = GEMM_EX_SPLITS;
+    if (nsplit > cap) nsplit = cap;
     if (nsplit < 1) nsplit = 1;
   }
   GemmTnArgs g;
@@ -503,6 +545,12 @@ static int launch_gemm_tn(const float *A, long lda, const float *B, long ldb, fl
   HN_LAUNCH_CHECK("gemm_tn");
   if (g.nsplit > 1) {
     const long mn = (long)M * N;
+    if (g.nsplit > GEMM_EX_SPLITS && batch == 1) {
+      hipLaunchKernelGGL(splitk_reduce_wide_kernel, dim3((unsigned)ceil_div_ll(mn + (colsum ? M : 0), 64)), dim3(256), 0, s, scratch, g.nsplit, mn, N,
+                         C, ldc, alpha, accumulate, colsum ? g.colsum : nullptr, M, colsum, colsum_accumulate);
+      HN_LAUNCH_CHECK("splitk_reduce_wide");
+      return HN_OK;
+    }
     long blocks = ceil_div_ll(mn + (colsum ? M : 0), 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(splitk_reduce_alpha_kernel, dim3((unsigned)blocks, batch), dim3(256), 0, s, scratch, g.nsplit, mn, N, C, ldc, alpha,
@@ -774,7 +822,8 @@ int launch_colsum(const float *X, long ld, long rows, int cols, float scale, flo
 size_t reduce_scratch_floats(long max_mn, int max_cols) {
   const size_t a = (size_t)GEMM_EX_SPLITS * (max_mn + max_cols), c = (size_t)COLSUM_CHUNKS * max_cols;   // split-k partials (+ colsum partials)
   // (kv_weight_grads needs 2 * KVG_CHUNKS * D floats: covered by a, since max_mn >= 2 * inner * D)
-  return a > c ? a : c;
+  const size_t m = a > c ? a : c;
+  return m > (size_t)TN_SCRATCH_MIN_FLOATS ? m : (size_t)TN_SCRATCH_MIN_FLOATS;      // (launch_gemm_tn: up to 128 slices of small outputs)
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -823,6 +823,111 @@ int launch_gemm_skinny_multi(const GemmSkinnyMulti &g, hipStream_t s) {
   return HN_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Tall and narrow: C (M, N <= 128) = alpha * pro(A) W^T with M in the tens of thousands -- the K/V projection of a patch bag
+// through ONE 16 .. 64-wide head (the reference's tuned configs: 32 768 x 773 -> 32 / 64 / 128 columns).  The product is an HBM
+// stream of A (101 MB, 1.6 GFLOP at N = 32): what matters is bytes in flight, not tiles.  On the 128 x 128 kernel above 256
+// workgroups each keep 8 KB of A in flight behind a barrier per k-step: 1.3 TB/s (79 us).  Here a wave owns 16 rows and reads
+// them straight into registers with 16-byte loads, one 64-column chunk ahead (no LDS, no barrier on the A side); the MFMA
+// 16x16x4 contracts k = 4 g + e in its e-th issue, so a lane's float4 IS its A operand of four consecutive MFMAs and the same
+// holds for a float4 of a W row on the B side.  W (any alignment) is staged per chunk in LDS with dword loads, double-buffered.
+// 64 rows per workgroup, 17 - 70 KB of LDS: 2 - 4 workgroups per CU.
+// ------------------------------------------------------------------------------------------------
+template <int NT, int KC>      // N <= 16 * NT; k-chunk of KC columns (NT = 8: 32, the static LDS limit)
+__global__ __launch_bounds__(256) void gemm_tall_narrow_kernel(GemmArgs g) {
+  constexpr int WP = KC + 4, NW = 16 * NT, NJ = KC / 16, WQ = NW * KC / 256;
+  __shared__ __attribute__((aligned(16))) float Ws[2][NW * WP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, gq = lane >> 4;
+  const long row0 = (long)blockIdx.x * 64 + wave * 16;
+  const long arow_i = row0 + i < g.M ? row0 + i : g.M - 1;
+  const float *arow = g.A + arow_i * g.lda;
+  const int nchunks = (g.K + KC - 1) / KC;
+  const bool affine = g.pro == PRO_AFFINE;
+
+  auto load_a = [&](int c, float4 (&a)[NJ]) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int k = c * KC + 16 * j + 4 * gq;
+      // (a float4 past K stays inside the row's pitch or the next row; clamped to the last whole quad of the row)
+      const int kl = k + 4 <= g.lda ? k : (int)g.lda - 4;
+      float4 v = *(const float4 *)(arow + kl);
+      if (kl != k) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (affine) {
+        const float4 ga = k + 4 <= g.K ? *(const float4 *)(g.gamma + k) : make_float4(k < g.K ? g.gamma[k] : 0.f, k + 1 < g.K ? g.gamma[k + 1] : 0.f, k + 2 < g.K ? g.gamma[k + 2] : 0.f, 0.f);
+        const float4 be = k + 4 <= g.K ? *(const float4 *)(g.beta + k) : make_float4(k < g.K ? g.beta[k] : 0.f, k + 1 < g.K ? g.beta[k + 1] : 0.f, k + 2 < g.K ? g.beta[k + 2] : 0.f, 0.f);
+        v.x = v.x * ga.x + be.x; v.y = v.y * ga.y + be.y; v.z = v.z * ga.z + be.z; v.w = v.w * ga.w + be.w;
+      }
+      // columns past K contribute nothing whatever the buffer holds there
+      v.x = k < g.K ? v.x : 0.0f; v.y = k + 1 < g.K ? v.y : 0.0f; v.z = k + 2 < g.K ? v.z : 0.0f; v.w = k + 3 < g.K ? v.w : 0.0f;
+      a[j] = v;
+    }
+  };
+  // W chunk c: NW rows x 64 columns, thread t takes elements t, t + 256, ... (a row's 64 floats are contiguous: coalesced)
+  float wreg[WQ];
+  auto load_w = [&](int c) {
+#pragma unroll
+    for (int q = 0; q < WQ; ++q) {
+      const int idx = tid + 256 * q, n = idx / KC, kk = idx % KC, k = c * KC + kk;
+      wreg[q] = (n < g.N && k < g.K) ? g.W[(long)n * g.ldw + k] : 0.0f;
+    }
+  };
+  auto store_w = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < WQ; ++q) {
+      const int idx = tid + 256 * q;
+      Ws[buf][(idx / KC) * WP + (idx % KC)] = wreg[q];
+    }
+  };
+
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // One chunk ahead in registers.  Measured at 32 768 x 773 -> 32 (profiles/r03_zc_*): 54 us = 1.9 TB/s against 79 us on the
+  // 128 x 128 kernel; three chunks in flight per wave: 62 us; 208-column chunks (832 contiguous bytes per row and wave, 256
+  // VGPRs): 103 us.  What is left is not latency: the wave count is fixed at M / 16 (two per SIMD) and every load instruction
+  // touches 16 rows 3 KB apart.
+  float4 a_cur[NJ], a_nxt[NJ];
+  load_a(0, a_cur);
+  load_w(0);
+  store_w(0);
+  __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    const int buf = c & 1;
+    const bool more = c + 1 < nchunks;
+    if (more) { load_a(c + 1, a_nxt); load_w(c + 1); }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float4 bw = *(const float4 *)&Ws[buf][(16 * t + i) * WP + 16 * j + 4 * gq];
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[j].x, bw.x, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[j].y, bw.y, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[j].z, bw.z, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[j].w, bw.w, acc[t], 0, 0, 0);
+      }
+    }
+    if (more) {
+      store_w(buf ^ 1);                      // (the other buffer: its readers passed the barrier of the previous iteration)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) a_cur[j] = a_nxt[j];
+    }
+    __syncthreads();
+  }
+  // accumulator element r: row 4 gq + r, column 16 t + i
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int n = 16 * t + i;
+    if (n >= g.N) continue;
+    const int col = g.col_group > 0 ? (n / g.col_group) * g.col_group_pitch + n % g.col_group : n;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long row = row0 + 4 * gq + r;
+      if (row < g.M) g.C[row * g.ldc + col] = g.alpha * acc[t][r];
+    }
+  }
+}
+
 static bool aligned_eligible(const GemmArgs &g) {
   auto al16 = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
   if (g.K % 4 != 0 || g.lda % 4 != 0 || g.ldw % 4 != 0) return false;
@@ -866,6 +971,18 @@ int launch_gemm(const GemmArgs &g_in, hipStream_t s) {
   if ((g.M <= 32 || (g.M <= 512 && !aligned_eligible(g))) && !glu && g.pro != PRO_LAYERNORM && g.K >= 512) {
     hipLaunchKernelGGL(gemm_skinny_kernel, dim3(ceil_div(g.N, 4), ceil_div(g.M, 32), g.batch), dim3(256), 0, s, g);
     HN_LAUNCH_CHECK("gemm_skinny");
+    return HN_OK;
+  }
+  // tall and narrow (one 16 .. 64-wide head over a patch bag): the register-streaming kernel
+  static const bool no_tall = getenv("HN_NO_TALL_NARROW") != nullptr;      // development switch
+  if (!no_tall && !glu && g.batch == 1 && (g.pro == PRO_NONE || g.pro == PRO_AFFINE) && g.M >= 2048 && g.K >= 128 && g.N >= 16 && g.N <= 128 &&
+      !g.bias && !g.R && g.act == ACT_NONE && g.lda % 4 == 0 && g.lda >= 4 && ((uintptr_t)g.A & 15) == 0 &&
+      (g.pro == PRO_NONE || (((uintptr_t)g.gamma | (uintptr_t)g.beta) & 15) == 0)) {
+    const dim3 grid((unsigned)ceil_div(g.M, 64));
+    if (g.N <= 32) hipLaunchKernelGGL((gemm_tall_narrow_kernel<2, 64>), grid, dim3(256), 0, s, g);
+    else if (g.N <= 64) hipLaunchKernelGGL((gemm_tall_narrow_kernel<4, 64>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((gemm_tall_narrow_kernel<8, 32>), grid, dim3(256), 0, s, g);
+    HN_LAUNCH_CHECK("gemm_tall_narrow");
     return HN_OK;
   }
   // (N >= 256, or from 32 columns when the operands are not 16-byte aligned -- one cross head of 16 .. 103 on a 773-channel patch

@@ -30,6 +30,7 @@ from __future__ import annotations
 import ctypes as C
 import functools
 import json
+import os
 import threading
 from typing import Dict, List, Optional, Sequence
 
@@ -68,6 +69,7 @@ _lib.define("fusion_backward(Tensor dout, Tensor tape, Tensor?[] tensors, Tensor
 _lib.define("fusion_backward_into(Tensor dout, Tensor tape, Tensor?[] tensors, Tensor? mask, Tensor[] params, str spec, "
             "int skip_self, bool embeddings, Tensor? rng, Tensor(a!) grad_buffer, int[] grad_offsets) -> ()")
 
+_NO_HOST_CACHE = os.environ.get("HN_NO_HOST_CACHE", "0") == "1"      # development switch: size / layout queries on every call
 _FAKE_PTR = 256          # stands in for device addresses while tracing with FakeTensors (size queries only, nothing is launched)
 
 
@@ -163,6 +165,48 @@ class Spec:
             for p in params:
                 _ptr(p)                                  # the dtype / contiguity checks of the uncached route
             hit = cache[key] = self.model(params)
+        return hit
+
+    def model_train_cached(self, params: Sequence[torch.Tensor], rng: Optional[torch.Tensor]):
+        """Descriptor of a training forward / its backward, memoised like ``model_cached``: with dropout the blocks carry their
+        rates and only the generator state (seed, per-forward offset) changes from call to call -- it is patched into the cached
+        struct.  (At the reference's tuned TCGA shapes a training step is ~90 launches of 5-50 us: rebuilding ~125 pointer fields
+        through ctypes twice per step was a fifth of the host time that bounds it.)"""
+        if rng is None:
+            return self.model_cached(params)
+        key = ("drop",) + tuple(p.data_ptr() for p in params)
+        cache = self.__dict__.setdefault("_model_cache", {})
+        hit = cache.get(key)
+        if hit is None:
+            if len(cache) >= 8:
+                cache.clear()
+            hit = cache[key] = self.model(params, rng)
+        model = hit[0]
+        model.rng.seed, model.rng.offset = int(rng[0]) & 0xFFFFFFFFFFFFFFFF, int(rng[1]) & 0xFFFFFFFF
+        return hit
+
+    def grads_cached(self, gptr: Sequence[Optional[int]]):
+        key = tuple(gptr)
+        cache = self.__dict__.setdefault("_grads_cache", {})
+        hit = cache.get(key)
+        if hit is None:
+            if len(cache) >= 8:
+                cache.clear()
+            hit = cache[key] = self.grads(gptr)
+        return hit
+
+    def sizes_cached(self, kind: str, key, compute):
+        """Workspace / tape sizes and the tape layout of one call shape (they depend on the structure, the batch, the input shapes
+        and whether blocks drop -- not on addresses): each is a planning pass inside the library."""
+        if _NO_HOST_CACHE:
+            return compute()
+        cache = self.__dict__.setdefault("_size_cache", {})
+        k = (kind, key)
+        hit = cache.get(k)
+        if hit is None:
+            if len(cache) >= 64:
+                cache.clear()
+            hit = cache[k] = compute()
         return hit
 
     def grads(self, gptr: Sequence[Optional[int]]):
@@ -658,7 +702,8 @@ def _fusion_forward(tensors, mask, params, spec, skip_self, embeddings, keep_sta
     with torch.cuda.device(device):        # kernels are launched on the CURRENT device of the calling thread
         model, keep = sp.model_cached(params)
         inp, held, b = sp.inputs(tensors)
-        need = lib.hn_fusion_workspace_bytes(C.byref(model), inp, b)
+        shape_key = (b, tuple(None if t is None else (tuple(t.shape), t.dtype) for t in held))
+        need = sp.sizes_cached("fwd", shape_key, lambda: lib.hn_fusion_workspace_bytes(C.byref(model), inp, b))
         if need == 0:
             _capi.check(-1, "hn_fusion_workspace_bytes")
         ws = WS.get(device, need)
@@ -711,11 +756,12 @@ def _fusion_forward_train(tensors, mask, params, spec, skip_self, embeddings, rn
     sp = spec_of(spec)
     device = params[0].device
     with torch.cuda.device(device):
-        model, keep = sp.model(params, rng)
+        model, keep = sp.model_train_cached(params, rng)
         inp, held, b = sp.inputs(tensors)
         masked = int(mask is not None)
-        tape_bytes = lib.hn_fusion_tape_bytes(C.byref(model), inp, b, masked, int(skip_self))
-        need = lib.hn_fusion_workspace_bytes(C.byref(model), inp, b)
+        shape_key = (b, masked, int(skip_self), rng is not None, tuple(None if t is None else (tuple(t.shape), t.dtype) for t in held))
+        tape_bytes, need = sp.sizes_cached("train", shape_key, lambda: (
+            lib.hn_fusion_tape_bytes(C.byref(model), inp, b, masked, int(skip_self)), lib.hn_fusion_workspace_bytes(C.byref(model), inp, b)))
         if tape_bytes == 0 or need == 0:
             _capi.check(-1, "hn_fusion_tape_bytes")
         tape = torch.empty(tape_bytes, dtype=torch.uint8, device=device)
@@ -726,10 +772,12 @@ def _fusion_forward_train(tensors, mask, params, spec, skip_self, embeddings, rn
                                                 _stream_ptr(device)), "hn_fusion_forward_train")
         # where the tape keeps every attention block's softmax statistics / input (float offsets; -1 = block not executed):
         # the host views them in place for Attention.attn_weights -- laid out with THIS call's descriptor (dropout included)
-        so, xo = (C.c_size_t * sp.n_slots)(), (C.c_size_t * sp.n_slots)()
-        _capi.check(lib.hn_fusion_tape_layout(C.byref(model), inp, b, masked, int(skip_self), so, xo), "hn_fusion_tape_layout")
-        none = C.c_size_t(-1).value
-        layout = torch.tensor([-1 if v == none else int(v) for v in list(so) + list(xo)], dtype=torch.int64)
+        def _layout():
+            so, xo = (C.c_size_t * sp.n_slots)(), (C.c_size_t * sp.n_slots)()
+            _capi.check(lib.hn_fusion_tape_layout(C.byref(model), inp, b, masked, int(skip_self), so, xo), "hn_fusion_tape_layout")
+            none = C.c_size_t(-1).value
+            return torch.tensor([-1 if v == none else int(v) for v in list(so) + list(xo)], dtype=torch.int64)
+        layout = sp.sizes_cached("layout", shape_key, _layout).clone()      # (a fresh tensor per call: autograd owns the outputs)
     return out, tape, layout
 
 
@@ -750,11 +798,12 @@ def _run_fusion_backward(dout, tape, tensors, mask, params, spec, skip_self, emb
     lib = _capi.lib()
     sp = spec_of(spec)
     device = params[0].device
-    model, keep = sp.model(params, rng)
+    model, keep = sp.model_train_cached(params, rng)
     inp, held, b = sp.inputs(tensors)
-    grads, keep_g = sp.grads(gptr)
+    grads, keep_g = sp.grads_cached(gptr)
     masked = int(mask is not None)
-    need = lib.hn_fusion_backward_workspace_bytes(C.byref(model), inp, b, masked)
+    shape_key = (b, masked, rng is not None, tuple(None if t is None else (tuple(t.shape), t.dtype) for t in held))
+    need = sp.sizes_cached("bwd", shape_key, lambda: lib.hn_fusion_backward_workspace_bytes(C.byref(model), inp, b, masked))
     if need == 0:
         _capi.check(-1, "hn_fusion_backward_workspace_bytes")
     ws = WS.get(device, need)

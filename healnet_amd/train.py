@@ -128,7 +128,9 @@ class FlatParameters:
         ``grads`` (-1: not trainable), or None when some trainable parameter's ``.grad`` is not its slot of the flat buffer
         (set_to_none zeroing, a foreign ``.grad``) -- the backward then returns ordinary gradients to autograd and
         ``relink()`` repairs the layout before the next optimizer step."""
-        slot = {id(p): off for p, off in zip(self.views, self.offsets)}
+        slot = self.__dict__.get("_slot_of")
+        if slot is None:
+            slot = self._slot_of = {id(p): off for p, off in zip(self.views, self.offsets)}
         base = self.grads.data_ptr()
         out = []
         for p in params:
