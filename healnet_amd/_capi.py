@@ -12,7 +12,7 @@ import sys
 from typing import Optional
 
 HN_MAX_AXES = 4
-HN_ABI_VERSION = 4
+HN_ABI_VERSION = 5
 HN_F32, HN_BF16, HN_U8 = 0, 1, 2
 HN_CORE_F32, HN_CORE_BF16, HN_CORE_BF16X3 = 0, 1, 2
 _HERE = os.path.dirname(os.path.abspath(__file__))

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HN_ABI_VERSION 4
+#define HN_ABI_VERSION 5
 #define HN_MAX_AXES 4
 
 typedef enum hn_status {

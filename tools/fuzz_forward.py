@@ -106,6 +106,22 @@ def random_case(rng):
     return kw, shapes, b, masked
 
 
+def random_case_staged(rng):
+    """Shapes outside the latent chains' own that FIT them after zero padding (staged models) -- odd latent widths
+    up to 128, any latent count, odd head widths with heads * padded width <= 512 -- over the small case's modality mixes."""
+    kw, shapes, b, masked = random_case(rng)
+
+    def heads_dim():
+        dh = rng.choice([5, 11, 16, 20, 27, 31, 48, 63, 64, 103, 127])
+        dhp = 16 if dh <= 16 else 32 if dh <= 32 else 64 if dh <= 64 else 128
+        return rng.choice([h for h in (1, 2, 3, 4, 8) if h * dhp <= 512]), dh
+    xh, xd = heads_dim()
+    lh, ld = heads_dim()
+    kw.update(l_d=rng.choice([9, 30, 62, 65, 100, 119, 126, 128]), l_c=rng.choice([3, 8, 16, 17, 25, 40]), x_heads=xh, cross_dim_head=xd,
+              l_heads=lh, latent_dim_head=ld)
+    return kw, shapes, min(b, 9), masked
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=60)
@@ -114,7 +130,7 @@ def main(argv=None):
     ap.add_argument("--data-seed", type=int, default=0, help="offset of the input / weight seeds (same configurations, other numbers)")
     ap.add_argument("--dropout", action="store_true", help="training mode with random attention / feed-forward dropout; the oracle replays the build's exported Philox masks")
     ap.add_argument("--attn", action="store_true", help="also compare get_attention_weights() / get_attention_importance() of the inference forward (untied weights, nothing missing)")
-    ap.add_argument("--scale", default="small", choices=["small", "medium", "chain"])
+    ap.add_argument("--scale", default="small", choices=["small", "medium", "chain", "staged"])
     ap.add_argument("--core-precision", default="fp32", choices=["fp32", "bf16", "bf16x3"], help="attention core of the inference forward")
     ap.add_argument("--only", type=int, nargs="*", default=None, help="case indices to run (the others are generated and skipped)")
     args = ap.parse_args(argv)
@@ -123,7 +139,7 @@ def main(argv=None):
     bad = 0
     for case in range(args.n):
         kw, shapes, b, masked = (random_case_medium(rng) if args.scale == "medium" else random_case_chain(rng) if args.scale == "chain"
-                                 else random_case(rng))
+                                 else random_case_staged(rng) if args.scale == "staged" else random_case(rng))
         if args.dropout:
             kw["attn_dropout"] = rng.choice([0.0, 0.1, 0.3])
             kw["ff_dropout"] = rng.choice([0.0, 0.2]) if kw["attn_dropout"] > 0 else 0.2
