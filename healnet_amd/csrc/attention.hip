@@ -277,12 +277,26 @@ __global__ __launch_bounds__(256) void attn_core_kernel(AttnCoreArgs a, int ngro
         }
       }
       if (DROP) {   // nn.Dropout on the NORMALISED probabilities (:421): l keeps the full sum, the P V operand is thinned
+        // (kept or zero here; the factor 1 / (1 - p) multiplies the accumulators once, in the epilogue)
+        // 16-bit decisions, rows 16 apart share a generator call (common.h): with an even tile count per wave and the (b, h)
+        // block starting on a multiple of 32 rows (wave-uniform) the lane's tiles pair up -- NQ / 2 calls instead of NQ
+        const uint32_t row0 = (uint32_t)(bh * L + qg * NQ * 16 + j), quad = (uint32_t)(t0 + 4 * g) >> 2;
+        if (NQ % 2 == 0 && ((bh * L) & 31) == 0) {
 #pragma unroll
-        for (int i = 0; i < NQ; ++i) {
-          float dm[4];
-          drop_quad(a.drop, (uint32_t)(t0 + 4 * g) >> 2, (uint32_t)(bh * L + (qg * NQ + i) * 16 + j), dm);
+          for (int i = 0; i + 1 < NQ; i += 2) {
+            bool lo[4], hi[4];
+            drop_pair(a.drop, quad, row0 + 16 * i, lo, hi);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) P[i][r] *= dm[r];
+            for (int r = 0; r < 4; ++r) { P[i][r] = lo[r] ? P[i][r] : 0.0f; P[i + 1][r] = hi[r] ? P[i + 1][r] : 0.0f; }
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < NQ; ++i) {
+            bool keep[4];
+            drop_quad_attn(a.drop, quad, row0 + 16 * i, keep);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) P[i][r] = keep[r] ? P[i][r] : 0.0f;
+          }
         }
       }
     }
@@ -323,7 +337,7 @@ __global__ __launch_bounds__(256) void attn_core_kernel(AttnCoreArgs a, int ngro
 #pragma unroll
         for (int d = 0; d < DT; ++d) {
           const int col = 16 * d + j;
-          if (q < L && col < a.dh) a.Ofinal[((long)bi * L + q) * a.ldo + hi * a.dh + col] = O[i][d][r] * ir;
+          if (q < L && col < a.dh) a.Ofinal[((long)bi * L + q) * a.ldo + hi * a.dh + col] = O[i][d][r] * (DROP ? ir * a.drop.scale : ir);
         }
       }
       if (a.stats && g == 0 && tile * 16 + j < L) {
@@ -344,7 +358,7 @@ __global__ __launch_bounds__(256) void attn_core_kernel(AttnCoreArgs a, int ngro
       for (int d = 0; d < DT; ++d)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          a.Opart[(prow + tile * 16 + 4 * g + r) * DP + 16 * d + j] = O[i][d][r];
+          a.Opart[(prow + tile * 16 + 4 * g + r) * DP + 16 * d + j] = DROP ? O[i][d][r] * a.drop.scale : O[i][d][r];
       if (ONES) {
         if (g == 0) a.Mpart[prow + tile * 16 + j] = m[i];
         if (j == 15) {

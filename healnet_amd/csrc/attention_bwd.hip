@@ -151,12 +151,28 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a, int ngr
       }
     }
     if (DROP) {   // O = (P * d) V with the forward's keep/scale factors d:  dP <- d * (dO V^T) - D
+      const uint32_t row0 = (uint32_t)(bh * L + qg * NQ * 16 + j), quad = (uint32_t)(t0 + 4 * g) >> 2;
+      if (NQ % 2 == 0 && ((bh * L) & 31) == 0) {      // rows 16 apart share a generator call (common.h; as in the forward core)
 #pragma unroll
-      for (int i = 0; i < NQ; ++i) {
-        float dm[4];
-        drop_quad(a.drop, (uint32_t)(t0 + 4 * g) >> 2, (uint32_t)(bh * L + (qg * NQ + i) * 16 + j), dm);
+        for (int i = 0; i + 1 < NQ; i += 2) {
+          bool lo[4], hi[4];
+          drop_pair(a.drop, quad, row0 + 16 * i, lo, hi);
+          const float sc = a.drop.scale;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dP[i][r] = dP[i][r] * dm[r] - drow[i];
+          for (int r = 0; r < 4; ++r) {
+            dP[i][r] = lo[r] ? fmaf(dP[i][r], sc, -drow[i]) : -drow[i];
+            dP[i + 1][r] = hi[r] ? fmaf(dP[i + 1][r], sc, -drow[i + 1]) : -drow[i + 1];
+          }
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+          bool keep[4];
+          drop_quad_attn(a.drop, quad, row0 + 16 * i, keep);
+          const float sc = a.drop.scale;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dP[i][r] = keep[r] ? fmaf(dP[i][r], sc, -drow[i]) : -drow[i];
+        }
       }
     }
     // token validity of lane (g, j): tokens t0 + 4 g + r -- only the ragged tail / masked launches pay for it

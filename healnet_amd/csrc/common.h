@@ -129,20 +129,31 @@ enum { ACT_NONE = 0, ACT_LEAKY = 1, ACT_GLU_SELU = 2, ACT_GLU_GELU = 3 };
 // passes BigCrush in Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11 -- 10 is the library default's safety
 // margin, and inside the attention core every round is paid per score quad); one call yields the four decisions of an aligned
 // column quad (row, 4 c .. 4 c + 3): keep iff word >= thr, P(keep) = 1 - p.
+// ATTENTION masks (stream ids without DROP_SID_FF; round 3) take 16-bit decisions, EIGHT per call: the call of (row R with bit 4
+// clear, quad c) decides the column quad of row R with the low halves of its words and that of row R + 16 with the high halves
+// (keep iff half >= thr, thr = p * 2^16 rounded down, kept values scaled by 1 / (1 - p) as nn.Dropout does).  Inside the
+// image cores the generator is what dropout costs (4 calls of ~55 vector instructions per lane and 16-token step against 28
+// MFMAs); a lane's query tiles are 16 rows apart, so two of them share a call.
 // ------------------------------------------------------------------------------------------------
+constexpr uint32_t DROP_SID_FF = 0x80000000u;      // stream ids of feed-forward blocks carry this bit
 struct DropCfg {
-  uint32_t thr;        // p * 2^32; 0 = dropout disabled
+  uint32_t thr;        // feed-forward: p * 2^32; attention: p * 2^16; 0 = dropout disabled
   float scale;         // 1 / (1 - p)
   uint32_t seed_lo, seed_hi, sid, offset;
 };
 static inline DropCfg make_drop(float p, uint64_t seed, uint32_t offset, uint32_t sid) {
   DropCfg d;
   d.thr = 0; d.scale = 1.0f; d.seed_lo = (uint32_t)seed; d.seed_hi = (uint32_t)(seed >> 32); d.sid = sid; d.offset = offset;
-  if (p > 0.0f) {
+  if (p > 0.0f && (sid & DROP_SID_FF)) {
     double t = (double)p * 4294967296.0;
     d.thr = t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t;
     if (d.thr == 0) d.thr = 1;
     d.scale = (float)(1.0 / (1.0 - (double)p));
+  } else if (p > 0.0f) {
+    double t = (double)p * 65536.0;
+    d.thr = t >= 65535.0 ? 65535u : (uint32_t)t;
+    if (d.thr == 0) d.thr = 1;
+    d.scale = (float)(1.0 / (1.0 - (double)p));      // nn.Dropout's factor (the keep rate itself is p rounded down to 2^-16)
   }
   return d;
 }
@@ -166,34 +177,57 @@ __device__ __forceinline__ void drop_quad(const DropCfg &d, uint32_t quad, uint3
 #pragma unroll
   for (int r = 0; r < 4; ++r) m[r] = w[r] >= d.thr ? d.scale : 0.0f;
 }
+// ---- attention masks: rows R (bit 4 clear) and R + 16 share the call of (R, quad)
+// both rows of a pair at once: lo[r] / hi[r] = multipliers of (R, 4 quad + r) / (R + 16, 4 quad + r); `row` must have bit 4 clear
+// (keep decisions only -- the callers fold the scale elsewhere: (w << 16) >= (thr << 16) for the low half, w >= (thr << 16) for the
+// high half: one shift and two compares per pair of elements)
+__device__ __forceinline__ void drop_pair(const DropCfg &d, uint32_t quad, uint32_t row, bool (&lo)[4], bool (&hi)[4]) {
+  uint32_t w[4];
+  philox4x32(d.seed_lo, d.seed_hi, quad, row, d.sid, d.offset, w);
+  const uint32_t th = d.thr << 16;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    lo[r] = (w[r] << 16) >= th;
+    hi[r] = w[r] >= th;
+  }
+}
+// one row of a pair (any row): its own half of the pair's call
+__device__ __forceinline__ void drop_quad_attn(const DropCfg &d, uint32_t quad, uint32_t row, bool (&keep)[4]) {
+  uint32_t w[4];
+  philox4x32(d.seed_lo, d.seed_hi, quad, row & ~16u, d.sid, d.offset, w);
+  const uint32_t sh = row & 16u;               // 0: low halves, 16: high halves
+#pragma unroll
+  for (int r = 0; r < 4; ++r) keep[r] = ((w[r] >> sh) & 0xffffu) >= d.thr;
+}
 __device__ __forceinline__ float drop_one(const DropCfg &d, uint32_t col, uint32_t row) {
   uint32_t w[4];
-  philox4x32(d.seed_lo, d.seed_hi, col >> 2, row, d.sid, d.offset, w);
+  const bool ff = (d.sid & DROP_SID_FF) != 0;
+  philox4x32(d.seed_lo, d.seed_hi, col >> 2, ff ? row : (row & ~16u), d.sid, d.offset, w);
   const uint32_t c = col & 3;
-  const uint32_t v = c == 0 ? w[0] : (c == 1 ? w[1] : (c == 2 ? w[2] : w[3]));
+  uint32_t v = c == 0 ? w[0] : (c == 1 ? w[1] : (c == 2 ? w[2] : w[3]));
+  if (!ff) v = (v >> (row & 16u)) & 0xffffu;
   return v >= d.thr ? d.scale : 0.0f;
 }
 // Four lanes that are adjacent in a wave (a DPP quad) and hold the SAME column quad of four different rows -- the layout of
 // attn_bwd_dkv_kernel: lane e of the quad has column 4 c + e of rows row0 .. row0 + 3 -- need 4 calls, not 16: lane e runs the
 // call of row row0 + e, then word e of every call is fetched from the lane that ran it (quad_perm broadcasts, one VALU move each).
 // m[r] = multiplier of (row0 + r, 4 quad + e).
+// (attention masks: the call of row row0 + e is the one of its pair, every row picks its own half)
 __device__ __forceinline__ void drop_quad_transposed(const DropCfg &d, uint32_t quad, uint32_t row0, uint32_t e, float (&m)[4]) {
   uint32_t w[4];
-  philox4x32(d.seed_lo, d.seed_hi, quad, row0 + e, d.sid, d.offset, w);
+  philox4x32(d.seed_lo, d.seed_hi, quad, (row0 + e) & ~16u, d.sid, d.offset, w);
 #define HN_QUAD_BCAST(v, r) (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (r) * 0x55, 0xf, 0xf, true)
 #define HN_QUAD_WORD(r)                                                                                          \
   {                                                                                                              \
     const uint32_t t0_ = HN_QUAD_BCAST(w[0], r), t1_ = HN_QUAD_BCAST(w[1], r), t2_ = HN_QUAD_BCAST(w[2], r),     \
                    t3_ = HN_QUAD_BCAST(w[3], r);                                                                 \
     const uint32_t v_ = e == 0 ? t0_ : (e == 1 ? t1_ : (e == 2 ? t2_ : t3_));                                    \
-    m[r] = v_ >= d.thr ? d.scale : 0.0f;                                                                         \
+    m[r] = ((v_ >> ((row0 + (r)) & 16u)) & 0xffffu) >= d.thr ? d.scale : 0.0f;                                   \
   }
   HN_QUAD_WORD(0) HN_QUAD_WORD(1) HN_QUAD_WORD(2) HN_QUAD_WORD(3)
 #undef HN_QUAD_WORD
 #undef HN_QUAD_BCAST
 }
-constexpr uint32_t DROP_SID_FF = 0x80000000u;      // stream ids of feed-forward blocks carry this bit
-
 struct GemmArgs {
   const float *A; long lda; long strideA;
   const float *W; long ldw; long strideW;      // W[n][k], NT

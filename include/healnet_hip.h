@@ -87,8 +87,11 @@ int hn_context_pitch(int D, int dim_head);
  *                                                      Attention.forward :400-426 (+ residual :236/:244)
  * ------------------------------------------------------------------------------------------- */
 /* Counter-based dropout: whether element (row, col) of a block's mask is kept is a pure function of
- * (seed, offset, stream, row, col) -- Philox4x32 with 7 rounds, one call per aligned column quad, keep iff word >= p * 2^32,
- * kept values scaled by 1 / (1 - p).  `seed` is the generator seed, `offset` a per-forward counter (a fresh mask every
+ * (seed, offset, stream, row, col) -- Philox4x32 with 7 rounds, kept values scaled by 1 / (1 - p).  Feed-forward masks: one call
+ * per aligned column quad of a row, keep iff word >= p * 2^32.  Attention masks: 16-bit decisions, one call per aligned column
+ * quad of the row PAIR (R, R + 16) (R = row index in the (b * heads * L, N) matrix with bit 4 clear): low halves of the four
+ * words decide row R, high halves row R + 16, keep iff half >= p * 2^16 (rounded down) -- inside the attention cores the
+ * generator is what dropout costs, and a wave's query tiles are 16 rows apart.  `seed` is the generator seed, `offset` a per-forward counter (a fresh mask every
  * iteration; the backward is called with the forward's value), `stream` tells the blocks of a model apart: the fused
  * entry points use hn_model.rng and set stream = index of the block in execution order (feed-forward blocks have
  * bit 31 set).  The masks are reproducible bit for bit by hn_dropout_mask. */
