@@ -2495,8 +2495,11 @@ int hn_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, con
   static thread_local std::vector<float *> xt;
   xt.assign((size_t)n_slots, nullptr);
   if (x_trace)
-    for (int i = 0; i < n_slots; ++i)
-      if (x_trace[i]) xt[i] = (float *)(base + wbytes + (size_t)i * xn);
+    for (int i = 0; i < n_slots; ++i) {
+      const int j = i % (m->n_modalities + 1);      // (slots of blocks that cannot run are left alone, as on the direct route)
+      const bool live = j < m->n_modalities ? in[j].data != nullptr : m->self_per_cross_attn > 0;
+      if (x_trace[i] && live) xt[i] = (float *)(base + wbytes + (size_t)i * xn);
+    }
   rc = impl_fusion_forward(&st.sm, in, b, mask, skip_self_on_missing, return_embeddings, emb ? out_pad : out, attn_stats,
                            x_trace ? xt.data() : nullptr, base + head, workspace_bytes - head, stream, prof);
   if (rc != HN_OK) return rc;
@@ -2506,7 +2509,7 @@ int hn_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, con
   if (emb) outp.push_back({out_pad, out, rows, m->l_d, 128, rows, m->l_d, m->l_d});
   if (x_trace)
     for (int i = 0; i < n_slots; ++i)
-      if (x_trace[i]) outp.push_back({xt[i], x_trace[i], rows, m->l_d, 128, rows, m->l_d, m->l_d});
+      if (x_trace[i] && xt[i]) outp.push_back({xt[i], x_trace[i], rows, m->l_d, 128, rows, m->l_d, m->l_d});
   return st.run(outp, 0, s);
 }
 
