@@ -162,8 +162,11 @@ __device__ __forceinline__ void philox4x32(uint32_t k0, uint32_t k1, uint32_t c0
                                            uint32_t (&out)[4]) {
 #pragma unroll
   for (int r = 0; r < PHILOX_ROUNDS; ++r) {
-    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    // 64-bit products: ONE v_mad_u64_u32 each instead of a v_mul_hi_u32 + v_mul_lo_u32 pair (32-bit integer multiplies issue at a
+    // quarter of the vector rate; cfg2 b = 32 step with dropout 12.76 -> 12.46 ms)
+    const uint64_t p0 = (uint64_t)0xD2511F53u * (uint64_t)c0, p1 = (uint64_t)0xCD9E8D57u * (uint64_t)c2;
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
     const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
     c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
