@@ -169,6 +169,12 @@ ATTN_CASES = [
     dict(b=2, L=16, N=50, D=13, heads=2, dh=16, qd=32, norm=False),              # bare Attention, raw 13-wide context
     dict(b=2, L=128, N=9000, D=200, heads=8, dh=64, qd=128),                     # explicit cross, 18 000-row contraction: LDS-staged
                                                                                  # weight-gradient GEMM with a ragged column tile
+    # one narrow head over a long bag (the reference's tuned shapes): gemm_tall_narrow_kernel<2 / 4 / 8> for the K/V projection
+    # (3000 rows: ragged against its 64-row tiles; K = 773 / 131: unaligned weight rows, a partial last quad; head padding 27 -> 32
+    # through the column-group store; with and without the context affine), > 32 k-slices + the wide reduce for G = dKV^T z
+    dict(b=3, L=25, N=1000, D=773, heads=1, dh=16, qd=32),
+    dict(b=2, L=16, N=1100, D=131, heads=1, dh=27, qd=32),
+    dict(b=2, L=16, N=1200, D=200, heads=2, dh=32, qd=32, norm=False),
 ]
 CASE_INDEX = {id(c): k for k, c in enumerate(ATTN_CASES)}
 
