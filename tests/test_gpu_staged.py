@@ -232,3 +232,140 @@ def test_two_forwards_one_backward_on_the_flat_route_staged(hn):
     for k, p in model.named_parameters():
         ref = sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])
         assert float((p.grad.cpu() - ref).abs().max()) <= 5e-4 * scale, k
+
+
+def test_a_host_that_keeps_padded_weights_passes_the_staged_descriptor_itself(hn):
+    """include/healnet_hip.h "Staged models": instead of letting every forward stage the weights, a host may keep the zero-padded
+    images itself and hand over the padded descriptor with the *_valid fields set.  Built here by hand from the documented layout
+    (l_d -> 128 columns; head h of a projection at rows h * dhp; w_q rows / w_out pitch / a self block's w_kv rows up to a multiple
+    of 128; W1's value rows at 0 and gate rows at 512) and run through hn_fusion_forward directly: same logits as the model's own
+    (auto-staged) forward, and hn_fusion_is_staged says 0 for it -- it is not staged a second time."""
+    import ctypes as C
+    import json
+    from healnet_amd import _capi, ops
+    from healnet_amd._rt import stream_ptr
+    kw = dict(n_modalities=2, channel_dims=[40, 30], num_spatial_axes=[1, 1], out_dims=3, depth=2, l_c=16, l_d=62, x_heads=2,
+              cross_dim_head=27, l_heads=2, latent_dim_head=20)
+    torch.manual_seed(321)
+    model = hn.HealNet(**kw).eval().to(DEV)
+    assert model.runs_staged()
+    ins = [t.to(DEV) for t in _inputs(kw, 3, 50, 322)]
+    with torch.no_grad():
+        want = model(list(ins))
+    ld, L = kw["l_d"], kw["l_c"]
+    up128 = lambda v: (v + 127) // 128 * 128                                  # noqa: E731
+    pad_dh = lambda d: 16 if d <= 16 else 32 if d <= 32 else 64 if d <= 64 else 128      # noqa: E731
+    spec = json.loads(model._spec_text)
+    params = list(model.parameters())
+    padded = list(params)
+
+    def vec(i, n):
+        if i >= 0:
+            v = torch.zeros(n, device=DEV)
+            v[:params[i].numel()] = params[i].detach()
+            padded[i] = v
+
+    def attn(a, cross):
+        H, dh = a["heads"], a["dim_head"]
+        dhp, inner_s = pad_dh(dh), H * pad_dh(dh)
+        ip = up128(inner_s)
+        nw, nb, cg, cb, wq, wkv, wo, bo = a["p"]
+        vec(nw, 128); vec(nb, 128); vec(bo, 128)
+        q = torch.zeros(ip, 128, device=DEV)
+        o = torch.zeros(128, ip, device=DEV)
+        for h in range(H):
+            q[h * dhp:h * dhp + dh, :ld] = params[wq].detach()[h * dh:(h + 1) * dh]
+            o[:ld, h * dhp:h * dhp + dh] = params[wo].detach()[:, h * dh:(h + 1) * dh]
+        padded[wq], padded[wo] = q, o
+        src = params[wkv].detach()
+        if cross:
+            kv = torch.zeros(2 * inner_s, src.shape[1], device=DEV)
+            for j in range(2 * H):
+                kv[j * dhp:j * dhp + dh] = src[j * dh:(j + 1) * dh]
+        else:
+            kv = torch.zeros(up128(2 * inner_s), 128, device=DEV)
+            for j in range(2 * H):
+                kv[j * dhp:j * dhp + dh, :ld] = src[j * dh:(j + 1) * dh]
+        padded[wkv] = kv
+        a["dim_head"], a["query_dim"] = dhp, 128
+        return dh
+
+    def ff(f):
+        nw, nb, w1, b1, w2, b2 = f["p"]
+        vec(nw, 128); vec(nb, 128); vec(b2, 128)
+        hid = 4 * ld
+        W1 = torch.zeros(1024, 128, device=DEV)
+        W1[:hid, :ld] = params[w1].detach()[:hid]
+        W1[512:512 + hid, :ld] = params[w1].detach()[hid:]
+        B1 = torch.zeros(1024, device=DEV)
+        B1[:hid] = params[b1].detach()[:hid]
+        B1[512:512 + hid] = params[b1].detach()[hid:]
+        W2 = torch.zeros(128, 512, device=DEV)
+        W2[:ld, :hid] = params[w2].detach()
+        padded[w1], padded[b1], padded[w2] = W1, B1, W2
+        f["dim"] = 128
+
+    real_dh_cross = [attn(a, True) for a in spec["cross_attn"]]
+    for f in spec["cross_ff"]:
+        ff(f)
+    real_dh_self = [attn(a, False) for a in spec["self_attn"]]
+    for f in spec["self_ff"]:
+        ff(f)
+    lat = torch.zeros(L, 128, device=DEV)
+    lat[:, :ld] = params[spec["latents"]].detach()
+    padded[spec["latents"]] = lat
+    hnw, hnb, hw, hb = spec["head_p"]
+    vec(hnw, 128); vec(hnb, 128)
+    HW = torch.zeros(kw["out_dims"], 128, device=DEV)
+    HW[:, :ld] = params[hw].detach()
+    padded[hw] = HW
+    spec["l_d"] = 128
+    sp = ops.Spec(json.dumps(spec, sort_keys=True))
+    desc, keep = sp.model([t.contiguous() for t in padded])
+    ca, cf, sa, sf = keep[0], keep[1], keep[2], keep[3]
+    desc.l_d_valid = ld
+    for k, dh in enumerate(real_dh_cross):
+        ca[k].dim_head_valid, ca[k].query_dim_valid, cf[k].dim_valid = dh, ld, ld
+    for k, dh in enumerate(real_dh_self):
+        sa[k].dim_head_valid, sa[k].query_dim_valid, sf[k].dim_valid = dh, ld, ld
+    lib = _capi.lib()
+    assert lib.hn_fusion_is_staged(C.byref(desc)) == 0
+    inp, held, b = sp.inputs(ins)
+    need = lib.hn_fusion_workspace_bytes(C.byref(desc), inp, b)
+    assert need > 0
+    ws = torch.empty(need, dtype=torch.uint8, device=DEV)
+    out = torch.empty(b, kw["out_dims"], device=DEV)
+    _capi.check(lib.hn_fusion_forward(C.byref(desc), inp, b, None, 0, 0, out.data_ptr(), None, None, ws.data_ptr(), ws.numel(),
+                                      stream_ptr(torch.device(DEV)), None), "hn_fusion_forward")
+    assert_close(out.cpu(), want.cpu(), rel=1e-5, floor=0.0, abs_floor=1e-6, what="pre-staged descriptor vs the model's own forward")
+
+
+def test_graph_replay_of_a_staged_model(hn):
+    """HealNet.capture on a staged shape: the weight-staging launch is part of the captured graph, so a replay equals the eager
+    forward bit for bit on new input values, sees an in-place weight update, and serves attention weights from its static buffers."""
+    kw = dict(COMMON, **TUNED["brca"])
+    kw.pop("attn_dropout"); kw.pop("ff_dropout")
+    torch.manual_seed(41)
+    model = hn.HealNet(**kw).eval().to(DEV)
+    assert model.runs_staged()
+    graph = model.capture([t.to(DEV) for t in _inputs(kw, 2, 300, 42)])
+    for trial in range(2):
+        ins = [t.to(DEV) for t in _inputs(kw, 2, 300, 43 + trial)]
+        with torch.no_grad():
+            got = graph(list(ins)).clone()
+            eager = model(list(ins))
+        assert torch.equal(got, eager), f"trial {trial}: graph replay differs from the eager forward"
+    with torch.no_grad():
+        for p in model.parameters():
+            p.mul_(1.01)                                  # in place: the replay stages the updated weights
+        got = graph(list(ins)).clone()
+        eager = model(list(ins))
+    assert torch.equal(got, eager) and not torch.equal(got, torch.zeros_like(got))
+    with torch.no_grad():
+        graph(list(ins))
+        w_graph = [w.clone() for w in model.get_attention_weights() if w is not None]
+        model(list(ins))
+        w_eager = [w for w in model.get_attention_weights() if w is not None]
+    assert len(w_graph) == len(w_eager) > 0
+    for a, c in zip(w_graph, w_eager):
+        assert torch.equal(a, c)
