@@ -5,6 +5,8 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unordered_map>
+#include <vector>
 
 namespace hn {
 
@@ -2235,9 +2237,6 @@ int hn_latent_block_bwd(const hn_attn_params *attn, const hn_ff_params *ff, cons
 // gradients of pad entries are never read.  A training forward keeps the staged weights on the tape for its backward.
 // HN_NO_STAGING=1: development switch (the generic per-block route these shapes took before).
 // ------------------------------------------------------------------------------------------------
-#include <vector>
-#include <unordered_map>
-
 namespace hn {
 namespace {
 
