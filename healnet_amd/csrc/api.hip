@@ -344,13 +344,21 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
   AttnCoreArgs core;
   const int pack_ks = (pl.rank_d && pl.ones && ctx_has_ones && p->ctx_gamma) ? ctx_pack_ks : 0;
   if ((rc = attn_prepare(p, pl, x_in, ctx, ld_ctx, b, L, s, &core, pack_ks,
-                         saved_kv(pl, ctx != nullptr, mask != nullptr || dropping, b, L, o_save), false, !dropping, bound_flag, ext)) != HN_OK) return rc;
+                         saved_kv(pl, ctx != nullptr, mask != nullptr || dropping, b, L, o_save), false, !dropping || (pl.rank_d && pl.ones),
+                         bound_flag, ext)) != HN_OK) return rc;
   core.mask = mask;
   core.ones_in_mem = (ctx_has_ones && pl.ones) ? 1 : 0;
   core.drop = drop_off();
   const int srow = (dropping && pl.rank_d) ? 1 : 0;       // the thinned probabilities' row sum rides in column dp-1
   HN_REQUIRE(!srow || pl.ones, HN_E_UNSUPPORTED, "attn: dropout on the shared-context binding needs a free column (D <= dp - 1)");
-  if (dropping) { core.ones_col = 0; core.ones_in_mem = 0; core.drop = drop_of(p->dropout, p->rng, false); core.drop_rowsum = srow; core.bound = nullptr; core.bound_flag = nullptr; }
+  if (dropping) {
+    // shared-context binding with a score bound (LayerNorm-ed context): the bounded softmax stays, the ones column (injected in
+    // registers: the context is laid out without one under dropout) is the row-sum channel; otherwise the general path
+    static const bool no_bound = getenv("HN_NO_DROP_BOUND") != nullptr;      // development switch
+    const bool keep_bound = srow && core.bound != nullptr && (pl.dp == 16 || pl.dp == 32) && !no_bound;
+    core.ones_col = keep_bound ? 1 : 0; core.ones_in_mem = 0; core.drop = drop_of(p->dropout, p->rng, false); core.drop_rowsum = srow;
+    if (!keep_bound) { core.bound = nullptr; core.bound_flag = nullptr; }
+  }
   if (o_save && !pl.rank_d) pl.obuf = o_save;      // training, explicit binding: the merged O is produced straight in its tape slot
   const bool direct = !pl.rank_d && pl.nsplit == 1;
   if (direct) { core.Ofinal = pl.obuf; core.ldo = pl.inner; core.dh = pl.dh; core.stats = stats; }

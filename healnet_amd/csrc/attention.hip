@@ -229,6 +229,7 @@ __global__ __launch_bounds__(256) void attn_core_kernel(AttnCoreArgs a, int ngro
           if (!(delta > -3.0e38f)) delta = 0.0f;          // row saw only -inf scores: keep the reference
           const float alpha = unset ? 1.0f : fast_exp2(-delta);
           m[i] += delta;
+          if (DROP) l[i] *= alpha;           // (with dropout the denominator lives on the VALU, see below)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float ar = __shfl(alpha, 4 * g + r);
@@ -239,6 +240,10 @@ __global__ __launch_bounds__(256) void attn_core_kernel(AttnCoreArgs a, int ngro
           negm[i] = (f32x4){-m[i], -m[i], -m[i], -m[i]};
         }
         unset = false;
+      }
+      if (DROP) {      // the ones column of V will sum the THINNED probabilities (the row-sum channel): the full sum is added here
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) l[i] += (P[i][0] + P[i][1]) + (P[i][2] + P[i][3]);
       }
     } else {
       bool need = false;
@@ -276,27 +281,27 @@ __global__ __launch_bounds__(256) void attn_core_kernel(AttnCoreArgs a, int ngro
           P[i][r] = p;
         }
       }
-      if (DROP) {   // nn.Dropout on the NORMALISED probabilities (:421): l keeps the full sum, the P V operand is thinned
-        // (kept or zero here; the factor 1 / (1 - p) multiplies the accumulators once, in the epilogue)
-        // 16-bit decisions, rows 16 apart share a generator call (common.h): with an even tile count per wave and the (b, h)
-        // block starting on a multiple of 32 rows (wave-uniform) the lane's tiles pair up -- NQ / 2 calls instead of NQ
-        const uint32_t row0 = (uint32_t)(bh * L + qg * NQ * 16 + j), quad = (uint32_t)(t0 + 4 * g) >> 2;
-        if (NQ % 2 == 0 && ((bh * L) & 31) == 0) {
+    }
+    if (DROP) {   // nn.Dropout on the NORMALISED probabilities (:421): l keeps the full sum, the P V operand is thinned
+      // (kept or zero here; the factor 1 / (1 - p) multiplies the accumulators once, in the epilogue)
+      // 16-bit decisions, rows 16 apart share a generator call (common.h): with an even tile count per wave and the (b, h)
+      // block starting on a multiple of 32 rows (wave-uniform) the lane's tiles pair up -- NQ / 2 calls instead of NQ
+      const uint32_t row0 = (uint32_t)(bh * L + qg * NQ * 16 + j), quad = (uint32_t)(t0 + 4 * g) >> 2;
+      if (NQ % 2 == 0 && ((bh * L) & 31) == 0) {
 #pragma unroll
-          for (int i = 0; i + 1 < NQ; i += 2) {
-            bool lo[4], hi[4];
-            drop_pair(a.drop, quad, row0 + 16 * i, lo, hi);
+        for (int i = 0; i + 1 < NQ; i += 2) {
+          bool lo[4], hi[4];
+          drop_pair(a.drop, quad, row0 + 16 * i, lo, hi);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { P[i][r] = lo[r] ? P[i][r] : 0.0f; P[i + 1][r] = hi[r] ? P[i + 1][r] : 0.0f; }
-          }
-        } else {
+          for (int r = 0; r < 4; ++r) { P[i][r] = lo[r] ? P[i][r] : 0.0f; P[i + 1][r] = hi[r] ? P[i + 1][r] : 0.0f; }
+        }
+      } else {
 #pragma unroll
-          for (int i = 0; i < NQ; ++i) {
-            bool keep[4];
-            drop_quad_attn(a.drop, quad, row0 + 16 * i, keep);
+        for (int i = 0; i < NQ; ++i) {
+          bool keep[4];
+          drop_quad_attn(a.drop, quad, row0 + 16 * i, keep);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) P[i][r] = keep[r] ? P[i][r] : 0.0f;
-          }
+          for (int r = 0; r < 4; ++r) P[i][r] = keep[r] ? P[i][r] : 0.0f;
         }
       }
     }
@@ -359,7 +364,7 @@ __global__ __launch_bounds__(256) void attn_core_kernel(AttnCoreArgs a, int ngro
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           a.Opart[(prow + tile * 16 + 4 * g + r) * DP + 16 * d + j] = DROP ? O[i][d][r] * a.drop.scale : O[i][d][r];
-      if (ONES) {
+      if (ONES && !DROP) {
         if (g == 0) a.Mpart[prow + tile * 16 + j] = m[i];
         if (j == 15) {
 #pragma unroll
@@ -443,7 +448,8 @@ int launch_attn_core(const AttnCoreArgs &a, hipStream_t s) {
              "attn_core: one sample's K/V rows must span < 2 GiB (N=%d ld=%d)", a.N, a.ldk);
   HN_REQUIRE(a.Ofinal == nullptr || (a.nsplit == 1 && !a.ones_col), HN_E_SHAPE, "attn_core: direct output needs a single split");
   HN_REQUIRE(!a.ones_col || (a.dp <= 32 && a.Kp == a.Vp), HN_E_UNSUPPORTED, "attn_core: ones column needs the shared-context binding");
-  HN_REQUIRE(a.drop.thr == 0 || !a.ones_col, HN_E_SHAPE, "attn_core: dropout needs the explicit denominator (ones_col = 0)");
+  HN_REQUIRE(a.drop.thr == 0 || !a.ones_col || (!a.ones_in_mem && (a.dp == 16 || a.dp == 32)), HN_E_SHAPE,
+             "attn_core: dropout with the ones column needs it injected in registers (the row-sum channel), dp = 16 / 32");
   if (self_core_lds_eligible(a)) return launch_self_core_lds(a, s);
   const int dt = a.dp / 16;
   int nq = a.nq > 0 ? a.nq : nq_for(dt);
@@ -459,7 +465,14 @@ int launch_attn_core(const AttnCoreArgs &a, hipStream_t s) {
   const int ks = a.qk_steps > 0 ? a.qk_steps : 4 * dt;
   HN_REQUIRE(ks >= 1 && ks <= 4 * dt && (ks == 4 * dt || (a.ones_col && a.ones_in_mem)), HN_E_SHAPE, "attn_core: qk_steps=%d", a.qk_steps);
 #define HN_CORE(DT_, NQ_, ONES_, KS_) hipLaunchKernelGGL((attn_core_kernel<DT_, NQ_, ONES_, KS_>), grid, block, 0, s, a, ngroups, gy, wpb)
-  if (dt == 1 && a.ones_col && (nq == 2 || nq == 1) && ks != 4) {
+  if (a.drop.thr != 0 && a.ones_col) {
+    // dropout on the shared-context binding with the score-bound softmax: the reference of a row is fixed (no running maximum, no
+    // rescale), the ones column -- injected in registers -- is the row-sum channel, the denominator is summed on the VALU
+    HN_REQUIRE((dt == 1 && nq == 4) || (dt == 2 && nq == 2), HN_E_UNSUPPORTED, "attn_core: dropout variant dp=%d nq=%d", a.dp, nq);
+    HN_REQUIRE(ks == 4 * dt, HN_E_SHAPE, "attn_core: dropout runs on the unpacked context (qk_steps=%d)", ks);
+    if (dt == 1) hipLaunchKernelGGL((attn_core_kernel<1, 4, true, 4, true>), grid, block, 0, s, a, ngroups, gy, wpb);
+    else hipLaunchKernelGGL((attn_core_kernel<2, 2, true, 8, true>), grid, block, 0, s, a, ngroups, gy, wpb);
+  } else if (dt == 1 && a.ones_col && (nq == 2 || nq == 1) && ks != 4) {
     HN_REQUIRE(ks >= 1 && ks <= 3, HN_E_SHAPE, "attn_core: qk_steps=%d", ks);
     if (nq == 2) { if (ks == 1) HN_CORE(1, 2, true, 1); else if (ks == 2) HN_CORE(1, 2, true, 2); else HN_CORE(1, 2, true, 3); }
     else { if (ks == 1) HN_CORE(1, 1, true, 1); else if (ks == 2) HN_CORE(1, 1, true, 2); else HN_CORE(1, 1, true, 3); }
