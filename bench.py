@@ -20,6 +20,7 @@ Rank 0 prints ONE JSON line.  Besides the driver's contract it carries
                  forward on this runtime, so it stays out of the region `value` comes from);
   cpu_baseline : oracle/healnet_cpu.py (the op-for-op CPU restatement of the reference) timed on this
                  box's host cores on a bounded sample (b=4 of the same workload; 1 warm-up + median of 3 runs), rank 0 at N=1 only;
+  staged_models: forward + backward of the reference's four tuned TCGA configurations (config/best_hyperparams.yml) at b=8, N=1 only
   train_step   : SURVEY.md 8(d)'s second figure -- the training step of BASELINE configs[3] (TCGA-BRCA shape: omic 1x2000 + WSI bag
                  4096x768, b=8 per GPU): forward with tape, survival NLL, fused backward, gradient all-reduce over RCCL
                  (overlapped with the backward through hn_grad_ready, healnet_amd.dist.GradReadyAllReduce) and the fused
@@ -259,6 +260,43 @@ def self_launch(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+TUNED = {   # config/best_hyperparams.yml of the reference: depth, num_latents, latent_dim, cross_dim_head, latent_dim_head, dropouts
+    "blca": dict(depth=2, l_c=25, l_d=119, cross_dim_head=16, latent_dim_head=127, attn_dropout=0.0830, ff_dropout=0.4733),
+    "brca": dict(depth=2, l_c=17, l_d=126, cross_dim_head=63, latent_dim_head=20, attn_dropout=0.4553, ff_dropout=0.3647),
+    "kirp": dict(depth=5, l_c=17, l_d=62, cross_dim_head=27, latent_dim_head=113, attn_dropout=0.3179, ff_dropout=0.0474),
+    "ucec": dict(depth=2, l_c=16, l_d=65, cross_dim_head=103, latent_dim_head=51, attn_dropout=0.2488, ff_dropout=0.0571),
+}
+
+
+def staged_models_record(dev, steps=15, warmup=3):
+    """The reference's four tuned TCGA configurations (odd latent widths, ONE narrow cross head, dropout on), forward + backward at
+    b = 8 on the cfg4 input shapes: they run the fused latent kernels as zero-padded images (DESIGN.md 4.10 "staged models")."""
+    import healnet_amd as hn
+    gen = torch.Generator().manual_seed(1)
+    ins = [torch.rand(TRAIN_BATCH, *s, generator=gen).to(dev) for s in TRAIN_SHAPES]
+    rec = {"workload": "forward + backward (both dropouts on), b=8, omic (b,1,2000) + WSI bag (b,4096,768), gradients into the flat buffer",
+           "unit": "ms", "steps": steps, "warmup": warmup, "configs": {}}
+    for name, kw in TUNED.items():
+        torch.manual_seed(0)
+        model = hn.HealNet(n_modalities=2, channel_dims=[2000, 768], num_spatial_axes=[1, 1], out_dims=4, x_heads=1, l_heads=8,
+                           self_per_cross_attn=0, num_freq_bands=2, max_freq=2.0, **kw).to(dev).train()
+        flat = hn.train.flatten_parameters(model)
+
+        def step():
+            flat.zero_grad()
+            model(list(ins)).sum().backward()
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize(dev)
+        rec["configs"][name] = {"fwd_bwd_ms": round((time.perf_counter() - t0) / steps * 1e3, 4), "staged": bool(model.runs_staged())}
+        del model, flat
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -266,6 +304,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=BATCH, help="samples per GPU per step (headline config: 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-staged-models", action="store_true", help="skip the tuned-shape (staged models) record")
     ap.add_argument("--no-train-step", action="store_true", help="skip the cfg4 training-step record")
     ap.add_argument("--train-steps", type=int, default=30)
     ap.add_argument("--core-precision", choices=["fp32", "bf16", "bf16x3"], default="fp32",
@@ -428,6 +467,8 @@ def main():
     if rank == 0:
         if train_rec is not None:
             result["train_step"] = train_rec
+        if world == 1 and not args.no_staged_models:
+            result["staged_models"] = staged_models_record(dev)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline()
         print(json.dumps(result))

@@ -33,6 +33,9 @@ def test_bench_prints_one_contract_line():
     assert t["batch_per_gpu"] == 8 and t["world_size"] == 1 and t["unit"] == "samples/s" and t["steps"] == 3
     assert abs(t["value"] - 8 * 1000.0 / t["ms_per_step"]) <= 1e-3 * t["value"] and t["final_loss"] == t["final_loss"]
     assert sum(t["allreduce_buckets_floats"]) == t["gradient_floats"]
+    sm = j["staged_models"]                               # the reference's tuned TCGA shapes, run as zero-padded images
+    assert set(sm["configs"]) == {"blca", "brca", "kirp", "ucec"} and sm["unit"] == "ms"
+    assert all(c["staged"] and 0.1 < c["fwd_bwd_ms"] < 50.0 for c in sm["configs"].values())
 
 
 def test_plain_gpus_n_command_launches_its_own_ranks():
