@@ -66,12 +66,14 @@ struct Bf16Context {              // bf16 images of one modality's normalised co
 struct AttnPlan {
   int heads, dh, inner, dhp, Lp, N, D, dp;
   bool rank_d, self_attn, ones, bf16core;
+  const uint16_t *ctx16;          // explicit binding under core_precision = bf16 (inference): bf16 image of the context rows -> the K/V projection runs on bf16 MFMA
   int nsplit, chunk;
   int nq;                         // query tiles per wave the forward split was planned for (0: the kernel's default)
   int nsplit_bwd, chunk_bwd;      // token split of attn_bwd_dq_kernel (≈150 VGPRs: 3 waves per SIMD)
   float cscale;
   // workspace carve
   float *obuf, *q, *qf, *kv, *opart, *mpart, *lpart, *bound;
+  float *wstage;                  // explicit cross binding: scratch of launch_gemm_bf16 (bf16 image of to_kv.weight + its beta row)
   size_t bytes;
 };
 
@@ -124,6 +126,8 @@ static int plan_attn(const hn_attn_params *p, bool has_ctx, int ld_ctx, int b, i
     pl->qf = nullptr;
     pl->kv = ar.take<float>((size_t)b * pl->N * 2 * p->heads * pl->dhp);
   }
+  pl->ctx16 = nullptr;
+  pl->wstage = (has_ctx && !pl->rank_d && pl->N > 1) ? ar.take<float>(gemm_bf16_stage_floats(2 * pl->inner, pl->D)) : nullptr;
   const size_t prow = (size_t)b * p->heads * pl->nsplit * pl->Lp;
   pl->opart = ar.take<float>(prow * pl->dp);
   pl->mpart = ar.take<float>(prow);
@@ -249,7 +253,9 @@ static int attn_prepare(const hn_attn_params *p, const AttnPlan &pl, const float
       gk.W = p->w_kv; gk.ldw = pl.D;
       gk.N = 2 * pl.inner;
       gk.C = kvbuf; gk.ldc = kvpitch; gk.col_group = pl.dh; gk.col_group_pitch = pl.dhp;
-      if ((rc = launch_gemm(gk, s)) != HN_OK) return rc;
+      if (ctx && pl.ctx16 && pl.wstage && gemm_bf16_eligible(gk)) rc = launch_gemm_bf16(gk, pl.ctx16, pl.wstage, s);
+      else rc = launch_gemm(gk, s);
+      if (rc != HN_OK) return rc;
     }
     core->Q = qbuf; core->q_b = (long)L * qpitch; core->q_h = pl.dhp; core->ldq = qpitch;
     core->Kp = kvbuf; core->k_b = (long)pl.N * kvpitch; core->k_h = pl.dhp; core->ldk = kvpitch;
@@ -262,7 +268,7 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
                          int ld_ctx, int b, int L, int N, int D, const uint8_t *mask, float *stats, void *ws,
                          size_t ws_bytes, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, float *o_save = nullptr,
                          bool ctx_has_ones = false, int ctx_pack_ks = 0, const Bf16Context *bc = nullptr, int *bound_flag = nullptr,
-                         AttnExt *ext = nullptr) {
+                         AttnExt *ext = nullptr, const uint16_t *ctx16 = nullptr) {
   HN_REQUIRE(x_in && (x_out || (ext && ext->defer_out)), HN_E_NULL, "attn: x is NULL");
   HN_REQUIRE(p && p->w_q && p->w_kv && p->w_out, HN_E_NULL, "attn: weight pointer is NULL");
   AttnPlan pl;
@@ -270,6 +276,7 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
   if (rc != HN_OK) return rc;
   if ((rc = check_ws(ws, ws_bytes, pl.bytes, "attn")) != HN_OK) return rc;
   if ((rc = plan_attn(p, ctx != nullptr, ld_ctx, b, L, N, D, ws, ws_bytes, &pl, bc ? bc->ns : 0)) != HN_OK) return rc;
+  pl.ctx16 = o_save == nullptr ? ctx16 : nullptr;      // (training keeps the fp32 projection: the backward differentiates THAT product)
 
   // ---- one-token context without a mask (tabular / omic modality): softmax over a single key is exactly 1, so the
   // block reduces to y = LeakyReLU(W_out (W_v c) + b_out) broadcast over the latent rows; Q and K are dead
@@ -853,6 +860,7 @@ struct FusionPlan {
   float *wvf[16];  // inference: folded value projections of all layers (depth, inner, 16) for the chain's merge head, or NULL
   int pack[16];    // ... and uses the packed channel layout with this many QK^T k-steps (0 = natural)
   bool bf16[16];   // core_precision = bf16: z holds the bf16 images (zb, then zT) instead of the fp32 rows
+  uint16_t *z16[16];   // core_precision = bf16, explicit binding of a large patch bag: bf16 image of the rows of z (pitch gemm_bf16_pitch(D)) for the K/V projections, or NULL
   int Np[16], ns[16];
   int *flags;      // one pre-zeroed fallback flag of the score-bound softmax per (layer, modality), then the chain cluster flags
   float *xchg;     // exchange buffer of the latent chain's cluster mode (small batches)
@@ -880,6 +888,7 @@ static int plan_fusion(const hn_model *m, const hn_modality_input *in, int b, vo
   long best = -1;
   for (int i = 0; i < m->n_modalities; ++i) {
     fp->z[i] = nullptr;
+    fp->z16[i] = nullptr;
     if (in[i].data == nullptr) continue;
     const int axes = m->num_spatial_axes[i];
     HN_REQUIRE(axes >= 1 && axes <= HN_MAX_AXES, HN_E_UNSUPPORTED, "fusion: modality %d has %d spatial axes (1..%d)", i, axes,
@@ -942,6 +951,13 @@ static int plan_fusion(const hn_model *m, const hn_modality_input *in, int b, vo
       if (zb16 > zbytes) zbytes = zb16;
     }
     fp->z[i] = (float *)ar.take<char>(zbytes);
+    // (sized whether or not this call is the inference forward: one workspace size serves all entry points; used by inference only)
+    fp->z16[i] = nullptr;
+    if (m->core_precision == HN_CORE_BF16 && !fp->ones[i] && n > 1 && fp->ldz[i] % 4 == 0 &&
+        gemm_bf16_shape_ok((long)b * n, 2 * ap->heads * ap->dim_head, fp->D[i])) {
+      uint16_t *img = (uint16_t *)ar.take<char>((size_t)b * n * gemm_bf16_pitch(fp->D[i]) * sizeof(uint16_t));
+      if (inference) fp->z16[i] = img;
+    }
     // one-token context (tabular / omic): y_l = LeakyReLU(W_out,l (W_v,l c_hat_l) + b_out,l) does not depend on the latent array,
     // so the inference forward evaluates all layers' vectors up front (weight-streaming GEMV shapes only, equal heads / dims)
     fp->tab_ahead[i] = false;
@@ -1423,6 +1439,7 @@ static int impl_fusion_forward(const hn_model *m, const hn_modality_input *in, i
       rc = launch_encode(in[i].data, in[i].dtype, b, m->num_spatial_axes[i], in[i].spatial, m->channel_dims[i], m->num_freq_bands,
                          m->max_freq, m->fourier_encode_data, 1, 1e-5f, fp.z[i], fp.ldz[i], s, fp.ones[i] ? fp.ldz[i] - 1 : -1,
                          fp.pack[i]);
+      if (rc == HN_OK && fp.z16[i]) rc = launch_rows_to_bf16(fp.z[i], fp.ldz[i], (long)b * fp.N[i], fp.D[i], fp.z16[i], s);
     }
     if (rc != HN_OK) return rc;
   }
@@ -1510,7 +1527,8 @@ static int impl_fusion_forward(const hn_model *m, const hn_modality_input *in, i
     bc.Np = fp.Np[i]; bc.DV = fp.ldz[i]; bc.ns = fp.ns[i];
     return attn_fwd_impl(ap, xin, xout, 1, fp.z[i], fp.ldz[i], b, L, fp.N[i], fp.D[i], mask,
                          attn_stats ? attn_stats[slot_of(st)] : nullptr, fp.op_ws, fp.op_ws_bytes, s, e0, e1, nullptr,
-                         fp.ones[i], fp.pack[i], fp.bf16[i] ? &bc : nullptr, fp.flags + layer * M + i, ext);
+                         fp.ones[i], fp.pack[i], fp.bf16[i] ? &bc : nullptr, fp.flags + layer * M + i, ext,
+                         fp.z16[i]);
   };
   auto ff_of = [&](const Step &st) { return st.kind == STEP_CROSS_FF ? &m->cross_ff[st.layer * M + st.m] : &m->self_ff[st.layer]; };
   auto is_attn = [](const Step &st) { return st.kind == STEP_CROSS_ATTN || st.kind == STEP_SELF_ATTN; };

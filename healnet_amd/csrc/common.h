@@ -248,6 +248,15 @@ struct GemmArgs {
   const float *W2; float *C2; long ldc2; int N2; float alpha2; int col_group2, col_group_pitch2;
 };
 int launch_gemm(const GemmArgs &g, hipStream_t s);
+// bf16-MFMA form of C = alpha * (A gamma + beta) W^T for the patch-bag K/V projection under core_precision = bf16 (gemm_bf16.hip):
+// operands rounded to bf16 once, fp32 accumulation.  Ab = launch_rows_to_bf16(A) (M rows of gemm_bf16_pitch(K) bf16, once per
+// forward), `stage` = gemm_bf16_stage_floats(N, K) floats of 16-byte aligned scratch per call
+int gemm_bf16_pitch(int K);
+bool gemm_bf16_shape_ok(long M, int N, int K);
+bool gemm_bf16_eligible(const GemmArgs &g);
+size_t gemm_bf16_stage_floats(int N, int K);
+int launch_rows_to_bf16(const float *A, long lda, long M, int K, uint16_t *out, hipStream_t s);
+int launch_gemm_bf16(const GemmArgs &g, const uint16_t *Ab, float *stage, hipStream_t s);
 
 // Several skinny products of one shape in ONE launch, operands given per entry (the one-token projections of all layers of a
 // forward: they do not depend on the latent array, and each is a ~9 us latency-bound launch on its own)

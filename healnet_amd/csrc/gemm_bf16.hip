@@ -1,0 +1,235 @@
+// bf16-MFMA form of the patch-bag K/V projection (core_precision = "bf16", inference forward only).
+//
+//   C (M, N) = alpha * (A * gamma + beta) W^T      A (M, K) fp32 = the normalised context rows of an explicit binding (b * N tokens,
+//                                                  K = D = 773 at cfg4 / cfg5), W (N = 2 * inner, K) fp32 = to_kv.weight
+//
+// is 52 GF per block at cfg4 and 42 % of the cfg5 forward on fp32 MFMA (gemm_big_kernel at 0.7 of the 157 TF/s peak).  With the
+// operands rounded to bf16 ONCE and fp32 accumulation (the same contract as the bf16 image / volume core, SURVEY.md 8d, tolerance
+// 2e-2 against the fp32 oracle) the same product runs on v_mfma_f32_16x16x32_bf16:
+//
+//   * the affine prologue leaves the loop:  (A gamma + beta) W^T = A (W gamma)^T + W beta.  gemm_bf16_stage_kernel writes
+//     Wb = bf16(W * gamma) with rows zero-padded to a multiple of 64 columns (16-byte aligned whatever ldw is -- 773 floats at
+//     cfg4) and the fp32 row vector cb = W beta (exact: it never passes through bf16); one launch of N workgroups per call.
+//   * the context rows are rounded ONCE per forward (rows_to_bf16_kernel: Ab, same zero-padded 64-column pitch -- rows start on
+//     128-byte lines) and serve every layer's projection: half the bytes per k-tile, no conversion in the loop.
+//   * gemm_bf16_kernel: 128 x 128 output tile, 64-wide k-tiles, both operands as 16-byte pieces (8 lanes = one line of a row)
+//     through registers into LDS, one k-tile ahead.  The LDS image of an operand is [k-half][row][32 bf16] -- a 16 x 32 sub-tile
+//     is ONE contiguous KB in exactly the order the MFMA operand fragment reads it (lane (g, j) = row j, k = 8 g .. 8 g + 7:
+//     16 bytes at (16 t + j) * 64 + 16 g), so fragment reads and loader writes are conflict free without padding or swizzle.
+//   * W sub-tiles are the MFMA's A operand and context sub-tiles its B operand: the accumulator quad of a lane is then four
+//     CONSECUTIVE output columns of one row -> float4 stores.
+//   * work-item order as gemm_big_kernel: the column tiles that share a 128-row block of A run back to back on one XCD.
+#include "common.h"
+
+namespace hn {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int HM = 128, HNT = 128, HK = 64;
+constexpr int PLANE = 128 * 64;      // bytes of one k-half of an operand tile: 128 rows x 32 bf16
+
+__device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+
+// Wb[n][k] = bf16(W[n][k] * gamma[k]) for k < K, 0 up to Kp; cb[n] = sum_k W[n][k] * beta[k] (gamma / beta NULL: 1 / 0)
+__global__ __launch_bounds__(256) void gemm_bf16_stage_kernel(const float *__restrict__ W, long ldw, const float *__restrict__ gamma,
+                                                              const float *__restrict__ beta, int K, int Kp, unsigned *__restrict__ Wb,
+                                                              float *__restrict__ cb) {
+  __shared__ float red[4];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const float *w = W + (long)n * ldw;
+  unsigned *out = Wb + (long)n * (Kp / 2);
+  float part = 0.0f;
+  for (int k = 2 * tid; k < Kp; k += 512) {
+    float v[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int ke = k + e;
+      float x = 0.0f;
+      if (ke < K) {
+        x = w[ke];
+        if (beta) part = fmaf(x, beta[ke], part);
+        if (gamma) x *= gamma[ke];
+      }
+      v[e] = x;
+    }
+    out[k / 2] = pk_bf16(v[0], v[1]);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+  if ((tid & 63) == 0) red[tid >> 6] = part;
+  __syncthreads();
+  if (tid == 0) cb[n] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// Ab[m][k] = bf16(A[m][k]) for k < K, 0 up to Kp: the normalised context of a patch-bag modality, once per forward (every layer's
+// K/V projection reads it).  One 16-byte piece (8 columns) per thread.
+__global__ __launch_bounds__(256) void rows_to_bf16_kernel(const float *__restrict__ A, long lda, long M, int K, int Kp, u32x4 *__restrict__ out) {
+  const int ppr = Kp / 8;
+  const long id = (long)blockIdx.x * 256 + threadIdx.x;
+  if (id >= M * ppr) return;
+  const long m = id / ppr;
+  const int k = (int)(id - m * ppr) * 8;
+  const float *a = A + m * lda + k;
+  float v[8];
+  if (k + 7 < K) {
+    const f32x4 lo = *(const f32x4 *)a, hi = *(const f32x4 *)(a + 4);
+    v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = k + e < K ? a[e] : 0.0f;      // nothing is read past column K - 1 (pad columns may hold anything)
+  }
+  u32x4 o;
+  o.x = pk_bf16(v[0], v[1]); o.y = pk_bf16(v[2], v[3]); o.z = pk_bf16(v[4], v[5]); o.w = pk_bf16(v[6], v[7]);
+  out[id] = o;
+}
+
+struct Bf16GemmArgs {
+  const uint16_t *Ab, *Wb;      // (M, Kp) and (N, Kp) bf16 images, Kp % 64 == 0, zero beyond K
+  const float *cb;              // (N) fp32: W beta
+  float *C; long ldc;
+  float alpha;
+  int M, Kp, ntm, ntn;
+};
+
+__global__ __launch_bounds__(256, 3) void gemm_bf16_kernel(Bf16GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) unsigned char As[2 * PLANE];
+  __shared__ __attribute__((aligned(16))) unsigned char Bs[2 * PLANE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int id = blockIdx.x, xcd = id & 7, seq = id >> 3;
+  const int n_tile = seq % g.ntn, m_tile = (seq / g.ntn) * 8 + xcd;
+  if (m_tile >= g.ntm) return;
+  const int m0 = m_tile * HM, n0 = n_tile * HNT;
+  const int Kp = g.Kp;
+
+  // loader (both operands): 16-byte piece lp of the 8 of a 64-wide row piece, rows lr + 32 j: 8 lanes = one 128-byte line
+  const int lp = tid & 7, lr = tid >> 3;
+  const uint16_t *arow[4], *wrow[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    arow[j] = g.Ab + (long)min(m0 + lr + 32 * j, g.M - 1) * Kp + 8 * lp;
+    wrow[j] = g.Wb + (long)(n0 + lr + 32 * j) * Kp + 8 * lp;
+  }
+  u32x4 ra[4], rb[4];
+  auto load_tile = [&](int k0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      ra[j] = *(const u32x4 *)(arow[j] + k0);
+      rb[j] = *(const u32x4 *)(wrow[j] + k0);
+    }
+  };
+  const int dst = (lp >> 2) * PLANE + lr * 64 + (lp & 3) * 16;
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      *(u32x4 *)(As + dst + j * 32 * 64) = ra[j];
+      *(u32x4 *)(Bs + dst + j * 32 * 64) = rb[j];
+    }
+  };
+
+  const int wm = wave >> 1, wn = wave & 1;      // a wave owns 64 rows x 64 columns = 4 x 4 MFMA tiles
+  const int fj = lane & 15, fg = lane >> 4;
+  const unsigned char *a_frag = As + (wm * 64 + fj) * 64 + fg * 16;
+  const unsigned char *w_frag = Bs + (wn * 64 + fj) * 64 + fg * 16;
+  f32x4 acc[4][4];      // [column sub-tile i][row sub-tile t]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[i][t] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+
+  const int nk = Kp / HK;
+  load_tile(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    store_tile();
+    __syncthreads();
+    if (kt + 1 < nk) load_tile((kt + 1) * HK);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 fa[4], fw[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        fa[t] = *(const bf16x8 *)(a_frag + kk * PLANE + t * 16 * 64);
+        fw[t] = *(const bf16x8 *)(w_frag + kk * PLANE + t * 16 * 64);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fa[t], acc[i][t], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // D[n_local = 4 fg + r][m_local = fj]: four consecutive columns of row fj
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + wn * 64 + 16 * i + 4 * fg;
+    const f32x4 c4 = *(const f32x4 *)(g.cb + n);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int m = m0 + wm * 64 + 16 * t + fj;
+      if (m < g.M) *(f32x4 *)(g.C + (long)m * g.ldc + n) = (acc[i][t] + c4) * g.alpha;
+    }
+  }
+}
+
+}  // namespace
+
+int gemm_bf16_pitch(int K) { return (K + HK - 1) / HK * HK; }
+
+// floats of scratch launch_gemm_bf16 needs for an (N, K) weight: the fp32 row vector W beta + the bf16 image (rows padded to 64 columns)
+size_t gemm_bf16_stage_floats(int N, int K) { return (size_t)N * gemm_bf16_pitch(K) / 2 + (size_t)N + 64; }
+
+// shape side of the eligibility (plan time: decides whether a modality keeps a bf16 image of its context rows)
+bool gemm_bf16_shape_ok(long M, int N, int K) {
+  static const bool off = getenv("HN_NO_BF16_PROJ") != nullptr;      // development switch: the fp32 projection under core_precision = bf16
+  return !off && M >= 2048 && M < (1L << 31) && K >= 256 && N >= HNT && N % HNT == 0;
+}
+
+bool gemm_bf16_eligible(const GemmArgs &g) {
+  const bool plain = g.W2 == nullptr && g.batch == 1 && (g.pro == PRO_NONE || g.pro == PRO_AFFINE) && !g.bias && !g.R && g.act == ACT_NONE &&
+                     g.glu_offset == 0 && (g.col_group == 0 || g.col_group == g.col_group_pitch);
+  return plain && gemm_bf16_shape_ok(g.M, g.N, g.K) && g.ldc % 4 == 0 && ((uintptr_t)g.C & 15) == 0;
+}
+
+int launch_rows_to_bf16(const float *A, long lda, long M, int K, uint16_t *out, hipStream_t s) {
+  HN_REQUIRE(A && out, HN_E_NULL, "rows_to_bf16: NULL operand");
+  HN_REQUIRE(lda % 4 == 0 && (((uintptr_t)A | (uintptr_t)out) & 15) == 0, HN_E_SHAPE, "rows_to_bf16: unaligned operand (lda=%ld)", lda);
+  const int Kp = gemm_bf16_pitch(K);
+  const long blocks = (M * (Kp / 8) + 255) / 256;
+  HN_REQUIRE(blocks < (1L << 31), HN_E_UNSUPPORTED, "rows_to_bf16: grid too large");
+  hipLaunchKernelGGL(rows_to_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, A, lda, M, K, Kp, (u32x4 *)out);
+  HN_LAUNCH_CHECK("rows_to_bf16");
+  return HN_OK;
+}
+
+// g describes the fp32 product (A is not read: Ab = its bf16 image from launch_rows_to_bf16, pitch gemm_bf16_pitch(K))
+int launch_gemm_bf16(const GemmArgs &g, const uint16_t *Ab, float *stage, hipStream_t s) {
+  HN_REQUIRE(Ab && g.W && g.C && stage, HN_E_NULL, "gemm_bf16: NULL operand");
+  HN_REQUIRE(gemm_bf16_eligible(g), HN_E_UNSUPPORTED, "gemm_bf16: M=%d N=%d K=%d not eligible", g.M, g.N, g.K);
+  HN_REQUIRE((((uintptr_t)stage | (uintptr_t)Ab) & 15) == 0, HN_E_WORKSPACE, "gemm_bf16: staging buffers must be 16-byte aligned");
+  HN_REQUIRE(g.pro == PRO_NONE || (g.gamma && g.beta), HN_E_NULL, "gemm_bf16: prologue needs gamma and beta");
+  const int Kp = gemm_bf16_pitch(g.K);
+  float *cb = stage;                                        // N floats (N % 128 == 0: the image behind it stays 16-byte aligned)
+  uint16_t *Wb = (uint16_t *)(stage + g.N);
+  const bool affine = g.pro == PRO_AFFINE;
+  hipLaunchKernelGGL(gemm_bf16_stage_kernel, dim3((unsigned)g.N), dim3(256), 0, s, g.W, g.ldw, affine ? g.gamma : nullptr,
+                     affine ? g.beta : nullptr, g.K, Kp, (unsigned *)Wb, cb);
+  HN_LAUNCH_CHECK("gemm_bf16_stage");
+  Bf16GemmArgs a;
+  a.Ab = Ab; a.Wb = Wb; a.cb = cb; a.C = g.C; a.ldc = g.ldc; a.alpha = g.alpha; a.M = g.M; a.Kp = Kp;
+  a.ntm = (g.M + HM - 1) / HM; a.ntn = g.N / HNT;
+  const long blocks = (long)((a.ntm + 7) / 8) * 8 * a.ntn;
+  HN_REQUIRE(blocks < (1L << 31), HN_E_UNSUPPORTED, "gemm_bf16: grid too large");
+  hipLaunchKernelGGL(gemm_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  HN_LAUNCH_CHECK("gemm_bf16");
+  return HN_OK;
+}
+
+}  // namespace hn
