@@ -13,13 +13,17 @@
 //   * the context rows are rounded ONCE per forward (rows_to_bf16_kernel: Ab, same zero-padded 64-column pitch -- rows start on
 //     128-byte lines) and serve every layer's projection: half the bytes per k-tile, no conversion in the loop.
 //   * gemm_bf16_kernel: 128 x 128 output tile, 64-wide k-tiles, both operands as 16-byte pieces (8 lanes = one line of a row)
-//     through registers into LDS, one k-tile ahead.  The LDS image of an operand is [k-half][row][32 bf16] -- a 16 x 32 sub-tile
-//     is ONE contiguous KB in exactly the order the MFMA operand fragment reads it (lane (g, j) = row j, k = 8 g .. 8 g + 7:
-//     16 bytes at (16 t + j) * 64 + 16 g), so fragment reads and loader writes are conflict free without padding or swizzle.
+//     through registers into a two-stage LDS image [stage][A k-half 0, 1, W k-half 0, 1][row][32 bf16]: a 16 x 32 sub-tile is one
+//     KB in the order the MFMA operand fragment reads it (lane (g, j) = row j, k = 8 g .. 8 g + 7), with the 16-byte chunks of a
+//     row XOR-swizzled and the k-halves 64 bytes off a 128-byte multiple so that neither ds_read_b128 nor ds_write_b128 conflicts
+//     (lane groups of MI355X_MICROARCH.md "LDS"; SQ_LDS_BANK_CONFLICT was a third of the LDS cycles without the two).
+//   * one barrier per k-tile: tile kt is contracted from stage kt & 1 while tile kt + 1 moves registers -> other stage and tile
+//     kt + 2 is requested from memory, each of those instructions issued in the shadow of one MFMA of the first k-half.
 //   * W sub-tiles are the MFMA's A operand and context sub-tiles its B operand: the accumulator quad of a lane is then four
 //     CONSECUTIVE output columns of one row -> float4 stores.
 //   * work-item order as gemm_big_kernel: the column tiles that share a 128-row block of A run back to back on one XCD.
 #include "common.h"
+#include <type_traits>
 
 namespace hn {
 
@@ -30,7 +34,10 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 namespace {
 
 constexpr int HM = 128, HNT = 128, HK = 64;
-constexpr int PLANE = 128 * 64;      // bytes of one k-half of an operand tile: 128 rows x 32 bf16
+// bytes between the two k-halves of an operand tile (128 rows x 32 bf16 each) + 64: the 8 lanes ds_write_b128 serves per LDS cycle hold
+// the 8 pieces of ONE row -- 4 per k-half -- and the pad puts the second half's chunks on the other 16 banks of the 128-byte window
+// (without it: two-way conflicts on every store, a third of the LDS cycles of the loop by SQ_LDS_BANK_CONFLICT)
+constexpr int PLANE = 128 * 64 + 64;
 
 __device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
   unsigned r;
@@ -99,9 +106,8 @@ struct Bf16GemmArgs {
   int M, Kp, ntm, ntn;
 };
 
-__global__ __launch_bounds__(256, 3) void gemm_bf16_kernel(Bf16GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) unsigned char As[2 * PLANE];
-  __shared__ __attribute__((aligned(16))) unsigned char Bs[2 * PLANE];
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];      // two stages of {A k-half 0, 1, W k-half 0, 1}
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int id = blockIdx.x, xcd = id & 7, seq = id >> 3;
   const int n_tile = seq % g.ntn, m_tile = (seq / g.ntn) * 8 + xcd;
@@ -125,46 +131,78 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_kernel(Bf16GemmArgs g) {
       rb[j] = *(const u32x4 *)(wrow[j] + k0);
     }
   };
-  const int dst = (lp >> 2) * PLANE + lr * 64 + (lp & 3) * 16;
-  auto store_tile = [&]() {
+  // chunk swizzle: the 16-byte chunk c of row r lives at chunk c ^ s(r / 4 % 4), s = (0, 3, 2, 1): the 16 lanes ds_read_b128 serves per
+  // LDS cycle ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... of the wave: rows j and j + 12 of one k-chunk with rows j + 4 .. j + 11 of
+  // the next) then hit 16 different chunk columns (unswizzled: two-way conflicts, measured 5 % of the loop)
+  const int dst = (lp >> 2) * PLANE + lr * 64 + (((lp & 3) ^ ((0 - (lr >> 2)) & 3)) * 16);
+  auto store_tile = [&](unsigned char *stage) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      *(u32x4 *)(As + dst + j * 32 * 64) = ra[j];
-      *(u32x4 *)(Bs + dst + j * 32 * 64) = rb[j];
+      *(u32x4 *)(stage + dst + j * 32 * 64) = ra[j];
+      *(u32x4 *)(stage + 2 * PLANE + dst + j * 32 * 64) = rb[j];
     }
   };
 
   const int wm = wave >> 1, wn = wave & 1;      // a wave owns 64 rows x 64 columns = 4 x 4 MFMA tiles
   const int fj = lane & 15, fg = lane >> 4;
-  const unsigned char *a_frag = As + (wm * 64 + fj) * 64 + fg * 16;
-  const unsigned char *w_frag = Bs + (wn * 64 + fj) * 64 + fg * 16;
+  const int fsw = (fg ^ ((0 - (fj >> 2)) & 3)) * 16;
+  const int a_off = (wm * 64 + fj) * 64 + fsw, w_off = 2 * PLANE + (wn * 64 + fj) * 64 + fsw;
   f32x4 acc[4][4];      // [column sub-tile i][row sub-tile t]
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[i][t] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 
+  // Software pipeline, ONE barrier per k-tile: while tile kt is contracted from stage kt & 1, tile kt + 1 moves from registers into
+  // the other stage and tile kt + 2 is requested from memory (a whole contraction ahead of its first use).  With two barriers and
+  // one stage the phases of all resident workgroups ran in step and their costs added up (measured: matrix 33 + loads 22 + LDS 26 us
+  // = the 80 us of the loop).
   const int nk = Kp / HK;
   load_tile(0);
-  for (int kt = 0; kt < nk; ++kt) {
-    store_tile();
-    __syncthreads();
-    if (kt + 1 < nk) load_tile((kt + 1) * HK);
+  store_tile(lds_raw);
+  if (nk > 1) load_tile(HK);
+  __syncthreads();
+  auto tile = [&](int kt, auto do_store, auto do_load) {
+    const unsigned char *cur = lds_raw + (kt & 1) * 4 * PLANE;
+    unsigned char *nxt = lds_raw + ((kt + 1) & 1) * 4 * PLANE;
+    const int k2 = (kt + 2) * HK;
+    bf16x8 fa[2][4], fw[2][4];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 fa[4], fw[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        fa[t] = *(const bf16x8 *)(a_frag + kk * PLANE + t * 16 * 64);
-        fw[t] = *(const bf16x8 *)(w_frag + kk * PLANE + t * 16 * 64);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fa[t], acc[i][t], 0, 0, 0);
+    for (int t = 0; t < 4; ++t) {
+      fa[0][t] = *(const bf16x8 *)(cur + a_off + t * 16 * 64);
+      fw[0][t] = *(const bf16x8 *)(cur + w_off + t * 16 * 64);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    // first k-half: in the shadow of each MFMA one fragment read of the second k-half, then one LDS store (tile kt + 1) or one global
+    // load (tile kt + 2)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      acc[q >> 2][q & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[0][q >> 2], fa[0][q & 3], acc[q >> 2][q & 3], 0, 0, 0);
+      if (q < 4) fw[1][q] = *(const bf16x8 *)(cur + PLANE + w_off + q * 16 * 64);
+      else if (q < 8) fa[1][q - 4] = *(const bf16x8 *)(cur + PLANE + a_off + (q - 4) * 16 * 64);
+      if (q < 8) {
+        if constexpr (decltype(do_store)::value) {
+          if (q < 4) *(u32x4 *)(nxt + dst + q * 32 * 64) = ra[q & 3];
+          else *(u32x4 *)(nxt + 2 * PLANE + dst + (q - 4) * 32 * 64) = rb[q & 3];
+        }
+      } else {
+        if constexpr (decltype(do_load)::value) {
+          if (q < 12) ra[q & 3] = *(const u32x4 *)(arow[q & 3] + k2);
+          else rb[q & 3] = *(const u32x4 *)(wrow[q & 3] + k2);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+      acc[q >> 2][q & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[1][q >> 2], fa[1][q & 3], acc[q >> 2][q & 3], 0, 0, 0);
     __syncthreads();
-  }
+  };
+  const std::true_type yes;
+  const std::false_type no;
+  for (int kt = 0; kt + 2 < nk; ++kt) tile(kt, yes, yes);
+  if (nk >= 2) tile(nk - 2, yes, no);
+  tile(nk - 1, no, no);
 
   // D[n_local = 4 fg + r][m_local = fj]: four consecutive columns of row fj
 #pragma unroll
@@ -227,7 +265,15 @@ int launch_gemm_bf16(const GemmArgs &g, const uint16_t *Ab, float *stage, hipStr
   a.ntm = (g.M + HM - 1) / HM; a.ntn = g.N / HNT;
   const long blocks = (long)((a.ntm + 7) / 8) * 8 * a.ntn;
   HN_REQUIRE(blocks < (1L << 31), HN_E_UNSUPPORTED, "gemm_bf16: grid too large");
-  hipLaunchKernelGGL(gemm_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  constexpr int lds_bytes = 2 * 4 * PLANE;      // 66 048: above the 64 KB a kernel gets without asking
+  static bool configured[64] = {};
+  int dev = 0;
+  HN_HIP_CHECK(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64 || !configured[dev]) {
+    HN_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    if (dev >= 0 && dev < 64) configured[dev] = true;
+  }
+  hipLaunchKernelGGL(gemm_bf16_kernel, dim3((unsigned)blocks), dim3(256), lds_bytes, s, a);
   HN_LAUNCH_CHECK("gemm_bf16");
   return HN_OK;
 }
