@@ -20,6 +20,7 @@ import argparse, collections, csv, glob, json, os, shutil, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PEAK_FP32 = 157.3e12
+PEAK_BF16 = 2.5e15      # dense bf16 MFMA (the patch-bag K/V projection under core_precision = bf16, gemm_bf16.hip)
 PEAK_EXP = 256 * 4 * 64 / 16 * 2.4e9
 L, d, H, DH = 128, 128, 8, 64
 INNER = H * DH
@@ -94,7 +95,7 @@ def main():
     args = ap.parse_args()
     out = os.path.abspath(args.out)
     os.makedirs(out, exist_ok=True)
-    cases = [(c, p) for c in args.cfg for p in {2: ["fp32"], 3: ["bf16"], 4: ["fp32"], 5: ["fp32", "bf16"]}[c]]
+    cases = [(c, p) for c in args.cfg for p in {2: ["fp32"], 3: ["bf16"], 4: ["fp32", "bf16"], 5: ["fp32", "bf16"]}[c]]
     doc = {"peaks": {"fp32_mfma_flops": PEAK_FP32, "v_exp_f32_per_s": PEAK_EXP,
                      "derivation": "fp32 MFMA: MI355X_MICROARCH.md chip table; exp: 256 CUs x 4 SIMDs x 64 lanes / 16 cycles x 2.4 GHz"},
            "git_head": os.environ.get("HN_GIT_HEAD"), "configs": []}
@@ -149,7 +150,7 @@ def main():
         dom_us = float(dom["AverageNs"]) / 1e3
         # which modality the dominant kernel serves: the one with the largest core FLOPs
         mod = max(cfg["mods"], key=lambda m: core_flops(m, cfg["b"], prec)[0])
-        if "gemm_big" in dom_name:
+        if "gemm_big" in dom_name or "gemm_bf16_kernel" in dom_name:
             fl, formula = 2.0 * cfg["b"] * 4096 * 773 * 2 * INNER, "2*(b*N)*D*(2*inner) (patch-bag K/V projection, N=4096, D=773, inner=512)"
         else:
             fl, formula = core_flops(mod, cfg["b"], prec)
@@ -171,25 +172,47 @@ def main():
         }
         dk = entry["dominant_kernel"]
         n_scores = sum(1.0 * L * m[1] * H * cfg["b"] for m in cfg["mods"] if m[0] in ("img", "vol")) * cfg["depth"]
-        if prec == "bf16" and "bf16" in dom_name:
+        if prec == "bf16" and "attn_core_bf16" in dom_name:
             scores = 1.0 * L * mod[1] * H * cfg["b"]
             dk["scores_per_launch"] = scores
             dk["scores_per_s"] = scores / (dom_us * 1e-6)
             dk["bound"] = "valu (v_exp_f32)"
             dk["frac"] = round(dk["scores_per_s"] / PEAK_EXP, 4)
             dk["frac_of"] = "chip v_exp_f32 rate (one exponential per attention score)"
+        elif "gemm_bf16_kernel" in dom_name:
+            dk["bound"] = "mfma (bf16)"
+            dk["frac"] = round(fl / (dom_us * 1e-6) / PEAK_BF16, 4)
+            dk["frac_of"] = "dense bf16 MFMA peak 2.5 PF/s"
         else:
             dk["bound"] = "mfma (fp32)"
             dk["frac"] = round(fl / (dom_us * 1e-6) / PEAK_FP32, 4)
             dk["frac_of"] = "fp32 MFMA peak 157.3 TF/s"
+        # the bf16 K/V projection of the patch bags (core_precision = bf16), whether or not it dominates: both of its roofs
+        for k in kernels:
+            if "gemm_bf16_kernel" in k["Name"]:
+                us = float(k["AverageNs"]) / 1e3
+                pfl = 2.0 * cfg["b"] * 4096 * 773 * 2 * INNER
+                byts = cfg["b"] * 4096 * (2 * INNER * 4 + 832 * 2)       # fp32 K|V rows written + the bf16 context image read once
+                entry_kv = {"name": k["Name"], "calls": int(k["Calls"]), "avg_us": round(us, 2), "executed_flops_per_launch": pfl,
+                            "achieved_tflops": round(pfl / (us * 1e-6) / 1e12, 1), "frac_of_bf16_mfma_peak": round(pfl / (us * 1e-6) / PEAK_BF16, 4),
+                            "algorithmic_bytes_per_launch": byts, "achieved_tb_s": round(byts / (us * 1e-6) / 1e12, 2),
+                            "frac_of_hbm_8tb_s": round(byts / (us * 1e-6) / 8e12, 4),
+                            "note": "fp32 K|V output (b*N x 1024 floats) + bf16 context image (b*N x 832) per launch: the HBM side is the nearer roof"}
+                break
+        else:
+            entry_kv = None
+        if entry_kv:
+            entry["bf16_kv_projection_kernel"] = entry_kv
         if prec == "bf16":
             # two roofs in one forward: the bf16 cores are priced in exponentials (their bound), everything else in fp32 matrix
             # FLOPs; the end-to-end fraction is the sum of the two ideal times over the measured time
-            fp32_fl = sum(v for k, v in comp.items() if not k.startswith("attention cores (img") and not k.startswith("attention cores (vol"))
-            ideal = fp32_fl / PEAK_FP32 + n_scores / PEAK_EXP
-            entry["forward_ideal_ms"] = {"fp32_matrix": round(fp32_fl / PEAK_FP32 * 1e3, 4), "bf16_core_exponentials": round(n_scores / PEAK_EXP * 1e3, 4)}
+            proj_fl = comp.get("patch-bag K/V projection", 0.0)      # on bf16 MFMA under core_precision = bf16
+            fp32_fl = sum(v for k, v in comp.items() if not k.startswith("attention cores (img") and not k.startswith("attention cores (vol")) - proj_fl
+            ideal = fp32_fl / PEAK_FP32 + n_scores / PEAK_EXP + proj_fl / PEAK_BF16
+            entry["forward_ideal_ms"] = {"fp32_matrix": round(fp32_fl / PEAK_FP32 * 1e3, 4), "bf16_core_exponentials": round(n_scores / PEAK_EXP * 1e3, 4),
+                                         "bf16_kv_projection": round(proj_fl / PEAK_BF16 * 1e3, 4)}
             entry["forward_frac_executed"] = round(ideal / (ms * 1e-3), 4)
-            entry["forward_frac_of"] = "(fp32 matrix FLOPs outside the bf16 cores / fp32 MFMA peak + attention scores of the bf16 cores / chip v_exp_f32 rate) / forward time"
+            entry["forward_frac_of"] = "(fp32 matrix FLOPs outside the bf16 cores and the bf16 K/V projection / fp32 MFMA peak + attention scores of the bf16 cores / chip v_exp_f32 rate + patch-bag K/V projection FLOPs / bf16 MFMA peak) / forward time"
             entry["forward_scores_frac_of_exp_rate"] = round(n_scores / (ms * 1e-3) / PEAK_EXP, 4)
         else:
             entry["forward_frac_executed"] = round(total_fl / (ms * 1e-3) / PEAK_FP32, 4)
