@@ -113,6 +113,28 @@ def test_masked_bag_and_embeddings(hn):
     assert float((got - want).abs().max()) <= 2e-2 * float(want.abs().max())
 
 
+def test_graph_replay_with_the_bf16_projection(hn):
+    """HealNet.capture() on a fresh model (the FIRST bf16 projection launch of the process for this kernel configuration happens
+    inside the stream capture: the kernel's dynamic-LDS attribute is set there): replay == eager forward bit for bit on new values."""
+    kw = dict(n_modalities=2, channel_dims=[40, 300], num_spatial_axes=[1, 1], out_dims=4, depth=2, l_c=32, l_d=128, num_freq_bands=2,
+              max_freq=2.0)
+    torch.manual_seed(31)
+    model = hn.HealNet(**kw, core_precision="bf16").eval().to(DEV)
+    gen = torch.Generator().manual_seed(32)
+    shapes = [(2, 1, 40), (2, 1100, 300)]
+    graph = model.capture([torch.rand(*s, generator=gen).to(DEV) for s in shapes])
+    for trial in range(2):
+        ins = [torch.rand(*s, generator=gen).to(DEV) for s in shapes]
+        with torch.no_grad():
+            got = graph(list(ins)).clone()
+            eager = model(list(ins))
+        assert torch.equal(got, eager), f"trial {trial}"
+    model.core_precision = "fp32"
+    with torch.no_grad():
+        full = model(list(ins))
+    assert not torch.equal(full, eager) and float((full - eager).abs().max()) <= 2e-3 * float(full.abs().max())
+
+
 def test_training_forward_is_untouched(hn):
     """Training always projects in fp32 (the backward differentiates that product): logits and gradients of a
     core_precision='bf16' model in train mode are bit-identical to the fp32 model's."""
