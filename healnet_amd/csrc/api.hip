@@ -348,6 +348,62 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
     return launch_gemm(go, s);
   }
 
+  // ---- explicit binding of a large patch bag under core_precision = bf16 (inference): K / V projected on bf16 MFMA straight into
+  // the bf16 images of the explicit bf16 core (heads of 64, N % 32 == 0); otherwise the projection alone (fp32 rows, attn_prepare)
+  static const bool no_expl16 = getenv("HN_NO_BF16_EXPL_CORE") != nullptr;      // development switch
+  if (pl.ctx16 && pl.wstage && ctx && !pl.rank_d && !dropping && !no_expl16 && pl.dh == 64 && pl.dhp == 64 && pl.N % 32 == 0 &&
+      p->heads % 2 == 0 && !narrow_ln(p)) {
+    GemmArgs gk = gemm_defaults();
+    gk.A = ctx; gk.lda = ld_ctx; gk.M = b * pl.N; gk.K = pl.D;
+    if (p->ctx_gamma) { gk.pro = PRO_AFFINE; gk.gamma = p->ctx_gamma; gk.beta = p->ctx_beta; }
+    gk.W = p->w_kv; gk.ldw = pl.D;
+    gk.N = 2 * pl.inner;
+    gk.C = pl.kv; gk.ldc = 2 * pl.inner;      // (not written: the images below alias it)
+    if (gemm_bf16_eligible(gk)) {
+      // the fp32 K|V rows of this plan (b N x 2 inner floats) hold K16 (a quarter), V16 (a quarter) and the query image
+      uint16_t *K16 = (uint16_t *)pl.kv;
+      uint16_t *V16 = K16 + (size_t)b * pl.N * pl.inner;
+      uint16_t *Q16 = V16 + (size_t)b * pl.N * pl.inner;
+      HN_REQUIRE((size_t)b * p->heads * pl.Lp * 64 <= (size_t)b * pl.N * pl.inner * 2, HN_E_WORKSPACE, "attn: bf16 query image does not fit");
+      const bool q_done = ext && ext->q && ext->q_done;
+      float *qbuf = q_done ? ext->q : pl.q;
+      if (!q_done) {
+        GemmArgs gq = gemm_defaults();
+        gq.A = x_in; gq.lda = p->query_dim;
+        gq.W = p->w_q; gq.ldw = p->query_dim;
+        gq.M = b * L; gq.N = pl.inner; gq.K = p->query_dim;
+        if (p->norm_w) { gq.pro = PRO_LAYERNORM; gq.gamma = p->norm_w; gq.beta = p->norm_b; }
+        gq.C = qbuf; gq.ldc = pl.inner; gq.alpha = pl.cscale;
+        if ((rc = launch_gemm(gq, s)) != HN_OK) return rc;
+      }
+      if ((rc = launch_q_rows_to_bf16(qbuf, pl.inner, b, p->heads, L, pl.Lp, Q16, s)) != HN_OK) return rc;
+      if ((rc = launch_gemm_bf16(gk, pl.ctx16, pl.wstage, s, K16, V16, pl.N)) != HN_OK) return rc;
+      AttnCoreBf16Args ca;
+      memset(&ca, 0, sizeof(ca));
+      ca.Qf = Q16; ca.zb = K16; ca.zT = V16; ca.mask = mask;
+      ca.Opart = pl.opart; ca.Mpart = pl.mpart; ca.Lpart = pl.lpart;
+      ca.b = b; ca.h = p->heads; ca.Lq = L; ca.Lp = pl.Lp; ca.N = pl.N; ca.Np = pl.N; ca.DV = 64;
+      ca.chunk = (pl.chunk + 31) / 32 * 32;                    // (<= the plan's split count: the partial buffers are sized for it)
+      ca.nsplit = (pl.N + ca.chunk - 1) / ca.chunk;
+      ca.ns = 1; ca.expl = 1; ca.k_pitch = pl.inner * 2;
+      if (ev0) HN_HIP_CHECK(hipEventRecord(ev0, s));
+      if ((rc = launch_attn_core_bf16(ca, s)) != HN_OK) return rc;
+      if (ev1) HN_HIP_CHECK(hipEventRecord(ev1, s));
+      if ((rc = launch_merge_explicit(pl.opart, pl.mpart, pl.lpart, ca.nsplit, b, p->heads, L, pl.Lp, 64, pl.dh, pl.obuf, pl.inner, stats,
+                                      s)) != HN_OK) return rc;
+      if (ext && ext->defer_out) { ext->o_out = pl.obuf; ext->ldo_out = pl.inner; return HN_OK; }
+      GemmArgs go = gemm_defaults();
+      go.A = pl.obuf; go.lda = pl.inner;
+      go.W = p->w_out; go.ldw = wo_ld(p);
+      go.C = x_out; go.ldc = p->query_dim;
+      go.bias = p->b_out;
+      go.M = b * L; go.N = p->query_dim; go.K = pl.inner;
+      go.act = ACT_LEAKY;
+      if (residual) { go.R = x_in; go.ldr = p->query_dim; }
+      return launch_gemm(go, s);
+    }
+  }
+
   AttnCoreArgs core;
   const int pack_ks = (pl.rank_d && pl.ones && ctx_has_ones && p->ctx_gamma) ? ctx_pack_ks : 0;
   if ((rc = attn_prepare(p, pl, x_in, ctx, ld_ctx, b, L, s, &core, pack_ks,

@@ -46,10 +46,14 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
 }
 __device__ __forceinline__ bf16x8 as_bf16x8(const f32x4 &v) { return __builtin_bit_cast(bf16x8, v); }
 
-template <int DTV, int NQ, int NS>
+// EXPL: the explicit K / V binding of a patch bag under core_precision = bf16 (dim_head 64): K is the token-major bf16 image the
+// projection wrote ((b, N, inner): row pitch a.k_pitch bytes, head h at column 64 h), V its fragment-major image per (b, head)
+// ((N / 32, 4, 4, 16, 8): the same 1 KB tiles as zT), the query rows are the scaled projections themselves (64 slots), and the
+// softmax denominator is summed on the vector pipe (V has no ones column); running reference (no score bound), N % 32 == 0.
+template <int DTV, int NQ, int NS, bool EXPL = false>
 __global__ __launch_bounds__(256) void attn_core_bf16_kernel(AttnCoreBf16Args a, int ngroups, int gy, int waves_per_block) {
   constexpr int DV = 16 * DTV;
-  constexpr int NKQ = NS == 1 ? 1 : (DTV == 1 ? 2 : 3);      // 32-slot blocks of the QK^T contraction
+  constexpr int NKQ = EXPL ? 2 : (NS == 1 ? 1 : (DTV == 1 ? 2 : 3));      // 32-slot blocks of the QK^T contraction
   constexpr int ZP = 32 * NKQ;                                // slots per context / query row
   const int L = a.Lq;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -82,10 +86,12 @@ __global__ __launch_bounds__(256) void attn_core_bf16_kernel(AttnCoreBf16Args a,
   f32x4 O[NQ][DTV];
   f32x4 negm[NQ];
   float m[NQ];
+  float lsum[NQ];      // EXPL: this lane's share (8 of every 32 tokens) of its query row's denominator
 #pragma unroll
   for (int i = 0; i < NQ; ++i) {
     negm[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     m[i] = 0.0f;
+    lsum[i] = 0.0f;
 #pragma unroll
     for (int d = 0; d < DTV; ++d) O[i][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
@@ -107,9 +113,14 @@ __global__ __launch_bounds__(256) void attn_core_bf16_kernel(AttnCoreBf16Args a,
   const int t_end = min(a.N, t_begin + a.chunk);
   const uint8_t *mrow = a.mask ? a.mask + (long)bi * a.N : nullptr;
 
-  const i32x4 krs = make_rsrc(a.zb + (long)bi * a.Np * ZP, (unsigned)((long)a.Np * ZP * 2));
-  const i32x4 vrs = make_rsrc(a.zT + (long)bi * NS * DV * a.Np, (unsigned)((long)NS * DV * a.Np * 2));
-  const int koff = (8 * (j >> 2) + (j & 3)) * (ZP * 2) + 16 * g;
+  // (EXPL: the descriptor ends with this head's last row, so token rows past N read 0 whatever the other heads hold there)
+  const int kpitch = EXPL ? a.k_pitch : ZP * 2;      // bytes per token row of the QK^T image
+  const int hi = bh - bi * a.h;
+  const i32x4 krs = EXPL ? make_rsrc(a.zb + ((long)bi * a.N * kpitch) / 2 + hi * 64, (unsigned)((long)a.N * kpitch - hi * 128))
+                         : make_rsrc(a.zb + (long)bi * a.Np * ZP, (unsigned)((long)a.Np * ZP * 2));
+  const i32x4 vrs = EXPL ? make_rsrc(a.zT + (long)bh * DV * a.Np, (unsigned)((long)DV * a.Np * 2))
+                         : make_rsrc(a.zT + (long)bi * NS * DV * a.Np, (unsigned)((long)NS * DV * a.Np * 2));
+  const int koff = (8 * (j >> 2) + (j & 3)) * kpitch + 16 * g;
   int voff[NS][DTV];
 #pragma unroll
   for (int p = 0; p < NS; ++p)
@@ -120,7 +131,7 @@ __global__ __launch_bounds__(256) void attn_core_bf16_kernel(AttnCoreBf16Args a,
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
-      for (int k = 0; k < NKQ; ++k) kf[x][k] = hn_buffer_load_x4(krs, koff + x * 4 * (ZP * 2) + 64 * k, t0 * (ZP * 2), 0);
+      for (int k = 0; k < NKQ; ++k) kf[x][k] = hn_buffer_load_x4(krs, koff + x * 4 * kpitch + 64 * k, t0 * kpitch, 0);
 #pragma unroll
     for (int p = 0; p < NS; ++p)
 #pragma unroll
@@ -189,6 +200,7 @@ __global__ __launch_bounds__(256) void attn_core_bf16_kernel(AttnCoreBf16Args a,
         if (!(delta > -3.0e38f)) delta = 0.0f;          // row saw only -inf scores: keep the reference
         const float alpha = unset ? 1.0f : fast_exp2_b(-delta);
         m[i] += delta;
+        if (EXPL) lsum[i] *= alpha;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float ar = __shfl(alpha, 4 * g + r);    // accumulator reg r of lane (g, d) belongs to query row 4 g + r
@@ -204,6 +216,11 @@ __global__ __launch_bounds__(256) void attn_core_bf16_kernel(AttnCoreBf16Args a,
       unset = false;
     }
 
+    if (EXPL) {
+#pragma unroll
+      for (int i = 0; i < NQ; ++i)
+        lsum[i] += ((P[i][0][0] + P[i][0][1]) + (P[i][0][2] + P[i][0][3])) + ((P[i][1][0] + P[i][1][1]) + (P[i][1][2] + P[i][1][3]));
+    }
     // ---- O += P V: A = the eight probabilities of this lane's query, B = eight consecutive tokens of a channel
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
@@ -238,7 +255,7 @@ __global__ __launch_bounds__(256) void attn_core_bf16_kernel(AttnCoreBf16Args a,
   };
 
   f32x4 kA[2][NKQ], kB[2][NKQ], vA[NS][DTV], vB[NS][DTV];
-  if (NS == 1 && bounded && mrow == nullptr && !a.no_pipeline) {
+  if (!EXPL && NS == 1 && bounded && mrow == nullptr && !a.no_pipeline) {
     // ---- software-pipelined loop for the bounded reference without a key mask (the inference forward of BASELINE configs[2]).
     // tools/ubench/mfma_valu_overlap.hip: on gfx950 a block of v_mfma_f32_16x16x32_bf16 and a block of v_exp_f32 of the waves
     // of one SIMD do NOT overlap (both = 0.92 x the sum), but with the exponentials PINNED between the MFMAs of the same wave
@@ -323,7 +340,12 @@ __global__ __launch_bounds__(256) void attn_core_bf16_kernel(AttnCoreBf16Args a,
         for (int r = 0; r < 4; ++r)
           a.Opart[(prow + tile * 16 + 4 * g + r) * DV + 16 * d + j] = O[i][d][r];
       if (g == 0) a.Mpart[prow + tile * 16 + j] = m[i];
-      if (j == 15) {
+      if (EXPL) {
+        float l = lsum[i];
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        if (g == 0) a.Lpart[prow + tile * 16 + j] = l;
+      } else if (j == 15) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) a.Lpart[prow + tile * 16 + 4 * g + r] = O[i][DTV - 1][r];
       }
@@ -333,6 +355,21 @@ __global__ __launch_bounds__(256) void attn_core_bf16_kernel(AttnCoreBf16Args a,
 }
 
 int launch_attn_core_bf16(const AttnCoreBf16Args &a, hipStream_t s) {
+  if (a.expl) {
+    HN_REQUIRE(a.DV == 64 && a.ns == 1 && a.N % 32 == 0 && a.Np == a.N && a.k_pitch >= 128 && a.k_pitch % 16 == 0 && !a.bound, HN_E_UNSUPPORTED,
+               "attn_core_bf16 (explicit binding): DV=%d ns=%d N=%d k_pitch=%d", a.DV, a.ns, a.N, a.k_pitch);
+    HN_REQUIRE(a.Lp % 16 == 0 && a.chunk % 32 == 0 && a.nsplit >= 1 && (long)a.N * a.k_pitch < (1L << 31), HN_E_SHAPE,
+               "attn_core_bf16 (explicit binding): Lp=%d chunk=%d N=%d", a.Lp, a.chunk, a.N);
+    constexpr int NQE = 2;      // 4 x 16 output columns per query tile: two tiles per wave keep the accumulators + both prefetch sets in registers
+    const int ngroups = ceil_div(a.Lp / 16, NQE);
+    const int wpb = ngroups < 4 ? ngroups : 4;
+    const int gy = ceil_div(ngroups, wpb);
+    const long blocks = (long)a.nsplit * gy * a.b * a.h;
+    HN_REQUIRE(blocks < (1L << 31), HN_E_UNSUPPORTED, "attn_core_bf16: grid too large");
+    hipLaunchKernelGGL((attn_core_bf16_kernel<4, NQE, 1, true>), dim3((unsigned)blocks), dim3(64 * wpb), 0, s, a, ngroups, gy, wpb);
+    HN_LAUNCH_CHECK("attn_core_bf16(explicit)");
+    return HN_OK;
+  }
   HN_REQUIRE(a.DV == 16 || a.DV == 32, HN_E_UNSUPPORTED, "attn_core_bf16: DV=%d", a.DV);
   HN_REQUIRE(a.ns == 1 || a.ns == 2, HN_E_UNSUPPORTED, "attn_core_bf16: ns=%d", a.ns);
   HN_REQUIRE(a.Lp % 16 == 0 && a.chunk % 32 == 0 && a.nsplit >= 1 && a.Np % 32 == 0 && a.Np >= a.N, HN_E_SHAPE,

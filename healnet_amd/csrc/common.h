@@ -256,7 +256,8 @@ bool gemm_bf16_shape_ok(long M, int N, int K);
 bool gemm_bf16_eligible(const GemmArgs &g);
 size_t gemm_bf16_stage_floats(int N, int K);
 int launch_rows_to_bf16(const float *A, long lda, long M, int K, uint16_t *out, hipStream_t s);
-int launch_gemm_bf16(const GemmArgs &g, const uint16_t *Ab, float *stage, hipStream_t s);
+int launch_gemm_bf16(const GemmArgs &g, const uint16_t *Ab, float *stage, hipStream_t s, uint16_t *K16 = nullptr, uint16_t *V16 = nullptr, int tokens = 0);
+int launch_q_rows_to_bf16(const float *Q, long ldq, int b, int heads, int L, int Lp, uint16_t *Qf, hipStream_t s);
 
 // Several skinny products of one shape in ONE launch, operands given per entry (the one-token projections of all layers of a
 // forward: they do not depend on the latent array, and each is a ~9 us latency-bound launch on its own)
@@ -430,6 +431,7 @@ struct AttnCoreBf16Args {                        // bf16-MFMA core of the shared
   int ns;                                        // operand planes: 1 = plain bf16, 2 = hi + lo pairs ("bf16x3")
   int no_pipeline;                               // development knob HN_BF16_NO_PIPELINE: the general loop also for the bounded, unmasked case
   const float *bound; const int *bound_flag;     // per-row score bounds + fallback flag (qfold_bf16_kernel), or NULL
+  int expl, k_pitch;                             // explicit K / V binding (see the kernel): zb = K image with k_pitch bytes per token row, zT = V image per (b, head), Qf (b, h, Lp, 64)
 };
 // bf16 slots per context / query row of the QK^T contraction (see attention_bf16.hip)
 __host__ __device__ constexpr int bf16_row_slots(int DV, int ns) { return ns == 1 ? 32 : (DV == 16 ? 64 : 96); }

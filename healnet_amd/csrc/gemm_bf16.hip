@@ -104,8 +104,13 @@ struct Bf16GemmArgs {
   float *C; long ldc;
   float alpha;
   int M, Kp, ntm, ntn;
+  // IMG: instead of fp32 rows, the bf16 images attn_core_bf16_kernel<.., EXPL> reads (N = 2 * inner, dim_head 64, tokens % 32 == 0):
+  // K16 (M, inner) token-major; V16 per (sample, head) fragment-major (tokens / 32, 4, 4, 16, 8)
+  uint16_t *K16, *V16;
+  int inner, heads, tokens;
 };
 
+template <bool IMG>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];      // two stages of {A k-half 0, 1, W k-half 0, 1}
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -162,7 +167,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16GemmArgs g) {
   store_tile(lds_raw);
   if (nk > 1) load_tile(HK);
   __syncthreads();
-  auto tile = [&](int kt, auto do_store, auto do_load) {
+  auto tile = [&](int kt, auto do_store, auto do_load, auto flip) {
+    constexpr bool FLIP = decltype(flip)::value;      // context sub-tile as the MFMA's A operand: a lane's accumulator quad = four consecutive ROWS
     const unsigned char *cur = lds_raw + (kt & 1) * 4 * PLANE;
     unsigned char *nxt = lds_raw + ((kt + 1) & 1) * 4 * PLANE;
     const int k2 = (kt + 2) * HK;
@@ -177,7 +183,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16GemmArgs g) {
     // load (tile kt + 2)
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      acc[q >> 2][q & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[0][q >> 2], fa[0][q & 3], acc[q >> 2][q & 3], 0, 0, 0);
+      acc[q >> 2][q & 3] = FLIP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][q & 3], fw[0][q >> 2], acc[q >> 2][q & 3], 0, 0, 0)
+                                : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[0][q >> 2], fa[0][q & 3], acc[q >> 2][q & 3], 0, 0, 0);
       if (q < 4) fw[1][q] = *(const bf16x8 *)(cur + PLANE + w_off + q * 16 * 64);
       else if (q < 8) fa[1][q - 4] = *(const bf16x8 *)(cur + PLANE + a_off + (q - 4) * 16 * 64);
       if (q < 8) {
@@ -195,15 +202,46 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16GemmArgs g) {
     }
 #pragma unroll
     for (int q = 0; q < 16; ++q)
-      acc[q >> 2][q & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[1][q >> 2], fa[1][q & 3], acc[q >> 2][q & 3], 0, 0, 0);
+      acc[q >> 2][q & 3] = FLIP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][q & 3], fw[1][q >> 2], acc[q >> 2][q & 3], 0, 0, 0)
+                                : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[1][q >> 2], fa[1][q & 3], acc[q >> 2][q & 3], 0, 0, 0);
     __syncthreads();
   };
   const std::true_type yes;
   const std::false_type no;
-  for (int kt = 0; kt + 2 < nk; ++kt) tile(kt, yes, yes);
-  if (nk >= 2) tile(nk - 2, yes, no);
-  tile(nk - 1, no, no);
+  const bool v_half = IMG && n0 >= g.inner;      // (workgroup-uniform: a 128-column tile lies in the K or in the V half)
+  if (v_half) {
+    for (int kt = 0; kt + 2 < nk; ++kt) tile(kt, yes, yes, yes);
+    if (nk >= 2) tile(nk - 2, yes, no, yes);
+    tile(nk - 1, no, no, yes);
+  } else {
+    for (int kt = 0; kt + 2 < nk; ++kt) tile(kt, yes, yes, no);
+    if (nk >= 2) tile(nk - 2, yes, no, no);
+    tile(nk - 1, no, no, no);
+  }
 
+  if (v_half) {
+    // D[m_local = 4 fg + r][n_local = fj]: four consecutive tokens of column fj -> 8 bytes of one fragment-major V tile
+    // (tile (sample, head, token / 32, col / 16) = [token % 32 / 8][col % 16][token % 8])
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int n = n0 + wn * 64 + 16 * i + fj;
+      const float cbv = g.cb[n];
+      const int c_all = n - g.inner, head = c_all >> 6, c = c_all & 63;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int m = m0 + wm * 64 + 16 * t + 4 * fg;      // tokens % 4 == 0 and M % 4 == 0: the four rows are in or out together
+        if (m < g.M) {
+          const int bi = m / g.tokens, tok = m - bi * g.tokens;
+          const long tile_idx = (((long)bi * g.heads + head) * (g.tokens >> 5) + (tok >> 5)) * 4 + (c >> 4);
+          u32x2 v;
+          v.x = pk_bf16((acc[i][t][0] + cbv) * g.alpha, (acc[i][t][1] + cbv) * g.alpha);
+          v.y = pk_bf16((acc[i][t][2] + cbv) * g.alpha, (acc[i][t][3] + cbv) * g.alpha);
+          *(u32x2 *)(g.V16 + tile_idx * 512 + ((((tok & 31) >> 3) * 16 + (c & 15)) << 3) + (tok & 7)) = v;
+        }
+      }
+    }
+    return;
+  }
   // D[n_local = 4 fg + r][m_local = fj]: four consecutive columns of row fj
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -212,9 +250,38 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16GemmArgs g) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int m = m0 + wm * 64 + 16 * t + fj;
-      if (m < g.M) *(f32x4 *)(g.C + (long)m * g.ldc + n) = (acc[i][t] + c4) * g.alpha;
+      if (m < g.M) {
+        const f32x4 v = (acc[i][t] + c4) * g.alpha;
+        if (IMG) {
+          u32x2 o;
+          o.x = pk_bf16(v[0], v[1]);
+          o.y = pk_bf16(v[2], v[3]);
+          *(u32x2 *)(g.K16 + (long)m * g.inner + n) = o;
+        } else {
+          *(f32x4 *)(g.C + (long)m * g.ldc + n) = v;
+        }
+      }
     }
   }
+}
+
+// Qf[(sample, head)][row][64] = bf16(Q[sample * L + row][64 head ..]) for row < L, 0 up to Lp: the query side of the explicit bf16 core
+__global__ __launch_bounds__(256) void q_rows_to_bf16_kernel(const float *__restrict__ Q, long ldq, int heads, int L, int Lp, long total, u32x4 *__restrict__ out) {
+  const long id = (long)blockIdx.x * 256 + threadIdx.x;      // one 16-byte piece (8 columns)
+  if (id >= total) return;
+  const int piece = (int)(id & 7);
+  const long r = id >> 3;
+  const int row = (int)(r % Lp);
+  const long bh = r / Lp;
+  const int hi = (int)(bh % heads);
+  const long bi = bh / heads;
+  u32x4 o = (u32x4){0u, 0u, 0u, 0u};
+  if (row < L) {
+    const float *q = Q + (bi * L + row) * ldq + hi * 64 + piece * 8;
+    const f32x4 lo = *(const f32x4 *)q, hi4 = *(const f32x4 *)(q + 4);
+    o.x = pk_bf16(lo.x, lo.y); o.y = pk_bf16(lo.z, lo.w); o.z = pk_bf16(hi4.x, hi4.y); o.w = pk_bf16(hi4.z, hi4.w);
+  }
+  out[id] = o;
 }
 
 }  // namespace
@@ -248,8 +315,22 @@ int launch_rows_to_bf16(const float *A, long lda, long M, int K, uint16_t *out, 
 }
 
 // g describes the fp32 product (A is not read: Ab = its bf16 image from launch_rows_to_bf16, pitch gemm_bf16_pitch(K))
-int launch_gemm_bf16(const GemmArgs &g, const uint16_t *Ab, float *stage, hipStream_t s) {
-  HN_REQUIRE(Ab && g.W && g.C && stage, HN_E_NULL, "gemm_bf16: NULL operand");
+int launch_q_rows_to_bf16(const float *Q, long ldq, int b, int heads, int L, int Lp, uint16_t *Qf, hipStream_t s) {
+  HN_REQUIRE(Q && Qf, HN_E_NULL, "q_rows_to_bf16: NULL operand");
+  HN_REQUIRE(ldq % 4 == 0 && (((uintptr_t)Q | (uintptr_t)Qf) & 15) == 0, HN_E_SHAPE, "q_rows_to_bf16: unaligned operand (ldq=%ld)", ldq);
+  const long total = (long)b * heads * Lp * 8;
+  hipLaunchKernelGGL(q_rows_to_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, Q, ldq, heads, L, Lp, total, (u32x4 *)Qf);
+  HN_LAUNCH_CHECK("q_rows_to_bf16");
+  return HN_OK;
+}
+
+// K16 / V16 != NULL: write the bf16 K / V images of the explicit bf16 core instead of the fp32 rows g.C (heads of 64, g.N = 2 * 64 * heads,
+// `tokens` rows per sample, tokens % 32 == 0)
+int launch_gemm_bf16(const GemmArgs &g, const uint16_t *Ab, float *stage, hipStream_t s, uint16_t *K16, uint16_t *V16, int tokens) {
+  HN_REQUIRE(Ab && g.W && (g.C || K16) && stage, HN_E_NULL, "gemm_bf16: NULL operand");
+  const bool img = K16 != nullptr;
+  HN_REQUIRE(!img || (V16 && tokens > 0 && tokens % 32 == 0 && g.M % tokens == 0 && g.N % 256 == 0 && (((uintptr_t)K16 | (uintptr_t)V16) & 15) == 0),
+             HN_E_SHAPE, "gemm_bf16: image output needs tokens %% 32 == 0 (tokens=%d), N %% 256 == 0 (N=%d)", tokens, g.N);
   HN_REQUIRE(gemm_bf16_eligible(g), HN_E_UNSUPPORTED, "gemm_bf16: M=%d N=%d K=%d not eligible", g.M, g.N, g.K);
   HN_REQUIRE((((uintptr_t)stage | (uintptr_t)Ab) & 15) == 0, HN_E_WORKSPACE, "gemm_bf16: staging buffers must be 16-byte aligned");
   HN_REQUIRE(g.pro == PRO_NONE || (g.gamma && g.beta), HN_E_NULL, "gemm_bf16: prologue needs gamma and beta");
@@ -263,6 +344,7 @@ int launch_gemm_bf16(const GemmArgs &g, const uint16_t *Ab, float *stage, hipStr
   Bf16GemmArgs a;
   a.Ab = Ab; a.Wb = Wb; a.cb = cb; a.C = g.C; a.ldc = g.ldc; a.alpha = g.alpha; a.M = g.M; a.Kp = Kp;
   a.ntm = (g.M + HM - 1) / HM; a.ntn = g.N / HNT;
+  a.K16 = K16; a.V16 = V16; a.inner = g.N / 2; a.heads = g.N / 128; a.tokens = tokens;
   const long blocks = (long)((a.ntm + 7) / 8) * 8 * a.ntn;
   HN_REQUIRE(blocks < (1L << 31), HN_E_UNSUPPORTED, "gemm_bf16: grid too large");
   constexpr int lds_bytes = 2 * 4 * PLANE;      // 66 048: above the 64 KB a kernel gets without asking
@@ -270,10 +352,12 @@ int launch_gemm_bf16(const GemmArgs &g, const uint16_t *Ab, float *stage, hipStr
   int dev = 0;
   HN_HIP_CHECK(hipGetDevice(&dev));
   if (dev < 0 || dev >= 64 || !configured[dev]) {
-    HN_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    HN_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    HN_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     if (dev >= 0 && dev < 64) configured[dev] = true;
   }
-  hipLaunchKernelGGL(gemm_bf16_kernel, dim3((unsigned)blocks), dim3(256), lds_bytes, s, a);
+  if (img) hipLaunchKernelGGL(gemm_bf16_kernel<true>, dim3((unsigned)blocks), dim3(256), lds_bytes, s, a);
+  else hipLaunchKernelGGL(gemm_bf16_kernel<false>, dim3((unsigned)blocks), dim3(256), lds_bytes, s, a);
   HN_LAUNCH_CHECK("gemm_bf16");
   return HN_OK;
 }

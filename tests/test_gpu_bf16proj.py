@@ -6,7 +6,9 @@ multiple of 128); the bias term W beta stays fp32.  Held to the bf16 configurati
 oracle) -- observed deviations are ~1e-4 -- and checked to be the path that actually ran: a model with explicit
 bindings only is bit-identical under 'fp32' and 'bf16' wherever the projection is NOT eligible, and differs where it is.
 Shapes cover a k tail (D % 64 != 0, D % 4 != 0), a row tail (b * N % 128 != 0), a key-padding mask, two patch-bag modalities
-and the unchanged training forward (training always projects in fp32).
+and the unchanged training forward (training always projects in fp32).  With heads of 64 and N % 32 == 0 the projection writes
+bf16 K / V images and the block's attention core runs on bf16 MFMA too (attn_core_bf16_kernel<4, 2, 1, true>): covered by the
+*explicit_core* cases (ragged query tiles, masks, graph replay).
 """
 import os
 import subprocess
@@ -46,6 +48,13 @@ CASES = {
     # two heads of 64 -> N = 256 (two column tiles); D = 251 + 5 = 256 exactly (no tail); 2048 rows exactly
     "two_column_tiles": (dict(n_modalities=1, channel_dims=[251], num_spatial_axes=[1], out_dims=3, depth=2, l_c=16, l_d=64, x_heads=2,
                               l_heads=2, latent_dim_head=32, num_freq_bands=2, max_freq=2.0), [(1, 2048, 251)]),
+    # default heads (8 x 64), 2 x 1024 tokens (N % 32 == 0): projection straight into the bf16 K / V images + the explicit bf16 core
+    "bf16_explicit_core": (dict(n_modalities=2, channel_dims=[40, 300], num_spatial_axes=[1, 1], out_dims=4, depth=2, l_c=32, l_d=128,
+                                num_freq_bands=2, max_freq=2.0), [(2, 1, 40), (2, 1024, 300)]),
+    # ... with l_c = 40 (Lp = 48: ragged query tiles), one layer, no latent self-attention, 3 x 704 tokens (22 blocks of 32)
+    "bf16_explicit_core_ragged_queries": (dict(n_modalities=1, channel_dims=[300], num_spatial_axes=[1], out_dims=4, depth=1, l_c=40, l_d=64,
+                                               l_heads=2, latent_dim_head=32, self_per_cross_attn=0, num_freq_bands=2, max_freq=2.0),
+                                          [(3, 704, 300)]),
     # two patch bags of different widths in one model, cross head width 32 x 4 heads -> N = 256
     "two_bags": (dict(n_modalities=3, channel_dims=[30, 280, 400], num_spatial_axes=[1, 1, 1], out_dims=4, depth=2, l_c=32, l_d=128,
                       x_heads=4, cross_dim_head=32, num_freq_bands=2, max_freq=2.0), [(2, 1, 30), (2, 1024, 280), (2, 1200, 400)]),
@@ -91,16 +100,18 @@ def test_small_bags_keep_the_fp32_projection(hn):
     assert torch.equal(low, full)
 
 
-def test_masked_bag_and_embeddings(hn):
+@pytest.mark.parametrize("n_tokens", [1100, 1056], ids=["projection_only", "explicit_core"])
+def test_masked_bag_and_embeddings(hn, n_tokens):
     """Key-padding mask on the patch bag (zero-padded bags) + return_embeddings: the projection covers the padded
     tokens too (they are masked in the core), the latent array agrees with the oracle at the bf16 tolerance.  (One modality: the
     reference hands the same mask to every cross block, healnet.py:236.)"""
     kw = dict(n_modalities=1, channel_dims=[300], num_spatial_axes=[1], out_dims=4, depth=2, l_c=32, l_d=128, num_freq_bands=2,
               max_freq=2.0)
-    model, ins, sd = _case(hn, kw, [(2, 1100, 300)], 905)
-    mask = torch.ones(2, 1100, dtype=torch.bool)
+    model, ins, sd = _case(hn, kw, [(2, n_tokens, 300)], 905)
+    mask = torch.ones(2, n_tokens, dtype=torch.bool)
     mask[0, 700:] = False
     mask[1, 1033:] = False
+    mask[1, 5:40] = False
     with torch.no_grad():
         want = O.fusion_forward(sd, O.FusionConfig(**kw), [t.clone() for t in ins], mask=mask, return_embeddings=True)
     model.to(DEV)
@@ -121,7 +132,7 @@ def test_graph_replay_with_the_bf16_projection(hn):
     torch.manual_seed(31)
     model = hn.HealNet(**kw, core_precision="bf16").eval().to(DEV)
     gen = torch.Generator().manual_seed(32)
-    shapes = [(2, 1, 40), (2, 1100, 300)]
+    shapes = [(2, 1, 40), (2, 1024, 300)]
     graph = model.capture([torch.rand(*s, generator=gen).to(DEV) for s in shapes])
     for trial in range(2):
         ins = [torch.rand(*s, generator=gen).to(DEV) for s in shapes]
