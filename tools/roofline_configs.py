@@ -195,12 +195,13 @@ def main():
             if "gemm_bf16_kernel" in k["Name"]:
                 us = float(k["AverageNs"]) / 1e3
                 pfl = 2.0 * cfg["b"] * 4096 * 773 * 2 * INNER
-                byts = cfg["b"] * 4096 * (2 * INNER * 4 + 832 * 2)       # fp32 K|V rows written + the bf16 context image read once
+                img = "<true>" in k["Name"]                               # bf16 K / V images (explicit bf16 core behind it) or fp32 K|V rows
+                byts = cfg["b"] * 4096 * (2 * INNER * (2 if img else 4) + 832 * 2)       # K|V written + the bf16 context image read once
                 entry_kv = {"name": k["Name"], "calls": int(k["Calls"]), "avg_us": round(us, 2), "executed_flops_per_launch": pfl,
                             "achieved_tflops": round(pfl / (us * 1e-6) / 1e12, 1), "frac_of_bf16_mfma_peak": round(pfl / (us * 1e-6) / PEAK_BF16, 4),
                             "algorithmic_bytes_per_launch": byts, "achieved_tb_s": round(byts / (us * 1e-6) / 1e12, 2),
                             "frac_of_hbm_8tb_s": round(byts / (us * 1e-6) / 8e12, 4),
-                            "note": "fp32 K|V output (b*N x 1024 floats) + bf16 context image (b*N x 832) per launch: the HBM side is the nearer roof"}
+                            "note": ("bf16 K / V images" if img else "fp32 K|V rows") + " (b*N x 1024) written + bf16 context image (b*N x 832) read per launch"}
                 break
         else:
             entry_kv = None
