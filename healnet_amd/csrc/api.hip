@@ -383,7 +383,12 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
       ca.Qf = Q16; ca.zb = K16; ca.zT = V16; ca.mask = mask;
       ca.Opart = pl.opart; ca.Mpart = pl.mpart; ca.Lpart = pl.lpart;
       ca.b = b; ca.h = p->heads; ca.Lq = L; ca.Lp = pl.Lp; ca.N = pl.N; ca.Np = pl.N; ca.DV = 64;
-      ca.chunk = (pl.chunk + 31) / 32 * 32;                    // (<= the plan's split count: the partial buffers are sized for it)
+      // splits of >= 512 tokens (never more splits than the plan's, which sized the partial buffers): the sweep over {plan, 512, 1024,
+      // 2048} x {2, 4 query tiles per wave} at cfg4 / cfg5 picked 512 -- 1024 (0.78 / 5.64 ms against 0.80 / 5.87 with the fp32 core's split)
+      ca.chunk = (pl.chunk + 31) / 32 * 32;
+      if (ca.chunk < 512) ca.chunk = 512;
+      static const int chunk_knob = getenv("HN_BF16_EXPL_CHUNK") ? atoi(getenv("HN_BF16_EXPL_CHUNK")) : 0;      // development knob: coarser splits
+      if (chunk_knob > ca.chunk) ca.chunk = (chunk_knob + 31) / 32 * 32;
       ca.nsplit = (pl.N + ca.chunk - 1) / ca.chunk;
       ca.ns = 1; ca.expl = 1; ca.k_pitch = pl.inner * 2;
       if (ev0) HN_HIP_CHECK(hipEventRecord(ev0, s));

@@ -360,13 +360,17 @@ int launch_attn_core_bf16(const AttnCoreBf16Args &a, hipStream_t s) {
                "attn_core_bf16 (explicit binding): DV=%d ns=%d N=%d k_pitch=%d", a.DV, a.ns, a.N, a.k_pitch);
     HN_REQUIRE(a.Lp % 16 == 0 && a.chunk % 32 == 0 && a.nsplit >= 1 && (long)a.N * a.k_pitch < (1L << 31), HN_E_SHAPE,
                "attn_core_bf16 (explicit binding): Lp=%d chunk=%d N=%d", a.Lp, a.chunk, a.N);
-    constexpr int NQE = 2;      // 4 x 16 output columns per query tile: two tiles per wave keep the accumulators + both prefetch sets in registers
+    // query tiles per wave: 2 (180 VGPRs, two waves per SIMD; the 4 query groups of a (sample, head) each stream its K / V tiles) or
+    // 4 (279 VGPRs, one wave per SIMD, half the K / V traffic): HN_BF16_EXPL_NQ, development knob
+    static const int nqe = getenv("HN_BF16_EXPL_NQ") ? atoi(getenv("HN_BF16_EXPL_NQ")) : 2;
+    const int NQE = nqe == 4 ? 4 : 2;
     const int ngroups = ceil_div(a.Lp / 16, NQE);
     const int wpb = ngroups < 4 ? ngroups : 4;
     const int gy = ceil_div(ngroups, wpb);
     const long blocks = (long)a.nsplit * gy * a.b * a.h;
     HN_REQUIRE(blocks < (1L << 31), HN_E_UNSUPPORTED, "attn_core_bf16: grid too large");
-    hipLaunchKernelGGL((attn_core_bf16_kernel<4, NQE, 1, true>), dim3((unsigned)blocks), dim3(64 * wpb), 0, s, a, ngroups, gy, wpb);
+    if (NQE == 4) hipLaunchKernelGGL((attn_core_bf16_kernel<4, 4, 1, true>), dim3((unsigned)blocks), dim3(64 * wpb), 0, s, a, ngroups, gy, wpb);
+    else hipLaunchKernelGGL((attn_core_bf16_kernel<4, 2, 1, true>), dim3((unsigned)blocks), dim3(64 * wpb), 0, s, a, ngroups, gy, wpb);
     HN_LAUNCH_CHECK("attn_core_bf16(explicit)");
     return HN_OK;
   }
