@@ -55,6 +55,10 @@ CASES = {
     "bf16_explicit_core_ragged_queries": (dict(n_modalities=1, channel_dims=[300], num_spatial_axes=[1], out_dims=4, depth=1, l_c=40, l_d=64,
                                                l_heads=2, latent_dim_head=32, self_per_cross_attn=0, num_freq_bands=2, max_freq=2.0),
                                           [(3, 704, 300)]),
+    # a STAGED model (odd latent width, one cross head of 63 run as a zero-padded head of 64: DESIGN 4.10): N = 2 x 64 = one column tile
+    "staged_one_head": (dict(n_modalities=2, channel_dims=[40, 300], num_spatial_axes=[1, 1], out_dims=4, depth=2, l_c=17, l_d=126,
+                             x_heads=1, cross_dim_head=63, l_heads=8, latent_dim_head=20, self_per_cross_attn=0, num_freq_bands=2,
+                             max_freq=2.0), [(3, 1, 40), (3, 1024, 300)]),
     # two patch bags of different widths in one model, cross head width 32 x 4 heads -> N = 256
     "two_bags": (dict(n_modalities=3, channel_dims=[30, 280, 400], num_spatial_axes=[1, 1, 1], out_dims=4, depth=2, l_c=32, l_d=128,
                       x_heads=4, cross_dim_head=32, num_freq_bands=2, max_freq=2.0), [(2, 1, 30), (2, 1024, 280), (2, 1200, 400)]),
