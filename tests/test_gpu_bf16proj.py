@@ -179,7 +179,7 @@ _POISON = textwrap.dedent("""
     torch.manual_seed(3)
     model = hn.HealNet(**kw, core_precision="bf16").eval().to("cuda:0")
     gen = torch.Generator().manual_seed(4)
-    ins = [torch.rand(2, 1, 40, generator=gen).cuda(), torch.rand(2, 1100, 300, generator=gen).cuda()]
+    ins = [torch.rand(2, 1, 40, generator=gen).cuda(), torch.rand(2, {n_tokens}, 300, generator=gen).cuda()]
     with torch.no_grad():
         runs = [model(list(ins)).cpu() for _ in range(3)]
     print("RESULT " + json.dumps(dict(finite=bool(all(torch.isfinite(r).all() for r in runs)),
@@ -187,12 +187,14 @@ _POISON = textwrap.dedent("""
 """)
 
 
-def test_poisoned_workspace():
+@pytest.mark.parametrize("n_tokens", [1100, 1024], ids=["projection_only", "explicit_core"])
+def test_poisoned_workspace(n_tokens):
     """HN_POISON_WS=1: every call starts from an all-NaN workspace -- the staged weight image, its zero pad columns, the bias row and
-    the context's pad columns (never read past D - 1) must all be produced / masked by the call itself."""
+    the context's pad columns (never read past D - 1), and with the explicit bf16 core the K / V / query images (pad query rows
+    included) must all be produced / masked by the call itself."""
     import json
     env = dict(os.environ, HN_POISON_WS="1")
-    out = subprocess.run([sys.executable, "-c", _POISON.format(root=ROOT)], cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    out = subprocess.run([sys.executable, "-c", _POISON.format(root=ROOT, n_tokens=n_tokens)], cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1][len("RESULT "):])
     assert res["finite"] and res["same"], res
