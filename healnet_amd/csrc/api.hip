@@ -349,10 +349,9 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
   }
 
   // ---- explicit binding of a large patch bag under core_precision = bf16 (inference): K / V projected on bf16 MFMA straight into
-  // the bf16 images of the explicit bf16 core (heads of 64, N % 32 == 0); otherwise the projection alone (fp32 rows, attn_prepare)
+  // the bf16 images of the explicit bf16 core (heads of 64); otherwise the projection alone (fp32 rows, attn_prepare)
   static const bool no_expl16 = getenv("HN_NO_BF16_EXPL_CORE") != nullptr;      // development switch
-  if (pl.ctx16 && pl.wstage && ctx && !pl.rank_d && !dropping && !no_expl16 && pl.dh == 64 && pl.dhp == 64 && pl.N % 32 == 0 &&
-      p->heads % 2 == 0 && !narrow_ln(p)) {
+  if (pl.ctx16 && pl.wstage && ctx && !pl.rank_d && !dropping && !no_expl16 && pl.dh == 64 && pl.dhp == 64 && p->heads % 2 == 0 && !narrow_ln(p)) {
     GemmArgs gk = gemm_defaults();
     gk.A = ctx; gk.lda = ld_ctx; gk.M = b * pl.N; gk.K = pl.D;
     if (p->ctx_gamma) { gk.pro = PRO_AFFINE; gk.gamma = p->ctx_gamma; gk.beta = p->ctx_beta; }
@@ -360,11 +359,14 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
     gk.N = 2 * pl.inner;
     gk.C = pl.kv; gk.ldc = 2 * pl.inner;      // (not written: the images below alias it)
     if (gemm_bf16_eligible(gk)) {
-      // the fp32 K|V rows of this plan (b N x 2 inner floats) hold K16 (a quarter), V16 (a quarter) and the query image
+      // the fp32 K|V rows of this plan (b N x 2 inner floats) hold K16 (a quarter), V16 (a quarter; token slots rounded up to 32 per
+      // sample) and the query image
+      const int Np = (pl.N + 31) / 32 * 32;
       uint16_t *K16 = (uint16_t *)pl.kv;
-      uint16_t *V16 = K16 + (size_t)b * pl.N * pl.inner;
-      uint16_t *Q16 = V16 + (size_t)b * pl.N * pl.inner;
-      HN_REQUIRE((size_t)b * p->heads * pl.Lp * 64 <= (size_t)b * pl.N * pl.inner * 2, HN_E_WORKSPACE, "attn: bf16 query image does not fit");
+      uint16_t *V16 = K16 + align_up((size_t)b * pl.N * pl.inner, 8);
+      uint16_t *Q16 = V16 + (size_t)b * Np * pl.inner;
+      HN_REQUIRE(align_up((size_t)b * pl.N * pl.inner, 8) + (size_t)b * Np * pl.inner + (size_t)b * p->heads * pl.Lp * 64 <= (size_t)b * pl.N * pl.inner * 4,
+                 HN_E_WORKSPACE, "attn: the bf16 K / V / query images do not fit the plan's K|V buffer");
       const bool q_done = ext && ext->q && ext->q_done;
       float *qbuf = q_done ? ext->q : pl.q;
       if (!q_done) {
@@ -382,7 +384,7 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
       memset(&ca, 0, sizeof(ca));
       ca.Qf = Q16; ca.zb = K16; ca.zT = V16; ca.mask = mask;
       ca.Opart = pl.opart; ca.Mpart = pl.mpart; ca.Lpart = pl.lpart;
-      ca.b = b; ca.h = p->heads; ca.Lq = L; ca.Lp = pl.Lp; ca.N = pl.N; ca.Np = pl.N; ca.DV = 64;
+      ca.b = b; ca.h = p->heads; ca.Lq = L; ca.Lp = pl.Lp; ca.N = pl.N; ca.Np = Np; ca.DV = 64;
       // splits of >= 512 tokens (never more splits than the plan's, which sized the partial buffers): the sweep over {plan, 512, 1024,
       // 2048} x {2, 4 query tiles per wave} at cfg4 / cfg5 picked 512 -- 1024 (0.78 / 5.64 ms against 0.80 / 5.87 with the fp32 core's split)
       ca.chunk = (pl.chunk + 31) / 32 * 32;

@@ -48,8 +48,9 @@ __device__ __forceinline__ bf16x8 as_bf16x8(const f32x4 &v) { return __builtin_b
 
 // EXPL: the explicit K / V binding of a patch bag under core_precision = bf16 (dim_head 64): K is the token-major bf16 image the
 // projection wrote ((b, N, inner): row pitch a.k_pitch bytes, head h at column 64 h), V its fragment-major image per (b, head)
-// ((N / 32, 4, 4, 16, 8): the same 1 KB tiles as zT), the query rows are the scaled projections themselves (64 slots), and the
-// softmax denominator is summed on the vector pipe (V has no ones column); running reference (no score bound), N % 32 == 0.
+// ((Np / 32, 4, 4, 16, 8): the same 1 KB tiles as zT), the query rows are the scaled projections themselves (64 slots), and the
+// softmax denominator is summed on the vector pipe (V has no ones column); running reference (no score bound); the V image holds
+// Np = roundup32(N) token slots per (sample, head), the pad slots zero.
 template <int DTV, int NQ, int NS, bool EXPL = false>
 __global__ __launch_bounds__(256) void attn_core_bf16_kernel(AttnCoreBf16Args a, int ngroups, int gy, int waves_per_block) {
   constexpr int DV = 16 * DTV;
@@ -356,8 +357,8 @@ __global__ __launch_bounds__(256) void attn_core_bf16_kernel(AttnCoreBf16Args a,
 
 int launch_attn_core_bf16(const AttnCoreBf16Args &a, hipStream_t s) {
   if (a.expl) {
-    HN_REQUIRE(a.DV == 64 && a.ns == 1 && a.N % 32 == 0 && a.Np == a.N && a.k_pitch >= 128 && a.k_pitch % 16 == 0 && !a.bound, HN_E_UNSUPPORTED,
-               "attn_core_bf16 (explicit binding): DV=%d ns=%d N=%d k_pitch=%d", a.DV, a.ns, a.N, a.k_pitch);
+    HN_REQUIRE(a.DV == 64 && a.ns == 1 && a.Np % 32 == 0 && a.Np >= a.N && a.Np < a.N + 32 && a.k_pitch >= 128 && a.k_pitch % 16 == 0 && !a.bound,
+               HN_E_UNSUPPORTED, "attn_core_bf16 (explicit binding): DV=%d ns=%d N=%d Np=%d k_pitch=%d", a.DV, a.ns, a.N, a.Np, a.k_pitch);
     HN_REQUIRE(a.Lp % 16 == 0 && a.chunk % 32 == 0 && a.nsplit >= 1 && (long)a.N * a.k_pitch < (1L << 31), HN_E_SHAPE,
                "attn_core_bf16 (explicit binding): Lp=%d chunk=%d N=%d", a.Lp, a.chunk, a.N);
     // query tiles per wave: 2 (180 VGPRs, two waves per SIMD; the 4 query groups of a (sample, head) each stream its K / V tiles) or

@@ -107,10 +107,10 @@ struct Bf16GemmArgs {
   float *C; long ldc;
   float alpha;
   int M, Kp, ntm, ntn;
-  // IMG: instead of fp32 rows, the bf16 images attn_core_bf16_kernel<.., EXPL> reads (N = 2 * inner, dim_head 64, tokens % 32 == 0):
-  // K16 (M, inner) token-major; V16 per (sample, head) fragment-major (tokens / 32, 4, 4, 16, 8)
+  // IMG: instead of fp32 rows, the bf16 images attn_core_bf16_kernel<.., EXPL> reads (N = 2 * inner, dim_head 64):
+  // K16 (M, inner) token-major; V16 per (sample, head) fragment-major (np / 32, 4, 4, 16, 8)
   uint16_t *K16, *V16;
-  int inner, heads, tokens;
+  int inner, heads, tokens, np;      // tokens per sample and that rounded up to 32 (V tiles hold 32 tokens; the pad slots are zeroed)
 };
 
 template <bool IMG>
@@ -224,7 +224,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16GemmArgs g) {
 
   if (v_half) {
     // D[m_local = 4 fg + r][n_local = fj]: four consecutive tokens of column fj -> 8 bytes of one fragment-major V tile
-    // (tile (sample, head, token / 32, col / 16) = [token % 32 / 8][col % 16][token % 8])
+    // (tile (sample, head, token / 32, col / 16) = [token % 32 / 8][col % 16][token % 8]); token counts that are not multiples of 4
+    // let a row quad straddle two samples: element-wise stores there
+    const int blocks_per = g.np >> 5;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int n = n0 + wn * 64 + 16 * i + fj;
@@ -232,14 +234,26 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16GemmArgs g) {
       const int c_all = n - g.inner, head = c_all >> 6, c = c_all & 63;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const int m = m0 + wm * 64 + 16 * t + 4 * fg;      // tokens % 4 == 0 and M % 4 == 0: the four rows are in or out together
-        if (m < g.M) {
-          const int bi = m / g.tokens, tok = m - bi * g.tokens;
-          const long tile_idx = (((long)bi * g.heads + head) * (g.tokens >> 5) + (tok >> 5)) * 4 + (c >> 4);
-          u32x2 v;
-          v.x = pk_bf16((acc[i][t][0] + cbv) * g.alpha, (acc[i][t][1] + cbv) * g.alpha);
-          v.y = pk_bf16((acc[i][t][2] + cbv) * g.alpha, (acc[i][t][3] + cbv) * g.alpha);
-          *(u32x2 *)(g.V16 + tile_idx * 512 + ((((tok & 31) >> 3) * 16 + (c & 15)) << 3) + (tok & 7)) = v;
+        const int m = m0 + wm * 64 + 16 * t + 4 * fg;
+        if ((g.tokens & 3) == 0) {      // (then M % 4 == 0 too: the four rows are in or out together)
+          if (m < g.M) {
+            const int bi = m / g.tokens, tok = m - bi * g.tokens;
+            const long tile_idx = (((long)bi * g.heads + head) * blocks_per + (tok >> 5)) * 4 + (c >> 4);
+            u32x2 v;
+            v.x = pk_bf16((acc[i][t][0] + cbv) * g.alpha, (acc[i][t][1] + cbv) * g.alpha);
+            v.y = pk_bf16((acc[i][t][2] + cbv) * g.alpha, (acc[i][t][3] + cbv) * g.alpha);
+            *(u32x2 *)(g.V16 + tile_idx * 512 + ((((tok & 31) >> 3) * 16 + (c & 15)) << 3) + (tok & 7)) = v;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int mr = m + r;
+            if (mr < g.M) {
+              const int bi = mr / g.tokens, tok = mr - bi * g.tokens;
+              const long tile_idx = (((long)bi * g.heads + head) * blocks_per + (tok >> 5)) * 4 + (c >> 4);
+              g.V16[tile_idx * 512 + ((((tok & 31) >> 3) * 16 + (c & 15)) << 3) + (tok & 7)] = (uint16_t)pk_bf16((acc[i][t][r] + cbv) * g.alpha, 0.0f);
+            }
+          }
         }
       }
     }
@@ -266,6 +280,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16GemmArgs g) {
       }
     }
   }
+}
+
+// token counts that are not multiples of 32: the last 32-token block of every (sample, head) V image (4 tiles = 4 KB) is zeroed before
+// the projection writes its valid tokens -- the core multiplies the pad slots by probabilities that are exactly 0, which NaNs survive
+__global__ __launch_bounds__(256) void v_tail_zero_kernel(u32x4 *__restrict__ V16, int blocks_per) {
+  V16[((long)blockIdx.x * blocks_per + (blocks_per - 1)) * 256 + threadIdx.x] = (u32x4){0u, 0u, 0u, 0u};      // 4 tiles x 1 KB = 256 pieces
 }
 
 // Qf[(sample, head)][row][64] = bf16(Q[sample * L + row][64 head ..]) for row < L, 0 up to Lp: the query side of the explicit bf16 core
@@ -328,12 +348,12 @@ int launch_q_rows_to_bf16(const float *Q, long ldq, int b, int heads, int L, int
 }
 
 // K16 / V16 != NULL: write the bf16 K / V images of the explicit bf16 core instead of the fp32 rows g.C (heads of 64, g.N = 2 * 64 * heads,
-// `tokens` rows per sample, tokens % 32 == 0)
+// `tokens` rows per sample; V16 holds (M / tokens) * heads images of roundup32(tokens) x 64)
 int launch_gemm_bf16(const GemmArgs &g, const uint16_t *Ab, float *stage, hipStream_t s, uint16_t *K16, uint16_t *V16, int tokens) {
   HN_REQUIRE(Ab && g.W && (g.C || K16) && stage, HN_E_NULL, "gemm_bf16: NULL operand");
   const bool img = K16 != nullptr;
-  HN_REQUIRE(!img || (V16 && tokens > 0 && tokens % 32 == 0 && g.M % tokens == 0 && g.N % 256 == 0 && (((uintptr_t)K16 | (uintptr_t)V16) & 15) == 0),
-             HN_E_SHAPE, "gemm_bf16: image output needs tokens %% 32 == 0 (tokens=%d), N %% 256 == 0 (N=%d)", tokens, g.N);
+  HN_REQUIRE(!img || (V16 && tokens > 0 && g.M % tokens == 0 && g.N % 256 == 0 && (((uintptr_t)K16 | (uintptr_t)V16) & 15) == 0),
+             HN_E_SHAPE, "gemm_bf16: image output needs whole samples (M=%d, tokens=%d) and N %% 256 == 0 (N=%d)", g.M, tokens, g.N);
   HN_REQUIRE(gemm_bf16_eligible(g), HN_E_UNSUPPORTED, "gemm_bf16: M=%d N=%d K=%d not eligible", g.M, g.N, g.K);
   HN_REQUIRE((((uintptr_t)stage | (uintptr_t)Ab) & 15) == 0, HN_E_WORKSPACE, "gemm_bf16: staging buffers must be 16-byte aligned");
   HN_REQUIRE(g.pro == PRO_NONE || (g.gamma && g.beta), HN_E_NULL, "gemm_bf16: prologue needs gamma and beta");
@@ -347,7 +367,11 @@ int launch_gemm_bf16(const GemmArgs &g, const uint16_t *Ab, float *stage, hipStr
   Bf16GemmArgs a;
   a.Ab = Ab; a.Wb = Wb; a.cb = cb; a.C = g.C; a.ldc = g.ldc; a.alpha = g.alpha; a.M = g.M; a.Kp = Kp;
   a.ntm = (g.M + HM - 1) / HM; a.ntn = g.N / HNT;
-  a.K16 = K16; a.V16 = V16; a.inner = g.N / 2; a.heads = g.N / 128; a.tokens = tokens;
+  a.K16 = K16; a.V16 = V16; a.inner = g.N / 2; a.heads = g.N / 128; a.tokens = tokens; a.np = (tokens + 31) / 32 * 32;
+  if (img && tokens % 32 != 0) {
+    hipLaunchKernelGGL(v_tail_zero_kernel, dim3((unsigned)((g.M / tokens) * a.heads)), dim3(256), 0, s, (u32x4 *)V16, a.np / 32);
+    HN_LAUNCH_CHECK("v_tail_zero");
+  }
   const long blocks = (long)((a.ntm + 7) / 8) * 8 * a.ntn;
   HN_REQUIRE(blocks < (1L << 31), HN_E_UNSUPPORTED, "gemm_bf16: grid too large");
   constexpr int lds_bytes = 2 * 4 * PLANE;      // 66 048: above the 64 KB a kernel gets without asking

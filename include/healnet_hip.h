@@ -53,7 +53,7 @@ typedef enum hn_dtype { HN_F32 = 0, HN_BF16 = 1, HN_U8 = 2 } hn_dtype;
  *              K/V binding (patch bags: BASELINE configs[3] / [4]), the context-side K/V projection on bf16 MFMA -- context
  *              and to_kv.weight (with the context LayerNorm's gain folded in) rounded to bf16 once, fp32 accumulation, the
  *              LayerNorm's bias term kept in fp32 -- when it is large enough to matter (>= 2048 context rows, D >= 256, 2 * inner
- *              a multiple of 128); with heads of 64 and a token count that is a multiple of 32 that projection writes bf16
+ *              a multiple of 128); with heads of 64 (an even number of them) that projection writes bf16
  *              K / V images and the block's attention core runs on bf16 MFMA as well (scaled queries and probabilities
  *              rounded to bf16 once, fp32 softmax statistics and accumulation).  Everything else -- LayerNorms, the other
  *              projections, softmax statistics, feed-forward, head -- stays fp32.  Training always uses HN_CORE_F32.

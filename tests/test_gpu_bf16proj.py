@@ -6,9 +6,11 @@ multiple of 128); the bias term W beta stays fp32.  Held to the bf16 configurati
 oracle) -- observed deviations are ~1e-4 -- and checked to be the path that actually ran: a model with explicit
 bindings only is bit-identical under 'fp32' and 'bf16' wherever the projection is NOT eligible, and differs where it is.
 Shapes cover a k tail (D % 64 != 0, D % 4 != 0), a row tail (b * N % 128 != 0), a key-padding mask, two patch-bag modalities
-and the unchanged training forward (training always projects in fp32).  With heads of 64 and N % 32 == 0 the projection writes
-bf16 K / V images and the block's attention core runs on bf16 MFMA too (attn_core_bf16_kernel<4, 2, 1, true>): covered by the
-*explicit_core* cases (ragged query tiles, masks, graph replay).
+and the unchanged training forward (training always projects in fp32).  With heads of 64 the projection writes bf16 K / V images
+and the block's attention core runs on bf16 MFMA too (attn_core_bf16_kernel<4, 2, 1, true>): every default-heads case here (token
+counts that are multiples of 32, of 4 only -- 1100 -- and odd -- 1101: zeroed pad slots of the last V tile, element-wise stores --
+ragged query tiles, masks, graph replay, poisoned workspace); cross heads of 32 and the staged one-head model keep the fp32 core
+behind the bf16 projection.
 """
 import os
 import subprocess
@@ -42,10 +44,12 @@ def _case(hn, kw, shapes, seed):
 
 
 CASES = {
-    # channels 300 + 5 position columns = D 305: k tail 49 of 64, D % 4 = 1; rows 2 * 1100 = 2200 = 17 tiles + 24 rows
+    # channels 300 + 5 position columns = D 305: k tail 49 of 64, D % 4 = 1; rows 2 * 1100 = 2200 = 17 tiles + 24 rows; 1100 = 34 blocks of 32 + 12
     "k_and_row_tails": (dict(n_modalities=2, channel_dims=[40, 300], num_spatial_axes=[1, 1], out_dims=4, depth=2, l_c=32, l_d=128,
                              num_freq_bands=2, max_freq=2.0), [(2, 1, 40), (2, 1100, 300)]),
     # two heads of 64 -> N = 256 (two column tiles); D = 251 + 5 = 256 exactly (no tail); 2048 rows exactly
+    "odd_token_count": (dict(n_modalities=2, channel_dims=[40, 300], num_spatial_axes=[1, 1], out_dims=4, depth=2, l_c=32, l_d=128,
+                             num_freq_bands=2, max_freq=2.0), [(2, 1, 40), (2, 1101, 300)]),
     "two_column_tiles": (dict(n_modalities=1, channel_dims=[251], num_spatial_axes=[1], out_dims=3, depth=2, l_c=16, l_d=64, x_heads=2,
                               l_heads=2, latent_dim_head=32, num_freq_bands=2, max_freq=2.0), [(1, 2048, 251)]),
     # default heads (8 x 64), 2 x 1024 tokens (N % 32 == 0): projection straight into the bf16 K / V images + the explicit bf16 core
@@ -104,7 +108,7 @@ def test_small_bags_keep_the_fp32_projection(hn):
     assert torch.equal(low, full)
 
 
-@pytest.mark.parametrize("n_tokens", [1100, 1056], ids=["projection_only", "explicit_core"])
+@pytest.mark.parametrize("n_tokens", [1100, 1056, 1101], ids=["ragged_block", "whole_blocks", "odd_tokens"])
 def test_masked_bag_and_embeddings(hn, n_tokens):
     """Key-padding mask on the patch bag (zero-padded bags) + return_embeddings: the projection covers the padded
     tokens too (they are masked in the core), the latent array agrees with the oracle at the bf16 tolerance.  (One modality: the
@@ -187,7 +191,7 @@ _POISON = textwrap.dedent("""
 """)
 
 
-@pytest.mark.parametrize("n_tokens", [1100, 1024], ids=["projection_only", "explicit_core"])
+@pytest.mark.parametrize("n_tokens", [1100, 1024, 1101], ids=["ragged_block", "whole_blocks", "odd_tokens"])
 def test_poisoned_workspace(n_tokens):
     """HN_POISON_WS=1: every call starts from an all-NaN workspace -- the staged weight image, its zero pad columns, the bias row and
     the context's pad columns (never read past D - 1), and with the explicit bf16 core the K / V / query images (pad query rows
