@@ -22,7 +22,7 @@
 //   * W sub-tiles are the MFMA's A operand and context sub-tiles its B operand: the accumulator quad of a lane is then four
 //     CONSECUTIVE output columns of one row -> float4 stores.
 //   * work-item order as gemm_big_kernel: the column tiles that share a 128-row block of A run back to back on one XCD.
-//   * gemm_bf16_kernel<true> (heads of 64, token counts that are multiples of 32): the output goes straight into the bf16 images of
+//   * gemm_bf16_kernel<true> (heads of 64): the output goes straight into the bf16 images of
 //     the explicit bf16 core (attention_bf16.hip, EXPL) -- K token-major, V fragment-major per (sample, head); the column tiles of
 //     the V half swap the MFMA operands so that a lane holds four consecutive tokens of a column = 8 contiguous bytes of a V tile.
 #include "common.h"
