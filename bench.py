@@ -21,6 +21,7 @@ Rank 0 prints ONE JSON line.  Besides the driver's contract it carries
   cpu_baseline : oracle/healnet_cpu.py (the op-for-op CPU restatement of the reference) timed on this
                  box's host cores on a bounded sample (b=4 of the same workload; 1 warm-up + median of 3 runs), rank 0 at N=1 only;
   staged_models: forward + backward of the reference's four tuned TCGA configurations (config/best_hyperparams.yml) at b=8, N=1 only
+  patch_bag_precisions: the inference forward of BASELINE configs[3]'s shape (b=8) in fp32 and with core_precision="bf16", N=1 only
   train_step   : SURVEY.md 8(d)'s second figure -- the training step of BASELINE configs[3] (TCGA-BRCA shape: omic 1x2000 + WSI bag
                  4096x768, b=8 per GPU): forward with tape, survival NLL, fused backward, gradient all-reduce over RCCL
                  (overlapped with the backward through hn_grad_ready, healnet_amd.dist.GradReadyAllReduce) and the fused
@@ -297,6 +298,35 @@ def staged_models_record(dev, steps=15, warmup=3):
     return rec
 
 
+def patch_bag_record(dev, steps=30, warmup=5):
+    """Inference forward of BASELINE configs[3]'s shape (omic 1x2000 + WSI bag 4096x768, b=8) in fp32 and with
+    core_precision="bf16" (the bag's K/V projection and attention core on bf16 MFMA; tolerance of that
+    configuration 2e-2 max-norm against the fp32 oracle, tests/test_gpu_bf16proj.py)."""
+    import healnet_amd as hn
+    gen = torch.Generator().manual_seed(1)
+    ins = [torch.rand(TRAIN_BATCH, *s, generator=gen).to(dev) for s in TRAIN_SHAPES]
+    rec = {"workload": "inference forward, b=8, omic (b,1,2000) + WSI bag (b,4096,768), fp32 tensors, eval / no_grad", "unit": "ms",
+           "steps": steps, "warmup": warmup}
+    outs = {}
+    for prec in ("fp32", "bf16"):
+        torch.manual_seed(0)
+        model = hn.HealNet(**TRAIN_KW, core_precision=prec).eval().to(dev)
+        model.keep_attention_stats = False
+        with torch.no_grad():
+            for _ in range(warmup):
+                y = model(list(ins))
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                y = model(list(ins))
+            torch.cuda.synchronize(dev)
+        rec[f"{prec}_ms"] = round((time.perf_counter() - t0) / steps * 1e3, 4)
+        outs[prec] = y.float()
+        del model
+    rec["bf16_maxnorm_diff_vs_fp32"] = float((outs["bf16"] - outs["fp32"]).abs().max() / outs["fp32"].abs().max())
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -469,6 +499,7 @@ def main():
             result["train_step"] = train_rec
         if world == 1 and not args.no_staged_models:
             result["staged_models"] = staged_models_record(dev)
+            result["patch_bag_precisions"] = patch_bag_record(dev)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline()
         print(json.dumps(result))

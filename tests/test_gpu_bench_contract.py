@@ -36,6 +36,8 @@ def test_bench_prints_one_contract_line():
     sm = j["staged_models"]                               # the reference's tuned TCGA shapes, run as zero-padded images
     assert set(sm["configs"]) == {"blca", "brca", "kirp", "ucec"} and sm["unit"] == "ms"
     assert all(c["staged"] and 0.1 < c["fwd_bwd_ms"] < 50.0 for c in sm["configs"].values())
+    pb = j["patch_bag_precisions"]                        # BASELINE configs[3]'s shape: fp32 vs the bf16 projection + core
+    assert 0.1 < pb["bf16_ms"] < pb["fp32_ms"] < 50.0 and 0.0 < pb["bf16_maxnorm_diff_vs_fp32"] < 2e-2
 
 
 def test_plain_gpus_n_command_launches_its_own_ranks():
