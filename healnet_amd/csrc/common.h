@@ -248,6 +248,24 @@ struct GemmArgs {
   const float *W2; float *C2; long ldc2; int N2; float alpha2; int col_group2, col_group_pitch2;
 };
 int launch_gemm(const GemmArgs &g, hipStream_t s);
+// fp32 patch-bag K/V projection on LDS-DMA staged operands (gemm_nt.hip): C = alpha * A Ws^T + bs, Ws / bs staged by
+// launch_gemm_nt_stage (LayerNorm affine of the context folded in, zero-padded to a multiple of 16 columns)
+struct GemmNtArgs {
+  const float *A; long lda;                    // (M, K), rows 16-byte aligned; columns K .. lda-1 must hold finite values
+  const float *W; long ldw;                    // staged weight (N, ldw >= gemm_nt_ldws(K)), zero beyond K
+  const float *bias;                           // staged bias row (N) or NULL
+  float *C; long ldc;
+  int M, N, K;
+  float alpha;
+  int col_group, col_group_pitch;              // as GemmArgs
+  int ntm, ntn;                                // internal
+};
+bool gemm_nt_eligible(long M, int N, int K, long lda, const float *A, int col_group, int col_group_pitch, long ldc, const float *C);
+int gemm_nt_ldws(int K);
+size_t gemm_nt_stage_floats(int N, int K);
+int launch_gemm_nt_stage(const float *W, long ldw, const float *gamma, const float *beta, const float *bias, int N, int K, float *Ws,
+                         float *bs, hipStream_t s);
+int launch_gemm_nt(const GemmNtArgs &g, int variant, hipStream_t s);
 // bf16-MFMA form of C = alpha * (A gamma + beta) W^T for the patch-bag K/V projection under core_precision = bf16 (gemm_bf16.hip):
 // operands rounded to bf16 once, fp32 accumulation.  Ab = launch_rows_to_bf16(A) (M rows of gemm_bf16_pitch(K) bf16, once per
 // forward), `stage` = gemm_bf16_stage_floats(N, K) floats of 16-byte aligned scratch per call

@@ -1,0 +1,119 @@
+// A/B bench of the fp32 patch-bag K/V projection (cfg4: 32 768 x 773 -> 1024): the round-3 kernel (gemm_big_kernel behind
+// hn::launch_gemm, affine prologue in the loader) against the LDS-DMA kernel of gemm_nt.hip, interleaved in one process on
+// uniform random operands, each variant checked against the other and against an fp64 host reference on sampled elements.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form=1 -o gemm_f32_bench gemm_f32_bench.hip
+#define HN_GEMM_NT_BENCH 1
+#include "../../healnet_amd/csrc/gemm.hip"
+#include "../../healnet_amd/csrc/gemm_nt.hip"
+#include <vector>
+#include <algorithm>
+#include <random>
+#include <string>
+
+namespace hn {
+void debug_after_launch(hipStream_t) {}
+void set_error(const char *, ...) {}
+int fail(int code, const char *fmt, ...) {
+  va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr);
+  return code;
+}
+}  // namespace hn
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+int main(int argc, char **argv) {
+  const int M = argc > 1 ? atoi(argv[1]) : 32768, N = argc > 2 ? atoi(argv[2]) : 1024, K = argc > 3 ? atoi(argv[3]) : 773;
+  const int rounds = argc > 4 ? atoi(argv[4]) : 5, iters = 10;
+  const int lda = (K + 3) / 4 * 4, ldws = hn::gemm_nt_ldws(K);
+  std::mt19937 rng(1234);
+  std::uniform_real_distribution<float> U(-1.f, 1.f);
+  std::vector<float> hA((size_t)M * lda), hW((size_t)N * K), hg(K), hb(K);
+  for (auto &v : hA) v = U(rng);
+  for (auto &v : hW) v = U(rng) * 0.05f;
+  for (auto &v : hg) v = 1.0f + 0.3f * U(rng);
+  for (auto &v : hb) v = 0.2f * U(rng);
+  float *A, *W, *gam, *bet, *C0, *C1, *Ws, *bs;
+  CK(hipMalloc(&A, hA.size() * 4)); CK(hipMalloc(&W, hW.size() * 4)); CK(hipMalloc(&gam, K * 4)); CK(hipMalloc(&bet, K * 4));
+  CK(hipMalloc(&C0, (size_t)M * N * 4)); CK(hipMalloc(&C1, (size_t)M * N * 4));
+  CK(hipMalloc(&Ws, (size_t)N * ldws * 4 + 4096)); CK(hipMalloc(&bs, N * 4));
+  CK(hipMemcpy(A, hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(W, hW.data(), hW.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(gam, hg.data(), K * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(bet, hb.data(), K * 4, hipMemcpyHostToDevice));
+  hipStream_t s; CK(hipStreamCreate(&s));
+
+  hn::GemmArgs g0{};
+  g0.A = A; g0.lda = lda; g0.W = W; g0.ldw = K; g0.C = C0; g0.ldc = N; g0.M = M; g0.N = N; g0.K = K; g0.batch = 1;
+  g0.pro = hn::PRO_AFFINE; g0.gamma = gam; g0.beta = bet; g0.alpha = 1.0f; g0.act = hn::ACT_NONE;
+  hn::GemmNtArgs g1{};
+  g1.A = A; g1.lda = lda; g1.W = Ws; g1.ldw = ldws; g1.bias = bs; g1.C = C1; g1.ldc = N; g1.M = M; g1.N = N; g1.K = K; g1.alpha = 1.0f;
+
+  // -1: round-3 kernel; >= 0: gemm_nt variants (10..13: ablations of variant 0 -- wrong results by construction)
+  const int ids[] = {-1, 0, 1, 2, 3, 4, 10, 11, 12, 13};
+  const int nvar = sizeof(ids) / sizeof(ids[0]);
+  auto run = [&](int v) {
+    if (ids[v] < 0) return hn::launch_gemm(g0, s);
+    return hn::launch_gemm_nt(g1, ids[v], s);
+  };
+  if (hn::launch_gemm_nt_stage(W, K, gam, bet, nullptr, N, K, Ws, bs, s) != 0) return 1;
+  CK(hipStreamSynchronize(s));
+
+  // ---- correctness: every variant against fp64 on sampled elements, and the new ones against the round-3 output everywhere
+  std::vector<float> h0((size_t)M * N), h1((size_t)M * N);
+  if (run(0) != 0) return 1;
+  CK(hipStreamSynchronize(s));
+  CK(hipMemcpy(h0.data(), C0, h0.size() * 4, hipMemcpyDeviceToHost));
+  double ref_scale = 0.0;
+  for (size_t i = 0; i < h0.size(); i += 997) ref_scale = std::max(ref_scale, (double)fabsf(h0[i]));
+  auto spot = [&](const std::vector<float> &h) {
+    double worst = 0.0;
+    std::mt19937 r2(7);
+    for (int t = 0; t < 2000; ++t) {
+      const int m = t < 64 ? (t < 32 ? t : M - 1 - (t - 32)) : (int)(r2() % M), n = t < 64 ? (t * 37) % N : (int)(r2() % N);
+      double acc = 0.0;
+      for (int k = 0; k < K; ++k) acc += ((double)hA[(size_t)m * lda + k] * hg[k] + hb[k]) * hW[(size_t)n * K + k];
+      worst = std::max(worst, fabs(acc - h[(size_t)m * N + n]));
+    }
+    return worst / ref_scale;
+  };
+  printf("shape M=%d N=%d K=%d  |C|max~%.3f\n", M, N, K, ref_scale);
+  printf("variant 0 (gemm_big): fp64 spot rel err %.3e\n", spot(h0));
+  int bad = 0;
+  for (int v = 1; v < nvar; ++v) {
+    CK(hipMemsetAsync(C1, 0xff, (size_t)M * N * 4, s));
+    if (run(v) != 0) return 1;
+    CK(hipStreamSynchronize(s));
+    CK(hipMemcpy(h1.data(), C1, h1.size() * 4, hipMemcpyDeviceToHost));
+    double worst = 0.0;
+    size_t nan = 0;
+    for (size_t i = 0; i < h1.size(); ++i) {
+      if (!(h1[i] == h1[i])) { ++nan; continue; }
+      worst = std::max(worst, (double)fabsf(h1[i] - h0[i]));
+    }
+    const double sp = spot(h1);
+    printf("variant %d (gemm_nt %d): vs gemm_big max rel %.3e, NaN %zu, fp64 spot rel err %.3e\n", v, ids[v], worst / ref_scale, nan, sp);
+    if (ids[v] < 10 && (nan || worst / ref_scale > 1e-4 || sp > 1e-5)) bad = 1;
+  }
+
+  // ---- timing: interleaved rounds
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  std::vector<std::vector<float>> us(nvar);
+  for (int w = 0; w < 30; ++w) run(w % nvar);     // settle the clocks
+  for (int r = 0; r < rounds; ++r)
+    for (int v = 0; v < nvar; ++v) {
+      run(v);
+      CK(hipEventRecord(e0, s));
+      for (int i = 0; i < iters; ++i) run(v);
+      CK(hipEventRecord(e1, s));
+      CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      us[v].push_back(ms * 1000.0f / iters);
+    }
+  const double flops = 2.0 * M * N * K;
+  for (int v = 0; v < nvar; ++v) {
+    std::sort(us[v].begin(), us[v].end());
+    const float med = us[v][us[v].size() / 2], mn = us[v][0];
+    printf("variant %d [id %d]: median %.1f us (%.1f TF/s, %.3f of 157.3)  min %.1f us\n", v, ids[v], med, flops / med * 1e-6, flops / med * 1e-6 / 157.3, mn);
+  }
+  return bad;
+}
