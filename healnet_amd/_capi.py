@@ -12,14 +12,14 @@ import sys
 from typing import Optional
 
 HN_MAX_AXES = 4
-HN_ABI_VERSION = 5
+HN_ABI_VERSION = 6
 HN_F32, HN_BF16, HN_U8 = 0, 1, 2
 HN_CORE_F32, HN_CORE_BF16, HN_CORE_BF16X3 = 0, 1, 2
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HN_LIB_PATH") or os.path.join(_HERE, "libhealnet_hip.so")   # HN_LIB_PATH: kernel experiments (tools/)
 CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ["api.hip", "gemm.hip", "attention.hip", "attention_bf16.hip", "attention_bwd.hip", "encode.hip", "misc.hip",
-           "backward.hip", "train.hip", "chain.hip", "self_attention.hip", "bchain.hip", "gemm_bf16.hip"]
+           "backward.hip", "train.hip", "chain.hip", "self_attention.hip", "bchain.hip", "gemm_bf16.hip", "gemm_nt.hip"]
 
 c_float_p = C.POINTER(C.c_float)
 
@@ -99,6 +99,7 @@ class GradReady(C.Structure):
 # every symbol include/healnet_hip.h declares: name -> (restype, argtypes)
 SIGNATURES = {
     "hn_abi_version": (C.c_int, []),
+    "hn_build_id": (C.c_char_p, []),
     "hn_last_error_string": (C.c_char_p, []),
     "hn_fourier_encode_concat": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_float,
                                            C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
@@ -165,59 +166,101 @@ SIGNATURES = {
 _lib: Optional[C.CDLL] = None
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP translation unit for gfx950 into healnet_amd/libhealnet_hip.so (in-tree).  One hipcc process per
-    translation unit, in parallel, objects under healnet_amd/build/ (git-ignored); a unit is recompiled when it, common.h or
-    the public header is newer than its object.  ``force`` (or HN_FORCE_REBUILD=1) rebuilds everything from a clean slate."""
-    from concurrent.futures import ThreadPoolExecutor
-    force = force or os.environ.get("HN_FORCE_REBUILD", "0") == "1"
-    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "chain_common.h"), os.path.join(_HERE, "..", "include", "healnet_hip.h")]
-    objdir = os.path.join(_HERE, "build")
-    os.makedirs(objdir, exist_ok=True)
+def _headers():
+    hdrs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
+    return hdrs + [os.path.join(_HERE, "..", "include", "healnet_hip.h")]
+
+
+def _digest(paths, flag_text: str) -> str:
+    import hashlib
+    h = hashlib.sha256(flag_text.encode())
+    for path in paths:
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _flags():
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # -amdgpu-mfma-vgpr-form: MFMA accumulators live in plain VGPRs (gfx950 has a unified register file), which
     # removes the per-iteration v_accvgpr_read/write shuffles hipcc otherwise emits around the softmax / epilogues.
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form=1"] + \
         os.environ.get("HN_EXTRA_HIPCC_FLAGS", "").split()
-    stamp = os.path.join(objdir, "flags.txt")
+    return hipcc, flags
+
+
+def source_build_id() -> str:
+    """Build id the CURRENT sources + flags would produce: sha256 over the compile flags, every csrc/*.h, include/healnet_hip.h and
+    every translation unit (first 16 hex digits).  The library embeds the id it was built from (``hn_build_id()``)."""
+    hipcc, flags = _flags()
+    return _digest(_headers() + [os.path.join(CSRC, src) for src in SOURCES], " ".join([hipcc] + flags))[:16]
+
+
+def library_build_id(path: str = "") -> Optional[str]:
+    """Build id embedded in the library FILE at ``path`` (default: LIB_PATH) -- read by scanning for its marker, not by loading it (a
+    process that already mapped an older copy would otherwise keep seeing that one) -- or None when absent / unstamped."""
+    import mmap
+    path = path or LIB_PATH
+    if not os.path.exists(path) or os.path.getsize(path) == 0:
+        return None
+    with open(path, "rb") as f, mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) as m:
+        at = m.find(b"HN_BUILD_ID=")
+        if at < 0:
+            return None
+        end = m.find(b"\0", at, at + 64)
+        return m[at + 12:end].decode() if end > 0 else None
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP translation unit for gfx950 into healnet_amd/libhealnet_hip.so (in-tree).  Freshness is decided by CONTENT,
+    never by mtime: the library embeds the sha256 of the flags + headers + sources it was built from (``hn_build_id()``) and is kept
+    only when that equals ``source_build_id()`` -- so a prebuilt library that travelled to a GPU box (mtimes rewritten, no build/
+    directory) is trusted exactly when it matches the sources next to it, and rebuilt there otherwise.  Objects under
+    healnet_amd/build/ (git-ignored) carry a per-unit digest (`<unit>.o.sha`) of flags + headers + that unit; one hipcc process per
+    stale unit, in parallel.  ``force`` (or HN_FORCE_REBUILD=1) rebuilds everything."""
+    from concurrent.futures import ThreadPoolExecutor
+    force = force or os.environ.get("HN_FORCE_REBUILD", "0") == "1"
+    hipcc, flags = _flags()
     flag_text = " ".join([hipcc] + flags)
-    # a rebuild is forced only when a flag stamp EXISTS and differs; a box that received the prebuilt library without the
-    # build/ directory (no stamp) keeps it as long as it is newer than every source
-    if os.path.exists(stamp) and open(stamp).read() != flag_text:
-        force = True
-    hdr_time = max(os.path.getmtime(h) for h in hdrs)
-    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(
-            [hdr_time] + [os.path.getmtime(os.path.join(CSRC, src)) for src in SOURCES]):
-        if not os.path.exists(stamp):
-            try:
-                with open(stamp, "w") as f:
-                    f.write(flag_text)
-            except OSError:
-                pass
-        return LIB_PATH          # up to date (also the case on a GPU box that received the prebuilt library without objects)
-    jobs = []
+    want = source_build_id()
+    if not force and library_build_id() == want:
+        return LIB_PATH
+    objdir = os.path.join(_HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    hdrs = _headers()
+    jobs, objs = [], []
     for src in SOURCES:
         path, obj = os.path.join(CSRC, src), os.path.join(objdir, src + ".o")
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(path), hdr_time):
-            jobs.append((path, obj))
-    objs = [os.path.join(objdir, src + ".o") for src in SOURCES]
-    if not jobs and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(o) for o in objs):
-        return LIB_PATH
+        # api.hip embeds the library-wide id, so it is rebuilt whenever anything changed
+        unit = _digest(hdrs + [path], flag_text + (want if src == "api.hip" else ""))
+        sha = obj + ".sha"
+        fresh = not force and os.path.exists(obj) and os.path.exists(sha) and open(sha).read() == unit
+        if not fresh:
+            jobs.append((path, obj, sha, unit, ["-DHN_BUILD_ID=\"%s\"" % want] if src == "api.hip" else []))
+        objs.append(obj)
 
     def compile_one(job):
-        cmd = [hipcc] + flags + ["-c", job[0], "-o", job[1]]
+        path, obj, sha, unit, extra = job
+        cmd = [hipcc] + flags + extra + ["-c", path, "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
+        if os.path.exists(sha):
+            os.remove(sha)
         subprocess.run(cmd, check=True, cwd=CSRC)
+        with open(sha, "w") as f:
+            f.write(unit)
 
-    with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as pool:
-        list(pool.map(compile_one, jobs))
+    if jobs:
+        with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as pool:
+            list(pool.map(compile_one, jobs))
     link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
     if verbose:
         print(" ".join(link), file=sys.stderr)
     subprocess.run(link, check=True, cwd=CSRC)
-    with open(stamp, "w") as f:
-        f.write(flag_text)
+    got = library_build_id()
+    if got != want:
+        raise RuntimeError(f"healnet_amd: built library reports build id {got!r}, expected {want!r}")
     return LIB_PATH
 
 
@@ -229,6 +272,12 @@ def lib() -> C.CDLL:
             raise RuntimeError(
                 f"healnet_amd: {LIB_PATH} is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        if "HN_LIB_PATH" not in os.environ and os.path.isdir(CSRC):
+            # a library that was not built from the sources next to it (stale prebuilt copy) is never used silently
+            have, want = library_build_id(), source_build_id()
+            if have != want:
+                print(f"healnet_amd: {LIB_PATH} has build id {have}, the sources {want}: rebuilding", file=sys.stderr)
+                build()
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)   # AttributeError if the symbol is not exported

@@ -127,7 +127,10 @@ static int plan_attn(const hn_attn_params *p, bool has_ctx, int ld_ctx, int b, i
     pl->kv = ar.take<float>((size_t)b * pl->N * 2 * p->heads * pl->dhp);
   }
   pl->ctx16 = nullptr;
-  pl->wstage = (has_ctx && !pl->rank_d && pl->N > 1) ? ar.take<float>(gemm_bf16_stage_floats(2 * pl->inner, pl->D)) : nullptr;
+  {
+    const size_t w16 = gemm_bf16_stage_floats(2 * pl->inner, pl->D), w32 = gemm_nt_stage_floats(2 * pl->inner, pl->D);
+    pl->wstage = (has_ctx && !pl->rank_d && pl->N > 1) ? ar.take<float>(w16 > w32 ? w16 : w32) : nullptr;
+  }
   const size_t prow = (size_t)b * p->heads * pl->nsplit * pl->Lp;
   pl->opart = ar.take<float>(prow * pl->dp);
   pl->mpart = ar.take<float>(prow);
@@ -253,8 +256,20 @@ static int attn_prepare(const hn_attn_params *p, const AttnPlan &pl, const float
       gk.W = p->w_kv; gk.ldw = pl.D;
       gk.N = 2 * pl.inner;
       gk.C = kvbuf; gk.ldc = kvpitch; gk.col_group = pl.dh; gk.col_group_pitch = pl.dhp;
+      static const bool no_glds = getenv("HN_NO_GLDS_GEMM") != nullptr;      // development switch: gemm_big_kernel
       if (ctx && pl.ctx16 && pl.wstage && gemm_bf16_eligible(gk)) rc = launch_gemm_bf16(gk, pl.ctx16, pl.wstage, s);
-      else rc = launch_gemm(gk, s);
+      else if (ctx && pl.wstage && !no_glds && gk.pro != PRO_LAYERNORM &&
+               gemm_nt_eligible(gk.M, gk.N, gk.K, gk.lda, gk.A, gk.col_group, gk.col_group_pitch, gk.ldc, gk.C)) {
+        // patch-bag K/V projection: LayerNorm affine folded into the staged weight, operands by LDS-DMA (gemm_nt.hip)
+        float *ws_w = pl.wstage, *ws_b = pl.wstage + (size_t)gk.N * gemm_nt_ldws(gk.K);
+        if ((rc = launch_gemm_nt_stage(gk.W, gk.ldw, gk.pro == PRO_AFFINE ? gk.gamma : nullptr, gk.pro == PRO_AFFINE ? gk.beta : nullptr, nullptr,
+                                       gk.N, gk.K, ws_w, ws_b, s)) != HN_OK) return rc;
+        GemmNtArgs gn;
+        gn.A = gk.A; gn.lda = gk.lda; gn.W = ws_w; gn.ldw = gemm_nt_ldws(gk.K); gn.bias = ws_b; gn.C = gk.C; gn.ldc = gk.ldc;
+        gn.M = gk.M; gn.N = gk.N; gn.K = gk.K; gn.alpha = 1.0f; gn.col_group = gk.col_group; gn.col_group_pitch = gk.col_group_pitch;
+        gn.ntm = gn.ntn = 0;
+        rc = launch_gemm_nt(gn, 0, s);
+      } else rc = launch_gemm(gk, s);
       if (rc != HN_OK) return rc;
     }
     core->Q = qbuf; core->q_b = (long)L * qpitch; core->q_h = pl.dhp; core->ldq = qpitch;
@@ -358,15 +373,16 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
     gk.W = p->w_kv; gk.ldw = pl.D;
     gk.N = 2 * pl.inner;
     gk.C = pl.kv; gk.ldc = 2 * pl.inner;      // (not written: the images below alias it)
-    if (gemm_bf16_eligible(gk)) {
-      // the fp32 K|V rows of this plan (b N x 2 inner floats) hold K16 (a quarter), V16 (a quarter; token slots rounded up to 32 per
-      // sample) and the query image
-      const int Np = (pl.N + 31) / 32 * 32;
+    // the fp32 K|V rows of this plan (b N x 2 inner floats) hold K16 (a quarter), V16 (a quarter; token slots rounded up to 32 per
+    // sample) and the query image: a bag too small for that (few tokens against l_c query rows) keeps the fp32 core behind the
+    // bf16 projection (attn_prepare) instead of failing
+    const int Np = (pl.N + 31) / 32 * 32;
+    const bool images_fit = align_up((size_t)b * pl.N * pl.inner, 8) + (size_t)b * Np * pl.inner + (size_t)b * p->heads * pl.Lp * 64 <=
+                            (size_t)b * pl.N * pl.inner * 4;
+    if (images_fit && gemm_bf16_eligible(gk)) {
       uint16_t *K16 = (uint16_t *)pl.kv;
       uint16_t *V16 = K16 + align_up((size_t)b * pl.N * pl.inner, 8);
       uint16_t *Q16 = V16 + (size_t)b * Np * pl.inner;
-      HN_REQUIRE(align_up((size_t)b * pl.N * pl.inner, 8) + (size_t)b * Np * pl.inner + (size_t)b * p->heads * pl.Lp * 64 <= (size_t)b * pl.N * pl.inner * 4,
-                 HN_E_WORKSPACE, "attn: the bf16 K / V / query images do not fit the plan's K|V buffer");
       const bool q_done = ext && ext->q && ext->q_done;
       float *qbuf = q_done ? ext->q : pl.q;
       if (!q_done) {
@@ -1301,6 +1317,13 @@ using namespace hn;
 extern "C" {
 
 int hn_abi_version(void) { return HN_ABI_VERSION; }
+#ifndef HN_BUILD_ID
+#define HN_BUILD_ID "unstamped"
+#endif
+// the marker is also what the host side scans the FILE for (no dlopen: a process that has the old library mapped must still be able
+// to read the id of a freshly linked one)
+static const char kBuildIdMarker[] = "HN_BUILD_ID=" HN_BUILD_ID;
+const char *hn_build_id(void) { return kBuildIdMarker + 12; }
 const char *hn_last_error_string(void) { return g_err; }
 
 int hn_context_pitch(int D, int dim_head) { return context_pitch(D, dim_head); }

@@ -507,6 +507,14 @@ static int launch_gemm_tn(const float *A, long lda, const float *B, long ldb, fl
                           int accumulate, float *scratch, hipStream_t s, float *colsum = nullptr, int colsum_accumulate = 0,
                           int batch = 1, long strideA = 0, long strideB = 0, long strideC = 0) {
   HN_REQUIRE(batch == 1 || colsum == nullptr, HN_E_UNSUPPORTED, "gemm_tn: the fused column sum is not batched");
+  // long contraction, wide output (the patch-bag G = dKV^T z): the LDS-DMA kernel (gemm_nt.hip).  Every split-k scratch buffer holds
+  // at least GEMM_EX_SPLITS * (M N + M) floats (reduce_scratch_floats)
+  static const bool no_glds = getenv("HN_NO_GLDS_GEMM") != nullptr;      // development switch: the round-3 kernels
+  if (!no_glds && scratch && batch == 1 && gemm_tn_glds_eligible(A, lda, B, ldb, M, N, K)) {
+    size_t cap = (size_t)GEMM_EX_SPLITS * ((size_t)M * N + M);
+    if (cap < (size_t)TN_SCRATCH_MIN_FLOATS) cap = (size_t)TN_SCRATCH_MIN_FLOATS;
+    return launch_gemm_tn_glds(A, lda, B, ldb, C, ldc, M, N, K, alpha, accumulate, scratch, cap, colsum, colsum_accumulate, s);
+  }
   const int tiles = ceil_div(M, 128) * ceil_div(N, 128) * batch;
   int nsplit = 1;
   if (scratch) {

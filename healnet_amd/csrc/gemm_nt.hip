@@ -146,6 +146,18 @@ __global__ __launch_bounds__(NWM *NWN * 64) void gemm_nt_glds_kernel(GemmNtArgs 
   for (int kt = 0; kt < nk; ++kt) {
     const bool last = kt + 1 == nk, two = !last || tail_steps == 2;
     if (two) read_frags(kt, 1, f1);
+    if (last) {
+      // columns K .. of the last step(s) belong to the row's pad / the next row: whatever they hold (NaNs included) must not reach
+      // the accumulators -- the A fragment is masked in registers (once per tile; the staged weight is zero there as well)
+      const int kc = kt * 32 + 4 * fg;
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          f0.a[i][e] = kc + e < g.K ? f0.a[i][e] : 0.0f;
+          if (two) f1.a[i][e] = kc + 16 + e < g.K ? f1.a[i][e] : 0.0f;
+        }
+    }
     __builtin_amdgcn_sched_barrier(0);
     mfma_step(f0);
     __builtin_amdgcn_sched_barrier(0);
@@ -180,6 +192,230 @@ __global__ __launch_bounds__(NWM *NWN * 64) void gemm_nt_glds_kernel(GemmNtArgs 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// TN product on the same staging: C[i, j] = sum_r A[r, i] * B[r, j] over a LONG contraction (the patch-bag weight gradient
+// G = dKV^T z of healnet.py:405's autograd: 1024 x 773 over 32 768 rows, 52 GF per block), split over row slices into partials that
+// gemm_tn_reduce_kernel folds in a fixed order.  Both operands are contraction-major, so a k-tile is 32 rows of 512 contiguous
+// bytes per operand, landed by LDS-DMA as it lies ([k][128] images, no swizzle: the fragment reads below are conflict-free or
+// 2-way at a rate where it does not matter).
+//   * 773 = 6 * 128 + 5: on 128-wide tiles the seventh column tile is almost empty (7.6 % of the round-3 kernel's MFMAs).  Here a
+//     tile is 128 (i) x NB * 16 (j) with NB = 7: 7 x 112 = 784 columns, 1.4 % padding; the loads still fetch 128 columns per row.
+//   * a wave owns 32 (i) x 112 (j): per 4-row step ONE ds_read_b64 (i = 32 w + 2 fi + e: 2 blocks), one ds_read_b128 (j = 4 fi + e:
+//     4 blocks) and 3 ds_read_b32 (j = 64 + 16 e + fi) feed 14 MFMAs; the MFMA takes the B fragment as its A operand, so a lane
+//     ends up with FOUR CONSECUTIVE j of one i: dwordx4 partial stores (partial pitch = tiles * 112, 16-byte aligned).
+//   * colsum_i = sum_r A[r, i] (the bias-gradient / LayerNorm-beta term) rides along in the first column tile: its threads re-read
+//     the landed A tile from LDS (4 ds_read_b128 + 16 adds per thread and k-tile).
+// ------------------------------------------------------------------------------------------------
+struct GemmTnGArgs {
+  const float *A; long lda;        // (K, M)
+  const float *B; long ldb;        // (K, N)
+  float *part; long ldp;           // (nsplit, M, ldp) partials
+  float *cs_part;                  // (nsplit, M) column-sum partials or NULL
+  int M, N, K, kslice, nsplit, ntm, ntn;
+};
+
+template <int NB>
+__global__ __launch_bounds__(256) void gemm_tn_glds_kernel(GemmTnGArgs g) {
+  constexpr int S = 2, STAGE = 2 * 32 * 128, LW = 8;       // floats per ring slot: A tile [32][128] then B tile [32][128]
+  constexpr int BNT = NB * 16;
+  __shared__ __attribute__((aligned(16))) float lds[S * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile = blockIdx.x, z = blockIdx.y;
+  const int m_tile = tile % g.ntm, n_tile = tile / g.ntm;
+  const int m0 = m_tile * 128, n0 = n_tile * BNT;
+  const int k_begin = z * g.kslice, rows = min(g.K, k_begin + g.kslice) - k_begin;
+  const int lda = (int)g.lda, ldb = (int)g.ldb;
+  // descriptors based at (slice row 0, tile column 0): rows past the slice read as zero
+  const long a_bytes = ((long)(rows - 1) * lda + (g.M - m0)) * 4, b_bytes = ((long)(rows - 1) * ldb + (g.N - n0)) * 4;
+  const i32x4 rsA = make_rsrc(g.A + (long)k_begin * lda + m0, (unsigned)(a_bytes > 0 ? a_bytes : 0));
+  const i32x4 rsB = make_rsrc(g.B + (long)k_begin * ldb + n0, (unsigned)(b_bytes > 0 ? b_bytes : 0));
+  // loader: one instruction = 2 rows x 512 bytes; lane -> (row lane >> 5, 16-byte piece lane & 31)
+  const int voffA = (lane >> 5) * lda * 4 + ((lane & 31) << 4), voffB = (lane >> 5) * ldb * 4 + ((lane & 31) << 4);
+  auto issue = [&](int kt) {
+    float *st = lds + (kt % S) * STAGE;
+#pragma unroll
+    for (int q = 0; q < LW; ++q) {
+      const int u = wave + 4 * q;                                 // u < 16: A rows 2u, 2u + 1; else B rows 2(u - 16) ..
+      auto dst = (__attribute__((address_space(3))) void *)(st + u * 256);
+      if (q < 4) hn_glds16(rsA, dst, 16, voffA, (kt * 32 + 2 * u) * lda * 4, 0, 0);
+      else hn_glds16(rsB, dst, 16, voffB, (kt * 32 + 2 * (u - 16)) * ldb * 4, 0, 0);
+    }
+  };
+  const int fi = lane & 15, fg = lane >> 4;
+  const int a_off = fg * 128 + 32 * wave + 2 * fi;                // + 512 per 4-row step
+  const int b_off = 32 * 128 + fg * 128;
+  struct Frags { float2 a[4]; f32x4 b[4]; float c[4][NB - 4]; };
+  auto read_frags = [&](int kt, int half, Frags &f) {
+    const float *st = lds + (kt % S) * STAGE;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int step = (half * 4 + q) * 512;
+      f.a[q] = *(const float2 *)&st[a_off + step];
+      f.b[q] = *(const f32x4 *)&st[b_off + step + 4 * fi];
+      if (NB == 8) {
+        const f32x4 t = *(const f32x4 *)&st[b_off + step + 64 + 4 * fi];
+#pragma unroll
+        for (int e = 0; e < NB - 4; ++e) f.c[q][e] = t[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < NB - 4; ++e) f.c[q][e] = st[b_off + step + 64 + 16 * e + fi];
+      }
+    }
+  };
+  f32x4 acc[2][NB];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  auto mfma_half = [&](const Frags &f) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float av[2] = {f.a[q].x, f.a[q].y};
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.b[q][j], av[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 4; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.c[q][j - 4], av[i], acc[i][j], 0, 0, 0);
+      }
+    }
+  };
+  const bool do_cs = g.cs_part != nullptr && n_tile == 0;
+  f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+  const int cs_off = (tid >> 5) * 128 + ((tid & 31) << 2);         // rows (tid >> 5) + 8 q of the A tile, 4 columns
+
+  const int nk = (rows + 31) >> 5;
+  if (nk > 0) issue(0);
+  if (nk > 1) issue(1);
+  auto wait_tile = [&](int kt) {
+    if (kt + 1 < nk) wait_vmcnt<LW>(); else wait_vmcnt<0>();
+  };
+  Frags f0, f1;
+  if (nk > 0) {
+    wait_tile(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    read_frags(0, 0, f0);
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool last = kt + 1 == nk;
+    read_frags(kt, 1, f1);
+    if (do_cs) {
+      asm volatile("" ::: "memory");
+      const float *st = lds + (kt % S) * STAGE;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) csum += *(const f32x4 *)&st[cs_off + q * 1024];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_half(f0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!last) {
+      wait_tile(kt + 1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (kt + S < nk) issue(kt + S);
+      read_frags(kt + 1, 0, f0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    mfma_half(f1);
+  }
+
+  if (do_cs) {          // 8 row groups x 128 columns of partial sums through LDS (every wave is past its last tile read)
+    __syncthreads();
+    *(f32x4 *)&lds[(tid >> 5) * 128 + ((tid & 31) << 2)] = csum;
+    __syncthreads();
+    if (tid < 128 && m0 + tid < g.M) {
+      float v = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v += lds[r * 128 + tid];
+      g.cs_part[(long)z * g.M + m0 + tid] = v;
+    }
+  }
+  // D of mfma(B fragment, A fragment): row rho = 4 fg + r <-> j, column fi <-> i.  Blocks 0..3: j = 4 rho + block -> the lane's
+  // four blocks hold j = 16 fg + 4 r + {0, 1, 2, 3}; blocks 4..: j = 64 + 16 (block - 4) + 4 fg + {r}
+  float *P = g.part + (long)z * g.M * g.ldp;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + 32 * wave + 2 * fi + i;
+    if (m >= g.M) continue;
+    float *row = P + (long)m * g.ldp + n0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) *(f32x4 *)&row[16 * fg + 4 * r] = (f32x4){acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+    if (NB == 8) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) *(f32x4 *)&row[64 + 16 * fg + 4 * r] = (f32x4){acc[i][4][r], acc[i][NB - 3][r], acc[i][NB - 2][r], acc[i][NB - 1][r]};
+    } else {
+#pragma unroll
+      for (int j = 4; j < NB; ++j) *(f32x4 *)&row[64 + 16 * (j - 4) + 4 * fg] = acc[i][j];
+    }
+  }
+}
+
+// C[m, n] (+)= alpha * sum_z part[z, m, n] for n < N; colsum[m] (+)= sum_z cs_part[z, m].  Fixed order: bitwise reproducible.
+__global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float *__restrict__ part, int nsplit, int M, int N, long ldp,
+                                                             float *__restrict__ C, long ldc, float alpha, int accumulate,
+                                                             const float *__restrict__ cs_part, float *__restrict__ cs_out, int cs_accumulate) {
+  const long mn = (long)M * N, total = mn + (cs_part ? M : 0), slab = (long)M * ldp;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    if (i >= mn) {
+      const int m = (int)(i - mn);
+      float acc = 0.0f;
+      for (int k = 0; k < nsplit; ++k) acc += cs_part[(long)k * M + m];
+      cs_out[m] = cs_accumulate ? cs_out[m] + acc : acc;
+      continue;
+    }
+    const long m = i / N, n = i % N;
+    const float *src = part + m * ldp + n;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    int k = 0;
+    for (; k + 4 <= nsplit; k += 4) {
+      a0 += src[(long)k * slab]; a1 += src[(long)(k + 1) * slab]; a2 += src[(long)(k + 2) * slab]; a3 += src[(long)(k + 3) * slab];
+    }
+    for (; k < nsplit; ++k) a0 += src[(long)k * slab];
+    const float acc = (a0 + a1) + (a2 + a3);
+    float *dst = C + m * ldc + n;
+    *dst = accumulate ? *dst + alpha * acc : alpha * acc;
+  }
+}
+
+bool gemm_tn_glds_eligible(const float *A, long lda, const float *B, long ldb, int M, int N, int K) {
+  return K >= 4096 && M >= 128 && N >= 112 && M % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 &&
+         (long)K * lda * 4 < (1L << 31) && (long)K * ldb * 4 < (1L << 31);
+}
+
+// scratch_floats: capacity of `scratch` (partials + column-sum partials)
+int launch_gemm_tn_glds(const float *A, long lda, const float *B, long ldb, float *C, long ldc, int M, int N, int K, float alpha,
+                        int accumulate, float *scratch, size_t scratch_floats, float *colsum, int colsum_accumulate, hipStream_t s) {
+  HN_REQUIRE(A && B && C && scratch, HN_E_NULL, "gemm_tn_glds: NULL operand");
+  GemmTnGArgs g;
+  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.M = M; g.N = N; g.K = K;
+  // 112- or 128-wide column tiles, whichever pads less
+  const int nb = ceil_div(N, 112) * 112 <= ceil_div(N, 128) * 128 ? 7 : 8;
+  g.ntm = ceil_div(M, 128); g.ntn = ceil_div(N, nb * 16);
+  g.ldp = (long)g.ntn * nb * 16;
+  const int tiles = g.ntm * g.ntn;
+  int nsplit = 512 / tiles;                                  // 64 KB of LDS: 2 workgroups per CU, one resident round
+  if (nsplit < 1) nsplit = 1;
+  const size_t per = (size_t)M * g.ldp + (colsum ? M : 0);
+  if ((size_t)nsplit * per > scratch_floats) nsplit = (int)(scratch_floats / per);
+  HN_REQUIRE(nsplit >= 1, HN_E_WORKSPACE, "gemm_tn_glds: scratch %zu floats < %zu", scratch_floats, per);
+  g.kslice = ceil_div(ceil_div(K, nsplit), 32) * 32;
+  g.nsplit = ceil_div(K, g.kslice);
+  g.part = scratch;
+  g.cs_part = colsum ? scratch + (size_t)g.nsplit * M * g.ldp : nullptr;
+  if (nb == 7) hipLaunchKernelGGL(gemm_tn_glds_kernel<7>, dim3(tiles, g.nsplit), dim3(256), 0, s, g);
+  else hipLaunchKernelGGL(gemm_tn_glds_kernel<8>, dim3(tiles, g.nsplit), dim3(256), 0, s, g);
+  HN_LAUNCH_CHECK("gemm_tn_glds");
+  long blocks = ceil_div_ll((long)M * N + (colsum ? M : 0), 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, scratch, g.nsplit, M, N, g.ldp, C, ldc, alpha, accumulate,
+                     g.cs_part, colsum, colsum_accumulate);
+  HN_LAUNCH_CHECK("gemm_tn_reduce");
+  return HN_OK;
+}
+
 bool gemm_nt_eligible(long M, int N, int K, long lda, const float *A, int col_group, int col_group_pitch, long ldc, const float *C) {
   return M >= 2048 && N >= 256 && N % 4 == 0 && K >= 64 && lda % 4 == 0 && lda >= K && ((uintptr_t)A & 15) == 0 && ldc % 4 == 0 &&
          ((uintptr_t)C & 15) == 0 && (col_group == 0 || (col_group % 4 == 0 && col_group_pitch % 4 == 0));
@@ -187,8 +423,10 @@ bool gemm_nt_eligible(long M, int N, int K, long lda, const float *A, int col_gr
 int gemm_nt_ldws(int K) { return (K + 15) / 16 * 16; }
 size_t gemm_nt_stage_floats(int N, int K) { return (size_t)N * gemm_nt_ldws(K) + (size_t)(N + 63) / 64 * 64 + 64; }
 
-// variant: 0 = 128 x 128 / 4 waves / 2 slots (64 KB, 2 workgroups per CU), 1 = 128 x 128 / 4 waves / 3 slots, 2 = 256 x 128 / 8 waves / 2
-// slots, 3 = 256 x 128 / 8 waves / 3 slots
+// variant 0 (the product's): 128 x 128 tile, 4 waves of 64 x 64, 2 ring slots = 64 KB of LDS, 2 workgroups per CU.  Measured at cfg4's
+// shape (tools/ubench/gemm_f32_bench.hip, profiles/r04_a_gemm_nt_ab.log): 382 us = 0.863 of the fp32 MFMA peak against 459 us
+// (0.718) for gemm_big_kernel; 3 slots at one workgroup per CU 448 us, 256 x 128 on 8 waves 407 us, 256 x 256 (128 x 64 per wave)
+// 392 us; without its stores 369 us, without loads / barriers 378-383 us, MFMAs + fragment reads alone 363 us (0.909: the clock).
 int launch_gemm_nt(const GemmNtArgs &g_in, int variant, hipStream_t s) {
   GemmNtArgs g = g_in;
   HN_REQUIRE(g.A && g.W && g.C, HN_E_NULL, "gemm_nt: NULL operand");
@@ -199,10 +437,10 @@ int launch_gemm_nt(const GemmNtArgs &g_in, int variant, hipStream_t s) {
   HN_REQUIRE(blocks < (1L << 31), HN_E_UNSUPPORTED, "gemm_nt: grid too large");
   switch (variant) {
     case 0: hipLaunchKernelGGL((gemm_nt_glds_kernel<4, 4, 2, 2, 2>), dim3((unsigned)blocks), dim3(256), 0, s, g); break;
+#ifdef HN_GEMM_NT_BENCH
     case 1: hipLaunchKernelGGL((gemm_nt_glds_kernel<4, 4, 2, 2, 3>), dim3((unsigned)blocks), dim3(256), 0, s, g); break;
     case 2: hipLaunchKernelGGL((gemm_nt_glds_kernel<4, 4, 4, 2, 2>), dim3((unsigned)blocks), dim3(512), 0, s, g); break;
     case 3: hipLaunchKernelGGL((gemm_nt_glds_kernel<4, 4, 4, 2, 3>), dim3((unsigned)blocks), dim3(512), 0, s, g); break;
-#ifdef HN_GEMM_NT_BENCH
     case 4: hipLaunchKernelGGL((gemm_nt_glds_kernel<8, 4, 2, 4, 2>), dim3((unsigned)blocks), dim3(512), 0, s, g); break;
     case 10: hipLaunchKernelGGL((gemm_nt_glds_kernel<4, 4, 2, 2, 2, 1>), dim3((unsigned)blocks), dim3(256), 0, s, g); break;
     case 11: hipLaunchKernelGGL((gemm_nt_glds_kernel<4, 4, 2, 2, 2, 2>), dim3((unsigned)blocks), dim3(256), 0, s, g); break;

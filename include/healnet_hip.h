@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HN_ABI_VERSION 5
+#define HN_ABI_VERSION 6
 #define HN_MAX_AXES 4
 
 typedef enum hn_status {
@@ -63,6 +63,9 @@ typedef enum hn_dtype { HN_F32 = 0, HN_BF16 = 1, HN_U8 = 2 } hn_dtype;
 typedef enum hn_core_precision { HN_CORE_F32 = 0, HN_CORE_BF16 = 1, HN_CORE_BF16X3 = 2 } hn_core_precision;
 
 int hn_abi_version(void);
+/* 16 hex digits: sha256 over the compile flags, headers and translation units this library was built from (the host side
+ * rebuilds when it differs from the sources next to it; bench.py prints it). */
+const char *hn_build_id(void);
 const char *hn_last_error_string(void);
 
 /* ---------------------------------------------------------------------------------------------

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     lib = _capi.lib()                      # raises if the .so is missing: build() must have run
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.hn_abi_version() == _capi.HN_ABI_VERSION == 5
+    assert lib.hn_abi_version() == _capi.HN_ABI_VERSION == 6
     assert lib.hn_context_pitch(13, 64) == 16 and lib.hn_context_pitch(18, 64) == 32
     assert lib.hn_context_pitch(773, 64) == 776 and lib.hn_context_pitch(2005, 64) == 2008
     assert lib.hn_context_pitch(20, 16) == 20          # rank-D path would not pay: dp 32 > dim_head 16
@@ -228,3 +228,47 @@ def test_non_fp32_parameters_are_refused():
         with pytest.raises(TypeError, match="float32"):
             getattr(HealNet(n_modalities=1, channel_dims=[3], num_spatial_axes=[2], out_dims=2, depth=1, l_c=4, l_d=8, x_heads=1,
                             l_heads=1, cross_dim_head=8, latent_dim_head=8), cast)()._descriptor()
+
+
+def test_reference_import_lines_resolve():
+    """The import lines a user of konst-int-i/healnet writes (README.md:70-71, healnet/models/__init__.py:1-11, main.py, explainer.py,
+    tests/test_healnet.py) resolve to the HIP-backed classes -- executed verbatim."""
+    ns = {}
+    exec("from healnet import HealNet\n"
+         "from healnet.etl import MMDataset\n"
+         "from healnet.models import HealNet as H2, Attention\n"
+         "from healnet.models import *\n"
+         "from healnet.models.healnet import fourier_encode, temperature_softmax, Attention as A2\n"
+         "from healnet.etl.loaders import MMDataset as M2\n", ns)
+    import healnet_amd
+    assert ns["HealNet"] is ns["H2"] is healnet_amd.HealNet
+    assert ns["Attention"] is ns["A2"] is healnet_amd.Attention
+    assert ns["MMDataset"] is ns["M2"] is healnet_amd.MMDataset
+    assert ns["fourier_encode"] is healnet_amd.fourier_encode
+    import healnet.models as hm
+    with pytest.raises(AttributeError, match="not provided"):
+        hm.FCNN  # noqa: B018  (out of scope: named, not silently missing)
+
+
+def test_build_id_is_content_addressed(tmp_path):
+    """The library embeds the digest of the sources + flags it was built from; the host side trusts a prebuilt copy exactly when
+    that digest matches the sources next to it (never by mtime)."""
+    from healnet_amd import _capi
+    lib = _capi.lib()
+    want = _capi.source_build_id()
+    assert lib.hn_build_id().decode() == want == _capi.library_build_id()
+    assert len(want) == 16 and int(want, 16) >= 0
+    # the digest moves with the flags and with any source byte
+    hipcc, flags = _capi._flags()
+    a = _capi._digest(_capi._headers(), " ".join([hipcc] + flags))
+    b = _capi._digest(_capi._headers(), " ".join([hipcc] + flags + ["-DX"]))
+    assert a != b
+    p = tmp_path / "x.h"
+    p.write_text("int a;")
+    d1 = _capi._digest([str(p)], "f")
+    p.write_text("int b;")
+    assert _capi._digest([str(p)], "f") != d1
+    # a file without the marker (or a missing one) has no id
+    q = tmp_path / "lib.so"
+    q.write_bytes(b"\x7fELF" + b"\0" * 64)
+    assert _capi.library_build_id(str(q)) is None and _capi.library_build_id(str(tmp_path / "none.so")) is None

@@ -5,6 +5,7 @@
 #define HN_GEMM_NT_BENCH 1
 #include "../../healnet_amd/csrc/gemm.hip"
 #include "../../healnet_amd/csrc/gemm_nt.hip"
+#include "../../healnet_amd/csrc/backward.hip"
 #include <vector>
 #include <algorithm>
 #include <random>
@@ -114,6 +115,61 @@ int main(int argc, char **argv) {
     std::sort(us[v].begin(), us[v].end());
     const float med = us[v][us[v].size() / 2], mn = us[v][0];
     printf("variant %d [id %d]: median %.1f us (%.1f TF/s, %.3f of 157.3)  min %.1f us\n", v, ids[v], med, flops / med * 1e-6, flops / med * 1e-6 / 157.3, mn);
+  }
+  // ================= TN: G = dKV^T z (cfg4: 1024 x 773 over 32 768 rows), round-3 route (launch_gemm_ex -> gemm_tn_lds_kernel) vs gemm_tn_glds
+  {
+    const int TM = N, TNn = K, TK = M;           // 1024 x 773, contraction over the 32 768 rows: A = C0 (M x N, from above), B = A (M x lda)
+    float *G0, *G1, *cs0, *cs1, *scr;
+    const size_t scr_floats = hn::reduce_scratch_floats((long)TM * TNn, TM);
+    CK(hipMalloc(&G0, (size_t)TM * TNn * 4)); CK(hipMalloc(&G1, (size_t)TM * TNn * 4)); CK(hipMalloc(&cs0, TM * 4)); CK(hipMalloc(&cs1, TM * 4));
+    CK(hipMalloc(&scr, scr_floats * 4));
+    run(0);                                       // C0 = the projected K|V rows, used as "dKV"
+    hn::GemmExArgs e{};
+    e.A = C0; e.a_rs = 1; e.a_cs = N; e.B = A; e.b_rs = 1; e.b_cs = lda; e.C = G0; e.ldc = TNn; e.M = TM; e.N = TNn; e.K = TK; e.batch = 1;
+    e.alpha = 1.0f; e.accumulate = 0; e.colsum = cs0; e.colsum_accumulate = 0;
+    auto run_tn = [&](int v) {
+      if (v == 0) return hn::launch_gemm_ex(e, s, scr);
+      return hn::launch_gemm_tn_glds(C0, N, A, lda, G1, TNn, TM, TNn, TK, 1.0f, 0, scr, scr_floats, cs1, 0, s);
+    };
+    if (run_tn(0) != 0) return 1;
+    CK(hipMemsetAsync(G1, 0xff, (size_t)TM * TNn * 4, s));
+    if (run_tn(1) != 0) return 1;
+    CK(hipStreamSynchronize(s));
+    std::vector<float> g0((size_t)TM * TNn), g1v((size_t)TM * TNn), c0(TM), c1(TM);
+    CK(hipMemcpy(g0.data(), G0, g0.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(g1v.data(), G1, g1v.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(c0.data(), cs0, TM * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(c1.data(), cs1, TM * 4, hipMemcpyDeviceToHost));
+    double sc = 0, worst = 0, csc = 0, cworst = 0; size_t nan = 0;
+    for (size_t i = 0; i < g0.size(); ++i) { sc = std::max(sc, (double)fabsf(g0[i])); if (!(g1v[i] == g1v[i])) ++nan; else worst = std::max(worst, (double)fabsf(g0[i] - g1v[i])); }
+    for (int i = 0; i < TM; ++i) { csc = std::max(csc, (double)fabsf(c0[i])); cworst = std::max(cworst, (double)fabsf(c0[i] - c1[i])); }
+    // fp64 spot check of the new kernel
+    double sworst = 0;
+    std::mt19937 r3(11);
+    for (int t = 0; t < 200; ++t) {
+      const int i = t < 8 ? t * 146 % TM : (int)(r3() % TM), j = t < 8 ? TNn - 1 - t : (int)(r3() % TNn);
+      double acc = 0;
+      for (int r = 0; r < TK; ++r) acc += (double)h0[(size_t)r * N + i] * hA[(size_t)r * lda + j];
+      sworst = std::max(sworst, fabs(acc - g1v[(size_t)i * TNn + j]));
+    }
+    printf("TN %d x %d over %d: glds vs round-3 max rel %.3e (NaN %zu), colsum rel %.3e, fp64 spot rel %.3e (scale %.1f)\n", TM, TNn, TK, worst / sc, nan,
+           cworst / csc, sworst / sc, sc);
+    if (nan || worst / sc > 1e-4 || cworst / csc > 1e-4 || sworst / sc > 1e-4) bad = 1;
+    std::vector<float> t_us[2];
+    for (int r = 0; r < rounds; ++r)
+      for (int v = 0; v < 2; ++v) {
+        run_tn(v);
+        CK(hipEventRecord(e0, s));
+        for (int i = 0; i < iters; ++i) run_tn(v);
+        CK(hipEventRecord(e1, s));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        t_us[v].push_back(ms * 1000.0f / iters);
+      }
+    for (int v = 0; v < 2; ++v) {
+      std::sort(t_us[v].begin(), t_us[v].end());
+      const float med = t_us[v][t_us[v].size() / 2];
+      printf("TN variant %d (%s, incl. its reduce): median %.1f us (%.1f TF/s, %.3f of 157.3)  min %.1f us\n", v, v ? "gemm_tn_glds" : "round 3", med,
+             2.0 * TM * TNn * TK / med * 1e-6, 2.0 * TM * TNn * TK / med * 1e-6 / 157.3, t_us[v][0]);
+    }
   }
   return bad;
 }
