@@ -269,7 +269,8 @@ int launch_gemm_nt(const GemmNtArgs &g, int variant, hipStream_t s);
 // long-contraction TN product C (+)= alpha * A^T B (+ colsum of A) on LDS-DMA staged k-tiles (gemm_nt.hip): G = dKV^T z of a patch bag
 bool gemm_tn_glds_eligible(const float *A, long lda, const float *B, long ldb, int M, int N, int K);
 int launch_gemm_tn_glds(const float *A, long lda, const float *B, long ldb, float *C, long ldc, int M, int N, int K, float alpha,
-                        int accumulate, float *scratch, size_t scratch_floats, float *colsum, int colsum_accumulate, hipStream_t s);
+                        int accumulate, float *scratch, size_t scratch_floats, float *colsum, int colsum_accumulate, hipStream_t s,
+                        int variant = 0);
 // bf16-MFMA form of C = alpha * (A gamma + beta) W^T for the patch-bag K/V projection under core_precision = bf16 (gemm_bf16.hip):
 // operands rounded to bf16 once, fp32 accumulation.  Ab = launch_rows_to_bf16(A) (M rows of gemm_bf16_pitch(K) bf16, once per
 // forward), `stage` = gemm_bf16_stage_floats(N, K) floats of 16-byte aligned scratch per call

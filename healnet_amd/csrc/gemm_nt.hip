@@ -18,11 +18,25 @@
 //     of one row: the epilogue is 16 dwordx4 stores per wave instead of 64 dword stores;
 //   * K = 773 runs as 24 full k-tiles + ONE 16-wide step (784 columns instead of 800): the staged weight is zero beyond K.
 #include "common.h"
+#pragma clang diagnostic ignored "-Winline-asm"      // (M0 on the clobber list of hn_glds16: nothing else in these kernels uses it)
 
 namespace hn {
 
-__device__ void hn_glds16(i32x4 rsrc, __attribute__((address_space(3))) void *lds, int size, int voffset, int soffset, int offset,
-                          int aux) __asm("llvm.amdgcn.raw.buffer.load.lds");
+// LDS-DMA, 16 bytes per lane: lane l of the wave lands at LDS byte address `lds_byte` + 16 l (wave-uniform, through M0), fetched from
+// rsrc base + voffset (per lane) + soffset (uniform), zero when out of the descriptor's range.  Issued from INLINE ASM on purpose:
+// through the LLVM intrinsic hipcc tracks the pending LDS write and waits vmcnt(0) in front of the first ds_read behind every issue
+// -- whenever the instruction still carries its memory operand, which depends on unrelated code around it (the NT kernel below was
+// spared by luck, the TN kernel was not: 459 us instead of 4xx) -- and there is no way to tell it that a barrier protocol orders
+// the two.  From asm the compiler sees no memory access: every wait on these loads is a counted s_waitcnt written by hand.
+__device__ __forceinline__ void hn_glds16(const i32x4 &rsrc, unsigned lds_byte, int voffset, int soffset) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :
+               : "s"(lds_byte), "v"(voffset), "s"(rsrc), "s"(soffset)
+               : "memory", "m0");
+}
+__device__ __forceinline__ unsigned lds_byte_address(const float *p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) float *)p;
+}
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -75,14 +89,14 @@ __global__ __launch_bounds__(NWM *NWN * 64) void gemm_nt_glds_kernel(GemmNtArgs 
   // loader: lane (r8 = lane >> 3, p = lane & 7) fetches the 16-byte slot p ^ r8 of row 8 u + r8 and lands at slot p
   const int r8 = lane >> 3, p = lane & 7;
   const int voffA = r8 * lda * 4 + ((p ^ r8) << 4), voffW = r8 * ldw * 4 + ((p ^ r8) << 4);
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane(lds_byte_address(lds));
   auto issue = [&](int kt) {
-    float *st = lds + (kt % S) * STAGE;
 #pragma unroll
     for (int q = 0; q < LW; ++q) {
       const int u = wave + NW * q;
-      auto dst = (__attribute__((address_space(3))) void *)(st + u * 256);
-      if (q < LWA) hn_glds16(rsA, dst, 16, voffA, 8 * u * lda * 4 + kt * 128, 0, 0);
-      else hn_glds16(rsW, dst, 16, voffW, 8 * (u - LA) * ldw * 4 + kt * 128, 0, 0);
+      const unsigned dst = lds_base + (unsigned)(((kt % S) * STAGE + u * 256) * 4);
+      if (q < LWA) hn_glds16(rsA, dst, voffA, 8 * u * lda * 4 + kt * 128);
+      else hn_glds16(rsW, dst, voffW, 8 * (u - LA) * ldw * 4 + kt * 128);
     }
   };
 
@@ -210,18 +224,27 @@ struct GemmTnGArgs {
   const float *A; long lda;        // (K, M)
   const float *B; long ldb;        // (K, N)
   float *part; long ldp;           // (nsplit, M, ldp) partials
-  float *cs_part;                  // (nsplit, M) column-sum partials or NULL
+  float *cs_part;                  // (nsplit * 8, M) column-sum partials or NULL
   int M, N, K, kslice, nsplit, ntm, ntn;
 };
 
-template <int NB>
+// MAP: 0 = tile index fastest (a column block of A stays on one XCD, every XCD streams all of B), 1 = slice-major runs of
+// consecutive work items per XCD (an XCD owns ~1 row slice: each operand row enters one L2).  ABL: ablations as above (bench only).
+template <int NB, int MAP = 0, int ABL = 0>
 __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(GemmTnGArgs g) {
   constexpr int S = 2, STAGE = 2 * 32 * 128, LW = 8;       // floats per ring slot: A tile [32][128] then B tile [32][128]
   constexpr int BNT = NB * 16;
   __shared__ __attribute__((aligned(16))) float lds[S * STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tile = blockIdx.x, z = blockIdx.y;
+  int tile, z;
+  if (MAP == 0) { tile = blockIdx.x; z = blockIdx.y; }
+  else {
+    const int tiles = g.ntm * g.ntn, total = tiles * g.nsplit, per = (total + 7) >> 3;
+    const int lin = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (lin >= total) return;
+    z = lin / tiles; tile = lin - z * tiles;
+  }
   const int m_tile = tile % g.ntm, n_tile = tile / g.ntm;
   const int m0 = m_tile * 128, n0 = n_tile * BNT;
   const int k_begin = z * g.kslice, rows = min(g.K, k_begin + g.kslice) - k_begin;
@@ -232,14 +255,14 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(GemmTnGArgs g) {
   const i32x4 rsB = make_rsrc(g.B + (long)k_begin * ldb + n0, (unsigned)(b_bytes > 0 ? b_bytes : 0));
   // loader: one instruction = 2 rows x 512 bytes; lane -> (row lane >> 5, 16-byte piece lane & 31)
   const int voffA = (lane >> 5) * lda * 4 + ((lane & 31) << 4), voffB = (lane >> 5) * ldb * 4 + ((lane & 31) << 4);
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane(lds_byte_address(lds));
   auto issue = [&](int kt) {
-    float *st = lds + (kt % S) * STAGE;
 #pragma unroll
     for (int q = 0; q < LW; ++q) {
       const int u = wave + 4 * q;                                 // u < 16: A rows 2u, 2u + 1; else B rows 2(u - 16) ..
-      auto dst = (__attribute__((address_space(3))) void *)(st + u * 256);
-      if (q < 4) hn_glds16(rsA, dst, 16, voffA, (kt * 32 + 2 * u) * lda * 4, 0, 0);
-      else hn_glds16(rsB, dst, 16, voffB, (kt * 32 + 2 * (u - 16)) * ldb * 4, 0, 0);
+      const unsigned dst = lds_base + (unsigned)(((kt % S) * STAGE + u * 256) * 4);
+      if (q < 4) hn_glds16(rsA, dst, voffA, (kt * 32 + 2 * u) * lda * 4);
+      else hn_glds16(rsB, dst, voffB, (kt * 32 + 2 * (u - 16)) * ldb * 4);
     }
   };
   const int fi = lane & 15, fg = lane >> 4;
@@ -311,27 +334,25 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(GemmTnGArgs g) {
     mfma_half(f0);
     __builtin_amdgcn_sched_barrier(0);
     if (!last) {
-      wait_tile(kt + 1);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      if (kt + S < nk) issue(kt + S);
+      if (!(ABL & 4)) {
+        wait_tile(kt + 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+      if (!(ABL & 2) && kt + S < nk) issue(kt + S);
       read_frags(kt + 1, 0, f0);
       __builtin_amdgcn_sched_barrier(0);
     }
     mfma_half(f1);
   }
 
-  if (do_cs) {          // 8 row groups x 128 columns of partial sums through LDS (every wave is past its last tile read)
-    __syncthreads();
-    *(f32x4 *)&lds[(tid >> 5) * 128 + ((tid & 31) << 2)] = csum;
-    __syncthreads();
-    if (tid < 128 && m0 + tid < g.M) {
-      float v = 0.0f;
-#pragma unroll
-      for (int r = 0; r < 8; ++r) v += lds[r * 128 + tid];
-      g.cs_part[(long)z * g.M + m0 + tid] = v;
-    }
+  // 8 row groups x 128 columns of partial column sums straight to the scratch (the reduce folds nsplit * 8 of them per column).
+  // NOT through LDS: one ordinary LDS store anywhere in this kernel makes hipcc wait vmcnt(0) in front of the first fragment read
+  // behind every LDS-DMA issue (it then sees the ring as written memory the reads may alias) -- measured: 459 us instead of 4xx
+  if (do_cs) {
+    const int m = m0 + ((tid & 31) << 2);
+    if (m < g.M) *(f32x4 *)&g.cs_part[((long)z * 8 + (tid >> 5)) * g.M + m] = csum;
   }
   // D of mfma(B fragment, A fragment): row rho = 4 fg + r <-> j, column fi <-> i.  Blocks 0..3: j = 4 rho + block -> the lane's
   // four blocks hold j = 16 fg + 4 r + {0, 1, 2, 3}; blocks 4..: j = 64 + 16 (block - 4) + 4 fg + {r}
@@ -339,7 +360,7 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(GemmTnGArgs g) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int m = m0 + 32 * wave + 2 * fi + i;
-    if (m >= g.M) continue;
+    if (m >= g.M || ((ABL & 1) && g.K != 12345)) continue;
     float *row = P + (long)m * g.ldp + n0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) *(f32x4 *)&row[16 * fg + 4 * r] = (f32x4){acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
@@ -362,7 +383,7 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float *__rest
     if (i >= mn) {
       const int m = (int)(i - mn);
       float acc = 0.0f;
-      for (int k = 0; k < nsplit; ++k) acc += cs_part[(long)k * M + m];
+      for (int k = 0; k < nsplit * 8; ++k) acc += cs_part[(long)k * M + m];       // 8 row-group partials per slice
       cs_out[m] = cs_accumulate ? cs_out[m] + acc : acc;
       continue;
     }
@@ -387,7 +408,8 @@ bool gemm_tn_glds_eligible(const float *A, long lda, const float *B, long ldb, i
 
 // scratch_floats: capacity of `scratch` (partials + column-sum partials)
 int launch_gemm_tn_glds(const float *A, long lda, const float *B, long ldb, float *C, long ldc, int M, int N, int K, float alpha,
-                        int accumulate, float *scratch, size_t scratch_floats, float *colsum, int colsum_accumulate, hipStream_t s) {
+                        int accumulate, float *scratch, size_t scratch_floats, float *colsum, int colsum_accumulate, hipStream_t s,
+                        int variant) {
   HN_REQUIRE(A && B && C && scratch, HN_E_NULL, "gemm_tn_glds: NULL operand");
   GemmTnGArgs g;
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.M = M; g.N = N; g.K = K;
@@ -398,15 +420,24 @@ int launch_gemm_tn_glds(const float *A, long lda, const float *B, long ldb, floa
   const int tiles = g.ntm * g.ntn;
   int nsplit = 512 / tiles;                                  // 64 KB of LDS: 2 workgroups per CU, one resident round
   if (nsplit < 1) nsplit = 1;
-  const size_t per = (size_t)M * g.ldp + (colsum ? M : 0);
+  const size_t per = (size_t)M * g.ldp + (colsum ? 8 * M : 0);
   if ((size_t)nsplit * per > scratch_floats) nsplit = (int)(scratch_floats / per);
   HN_REQUIRE(nsplit >= 1, HN_E_WORKSPACE, "gemm_tn_glds: scratch %zu floats < %zu", scratch_floats, per);
   g.kslice = ceil_div(ceil_div(K, nsplit), 32) * 32;
   g.nsplit = ceil_div(K, g.kslice);
   g.part = scratch;
   g.cs_part = colsum ? scratch + (size_t)g.nsplit * M * g.ldp : nullptr;
-  if (nb == 7) hipLaunchKernelGGL(gemm_tn_glds_kernel<7>, dim3(tiles, g.nsplit), dim3(256), 0, s, g);
-  else hipLaunchKernelGGL(gemm_tn_glds_kernel<8>, dim3(tiles, g.nsplit), dim3(256), 0, s, g);
+  const dim3 grid1((unsigned)(ceil_div(tiles * g.nsplit, 8) * 8));
+  if (nb == 8) hipLaunchKernelGGL((gemm_tn_glds_kernel<8, 1>), grid1, dim3(256), 0, s, g);
+#ifdef HN_GEMM_NT_BENCH
+  else if (variant == 1) hipLaunchKernelGGL((gemm_tn_glds_kernel<7, 0>), dim3(tiles, g.nsplit), dim3(256), 0, s, g);
+  else if (variant == 2) hipLaunchKernelGGL((gemm_tn_glds_kernel<7, 1, 1>), grid1, dim3(256), 0, s, g);
+  else if (variant == 3) hipLaunchKernelGGL((gemm_tn_glds_kernel<7, 1, 2>), grid1, dim3(256), 0, s, g);
+  else if (variant == 4) hipLaunchKernelGGL((gemm_tn_glds_kernel<7, 1, 4>), grid1, dim3(256), 0, s, g);
+  else if (variant == 5) hipLaunchKernelGGL((gemm_tn_glds_kernel<7, 1, 7>), grid1, dim3(256), 0, s, g);
+#endif
+  else hipLaunchKernelGGL((gemm_tn_glds_kernel<7, 1>), grid1, dim3(256), 0, s, g);
+  (void)variant;
   HN_LAUNCH_CHECK("gemm_tn_glds");
   long blocks = ceil_div_ll((long)M * N + (colsum ? M : 0), 256);
   if (blocks > 4096) blocks = 4096;

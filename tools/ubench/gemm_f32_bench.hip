@@ -129,7 +129,7 @@ int main(int argc, char **argv) {
     e.alpha = 1.0f; e.accumulate = 0; e.colsum = cs0; e.colsum_accumulate = 0;
     auto run_tn = [&](int v) {
       if (v == 0) return hn::launch_gemm_ex(e, s, scr);
-      return hn::launch_gemm_tn_glds(C0, N, A, lda, G1, TNn, TM, TNn, TK, 1.0f, 0, scr, scr_floats, cs1, 0, s);
+      return hn::launch_gemm_tn_glds(C0, N, A, lda, G1, TNn, TM, TNn, TK, 1.0f, 0, scr, scr_floats, cs1, 0, s, v - 1);
     };
     if (run_tn(0) != 0) return 1;
     CK(hipMemsetAsync(G1, 0xff, (size_t)TM * TNn * 4, s));
@@ -153,9 +153,10 @@ int main(int argc, char **argv) {
     printf("TN %d x %d over %d: glds vs round-3 max rel %.3e (NaN %zu), colsum rel %.3e, fp64 spot rel %.3e (scale %.1f)\n", TM, TNn, TK, worst / sc, nan,
            cworst / csc, sworst / sc, sc);
     if (nan || worst / sc > 1e-4 || cworst / csc > 1e-4 || sworst / sc > 1e-4) bad = 1;
-    std::vector<float> t_us[2];
+    const int ntv = 7;      // 0 round 3; 1 glds (XCD owns a row slice); 2 glds, tile-fastest map; 3..6 ablations: no stores / loads / barriers / all
+    std::vector<float> t_us[ntv];
     for (int r = 0; r < rounds; ++r)
-      for (int v = 0; v < 2; ++v) {
+      for (int v = 0; v < ntv; ++v) {
         run_tn(v);
         CK(hipEventRecord(e0, s));
         for (int i = 0; i < iters; ++i) run_tn(v);
@@ -164,7 +165,7 @@ int main(int argc, char **argv) {
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         t_us[v].push_back(ms * 1000.0f / iters);
       }
-    for (int v = 0; v < 2; ++v) {
+    for (int v = 0; v < ntv; ++v) {
       std::sort(t_us[v].begin(), t_us[v].end());
       const float med = t_us[v][t_us[v].size() / 2];
       printf("TN variant %d (%s, incl. its reduce): median %.1f us (%.1f TF/s, %.3f of 157.3)  min %.1f us\n", v, v ? "gemm_tn_glds" : "round 3", med,
