@@ -19,13 +19,18 @@ Rank 0 prints ONE JSON line.  Besides the driver's contract it carries
                  same K steps right after the timed region (recording events between kernels costs ~1 ms per
                  forward on this runtime, so it stays out of the region `value` comes from);
   cpu_baseline : oracle/healnet_cpu.py (the op-for-op CPU restatement of the reference) timed on this
-                 box's host cores on a bounded sample (b=4 of the same workload; 1 warm-up + median of 3 runs), rank 0 at N=1 only;
+                 box's host cores on a bounded sample (the same workload at the config's own b=32 when the host has the RAM: one timed run
+                 of ~20 s after a calibration of the thread count and a warm-up), rank 0 at N=1 only; train_step carries the oracle's
+                 cfg4 forward (b=8) the same way;
+  build_id     : hn_build_id() of the loaded library (sha256 of the sources + flags it was built from);
   staged_models: forward + backward of the reference's four tuned TCGA configurations (config/best_hyperparams.yml) at b=8, N=1 only
   patch_bag_precisions: the inference forward of BASELINE configs[3]'s shape (b=8) in fp32 and with core_precision="bf16", N=1 only
   train_step   : SURVEY.md 8(d)'s second figure -- the training step of BASELINE configs[3] (TCGA-BRCA shape: omic 1x2000 + WSI bag
                  4096x768, b=8 per GPU): forward with tape, survival NLL, fused backward, gradient all-reduce over RCCL
                  (overlapped with the backward through hn_grad_ready, healnet_amd.dist.GradReadyAllReduce) and the fused
-                 L1 + Adam step, timed after the forward region with the same barrier / max-over-ranks rule.
+                 L1 + Adam step, timed after the forward region with the same barrier / max-over-ranks rule; its `roofline` object
+                 prices the step's executed matrix FLOPs against the fp32 MFMA peak and carries the two dominant kernels (the patch
+                 bag's K/V projection and weight gradient) timed with HIP events in an instrumented replay of the same steps.
 """
 import argparse
 import ctypes
@@ -123,10 +128,40 @@ def pmc_traffic():
         return None, {"source": os.path.relpath(path, ROOT), "reason": f"unreadable: {e}"}
 
 
-def cpu_baseline(budget_s=30.0):
-    """Oracle forward on the host cores (BASELINE.md §3 protocol): the thread count is calibrated on one sample (a 256-core box
-    runs this small-GEMM / elementwise mix far slower with every core than with a few dozen), then b=4 of the same workload
-    (BASELINE.json configs[0]) runs once untimed (warm-up) and 3 times timed; the median is reported."""
+def _host_ram_gb():
+    try:
+        with open("/proc/meminfo") as f:
+            for line in f:
+                if line.startswith("MemAvailable:"):
+                    return int(line.split()[1]) / 2 ** 20
+    except OSError:
+        pass
+    return 0.0
+
+
+def _calibrate_threads(run_one, t_all, budget_s):
+    """Fastest thread count of {8, 16, 32, 64} on ONE sample (every core of a 256-core box runs this small-GEMM / elementwise mix 50x
+    slower than 32 threads -- 31.7 s per sample measured -- so counts above 64 are not tried)."""
+    ncpu = os.cpu_count() or 1
+    calib = {}
+    for threads in sorted({t for t in (8, 16, 32, 64, min(ncpu, 64)) if t <= ncpu}):
+        if time.time() - t_all > budget_s:
+            break
+        torch.set_num_threads(threads)
+        run_one()                                              # warm-up at this thread count
+        t0 = time.time()
+        run_one()
+        calib[threads] = time.time() - t0
+    best = min(calib, key=calib.get)
+    torch.set_num_threads(best)
+    return best, calib
+
+
+def cpu_baseline(budget_s=45.0):
+    """Oracle forward on the host cores (BASELINE.md §3 protocol): thread count calibrated on one sample, one untimed warm-up, then the
+    workload AT THE CONFIG'S OWN BATCH (cfg2: b = 32; the oracle materialises K/V, scores and probabilities: ~0.6 GB per sample and
+    block, so b = 32 wants ~25 GB of free host RAM -- with less, b = 4 is timed and the reason recorded).  One timed run at b = 32
+    (~20 s of CPU work; throughput is flat in b: 1.78-1.89 samples/s at b = 1..4 in the survey container)."""
     from oracle import healnet_cpu as O
     import healnet_amd
     torch.manual_seed(0)
@@ -134,43 +169,117 @@ def cpu_baseline(budget_s=30.0):
     sd = {k: v.detach() for k, v in model.state_dict().items()}
     cfg = O.FusionConfig(**KW)
     gen = torch.Generator().manual_seed(1234)
-    b = 4
+    ram = _host_ram_gb()
+    b = BATCH if ram >= 64.0 else 4
     tab, img = torch.rand(b, *TAB, generator=gen), torch.rand(b, *IMG, generator=gen)
     ncpu = os.cpu_count() or 1
     t_all = time.time()
-    calib = {}
     with torch.no_grad():
-        # (every core of a 256-core box runs this small-GEMM mix 50x slower than 32 threads -- 31.7 s per sample measured --
-        # so thread counts above 64 are not tried)
-        for threads in sorted({t for t in (8, 16, 32, 64, min(ncpu, 64)) if t <= ncpu}):
-            if time.time() - t_all > budget_s / 3:
-                break
-            torch.set_num_threads(threads)
-            O.fusion_forward(sd, cfg, [tab[:1], img[:1]])      # warm-up at this thread count
-            t0 = time.time()
-            O.fusion_forward(sd, cfg, [tab[:1], img[:1]])
-            calib[threads] = time.time() - t0
-        best_threads = min(calib, key=calib.get)
-        torch.set_num_threads(best_threads)
-        O.fusion_forward(sd, cfg, [tab, img])                  # warm-up of the timed shape
+        best_threads, calib = _calibrate_threads(lambda: O.fusion_forward(sd, cfg, [tab[:1], img[:1]]), t_all, budget_s / 4)
+        O.fusion_forward(sd, cfg, [tab[:2], img[:2]])          # warm-up (allocator, thread pool) at the chosen count
         times = []
-        for _ in range(3):
+        for _ in range(1 if b > 4 else 3):
             t0 = time.time()
             O.fusion_forward(sd, cfg, [tab, img])
             times.append(time.time() - t0)
     times.sort()
     med = times[len(times) // 2]
     return {"value": round(b / med, 3), "unit": "samples/s", "cores": best_threads, "kind": "port", "host_cores": ncpu,
+            "batch": b, "host_ram_available_gb": round(ram, 1),
             "runs_s": [round(t, 3) for t in times], "calibration_s_per_sample": {str(k): round(v, 3) for k, v in calib.items()},
-            "sample": f"oracle/healnet_cpu.py fusion_forward, b={b} of the same 2-modality workload, fp32, torch {torch.__version__} "
-                      f"CPU, 1 warm-up + median of {len(times)} runs; {best_threads} threads (fastest of {sorted(calib)} on one "
-                      f"sample) out of {ncpu} host cores"}
+            "sample": f"oracle/healnet_cpu.py fusion_forward, b={b} of the same 2-modality workload"
+                      f"{' (the config batch)' if b == BATCH else ' (host RAM below 64 GB: not the config batch of 32)'}, fp32, torch "
+                      f"{torch.__version__} CPU, 1 warm-up + {len(times)} timed run(s); {best_threads} threads (fastest of {sorted(calib)} "
+                      f"on one sample) out of {ncpu} host cores"}
+
+
+def cpu_baseline_cfg4(budget_s=20.0):
+    """The oracle's forward of BASELINE configs[3] (omic 1x2000 + WSI bag 4096x768) at the config's b = 8 on the host cores, beside
+    train_step / patch_bag_precisions: same thread calibration, 1 warm-up + median of 3."""
+    from oracle import healnet_cpu as O
+    import healnet_amd
+    torch.manual_seed(0)
+    sd = {k: v.detach() for k, v in healnet_amd.HealNet(**TRAIN_KW).state_dict().items()}
+    cfg = O.FusionConfig(**TRAIN_KW)
+    gen = torch.Generator().manual_seed(4321)
+    ins = [torch.rand(TRAIN_BATCH, *s, generator=gen) for s in TRAIN_SHAPES]
+    t_all = time.time()
+    with torch.no_grad():
+        best_threads, calib = _calibrate_threads(lambda: O.fusion_forward(sd, cfg, [t[:1].clone() for t in ins]), t_all, budget_s / 3)
+        O.fusion_forward(sd, cfg, [t.clone() for t in ins])
+        times = []
+        for _ in range(3):
+            t0 = time.time()
+            O.fusion_forward(sd, cfg, [t.clone() for t in ins])
+            times.append(time.time() - t0)
+    times.sort()
+    med = times[1]
+    return {"value": round(TRAIN_BATCH / med, 3), "unit": "samples/s (forward)", "cores": best_threads, "kind": "port", "batch": TRAIN_BATCH,
+            "runs_s": [round(t, 3) for t in times], "calibration_s_per_sample": {str(k): round(v, 3) for k, v in calib.items()},
+            "sample": f"oracle/healnet_cpu.py fusion_forward of cfg4 at b={TRAIN_BATCH}, fp32, no_grad, 1 warm-up + median of 3; {best_threads} threads"}
 
 
 # BASELINE.json configs[3]: TCGA-BRCA-shaped training step, per-GPU batch 8
 TRAIN_KW = dict(n_modalities=2, channel_dims=[2000, 768], num_spatial_axes=[1, 1], out_dims=4)
 TRAIN_SHAPES = [(1, 2000), (4096, 768)]
 TRAIN_BATCH = 8
+
+
+def exec_flops_train_step_per_sample(depth=3, l_c=128, l_d=128, heads=8, dh=64, n_bag=4096, d_bag=773, d_omic=2005):
+    """EXECUTED matrix FLOPs of one cfg4 training step per sample (forward with tape + backward; real dimensions, no tile padding).
+    Per layer (healnet.py:225-245): omic one-token block + FF, latent self block + FF, bag cross block + FF, latent self block + FF.
+    Backward of a Linear = 2x its forward (dX and dW) except the bag K/V projection (the context carries no gradient: dW only);
+    attention cores: dQ kernel 6 l_c N dh h (recomputes S and dP), dK/dV kernel 8 l_c N dh h; the fused feed-forward backward
+    recomputes its first layer.  58.0 GF per sample; the two patch-bag GEMMs (K/V projection, G = dKV^T z) are 38.9 GF of it."""
+    inner = heads * dh
+    ff1, ff2 = 2.0 * l_c * l_d * 8 * l_d, 2.0 * l_c * 4 * l_d * l_d
+    ff_f, ff_b = ff1 + ff2, 2 * (ff1 + ff2) + ff1
+    q_proj, out_proj = 2.0 * l_c * l_d * inner, 2.0 * l_c * inner * l_d
+    kv_bag = 2.0 * n_bag * d_bag * 2 * inner
+    core_f = lambda n: 4.0 * l_c * n * dh * heads           # noqa: E731
+    core_b = lambda n: 14.0 * l_c * n * dh * heads          # noqa: E731
+    bag_f = q_proj + kv_bag + core_f(n_bag) + out_proj + ff_f
+    bag_b = 2 * q_proj + kv_bag + core_b(n_bag) + 2 * out_proj + ff_b
+    self_f = 3 * q_proj + core_f(l_c) + out_proj + ff_f
+    self_b = 6 * q_proj + core_b(l_c) + 2 * out_proj + ff_b
+    omic_f = 2.0 * d_omic * inner + 2.0 * inner * l_d + ff_f          # one-token shortcut: V projection + out-projection on one row
+    omic_b = 2 * (2.0 * d_omic * inner + 2.0 * inner * l_d) + ff_b
+    fwd = depth * (bag_f + omic_f + 2 * self_f)
+    bwd = depth * (bag_b + omic_b + 2 * self_b)
+    return fwd, bwd, depth * 2 * kv_bag
+
+
+class KernelTimers:
+    """hn_set_kernel_timers (include/healnet_hip.h): hipEvent pairs around every launch of the named kernel classes, recorded on the
+    launch stream inside the training forward / backward."""
+
+    def __init__(self, names, per_name):
+        from healnet_amd import _capi
+        self.lib = _capi.lib()
+        self.names = names
+        self.events = [HipEvents(per_name) for _ in names]
+        self.table = (_capi.KernelTimer * len(names))()
+        for i, (name, ev) in enumerate(zip(names, self.events)):
+            self.table[i].kernel = name.encode()
+            self.table[i].ev_start = ctypes.cast(ev.start, ctypes.POINTER(ctypes.c_void_p))
+            self.table[i].ev_stop = ctypes.cast(ev.stop, ctypes.POINTER(ctypes.c_void_p))
+            self.table[i].n_events = per_name
+            self.table[i].n_recorded = 0
+
+    def __enter__(self):
+        assert self.lib.hn_set_kernel_timers(self.table, len(self.names)) == 0
+        return self
+
+    def __exit__(self, *exc):
+        self.lib.hn_set_kernel_timers(None, 0)
+
+    def averages_ms(self):
+        out = {}
+        for i, name in enumerate(self.names):
+            n = min(int(self.table[i].n_recorded), int(self.table[i].n_events))
+            ms = self.events[i].elapsed_ms(n)
+            out[name] = (sum(ms) / len(ms) if ms else None, len(ms))
+        return out
 
 
 def train_step_record(dev, rank, world, distributed, barrier, steps, warmup):
@@ -235,6 +344,39 @@ def train_step_record(dev, rank, world, distributed, barrier, steps, warmup):
             hdist.allreduce_mean_([flat.grads])
         barrier()
         rec["allreduce_alone_ms"] = round((time.perf_counter() - t0) / 10 * 1e3, 4)
+    # ---- roofline of the step: instrumented replay of the same K steps (hipEvent pairs around every launch of the two patch-bag
+    # GEMMs -- half of the step's executed FLOPs -- recorded on the launch stream inside the training forward / backward)
+    fwd_f, bwd_f, gemm_f = exec_flops_train_step_per_sample()
+    per_launch = 2.0 * (b * TRAIN_SHAPES[1][0]) * (TRAIN_SHAPES[1][1] + 5) * 1024        # 2 M K N of either GEMM (D = 768 + 5)
+    with KernelTimers(["gemm_nt_glds", "gemm_tn_glds"], 3 * steps + 8) as kt:
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(True)
+        barrier()
+        dt_instr = time.perf_counter() - t0
+    avg = kt.averages_ms()
+    step_s = dt / steps
+    roof = {"bound": "mfma", "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "flops_executed_per_step": (fwd_f + bwd_f) * b,
+            "achieved": round((fwd_f + bwd_f) * b / step_s / 1e12, 2),
+            "frac": round((fwd_f + bwd_f) * b / step_s / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+            "forward_flops": fwd_f * b, "backward_flops": bwd_f * b,
+            "dominant_kernels": {}, "instrumented_ms_per_step": round(dt_instr / steps * 1e3, 4),
+            "timing": "hipEvent pairs on the launch stream around every launch of the two kernels (hn_set_kernel_timers), in an "
+                      "instrumented replay of the same K steps right after the timed region",
+            "note": "frac = executed matrix FLOPs of the whole step (forward with tape + backward: exec_flops_train_step_per_sample, "
+                    "real dimensions) / driver-timed step / fp32 MFMA peak; the survival loss, L1 + Adam sweep, LayerNorm / softmax "
+                    "vector work and the all-reduce are time without matrix FLOPs"}
+    for name, what in (("gemm_nt_glds", "hn::gemm_nt_glds_kernel (bag K/V projection, forward)"),
+                       ("gemm_tn_glds", "hn::gemm_tn_glds_kernel (bag weight gradient G = dKV^T z, backward)")):
+        ms, n = avg[name]
+        roof["dominant_kernels"][name] = {
+            "kernel": what, "launches_timed": n, "launches_per_step": 3, "flops_per_launch": per_launch,
+            "avg_launch_ms": None if ms is None else round(ms, 4),
+            "achieved": None if not ms else round(per_launch / (ms * 1e-3) / 1e12, 2),
+            "frac": None if not ms else round(per_launch / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
+    rec["roofline"] = roof
     # forward (tape-recording) share of the step
     with torch.enable_grad():
         barrier()
@@ -495,7 +637,10 @@ def main():
         torch.cuda.empty_cache()
         train_rec = train_step_record(dev, rank, world, distributed, barrier, args.train_steps, 5)
     if rank == 0:
+        result["build_id"] = _capi.lib().hn_build_id().decode()
         if train_rec is not None:
+            if world == 1 and not args.no_cpu_baseline:
+                train_rec["cpu_baseline_forward"] = cpu_baseline_cfg4()
             result["train_step"] = train_rec
         if world == 1 and not args.no_staged_models:
             result["staged_models"] = staged_models_record(dev)

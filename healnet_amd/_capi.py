@@ -89,6 +89,11 @@ class Profile(C.Structure):
                 ("n_events", C.c_int), ("n_recorded", C.c_int)]
 
 
+class KernelTimer(C.Structure):
+    _fields_ = [("kernel", C.c_char_p), ("ev_start", C.POINTER(C.c_void_p)), ("ev_stop", C.POINTER(C.c_void_p)),
+                ("n_events", C.c_int), ("n_recorded", C.c_int)]
+
+
 READY_FN = C.CFUNCTYPE(None, C.c_int, C.c_void_p)
 
 
@@ -100,6 +105,7 @@ class GradReady(C.Structure):
 SIGNATURES = {
     "hn_abi_version": (C.c_int, []),
     "hn_build_id": (C.c_char_p, []),
+    "hn_set_kernel_timers": (C.c_int, [C.POINTER(KernelTimer), C.c_int]),
     "hn_last_error_string": (C.c_char_p, []),
     "hn_fourier_encode_concat": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_float,
                                            C.c_int, C.c_void_p, C.c_int, C.c_void_p]),

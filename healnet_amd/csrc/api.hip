@@ -27,6 +27,27 @@ int fail(int code, const char *fmt, ...) {
   return code;
 }
 
+// process-wide on purpose: a training step launches its forward from the caller's thread and its backward from the autograd
+// engine's device thread, and one table has to see both.  Slots are claimed with an atomic increment.
+static hn_kernel_timer *volatile g_timers = nullptr;
+static volatile int g_ntimers = 0;
+KernelTimerScope::KernelTimerScope(const char *kernel, hipStream_t stream) : stop(nullptr), s(stream) {
+  hn_kernel_timer *tab = g_timers;
+  const int n = g_ntimers;
+  if (tab == nullptr) return;
+  for (int i = 0; i < n; ++i) {
+    hn_kernel_timer &t = tab[i];
+    if (t.kernel && strcmp(t.kernel, kernel) == 0) {
+      const int slot = __atomic_fetch_add(&t.n_recorded, 1, __ATOMIC_RELAXED);
+      if (slot < t.n_events) {
+        (void)hipEventRecord((hipEvent_t)t.ev_start[slot], stream);
+        stop = (hipEvent_t)t.ev_stop[slot];
+      }
+      return;
+    }
+  }
+}
+
 static inline DropCfg drop_off() { return make_drop(0.0f, 0, 0, 0); }
 static inline DropCfg drop_of(float p, const hn_rng &r, bool ff) {
   return p > 0.0f ? make_drop(p, r.seed, r.offset, ff ? (r.stream | DROP_SID_FF) : (r.stream & ~DROP_SID_FF)) : drop_off();
@@ -1317,6 +1338,13 @@ using namespace hn;
 extern "C" {
 
 int hn_abi_version(void) { return HN_ABI_VERSION; }
+int hn_set_kernel_timers(hn_kernel_timer *timers, int n) {
+  if (n < 0 || (n > 0 && timers == nullptr)) return fail(HN_E_SHAPE, "hn_set_kernel_timers: n=%d", n);
+  g_ntimers = 0;
+  g_timers = n > 0 ? timers : nullptr;
+  g_ntimers = n > 0 ? n : 0;
+  return HN_OK;
+}
 #ifndef HN_BUILD_ID
 #define HN_BUILD_ID "unstamped"
 #endif

@@ -16,6 +16,14 @@ void debug_after_launch(hipStream_t s);
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// hn_set_kernel_timers (api.hip): brackets the launches of a named kernel class with the caller's event pairs
+struct KernelTimerScope {
+  hipEvent_t stop;
+  hipStream_t s;
+  KernelTimerScope(const char *kernel, hipStream_t stream);
+  ~KernelTimerScope() { if (stop) (void)hipEventRecord(stop, s); }
+};
+
 // thread-local error string behind hn_last_error_string()
 void set_error(const char *fmt, ...);
 int fail(int code, const char *fmt, ...);

@@ -146,13 +146,17 @@ __global__ __launch_bounds__(NWM *NWN * 64) void gemm_nt_glds_kernel(GemmNtArgs 
   // The barrier sits in the MIDDLE of a k-tile: when a wave arrives it has read both fragment sets of tile kt (slot kt % S is free
   // for the loads of tile kt + S) and its own share of tile kt + 1 has landed; behind it the first fragments of tile kt + 1 are
   // requested under the second half of tile kt's MFMAs -- no LDS round trip is exposed behind a barrier.
-  auto wait_tile = [&](int kt) {                                   // own loads of tile kt done: at most the tiles behind it outstanding
-    const int ahead = min(S - 1, nk - 1 - kt);
-    if (S >= 3 && ahead == 2) wait_vmcnt<2 * LW>();
-    else if (S >= 2 && ahead >= 1) wait_vmcnt<LW>();
+  // Counted waits.  Loads retire in order, so "this wave's share of tile t has landed" == "at most the loads of the tiles issued
+  // behind t are outstanding".  In front of the first barrier tiles 0 .. S-1 are issued (tile 0 needed: up to S-1 tiles may stay in
+  // flight); at the mid-tile barrier of tile kt tiles .. kt+S-1 are issued and tile kt+1 is needed: up to S-2 tiles (none with two
+  // slots: a tile's loads then have exactly one tile time -- ~2 us of MFMAs -- to land).
+  auto wait_outstanding = [&](int tiles) {
+    if (S >= 3 && tiles >= 2) wait_vmcnt<2 * LW>();
+    else if (S >= 2 && tiles == 1) wait_vmcnt<LW>();
     else wait_vmcnt<0>();
   };
-  wait_tile(0);
+  auto wait_tile = [&](int kt) { wait_outstanding(min(S - 2, nk - 1 - kt)); };
+  wait_outstanding(min(S - 1, nk - 1));
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   Frags f0, f1;
@@ -311,12 +315,11 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(GemmTnGArgs g) {
   const int nk = (rows + 31) >> 5;
   if (nk > 0) issue(0);
   if (nk > 1) issue(1);
-  auto wait_tile = [&](int kt) {
-    if (kt + 1 < nk) wait_vmcnt<LW>(); else wait_vmcnt<0>();
-  };
+  // two slots: the tile needed at a mid-tile barrier is the only one in flight (see gemm_nt_glds_kernel)
+  auto wait_tile = [&](int) { wait_vmcnt<0>(); };
   Frags f0, f1;
   if (nk > 0) {
-    wait_tile(0);
+    if (nk > 1) wait_vmcnt<LW>(); else wait_vmcnt<0>();            // tile 0 landed, tile 1 may be in flight
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     read_frags(0, 0, f0);
@@ -428,6 +431,8 @@ int launch_gemm_tn_glds(const float *A, long lda, const float *B, long ldb, floa
   g.part = scratch;
   g.cs_part = colsum ? scratch + (size_t)g.nsplit * M * g.ldp : nullptr;
   const dim3 grid1((unsigned)(ceil_div(tiles * g.nsplit, 8) * 8));
+  {
+  KernelTimerScope timer("gemm_tn_glds", s);
   if (nb == 8) hipLaunchKernelGGL((gemm_tn_glds_kernel<8, 1>), grid1, dim3(256), 0, s, g);
 #ifdef HN_GEMM_NT_BENCH
   else if (variant == 1) hipLaunchKernelGGL((gemm_tn_glds_kernel<7, 0>), dim3(tiles, g.nsplit), dim3(256), 0, s, g);
@@ -438,6 +443,7 @@ int launch_gemm_tn_glds(const float *A, long lda, const float *B, long ldb, floa
 #endif
   else hipLaunchKernelGGL((gemm_tn_glds_kernel<7, 1>), grid1, dim3(256), 0, s, g);
   (void)variant;
+  }
   HN_LAUNCH_CHECK("gemm_tn_glds");
   long blocks = ceil_div_ll((long)M * N + (colsum ? M : 0), 256);
   if (blocks > 4096) blocks = 4096;
@@ -466,6 +472,7 @@ int launch_gemm_nt(const GemmNtArgs &g_in, int variant, hipStream_t s) {
   g.ntm = ceil_div(g.M, bm); g.ntn = ceil_div(g.N, bn);
   const long blocks = (long)ceil_div(g.ntm, 8) * 8 * g.ntn;
   HN_REQUIRE(blocks < (1L << 31), HN_E_UNSUPPORTED, "gemm_nt: grid too large");
+  KernelTimerScope timer("gemm_nt_glds", s);
   switch (variant) {
     case 0: hipLaunchKernelGGL((gemm_nt_glds_kernel<4, 4, 2, 2, 2>), dim3((unsigned)blocks), dim3(256), 0, s, g); break;
 #ifdef HN_GEMM_NT_BENCH

@@ -296,6 +296,22 @@ typedef struct hn_profile {
   int n_recorded;
 } hn_profile;
 
+/* Measurement hook for kernels launched from inside other entry points (the training forward / backward): while a table is set,
+ * every launch of a kernel class named in it is bracketed by the next unused hipEvent pair of that entry, recorded on the launch
+ * stream (n_recorded counts the launches seen, also beyond n_events).  Classes: "gemm_nt_glds" (patch-bag K/V projection),
+ * "gemm_tn_glds" (patch-bag weight gradient G = dKV^T z).  The table and the event arrays belong to the caller and must stay valid
+ * until hn_set_kernel_timers(NULL, 0) clears them.  PROCESS-WIDE (a training step's backward is launched from the autograd engine's
+ * thread, not the caller's): a measurement aid for one step loop at a time, not a facility for concurrent callers.  bench.py's
+ * train_step.roofline is read through it. */
+typedef struct hn_kernel_timer {
+  const char *kernel;
+  void **ev_start;
+  void **ev_stop;
+  int n_events;
+  int n_recorded;
+} hn_kernel_timer;
+int hn_set_kernel_timers(hn_kernel_timer *timers, int n);
+
 /* out: (b, out_dims) logits, or (b, l_c, l_d) when return_embeddings != 0 or the model has no head.
  * skip_self_on_missing reproduces the reference's verbose=True quirk (:229-232): bit i set -> when modality i is
  * missing, that iteration's latent self block is skipped as well (the `continue` under `if verbose`).  The reference

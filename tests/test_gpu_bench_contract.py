@@ -33,6 +33,14 @@ def test_bench_prints_one_contract_line():
     assert t["batch_per_gpu"] == 8 and t["world_size"] == 1 and t["unit"] == "samples/s" and t["steps"] == 3
     assert abs(t["value"] - 8 * 1000.0 / t["ms_per_step"]) <= 1e-3 * t["value"] and t["final_loss"] == t["final_loss"]
     assert sum(t["allreduce_buckets_floats"]) == t["gradient_floats"]
+    tr = t["roofline"]                                    # the step on the fp32 MFMA roof + its two dominant kernels, timed in the same run
+    assert tr["bound"] == "mfma" and tr["peak"] == 157.3 and 0.2 < tr["frac"] <= 1.0
+    assert abs(tr["frac"] - tr["flops_executed_per_step"] / (t["ms_per_step"] * 1e-3) / 1e12 / 157.3) < 2e-3
+    for name in ("gemm_nt_glds", "gemm_tn_glds"):
+        k = tr["dominant_kernels"][name]
+        assert k["launches_timed"] == 3 * t["steps"] and 0.5 < k["frac"] <= 1.0, (name, k)
+        assert abs(k["frac"] - k["flops_per_launch"] / (k["avg_launch_ms"] * 1e-3) / 1e12 / 157.3) < 2e-3
+    assert len(j["build_id"]) == 16
     sm = j["staged_models"]                               # the reference's tuned TCGA shapes, run as zero-padded images
     assert set(sm["configs"]) == {"blca", "brca", "kirp", "ucec"} and sm["unit"] == "ms"
     assert all(c["staged"] and 0.1 < c["fwd_bwd_ms"] < 50.0 for c in sm["configs"].values())

@@ -10,9 +10,11 @@
 #include <algorithm>
 #include <random>
 #include <string>
+#include <string.h>
 
 namespace hn {
 void debug_after_launch(hipStream_t) {}
+KernelTimerScope::KernelTimerScope(const char *, hipStream_t stream) : stop(nullptr), s(stream) {}
 void set_error(const char *, ...) {}
 int fail(int code, const char *fmt, ...) {
   va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr);
@@ -23,6 +25,7 @@ int fail(int code, const char *fmt, ...) {
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 int main(int argc, char **argv) {
+  setenv("HN_NO_GLDS_GEMM", "1", 1);      // hn::launch_gemm_ex below = the round-3 route (gemm_tn_lds_kernel)
   const int M = argc > 1 ? atoi(argv[1]) : 32768, N = argc > 2 ? atoi(argv[2]) : 1024, K = argc > 3 ? atoi(argv[3]) : 773;
   const int rounds = argc > 4 ? atoi(argv[4]) : 5, iters = 10;
   const int lda = (K + 3) / 4 * 4, ldws = hn::gemm_nt_ldws(K);
@@ -91,6 +94,18 @@ int main(int argc, char **argv) {
       if (!(h1[i] == h1[i])) { ++nan; continue; }
       worst = std::max(worst, (double)fabsf(h1[i] - h0[i]));
     }
+    size_t flips = 0;
+    if (ids[v] < 10) {
+      std::vector<float> h2(h1.size());
+      for (int rep = 0; rep < 4; ++rep) {
+        CK(hipMemsetAsync(C1, 0xff, (size_t)M * N * 4, s));
+        run(0); run(v);                          // (another kernel in between: different L2 / clock state)
+        CK(hipStreamSynchronize(s));
+        CK(hipMemcpy(h2.data(), C1, h2.size() * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < h1.size(); ++i) flips += memcmp(&h1[i], &h2[i], 4) != 0;
+      }
+      if (flips) { printf("variant %d: %zu elements differ between repeated runs (RACE)\n", v, flips); bad = 1; }
+    }
     const double sp = spot(h1);
     printf("variant %d (gemm_nt %d): vs gemm_big max rel %.3e, NaN %zu, fp64 spot rel err %.3e\n", v, ids[v], worst / ref_scale, nan, sp);
     if (ids[v] < 10 && (nan || worst / ref_scale > 1e-4 || sp > 1e-5)) bad = 1;
@@ -149,6 +164,19 @@ int main(int argc, char **argv) {
       double acc = 0;
       for (int r = 0; r < TK; ++r) acc += (double)h0[(size_t)r * N + i] * hA[(size_t)r * lda + j];
       sworst = std::max(sworst, fabs(acc - g1v[(size_t)i * TNn + j]));
+    }
+    {
+      std::vector<float> g2(g1v.size());
+      size_t flips = 0;
+      for (int rep = 0; rep < 6; ++rep) {
+        CK(hipMemsetAsync(G1, 0xff, (size_t)TM * TNn * 4, s));
+        run(rep % 3); run_tn(1);
+        CK(hipStreamSynchronize(s));
+        CK(hipMemcpy(g2.data(), G1, g2.size() * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < g2.size(); ++i) flips += memcmp(&g1v[i], &g2[i], 4) != 0;
+      }
+      printf("TN glds: %zu elements differ over 6 repeated runs%s\n", flips, flips ? " (RACE)" : "");
+      if (flips) bad = 1;
     }
     printf("TN %d x %d over %d: glds vs round-3 max rel %.3e (NaN %zu), colsum rel %.3e, fp64 spot rel %.3e (scale %.1f)\n", TM, TNn, TK, worst / sc, nan,
            cworst / csc, sworst / sc, sc);
