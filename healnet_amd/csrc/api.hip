@@ -127,7 +127,7 @@ static int plan_attn(const hn_attn_params *p, bool has_ctx, int ld_ctx, int b, i
   if (pl->bf16core) {
     // the plain dp = 16 bf16 core holds 161 VGPRs = 3 resident waves per SIMD: size the split for 3 (a split sized for 4 runs
     // a second, mostly idle round).  The larger variants measured faster with the default split (cfg3: 7.6 vs 11.2 ms).
-    static const int w16 = getenv("HN_BF16_WAVES16") ? atoi(getenv("HN_BF16_WAVES16")) : 3;      // development knob
+    static const int w16 = tuning_env("HN_BF16_WAVES16") ? atoi(tuning_env("HN_BF16_WAVES16")) : 3;      // development knob
     if (pl->dp == 16 && bf16core == 1) attn_core_geometry(b, p->heads, pl->Lp, pl->N, pl->dp, &pl->nsplit, &pl->chunk, w16);
     pl->chunk = (pl->chunk + 31) / 32 * 32;
     pl->nsplit = (pl->N + pl->chunk - 1) / pl->chunk;
@@ -426,7 +426,7 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
       // 2048} x {2, 4 query tiles per wave} at cfg4 / cfg5 picked 512 -- 1024 (0.78 / 5.64 ms against 0.80 / 5.87 with the fp32 core's split)
       ca.chunk = (pl.chunk + 31) / 32 * 32;
       if (ca.chunk < 512) ca.chunk = 512;
-      static const int chunk_knob = getenv("HN_BF16_EXPL_CHUNK") ? atoi(getenv("HN_BF16_EXPL_CHUNK")) : 0;      // development knob: coarser splits
+      static const int chunk_knob = tuning_env("HN_BF16_EXPL_CHUNK") ? atoi(tuning_env("HN_BF16_EXPL_CHUNK")) : 0;      // development knob: coarser splits
       if (chunk_knob > ca.chunk) ca.chunk = (chunk_knob + 31) / 32 * 32;
       ca.nsplit = (pl.N + ca.chunk - 1) / ca.chunk;
       ca.ns = 1; ca.expl = 1; ca.k_pitch = pl.inner * 2;

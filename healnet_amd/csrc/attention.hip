@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256) void attn_core_kernel(AttnCoreArgs a, int ngro
 static int nq_dt1() {
   static int v = -1;
   if (v < 0) {
-    const char *e = getenv("HN_CORE_NQ");
+    const char *e = tuning_env("HN_CORE_NQ");
     v = e ? atoi(e) : 4;
     if (v != 2 && v != 4 && v != 8) v = 4;
   }
@@ -401,7 +401,7 @@ static int nq_for(int dt) { return dt == 1 ? nq_dt1() : (dt == 2 ? 2 : (dt == 4 
 // from 12 splits or fewer, which the chain behind the block merges itself.  0 = keep the default.
 static int sb_env(const char *name) { const char *e = getenv(name); return e ? atoi(e) : 0; }
 int attn_core_nq_small_batch(int dp, int b, int h, int Lp) {
-  static const bool off = getenv("HN_CORE_NQ") != nullptr || getenv("HN_NO_SMALL_BATCH_GEOMETRY") != nullptr;
+  static const bool off = tuning_env("HN_CORE_NQ") != nullptr || getenv("HN_NO_SMALL_BATCH_GEOMETRY") != nullptr;
   static const int force_nq = sb_env("HN_SB_NQ");       // development knobs: fixed tiles per wave / split cap of the small-batch plan
   if (off || dp != 16) return 0;
   if (force_nq > 0) return force_nq;
@@ -423,10 +423,10 @@ void attn_core_geometry(int b, int h, int Lp, int N, int dp, int *nsplit, int *c
   const int dt = dp / 16;
   const int ngroups = ceil_div(Lp / 16, nq > 0 ? nq : nq_for(dt));
   static long target_waves = 0;   // development knob HN_CORE_WAVES: resident waves the token split aims for
-  if (target_waves == 0) { const char *e = getenv("HN_CORE_WAVES"); target_waves = e ? atol(e) : 256L * 4 * 4; if (target_waves < 64) target_waves = 4096; }
+  if (target_waves == 0) { const char *e = tuning_env("HN_CORE_WAVES"); target_waves = e ? atol(e) : 256L * 4 * 4; if (target_waves < 64) target_waves = 4096; }
   const long tw = waves_per_simd > 0 ? 256L * 4 * waves_per_simd : target_waves;
   static int geom_floor = -1;      // development knob HN_GEOM_CEIL=1: the old rounding
-  if (geom_floor < 0) { const char *e = getenv("HN_GEOM_CEIL"); geom_floor = (e && e[0] == '1') ? 0 : 1; }
+  if (geom_floor < 0) { const char *e = tuning_env("HN_GEOM_CEIL"); geom_floor = (e && e[0] == '1') ? 0 : 1; }
   // floor: all waves resident in ONE round (a ceil that overshoots the slots by a few waves costs a whole second round)
   long want = geom_floor ? tw / ((long)b * h * ngroups) : ceil_div_ll(tw, (long)b * h * ngroups);
   long max_splits = N / 128;

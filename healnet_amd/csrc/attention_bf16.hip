@@ -363,7 +363,7 @@ int launch_attn_core_bf16(const AttnCoreBf16Args &a, hipStream_t s) {
                "attn_core_bf16 (explicit binding): Lp=%d chunk=%d N=%d", a.Lp, a.chunk, a.N);
     // query tiles per wave: 2 (180 VGPRs, two waves per SIMD; the 4 query groups of a (sample, head) each stream its K / V tiles) or
     // 4 (279 VGPRs, one wave per SIMD, half the K / V traffic): HN_BF16_EXPL_NQ, development knob
-    static const int nqe = getenv("HN_BF16_EXPL_NQ") ? atoi(getenv("HN_BF16_EXPL_NQ")) : 2;
+    static const int nqe = tuning_env("HN_BF16_EXPL_NQ") ? atoi(tuning_env("HN_BF16_EXPL_NQ")) : 2;
     const int NQE = nqe == 4 ? 4 : 2;
     const int ngroups = ceil_div(a.Lp / 16, NQE);
     const int wpb = ngroups < 4 ? ngroups : 4;

@@ -14,6 +14,8 @@
 //   attn_bwd_dkv_kernel  token-parallel (explicit K/V only): a wave owns one 16-token tile, walks all query tiles
 //                        and keeps dK / dV of its tokens in registers: no cross-wave reduction, deterministic.
 #include "common.h"
+#include <stdlib.h>
+#pragma clang diagnostic ignored "-Winline-asm"
 
 namespace hn {
 
@@ -407,11 +409,182 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs a, int nt
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// dK, dV with the query side in LDS (dp = 64, L * 64 floats x 2 <= 64 KB: the patch-bag cross block and the latent self block of the
+// default model).  The kernel above re-fetches Q and dO of its (sample, head) from L2 for every 16-token tile -- 44 fragment-shaped
+// loads (16 rows x 64 B each) per 64 MFMAs, the pattern that runs at a third of the full-line rate -- and sits at 0.49
+// of the fp32 MFMA peak at cfg4 (225 us).  Here a workgroup lands Q and dO ONCE by LDS-DMA in full 256-byte rows (8 KB per 16-row
+// query tile, requested up front in tile order, consumed behind counted waits + one barrier per query tile) and its four waves own
+// TWO token tiles each, so one set of fragment reads feeds 128 MFMAs.
+//   LDS image: row r of Q / dO is 16 slots of 16 bytes, slot c stored at c ^ sw(r & 15), sw(x) = ((x & 3) << 2) | (x >> 2).  With
+//   the S / dP contraction ordered k = 16 g + 4 s + e (lane group g reads slot 4 g + s) both access patterns are conflict-free:
+//   the A fragments (16 rows, slots 4 g + s) and the B fragments of dK += dS^T Q / dV += P^T dO (rows 4 g + r, ALL 16 slots: lane j
+//   takes slot j, i.e. columns 4 j .. 4 j + 3 -- MFMA e of a quad then produces the output columns {4 j + e}, and a lane ends up with
+//   four CONSECUTIVE columns of its token rows: float4 stores).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void dkv_glds16(const i32x4 &rsrc, unsigned lds_byte, int voffset, int soffset) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :
+               : "s"(lds_byte), "v"(voffset), "s"(rsrc), "s"(soffset)
+               : "memory", "m0");
+}
+template <int N> __device__ __forceinline__ void dkv_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int TPW>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_lds_kernel(AttnBwdArgs a, int ntiles, int dh, int inner) {
+  constexpr int DT = 4, DP = 64, MAXL = 128;
+  __shared__ __attribute__((aligned(16))) float lds[2 * MAXL * DP];          // Q image, then dO image
+  const int L = a.Lq, nq = (L + 15) >> 4;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, j = lane & 15;
+  const int bh = blockIdx.y, bi = bh / a.h, hi = bh % a.h;
+  const int tile0 = (blockIdx.x * 4 + wave) * TPW;
+
+  const i32x4 rsQ = make_rsrc(a.Q + (long)bi * a.q_b + (long)hi * a.q_h, rsrc_bytes(L, a.ldq, DP));
+  const i32x4 rsG = make_rsrc(a.dO + (long)bi * a.do_b + (long)hi * a.do_h, rsrc_bytes(L, a.lddo, DP));
+  const i32x4 krs = make_rsrc(a.Kp + (long)bi * a.k_b + (long)hi * a.k_h, rsrc_bytes(a.N, a.ldk, DP));
+  const i32x4 vrs = make_rsrc(a.Vp + (long)bi * a.v_b + (long)hi * a.v_h, rsrc_bytes(a.N, a.ldv, DP));
+
+  // ---- request the whole query side: per 16-row tile 4 + 4 one-KB pieces (4 rows each), wave w takes piece w of Q and of dO.
+  // Lane (r4 = lane >> 4, p = lane & 15) fetches slot p ^ sw(row & 15) of row 16 t + 4 w + r4 and lands at slot p.
+  {
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(const __attribute__((address_space(3))) float *)lds);
+    const int r4 = lane >> 4, p = lane & 15, rl = 4 * wave + r4;             // row within the tile
+    const int sw = ((rl & 3) << 2) | (rl >> 2);
+    const int voq = (rl * a.ldq + ((p ^ sw) << 2)) * 4, vog = (rl * a.lddo + ((p ^ sw) << 2)) * 4;
+    for (int t = 0; t < nq; ++t) {
+      const unsigned dst = lds_base + (unsigned)((t * 16 + 4 * wave) * DP * 4);
+      dkv_glds16(rsQ, dst, voq, t * 16 * a.ldq * 4);
+      dkv_glds16(rsG, dst + MAXL * DP * 4, vog, t * 16 * a.lddo * 4);
+    }
+  }
+
+  // token side: B operands of S / dP, lane (g, j = token) holds K[t][16 g + 4 s ..] (the contraction order of the header)
+  float4 kf[TPW][DT], vf[TPW][DT];
+  float live[TPW];
+#pragma unroll
+  for (int u = 0; u < TPW; ++u) {
+    const int t0 = (tile0 + u) * 16;
+#pragma unroll
+    for (int s = 0; s < DT; ++s) {
+      kf[u][s] = buf4(krs, ((t0 + j) * a.ldk + 16 * g + 4 * s) * 4);
+      vf[u][s] = buf4(vrs, ((t0 + j) * a.ldv + 16 * g + 4 * s) * 4);
+    }
+    live[u] = (t0 + j) < a.N ? 1.0f : 0.0f;
+    if (a.mask) live[u] *= a.mask[(long)bi * a.N + min(t0 + j, a.N - 1)] ? 1.0f : 0.0f;
+  }
+  f32x4 dK[TPW][DT], dV[TPW][DT];
+#pragma unroll
+  for (int u = 0; u < TPW; ++u)
+#pragma unroll
+    for (int d = 0; d < DT; ++d) { dK[u][d] = (f32x4){0.f, 0.f, 0.f, 0.f}; dV[u][d] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+  const i32x4 rsS = make_rsrc(a.stats + (long)bh * L * 2, (unsigned)L * 8u);
+  const i32x4 rsD = make_rsrc(a.delta + (long)bh * L, (unsigned)L * 4u);
+  const int swj = ((j & 3) << 2) | (j >> 2);
+  // row statistics of query tile 0 (rows 4 g + r); those of tile t + 1 are requested under tile t's MFMAs
+  float mr[4], ls[4], dl[4];
+  auto load_stats = [&](int q0, float (&m_)[4], float (&l_)[4], float (&d_)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      m_[r] = hn_buffer_load_x1(rsS, (4 * g + r) * 8, q0 * 8, 0);
+      l_[r] = hn_buffer_load_x1(rsS, (4 * g + r) * 8 + 4, q0 * 8, 0);
+      d_[r] = hn_buffer_load_x1(rsD, (4 * g + r) * 4, q0 * 4, 0);
+    }
+  };
+  load_stats(0, mr, ls, dl);
+  // The compiler counts its OWN loads only (the LDS-DMA above is invisible to it), so its waits on kf / vf / statistics are
+  // conservative; the landed query tiles are ordered by hand: this wave's 2 pieces of tile t are done once at most the
+  // 2 (nq - 1 - t) pieces behind them -- plus whatever ordinary loads were issued later -- are outstanding.  The ordinary loads
+  // above are all older than nothing here: they were issued AFTER the DMA pieces, so a full drain in front of the first tile is
+  // the simple correct wait (the K / V fragments are needed there anyway); later tiles need no further VMEM wait at all.
+  dkv_wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  for (int t = 0; t < nq; ++t) {
+    const int q0 = t * 16;
+    const float *Qs = lds + q0 * DP, *Gs = lds + MAXL * DP + q0 * DP;
+    float4 qa[DT], ga[DT], qb[4], gb[4];
+#pragma unroll
+    for (int s = 0; s < DT; ++s) {
+      qa[s] = *(const float4 *)&Qs[j * DP + (((4 * g + s) ^ swj) << 2)];
+      ga[s] = *(const float4 *)&Gs[j * DP + (((4 * g + s) ^ swj) << 2)];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                // row 4 g + r: sw = (r << 2) | g
+      qb[r] = *(const float4 *)&Qs[(4 * g + r) * DP + ((j ^ ((r << 2) | g)) << 2)];
+      gb[r] = *(const float4 *)&Gs[(4 * g + r) * DP + ((j ^ ((r << 2) | g)) << 2)];
+    }
+    float il[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) il[r] = (q0 + 4 * g + r < L) ? __builtin_amdgcn_rcpf(ls[r]) : 0.0f;
+    float mc[4] = {mr[0], mr[1], mr[2], mr[3]}, dc[4] = {dl[0], dl[1], dl[2], dl[3]};
+    if (t + 1 < nq) load_stats(q0 + 16, mr, ls, dl);
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+      f32x4 S = {0.f, 0.f, 0.f, 0.f}, dP = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < DT; ++s) {
+        S = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s].x, kf[u][s].x, S, 0, 0, 0);
+        dP = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s].x, vf[u][s].x, dP, 0, 0, 0);
+        S = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s].y, kf[u][s].y, S, 0, 0, 0);
+        dP = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s].y, vf[u][s].y, dP, 0, 0, 0);
+        S = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s].z, kf[u][s].z, S, 0, 0, 0);
+        dP = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s].z, vf[u][s].z, dP, 0, 0, 0);
+        S = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s].w, kf[u][s].w, S, 0, 0, 0);
+        dP = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s].w, vf[u][s].w, dP, 0, 0, 0);
+      }
+      float P[4], dS[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pn = fexp2(S[r] - mc[r]) * il[r] * live[u];
+        dS[r] = pn * (dP[r] - dc[r]);
+        P[r] = pn;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float qv[4] = {qb[r].x, qb[r].y, qb[r].z, qb[r].w}, gv[4] = {gb[r].x, gb[r].y, gb[r].z, gb[r].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          dV[u][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(P[r], gv[e], dV[u][e], 0, 0, 0);
+          dK[u][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(dS[r], qv[e], dK[u][e], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // accumulator e, element r: token 4 g + r, column 4 j + e.  Compact (b*N, 2*inner) layout: [dK | dV]
+#pragma unroll
+  for (int u = 0; u < TPW; ++u) {
+    if (tile0 + u >= ntiles) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int tok = (tile0 + u) * 16 + 4 * g + r, col = 4 * j;
+      if (tok < a.N && col < dh) {
+        float *row = a.dKV + ((long)bi * a.N + tok) * (2 * inner) + hi * dh + col;
+        *(f32x4 *)row = (f32x4){dK[u][0][r], dK[u][1][r], dK[u][2][r], dK[u][3][r]} * a.dk_scale;
+        *(f32x4 *)(row + inner) = (f32x4){dV[u][0][r], dV[u][1][r], dV[u][2][r], dV[u][3][r]};
+      }
+    }
+  }
+}
+
 int launch_attn_bwd_dkv(const AttnBwdArgs &a, int dh, int inner, hipStream_t s) {
   HN_REQUIRE(a.dp == 16 || a.dp == 32 || a.dp == 64 || a.dp == 128, HN_E_UNSUPPORTED, "attn_bwd_dkv: dp=%d", a.dp);
   const int ntiles = ceil_div(a.N, 16);
   dim3 grid(ceil_div(ntiles, 4), a.b * a.h), block(256);
   HN_REQUIRE(grid.y <= 65535, HN_E_UNSUPPORTED, "attn_bwd_dkv: b*h too large");
+  // query side in LDS: dp = 64, <= 128 query rows, no dropout, 16-byte aligned rows on both sides of the DMA and of the stores
+  static const bool no_lds = getenv("HN_NO_DKV_LDS") != nullptr;      // development switch: the register-only kernel
+  auto al16p = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
+  if (!no_lds && a.dp == 64 && a.Lq <= 128 && a.drop.thr == 0 && dh % 4 == 0 && inner % 4 == 0 && a.ldq % 4 == 0 && a.lddo % 4 == 0 &&
+      a.q_b % 4 == 0 && a.q_h % 4 == 0 && a.do_b % 4 == 0 && a.do_h % 4 == 0 && al16p(a.Q) && al16p(a.dO) && al16p(a.dKV) && a.N >= 64) {
+    if (ntiles >= 64) hipLaunchKernelGGL(attn_bwd_dkv_lds_kernel<2>, dim3(ceil_div(ntiles, 8), a.b * a.h), block, 0, s, a, ntiles, dh, inner);
+    else hipLaunchKernelGGL(attn_bwd_dkv_lds_kernel<1>, dim3(ceil_div(ntiles, 4), a.b * a.h), block, 0, s, a, ntiles, dh, inner);
+    HN_LAUNCH_CHECK("attn_bwd_dkv_lds");
+    return HN_OK;
+  }
 #define HN_DKV(DT_)                                                                                              \
   if (a.drop.thr != 0) hipLaunchKernelGGL((attn_bwd_dkv_kernel<DT_, true>), grid, block, 0, s, a, ntiles, dh, inner); \
   else hipLaunchKernelGGL((attn_bwd_dkv_kernel<DT_, false>), grid, block, 0, s, a, ntiles, dh, inner);

@@ -574,7 +574,7 @@ static void plan_tn_multi(GemmTnMulti &m) {
   int tiles = 0;
   for (int i = 0; i < m.n; ++i) { m.tile0[i] = tiles; tiles += ceil_div(m.p[i].M, 128) * ceil_div(m.p[i].N, 128); }
   m.tile0[m.n] = tiles;
-  static const int slots = getenv("HN_TN_MULTI_SLOTS") ? atoi(getenv("HN_TN_MULTI_SLOTS")) : 768;      // development knob
+  static const int slots = tuning_env("HN_TN_MULTI_SLOTS") ? atoi(tuning_env("HN_TN_MULTI_SLOTS")) : 768;      // development knob
   int nsplit = tiles > 0 ? slots / tiles : 1;
   const int max_by_k = ceil_div(m.K, 64);
   if (nsplit > max_by_k) nsplit = max_by_k;

@@ -296,15 +296,17 @@ __global__ __launch_bounds__(512) void latent_bchain_kernel(const BChainArgs arg
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) __hip_atomic_store(flags + member, args.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int timed_out = 0;
     if (tid < a_C) {
       int spins = 0;
       while (__hip_atomic_load(flags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < args.seq) {
         __builtin_amdgcn_s_sleep(2);
-        if (++spins > (1 << 22)) { args.xflags[2 * ntiles * a_C] = 1; break; }      // error marker instead of a hang
+        if (++spins > (1 << 22)) { args.xflags[2 * ntiles * a_C] = 1; timed_out = 1; break; }      // no hang ...
       }
     }
-    __syncthreads();
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    // ... and no silently incomplete sum either: a tile that gave up on a member becomes NaN (chain.hip explains)
+    const bool lost = __syncthreads_or(timed_out) != 0;
+    float4 acc = lost ? make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")) : make_float4(0.f, 0.f, 0.f, 0.f);
     for (int c = 0; c < a_C; ++c) {
       const float *pp = slot + (long)c * (CR * CD) + row * CD + 4 * l32;
       acc.x += __hip_atomic_load(pp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

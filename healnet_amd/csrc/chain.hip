@@ -550,14 +550,20 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
       __syncthreads();
       if (tid == 0)                          // ... before the member's flag goes up
         __hip_atomic_store(args.xflags + tile * a_C + member, args.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (tid < a_C) {                       // one lane per member flag; bounded spin (a lost member must not hang the device)
+      // one lane per member flag; bounded spin: a member that is never scheduled beside us (the launcher sizes the grid so that all
+      // members are resident, but nothing in HIP guarantees co-residency: a CU mask, another process, a collective kernel parked on
+      // the CUs) must not hang the device.  A tile that gives up is NOT allowed to carry on with incomplete sums silently: the
+      // whole tile becomes NaN, which reaches the logits / gradients of its sample -- HN_NO_CHAIN_CLUSTER=1 runs such a
+      // setup without the exchange.
+      int timed_out = 0;
+      if (tid < a_C) {
         int spins = 0;
         while (__hip_atomic_load(args.xflags + tile * a_C + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < args.seq) {
           __builtin_amdgcn_s_sleep(2);
-          if (++spins > (1 << 22)) { args.xflags[ntiles * a_C] = 1; break; }      // error marker (members not co-resident): no hang
+          if (++spins > (1 << 22)) { args.xflags[ntiles * a_C] = 1; timed_out = 1; break; }
         }
       }
-      __syncthreads();
+      const bool lost = __syncthreads_or(timed_out) != 0;
       {
         const int row = tid >> 5, l32 = tid & 31;
         float4 x = lld4(lds, xs + row * XP + 4 * l32);
@@ -581,6 +587,7 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
         } else {
           x = f;
         }
+        if (lost) x = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
         lst4(lds, xs + row * XP + 4 * l32, x);
       }
     }
@@ -723,7 +730,7 @@ int launch_latent_chain(const ChainArgs &a, hipStream_t s) {
   // cluster mode for small batches (see the kernel): 4 workgroups per row tile up to 64 tiles, 2 up to 128 -- at most 256
   // workgroups, all resident (the exchange spins on the other members' flags)
   static const bool no_cluster = getenv("HN_NO_CHAIN_CLUSTER") != nullptr;
-  static const int max_tiles = getenv("HN_CHAIN_CLUSTER_TILES") ? atoi(getenv("HN_CHAIN_CLUSTER_TILES")) : 128;      // development knob
+  static const int max_tiles = tuning_env("HN_CHAIN_CLUSTER_TILES") ? atoi(tuning_env("HN_CHAIN_CLUSTER_TILES")) : 128;      // development knob
   ChainArgs ac = a;
   const int tiles = (a.rows + CR - 1) / CR;
   // members of a tile sit `gtiles` workgroups apart and must share an XCD (workgroups are dealt round-robin over the 8 XCDs):

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <stdarg.h>
 
 #include "../../include/healnet_hip.h"
@@ -15,6 +16,17 @@ void debug_after_launch(hipStream_t s);
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Environment knobs.  ROUTE switches (HN_NO_* / HN_FORCE_*: take the generic route of a fused kernel, or force a fused one below its
+// size gate -- the A/B tests compare the two routes) are read in every build.  TUNING knobs, which change a kernel's GEOMETRY (query
+// tiles per wave, resident-wave targets, split sizes, cluster limits), exist only in a build made with -DHN_TUNING_KNOBS
+// (HN_EXTRA_HIPCC_FLAGS=-DHN_TUNING_KNOBS, the sweep tools under tools/): a product build cannot be steered into an untested
+// geometry from the environment.
+#ifdef HN_TUNING_KNOBS
+static inline const char *tuning_env(const char *name) { return getenv(name); }
+#else
+static inline const char *tuning_env(const char *) { return nullptr; }
+#endif
 
 // hn_set_kernel_timers (api.hip): brackets the launches of a named kernel class with the caller's event pairs
 struct KernelTimerScope {

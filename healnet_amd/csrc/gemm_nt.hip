@@ -49,14 +49,22 @@ __global__ __launch_bounds__(256) void gemm_nt_stage_kernel(const float *__restr
   const float *w = W + (long)n * ldw;
   float *o = Ws + (long)n * ldws;
   float acc = 0.0f;
-  for (int k = lane; k < ldws; k += 64) {
-    float v = 0.0f;
-    if (k < K) {
-      const float x = w[k];
-      v = gamma ? x * gamma[k] : x;
-      if (beta) acc += x * beta[k];
+  // four column groups of 64 per trip, their loads issued together (one dependent round trip per 256 columns instead of per 64)
+  for (int k0 = 0; k0 < ldws; k0 += 256) {
+    float x[4], gm[4], bt[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = k0 + 64 * u + lane, kc = k < K ? k : K - 1;
+      x[u] = w[kc];
+      gm[u] = gamma ? gamma[kc] : 1.0f;
+      bt[u] = beta ? beta[kc] : 0.0f;
     }
-    o[k] = v;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = k0 + 64 * u + lane;
+      if (k < ldws) o[k] = k < K ? x[u] * gm[u] : 0.0f;
+      if (k < K) acc += x[u] * bt[u];
+    }
   }
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d);
@@ -392,13 +400,15 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float *__rest
     }
     const long m = i / N, n = i % N;
     const float *src = part + m * ldp + n;
-    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-    int k = 0;
-    for (; k + 4 <= nsplit; k += 4) {
-      a0 += src[(long)k * slab]; a1 += src[(long)(k + 1) * slab]; a2 += src[(long)(k + 2) * slab]; a3 += src[(long)(k + 3) * slab];
+    // up to 16 slices in flight per trip (independent loads), summed in slice order: bitwise reproducible
+    float acc = 0.0f;
+    for (int k0 = 0; k0 < nsplit; k0 += 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = src[(long)min(k0 + u, nsplit - 1) * slab];      // unconditional (a guarded load serialises)
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc += k0 + u < nsplit ? v[u] : 0.0f;
     }
-    for (; k < nsplit; ++k) a0 += src[(long)k * slab];
-    const float acc = (a0 + a1) + (a2 + a3);
     float *dst = C + m * ldc + n;
     *dst = accumulate ? *dst + alpha * acc : alpha * acc;
   }
