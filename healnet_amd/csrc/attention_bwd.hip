@@ -433,7 +433,7 @@ template <int N> __device__ __forceinline__ void dkv_wait_vmcnt() { asm volatile
 template <int TPW>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_lds_kernel(AttnBwdArgs a, int ntiles, int dh, int inner) {
   constexpr int DT = 4, DP = 64, MAXL = 128;
-  __shared__ __attribute__((aligned(16))) float lds[2 * MAXL * DP];          // Q image, then dO image
+  __shared__ __attribute__((aligned(16))) float lds[2 * MAXL * DP + 4 * 256];          // Q image, dO image, (max, sum) rows, delta
   const int L = a.Lq, nq = (L + 15) >> 4;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -446,19 +446,30 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_lds_kernel(AttnBwdArgs a, in
   const i32x4 krs = make_rsrc(a.Kp + (long)bi * a.k_b + (long)hi * a.k_h, rsrc_bytes(a.N, a.ldk, DP));
   const i32x4 vrs = make_rsrc(a.Vp + (long)bi * a.v_b + (long)hi * a.v_h, rsrc_bytes(a.N, a.ldv, DP));
 
-  // ---- request the whole query side: per 16-row tile 4 + 4 one-KB pieces (4 rows each), wave w takes piece w of Q and of dO.
-  // Lane (r4 = lane >> 4, p = lane & 15) fetches slot p ^ sw(row & 15) of row 16 t + 4 w + r4 and lands at slot p.
+  // ---- the query side by LDS-DMA: per 16-row tile 4 + 4 one-KB pieces (4 rows each), wave w takes piece w of Q and of dO.  Lane
+  // (r4 = lane >> 4, p = lane & 15) fetches slot p ^ sw(row & 15) of row 16 t + 4 w + r4 and lands at slot p.  Wave 0 also lands the
+  // row statistics (max, sum) and delta of the (sample, head): (L, 2) + (L) floats behind the two images.
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(const __attribute__((address_space(3))) float *)lds);
+  const int r4 = lane >> 4, p16 = lane & 15, rl = 4 * wave + r4;            // row within a query tile
+  const int swl = ((rl & 3) << 2) | (rl >> 2);
+  const int voq = (rl * a.ldq + ((p16 ^ swl) << 2)) * 4, vog = (rl * a.lddo + ((p16 ^ swl) << 2)) * 4;
+  auto request_tile = [&](int t) {
+    const unsigned dst = lds_base + (unsigned)((t * 16 + 4 * wave) * DP * 4);
+    dkv_glds16(rsQ, dst, voq, t * 16 * a.ldq * 4);
+    dkv_glds16(rsG, dst + MAXL * DP * 4, vog, t * 16 * a.lddo * 4);
+  };
+  constexpr int STATS = 2 * MAXL * DP;                                       // float offset of the statistics block
   {
-    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(const __attribute__((address_space(3))) float *)lds);
-    const int r4 = lane >> 4, p = lane & 15, rl = 4 * wave + r4;             // row within the tile
-    const int sw = ((rl & 3) << 2) | (rl >> 2);
-    const int voq = (rl * a.ldq + ((p ^ sw) << 2)) * 4, vog = (rl * a.lddo + ((p ^ sw) << 2)) * 4;
-    for (int t = 0; t < nq; ++t) {
-      const unsigned dst = lds_base + (unsigned)((t * 16 + 4 * wave) * DP * 4);
-      dkv_glds16(rsQ, dst, voq, t * 16 * a.ldq * 4);
-      dkv_glds16(rsG, dst + MAXL * DP * 4, vog, t * 16 * a.lddo * 4);
-    }
+    const i32x4 rsS = make_rsrc(a.stats + (long)bh * L * 2, (unsigned)L * 8u);
+    const i32x4 rsD = make_rsrc(a.delta + (long)bh * L, (unsigned)L * 4u);
+    // every wave issues the same number of pieces (the counted waits below are per wave): waves 0 / 1 carry the statistics and
+    // delta, waves 2 / 3 an out-of-range dummy (lands zeros in an unused slab)
+    const unsigned sdst = lds_base + (unsigned)((STATS + wave * 256) * 4);
+    if (wave == 0) dkv_glds16(rsS, sdst, lane * 16, 0);
+    else if (wave == 1) dkv_glds16(rsD, sdst, lane * 16, 0);
+    else dkv_glds16(rsD, sdst, 0x7ffffff0, 0);
   }
+  request_tile(0);
 
   // token side: B operands of S / dP, lane (g, j = token) holds K[t][16 g + 4 s ..] (the contraction order of the header)
   float4 kf[TPW][DT], vf[TPW][DT];
@@ -474,37 +485,42 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_lds_kernel(AttnBwdArgs a, in
     live[u] = (t0 + j) < a.N ? 1.0f : 0.0f;
     if (a.mask) live[u] *= a.mask[(long)bi * a.N + min(t0 + j, a.N - 1)] ? 1.0f : 0.0f;
   }
+  // Everything requested so far -- statistics, query tile 0, the K / V fragments -- is what the first tile needs: ONE full wait,
+  // made here by hand AND through a use of the last fragment (the compiler counts only its own loads: without the use it would
+  // put its vmcnt(0) in front of the first MFMA, behind the requests below, and drain them all).  The other query tiles are requested
+  // behind it and land under tile 0's MFMAs; no ordinary load is issued after this point.
+  dkv_wait_vmcnt<0>();
+#pragma unroll
+  for (int u = 0; u < TPW; ++u) {
+    asm volatile("" ::"v"(vf[u][DT - 1].w), "v"(kf[u][DT - 1].w), "v"(live[u]));
+  }
+  for (int t = 1; t < nq; ++t) request_tile(t);
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
   f32x4 dK[TPW][DT], dV[TPW][DT];
 #pragma unroll
   for (int u = 0; u < TPW; ++u)
 #pragma unroll
     for (int d = 0; d < DT; ++d) { dK[u][d] = (f32x4){0.f, 0.f, 0.f, 0.f}; dV[u][d] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-
-  const i32x4 rsS = make_rsrc(a.stats + (long)bh * L * 2, (unsigned)L * 8u);
-  const i32x4 rsD = make_rsrc(a.delta + (long)bh * L, (unsigned)L * 4u);
   const int swj = ((j & 3) << 2) | (j >> 2);
-  // row statistics of query tile 0 (rows 4 g + r); those of tile t + 1 are requested under tile t's MFMAs
-  float mr[4], ls[4], dl[4];
-  auto load_stats = [&](int q0, float (&m_)[4], float (&l_)[4], float (&d_)[4]) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      m_[r] = hn_buffer_load_x1(rsS, (4 * g + r) * 8, q0 * 8, 0);
-      l_[r] = hn_buffer_load_x1(rsS, (4 * g + r) * 8 + 4, q0 * 8, 0);
-      d_[r] = hn_buffer_load_x1(rsD, (4 * g + r) * 4, q0 * 4, 0);
-    }
-  };
-  load_stats(0, mr, ls, dl);
-  // The compiler counts its OWN loads only (the LDS-DMA above is invisible to it), so its waits on kf / vf / statistics are
-  // conservative; the landed query tiles are ordered by hand: this wave's 2 pieces of tile t are done once at most the
-  // 2 (nq - 1 - t) pieces behind them -- plus whatever ordinary loads were issued later -- are outstanding.  The ordinary loads
-  // above are all older than nothing here: they were issued AFTER the DMA pieces, so a full drain in front of the first tile is
-  // the simple correct wait (the K / V fragments are needed there anyway); later tiles need no further VMEM wait at all.
-  dkv_wait_vmcnt<0>();
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
+  const float *st_ms = lds + STATS, *st_dl = lds + STATS + 256;
 
   for (int t = 0; t < nq; ++t) {
     const int q0 = t * 16;
+    if (t > 0) {
+      // this wave's two pieces of tile t have landed once at most the 2 (nq - 1 - t) pieces behind them are outstanding
+      const int behind = nq - 1 - t;
+      if (behind >= 6) dkv_wait_vmcnt<12>();
+      else if (behind == 5) dkv_wait_vmcnt<10>();
+      else if (behind == 4) dkv_wait_vmcnt<8>();
+      else if (behind == 3) dkv_wait_vmcnt<6>();
+      else if (behind == 2) dkv_wait_vmcnt<4>();
+      else if (behind == 1) dkv_wait_vmcnt<2>();
+      else dkv_wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
     const float *Qs = lds + q0 * DP, *Gs = lds + MAXL * DP + q0 * DP;
     float4 qa[DT], ga[DT], qb[4], gb[4];
 #pragma unroll
@@ -517,11 +533,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_lds_kernel(AttnBwdArgs a, in
       qb[r] = *(const float4 *)&Qs[(4 * g + r) * DP + ((j ^ ((r << 2) | g)) << 2)];
       gb[r] = *(const float4 *)&Gs[(4 * g + r) * DP + ((j ^ ((r << 2) | g)) << 2)];
     }
-    float il[4];
+    float il[4], mc[4], dc[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) il[r] = (q0 + 4 * g + r < L) ? __builtin_amdgcn_rcpf(ls[r]) : 0.0f;
-    float mc[4] = {mr[0], mr[1], mr[2], mr[3]}, dc[4] = {dl[0], dl[1], dl[2], dl[3]};
-    if (t + 1 < nq) load_stats(q0 + 16, mr, ls, dl);
+    for (int r = 0; r < 4; ++r) {
+      const float2 ms = *(const float2 *)&st_ms[(q0 + 4 * g + r) * 2];
+      mc[r] = ms.x;
+      il[r] = (q0 + 4 * g + r < L) ? __builtin_amdgcn_rcpf(ms.y) : 0.0f;
+      dc[r] = st_dl[q0 + 4 * g + r];
+    }
 #pragma unroll
     for (int u = 0; u < TPW; ++u) {
       f32x4 S = {0.f, 0.f, 0.f, 0.f}, dP = {0.f, 0.f, 0.f, 0.f};
