@@ -185,6 +185,10 @@ class GradReadyAllReduce:
         self.buckets = grad_ready_buckets(model, flat.views, flat.offsets)
         self.depth = depth
         self.reduce_fn = reduce_fn or self._allreduce_mean
+        # a single rank with the default collective has nothing to exchange: the signals are still taken (bookkeeping, tests of
+        # the bucket plan), but no side-stream hand-off is made -- each cross-stream event wait costs tens of microseconds on this
+        # runtime (0.2 ms of a 5.9 ms cfg4 step for the four hops of a depth-3 model)
+        self._idle = reduce_fn is None
         self.side = torch.cuda.Stream(self.device)
         self.events = [torch.cuda.Event() for _ in range(depth + 1)]
         for ev in self.events:                               # torch creates the hipEvent_t lazily at the first record
@@ -209,10 +213,14 @@ class GradReadyAllReduce:
             dist.all_reduce(view, op=dist.ReduceOp.SUM)
             view.div_(dist.get_world_size())
 
+    def _skip(self) -> bool:
+        return self._idle and not _active()
+
     def _release(self, idx: int) -> None:
         for lo, hi in self.buckets.get(idx, []):
-            with torch.cuda.stream(self.side):
-                self.reduce_fn(self.flat.grads[lo:hi])
+            if not self._skip():
+                with torch.cuda.stream(self.side):
+                    self.reduce_fn(self.flat.grads[lo:hi])
             self.launched.append((idx, lo, hi))
 
     # -- called by torch.ops.healnet_hip.fusion_backward around / from inside hn_fusion_backward -------------------
@@ -223,7 +231,8 @@ class GradReadyAllReduce:
     def _notify(self, idx, user) -> None:                    # host callback: events[idx] has just been recorded
         try:
             if idx in self.buckets and idx >= 1:
-                self.side.wait_event(self.events[idx])
+                if not self._skip():
+                    self.side.wait_event(self.events[idx])
                 self._release(idx)
         except BaseException as e:                           # exceptions cannot cross the C frame
             self._error = e
@@ -231,14 +240,16 @@ class GradReadyAllReduce:
     def end(self, stream_ptr: int) -> None:
         if self._error is not None:
             raise self._error
-        done = torch.cuda.Event()
-        done.record(torch.cuda.current_stream(self.device))
-        self.side.wait_event(done)
+        if not self._skip():
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(self.device))
+            self.side.wait_event(done)
         self._release(-1)
 
     def wait(self) -> None:
         """Make the current stream wait for every all-reduce released by the last backward."""
-        torch.cuda.current_stream(self.device).wait_stream(self.side)
+        if not self._skip():
+            torch.cuda.current_stream(self.device).wait_stream(self.side)
 
 
 def max_over_ranks(value: float, device: Optional[torch.device] = None) -> float:

@@ -85,7 +85,7 @@ def test_head_backward(capi, b, L, d, out):
         assert_close(got.cpu(), want.grad, rel=2e-4, what="head." + nm)
 
 
-def _attn_case(capi, b, L, N, D, heads, dh, qd, self_attn=False, masked=False, norm=True, residual=True, seed=0, _depth=0):
+def _attn_case(capi, b, L, N, D, heads, dh, qd, self_attn=False, masked=False, norm=True, residual=True, seed=0, _depth=0, nan_pad=False):
     import healnet_amd.healnet as H
     gen = torch.Generator().manual_seed(seed)
     inner = heads * dh
@@ -108,7 +108,7 @@ def _attn_case(capi, b, L, N, D, heads, dh, qd, self_attn=False, masked=False, n
     # |pre| of the LeakyReLU from its output: act = pre (pre > 0) or 0.01 pre (pre < 0)
     margin = float(torch.where(act > 0, act, act * 100).abs().min())
     if margin < 1e-5 and _depth < 20:
-        return _attn_case(capi, b, L, N, D, heads, dh, qd, self_attn, masked, norm, residual, seed + 1, _depth + 1)
+        return _attn_case(capi, b, L, N, D, heads, dh, qd, self_attn, masked, norm, residual, seed + 1, _depth + 1, nan_pad)
     y = act + (x if residual else 0)
     y.backward(dy)
 
@@ -131,6 +131,9 @@ def _attn_case(capi, b, L, N, D, heads, dh, qd, self_attn=False, masked=False, n
         if norm:
             ld = lib.hn_context_pitch(D, dh)
             z = H._normalise_context(ctx.to(DEV).contiguous(), ld)
+            if nan_pad:      # the pad columns D .. ld-1 of a context row belong to nobody: whatever they hold must not reach a result
+                assert ld > D
+                z.view(b, N, ld)[..., D:] = float("nan")
         else:
             z, ld = ctx.to(DEV).contiguous(), D
     m8 = None if mask is None else mask.to(DEV).to(torch.uint8).contiguous()
@@ -175,6 +178,11 @@ ATTN_CASES = [
     dict(b=3, L=25, N=1000, D=773, heads=1, dh=16, qd=32),
     dict(b=2, L=16, N=1100, D=131, heads=1, dh=27, qd=32),
     dict(b=2, L=16, N=1200, D=200, heads=2, dh=32, qd=32, norm=False),
+    # LDS-DMA GEMMs (gemm_nt.hip) away from cfg4's shape: odd D with NaN-filled pad columns (the masked last k-step), a ragged last row
+    # tile, 2 * inner = 256 columns; 4600-row contraction over 48 slices of 3 k-tiles for G = dKV^T z, 141 = 112 + 29 columns
+    dict(b=2, L=128, N=2300, D=141, heads=2, dh=64, qd=128, nan_pad=True),
+    dict(b=1, L=32, N=4200, D=773, heads=8, dh=64, qd=128, nan_pad=True),       # one bag of cfg4's width, ragged rows (4200 = 32 * 128 + 104)
+    dict(b=2, L=16, N=2100, D=96, heads=4, dh=64, qd=32, norm=False),           # no context LayerNorm: the weight is staged without the affine
 ]
 CASE_INDEX = {id(c): k for k, c in enumerate(ATTN_CASES)}
 
