@@ -130,6 +130,20 @@ def _normalise_context(ctx: torch.Tensor, pitch: int) -> torch.Tensor:
     return z
 
 
+# Every (re-)registration of a submodule or parameter anywhere in the process bumps this counter; HealNet._params() re-resolves its
+# (module, name) slots when it has moved, so a replaced submodule / added parameter is never read through a stale slot.
+_REGISTRATION_VERSION = [0]
+
+
+def _bump_registration(*_args):
+    _REGISTRATION_VERSION[0] += 1
+    return None
+
+
+nn.modules.module.register_module_module_registration_hook(_bump_registration)
+nn.modules.module.register_module_parameter_registration_hook(_bump_registration)
+
+
 # ------------------------------------------------------------------------------------------------
 # parameter containers with the reference's state_dict keys
 # ------------------------------------------------------------------------------------------------
@@ -510,6 +524,8 @@ class HealNet(nn.Module):
         modules): the (module, name) slots are resolved once, the Parameter objects are read from them on every call, so
         re-assigned / re-homed parameters are seen.  Same order and de-duplication (tied blocks) as ``parameters()``."""
         slots = self.__dict__.get("_hn_param_slots")
+        if slots is not None and self.__dict__.get("_hn_param_ver") != _REGISTRATION_VERSION[0]:
+            slots = None                                     # some module / parameter was (re-)registered since: resolve again (ADVICE r3)
         if slots is None:
             slots, seen = [], set()
             for mod in self.modules():                       # de-duplicated, registration order: what named_parameters() walks
@@ -519,6 +535,7 @@ class HealNet(nn.Module):
                     seen.add(id(prm))
                     slots.append((mod._parameters, name))
             self.__dict__["_hn_param_slots"] = slots
+            self.__dict__["_hn_param_ver"] = _REGISTRATION_VERSION[0]
         return [d[n] for d, n in slots]
 
     def _descriptor(self, rng=None):

@@ -272,3 +272,28 @@ def test_build_id_is_content_addressed(tmp_path):
     q = tmp_path / "lib.so"
     q.write_bytes(b"\x7fELF" + b"\0" * 64)
     assert _capi.library_build_id(str(q)) is None and _capi.library_build_id(str(tmp_path / "none.so")) is None
+
+
+def test_parameter_slots_follow_reregistration():
+    """HealNet._params() caches (module, name) slots; replacing a submodule or adding a parameter after the first use must be
+    seen: the list stays identical to list(parameters())."""
+    import healnet_amd
+    from torch import nn
+    m = healnet_amd.HealNet(n_modalities=1, channel_dims=[8], num_spatial_axes=[1], out_dims=2, depth=1, l_c=4, l_d=8, x_heads=1,
+                            l_heads=1, cross_dim_head=4, latent_dim_head=4)
+    ids = lambda ps: [id(p) for p in ps]      # noqa: E731
+    assert ids(m._params()) == ids(m.parameters())
+    m.to_logits[2] = nn.Linear(8, 2)
+    assert ids(m._params()) == ids(m.parameters())
+    m.extra = nn.Parameter(torch.zeros(3))
+    assert ids(m._params()) == ids(m.parameters())
+
+
+def test_descriptor_cache_key_sees_dtype_and_layout():
+    from healnet_amd import ops
+    a, b = torch.zeros(4, 4), torch.zeros(4, 4)
+    k0 = ops.Spec._param_key([a, b])
+    assert k0 == ops.Spec._param_key([a, b])
+    assert ops.Spec._param_key([a, b.t()]) != k0 or b.t().is_contiguous()
+    c = torch.zeros(4, 4, dtype=torch.float64)
+    assert ops.Spec._param_key([a, c])[2][1] is False
