@@ -223,6 +223,7 @@ static int bwd_nq(int dt) { return dt == 1 ? 4 : (dt == 2 ? 2 : (dt == 4 ? 2 : 1
 
 int launch_attn_bwd_dq(const AttnBwdArgs &a, hipStream_t s) {
   HN_REQUIRE(a.dp == 16 || a.dp == 32 || a.dp == 64 || a.dp == 128, HN_E_UNSUPPORTED, "attn_bwd_dq: dp=%d", a.dp);
+  if (attn_bwd_dq_lds_eligible(a)) return launch_attn_bwd_dq_lds(a, s);
   const int dt = a.dp / 16, nq = bwd_nq(dt);
   const int ngroups = ceil_div(a.Lp / 16, nq);
   const int wpb = ngroups < 4 ? ngroups : 4;

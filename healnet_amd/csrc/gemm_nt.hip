@@ -91,8 +91,9 @@ __global__ __launch_bounds__(NWM *NWN * 64) void gemm_nt_glds_kernel(GemmNtArgs 
   const int lda = (int)g.lda, ldw = (int)g.ldw;
   const int rows_a = min(BM, g.M - m0), rows_w = min(BN, g.N - n0);
   // descriptors based at the tile: rows past the end read as zero, offsets stay small whatever M
-  const i32x4 rsA = make_rsrc(g.A + (long)m0 * lda, (unsigned)(rows_a * lda * 4));
-  const i32x4 rsW = make_rsrc(g.W + (long)n0 * ldw, (unsigned)(rows_w * ldw * 4));
+  const int a_bytes = rows_a * lda * 4, w_bytes = rows_w * ldw * 4;
+  const i32x4 rsA = make_rsrc(g.A + (long)m0 * lda, (unsigned)a_bytes);
+  const i32x4 rsW = make_rsrc(g.W + (long)n0 * ldw, (unsigned)w_bytes);
 
   // loader: lane (r8 = lane >> 3, p = lane & 7) fetches the 16-byte slot p ^ r8 of row 8 u + r8 and lands at slot p
   const int r8 = lane >> 3, p = lane & 7;
@@ -103,8 +104,10 @@ __global__ __launch_bounds__(NWM *NWN * 64) void gemm_nt_glds_kernel(GemmNtArgs 
     for (int q = 0; q < LW; ++q) {
       const int u = wave + NW * q;
       const unsigned dst = lds_base + (unsigned)(((kt % S) * STAGE + u * 256) * 4);
-      if (q < LWA) hn_glds16(rsA, dst, voffA, 8 * u * lda * 4 + kt * 128);
-      else hn_glds16(rsW, dst, voffW, 8 * (u - LA) * ldw * 4 + kt * 128);
+      // (the scalar offset must stay inside the descriptor -- the range check subtracts it from num_records: clamped, so a piece that
+      // starts past the last row of a ragged tile reads zeros instead of wrapping)
+      if (q < LWA) hn_glds16(rsA, dst, voffA, min(8 * u * lda * 4 + kt * 128, a_bytes));
+      else hn_glds16(rsW, dst, voffW, min(8 * (u - LA) * ldw * 4 + kt * 128, w_bytes));
     }
   };
 
@@ -263,8 +266,9 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(GemmTnGArgs g) {
   const int lda = (int)g.lda, ldb = (int)g.ldb;
   // descriptors based at (slice row 0, tile column 0): rows past the slice read as zero
   const long a_bytes = ((long)(rows - 1) * lda + (g.M - m0)) * 4, b_bytes = ((long)(rows - 1) * ldb + (g.N - n0)) * 4;
-  const i32x4 rsA = make_rsrc(g.A + (long)k_begin * lda + m0, (unsigned)(a_bytes > 0 ? a_bytes : 0));
-  const i32x4 rsB = make_rsrc(g.B + (long)k_begin * ldb + n0, (unsigned)(b_bytes > 0 ? b_bytes : 0));
+  const long a_clamp = a_bytes > 0 ? a_bytes : 0, b_clamp = b_bytes > 0 ? b_bytes : 0;
+  const i32x4 rsA = make_rsrc(g.A + (long)k_begin * lda + m0, (unsigned)a_clamp);
+  const i32x4 rsB = make_rsrc(g.B + (long)k_begin * ldb + n0, (unsigned)b_clamp);
   // loader: one instruction = 2 rows x 512 bytes; lane -> (row lane >> 5, 16-byte piece lane & 31)
   const int voffA = (lane >> 5) * lda * 4 + ((lane & 31) << 4), voffB = (lane >> 5) * ldb * 4 + ((lane & 31) << 4);
   const unsigned lds_base = __builtin_amdgcn_readfirstlane(lds_byte_address(lds));
@@ -273,8 +277,9 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(GemmTnGArgs g) {
     for (int q = 0; q < LW; ++q) {
       const int u = wave + 4 * q;                                 // u < 16: A rows 2u, 2u + 1; else B rows 2(u - 16) ..
       const unsigned dst = lds_base + (unsigned)(((kt % S) * STAGE + u * 256) * 4);
-      if (q < 4) hn_glds16(rsA, dst, voffA, (kt * 32 + 2 * u) * lda * 4);
-      else hn_glds16(rsB, dst, voffB, (kt * 32 + 2 * (u - 16)) * ldb * 4);
+      // (scalar offsets clamped into the descriptor: rows past the slice read zeros, never wrap)
+      if (q < 4) hn_glds16(rsA, dst, voffA, (int)min((long)(kt * 32 + 2 * u) * lda * 4, a_clamp));
+      else hn_glds16(rsB, dst, voffB, (int)min((long)(kt * 32 + 2 * (u - 16)) * ldb * 4, b_clamp));
     }
   };
   const int fi = lane & 15, fg = lane >> 4;
