@@ -123,7 +123,8 @@ static int plan_attn(const hn_attn_params *p, bool has_ctx, int ld_ctx, int b, i
   pl->bf16core = bf16core != 0 && pl->ones && pl->N > 1;
   pl->nq = (pl->rank_d && !pl->bf16core && p->dropout == 0.0f) ? attn_core_nq_small_batch(pl->dp, b, p->heads, pl->Lp) : 0;
   attn_core_geometry(b, p->heads, pl->Lp, pl->N, pl->dp, &pl->nsplit, &pl->chunk, 0, pl->nq);
-  attn_core_geometry(b, p->heads, pl->Lp, pl->N, pl->dp, &pl->nsplit_bwd, &pl->chunk_bwd, 3);
+  // (the explicit dp = 64 binding runs its dQ on the LDS ring, attention_lds.hip: 240 VGPRs = two resident waves per SIMD)
+  attn_core_geometry(b, p->heads, pl->Lp, pl->N, pl->dp, &pl->nsplit_bwd, &pl->chunk_bwd, (!pl->rank_d && pl->dp == 64 && pl->N >= 256) ? 2 : 3);
   if (pl->bf16core) {
     // the plain dp = 16 bf16 core holds 161 VGPRs = 3 resident waves per SIMD: size the split for 3 (a split sized for 4 runs
     // a second, mostly idle round).  The larger variants measured faster with the default split (cfg3: 7.6 vs 11.2 ms).

@@ -451,7 +451,6 @@ int launch_attn_core(const AttnCoreArgs &a, hipStream_t s) {
   HN_REQUIRE(a.drop.thr == 0 || !a.ones_col || (!a.ones_in_mem && (a.dp == 16 || a.dp == 32)), HN_E_SHAPE,
              "attn_core: dropout with the ones column needs it injected in registers (the row-sum channel), dp = 16 / 32");
   if (self_core_lds_eligible(a)) return launch_self_core_lds(a, s);
-  if (attn_core_lds_eligible(a)) return launch_attn_core_lds(a, s);
   const int dt = a.dp / 16;
   int nq = a.nq > 0 ? a.nq : nq_for(dt);
   // latent self-attention (dp = 64, one split) at small batches: fewer than one wave per two SIMDs with 2 tiles per wave;

@@ -1,13 +1,13 @@
-// Explicit-binding attention cores (dp = 64: patch bags, latent self-attention) on a workgroup-shared LDS ring of K / V tiles.
-// Forward core of healnet/models/healnet.py:409-424 and the dQ half of its autograd (the dK / dV half with the QUERY side in
-// LDS is attn_bwd_dkv_lds_kernel, attention_bwd.hip).
+// The dQ half of the explicit-binding attention backward (dp = 64: patch bags; autograd of healnet/models/healnet.py:409-424) on a
+// workgroup-shared LDS ring of K / V tiles (the dK / dV half with the QUERY side in LDS is attn_bwd_dkv_lds_kernel, attention_bwd.hip).
 //
-// attn_core_kernel / attn_bwd_dq_kernel (attention.hip, attention_bwd.hip) are register-only: every wave fetches the K / V
-// fragments of every 16-token step itself, as fragment-shaped loads (16 rows x 64 B per instruction -- the pattern that runs at a
-// third of the full-line rate), although the four waves of a workgroup (its query-tile groups) walk the SAME tokens.
-// At cfg4 that is 0.69 / 0.60 of the fp32 MFMA peak (79 / 134 us).  Here the workgroup lands each 32-token K / V tile ONCE by
-// LDS-DMA in full 256-byte rows (gemm_nt.hip's skeleton: two ring slots, one barrier per tile in the MIDDLE of the tile, inline-asm
-// DMA with hand-counted waits) and its waves read their fragments from LDS.
+// attn_bwd_dq_kernel (attention_bwd.hip) is register-only: every wave fetches the K / V fragments of every 16-token step itself, as
+// fragment-shaped loads (16 rows x 64 B per instruction -- the pattern that runs at a third of the full-line rate),
+// although the four waves of a workgroup (its query-tile groups) walk the SAME tokens: 0.60 of the fp32 MFMA peak at cfg4 (134 us).
+// Here the workgroup lands each 32-token K / V tile ONCE by LDS-DMA in full 256-byte rows (gemm_nt.hip's skeleton: two ring slots,
+// one barrier per tile in the MIDDLE of the tile, inline-asm DMA with hand-counted waits) and its waves read their fragments from
+// LDS: 134 -> 115 us.  (The FORWARD core was built on the same ring and measured: 81.8 against 79.2 us for attn_core_kernel -- its
+// softmax needs the third resident wave per SIMD that 175 VGPRs do not leave -- and is not kept.)
 //   LDS image of a tile: 32 rows (tokens) of 16 slots of 16 bytes, K rows then V rows; slot c of row r is stored at
 //   c ^ sw(r & 15), sw(x) = ((x & 3) << 2) | (x >> 2).  With the channel contraction of S (and dP) ordered k = 16 g + 4 s + e
 //   (lane group g reads slot 4 g + s of its token row) and the B fragments of P V / dS K taking ALL 16 slots of rows 4 g + r (lane j:
@@ -22,8 +22,6 @@ namespace {
 
 constexpr int TT = 32, DP = 64, DT = 4;
 constexpr int SLOT = 2 * TT * DP;                 // floats per ring slot: K rows, then V rows (16 KB)
-constexpr float kNegBigL = -3.0e38f;
-constexpr float kRescaleThresholdL = 8.0f;        // as attention.hip: rescale when a score exceeds the running reference by 2^8
 
 __device__ __forceinline__ void kv_glds16(const i32x4 &rsrc, unsigned lds_byte, int voffset, unsigned soffset) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
@@ -71,229 +69,7 @@ __device__ __forceinline__ KvRing make_ring(const float *kbase, const float *vba
   return r;
 }
 
-// fragments of one 16-token half tile (sub = 0 / 1) out of a landed slot
-struct KvFrags { float4 ka[DT]; float4 vb[4]; };
-__device__ __forceinline__ void read_kv(const float *slot, int sub, int g, int j, KvFrags &f) {
-  const int swj = ((j & 3) << 2) | (j >> 2);
-  const float *K = slot + (sub * 16) * DP, *V = slot + TT * DP + (sub * 16) * DP;
-#pragma unroll
-  for (int s = 0; s < DT; ++s) f.ka[s] = *(const float4 *)&K[j * DP + (((4 * g + s) ^ swj) << 2)];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) f.vb[r] = *(const float4 *)&V[(4 * g + r) * DP + ((j ^ ((r << 2) | g)) << 2)];
-}
-
 }  // namespace
-
-// ------------------------------------------------------------------------------------------------
-// forward core.  Work items as attn_core_kernel: (sample, head) x token split x query-tile groups; the waves of a workgroup are
-// its query-tile groups (NQ tiles each) and share the split's tokens.
-// ------------------------------------------------------------------------------------------------
-template <int NQ>
-__global__ __launch_bounds__(256) void attn_core_lds_kernel(AttnCoreArgs a, int ngroups, int gy, int waves_per_block) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * SLOT];
-  const int L = a.Lq;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int g = lane >> 4, j = lane & 15;
-  long total = (long)gridDim.x, id = blockIdx.x;
-  if ((total & 7) == 0) id = (id & 7) * (total >> 3) + (id >> 3);
-  const int split = (int)(id % a.nsplit);
-  const int yb = (int)((id / a.nsplit) % gy);
-  const int bh = (int)(id / ((long)a.nsplit * gy));
-  const int qg = yb * waves_per_block + wave;
-  const bool active = qg < ngroups;                      // (a wave without query tiles still lands its share of the ring)
-  const int bi = bh / a.h, hi = bh % a.h;
-  const int t_begin = split * a.chunk, t_end = min(a.N, t_begin + a.chunk);
-  const int ntiles = (t_end - t_begin + TT - 1) / TT;
-
-  const KvRing ring = make_ring(a.Kp + (long)bi * a.k_b + (long)hi * a.k_h, a.Vp + (long)bi * a.v_b + (long)hi * a.v_h, a.N, a.ldk, a.ldv,
-                                lds, lane, wave);
-  if (ntiles > 0) ring.issue(0, t_begin);
-
-  // query fragments (B operand of S^T = K Q^T): lane (g, j) holds Q[row = tile * 16 + j][16 g + 4 s ..]
-  float4 qf[NQ][DT];
-  {
-    const i32x4 rsQ = make_rsrc(a.Q + (long)bi * a.q_b + (long)hi * a.q_h, rsrc_bytes(L, a.ldq, DP));
-#pragma unroll
-    for (int i = 0; i < NQ; ++i) {
-      const int row = (qg * NQ + i) * 16 + j;
-#pragma unroll
-      for (int s = 0; s < DT; ++s) qf[i][s] = buf4(rsQ, active ? (row * a.ldq + 16 * g + 4 * s) * 4 : 0x7ffffff0);
-    }
-  }
-  // tile 0 and the query fragments behind ONE wait, made by hand and through a use (the compiler counts only its own loads: left
-  // alone it waits vmcnt(0) in front of the first MFMA, behind the request of tile 1, and drains it)
-  kv_wait_vmcnt<0>();
-#pragma unroll
-  for (int i = 0; i < NQ; ++i) asm volatile("" ::"v"(qf[i][DT - 1].w));
-  if (ntiles > 1) ring.issue(1, t_begin);
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-
-  f32x4 O[NQ][4];
-  float m[NQ], l[NQ];
-#pragma unroll
-  for (int i = 0; i < NQ; ++i) {
-    m[i] = kNegBigL;
-    l[i] = 0.0f;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) O[i][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  }
-
-  auto half_step = [&](int t0, const KvFrags &f) {
-    f32x4 S[NQ];
-#pragma unroll
-    for (int i = 0; i < NQ; ++i) S[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < DT; ++s) {
-#pragma unroll
-      for (int i = 0; i < NQ; ++i) {
-        S[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.ka[s].x, qf[i][s].x, S[i], 0, 0, 0);
-        S[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.ka[s].y, qf[i][s].y, S[i], 0, 0, 0);
-        S[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.ka[s].z, qf[i][s].z, S[i], 0, 0, 0);
-        S[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.ka[s].w, qf[i][s].w, S[i], 0, 0, 0);
-      }
-    }
-    if (t0 + 16 > t_end) {                                  // ragged tail: lane (g, j) holds tokens t0 + 4 g + r
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (t0 + 4 * g + r >= t_end) {
-#pragma unroll
-          for (int i = 0; i < NQ; ++i) S[i][r] = -__builtin_inff();
-        }
-    }
-    bool need = false;
-    float tmax[NQ];
-#pragma unroll
-    for (int i = 0; i < NQ; ++i) {
-      tmax[i] = fmaxf(fmaxf(S[i][0], S[i][1]), fmaxf(S[i][2], S[i][3]));
-      need |= tmax[i] > m[i] + kRescaleThresholdL;
-    }
-    if (__any(need)) {
-#pragma unroll
-      for (int i = 0; i < NQ; ++i) {
-        float tm = tmax[i];
-        tm = fmaxf(tm, __shfl_xor(tm, 16));
-        tm = fmaxf(tm, __shfl_xor(tm, 32));
-        const float mn = fmaxf(m[i], tm);
-        const float alpha = lexp2(m[i] - mn);
-        l[i] *= alpha;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {                       // accumulator reg r of lane (g, .) belongs to query row 4 g + r
-          const float ar = __shfl(alpha, 4 * g + r);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) O[i][e][r] *= ar;
-        }
-        m[i] = mn;
-      }
-    }
-    f32x4 P[NQ];
-#pragma unroll
-    for (int i = 0; i < NQ; ++i) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float p = lexp2(S[i][r] - m[i]);
-        l[i] += p;
-        P[i][r] = p;
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float vv[4] = {f.vb[r].x, f.vb[r].y, f.vb[r].z, f.vb[r].w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int i = 0; i < NQ; ++i) O[i][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(P[i][r], vv[e], O[i][e], 0, 0, 0);
-    }
-  };
-
-  KvFrags fa, fb;
-  if (ntiles > 0) read_kv(lds, 0, g, j, fa);
-  for (int kt = 0; kt < ntiles; ++kt) {
-    const float *slot = lds + (kt & 1) * SLOT;
-    const int t0 = t_begin + kt * TT;
-    read_kv(slot, 1, g, j, fb);
-    __builtin_amdgcn_sched_barrier(0);
-    if (active) half_step(t0, fa);
-    __builtin_amdgcn_sched_barrier(0);
-    if (kt + 1 < ntiles) {
-      // two slots: the tile needed now is the only one in flight (gemm_nt.hip)
-      kv_wait_vmcnt<0>();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      if (kt + 2 < ntiles) ring.issue(kt + 2, t_begin);
-      read_kv(lds + ((kt + 1) & 1) * SLOT, 0, g, j, fa);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (active && t0 + 16 < t_end) half_step(t0 + 16, fb);
-  }
-  if (!active) return;
-
-  // accumulator e, element r: query row 4 g + r of the tile, channel 4 j + e
-  if (a.Ofinal != nullptr) {                               // single split: normalise and write O in its final layout
-#pragma unroll
-    for (int i = 0; i < NQ; ++i) {
-      const int tile = qg * NQ + i;
-      float li = l[i];
-      li += __shfl_xor(li, 16);
-      li += __shfl_xor(li, 32);
-      const float inv = 1.0f / li;                         // lane (g, j): row j of the tile
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float ir = __shfl(inv, 4 * g + r);
-        const int q = tile * 16 + 4 * g + r;
-        if (q < L && 4 * j < a.dh)
-          *(f32x4 *)&a.Ofinal[((long)bi * L + q) * a.ldo + hi * a.dh + 4 * j] = (f32x4){O[i][0][r], O[i][1][r], O[i][2][r], O[i][3][r]} * ir;
-      }
-      if (a.stats && g == 0 && tile * 16 + j < L) {
-        a.stats[((long)bh * L + tile * 16 + j) * 2 + 0] = m[i];
-        a.stats[((long)bh * L + tile * 16 + j) * 2 + 1] = li;
-      }
-    }
-    return;
-  }
-  const long prow = ((long)bh * a.nsplit + split) * a.Lp;
-#pragma unroll
-  for (int i = 0; i < NQ; ++i) {
-    const int tile = qg * NQ + i;
-    if (tile * 16 < a.Lp) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        *(f32x4 *)&a.Opart[(prow + tile * 16 + 4 * g + r) * DP + 4 * j] = (f32x4){O[i][0][r], O[i][1][r], O[i][2][r], O[i][3][r]};
-      float li = l[i];
-      li += __shfl_xor(li, 16);
-      li += __shfl_xor(li, 32);
-      if (g == 0) {
-        a.Mpart[prow + tile * 16 + j] = m[i];
-        a.Lpart[prow + tile * 16 + j] = li;
-      }
-    }
-  }
-}
-
-bool attn_core_lds_eligible(const AttnCoreArgs &a) {
-  static const bool off = getenv("HN_NO_ATTN_LDS") != nullptr;      // development switch: the register-only kernels
-  auto al16 = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
-  return !off && a.dp == 64 && !a.ones_col && a.drop.thr == 0 && a.mask == nullptr && a.N >= 256 && a.ldk % 4 == 0 && a.ldv % 4 == 0 &&
-         a.k_b % 4 == 0 && a.k_h % 4 == 0 && a.v_b % 4 == 0 && a.v_h % 4 == 0 && a.ldq % 4 == 0 && a.q_b % 4 == 0 && a.q_h % 4 == 0 &&
-         al16(a.Kp) && al16(a.Vp) && al16(a.Q) && al16(a.Opart) && (a.Ofinal == nullptr || (a.dh % 4 == 0 && a.ldo % 4 == 0 && al16(a.Ofinal))) &&
-         ((long)a.N * a.ldk + DP) * 4 < (1L << 31) && ((long)a.N * a.ldv + DP) * 4 < (1L << 31);
-}
-
-int launch_attn_core_lds(const AttnCoreArgs &a, hipStream_t s) {
-  const int tiles = a.Lp / 16;
-  const int nq = tiles >= 8 ? 2 : 1;
-  const int ngroups = ceil_div(tiles, nq);
-  const int gy = ceil_div(ngroups, 4);
-  const long blocks = (long)a.nsplit * gy * a.b * a.h;
-  HN_REQUIRE(blocks < (1L << 31), HN_E_UNSUPPORTED, "attn_core_lds: grid too large");
-  // (the ring's pieces are dealt to FOUR waves: a workgroup always has four, the surplus ones only load)
-  if (nq == 2) hipLaunchKernelGGL(attn_core_lds_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, a, ngroups, gy, 4);
-  else hipLaunchKernelGGL(attn_core_lds_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, a, ngroups, gy, 4);
-  HN_LAUNCH_CHECK("attn_core_lds");
-  return HN_OK;
-}
 
 // ------------------------------------------------------------------------------------------------
 // dQ.  S^T = K Q^T and dP^T = V dO^T share the fragment shape (A = token rows from the ring, B = Q / dO fragments held in

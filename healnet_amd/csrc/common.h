@@ -455,9 +455,6 @@ struct AttnCoreArgs {
   int nq;                                       // query tiles per wave the token split was planned for (0: the kernel's default)
 };
 int launch_attn_core(const AttnCoreArgs &a, hipStream_t s);
-// explicit binding, dp = 64, on a workgroup-shared LDS ring of K / V tiles (attention_lds.hip)
-bool attn_core_lds_eligible(const AttnCoreArgs &a);
-int launch_attn_core_lds(const AttnCoreArgs &a, hipStream_t s);
 bool launch_qfold_mfma_bf16(const float *Q, int ldq_row, const float *w_k, int D, const float *gamma, float cscale, uint16_t *Qf,
                             int b, int h, int L, int Lp, int dh, hipStream_t s, float *bound, int *bound_flag);
 // small batches of the dp = 16 shared-context binding: fewer query tiles per wave (more work items) and at most 12 splits, so that
@@ -574,6 +571,7 @@ struct AttnBwdArgs {
 };
 int launch_pack_fold(float *x, int ld, int h, int D, int dp, int ks, int mode, long rows, hipStream_t s);
 int launch_attn_bwd_dq(const AttnBwdArgs &a, hipStream_t s);
+// explicit binding, dp = 64: dQ on a workgroup-shared LDS ring of K / V tiles (attention_lds.hip)
 bool attn_bwd_dq_lds_eligible(const AttnBwdArgs &a);
 int launch_attn_bwd_dq_lds(const AttnBwdArgs &a, hipStream_t s);
 int launch_dq_reduce(const float *part, int nsplit, int b, int h, int L, int Lp, int dp, int width, float scale, float *out,
