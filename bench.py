@@ -296,7 +296,7 @@ def train_step_record(dev, rank, world, distributed, barrier, steps, warmup):
     c = torch.randint(0, 2, (b,), generator=gen).to(dev)
     flat = hn.train.flatten_parameters(model)
     opt = hn.train.FusedL1Adam(flat, lr=1e-4, l1=1e-4)
-    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=1e-3, total_steps=2 * (steps + warmup) + 4)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=1e-3, total_steps=5 * (steps + warmup) + 8)
     sync = hdist.GradReadyAllReduce(model, flat)
 
     def step(overlap):
@@ -386,6 +386,25 @@ def train_step_record(dev, rank, world, distributed, barrier, steps, warmup):
         barrier()
     rec["forward_train_ms"] = round((time.perf_counter() - t0) / steps * 1e3, 4)
     sync.close()
+    # ---- the same step with its gradient half (zero_grad + forward + loss + backward) replayed as ONE HIP graph
+    # (healnet_amd.train.GraphedStep): what the step costs when the host enqueues one launch instead of ~450.  N = 1 only -- with more
+    # ranks the overlapped all-reduce is released from host callbacks inside the backward, which a capture cannot hold.
+    if not distributed:
+        gstep = hn.train.GraphedStep(model, lambda logits, yy, cc: hn.train.surv_nll_loss(logits, yy, cc).loss, list(ins), (y, c))
+
+        def graphed():
+            gstep(ins, (y, c))
+            opt.step()
+            sched.step()
+        for _ in range(warmup):
+            graphed()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            graphed()
+        barrier()
+        rec["graphed_ms_per_step"] = round((time.perf_counter() - t0) / steps * 1e3, 4)
+        gstep.close()
     return rec
 
 
@@ -436,7 +455,17 @@ def staged_models_record(dev, steps=15, warmup=3):
             step()
         torch.cuda.synchronize(dev)
         rec["configs"][name] = {"fwd_bwd_ms": round((time.perf_counter() - t0) / steps * 1e3, 4), "staged": bool(model.runs_staged())}
-        del model, flat
+        gstep = hn.train.GraphedStep(model, lambda out: out.sum(), list(ins), ())          # the same work as one graph replay
+        for _ in range(warmup):
+            gstep(ins)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            gstep(ins)
+        torch.cuda.synchronize(dev)
+        rec["configs"][name]["fwd_bwd_graphed_ms"] = round((time.perf_counter() - t0) / steps * 1e3, 4)
+        gstep.close()
+        del model, flat, gstep
     return rec
 
 

@@ -12,7 +12,7 @@ import sys
 from typing import Optional
 
 HN_MAX_AXES = 4
-HN_ABI_VERSION = 6
+HN_ABI_VERSION = 7
 HN_F32, HN_BF16, HN_U8 = 0, 1, 2
 HN_CORE_F32, HN_CORE_BF16, HN_CORE_BF16X3 = 0, 1, 2
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -25,7 +25,8 @@ c_float_p = C.POINTER(C.c_float)
 
 
 class Rng(C.Structure):
-    _fields_ = [("seed", C.c_uint64), ("offset", C.c_uint32), ("stream", C.c_uint32)]
+    _fields_ = [("seed", C.c_uint64), ("offset", C.c_uint32), ("stream", C.c_uint32),
+                ("offset_dev", C.c_void_p)]      # optional device word added to `offset` by the kernels (graph replays; ABI v7)
 
 
 class AttnParams(C.Structure):

@@ -50,7 +50,7 @@ KernelTimerScope::KernelTimerScope(const char *kernel, hipStream_t stream) : sto
 
 static inline DropCfg drop_off() { return make_drop(0.0f, 0, 0, 0); }
 static inline DropCfg drop_of(float p, const hn_rng &r, bool ff) {
-  return p > 0.0f ? make_drop(p, r.seed, r.offset, ff ? (r.stream | DROP_SID_FF) : (r.stream & ~DROP_SID_FF)) : drop_off();
+  return p > 0.0f ? make_drop(p, r.seed, r.offset, ff ? (r.stream | DROP_SID_FF) : (r.stream & ~DROP_SID_FF), r.offset_dev) : drop_off();
 }
 // development switches, read ONCE per process (no getenv on the launch path)
 static bool chain_disabled() { static const bool off = getenv("HN_NO_CHAIN") != nullptr; return off; }
@@ -1904,7 +1904,7 @@ static int impl_fusion_forward_train(const hn_model *m, const hn_modality_input 
     const float *xin = T + tp.x_off[k];
     float *xout = T + tp.x_off[k + 1];
     // dropout: one generator state per forward (hn_model.rng), one stream id per executed block (its step index)
-    const hn_rng rng = {m->rng.seed, m->rng.offset, (uint32_t)k};
+    const hn_rng rng = {m->rng.seed, m->rng.offset, (uint32_t)k, m->rng.offset_dev};
     if (staged && use_chain && !is_attn_t(st)) {       // a feed-forward block not absorbed by the chain of an attention block: a chain without a head
       const hn_ff_params &fq = st.kind == STEP_CROSS_FF ? m->cross_ff[st.layer * M + st.m] : m->self_ff[st.layer];
       if (chain_ff_aligned(&fq) && al16(xin) && al16(xout) && fq.w1 && fq.b1 && fq.w2 && fq.b2) {
@@ -1961,7 +1961,7 @@ static int impl_fusion_forward_train(const hn_model *m, const hn_modality_input 
       ca.has_ff = 1; ca.gate = fq.gate; ca.f_nw = fq.norm_w; ca.f_nb = fq.norm_b;
       ca.w1 = fq.w1; ca.b1 = fq.b1; ca.w2 = fq.w2; ca.b2 = fq.b2;
       {
-        const hn_rng rng_ff = {m->rng.seed, m->rng.offset, (uint32_t)(k + 1)};     // the feed-forward block's stream id: its step index
+        const hn_rng rng_ff = {m->rng.seed, m->rng.offset, (uint32_t)(k + 1), m->rng.offset_dev};     // the feed-forward block's stream id: its step index
         ca.ff_drop = drop_of(fq.dropout, rng_ff, true);
       }
       ca.x_mid = xout;
@@ -2158,7 +2158,7 @@ static int impl_fusion_backward(const hn_model *m, const hn_modality_input *in, 
       ca.w2T = transpose_cache_lookup(f.w2, 4 * d, d, 4 * d); ca.w1T = transpose_cache_lookup(f.w1, d, 8 * d, d);
       ca.H = cb.H; ca.dU = cb.dU; ca.Xhat = cb.Xhat; ca.dYff = cb.dYff;
       {
-        const hn_rng rng_ff = {m->rng.seed, m->rng.offset, (uint32_t)ff_k};      // the forward's generator state and stream id
+        const hn_rng rng_ff = {m->rng.seed, m->rng.offset, (uint32_t)ff_k, m->rng.offset_dev};      // the forward's generator state and stream id
         ca.ff_drop = drop_of(f.dropout, rng_ff, true);
       }
       add_product(cb.dU, 8 * d, 8 * d, cb.Xhat, d, d, fg->w1, d, fg->b1);
@@ -2182,7 +2182,7 @@ static int impl_fusion_backward(const hn_model *m, const hn_modality_input *in, 
   auto run_attn = [&](int k, const float *dpre, const float *dO_in, bool skip_wout) -> int {
     const Step &st = tp.steps[k];
     hn_attn_params ap = attn_of(st);
-    const hn_rng rng = {m->rng.seed, m->rng.offset, (uint32_t)k};      // the forward's generator state and stream id
+    const hn_rng rng = {m->rng.seed, m->rng.offset, (uint32_t)k, m->rng.offset_dev};      // the forward's generator state and stream id
     ap.rng = rng;
     const bool defer = attn_chainable(st, ap) && al16(T + tp.x_off[k]);
     AttnBwdExt ext;
@@ -2209,7 +2209,7 @@ static int impl_fusion_backward(const hn_model *m, const hn_modality_input *in, 
   for (int k = tp.nsteps - 1; k >= 0;) {
     const Step &st = tp.steps[k];
     const float *xin = T + tp.x_off[k];
-    const hn_rng rng = {m->rng.seed, m->rng.offset, (uint32_t)k};      // the forward's generator state and stream id
+    const hn_rng rng = {m->rng.seed, m->rng.offset, (uint32_t)k, m->rng.offset_dev};      // the forward's generator state and stream id
     if (!is_attn_b(st) && ff_chainable(ff_of_b(st), xin)) {
       bool has_out = false, o_on_tape = false;
       const float *o_saved = nullptr;

@@ -421,7 +421,7 @@ __global__ __launch_bounds__(512) void latent_bchain_kernel(const BChainArgs arg
       float4 G = lld4(lds, B_gs + row * XP + 4 * l32);
       if (d_thr != 0) {                      // the forward's dropout on the block output: the block proper sees G * keep / (1 - p)
         uint32_t w[4];
-        philox4x32(args.ff_drop.seed_lo, args.ff_drop.seed_hi, (uint32_t)l32, (uint32_t)(m0 + row), args.ff_drop.sid, args.ff_drop.offset, w);
+        philox4x32(args.ff_drop.seed_lo, args.ff_drop.seed_hi, (uint32_t)l32, (uint32_t)(m0 + row), args.ff_drop.sid, drop_counter(args.ff_drop), w);
         const float d_scale = args.ff_drop.scale;
         G.x = w[0] >= d_thr ? G.x * d_scale : 0.0f; G.y = w[1] >= d_thr ? G.y * d_scale : 0.0f;
         G.z = w[2] >= d_thr ? G.z * d_scale : 0.0f; G.w = w[3] >= d_thr ? G.w * d_scale : 0.0f;

@@ -521,7 +521,7 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
         const float4 f = lld4(lds, Ahat + row * CD + 4 * l32);
         float4 x = lld4(lds, xs + row * XP + 4 * l32);
         uint32_t w[4];
-        philox4x32(args.ff_drop.seed_lo, args.ff_drop.seed_hi, (uint32_t)l32, (uint32_t)(m0 + row), args.ff_drop.sid, args.ff_drop.offset, w);
+        philox4x32(args.ff_drop.seed_lo, args.ff_drop.seed_hi, (uint32_t)l32, (uint32_t)(m0 + row), args.ff_drop.sid, drop_counter(args.ff_drop), w);
         const float d_scale = args.ff_drop.scale;
         x.x += w[0] >= d_thr ? f.x * d_scale : 0.0f; x.y += w[1] >= d_thr ? f.y * d_scale : 0.0f;
         x.z += w[2] >= d_thr ? f.z * d_scale : 0.0f; x.w += w[3] >= d_thr ? f.w * d_scale : 0.0f;
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
         }
         if (d_thr != 0) {                    // dropout on the block output: every member draws the same mask
           uint32_t w[4];
-          philox4x32(args.ff_drop.seed_lo, args.ff_drop.seed_hi, (uint32_t)l32, (uint32_t)(m0 + row), args.ff_drop.sid, args.ff_drop.offset, w);
+          philox4x32(args.ff_drop.seed_lo, args.ff_drop.seed_hi, (uint32_t)l32, (uint32_t)(m0 + row), args.ff_drop.sid, drop_counter(args.ff_drop), w);
           const float d_scale = args.ff_drop.scale;
           x.x += w[0] >= d_thr ? f.x * d_scale : 0.0f; x.y += w[1] >= d_thr ? f.y * d_scale : 0.0f;
           x.z += w[2] >= d_thr ? f.z * d_scale : 0.0f; x.w += w[3] >= d_thr ? f.w * d_scale : 0.0f;

@@ -160,10 +160,14 @@ struct DropCfg {
   uint32_t thr;        // feed-forward: p * 2^32; attention: p * 2^16; 0 = dropout disabled
   float scale;         // 1 / (1 - p)
   uint32_t seed_lo, seed_hi, sid, offset;
+  const uint32_t *offset_dev;   // hn_rng.offset_dev: added to `offset` on the device (graph replays), or NULL
 };
-static inline DropCfg make_drop(float p, uint64_t seed, uint32_t offset, uint32_t sid) {
+// the counter word every Philox call of a launch uses (a wave-uniform scalar load when the device word is set)
+__device__ __forceinline__ uint32_t drop_counter(const DropCfg &d) { return d.offset_dev ? d.offset + *d.offset_dev : d.offset; }
+static inline DropCfg make_drop(float p, uint64_t seed, uint32_t offset, uint32_t sid, const uint32_t *offset_dev = nullptr) {
   DropCfg d;
   d.thr = 0; d.scale = 1.0f; d.seed_lo = (uint32_t)seed; d.seed_hi = (uint32_t)(seed >> 32); d.sid = sid; d.offset = offset;
+  d.offset_dev = offset_dev;
   if (p > 0.0f && (sid & DROP_SID_FF)) {
     double t = (double)p * 4294967296.0;
     d.thr = t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t;
@@ -196,7 +200,7 @@ __device__ __forceinline__ void philox4x32(uint32_t k0, uint32_t k1, uint32_t c0
 // multipliers (scale or 0) of the aligned quad (row, 4 * quad .. 4 * quad + 3)
 __device__ __forceinline__ void drop_quad(const DropCfg &d, uint32_t quad, uint32_t row, float (&m)[4]) {
   uint32_t w[4];
-  philox4x32(d.seed_lo, d.seed_hi, quad, row, d.sid, d.offset, w);
+  philox4x32(d.seed_lo, d.seed_hi, quad, row, d.sid, drop_counter(d), w);
 #pragma unroll
   for (int r = 0; r < 4; ++r) m[r] = w[r] >= d.thr ? d.scale : 0.0f;
 }
@@ -206,7 +210,7 @@ __device__ __forceinline__ void drop_quad(const DropCfg &d, uint32_t quad, uint3
 // high half: one shift and two compares per pair of elements)
 __device__ __forceinline__ void drop_pair(const DropCfg &d, uint32_t quad, uint32_t row, bool (&lo)[4], bool (&hi)[4]) {
   uint32_t w[4];
-  philox4x32(d.seed_lo, d.seed_hi, quad, row, d.sid, d.offset, w);
+  philox4x32(d.seed_lo, d.seed_hi, quad, row, d.sid, drop_counter(d), w);
   const uint32_t th = d.thr << 16;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -217,7 +221,7 @@ __device__ __forceinline__ void drop_pair(const DropCfg &d, uint32_t quad, uint3
 // one row of a pair (any row): its own half of the pair's call
 __device__ __forceinline__ void drop_quad_attn(const DropCfg &d, uint32_t quad, uint32_t row, bool (&keep)[4]) {
   uint32_t w[4];
-  philox4x32(d.seed_lo, d.seed_hi, quad, row & ~16u, d.sid, d.offset, w);
+  philox4x32(d.seed_lo, d.seed_hi, quad, row & ~16u, d.sid, drop_counter(d), w);
   const uint32_t sh = row & 16u;               // 0: low halves, 16: high halves
 #pragma unroll
   for (int r = 0; r < 4; ++r) keep[r] = ((w[r] >> sh) & 0xffffu) >= d.thr;
@@ -225,7 +229,7 @@ __device__ __forceinline__ void drop_quad_attn(const DropCfg &d, uint32_t quad, 
 __device__ __forceinline__ float drop_one(const DropCfg &d, uint32_t col, uint32_t row) {
   uint32_t w[4];
   const bool ff = (d.sid & DROP_SID_FF) != 0;
-  philox4x32(d.seed_lo, d.seed_hi, col >> 2, ff ? row : (row & ~16u), d.sid, d.offset, w);
+  philox4x32(d.seed_lo, d.seed_hi, col >> 2, ff ? row : (row & ~16u), d.sid, drop_counter(d), w);
   const uint32_t c = col & 3;
   uint32_t v = c == 0 ? w[0] : (c == 1 ? w[1] : (c == 2 ? w[2] : w[3]));
   if (!ff) v = (v >> (row & 16u)) & 0xffffu;
@@ -238,7 +242,7 @@ __device__ __forceinline__ float drop_one(const DropCfg &d, uint32_t col, uint32
 // (attention masks: the call of row row0 + e is the one of its pair, every row picks its own half)
 __device__ __forceinline__ void drop_quad_transposed(const DropCfg &d, uint32_t quad, uint32_t row0, uint32_t e, float (&m)[4]) {
   uint32_t w[4];
-  philox4x32(d.seed_lo, d.seed_hi, quad, (row0 + e) & ~16u, d.sid, d.offset, w);
+  philox4x32(d.seed_lo, d.seed_hi, quad, (row0 + e) & ~16u, d.sid, drop_counter(d), w);
 #define HN_QUAD_BCAST(v, r) (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (r) * 0x55, 0xf, 0xf, true)
 #define HN_QUAD_WORD(r)                                                                                          \
   {                                                                                                              \

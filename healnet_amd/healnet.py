@@ -631,7 +631,8 @@ class HealNet(nn.Module):
             if dropping:
                 self._rng_offset = (self._rng_offset + 1) & 0xFFFFFFFF
                 rng = (torch.initial_seed(), self._rng_offset)
-                rng_t = torch.tensor([_wrap64(rng[0]), rng[1]], dtype=torch.int64)
+                word = self.__dict__.get("_hn_rng_word")      # healnet_amd.train.GraphedStep: the device word added to the offset
+                rng_t = torch.tensor([_wrap64(rng[0]), rng[1]] + ([word.data_ptr()] if word is not None else []), dtype=torch.int64)
             self._last_rng = rng
             # healnet_amd.train.flatten_parameters(): every p.grad is a view of one flat buffer -> the backward accumulates
             # straight into it (no per-parameter zero tensors, no AccumulateGrad pass) and autograd gets None back

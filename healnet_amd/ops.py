@@ -76,6 +76,12 @@ _FAKE_PTR = 256          # stands in for device addresses while tracing with Fak
 # ------------------------------------------------------------------------------------------------
 # model structure <-> C descriptors
 # ------------------------------------------------------------------------------------------------
+def _rng_dev(rng: torch.Tensor):
+    """The generator state travels as a CPU int64 tensor [seed, offset] or [seed, offset, address of a device uint32 word]: the
+    third entry is hn_rng.offset_dev (healnet_amd.train.GraphedStep keeps the word alive and advances it between replays)."""
+    return (int(rng[2]) or None) if rng.numel() > 2 else None
+
+
 class Spec:
     """Parsed ``spec`` string of the fusion ops: the structure of a HealNet (sizes, per-block head counts / dropout rates, and
     for every pointer field of hn_model the index of the tensor in ``params`` that backs it -- tied blocks simply repeat
@@ -139,9 +145,9 @@ class Spec:
         hp = d["head_p"] if self.head else [None] * 4
         if rng is not None:
             seed, offset = int(rng[0]) & 0xFFFFFFFFFFFFFFFF, int(rng[1]) & 0xFFFFFFFF
-            r = _capi.Rng(seed=seed, offset=offset, stream=0)
+            r = _capi.Rng(seed=seed, offset=offset, stream=0, offset_dev=_rng_dev(rng))
         else:
-            r = _capi.Rng(0, 0, 0)
+            r = _capi.Rng(0, 0, 0, None)
         model = _capi.Model(
             n_modalities=M, depth=depth, l_c=self.l_c, l_d=self.l_d, self_per_cross_attn=self.spca,
             final_classifier_head=int(self.head), out_dims=self.out_dims, num_freq_bands=d["num_freq_bands"],
@@ -201,6 +207,7 @@ class Spec:
             hit = cache[key] = self.model(params, rng)
         model = hit[0]
         model.rng.seed, model.rng.offset = int(rng[0]) & 0xFFFFFFFFFFFFFFFF, int(rng[1]) & 0xFFFFFFFF
+        model.rng.offset_dev = _rng_dev(rng)
         return hit
 
     def grads_cached(self, gptr: Sequence[Optional[int]]):

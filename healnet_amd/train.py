@@ -230,3 +230,79 @@ class FusedL1Adam(torch.optim.Optimizer):
                                                 st["step"], self.reg_loss.data_ptr(), self._ws.data_ptr(), self._ws.numel(),
                                                 _stream(f.params.device)), "hn_l1_adam_step")
         return loss
+
+
+class GraphedStep:
+    """The gradient half of a training step -- zero the flat gradients, tape-recording forward, loss, fused backward -- captured ONCE
+    into a HIP graph and replayed with one launch (SURVEY.md 8 f; serves the loop body of healnet/main.py:425-467).
+
+    Why: the step of a patch-bag model is ~450 kernel launches behind two operator calls.  At BASELINE configs[3] the host needs
+    3.8-4.9 ms to enqueue what the GPU runs in 5.5 ms, so on a slow or busy host the step stretches to 6.2-6.8 ms; at the reference's
+    tuned TCGA shapes (~90 launches of 5-50 us) the step is host-bound outright.  A replay costs ~0.06 ms of host time.
+
+        flat = healnet_amd.train.flatten_parameters(model)
+        opt = healnet_amd.train.FusedL1Adam(flat, ...)
+        step = healnet_amd.train.GraphedStep(model, lambda logits, y, c: surv_nll_loss(logits, y, c).loss, [omic, wsi], (y, c))
+        for omic, wsi, y, c in loader:
+            loss, logits = step([omic, wsi], (y, c))      # gradients are in flat.grads; loss / logits are the graph's static outputs
+            opt.step()
+
+    * Inputs and loss arguments are copied into static device buffers (same shapes and dtypes as the examples); parameters are read
+      in place, so optimizer updates are seen.  The model must have been through ``flatten_parameters`` (the backward then
+      accumulates into one static buffer and autograd allocates nothing).
+    * Dropout: a captured launch bakes the Philox offset into its kernel arguments, so every replay would draw the SAME masks.  The
+      model therefore hands its kernels a device word (``hn_rng.offset_dev``) that is added to the offset on the device, and the
+      graph's first node increments it: every replay draws fresh masks, forward and backward of one replay the same ones.
+    * ``loss_fn(output, *loss_args)`` must return a scalar tensor and may only use capture-safe operations (no ``.item()``, no
+      host synchronisation)."""
+
+    def __init__(self, model: torch.nn.Module, loss_fn, example_inputs: Sequence[Optional[torch.Tensor]], loss_args: Sequence[torch.Tensor] = (),
+                 mask: Optional[torch.Tensor] = None, warmup: int = 3):
+        flat = model.__dict__.get("_hn_flat")
+        if flat is None:
+            raise ValueError("GraphedStep needs healnet_amd.train.flatten_parameters(model) first (static gradient buffer)")
+        dev = flat.grads.device
+        self.model, self.flat, self.loss_fn = model, flat, loss_fn
+        self.inputs = [None if t is None else t.detach().to(dev).clone() for t in example_inputs]
+        self.loss_args = [t.detach().to(dev).clone() for t in loss_args]
+        self.mask = None if mask is None else mask.detach().to(dev).clone()
+        # the device word of the dropout generator (harmless without dropout); kept on the model so that its forward passes it on
+        self.word = torch.zeros(1, dtype=torch.int32, device=dev)
+        model.__dict__["_hn_rng_word"] = self.word
+
+        def body():
+            self.word.add_(1)
+            flat.zero_grad()
+            out = model(list(self.inputs), mask=self.mask)
+            loss = loss_fn(out, *self.loss_args)
+            loss.backward()
+            return loss.detach(), out.detach()
+
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):          # allocator, workspaces, descriptor caches and the autograd thread's state settle
+                body()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss, self.output = body()
+
+    def __call__(self, inputs: Sequence[Optional[torch.Tensor]], loss_args: Sequence[torch.Tensor] = (), mask: Optional[torch.Tensor] = None):
+        for dst, src in zip(self.inputs, inputs):
+            if (dst is None) != (src is None):
+                raise ValueError("GraphedStep: the set of present modalities is part of the captured graph")
+            if dst is not None:
+                if dst.shape != src.shape or dst.dtype != src.dtype:
+                    raise ValueError(f"GraphedStep: captured for {tuple(dst.shape)} {dst.dtype}, got {tuple(src.shape)} {src.dtype}")
+                dst.copy_(src, non_blocking=True)
+        for dst, src in zip(self.loss_args, loss_args):
+            dst.copy_(src, non_blocking=True)
+        if self.mask is not None and mask is not None:
+            self.mask.copy_(mask, non_blocking=True)
+        self.graph.replay()
+        return self.loss, self.output
+
+    def close(self) -> None:
+        """Detach from the model (its eager forwards go back to host-advanced offsets only)."""
+        self.model.__dict__.pop("_hn_rng_word", None)

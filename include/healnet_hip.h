@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HN_ABI_VERSION 6
+#define HN_ABI_VERSION 7
 #define HN_MAX_AXES 4
 
 typedef enum hn_status {
@@ -108,6 +108,9 @@ typedef struct hn_rng {
   uint64_t seed;
   uint32_t offset;
   uint32_t stream;
+  const uint32_t *offset_dev;   /* optional (ABI v7): a DEVICE word added to `offset` by every mask-drawing kernel when it runs -- a
+                                 * training step captured into a HIP graph bakes `offset` into its kernel arguments, so the host
+                                 * advances this word between replays instead (healnet_amd.train.GraphedStep); NULL = none */
 } hn_rng;
 
 typedef struct hn_attn_params {

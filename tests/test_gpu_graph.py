@@ -121,3 +121,80 @@ def test_cached_descriptor_follows_rehomed_parameters(hn):
         c = model([t.to(DEV) for t in ins])
     assert torch.equal(c, b_)
     assert flat.numel > 0
+
+
+# ------------------------------------------------------------------------------------------------
+# healnet_amd.train.GraphedStep: zero_grad + tape forward + loss + fused backward as ONE graph replay (round 4)
+# ------------------------------------------------------------------------------------------------
+def _bag_model(hn, dropout):
+    kw = dict(n_modalities=2, channel_dims=[40, 96], num_spatial_axes=[1, 1], out_dims=4, depth=2)
+    if dropout:      # one of the reference's tuned shapes in small: odd latent width, one narrow cross head, both dropouts on (staged route)
+        kw.update(l_c=17, l_d=62, x_heads=1, cross_dim_head=27, l_heads=8, latent_dim_head=16, self_per_cross_attn=0,
+                  attn_dropout=0.3, ff_dropout=0.2)
+    torch.manual_seed(31)
+    model = hn.HealNet(**kw).train().to(DEV)
+    flat = hn.train.flatten_parameters(model)
+    return model, flat
+
+
+def _batch(gen, b=4):
+    return ([torch.rand(b, 1, 40, generator=gen).to(DEV), torch.rand(b, 300, 96, generator=gen).to(DEV)],
+            (torch.randint(0, 4, (b,), generator=gen).to(DEV), torch.randint(0, 2, (b,), generator=gen).to(DEV)))
+
+
+def _loss(hn):
+    return lambda logits, y, c: hn.train.surv_nll_loss(logits, y, c).loss
+
+
+def test_graphed_step_equals_eager_bit_for_bit(hn):
+    model, flat = _bag_model(hn, dropout=False)
+    gen = torch.Generator().manual_seed(32)
+    ins, la = _batch(gen)
+    step = hn.train.GraphedStep(model, _loss(hn), ins, la)
+    for trial in range(3):
+        ins, la = _batch(gen)                                 # new VALUES of the captured shapes
+        loss_g, out_g = step(ins, la)
+        loss_g, out_g, grads_g = loss_g.clone(), out_g.clone(), flat.grads.clone()
+        flat.zero_grad()
+        out_e = model(list(ins))
+        loss_e = _loss(hn)(out_e, *la)
+        loss_e.backward()
+        assert torch.equal(out_g, out_e.detach()) and torch.equal(loss_g, loss_e.detach()), trial
+        assert torch.equal(grads_g, flat.grads), f"trial {trial}: replayed gradients differ from the eager step"
+        with torch.no_grad():                                 # parameters are read in place: an update is seen by the next replay
+            flat.params.mul_(1.0 + 1e-3 * (trial + 1))
+    with pytest.raises(ValueError, match="captured for"):
+        step([ins[0], ins[1][:, :100]], la)
+    with pytest.raises(ValueError, match="flatten_parameters"):
+        hn.train.GraphedStep(hn.HealNet(n_modalities=1, channel_dims=[8], num_spatial_axes=[1], out_dims=2, depth=1).train().to(DEV),
+                             _loss(hn), [torch.rand(2, 1, 8, device=DEV)], ())
+
+
+def test_graphed_step_draws_fresh_dropout_masks(hn):
+    """A captured launch bakes the Philox offset into its arguments; the device word (hn_rng.offset_dev) the graph increments makes
+    every replay draw new masks, and a replay is reproduced bit for bit by an eager step run at the same counter."""
+    model, flat = _bag_model(hn, dropout=True)
+    assert model.runs_staged()
+    gen = torch.Generator().manual_seed(33)
+    ins, la = _batch(gen)
+    step = hn.train.GraphedStep(model, _loss(hn), ins, la)
+    baked = model._rng_offset                                 # the offset the capture baked into the graph
+    losses, grads = [], []
+    for _ in range(4):
+        loss, _ = step(ins, la)
+        losses.append(float(loss))
+        grads.append(flat.grads.clone())
+    assert len(set(losses)) == 4, f"replays repeated a mask: {losses}"
+    assert not torch.equal(grads[0], grads[1])
+    # same inputs, same counter -> same masks: eager with (offset = baked, word = w) must equal the replay that ran at word w
+    w = int(step.word.item())
+    loss_g, _ = step(ins, la)                                 # runs at word w + 1
+    loss_g, grads_g = float(loss_g), flat.grads.clone()
+    model._rng_offset = baked - 1                             # the eager forward advances it to `baked`
+    flat.zero_grad()
+    loss_e = _loss(hn)(model(list(ins)), *la)                 # word is w + 1 now
+    loss_e.backward()
+    assert int(step.word.item()) == w + 1
+    assert float(loss_e) == loss_g and torch.equal(flat.grads, grads_g)
+    step.close()
+    assert "_hn_rng_word" not in model.__dict__
