@@ -400,12 +400,17 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float *__rest
                                                              float *__restrict__ C, long ldc, float alpha, int accumulate,
                                                              const float *__restrict__ cs_part, float *__restrict__ cs_out, int cs_accumulate) {
   const int m = blockIdx.y;
-  if (m == M) {                                             // column sums: nsplit * 8 row-group partials per column
-    for (int c = blockIdx.x * 256 + threadIdx.x; c < M; c += gridDim.x * 256) {
-      float acc = 0.0f;
-      for (int k = 0; k < nsplit * 8; ++k) acc += cs_part[(long)k * M + c];
-      cs_out[c] = cs_accumulate ? cs_out[c] + acc : acc;
+  if (m >= M) {                                             // column sums: nsplit * 8 row-group partials per column, 256 columns per row of
+    const int c = (m - M) * 256 + threadIdx.x;              // blocks, eight independent chains per thread (fixed order)
+    if (blockIdx.x != 0 || c >= M) return;
+    float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int np = nsplit * 8;
+    for (int k = 0; k < np; k += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a8[u] += cs_part[(long)(k + u) * M + c];
     }
+    const float acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+    cs_out[c] = cs_accumulate ? cs_out[c] + acc : acc;
     return;
   }
   const int n = (blockIdx.x * 256 + threadIdx.x) * 4;
@@ -427,7 +432,7 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float *__rest
 }
 
 bool gemm_tn_glds_eligible(const float *A, long lda, const float *B, long ldb, int M, int N, int K) {
-  return K >= 4096 && M >= 128 && M < 65535 && N >= 112 && M % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 &&
+  return K >= 4096 && M >= 128 && M < 65000 && N >= 112 && M % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 &&
          (long)K * lda * 4 < (1L << 31) && (long)K * ldb * 4 < (1L << 31);
 }
 
@@ -467,7 +472,7 @@ int launch_gemm_tn_glds(const float *A, long lda, const float *B, long ldb, floa
   (void)variant;
   }
   HN_LAUNCH_CHECK("gemm_tn_glds");
-  hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)ceil_div(ceil_div(N, 4), 256), (unsigned)(M + (colsum ? 1 : 0))), dim3(256), 0, s,
+  hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)ceil_div(ceil_div(N, 4), 256), (unsigned)(M + (colsum ? ceil_div(M, 256) : 0))), dim3(256), 0, s,
                      scratch, g.nsplit, M, N, g.ldp, C, ldc, alpha, accumulate, g.cs_part, colsum, colsum_accumulate);
   HN_LAUNCH_CHECK("gemm_tn_reduce");
   return HN_OK;
