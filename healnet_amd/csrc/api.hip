@@ -150,7 +150,7 @@ static int plan_attn(const hn_attn_params *p, bool has_ctx, int ld_ctx, int b, i
   }
   pl->ctx16 = nullptr;
   {
-    const size_t w16 = gemm_bf16_stage_floats(2 * pl->inner, pl->D), w32 = gemm_nt_stage_floats(2 * pl->inner, pl->D);
+    const size_t w16 = gemm_bf16_stage_floats(2 * pl->inner, pl->D), w32 = gemm_nt_stage_floats(2 * p->heads * pl->dhp, pl->D);
     pl->wstage = (has_ctx && !pl->rank_d && pl->N > 1) ? ar.take<float>(w16 > w32 ? w16 : w32) : nullptr;
   }
   const size_t prow = (size_t)b * p->heads * pl->nsplit * pl->Lp;
@@ -251,11 +251,15 @@ static int attn_prepare(const hn_attn_params *p, const AttnPlan &pl, const float
     HN_REQUIRE(!(ext && ext->kv_done) || kv_ext, HN_E_SHAPE, "attn: external K/V projections exist for latent self-attention only");
     float *kvbuf = kv_tape ? kv_tape : (kv_ext ? ext->kv : ((ext && ext->kv_home && !ctx) ? ext->kv_home : pl.kv));
     if (kv_ext) kv_ready = true;
+    static const bool no_glds = getenv("HN_NO_GLDS_GEMM") != nullptr;      // development switch: gemm_big_kernel / gemm_tall_narrow
+    // the LDS-DMA projection lays the padded head width out itself (pad columns = 0): no fill in front of it
+    const bool kv_nt = ctx && !kv_ready && !pl.ctx16 && pl.wstage && !no_glds &&
+                       gemm_nt_eligible((long)b * pl.N, 2 * pl.inner, pl.D, ld_ctx, ctx, pl.dh, pl.dhp, kvpitch, kvbuf);
     if (pl.dhp != pl.dh) {
       // (projections found ready with a padded head width were written by this block's own forward into its tape slot, pad
       // columns included: the chain only projects for dim_head in {16, 32, 64, 128})
       if (!q_done) { int rc_ = launch_fill(qbuf, 0.0f, (long)((size_t)rows * qpitch), s); if (rc_ != HN_OK) return rc_; }
-      if (!kv_ready) { int rc_ = launch_fill(kvbuf, 0.0f, (long)((size_t)b * pl.N * kvpitch), s); if (rc_ != HN_OK) return rc_; }
+      if (!kv_ready && !kv_nt) { int rc_ = launch_fill(kvbuf, 0.0f, (long)((size_t)b * pl.N * kvpitch), s); if (rc_ != HN_OK) return rc_; }
     }
     gq.C = qbuf; gq.ldc = qpitch; gq.alpha = pl.cscale;
     gq.col_group = pl.dh; gq.col_group_pitch = pl.dhp;
@@ -278,17 +282,18 @@ static int attn_prepare(const hn_attn_params *p, const AttnPlan &pl, const float
       gk.W = p->w_kv; gk.ldw = pl.D;
       gk.N = 2 * pl.inner;
       gk.C = kvbuf; gk.ldc = kvpitch; gk.col_group = pl.dh; gk.col_group_pitch = pl.dhp;
-      static const bool no_glds = getenv("HN_NO_GLDS_GEMM") != nullptr;      // development switch: gemm_big_kernel
       if (ctx && pl.ctx16 && pl.wstage && gemm_bf16_eligible(gk)) rc = launch_gemm_bf16(gk, pl.ctx16, pl.wstage, s);
       else if (ctx && pl.wstage && !no_glds && gk.pro != PRO_LAYERNORM &&
                gemm_nt_eligible(gk.M, gk.N, gk.K, gk.lda, gk.A, gk.col_group, gk.col_group_pitch, gk.ldc, gk.C)) {
-        // patch-bag K/V projection: LayerNorm affine folded into the staged weight, operands by LDS-DMA (gemm_nt.hip)
-        float *ws_w = pl.wstage, *ws_b = pl.wstage + (size_t)gk.N * gemm_nt_ldws(gk.K);
+        // patch-bag K/V projection: LayerNorm affine folded into the staged weight, operands by LDS-DMA (gemm_nt.hip); a padded head
+        // width is laid out by the staging, so the product writes dense rows (pad columns = 0) and needs no fill in front
+        const int np = gemm_nt_padded_cols(gk.N, gk.col_group, gk.col_group_pitch);
+        float *ws_w = pl.wstage, *ws_b = pl.wstage + (size_t)np * gemm_nt_ldws(gk.K);
         if ((rc = launch_gemm_nt_stage(gk.W, gk.ldw, gk.pro == PRO_AFFINE ? gk.gamma : nullptr, gk.pro == PRO_AFFINE ? gk.beta : nullptr, nullptr,
-                                       gk.N, gk.K, ws_w, ws_b, s)) != HN_OK) return rc;
+                                       gk.N, gk.K, ws_w, ws_b, s, gk.col_group, gk.col_group_pitch)) != HN_OK) return rc;
         GemmNtArgs gn;
         gn.A = gk.A; gn.lda = gk.lda; gn.W = ws_w; gn.ldw = gemm_nt_ldws(gk.K); gn.bias = ws_b; gn.C = gk.C; gn.ldc = gk.ldc;
-        gn.M = gk.M; gn.N = gk.N; gn.K = gk.K; gn.alpha = 1.0f; gn.col_group = gk.col_group; gn.col_group_pitch = gk.col_group_pitch;
+        gn.M = gk.M; gn.N = np; gn.K = gk.K; gn.alpha = 1.0f; gn.col_group = 0; gn.col_group_pitch = 0;
         gn.ntm = gn.ntn = 0;
         rc = launch_gemm_nt(gn, 0, s);
       } else rc = launch_gemm(gk, s);

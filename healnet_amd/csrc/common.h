@@ -287,8 +287,11 @@ struct GemmNtArgs {
 bool gemm_nt_eligible(long M, int N, int K, long lda, const float *A, int col_group, int col_group_pitch, long ldc, const float *C);
 int gemm_nt_ldws(int K);
 size_t gemm_nt_stage_floats(int N, int K);
+int gemm_nt_padded_cols(int N, int col_group, int col_group_pitch);
+// col_group > 0: the staged image is head re-pitched (pitch rows per group of col_group source rows, pads zero): run the GEMM
+// behind it with N = gemm_nt_padded_cols(...) and no column mapping
 int launch_gemm_nt_stage(const float *W, long ldw, const float *gamma, const float *beta, const float *bias, int N, int K, float *Ws,
-                         float *bs, hipStream_t s);
+                         float *bs, hipStream_t s, int col_group = 0, int col_group_pitch = 0);
 int launch_gemm_nt(const GemmNtArgs &g, int variant, hipStream_t s);
 // long-contraction TN product C (+)= alpha * A^T B (+ colsum of A) on LDS-DMA staged k-tiles (gemm_nt.hip): G = dKV^T z of a patch bag
 bool gemm_tn_glds_eligible(const float *A, long lda, const float *B, long ldb, int M, int N, int K);

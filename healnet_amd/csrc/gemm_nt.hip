@@ -40,14 +40,27 @@ __device__ __forceinline__ unsigned lds_byte_address(const float *p) {
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// Ws[n, k] = W[n, k] * gamma[k] for k < K, 0 for K <= k < ldws;  bs[n] = sum_k W[n, k] * beta[k] (+ bias[n]).  One wave per row.
+// Ws[n', k] = W[n, k] * gamma[k] for k < K, 0 for K <= k < ldws;  bs[n'] = sum_k W[n, k] * beta[k] (+ bias[n]).  One wave per row.
+// Head re-pitching happens HERE: with col_group > 0 the staged image has col_group_pitch rows per group of col_group source rows
+// (n' = (n / col_group) * pitch + n % col_group; the pad rows and their bias entries are zero), so the GEMM behind it writes a
+// dense, 16-byte aligned row whatever the head width (27, 63, 103: the reference's tuned shapes) and the pad columns of K / V
+// come out as zeros without a fill launch.
 __global__ __launch_bounds__(256) void gemm_nt_stage_kernel(const float *__restrict__ W, long ldw, const float *__restrict__ gamma,
-                                                            const float *__restrict__ beta, const float *__restrict__ bias, int N, int K,
-                                                            float *__restrict__ Ws, int ldws, float *__restrict__ bs) {
-  const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (n >= N) return;
+                                                            const float *__restrict__ beta, const float *__restrict__ bias, int Np, int K,
+                                                            float *__restrict__ Ws, int ldws, float *__restrict__ bs, int col_group,
+                                                            int col_group_pitch) {
+  const int lane = threadIdx.x & 63, np = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (np >= Np) return;
+  int n = np;
+  bool pad = false;
+  if (col_group > 0) { const int c = np % col_group_pitch; pad = c >= col_group; n = (np / col_group_pitch) * col_group + (pad ? 0 : c); }
+  if (pad) {
+    for (int k = lane; k < ldws; k += 64) Ws[(long)np * ldws + k] = 0.0f;
+    if (lane == 0) bs[np] = 0.0f;
+    return;
+  }
   const float *w = W + (long)n * ldw;
-  float *o = Ws + (long)n * ldws;
+  float *o = Ws + (long)np * ldws;
   float acc = 0.0f;
   // four column groups of 64 per trip, their loads issued together (one dependent round trip per 256 columns instead of per 64)
   for (int k0 = 0; k0 < ldws; k0 += 256) {
@@ -68,7 +81,7 @@ __global__ __launch_bounds__(256) void gemm_nt_stage_kernel(const float *__restr
   }
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d);
-  if (lane == 0) bs[n] = acc + (bias ? bias[n] : 0.0f);
+  if (lane == 0) bs[np] = acc + (bias ? bias[n] : 0.0f);
 }
 
 // ABL: development ablations (tools/ubench/gemm_f32_bench.hip): 1 = no output stores, 2 = no operand loads behind the prologue,
@@ -478,10 +491,13 @@ int launch_gemm_tn_glds(const float *A, long lda, const float *B, long ldb, floa
   return HN_OK;
 }
 
+// N = output columns of the SOURCE weight; with col_group > 0 the staged / written width is gemm_nt_padded_cols(N, ...)
 bool gemm_nt_eligible(long M, int N, int K, long lda, const float *A, int col_group, int col_group_pitch, long ldc, const float *C) {
-  return M >= 2048 && N >= 256 && N % 4 == 0 && K >= 64 && lda % 4 == 0 && lda >= K && ((uintptr_t)A & 15) == 0 && ldc % 4 == 0 &&
-         ((uintptr_t)C & 15) == 0 && (col_group == 0 || (col_group % 4 == 0 && col_group_pitch % 4 == 0));
+  const int np = gemm_nt_padded_cols(N, col_group, col_group_pitch);
+  return M >= 2048 && np >= 32 && np % 4 == 0 && K >= 64 && lda % 4 == 0 && lda >= K && ((uintptr_t)A & 15) == 0 && ldc % 4 == 0 &&
+         ((uintptr_t)C & 15) == 0 && (col_group == 0 || (N % col_group == 0 && col_group_pitch >= col_group));
 }
+int gemm_nt_padded_cols(int N, int col_group, int col_group_pitch) { return col_group > 0 ? N / col_group * col_group_pitch : N; }
 int gemm_nt_ldws(int K) { return (K + 15) / 16 * 16; }
 size_t gemm_nt_stage_floats(int N, int K) { return (size_t)N * gemm_nt_ldws(K) + (size_t)(N + 63) / 64 * 64 + 64; }
 
@@ -493,13 +509,20 @@ int launch_gemm_nt(const GemmNtArgs &g_in, int variant, hipStream_t s) {
   GemmNtArgs g = g_in;
   HN_REQUIRE(g.A && g.W && g.C, HN_E_NULL, "gemm_nt: NULL operand");
   HN_REQUIRE(g.ldw % 4 == 0 && g.ldw >= gemm_nt_ldws(g.K) && ((uintptr_t)g.W & 15) == 0, HN_E_SHAPE, "gemm_nt: staged weight pitch %ld", g.ldw);
-  const int bm = (variant >= 2 && variant <= 4) ? 256 : 128, bn = variant == 4 ? 256 : 128;
+  if (variant == 0 && g.N <= 128) variant = g.N <= 32 ? 20 : (g.N <= 64 ? 21 : 22);      // narrow outputs: the streaming tilings
+  int bm = (variant >= 2 && variant <= 4) ? 256 : 128, bn = variant == 4 ? 256 : 128;
+  if (variant >= 20 && variant <= 22) { bm = 64; bn = 32 << (variant - 20); }
   g.ntm = ceil_div(g.M, bm); g.ntn = ceil_div(g.N, bn);
   const long blocks = (long)ceil_div(g.ntm, 8) * 8 * g.ntn;
   HN_REQUIRE(blocks < (1L << 31), HN_E_UNSUPPORTED, "gemm_nt: grid too large");
   KernelTimerScope timer("gemm_nt_glds", s);
   switch (variant) {
     case 0: hipLaunchKernelGGL((gemm_nt_glds_kernel<4, 4, 2, 2, 2>), dim3((unsigned)blocks), dim3(256), 0, s, g); break;
+    // narrow outputs (one 16 .. 64-wide head: 2 * dhp = 32 / 64 / 128 columns): an HBM stream of the context, not a matrix problem --
+    // 64-row tiles (two to three workgroups per CU) and four ring slots keep ~100 KB per CU in flight
+    case 20: hipLaunchKernelGGL((gemm_nt_glds_kernel<2, 1, 2, 2, 4>), dim3((unsigned)blocks), dim3(256), 0, s, g); break;
+    case 21: hipLaunchKernelGGL((gemm_nt_glds_kernel<2, 2, 2, 2, 4>), dim3((unsigned)blocks), dim3(256), 0, s, g); break;
+    case 22: hipLaunchKernelGGL((gemm_nt_glds_kernel<2, 4, 2, 2, 3>), dim3((unsigned)blocks), dim3(256), 0, s, g); break;
 #ifdef HN_GEMM_NT_BENCH
     case 1: hipLaunchKernelGGL((gemm_nt_glds_kernel<4, 4, 2, 2, 3>), dim3((unsigned)blocks), dim3(256), 0, s, g); break;
     case 2: hipLaunchKernelGGL((gemm_nt_glds_kernel<4, 4, 4, 2, 2>), dim3((unsigned)blocks), dim3(512), 0, s, g); break;
@@ -517,8 +540,10 @@ int launch_gemm_nt(const GemmNtArgs &g_in, int variant, hipStream_t s) {
 }
 
 int launch_gemm_nt_stage(const float *W, long ldw, const float *gamma, const float *beta, const float *bias, int N, int K, float *Ws,
-                         float *bs, hipStream_t s) {
-  hipLaunchKernelGGL(gemm_nt_stage_kernel, dim3(ceil_div(N, 4)), dim3(256), 0, s, W, ldw, gamma, beta, bias, N, K, Ws, gemm_nt_ldws(K), bs);
+                         float *bs, hipStream_t s, int col_group, int col_group_pitch) {
+  const int np = gemm_nt_padded_cols(N, col_group, col_group_pitch);
+  hipLaunchKernelGGL(gemm_nt_stage_kernel, dim3(ceil_div(np, 4)), dim3(256), 0, s, W, ldw, gamma, beta, bias, np, K, Ws, gemm_nt_ldws(K), bs,
+                     col_group, col_group_pitch);
   HN_LAUNCH_CHECK("gemm_nt_stage");
   return HN_OK;
 }

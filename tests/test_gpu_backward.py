@@ -183,6 +183,12 @@ ATTN_CASES = [
     dict(b=2, L=128, N=2300, D=141, heads=2, dh=64, qd=128, nan_pad=True),
     dict(b=1, L=32, N=4200, D=773, heads=8, dh=64, qd=128, nan_pad=True),       # one bag of cfg4's width, ragged rows (4200 = 32 * 128 + 104)
     dict(b=2, L=16, N=2100, D=96, heads=4, dh=64, qd=32, norm=False),           # no context LayerNorm: the weight is staged without the affine
+    # narrow-output LDS-DMA projections (gemm_nt variants 20-22) with the head width re-pitched by the weight staging: the
+    # reference's tuned one-head TCGA shapes (dim_head 63 / 27 / 103 / 16)
+    dict(b=2, L=17, N=1500, D=773, heads=1, dh=63, qd=19, nan_pad=True),
+    dict(b=2, L=24, N=1100, D=131, heads=1, dh=103, qd=33, nan_pad=True),
+    dict(b=1, L=16, N=2050, D=65, heads=2, dh=27, qd=32, masked=True),
+    dict(b=2, L=20, N=1030, D=773, heads=1, dh=16, qd=26, nan_pad=True),
 ]
 CASE_INDEX = {id(c): k for k, c in enumerate(ATTN_CASES)}
 

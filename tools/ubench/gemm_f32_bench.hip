@@ -200,5 +200,37 @@ int main(int argc, char **argv) {
              2.0 * TM * TNn * TK / med * 1e-6, 2.0 * TM * TNn * TK / med * 1e-6 / 157.3, t_us[v][0]);
     }
   }
+  // ================= narrow outputs (one head of a tuned shape: N = 32 / 64 / 128 columns over the same 32 768 x 773 context)
+  for (int N2 : {32, 64, 128}) {
+    float *W2, *Ws2, *bs2, *D0, *D1;
+    CK(hipMalloc(&W2, (size_t)N2 * K * 4)); CK(hipMalloc(&Ws2, (size_t)N2 * ldws * 4 + 4096)); CK(hipMalloc(&bs2, 512 * 4));
+    CK(hipMalloc(&D0, (size_t)M * N2 * 4)); CK(hipMalloc(&D1, (size_t)M * N2 * 4));
+    CK(hipMemcpy(W2, hW.data(), (size_t)N2 * K * 4, hipMemcpyHostToDevice));
+    hn::GemmArgs a0 = g0; a0.W = W2; a0.N = N2; a0.C = D0; a0.ldc = N2;
+    hn::GemmNtArgs a1 = g1; a1.W = Ws2; a1.bias = bs2; a1.N = N2; a1.C = D1; a1.ldc = N2;
+    const int var = N2 == 32 ? 20 : (N2 == 64 ? 21 : 22);
+    if (hn::launch_gemm_nt_stage(W2, K, gam, bet, nullptr, N2, K, Ws2, bs2, s) != 0) return 1;
+    if (hn::launch_gemm(a0, s) != 0 || hn::launch_gemm_nt(a1, var, s) != 0) return 1;
+    CK(hipStreamSynchronize(s));
+    std::vector<float> d0((size_t)M * N2), d1((size_t)M * N2);
+    CK(hipMemcpy(d0.data(), D0, d0.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(d1.data(), D1, d1.size() * 4, hipMemcpyDeviceToHost));
+    double w = 0, sc = 0;
+    for (size_t i = 0; i < d0.size(); ++i) { sc = std::max(sc, (double)fabsf(d0[i])); w = std::max(w, (double)fabsf(d0[i] - d1[i])); if (!(d1[i] == d1[i])) w = 1e30; }
+    if (w / sc > 1e-4) bad = 1;
+    float t[2] = {0, 0};
+    for (int v = 0; v < 2; ++v) {
+      std::vector<float> tt;
+      for (int r = 0; r < rounds; ++r) {
+        CK(hipEventRecord(e0, s));
+        for (int i = 0; i < iters; ++i) { if (v == 0) hn::launch_gemm(a0, s); else hn::launch_gemm_nt(a1, var, s); }
+        CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); tt.push_back(ms * 1000.0f / iters);
+      }
+      std::sort(tt.begin(), tt.end()); t[v] = tt[tt.size() / 2];
+    }
+    const double bytes = (double)M * lda * 4 + (double)M * N2 * 4;
+    printf("narrow N=%d: tall_narrow %.1f us (%.2f TB/s)  gemm_nt[%d] %.1f us (%.2f TB/s)  max rel diff %.2e\n", N2, t[0], bytes / t[0] * 1e-6, var, t[1],
+           bytes / t[1] * 1e-6, w / sc);
+  }
   return bad;
 }
