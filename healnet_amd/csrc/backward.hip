@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_alpha_kernel(const float *_
   }
 }
 
-constexpr long TN_SCRATCH_MIN_FLOATS = 4L << 20;      // 16 MB: floor of every split-k scratch buffer (reduce_scratch_floats)
+constexpr long TN_SCRATCH_MIN_FLOATS = 6L << 20;      // 24 MB: floor of every split-k scratch buffer (reduce_scratch_floats)
 // Many slices of a small output (launch_gemm_tn: up to 128): one thread per element walking all slices is a chain of ~30 dependent
 // loads on a hundred workgroups.  Here a workgroup takes 64 elements and its four waves a quarter of the slices each (two
 // independent chains per wave), folded through LDS in a fixed order: deterministic, 4x the loads in flight.

@@ -405,48 +405,252 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(GemmTnGArgs g) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same product for a NARROW A (M <= 64 output rows per tile: G = dKV^T z of a one-head model, dim_head 16 / 27 -> M = 32 / 64;
+// the reference's tuned TCGA shapes).  On the 128-row tile above half or three quarters of the MFMAs would multiply columns nobody
+// owns; here a tile is MT (32 | 64) x NB * 16 and the four waves split the M tile (MW = MT / 32 ways) AND the k-tile's eight 4-row
+// steps (KW = 4 / MW ways): every wave still owns a 32 x 112 accumulator, fed by 1 / KW of the steps.  The KW partial accumulators
+// of a tile are folded through LDS in a fixed order after the last k-tile (the ring is free by then), so a workgroup writes ONE
+// partial tile.  A k-tile is 32 rows x (MT + 128) floats = 20 / 24 KB by LDS-DMA, 5 / 6 instructions per wave; two ring slots fit
+// three workgroups per CU.  Bound by the B stream (z: 101 MB at the tuned shapes), not by the matrix pipe.
+// ------------------------------------------------------------------------------------------------
+template <int MT, int NB>
+__global__ __launch_bounds__(256) void gemm_tn_narrow_kernel(GemmTnGArgs g) {
+  constexpr int S = 2, MW = MT / 32, KW = 4 / MW, QS = 4 / KW;      // QS steps of each half of a k-tile per wave
+  constexpr int STAGE = 32 * MT + 32 * 128;
+  constexpr int NA = MT / 8, RA = 256 / MT, LW = (NA + 16) / 4;     // A: NA instructions of RA rows; B: 16 instructions of 2 rows
+  constexpr int BNT = NB * 16;
+  constexpr int RED = (KW - 1) * MW * 2 * NB * 4 * 64;             // floats of the cross-k-group fold
+  constexpr int LDSF = S * STAGE > RED + 1024 ? S * STAGE : RED + 1024;      // (+ 256 x 4 floats: the column-sum fold)
+  __shared__ __attribute__((aligned(16))) float lds[LDSF];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % MW, kw = wave / MW;
+  const int tiles = g.ntm * g.ntn, total = tiles * g.nsplit, per = (total + 7) >> 3;
+  const int lin = (blockIdx.x & 7) * per + (blockIdx.x >> 3);     // an XCD owns a run of consecutive (slice, tile) items
+  if (lin >= total) return;
+  const int z = lin / tiles, tile = lin - z * tiles;
+  const int m_tile = tile % g.ntm, n_tile = tile / g.ntm;
+  const int m0 = m_tile * MT, n0 = n_tile * BNT;
+  const int k_begin = z * g.kslice, rows = min(g.K, k_begin + g.kslice) - k_begin;
+  const int lda = (int)g.lda, ldb = (int)g.ldb;
+  const long a_bytes = ((long)(rows - 1) * lda + (g.M - m0)) * 4, b_bytes = ((long)(rows - 1) * ldb + (g.N - n0)) * 4;
+  const unsigned a_clamp = (unsigned)(a_bytes > 0 ? a_bytes : 0), b_clamp = (unsigned)(b_bytes > 0 ? b_bytes : 0);
+  const i32x4 rsA = make_rsrc(g.A + (long)k_begin * lda + m0, a_clamp);
+  const i32x4 rsB = make_rsrc(g.B + (long)k_begin * ldb + n0, b_clamp);
+  const int voffA = (lane / (MT / 4)) * lda * 4 + ((lane % (MT / 4)) << 4), voffB = (lane >> 5) * ldb * 4 + ((lane & 31) << 4);
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane(lds_byte_address(lds));
+  auto issue = [&](int kt) {
+#pragma unroll
+    for (int q = 0; q < LW; ++q) {
+      const int u = wave + 4 * q;                                 // u < NA: A rows RA u ..; else B rows 2 (u - NA) ..  (NA % 4 == 0: q decides)
+      const unsigned dst = lds_base + (unsigned)(((kt % S) * STAGE + u * 256) * 4);
+      if (4 * q < NA) hn_glds16(rsA, dst, voffA, (int)min((unsigned)((kt * 32 + RA * u) * lda * 4), a_clamp));
+      else hn_glds16(rsB, dst, voffB, (int)min((unsigned)((kt * 32 + 2 * (u - NA)) * ldb * 4), b_clamp));
+    }
+  };
+  const int fi = lane & 15, fg = lane >> 4;
+  const int a_off = fg * MT + 32 * wm + 2 * fi;                   // + 4 MT per 4-row step
+  const int b_off = 32 * MT + fg * 128;                           // + 512 per step
+  struct Frags { float2 a[QS]; f32x4 b[QS]; float c[QS][NB - 4]; };
+  auto read_frags = [&](int kt, int half, Frags &f) {
+    const float *st = lds + (kt % S) * STAGE;
+#pragma unroll
+    for (int q = 0; q < QS; ++q) {
+      const int step = half * 4 + kw * QS + q;
+      f.a[q] = *(const float2 *)&st[a_off + step * 4 * MT];
+      f.b[q] = *(const f32x4 *)&st[b_off + step * 512 + 4 * fi];
+      if (NB == 8) {
+        const f32x4 t = *(const f32x4 *)&st[b_off + step * 512 + 64 + 4 * fi];
+#pragma unroll
+        for (int e = 0; e < NB - 4; ++e) f.c[q][e] = t[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < NB - 4; ++e) f.c[q][e] = st[b_off + step * 512 + 64 + 16 * e + fi];
+      }
+    }
+  };
+  f32x4 acc[2][NB];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  auto mfma_half = [&](const Frags &f) {
+#pragma unroll
+    for (int q = 0; q < QS; ++q) {
+      const float av[2] = {f.a[q].x, f.a[q].y};
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.b[q][j], av[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 4; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.c[q][j - 4], av[i], acc[i][j], 0, 0, 0);
+      }
+    }
+  };
+  // column sums of A: 256 threads = (1024 / MT) row groups x MT / 4 column quads, 32 MT / 1024 rows each
+  constexpr int RG = 1024 / MT, CQ = 32 / RG;
+  const bool do_cs = g.cs_part != nullptr && n_tile == 0;
+  f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+  const int cs_off = (tid / (MT / 4)) * MT + ((tid % (MT / 4)) << 2);
+
+  const int nk = (rows + 31) >> 5;
+  if (nk > 0) issue(0);
+  if (nk > 1) issue(1);
+  Frags f0, f1;
+  if (nk > 0) {
+    if (nk > 1) wait_vmcnt<LW>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    read_frags(0, 0, f0);
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool last = kt + 1 == nk;
+    read_frags(kt, 1, f1);
+    if (do_cs) {
+      asm volatile("" ::: "memory");
+      const float *st = lds + (kt % S) * STAGE;
+#pragma unroll
+      for (int q = 0; q < CQ; ++q) csum += *(const f32x4 *)&st[cs_off + q * RG * MT];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_half(f0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!last) {
+      wait_vmcnt<0>();                                            // two slots: the tile needed next is the only one in flight
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (kt + S < nk) issue(kt + S);
+      read_frags(kt + 1, 0, f0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    mfma_half(f1);
+  }
+  // fold the KW k-groups of a tile: groups 1.. park their accumulators in LDS (lane-major, 16-byte pieces), group 0 adds them in
+  // order.  (All fragment reads of the ring are behind the barrier.)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+  f32x4 *red = (f32x4 *)lds;
+  if (kw > 0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j) red[(((kw - 1) * MW + wm) * 2 * NB + i * NB + j) * 64 + lane] = acc[i][j];
+  }
+  if (do_cs) red[RED / 4 + tid] = csum;
+  __syncthreads();
+  if (do_cs && tid < MT / 4) {                                    // the RG row groups of a column quad, in order: ONE column-sum row per slice
+    f32x4 t = red[RED / 4 + tid];
+#pragma unroll
+    for (int rg = 1; rg < RG; ++rg) t += red[RED / 4 + rg * (MT / 4) + tid];
+    const int m = m0 + (tid << 2);
+    if (m < g.M) *(f32x4 *)&g.cs_part[(long)z * g.M + m] = t;
+  }
+  if (kw > 0) return;
+#pragma unroll
+  for (int k2 = 1; k2 < KW; ++k2)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc[i][j] += red[(((k2 - 1) * MW + wm) * 2 * NB + i * NB + j) * 64 + lane];
+  float *P = g.part + (long)z * g.M * g.ldp;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + 32 * wm + 2 * fi + i;
+    if (m >= g.M) continue;
+    float *row = P + (long)m * g.ldp + n0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) *(f32x4 *)&row[16 * fg + 4 * r] = (f32x4){acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+    if (NB == 8) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) *(f32x4 *)&row[64 + 16 * fg + 4 * r] = (f32x4){acc[i][4][r], acc[i][NB - 3][r], acc[i][NB - 2][r], acc[i][NB - 1][r]};
+    } else {
+#pragma unroll
+      for (int j = 4; j < NB; ++j) *(f32x4 *)&row[64 + 16 * (j - 4) + 4 * fg] = acc[i][j];
+    }
+  }
+}
+
 // C[m, n] (+)= alpha * sum_z part[z, m, n] for n < N; colsum[m] (+)= sum_z cs_part[z, m].  Fixed order: bitwise reproducible.
-// blockIdx.y = output row (row M: the column sums), a thread takes four consecutive columns of it: one 16-byte load per slice (the
+// blockIdx.y = output row (rows >= M: the column sums), a thread takes four consecutive columns of it: one 16-byte load per slice (the
 // partial rows are 16-byte aligned), four slices in flight per trip, no index division.  (One element per thread with a 64-bit
 // divide and 16 clamped loads ran at 1.2 TB/s: 24 us for 29 MB.)
+// SG = slice groups per workgroup: a narrow output (M = 32: 32 rows x 194 column quads) has too few (row, quad) pairs to fill the
+// chip and ~100 slices to sum per pair -- one chain of dependent loads per thread took 50+ us.  With SG > 1 a workgroup is
+// SG x (256 / SG) threads, group sg sums the slices k = sg (mod SG) and the groups are folded through LDS in index order.
+template <int SG>
 __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float *__restrict__ part, int nsplit, int M, int N, long ldp,
                                                              float *__restrict__ C, long ldc, float alpha, int accumulate,
-                                                             const float *__restrict__ cs_part, float *__restrict__ cs_out, int cs_accumulate) {
+                                                             const float *__restrict__ cs_part, float *__restrict__ cs_out, int cs_accumulate,
+                                                             int cs_groups) {
+  constexpr int QB = 256 / SG;                              // column quads per workgroup
+  __shared__ f32x4 fold[SG > 1 ? 256 : 1];
   const int m = blockIdx.y;
-  if (m >= M) {                                             // column sums: nsplit * 8 row-group partials per column, 256 columns per row of
-    const int c = (m - M) * 256 + threadIdx.x;              // blocks, eight independent chains per thread (fixed order)
+  if (m >= M) {                                             // column sums: nsplit * cs_groups row-group partials per column, 256 columns
+    const int c = (m - M) * 256 + threadIdx.x;              // per row of blocks, eight independent chains per thread (fixed order)
     if (blockIdx.x != 0 || c >= M) return;
     float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const int np = nsplit * 8;
-    for (int k = 0; k < np; k += 8) {
+    const int np = nsplit * cs_groups;
+    int k = 0;
+    for (; k + 8 <= np; k += 8) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) a8[u] += cs_part[(long)(k + u) * M + c];
     }
+    for (; k < np; ++k) a8[k & 7] += cs_part[(long)k * M + c];
     const float acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
     cs_out[c] = cs_accumulate ? cs_out[c] + acc : acc;
     return;
   }
-  const int n = (blockIdx.x * 256 + threadIdx.x) * 4;
-  if (n >= N) return;
+  const int sg = threadIdx.x / QB, n = (blockIdx.x * QB + threadIdx.x % QB) * 4;
   const long slab = (long)M * ldp;
-  const float *src = part + (long)m * ldp + n;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  int k = 0;
-  for (; k + 4 <= nsplit; k += 4) {
-    const f32x4 v0 = *(const f32x4 *)&src[(long)k * slab], v1 = *(const f32x4 *)&src[(long)(k + 1) * slab];
-    const f32x4 v2 = *(const f32x4 *)&src[(long)(k + 2) * slab], v3 = *(const f32x4 *)&src[(long)(k + 3) * slab];
-    acc += v0; acc += v1; acc += v2; acc += v3;
+  if (n < N) {
+    const float *src = part + (long)m * ldp + n;
+    int k = sg;
+    for (; k + 3 * SG < nsplit; k += 4 * SG) {
+      const f32x4 v0 = *(const f32x4 *)&src[(long)k * slab], v1 = *(const f32x4 *)&src[(long)(k + SG) * slab];
+      const f32x4 v2 = *(const f32x4 *)&src[(long)(k + 2 * SG) * slab], v3 = *(const f32x4 *)&src[(long)(k + 3 * SG) * slab];
+      acc += v0; acc += v1; acc += v2; acc += v3;
+    }
+    for (; k < nsplit; k += SG) acc += *(const f32x4 *)&src[(long)k * slab];
   }
-  for (; k < nsplit; ++k) acc += *(const f32x4 *)&src[(long)k * slab];
+  if (SG > 1) {
+    fold[threadIdx.x] = acc;
+    __syncthreads();
+    if (sg != 0) return;
+#pragma unroll
+    for (int u = 1; u < SG; ++u) acc += fold[u * QB + threadIdx.x];
+  }
+  if (n >= N) return;
   float *dst = C + (long)m * ldc + n;
 #pragma unroll
   for (int e = 0; e < 4; ++e)
     if (n + e < N) dst[e] = accumulate ? dst[e] + alpha * acc[e] : alpha * acc[e];
 }
 
+#ifdef HN_GEMM_NT_BENCH
+static bool g_tn_bench_skip_reduce = false;
+#endif
 bool gemm_tn_glds_eligible(const float *A, long lda, const float *B, long ldb, int M, int N, int K) {
-  return K >= 4096 && M >= 128 && M < 65000 && N >= 112 && M % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 &&
+  return K >= 4096 && M >= 32 && M < 65000 && N >= 112 && M % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 &&
          (long)K * lda * 4 < (1L << 31) && (long)K * ldb * 4 < (1L << 31);
+}
+
+// row tile of the TN product: 128 (gemm_tn_glds_kernel) or the narrow kernel's 64 / 32 where those pad M less
+static int gemm_tn_row_tile(int M) {
+  // measured over 32 768 x 773 (tools/ubench/gemm_f32_bench, incl. the reduce): M = 32: 32 us on 32-row tiles (43 on 64, 82 on
+  // 128); M = 64: 42 / 46 / 82; M = 128: 63 / 64 / 89; M = 256: 114 on 64-row tiles against 139 on 128
+  if (M <= 64) return 32;
+  if (M <= 256) return 64;
+  return 128;
+}
+
+// floats of scratch one row slice needs (partials + column-sum partials); the routes size their scratch for >= 32 slices of it
+size_t gemm_tn_glds_slice_floats(int M, int N, bool colsum) {
+  const int nb = ceil_div(N, 112) * 112 <= ceil_div(N, 128) * 128 ? 7 : 8;
+  const int mt = gemm_tn_row_tile(M);
+  return (size_t)M * ceil_div(N, nb * 16) * nb * 16 + (colsum ? (size_t)(mt == 128 ? 8 : 1) * M : 0);
 }
 
 // scratch_floats: capacity of `scratch` (partials + column-sum partials)
@@ -458,12 +662,17 @@ int launch_gemm_tn_glds(const float *A, long lda, const float *B, long ldb, floa
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.M = M; g.N = N; g.K = K;
   // 112- or 128-wide column tiles, whichever pads less
   const int nb = ceil_div(N, 112) * 112 <= ceil_div(N, 128) * 128 ? 7 : 8;
-  g.ntm = ceil_div(M, 128); g.ntn = ceil_div(N, nb * 16);
+  int mt = gemm_tn_row_tile(M);
+#ifdef HN_GEMM_NT_BENCH
+  if (variant >= 32) { mt = variant & ~3; variant = 0; }     // bench: force the row tile (32 | 64 | 128)
+#endif
+  const int cs_groups = mt == 128 ? 8 : 1;                   // rows of column-sum partials per slice (the narrow kernel folds its row groups)
+  g.ntm = ceil_div(M, mt); g.ntn = ceil_div(N, nb * 16);
   g.ldp = (long)g.ntn * nb * 16;
   const int tiles = g.ntm * g.ntn;
-  int nsplit = 512 / tiles;                                  // 64 KB of LDS: 2 workgroups per CU, one resident round
+  int nsplit = (mt == 128 ? 512 : 768) / tiles;              // 64 KB (48 / 42 KB narrow) of LDS: 2 (3) workgroups per CU, one resident round
   if (nsplit < 1) nsplit = 1;
-  const size_t per = (size_t)M * g.ldp + (colsum ? 8 * M : 0);
+  const size_t per = (size_t)M * g.ldp + (colsum ? (size_t)cs_groups * M : 0);
   if ((size_t)nsplit * per > scratch_floats) nsplit = (int)(scratch_floats / per);
   HN_REQUIRE(nsplit >= 1, HN_E_WORKSPACE, "gemm_tn_glds: scratch %zu floats < %zu", scratch_floats, per);
   g.kslice = ceil_div(ceil_div(K, nsplit), 32) * 32;
@@ -473,7 +682,13 @@ int launch_gemm_tn_glds(const float *A, long lda, const float *B, long ldb, floa
   const dim3 grid1((unsigned)(ceil_div(tiles * g.nsplit, 8) * 8));
   {
   KernelTimerScope timer("gemm_tn_glds", s);
-  if (nb == 8) hipLaunchKernelGGL((gemm_tn_glds_kernel<8, 1>), grid1, dim3(256), 0, s, g);
+  if (mt == 64) {
+    if (nb == 8) hipLaunchKernelGGL((gemm_tn_narrow_kernel<64, 8>), grid1, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((gemm_tn_narrow_kernel<64, 7>), grid1, dim3(256), 0, s, g);
+  } else if (mt == 32) {
+    if (nb == 8) hipLaunchKernelGGL((gemm_tn_narrow_kernel<32, 8>), grid1, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((gemm_tn_narrow_kernel<32, 7>), grid1, dim3(256), 0, s, g);
+  } else if (nb == 8) hipLaunchKernelGGL((gemm_tn_glds_kernel<8, 1>), grid1, dim3(256), 0, s, g);
 #ifdef HN_GEMM_NT_BENCH
   else if (variant == 1) hipLaunchKernelGGL((gemm_tn_glds_kernel<7, 0>), dim3(tiles, g.nsplit), dim3(256), 0, s, g);
   else if (variant == 2) hipLaunchKernelGGL((gemm_tn_glds_kernel<7, 1, 1>), grid1, dim3(256), 0, s, g);
@@ -485,8 +700,16 @@ int launch_gemm_tn_glds(const float *A, long lda, const float *B, long ldb, floa
   (void)variant;
   }
   HN_LAUNCH_CHECK("gemm_tn_glds");
-  hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)ceil_div(ceil_div(N, 4), 256), (unsigned)(M + (colsum ? ceil_div(M, 256) : 0))), dim3(256), 0, s,
-                     scratch, g.nsplit, M, N, g.ldp, C, ldc, alpha, accumulate, g.cs_part, colsum, colsum_accumulate);
+#ifdef HN_GEMM_NT_BENCH
+  if (g_tn_bench_skip_reduce) return HN_OK;
+#endif
+  const unsigned red_rows = (unsigned)(M + (colsum ? ceil_div(M, 256) : 0));
+  if (M >= 512)
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel<1>, dim3((unsigned)ceil_div(ceil_div(N, 4), 256), red_rows), dim3(256), 0, s, scratch, g.nsplit, M, N, g.ldp, C,
+                       ldc, alpha, accumulate, g.cs_part, colsum, colsum_accumulate, cs_groups);
+  else
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel<16>, dim3((unsigned)ceil_div(ceil_div(N, 4), 16), red_rows), dim3(256), 0, s, scratch, g.nsplit, M, N, g.ldp, C,
+                       ldc, alpha, accumulate, g.cs_part, colsum, colsum_accumulate, cs_groups);
   HN_LAUNCH_CHECK("gemm_tn_reduce");
   return HN_OK;
 }

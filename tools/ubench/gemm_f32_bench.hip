@@ -200,6 +200,82 @@ int main(int argc, char **argv) {
              2.0 * TM * TNn * TK / med * 1e-6, 2.0 * TM * TNn * TK / med * 1e-6 / 157.3, t_us[v][0]);
     }
   }
+  // ================= TN with a narrow A (G = dKV^T z of a one-head model: M2 = 32 / 64 / 128 / 256 rows x 773 over the 32 768 rows)
+  for (int M2 : {32, 64, 128, 256, 512}) {
+    if (M2 > N) continue;
+    const int TNn = K, TK = M;
+    float *G0, *G1, *cs0, *cs1, *scr;
+    const size_t scr_floats = hn::reduce_scratch_floats((long)M2 * TNn, M2);
+    CK(hipMalloc(&G0, (size_t)M2 * TNn * 4)); CK(hipMalloc(&G1, (size_t)M2 * TNn * 4)); CK(hipMalloc(&cs0, M2 * 4)); CK(hipMalloc(&cs1, M2 * 4));
+    CK(hipMalloc(&scr, scr_floats * 4));
+    // A = the first M2 columns of C0 taken as a dense (TK, M2) matrix with pitch M2: reinterpret the buffer (values are arbitrary finite numbers)
+    hn::GemmExArgs e{};
+    e.A = C0; e.a_rs = 1; e.a_cs = M2; e.B = A; e.b_rs = 1; e.b_cs = lda; e.C = G0; e.ldc = TNn; e.M = M2; e.N = TNn; e.K = TK; e.batch = 1;
+    e.alpha = 1.0f; e.accumulate = 0; e.colsum = cs0; e.colsum_accumulate = 0;
+    setenv("HN_NO_GLDS_GEMM", "1", 1);
+    auto run2 = [&](int v) {
+      if (v == 0) return hn::launch_gemm_ex(e, s, scr);
+      return hn::launch_gemm_tn_glds(C0, M2, A, lda, G1, TNn, M2, TNn, TK, 1.0f, 0, scr, scr_floats, cs1, 0, s, v);
+    };
+    const int forced[4] = {0, 32, 64, 128};
+    if (run2(0) != 0) return 1;
+    CK(hipStreamSynchronize(s));
+    std::vector<float> g0v((size_t)M2 * TNn), g1v((size_t)M2 * TNn), c0(M2), c1(M2), g2v((size_t)M2 * TNn);
+    CK(hipMemcpy(g0v.data(), G0, g0v.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(c0.data(), cs0, M2 * 4, hipMemcpyDeviceToHost));
+    for (int fv = 1; fv < 4; ++fv) {
+      if (forced[fv] < 128 && forced[fv] * 8 < M2) continue;      // (keep the tile counts sane)
+      CK(hipMemsetAsync(G1, 0xff, (size_t)M2 * TNn * 4, s)); CK(hipMemsetAsync(cs1, 0xff, M2 * 4, s));
+      if (run2(forced[fv]) != 0) return 1;
+      CK(hipStreamSynchronize(s));
+      CK(hipMemcpy(g1v.data(), G1, g1v.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(c1.data(), cs1, M2 * 4, hipMemcpyDeviceToHost));
+      double sc = 0, worst = 0, csc = 0, cworst = 0; size_t nan = 0, flips = 0;
+      for (size_t i = 0; i < g0v.size(); ++i) { sc = std::max(sc, (double)fabsf(g0v[i])); if (!(g1v[i] == g1v[i])) ++nan; else worst = std::max(worst, (double)fabsf(g0v[i] - g1v[i])); }
+      for (int i = 0; i < M2; ++i) { csc = std::max(csc, (double)fabsf(c0[i])); if (!(c1[i] == c1[i])) ++nan; else cworst = std::max(cworst, (double)fabsf(c0[i] - c1[i])); }
+      for (int rep = 0; rep < 4; ++rep) {
+        CK(hipMemsetAsync(G1, 0xff, (size_t)M2 * TNn * 4, s));
+        run(rep % 3); run2(forced[fv]);
+        CK(hipStreamSynchronize(s));
+        CK(hipMemcpy(g2v.data(), G1, g2v.size() * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < g2v.size(); ++i) flips += memcmp(&g1v[i], &g2v[i], 4) != 0;
+      }
+      run(0);
+      std::vector<float> tt;
+      for (int r = 0; r < rounds; ++r) {
+        CK(hipEventRecord(e0, s));
+        for (int i = 0; i < iters; ++i) run2(forced[fv]);
+        CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); tt.push_back(ms * 1000.0f / iters);
+      }
+      std::sort(tt.begin(), tt.end());
+      std::vector<float> t2;
+      hn::g_tn_bench_skip_reduce = true;
+      for (int r = 0; r < rounds; ++r) {
+        CK(hipEventRecord(e0, s));
+        for (int i = 0; i < iters; ++i) run2(forced[fv]);
+        CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); t2.push_back(ms * 1000.0f / iters);
+      }
+      hn::g_tn_bench_skip_reduce = false;
+      std::sort(t2.begin(), t2.end());
+      printf("  (without the reduce: %.1f us)  ", t2[t2.size() / 2]);
+      printf("TN narrow M=%d row tile %d (incl. reduce): %.1f us  max rel %.2e colsum rel %.2e NaN %zu flips %zu%s\n", M2, forced[fv], tt[tt.size() / 2],
+             worst / sc, cworst / csc, nan, flips, flips ? " (RACE)" : "");
+      if (nan || flips || worst / sc > 1e-4 || cworst / csc > 1e-4) bad = 1;
+    }
+    {
+      std::vector<float> tt;
+      for (int r = 0; r < rounds; ++r) {
+        CK(hipEventRecord(e0, s));
+        for (int i = 0; i < iters; ++i) run2(0);
+        CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); tt.push_back(ms * 1000.0f / iters);
+      }
+      std::sort(tt.begin(), tt.end());
+      printf("TN narrow M=%d round-3 route: %.1f us\n", M2, tt[tt.size() / 2]);
+    }
+    unsetenv("HN_NO_GLDS_GEMM");
+    CK(hipFree(G0)); CK(hipFree(G1)); CK(hipFree(cs0)); CK(hipFree(cs1)); CK(hipFree(scr));
+  }
   // ================= narrow outputs (one head of a tuned shape: N = 32 / 64 / 128 columns over the same 32 768 x 773 context)
   for (int N2 : {32, 64, 128}) {
     float *W2, *Ws2, *bs2, *D0, *D1;
