@@ -705,7 +705,7 @@ template <int EPT, typename Keep>
 __device__ __forceinline__ void merge_splits(MergeWeights &mw, const float *Opart, const float *Mpart, const float *Lpart,
                                              long pbase, int nsplit, int Lp, int dp, int q0, int L, int R, int width, Keep keep,
                                              float (&acc)[EPT]) {
-  constexpr int PF = EPT <= 4 ? 8 : 4;                   // splits per group (EPT * PF values in registers)
+  constexpr int PF = EPT == 1 ? 16 : (EPT <= 4 ? 8 : 4);   // splits per group (EPT * PF values in registers)
   const int tid = threadIdx.x;
   const long sstride = (long)Lp * dp;
   long eoff[EPT];
@@ -734,7 +734,13 @@ __device__ __forceinline__ void merge_splits(MergeWeights &mw, const float *Opar
   const bool wlive = wq < R && q0 + wq < L;
   const long wrow = pbase + min(q0 + wq, Lp - 1);
   float M = kNegBig;
-  if (wlive) for (int s = j; s < nsplit; s += 8) M = fmaxf(M, Mpart[wrow + (long)s * Lp]);
+  if (wlive) for (int s = j; s < nsplit; s += 32) {      // four independent loads per trip (clamped: a repeated split does not move a maximum)
+    float m4[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) m4[u] = Mpart[wrow + (long)min(s + 8 * u, nsplit - 1) * Lp];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) M = fmaxf(M, m4[u]);
+  }
   M = fmaxf(M, __shfl_xor(M, 1));
   M = fmaxf(M, __shfl_xor(M, 2));
   M = fmaxf(M, __shfl_xor(M, 4));
@@ -743,13 +749,26 @@ __device__ __forceinline__ void merge_splits(MergeWeights &mw, const float *Opar
     const int s1 = min(nsplit, s0 + MERGE_MAXS);
     const int s1p = min(s0 + MERGE_MAXS, (s1 + PF - 1) / PF * PF);       // weights up to the end of the last group: 0
     const bool last = s1 == nsplit;
-    if (wq < R) for (int s = s0 + j; s < s1p; s += 8) {
-      float w = 0.0f;
-      if (wlive && s < s1) {
-        w = fast_exp2(Mpart[wrow + (long)s * Lp] - M);
-        lsum = fmaf(w, Lpart[wrow + (long)s * Lp], lsum);
+    if (wq < R) {                                        // the lane's <= 8 splits of the chunk: all (m, l) pairs requested before the first use
+      float mv[MERGE_MAXS / 8], lv[MERGE_MAXS / 8];
+#pragma unroll
+      for (int u = 0; u < MERGE_MAXS / 8; ++u) {
+        const long at = wrow + (long)min(s0 + j + 8 * u, nsplit - 1) * Lp;
+        mv[u] = Mpart[at];
+        lv[u] = Lpart[at];
       }
-      mw.w[wq][s - s0] = w;
+#pragma unroll
+      for (int u = 0; u < MERGE_MAXS / 8; ++u) {
+        const int s = s0 + j + 8 * u;
+        if (s < s1p) {
+          float w = 0.0f;
+          if (wlive && s < s1) {
+            w = fast_exp2(mv[u] - M);
+            lsum = fmaf(w, lv[u], lsum);
+          }
+          mw.w[wq][s - s0] = w;
+        }
+      }
     }
     if (last) {           // the merged (M, l) ride on the barrier the last chunk needs anyway: one barrier in all for <= 64 splits
       lsum += __shfl_xor(lsum, 1);
@@ -865,6 +884,10 @@ int launch_merge_vproj(const float *Opart, const float *Mpart, const float *Lpar
   return HN_OK;
 }
 
+// EPT = output elements per thread (R * dh <= 256 EPT): one narrow head over few rows (R = 8, dim_head 27: 216 elements) takes
+// EPT = 1 and sixteen splits in flight per trip -- with the 16-element form it issued 15 dead loads per live one and spent
+// nsplit / 4 dependent round trips (14 us at 64 splits)
+template <int EPT>
 __global__ __launch_bounds__(256) void merge_explicit_kernel(const float *__restrict__ Opart, const float *__restrict__ Mpart,
                                                              const float *__restrict__ Lpart, int nsplit, int h, int L,
                                                              int Lp, int dp, int dh, float *__restrict__ O, int ldo,
@@ -873,14 +896,14 @@ __global__ __launch_bounds__(256) void merge_explicit_kernel(const float *__rest
   const int q0 = blockIdx.y * R;
   const long pbase = (long)bh * nsplit * Lp;
   __shared__ MergeWeights mw;
-  float acc[16];                         // R * dh <= 32 * 128 elements
-  merge_splits<16>(mw, Opart, Mpart, Lpart, pbase, nsplit, Lp, dp, q0, L, R, dh, [](int) { return true; }, acc);
+  float acc[EPT];                        // R * dh <= 32 * 128 elements
+  merge_splits<EPT>(mw, Opart, Mpart, Lpart, pbase, nsplit, Lp, dp, q0, L, R, dh, [](int) { return true; }, acc);
   if (stats && threadIdx.x < R && q0 + threadIdx.x < L) {
     stats[((long)bh * L + q0 + threadIdx.x) * 2 + 0] = mw.M[threadIdx.x];
     stats[((long)bh * L + q0 + threadIdx.x) * 2 + 1] = mw.l[threadIdx.x];
   }
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
+  for (int k = 0; k < EPT; ++k) {
     const int idx = threadIdx.x + 256 * k;
     if (idx < R * dh) {
       const int qq = idx / dh, e = idx % dh, q = q0 + qq;
@@ -893,8 +916,13 @@ int launch_merge_explicit(const float *Opart, const float *Mpart, const float *L
                           int Lp, int dp, int dh, float *O, int ldo, float *stats, hipStream_t s) {
   HN_REQUIRE(dh <= 128, HN_E_UNSUPPORTED, "merge_explicit: dh=%d", dh);
   const int R = merge_rows_per_block(b, h, L);
-  hipLaunchKernelGGL(merge_explicit_kernel, dim3(b * h, ceil_div(L, R)), dim3(256), 0, s, Opart, Mpart, Lpart,
-                     nsplit, h, L, Lp, dp, dh, O, ldo, stats, R);
+  const dim3 grid(b * h, ceil_div(L, R));
+  if (R * dh <= 256)
+    hipLaunchKernelGGL(merge_explicit_kernel<1>, grid, dim3(256), 0, s, Opart, Mpart, Lpart, nsplit, h, L, Lp, dp, dh, O, ldo, stats, R);
+  else if (R * dh <= 1024)
+    hipLaunchKernelGGL(merge_explicit_kernel<4>, grid, dim3(256), 0, s, Opart, Mpart, Lpart, nsplit, h, L, Lp, dp, dh, O, ldo, stats, R);
+  else
+    hipLaunchKernelGGL(merge_explicit_kernel<16>, grid, dim3(256), 0, s, Opart, Mpart, Lpart, nsplit, h, L, Lp, dp, dh, O, ldo, stats, R);
   HN_LAUNCH_CHECK("merge_explicit");
   return HN_OK;
 }

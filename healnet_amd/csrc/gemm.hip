@@ -698,8 +698,8 @@ __global__ __launch_bounds__(256 * SPLIT) void gemm_t32a2_kernel(GemmArgs g) {
 // the k range, every lane keeps 32 x 4 partial sums which are folded across the wave with a
 // reduce-scatter butterfly (126 shuffles instead of 768) and across the waves through LDS.
 // ------------------------------------------------------------------------------------------------
-template <int CNT>
-__device__ __forceinline__ void fold_half(float (&v)[128], int lane, int mask) {
+template <int CNT, int NV>
+__device__ __forceinline__ void fold_half(float (&v)[NV], int lane, int mask) {
   const bool up = (lane & mask) != 0;
 #pragma unroll
   for (int i = 0; i < CNT; ++i) {
@@ -709,44 +709,64 @@ __device__ __forceinline__ void fold_half(float (&v)[128], int lane, int mask) {
   }
 }
 
+// SM = rows per workgroup: 32, or 8 for batches of up to 8 samples (the reference's tuned runs): a quarter of the row loads and
+// accumulators, which pays for FOUR k-chunks in flight per trip (K = 2005: 2 dependent round trips per wave instead of 8 --
+// 12.5 us at b = 8 before, where 14 workgroups cannot hide any of them)
+template <int SM>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
-  constexpr int SN = 4, SM = 32;
+  constexpr int SN = 4, U = SM == 8 ? 4 : 1;
   __shared__ float part[4][SM * SN];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n0 = blockIdx.x * SN, z = blockIdx.z, m0 = blockIdx.y * SM;      // blockIdx.y: 32-row chunk (batches above 32 samples)
+  const int n0 = blockIdx.x * SN, z = blockIdx.z, m0 = blockIdx.y * SM;      // blockIdx.y: SM-row chunk (batches above SM samples)
   const i32x4 rsA = make_rsrc(g.A + (long)z * g.strideA, rsrc_bytes(g.M, g.lda, g.K));
   const i32x4 rsW = make_rsrc(g.W + (long)z * g.strideW, rsrc_bytes(g.N, g.ldw, g.K));
   float acc[SM * SN];
 #pragma unroll
   for (int i = 0; i < SM * SN; ++i) acc[i] = 0.0f;
-  for (int k0 = wave * 64; k0 < g.K; k0 += 256) {
-    const int k = k0 + lane;
-    const float km = k < g.K ? 1.0f : 0.0f;
-    const int kc = min(k, g.K - 1);
-    float w[SN], av[SM];
+  for (int k0 = wave * 64; k0 < g.K; k0 += 256 * U) {
+    float w[U][SN], av[U][SM], gam[U], bet[U];
 #pragma unroll
-    for (int j = 0; j < SN; ++j) w[j] = hn_buffer_load_x1(rsW, ((n0 + j) * (int)g.ldw + kc) * 4, 0, 0);
+    for (int u = 0; u < U; ++u) {
+      const int k = k0 + 256 * u + lane;
+      const float km = k < g.K ? 1.0f : 0.0f;
+      const int kc = min(k, g.K - 1);
 #pragma unroll
-    for (int m = 0; m < SM; ++m) av[m] = hn_buffer_load_x1(rsA, ((m0 + m) * (int)g.lda + kc) * 4, 0, 0);
-    float gam = 1.0f, bet = 0.0f;
-    if (g.pro == PRO_AFFINE) { gam = g.gamma[kc]; bet = g.beta[kc]; }
-    gam *= km;
-    bet *= km;
+      for (int j = 0; j < SN; ++j) w[u][j] = hn_buffer_load_x1(rsW, ((n0 + j) * (int)g.ldw + kc) * 4, 0, 0);
 #pragma unroll
-    for (int m = 0; m < SM; ++m) {
-      const float a = av[m] * gam + bet;           // rows past M carry beta only, into outputs nobody stores
-#pragma unroll
-      for (int j = 0; j < SN; ++j) acc[m * SN + j] = fmaf(a, w[j], acc[m * SN + j]);
+      for (int m = 0; m < SM; ++m) av[u][m] = hn_buffer_load_x1(rsA, ((m0 + m) * (int)g.lda + kc) * 4, 0, 0);
+      gam[u] = 1.0f; bet[u] = 0.0f;
+      if (g.pro == PRO_AFFINE) { gam[u] = g.gamma[kc]; bet[u] = g.beta[kc]; }
+      gam[u] *= km;
+      bet[u] *= km;
     }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int m = 0; m < SM; ++m) {
+        const float a = av[u][m] * gam[u] + bet[u];           // rows past M carry beta only, into outputs nobody stores
+#pragma unroll
+        for (int j = 0; j < SN; ++j) acc[m * SN + j] = fmaf(a, w[u][j], acc[m * SN + j]);
+      }
   }
-  fold_half<64>(acc, lane, 32);
-  fold_half<32>(acc, lane, 16);
-  fold_half<16>(acc, lane, 8);
-  fold_half<8>(acc, lane, 4);
-  fold_half<4>(acc, lane, 2);
-  fold_half<2>(acc, lane, 1);
-  part[wave][2 * lane] = acc[0];          // lane now owns flattened outputs 2*lane, 2*lane + 1 (index = m*SN + j)
-  part[wave][2 * lane + 1] = acc[1];
+  // reduce-scatter butterfly: after the fold over lane bit b the lane keeps the half of its values whose index bit matches
+  if constexpr (SM == 32) {
+    fold_half<64>(acc, lane, 32);
+    fold_half<32>(acc, lane, 16);
+    fold_half<16>(acc, lane, 8);
+    fold_half<8>(acc, lane, 4);
+    fold_half<4>(acc, lane, 2);
+    fold_half<2>(acc, lane, 1);
+    part[wave][2 * lane] = acc[0];          // lane now owns flattened outputs 2*lane, 2*lane + 1 (index = m*SN + j)
+    part[wave][2 * lane + 1] = acc[1];
+  } else {
+    fold_half<16>(acc, lane, 32);
+    fold_half<8>(acc, lane, 16);
+    fold_half<4>(acc, lane, 8);
+    fold_half<2>(acc, lane, 4);
+    fold_half<1>(acc, lane, 2);
+    acc[0] += __shfl_xor(acc[0], 1);        // 32 outputs on 64 lanes: the pair (lane, lane ^ 1) owns output lane >> 1
+    if ((lane & 1) == 0) part[wave][lane >> 1] = acc[0];
+  }
   __syncthreads();
   if (threadIdx.x < SM * SN) {
     const int idx = threadIdx.x, m = m0 + idx / SN, n = n0 + idx % SN;
@@ -969,7 +989,8 @@ int launch_gemm(const GemmArgs &g_in, hipStream_t s) {
   // M <= 32 always; up to 512 rows (32-row chunks re-stream the weight from L2) when the operands are not 16-byte aligned
   // (K = 2005: the tile kernels do not apply and the generic one runs 8 workgroups -- 265 us at b = 64 against 2 x 9)
   if ((g.M <= 32 || (g.M <= 512 && !aligned_eligible(g))) && !glu && g.pro != PRO_LAYERNORM && g.K >= 512) {
-    hipLaunchKernelGGL(gemm_skinny_kernel, dim3(ceil_div(g.N, 4), ceil_div(g.M, 32), g.batch), dim3(256), 0, s, g);
+    if (g.M <= 8) hipLaunchKernelGGL(gemm_skinny_kernel<8>, dim3(ceil_div(g.N, 4), 1, g.batch), dim3(256), 0, s, g);
+    else hipLaunchKernelGGL(gemm_skinny_kernel<32>, dim3(ceil_div(g.N, 4), ceil_div(g.M, 32), g.batch), dim3(256), 0, s, g);
     HN_LAUNCH_CHECK("gemm_skinny");
     return HN_OK;
   }
