@@ -147,13 +147,13 @@ def main():
         # dominant kernel
         # (among the kernels this tool can price: attention cores and the patch-bag projection; at cfg4 with the bf16 projection the
         # latent chain's 12 launches add up to as much as either, see the "kernels" table of the entry)
-        priced = [k for k in kernels if any(t in k["Name"] for t in ("attn_core", "gemm_big", "gemm_bf16_kernel"))]
+        priced = [k for k in kernels if any(t in k["Name"] for t in ("attn_core", "gemm_big", "gemm_nt_glds", "gemm_bf16_kernel"))]
         dom = max(priced or kernels, key=lambda k: float(k["TotalDurationNs"]))
         dom_name = dom["Name"]
         dom_us = float(dom["AverageNs"]) / 1e3
         # which modality the dominant kernel serves: the one with the largest core FLOPs
         mod = max(cfg["mods"], key=lambda m: core_flops(m, cfg["b"], prec)[0])
-        if "gemm_big" in dom_name or "gemm_bf16_kernel" in dom_name:
+        if "gemm_big" in dom_name or "gemm_nt_glds" in dom_name or "gemm_bf16_kernel" in dom_name:
             fl, formula = 2.0 * cfg["b"] * 4096 * 773 * 2 * INNER, "2*(b*N)*D*(2*inner) (patch-bag K/V projection, N=4096, D=773, inner=512)"
         else:
             fl, formula = core_flops(mod, cfg["b"], prec)
