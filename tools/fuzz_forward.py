@@ -122,6 +122,28 @@ def random_case_staged(rng):
     return kw, shapes, min(b, 9), masked
 
 
+def random_case_tuned(rng):
+    """The reference's tuned regime (config/best_hyperparams.yml): ONE or two narrow cross heads of odd width over a long patch bag
+    (>= 2048 context rows per batch: the narrow LDS-DMA projection and weight-gradient kernels of gemm_nt.hip, the skinny GEMV's 8-row
+    form, the one-element split merge) beside a wide one-token modality, staged latent sizes."""
+    def heads_dim():
+        dh = rng.choice([16, 27, 48, 63, 64, 103])
+        dhp = 16 if dh <= 16 else 32 if dh <= 32 else 64 if dh <= 64 else 128
+        return rng.choice([h for h in (1, 1, 2) if h * dhp <= 256]), dh
+    xh, xd = heads_dim()
+    lh, ld = heads_dim()
+    b = rng.choice([2, 5, 8])
+    n_bag = rng.choice([600, 1100, 2500]) if b > 2 else rng.choice([1100, 2500, 4200])
+    chans, axes, shapes = [rng.choice([600, 2000]), rng.choice([127, 296, 768])], [1, 1], [(1,), (n_bag,)]
+    if rng.random() < 0.3:
+        chans, axes, shapes = chans[::-1], axes[::-1], shapes[::-1]
+    kw = dict(n_modalities=2, channel_dims=chans, num_spatial_axes=axes, out_dims=4, depth=rng.choice([1, 2]),
+              l_c=rng.choice([16, 17, 25]), l_d=rng.choice([62, 65, 119, 126]), x_heads=xh, l_heads=lh,
+              cross_dim_head=xd, latent_dim_head=ld, num_freq_bands=2, max_freq=10.0, snn=rng.random() < 0.7,
+              weight_tie_layers=False, self_per_cross_attn=rng.choice([0, 1]), fourier_encode_data=True, final_classifier_head=True)
+    return kw, shapes, b, False
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=60)
@@ -130,7 +152,7 @@ def main(argv=None):
     ap.add_argument("--data-seed", type=int, default=0, help="offset of the input / weight seeds (same configurations, other numbers)")
     ap.add_argument("--dropout", action="store_true", help="training mode with random attention / feed-forward dropout; the oracle replays the build's exported Philox masks")
     ap.add_argument("--attn", action="store_true", help="also compare get_attention_weights() / get_attention_importance() of the inference forward (untied weights, nothing missing)")
-    ap.add_argument("--scale", default="small", choices=["small", "medium", "chain", "staged"])
+    ap.add_argument("--scale", default="small", choices=["small", "medium", "chain", "staged", "tuned"])
     ap.add_argument("--core-precision", default="fp32", choices=["fp32", "bf16", "bf16x3"], help="attention core of the inference forward")
     ap.add_argument("--only", type=int, nargs="*", default=None, help="case indices to run (the others are generated and skipped)")
     args = ap.parse_args(argv)
@@ -139,7 +161,8 @@ def main(argv=None):
     bad = 0
     for case in range(args.n):
         kw, shapes, b, masked = (random_case_medium(rng) if args.scale == "medium" else random_case_chain(rng) if args.scale == "chain"
-                                 else random_case_staged(rng) if args.scale == "staged" else random_case(rng))
+                                 else random_case_staged(rng) if args.scale == "staged" else random_case_tuned(rng) if args.scale == "tuned"
+                                 else random_case(rng))
         if args.dropout:
             kw["attn_dropout"] = rng.choice([0.0, 0.1, 0.3])
             kw["ff_dropout"] = rng.choice([0.0, 0.2]) if kw["attn_dropout"] > 0 else 0.2
