@@ -209,16 +209,56 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs g) {
     for (int j = 0; j < 2; ++j) {
       const int n = n0 + 32 * j + col;
       if (n >= g.N) continue;
+      // accumulate: all sixteen old values are requested before the first store (a load behind a store to possibly the same
+      // address waits for it: the one-by-one form was 64 dependent round trips per lane, 34 us for a 128 x 512 x 8 product)
+      float old[16];
+      const bool rmw = g.nsplit == 1 && g.accumulate;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (m < g.M) {
-          float *dst = C + (long)m * g.ldc + n;
-          if (g.nsplit > 1) *dst = acc[i][j][r];
-          else { const float v = g.alpha * acc[i][j][r]; *dst = g.accumulate ? *dst + v : v; }
-        }
+        old[r] = (rmw && m < g.M) ? C[(long)m * g.ldc + n] : 0.0f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (m < g.M) C[(long)m * g.ldc + n] = g.nsplit > 1 ? acc[i][j][r] : old[r] + g.alpha * acc[i][j][r];
       }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K <= 16 rows: the weight gradient of a one-token context (the omic K/V projection: dW[1024, 2005] = dKV^T c over the b <= 16
+// samples of a batch) is an outer-product sum -- 8 MB of output for 33 MFLOP.  On the MFMA kernel above 128 workgroups computed
+// 128 x 128 tiles over four k-pairs and stored them as 64 scattered dwords per lane (21.5 us); here a thread keeps its column of
+// B (K values) in registers, takes 8 rows of A as wave-uniform scalars and writes 8 coalesced row segments: one pass at the
+// store rate.  The bias gradient (column sums of A) rides in the first column block.
+// ------------------------------------------------------------------------------------------------
+constexpr int TNS_KMAX = 16, TNS_ROWS = 8;
+__global__ __launch_bounds__(256) void gemm_tn_smallk_kernel(const float *__restrict__ A, long lda, const float *__restrict__ B, long ldb,
+                                                             float *__restrict__ C, long ldc, int M, int N, int K, float alpha,
+                                                             int accumulate, float *__restrict__ colsum, int colsum_accumulate) {
+  const int n = blockIdx.x * 256 + threadIdx.x, m0 = blockIdx.y * TNS_ROWS;
+  float bv[TNS_KMAX];
+#pragma unroll
+  for (int k = 0; k < TNS_KMAX; ++k) bv[k] = (k < K && n < N) ? B[(long)k * ldb + n] : 0.0f;
+  float acc[TNS_ROWS], old[TNS_ROWS];
+#pragma unroll
+  for (int r = 0; r < TNS_ROWS; ++r) {
+    const int m = min(m0 + r, M - 1);
+    old[r] = (accumulate && n < N) ? C[(long)m * ldc + n] : 0.0f;      // all old values requested ahead of the stores
+    float a_ = 0.0f, cs = 0.0f;
+#pragma unroll
+    for (int k = 0; k < TNS_KMAX; ++k) {
+      const float a = k < K ? A[(long)k * lda + m] : 0.0f;      // wave-uniform: scalar loads
+      a_ = fmaf(a, bv[k], a_);
+      cs += a;
+    }
+    acc[r] = a_;
+    if (colsum && blockIdx.x == 0 && threadIdx.x == 0 && m0 + r < M) colsum[m] = colsum_accumulate ? colsum[m] + cs : cs;
+  }
+#pragma unroll
+  for (int r = 0; r < TNS_ROWS; ++r)
+    if (m0 + r < M && n < N) C[(long)(m0 + r) * ldc + n] = old[r] + alpha * acc[r];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -358,14 +398,17 @@ __device__ __forceinline__ void gemm_tn_lds_body(GemmTnArgs g, int bx, int by, i
     for (int j = 0; j < 2; ++j) {
       const int n = n0 + 32 * j + col;
       if (n >= g.N) continue;
+      float old[16];                                  // (accumulate: loads first, see gemm_tn_kernel)
+      const bool rmw = g.nsplit == 1 && g.accumulate;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (m < g.M) {
-          float *dst = C + (long)m * g.ldc + n;
-          if (g.nsplit > 1) *dst = acc[i][j][r];
-          else { const float v = g.alpha * acc[i][j][r]; *dst = g.accumulate ? *dst + v : v; }
-        }
+        old[r] = (rmw && m < g.M) ? C[(long)m * g.ldc + n] : 0.0f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (m < g.M) C[(long)m * g.ldc + n] = g.nsplit > 1 ? acc[i][j][r] : old[r] + g.alpha * acc[i][j][r];
       }
     }
 }
@@ -514,6 +557,12 @@ static int launch_gemm_tn(const float *A, long lda, const float *B, long ldb, fl
     size_t cap = (size_t)GEMM_EX_SPLITS * ((size_t)M * N + M);
     if (cap < (size_t)TN_SCRATCH_MIN_FLOATS) cap = (size_t)TN_SCRATCH_MIN_FLOATS;
     return launch_gemm_tn_glds(A, lda, B, ldb, C, ldc, M, N, K, alpha, accumulate, scratch, cap, colsum, colsum_accumulate, s);
+  }
+  if (K <= TNS_KMAX && batch == 1 && (long)M * N >= (1L << 14)) {      // outer-product sum over a handful of rows, wide output
+    hipLaunchKernelGGL(gemm_tn_smallk_kernel, dim3(ceil_div(N, 256), ceil_div(M, TNS_ROWS)), dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, K, alpha,
+                       accumulate, colsum, colsum_accumulate);
+    HN_LAUNCH_CHECK("gemm_tn_smallk");
+    return HN_OK;
   }
   const int tiles = ceil_div(M, 128) * ceil_div(N, 128) * batch;
   int nsplit = 1;
@@ -977,11 +1026,22 @@ __global__ __launch_bounds__(256) void kv_weight_grads_kernel(const float *__res
   float sg = 0.0f, sb = 0.0f;
   if (c < D) {
     const float gm = gamma ? gamma[c] : 1.0f, bt = beta ? beta[c] : 0.0f;
-    for (int n = n0 + wv; n < n1; n += 4) {
-      const float gv = G[(long)n * D + c], wv_ = w[(long)n * D + c], csn = cs[n];
-      if (dw) dw[(long)n * D + c] += gv * gm + csn * bt;
-      sg += wv_ * gv;
-      sb += wv_ * csn;
+    // four rows per trip, every load (the old dW values too) requested before the first store
+    for (int n = n0 + wv; n < n1; n += 16) {
+      float gv[4], wv_[4], csn[4], od[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int nn = min(n + 4 * u, n1 - 1);
+        gv[u] = G[(long)nn * D + c]; wv_[u] = w[(long)nn * D + c]; csn[u] = cs[nn];
+        od[u] = dw ? dw[(long)nn * D + c] : 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (n + 4 * u >= n1) break;
+        if (dw) dw[(long)(n + 4 * u) * D + c] = od[u] + (gv[u] * gm + csn[u] * bt);
+        sg += wv_[u] * gv[u];
+        sb += wv_[u] * csn[u];
+      }
     }
   }
   pg[wv][threadIdx.x & 63] = sg;
@@ -1170,7 +1230,13 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float *__restrict__
     const int wv = tid >> 6, ln = tid & 63;
     for (int c = ln; c < d; c += 64) {
       float s = 0.0f;
-      for (int r = wv; r < L; r += 4) s += xb[(long)r * d + c];
+      for (int r = wv; r < L; r += 32) {                       // eight rows in flight per trip (one dependent load per row: 32 us at L = 128)
+        float v8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v8[u] = r + 4 * u < L ? xb[(long)(r + 4 * u) * d + c] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v8[u];
+      }
       part[wv * d + c] = s;
     }
   }

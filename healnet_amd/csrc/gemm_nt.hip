@@ -624,9 +624,12 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float *__rest
   }
   if (n >= N) return;
   float *dst = C + (long)m * ldc + n;
+  float old[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) old[e] = (accumulate && n + e < N) ? dst[e] : 0.0f;
 #pragma unroll
   for (int e = 0; e < 4; ++e)
-    if (n + e < N) dst[e] = accumulate ? dst[e] + alpha * acc[e] : alpha * acc[e];
+    if (n + e < N) dst[e] = old[e] + alpha * acc[e];
 }
 
 #ifdef HN_GEMM_NT_BENCH
