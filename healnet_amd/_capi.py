@@ -12,7 +12,7 @@ import sys
 from typing import Optional
 
 HN_MAX_AXES = 4
-HN_ABI_VERSION = 7
+HN_ABI_VERSION = 8
 HN_F32, HN_BF16, HN_U8 = 0, 1, 2
 HN_CORE_F32, HN_CORE_BF16, HN_CORE_BF16X3 = 0, 1, 2
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -112,6 +112,13 @@ SIGNATURES = {
                                            C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "hn_encode_norm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_float, C.c_int,
                                  C.c_float, C.c_void_p, C.c_int, C.c_void_p]),
+    "hn_encode_norm_slab": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_float, C.c_int,
+                                      C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "hn_attn_partial_fwd": (C.c_int, [C.POINTER(AttnParams), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "hn_attn_merge_workspace_bytes": (C.c_size_t, [C.POINTER(AttnParams), C.c_int, C.c_int]),
+    "hn_attn_merge_fwd": (C.c_int, [C.POINTER(AttnParams), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                    C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "hn_context_pitch": (C.c_int, [C.c_int, C.c_int]),
     "hn_attn_fwd": (C.c_int, [C.POINTER(AttnParams), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                               C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

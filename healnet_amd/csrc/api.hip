@@ -506,6 +506,43 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
   return launch_gemm(go, s);
 }
 
+// o (b*L, inner) = sum_r w_r o_r / sum_r w_r,  w_r = 2^(M_r - M) l_r,  M = max_r M_r  per (sample, head, row); fixed order
+template <int V>      // V columns per thread: 4 (dim_head % 4 == 0: 16-byte pieces) or 1
+__global__ __launch_bounds__(256) void attn_merge_parts_kernel(const float *__restrict__ o_parts, const float *__restrict__ st_parts,
+                                                               int n_parts, int b, int heads, int L, int dh, float *__restrict__ o,
+                                                               float *__restrict__ st_out) {
+  const int inner = heads * dh, pieces = inner / V;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)b * L * pieces) return;
+  const long row = idx / pieces;
+  const int c = (int)(idx - row * pieces) * V, h = c / dh;
+  const int bi = (int)(row / L), q = (int)(row - (long)bi * L);
+  const long srow = (((long)bi * heads + h) * L + q) * 2, sstride = (long)b * heads * L * 2, ostride = (long)b * L * inner;
+  float M = -3.0e38f;
+  for (int r = 0; r < n_parts; ++r) M = fmaxf(M, st_parts[r * sstride + srow]);
+  float wsum = 0.0f, acc[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) acc[e] = 0.0f;
+  for (int r = 0; r < n_parts; ++r) {
+    const float w = exp2f(st_parts[r * sstride + srow] - M) * st_parts[r * sstride + srow + 1];
+    if (!(w > 0.0f)) continue;        // a shard whose keys are all masked has l = 0 and a 0 / 0 output: weight zero, never read
+                                      // (every shard dead: 0 / 0 = NaN, like the reference's softmax over a fully masked row)
+    const float *src = &o_parts[r * ostride + row * inner + c];
+    if (V == 4) {
+      const f32x4 v = *(const f32x4 *)src;
+#pragma unroll
+      for (int e = 0; e < V; ++e) acc[e] = fmaf(w, v[e], acc[e]);
+    } else {
+      acc[0] = fmaf(w, src[0], acc[0]);
+    }
+    wsum += w;
+  }
+  const float inv = 1.0f / wsum;
+#pragma unroll
+  for (int e = 0; e < V; ++e) o[row * inner + c + e] = acc[e] * inv;
+  if (st_out && c == h * dh) { st_out[srow] = M; st_out[srow + 1] = wsum; }
+}
+
 // ------------------------------------------------------------------------------------------------
 // attention block, backward
 // ------------------------------------------------------------------------------------------------
@@ -1372,6 +1409,74 @@ int hn_encode_norm(const float *data, int b, int n_axes, const int *spatial, int
                    float max_freq, int fourier, float eps, float *z, int ld_out, void *stream) {
   return launch_encode(data, HN_F32, b, n_axes, spatial, channels, num_freq_bands, max_freq, fourier, 1, eps, z, ld_out,
                        (hipStream_t)stream);
+}
+
+int hn_encode_norm_slab(const float *data, int b, int n_axes, const int *spatial, int channels, int num_freq_bands,
+                        float max_freq, int fourier, float eps, float *z, int ld_out, int axis0_begin, int axis0_total,
+                        void *stream) {
+  HN_REQUIRE(axis0_total > 0, HN_E_SHAPE, "encode_norm_slab: axis0_total=%d", axis0_total);
+  return launch_encode(data, HN_F32, b, n_axes, spatial, channels, num_freq_bands, max_freq, fourier, 1, eps, z, ld_out,
+                       (hipStream_t)stream, -1, 0, axis0_begin, axis0_total);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Context split over ranks (second axis): a rank attends to ITS tokens only and hands back the normalised
+// output of its shard with the softmax statistics; hn_attn_merge_fwd folds the shards of all ranks (the split-KV merge, one
+// level up) and finishes the block.
+// ------------------------------------------------------------------------------------------------
+int hn_attn_partial_fwd(const hn_attn_params *p, const float *x_in, const float *ctx, int ld_ctx, int b, int L, int N, int D,
+                        const uint8_t *mask, float *o_part, float *stats, void *workspace, size_t workspace_bytes, void *stream) {
+  HN_REQUIRE(p && x_in && ctx && o_part && stats, HN_E_NULL, "attn_partial_fwd: NULL pointer");
+  HN_REQUIRE(p->dropout == 0.0f, HN_E_UNSUPPORTED, "attn_partial_fwd: inference only (dropout = %g)", (double)p->dropout);
+  HN_REQUIRE(N >= 2 || mask != nullptr, HN_E_UNSUPPORTED, "attn_partial_fwd: a one-token shard has no statistics; give it to hn_attn_fwd whole");
+  hipStream_t s = (hipStream_t)stream;
+  AttnExt ext;
+  memset(&ext, 0, sizeof(ext));
+  ext.defer_out = true;
+  int rc = attn_fwd_impl(p, x_in, nullptr, 0, ctx, ld_ctx, b, L, N, D, mask, stats, workspace, workspace_bytes, s, nullptr, nullptr,
+                         nullptr, false, 0, nullptr, nullptr, &ext);
+  if (rc != HN_OK) return rc;
+  HN_REQUIRE(ext.o_out != nullptr && !ext.merge_deferred, HN_E_UNSUPPORTED, "attn_partial_fwd: the block did not report its output");
+  const int inner = p->heads * p->dim_head;
+  if (ext.ldo_out == inner) return launch_copy(o_part, ext.o_out, (long)((size_t)b * L * inner), s);
+  HN_HIP_CHECK(hipMemcpy2DAsync(o_part, (size_t)inner * 4, ext.o_out, (size_t)ext.ldo_out * 4, (size_t)inner * 4, (size_t)b * L,
+                                hipMemcpyDeviceToDevice, s));
+  return HN_OK;
+}
+
+size_t hn_attn_merge_workspace_bytes(const hn_attn_params *p, int b, int L) {
+  if (!p || b <= 0 || L <= 0) return 0;
+  return align_up((size_t)b * L * p->heads * p->dim_head * sizeof(float), 256);
+}
+
+int hn_attn_merge_fwd(const hn_attn_params *p, const float *x_in, float *x_out, int residual, const float *o_parts,
+                      const float *stats_parts, int n_parts, int b, int L, float *stats, void *workspace, size_t workspace_bytes,
+                      void *stream) {
+  HN_REQUIRE(p && x_in && x_out && o_parts && stats_parts && p->w_out, HN_E_NULL, "attn_merge_fwd: NULL pointer");
+  HN_REQUIRE(n_parts >= 1 && b > 0 && L > 0, HN_E_SHAPE, "attn_merge_fwd: parts=%d b=%d L=%d", n_parts, b, L);
+  int rc = check_ws(workspace, workspace_bytes, hn_attn_merge_workspace_bytes(p, b, L), "attn_merge_fwd");
+  if (rc != HN_OK) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const int inner = p->heads * p->dim_head;
+  float *obuf = (float *)workspace;
+  const bool vec = p->dim_head % 4 == 0 && (((uintptr_t)o_parts | (uintptr_t)obuf) & 15) == 0;
+  const long pieces = (long)b * L * (vec ? inner >> 2 : inner);
+  if (vec)
+    hipLaunchKernelGGL(attn_merge_parts_kernel<4>, dim3((unsigned)ceil_div_ll(pieces, 256)), dim3(256), 0, s, o_parts, stats_parts, n_parts, b,
+                       p->heads, L, p->dim_head, obuf, stats);
+  else
+    hipLaunchKernelGGL(attn_merge_parts_kernel<1>, dim3((unsigned)ceil_div_ll(pieces, 256)), dim3(256), 0, s, o_parts, stats_parts, n_parts, b,
+                       p->heads, L, p->dim_head, obuf, stats);
+  HN_LAUNCH_CHECK("attn_merge_parts");
+  GemmArgs go = gemm_defaults();
+  go.A = obuf; go.lda = inner;
+  go.W = p->w_out; go.ldw = wo_ld(p);
+  go.C = x_out; go.ldc = p->query_dim;
+  go.bias = p->b_out;
+  go.M = b * L; go.N = p->query_dim; go.K = inner;
+  go.act = ACT_LEAKY;
+  if (residual) { go.R = x_in; go.ldr = p->query_dim; }
+  return launch_gemm(go, s);
 }
 
 size_t hn_attn_workspace_bytes(const hn_attn_params *p, int has_ctx, int ld_ctx, int b, int L, int N, int D) {

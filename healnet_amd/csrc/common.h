@@ -436,7 +436,7 @@ int launch_vfold(const VfoldMulti &v, hipStream_t s);
 // ------------------------------------------------------------------------------------------------
 int launch_encode(const void *data, int in_dtype, int b, int n_axes, const int *spatial, int C, int F, float max_freq,
                   int fourier, int normalize, float eps, float *out, int ld_out, hipStream_t s, int ones_col = -1,
-                  int pack_ks = 0);
+                  int pack_ks = 0, int axis0_begin = 0, int axis0_total = 0);      // axis0_total > 0: `spatial[0]` rows from axis0_begin of a longer axis
 int launch_encode_bf16ctx(const void *data, int in_dtype, int b, int n_axes, const int *spatial, int C, int F, float max_freq,
                           int fourier, float eps, uint16_t *zb, uint16_t *zT, int Np, int DV, int ns, hipStream_t s);
 

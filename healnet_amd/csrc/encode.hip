@@ -24,6 +24,9 @@ struct EncGeom {
   int fourier, normalize;
   float eps;
   int ones_col;   // >= 0: this padding column is written as 1.0 (the attention core's synthetic ones column)
+  // window along axis 0 (context split over ranks, healnet_amd.dist.context_parallel_forward): the data holds rows
+  // [off0, off0 + S[0]) of an axis of full0 positions; off0 = 0, full0 = S[0] for a whole modality
+  int off0, full0;
 };
 
 // torch.linspace(-1, 1, S)[i] in fp32 (ATen's symmetric formulation: ascending from the start for the
@@ -56,11 +59,16 @@ __device__ __forceinline__ void token_coords(long n, const EncGeom &g, int *idx)
   }
 }
 
+// position of coordinate idx[a] on axis a (axis 0 may be a window of a longer axis)
+__device__ __forceinline__ float axis_pos_of(int a, const int *idx, const EncGeom &g) {
+  return a == 0 ? axis_pos(idx[0] + g.off0, g.full0) : axis_pos(idx[a], g.S[a]);
+}
+
 // positional feature j (0 <= j < n_axes*(2F+1)) of a token with coordinates idx
 __device__ __forceinline__ float pos_feature(int j, const int *idx, const EncGeom &g) {
   const int per = 2 * g.F + 1;
   int a = j / per, w = j - a * per;
-  float p = axis_pos(idx[a], g.S[a]);
+  float p = axis_pos_of(a, idx, g);
   if (w == 2 * g.F) return p;
   int f = (w < g.F) ? w : w - g.F;
   float arg = __fmul_rn(__fmul_rn(p, band_scale(f, g.F, g.max_freq)), 3.14159265358979323846f);  // (p*s)*pi, :299
@@ -103,7 +111,7 @@ __global__ __launch_bounds__(256) void encode_token_kernel(const IN *__restrict_
     for (int c = 0; c < LD; ++c) v[c] = c < SC ? in_at(src, c) : 0.0f;
 #pragma unroll
     for (int a = 0; a < SA; ++a) {
-      const float p = axis_pos(idx[a], g.S[a]);
+      const float p = axis_pos_of(a, idx, g);
 #pragma unroll
       for (int f = 0; f < SF; ++f) {
         const float arg = __fmul_rn(__fmul_rn(p, band_scale(f, SF, g.max_freq)), 3.14159265358979323846f);  // (p*s)*pi, :299
@@ -355,6 +363,8 @@ static int fill_geom(EncGeom *g, int b, int n_axes, const int *spatial, int C, i
   g->eps = eps;
   g->ones_col = -1;
   g->ld_out = 0;
+  g->off0 = 0;
+  g->full0 = g->S[0];
   return HN_OK;
 }
 
@@ -409,7 +419,8 @@ static int launch_encode_t(const IN *data, EncGeom g, int b, float *out, int ld_
 }
 
 int launch_encode(const void *data, int in_dtype, int b, int n_axes, const int *spatial, int C, int F, float max_freq,
-                  int fourier, int normalize, float eps, float *out, int ld_out, hipStream_t s, int ones_col, int pack_ks) {
+                  int fourier, int normalize, float eps, float *out, int ld_out, hipStream_t s, int ones_col, int pack_ks,
+                  int axis0_begin, int axis0_total) {
   HN_REQUIRE(data && out, HN_E_NULL, "encode: NULL pointer");
   HN_REQUIRE(in_dtype == HN_F32 || in_dtype == HN_BF16 || in_dtype == HN_U8, HN_E_UNSUPPORTED,
              "encode: dtype=%d (0 = fp32, 1 = bf16, 2 = uint8)", in_dtype);
@@ -419,6 +430,11 @@ int launch_encode(const void *data, int in_dtype, int b, int n_axes, const int *
   g.ld_out = ld_out;
   g.ones_col = (ones_col >= g.D && ones_col < ld_out) ? ones_col : -1;
   HN_REQUIRE(ld_out >= g.D, HN_E_SHAPE, "encode: ld_out=%d < D=%d", ld_out, g.D);
+  if (axis0_total > 0) {
+    HN_REQUIRE(axis0_begin >= 0 && axis0_begin + g.S[0] <= axis0_total, HN_E_SHAPE, "encode: axis-0 window [%d, %d) of %d", axis0_begin,
+               axis0_begin + g.S[0], axis0_total);
+    g.off0 = axis0_begin; g.full0 = axis0_total;
+  }
   if (in_dtype == HN_BF16) return launch_encode_t((const uint16_t *)data, g, b, out, ld_out, s, pack_ks);
   if (in_dtype == HN_U8) return launch_encode_t((const uint8_t *)data, g, b, out, ld_out, s, pack_ks);
   return launch_encode_t((const float *)data, g, b, out, ld_out, s, pack_ks);
@@ -457,7 +473,7 @@ __global__ __launch_bounds__(256) void encode_bf16ctx_kernel(const IN *__restric
       for (int c = 0; c < SC; ++c) v[c] = in_at(src, c);
 #pragma unroll
       for (int a = 0; a < SA; ++a) {
-        const float p = axis_pos(idx[a], g.S[a]);
+        const float p = axis_pos_of(a, idx, g);
 #pragma unroll
         for (int f = 0; f < SF; ++f) {
           const float arg = __fmul_rn(__fmul_rn(p, band_scale(f, SF, g.max_freq)), 3.14159265358979323846f);  // (p*s)*pi, :299

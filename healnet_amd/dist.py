@@ -259,3 +259,99 @@ def max_over_ranks(value: float, device: Optional[torch.device] = None) -> float
     t = torch.tensor([value], dtype=torch.float64, device=device or "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+# ------------------------------------------------------------------------------------------------
+# Context split: the optional second axis of SURVEY.md 8(e) -- b < #GPUs, one huge volume
+# ------------------------------------------------------------------------------------------------
+def slab_bounds(n_rows: int, rank: int, world: int) -> Tuple[int, int]:
+    """Rows [lo, hi) of a modality's first spatial axis that `rank` attends to (contiguous, the first n_rows % world ranks take
+    one extra row; a rank may get none when there are fewer rows than ranks)."""
+    return shard_bounds(n_rows, rank, world)
+
+
+def gather_partials(o_part: torch.Tensor, stats: torch.Tensor, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """ONE all-gather of a cross-attention block's per-rank (normalised output (b, L, inner), statistics (b, heads, L, 2)) pairs:
+    b * L * (inner + 2 * heads) floats per rank (270 KB per sample with the default model) -> (G, b, L, inner), (G, b, heads, L, 2),
+    rank-major.  The xGMI mesh is point-to-point: one small message per peer, no ring."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1 and not force_collectives():
+        return o_part.unsqueeze(0), stats.unsqueeze(0)
+    n_o = o_part.numel()
+    flat = torch.cat([o_part.reshape(-1), stats.reshape(-1)])
+    out = torch.empty(world * flat.numel(), dtype=flat.dtype, device=flat.device)
+    dist.all_gather_into_tensor(out, flat, group=group)
+    out = out.view(world, -1)
+    return out[:, :n_o].reshape((world,) + tuple(o_part.shape)).contiguous(), out[:, n_o:].reshape((world,) + tuple(stats.shape)).contiguous()
+
+
+def context_parallel_forward(model, tensors: Sequence[Optional[torch.Tensor]], group=None, return_embeddings: bool = False,
+                             min_rows_per_rank: int = 2, rank: Optional[int] = None, world: Optional[int] = None,
+                             gather=None) -> torch.Tensor:
+    """Inference forward of a HealNet whose CONTEXTS are split over the ranks of `group` (every rank passes the SAME full-batch
+    `tensors`; a rank reads only its slab of each split modality): the reference's fusion loop (healnet.py:225-250) block by
+    block through the C ABI --
+
+      cross block of a split modality   hn_encode_norm_slab (once per modality) -> hn_attn_partial_fwd on the rank's tokens ->
+                                        one all-gather of (output, statistics) per block -> hn_attn_merge_fwd (every rank folds
+                                        all shards in rank order: bit-identical latents everywhere, no broadcast needed)
+      everything else                   replicated: cross blocks of short modalities (fewer than `min_rows_per_rank` rows per
+                                        rank, e.g. the one-token tabular input), feed-forward blocks, latent self blocks, head.
+
+    Partition = the first spatial axis (image rows, volume slices, bag patches), contiguous slabs.  For b >= #GPUs shard the BATCH
+    instead (no forward collective at all).  No mask, no dropout, no missing modalities (the plain inference forward)."""
+    from . import healnet as hm                              # (late: healnet.py imports this package's ops)
+    hip = torch.ops.healnet_hip
+    if rank is None:
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if world is None:
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+    gather = gather or (lambda o, st: gather_partials(o, st, group))
+    M = model.modalities
+    if len(tensors) != M or any(t is None for t in tensors):
+        raise ValueError("context_parallel_forward takes every modality (missing modalities: use the plain forward)")
+    if model.training and model._any_dropout:
+        raise NotImplementedError("context_parallel_forward is an inference path (dropout off)")
+    b = tensors[0].shape[0]
+    ctx: List[Optional[torch.Tensor]] = [None] * M          # the rank's normalised slab, or the whole context of a replicated modality
+    split = [False] * M
+    with torch.no_grad():
+        for m, data in enumerate(tensors):
+            att = model.layers[0][2 * m].fn
+            pitch = _capi_lib().hn_context_pitch(model.context_dims[m], att.dim_head)
+            rows = data.shape[1]
+            tokens_per_row = data[0, 0].numel() // data.shape[-1]
+            split[m] = world > 1 and rows >= world * max(1, min_rows_per_rank) and (rows // world) * tokens_per_row >= 2
+            if split[m]:
+                lo, hi = slab_bounds(rows, rank, world)
+                ctx[m] = hip.encode_norm_slab(data[:, lo:hi].contiguous(), model.num_freq_bands, model.max_freq, model.fourier_encode_data,
+                                              pitch, lo, rows)
+            else:
+                ctx[m] = hip.encode_norm(data, model.num_freq_bands, model.max_freq, model.fourier_encode_data, pitch)
+        x = model.latents.detach().unsqueeze(0).expand(b, -1, -1).contiguous()
+        for layer in model.layers:
+            for m in range(M):
+                pn, ff = layer[2 * m], layer[2 * m + 1]
+                a = pn.fn
+                wts = (pn.norm.weight, pn.norm.bias, pn.norm_context.weight, pn.norm_context.bias, a.to_q.weight, a.to_kv.weight,
+                       a.to_out[0].weight, a.to_out[0].bias)
+                if split[m]:
+                    o, st = hip.attention_partial(x, ctx[m], None, *wts, a.heads)
+                    o_all, st_all = gather(o, st)
+                    x, _ = hip.attention_merge(x, o_all, st_all, a.to_q.weight, a.to_out[0].weight, a.to_out[0].bias, a.heads, True)
+                else:
+                    x = hip.attention(x, ctx[m], None, *wts, a.heads, True)
+                f = ff.fn
+                x = hip.feed_forward(x, ff.norm.weight, ff.norm.bias, f.net[0].weight, f.net[0].bias, f.net[2].weight, f.net[2].bias,
+                                     not f.snn, True)
+                if model.self_per_cross_attn > 0:
+                    x = hm.latent_block(layer[2 * M][0], layer[2 * M][1], x)
+        if return_embeddings or not model.final_classifier_head:
+            return x
+        ln, lin = model.to_logits[1], model.to_logits[2]
+        return hip.head(x, ln.weight, ln.bias, lin.weight, lin.bias)
+
+
+def _capi_lib():
+    from . import _capi
+    return _capi.lib()

@@ -42,6 +42,12 @@ from ._rt import WS, f32c as _f32c, ptr as _ptr, stream_ptr as _stream_ptr
 _lib = torch.library.Library("healnet_hip", "DEF")
 _lib.define("fourier_encode_concat(Tensor data, int num_freq_bands, float max_freq, bool fourier_encode_data) -> Tensor")
 _lib.define("encode_norm(Tensor data, int num_freq_bands, float max_freq, bool fourier_encode_data, int pitch) -> Tensor")
+_lib.define("encode_norm_slab(Tensor data, int num_freq_bands, float max_freq, bool fourier_encode_data, int pitch, int axis0_begin, "
+            "int axis0_total) -> Tensor")
+_lib.define("attention_partial(Tensor x, Tensor context, Tensor? mask, Tensor? norm_w, Tensor? norm_b, Tensor? ctx_gamma, "
+            "Tensor? ctx_beta, Tensor w_q, Tensor w_kv, Tensor w_out, Tensor b_out, int heads) -> (Tensor, Tensor)")
+_lib.define("attention_merge(Tensor x, Tensor o_parts, Tensor stats_parts, Tensor w_q, Tensor w_out, Tensor b_out, int heads, "
+            "bool residual) -> (Tensor, Tensor)")
 _ATTN_ARGS = ("Tensor x, Tensor? context, Tensor? mask, Tensor? norm_w, Tensor? norm_b, Tensor? ctx_gamma, Tensor? ctx_beta, "
               "Tensor w_q, Tensor w_kv, Tensor w_out, Tensor b_out, int heads, bool residual")
 _lib.define(f"attention({_ATTN_ARGS}) -> Tensor")
@@ -357,6 +363,26 @@ def _(data, num_freq_bands, max_freq, fourier_encode_data, pitch):
     return data.new_empty((data.shape[0], n, pitch), dtype=torch.float32)
 
 
+def _encode_norm_slab(data, num_freq_bands, max_freq, fourier_encode_data, pitch, axis0_begin, axis0_total):
+    """hn_encode_norm_slab: rows [axis0_begin, axis0_begin + data.shape[1]) of a modality whose first spatial axis has axis0_total
+    positions (context split over ranks): the tokens get the positional features they have in the whole tensor."""
+    x = _f32c(data)
+    spatial, n = _spatial(x)
+    b, ch = x.shape[0], x.shape[-1]
+    z = torch.empty(b, n, pitch, dtype=torch.float32, device=x.device)
+    sp = (C.c_int * len(spatial))(*spatial)
+    _capi.check(_capi.lib().hn_encode_norm_slab(x.data_ptr(), b, len(spatial), sp, ch, num_freq_bands, float(max_freq),
+                                                int(fourier_encode_data), 1e-5, z.data_ptr(), pitch, int(axis0_begin),
+                                                int(axis0_total), _stream_ptr(x.device)), "hn_encode_norm_slab")
+    return z
+
+
+@torch.library.register_fake("healnet_hip::encode_norm_slab")
+def _(data, num_freq_bands, max_freq, fourier_encode_data, pitch, axis0_begin, axis0_total):
+    _, n = _spatial(data)
+    return data.new_empty((data.shape[0], n, pitch), dtype=torch.float32)
+
+
 def _temperature_softmax(logits, temperature):
     x = _f32c(logits)
     y = torch.empty_like(x)
@@ -426,6 +452,56 @@ def _(x, context, mask, norm_w, norm_b, ctx_gamma, ctx_beta, w_q, w_kv, w_out, b
         n_saved = _capi.lib().hn_attn_saved_floats(C.byref(p), int(context is not None), ld, b, L, N, D, int(mask is not None))
     return (x.new_empty(x.shape, dtype=torch.float32), x.new_empty((b, heads, L, 2), dtype=torch.float32),
             x.new_empty((n_saved,), dtype=torch.float32))
+
+
+def _attention_partial(x, context, mask, norm_w, norm_b, ctx_gamma, ctx_beta, w_q, w_kv, w_out, b_out, heads):
+    """hn_attn_partial_fwd: the block of healnet.py:400-424 over THIS rank's tokens -> (normalised output of the shard
+    (b, L, inner), softmax statistics (b, heads, L, 2)).  Inference only."""
+    lib = _capi.lib()
+    x = _f32c(x)
+    ctx = _f32c(context)
+    p, (b, L, N, D, ld) = _attn_params(x, ctx, norm_w, norm_b, ctx_gamma, ctx_beta, w_q, w_kv, w_out, b_out, heads)
+    m = _mask_u8(mask, b)
+    need = lib.hn_attn_workspace_bytes(C.byref(p), 1, ld, b, L, N, D)
+    if need == 0:
+        _capi.check(-1, "hn_attn_workspace_bytes")
+    ws = WS.get(x.device, need)
+    o = torch.empty(b, L, w_q.shape[0], dtype=torch.float32, device=x.device)
+    stats = torch.empty(b, heads, L, 2, dtype=torch.float32, device=x.device)
+    _capi.check(lib.hn_attn_partial_fwd(C.byref(p), x.data_ptr(), ctx.data_ptr(), ld, b, L, N, D, _ptr(m), o.data_ptr(),
+                                        stats.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(x.device)), "hn_attn_partial_fwd")
+    return o, stats
+
+
+@torch.library.register_fake("healnet_hip::attention_partial")
+def _(x, context, mask, norm_w, norm_b, ctx_gamma, ctx_beta, w_q, w_kv, w_out, b_out, heads):
+    b, L = x.shape[0], x.shape[1]
+    return x.new_empty((b, L, w_q.shape[0]), dtype=torch.float32), x.new_empty((b, heads, L, 2), dtype=torch.float32)
+
+
+def _attention_merge(x, o_parts, stats_parts, w_q, w_out, b_out, heads, residual):
+    """hn_attn_merge_fwd: fold the shards' (output, statistics) pairs -- (G, b, L, inner), (G, b, heads, L, 2) -- and finish the
+    block (healnet.py:425-426 + the residual).  Returns (x_out, merged statistics)."""
+    lib = _capi.lib()
+    x = _f32c(x)
+    o_parts, stats_parts = _f32c(o_parts), _f32c(stats_parts)
+    b, L, qd = x.shape
+    inner = w_q.shape[0]
+    p = _capi.AttnParams(heads=heads, dim_head=inner // heads, query_dim=qd, w_q=_ptr(w_q), w_kv=_ptr(w_q), w_out=_ptr(w_out),
+                         b_out=_ptr(b_out))
+    need = lib.hn_attn_merge_workspace_bytes(C.byref(p), b, L)
+    ws = WS.get(x.device, need)
+    out = torch.empty_like(x)
+    stats = torch.empty(b, heads, L, 2, dtype=torch.float32, device=x.device)
+    _capi.check(lib.hn_attn_merge_fwd(C.byref(p), x.data_ptr(), out.data_ptr(), int(residual), o_parts.data_ptr(),
+                                      stats_parts.data_ptr(), int(o_parts.shape[0]), b, L, stats.data_ptr(), ws.data_ptr(), ws.numel(),
+                                      _stream_ptr(x.device)), "hn_attn_merge_fwd")
+    return out, stats
+
+
+@torch.library.register_fake("healnet_hip::attention_merge")
+def _(x, o_parts, stats_parts, w_q, w_out, b_out, heads, residual):
+    return x.new_empty(x.shape, dtype=torch.float32), x.new_empty((x.shape[0], heads, x.shape[1], 2), dtype=torch.float32)
 
 
 def _opt_out(t: Optional[torch.Tensor], like: Optional[torch.Tensor]):
@@ -927,7 +1003,9 @@ for _name, _fn in (("fourier_encode_concat", _fourier_encode_concat), ("encode_n
                    ("head", _head), ("head_bwd", _head_bwd), ("temperature_softmax", _temperature_softmax),
                    ("latent_block_fwd", _latent_block_fwd), ("latent_block_bwd", _latent_block_bwd),
                    ("fusion_forward", _fusion_forward), ("fusion_forward_train", _fusion_forward_train),
-                   ("fusion_backward", _fusion_backward), ("fusion_backward_into", _fusion_backward_into)):
+                   ("fusion_backward", _fusion_backward), ("fusion_backward_into", _fusion_backward_into),
+                   ("encode_norm_slab", _encode_norm_slab), ("attention_partial", _attention_partial),
+                   ("attention_merge", _attention_merge)):
     _lib.impl(_name, _fn, "CUDA")
 _lib.impl("attention", _attention, "CompositeImplicitAutograd")
 _lib.impl("latent_block", _latent_block, "CompositeImplicitAutograd")

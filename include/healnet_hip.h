@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HN_ABI_VERSION 7
+#define HN_ABI_VERSION 8
 #define HN_MAX_AXES 4
 
 typedef enum hn_status {
@@ -86,6 +86,13 @@ int hn_fourier_encode_concat(const float *data, int b, int n_axes, const int *sp
 int hn_encode_norm(const float *data, int b, int n_axes, const int *spatial, int channels,
                    int num_freq_bands, float max_freq, int fourier, float eps, float *z, int ld_out,
                    void *stream);
+
+/* hn_encode_norm for a SLAB of a modality along its first spatial axis (context split over ranks, below): `data` holds rows
+ * [axis0_begin, axis0_begin + spatial[0]) of an axis of axis0_total positions; the positional features are those of the whole
+ * tensor (bit-identical to the rows hn_encode_norm writes for the same tokens). */
+int hn_encode_norm_slab(const float *data, int b, int n_axes, const int *spatial, int channels,
+                        int num_freq_bands, float max_freq, int fourier, float eps, float *z, int ld_out,
+                        int axis0_begin, int axis0_total, void *stream);
 
 /* Row pitch hn_fusion_forward uses for the normalised context of a modality with D encoded channels
  * when attending with `dim_head`: 16/32 for the rank-D reassociated path, else D rounded up to 4. */
@@ -146,6 +153,25 @@ int hn_attn_fwd(const hn_attn_params *p, const float *x_in, float *x_out, int re
                 const float *ctx, int ld_ctx, int b, int L, int N, int D, const uint8_t *mask,
                 float *stats, void *workspace, size_t workspace_bytes, void *stream);
 size_t hn_attn_workspace_bytes(const hn_attn_params *p, int has_ctx, int ld_ctx, int b, int L, int N, int D);
+
+/* Context split over ranks (the optional second axis: b < #GPUs, one huge volume): every rank holds the latent
+ * array and the parameters and attends to ITS N tokens only.
+ *   hn_attn_partial_fwd: LayerNorm(x), projections and the attention core of :400-424 over the shard -> o_part (b*L, heads*dim_head),
+ *     the NORMALISED attention output of the shard (head space: for the shared-context binding after the folded value
+ *     projection), and stats (b, heads, L, 2) = {reference exponent M in log2 units, l = sum_t 2^(s_t - M)} of the shard.
+ *     Inference only (dropout must be 0); a one-token shard without a mask is rejected (run such a modality whole).
+ *   The caller gathers o_part / stats of all ranks (one all-gather of b*L*(inner + 2*heads) floats per rank: 270 KB per sample
+ *   with the default model) into o_parts (n_parts, b*L, inner) and stats_parts (n_parts, b, heads, L, 2).
+ *   hn_attn_merge_fwd: o = sum_r w_r o_r / sum_r w_r with w_r = 2^(M_r - max M) l_r (exactly the softmax over the union of the
+ *     shards), then :425-426 + the residual: x_out = LeakyReLU(o W_out^T + b_out) [+ x_in].  stats (optional) receives the merged
+ *     pair.  Parts are folded in index order: every rank computes bit-identical x_out. */
+int hn_attn_partial_fwd(const hn_attn_params *p, const float *x_in, const float *ctx, int ld_ctx, int b, int L, int N, int D,
+                        const uint8_t *mask, float *o_part, float *stats, void *workspace, size_t workspace_bytes,
+                        void *stream);           /* workspace: hn_attn_workspace_bytes(p, 1, ld_ctx, b, L, N, D) */
+size_t hn_attn_merge_workspace_bytes(const hn_attn_params *p, int b, int L);
+int hn_attn_merge_fwd(const hn_attn_params *p, const float *x_in, float *x_out, int residual, const float *o_parts,
+                      const float *stats_parts, int n_parts, int b, int L, float *stats, void *workspace,
+                      size_t workspace_bytes, void *stream);
 
 /* fourier_encode(x, max_freq, num_bands) (healnet/models/healnet.py:292-302) on a flat array of n positions:
  * out (n, 2*num_bands+1) = [sin(x s_f pi) .., cos(x s_f pi) .., x], s = linspace(1, max_freq/2, num_bands).

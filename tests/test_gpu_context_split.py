@@ -1,0 +1,195 @@
+"""GPU: the context split over ranks (the optional second axis: b < #GPUs).
+
+  * hn_encode_norm_slab: a slab of a modality along its first spatial axis gets, bit for bit, the rows hn_encode_norm writes for
+    the same tokens of the whole tensor;
+  * hn_attn_partial_fwd over G shards + hn_attn_merge_fwd == hn_attn_fwd over the whole context == the CPU oracle
+    (shared-context / rank-D binding, explicit K/V binding, with and without a key mask, even and ragged shards, a shard whose keys
+    are all masked);
+  * healnet_amd.dist.context_parallel_forward with 2 and 3 processes on one GPU (gloo moves the partials): logits equal to the plain
+    forward and to the oracle, identical on every rank.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("shape,parts", [((2, 9, 5, 3), 2), ((1, 7, 4, 6, 2), 3), ((3, 40, 11), 4), ((2, 224, 8, 3), 8)],
+                         ids=["image", "volume", "bag", "image-8"])
+def test_encode_slabs_are_rows_of_the_whole_encode(shape, parts):
+    import healnet_amd  # noqa: F401
+    from healnet_amd import dist as hd
+    hip = torch.ops.healnet_hip
+    gen = torch.Generator().manual_seed(1)
+    data = torch.rand(*shape, generator=gen).to(DEV)
+    pitch = 32
+    whole = hip.encode_norm(data, 2, 10.0, True, pitch)
+    per_row = int(np.prod(shape[2:-1])) if len(shape) > 3 else 1
+    for r in range(parts):
+        lo, hi = hd.slab_bounds(shape[1], r, parts)
+        slab = hip.encode_norm_slab(data[:, lo:hi].contiguous(), 2, 10.0, True, pitch, lo, shape[1])
+        assert torch.equal(slab, whole[:, lo * per_row:hi * per_row]), f"slab {r} of {parts}"
+
+
+def _block(qd, D, heads, dh, seed):
+    import healnet_amd as hn
+    torch.manual_seed(seed)
+    pn = hn.healnet.PreNorm(qd, hn.Attention(qd, D, heads=heads, dim_head=dh), context_dim=D).to(DEV).eval()
+    with torch.no_grad():
+        for p in pn.parameters():
+            if p.dim() == 1:
+                p.add_(0.2 * torch.randn_like(p))
+    return pn
+
+
+CASES = [
+    dict(b=2, L=32, N=900, D=13, heads=4, dh=32, qd=64, parts=3),                    # shared-context (rank-D) binding, ragged shards
+    dict(b=1, L=128, N=6000, D=13, heads=8, dh=64, qd=128, parts=8),                 # the default model's image block, 8 ranks
+    dict(b=2, L=16, N=700, D=96, heads=2, dh=32, qd=32, parts=2),                    # explicit K/V binding
+    dict(b=1, L=128, N=4400, D=200, heads=8, dh=64, qd=128, parts=4),                # explicit binding on the LDS-DMA projection
+    dict(b=2, L=24, N=500, D=18, heads=2, dh=27, qd=40, parts=2, masked=True),       # padded head width + key mask
+    dict(b=2, L=16, N=600, D=13, heads=2, dh=16, qd=32, parts=3, masked=True, dead_shard=1),   # every key of one shard masked
+]
+
+
+@pytest.mark.parametrize("kw", CASES, ids=[f"case{i}" for i in range(len(CASES))])
+def test_partial_plus_merge_equals_the_whole_block(kw):
+    from healnet_amd import _capi
+    from healnet_amd import dist as hd
+    from oracle import healnet_cpu as O
+    hip = torch.ops.healnet_hip
+    b, L, N, D, heads, dh, qd, parts = (kw[k] for k in ("b", "L", "N", "D", "heads", "dh", "qd", "parts"))
+    pn = _block(qd, D, heads, dh, 7)
+    a = pn.fn
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(b, L, qd, generator=gen).to(DEV)
+    ctx = torch.randn(b, N, D, generator=gen)
+    mask = None
+    if kw.get("masked"):
+        mask = torch.rand(b, N, generator=gen) > 0.3
+        if "dead_shard" in kw:
+            lo, hi = hd.slab_bounds(N, kw["dead_shard"], parts)
+            mask[:, lo:hi] = False
+    pitch = _capi.lib().hn_context_pitch(D, dh)
+    z = hip.encode_norm(ctx.to(DEV).unsqueeze(2).reshape(b, N, D), 0, 0.0, False, pitch)      # affine-free LayerNorm of the context
+    m_dev = None if mask is None else mask.to(DEV).to(torch.uint8)
+    wts = (pn.norm.weight, pn.norm.bias, pn.norm_context.weight, pn.norm_context.bias, a.to_q.weight, a.to_kv.weight, a.to_out[0].weight,
+           a.to_out[0].bias)
+    with torch.no_grad():
+        whole, st_whole, _ = hip.attention_fwd(x, z, m_dev, *wts, heads, True, False)
+        o_parts, st_parts = [], []
+        for r in range(parts):
+            lo, hi = hd.slab_bounds(N, r, parts)
+            o, st = hip.attention_partial(x, z[:, lo:hi].contiguous(), None if m_dev is None else m_dev[:, lo:hi].contiguous(), *wts, heads)
+            o_parts.append(o)
+            st_parts.append(st)
+        got, st = hip.attention_merge(x, torch.stack(o_parts), torch.stack(st_parts), a.to_q.weight, a.to_out[0].weight, a.to_out[0].bias,
+                                      heads, True)
+        got2, _ = hip.attention_merge(x, torch.stack(o_parts), torch.stack(st_parts), a.to_q.weight, a.to_out[0].weight, a.to_out[0].bias,
+                                      heads, True)
+    assert torch.equal(got, got2)
+    assert_close(got.cpu(), whole.cpu(), rel=2e-5, floor=2e-6, what="merged shards vs the whole block")
+    # merged statistics describe the same softmax as the whole block's: log2-sum-exp M + log2(l) agrees
+    lse = lambda s_: (s_[..., 0].double() + torch.log2(s_[..., 1].double()))      # noqa: E731
+    live = torch.isfinite(lse(st_whole.cpu())) & (st_whole[..., 0].cpu() > -1e30)
+    assert_close(lse(st.cpu())[live].float(), lse(st_whole.cpu())[live].float(), rel=1e-5, floor=1e-4, what="merged log-sum-exp")
+    # the oracle on the same numbers
+    xc, cc = x.cpu(), ctx
+    sd = {k: v.detach().cpu() for k, v in pn.state_dict().items()}
+    xn = O.layer_norm(xc, sd["norm.weight"], sd["norm.bias"])
+    cn = O.layer_norm(cc, sd["norm_context.weight"], sd["norm_context.bias"])
+    want = O.attention(xn, cn, sd["fn.to_q.weight"], sd["fn.to_kv.weight"], sd["fn.to_out.0.weight"], sd["fn.to_out.0.bias"], heads=heads,
+                       mask=mask) + xc
+    assert_close(got.cpu(), want, rel=2e-4, floor=2e-5, what="merged shards vs the oracle")
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+KW = dict(n_modalities=3, channel_dims=[200, 3, 64], num_spatial_axes=[1, 2, 1], out_dims=4, depth=2, l_c=32, l_d=64, x_heads=4, l_heads=4,
+          cross_dim_head=32, latent_dim_head=16)      # one-token tabular (replicated) + image (rank-D binding) + bag (explicit binding)
+
+
+def _inputs(b):
+    gen = torch.Generator().manual_seed(21)
+    return [torch.rand(b, 1, 200, generator=gen), torch.rand(b, 37, 20, 3, generator=gen), torch.rand(b, 301, 64, generator=gen)]
+
+
+def _cp_worker(rank, world, port, b, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    import healnet_amd as hn
+    from healnet_amd import dist as hd
+    try:
+        torch.cuda.set_device(0)
+        hd.init_from_env("gloo")
+        dev = torch.device("cuda", 0)
+        torch.manual_seed(5)
+        model = hn.HealNet(**KW).eval().to(dev)
+        ins = [t.to(dev) for t in _inputs(b)]
+        out = hd.context_parallel_forward(model, ins)
+        emb = hd.context_parallel_forward(model, ins, return_embeddings=True)
+        torch.cuda.synchronize()
+        q.put((rank, "ok", out.cpu().numpy(), emb.cpu().numpy()))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "".join(traceback.format_exception(type(e), e, e.__traceback__)), None, None))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,b", [(2, 1), (3, 2)], ids=["2-ranks-b1", "3-ranks-b2"])
+def test_context_parallel_forward_matches_the_plain_forward(world, b):
+    import healnet_amd as hn
+    from oracle import healnet_cpu as O
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cp_worker, args=(r, world, port, b, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=600) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+    assert [r[1] for r in results] == ["ok"] * world, [r[1] for r in results]
+    torch.manual_seed(5)
+    model = hn.HealNet(**KW).eval().to(DEV)
+    ins = _inputs(b)
+    with torch.no_grad():
+        plain = model([t.to(DEV) for t in ins]).cpu()
+        plain_emb = model([t.to(DEV) for t in ins], return_embeddings=True).cpu()
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    want = O.fusion_forward(sd, O.FusionConfig(**KW), [t.clone() for t in ins])
+    for rank, _, out, emb in results:
+        assert_close(torch.from_numpy(out), plain, rel=2e-5, floor=2e-6, what=f"rank {rank}: context-parallel logits vs the plain forward")
+        assert_close(torch.from_numpy(emb), plain_emb, rel=2e-5, floor=2e-6, what=f"rank {rank}: embeddings")
+        assert_close(torch.from_numpy(out), want, rel=1e-4, floor=1e-5, what=f"rank {rank}: context-parallel logits vs the oracle")
+        assert np.array_equal(out, results[0][2]) and np.array_equal(emb, results[0][3]), "ranks diverged"
+
+
+def test_single_rank_and_validation():
+    """world == 1 degenerates to the block-by-block forward (no collective); refused inputs say why."""
+    import healnet_amd as hn
+    from healnet_amd import dist as hd
+    torch.manual_seed(5)
+    model = hn.HealNet(**KW).eval().to(DEV)
+    ins = [t.to(DEV) for t in _inputs(2)]
+    with torch.no_grad():
+        plain = model(ins)
+    got = hd.context_parallel_forward(model, ins, rank=0, world=1)
+    assert_close(got.cpu(), plain.cpu(), rel=2e-5, floor=2e-6, what="block-by-block forward vs the fused forward")
+    with pytest.raises(ValueError):
+        hd.context_parallel_forward(model, [ins[0], None, ins[2]], rank=0, world=1)
