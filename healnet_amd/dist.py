@@ -286,7 +286,7 @@ def gather_partials(o_part: torch.Tensor, stats: torch.Tensor, group=None) -> Tu
 
 
 def context_parallel_forward(model, tensors: Sequence[Optional[torch.Tensor]], group=None, return_embeddings: bool = False,
-                             min_rows_per_rank: int = 2, rank: Optional[int] = None, world: Optional[int] = None,
+                             min_rows_per_rank: int = 1, rank: Optional[int] = None, world: Optional[int] = None,
                              gather=None) -> torch.Tensor:
     """Inference forward of a HealNet whose CONTEXTS are split over the ranks of `group` (every rank passes the SAME full-batch
     `tensors`; a rank reads only its slab of each split modality): the reference's fusion loop (healnet.py:225-250) block by
@@ -295,8 +295,8 @@ def context_parallel_forward(model, tensors: Sequence[Optional[torch.Tensor]], g
       cross block of a split modality   hn_encode_norm_slab (once per modality) -> hn_attn_partial_fwd on the rank's tokens ->
                                         one all-gather of (output, statistics) per block -> hn_attn_merge_fwd (every rank folds
                                         all shards in rank order: bit-identical latents everywhere, no broadcast needed)
-      everything else                   replicated: cross blocks of short modalities (fewer than `min_rows_per_rank` rows per
-                                        rank, e.g. the one-token tabular input), feed-forward blocks, latent self blocks, head.
+      everything else                   replicated: cross blocks of short modalities (fewer than `min_rows_per_rank` rows or two
+                                        tokens per rank, e.g. the one-token tabular input), feed-forward blocks, latent self blocks, head.
 
     Partition = the first spatial axis (image rows, volume slices, bag patches), contiguous slabs.  For b >= #GPUs shard the BATCH
     instead (no forward collective at all).  No mask, no dropout, no missing modalities (the plain inference forward)."""
