@@ -11,6 +11,7 @@ the box:
     flat gradient == the gradient of the same step without any hook, bit for bit (an average over one rank is the identity);
   * `allreduce_mean_` (flat in-place bucket and the cat / scatter bucket route), `max_over_ranks` (MAX all-reduce of a double on
     the device), `gather_outputs` (all_gather with the ragged-shard padding);
+  * `gather_partials` (the context split's one exchange per cross block: `all_gather_into_tensor`);
   * bench.py's `distributed` branch end to end on RCCL (`HN_BENCH_FORCE_DIST=1 python bench.py --gpus 1`), and `--gpus N`
     beyond the visible GPUs exiting with one clear line instead of a rendezvous hang.
 
@@ -93,6 +94,15 @@ def _worker(port, q):
         loc = torch.randn(5, 4, generator=gen).to(dev)
         got = hd.gather_outputs(loc, 5)
         assert torch.equal(got, loc) and calls["all_gather"] == 1
+        # the context split's exchange (healnet_amd.dist.gather_partials): ncclAllGather into one flat tensor, then the merge kernel
+        # over the gathered parts -- one rank, so the merged block must equal the whole block bit for bit up to the merge's own rounding
+        o = torch.randn(2, 32, 128, generator=gen).to(dev)
+        st = torch.rand(2, 4, 32, 2, generator=gen).to(dev) + 0.5
+        o_all, st_all = hd.gather_partials(o, st)
+        torch.cuda.synchronize(dev)
+        assert o_all.shape == (1, 2, 32, 128) and st_all.shape == (1, 2, 4, 32, 2)
+        assert torch.equal(o_all[0], o) and torch.equal(st_all[0], st), "all_gather_into_tensor over one rank must return the input"
+        report["context_split_gather_floats"] = int(o.numel() + st.numel())
         report["helpers"] = dict(calls)
 
         # ---- the overlapped gradient all-reduce on real backwards ----------------------------------------------------
