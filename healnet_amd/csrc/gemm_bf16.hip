@@ -27,6 +27,7 @@
 //     the V half swap the MFMA operands so that a lane holds four consecutive tokens of a column = 8 contiguous bytes of a V tile.
 #include "common.h"
 #include <type_traits>
+#pragma clang diagnostic ignored "-Winline-asm"      // (M0 on the clobber list of bf_glds16)
 
 namespace hn {
 
@@ -111,7 +112,72 @@ struct Bf16GemmArgs {
   // K16 (M, inner) token-major; V16 per (sample, head) fragment-major (np / 32, 4, 4, 16, 8)
   uint16_t *K16, *V16;
   int inner, heads, tokens, np;      // tokens per sample and that rounded up to 32 (V tiles hold 32 tokens; the pad slots are zeroed)
+  int abl;                           // bench builds only (HN_GEMM_BF16_BENCH): 1 = no stores, 2 = no loads, 4 = no MFMAs
 };
+
+// Epilogue shared by both kernels: acc[column sub-tile i][row sub-tile t] of the wave's 64 x 64 block (see gemm_bf16_kernel)
+template <bool IMG>
+__device__ __forceinline__ void bf16_epilogue(const Bf16GemmArgs &g, f32x4 (&acc)[4][4], int m0, int n0, int wm, int wn, int fj, int fg,
+                                              bool v_half) {
+  if (v_half) {
+    // D[m_local = 4 fg + r][n_local = fj]: four consecutive tokens of column fj -> 8 bytes of one fragment-major V tile
+    // (tile (sample, head, token / 32, col / 16) = [token % 32 / 8][col % 16][token % 8]); token counts that are not multiples of 4
+    // let a row quad straddle two samples: element-wise stores there
+    const int blocks_per = g.np >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int n = n0 + wn * 64 + 16 * i + fj;
+      const float cbv = g.cb[n];
+      const int c_all = n - g.inner, head = c_all >> 6, c = c_all & 63;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int m = m0 + wm * 64 + 16 * t + 4 * fg;
+        if ((g.tokens & 3) == 0) {      // (then M % 4 == 0 too: the four rows are in or out together)
+          if (m < g.M) {
+            const int bi = m / g.tokens, tok = m - bi * g.tokens;
+            const long tile_idx = (((long)bi * g.heads + head) * blocks_per + (tok >> 5)) * 4 + (c >> 4);
+            u32x2 v;
+            v.x = pk_bf16((acc[i][t][0] + cbv) * g.alpha, (acc[i][t][1] + cbv) * g.alpha);
+            v.y = pk_bf16((acc[i][t][2] + cbv) * g.alpha, (acc[i][t][3] + cbv) * g.alpha);
+            *(u32x2 *)(g.V16 + tile_idx * 512 + ((((tok & 31) >> 3) * 16 + (c & 15)) << 3) + (tok & 7)) = v;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int mr = m + r;
+            if (mr < g.M) {
+              const int bi = mr / g.tokens, tok = mr - bi * g.tokens;
+              const long tile_idx = (((long)bi * g.heads + head) * blocks_per + (tok >> 5)) * 4 + (c >> 4);
+              g.V16[tile_idx * 512 + ((((tok & 31) >> 3) * 16 + (c & 15)) << 3) + (tok & 7)] = (uint16_t)pk_bf16((acc[i][t][r] + cbv) * g.alpha, 0.0f);
+            }
+          }
+        }
+      }
+    }
+    return;
+  }
+  // D[n_local = 4 fg + r][m_local = fj]: four consecutive columns of row fj
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + wn * 64 + 16 * i + 4 * fg;
+    const f32x4 c4 = *(const f32x4 *)(g.cb + n);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int m = m0 + wm * 64 + 16 * t + fj;
+      if (m < g.M) {
+        const f32x4 v = (acc[i][t] + c4) * g.alpha;
+        if (IMG) {
+          u32x2 o;
+          o.x = pk_bf16(v[0], v[1]);
+          o.y = pk_bf16(v[2], v[3]);
+          *(u32x2 *)(g.K16 + (long)m * g.inner + n) = o;
+        } else {
+          *(f32x4 *)(g.C + (long)m * g.ldc + n) = v;
+        }
+      }
+    }
+  }
+}
 
 template <bool IMG>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16GemmArgs g) {
@@ -222,64 +288,111 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16GemmArgs g) {
     tile(nk - 1, no, no, no);
   }
 
-  if (v_half) {
-    // D[m_local = 4 fg + r][n_local = fj]: four consecutive tokens of column fj -> 8 bytes of one fragment-major V tile
-    // (tile (sample, head, token / 32, col / 16) = [token % 32 / 8][col % 16][token % 8]); token counts that are not multiples of 4
-    // let a row quad straddle two samples: element-wise stores there
-    const int blocks_per = g.np >> 5;
+  bf16_epilogue<IMG>(g, acc, m0, n0, wm, wn, fj, fg, v_half);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same product on the skeleton of gemm_nt.hip (round 4): both operands land in LDS by LDS-DMA (buffer_load_dwordx4 ... lds, issued
+// from inline asm, every wait counted by hand), two ring slots of 32 KB, ONE barrier in the MIDDLE of a 64-wide k-tile, two 4-wave
+// workgroups per CU.  A bf16 row piece of 64 columns is 128 bytes -- the byte geometry of the fp32 kernel's 32-float rows -- so an
+// instruction lands 8 rows x 8 16-byte chunks (whole lines) as [row][128 B]; chunk c of row r sits at position c ^ ((r >> 1) & 7),
+// applied on the SOURCE address of the DMA (the destination is linear) and again by the fragment reads.  With that swizzle the 16
+// lanes ds_read_b128 serves per LDS cycle (rows {0-3, 12-15} of one chunk with rows {4-11} of the next) touch 16 different 16-byte
+// slots of the 256-byte bank window.  No staging registers, no ds_write, nothing of the loader on the VALU.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bf_glds16(const i32x4 &rsrc, unsigned lds_byte, int voffset, int soffset) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :
+               : "s"(lds_byte), "v"(voffset), "s"(rsrc), "s"(soffset)
+               : "memory", "m0");
+}
+template <int N> __device__ __forceinline__ void bf_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <bool IMG>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_glds_kernel(Bf16GemmArgs g) {
+  constexpr int S = 2, OPB = 128 * 128, STAGE_B = 2 * OPB, LW = 8;      // ring slot: A [128][128 B] then W [128][128 B]
+  __shared__ __attribute__((aligned(16))) unsigned char lds[S * STAGE_B];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int id = blockIdx.x, xcd = id & 7, seq = id >> 3;
+  const int n_tile = seq % g.ntn, m_tile = (seq / g.ntn) * 8 + xcd;
+  if (m_tile >= g.ntm) return;
+  const int m0 = m_tile * HM, n0 = n_tile * HNT;
+  const int Kp = g.Kp, rowb = Kp * 2;                                   // bytes per operand row
+  const int rows_a = min(HM, g.M - m0);
+  const unsigned a_clamp = (unsigned)rows_a * (unsigned)rowb, w_clamp = (unsigned)HNT * (unsigned)rowb;
+  const i32x4 rsA = make_rsrc(g.Ab + (long)m0 * Kp, a_clamp);          // rows past M read as zero
+  const i32x4 rsW = make_rsrc(g.Wb + (long)n0 * Kp, w_clamp);
+  // loader: lane -> (row lane >> 3 of the 8-row group, position lane & 7); row group u = wave + 4 q, so (u & 1) == (wave & 1)
+  const int voff = (lane >> 3) * rowb + ((((lane & 7) ^ (((wave & 1) << 2) | (lane >> 4))) << 4));
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char *)lds);
+  auto issue = [&](int kt) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int n = n0 + wn * 64 + 16 * i + fj;
-      const float cbv = g.cb[n];
-      const int c_all = n - g.inner, head = c_all >> 6, c = c_all & 63;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int m = m0 + wm * 64 + 16 * t + 4 * fg;
-        if ((g.tokens & 3) == 0) {      // (then M % 4 == 0 too: the four rows are in or out together)
-          if (m < g.M) {
-            const int bi = m / g.tokens, tok = m - bi * g.tokens;
-            const long tile_idx = (((long)bi * g.heads + head) * blocks_per + (tok >> 5)) * 4 + (c >> 4);
-            u32x2 v;
-            v.x = pk_bf16((acc[i][t][0] + cbv) * g.alpha, (acc[i][t][1] + cbv) * g.alpha);
-            v.y = pk_bf16((acc[i][t][2] + cbv) * g.alpha, (acc[i][t][3] + cbv) * g.alpha);
-            *(u32x2 *)(g.V16 + tile_idx * 512 + ((((tok & 31) >> 3) * 16 + (c & 15)) << 3) + (tok & 7)) = v;
-          }
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int mr = m + r;
-            if (mr < g.M) {
-              const int bi = mr / g.tokens, tok = mr - bi * g.tokens;
-              const long tile_idx = (((long)bi * g.heads + head) * blocks_per + (tok >> 5)) * 4 + (c >> 4);
-              g.V16[tile_idx * 512 + ((((tok & 31) >> 3) * 16 + (c & 15)) << 3) + (tok & 7)] = (uint16_t)pk_bf16((acc[i][t][r] + cbv) * g.alpha, 0.0f);
-            }
-          }
-        }
-      }
+    for (int q = 0; q < LW; ++q) {
+      const int u = wave + 4 * q;                                       // u < 16: A row group u; else W row group u - 16
+      const unsigned dst = lds_base + (unsigned)((kt % S) * STAGE_B + u * 1024);
+      const unsigned so = (unsigned)(8 * (u & 15) * rowb + kt * 128);
+      if (q < 4) bf_glds16(rsA, dst, voff, (int)min(so, a_clamp));
+      else bf_glds16(rsW, dst, voff, (int)min(so, w_clamp));
     }
-    return;
-  }
-  // D[n_local = 4 fg + r][m_local = fj]: four consecutive columns of row fj
+  };
+  const int wm = wave >> 1, wn = wave & 1;      // a wave owns 64 rows x 64 columns = 4 x 4 MFMA tiles
+  const int fj = lane & 15, fg = lane >> 4;
+  const int sw = fj >> 1;                        // ((row >> 1) & 7) of row = 16 t + fj (+ 64 wm)
+  const int a_row = (wm * 64 + fj) * 128, w_row = OPB + (wn * 64 + fj) * 128;
+  f32x4 acc[4][4];      // [column sub-tile i][row sub-tile t]
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int n = n0 + wn * 64 + 16 * i + 4 * fg;
-    const f32x4 c4 = *(const f32x4 *)(g.cb + n);
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[i][t] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+  struct Frags { bf16x8 a[4], w[4]; };
+  auto read_frags = [&](int kt, int kh, Frags &f) {
+    const unsigned char *st = lds + (kt % S) * STAGE_B;
+    const int pos = ((kh * 4 + fg) ^ sw) << 4;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const int m = m0 + wm * 64 + 16 * t + fj;
-      if (m < g.M) {
-        const f32x4 v = (acc[i][t] + c4) * g.alpha;
-        if (IMG) {
-          u32x2 o;
-          o.x = pk_bf16(v[0], v[1]);
-          o.y = pk_bf16(v[2], v[3]);
-          *(u32x2 *)(g.K16 + (long)m * g.inner + n) = o;
-        } else {
-          *(f32x4 *)(g.C + (long)m * g.ldc + n) = v;
-        }
-      }
+      f.a[t] = *(const bf16x8 *)(st + a_row + t * 16 * 128 + pos);
+      f.w[t] = *(const bf16x8 *)(st + w_row + t * 16 * 128 + pos);
     }
-  }
+  };
+  const bool v_half = IMG && n0 >= g.inner;      // (workgroup-uniform: a 128-column tile lies in the K or in the V half)
+  auto run = [&](auto flip) {
+    constexpr bool FLIP = decltype(flip)::value;      // context sub-tile as the MFMA's A operand: a lane's accumulator quad = four consecutive ROWS
+    auto mfma_half = [&](const Frags &f) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        acc[q >> 2][q & 3] = FLIP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[q & 3], f.w[q >> 2], acc[q >> 2][q & 3], 0, 0, 0)
+                                  : __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.w[q >> 2], f.a[q & 3], acc[q >> 2][q & 3], 0, 0, 0);
+    };
+    const int nk = Kp / HK;
+    issue(0);
+    if (nk > 1) issue(1);
+    Frags f0, f1;
+    if (nk > 1) bf_wait_vmcnt<LW>(); else bf_wait_vmcnt<0>();            // tile 0 landed, tile 1 may be in flight
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    read_frags(0, 0, f0);
+    for (int kt = 0; kt < nk; ++kt) {
+      const bool last = kt + 1 == nk;
+      read_frags(kt, 1, f1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(g.abl & 4)) mfma_half(f0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!last) {
+        bf_wait_vmcnt<0>();                                             // two slots: the tile needed next is the only one in flight
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + S < nk && !(g.abl & 2)) issue(kt + S);
+        read_frags(kt + 1, 0, f0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (!(g.abl & 4)) mfma_half(f1);
+    }
+  };
+  if (v_half) run(std::true_type{}); else run(std::false_type{});
+  if (g.abl & 1) { if (g.alpha != 12345.0f) return; }
+  bf16_epilogue<IMG>(g, acc, m0, n0, wm, wn, fj, fg, v_half);
 }
 
 // token counts that are not multiples of 32: the last 32-token block of every (sample, head) V image (4 tiles = 4 KB) is zeroed before
@@ -367,6 +480,10 @@ int launch_gemm_bf16(const GemmArgs &g, const uint16_t *Ab, float *stage, hipStr
   Bf16GemmArgs a;
   a.Ab = Ab; a.Wb = Wb; a.cb = cb; a.C = g.C; a.ldc = g.ldc; a.alpha = g.alpha; a.M = g.M; a.Kp = Kp;
   a.ntm = (g.M + HM - 1) / HM; a.ntn = g.N / HNT;
+  a.abl = 0;
+#ifdef HN_GEMM_BF16_BENCH
+  if (const char *e = getenv("HN_BF16_ABL")) a.abl = atoi(e);
+#endif
   a.K16 = K16; a.V16 = V16; a.inner = g.N / 2; a.heads = g.N / 128; a.tokens = tokens; a.np = (tokens + 31) / 32 * 32;
   if (img && tokens % 32 != 0) {
     hipLaunchKernelGGL(v_tail_zero_kernel, dim3((unsigned)((g.M / tokens) * a.heads)), dim3(256), 0, s, (u32x4 *)V16, a.np / 32);
@@ -383,7 +500,11 @@ int launch_gemm_bf16(const GemmArgs &g, const uint16_t *Ab, float *stage, hipStr
     HN_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     if (dev >= 0 && dev < 64) configured[dev] = true;
   }
-  if (img) hipLaunchKernelGGL(gemm_bf16_kernel<true>, dim3((unsigned)blocks), dim3(256), lds_bytes, s, a);
+  static const bool no_glds = getenv("HN_NO_GLDS_GEMM") != nullptr;      // development switch: the register-staged kernel
+  if (!no_glds && (long)g.M * Kp * 2 < (1L << 31)) {                     // (the DMA descriptors address a tile's rows with 32-bit offsets anyway;
+    if (img) hipLaunchKernelGGL(gemm_bf16_glds_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, a);      //  the bound keeps row * pitch in 31 bits)
+    else hipLaunchKernelGGL(gemm_bf16_glds_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  } else if (img) hipLaunchKernelGGL(gemm_bf16_kernel<true>, dim3((unsigned)blocks), dim3(256), lds_bytes, s, a);
   else hipLaunchKernelGGL(gemm_bf16_kernel<false>, dim3((unsigned)blocks), dim3(256), lds_bytes, s, a);
   HN_LAUNCH_CHECK("gemm_bf16");
   return HN_OK;
