@@ -793,6 +793,12 @@ __device__ __forceinline__ void merge_splits(MergeWeights &mw, const float *Opar
 static int merge_rows_per_block(int b, int h, int L) {       // 32 rows, or 8 while 32 would give fewer workgroups than CUs
   return (long)b * h * ceil_div(L, MERGE_ROWS) >= 256 ? MERGE_ROWS : 8;
 }
+// The explicit merge has no per-workgroup staging (merge_vproj_kernel loads the folded value projection into LDS first: fewer,
+// fatter workgroups pay there), so it takes the 8-row form up to FOUR workgroups per CU: a merge is a few groups of dependent
+// loads, and at one workgroup per CU -- cfg4: 256 workgroups of 32 rows -- nothing hides them (13.8 us for 8 splits).
+static int merge_rows_per_block_explicit(int b, int h, int L) {
+  return (long)b * h * ceil_div(L, MERGE_ROWS) >= 1024 ? MERGE_ROWS : 8;
+}
 
 __global__ __launch_bounds__(256) void merge_vproj_kernel(const float *__restrict__ Opart, const float *__restrict__ Mpart,
                                                           const float *__restrict__ Lpart, int nsplit, int h, int L, int Lp,
@@ -915,7 +921,7 @@ __global__ __launch_bounds__(256) void merge_explicit_kernel(const float *__rest
 int launch_merge_explicit(const float *Opart, const float *Mpart, const float *Lpart, int nsplit, int b, int h, int L,
                           int Lp, int dp, int dh, float *O, int ldo, float *stats, hipStream_t s) {
   HN_REQUIRE(dh <= 128, HN_E_UNSUPPORTED, "merge_explicit: dh=%d", dh);
-  const int R = merge_rows_per_block(b, h, L);
+  const int R = merge_rows_per_block_explicit(b, h, L);
   const dim3 grid(b * h, ceil_div(L, R));
   if (R * dh <= 256)
     hipLaunchKernelGGL(merge_explicit_kernel<1>, grid, dim3(256), 0, s, Opart, Mpart, Lpart, nsplit, h, L, Lp, dp, dh, O, ldo, stats, R);

@@ -780,9 +780,10 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
   }
 }
 
-// gemm_skinny_kernel with per-entry operands (blockIdx.z): see GemmSkinnyMulti
+// gemm_skinny_kernel with per-entry operands (blockIdx.z): see GemmSkinnyMulti.  SM = 8 for batches of up to 8 samples, as above.
+template <int SM>
 __global__ __launch_bounds__(256) void gemm_skinny_multi_kernel(GemmSkinnyMulti g) {
-  constexpr int SN = 4, SM = 32;
+  constexpr int SN = 4, U = SM == 8 ? 4 : 1;
   __shared__ float part[4][SM * SN];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n0 = blockIdx.x * SN, z = blockIdx.z, m0 = blockIdx.y * SM;
@@ -793,34 +794,49 @@ __global__ __launch_bounds__(256) void gemm_skinny_multi_kernel(GemmSkinnyMulti 
   float acc[SM * SN];
 #pragma unroll
   for (int i = 0; i < SM * SN; ++i) acc[i] = 0.0f;
-  for (int k0 = wave * 64; k0 < g.K; k0 += 256) {
-    const int k = k0 + lane;
-    const float km = k < g.K ? 1.0f : 0.0f;
-    const int kc = min(k, g.K - 1);
-    float w[SN], av[SM];
+  for (int k0 = wave * 64; k0 < g.K; k0 += 256 * U) {
+    float w[U][SN], av[U][SM], gam[U], bet[U];
 #pragma unroll
-    for (int j = 0; j < SN; ++j) w[j] = hn_buffer_load_x1(rsW, ((n0 + j) * (int)g.ldw + kc) * 4, 0, 0);
+    for (int u = 0; u < U; ++u) {
+      const int k = k0 + 256 * u + lane;
+      const float km = k < g.K ? 1.0f : 0.0f;
+      const int kc = min(k, g.K - 1);
 #pragma unroll
-    for (int m = 0; m < SM; ++m) av[m] = hn_buffer_load_x1(rsA, ((m0 + m) * (int)g.lda + kc) * 4, 0, 0);
-    float gam = 1.0f, bet = 0.0f;
-    if (g.pro == PRO_AFFINE) { gam = gam_p[kc]; bet = bet_p[kc]; }
-    gam *= km;
-    bet *= km;
+      for (int j = 0; j < SN; ++j) w[u][j] = hn_buffer_load_x1(rsW, ((n0 + j) * (int)g.ldw + kc) * 4, 0, 0);
 #pragma unroll
-    for (int m = 0; m < SM; ++m) {
-      const float a = av[m] * gam + bet;
-#pragma unroll
-      for (int j = 0; j < SN; ++j) acc[m * SN + j] = fmaf(a, w[j], acc[m * SN + j]);
+      for (int m = 0; m < SM; ++m) av[u][m] = hn_buffer_load_x1(rsA, ((m0 + m) * (int)g.lda + kc) * 4, 0, 0);
+      gam[u] = 1.0f; bet[u] = 0.0f;
+      if (g.pro == PRO_AFFINE) { gam[u] = gam_p[kc]; bet[u] = bet_p[kc]; }
+      gam[u] *= km;
+      bet[u] *= km;
     }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int m = 0; m < SM; ++m) {
+        const float a = av[u][m] * gam[u] + bet[u];
+#pragma unroll
+        for (int j = 0; j < SN; ++j) acc[m * SN + j] = fmaf(a, w[u][j], acc[m * SN + j]);
+      }
   }
-  fold_half<64>(acc, lane, 32);
-  fold_half<32>(acc, lane, 16);
-  fold_half<16>(acc, lane, 8);
-  fold_half<8>(acc, lane, 4);
-  fold_half<4>(acc, lane, 2);
-  fold_half<2>(acc, lane, 1);
-  part[wave][2 * lane] = acc[0];
-  part[wave][2 * lane + 1] = acc[1];
+  if constexpr (SM == 32) {
+    fold_half<64>(acc, lane, 32);
+    fold_half<32>(acc, lane, 16);
+    fold_half<16>(acc, lane, 8);
+    fold_half<8>(acc, lane, 4);
+    fold_half<4>(acc, lane, 2);
+    fold_half<2>(acc, lane, 1);
+    part[wave][2 * lane] = acc[0];
+    part[wave][2 * lane + 1] = acc[1];
+  } else {
+    fold_half<16>(acc, lane, 32);
+    fold_half<8>(acc, lane, 16);
+    fold_half<4>(acc, lane, 8);
+    fold_half<2>(acc, lane, 4);
+    fold_half<1>(acc, lane, 2);
+    acc[0] += __shfl_xor(acc[0], 1);
+    if ((lane & 1) == 0) part[wave][lane >> 1] = acc[0];
+  }
   __syncthreads();
   if (threadIdx.x < SM * SN) {
     const int idx = threadIdx.x, m = m0 + idx / SN, n = n0 + idx % SN;
@@ -838,7 +854,8 @@ int launch_gemm_skinny_multi(const GemmSkinnyMulti &g, hipStream_t s) {
              g.nz, g.M, g.N, g.K);
   HN_REQUIRE(((long)(g.M + 64) * g.lda) * 4 < (1L << 31) && ((long)(g.N + 64) * g.ldw) * 4 < (1L << 31), HN_E_UNSUPPORTED,
              "gemm_skinny_multi: an operand spans more than 2 GiB");
-  hipLaunchKernelGGL(gemm_skinny_multi_kernel, dim3(ceil_div(g.N, 4), ceil_div(g.M, 32), g.nz), dim3(256), 0, s, g);
+  if (g.M <= 8) hipLaunchKernelGGL(gemm_skinny_multi_kernel<8>, dim3(ceil_div(g.N, 4), 1, g.nz), dim3(256), 0, s, g);
+  else hipLaunchKernelGGL(gemm_skinny_multi_kernel<32>, dim3(ceil_div(g.N, 4), ceil_div(g.M, 32), g.nz), dim3(256), 0, s, g);
   HN_LAUNCH_CHECK("gemm_skinny_multi");
   return HN_OK;
 }
