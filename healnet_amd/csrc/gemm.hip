@@ -714,7 +714,7 @@ __device__ __forceinline__ void fold_half(float (&v)[NV], int lane, int mask) {
 // 12.5 us at b = 8 before, where 14 workgroups cannot hide any of them)
 template <int SM>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
-  constexpr int SN = 4, U = SM == 8 ? 4 : 1;
+  constexpr int SN = 4, U = SM == 8 ? 4 : 2;      // k-chunks in flight per trip
   __shared__ float part[4][SM * SN];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n0 = blockIdx.x * SN, z = blockIdx.z, m0 = blockIdx.y * SM;      // blockIdx.y: SM-row chunk (batches above SM samples)
@@ -783,7 +783,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
 // gemm_skinny_kernel with per-entry operands (blockIdx.z): see GemmSkinnyMulti.  SM = 8 for batches of up to 8 samples, as above.
 template <int SM>
 __global__ __launch_bounds__(256) void gemm_skinny_multi_kernel(GemmSkinnyMulti g) {
-  constexpr int SN = 4, U = SM == 8 ? 4 : 1;
+  constexpr int SN = 4, U = SM == 8 ? 4 : 2;      // k-chunks in flight per trip
   __shared__ float part[4][SM * SN];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n0 = blockIdx.x * SN, z = blockIdx.z, m0 = blockIdx.y * SM;

@@ -154,6 +154,14 @@ __global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ x, 
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
     if (gr < groups) {
       int r = gr;
+      for (; r + 3 * groups < L; r += 4 * groups) {          // four rows in flight per trip (L = 128, 8 groups: 4 trips instead of 8)
+        const float4 v0 = *(const float4 *)(xb + (long)r * d + 4 * cq), v1 = *(const float4 *)(xb + (long)(r + groups) * d + 4 * cq);
+        const float4 v2 = *(const float4 *)(xb + (long)(r + 2 * groups) * d + 4 * cq), v3 = *(const float4 *)(xb + (long)(r + 3 * groups) * d + 4 * cq);
+        a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+        a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+        a0.x += v2.x; a0.y += v2.y; a0.z += v2.z; a0.w += v2.w;
+        a1.x += v3.x; a1.y += v3.y; a1.z += v3.z; a1.w += v3.w;
+      }
       for (; r + groups < L; r += 2 * groups) {
         const float4 v0 = *(const float4 *)(xb + (long)r * d + 4 * cq), v1 = *(const float4 *)(xb + (long)(r + groups) * d + 4 * cq);
         a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
