@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void encode_token_kernel(const IN *__restrict_
   if (SC > 0) { g.C = SC; g.n_axes = SA; g.F = SF; g.D = SC + SA * (2 * SF + 1); }
   long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   // 16-float rows leave through LDS (below): every lane of a wave takes part, the ones past the end on the last token's data
-  const bool staged_store = LD == 16 && g.ld_out == 16;
+  const bool staged_store = (LD == 16 || LD == 32) && g.ld_out == LD;
   const bool live = gid < total;
   if (!live) { if (!staged_store) return; gid = total - 1; }
   long n = gid % g.N;
@@ -162,23 +162,25 @@ __global__ __launch_bounds__(256) void encode_token_kernel(const IN *__restrict_
 #pragma unroll
   for (int c = 0; c < LD; ++c)
     if (c == g.ones_col) v[c] = 1.0f;
-  if (LD == 16 && staged_store) {
-    // A lane holds one token's 64-byte row: stored directly, a wave instruction would write 64 quarter-rows 64 bytes apart.  Through a
-    // per-wave 4 KB LDS image instead (quad q of lane l at slot 4 l + (q ^ (l >> 2 & 3)): conflict-free both ways), read back
-    // linearly, so that an instruction writes 16 whole rows = 1 KB of consecutive memory (cfg2: 36 -> us for 103 MB).
-    __shared__ float4 stage[4][256];
+  if ((LD == 16 || LD == 32) && staged_store) {
+    // A lane holds one token's 64- / 128-byte row: stored directly, a wave instruction would write 64 pieces 64 / 128 bytes apart.
+    // Through a per-wave LDS image instead (quad q of lane l at slot Q l + (q ^ sw(l)), Q = LD / 4 quads per row, sw = l >> 2 & 3 for
+    // Q = 4, l >> 1 & 7 for Q = 8: conflict-free both ways), read back linearly, so that an instruction writes whole rows = 1 KB of
+    // consecutive memory (cfg2: 36.1 -> 20.5 us for 19 MB in + 103 MB out = 6 TB/s).
+    constexpr int Q = LD / 4;
+    __shared__ float4 stage[4][64 * Q];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int sw = (lane >> 2) & 3;
+    const int sw = Q == 4 ? (lane >> 2) & 3 : (lane >> 1) & 7;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) stage[wv][4 * lane + (q ^ sw)] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    for (int q = 0; q < Q; ++q) stage[wv][Q * lane + (q ^ sw)] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
     __builtin_amdgcn_wave_barrier();
     const long wave_tok0 = (long)blockIdx.x * blockDim.x + 64 * wv;      // first token of this wave
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int slot = lane + 64 * k, tl = slot >> 2;                    // token tl of the wave, position slot & 3 of its row image
-      const int q = (slot & 3) ^ ((tl >> 2) & 3);
+    for (int k = 0; k < Q; ++k) {
+      const int slot = lane + 64 * k, tl = slot / Q;                     // token tl of the wave, position slot % Q of its row image
+      const int q = (slot % Q) ^ (Q == 4 ? (tl >> 2) & 3 : (tl >> 1) & 7);
       const float4 val = stage[wv][slot];
-      if (wave_tok0 + tl < total) *(float4 *)(out + (wave_tok0 + tl) * 16 + 4 * q) = val;
+      if (wave_tok0 + tl < total) *(float4 *)(out + (wave_tok0 + tl) * LD + 4 * q) = val;
     }
     return;
   }
