@@ -300,6 +300,66 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16GemmArgs g) {
 // lanes ds_read_b128 serves per LDS cycle (rows {0-3, 12-15} of one chunk with rows {4-11} of the next) touch 16 different 16-byte
 // slots of the 256-byte bank window.  No staging registers, no ds_write, nothing of the loader on the VALU.
 // ------------------------------------------------------------------------------------------------
+// Image epilogue of the LDS-DMA kernel through LDS (whole samples per tile: tokens % 128 == 0, M % 128 == 0): the direct form stores
+// 8 bytes per lane -- 32-byte pieces of K rows, single 8-byte pieces of V tiles -- the pattern that held the token encoder at half its
+// rate.  Here the workgroup assembles its 128 x 128 bf16 block in the (free) ring in its FINAL layout -- K: token-major
+// rows of 256 bytes, 16-byte chunks XOR-swizzled by the row; V: the 32 fragment-major 1 KB tiles [token % 32 / 8][col % 16][token % 8] --
+// and copies it out in 16-byte pieces: whole 256-byte rows / whole 1 KB tiles of consecutive memory per 16 / 64 lanes.
+__device__ __forceinline__ void bf16_epilogue_img_lds(const Bf16GemmArgs &g, f32x4 (&acc)[4][4], unsigned char *lds, int m0, int n0, int wm,
+                                                      int wn, int fj, int fg, bool v_half, int tid) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();                                     // every wave is done with the ring
+  if (!v_half) {
+    // D[n_local = 4 fg + r][m_local = fj]: four consecutive columns of row fj
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int nl = wn * 64 + 16 * i + 4 * fg;
+      const f32x4 c4 = *(const f32x4 *)(g.cb + n0 + nl);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int ml = wm * 64 + 16 * t + fj;
+        const f32x4 v = (acc[i][t] + c4) * g.alpha;
+        u32x2 o;
+        o.x = pk_bf16(v[0], v[1]);
+        o.y = pk_bf16(v[2], v[3]);
+        *(u32x2 *)(lds + ml * 256 + ((((nl >> 3) ^ (ml & 15)) << 4) | ((nl & 4) << 1))) = o;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int idx = tid + 256 * k, row = idx >> 4, pos = idx & 15;
+      const u32x4 v = *(const u32x4 *)(lds + row * 256 + (pos << 4));
+      *(u32x4 *)(g.K16 + (long)(m0 + row) * g.inner + n0 + ((pos ^ (row & 15)) << 3)) = v;
+    }
+    return;
+  }
+  // D[m_local = 4 fg + r][n_local = fj]: four consecutive tokens of column fj
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int nl = wn * 64 + 16 * i + fj;
+    const float cbv = g.cb[n0 + nl];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int ml = wm * 64 + 16 * t + 4 * fg;
+      u32x2 v;
+      v.x = pk_bf16((acc[i][t][0] + cbv) * g.alpha, (acc[i][t][1] + cbv) * g.alpha);
+      v.y = pk_bf16((acc[i][t][2] + cbv) * g.alpha, (acc[i][t][3] + cbv) * g.alpha);
+      *(u32x2 *)(lds + (((ml >> 5) * 8 + (nl >> 4)) << 10) + (((ml & 31) >> 3) << 8) + ((nl & 15) << 4) + ((ml & 7) << 1)) = v;
+    }
+  }
+  __syncthreads();
+  const int bi = m0 / g.tokens, tok0 = m0 - bi * g.tokens, blocks_per = g.np >> 5;
+  const int head0 = (n0 - g.inner) >> 6;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int idx = tid + 256 * k, tile = idx >> 6, piece = idx & 63;      // tile = token block (0..3) * 8 + column block (0..7)
+    const int tb = tile >> 3, cb = tile & 7;
+    const long tile_idx = (((long)bi * g.heads + head0 + (cb >> 2)) * blocks_per + (tok0 >> 5) + tb) * 4 + (cb & 3);
+    *(u32x4 *)(g.V16 + tile_idx * 512 + piece * 8) = *(const u32x4 *)(lds + (tile << 10) + (piece << 4));
+  }
+}
+
 __device__ __forceinline__ void bf_glds16(const i32x4 &rsrc, unsigned lds_byte, int voffset, int soffset) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                :
@@ -392,6 +452,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_glds_kernel(Bf16GemmArgs g) 
   };
   if (v_half) run(std::true_type{}); else run(std::false_type{});
   if (g.abl & 1) { if (g.alpha != 12345.0f) return; }
+  if (IMG && g.tokens % 128 == 0 && g.M % 128 == 0 && !(g.abl & 8)) {      // (workgroup-uniform)
+    bf16_epilogue_img_lds(g, acc, lds, m0, n0, wm, wn, fj, fg, v_half, tid);
+    return;
+  }
   bf16_epilogue<IMG>(g, acc, m0, n0, wm, wn, fj, fg, v_half);
 }
 
