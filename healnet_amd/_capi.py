@@ -12,7 +12,7 @@ import sys
 from typing import Optional
 
 HN_MAX_AXES = 4
-HN_ABI_VERSION = 8
+HN_ABI_VERSION = 9
 HN_F32, HN_BF16, HN_U8 = 0, 1, 2
 HN_CORE_F32, HN_CORE_BF16, HN_CORE_BF16X3 = 0, 1, 2
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -102,6 +102,14 @@ class GradReady(C.Structure):
     _fields_ = [("events", C.POINTER(C.c_void_p)), ("notify", READY_FN), ("user", C.c_void_p)]
 
 
+CP_EXCHANGE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_void_p)
+
+
+class ContextSplit(C.Structure):       # hn_context_split (ABI v9)
+    _fields_ = [("n_parts", C.c_int), ("split_mask", C.c_uint), ("axis0_begin", C.c_int * 16), ("axis0_total", C.c_int * 16),
+                ("local", C.c_void_p), ("parts", C.c_void_p), ("exchange", CP_EXCHANGE_FN), ("user", C.c_void_p)]
+
+
 # every symbol include/healnet_hip.h declares: name -> (restype, argtypes)
 SIGNATURES = {
     "hn_abi_version": (C.c_int, []),
@@ -119,6 +127,9 @@ SIGNATURES = {
     "hn_attn_merge_workspace_bytes": (C.c_size_t, [C.POINTER(AttnParams), C.c_int, C.c_int]),
     "hn_attn_merge_fwd": (C.c_int, [C.POINTER(AttnParams), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                     C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "hn_context_split_floats": (C.c_size_t, [C.POINTER(Model), C.c_int]),
+    "hn_fusion_forward_cp": (C.c_int, [C.POINTER(Model), C.POINTER(ModalityInput), C.c_int, C.c_int, C.POINTER(ContextSplit), C.c_void_p,
+                                       C.c_void_p, C.c_size_t, C.c_void_p]),
     "hn_context_pitch": (C.c_int, [C.c_int, C.c_int]),
     "hn_attn_fwd": (C.c_int, [C.POINTER(AttnParams), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                               C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

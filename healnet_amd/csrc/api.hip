@@ -510,14 +510,14 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
 template <int V>      // V columns per thread: 4 (dim_head % 4 == 0: 16-byte pieces) or 1
 __global__ __launch_bounds__(256) void attn_merge_parts_kernel(const float *__restrict__ o_parts, const float *__restrict__ st_parts,
                                                                int n_parts, int b, int heads, int L, int dh, float *__restrict__ o,
-                                                               float *__restrict__ st_out) {
+                                                               float *__restrict__ st_out, long ostride, long sstride) {
   const int inner = heads * dh, pieces = inner / V;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (long)b * L * pieces) return;
   const long row = idx / pieces;
   const int c = (int)(idx - row * pieces) * V, h = c / dh;
   const int bi = (int)(row / L), q = (int)(row - (long)bi * L);
-  const long srow = (((long)bi * heads + h) * L + q) * 2, sstride = (long)b * heads * L * 2, ostride = (long)b * L * inner;
+  const long srow = (((long)bi * heads + h) * L + q) * 2;
   float M = -3.0e38f;
   for (int r = 0; r < n_parts; ++r) M = fmaxf(M, st_parts[r * sstride + srow]);
   float wsum = 0.0f, acc[V];
@@ -1463,10 +1463,10 @@ int hn_attn_merge_fwd(const hn_attn_params *p, const float *x_in, float *x_out, 
   const long pieces = (long)b * L * (vec ? inner >> 2 : inner);
   if (vec)
     hipLaunchKernelGGL(attn_merge_parts_kernel<4>, dim3((unsigned)ceil_div_ll(pieces, 256)), dim3(256), 0, s, o_parts, stats_parts, n_parts, b,
-                       p->heads, L, p->dim_head, obuf, stats);
+                       p->heads, L, p->dim_head, obuf, stats, (long)b * L * inner, (long)b * p->heads * L * 2);
   else
     hipLaunchKernelGGL(attn_merge_parts_kernel<1>, dim3((unsigned)ceil_div_ll(pieces, 256)), dim3(256), 0, s, o_parts, stats_parts, n_parts, b,
-                       p->heads, L, p->dim_head, obuf, stats);
+                       p->heads, L, p->dim_head, obuf, stats, (long)b * L * inner, (long)b * p->heads * L * 2);
   HN_LAUNCH_CHECK("attn_merge_parts");
   GemmArgs go = gemm_defaults();
   go.A = obuf; go.lda = inner;
@@ -1640,9 +1640,12 @@ static size_t impl_fusion_workspace_bytes(const hn_model *model, const hn_modali
 
 static int impl_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, const uint8_t *mask, int skip_self_on_missing,
                       int return_embeddings, float *out, float **attn_stats, float **x_trace, void *workspace,
-                      size_t workspace_bytes, void *stream, hn_profile *prof) {
+                      size_t workspace_bytes, void *stream, hn_profile *prof, const hn_context_split *cp = nullptr) {
   hipStream_t s = (hipStream_t)stream;
   HN_REQUIRE(out, HN_E_NULL, "fusion: out is NULL");
+  // cp: the context of the modalities in cp->split_mask is split over cp->n_parts ranks (hn_fusion_forward_cp): in[i] is this
+  // rank's slab, the cross blocks of such a modality exchange their (output, statistics) pairs through cp->exchange
+  auto is_split = [&](int i) { return cp != nullptr && ((cp->split_mask >> i) & 1u) != 0; };
   FusionPlan fp;
   int rc = plan_fusion(m, in, b, nullptr, 0, &fp, true);
   if (rc != HN_OK) return rc;
@@ -1655,6 +1658,8 @@ static int impl_fusion_forward(const hn_model *m, const hn_modality_input *in, i
   // K1 once per forward: the normalised context of every present modality (layer independent)
   for (int i = 0; i < M; ++i) {
     if (!in[i].data) continue;
+    HN_REQUIRE(!is_split(i) || (!fp.bf16[i] && fp.N[i] >= 2), HN_E_UNSUPPORTED,
+               "fusion: a split modality needs the fp32 core and at least two tokens per rank (modality %d: N=%ld)", i, (long)fp.N[i]);
     if (fp.bf16[i]) {
       uint16_t *zb = (uint16_t *)fp.z[i], *zT = zb + (size_t)b * fp.Np[i] * bf16_row_slots(fp.ldz[i], fp.ns[i]);
       rc = launch_encode_bf16ctx(in[i].data, in[i].dtype, b, m->num_spatial_axes[i], in[i].spatial, m->channel_dims[i],
@@ -1663,7 +1668,7 @@ static int impl_fusion_forward(const hn_model *m, const hn_modality_input *in, i
     } else {
       rc = launch_encode(in[i].data, in[i].dtype, b, m->num_spatial_axes[i], in[i].spatial, m->channel_dims[i], m->num_freq_bands,
                          m->max_freq, m->fourier_encode_data, 1, 1e-5f, fp.z[i], fp.ldz[i], s, fp.ones[i] ? fp.ldz[i] - 1 : -1,
-                         fp.pack[i]);
+                         fp.pack[i], is_split(i) ? cp->axis0_begin[i] : 0, is_split(i) ? cp->axis0_total[i] : 0);
       if (rc == HN_OK && fp.z16[i]) rc = launch_rows_to_bf16(fp.z[i], fp.ldz[i], (long)b * fp.N[i], fp.D[i], fp.z16[i], s);
     }
     if (rc != HN_OK) return rc;
@@ -1734,6 +1739,7 @@ static int impl_fusion_forward(const hn_model *m, const hn_modality_input *in, i
   const bool head = m->final_classifier_head && !return_embeddings;
   const bool use_chain = fp.chain && !chain_disabled();      // HN_NO_CHAIN: development switch, the unfused launch sequence
 
+  float *stats_override = nullptr;      // (context split: the statistics of a split block go to the exchange buffer)
   auto run_attn = [&](const Step &st, const float *xin, float *xout, AttnExt *ext) -> int {
     const int layer = st.layer, i = st.m;
     if (st.kind == STEP_SELF_ATTN)                                                              // :241-245
@@ -1751,7 +1757,7 @@ static int impl_fusion_forward(const hn_model *m, const hn_modality_input *in, i
     bc.zb = (const uint16_t *)fp.z[i]; bc.zT = bc.zb + (size_t)b * fp.Np[i] * bf16_row_slots(fp.ldz[i], fp.ns[i]);
     bc.Np = fp.Np[i]; bc.DV = fp.ldz[i]; bc.ns = fp.ns[i];
     return attn_fwd_impl(ap, xin, xout, 1, fp.z[i], fp.ldz[i], b, L, fp.N[i], fp.D[i], mask,
-                         attn_stats ? attn_stats[slot_of(st)] : nullptr, fp.op_ws, fp.op_ws_bytes, s, e0, e1, nullptr,
+                         stats_override ? stats_override : (attn_stats ? attn_stats[slot_of(st)] : nullptr), fp.op_ws, fp.op_ws_bytes, s, e0, e1, nullptr,
                          fp.ones[i], fp.pack[i], fp.bf16[i] ? &bc : nullptr, fp.flags + layer * M + i, ext,
                          fp.z16[i]);
   };
@@ -1826,6 +1832,8 @@ static int impl_fusion_forward(const hn_model *m, const hn_modality_input *in, i
     if (fuse && !is_tab(st)) fuse = ap->query_dim == d && (inner % 128 == 0 || staged_attn(ap)) && inner % 16 == 0 && inner <= 512 &&
                                     chain_out_aligned(ap) && !(st.kind == STEP_CROSS_ATTN && fp.N[st.m] == 1 && mask == nullptr);
     if (!fuse) {
+      HN_REQUIRE(!(st.kind == STEP_CROSS_ATTN && is_split(st.m)), HN_E_UNSUPPORTED,
+                 "fusion: the context split inside the fused forward needs the chain's shapes (modality %d): use the block-level entry points", st.m);
       float *dst = input_buffer(k + 1);
       if (is_tab(st)) rc = launch_add_row_broadcast(fp.taby[st.m] + (size_t)st.layer * b * ap->query_dim, cur, dst, b, L, ap->query_dim, s);
       else {
@@ -1843,8 +1851,30 @@ static int impl_fusion_forward(const hn_model *m, const hn_modality_input *in, i
       ca.head = 2; ca.y = fp.taby[st.m] + (size_t)st.layer * b * ap->query_dim;
     } else {
       AttnExt ext = {fp.cq, fp.ckv, q_done, kv_done, true, nullptr, 0, false, false, nullptr, nullptr, nullptr, 0, 0, 0};
-      ext.allow_defer_merge = st.kind == STEP_CROSS_ATTN && vmerge[st.m] && inner % 128 == 0;
-      if ((rc = run_attn(st, cur, nullptr, &ext)) != HN_OK) return rc;
+      const bool split = st.kind == STEP_CROSS_ATTN && is_split(st.m);
+      ext.allow_defer_merge = st.kind == STEP_CROSS_ATTN && vmerge[st.m] && inner % 128 == 0 && !split;
+      const long n_o = (long)b * L * inner, n_s = (long)b * ap->heads * L * 2;
+      if (split) stats_override = cp->local + n_o;
+      rc = run_attn(st, cur, nullptr, &ext);
+      stats_override = nullptr;
+      if (rc != HN_OK) return rc;
+      if (split) {
+        // this rank's (normalised output | statistics) -> one all-gather -> every rank folds all parts in rank order into the block's
+        // O buffer, and the chain carries on from there (out-projection, feed-forward, next projections)
+        HN_REQUIRE(!ext.merge_deferred && ext.o_out && ext.ldo_out == inner, HN_E_UNSUPPORTED, "fusion: split block did not report its output");
+        if ((rc = launch_copy(cp->local, ext.o_out, n_o, s)) != HN_OK) return rc;
+        cp->exchange(cp->user, (int)(n_o + n_s), stream);
+        float *st_out = attn_stats ? attn_stats[slot_of(st)] : nullptr;
+        const bool vec = ap->dim_head % 4 == 0 && (((uintptr_t)cp->parts | (uintptr_t)ext.o_out) & 15) == 0 && (n_o + n_s) % 4 == 0;
+        const long pieces = (long)b * L * (vec ? inner >> 2 : inner);
+        if (vec)
+          hipLaunchKernelGGL(attn_merge_parts_kernel<4>, dim3((unsigned)ceil_div_ll(pieces, 256)), dim3(256), 0, s, cp->parts, cp->parts + n_o,
+                             cp->n_parts, b, ap->heads, L, ap->dim_head, (float *)ext.o_out, st_out, n_o + n_s, n_o + n_s);
+        else
+          hipLaunchKernelGGL(attn_merge_parts_kernel<1>, dim3((unsigned)ceil_div_ll(pieces, 256)), dim3(256), 0, s, cp->parts, cp->parts + n_o,
+                             cp->n_parts, b, ap->heads, L, ap->dim_head, (float *)ext.o_out, st_out, n_o + n_s, n_o + n_s);
+        HN_LAUNCH_CHECK("attn_merge_parts");
+      }
       ca.inner_o = up128(inner); ca.o_cols = inner; ca.w_out = ap->w_out; ca.b_out = ap->b_out;
       if (ext.merge_deferred) {              // the chain merges the core's split partials and applies the value projection itself
         ca.head = 3; ca.Opart = ext.opart; ca.Mpart = ext.mpart; ca.Lpart = ext.lpart;
@@ -2719,6 +2749,27 @@ size_t hn_fusion_workspace_bytes(const hn_model *m, const hn_modality_input *in,
   const size_t xn = align_up(rows16((size_t)b * m->l_c) * 128 * sizeof(float), 256);
   const size_t n_slots = (size_t)m->depth * (m->n_modalities + 1);
   return align_up(st.floats * sizeof(float), 256) + (n_slots + 1) * xn + inner;      // shadow weights | trace slots | output | inner
+}
+
+size_t hn_context_split_floats(const hn_model *m, int b) {
+  if (!m || b <= 0) return 0;
+  size_t worst = 0;
+  for (int i = 0; i < m->depth * m->n_modalities; ++i) {
+    const hn_attn_params &a = m->cross_attn[i];
+    const size_t f = (size_t)b * m->l_c * ((size_t)a.heads * a.dim_head + 2 * (size_t)a.heads);
+    if (f > worst) worst = f;
+  }
+  return (worst + 63) / 64 * 64;
+}
+
+int hn_fusion_forward_cp(const hn_model *m, const hn_modality_input *in, int b, int return_embeddings, const hn_context_split *cp,
+                         float *out, void *workspace, size_t workspace_bytes, void *stream) {
+  HN_REQUIRE(m && in && cp && out, HN_E_NULL, "fusion_cp: NULL pointer");
+  HN_REQUIRE(cp->n_parts >= 1 && cp->local && cp->parts && cp->exchange, HN_E_NULL, "fusion_cp: exchange buffers / callback missing");
+  HN_REQUIRE(m->n_modalities <= 16, HN_E_UNSUPPORTED, "fusion_cp: %d modalities", m->n_modalities);
+  HN_REQUIRE(!stage_wanted(m), HN_E_UNSUPPORTED, "fusion_cp: staged models take the block-level entry points");
+  for (int i = 0; i < m->n_modalities; ++i) HN_REQUIRE(in[i].data, HN_E_UNSUPPORTED, "fusion_cp: modality %d is missing", i);
+  return impl_fusion_forward(m, in, b, nullptr, 0, return_embeddings, out, nullptr, nullptr, workspace, workspace_bytes, stream, nullptr, cp);
 }
 
 int hn_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, const uint8_t *mask, int skip_self_on_missing,

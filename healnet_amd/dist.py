@@ -285,9 +285,61 @@ def gather_partials(o_part: torch.Tensor, stats: torch.Tensor, group=None) -> Tu
     return out[:, :n_o].reshape((world,) + tuple(o_part.shape)).contiguous(), out[:, n_o:].reshape((world,) + tuple(stats.shape)).contiguous()
 
 
+def _gather_flat(local: torch.Tensor, parts: torch.Tensor, group=None) -> None:
+    """parts (world * n floats, rank-major) <- all-gather of local (n floats)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1 and not force_collectives():
+        parts.copy_(local)
+    else:
+        dist.all_gather_into_tensor(parts, local, group=group)
+
+
+def _fused_context_parallel(model, slabs, begins, totals, split, world, return_embeddings, gather_flat):
+    """hn_fusion_forward_cp: the fused forward (latent chains and all) over this rank's slabs; the C side calls back once per split
+    cross block for the all-gather of its (output | statistics) buffer."""
+    import ctypes as C
+    from . import _capi, ops
+    from ._rt import WS, stream_ptr
+    lib = _capi.lib()
+    sp = ops.spec_of(model._spec_text)
+    params = model._params()
+    device = params[0].device
+    emb = bool(return_embeddings) or not model.final_classifier_head
+    with torch.cuda.device(device), torch.no_grad():
+        mdl, _keep = sp.model_cached(params)
+        inp, held, b = sp.inputs(slabs)
+        need = lib.hn_fusion_workspace_bytes(C.byref(mdl), inp, b)
+        if need == 0:
+            _capi.check(-1, "hn_fusion_workspace_bytes")
+        ws = WS.get(device, need)
+        nf = int(lib.hn_context_split_floats(C.byref(mdl), b))
+        local = torch.empty(nf, dtype=torch.float32, device=device)
+        parts = torch.empty(world * nf, dtype=torch.float32, device=device)
+        failure = []
+
+        def exchange(_user, floats, _stream):
+            try:                                   # (an exception must not unwind through the C frame)
+                gather_flat(local[:floats], parts[: world * floats])
+            except BaseException as e:             # noqa: BLE001
+                failure.append(e)
+
+        cb = _capi.CP_EXCHANGE_FN(exchange)
+        cp = _capi.ContextSplit(n_parts=world, split_mask=sum(1 << i for i, f in enumerate(split) if f), local=local.data_ptr(),
+                                parts=parts.data_ptr(), exchange=cb, user=None)
+        for i in range(len(split)):
+            cp.axis0_begin[i], cp.axis0_total[i] = int(begins[i]), int(totals[i])
+        out = torch.empty(ops._out_shape(sp, b, emb), dtype=torch.float32, device=device)
+        status = lib.hn_fusion_forward_cp(C.byref(mdl), inp, b, int(emb), C.byref(cp), out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                          stream_ptr(device))
+        if failure:
+            raise failure[0]
+        _capi.check(status, "hn_fusion_forward_cp")
+    return out
+
+
 def context_parallel_forward(model, tensors: Sequence[Optional[torch.Tensor]], group=None, return_embeddings: bool = False,
                              min_rows_per_rank: int = 1, rank: Optional[int] = None, world: Optional[int] = None,
-                             gather=None) -> torch.Tensor:
+                             gather=None, fused: Optional[bool] = None, gather_flat=None) -> torch.Tensor:
     """Inference forward of a HealNet whose CONTEXTS are split over the ranks of `group` (every rank passes the SAME full-batch
     `tensors`; a rank reads only its slab of each split modality): the reference's fusion loop (healnet.py:225-250) block by
     block through the C ABI --
@@ -299,13 +351,18 @@ def context_parallel_forward(model, tensors: Sequence[Optional[torch.Tensor]], g
                                         tokens per rank, e.g. the one-token tabular input), feed-forward blocks, latent self blocks, head.
 
     Partition = the first spatial axis (image rows, volume slices, bag patches), contiguous slabs.  For b >= #GPUs shard the BATCH
-    instead (no forward collective at all).  No mask, no dropout, no missing modalities (the plain inference forward)."""
+    instead (no forward collective at all).  No mask, no dropout, no missing modalities (the plain inference forward).
+
+    `fused` (default: try it, fall back): run the whole loop inside ONE C call, hn_fusion_forward_cp -- the fused forward with its
+    latent chains, calling back once per split cross block for the all-gather -- instead of block by block (models whose shapes
+    the chains do not take, staged models and bf16 cores stay on the block-by-block route)."""
     from . import healnet as hm                              # (late: healnet.py imports this package's ops)
     hip = torch.ops.healnet_hip
     if rank is None:
         rank = dist.get_rank(group) if dist.is_initialized() else 0
     if world is None:
         world = dist.get_world_size(group) if dist.is_initialized() else 1
+    custom_gather = gather is not None
     gather = gather or (lambda o, st: gather_partials(o, st, group))
     M = model.modalities
     if len(tensors) != M or any(t is None for t in tensors):
@@ -315,6 +372,27 @@ def context_parallel_forward(model, tensors: Sequence[Optional[torch.Tensor]], g
     b = tensors[0].shape[0]
     ctx: List[Optional[torch.Tensor]] = [None] * M          # the rank's normalised slab, or the whole context of a replicated modality
     split = [False] * M
+    can_fuse = not custom_gather and not model.runs_staged() and getattr(model, "core_precision", "fp32") == "fp32"
+    if fused and not can_fuse:
+        raise RuntimeError("healnet_amd: hn_fusion_forward_cp (the fused context split) takes unstaged fp32-core models and the flat "
+                           "gather; this model / call runs block by block (fused=None or False)")
+    if fused is not False and can_fuse:
+        slabs, begins, totals = [], [], []
+        for m, data in enumerate(tensors):
+            rows = data.shape[1]
+            tokens_per_row = data[0, 0].numel() // data.shape[-1]
+            split[m] = world > 1 and rows >= world * max(1, min_rows_per_rank) and (rows // world) * tokens_per_row >= 2
+            lo, hi = slab_bounds(rows, rank, world) if split[m] else (0, rows)
+            slabs.append(data[:, lo:hi].contiguous() if split[m] else data)
+            begins.append(lo)
+            totals.append(rows)
+        try:
+            return _fused_context_parallel(model, slabs, begins, totals, split, world, return_embeddings,
+                                           gather_flat or (lambda lo_, pa_: _gather_flat(lo_, pa_, group)))
+        except RuntimeError as e:
+            if fused or "fusion" not in str(e):
+                raise
+        split = [False] * M
     with torch.no_grad():
         for m, data in enumerate(tensors):
             att = model.layers[0][2 * m].fn

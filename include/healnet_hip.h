@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HN_ABI_VERSION 8
+#define HN_ABI_VERSION 9
 #define HN_MAX_AXES 4
 
 typedef enum hn_status {
@@ -355,6 +355,28 @@ int hn_fusion_forward(const hn_model *model, const hn_modality_input *inputs, in
                       float **x_trace, void *workspace, size_t workspace_bytes, void *stream,
                       hn_profile *profile);
 size_t hn_fusion_workspace_bytes(const hn_model *model, const hn_modality_input *inputs, int b);
+
+/* The fused forward with the CONTEXT of some modalities split over ranks (SURVEY.md 8(e) second axis; ABI v9) -- the fused form of
+ * hn_encode_norm_slab + hn_attn_partial_fwd + hn_attn_merge_fwd: inputs[i] of a modality in `split_mask` is THIS rank's slab (rows
+ * [axis0_begin[i], axis0_begin[i] + spatial[0]) of an axis of axis0_total[i] positions); behind the attention core of each of its
+ * cross blocks the entry point writes the rank's (normalised output | statistics) to `local`, calls `exchange(user, floats, stream)`
+ * -- the caller enqueues ONE all-gather of `floats` floats per rank from `local` into `parts` (rank-major, stride `floats`) on
+ * `stream` -- and folds the parts in rank order; out-projection, feed-forward and the next projections run on the latent chains as
+ * in hn_fusion_forward.  Everything else is replicated.  fp32 core, no mask, no missing modality, default (unstaged) shapes; a
+ * model the chains do not take is refused (HN_E_UNSUPPORTED: use the block-level entry points).  `local` / `parts` hold
+ * hn_context_split_floats() / n_parts times that many floats.  Workspace: hn_fusion_workspace_bytes() of the slab inputs. */
+typedef void (*hn_cp_exchange_fn)(void *user, int floats, void *stream);
+typedef struct hn_context_split {
+  int n_parts;
+  unsigned split_mask;
+  int axis0_begin[16], axis0_total[16];
+  float *local, *parts;
+  hn_cp_exchange_fn exchange;
+  void *user;
+} hn_context_split;
+size_t hn_context_split_floats(const hn_model *model, int b);
+int hn_fusion_forward_cp(const hn_model *model, const hn_modality_input *inputs, int b, int return_embeddings,
+                         const hn_context_split *cp, float *out, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Staged models.  The fused latent side (chain.hip / bchain.hip) is built for l_d = 128, head widths of 16 / 32 / 64 / 128, inner
  * widths that are multiples of 128 and 16-row tiles.  A model outside those shapes that fits them after ZERO PADDING -- l_d <= 128,

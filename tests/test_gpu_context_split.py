@@ -121,12 +121,16 @@ KW = dict(n_modalities=3, channel_dims=[200, 3, 64], num_spatial_axes=[1, 2, 1],
           cross_dim_head=32, latent_dim_head=16)      # one-token tabular (replicated) + image (rank-D binding) + bag (explicit binding)
 
 
+KW_CHAIN = dict(n_modalities=3, channel_dims=[200, 3, 64], num_spatial_axes=[1, 2, 1], out_dims=4, depth=2)      # default widths: the
+# latent chains take it, so hn_fusion_forward_cp (the fused route) runs
+
+
 def _inputs(b):
     gen = torch.Generator().manual_seed(21)
     return [torch.rand(b, 1, 200, generator=gen), torch.rand(b, 37, 20, 3, generator=gen), torch.rand(b, 301, 64, generator=gen)]
 
 
-def _cp_worker(rank, world, port, b, q):
+def _cp_worker(rank, world, port, b, q, kw=None, fused=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch.distributed as dist
@@ -137,10 +141,10 @@ def _cp_worker(rank, world, port, b, q):
         hd.init_from_env("gloo")
         dev = torch.device("cuda", 0)
         torch.manual_seed(5)
-        model = hn.HealNet(**KW).eval().to(dev)
+        model = hn.HealNet(**(kw or KW)).eval().to(dev)
         ins = [t.to(dev) for t in _inputs(b)]
-        out = hd.context_parallel_forward(model, ins)
-        emb = hd.context_parallel_forward(model, ins, return_embeddings=True)
+        out = hd.context_parallel_forward(model, ins, fused=fused)
+        emb = hd.context_parallel_forward(model, ins, return_embeddings=True, fused=fused)
         torch.cuda.synchronize()
         q.put((rank, "ok", out.cpu().numpy(), emb.cpu().numpy()))
     except Exception as e:  # pragma: no cover
@@ -151,14 +155,16 @@ def _cp_worker(rank, world, port, b, q):
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,b", [(2, 1), (3, 2)], ids=["2-ranks-b1", "3-ranks-b2"])
-def test_context_parallel_forward_matches_the_plain_forward(world, b):
+@pytest.mark.parametrize("world,b,route", [(2, 1, "blocks"), (3, 2, "blocks"), (2, 2, "fused"), (3, 1, "fused")],
+                         ids=["2-ranks-b1", "3-ranks-b2", "2-ranks-b2-fused", "3-ranks-b1-fused"])
+def test_context_parallel_forward_matches_the_plain_forward(world, b, route):
     import healnet_amd as hn
     from oracle import healnet_cpu as O
+    KW_ = KW_CHAIN if route == "fused" else KW
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_cp_worker, args=(r, world, port, b, q)) for r in range(world)]
+    procs = [ctx.Process(target=_cp_worker, args=(r, world, port, b, q, KW_, True if route == "fused" else False)) for r in range(world)]
     for p in procs:
         p.start()
     results = sorted([q.get(timeout=600) for _ in procs], key=lambda r: r[0])
@@ -166,13 +172,13 @@ def test_context_parallel_forward_matches_the_plain_forward(world, b):
         p.join(timeout=120)
     assert [r[1] for r in results] == ["ok"] * world, [r[1] for r in results]
     torch.manual_seed(5)
-    model = hn.HealNet(**KW).eval().to(DEV)
+    model = hn.HealNet(**KW_).eval().to(DEV)
     ins = _inputs(b)
     with torch.no_grad():
         plain = model([t.to(DEV) for t in ins]).cpu()
         plain_emb = model([t.to(DEV) for t in ins], return_embeddings=True).cpu()
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-    want = O.fusion_forward(sd, O.FusionConfig(**KW), [t.clone() for t in ins])
+    want = O.fusion_forward(sd, O.FusionConfig(**KW_), [t.clone() for t in ins])
     for rank, _, out, emb in results:
         assert_close(torch.from_numpy(out), plain, rel=2e-5, floor=2e-6, what=f"rank {rank}: context-parallel logits vs the plain forward")
         assert_close(torch.from_numpy(emb), plain_emb, rel=2e-5, floor=2e-6, what=f"rank {rank}: embeddings")
@@ -189,7 +195,20 @@ def test_single_rank_and_validation():
     ins = [t.to(DEV) for t in _inputs(2)]
     with torch.no_grad():
         plain = model(ins)
-    got = hd.context_parallel_forward(model, ins, rank=0, world=1)
+    got = hd.context_parallel_forward(model, ins, rank=0, world=1, fused=False)
     assert_close(got.cpu(), plain.cpu(), rel=2e-5, floor=2e-6, what="block-by-block forward vs the fused forward")
+    # the fused route: refused for this model (l_d = 64: not a chain shape) with fused=True, silently replaced by default
+    with pytest.raises(RuntimeError):
+        hd.context_parallel_forward(model, ins, rank=1, world=2, fused=True, gather_flat=lambda lo, pa: pa.copy_(lo.repeat(2)))
+    # ... and taken by a default-width model: one rank of two with a stand-in exchange (its own part twice) still runs end to end,
+    # and world = 1 through the fused entry point reproduces the plain forward
+    torch.manual_seed(5)
+    big = hn.HealNet(**KW_CHAIN).eval().to(DEV)
+    with torch.no_grad():
+        plain_big = big(ins)
+    got_big = hd.context_parallel_forward(big, ins, rank=0, world=1, fused=True)
+    assert_close(got_big.cpu(), plain_big.cpu(), rel=2e-5, floor=2e-6, what="hn_fusion_forward_cp with one part vs hn_fusion_forward")
+    half = hd.context_parallel_forward(big, ins, rank=1, world=2, fused=True, gather_flat=lambda lo, pa: pa.copy_(lo.repeat(2)))
+    assert torch.isfinite(half).all()
     with pytest.raises(ValueError):
         hd.context_parallel_forward(model, [ins[0], None, ins[2]], rank=0, world=1)
