@@ -54,20 +54,27 @@ for G in (1, 2, 4, 8):
                gathered_kb_per_rank_and_block=round(gathered.get("floats_per_rank", 0) * 4 / 1024, 1),
                speedup_vs_one_rank=None)
     rows.append(row)
-one = next(r["ms"] for r in rows if r["ranks"] == 1 and r["path"].startswith("block"))
-for r in rows:
-    if r["path"].startswith("block"):
-        r["speedup_vs_one_rank"] = round(one / r["ms"], 2)
+    # the fused route (hn_fusion_forward_cp: latent chains and all, one C call, the exchange as a callback)
+    ms = timeit(lambda: hd.context_parallel_forward(model, ins, rank=0, world=G, fused=True,
+                                                    gather_flat=lambda lo, pa, G=G: pa.copy_(lo.repeat(G))))
+    rows.append(dict(path="fused (hn_fusion_forward_cp), rank 0 of G (stand-in gather)", ranks=G, ms=round(ms, 3), speedup_vs_one_rank=None))
+for kind in ("block", "fused ("):
+    one = next(r["ms"] for r in rows if r["ranks"] == 1 and r["path"].startswith(kind))
+    for r in rows:
+        if r["path"].startswith(kind):
+            r["speedup_vs_one_rank"] = round(one / r["ms"], 2)
 # G = 1 of the block-by-block path must reproduce the fused forward
 with torch.no_grad():
-    got = hd.context_parallel_forward(model, ins, rank=0, world=1)
+    got = hd.context_parallel_forward(model, ins, rank=0, world=1, fused=False)
+    got_f = hd.context_parallel_forward(model, ins, rank=0, world=1, fused=True)
 err = float((got - ref).abs().max() / ref.abs().max())
+err_f = float((got_f - ref).abs().max() / ref.abs().max())
 doc = dict(workload=f"cfg3-shaped model, b = {b}: tab (b,1,2000) + img (b,224,224,3) + vol (b,12,224,224,3), fp32, eval", rows=rows,
-           block_by_block_vs_fused_rel_err=err,
+           block_by_block_vs_fused_rel_err=err, fused_cp_one_part_vs_fused_rel_err=err_f,
            note="compute of ONE rank on one GPU; no communication is measured (stand-in gather); no multi-GPU number is claimed")
 for r in rows:
     print(r)
-print("rel err block-by-block vs fused:", err)
+print("rel err block-by-block vs fused:", err, " hn_fusion_forward_cp (one part) vs fused:", err_f)
 if args.json:
     with open(args.json, "w") as f:
         json.dump(doc, f, indent=1)
