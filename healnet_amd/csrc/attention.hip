@@ -284,10 +284,20 @@ __global__ __launch_bounds__(256) void attn_core_kernel(AttnCoreArgs a, int ngro
     }
     if (DROP) {   // nn.Dropout on the NORMALISED probabilities (:421): l keeps the full sum, the P V operand is thinned
       // (kept or zero here; the factor 1 / (1 - p) multiplies the accumulators once, in the epilogue)
-      // 16-bit decisions, rows 16 apart share a generator call (common.h): with an even tile count per wave and the (b, h)
-      // block starting on a multiple of 32 rows (wave-uniform) the lane's tiles pair up -- NQ / 2 calls instead of NQ
+      // 16-bit decisions, rows 16 apart share a generator call (common.h): four tiles per call when the wave's tiles come in
+      // fours and the (b, h) block starts on a multiple of 64 rows (wave-uniform), two per call for pairs on a multiple of 32
       const uint32_t row0 = (uint32_t)(bh * L + qg * NQ * 16 + j), quad = (uint32_t)(t0 + 4 * g) >> 2;
-      if (NQ % 2 == 0 && ((bh * L) & 31) == 0) {
+      if (NQ % 4 == 0 && ((bh * L) & 63) == 0) {
+#pragma unroll
+        for (int i = 0; i + 3 < NQ; i += 4) {
+          bool keep[4][4];
+          drop_rows4(a.drop, quad, row0 + 16 * i, keep);
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) P[i + k][r] = keep[k][r] ? P[i + k][r] : 0.0f;
+        }
+      } else if (NQ % 2 == 0 && ((bh * L) & 31) == 0) {
 #pragma unroll
         for (int i = 0; i + 1 < NQ; i += 2) {
           bool lo[4], hi[4];

@@ -154,7 +154,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a, int ngr
     }
     if (DROP) {   // O = (P * d) V with the forward's keep/scale factors d:  dP <- d * (dO V^T) - D
       const uint32_t row0 = (uint32_t)(bh * L + qg * NQ * 16 + j), quad = (uint32_t)(t0 + 4 * g) >> 2;
-      if (NQ % 2 == 0 && ((bh * L) & 31) == 0) {      // rows 16 apart share a generator call (common.h; as in the forward core)
+      if (NQ % 4 == 0 && ((bh * L) & 63) == 0) {      // rows 16 apart share a generator call (common.h; as in the forward core)
+#pragma unroll
+        for (int i = 0; i + 3 < NQ; i += 4) {
+          bool keep[4][4];
+          drop_rows4(a.drop, quad, row0 + 16 * i, keep);
+          const float sc = a.drop.scale;
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dP[i + k][r] = keep[k][r] ? fmaf(dP[i + k][r], sc, -drow[i + k]) : -drow[i + k];
+        }
+      } else if (NQ % 2 == 0 && ((bh * L) & 31) == 0) {
 #pragma unroll
         for (int i = 0; i + 1 < NQ; i += 2) {
           bool lo[4], hi[4];

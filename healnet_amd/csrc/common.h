@@ -149,11 +149,18 @@ enum { ACT_NONE = 0, ACT_LEAKY = 1, ACT_GLU_SELU = 2, ACT_GLU_GELU = 3 };
 // passes BigCrush in Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11 -- 10 is the library default's safety
 // margin, and inside the attention core every round is paid per score quad); one call yields the four decisions of an aligned
 // column quad (row, 4 c .. 4 c + 3): keep iff word >= thr, P(keep) = 1 - p.
-// ATTENTION masks (stream ids without DROP_SID_FF; round 3) take 16-bit decisions, EIGHT per call: the call of (row R with bit 4
-// clear, quad c) decides the column quad of row R with the low halves of its words and that of row R + 16 with the high halves
-// (keep iff half >= thr, thr = p * 2^16 rounded down, kept values scaled by 1 / (1 - p) as nn.Dropout does).  Inside the
-// image cores the generator is what dropout costs (4 calls of ~55 vector instructions per lane and 16-token step against 28
-// MFMAs); a lane's query tiles are 16 rows apart, so two of them share a call.
+// ATTENTION masks (stream ids without DROP_SID_FF) take 16-bit decisions, SIXTEEN per call (round 4; round 3 took eight): the
+// call of (row R with bits 4 and 5 clear, quad c) decides the column quad of the four rows R, R + 16, R + 32, R + 48 -- a lane's
+// query tiles in the cores are 16 rows apart, so the four tiles of a wave share ONE call.  Row R + 16 k reads, from word r of the
+// call (column 4 c + r), the 16-bit WINDOW that starts at byte k of the word, cyclically: bytes (1,0), (2,1), (3,2), (0,3) for
+// k = 0 .. 3, high byte first; keep iff window >= thr, thr = p * 2^16 rounded down, kept values scaled by 1 / (1 - p) as nn.Dropout
+// does.  Every window is a uniform 16-bit number, so every decision has P(keep) = 1 - thr / 2^16 EXACTLY (the rate keeps its 2^-16
+// resolution -- 8-bit decisions would have quantised it to 1/256); the windows of rows 16 apart share one byte, as the LOW byte
+// of one and the HIGH byte of the other: decision k looks at its low byte only when its high byte equals the threshold's (1 in
+// 256), so the covariance of the two decisions is <= 2^-8 / 4 (correlation <= 0.5 %, exactly 0 when thr is a multiple of 256,
+// e.g. p = 0.25 / 0.5); columns, other rows, blocks, offsets and seeds stay independent calls.  tests/test_gpu_dropout.py bounds
+// it.  Inside the image cores the generator is what dropout costs (~55 vector instructions per call against the 28 MFMAs of a
+// 16-token step): one call per lane and step instead of round 3's two (round 2: four).
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t DROP_SID_FF = 0x80000000u;      // stream ids of feed-forward blocks carry this bit
 struct DropCfg {
@@ -204,52 +211,67 @@ __device__ __forceinline__ void drop_quad(const DropCfg &d, uint32_t quad, uint3
 #pragma unroll
   for (int r = 0; r < 4; ++r) m[r] = w[r] >= d.thr ? d.scale : 0.0f;
 }
-// ---- attention masks: rows R (bit 4 clear) and R + 16 share the call of (R, quad)
-// both rows of a pair at once: lo[r] / hi[r] = multipliers of (R, 4 quad + r) / (R + 16, 4 quad + r); `row` must have bit 4 clear
-// (keep decisions only -- the callers fold the scale elsewhere: (w << 16) >= (thr << 16) for the low half, w >= (thr << 16) for the
-// high half: one shift and two compares per pair of elements)
-__device__ __forceinline__ void drop_pair(const DropCfg &d, uint32_t quad, uint32_t row, bool (&lo)[4], bool (&hi)[4]) {
+// ---- attention masks: rows R (bits 4, 5 clear), R + 16, R + 32, R + 48 share the call of (R, quad)
+// window k of a word, in the word's top half (the bottom half is don't-care: the compares are against thr << 16)
+__device__ __forceinline__ uint32_t drop_window(uint32_t w, uint32_t k) { return __builtin_amdgcn_alignbit(w, w, (16u + 8u * k) & 31u); }
+// all four rows at once: keep[k][r] = decision of (R + 16 k, 4 quad + r); `row` must have bits 4 and 5 clear
+// (keep decisions only -- the callers fold the scale elsewhere; 7 vector instructions per word: w << 16, w << 8, rotate, 4 compares)
+__device__ __forceinline__ void drop_rows4(const DropCfg &d, uint32_t quad, uint32_t row, bool (&keep)[4][4]) {
   uint32_t w[4];
   philox4x32(d.seed_lo, d.seed_hi, quad, row, d.sid, drop_counter(d), w);
   const uint32_t th = d.thr << 16;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    lo[r] = (w[r] << 16) >= th;
-    hi[r] = w[r] >= th;
+    keep[0][r] = (w[r] << 16) >= th;
+    keep[1][r] = (w[r] << 8) >= th;
+    keep[2][r] = w[r] >= th;
+    keep[3][r] = __builtin_amdgcn_alignbit(w[r], w[r], 8) >= th;
   }
 }
-// one row of a pair (any row): its own half of the pair's call
+// two rows 16 apart: lo[r] / hi[r] = decisions of (R, 4 quad + r) / (R + 16, 4 quad + r); `row` must have bit 4 clear
+__device__ __forceinline__ void drop_pair(const DropCfg &d, uint32_t quad, uint32_t row, bool (&lo)[4], bool (&hi)[4]) {
+  uint32_t w[4];
+  philox4x32(d.seed_lo, d.seed_hi, quad, row & ~48u, d.sid, drop_counter(d), w);
+  const uint32_t th = d.thr << 16, k = (row >> 4) & 3u;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    lo[r] = drop_window(w[r], k) >= th;
+    hi[r] = drop_window(w[r], k + 1) >= th;
+  }
+}
+// one row (any row): its own window of its group's call
 __device__ __forceinline__ void drop_quad_attn(const DropCfg &d, uint32_t quad, uint32_t row, bool (&keep)[4]) {
   uint32_t w[4];
-  philox4x32(d.seed_lo, d.seed_hi, quad, row & ~16u, d.sid, drop_counter(d), w);
-  const uint32_t sh = row & 16u;               // 0: low halves, 16: high halves
+  philox4x32(d.seed_lo, d.seed_hi, quad, row & ~48u, d.sid, drop_counter(d), w);
+  const uint32_t th = d.thr << 16, k = (row >> 4) & 3u;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) keep[r] = ((w[r] >> sh) & 0xffffu) >= d.thr;
+  for (int r = 0; r < 4; ++r) keep[r] = drop_window(w[r], k) >= th;
 }
 __device__ __forceinline__ float drop_one(const DropCfg &d, uint32_t col, uint32_t row) {
   uint32_t w[4];
   const bool ff = (d.sid & DROP_SID_FF) != 0;
-  philox4x32(d.seed_lo, d.seed_hi, col >> 2, ff ? row : (row & ~16u), d.sid, drop_counter(d), w);
+  philox4x32(d.seed_lo, d.seed_hi, col >> 2, ff ? row : (row & ~48u), d.sid, drop_counter(d), w);
   const uint32_t c = col & 3;
-  uint32_t v = c == 0 ? w[0] : (c == 1 ? w[1] : (c == 2 ? w[2] : w[3]));
-  if (!ff) v = (v >> (row & 16u)) & 0xffffu;
+  const uint32_t v = c == 0 ? w[0] : (c == 1 ? w[1] : (c == 2 ? w[2] : w[3]));
+  if (!ff) return drop_window(v, (row >> 4) & 3u) >= (d.thr << 16) ? d.scale : 0.0f;
   return v >= d.thr ? d.scale : 0.0f;
 }
 // Four lanes that are adjacent in a wave (a DPP quad) and hold the SAME column quad of four different rows -- the layout of
 // attn_bwd_dkv_kernel: lane e of the quad has column 4 c + e of rows row0 .. row0 + 3 -- need 4 calls, not 16: lane e runs the
 // call of row row0 + e, then word e of every call is fetched from the lane that ran it (quad_perm broadcasts, one VALU move each).
 // m[r] = multiplier of (row0 + r, 4 quad + e).
-// (attention masks: the call of row row0 + e is the one of its pair, every row picks its own half)
+// (attention masks: the call of row row0 + e is the one of its group of four, every row picks its own window)
 __device__ __forceinline__ void drop_quad_transposed(const DropCfg &d, uint32_t quad, uint32_t row0, uint32_t e, float (&m)[4]) {
   uint32_t w[4];
-  philox4x32(d.seed_lo, d.seed_hi, quad, (row0 + e) & ~16u, d.sid, drop_counter(d), w);
+  philox4x32(d.seed_lo, d.seed_hi, quad, (row0 + e) & ~48u, d.sid, drop_counter(d), w);
+  const uint32_t th = d.thr << 16;
 #define HN_QUAD_BCAST(v, r) (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (r) * 0x55, 0xf, 0xf, true)
 #define HN_QUAD_WORD(r)                                                                                          \
   {                                                                                                              \
     const uint32_t t0_ = HN_QUAD_BCAST(w[0], r), t1_ = HN_QUAD_BCAST(w[1], r), t2_ = HN_QUAD_BCAST(w[2], r),     \
                    t3_ = HN_QUAD_BCAST(w[3], r);                                                                 \
     const uint32_t v_ = e == 0 ? t0_ : (e == 1 ? t1_ : (e == 2 ? t2_ : t3_));                                    \
-    m[r] = ((v_ >> ((row0 + (r)) & 16u)) & 0xffffu) >= d.thr ? d.scale : 0.0f;                                   \
+    m[r] = drop_window(v_, ((row0 + (r)) >> 4) & 3u) >= th ? d.scale : 0.0f;                                     \
   }
   HN_QUAD_WORD(0) HN_QUAD_WORD(1) HN_QUAD_WORD(2) HN_QUAD_WORD(3)
 #undef HN_QUAD_WORD

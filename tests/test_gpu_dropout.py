@@ -80,6 +80,15 @@ CASES = [
     dict(kw=dict(n_modalities=1, channel_dims=[21], num_spatial_axes=[1], out_dims=4, depth=1, l_c=16, l_d=65, x_heads=1,
                  l_heads=8, cross_dim_head=103, latent_dim_head=51, attn_dropout=0.25, ff_dropout=0.06, self_per_cross_attn=0),
          shapes=[(33, 21)]),
+    # l_c = 64: the (b, h) blocks start on multiples of 64 rows -> the cores' four query tiles share ONE generator call
+    # (common.h drop_rows4: windows 0 .. 3); both bindings (tabular explicit, image rank-D)
+    dict(kw=dict(n_modalities=2, channel_dims=[40, 3], num_spatial_axes=[1, 2], out_dims=4, depth=1, l_c=64, l_d=32, x_heads=2,
+                 l_heads=2, cross_dim_head=16, latent_dim_head=16, attn_dropout=0.3, ff_dropout=0.1),
+         shapes=[(9, 40), (11, 13, 3)]),
+    # l_c = 32: every other block starts at 32 mod 64 -> tile pairs on windows (2, 3) of their group's call (drop_pair)
+    dict(kw=dict(n_modalities=2, channel_dims=[40, 3], num_spatial_axes=[1, 2], out_dims=4, depth=1, l_c=32, l_d=32, x_heads=3,
+                 l_heads=2, cross_dim_head=16, latent_dim_head=16, attn_dropout=0.2, ff_dropout=0.0),
+         shapes=[(9, 40), (11, 13, 3)]),
 ]
 
 
@@ -149,6 +158,18 @@ def test_mask_statistics(hn):
     c = float(((m0[:, 1:] - (1 - p)) * (m0[:, :-1] - (1 - p))).mean())
     r = float(((m0[1:] - (1 - p)) * (m0[:-1] - (1 - p))).mean())
     assert abs(c) < 2e-3 and abs(r) < 2e-3
+    # attention masks: rows 16 / 32 / 48 apart share a generator call (16 decisions of 16 bits from overlapping windows of the
+    # call's 128 bits, common.h): exact marginals, covariance of window neighbours <= 2^-10 by construction
+    for d in (16, 32, 48, 64):
+        r16 = float(((m0[d:] - (1 - p)) * (m0[:-d] - (1 - p))).mean())
+        assert abs(r16) < 2e-3, (d, r16)
+    # the rate keeps its 2^-16 resolution: p = 0.3 + 1/512 is told apart from 0.3 (8-bit decisions could not)
+    for pq in (0.3 + 1.0 / 512, 0.05, 0.7):
+        mq = _mask(hn, pq, 77, 3, 9, False, 4096, 2048).float()
+        assert abs(float(mq.mean()) - (1 - pq)) < 7e-4, (pq, float(mq.mean()))
+        for k in range(4):          # every window position on its own
+            rows = torch.arange(4096).div(16, rounding_mode="floor").remainder(4) == k
+            assert abs(float(mq[rows].mean()) - (1 - pq)) < 1.2e-3, (pq, k)
     assert float(_mask(hn, 0.0, 1, 1, 1, False, 8, 8).float().mean()) == 1.0
 
 
