@@ -200,6 +200,10 @@ static GemmArgs gemm_defaults() {
 
 // Steps shared by hn_attn_fwd and hn_attn_probs: the scaled query operand of the attention core and
 // (explicit path) the projected keys / values.
+static bool drop_bound_disabled() {      // development switch: dropout on the shared-context binding through the general core
+  static const bool off = getenv("HN_NO_DROP_BOUND") != nullptr;
+  return off;
+}
 static float *saved_kv(const AttnPlan &pl, bool has_ctx, bool masked, int b, int L, float *saved) {
   if (!saved || !has_ctx || pl.rank_d || (pl.N == 1 && !masked)) return nullptr;
   return saved + align_up(rows16((size_t)b * L) * pl.inner, 64);
@@ -465,11 +469,11 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
   const int srow = (dropping && pl.rank_d) ? 1 : 0;       // the thinned probabilities' row sum rides in column dp-1
   HN_REQUIRE(!srow || pl.ones, HN_E_UNSUPPORTED, "attn: dropout on the shared-context binding needs a free column (D <= dp - 1)");
   if (dropping) {
-    // shared-context binding with a score bound (LayerNorm-ed context): the bounded softmax stays, the ones column (injected in
-    // registers: the context is laid out without one under dropout) is the row-sum channel; otherwise the general path
-    static const bool no_bound = getenv("HN_NO_DROP_BOUND") != nullptr;      // development switch
-    const bool keep_bound = srow && core.bound != nullptr && (pl.dp == 16 || pl.dp == 32) && !no_bound;
-    core.ones_col = keep_bound ? 1 : 0; core.ones_in_mem = 0; core.drop = drop_of(p->dropout, p->rng, false); core.drop_rowsum = srow;
+    // shared-context binding with a score bound (LayerNorm-ed context): the bounded softmax stays, the ones column (in the
+    // context rows of the training layout, else injected in registers) is the row-sum channel; otherwise the general path
+    const bool keep_bound = srow && core.bound != nullptr && (pl.dp == 16 || pl.dp == 32) && !drop_bound_disabled();
+    HN_REQUIRE(keep_bound || !core.ones_in_mem, HN_E_SHAPE, "attn: a context laid out with the ones column needs the bounded dropout core");
+    core.ones_col = keep_bound ? 1 : 0; core.drop = drop_of(p->dropout, p->rng, false); core.drop_rowsum = srow;
     if (!keep_bound) { core.bound = nullptr; core.bound_flag = nullptr; }
   }
   if (o_save && !pl.rank_d) pl.obuf = o_save;      // training, explicit binding: the merged O is produced straight in its tape slot
@@ -712,8 +716,8 @@ static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float
   // ---- recompute the operands of the core (scaled Q, and K/V or the folded queries)
   AttnCoreArgs core;
   float *kv_saved = saved_kv(pl, has_ctx, general, b, L, const_cast<float *>(saved));
-  // packed shared context (the training forward's layout when nothing is dropped): folded queries, dO' and dQ'' in slot order
-  const int pack_ks = (pl.rank_d && pl.ones && p->ctx_gamma && !dropping) ? ctx_pack_ks : 0;
+  // packed shared context (the training forward's layout, train_context_layout): folded queries, dO' and dQ'' in slot order
+  const int pack_ks = (pl.rank_d && pl.ones && p->ctx_gamma) ? ctx_pack_ks : 0;
   float *kv_from = kv_saved ? kv_saved : ((ext && ext->kv_taped && !has_ctx) ? const_cast<float *>(ext->kv_taped) : nullptr);
   AttnExt pe;
   memset(&pe, 0, sizeof(pe));
@@ -772,7 +776,7 @@ static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float
     if ((rc = launch_rowdot_heads(bp.dOp, hp, pl.dp, saved, hp, pl.dp, h, L, srow ? pl.dp : pl.D, rows, bp.delta, s)) != HN_OK) return rc;
     ba.dO = bp.dOp; ba.do_b = (long)L * hp; ba.do_h = pl.dp; ba.lddo = hp;
     ba.qk_steps = pack_ks;
-    if (pack_ks && (rc = launch_pack_fold(bp.dOp, hp, h, pl.D, pl.dp, pack_ks, 0, rows, s)) != HN_OK) return rc;
+    if (pack_ks && (rc = launch_pack_fold(bp.dOp, hp, h, pl.D, pl.dp, pack_ks, 0, rows, s, srow ? 1 : 0)) != HN_OK) return rc;
     if ((rc = launch_attn_bwd_dq(ba, s)) != HN_OK) return rc;
     // dQacc (rows, h*dp) = sum over splits; folded-query chain  Qf = c * gamma * T,  T = Q_h W_k,h
     if ((rc = launch_dq_reduce(bp.dQpart, pl.nsplit_bwd, b, h, L, pl.Lp, pl.dp, pl.dp, 1.0f, bp.E, hp, pl.dp, s)) != HN_OK) return rc;
@@ -1911,9 +1915,10 @@ static size_t impl_fusion_tape_bytes(const hn_model *m, const hn_modality_input 
 
 }  // extern "C"
 
-// Context layout of the training forward / backward: the ones column and the packed channel order of the inference forward
-// whenever none of the modality's cross-attention blocks drops probabilities (dropout needs column dp-1 for the row-sum
-// channel and the explicit denominator).
+// Context layout of the training forward / backward: the ones column and the packed channel order of the inference forward.
+// Round 4: under dropout on the probabilities too -- the ones column's accumulator is the thinned row sum the rank-D binding
+// needs there anyway (the full denominator is summed on the VALU), and the packed order saves one QK^T k-step in the forward
+// core and two of twelve in the dQ kernel.  (Dropping blocks need the bounded core for that: a LayerNorm-ed context.)
 static void train_context_layout(const hn_model *m, const FusionPlan &fp, bool *ones, int *pack) {
   for (int i = 0; i < m->n_modalities; ++i) {
     bool dropping = false, affine = true;
@@ -1922,7 +1927,7 @@ static void train_context_layout(const hn_model *m, const FusionPlan &fp, bool *
       dropping = dropping || ap.dropout > 0.0f;
       affine = affine && ap.ctx_gamma != nullptr;
     }
-    ones[i] = fp.z[i] != nullptr && fp.ones[i] && !dropping && affine;
+    ones[i] = fp.z[i] != nullptr && fp.ones[i] && affine && (!dropping || !drop_bound_disabled());
     // (the backward's dq kernel has no variant whose last 16-column block contributes zero k-steps: D = 16 / 17 on a 32-column
     // row packs into exactly 4 steps -- that shape trains on the natural layout)
     pack[i] = (ones[i] && fp.pack[i] % 4 != 0) ? fp.pack[i] : 0;

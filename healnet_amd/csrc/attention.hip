@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void attn_core_kernel(AttnCoreArgs a, int ngro
     // through the descriptor.  Behind a branch the request count differs between the two paths into the join, and the
     // compiler then waits vmcnt(0) -- for the prefetch it has just issued -- in front of the tile's first MFMA.
     load_kv(t0 + 16, kn, vn);
-    if (DROP && a.drop_rowsum) {       // shared-context binding under dropout: accumulator column DP-1 = sum_t p'_t, the row sum
+    if (DROP && a.drop_rowsum && !a.ones_in_mem) {   // shared-context binding under dropout: accumulator column DP-1 = sum_t p'_t, the row sum
       if (j == 15) {                    // of the THINNED probabilities (no longer 1), needed by the beta term of the values
 #pragma unroll
         for (int r = 0; r < 4; ++r) vf[DT - 1][r] = 1.0f;
@@ -458,8 +458,8 @@ int launch_attn_core(const AttnCoreArgs &a, hipStream_t s) {
              "attn_core: one sample's K/V rows must span < 2 GiB (N=%d ld=%d)", a.N, a.ldk);
   HN_REQUIRE(a.Ofinal == nullptr || (a.nsplit == 1 && !a.ones_col), HN_E_SHAPE, "attn_core: direct output needs a single split");
   HN_REQUIRE(!a.ones_col || (a.dp <= 32 && a.Kp == a.Vp), HN_E_UNSUPPORTED, "attn_core: ones column needs the shared-context binding");
-  HN_REQUIRE(a.drop.thr == 0 || !a.ones_col || (!a.ones_in_mem && (a.dp == 16 || a.dp == 32)), HN_E_SHAPE,
-             "attn_core: dropout with the ones column needs it injected in registers (the row-sum channel), dp = 16 / 32");
+  HN_REQUIRE(a.drop.thr == 0 || !a.ones_col || a.dp == 16 || a.dp == 32, HN_E_SHAPE,
+             "attn_core: dropout with the ones column (the row-sum channel) runs on dp = 16 / 32");
   if (self_core_lds_eligible(a)) return launch_self_core_lds(a, s);
   const int dt = a.dp / 16;
   int nq = a.nq > 0 ? a.nq : nq_for(dt);
@@ -479,9 +479,17 @@ int launch_attn_core(const AttnCoreArgs &a, hipStream_t s) {
     // dropout on the shared-context binding with the score-bound softmax: the reference of a row is fixed (no running maximum, no
     // rescale), the ones column -- injected in registers -- is the row-sum channel, the denominator is summed on the VALU
     HN_REQUIRE((dt == 1 && nq == 4) || (dt == 2 && nq == 2), HN_E_UNSUPPORTED, "attn_core: dropout variant dp=%d nq=%d", a.dp, nq);
-    HN_REQUIRE(ks == 4 * dt, HN_E_SHAPE, "attn_core: dropout runs on the unpacked context (qk_steps=%d)", ks);
-    if (dt == 1) hipLaunchKernelGGL((attn_core_kernel<1, 4, true, 4, true>), grid, block, 0, s, a, ngroups, gy, wpb);
-    else hipLaunchKernelGGL((attn_core_kernel<2, 2, true, 8, true>), grid, block, 0, s, a, ngroups, gy, wpb);
+    // (round 4: the packed context -- ks < 4 dt k-steps, the ones column in memory -- under dropout as well; the thinned row sum
+    // rides in the ones column's accumulator either way)
+#define HN_CORE_DROP_ONES(DT_, NQ_, KS_) hipLaunchKernelGGL((attn_core_kernel<DT_, NQ_, true, KS_, true>), grid, block, 0, s, a, ngroups, gy, wpb)
+    if (dt == 1) {
+      if (ks == 1) HN_CORE_DROP_ONES(1, 4, 1); else if (ks == 2) HN_CORE_DROP_ONES(1, 4, 2); else if (ks == 3) HN_CORE_DROP_ONES(1, 4, 3);
+      else HN_CORE_DROP_ONES(1, 4, 4);
+    } else {
+      if (ks == 5) HN_CORE_DROP_ONES(2, 2, 5); else if (ks == 6) HN_CORE_DROP_ONES(2, 2, 6); else if (ks == 7) HN_CORE_DROP_ONES(2, 2, 7);
+      else { HN_REQUIRE(ks == 8, HN_E_SHAPE, "attn_core: dropout variant qk_steps=%d dp=32", ks); HN_CORE_DROP_ONES(2, 2, 8); }
+    }
+#undef HN_CORE_DROP_ONES
   } else if (dt == 1 && a.ones_col && (nq == 2 || nq == 1) && ks != 4) {
     HN_REQUIRE(ks >= 1 && ks <= 3, HN_E_SHAPE, "attn_core: qk_steps=%d", ks);
     if (nq == 2) { if (ks == 1) HN_CORE(1, 2, true, 1); else if (ks == 2) HN_CORE(1, 2, true, 2); else HN_CORE(1, 2, true, 3); }
@@ -874,7 +882,7 @@ __global__ __launch_bounds__(256) void merge_vproj_kernel(const float *__restric
       if (c < D - 1) v = oh[qq * (dp + 1) + packed_slot(c, pack_ks)];
       else if (c == D - 1) {
         for (int k = 0; k < D - 1; ++k) v -= oh[qq * (dp + 1) + packed_slot(k, pack_ks)];
-      }
+      } else if (srow && c == dp - 1) v = oh[qq * (dp + 1) + dp - 1];      // the thinned row sum keeps its column
       oprime_save[((long)bi * L + q) * (h * dp) + hi * dp + c] = v;
     }
   }
@@ -891,7 +899,6 @@ int launch_merge_vproj(const float *Opart, const float *Mpart, const float *Lpar
                        int Lp, int dp, int D, const float *gamma, const float *beta, const float *w_v, int dh,
                        float *O, int ldo, float *stats, float *oprime_save, hipStream_t s, int pack_ks, int srow) {
   size_t lds = ((size_t)MERGE_ROWS * (dp + 1) + (size_t)dh * (dp + 1) + (size_t)dh * D + 2 * (size_t)D) * sizeof(float);
-  HN_REQUIRE(!(pack_ks && srow), HN_E_SHAPE, "merge_vproj: the row-sum channel needs the natural channel layout");
   HN_REQUIRE(dp <= 32, HN_E_UNSUPPORTED, "merge_vproj: dp=%d", dp);
   const int R = merge_rows_per_block(b, h, L);
   hipLaunchKernelGGL(merge_vproj_kernel, dim3(b * h, ceil_div(L, R)), dim3(256), lds, s, Opart, Mpart, Lpart,

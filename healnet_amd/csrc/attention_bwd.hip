@@ -67,6 +67,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a, int ngr
   for (int i = 0; i < NQ; ++i) {
     negm[i] = (f32x4){-mrow[i], -mrow[i], -mrow[i], -mrow[i]};
     negd[i] = (f32x4){-drow[i], -drow[i], -drow[i], -drow[i]};
+    if (DROP && KS > 0) {
+      // packed context under dropout: the dP chain skips the k-step of the ones column, so the row-sum channel's gradient
+      // ds = dO'[row j][DP - 1] (held by lane (3, j)) starts the chain instead -- dP = dO' V^T + ds, thinned afterwards
+      const float ds = a.drop_rowsum ? __shfl(gf[i][DT - 1].w, 48 + j) : 0.0f;
+      negd[i] = (f32x4){ds, ds, ds, ds};
+    }
 #pragma unroll
     for (int d = 0; d < DT; ++d) dQ[i][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
@@ -119,11 +125,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a, int ngr
     // subtracted, so that variant starts dP from 0.)
     f32x4 S[NQ], dP[NQ];
 #pragma unroll
-    for (int i = 0; i < NQ; ++i) { S[i] = negm[i]; dP[i] = DROP ? (f32x4){0.f, 0.f, 0.f, 0.f} : negd[i]; }
+    for (int i = 0; i < NQ; ++i) { S[i] = negm[i]; dP[i] = (DROP && KS == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : negd[i]; }
 #pragma unroll
     for (int s = 0; s < DT; ++s) {
       float4 vv = SHARED_KV ? kf[s] : vf[s];
-      if (DROP && SHARED_KV && s == DT - 1 && a.drop_rowsum && g == 3) vv.w = 1.0f;      // the values' ones column dp-1 (row-sum channel)
+      if (DROP && KS == 0 && SHARED_KV && s == DT - 1 && a.drop_rowsum && g == 3) vv.w = 1.0f;      // the values' ones column dp-1 (row-sum channel)
       const int steps = s == DT - 1 ? LAST : 4;
 #pragma unroll
       for (int i = 0; i < NQ; ++i) {
@@ -250,9 +256,23 @@ int launch_attn_bwd_dq(const AttnBwdArgs &a, hipStream_t s) {
   else if (drop) hipLaunchKernelGGL((attn_bwd_dq_kernel<DT_, NQ_, false, true>), grid, block, 0, s, a, ngroups, gy, wpb);        \
   else hipLaunchKernelGGL((attn_bwd_dq_kernel<DT_, NQ_, false, false>), grid, block, 0, s, a, ngroups, gy, wpb);
 #define HN_DQ_PACKED(DT_, NQ_, KS_) hipLaunchKernelGGL((attn_bwd_dq_kernel<DT_, NQ_, true, false, KS_>), grid, block, 0, s, a, ngroups, gy, wpb)
-  if (a.qk_steps > 0) {     // packed shared context (rank-D binding without dropout)
-    HN_REQUIRE(shared && !drop && (dt == 1 || dt == 2) && a.qk_steps > 4 * (dt - 1) && a.qk_steps < 4 * dt, HN_E_SHAPE,
+  if (a.qk_steps > 0) {     // packed shared context (rank-D binding; round 4: under dropout as well)
+    HN_REQUIRE(shared && (dt == 1 || dt == 2) && a.qk_steps > 4 * (dt - 1) && a.qk_steps < 4 * dt, HN_E_SHAPE,
                "attn_bwd_dq: qk_steps=%d dp=%d", a.qk_steps, a.dp);
+#define HN_DQ_PACKED_DROP(DT_, NQ_, KS_) hipLaunchKernelGGL((attn_bwd_dq_kernel<DT_, NQ_, true, true, KS_>), grid, block, 0, s, a, ngroups, gy, wpb)
+    if (drop) {
+      switch (a.qk_steps) {
+        case 1: HN_DQ_PACKED_DROP(1, 4, 1); break;
+        case 2: HN_DQ_PACKED_DROP(1, 4, 2); break;
+        case 3: HN_DQ_PACKED_DROP(1, 4, 3); break;
+        case 5: HN_DQ_PACKED_DROP(2, 2, 5); break;
+        case 6: HN_DQ_PACKED_DROP(2, 2, 6); break;
+        default: HN_DQ_PACKED_DROP(2, 2, 7); break;
+      }
+      HN_LAUNCH_CHECK("attn_bwd_dq(packed, dropout)");
+      return HN_OK;
+    }
+#undef HN_DQ_PACKED_DROP
     switch (a.qk_steps) {
       case 1: HN_DQ_PACKED(1, 4, 1); break;
       case 2: HN_DQ_PACKED(1, 4, 2); break;
@@ -705,7 +725,7 @@ int launch_head_affine(const float *src, int lds, int spitch, const float *mul, 
 //     du_c = dup_{slot(c)}  (c < D-1),   du_{D-1} = - sum_c dup_{slot(c)}   -> unfold (mode 1): packed -> natural
 // One thread per (row, head), in place, (rows, h, dp) head-pitched.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pack_fold_kernel(float *__restrict__ x, int ld, int h, int D, int dp, int ks, int mode, long total) {
+__global__ __launch_bounds__(256) void pack_fold_kernel(float *__restrict__ x, int ld, int h, int D, int dp, int ks, int mode, long total, int srow) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   float *row = x + (i / h) * ld + (i % h) * dp;
@@ -717,6 +737,7 @@ __global__ __launch_bounds__(256) void pack_fold_kernel(float *__restrict__ x, i
       const int c = packed_chan(sl, ks);
       row[sl] = (c >= 0 && c < D - 1) ? v[c] - last : 0.0f;
     }
+    if (srow) row[dp - 1] = v[dp - 1];      // dropout: the row-sum channel's gradient keeps its column (never a packed slot)
   } else {
     float sum = 0.0f;
     for (int c = 0; c < dp; ++c) {   // channels in order: every kept one is in `sum` when c reaches D - 1
@@ -728,10 +749,10 @@ __global__ __launch_bounds__(256) void pack_fold_kernel(float *__restrict__ x, i
   }
 }
 
-int launch_pack_fold(float *x, int ld, int h, int D, int dp, int ks, int mode, long rows, hipStream_t s) {
+int launch_pack_fold(float *x, int ld, int h, int D, int dp, int ks, int mode, long rows, hipStream_t s, int srow) {
   HN_REQUIRE(dp <= 32 && ks > 0 && D >= 2 && D <= dp - 1, HN_E_SHAPE, "pack_fold: D=%d dp=%d ks=%d", D, dp, ks);
   const long total = rows * h;
-  hipLaunchKernelGGL(pack_fold_kernel, dim3((unsigned)ceil_div_ll(total, 256)), dim3(256), 0, s, x, ld, h, D, dp, ks, mode, total);
+  hipLaunchKernelGGL(pack_fold_kernel, dim3((unsigned)ceil_div_ll(total, 256)), dim3(256), 0, s, x, ld, h, D, dp, ks, mode, total, srow);
   HN_LAUNCH_CHECK("pack_fold");
   return HN_OK;
 }

@@ -598,7 +598,7 @@ struct AttnBwdArgs {
   int drop_rowsum;                               // shared-context binding under dropout: V carries a ones column dp-1
   int qk_steps;                                  // > 0: packed shared context, k-steps of the channel contractions (see attn_core)
 };
-int launch_pack_fold(float *x, int ld, int h, int D, int dp, int ks, int mode, long rows, hipStream_t s);
+int launch_pack_fold(float *x, int ld, int h, int D, int dp, int ks, int mode, long rows, hipStream_t s, int srow = 0);
 int launch_attn_bwd_dq(const AttnBwdArgs &a, hipStream_t s);
 // explicit binding, dp = 64: dQ on a workgroup-shared LDS ring of K / V tiles (attention_lds.hip)
 bool attn_bwd_dq_lds_eligible(const AttnBwdArgs &a);
