@@ -599,6 +599,7 @@ int launch_latent_bchain(const BChainArgs &a, hipStream_t s) {
     const int cus = (dev >= 0 && dev < 64) ? cu_count[dev] : 1;
     if (gtiles * C <= cus) ac.cluster = C;
   }
+  if (ac.cluster > 1) cluster_stream_guard(dev, s);
   const bool ext = a.rows % CR != 0 || (a.dv > 0 && a.dv < CD) || a.ff_drop.thr != 0 || (a.has_p && a.q_cols > 0 && a.q_cols < a.nq) ||
                    (a.has_p && a.kv_cols > 0 && a.kv_cols < a.nkv) || (a.has_out && a.o_cols > 0 && a.o_cols < a.inner_o) ||
                    (ac.cluster > 1 && gtiles != tiles);

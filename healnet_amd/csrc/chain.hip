@@ -59,6 +59,7 @@
 // Shapes: l_d = 128, hidden 512, K a multiple of 128, N a multiple of 128, rows % 16 == 0.
 #include "common.h"
 #include <stdlib.h>
+#include <mutex>
 
 namespace hn {
 
@@ -749,6 +750,7 @@ int launch_latent_chain(const ChainArgs &a, hipStream_t s) {
     const int cus = (dev >= 0 && dev < 64) ? cu_count[dev] : 1, C = gtiles <= 64 ? 4 : 2;
     if (gtiles * C <= 2 * cus && gtiles * C <= CHAIN_XCHG_FLAGS - 1) ac.cluster = C;
   }
+  if (ac.cluster > 1) cluster_stream_guard(dev, s);
   const bool ext = a.rows % CR != 0 || (a.dv > 0 && a.dv < CD) || a.ff_drop.thr != 0 || (a.o_cols > 0 && a.o_cols < a.inner_o) ||
                    (a.q_cols > 0 && a.q_cols < a.nq) || (a.kv_cols > 0 && a.kv_cols < a.nkv) || (ac.cluster > 1 && gtiles != tiles);
   const dim3 grid(ac.cluster > 1 ? gtiles * ac.cluster : tiles);
@@ -756,6 +758,34 @@ int launch_latent_chain(const ChainArgs &a, hipStream_t s) {
   else hipLaunchKernelGGL(latent_chain_kernel<false>, grid, dim3(512), lds_bytes, s, ac);
   HN_LAUNCH_CHECK("latent_chain");
   return HN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// See common.h.  Submission order under the mutex is a total order of the device's cluster launches, and every one of them is
+// ordered behind its predecessor when that went to another stream, so no two cluster kernels of this process ever run at once.
+// A single-stream caller pays one uncontended lock and one capture query per cluster launch.  Streams under graph capture are
+// left alone (an outside event must not enter a capture; a replayed graph is the caller's to order), other processes on the
+// same GPU cannot be seen at all: HN_NO_CHAIN_CLUSTER=1 is the switch for those set-ups.
+// ------------------------------------------------------------------------------------------------
+void cluster_stream_guard(int dev, hipStream_t s) {
+  struct Guard { std::mutex mu; hipEvent_t ev = nullptr; hipStream_t last = nullptr; bool valid = false; };
+  static Guard guards[64];
+  if (dev < 0 || dev >= 64) return;
+  Guard &g = guards[dev];
+  std::lock_guard<std::mutex> lock(g.mu);
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return; }
+  if (st != hipStreamCaptureStatusNone) return;
+  if (g.valid && g.last != s) {
+    hipStreamCaptureStatus lst = hipStreamCaptureStatusNone;
+    bool ok = hipStreamIsCapturing(g.last, &lst) == hipSuccess && lst == hipStreamCaptureStatusNone;      // (a destroyed stream fails here)
+    if (ok && g.ev == nullptr) ok = hipEventCreateWithFlags(&g.ev, hipEventDisableTiming) == hipSuccess;
+    if (ok) ok = hipEventRecord(g.ev, g.last) == hipSuccess;
+    if (ok) ok = hipStreamWaitEvent(s, g.ev, 0) == hipSuccess;
+    if (!ok) (void)hipGetLastError();
+  }
+  g.last = s;
+  g.valid = true;
 }
 
 }  // namespace hn

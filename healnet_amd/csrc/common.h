@@ -535,6 +535,11 @@ int launch_temperature_softmax(const float *x, float *y, long rows, int n, float
 int launch_fill_bytes(uint8_t *dst, uint8_t value, long n, hipStream_t s);
 int launch_dropout_apply(const float *src, const float *add, float *out, long rows, int cols, const DropCfg &d, hipStream_t s);
 int launch_dropout_mask(uint8_t *mask, long rows, int cols, const DropCfg &d, hipStream_t s);
+// Cluster-mode chain launches (chain.hip / bchain.hip) spin on the flags of co-resident workgroups; two of them running at once
+// from DIFFERENT streams of one device can starve each other's members (tools/two_stream.py reproduced it: four
+// streams of b = 16 ran into the spin limit).  Called right before such a launch: orders it behind the previous cluster launch
+// of the device when that went to another stream (one event record + stream wait, only in that case).
+void cluster_stream_guard(int dev, hipStream_t s);
 
 // training-step tail (train.hip)
 int launch_surv_nll(const float *logits, const long long *y, const float *cens, const float *weights, int b, int K, float alpha,
