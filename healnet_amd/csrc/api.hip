@@ -55,6 +55,7 @@ static inline DropCfg drop_of(float p, const hn_rng &r, bool ff) {
 // development switches, read ONCE per process (no getenv on the launch path)
 static bool chain_disabled() { static const bool off = getenv("HN_NO_CHAIN") != nullptr; return off; }
 static bool bchain_disabled() { static const bool off = getenv("HN_NO_BCHAIN") != nullptr; return off; }
+static bool qfold_chain_disabled() { static const bool off = getenv("HN_NO_QFOLD_CHAIN") != nullptr; return off; }
 static bool merge_chain_disabled() { static const bool off = getenv("HN_NO_MERGE_CHAIN") != nullptr; return off; }
 // operands the latent chain reads with 16-byte loads: an unaligned one (a parameter that is a view at an odd float offset of a
 // user-made flat buffer, a tape / trace slot) sends the block down the per-block launches instead of failing the forward
@@ -180,6 +181,9 @@ struct AttnExt {
   // training: the block's projections live in the tape (sized from THIS block's plan) -- produced there by the chain in front
   // (q / kv above point at the same slots) or by the block's own GEMMs -- so that the backward does not recompute them
   float *q_home, *kv_home;
+  // inference, rank-D block: the chain in front has written the FOLDED query and its score bounds (ChainArgs.qf): neither the
+  // query projection nor qfold runs
+  float *qf, *qf_bound; bool qf_done;
 };
 
 static int check_ws(void *ws, size_t ws_bytes, size_t need, const char *who) {
@@ -233,7 +237,16 @@ static int attn_prepare(const hn_attn_params *p, const AttnPlan &pl, const float
   core->nsplit = pl.nsplit; core->chunk = pl.chunk; core->nq = pl.nq;
   core->Opart = pl.opart; core->Mpart = pl.mpart; core->Lpart = pl.lpart;
   int rc;
-  if (pl.rank_d) {
+  if (pl.rank_d && ext && ext->qf_done) {
+    HN_REQUIRE(pl.ones && p->ctx_gamma && use_bound && ext_flag && pack_ks == packed_steps(pl.D, pl.dp) && pl.dp == 16 && pl.Lp == L, HN_E_SHAPE,
+               "attn: folded query from the chain needs the bounded packed core (dp=%d Lp=%d)", pl.dp, pl.Lp);
+    core->bound = ext->qf_bound; core->bound_flag = ext_flag;
+    core->qk_steps = pack_ks;
+    core->Q = ext->qf; core->q_b = (long)p->heads * pl.Lp * pl.dp; core->q_h = (long)pl.Lp * pl.dp; core->ldq = pl.dp;
+    core->Kp = ctx; core->k_b = (long)pl.N * ld_ctx; core->k_h = 0; core->ldk = ld_ctx;
+    core->Vp = ctx; core->v_b = core->k_b; core->v_h = 0; core->ldv = ld_ctx;
+    core->ones_col = 1;
+  } else if (pl.rank_d) {
     gq.C = qbuf; gq.ldc = pl.inner;
     if (!q_done && (rc = launch_gemm(gq, s)) != HN_OK) return rc;
     // score bounds need |z|^2 <= D, i.e. a context that went through the LayerNorm of PreNorm.norm_context (ctx_gamma set)
@@ -1005,6 +1018,8 @@ struct FusionPlan {
   int ldz[16], N[16], D[16];
   bool ones[16];   // z carries the synthetic ones column (rank-D pitch with a free last column)
   float *wvf[16];  // inference: folded value projections of all layers (depth, inner, 16) for the chain's merge head, or NULL
+  float *wqf[16];  // inference: folded query projections of all layers (depth, 128, l_d) for the chain's Q stage (ChainArgs.qf), or NULL
+  float *cbound;   // score bounds written by that stage, (b, heads, l_c)
   int pack[16];    // ... and uses the packed channel layout with this many QK^T k-steps (0 = natural)
   bool bf16[16];   // core_precision = bf16: z holds the bf16 images (zb, then zT) instead of the fp32 rows
   uint16_t *z16[16];   // core_precision = bf16, explicit binding of a large patch bag: bf16 image of the rows of z (pitch gemm_bf16_pitch(D)) for the K/V projections, or NULL
@@ -1073,6 +1088,7 @@ static int plan_fusion(const hn_model *m, const hn_modality_input *in, int b, vo
     // the chain behind a shared-context block can merge its split partials itself when the folded value projections of the
     // modality's layers are staged up front (one launch per forward): dp = 16, equal heads / dim_head over the layers
     fp->wvf[i] = nullptr;
+    fp->wqf[i] = nullptr;
     if (inference && fp->ones[i] && fp->ldz[i] == 16 && m->depth <= HN_SKINNY_MAXZ) {
       const hn_attn_params &a0 = m->cross_attn[i];
       bool ok = a0.heads <= 8 && (a0.dim_head == 16 || a0.dim_head == 32 || a0.dim_head == 64) && a0.ctx_gamma != nullptr;
@@ -1081,6 +1097,9 @@ static int plan_fusion(const hn_model *m, const hn_modality_input *in, int b, vo
         ok = al.heads == a0.heads && al.dim_head == a0.dim_head && al.ctx_gamma != nullptr;
       }
       if (ok) fp->wvf[i] = ar.take<float>((size_t)m->depth * a0.heads * a0.dim_head * 16);
+      // ... and the query side: eight heads of 16 packed slots fill the chain's 128-column Q stage exactly
+      if (ok && a0.heads * 16 == 128 && m->l_d == 128 && m->l_c % 16 == 0 && a0.dim_head <= 128 && a0.query_dim == m->l_d && fp->pack[i] > 0)
+        fp->wqf[i] = ar.take<float>((size_t)m->depth * 128 * m->l_d);
     }
     // One workspace size serves the inference forward (which may use the bf16 core) and the training forward / backward
     // (always fp32) of the same model: size for the larger of the two layouts.
@@ -1091,7 +1110,7 @@ static int plan_fusion(const hn_model *m, const hn_modality_input *in, int b, vo
                "fusion: modality %d dtype=%d", i, in[i].dtype);
     fp->bf16[i] = want_bf16 && inference;
     fp->Np[i] = (int)((n + 31) / 32 * 32);
-    if (fp->bf16[i]) { fp->pack[i] = 0; fp->wvf[i] = nullptr; }
+    if (fp->bf16[i]) { fp->pack[i] = 0; fp->wvf[i] = nullptr; fp->wqf[i] = nullptr; }
     size_t zbytes = (size_t)b * n * fp->ldz[i] * sizeof(float);
     if (want_bf16) {
       const size_t zb16 = (size_t)b * fp->Np[i] * (bf16_row_slots(fp->ldz[i], ns) + ns * fp->ldz[i]) * sizeof(uint16_t);
@@ -1165,7 +1184,9 @@ static int plan_fusion(const hn_model *m, const hn_modality_input *in, int b, vo
     // that is not a multiple of 16 needs the staged route (internal, row-padded buffers).
     fp->chain = m->l_d == 128 && (m->l_c % 16 == 0 || m->l_d_valid > 0);
     fp->cq = fp->ckv = nullptr;
+    fp->cbound = nullptr;
     if (fp->chain) {
+      fp->cbound = ar.take<float>((size_t)b * 8 * m->l_c);
       fp->cq = ar.take<float>(rows16((size_t)b * m->l_c) * max_inner);
       fp->ckv = ar.take<float>(rows16((size_t)b * m->l_c) * 2 * (max_inner_self > 0 ? max_inner_self : 1));
     }
@@ -1707,9 +1728,9 @@ static int impl_fusion_forward(const hn_model *m, const hn_modality_input *in, i
 
   // folded value projections for the chains that merge the split partials of a shared-context block themselves (one launch per
   // modality and forward; only when the chain is the route)
-  bool vmerge[16];
+  bool vmerge[16], qfolded[16];
   for (int i = 0; i < M; ++i) {
-    vmerge[i] = false;
+    vmerge[i] = false; qfolded[i] = false;
     if (!in[i].data || !fp.wvf[i] || !fp.chain || merge_chain_disabled() || chain_disabled()) continue;
     VfoldMulti vf;
     memset(&vf, 0, sizeof(vf));
@@ -1720,6 +1741,17 @@ static int impl_fusion_forward(const hn_model *m, const hn_modality_input *in, i
       const hn_attn_params &al = m->cross_attn[layer * M + i];
       HN_REQUIRE(al.w_kv, HN_E_NULL, "attn: weight pointer is NULL");
       vf.w_v[layer] = al.w_kv + (long)al.heads * al.dim_head * fp.D[i]; vf.gamma[layer] = al.ctx_gamma; vf.beta[layer] = al.ctx_beta;
+    }
+    qfolded[i] = fp.wqf[i] != nullptr && fp.cbound != nullptr && !qfold_chain_disabled();
+    if (qfolded[i]) {
+      AttnPlan p0;
+      if ((rc = plan_attn(&a0, true, fp.ldz[i], b, L, fp.N[i], fp.D[i], nullptr, 0, &p0)) != HN_OK) return rc;
+      vf.cscale = p0.cscale; vf.l_d = d; vf.qout = fp.wqf[i]; vf.qout_stride = (long)128 * d;
+      for (int layer = 0; layer < m->depth; ++layer) {
+        const hn_attn_params &al = m->cross_attn[layer * M + i];
+        HN_REQUIRE(al.w_q, HN_E_NULL, "attn: weight pointer is NULL");
+        vf.w_k[layer] = al.w_kv; vf.w_q[layer] = al.w_q;
+      }
     }
     if ((rc = launch_vfold(vf, s)) != HN_OK) return rc;
     vmerge[i] = true;
@@ -1770,11 +1802,11 @@ static int impl_fusion_forward(const hn_model *m, const hn_modality_input *in, i
   // one-token cross block whose output vectors were computed ahead of the layer loop
   auto is_tab = [&](const Step &st) { return st.kind == STEP_CROSS_ATTN && tab_ready[st.m]; };
 
-  bool q_done = false, kv_done = false;      // projections of the attention block at `k` already produced by the chain in front of it
+  bool q_done = false, kv_done = false, qf_done = false;      // projections of the attention block at `k` already produced by the chain in front of it
   const bool staged = m->l_d_valid > 0;      // staged model: every LayerNorm of the latent side runs inside a chain (valid width)
   // projections of the attention block at step kn (if it is one that needs them) as the last stages of chain `ca`
   auto add_next_proj = [&](ChainArgs &ca, int kn) -> int {
-    q_done = kv_done = false;
+    q_done = kv_done = qf_done = false;
     if (!(kn < nsteps && is_attn(steps[kn]) && !is_tab(steps[kn]))) return HN_OK;
     const Step &sn = steps[kn];
     const bool self = sn.kind == STEP_SELF_ATTN;
@@ -1790,6 +1822,14 @@ static int impl_fusion_forward(const hn_model *m, const hn_modality_input *in, i
       ca.alpha_q = pn.rank_d ? 1.0f : pn.cscale;       // the rank-D binding scales in its query fold
       q_done = true;
       if (self) { ca.nkv = up128(2 * pn.inner); ca.kv_cols = 2 * pn.inner; ca.wkv = an->w_kv; ca.KV = fp.ckv; ca.ldkv = 2 * pn.inner; kv_done = true; }
+      // shared-context block whose query fold was staged (vfold launch): the Q stage projects 128 instead of `inner` columns and
+      // leaves the folded, packed query with its score bounds -- qfold's launch and the wider projection disappear
+      if (!self && qfolded[sn.m] && pn.rank_d && pn.ones && pn.dp == 16 && pn.Lp == L && an->ctx_gamma && !staged && mask == nullptr &&
+          !fp.bf16[sn.m] && fp.ones[sn.m] && fp.pack[sn.m] == packed_steps(pn.D, pn.dp)) {
+        ca.nq = 128; ca.q_cols = 128; ca.wq = fp.wqf[sn.m] + (size_t)sn.layer * 128 * d; ca.Q = nullptr; ca.ldq = 0; ca.alpha_q = 1.0f;
+        ca.qf = fp.cq; ca.qf_bound = fp.cbound; ca.qf_flag = fp.flags + sn.layer * M + sn.m; ca.qf_heads = an->heads; ca.qf_D = pn.D;
+        qf_done = true;
+      }
     }
     return HN_OK;
   };
@@ -1842,10 +1882,11 @@ static int impl_fusion_forward(const hn_model *m, const hn_modality_input *in, i
       if (is_tab(st)) rc = launch_add_row_broadcast(fp.taby[st.m] + (size_t)st.layer * b * ap->query_dim, cur, dst, b, L, ap->query_dim, s);
       else {
         AttnExt ext = {fp.cq, fp.ckv, q_done, kv_done, false, nullptr, 0, false, false, nullptr, nullptr, nullptr, 0, 0, 0};
+        ext.qf = fp.cq; ext.qf_bound = fp.cbound; ext.qf_done = qf_done;
         rc = run_attn(st, cur, dst, (q_done || kv_done) ? &ext : nullptr);
       }
       if (rc != HN_OK) return rc;
-      cur = dst; ++k; q_done = kv_done = false;
+      cur = dst; ++k; q_done = kv_done = qf_done = false;
       continue;
     }
     ChainArgs ca;
@@ -1855,6 +1896,7 @@ static int impl_fusion_forward(const hn_model *m, const hn_modality_input *in, i
       ca.head = 2; ca.y = fp.taby[st.m] + (size_t)st.layer * b * ap->query_dim;
     } else {
       AttnExt ext = {fp.cq, fp.ckv, q_done, kv_done, true, nullptr, 0, false, false, nullptr, nullptr, nullptr, 0, 0, 0};
+      ext.qf = fp.cq; ext.qf_bound = fp.cbound; ext.qf_done = qf_done;
       const bool split = st.kind == STEP_CROSS_ATTN && is_split(st.m);
       ext.allow_defer_merge = st.kind == STEP_CROSS_ATTN && vmerge[st.m] && inner % 128 == 0 && !split;
       const long n_o = (long)b * L * inner, n_s = (long)b * ap->heads * L * 2;

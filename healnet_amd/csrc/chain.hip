@@ -615,10 +615,31 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
       const int j = isq ? pj : pj - nq_ch;
       f32x4 c0 = zero, c1 = zero;
       run_chunk_k128(Ahat, c0, c1);
+      const float v[4] = {c0.x + c1.x, c0.y + c1.y, c0.z + c1.z, c0.w + c1.w};
+      if (isq && args.qf != nullptr) {
+        // folded query of a rank-D block: this wave's 16 columns are head `wave`'s packed slots; rows of 64 contiguous bytes in the
+        // head-major image, and the row's score bound from the squares summed over the 16 lanes that share it
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lds[stg + (4 * fg + r) * 16 + fi] = v[r];
+        const int srow = lane >> 2, c4 = lane & 3;
+        const int grow = m0 + srow, bi = grow / args.L, q = grow - bi * args.L;
+        gst4_nt((gf32 *)args.qf + (((long)bi * args.qf_heads + wave) * args.L + q) * 16 + 4 * c4, lld4(lds, stg + srow * 16 + 4 * c4));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float ss = v[r] * v[r];
+          ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4); ss += __shfl_xor(ss, 8);
+          if (fi == 0) {
+            const int gr = m0 + 4 * fg + r, b2 = gr / args.L, q2 = gr - b2 * args.L;
+            const float bq = sqrtf(ss * (float)args.qf_D) * 1.00002f + 1e-6f;
+            gst1((gf32 *)args.qf_bound + ((long)b2 * args.qf_heads + wave) * args.L + q2, bq);
+            if (bq > 60.0f) atomicOr(args.qf_flag, 1);
+          }
+        }
+        continue;
+      }
       gf32 *C = isq ? a_Q : a_KV;
       const long ldc = isq ? a_ldq : a_ldkv;
       const float al = isq ? a_alpha_q : 1.0f;
-      const float v[4] = {c0.x + c1.x, c0.y + c1.y, c0.z + c1.z, c0.w + c1.w};
       // through LDS to ONE 16-byte store per lane (16 rows x 64 contiguous bytes per wave) instead of four 4-byte ones: a store
       // counts against vmcnt like a load, so every outstanding store shortens the weight ring's lead
 #pragma unroll
@@ -677,10 +698,41 @@ __global__ __launch_bounds__(256) void vfold_kernel(VfoldMulti v) {
     }
     out[(long)(hi * v.dh + e) * dp + d] = w;
   }
+  if (v.qout == nullptr) return;
+  // query side: the head's folded key weights (what qfold_mfma_kernel stages per workgroup: scale, gamma, packed channel order),
+  // then W_f[hi * 16 + d][c] = sum_e wk[e][d] * W_q[hi * dh + e][c]
+  __shared__ float wk[128 * 16];
+  const float *w_k = v.w_k[z], *w_q = v.w_q[z];
+  for (int idx = threadIdx.x; idx < v.dh * dp; idx += blockDim.x) {
+    const int e = idx / dp, d = idx % dp;
+    const float *wr = w_k + (long)(hi * v.dh + e) * v.D;
+    float w = 0.0f;
+    if (v.pack_ks == 0) {
+      if (d < v.D) w = wr[d] * (gamma ? gamma[d] : 1.0f);
+    } else {
+      const int c = packed_chan(d, v.pack_ks);
+      if (c >= 0 && c < v.D - 1) w = wr[c] * (gamma ? gamma[c] : 1.0f) - wr[v.D - 1] * (gamma ? gamma[v.D - 1] : 1.0f);
+    }
+    wk[idx] = w * v.cscale;
+  }
+  __syncthreads();
+  float *qo = v.qout + (long)z * v.qout_stride + (long)hi * dp * v.l_d;
+  for (int idx = threadIdx.x; idx < 2 * v.l_d; idx += blockDim.x) {      // thread: one input column c, eight of the 16 slots
+    const int c = idx % v.l_d, d0 = (idx / v.l_d) * 8;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int e = 0; e < v.dh; ++e) {
+      const float wq = w_q[(long)(hi * v.dh + e) * v.l_d + c];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] = fmaf(wk[e * dp + d0 + k], wq, acc[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) qo[(long)(d0 + k) * v.l_d + c] = acc[k];
+  }
 }
 
 int launch_vfold(const VfoldMulti &v, hipStream_t s) {
   HN_REQUIRE(v.n >= 1 && v.n <= 16 && v.out && v.D >= 1 && v.D <= 15 && v.heads >= 1, HN_E_SHAPE, "vfold: n=%d D=%d heads=%d", v.n, v.D, v.heads);
+  HN_REQUIRE(v.qout == nullptr || (v.dh <= 128 && v.l_d >= 1), HN_E_SHAPE, "vfold: query fold dh=%d l_d=%d", v.dh, v.l_d);
   hipLaunchKernelGGL(vfold_kernel, dim3(v.heads, v.n), dim3(256), 0, s, v);
   HN_LAUNCH_CHECK("vfold");
   return HN_OK;
@@ -714,7 +766,10 @@ int launch_latent_chain(const ChainArgs &a, hipStream_t s) {
     HN_REQUIRE(al16(a.w1) && al16(a.w2) && (!a.f_nw || (al16(a.f_nw) && al16(a.f_nb))), HN_E_SHAPE, "latent_chain: unaligned operand");
   }
   HN_REQUIRE(a.nq >= 0 && a.nkv >= 0 && a.nq % WN == 0 && a.nkv % WN == 0, HN_E_SHAPE, "latent_chain: nq=%d nkv=%d", a.nq, a.nkv);
-  HN_REQUIRE(a.nq == 0 || (a.wq && a.Q && al16(a.wq)), HN_E_NULL, "latent_chain: Q projection operand is NULL");
+  HN_REQUIRE(a.nq == 0 || (a.wq && (a.Q || a.qf) && al16(a.wq)), HN_E_NULL, "latent_chain: Q projection operand is NULL");
+  HN_REQUIRE(a.qf == nullptr || (a.nq == WN && a.qf_heads * 16 == WN && a.qf_bound && a.qf_flag && a.qf_D >= 1 && a.L % CR == 0 &&
+                                 a.rows % a.L == 0 && al16(a.qf) && (a.q_cols == 0 || a.q_cols == a.nq)),
+             HN_E_SHAPE, "latent_chain: folded query stage nq=%d heads=%d L=%d", a.nq, a.qf_heads, a.L);
   HN_REQUIRE(a.nkv == 0 || (a.wkv && a.KV && al16(a.wkv)), HN_E_NULL, "latent_chain: KV projection operand is NULL");
   HN_REQUIRE(al16(a.x_in) && (!a.x_out || al16(a.x_out)) && (!a.x_mid || al16(a.x_mid)) && (!a.p_nw || (al16(a.p_nw) && al16(a.p_nb))), HN_E_SHAPE,
              "latent_chain: unaligned operand");

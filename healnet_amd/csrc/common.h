@@ -368,6 +368,12 @@ struct ChainArgs {
   const float *p_nw, *p_nb;             // that block's LayerNorm on x (NULL: none)
   const float *wq; float *Q; int ldq; float alpha_q;
   const float *wkv; float *KV; int ldkv;
+  // Folded query of a shared-context (rank-D) block (inference; qfold_stage in vfold_kernel): with qf set, wq is the staged
+  // (128, 128) product of W_q with the block's folded key weights (scale, gamma and the packed channel order included), nq = 128,
+  // and the Q stage leaves what qfold_mfma_kernel would have produced from Q -- wave w = head w, 16 packed columns each:
+  // qf (b, qf_heads = 8, Lp = L, 16) head-major, the Cauchy-Schwarz score bound of every row (sqrt(|qf row|^2 * qf_D), attention.hip)
+  // and the fallback flag for bounds beyond the fp32-safe range
+  float *qf, *qf_bound; int *qf_flag; int qf_heads, qf_D;
   // cluster mode (small batches; inference forward): exchange buffer (rows / 16 * 4 tiles of 16 x 128 floats), one flag per (tile,
   // member) + one error marker, zeroed at the start of the forward, and this chain's 1-based sequence number within the forward
   float *xchg; int *xflags; int seq;
@@ -450,6 +456,11 @@ struct VfoldMulti {                    // one entry per layer of a modality (<= 
   const float *w_v[16], *gamma[16], *beta[16];
   float *out; long out_stride;         // entry z writes out + z * out_stride, (heads * dh, 16)
   int D, heads, dh, pack_ks;
+  // query side (qout != NULL): W_f = (folded key weights of the layer)^T W_q, (heads * 16, l_d) per layer -- the latent chain in
+  // front of the block then projects LN(x) straight to the folded query (ChainArgs.qf)
+  const float *w_k[16], *w_q[16];
+  float cscale; int l_d;
+  float *qout; long qout_stride;
 };
 int launch_vfold(const VfoldMulti &v, hipStream_t s);
 

@@ -259,3 +259,54 @@ def test_cluster_chain_equals_one_workgroup_per_tile():
 def textwrap_dedent(s):
     import textwrap
     return textwrap.dedent(s)
+
+
+def test_query_fold_in_the_chain_vs_qfold_kernel_and_oracle():
+    """Default widths (8 heads of 16 packed slots = the chain's 128-column Q stage): the chain in front of an image block projects
+    LN(x) with the staged product W_q . folded W_k (vfold launch) and leaves the folded query + its score bounds itself
+    (ChainArgs.qf); HN_NO_QFOLD_CHAIN=1 (subprocess) keeps the 512-column projection + qfold_mfma_kernel.  Both against the
+    oracle, against each other to fp32 reassociation noise, at a cluster-mode batch and at a plain one; attention weights (which
+    re-run the block from the trace on the un-folded path) must still match the oracle."""
+    script = (
+        "import sys, torch\n"
+        "sys.path.insert(0, {root!r})\n"
+        "import healnet_amd as hn\n"
+        "from oracle import healnet_cpu as O\n"
+        "kw = dict(n_modalities=2, channel_dims=[2000, 3], num_spatial_axes=[1, 2], out_dims=4, depth=2)\n"
+        "torch.manual_seed(7)\n"
+        "m = hn.HealNet(**kw).eval().to('cuda:0')\n"
+        "with torch.no_grad():\n"
+        "    for p in m.parameters():\n"
+        "        if p.dim() == 1: p.add_(0.1 * torch.randn_like(p))\n"
+        "outs = []\n"
+        "for b in (3, 20):\n"
+        "    g = torch.Generator().manual_seed(8 + b)\n"
+        "    ins = [torch.rand(b, 1, 2000, generator=g), torch.rand(b, 44, 52, 3, generator=g)]\n"
+        "    sd = {{k: v.detach().cpu() for k, v in m.state_dict().items()}}\n"
+        "    with torch.no_grad():\n"
+        "        got = m([t.to('cuda:0') for t in ins]).cpu()\n"
+        "        probs = m.get_attention_weights()[1].float().sum(-1).cpu()\n"
+        "        want = O.fusion_forward(sd, O.FusionConfig(**kw), [t.clone() for t in ins[:1]] + [ins[1].clone()]) if b == 3 else None\n"
+        "    outs.append((got, want, probs))\n"
+        "torch.save(outs, {dst!r})\n"
+    )
+    import tempfile
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        for tag, env in (("fold", {}), ("plain", {"HN_NO_QFOLD_CHAIN": "1"})):
+            dst = os.path.join(td, tag + ".pt")
+            e = dict(os.environ, **env)
+            if not env:
+                e.pop("HN_NO_QFOLD_CHAIN", None)
+            r = subprocess.run([sys.executable, "-c", script.format(root=ROOT, dst=dst)], cwd=ROOT, env=e, capture_output=True, text=True,
+                               timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            res[tag] = torch.load(dst)
+    for (gf, wf, pf), (gp, wp, pp) in zip(res["fold"], res["plain"]):
+        assert torch.isfinite(gf).all()
+        assert_close(gf, gp, rel=2e-5, floor=2e-6, what="query fold in the chain vs qfold kernel")
+        if wf is not None:
+            assert_close(gf, wf, rel=1e-3, floor=0.0, abs_floor=1e-5, what="query fold in the chain vs oracle")
+            assert_close(gp, wp, rel=1e-3, floor=0.0, abs_floor=1e-5, what="qfold kernel vs oracle")
+        assert_close(pf, torch.ones_like(pf), rel=1e-4, floor=0.0, abs_floor=1e-4, what="image block probabilities")
+    assert any(not torch.equal(a[0], b_[0]) for a, b_ in zip(res["fold"], res["plain"])), "HN_NO_QFOLD_CHAIN did not change the route?"
