@@ -1681,6 +1681,8 @@ static int impl_fusion_forward(const hn_model *m, const hn_modality_input *in, i
   if (prof) prof->n_recorded = 0;
 
   // K1 once per forward: the normalised context of every present modality (layer independent)
+  // (measured and dropped, round 4: the long modalities' encode on a side stream beside the one-token prelude -- the two
+  // HBM-bound kernels slow each other down (skinny GEMMs 10 -> 18 us) and the join costs what is left: -1 % at cfg2 b = 32)
   for (int i = 0; i < M; ++i) {
     if (!in[i].data) continue;
     HN_REQUIRE(!is_split(i) || (!fp.bf16[i] && fp.N[i] >= 2), HN_E_UNSUPPORTED,

@@ -676,6 +676,45 @@ __global__ __launch_bounds__(256) void vfold_kernel(VfoldMulti v) {
   const int hi = blockIdx.x, z = blockIdx.y, dp = 16;
   const float *w_v = v.w_v[z], *gamma = v.gamma[z], *beta = v.beta[z];
   float *out = v.out + (long)z * v.out_stride;
+  if (blockIdx.z > 0) {
+    // query side (grid.z = 1 + slices of 32 input columns): the head's folded key weights (what qfold_mfma_kernel stages per
+    // workgroup: scale, gamma, packed channel order), then W_f[hi * 16 + d][c] = sum_e wk[e][d] * W_q[hi * dh + e][c]
+    __shared__ float wk[128 * 16];
+    const float *w_k = v.w_k[z], *w_q = v.w_q[z];
+    for (int idx = threadIdx.x; idx < v.dh * dp; idx += blockDim.x) {
+      const int e = idx / dp, d = idx % dp;
+      const float *wr = w_k + (long)(hi * v.dh + e) * v.D;
+      float w = 0.0f;
+      if (v.pack_ks == 0) {
+        if (d < v.D) w = wr[d] * (gamma ? gamma[d] : 1.0f);
+      } else {
+        const int c = packed_chan(d, v.pack_ks);
+        if (c >= 0 && c < v.D - 1) w = wr[c] * (gamma ? gamma[c] : 1.0f) - wr[v.D - 1] * (gamma ? gamma[v.D - 1] : 1.0f);
+      }
+      wk[idx] = w * v.cscale;
+    }
+    __syncthreads();
+    // thread: input column c of this block's slice, two of the 16 slots; the W_q column is read 16 rows at a time
+    const int c = (blockIdx.z - 1) * 32 + (threadIdx.x & 31), d0 = (threadIdx.x >> 5) * 2;
+    if (c >= v.l_d) return;
+    const float *wq = w_q + (long)hi * v.dh * v.l_d + c;
+    float a0 = 0.0f, a1 = 0.0f;
+    for (int e0 = 0; e0 < v.dh; e0 += 16) {
+      float x[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) x[k] = e0 + k < v.dh ? wq[(long)(e0 + k) * v.l_d] : 0.0f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int e = e0 + k < v.dh ? e0 + k : 0;
+        a0 = fmaf(wk[e * dp + d0], x[k], a0);
+        a1 = fmaf(wk[e * dp + d0 + 1], x[k], a1);
+      }
+    }
+    float *qo = v.qout + (long)z * v.qout_stride + (long)hi * dp * v.l_d;
+    qo[(long)d0 * v.l_d + c] = a0;
+    qo[(long)(d0 + 1) * v.l_d + c] = a1;
+    return;
+  }
   for (int idx = threadIdx.x; idx < v.dh * dp; idx += blockDim.x) {
     const int e = idx / dp, d = idx % dp;
     const float *wr = w_v + (long)(hi * v.dh + e) * v.D;
@@ -698,42 +737,12 @@ __global__ __launch_bounds__(256) void vfold_kernel(VfoldMulti v) {
     }
     out[(long)(hi * v.dh + e) * dp + d] = w;
   }
-  if (v.qout == nullptr) return;
-  // query side: the head's folded key weights (what qfold_mfma_kernel stages per workgroup: scale, gamma, packed channel order),
-  // then W_f[hi * 16 + d][c] = sum_e wk[e][d] * W_q[hi * dh + e][c]
-  __shared__ float wk[128 * 16];
-  const float *w_k = v.w_k[z], *w_q = v.w_q[z];
-  for (int idx = threadIdx.x; idx < v.dh * dp; idx += blockDim.x) {
-    const int e = idx / dp, d = idx % dp;
-    const float *wr = w_k + (long)(hi * v.dh + e) * v.D;
-    float w = 0.0f;
-    if (v.pack_ks == 0) {
-      if (d < v.D) w = wr[d] * (gamma ? gamma[d] : 1.0f);
-    } else {
-      const int c = packed_chan(d, v.pack_ks);
-      if (c >= 0 && c < v.D - 1) w = wr[c] * (gamma ? gamma[c] : 1.0f) - wr[v.D - 1] * (gamma ? gamma[v.D - 1] : 1.0f);
-    }
-    wk[idx] = w * v.cscale;
-  }
-  __syncthreads();
-  float *qo = v.qout + (long)z * v.qout_stride + (long)hi * dp * v.l_d;
-  for (int idx = threadIdx.x; idx < 2 * v.l_d; idx += blockDim.x) {      // thread: one input column c, eight of the 16 slots
-    const int c = idx % v.l_d, d0 = (idx / v.l_d) * 8;
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int e = 0; e < v.dh; ++e) {
-      const float wq = w_q[(long)(hi * v.dh + e) * v.l_d + c];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) acc[k] = fmaf(wk[e * dp + d0 + k], wq, acc[k]);
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) qo[(long)(d0 + k) * v.l_d + c] = acc[k];
-  }
 }
 
 int launch_vfold(const VfoldMulti &v, hipStream_t s) {
   HN_REQUIRE(v.n >= 1 && v.n <= 16 && v.out && v.D >= 1 && v.D <= 15 && v.heads >= 1, HN_E_SHAPE, "vfold: n=%d D=%d heads=%d", v.n, v.D, v.heads);
   HN_REQUIRE(v.qout == nullptr || (v.dh <= 128 && v.l_d >= 1), HN_E_SHAPE, "vfold: query fold dh=%d l_d=%d", v.dh, v.l_d);
-  hipLaunchKernelGGL(vfold_kernel, dim3(v.heads, v.n), dim3(256), 0, s, v);
+  hipLaunchKernelGGL(vfold_kernel, dim3(v.heads, v.n, v.qout ? 1 + (v.l_d + 31) / 32 : 1), dim3(256), 0, s, v);
   HN_LAUNCH_CHECK("vfold");
   return HN_OK;
 }
