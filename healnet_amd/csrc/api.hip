@@ -1233,6 +1233,10 @@ struct TapePlan {
   size_t x_off[kMaxSteps + 1];       // float offsets of the latent array before step k (x_off[nsteps] = final)
   size_t stats_off[kMaxSteps], saved_off[kMaxSteps];
   size_t q_off[kMaxSteps], kv_off[kMaxSteps];      // projections of the attention block at step k kept for the backward (kNoSlot: none)
+  // the normalised contexts z (K1's output) of the present modalities: written here by the training forward and read back by the
+  // backward instead of a second encode (round 4: 102 MB per patch bag of cfg4 against a 43 us HBM pass per step -- the tape has
+  // the room on a 288 GB part; HN_NO_Z_TAPE=1 keeps them in the workspace and re-encodes)
+  size_t z_off[16];
   size_t floats;
 };
 constexpr size_t kNoSlot = (size_t)-1;
@@ -1265,6 +1269,12 @@ static int plan_tape(const hn_model *m, const hn_modality_input *in, int b, int 
         if (!cross) { tp->kv_off[k] = off; off += align_up(rows * 2 * pl.heads * pl.dhp, 64); }
       }
     }
+  }
+  static const bool no_z_tape = getenv("HN_NO_Z_TAPE") != nullptr;
+  for (int i = 0; i < m->n_modalities; ++i) {
+    tp->z_off[i] = kNoSlot;
+    if (no_z_tape || !in[i].data || fp.N[i] <= 0) continue;
+    tp->z_off[i] = off; off += align_up((size_t)b * fp.N[i] * fp.ldz[i], 64);
   }
   tp->floats = off;
   return HN_OK;
@@ -2020,6 +2030,7 @@ static int impl_fusion_forward_train(const hn_model *m, const hn_modality_input 
   train_context_layout(m, fp, tones, tpack);
   for (int i = 0; i < M; ++i) {
     if (!in[i].data) continue;
+    if (tp.z_off[i] != kNoSlot && fp.z[i]) fp.z[i] = T + tp.z_off[i];      // the context lives on the tape: the backward reads it back
     if ((rc = launch_encode(in[i].data, in[i].dtype, b, m->num_spatial_axes[i], in[i].spatial, m->channel_dims[i], m->num_freq_bands,
                             m->max_freq, m->fourier_encode_data, 1, 1e-5f, fp.z[i], fp.ldz[i], s, tones[i] ? fp.ldz[i] - 1 : -1,
                             tpack[i])) != HN_OK)
@@ -2237,8 +2248,9 @@ static int impl_fusion_backward(const hn_model *m, const hn_modality_input *in, 
   const size_t xn = (size_t)b * L * d;
   bool tones[16]; int tpack[16];
   train_context_layout(m, fp, tones, tpack);
-  for (int i = 0; i < M; ++i) {     // the normalised contexts are recomputed (one HBM pass) rather than kept on the tape
+  for (int i = 0; i < M; ++i) {     // the normalised contexts: from the tape, or recomputed (one HBM pass) when they were not kept
     if (!in[i].data) continue;
+    if (tp.z_off[i] != kNoSlot && fp.z[i]) { fp.z[i] = const_cast<float *>(T) + tp.z_off[i]; continue; }
     if ((rc = launch_encode(in[i].data, in[i].dtype, b, m->num_spatial_axes[i], in[i].spatial, m->channel_dims[i], m->num_freq_bands,
                             m->max_freq, m->fourier_encode_data, 1, 1e-5f, fp.z[i], fp.ldz[i], s, tones[i] ? fp.ldz[i] - 1 : -1,
                             tpack[i])) != HN_OK)
