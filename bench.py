@@ -113,19 +113,25 @@ def pmc_traffic():
     files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_cfg2_b32.json")) if "bf16core" not in f)
     if not files:
         return None, {"source": None, "reason": "no PMC profile committed"}
-    path = files[-1]
-    try:
-        with open(path) as f:
-            doc = json.load(f)
-        now = _sha256(os.path.join(ROOT, "healnet_amd", "csrc", "attention.hip"))
-        then = (doc.get("source_sha256") or {}).get("attention.hip")
-        label = {"source": os.path.relpath(path, ROOT), "attention_hip_sha256": then, "collected_at_commit": doc.get("git_head")}
-        if then != now:
-            label["reason"] = "attention.hip changed since the PMC passes were collected (sha256 mismatch): stale, dropped"
-            return None, label
-        return float(doc["dominant_kernel_traffic_bytes_per_launch"]["fetch_doubled"]), label
-    except Exception as e:      # noqa: BLE001
-        return None, {"source": os.path.relpath(path, ROOT), "reason": f"unreadable: {e}"}
+    now = _sha256(os.path.join(ROOT, "healnet_amd", "csrc", "attention.hip"))
+    stale = None
+    # newest first by name (rNN_<call>); file names of one round do not sort by time (r04_zz sorts behind r04_ao), so the passes
+    # that were taken from THIS attention.hip are looked for among all of them -- the newest round's first
+    for path in reversed(files):
+        try:
+            with open(path) as f:
+                doc = json.load(f)
+            then = (doc.get("source_sha256") or {}).get("attention.hip")
+            label = {"source": os.path.relpath(path, ROOT), "attention_hip_sha256": then, "collected_at_commit": doc.get("git_head")}
+            if then == now:
+                return float(doc["dominant_kernel_traffic_bytes_per_launch"]["fetch_doubled"]), label
+            if stale is None:
+                label["reason"] = "attention.hip changed since the PMC passes were collected (sha256 mismatch): stale, dropped"
+                stale = label
+        except Exception as e:      # noqa: BLE001
+            if stale is None:
+                stale = {"source": os.path.relpath(path, ROOT), "reason": f"unreadable: {e}"}
+    return None, stale
 
 
 def _host_ram_gb():

@@ -189,3 +189,16 @@ def test_expected_output_matches_the_dropout_free_model(hn):
         model.eval()
         ref = model([img])
     assert rel_err(acc / n, ref) < 5e-2
+
+
+def test_general_dropout_core_route_still_matches(hn):
+    """HN_NO_DROP_BOUND=1 (subprocess): dropping modalities keep the natural context layout and the general softmax path of the
+    core -- the route every rank-D dropout block took before the bounded / packed variants; same parity cases, same bounds."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HN_NO_DROP_BOUND="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_dropout.py"), "-q", "-x", "-m", "gpu",
+                        "-k", "exported_masks"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
