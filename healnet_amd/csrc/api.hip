@@ -647,6 +647,7 @@ struct AttnBwdExt {
   const float *dQ, *dKV, *xhat;   // out (defer_proj): (rows, inner) scaled, (rows, 2 inner) or NULL (cross blocks), LN(x_in) (rows, query_dim)
   const float *O;            // out: the block's attention output (rows, inner) -- the tape's or the recomputed one
   const float *q_taped, *kv_taped;      // in: the forward's projections from the tape (NULL: recomputed here)
+  const float *xhat_taped;              // in: LN(x_in) from the tape (NULL: recomputed here)
 };
 
 static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float *x_out, int residual, const float *ctx,
@@ -739,7 +740,8 @@ static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float
   if ((rc = attn_prepare(p, pl, x_in, ctx, ld_ctx, b, L, s, &core, pack_ks, kv_from, kv_from != nullptr, false, nullptr,
                          (ext && ext->q_taped) ? &pe : nullptr)) != HN_OK) return rc;
   const float *xhat = x_in;
-  if (p->norm_w) {
+  if (p->norm_w && ext && ext->xhat_taped) xhat = ext->xhat_taped;
+  else if (p->norm_w) {
     if ((rc = launch_ln_fwd(x_in, p->norm_w, p->norm_b, rows, qd, bp.xhat, s, p->query_dim_valid)) != HN_OK) return rc;
     xhat = bp.xhat;
   }
@@ -1237,6 +1239,9 @@ struct TapePlan {
   // backward instead of a second encode (round 4: 102 MB per patch bag of cfg4 against a 43 us HBM pass per step -- the tape has
   // the room on a 288 GB part; HN_NO_Z_TAPE=1 keeps them in the workspace and re-encodes)
   size_t z_off[16];
+  // LN(x) of an attention block's input, the operand of its dW_q / dW_kv products: written by the chain that projects for the block
+  // (it holds the tile in LDS anyway) or by the block itself, instead of a LayerNorm launch in front of every block backward
+  size_t xhat_off[kMaxSteps];
   size_t floats;
 };
 constexpr size_t kNoSlot = (size_t)-1;
@@ -1250,7 +1255,7 @@ static int plan_tape(const hn_model *m, const hn_modality_input *in, int b, int 
   for (int k = 0; k < tp->nsteps; ++k) {
     const Step &st = tp->steps[k];
     tp->stats_off[k] = tp->saved_off[k] = 0;
-    tp->q_off[k] = tp->kv_off[k] = kNoSlot;
+    tp->q_off[k] = tp->kv_off[k] = tp->xhat_off[k] = kNoSlot;
     if (st.kind == STEP_CROSS_ATTN || st.kind == STEP_SELF_ATTN) {
       const bool cross = st.kind == STEP_CROSS_ATTN;
       const hn_attn_params *ap = cross ? &m->cross_attn[st.layer * m->n_modalities + st.m] : &m->self_attn[st.layer];
@@ -1267,6 +1272,8 @@ static int plan_tape(const hn_model *m, const hn_modality_input *in, int b, int 
         const size_t rows = rows16((size_t)b * m->l_c);
         tp->q_off[k] = off; off += align_up(rows * (pl.rank_d ? pl.inner : pl.heads * pl.dhp), 64);
         if (!cross) { tp->kv_off[k] = off; off += align_up(rows * 2 * pl.heads * pl.dhp, 64); }
+        static const bool no_xhat_tape = getenv("HN_NO_XHAT_TAPE") != nullptr;
+        if (ap->norm_w && ap->query_dim == m->l_d && !no_xhat_tape) { tp->xhat_off[k] = off; off += align_up(rows * m->l_d, 64); }
       }
     }
   }
@@ -2079,6 +2086,7 @@ static int impl_fusion_forward_train(const hn_model *m, const hn_modality_input 
       ca.nq = up128(pn.inner); ca.q_cols = pn.inner; ca.wq = an->w_q; ca.ldq = pn.inner;
       ca.Q = tp.q_off[kn] != kNoSlot ? T + tp.q_off[kn] : fp.cq;      // straight into the next block's tape slot
       ca.alpha_q = pn.rank_d ? 1.0f : pn.cscale;
+      ca.xhat_out = (tp.xhat_off[kn] != kNoSlot && an->norm_w) ? T + tp.xhat_off[kn] : nullptr;
       q_done = true;
       if (nself) {
         ca.nkv = up128(2 * pn.inner); ca.kv_cols = 2 * pn.inner; ca.wkv = an->w_kv; ca.ldkv = 2 * pn.inner; kv_done = true;
@@ -2134,6 +2142,11 @@ static int impl_fusion_forward_train(const hn_model *m, const hn_modality_input 
              inner % 16 == 0 && inner <= 512 &&
              chain_ff_aligned(&fq) && chain_out_aligned(&aq) && al16(xin) && al16(xout) && al16(T + tp.x_off[k + 2]) &&
              !(st.kind == STEP_CROSS_ATTN && fp.N[st.m] == 1 && mask == nullptr && !(aq.dropout > 0.0f));
+    }
+    // LN(x) of the block's input for the backward's dW_q / dW_kv: the chain that projected for the block wrote it (q_done), else here
+    if (is_attn_t(st) && tp.xhat_off[k] != kNoSlot && !q_done) {
+      const hn_attn_params &aq = st.kind == STEP_SELF_ATTN ? m->self_attn[st.layer] : m->cross_attn[st.layer * M + st.m];
+      if ((rc = launch_ln_fwd(xin, aq.norm_w, aq.norm_b, b * L, d, T + tp.xhat_off[k], s, aq.query_dim_valid)) != HN_OK) return rc;
     }
     if (fuse) {
       const bool self = st.kind == STEP_SELF_ATTN;
@@ -2391,7 +2404,8 @@ static int impl_fusion_backward(const hn_model *m, const hn_modality_input *in, 
     ext.dpre = dpre; ext.dO = dO_in; ext.skip_wout = skip_wout; ext.defer_proj = defer;
     if (tp.q_off[k] != kNoSlot) ext.q_taped = T + tp.q_off[k];
     if (tp.kv_off[k] != kNoSlot) ext.kv_taped = T + tp.kv_off[k];
-    AttnBwdExt *extp = (dpre || defer || ext.q_taped) ? &ext : nullptr;
+    if (tp.xhat_off[k] != kNoSlot) ext.xhat_taped = T + tp.xhat_off[k];
+    AttnBwdExt *extp = (dpre || defer || ext.q_taped || ext.xhat_taped) ? &ext : nullptr;
     const float *xin = T + tp.x_off[k], *xout = T + tp.x_off[k + 1];
     int rc2;
     if (st.kind == STEP_CROSS_ATTN)

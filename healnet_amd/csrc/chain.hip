@@ -422,7 +422,7 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 
   // LayerNorm of the x tile -> Ahat (A layout); no affine: the rows as they are
-  auto layer_norm = [&](bool affine, int gamma, int beta) {
+  auto layer_norm = [&](bool affine, int gamma, int beta, gf32 *keep = nullptr) {
     const int row = tid >> 5, l32 = tid & 31;
     float4 v = lld4(lds, xs + row * XP + 4 * l32);
     if (affine) {
@@ -438,6 +438,7 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
       v.x = v.x * rs * g0.x + b0.x; v.y = v.y * rs * g0.y + b0.y; v.z = v.z * rs * g0.z + b0.z; v.w = v.w * rs * g0.w + b0.w;
     }
     lst4(lds, Ahat + (l32 >> 3) * ATILE + row * WK + (((l32 & 7) ^ (row & 7)) * 4), v);   // k = 4 l32: k-tile l32 >> 3, slot l32 & 7
+    if (keep) gst4_nt(keep + (long)(m0 + row) * CD + 4 * l32, v);
   };
   // accumulator element r: row 4 fg + r, column 16 wave + fi of the 128-column chunk
   const int ncol = wave * 16 + fi;
@@ -604,7 +605,7 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
 
   // ================= stages Q / KV: the next attention block's projections of LN'(x) =================
   if (my_proj > 0) {
-    layer_norm(a_p_nw != nullptr, p_pnw, p_pnb);
+    layer_norm(a_p_nw != nullptr, p_pnw, p_pnb, (args.xhat_out && member == 0) ? (gf32 *)args.xhat_out : nullptr);
     __syncthreads();
     CHAIN_PROF(7);
     read_a(fa0, Ahat, 0);

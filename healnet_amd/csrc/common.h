@@ -374,6 +374,7 @@ struct ChainArgs {
   // qf (b, qf_heads = 8, Lp = L, 16) head-major, the Cauchy-Schwarz score bound of every row (sqrt(|qf row|^2 * qf_D), attention.hip)
   // and the fallback flag for bounds beyond the fp32-safe range
   float *qf, *qf_bound; int *qf_flag; int qf_heads, qf_D;
+  float *xhat_out;                      // training: LN'(x) of the projection stage (rows, 128) goes to the tape (the backward's dW_q / dW_kv operand), or NULL
   // cluster mode (small batches; inference forward): exchange buffer (rows / 16 * 4 tiles of 16 x 128 floats), one flag per (tile,
   // member) + one error marker, zeroed at the start of the forward, and this chain's 1-based sequence number within the forward
   float *xchg; int *xflags; int seq;
