@@ -827,10 +827,16 @@ static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float
       if ((rc = launch_head_affine(dO, inner, dh, nullptr, 0, 0, nullptr, nullptr, 1.0f, h, dh, pl.dhp, qp, rows, bp.dOp, s)) != HN_OK) return rc;
       ba.dO = bp.dOp; ba.do_b = (long)L * qp; ba.do_h = pl.dhp; ba.lddo = qp;
     }
-    if ((rc = launch_attn_bwd_dq(ba, s)) != HN_OK) return rc;
-    if ((rc = launch_dq_reduce(bp.dQpart, pl.nsplit_bwd, b, h, L, pl.Lp, pl.dp, dh, two_scale, bp.dQ, inner, dh, s)) != HN_OK) return rc;
     ba.dKV = bp.dKV; ba.dk_scale = 0.69314718055994530942f;
-    if ((rc = launch_attn_bwd_dkv(ba, dh, inner, s)) != HN_OK) return rc;
+    int rc_pair = HN_OK;
+    if (!has_ctx && launch_attn_bwd_self_pair(ba, dh, inner, s, &rc_pair)) {      // latent self-attention: both products in one launch
+      if (rc_pair != HN_OK) return rc_pair;
+      if ((rc = launch_dq_reduce(bp.dQpart, pl.nsplit_bwd, b, h, L, pl.Lp, pl.dp, dh, two_scale, bp.dQ, inner, dh, s)) != HN_OK) return rc;
+    } else {
+      if ((rc = launch_attn_bwd_dq(ba, s)) != HN_OK) return rc;
+      if ((rc = launch_dq_reduce(bp.dQpart, pl.nsplit_bwd, b, h, L, pl.Lp, pl.dp, dh, two_scale, bp.dQ, inner, dh, s)) != HN_OK) return rc;
+      if ((rc = launch_attn_bwd_dkv(ba, dh, inner, s)) != HN_OK) return rc;
+    }
     const long krows = (long)b * pl.N;
     if (has_ctx) {   // gradients of to_kv and of the context LayerNorm affine from G = dKV^T z and colsum(dKV)
       GemmExArgs e = gex(bp.dKV, 1, 2 * inner, ctx, 1, ld_ctx, bp.G, pl.D, 2 * inner, pl.D, (int)krows, 0);

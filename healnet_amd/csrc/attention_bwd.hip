@@ -28,14 +28,15 @@ __device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(
 // ------------------------------------------------------------------------------------------------
 // KS > 0: packed context (common.h packed_slot) -- the channel contractions of S and dP run KS steps instead of 4 DT, the last
 // 16-column block only its first KS - 4 (DT - 1) k-steps (the skipped ones hold unused columns and the ones column).
+// (the body is a device function so that attn_bwd_self_pair_kernel below can run it beside the dK/dV body in one launch; `id` of
+// `total` = the workgroup's index in the dQ part of the grid)
 template <int DT, int NQ, bool SHARED_KV, bool DROP = false, int KS = 0>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a, int ngroups, int gy, int waves_per_block) {
+__device__ __forceinline__ void attn_bwd_dq_body(const AttnBwdArgs &a, int ngroups, int gy, int waves_per_block, long id, long total) {
   constexpr int DP = 16 * DT;
   constexpr int LAST = KS > 0 ? KS - 4 * (DT - 1) : 4;     // k-steps of the last 16-column block
   const int L = a.Lq;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, j = lane & 15;
-  long total = (long)gridDim.x, id = blockIdx.x;
   if ((total & 7) == 0) id = (id & 7) * (total >> 3) + (id >> 3);
   const int split = (int)(id % a.nsplit);
   const int yb = (int)((id / a.nsplit) % gy);
@@ -234,6 +235,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a, int ngr
           a.dQpart[(prow + tile * 16 + 4 * g + r) * DP + 16 * d + j] = dQ[i][d][r] * __shfl(invl[i], 4 * g + r);
     }
   }
+}
+
+template <int DT, int NQ, bool SHARED_KV, bool DROP = false, int KS = 0>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a, int ngroups, int gy, int waves_per_block) {
+  attn_bwd_dq_body<DT, NQ, SHARED_KV, DROP, KS>(a, ngroups, gy, waves_per_block, (long)blockIdx.x, (long)gridDim.x);
 }
 
 static int bwd_nq(int dt) { return dt == 1 ? 4 : (dt == 2 ? 2 : (dt == 4 ? 2 : 1)); }
@@ -463,15 +469,15 @@ __device__ __forceinline__ void dkv_glds16(const i32x4 &rsrc, unsigned lds_byte,
 template <int N> __device__ __forceinline__ void dkv_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <int TPW>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_lds_kernel(AttnBwdArgs a, int ntiles, int dh, int inner) {
+__device__ __forceinline__ void attn_bwd_dkv_lds_body(const AttnBwdArgs &a, int ntiles, int dh, int inner, int bx, int by) {
   constexpr int DT = 4, DP = 64, MAXL = 128;
   __shared__ __attribute__((aligned(16))) float lds[2 * MAXL * DP + 4 * 256];          // Q image, dO image, (max, sum) rows, delta
   const int L = a.Lq, nq = (L + 15) >> 4;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, j = lane & 15;
-  const int bh = blockIdx.y, bi = bh / a.h, hi = bh % a.h;
-  const int tile0 = (blockIdx.x * 4 + wave) * TPW;
+  const int bh = by, bi = bh / a.h, hi = bh % a.h;
+  const int tile0 = (bx * 4 + wave) * TPW;
 
   const i32x4 rsQ = make_rsrc(a.Q + (long)bi * a.q_b + (long)hi * a.q_h, rsrc_bytes(L, a.ldq, DP));
   const i32x4 rsG = make_rsrc(a.dO + (long)bi * a.do_b + (long)hi * a.do_h, rsrc_bytes(L, a.lddo, DP));
@@ -619,6 +625,54 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_lds_kernel(AttnBwdArgs a, in
       }
     }
   }
+}
+
+template <int TPW>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_lds_kernel(AttnBwdArgs a, int ntiles, int dh, int inner) {
+  attn_bwd_dkv_lds_body<TPW>(a, ntiles, dh, inner, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Latent self-attention backward (L = N <= 128, dim_head 64, explicit binding): dQ and dK/dV are independent once delta exists,
+// and at small batches each of the two launches leaves most of the chip idle (cfg4 b = 8: 18 + 15 us for 64 (sample, head)
+// pairs).  One launch runs both bodies side by side: the first `n_dq` workgroups are the dQ kernel's grid, the rest the dK/dV
+// kernel's (bx, by) grid flattened.  Same code, same bits as the two launches.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_bwd_self_pair_kernel(AttnBwdArgs a, int ngroups, int gy, int wpb, int n_dq, int ntiles, int dh,
+                                                                 int inner, int dkv_bx) {
+  if ((int)blockIdx.x < n_dq) {
+    attn_bwd_dq_body<4, 2, false, false, 0>(a, ngroups, gy, wpb, (long)blockIdx.x, (long)n_dq);
+  } else {
+    const int r = (int)blockIdx.x - n_dq;
+    attn_bwd_dkv_lds_body<1>(a, ntiles, dh, inner, r % dkv_bx, r / dkv_bx);
+  }
+}
+
+// true: both products were launched (the caller still runs dq_reduce); false: not this shape, nothing launched
+bool launch_attn_bwd_self_pair(const AttnBwdArgs &a, int dh, int inner, hipStream_t s, int *rc_out) {
+  static const bool off = getenv("HN_NO_SELF_BWD_PAIR") != nullptr || getenv("HN_NO_DKV_LDS") != nullptr;
+  *rc_out = HN_OK;
+  auto al16p = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
+  const int ntiles = ceil_div(a.N, 16);
+  const bool dkv_ok = a.dp == 64 && a.Lq <= 128 && a.drop.thr == 0 && dh % 4 == 0 && inner % 4 == 0 && a.ldq % 4 == 0 && a.lddo % 4 == 0 &&
+                      a.q_b % 4 == 0 && a.q_h % 4 == 0 && a.do_b % 4 == 0 && a.do_h % 4 == 0 && al16p(a.Q) && al16p(a.dO) && al16p(a.dKV) &&
+                      a.N >= 64 && ntiles < 64;
+  const int nq = bwd_nq(4), ngroups = ceil_div(a.Lp / 16, nq), wpb = ngroups < 4 ? ngroups : 4;
+  // (measured: 64 (sample, head) pairs, cfg4 b = 8: 18 + 15 us -> the step 5.20 -> 5.11 ms; 256 pairs, cfg2 b = 32: each launch fills
+  // the chip on its own and the pair is 0.2 % slower -- up to 128 pairs it is)
+  if ((long)a.b * a.h > 128) return false;
+  if (off || !dkv_ok || a.Kp == a.Vp || a.qk_steps != 0 || a.mask != nullptr || attn_bwd_dq_lds_eligible(a) || wpb != 4 || a.Lp % 16 != 0 ||
+      a.chunk % 16 != 0)
+    return false;
+  const int gy = ceil_div(ngroups, wpb);
+  const long n_dq = (long)a.nsplit * gy * a.b * a.h;
+  const int dkv_bx = ceil_div(ntiles, 4);
+  const long n_dkv = (long)dkv_bx * a.b * a.h;
+  if (n_dq + n_dkv >= (1L << 31) || (long)a.b * a.h > 65535) return false;
+  hipLaunchKernelGGL(attn_bwd_self_pair_kernel, dim3((unsigned)(n_dq + n_dkv)), dim3(256), 0, s, a, ngroups, gy, wpb, (int)n_dq, ntiles, dh, inner,
+                     dkv_bx);
+  if (hipGetLastError() != hipSuccess) { *rc_out = HN_E_HIP; }
+  return true;
 }
 
 int launch_attn_bwd_dkv(const AttnBwdArgs &a, int dh, int inner, hipStream_t s) {

@@ -623,6 +623,8 @@ int launch_attn_bwd_dq_lds(const AttnBwdArgs &a, hipStream_t s);
 int launch_dq_reduce(const float *part, int nsplit, int b, int h, int L, int Lp, int dp, int width, float scale, float *out,
                      int ld_out, int head_pitch, hipStream_t s);
 int launch_attn_bwd_dkv(const AttnBwdArgs &a, int dh, int inner, hipStream_t s);
+// latent self-attention: dQ and dK/dV side by side in one launch (attention_bwd.hip); false = not this shape, nothing launched
+bool launch_attn_bwd_self_pair(const AttnBwdArgs &a, int dh, int inner, hipStream_t s, int *rc_out);
 int launch_rowdot_heads(const float *X, int ldx, int xpitch, const float *Y, int ldy, int ypitch, int h, int L, int width,
                         long rows, float *delta, hipStream_t s);
 int launch_head_affine(const float *src, int lds, int spitch, const float *mul, int ldm, int mpitch, const float *colscale,
