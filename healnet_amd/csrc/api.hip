@@ -184,6 +184,8 @@ struct AttnExt {
   // inference, rank-D block: the chain in front has written the FOLDED query and its score bounds (ChainArgs.qf): neither the
   // query projection nor qfold runs
   float *qf, *qf_bound; bool qf_done;
+  // one-token shortcut with defer_out: the block's output row per sample (b, query_dim), before the broadcast add (ChainArgs.y)
+  const float *y_out;
 };
 
 static int check_ws(void *ws, size_t ws_bytes, size_t need, const char *who) {
@@ -350,9 +352,9 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
     gv.A = ctx; gv.lda = ld_ctx; gv.M = b; gv.K = pl.D;
     if (p->ctx_gamma) { gv.pro = PRO_AFFINE; gv.gamma = p->ctx_gamma; gv.beta = p->ctx_beta; }
     gv.W = p->w_kv + (long)pl.inner * pl.D; gv.ldw = pl.D; gv.N = pl.inner;
+    if (o_save) vbuf = o_save;                              // training: V straight into its tape slot (no copy behind the product)
     gv.C = vbuf; gv.ldc = pl.inner;
     if ((rc = launch_gemm(gv, s)) != HN_OK) return rc;
-    if (o_save) { int rc_ = launch_copy(o_save, vbuf, (long)((size_t)b * pl.inner), s); if (rc_ != HN_OK) return rc_; }
     GemmArgs gy = gemm_defaults();
     gy.A = vbuf; gy.lda = pl.inner; gy.M = b; gy.K = pl.inner;
     gy.W = p->w_out; gy.ldw = wo_ld(p); gy.N = p->query_dim;
@@ -361,6 +363,7 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
     if ((rc = launch_gemm(gy, s)) != HN_OK) return rc;
     // (`stats` is not written on this path: p == 1 for every row, and hn_attn_probs / hn_attn_importance / the backward
     // special-case a one-token context without a mask instead of reading it)
+    if (ext && ext->defer_out) { ext->y_out = ybuf; return HN_OK; }      // the chain behind the block adds the row (ChainArgs.head == 2)
     return launch_add_row_broadcast(ybuf, residual ? x_in : nullptr, x_out, b, L, p->query_dim, s);
   }
 
@@ -2138,7 +2141,7 @@ static int impl_fusion_forward_train(const hn_model *m, const hn_modality_input 
     // the projections of the attention block after it), with the feed-forward block's input kept on the tape (x_mid): the
     // backward recomputes everything else of these blocks from the tape as before.  The feed-forward block's dropout is applied
     // inside the chain (same generator, same stream id as the per-block route).  Not behind the one-token shortcut.
-    bool fuse = false;
+    bool fuse = false, fuse_tab = false;
     if (use_chain && is_attn_t(st) && k + 1 < tp.nsteps && !is_attn_t(tp.steps[k + 1])) {
       const Step &sf = tp.steps[k + 1];
       const hn_ff_params &fq = sf.kind == STEP_CROSS_FF ? m->cross_ff[sf.layer * M + sf.m] : m->self_ff[sf.layer];
@@ -2148,6 +2151,14 @@ static int impl_fusion_forward_train(const hn_model *m, const hn_modality_input 
              inner % 16 == 0 && inner <= 512 &&
              chain_ff_aligned(&fq) && chain_out_aligned(&aq) && al16(xin) && al16(xout) && al16(T + tp.x_off[k + 2]) &&
              !(st.kind == STEP_CROSS_ATTN && fp.N[st.m] == 1 && mask == nullptr && !(aq.dropout > 0.0f));
+      // the one-token shortcut (tabular / omic modality): its two skinny products run as before, the broadcast add of the block's
+      // row, the feed-forward block and the next projections ride on ONE chain (head == 2) as in the inference forward
+      // (round 4: add_row + FF1 + FF2 + LayerNorm + projection = 40 us of launches per layer at cfg4 b = 8 became a 22 us chain)
+      static const bool no_tab_chain = getenv("HN_NO_TAB_CHAIN") != nullptr;
+      fuse_tab = !fuse && !no_tab_chain && !staged && st.kind == STEP_CROSS_ATTN && fp.N[st.m] == 1 && mask == nullptr && !(aq.dropout > 0.0f) &&
+                 fq.dim == d && fq.dropout >= 0.0f && fq.dropout < 1.0f && aq.query_dim == d && chain_ff_aligned(&fq) && al16(xin) &&
+                 al16(xout) && al16(T + tp.x_off[k + 2]) && aq.w_out && aq.b_out;
+      fuse = fuse || fuse_tab;
     }
     // LN(x) of the block's input for the backward's dW_q / dW_kv: the chain that projected for the block wrote it (q_done), else here
     if (is_attn_t(st) && tp.xhat_off[k] != kNoSlot && !q_done) {
@@ -2168,15 +2179,19 @@ static int impl_fusion_forward_train(const hn_model *m, const hn_modality_input 
                            fp.op_ws, fp.op_ws_bytes, s, nullptr, nullptr, T + tp.saved_off[k], tones[st.m], tpack[st.m], nullptr, nullptr,
                            &ext);
       if (rc != HN_OK) return rc;
-      HN_REQUIRE(ext.o_out != nullptr, HN_E_UNSUPPORTED, "fusion_forward_train: attention block did not defer its out-projection");
+      HN_REQUIRE(fuse_tab ? ext.y_out != nullptr : ext.o_out != nullptr, HN_E_UNSUPPORTED,
+                 "fusion_forward_train: attention block did not defer its out-projection");
       const Step &sf = tp.steps[k + 1];
       const hn_ff_params &fq = sf.kind == STEP_CROSS_FF ? m->cross_ff[sf.layer * M + sf.m] : m->self_ff[sf.layer];
       HN_REQUIRE(fq.w1 && fq.b1 && fq.w2 && fq.b2, HN_E_NULL, "ff: weight pointer is NULL");
       ChainArgs ca;
       memset(&ca, 0, sizeof(ca));
       ca.x_in = xin;
-      ca.head = 1; ca.O = ext.o_out; ca.ldo = ext.ldo_out; ca.inner_o = up128(ap.heads * ap.dim_head); ca.o_cols = ap.heads * ap.dim_head;
-      ca.w_out = ap.w_out; ca.b_out = ap.b_out;
+      if (fuse_tab) { ca.head = 2; ca.y = ext.y_out; }
+      else {
+        ca.head = 1; ca.O = ext.o_out; ca.ldo = ext.ldo_out; ca.inner_o = up128(ap.heads * ap.dim_head); ca.o_cols = ap.heads * ap.dim_head;
+        ca.w_out = ap.w_out; ca.b_out = ap.b_out;
+      }
       ca.has_ff = 1; ca.gate = fq.gate; ca.f_nw = fq.norm_w; ca.f_nb = fq.norm_b;
       ca.w1 = fq.w1; ca.b1 = fq.b1; ca.w2 = fq.w2; ca.b2 = fq.b2;
       {
