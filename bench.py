@@ -341,6 +341,14 @@ def train_step_record(dev, rank, world, distributed, barrier, steps, warmup):
                         "signals on a side stream while the lower layers run their backward",
            "allreduce_buckets_floats": [hi - lo for _, lo, hi in sync.launched], "gradient_floats": int(flat.numel),
            "final_loss": loss}
+    # cluster-mode latent chains beside the side-stream all-reduce (include/healnet_hip.h "failure signal"): what this rank's
+    # device reported during the timed steps -- `fallbacks` = calls re-run without clusters, `lost` = losses consumed, `enabled`
+    # = the mode is still on (it is switched off for good by the first loss), `optimizer_steps_skipped` = FusedL1Adam host skips
+    torch.cuda.synchronize(dev)
+    from healnet_amd import _capi as _hc
+    cst = _hc.cluster_status(dev.index if dev.index is not None else 0)
+    rec["cluster"] = {"fallbacks": cst["fallbacks"], "lost": cst["lost"], "pending": cst["pending"], "enabled": cst["enabled"],
+                      "optimizer_steps_skipped": int(getattr(opt, "skipped_steps", 0))}
     if distributed:
         dt2, _ = timed(False)
         rec["ms_per_step_blocking_allreduce"] = round(dt2 / steps * 1e3, 4)

@@ -1432,6 +1432,8 @@ using namespace hn;
 extern "C" {
 
 int hn_abi_version(void) { return HN_ABI_VERSION; }
+int hn_cluster_status(int device, int acknowledge, hn_cluster_info *info) { return cluster_status(device, acknowledge, info); }
+int hn_cluster_config(int device, int enable, int timeout_us) { return cluster_config(device, enable, timeout_us); }
 int hn_set_kernel_timers(hn_kernel_timer *timers, int n) {
   if (n < 0 || (n > 0 && timers == nullptr)) return fail(HN_E_SHAPE, "hn_set_kernel_timers: n=%d", n);
   g_ntimers = 0;
@@ -1677,6 +1679,7 @@ size_t hn_l1_adam_workspace_bytes(void) { return L1_ADAM_PARTIALS * sizeof(float
 int hn_l1_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, long n, double l1, double grad_scale,
                     double lr, double beta1, double beta2, double eps, int step, float *reg_loss, void *workspace,
                     size_t workspace_bytes, void *stream) {
+  { const int prc = cluster_poll("hn_l1_adam_step"); if (prc != HN_OK) return prc; }
   int rc = check_ws(workspace, workspace_bytes, hn_l1_adam_workspace_bytes(), "l1_adam");
   if (rc != HN_OK) return rc;
   return launch_l1_adam(params, grads, exp_avg, exp_avg_sq, n, l1, grad_scale, lr, beta1, beta2, eps, step, reg_loss,
@@ -1937,7 +1940,8 @@ static int impl_fusion_forward(const hn_model *m, const hn_modality_input *in, i
         // O buffer, and the chain carries on from there (out-projection, feed-forward, next projections)
         HN_REQUIRE(!ext.merge_deferred && ext.o_out && ext.ldo_out == inner, HN_E_UNSUPPORTED, "fusion: split block did not report its output");
         if ((rc = launch_copy(cp->local, ext.o_out, n_o, s)) != HN_OK) return rc;
-        cp->exchange(cp->user, (int)(n_o + n_s), stream);
+        HN_REQUIRE(cp->exchange(cp->user, (int)(n_o + n_s), stream) == 0, HN_E_HIP, "fusion_cp: the caller's exchange callback failed (layer %d, modality %d)",
+                   st.layer, st.m);
         float *st_out = attn_stats ? attn_stats[slot_of(st)] : nullptr;
         const bool vec = ap->dim_head % 4 == 0 && (((uintptr_t)cp->parts | (uintptr_t)ext.o_out) & 15) == 0 && (n_o + n_s) % 4 == 0;
         const long pieces = (long)b * L * (vec ? inner >> 2 : inner);
@@ -2860,6 +2864,7 @@ size_t hn_context_split_floats(const hn_model *m, int b) {
 
 int hn_fusion_forward_cp(const hn_model *m, const hn_modality_input *in, int b, int return_embeddings, const hn_context_split *cp,
                          float *out, void *workspace, size_t workspace_bytes, void *stream) {
+  { const int prc = cluster_poll("hn_fusion_forward_cp"); if (prc != HN_OK) return prc; }
   HN_REQUIRE(m && in && cp && out, HN_E_NULL, "fusion_cp: NULL pointer");
   HN_REQUIRE(cp->n_parts >= 1 && cp->local && cp->parts && cp->exchange, HN_E_NULL, "fusion_cp: exchange buffers / callback missing");
   HN_REQUIRE(m->n_modalities <= 16, HN_E_UNSUPPORTED, "fusion_cp: %d modalities", m->n_modalities);
@@ -2871,6 +2876,7 @@ int hn_fusion_forward_cp(const hn_model *m, const hn_modality_input *in, int b, 
 int hn_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, const uint8_t *mask, int skip_self_on_missing,
                       int return_embeddings, float *out, float **attn_stats, float **x_trace, void *workspace,
                       size_t workspace_bytes, void *stream, hn_profile *prof) {
+  { const int prc = cluster_poll("hn_fusion_forward"); if (prc != HN_OK) return prc; }
   if (!stage_wanted(m))
     return impl_fusion_forward(m, in, b, mask, skip_self_on_missing, return_embeddings, out, attn_stats, x_trace, workspace, workspace_bytes,
                                stream, prof);
@@ -2944,6 +2950,7 @@ int hn_fusion_tape_layout(const hn_model *m, const hn_modality_input *in, int b,
 int hn_fusion_forward_train(const hn_model *m, const hn_modality_input *in, int b, const uint8_t *mask, int skip_self_on_missing,
                             int return_embeddings, float *out, float **attn_stats, float **x_trace, void *tape,
                             size_t tape_bytes, void *workspace, size_t workspace_bytes, void *stream) {
+  { const int prc = cluster_poll("hn_fusion_forward_train"); if (prc != HN_OK) return prc; }
   if (!stage_wanted(m))
     return impl_fusion_forward_train(m, in, b, mask, skip_self_on_missing, return_embeddings, out, attn_stats, x_trace, tape, tape_bytes,
                                      workspace, workspace_bytes, stream);
@@ -2999,6 +3006,7 @@ size_t hn_fusion_backward_workspace_bytes(const hn_model *m, const hn_modality_i
 int hn_fusion_backward(const hn_model *m, const hn_modality_input *in, int b, const uint8_t *mask, int skip_self_on_missing,
                        int return_embeddings, const float *dout, const void *tape, const hn_model_grads *g, void *workspace,
                        size_t workspace_bytes, void *stream, const hn_grad_ready *ready) {
+  { const int prc = cluster_poll("hn_fusion_backward"); if (prc != HN_OK) return prc; }
   if (!stage_wanted(m))
     return impl_fusion_backward(m, in, b, mask, skip_self_on_missing, return_embeddings, dout, tape, g, workspace, workspace_bytes, stream, ready);
   hipStream_t s = (hipStream_t)stream;

@@ -93,7 +93,9 @@ __global__ __launch_bounds__(512) void latent_bchain_kernel(const BChainArgs arg
   // order by every member (identical bits everywhere); member 0 writes what is per row tile.
   const int a_C = args.cluster > 1 ? args.cluster : 1;
   const int ntiles = gridDim.x / a_C;
-  const int member = __builtin_amdgcn_readfirstlane((int)blockIdx.x / ntiles), tile = blockIdx.x - member * ntiles;
+  int member_, tile_;
+  cluster_decode((int)blockIdx.x, a_C, ntiles, args.split_order, member_, tile_);      // members of a tile: one XCD, consecutive in its dispatch order (chain_common.h)
+  const int member = __builtin_amdgcn_readfirstlane(member_), tile = __builtin_amdgcn_readfirstlane(tile_);
   if (EXT && tile >= args.tiles) return;            // (cluster grids are rounded up to 8 tiles per member row: idle workgroups)
   const int my_chunks = 4 / a_C;
   const int m0 = tile * CR;
@@ -295,15 +297,10 @@ __global__ __launch_bounds__(512) void latent_bchain_kernel(const BChainArgs arg
       __hip_atomic_store(slot + (long)member * (CR * CD) + (4 * fg + r) * CD + ncol, v[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(flags + member, args.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int timed_out = 0;
-    if (tid < a_C) {
-      int spins = 0;
-      while (__hip_atomic_load(flags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < args.seq) {
-        __builtin_amdgcn_s_sleep(2);
-        if (++spins > (1 << 22)) { args.xflags[2 * ntiles * a_C] = 1; timed_out = 1; break; }      // no hang ...
-      }
-    }
+    if (tid == 0 && !(args.inject_loss && member == a_C - 1))      // (fault injection: the last member's flag never goes up)
+      __hip_atomic_store(flags + member, args.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int timed_out = 0;                         // bounded wait, reported (cluster_wait, chain_common.h): no hang ...
+    if (tid < a_C) timed_out = cluster_wait(flags + tid, args.seq, args.wait_ticks, args.xflags + 2 * ntiles * a_C, args.status, args.token);
     // ... and no silently incomplete sum either: a tile that gave up on a member becomes NaN (chain.hip explains)
     const bool lost = __syncthreads_or(timed_out) != 0;
     float4 acc = lost ? make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -581,7 +578,7 @@ int launch_latent_bchain(const BChainArgs &a, hipStream_t s) {
     HN_HIP_CHECK(hipFuncSetAttribute((const void *)latent_bchain_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     if (dev >= 0 && dev < 64) configured[dev] = true;
   }
-  static const bool no_cluster = getenv("HN_NO_CHAIN_CLUSTER") != nullptr;
+  const bool no_cluster = !cluster_enabled(dev);
   BChainArgs ac = a;
   const int tiles = (a.rows + CR - 1) / CR;
   const int gtiles = (tiles + 7) / 8 * 8;    // member rows of a cluster grid: a multiple of 8 tiles (members of a tile share an XCD)
@@ -599,7 +596,13 @@ int launch_latent_bchain(const BChainArgs &a, hipStream_t s) {
     const int cus = (dev >= 0 && dev < 64) ? cu_count[dev] : 1;
     if (gtiles * C <= cus) ac.cluster = C;
   }
-  if (ac.cluster > 1) cluster_stream_guard(dev, s);
+  if (ac.cluster > 1) {
+    ClusterTicket t;
+    cluster_before_launch(dev, s, &t);
+    ac.status = t.status; ac.token = t.token; ac.wait_ticks = t.wait_ticks; ac.inject_loss = t.inject_loss;
+    static const bool split_order = getenv("HN_FORCE_CLUSTER_SPLIT_ORDER") != nullptr;      // route switch (A/B): the former grid order
+    ac.split_order = split_order ? 1 : 0;
+  }
   const bool ext = a.rows % CR != 0 || (a.dv > 0 && a.dv < CD) || a.ff_drop.thr != 0 || (a.has_p && a.q_cols > 0 && a.q_cols < a.nq) ||
                    (a.has_p && a.kv_cols > 0 && a.kv_cols < a.nkv) || (a.has_out && a.o_cols > 0 && a.o_cols < a.inner_o) ||
                    (ac.cluster > 1 && gtiles != tiles);
@@ -607,6 +610,7 @@ int launch_latent_bchain(const BChainArgs &a, hipStream_t s) {
   if (ext) hipLaunchKernelGGL(latent_bchain_kernel<true>, grid, dim3(512), lds_bytes, s, ac);
   else hipLaunchKernelGGL(latent_bchain_kernel<false>, grid, dim3(512), lds_bytes, s, ac);
   HN_LAUNCH_CHECK("latent_bchain");
+  if (ac.cluster > 1) cluster_after_launch(dev, s);
   return HN_OK;
 }
 

@@ -60,6 +60,7 @@
 #include "common.h"
 #include <stdlib.h>
 #include <mutex>
+#include <string.h>
 
 namespace hn {
 
@@ -153,10 +154,13 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
   // the LayerNorm anyway), then only ITS hidden chunks of the feed-forward block (FF1 columns and the matching k-tiles of FF2: a
   // partial x tile), the members exchange the partials ONCE through global memory (fixed summation order: all members hold the
   // same bits afterwards), and each computes its share of the projection chunks.  Members of a tile sit `ntiles` workgroups
-  // apart: with ntiles a multiple of 8 they share an XCD (its L2).
+  // 8 workgroups apart inside a group of 8 C (cluster_decode, chain_common.h): they share an XCD (its L2) and are dispatched
+  // back to back.
   const int a_C = args.cluster > 1 ? args.cluster : 1;
   const int ntiles = gridDim.x / a_C;
-  const int member = __builtin_amdgcn_readfirstlane((int)blockIdx.x / ntiles), tile = blockIdx.x - member * ntiles;
+  int member_, tile_;
+  cluster_decode((int)blockIdx.x, a_C, ntiles, args.split_order, member_, tile_);
+  const int member = __builtin_amdgcn_readfirstlane(member_), tile = __builtin_amdgcn_readfirstlane(tile_);
   if (EXT && tile >= args.tiles) return;            // cluster grids are rounded up to 8 tiles per member row (XCD alignment): idle workgroups
   const int my_chunks = 4 / a_C;             // hidden chunks (128 columns) of this member: member, member + C, ...
   const int m0 = tile * CR;
@@ -550,21 +554,15 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
       // the flag.
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (tid == 0)                          // ... before the member's flag goes up
+      if (tid == 0 && !(args.inject_loss && member == a_C - 1))      // ... before the member's flag goes up (fault injection: the last member's never does)
         __hip_atomic_store(args.xflags + tile * a_C + member, args.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      // one lane per member flag; bounded spin: a member that is never scheduled beside us (the launcher sizes the grid so that all
-      // members are resident, but nothing in HIP guarantees co-residency: a CU mask, another process, a collective kernel parked on
-      // the CUs) must not hang the device.  A tile that gives up is NOT allowed to carry on with incomplete sums silently: the
-      // whole tile becomes NaN, which reaches the logits / gradients of its sample -- HN_NO_CHAIN_CLUSTER=1 runs such a
-      // setup without the exchange.
+      // one lane per member flag; bounded wait (cluster_wait, chain_common.h): the dispatch order of a cluster grid keeps the
+      // members of a tile together, but a member that still never shows up must not hang the device.  A tile that gives up is NOT
+      // allowed to carry on with incomplete sums silently: the whole tile becomes NaN, which reaches the logits / gradients of its
+      // sample, and the launch reports itself in the device's status word (HN_E_CORESIDENCY).
       int timed_out = 0;
-      if (tid < a_C) {
-        int spins = 0;
-        while (__hip_atomic_load(args.xflags + tile * a_C + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < args.seq) {
-          __builtin_amdgcn_s_sleep(2);
-          if (++spins > (1 << 22)) { args.xflags[ntiles * a_C] = 1; timed_out = 1; break; }
-        }
-      }
+      if (tid < a_C)
+        timed_out = cluster_wait(args.xflags + tile * a_C + tid, args.seq, args.wait_ticks, args.xflags + ntiles * a_C, args.status, args.token);
       const bool lost = __syncthreads_or(timed_out) != 0;
       {
         const int row = tid >> 5, l32 = tid & 31;
@@ -795,7 +793,7 @@ int launch_latent_chain(const ChainArgs &a, hipStream_t s) {
   }
   // cluster mode for small batches (see the kernel): 4 workgroups per row tile up to 64 tiles, 2 up to 128 -- at most 256
   // workgroups, all resident (the exchange spins on the other members' flags)
-  static const bool no_cluster = getenv("HN_NO_CHAIN_CLUSTER") != nullptr;
+  const bool no_cluster = !cluster_enabled(dev);
   static const int max_tiles = tuning_env("HN_CHAIN_CLUSTER_TILES") ? atoi(tuning_env("HN_CHAIN_CLUSTER_TILES")) : 128;      // development knob
   ChainArgs ac = a;
   const int tiles = (a.rows + CR - 1) / CR;
@@ -815,42 +813,183 @@ int launch_latent_chain(const ChainArgs &a, hipStream_t s) {
     const int cus = (dev >= 0 && dev < 64) ? cu_count[dev] : 1, C = gtiles <= 64 ? 4 : 2;
     if (gtiles * C <= 2 * cus && gtiles * C <= CHAIN_XCHG_FLAGS - 1) ac.cluster = C;
   }
-  if (ac.cluster > 1) cluster_stream_guard(dev, s);
+  if (ac.cluster > 1) {
+    ClusterTicket t;
+    cluster_before_launch(dev, s, &t);
+    ac.status = t.status; ac.token = t.token; ac.wait_ticks = t.wait_ticks; ac.inject_loss = t.inject_loss;
+    static const bool split_order = getenv("HN_FORCE_CLUSTER_SPLIT_ORDER") != nullptr;      // route switch (A/B): the former grid order
+    ac.split_order = split_order ? 1 : 0;
+  }
   const bool ext = a.rows % CR != 0 || (a.dv > 0 && a.dv < CD) || a.ff_drop.thr != 0 || (a.o_cols > 0 && a.o_cols < a.inner_o) ||
                    (a.q_cols > 0 && a.q_cols < a.nq) || (a.kv_cols > 0 && a.kv_cols < a.nkv) || (ac.cluster > 1 && gtiles != tiles);
   const dim3 grid(ac.cluster > 1 ? gtiles * ac.cluster : tiles);
   if (ext) hipLaunchKernelGGL(latent_chain_kernel<true>, grid, dim3(512), lds_bytes, s, ac);
   else hipLaunchKernelGGL(latent_chain_kernel<false>, grid, dim3(512), lds_bytes, s, ac);
   HN_LAUNCH_CHECK("latent_chain");
+  if (ac.cluster > 1) cluster_after_launch(dev, s);
   return HN_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
-// See common.h.  Submission order under the mutex is a total order of the device's cluster launches, and every one of them is
-// ordered behind its predecessor when that went to another stream, so no two cluster kernels of this process ever run at once.
-// A single-stream caller pays one uncontended lock and one capture query per cluster launch.  Streams under graph capture are
-// left alone (an outside event must not enter a capture; a replayed graph is the caller's to order), other processes on the
-// same GPU cannot be seen at all: HN_NO_CHAIN_CLUSTER=1 is the switch for those set-ups.
+// Host side of the cluster contract (common.h explains the three parts).  One record per device; everything under its mutex:
+// submission order under the mutex is a total order of the device's cluster launches, and each is ordered behind its
+// predecessor when that went to another stream, so no two cluster kernels of this process run at once.  While only ONE stream
+// has ever carried cluster launches nothing is recorded (a lock and a capture query per launch); the first launch from a second
+// stream drains the device once and switches to recording an event behind every cluster launch.  Streams under graph capture are
+// left alone (an outside event must not enter a capture; a replayed graph is the caller's to order); other processes on the same
+// GPU cannot be seen at all -- the dispatch order of the grid and the bounded, reported wait are what covers those.
 // ------------------------------------------------------------------------------------------------
-void cluster_stream_guard(int dev, hipStream_t s) {
-  struct Guard { std::mutex mu; hipEvent_t ev = nullptr; hipStream_t last = nullptr; bool valid = false; };
-  static Guard guards[64];
-  if (dev < 0 || dev >= 64) return;
-  Guard &g = guards[dev];
-  std::lock_guard<std::mutex> lock(g.mu);
+namespace {
+struct ClusterDev {
+  std::mutex mu;
+  hipEvent_t ev = nullptr;
+  hipStream_t last = nullptr;             // compared only, never passed to HIP again
+  bool any = false, multi = false, ev_valid = false;
+  unsigned *word_host = nullptr, *word_dev = nullptr;
+  bool alloc_failed = false;
+  bool disabled = false;
+  bool inject = false;                    // hn_cluster_config(enable = 2): test hook, every cluster launch loses an exchange
+  unsigned next_token = 0, lost = 0, last_token = 0;
+  int timeout_us = -1;                    // -1: HN_CLUSTER_TIMEOUT_US or the default
+};
+ClusterDev g_cluster[64];
+constexpr int CLUSTER_TIMEOUT_US_DEFAULT = 100000;
+
+bool stream_capturing(hipStream_t s) {
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return; }
-  if (st != hipStreamCaptureStatusNone) return;
-  if (g.valid && g.last != s) {
-    hipStreamCaptureStatus lst = hipStreamCaptureStatusNone;
-    bool ok = hipStreamIsCapturing(g.last, &lst) == hipSuccess && lst == hipStreamCaptureStatusNone;      // (a destroyed stream fails here)
-    if (ok && g.ev == nullptr) ok = hipEventCreateWithFlags(&g.ev, hipEventDisableTiming) == hipSuccess;
-    if (ok) ok = hipEventRecord(g.ev, g.last) == hipSuccess;
-    if (ok) ok = hipStreamWaitEvent(s, g.ev, 0) == hipSuccess;
-    if (!ok) (void)hipGetLastError();
+  if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return true; }      // unknown: treat as "leave alone"
+  return st != hipStreamCaptureStatusNone;
+}
+// the status word: 64 bytes of host-coherent pinned memory, mapped into the device (the ONE allocation this library makes; a kernel
+// only writes it when a wait has run into its bound).  Not attempted from inside a capture.
+void ensure_status_word(ClusterDev &g) {
+  if (g.word_host || g.alloc_failed) return;
+  void *h = nullptr, *d = nullptr;
+  if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess || h == nullptr) {
+    (void)hipGetLastError();
+    g.alloc_failed = true;
+    return;
+  }
+  memset(h, 0, 64);
+  if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess || d == nullptr) {
+    (void)hipGetLastError();
+    (void)hipHostFree(h);
+    g.alloc_failed = true;
+    return;
+  }
+  g.word_host = (unsigned *)h;
+  g.word_dev = (unsigned *)d;
+}
+int timeout_us_of(const ClusterDev &g) {
+  if (g.timeout_us > 0) return g.timeout_us;
+  static const int env = getenv("HN_CLUSTER_TIMEOUT_US") ? atoi(getenv("HN_CLUSTER_TIMEOUT_US")) : 0;
+  return env > 0 ? env : CLUSTER_TIMEOUT_US_DEFAULT;
+}
+}  // namespace
+
+bool cluster_enabled(int dev) {
+  static const bool no_cluster = getenv("HN_NO_CHAIN_CLUSTER") != nullptr;
+  if (no_cluster || dev < 0 || dev >= 64) return false;
+  ClusterDev &g = g_cluster[dev];
+  std::lock_guard<std::mutex> lock(g.mu);
+  return !g.disabled;
+}
+
+void cluster_before_launch(int dev, hipStream_t s, ClusterTicket *t) {
+  t->status = nullptr; t->token = 1; t->wait_ticks = (unsigned)CLUSTER_TIMEOUT_US_DEFAULT * 100u; t->inject_loss = 0;
+  if (dev < 0 || dev >= 64) return;
+  ClusterDev &g = g_cluster[dev];
+  std::lock_guard<std::mutex> lock(g.mu);
+  const bool capturing = stream_capturing(s);
+  if (!capturing) ensure_status_word(g);
+  t->status = g.word_dev;
+  if (++g.next_token == 0) g.next_token = 1;     // 0 means "clean"
+  t->token = g.next_token;
+  t->wait_ticks = (unsigned)timeout_us_of(g) * 100u;      // s_memrealtime: 100 MHz
+  t->inject_loss = g.inject ? 1 : 0;
+  if (capturing) return;
+  if (g.any && g.last != s) {
+    if (!g.multi) {
+      // first cluster launch from a second stream: nothing was recorded behind the launches so far -- drain the device once
+      g.multi = true;
+      if (hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
+    } else if (g.ev_valid) {
+      if (hipStreamWaitEvent(s, g.ev, 0) != hipSuccess) (void)hipGetLastError();
+    }
   }
   g.last = s;
-  g.valid = true;
+  g.any = true;
+}
+
+void cluster_after_launch(int dev, hipStream_t s) {
+  if (dev < 0 || dev >= 64) return;
+  ClusterDev &g = g_cluster[dev];
+  std::lock_guard<std::mutex> lock(g.mu);
+  if (!g.multi || stream_capturing(s)) return;
+  if (g.ev == nullptr && hipEventCreateWithFlags(&g.ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); g.ev = nullptr; return; }
+  g.ev_valid = hipEventRecord(g.ev, s) == hipSuccess;
+  if (!g.ev_valid) (void)hipGetLastError();
+}
+
+int cluster_poll(const char *who) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return HN_OK; }
+  if (dev < 0 || dev >= 64) return HN_OK;
+  ClusterDev &g = g_cluster[dev];
+  std::lock_guard<std::mutex> lock(g.mu);
+  if (!g.word_host) return HN_OK;
+  const unsigned v = *(volatile unsigned *)g.word_host;
+  if (v == 0) return HN_OK;
+  g.disabled = true;
+  g.lost += 1;
+  g.last_token = v;
+  *(volatile unsigned *)g.word_host = 0;
+  return fail(HN_E_CORESIDENCY,
+              "%s: a cluster-mode latent chain launched earlier on device %d (launch token %u) gave up waiting for a member "
+              "workgroup (co-residency lost: busy / masked CUs); the rows of that tile -- and what was computed from them since "
+              "-- are NaN.  Cluster mode is now OFF for this device; repeat the step",
+              who, dev, v);
+}
+
+const unsigned *cluster_status_device_word(int dev) {
+  if (dev < 0 || dev >= 64) return nullptr;
+  ClusterDev &g = g_cluster[dev];
+  std::lock_guard<std::mutex> lock(g.mu);
+  return g.word_dev;
+}
+
+int cluster_status(int dev, int acknowledge, hn_cluster_info *info) {
+  HN_REQUIRE(dev >= 0 && dev < 64, HN_E_SHAPE, "cluster_status: device %d", dev);
+  ClusterDev &g = g_cluster[dev];
+  std::lock_guard<std::mutex> lock(g.mu);
+  int cur = 0;
+  const bool on_dev = hipGetDevice(&cur) == hipSuccess && cur == dev;
+  if (on_dev) ensure_status_word(g);             // (an eager caller asking early also makes sure the word exists before a capture)
+  unsigned v = g.word_host ? *(volatile unsigned *)g.word_host : 0u;
+  if (v != 0 && acknowledge) {
+    g.disabled = true;
+    g.lost += 1;
+    g.last_token = v;
+    *(volatile unsigned *)g.word_host = 0;
+  }
+  if (info) {
+    info->pending = v != 0;
+    info->lost = g.lost;
+    info->last_token = v != 0 ? v : g.last_token;
+    info->enabled = !g.disabled && getenv("HN_NO_CHAIN_CLUSTER") == nullptr;
+    info->timeout_us = timeout_us_of(g);
+    info->status_word = g.word_host;
+  }
+  return HN_OK;
+}
+
+int cluster_config(int dev, int enable, int timeout_us) {
+  HN_REQUIRE(dev >= 0 && dev < 64, HN_E_SHAPE, "cluster_config: device %d", dev);
+  ClusterDev &g = g_cluster[dev];
+  std::lock_guard<std::mutex> lock(g.mu);
+  if (enable >= 0) { g.disabled = enable == 0; g.inject = enable == 2; }
+  if (timeout_us >= 0) g.timeout_us = timeout_us == 0 ? -1 : timeout_us;
+  return HN_OK;
 }
 
 }  // namespace hn

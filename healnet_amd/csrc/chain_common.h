@@ -9,6 +9,43 @@ constexpr int WBLK = WN * WK;           // floats per block (16 KB)
 constexpr int ATILE = CR * WK;          // floats per A k-tile (16 rows x 32 k, 16-byte slots XOR-swizzled by row & 7)
 constexpr int XP = 132;                 // pitch of the x tile
 constexpr int WSLOT = 16 * WK;          // floats per wave and block: 16 weight rows x 32 k (2 KB = two wave-wide 16-byte loads)
+
+// ---- cluster grids (small batches: C = 2 or 4 workgroups share a row tile and exchange partial tiles through the L2) ----
+// Workgroup index -> (member, tile).  Workgroups are dealt round-robin over the 8 XCDs and, on each XCD, dispatched in index
+// order.  A group of 8 C consecutive workgroups holds 8 tiles: index = group * 8 C + member * 8 + tile % 8, so the C members of
+// a tile share an XCD (same index mod 8: one L2 for the exchange) and are CONSECUTIVE in that XCD's dispatch order.  The
+// exchange spins on the other members' flags, and nothing in HIP promises that all workgroups of a grid are resident at once (a
+// CU mask, another process, an RCCL kernel parked on some CUs): with this order the oldest unfinished tile of an XCD always has
+// its members resident or next in line, so the grid makes progress whenever an XCD can hold C workgroups -- the former order
+// (members `tiles` workgroups apart) deadlocked as soon as the LAST member row did not fit beside the others.
+// `split_order` (HN_FORCE_CLUSTER_SPLIT_ORDER=1, the A/B switch of tests/test_gpu_cluster.py) selects that former order.
+__device__ __forceinline__ void cluster_decode(int bid, int C, int ntiles, int split_order, int &member, int &tile) {
+  if (split_order) {
+    member = bid / ntiles;
+    tile = bid - member * ntiles;
+    return;
+  }
+  const int per = 8 * C, g = bid / per, r = bid - g * per;
+  member = r >> 3;
+  tile = g * 8 + (r & 7);
+}
+// Wait (one lane per member flag) until `flag` reaches `seq`, for at most `ticks` of the 100 MHz s_memrealtime clock.  A member
+// that never shows up must neither hang the device nor let the tile carry on with an incomplete sum: the caller turns the tile
+// into NaN, and the loss is REPORTED -- the launch's marker word in the workspace, and the launch's token in the host-mapped
+// status word of the device (hn_cluster_status; the next entry point returns HN_E_CORESIDENCY, hn_l1_adam_step skips).
+__device__ __forceinline__ int cluster_wait(const int *flag, int seq, unsigned ticks, int *marker, unsigned *status, unsigned token) {
+  if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= seq) return 0;
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seq) {
+    __builtin_amdgcn_s_sleep(2);
+    if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)ticks) {
+      *marker = 1;
+      if (status) __hip_atomic_store(status, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return 1;
+    }
+  }
+  return 0;
+}
 // Pointers that arrive inside the argument struct are generic: hipcc emits flat_load / flat_store for them, and with flat
 // operations in flight its wait-count insertion falls back to "wait for everything" in front of every use of a prefetched
 // register.  Everything outside the weight stream therefore goes through explicit global-address-space accesses.

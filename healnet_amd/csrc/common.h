@@ -388,6 +388,9 @@ struct ChainArgs {
   DropCfg ff_drop;                      // training: nn.Dropout on the feed-forward output (:347); thr == 0: off
   int cluster;                          // internal: members per row tile (launch_latent_chain decides)
   int tiles;                            // internal: row tiles (the grid may hold idle workgroups beyond them in cluster mode)
+  unsigned *status; unsigned token, wait_ticks;      // internal: cluster_before_launch (status word of the device, this launch's token, wait bound)
+  int split_order;                      // internal: HN_FORCE_CLUSTER_SPLIT_ORDER (chain_common.h cluster_decode)
+  int inject_loss;                      // internal: hn_cluster_config(enable = 2) -- the last member of every tile withholds its flag
 };
 constexpr int CHAIN_XCHG_FLOATS = 256 * 16 * 128;      // <= 256 workgroups x one partial tile
 constexpr int CHAIN_XCHG_FLAGS = 256 + 1;
@@ -424,6 +427,8 @@ struct BChainArgs {
   DropCfg ff_drop;                     // the forward's dropout on the feed-forward output (thr == 0: off)
   int cluster;                         // internal
   int tiles;                           // internal
+  unsigned *status; unsigned token, wait_ticks;      // internal (cluster_before_launch)
+  int split_order, inject_loss;        // internal
 };
 bool latent_bchain_supported(int rows, int d, int hidden);
 int launch_latent_bchain(const BChainArgs &a, hipStream_t s);
@@ -547,17 +552,31 @@ int launch_temperature_softmax(const float *x, float *y, long rows, int n, float
 int launch_fill_bytes(uint8_t *dst, uint8_t value, long n, hipStream_t s);
 int launch_dropout_apply(const float *src, const float *add, float *out, long rows, int cols, const DropCfg &d, hipStream_t s);
 int launch_dropout_mask(uint8_t *mask, long rows, int cols, const DropCfg &d, hipStream_t s);
-// Cluster-mode chain launches (chain.hip / bchain.hip) spin on the flags of co-resident workgroups; two of them running at once
-// from DIFFERENT streams of one device can starve each other's members (tools/two_stream.py reproduced it: four
-// streams of b = 16 ran into the spin limit).  Called right before such a launch: orders it behind the previous cluster launch
-// of the device when that went to another stream (one event record + stream wait, only in that case).
-void cluster_stream_guard(int dev, hipStream_t s);
+// ---- cluster-mode chain launches (chain.hip / bchain.hip): host side of the co-residency contract ----
+// A cluster launch spins on the flags of workgroups of the same grid.  Three things keep that safe:
+//  * the dispatch order of the grid (cluster_decode, chain_common.h) keeps the members of a tile together, so that a grid
+//    progresses on a partly occupied chip (an RCCL kernel on a side stream, a CU mask);
+//  * two cluster launches of one device never run at once: cluster_before_launch orders a launch behind the previous one when
+//    that went to ANOTHER stream, through an event recorded right behind that launch (cluster_after_launch) -- a stream handle is
+//    only ever compared, never used after the call it arrived in (the old guard recorded on a possibly destroyed stream);
+//  * a wait that still runs into its bound (HN_CLUSTER_TIMEOUT_US, default 100 ms) turns the tile into NaN and stores the
+//    launch's token into the device's host-mapped STATUS WORD.  cluster_poll() -- called first thing by every fused entry point
+//    -- sees a non-zero word, switches cluster mode off for the device (sticky), clears the word and returns HN_E_CORESIDENCY
+//    once; hn_l1_adam_step's kernel reads the word and leaves parameters and moments alone while it is set.
+struct ClusterTicket { unsigned *status; unsigned token, wait_ticks; int inject_loss; };
+bool cluster_enabled(int dev);                                         // false after a lost exchange / hn_cluster_config(enable = 0) / HN_NO_CHAIN_CLUSTER
+void cluster_before_launch(int dev, hipStream_t s, ClusterTicket *t);
+void cluster_after_launch(int dev, hipStream_t s);
+int cluster_poll(const char *who);                                     // HN_OK or HN_E_CORESIDENCY (current device)
+const unsigned *cluster_status_device_word(int dev);                   // device-visible address of the status word, or NULL (never allocated)
+int cluster_status(int dev, int acknowledge, hn_cluster_info *info);
+int cluster_config(int dev, int enable, int timeout_us);
 
 // training-step tail (train.hip)
 int launch_surv_nll(const float *logits, const long long *y, const float *cens, const float *weights, int b, int K, float alpha,
                     float eps, float grad_scale, float *loss, float *dlogits, float *hazards, float *survival, float *risk,
                     hipStream_t s);
-constexpr int L1_ADAM_PARTIALS = 1024;
+constexpr int L1_ADAM_PARTIALS = 1024 + 16;      // one partial |p| sum per block, then the step's snapshot of the cluster status word
 int launch_l1_adam(float *p, const float *g, float *m, float *v, long n, double l1, double grad_scale, double lr, double beta1,
                    double beta2, double eps, int step, float *reg_loss, float *partial, hipStream_t s);
 

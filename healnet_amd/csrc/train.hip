@@ -98,10 +98,26 @@ struct AdamArgs {
 };
 
 __global__ __launch_bounds__(256) void l1_adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
-                                                      float *__restrict__ v, long n, AdamArgs a, float *__restrict__ partial) {
+                                                      float *__restrict__ v, long n, AdamArgs a, float *__restrict__ partial,
+                                                      const unsigned *__restrict__ status_word) {
   float asum = 0.0f;
   const long n4 = n >> 2;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+  // The device's cluster status word (common.h): non-zero = a latent chain of this step lost an exchange and NaN has been on its
+  // way into these gradients since.  The update is then SKIPPED (only l1 * sum |p| is still produced), like a loss-scaler skips an
+  // overflowed step: the host learns of it at its next entry-point call, after this kernel was enqueued.  `status_word` is the
+  // step's SNAPSHOT of the host-mapped word in device memory (status_snapshot_kernel, one PCIe read): reading the mapped word
+  // here, from every wave, cost 750 us per step (r05b: ~90 ns per read, serialised).
+  if (status_word != nullptr && *status_word != 0u) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+      const float4 pp = ((const float4 *)p)[i];
+      asum += (fabsf(pp.x) + fabsf(pp.y)) + (fabsf(pp.z) + fabsf(pp.w));
+    }
+    if (blockIdx.x == 0)
+      for (long i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) asum += fabsf(p[i]);
+    n = 0;                                    // (both update loops below see an empty range)
+  }
+  const long n4u = n >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4u; i += (long)gridDim.x * blockDim.x) {
     float4 pp = ((float4 *)p)[i], gg = ((const float4 *)g)[i], mm = ((float4 *)m)[i], vv = ((float4 *)v)[i];
     float *pa = (float *)&pp, *ga = (float *)&gg, *ma = (float *)&mm, *va = (float *)&vv;
 #pragma unroll
@@ -122,7 +138,7 @@ __global__ __launch_bounds__(256) void l1_adam_kernel(float *__restrict__ p, con
     ((float4 *)v)[i] = vv;
   }
   if (blockIdx.x == 0) {
-    for (long i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) {
+    for (long i = (n4u << 2) + threadIdx.x; i < n; i += blockDim.x) {
       const float x = p[i];
       asum += fabsf(x);
       const float sgn = x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f);
@@ -143,6 +159,10 @@ __global__ __launch_bounds__(256) void l1_adam_kernel(float *__restrict__ p, con
     __syncthreads();
   }
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ void status_snapshot_kernel(const unsigned *__restrict__ host_word, unsigned *__restrict__ snap) {
+  snap[0] = __hip_atomic_load(host_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __global__ __launch_bounds__(256) void l1_norm_reduce_kernel(const float *__restrict__ partial, int n, float scale,
@@ -175,7 +195,16 @@ int launch_l1_adam(float *p, const float *g, float *m, float *v, long n, double 
   a.eps = (float)eps;
   long want = (n / 4 + 255) / 256;
   int blocks = (int)(want < 1 ? 1 : (want > ADAM_BLOCKS ? ADAM_BLOCKS : want));
-  hipLaunchKernelGGL(l1_adam_kernel, dim3(blocks), dim3(256), 0, s, p, g, m, v, n, a, partial);
+  int dev = 0;
+  HN_HIP_CHECK(hipGetDevice(&dev));
+  const unsigned *word = cluster_status_device_word(dev);
+  unsigned *snap = nullptr;
+  if (word != nullptr) {
+    snap = (unsigned *)(partial + ADAM_BLOCKS);
+    hipLaunchKernelGGL(status_snapshot_kernel, dim3(1), dim3(1), 0, s, word, snap);
+    HN_LAUNCH_CHECK("status_snapshot");
+  }
+  hipLaunchKernelGGL(l1_adam_kernel, dim3(blocks), dim3(256), 0, s, p, g, m, v, n, a, partial, (const unsigned *)snap);
   HN_LAUNCH_CHECK("l1_adam");
   if (reg_loss) {
     hipLaunchKernelGGL(l1_norm_reduce_kernel, dim3(1), dim3(256), 0, s, partial, blocks, (float)l1, reg_loss);

@@ -322,6 +322,8 @@ def _fused_context_parallel(model, slabs, begins, totals, split, world, return_e
                 gather_flat(local[:floats], parts[: world * floats])
             except BaseException as e:             # noqa: BLE001
                 failure.append(e)
+                return 1                           # the C loop stops here: no later block calls into a collective the peers left
+            return 0
 
         cb = _capi.CP_EXCHANGE_FN(exchange)
         cp = _capi.ContextSplit(n_parts=world, split_mask=sum(1 << i for i, f in enumerate(split) if f), local=local.data_ptr(),
@@ -389,8 +391,10 @@ def context_parallel_forward(model, tensors: Sequence[Optional[torch.Tensor]], g
         try:
             return _fused_context_parallel(model, slabs, begins, totals, split, world, return_embeddings,
                                            gather_flat or (lambda lo_, pa_: _gather_flat(lo_, pa_, group)))
-        except RuntimeError as e:
-            if fused or "fusion" not in str(e):
+        except _capi_mod().HealnetHipError as e:
+            # only "the chains do not take this model" falls back to the block-level route; launch / workspace / pointer errors (which
+            # also carry the entry point's name in their text -- the old `"fusion" not in str(e)` filter swallowed them all) propagate
+            if fused or e.status != _capi_mod().HN_E_UNSUPPORTED:
                 raise
         split = [False] * M
     with torch.no_grad():
@@ -433,3 +437,8 @@ def context_parallel_forward(model, tensors: Sequence[Optional[torch.Tensor]], g
 def _capi_lib():
     from . import _capi
     return _capi.lib()
+
+
+def _capi_mod():
+    from . import _capi
+    return _capi

@@ -792,6 +792,23 @@ torch.library.register_autograd("healnet_hip::head", _head_backward, setup_conte
 # ------------------------------------------------------------------------------------------------
 # whole fusion stack
 # ------------------------------------------------------------------------------------------------
+def _guarded(call, what: str, device: torch.device, rerun: bool) -> None:
+    """Run a fused entry point; on HN_E_CORESIDENCY (a cluster-mode chain launched EARLIER lost an exchange: include/healnet_hip.h)
+    drain the device, consume the report, warn once -- and either run the call again (``rerun``: its own inputs are clean, and
+    cluster mode is off from here on) or pass the error on (a backward whose tape may already hold the NaN rows: the step has to be
+    repeated from its forward, healnet_amd.train.retry_step does that)."""
+    try:
+        _capi.check(call(), what)
+    except _capi.CoresidencyLost as err:
+        if torch.cuda.is_current_stream_capturing():
+            raise
+        _capi.note_coresidency(err, device.index if device.index is not None else torch.cuda.current_device(),
+                               lambda: torch.cuda.synchronize(device))
+        if not rerun:
+            raise
+        _capi.check(call(), what)
+
+
 def _out_shape(spec: Spec, b: int, embeddings: bool):
     return (b, spec.l_c, spec.l_d) if (embeddings or not spec.head) else (b, spec.out_dims)
 
@@ -827,9 +844,9 @@ def _fusion_forward(tensors, mask, params, spec, skip_self, embeddings, keep_sta
             trace = torch.empty(0, dtype=torch.float32, device=device)
         profile = getattr(_tls, "profile", None)
         _tls.profile = None
-        _capi.check(lib.hn_fusion_forward(C.byref(model), inp, b, _ptr(mask), int(skip_self), int(embeddings), out.data_ptr(),
-                                          stats_ptrs, x_ptrs, ws.data_ptr(), ws.numel(), _stream_ptr(device), profile),
-                    "hn_fusion_forward")
+        _guarded(lambda: lib.hn_fusion_forward(C.byref(model), inp, b, _ptr(mask), int(skip_self), int(embeddings), out.data_ptr(),
+                                               stats_ptrs, x_ptrs, ws.data_ptr(), ws.numel(), _stream_ptr(device), profile),
+                 "hn_fusion_forward", device, rerun=True)
     return out, stats, trace
 
 
@@ -868,9 +885,9 @@ def _fusion_forward_train(tensors, mask, params, spec, skip_self, embeddings, rn
         tape = torch.empty(tape_bytes, dtype=torch.uint8, device=device)
         ws = WS.get(device, need)
         out = torch.empty(_out_shape(sp, b, embeddings), dtype=torch.float32, device=device)
-        _capi.check(lib.hn_fusion_forward_train(C.byref(model), inp, b, _ptr(mask), int(skip_self), int(embeddings), out.data_ptr(),
-                                                None, None, tape.data_ptr(), tape.numel(), ws.data_ptr(), ws.numel(),
-                                                _stream_ptr(device)), "hn_fusion_forward_train")
+        _guarded(lambda: lib.hn_fusion_forward_train(C.byref(model), inp, b, _ptr(mask), int(skip_self), int(embeddings), out.data_ptr(),
+                                                     None, None, tape.data_ptr(), tape.numel(), ws.data_ptr(), ws.numel(),
+                                                     _stream_ptr(device)), "hn_fusion_forward_train", device, rerun=True)
         # where the tape keeps every attention block's softmax statistics / input (float offsets; -1 = block not executed):
         # the host views them in place for Attention.attn_weights -- laid out with THIS call's descriptor (dropout included)
         def _layout():
@@ -913,9 +930,9 @@ def _run_fusion_backward(dout, tape, tensors, mask, params, spec, skip_self, emb
     if hook is not None:
         hook.begin(_stream_ptr(device))
         ready = C.byref(hook.ready)
-    _capi.check(lib.hn_fusion_backward(C.byref(model), inp, b, _ptr(mask), int(skip_self), int(embeddings), dout.data_ptr(),
-                                       tape.data_ptr(), C.byref(grads), ws.data_ptr(), ws.numel(), _stream_ptr(device), ready),
-                "hn_fusion_backward")
+    _guarded(lambda: lib.hn_fusion_backward(C.byref(model), inp, b, _ptr(mask), int(skip_self), int(embeddings), dout.data_ptr(),
+                                            tape.data_ptr(), C.byref(grads), ws.data_ptr(), ws.numel(), _stream_ptr(device), ready),
+             "hn_fusion_backward", device, rerun=False)
     if hook is not None:
         hook.end(_stream_ptr(device))
 

@@ -20,7 +20,7 @@ from __future__ import annotations
 
 import ctypes as C
 from dataclasses import dataclass
-from typing import List, Optional
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
 
@@ -224,54 +224,172 @@ class FusedL1Adam(torch.optim.Optimizer):
         st["step"] = int(st["step"]) + 1
         f = self.flat
         f.relink()
-        _capi.check(_capi.lib().hn_l1_adam_step(f.params.data_ptr(), f.grads.data_ptr(), st["exp_avg"].data_ptr(),
-                                                st["exp_avg_sq"].data_ptr(), f.numel, float(g["l1"]), float(g["grad_scale"]),
-                                                float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
-                                                st["step"], self.reg_loss.data_ptr(), self._ws.data_ptr(), self._ws.numel(),
-                                                _stream(f.params.device)), "hn_l1_adam_step")
+        try:
+            _capi.check(_capi.lib().hn_l1_adam_step(f.params.data_ptr(), f.grads.data_ptr(), st["exp_avg"].data_ptr(),
+                                                    st["exp_avg_sq"].data_ptr(), f.numel, float(g["l1"]), float(g["grad_scale"]),
+                                                    float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+                                                    st["step"], self.reg_loss.data_ptr(), self._ws.data_ptr(), self._ws.numel(),
+                                                    _stream(f.params.device)), "hn_l1_adam_step")
+        except _capi.CoresidencyLost as err:
+            # a cluster-mode chain of THIS step (or of one the host had run ahead of) lost an exchange: the gradients may carry NaN.
+            # The update is skipped -- on the device an already enqueued hn_l1_adam_step does the same by itself -- and the count
+            # taken back; the caller's next step runs without clusters (include/healnet_hip.h "failure signal").
+            dev = f.params.device
+            _capi.note_coresidency(err, dev.index if dev.index is not None else torch.cuda.current_device(),
+                                   lambda: torch.cuda.synchronize(dev))
+            st["step"] = int(st["step"]) - 1
+            self.skipped_steps = getattr(self, "skipped_steps", 0) + 1
         return loss
 
 
+def retry_step(step_fn: Callable[[], object], retries: int = 1):
+    """Run ``step_fn`` (forward + loss + backward of one batch, gradients zeroed INSIDE it) and, when a fused entry point reports
+    HN_E_CORESIDENCY -- a cluster-mode latent chain lost an exchange, the tape / gradients of this step may hold NaN -- run it
+    again: cluster mode is off by then, parameters have not been touched (the report reaches the host before ``opt.step()`` or
+    the device-side skip of hn_l1_adam_step covers it).  The loop body of healnet/main.py:425-467 wrapped once."""
+    for attempt in range(retries + 1):
+        try:
+            return step_fn()
+        except _capi.CoresidencyLost:
+            if attempt == retries:
+                raise
+
+
 class GraphedStep:
-    """The gradient half of a training step -- zero the flat gradients, tape-recording forward, loss, fused backward -- captured ONCE
-    into a HIP graph and replayed with one launch (SURVEY.md 8 f; serves the loop body of healnet/main.py:425-467).
+    """The gradient half of a training step -- zero the flat gradients, tape-recording forward, loss, fused backward -- captured
+    into a HIP graph per input signature and replayed with one launch (SURVEY.md 8 f; serves the loop body of
+    healnet/main.py:425-467).
 
     Why: the step of a patch-bag model is ~450 kernel launches behind two operator calls.  At BASELINE configs[3] the host needs
     3.8-4.9 ms to enqueue what the GPU runs in 5.5 ms, so on a slow or busy host the step stretches to 6.2-6.8 ms; at the reference's
-    tuned TCGA shapes (~90 launches of 5-50 us) the step is host-bound outright.  A replay costs ~0.06 ms of host time.
+    tuned TCGA shapes (~90 launches of 5-50 us) the eager step is host-bound outright (driver box, round 4: +60 % for blca).  A
+    replay costs ~0.06 ms of host time.
 
         flat = healnet_amd.train.flatten_parameters(model)
         opt = healnet_amd.train.FusedL1Adam(flat, ...)
-        step = healnet_amd.train.GraphedStep(model, lambda logits, y, c: surv_nll_loss(logits, y, c).loss, [omic, wsi], (y, c))
+        step = healnet_amd.train.GraphedStep(model, lambda logits, y, c: surv_nll_loss(logits, y, c).loss)
         for omic, wsi, y, c in loader:
             loss, logits = step([omic, wsi], (y, c))      # gradients are in flat.grads; loss / logits are the graph's static outputs
             opt.step()
 
-    * Inputs and loss arguments are copied into static device buffers (same shapes and dtypes as the examples); parameters are read
-      in place, so optimizer updates are seen.  The model must have been through ``flatten_parameters`` (the backward then
-      accumulates into one static buffer and autograd allocates nothing).
+    * A graph is captured the first time an input SIGNATURE is seen -- which modalities are present, every tensor's shape and dtype,
+      the loss arguments' shapes and dtypes, whether a mask is passed -- after ``warmup`` eager runs on a side stream, and replayed
+      from then on: the short last batch of an epoch, or a loader that alternates bag sizes, just adds a graph (``max_graphs``
+      least-recently-used ones are kept; all share one memory pool).  ``example_inputs`` / ``loss_args`` / ``mask`` given to the
+      constructor capture the first signature up front.
+    * Inputs and loss arguments are copied into static device buffers; parameters are read in place, so optimizer updates are
+      seen.  The model must have been through ``flatten_parameters`` (the backward then accumulates into one static buffer and
+      autograd allocates nothing).  The returned loss / output tensors are the graph's static outputs: overwritten by the next
+      replay of the same signature.
     * Dropout: a captured launch bakes the Philox offset into its kernel arguments, so every replay would draw the SAME masks.  The
-      model therefore hands its kernels a device word (``hn_rng.offset_dev``) that is added to the offset on the device, and the
-      graph's first node increments it: every replay draws fresh masks, forward and backward of one replay the same ones.
+      model therefore hands its kernels a device word (``hn_rng.offset_dev``) that is added to the offset on the device, and every
+      graph's first node increments it: every replay draws fresh masks, forward and backward of one replay the same ones.  The word
+      belongs to the MODEL and is shared (reference-counted) by all GraphedStep objects on it.
     * ``loss_fn(output, *loss_args)`` must return a scalar tensor and may only use capture-safe operations (no ``.item()``, no
-      host synchronisation)."""
+      host synchronisation).
+    * No entry point of the library runs during a replay, so the cluster-mode failure signal (include/healnet_hip.h) is polled
+      here: a pending report drops every captured graph (they hold cluster launches), and the step is captured again without
+      clusters and run."""
 
-    def __init__(self, model: torch.nn.Module, loss_fn, example_inputs: Sequence[Optional[torch.Tensor]], loss_args: Sequence[torch.Tensor] = (),
-                 mask: Optional[torch.Tensor] = None, warmup: int = 3):
+    def __init__(self, model: torch.nn.Module, loss_fn, example_inputs: Optional[Sequence[Optional[torch.Tensor]]] = None,
+                 loss_args: Sequence[torch.Tensor] = (), mask: Optional[torch.Tensor] = None, warmup: int = 3, max_graphs: int = 8):
         flat = model.__dict__.get("_hn_flat")
         if flat is None:
             raise ValueError("GraphedStep needs healnet_amd.train.flatten_parameters(model) first (static gradient buffer)")
-        dev = flat.grads.device
+        self.device = flat.grads.device
         self.model, self.flat, self.loss_fn = model, flat, loss_fn
-        self.inputs = [None if t is None else t.detach().to(dev).clone() for t in example_inputs]
+        self.warmup, self.max_graphs = max(1, int(warmup)), max(1, int(max_graphs))
+        # the device word of the dropout generator (harmless without dropout); kept on the model so that its forward passes it on
+        word = model.__dict__.get("_hn_rng_word")
+        if word is None:
+            word = torch.zeros(1, dtype=torch.int32, device=self.device)
+            model.__dict__["_hn_rng_word"] = word
+            model.__dict__["_hn_rng_word_users"] = 0
+        model.__dict__["_hn_rng_word_users"] = model.__dict__.get("_hn_rng_word_users", 0) + 1
+        self.word = word
+        self._closed = False
+        self._graphs: Dict[tuple, "_CapturedStep"] = {}
+        self._pool = None
+        self.captures = 0
+        _capi.cluster_status(self._dev_index())          # (creates the device's status word before anything is captured)
+        if example_inputs is not None:
+            self._get(self._signature(example_inputs, loss_args, mask), example_inputs, loss_args, mask)
+
+    # -- compatibility with the single-graph object of round 4 (tests / tools read these)
+    @property
+    def graph(self):
+        return next(reversed(self._graphs.values())).graph
+
+    def _dev_index(self) -> int:
+        return self.device.index if self.device.index is not None else torch.cuda.current_device()
+
+    @staticmethod
+    def _signature(inputs, loss_args, mask) -> tuple:
+        def sig(t):
+            return None if t is None else (tuple(t.shape), t.dtype)
+        return (tuple(sig(t) for t in inputs), tuple(sig(t) for t in loss_args), sig(mask))
+
+    def _get(self, key, inputs, loss_args, mask) -> "_CapturedStep":
+        g = self._graphs.pop(key, None)
+        if g is None:
+            while len(self._graphs) >= self.max_graphs:
+                self._graphs.pop(next(iter(self._graphs)))
+            if not self._graphs:
+                self._pool = None                  # (the shared pool dies with its last graph)
+            g = _CapturedStep(self, inputs, loss_args, mask)
+            self.captures += 1
+        self._graphs[key] = g                      # most recently used last
+        return g
+
+    def __call__(self, inputs: Sequence[Optional[torch.Tensor]], loss_args: Sequence[torch.Tensor] = (), mask: Optional[torch.Tensor] = None):
+        if self._closed:
+            raise RuntimeError("GraphedStep: called after close()")
+        for t in list(inputs) + list(loss_args) + [mask]:
+            if t is not None and not isinstance(t, torch.Tensor):
+                raise TypeError(f"GraphedStep: expected tensors, got {type(t).__name__}")
+        if _capi.cluster_status(self._dev_index())["pending"]:
+            # a replayed cluster launch lost an exchange (the device-side skip kept the optimizer from applying that step): every
+            # graph holds such launches -- drop them all, consume the report (cluster mode goes off), capture afresh below
+            torch.cuda.synchronize(self.device)
+            self._graphs.clear()
+            self._pool = None                      # (the shared pool dies with its last graph)
+            try:
+                raise _capi.CoresidencyLost(_capi.HN_E_CORESIDENCY, "GraphedStep", "a replayed cluster-mode latent chain lost an exchange; "
+                                            "the captured graphs were dropped and the step is captured again without cluster mode")
+            except _capi.CoresidencyLost as err:
+                _capi.note_coresidency(err, self._dev_index(), lambda: None)
+        g = self._get(self._signature(inputs, loss_args, mask), inputs, loss_args, mask)
+        g.load(inputs, loss_args, mask)
+        g.graph.replay()
+        return g.loss, g.output
+
+    def close(self) -> None:
+        """Detach from the model; when the last GraphedStep of the model closes, its eager forwards go back to host-advanced
+        offsets only."""
+        if self._closed:
+            return
+        self._closed = True
+        self._graphs.clear()
+        users = self.model.__dict__.get("_hn_rng_word_users", 1) - 1
+        if users <= 0:
+            self.model.__dict__.pop("_hn_rng_word", None)
+            self.model.__dict__.pop("_hn_rng_word_users", None)
+        else:
+            self.model.__dict__["_hn_rng_word_users"] = users
+
+
+class _CapturedStep:
+    """One captured signature of a GraphedStep: static input buffers, the graph, its static outputs."""
+
+    def __init__(self, owner: GraphedStep, inputs, loss_args, mask):
+        dev = owner.device
+        self.inputs = [None if t is None else t.detach().to(dev).clone() for t in inputs]
         self.loss_args = [t.detach().to(dev).clone() for t in loss_args]
         self.mask = None if mask is None else mask.detach().to(dev).clone()
-        # the device word of the dropout generator (harmless without dropout); kept on the model so that its forward passes it on
-        self.word = torch.zeros(1, dtype=torch.int32, device=dev)
-        model.__dict__["_hn_rng_word"] = self.word
+        model, flat, loss_fn, word = owner.model, owner.flat, owner.loss_fn, owner.word
 
         def body():
-            self.word.add_(1)
+            word.add_(1)
             flat.zero_grad()
             out = model(list(self.inputs), mask=self.mask)
             loss = loss_fn(out, *self.loss_args)
@@ -281,28 +399,27 @@ class GraphedStep:
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
-            for _ in range(max(1, warmup)):          # allocator, workspaces, descriptor caches and the autograd thread's state settle
-                body()
+            for _ in range(owner.warmup):            # allocator, workspaces, descriptor caches and the autograd thread's state settle
+                retry_step(body)
         torch.cuda.current_stream(dev).wait_stream(side)
+        # nothing may be pending when the capture starts (an entry point that finds a report returns HN_E_CORESIDENCY, which would
+        # abort the capture): drain, and consume a report of the warm-up runs -- the capture then holds no cluster launches
+        torch.cuda.synchronize(dev)
+        if _capi.cluster_status(owner._dev_index())["pending"]:
+            _capi.note_coresidency(_capi.CoresidencyLost(_capi.HN_E_CORESIDENCY, "GraphedStep", "a warm-up run lost a cluster exchange; "
+                                                         "capturing without cluster mode"), owner._dev_index(), lambda: None)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        if owner._pool is None:
+            owner._pool = torch.cuda.graph_pool_handle()
+        with torch.cuda.graph(self.graph, pool=owner._pool):
             self.loss, self.output = body()
 
-    def __call__(self, inputs: Sequence[Optional[torch.Tensor]], loss_args: Sequence[torch.Tensor] = (), mask: Optional[torch.Tensor] = None):
+    def load(self, inputs, loss_args, mask) -> None:
+        # (presence, shapes and dtypes are the signature this object was looked up by: they match)
         for dst, src in zip(self.inputs, inputs):
-            if (dst is None) != (src is None):
-                raise ValueError("GraphedStep: the set of present modalities is part of the captured graph")
             if dst is not None:
-                if dst.shape != src.shape or dst.dtype != src.dtype:
-                    raise ValueError(f"GraphedStep: captured for {tuple(dst.shape)} {dst.dtype}, got {tuple(src.shape)} {src.dtype}")
                 dst.copy_(src, non_blocking=True)
         for dst, src in zip(self.loss_args, loss_args):
             dst.copy_(src, non_blocking=True)
-        if self.mask is not None and mask is not None:
+        if self.mask is not None:
             self.mask.copy_(mask, non_blocking=True)
-        self.graph.replay()
-        return self.loss, self.output
-
-    def close(self) -> None:
-        """Detach from the model (its eager forwards go back to host-advanced offsets only)."""
-        self.model.__dict__.pop("_hn_rng_word", None)

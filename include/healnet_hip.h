@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HN_ABI_VERSION 9
+#define HN_ABI_VERSION 10
 #define HN_MAX_AXES 4
 
 typedef enum hn_status {
@@ -36,7 +36,9 @@ typedef enum hn_status {
   HN_E_UNSUPPORTED = -2, /* valid request the kernels do not cover (e.g. dim_head > 128)         */
   HN_E_WORKSPACE = -3,   /* workspace NULL, misaligned or smaller than hn_*_workspace_bytes()    */
   HN_E_HIP = -4,         /* a HIP runtime call / kernel launch failed                            */
-  HN_E_NULL = -5         /* a required pointer is NULL                                           */
+  HN_E_NULL = -5,        /* a required pointer is NULL                                           */
+  HN_E_CORESIDENCY = -6  /* ABI v10: a cluster-mode latent chain launched EARLIER on this device gave up waiting for a
+                          * member workgroup (see hn_cluster_status); nothing was launched by the call that returns it  */
 } hn_status;
 
 /* Gate of the feed-forward block: SELU (healnet.py:328-331, snn=True) or GELU (:323-326). */
@@ -341,6 +343,39 @@ typedef struct hn_kernel_timer {
 } hn_kernel_timer;
 int hn_set_kernel_timers(hn_kernel_timer *timers, int n);
 
+/* ---- Cluster mode of the latent chains and its failure signal (ABI v10) ------------------------------------------------------
+ * Small batches (b * l_c / 16 <= 128 row tiles) run the latent chains of hn_fusion_forward / _forward_train / _backward as
+ * CLUSTERS: 2 or 4 workgroups share a row tile and exchange partial sums through the L2, each spinning on the others' flags.
+ * HIP does not promise that all workgroups of a grid are resident at once.  The grid's dispatch order keeps the members of a
+ * tile adjacent, so a partly occupied chip (an RCCL kernel on another stream, a CU mask) only slows the launch down; should a
+ * member still not show up within the wait bound (default 100 ms, HN_CLUSTER_TIMEOUT_US / hn_cluster_config), the tile's rows
+ * become NaN -- never a silently incomplete sum -- and the launch stores its token into a host-mapped status word of the device
+ * (64 bytes of pinned memory, the only allocation this library ever makes; created by the first eager cluster launch or
+ * hn_cluster_status call on the device).  From then on:
+ *   - the NEXT call of hn_fusion_forward / hn_fusion_forward_cp / hn_fusion_forward_train / hn_fusion_backward / hn_l1_adam_step
+ *     on that device launches nothing, switches cluster mode off for the device (sticky), clears the word and returns
+ *     HN_E_CORESIDENCY (hn_last_error_string names the launch).  Outputs produced since the lost exchange may hold NaN: repeat
+ *     the step (all later launches run the same arithmetic without clusters);
+ *   - an hn_l1_adam_step that was ALREADY enqueued when the exchange was lost reads the word on the device and leaves
+ *     parameters and moments untouched, so a poisoned gradient never reaches the weights of this process;
+ *   - a caller that replays captured graphs (no entry point runs) polls hn_cluster_status itself.
+ * hn_cluster_status(device, acknowledge, info): query; with acknowledge != 0 a pending loss is consumed exactly as the entry
+ * points do (mode off, word cleared).  hn_cluster_config(device, enable, timeout_us): enable 0 / 1 switches the mode off / back on
+ * (-1: keep; 2: on WITH FAULT INJECTION -- the last member of every tile withholds its flag, so every cluster launch loses an
+ * exchange after the wait bound: the hook the tests drive this protocol with); timeout_us > 0 sets the wait bound, 0 restores
+ * the default (-1: keep).  HN_NO_CHAIN_CLUSTER=1 in the environment
+ * disables the mode for the process. */
+typedef struct hn_cluster_info {
+  int pending;                    /* a lost exchange has been reported by a kernel and not yet consumed              */
+  int enabled;                    /* cluster mode currently allowed on the device                                      */
+  unsigned lost;                  /* losses consumed so far (entry points + acknowledging status calls)                */
+  unsigned last_token;            /* token of the most recent reporting launch (0: none)                               */
+  int timeout_us;                 /* wait bound in force                                                               */
+  const volatile unsigned *status_word;   /* host address of the mapped word (0 = clean), or NULL before its creation  */
+} hn_cluster_info;
+int hn_cluster_status(int device, int acknowledge, hn_cluster_info *info);
+int hn_cluster_config(int device, int enable, int timeout_us);
+
 /* out: (b, out_dims) logits, or (b, l_c, l_d) when return_embeddings != 0 or the model has no head.
  * skip_self_on_missing reproduces the reference's verbose=True quirk (:229-232): bit i set -> when modality i is
  * missing, that iteration's latent self block is skipped as well (the `continue` under `if verbose`).  The reference
@@ -364,8 +399,10 @@ size_t hn_fusion_workspace_bytes(const hn_model *model, const hn_modality_input 
  * `stream` -- and folds the parts in rank order; out-projection, feed-forward and the next projections run on the latent chains as
  * in hn_fusion_forward.  Everything else is replicated.  fp32 core, no mask, no missing modality, default (unstaged) shapes; a
  * model the chains do not take is refused (HN_E_UNSUPPORTED: use the block-level entry points).  `local` / `parts` hold
- * hn_context_split_floats() / n_parts times that many floats.  Workspace: hn_fusion_workspace_bytes() of the slab inputs. */
-typedef void (*hn_cp_exchange_fn)(void *user, int floats, void *stream);
+ * hn_context_split_floats() / n_parts times that many floats.  Workspace: hn_fusion_workspace_bytes() of the slab inputs.
+ * ABI v10: the callback returns 0, or non-zero when the collective could not be enqueued -- the entry point then stops at once
+ * and returns HN_E_HIP (it used to carry on calling `exchange` for the later blocks while the peers sat in the failed one). */
+typedef int (*hn_cp_exchange_fn)(void *user, int floats, void *stream);
 typedef struct hn_context_split {
   int n_parts;
   unsigned split_mask;

@@ -163,8 +163,19 @@ def test_graphed_step_equals_eager_bit_for_bit(hn):
         assert torch.equal(grads_g, flat.grads), f"trial {trial}: replayed gradients differ from the eager step"
         with torch.no_grad():                                 # parameters are read in place: an update is seen by the next replay
             flat.params.mul_(1.0 + 1e-3 * (trial + 1))
-    with pytest.raises(ValueError, match="captured for"):
-        step([ins[0], ins[1][:, :100]], la)
+    # a new input signature (another bag length) is captured on first sight and replayed from then on (round 5; it used to raise)
+    assert step.captures == 1
+    short = [ins[0], ins[1][:, :100].contiguous()]
+    for trial in range(2):
+        loss_g, out_g = step(short, la)
+        loss_g, grads_g = loss_g.clone(), flat.grads.clone()
+        flat.zero_grad()
+        loss_e = _loss(hn)(model(list(short)), *la)
+        loss_e.backward()
+        assert torch.equal(loss_g, loss_e.detach()) and torch.equal(grads_g, flat.grads)
+    assert step.captures == 2
+    step(ins, la)
+    assert step.captures == 2                                 # the first signature's graph is still there
     with pytest.raises(ValueError, match="flatten_parameters"):
         hn.train.GraphedStep(hn.HealNet(n_modalities=1, channel_dims=[8], num_spatial_axes=[1], out_dims=2, depth=1).train().to(DEV),
                              _loss(hn), [torch.rand(2, 1, 8, device=DEV)], ())
@@ -198,3 +209,56 @@ def test_graphed_step_draws_fresh_dropout_masks(hn):
     assert float(loss_e) == loss_g and torch.equal(flat.grads, grads_g)
     step.close()
     assert "_hn_rng_word" not in model.__dict__
+
+
+def test_graphed_step_serves_the_reference_training_loop(hn):
+    """The loop body of healnet/main.py:425-467 on GraphedStep with no example batch: an "epoch" whose last batch is short and a
+    loader that alternates two bag lengths -- every (shape) signature is captured once (after its eager warm-up) and replayed; the
+    parameters after the epochs equal those of the same loop run eagerly (same optimizer, same data), bit for bit."""
+    def run(graphed):
+        model, flat = _bag_model(hn, dropout=False)
+        opt = hn.train.FusedL1Adam(flat, lr=1e-3, l1=1e-5)
+        step = hn.train.GraphedStep(model, _loss(hn), warmup=1) if graphed else None
+        gen = torch.Generator().manual_seed(77)
+        losses = []
+        for epoch in range(2):
+            for it, (b, n) in enumerate([(4, 300), (4, 200), (4, 300), (4, 200), (3, 300)]):      # the last batch of the epoch is short
+                ins = [torch.rand(b, 1, 40, generator=gen).to(DEV), torch.rand(b, n, 96, generator=gen).to(DEV)]
+                la = (torch.randint(0, 4, (b,), generator=gen).to(DEV), torch.randint(0, 2, (b,), generator=gen).to(DEV))
+                if graphed:
+                    loss, logits = step(ins, la)
+                else:
+                    opt.zero_grad()
+                    logits = model(list(ins))
+                    loss = _loss(hn)(logits, *la)
+                    loss.backward()
+                opt.step()
+                losses.append(float(loss))
+        if graphed:
+            assert step.captures == 3, step.captures
+            step.close()
+        return losses, flat.params.clone()
+
+    losses_e, params_e = run(False)
+    losses_g, params_g = run(True)
+    assert losses_g == losses_e
+    assert torch.equal(params_g, params_e)
+
+
+def test_graphed_steps_share_the_models_dropout_word(hn):
+    """Two GraphedStep objects on one model: the dropout word belongs to the model and is reference-counted -- closing
+    one leaves the other's replays drawing fresh masks; the last close detaches it."""
+    model, flat = _bag_model(hn, dropout=True)
+    gen = torch.Generator().manual_seed(35)
+    ins, la = _batch(gen)
+    a = hn.train.GraphedStep(model, _loss(hn), ins, la)
+    b = hn.train.GraphedStep(model, _loss(hn), ins, la)
+    assert a.word is b.word
+    a.close()
+    assert "_hn_rng_word" in model.__dict__
+    losses = [float(b(ins, la)[0]) for _ in range(3)]
+    assert len(set(losses)) == 3, losses
+    b.close()
+    assert "_hn_rng_word" not in model.__dict__
+    with pytest.raises(RuntimeError, match="after close"):
+        b(ins, la)
