@@ -215,6 +215,41 @@ static float *saved_kv(const AttnPlan &pl, bool has_ctx, bool masked, int b, int
   return saved + align_up(rows16((size_t)b * L) * pl.inner, 64);
 }
 
+// K | V = affine(ctx) W_kv^T of an explicit cross binding into `kvbuf` (pitch 2 heads dhp; pad columns of a padded head width are
+// zero): the bf16 product on the bf16 context image (inference, core_precision = bf16), the LDS-DMA fp32 product on the staged
+// weight (patch bags), or the generic GEMM.  `wstage`: the plan's staging scratch.
+static int project_ctx_kv(const hn_attn_params *p, const AttnPlan &pl, const float *ctx, int ld_ctx, int b, float *kvbuf, float *wstage,
+                          const uint16_t *ctx16, hipStream_t s) {
+  const int kvpitch = 2 * p->heads * pl.dhp;
+  static const bool no_glds = getenv("HN_NO_GLDS_GEMM") != nullptr;      // development switch: gemm_big_kernel / gemm_tall_narrow
+  // the LDS-DMA projection lays the padded head width out itself (pad columns = 0): no fill in front of it
+  const bool kv_nt = !ctx16 && wstage && !no_glds &&
+                     gemm_nt_eligible((long)b * pl.N, 2 * pl.inner, pl.D, ld_ctx, ctx, pl.dh, pl.dhp, kvpitch, kvbuf);
+  int rc;
+  if (pl.dhp != pl.dh && !kv_nt && (rc = launch_fill(kvbuf, 0.0f, (long)((size_t)b * pl.N * kvpitch), s)) != HN_OK) return rc;
+  GemmArgs gk = gemm_defaults();
+  gk.A = ctx; gk.lda = ld_ctx; gk.M = b * pl.N; gk.K = pl.D;
+  if (p->ctx_gamma) { gk.pro = PRO_AFFINE; gk.gamma = p->ctx_gamma; gk.beta = p->ctx_beta; }
+  gk.W = p->w_kv; gk.ldw = pl.D;
+  gk.N = 2 * pl.inner;
+  gk.C = kvbuf; gk.ldc = kvpitch; gk.col_group = pl.dh; gk.col_group_pitch = pl.dhp;
+  if (ctx16 && wstage && gemm_bf16_eligible(gk)) return launch_gemm_bf16(gk, ctx16, wstage, s);
+  if (wstage && !no_glds && gemm_nt_eligible(gk.M, gk.N, gk.K, gk.lda, gk.A, gk.col_group, gk.col_group_pitch, gk.ldc, gk.C)) {
+    // patch-bag K/V projection: LayerNorm affine folded into the staged weight, operands by LDS-DMA (gemm_nt.hip); a padded head
+    // width is laid out by the staging, so the product writes dense rows (pad columns = 0) and needs no fill in front
+    const int np = gemm_nt_padded_cols(gk.N, gk.col_group, gk.col_group_pitch);
+    float *ws_w = wstage, *ws_b = wstage + (size_t)np * gemm_nt_ldws(gk.K);
+    if ((rc = launch_gemm_nt_stage(gk.W, gk.ldw, gk.pro == PRO_AFFINE ? gk.gamma : nullptr, gk.pro == PRO_AFFINE ? gk.beta : nullptr, nullptr,
+                                   gk.N, gk.K, ws_w, ws_b, s, gk.col_group, gk.col_group_pitch)) != HN_OK) return rc;
+    GemmNtArgs gn;
+    gn.A = gk.A; gn.lda = gk.lda; gn.W = ws_w; gn.ldw = gemm_nt_ldws(gk.K); gn.bias = ws_b; gn.C = gk.C; gn.ldc = gk.ldc;
+    gn.M = gk.M; gn.N = np; gn.K = gk.K; gn.alpha = 1.0f; gn.col_group = 0; gn.col_group_pitch = 0;
+    gn.ntm = gn.ntn = 0;
+    return launch_gemm_nt(gn, 0, s);
+  }
+  return launch_gemm(gk, s);
+}
+
 // kv_tape (explicit cross binding, training): the projected K / V live in the tape instead of the workspace; the forward
 // writes them there, the backward (kv_ready) reads them back instead of re-running the K/V projection GEMM.
 static int attn_prepare(const hn_attn_params *p, const AttnPlan &pl, const float *x_in, const float *ctx, int ld_ctx,
@@ -270,15 +305,11 @@ static int attn_prepare(const hn_attn_params *p, const AttnPlan &pl, const float
     HN_REQUIRE(!(ext && ext->kv_done) || kv_ext, HN_E_SHAPE, "attn: external K/V projections exist for latent self-attention only");
     float *kvbuf = kv_tape ? kv_tape : (kv_ext ? ext->kv : ((ext && ext->kv_home && !ctx) ? ext->kv_home : pl.kv));
     if (kv_ext) kv_ready = true;
-    static const bool no_glds = getenv("HN_NO_GLDS_GEMM") != nullptr;      // development switch: gemm_big_kernel / gemm_tall_narrow
-    // the LDS-DMA projection lays the padded head width out itself (pad columns = 0): no fill in front of it
-    const bool kv_nt = ctx && !kv_ready && !pl.ctx16 && pl.wstage && !no_glds &&
-                       gemm_nt_eligible((long)b * pl.N, 2 * pl.inner, pl.D, ld_ctx, ctx, pl.dh, pl.dhp, kvpitch, kvbuf);
     if (pl.dhp != pl.dh) {
       // (projections found ready with a padded head width were written by this block's own forward into its tape slot, pad
       // columns included: the chain only projects for dim_head in {16, 32, 64, 128})
       if (!q_done) { int rc_ = launch_fill(qbuf, 0.0f, (long)((size_t)rows * qpitch), s); if (rc_ != HN_OK) return rc_; }
-      if (!kv_ready && !kv_nt) { int rc_ = launch_fill(kvbuf, 0.0f, (long)((size_t)b * pl.N * kvpitch), s); if (rc_ != HN_OK) return rc_; }
+      if (!kv_ready && !ctx) { int rc_ = launch_fill(kvbuf, 0.0f, (long)((size_t)b * pl.N * kvpitch), s); if (rc_ != HN_OK) return rc_; }
     }
     gq.C = qbuf; gq.ldc = qpitch; gq.alpha = pl.cscale;
     gq.col_group = pl.dh; gq.col_group_pitch = pl.dhp;
@@ -289,34 +320,16 @@ static int attn_prepare(const hn_attn_params *p, const AttnPlan &pl, const float
       gq.col_group2 = pl.dh; gq.col_group_pitch2 = pl.dhp;
     }
     if (!q_done && (rc = launch_gemm(gq, s)) != HN_OK) return rc;
-    if (!kv_ready && !fused_kv) {
+    if (!kv_ready && ctx) {
+      if ((rc = project_ctx_kv(p, pl, ctx, ld_ctx, b, kvbuf, pl.wstage, pl.ctx16, s)) != HN_OK) return rc;
+    } else if (!kv_ready && !fused_kv) {   // self-attention behind a chain that projected Q only: context = normalised x (healnet.py:404)
       GemmArgs gk = gemm_defaults();
-      if (ctx) {
-        gk.A = ctx; gk.lda = ld_ctx; gk.M = b * pl.N; gk.K = pl.D;
-        if (p->ctx_gamma) { gk.pro = PRO_AFFINE; gk.gamma = p->ctx_gamma; gk.beta = p->ctx_beta; }
-      } else {   // self-attention: context = normalised x (healnet.py:404)
-        gk.A = x_in; gk.lda = p->query_dim; gk.M = rows; gk.K = p->query_dim;
-        if (p->norm_w) { gk.pro = PRO_LAYERNORM; gk.gamma = p->norm_w; gk.beta = p->norm_b; }
-      }
+      gk.A = x_in; gk.lda = p->query_dim; gk.M = rows; gk.K = p->query_dim;
+      if (p->norm_w) { gk.pro = PRO_LAYERNORM; gk.gamma = p->norm_w; gk.beta = p->norm_b; }
       gk.W = p->w_kv; gk.ldw = pl.D;
       gk.N = 2 * pl.inner;
       gk.C = kvbuf; gk.ldc = kvpitch; gk.col_group = pl.dh; gk.col_group_pitch = pl.dhp;
-      if (ctx && pl.ctx16 && pl.wstage && gemm_bf16_eligible(gk)) rc = launch_gemm_bf16(gk, pl.ctx16, pl.wstage, s);
-      else if (ctx && pl.wstage && !no_glds && gk.pro != PRO_LAYERNORM &&
-               gemm_nt_eligible(gk.M, gk.N, gk.K, gk.lda, gk.A, gk.col_group, gk.col_group_pitch, gk.ldc, gk.C)) {
-        // patch-bag K/V projection: LayerNorm affine folded into the staged weight, operands by LDS-DMA (gemm_nt.hip); a padded head
-        // width is laid out by the staging, so the product writes dense rows (pad columns = 0) and needs no fill in front
-        const int np = gemm_nt_padded_cols(gk.N, gk.col_group, gk.col_group_pitch);
-        float *ws_w = pl.wstage, *ws_b = pl.wstage + (size_t)np * gemm_nt_ldws(gk.K);
-        if ((rc = launch_gemm_nt_stage(gk.W, gk.ldw, gk.pro == PRO_AFFINE ? gk.gamma : nullptr, gk.pro == PRO_AFFINE ? gk.beta : nullptr, nullptr,
-                                       gk.N, gk.K, ws_w, ws_b, s, gk.col_group, gk.col_group_pitch)) != HN_OK) return rc;
-        GemmNtArgs gn;
-        gn.A = gk.A; gn.lda = gk.lda; gn.W = ws_w; gn.ldw = gemm_nt_ldws(gk.K); gn.bias = ws_b; gn.C = gk.C; gn.ldc = gk.ldc;
-        gn.M = gk.M; gn.N = np; gn.K = gk.K; gn.alpha = 1.0f; gn.col_group = 0; gn.col_group_pitch = 0;
-        gn.ntm = gn.ntn = 0;
-        rc = launch_gemm_nt(gn, 0, s);
-      } else rc = launch_gemm(gk, s);
-      if (rc != HN_OK) return rc;
+      if ((rc = launch_gemm(gk, s)) != HN_OK) return rc;
     }
     core->Q = qbuf; core->q_b = (long)L * qpitch; core->q_h = pl.dhp; core->ldq = qpitch;
     core->Kp = kvbuf; core->k_b = (long)pl.N * kvpitch; core->k_h = pl.dhp; core->ldk = kvpitch;
