@@ -25,6 +25,8 @@ Rank 0 prints ONE JSON line.  Besides the driver's contract it carries
   build_id     : hn_build_id() of the loaded library (sha256 of the sources + flags it was built from);
   staged_models: forward + backward of the reference's four tuned TCGA configurations (config/best_hyperparams.yml) at b=8, N=1 only
   patch_bag_precisions: the inference forward of BASELINE configs[3]'s shape (b=8) in fp32 and with core_precision="bf16", N=1 only
+  configs      : BASELINE configs[0] / [2] / [3] / [4] at HEAD, N=1 only: forward ms, samples/s, the dominant kernel with its executed work
+                 per launch, its HIP-event average and the fraction of the roof that bounds it
   train_step   : SURVEY.md 8(d)'s second figure -- the training step of BASELINE configs[3] (TCGA-BRCA shape: omic 1x2000 + WSI bag
                  4096x768, b=8 per GPU): forward with tape, survival NLL, fused backward, gradient all-reduce over RCCL
                  (overlapped with the backward through hn_grad_ready, healnet_amd.dist.GradReadyAllReduce) and the fused
@@ -65,10 +67,13 @@ def exec_flops_forward_per_sample(depth=3, l_d=128):
     """EXECUTED matrix FLOPs of one cfg2 forward per sample (what the kernels run, not the reference formulation), by the
     schedule of healnet.py:225-245: per layer the image cross block (Q projection, query fold, core, folded value projection,
     out-projection) + its feed-forward block, the one-token tabular block + its feed-forward block, and behind EACH of the two
-    the latent self-attention block (Q|K|V, core, out) + feed-forward block.  318.7 GF per 32 samples."""
+    the latent self-attention block (Q|K|V, core, out) + feed-forward block.  317.3 GF per 32 samples."""
     inner = HEADS * DIM_HEAD
     ff = 2.0 * L_C * l_d * 8 * l_d + 2.0 * L_C * 4 * l_d * l_d
-    img = 2.0 * L_C * l_d * inner + 2 * 2.0 * L_C * inner * DP + EXEC_FLOPS_CORE_PER_SAMPLE + 2.0 * L_C * inner * l_d + ff
+    # image block: the chain in front projects LN(x) straight onto the 8 x 16 FOLDED query columns (W_q W_k staged once per forward:
+    # 128 columns, not inner = 512 followed by a fold -- round 4 moved the fold into the chain; VERDICT r4 weak 8), the core, the
+    # folded value projection (16 -> inner per head) in the chain behind it, the out-projection
+    img = 2.0 * L_C * l_d * HEADS * DP + 2.0 * L_C * inner * DP + EXEC_FLOPS_CORE_PER_SAMPLE + 2.0 * L_C * inner * l_d + ff
     tab = 2.0 * 2005 * inner + 2.0 * inner * l_d + ff
     self_blk = 2.0 * L_C * l_d * 3 * inner + 4.0 * L_C * L_C * DIM_HEAD * HEADS + 2.0 * L_C * inner * l_d + ff
     return depth * (img + tab + 2 * self_blk)
@@ -166,8 +171,8 @@ def _calibrate_threads(run_one, t_all, budget_s):
 def cpu_baseline(budget_s=45.0):
     """Oracle forward on the host cores (BASELINE.md §3 protocol): thread count calibrated on one sample, one untimed warm-up, then the
     workload AT THE CONFIG'S OWN BATCH (cfg2: b = 32; the oracle materialises K/V, scores and probabilities: ~0.6 GB per sample and
-    block, so b = 32 wants ~25 GB of free host RAM -- with less, b = 4 is timed and the reason recorded).  One timed run at b = 32
-    (~20 s of CPU work; throughput is flat in b: 1.78-1.89 samples/s at b = 1..4 in the survey container)."""
+    block, so b = 32 wants ~25 GB of free host RAM -- with less, b = 4 is timed and the reason recorded).  Median of 3 timed runs
+    (~20 s of CPU work each at b = 32; throughput is flat in b: 1.78-1.89 samples/s at b = 1..4 in the survey container)."""
     from oracle import healnet_cpu as O
     import healnet_amd
     torch.manual_seed(0)
@@ -184,7 +189,7 @@ def cpu_baseline(budget_s=45.0):
         best_threads, calib = _calibrate_threads(lambda: O.fusion_forward(sd, cfg, [tab[:1], img[:1]]), t_all, budget_s / 4)
         O.fusion_forward(sd, cfg, [tab[:2], img[:2]])          # warm-up (allocator, thread pool) at the chosen count
         times = []
-        for _ in range(1 if b > 4 else 3):
+        for _ in range(3):                                     # median of >= 3 (3 x ~20 s at the config batch)
             t0 = time.time()
             O.fusion_forward(sd, cfg, [tab, img])
             times.append(time.time() - t0)
@@ -422,6 +427,101 @@ def train_step_record(dev, rank, world, distributed, barrier, steps, warmup):
     return rec
 
 
+PEAK_EXP_PER_S = 256 * 4 * 64 / 16 * 2.4e9      # v_exp_f32 at quarter rate: 256 CUs x 4 SIMDs x 64 lanes / 16 cycles x 2.4 GHz (MI355X_MICROARCH.md)
+CONFIGS = {     # BASELINE.json configs[0], [2], [3], [4] (configs[1] is the headline above); cfg5 at the per-GPU share b = 32 / 8
+    "cfg1": dict(kw=dict(n_modalities=2, channel_dims=[2000, 3], num_spatial_axes=[1, 2], out_dims=4), b=4,
+                 shapes=[(1, 2000), (224, 224, 3)], dtype="float32", core="fp32", dom=("img", 224 * 224, 13)),
+    "cfg3": dict(kw=dict(n_modalities=3, channel_dims=[2000, 3, 3], num_spatial_axes=[1, 2, 3], out_dims=4), b=16,
+                 shapes=[(1, 2000), (224, 224, 3), (12, 224, 224, 3)], dtype="bfloat16", core="bf16", dom=("vol", 12 * 224 * 224, 18)),
+    "cfg4": dict(kw=dict(n_modalities=2, channel_dims=[2000, 768], num_spatial_axes=[1, 1], out_dims=4), b=8,
+                 shapes=[(1, 2000), (4096, 768)], dtype="float32", core="fp32", dom=("bag", 4096, 773)),
+    "cfg5": dict(kw=dict(n_modalities=4, channel_dims=[2000, 768, 768, 3], num_spatial_axes=[1, 1, 1, 3], out_dims=4, depth=8), b=4,
+                 shapes=[(1, 2000), (4096, 768), (4096, 768), (12, 224, 224, 3)], dtype="float32", core="fp32",
+                 dom=("vol", 12 * 224 * 224, 18)),
+}
+
+
+def configs_record(dev, steps=10, warmup=3):
+    """The other BASELINE configs at HEAD, one entry each: forward ms and samples/s over `steps`
+    un-instrumented forwards, then the dominant kernel timed with HIP events on the launch stream in an instrumented replay --
+    the attention core of the modality with the most tokens through hn_profile (as the headline's), the patch-bag K/V projection
+    through hn_set_kernel_timers -- with its executed work per launch (formula in the entry) and the fraction of the roof that
+    bounds it: fp32 MFMA for the fp32 kernels, the chip's v_exp_f32 rate for the bf16 core (one exponential per attention score:
+    DESIGN.md 4.4)."""
+    import healnet_amd as hn
+    from healnet_amd import _capi
+    out = {}
+    for name, c in CONFIGS.items():
+        torch.manual_seed(0)
+        model = hn.HealNet(**c["kw"], core_precision=c["core"]).eval().to(dev)
+        gen = torch.Generator().manual_seed(1234)
+        ins = [torch.rand(c["b"], *sh, generator=gen).to(dev).to(getattr(torch, c["dtype"])) for sh in c["shapes"]]
+        b, depth = c["b"], model.depth
+        kind, n_tok, d_ctx = c["dom"]
+        n_dom = sum(1 for sh in c["shapes"] if (len(sh) == 2 and sh[0] == n_tok and kind == "bag"))      # bags share one kernel class
+        with torch.no_grad():
+            for _ in range(warmup):
+                model(list(ins))
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                res = model(list(ins))
+            torch.cuda.synchronize(dev)
+            ms = (time.perf_counter() - t0) / steps * 1e3
+            assert torch.isfinite(res).all(), name
+            # instrumented replay
+            if kind == "bag":
+                with KernelTimers(["gemm_nt_glds"], depth * n_dom * steps + 8) as kt:
+                    for _ in range(steps):
+                        model(list(ins))
+                    torch.cuda.synchronize(dev)
+                avg_ms, n_timed = kt.averages_ms()["gemm_nt_glds"]
+                work = 2.0 * b * n_tok * d_ctx * 2 * HEADS * DIM_HEAD
+                entry_k = {"kernel": "hn::gemm_nt_glds_kernel (patch-bag K/V projection, LDS-DMA operands)", "launches_per_forward": depth * n_dom,
+                           "work_per_launch": work, "work_unit": "executed fp32 MFMA FLOPs",
+                           "formula": "2 (b N) D (2 inner), N = 4096, D = 773, inner = 512", "bound": "mfma", "peak": PEAK_FP32_MFMA_TFLOPS * 1e12}
+            else:
+                events = HipEvents(depth * steps)
+                prof = _capi.Profile(ev_start=events.start, ev_stop=events.stop, n_events=0, n_recorded=0)
+                recorded = 0
+                for step in range(steps):
+                    off = step * depth * ctypes.sizeof(ctypes.c_void_p)
+                    prof.ev_start = ctypes.cast(ctypes.addressof(events.start) + off, ctypes.POINTER(ctypes.c_void_p))
+                    prof.ev_stop = ctypes.cast(ctypes.addressof(events.stop) + off, ctypes.POINTER(ctypes.c_void_p))
+                    prof.n_events = depth
+                    prof.n_recorded = 0
+                    model(list(ins), _profile=ctypes.byref(prof))
+                    recorded += prof.n_recorded
+                torch.cuda.synchronize(dev)
+                t = events.elapsed_ms(recorded)
+                avg_ms, n_timed = (sum(t) / len(t) if t else None), len(t)
+                dp = 16 if d_ctx <= 15 else 32
+                kq = 4 * ((d_ctx - 1 + 3) // 4)
+                if c["core"] == "bf16":
+                    work = 1.0 * L_C * n_tok * HEADS * b
+                    entry_k = {"kernel": "hn::attn_core_bf16_kernel (split-KV core of the %s cross-attention on bf16 MFMA)" % kind,
+                               "launches_per_forward": depth, "work_per_launch": work, "work_unit": "attention scores (one v_exp_f32 each)",
+                               "formula": "l_c N h b, N = %d" % n_tok, "bound": "valu (v_exp_f32, quarter rate)", "peak": PEAK_EXP_PER_S}
+                else:
+                    work = 2.0 * L_C * n_tok * (kq + dp) * HEADS * b
+                    entry_k = {"kernel": "hn::attn_core_kernel (split-KV fp32 core of the %s cross-attention, rank-D binding)" % kind,
+                               "launches_per_forward": depth, "work_per_launch": work, "work_unit": "executed fp32 MFMA FLOPs",
+                               "formula": "2 l_c N (%d + %d) h b, N = %d (packed context: QK^T over %d channels, P V over %d columns)" % (kq, dp, n_tok, kq, dp),
+                               "bound": "mfma", "peak": PEAK_FP32_MFMA_TFLOPS * 1e12}
+        entry_k["avg_launch_ms"] = None if avg_ms is None else round(avg_ms, 4)
+        entry_k["launches_timed"] = n_timed
+        entry_k["achieved_per_s"] = None if not avg_ms else entry_k["work_per_launch"] / (avg_ms * 1e-3)
+        entry_k["frac"] = None if not avg_ms else round(entry_k["achieved_per_s"] / entry_k["peak"], 4)
+        entry_k["share_of_forward"] = None if not avg_ms else round(avg_ms * entry_k["launches_per_forward"] / ms, 4)
+        out[name] = {"workload": "HealNet(%s) forward, b=%d, inputs %s %s resident in HBM, core_precision=%s, eval / no_grad" %
+                                 (", ".join("%s=%s" % kv for kv in c["kw"].items()), b, c["shapes"], c["dtype"], c["core"]),
+                     "batch": b, "ms_per_forward": round(ms, 4), "samples_per_s": round(b / ms * 1e3, 1), "steps": steps, "warmup": warmup,
+                     "dominant_kernel": entry_k}
+        del model, ins
+        torch.cuda.empty_cache()
+    return out
+
+
 def self_launch(args):
     """`python bench.py --gpus N` outside torchrun: start N ranks of this script under torch.distributed.run."""
     import socket
@@ -520,6 +620,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH, help="samples per GPU per step (headline config: 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-staged-models", action="store_true", help="skip the tuned-shape (staged models) record")
+    ap.add_argument("--no-configs", action="store_true", help="skip the per-config record (cfg1 / cfg3 / cfg4 / cfg5 forwards at N = 1)")
     ap.add_argument("--no-train-step", action="store_true", help="skip the cfg4 training-step record")
     ap.add_argument("--train-steps", type=int, default=30)
     ap.add_argument("--core-precision", choices=["fp32", "bf16", "bf16x3"], default="fp32",
@@ -688,6 +789,8 @@ def main():
         if world == 1 and not args.no_staged_models:
             result["staged_models"] = staged_models_record(dev)
             result["patch_bag_precisions"] = patch_bag_record(dev)
+        if world == 1 and not args.no_configs:
+            result["configs"] = configs_record(dev)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline()
         print(json.dumps(result))

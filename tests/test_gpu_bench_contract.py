@@ -46,6 +46,17 @@ def test_bench_prints_one_contract_line():
     assert all(c["staged"] and 0.1 < c["fwd_bwd_ms"] < 50.0 for c in sm["configs"].values())
     pb = j["patch_bag_precisions"]                        # BASELINE configs[3]'s shape: fp32 vs the bf16 projection + core
     assert 0.1 < pb["bf16_ms"] < pb["fp32_ms"] < 50.0 and 0.0 < pb["bf16_maxnorm_diff_vs_fp32"] < 2e-2
+    cf = j["configs"]                                     # the other BASELINE configs at HEAD (round 5): forward + dominant kernel vs its roof
+    assert set(cf) == {"cfg1", "cfg3", "cfg4", "cfg5"}
+    for name, c in cf.items():
+        k = c["dominant_kernel"]
+        assert abs(c["samples_per_s"] - c["batch"] * 1000.0 / c["ms_per_forward"]) <= 2e-3 * c["samples_per_s"], name
+        assert k["launches_timed"] == k["launches_per_forward"] * c["steps"], (name, k)
+        assert 0.2 < k["frac"] <= 1.0 and abs(k["frac"] - k["work_per_launch"] / (k["avg_launch_ms"] * 1e-3) / k["peak"]) < 2e-3, (name, k)
+        assert 0.1 < k["share_of_forward"] <= 1.0, (name, k)
+    assert cf["cfg3"]["dominant_kernel"]["bound"].startswith("valu") and cf["cfg4"]["dominant_kernel"]["bound"] == "mfma"
+    cl = t["cluster"]                                     # the cluster-mode failure signal of the step (include/healnet_hip.h, ABI v10)
+    assert cl["lost"] == 0 and cl["fallbacks"] == 0 and cl["enabled"] and cl["optimizer_steps_skipped"] == 0
 
 
 def test_plain_gpus_n_command_launches_its_own_ranks():
