@@ -52,6 +52,14 @@ class Workspace:
         self._buf: Dict[tuple, torch.Tensor] = {}
 
     def get(self, device: torch.device, nbytes: int) -> torch.Tensor:
+        if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            # Under graph capture an allocation comes from the CAPTURE'S private memory pool.  Caching it here would outlive the
+            # graph that owns the pool: the next capture on the same stream found the buffer, baked its address into its kernels,
+            # and a replay faulted once the first graph -- and with it the pool -- had been destroyed (round 5: a GraphedForward
+            # followed by a GraphedStep in one process; "Memory access fault by GPU node").  A captured call gets scratch of its
+            # own, like any temporary a torch op allocates while capturing: it returns to the pool when the call ends, and stream
+            # order inside the graph keeps later users of the block behind this call's kernels.
+            return torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
         key = (device, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
         buf = self._buf.get(key)
         if buf is None or buf.numel() < nbytes:

@@ -250,6 +250,14 @@ static int project_ctx_kv(const hn_attn_params *p, const AttnPlan &pl, const flo
   return launch_gemm(gk, s);
 }
 
+// A shared-context block can take its query FOLDED and packed from the chain in front (ChainArgs.qf) exactly when its core is the
+// bounded packed one on 16-column rows.  ONE predicate for the producer (add_next_proj of the inference forward, which then projects
+// 128 folded columns and never produces the plain Q) and the consumer (attn_prepare, which has no route back once that happened):
+// the two copies of these conditions agreed, but nothing made them.
+static bool qfold_core_ok(const hn_attn_params *p, const AttnPlan &pl, int pack_ks, int L) {
+  return pl.rank_d && pl.ones && p->ctx_gamma != nullptr && pl.dp == 16 && pl.Lp == L && pack_ks == packed_steps(pl.D, pl.dp);
+}
+
 // kv_tape (explicit cross binding, training): the projected K / V live in the tape instead of the workspace; the forward
 // writes them there, the backward (kv_ready) reads them back instead of re-running the K/V projection GEMM.
 static int attn_prepare(const hn_attn_params *p, const AttnPlan &pl, const float *x_in, const float *ctx, int ld_ctx,
@@ -275,7 +283,7 @@ static int attn_prepare(const hn_attn_params *p, const AttnPlan &pl, const float
   core->Opart = pl.opart; core->Mpart = pl.mpart; core->Lpart = pl.lpart;
   int rc;
   if (pl.rank_d && ext && ext->qf_done) {
-    HN_REQUIRE(pl.ones && p->ctx_gamma && use_bound && ext_flag && pack_ks == packed_steps(pl.D, pl.dp) && pl.dp == 16 && pl.Lp == L, HN_E_SHAPE,
+    HN_REQUIRE(qfold_core_ok(p, pl, pack_ks, L) && use_bound && ext_flag, HN_E_SHAPE,
                "attn: folded query from the chain needs the bounded packed core (dp=%d Lp=%d)", pl.dp, pl.Lp);
     core->bound = ext->qf_bound; core->bound_flag = ext_flag;
     core->qk_steps = pack_ks;
@@ -1868,8 +1876,8 @@ static int impl_fusion_forward(const hn_model *m, const hn_modality_input *in, i
       if (self) { ca.nkv = up128(2 * pn.inner); ca.kv_cols = 2 * pn.inner; ca.wkv = an->w_kv; ca.KV = fp.ckv; ca.ldkv = 2 * pn.inner; kv_done = true; }
       // shared-context block whose query fold was staged (vfold launch): the Q stage projects 128 instead of `inner` columns and
       // leaves the folded, packed query with its score bounds -- qfold's launch and the wider projection disappear
-      if (!self && qfolded[sn.m] && pn.rank_d && pn.ones && pn.dp == 16 && pn.Lp == L && an->ctx_gamma && !staged && mask == nullptr &&
-          !fp.bf16[sn.m] && fp.ones[sn.m] && fp.pack[sn.m] == packed_steps(pn.D, pn.dp)) {
+      // (the consumer runs with use_bound = true and this forward's pre-zeroed flag: inference, no dropout)
+      if (!self && qfolded[sn.m] && qfold_core_ok(an, pn, fp.pack[sn.m], L) && !staged && mask == nullptr && !fp.bf16[sn.m] && fp.ones[sn.m]) {
         ca.nq = 128; ca.q_cols = 128; ca.wq = fp.wqf[sn.m] + (size_t)sn.layer * 128 * d; ca.Q = nullptr; ca.ldq = 0; ca.alpha_q = 1.0f;
         ca.qf = fp.cq; ca.qf_bound = fp.cbound; ca.qf_flag = fp.flags + sn.layer * M + sn.m; ca.qf_heads = an->heads; ca.qf_D = pn.D;
         qf_done = true;

@@ -262,3 +262,37 @@ def test_graphed_steps_share_the_models_dropout_word(hn):
     assert "_hn_rng_word" not in model.__dict__
     with pytest.raises(RuntimeError, match="after close"):
         b(ins, la)
+
+
+def test_scratch_of_a_capture_does_not_outlive_its_graph(hn):
+    """Round 5 regression: the per-stream workspace cache used to keep a buffer that had been allocated DURING a capture, i.e. from
+    that graph's private memory pool.  After the graph was destroyed the next capture on the same stream still found the buffer, and a
+    replay of it faulted ("Memory access fault by GPU node").  Sequence: an inference graph with a large workspace is captured,
+    replayed and destroyed; a GraphedStep then captures two signatures and replays them alternately; results equal the eager step."""
+    import gc
+    kw = dict(n_modalities=3, channel_dims=[2000, 3, 3], num_spatial_axes=[1, 2, 3], out_dims=4)
+    torch.manual_seed(51)
+    big = hn.HealNet(**kw).eval().to(DEV)
+    gen = torch.Generator().manual_seed(52)
+    ins3 = [torch.rand(4, *s, generator=gen).to(DEV) for s in [(1, 2000), (64, 48, 3), (3, 40, 36, 3)]]
+    g = big.capture(ins3)
+    with torch.no_grad():
+        assert torch.equal(g(ins3).clone(), big(ins3))
+    del g, big
+    gc.collect()
+    torch.cuda.synchronize()
+    model, flat = _bag_model(hn, dropout=False)
+    ins, la = _batch(gen)
+    short = [ins[0], ins[1][:, :100].contiguous()]
+    step = hn.train.GraphedStep(model, _loss(hn), ins, la)
+    for trial in range(3):
+        for batch in (ins, short, ins):
+            loss_g, _ = step(batch, la)
+            loss_g, grads_g = loss_g.clone(), flat.grads.clone()
+            flat.zero_grad()
+            loss_e = _loss(hn)(model(list(batch)), *la)
+            loss_e.backward()
+            torch.cuda.synchronize()
+            assert torch.equal(loss_g, loss_e.detach()) and torch.equal(grads_g, flat.grads), trial
+    assert step.captures == 2
+    step.close()
