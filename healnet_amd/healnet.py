@@ -641,14 +641,20 @@ class HealNet(nn.Module):
             if flatp is not None and not torch.compiler.is_compiling():
                 goffs = flatp.direct_offsets(params)
                 gbuf = flatp.grads if goffs else None
-            out, tape, layout = _hip.fusion_forward_train(held, mask_u8, params, self._spec_text, skip_bits, embeddings, rng_t, gbuf,
-                                                          goffs or [])
+            if _ops.FORCE_TORCH_OPS or torch.compiler.is_compiling():
+                out, tape, layout = _hip.fusion_forward_train(held, mask_u8, params, self._spec_text, skip_bits, embeddings, rng_t, gbuf,
+                                                              goffs or [])
+            else:      # the same implementation behind a lean autograd.Function (ops.FusionTrainFn explains: ~0.7 ms of dispatcher time per step)
+                out, tape, layout = _ops.FusionTrainFn.apply((len(held), mask_u8, rng_t, self._spec_text, skip_bits, embeddings, gbuf,
+                                                              goffs or []), *held, *params)
             self._last = dict(tape=tape, layout=layout, inputs=held, mask=mask_u8, b=b) if self.keep_attention_stats else None
         else:
             if _profile is not None:
                 _ops.set_profile(_profile)
-            out, stats, trace = _hip.fusion_forward(held, mask_u8, params, self._spec_text, skip_bits, embeddings,
-                                                    bool(self.keep_attention_stats))
+            # (nothing to differentiate on this branch: outside torch.compile the implementation is called directly, without the
+            # dispatcher's ~0.1 ms of list / pytree handling per call -- the b <= 4 forwards are host-bound)
+            fwd = _hip.fusion_forward if (_ops.FORCE_TORCH_OPS or torch.compiler.is_compiling()) else _ops._fusion_forward
+            out, stats, trace = fwd(held, mask_u8, params, self._spec_text, skip_bits, embeddings, bool(self.keep_attention_stats))
             self._last = dict(stats=stats, trace=trace, inputs=held, mask=mask_u8, b=b) if self.keep_attention_stats else None
         if verbose:
             for layer in range(self.depth):

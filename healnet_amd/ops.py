@@ -1015,6 +1015,58 @@ def _fusion_backward_formula(ctx, dout, dtape, dlayout):
 torch.library.register_autograd("healnet_hip::fusion_forward_train", _fusion_backward_formula, setup_context=_fusion_setup)
 
 
+class FusionTrainFn(torch.autograd.Function):
+    """The eager route of ``HealNet.forward`` in training: the SAME two implementations as ``torch.ops.healnet_hip.fusion_forward_train``
+    and its registered backward (``_fusion_forward_train`` / ``_run_fusion_backward``: one C-ABI call each), behind a plain
+    ``autograd.Function`` instead of the dispatcher.  Why: at the reference's tuned TCGA shapes a step is ~90 launches that the C side
+    enqueues in ~0.2 ms, while the operator route added ~0.7 ms of host time around them (cProfile on the GPU box, round 5: pytree
+    flatten / unflatten of the 40-tensor parameter list on every op call, ``torch.library``'s autograd wrapper, two redispatches) --
+    the eager step was host-bound at 1.2 ms against 0.73 ms of GPU work.  The registered operator stays what ``torch.compile`` traces
+    (``HealNet.forward`` takes it under ``torch.compiler.is_compiling()``; ``HN_FORCE_TORCH_OPS=1`` forces it everywhere).
+
+    apply(meta, *flat): ``meta`` = (n_tensors, mask?, rng?, spec, skip_self, embeddings, grad_buffer, grad_offsets) and ``flat`` = the
+    modality tensors (None for a missing one) followed by the parameters -- parameters must be positional for autograd to see them."""
+
+    @staticmethod
+    def forward(ctx, meta, *flat):
+        n_t, mask, rng, spec, skip_self, embeddings, grad_buffer, grad_offsets = meta
+        tensors, params = list(flat[:n_t]), list(flat[n_t:])
+        out, tape, layout = _fusion_forward_train(tensors, mask, params, spec, skip_self, embeddings, rng, grad_buffer, grad_offsets)
+        ctx.meta = meta
+        ctx.tensors, ctx.params = tensors, params           # (inputs and parameters are alive anyway; the tape is what this step owns)
+        ctx.tape = tape
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(tape, layout)
+        return out, tape, layout
+
+    @staticmethod
+    def backward(ctx, dout, _dtape, _dlayout):
+        n_t, mask, rng, spec, skip_self, embeddings, grad_buffer, grad_offsets = ctx.meta
+        n = 1 + n_t + len(ctx.params)
+        if dout is None:
+            return (None,) * n
+        params, tensors, tape = ctx.params, ctx.tensors, ctx.tape
+        device = params[0].device
+        with torch.cuda.device(device):
+            if grad_buffer is not None:
+                base = grad_buffer.data_ptr()
+                gptr = [base + 4 * off if off >= 0 else None for off in grad_offsets]
+                _run_fusion_backward(dout.contiguous(), tape, tensors, mask, params, spec, skip_self, embeddings, rng, gptr,
+                                     _BACKWARD_HOOKS.get(base))
+                grads = [None] * len(params)
+            else:
+                needs = ctx.needs_input_grad[1 + n_t:]
+                empty = None
+                outg = [torch.zeros_like(p, dtype=torch.float32) if need else empty for p, need in zip(params, needs)]
+                gptr = [g.data_ptr() if g is not None else None for g in outg]
+                _run_fusion_backward(dout.contiguous(), tape, tensors, mask, params, spec, skip_self, embeddings, rng, gptr, None)
+                grads = outg
+        return (None,) + (None,) * n_t + tuple(grads)
+
+
+FORCE_TORCH_OPS = os.environ.get("HN_FORCE_TORCH_OPS", "0") == "1"
+
+
 for _name, _fn in (("fourier_encode_concat", _fourier_encode_concat), ("encode_norm", _encode_norm), ("attention_fwd", _attention_fwd),
                    ("attention_bwd", _attention_bwd), ("feed_forward", _feed_forward), ("feed_forward_bwd", _feed_forward_bwd),
                    ("head", _head), ("head_bwd", _head_bwd), ("temperature_softmax", _temperature_softmax),
