@@ -672,6 +672,8 @@ struct AttnBwdExt {
   const float *O;            // out: the block's attention output (rows, inner) -- the tape's or the recomputed one
   const float *q_taped, *kv_taped;      // in: the forward's projections from the tape (NULL: recomputed here)
   const float *xhat_taped;              // in: LN(x_in) from the tape (NULL: recomputed here)
+  float *dQ_home, *dKV_home;            // in (defer_proj): where dQ (rows, inner) / dKV of a latent block (rows, 2 inner) are produced instead of
+                                        // the op workspace -- they outlive the next block's backward (batched weight-gradient products)
 };
 
 static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float *x_out, int residual, const float *ctx,
@@ -691,6 +693,10 @@ static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float
   if ((rc = check_ws(ws, ws_bytes, bp.bytes, "attn_bwd")) != HN_OK) return rc;
   if ((rc = plan_attn_bwd(p, pl, has_ctx, general, b, L, ws, ws_bytes, &bp)) != HN_OK) return rc;
   if ((rc = plan_attn(p, has_ctx, ld_ctx, b, L, N, D, bp.fwd_ws, bp.fwd_bytes, &pl)) != HN_OK) return rc;
+  if (ext && ext->defer_proj) {      // (the chain in front runs the projection backward: its operands may have to outlive this workspace)
+    if (ext->dQ_home) bp.dQ = ext->dQ_home;
+    if (ext->dKV_home && !has_ctx) bp.dKV = ext->dKV_home;
+  }
 
   const int rows = b * L, qd = p->query_dim, inner = pl.inner, h = p->heads, dh = pl.dh;
   const float two_scale = 2.0f / sqrtf((float)dh_valid(p));
@@ -1364,7 +1370,13 @@ static void register_transposes(const hn_model *m, const hn_modality_input *in, 
 
 // buffers of the fused latent backward (bchain.hip): what a chain hands to the batched weight-gradient launch and to the
 // attention core backward in front of it
-struct BChainBufs { float *H, *dU, *Xhat, *dYff, *dPre, *dO, *lnpart, *tn, *xchg; int *xflags; size_t tn_floats; bool ok; };
+// Scratch of the fused latent backward.  What a chain leaves for its weight-gradient products (H, dU, Xhat, dYff, dPre, lnpart) and
+// what the attention backward behind it leaves for the NEXT chain's (dQ, dKV of a latent block) exists BCHAIN_SETS times: the
+// products of up to BCHAIN_SETS - 1 consecutive chains -- normally all chains of a layer -- wait in one batch and run as ONE
+// gemm_tn_lds_multi launch + ONE reduce (round 5; a launch pair per chain until then: 12 x 27 us of 16-28 workgroups each at cfg4).
+constexpr int BCHAIN_SETS = 8;
+struct BChainSet { float *H, *dU, *Xhat, *dYff, *dPre, *lnpart, *dQ, *dKV; };
+struct BChainBufs { BChainSet set[BCHAIN_SETS]; float *dO, *tn, *xchg; int *xflags; size_t tn_floats; bool ok; };
 constexpr int BCHAIN_XFLAGS = 2 * 256 + 1;
 
 static size_t bchain_tn_scratch_floats(int rows) {
@@ -1428,14 +1440,19 @@ static int fusion_bwd_workspace(const hn_model *m, const hn_modality_input *in, 
   const size_t rows = rows16((size_t)b * m->l_c);
   cb.ok = latent_bchain_supported(b * m->l_c, m->l_d, 4 * m->l_d);
   if (cb.ok) {
-    cb.H = ar.take<float>(rows * 512);
-    cb.dU = ar.take<float>(rows * 1024);
-    cb.Xhat = ar.take<float>(rows * 128);
-    cb.dYff = ar.take<float>(rows * 128);
-    cb.dPre = ar.take<float>(rows * 128);
+    for (int j = 0; j < BCHAIN_SETS; ++j) {
+      BChainSet &bs = cb.set[j];
+      bs.H = ar.take<float>(rows * 512);
+      bs.dU = ar.take<float>(rows * 1024);
+      bs.Xhat = ar.take<float>(rows * 128);
+      bs.dYff = ar.take<float>(rows * 128);
+      bs.dPre = ar.take<float>(rows * 128);
+      bs.lnpart = ar.take<float>((rows / 16) * 4 * 128);
+      bs.dQ = ar.take<float>(rows * 512);             // latent blocks whose projection backward rides on a chain: inner <= 512
+      bs.dKV = ar.take<float>(rows * 1024);
+    }
     cb.dO = ar.take<float>(rows * 512);
-    cb.lnpart = ar.take<float>((rows / 16) * 4 * 128);
-    cb.tn_floats = bchain_tn_scratch_floats(rows);
+    cb.tn_floats = 2 * bchain_tn_scratch_floats(rows);
     cb.tn = ar.take<float>(cb.tn_floats);
     cb.xchg = ar.take<float>((size_t)2 * 256 * 16 * 128);      // cluster mode: two exchanges x <= 256 workgroups x one partial tile
     cb.xflags = ar.take<int>(BCHAIN_XFLAGS);
@@ -2341,8 +2358,10 @@ static int impl_fusion_backward(const hn_model *m, const hn_modality_input *in, 
   const bool use_bchain = cb.ok && fp.chain && !bchain_disabled() && !chain_disabled();
   int bchain_seq = 0;
   if (use_bchain && (rc = launch_fill((float *)cb.xflags, 0.0f, BCHAIN_XFLAGS, s)) != HN_OK) return rc;      // cluster flags (bchain.hip)
-  struct Pending { bool valid; int layer; hn_attn_params ap; const hn_attn_grads *ag; const float *x_in, *dQ, *dKV, *xhat; } pend;
+  // `durable`: dQ / dKV sit in a buffer set and LN(x) on the tape -- the products may wait for the batch's flush
+  struct Pending { bool valid, durable; int layer; hn_attn_params ap; const hn_attn_grads *ag; const float *x_in, *dQ, *dKV, *xhat; } pend;
   memset(&pend, 0, sizeof(pend));
+  int cur_set = 0;                     // buffer set of the chain that ran last (its dPre / dO feed the attention backward behind it)
   auto is_attn_b = [](const Step &q) { return q.kind == STEP_CROSS_ATTN || q.kind == STEP_SELF_ATTN; };
   auto attn_of = [&](const Step &q) { return q.kind == STEP_SELF_ATTN ? m->self_attn[q.layer] : m->cross_attn[q.layer * M + q.m]; };
   auto attn_grads_of = [&](const Step &q) -> const hn_attn_grads * {
@@ -2371,15 +2390,36 @@ static int impl_fusion_backward(const hn_model *m, const hn_modality_input *in, 
            al16(f.norm_b) && (f.norm_w != nullptr || f.norm_b == nullptr) && al16(x) && transpose_cache_lookup(f.w2, 4 * d, d, 4 * d) &&
            transpose_cache_lookup(f.w1, d, 8 * d, d);
   };
-  // one chain launch + its batched weight-gradient launch.  ff_k < 0: projection backward of `pend` only.
+  // ---- the weight-gradient products of the chains wait in `big` and run as ONE batched launch + ONE reduce per flush: at the end of
+  // a layer (in front of its gradient-ready signal), when the buffer sets or the batch's capacity run out, at the end of the pass.
+  // Chain number `chain_no` writes into buffer set chain_no % BCHAIN_SETS; the attention backward behind it leaves dQ / dKV for the
+  // NEXT chain in set (chain_no + 1) % BCHAIN_SETS.
+  static thread_local GemmTnMulti big;
+  big.n = big.n_ln = 0;
+  big.K = rows;
+  int chain_no = 0, pending_chains = 0;
+  bool flush_now = false;              // an operand of the batch lives in the op workspace (LN(x) not on the tape): no deferral
+  auto flush_products = [&]() -> int {
+    pending_chains = 0;
+    flush_now = false;
+    if (big.n == 0 && big.n_ln == 0) return HN_OK;
+    int rc2 = launch_gemm_tn_multi(big, cb.tn, cb.tn_floats, s);
+    big.n = big.n_ln = 0;
+    return rc2;
+  };
+  // one chain launch; its weight-gradient products join the batch.  ff_k < 0: projection backward of `pend` only.
   auto run_bchain = [&](int ff_k, bool has_out, const AttnBwdExt *out_ext_in, const float **o_saved) -> int {
     (void)out_ext_in;
+    int rc2 = HN_OK;
+    // room for this chain's products (<= 5) and LayerNorm entries (<= 4), and a free buffer set for the attention backward behind it
+    if (big.n + 5 > TN_MULTI_MAX || big.n_ln + 4 > TN_MULTI_LN_MAX || pending_chains >= BCHAIN_SETS - 2) {
+      if ((rc2 = flush_products()) != HN_OK) return rc2;
+    }
+    const BChainSet &bs = cb.set[chain_no % BCHAIN_SETS];
     BChainArgs ca;
     memset(&ca, 0, sizeof(ca));
-    GemmTnMulti mm;
-    memset(&mm, 0, sizeof(mm));
-    mm.K = rows;
-    int rc2 = HN_OK;
+    GemmTnMulti &mm = big;
+    const int n_before = mm.n, nln_before = mm.n_ln;
     auto add_product = [&](const float *A, long lda, int Mm, const float *B, long ldb, int Nn, float *C, long ldc, float *cs) {
       if (!C) {
         if (cs && rc2 == HN_OK) rc2 = launch_colsum(A, lda, rows, Mm, 1.0f, cs, 1, s);
@@ -2391,9 +2431,9 @@ static int impl_fusion_backward(const hn_model *m, const hn_modality_input *in, 
     auto add_ln = [&](int slot, float *out) {
       if (!out) return;
       LnPartial &lp = mm.ln[mm.n_ln++];
-      lp.part = cb.lnpart + (size_t)slot * 128; lp.nwg = (rows + 15) / 16; lp.width = 128; lp.stride = 4 * 128; lp.out = out;
+      lp.part = bs.lnpart + (size_t)slot * 128; lp.nwg = (rows + 15) / 16; lp.width = 128; lp.stride = 4 * 128; lp.out = out;
     };
-    ca.rows = rows; ca.L = L; ca.dy = dX; ca.dx_out = dX; ca.lnpart = cb.lnpart; ca.dv = m->l_d_valid;
+    ca.rows = rows; ca.L = L; ca.dy = dX; ca.dx_out = dX; ca.lnpart = bs.lnpart; ca.dv = m->l_d_valid;
     ca.xchg = cb.xchg; ca.xflags = cb.xflags; ca.seq = ++bchain_seq;
     if (pend.valid) {
       const int inner = pend.ap.heads * pend.ap.dim_head;
@@ -2408,6 +2448,7 @@ static int impl_fusion_backward(const hn_model *m, const hn_modality_input *in, 
       add_product(pend.dQ, inner, inner, pend.xhat, d, d, pend.ag->w_q, d, nullptr);
       if (pend.dKV) add_product(pend.dKV, 2 * inner, 2 * inner, pend.xhat, d, d, pend.ag->w_kv, d, nullptr);
       if (pend.ap.norm_w) { add_ln(0, pend.ag->norm_w); add_ln(1, pend.ag->norm_b); }
+      if (!pend.durable) flush_now = true;
     }
     if (ff_k >= 0) {
       const Step &sf = tp.steps[ff_k];
@@ -2416,13 +2457,13 @@ static int impl_fusion_backward(const hn_model *m, const hn_modality_input *in, 
       ca.has_ff = 1; ca.gate = f.gate; ca.f_x = T + tp.x_off[ff_k];
       ca.f_nw = f.norm_w; ca.f_nb = f.norm_b; ca.w1 = f.w1; ca.b1 = f.b1;
       ca.w2T = transpose_cache_lookup(f.w2, 4 * d, d, 4 * d); ca.w1T = transpose_cache_lookup(f.w1, d, 8 * d, d);
-      ca.H = cb.H; ca.dU = cb.dU; ca.Xhat = cb.Xhat; ca.dYff = cb.dYff;
+      ca.H = bs.H; ca.dU = bs.dU; ca.Xhat = bs.Xhat; ca.dYff = bs.dYff;
       {
         const hn_rng rng_ff = {m->rng.seed, m->rng.offset, (uint32_t)ff_k, m->rng.offset_dev};      // the forward's generator state and stream id
         ca.ff_drop = drop_of(f.dropout, rng_ff, true);
       }
-      add_product(cb.dU, 8 * d, 8 * d, cb.Xhat, d, d, fg->w1, d, fg->b1);
-      add_product(cb.dYff, d, d, cb.H, 4 * d, 4 * d, fg->w2, 4 * d, fg->b2);
+      add_product(bs.dU, 8 * d, 8 * d, bs.Xhat, d, d, fg->w1, d, fg->b1);
+      add_product(bs.dYff, d, d, bs.H, 4 * d, 4 * d, fg->w2, 4 * d, fg->b2);
       if (f.norm_w) { add_ln(2, fg->norm_w); add_ln(3, fg->norm_b); }
       if (has_out) {
         const Step &sa = tp.steps[ff_k - 1];
@@ -2430,13 +2471,20 @@ static int impl_fusion_backward(const hn_model *m, const hn_modality_input *in, 
         const int inner = oa.heads * oa.dim_head;
         ca.has_out = 1; ca.inner_o = up128(inner); ca.o_cols = inner; ca.o_x = T + tp.x_off[ff_k - 1];
         ca.woT = transpose_cache_lookup(oa.w_out, wo_ld(&oa), d, wo_ld(&oa));
-        ca.dPre = cb.dPre; ca.dO = cb.dO; ca.lddo = inner;
-        if (o_saved && *o_saved) add_product(cb.dPre, d, d, *o_saved, inner, inner, attn_grads_of(sa)->w_out, wo_ld(&oa), attn_grads_of(sa)->b_out);
+        ca.dPre = bs.dPre; ca.dO = cb.dO; ca.lddo = inner;
+        if (o_saved && *o_saved) add_product(bs.dPre, d, d, *o_saved, inner, inner, attn_grads_of(sa)->w_out, wo_ld(&oa), attn_grads_of(sa)->b_out);
       }
     }
     if ((rc2 = (rc2 != HN_OK ? rc2 : launch_latent_bchain(ca, s))) != HN_OK) return rc2;
     pend.valid = false;
-    return launch_gemm_tn_multi(mm, cb.tn, cb.tn_floats, s);
+    cur_set = chain_no % BCHAIN_SETS;
+    ++chain_no;
+    if (mm.n > n_before || mm.n_ln > nln_before) ++pending_chains;
+    static const bool no_batch = getenv("HN_NO_TN_BATCH") != nullptr;      // route switch (A/B): a launch pair per chain, as until round 5
+    if (flush_now || no_batch) return flush_products();
+    // (scratch: a batch never needs more than one chain's worst case -- the planner's split count shrinks as tiles are added, the
+    // partials stay below max(32 x one chain's outputs, 768 tiles) -- and the buffer holds twice that; launch_gemm_tn_multi checks)
+    return HN_OK;
   };
   // backward of an attention block with the chain hooks; `dpre` / `dO` non-NULL: its out-projection already ran in a chain
   auto run_attn = [&](int k, const float *dpre, const float *dO_in, bool skip_wout) -> int {
@@ -2452,6 +2500,10 @@ static int impl_fusion_backward(const hn_model *m, const hn_modality_input *in, 
     if (tp.kv_off[k] != kNoSlot) ext.kv_taped = T + tp.kv_off[k];
     if (tp.xhat_off[k] != kNoSlot) ext.xhat_taped = T + tp.xhat_off[k];
     AttnBwdExt *extp = (dpre || defer || ext.q_taped || ext.xhat_taped) ? &ext : nullptr;
+    if (defer) {      // dQ / dKV for the NEXT chain's products: into that chain's buffer set
+      const BChainSet &ns = cb.set[chain_no % BCHAIN_SETS];
+      ext.dQ_home = ns.dQ; ext.dKV_home = ns.dKV;
+    }
     const float *xin = T + tp.x_off[k], *xout = T + tp.x_off[k + 1];
     int rc2;
     if (st.kind == STEP_CROSS_ATTN)
@@ -2464,6 +2516,7 @@ static int impl_fusion_backward(const hn_model *m, const hn_modality_input *in, 
     if (defer) {
       pend.valid = true; pend.layer = st.layer; pend.ap = ap; pend.ag = attn_grads_of(st); pend.x_in = xin;
       pend.dQ = ext.dQ; pend.dKV = ext.dKV; pend.xhat = ext.xhat;
+      pend.durable = ext.xhat_taped != nullptr || !ap.norm_w;      // (no LayerNorm: xhat is the block's input on the tape)
     }
     return HN_OK;
   };
@@ -2490,7 +2543,7 @@ static int impl_fusion_backward(const hn_model *m, const hn_modality_input *in, 
       }
       if ((rc = run_bchain(k, has_out, nullptr, &o_saved)) != HN_OK) return rc;
       if (has_out) {
-        if ((rc = run_attn(k - 1, cb.dPre, cb.dO, o_on_tape)) != HN_OK) return rc;
+        if ((rc = run_attn(k - 1, cb.set[cur_set].dPre, cb.dO, o_on_tape)) != HN_OK) return rc;
         k -= 2;
       } else {
         k -= 1;
@@ -2507,15 +2560,20 @@ static int impl_fusion_backward(const hn_model *m, const hn_modality_input *in, 
       if (rc != HN_OK) return rc;
       k -= 1;
     }
-    if (ready) {
+    {
       int done_above = k >= 0 ? tp.steps[k].layer : -1;   // layers > done_above have no block left ...
       if (pend.valid && pend.layer > done_above) done_above = pend.layer;      // ... and no projection backward pending in a chain
-      for (; next_layer_event > done_above; --next_layer_event)
-        if ((rc = signal(next_layer_event)) != HN_OK) return rc;
+      if (next_layer_event > done_above) {
+        // a layer is complete: its chains' weight-gradient products run now, in one batch (and in front of its gradient-ready signal)
+        if ((rc = flush_products()) != HN_OK) return rc;
+        for (; next_layer_event > done_above; --next_layer_event)
+          if ((rc = signal(next_layer_event)) != HN_OK) return rc;
+      }
     }
   }
   if (pend.valid && (rc = run_bchain(-1, false, nullptr, nullptr)) != HN_OK) return rc;
-  for (; ready && next_layer_event >= 0; --next_layer_event)
+  if ((rc = flush_products()) != HN_OK) return rc;
+  for (; next_layer_event >= 0; --next_layer_event)
     if ((rc = signal(next_layer_event)) != HN_OK) return rc;
   if (g->latents) return launch_colsum(dX, (long)L * d, b, L * d, 1.0f, g->latents, 1, s);   // x0 = latents broadcast over the batch
   return HN_OK;

@@ -441,44 +441,61 @@ __global__ __launch_bounds__(256) void gemm_tn_lds_multi_kernel(GemmTnMulti mm) 
   gemm_tn_lds_body(g, t % tm, t / tm, blockIdx.y, As, Bs);
 }
 
-// blockIdx.y: product (entries n .. n + n_ln - 1: LayerNorm partial sums (nwg, width) -> out[width], same launch)
+// blockIdx.y: product (entries n .. n + n_ln - 1: LayerNorm partial sums (nwg, width) -> out[width], same launch).  Entries that
+// accumulate into the same destination form a chain (TnProduct.next): the head's blocks fold every member, in launch order.
 __global__ __launch_bounds__(256) void splitk_reduce_multi_kernel(GemmTnMulti mm) {
   const int pi = blockIdx.y;
   if (pi >= mm.n) {                                     // column sums of per-workgroup LayerNorm partials
-    const LnPartial &lp = mm.ln[pi - mm.n];
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < lp.width; c += gridDim.x * blockDim.x) {
-      float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-      int k = 0;
-      for (; k + 4 <= lp.nwg; k += 4) {
-        a0 += lp.part[(long)k * lp.stride + c]; a1 += lp.part[(long)(k + 1) * lp.stride + c];
-        a2 += lp.part[(long)(k + 2) * lp.stride + c]; a3 += lp.part[(long)(k + 3) * lp.stride + c];
+    const LnPartial &l0 = mm.ln[pi - mm.n];
+    if (l0.follower) return;
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < l0.width; c += gridDim.x * blockDim.x) {
+      float v = l0.out[c];
+      for (int e = pi - mm.n; e >= 0; e = mm.ln[e].next) {
+        const LnPartial &lp = mm.ln[e];
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+        int k = 0;
+        for (; k + 4 <= lp.nwg; k += 4) {
+          a0 += lp.part[(long)k * lp.stride + c]; a1 += lp.part[(long)(k + 1) * lp.stride + c];
+          a2 += lp.part[(long)(k + 2) * lp.stride + c]; a3 += lp.part[(long)(k + 3) * lp.stride + c];
+        }
+        for (; k < lp.nwg; ++k) a0 += lp.part[(long)k * lp.stride + c];
+        v += (a0 + a1) + (a2 + a3);
       }
-      for (; k < lp.nwg; ++k) a0 += lp.part[(long)k * lp.stride + c];
-      lp.out[c] += (a0 + a1) + (a2 + a3);
+      l0.out[c] = v;
     }
     return;
   }
-  const TnProduct &pr = mm.p[pi];
-  const float *part = mm.scratch + pr.part_off, *cs_part = pr.colsum ? mm.scratch + pr.cs_off : nullptr;
-  const long mn = (long)pr.M * pr.N, total = mn + (cs_part ? pr.M : 0);
+  const TnProduct &p0 = mm.p[pi];
+  if (p0.follower) return;
+  const long mn = (long)p0.M * p0.N, total = mn + (p0.colsum ? p0.M : 0);
   const int nsplit = mm.nsplit;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     if (i >= mn) {
       const int m = (int)(i - mn);
-      float acc = 0.0f;
-      for (int k = 0; k < nsplit; ++k) acc += cs_part[(long)k * pr.M + m];
-      pr.colsum[m] += acc;
+      float v = p0.colsum[m];
+      for (int e = pi; e >= 0; e = mm.p[e].next) {
+        const float *cs_part = mm.scratch + mm.p[e].cs_off;
+        float acc = 0.0f;
+        for (int k = 0; k < nsplit; ++k) acc += cs_part[(long)k * p0.M + m];
+        v += acc;
+      }
+      p0.colsum[m] = v;
       continue;
     }
-    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-    int k = 0;
-    for (; k + 4 <= nsplit; k += 4) {
-      a0 += part[(long)k * mn + i]; a1 += part[(long)(k + 1) * mn + i];
-      a2 += part[(long)(k + 2) * mn + i]; a3 += part[(long)(k + 3) * mn + i];
+    float *dst = p0.C + (i / p0.N) * p0.ldc + (i % p0.N);
+    float v = *dst;
+    for (int e = pi; e >= 0; e = mm.p[e].next) {
+      const float *part = mm.scratch + mm.p[e].part_off;
+      float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+      int k = 0;
+      for (; k + 4 <= nsplit; k += 4) {
+        a0 += part[(long)k * mn + i]; a1 += part[(long)(k + 1) * mn + i];
+        a2 += part[(long)(k + 2) * mn + i]; a3 += part[(long)(k + 3) * mn + i];
+      }
+      for (; k < nsplit; ++k) a0 += part[(long)k * mn + i];
+      v += (a0 + a1) + (a2 + a3);
     }
-    for (; k < nsplit; ++k) a0 += part[(long)k * mn + i];
-    float *dst = pr.C + (i / pr.N) * pr.ldc + (i % pr.N);
-    *dst += (a0 + a1) + (a2 + a3);
+    *dst = v;
   }
 }
 
@@ -655,7 +672,25 @@ size_t gemm_tn_multi_scratch_floats(const GemmTnMulti &mm) {
 }
 
 int launch_gemm_tn_multi(GemmTnMulti &m, float *scratch, size_t scratch_floats, hipStream_t s) {
-  HN_REQUIRE(m.n >= 0 && m.n <= TN_MULTI_MAX && m.n_ln >= 0 && m.n_ln <= 4 && m.K > 0, HN_E_SHAPE, "gemm_tn_multi: n=%d n_ln=%d K=%d", m.n, m.n_ln, m.K);
+  HN_REQUIRE(m.n >= 0 && m.n <= TN_MULTI_MAX && m.n_ln >= 0 && m.n_ln <= TN_MULTI_LN_MAX && m.K > 0, HN_E_SHAPE, "gemm_tn_multi: n=%d n_ln=%d K=%d", m.n, m.n_ln, m.K);
+  // destinations that occur more than once: one reduce pass per destination, members folded in launch order
+  for (int i = 0; i < m.n; ++i) { m.p[i].next = -1; m.p[i].follower = 0; }
+  for (int i = 0; i < m.n; ++i)
+    for (int j = i - 1; j >= 0; --j)
+      if (m.p[j].C == m.p[i].C) {
+        HN_REQUIRE(m.p[j].M == m.p[i].M && m.p[j].N == m.p[i].N && m.p[j].ldc == m.p[i].ldc && m.p[j].colsum == m.p[i].colsum, HN_E_SHAPE,
+                   "gemm_tn_multi: products %d and %d share a destination but not its shape", j, i);
+        m.p[j].next = i; m.p[i].follower = 1;
+        break;
+      }
+  for (int i = 0; i < m.n_ln; ++i) { m.ln[i].next = -1; m.ln[i].follower = 0; }
+  for (int i = 0; i < m.n_ln; ++i)
+    for (int j = i - 1; j >= 0; --j)
+      if (m.ln[j].out == m.ln[i].out) {
+        HN_REQUIRE(m.ln[j].width == m.ln[i].width, HN_E_SHAPE, "gemm_tn_multi: LayerNorm entries %d and %d share a destination but not its width", j, i);
+        m.ln[j].next = i; m.ln[i].follower = 1;
+        break;
+      }
   for (int i = 0; i < m.n; ++i) {
     const TnProduct &p = m.p[i];
     HN_REQUIRE(p.A && p.B && p.C && p.M >= 16 && p.N >= 16 && (p.lda & 3) == 0 && (p.ldb & 3) == 0 && ((uintptr_t)p.A & 15) == 0 &&

@@ -433,7 +433,8 @@ struct BChainArgs {
 bool latent_bchain_supported(int rows, int d, int hidden);
 int launch_latent_bchain(const BChainArgs &a, hipStream_t s);
 // several TN products C_i += A_i^T B_i (+ colsum_i += column sums of A_i) over ONE contraction length K in one launch + one reduce
-constexpr int TN_MULTI_MAX = 6;
+constexpr int TN_MULTI_MAX = 32;       // products of one batched launch (round 5: the chains of a whole layer; 6 until then: one chain)
+constexpr int TN_MULTI_LN_MAX = 16;    // LayerNorm partial-sum entries of one batched launch (the argument struct stays below 4 KB)
 struct TnProduct {
   const float *A; long lda;            // (K, M)
   const float *B; long ldb;            // (K, N)
@@ -441,16 +442,21 @@ struct TnProduct {
   int M, N;
   float *colsum;                       // (M) accumulated into, or NULL
   long part_off, cs_off;               // internal: scratch offsets of the split partials
+  // internal: products of one launch that accumulate into the SAME C (a module shared by two blocks of a layer: the latent self block
+  // runs behind every modality) are folded by ONE reduce pass, in launch order -- `next`: the following product of the chain or
+  // -1; `follower`: not the head of its chain (its reduce blocks return at once)
+  int next, follower;
 };
-struct LnPartial { const float *part; int nwg, width; long stride; float *out; };     // out[c] += sum_w part[w * stride + c]
+struct LnPartial { const float *part; int nwg, width; long stride; float *out; int next, follower; };     // out[c] += sum_w part[w * stride + c]
 struct GemmTnMulti {
   int n, n_ln;
   TnProduct p[TN_MULTI_MAX];
-  LnPartial ln[4];
+  LnPartial ln[TN_MULTI_LN_MAX];
   int tile0[TN_MULTI_MAX + 1];         // internal
   int K, kslice, nsplit;
   float *scratch;
 };
+static_assert(sizeof(GemmTnMulti) <= 3840, "GemmTnMulti travels as a kernel argument (4 KB limit)");
 size_t gemm_tn_multi_scratch_floats(const GemmTnMulti &m);
 int launch_gemm_tn_multi(GemmTnMulti &m, float *scratch, size_t scratch_floats, hipStream_t s);
 const float *transpose_cache_lookup(const float *src, long ld, int rows, int cols);
