@@ -702,10 +702,21 @@ static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float
   const float two_scale = 2.0f / sqrtf((float)dh_valid(p));
   // dpre = dy * LeakyReLU'(pre); the sign of pre is the sign of y = x_out - x_in
   const float *dpre = bp.dpre;
+  const bool one_token = has_ctx && pl.N == 1 && !general;
+  const bool one_token_fused = one_token && !ext && onetoken_bwd_fused_ok(b, qd);      // (forms dpre itself, row by row)
   if (ext && ext->dpre) dpre = ext->dpre;
-  else if ((rc = launch_leaky_bwd(dy, x_out, residual ? x_in : nullptr, bp.dpre, (long)rows * qd, s)) != HN_OK) return rc;
+  else if (!one_token_fused && (rc = launch_leaky_bwd(dy, x_out, residual ? x_in : nullptr, bp.dpre, (long)rows * qd, s)) != HN_OK) return rc;
 
-  if (has_ctx && pl.N == 1 && !general) {
+  if (one_token_fused) {
+    // ---- one-token context, three launches (backward.hip "Backward of the one-token cross block")
+    if ((rc = launch_onetoken_bwd(dy, x_out, residual ? x_in : nullptr, b, L, qd, p->w_out, wo_ld(p), inner, saved, ctx, ld_ctx, pl.D,
+                                  p->w_kv + (long)inner * pl.D, p->ctx_gamma, p->ctx_beta, bp.dyb, bp.dV, g->w_out, g->b_out,
+                                  g->w_kv ? g->w_kv + (long)inner * pl.D : nullptr, g->ctx_gamma, g->ctx_beta, bp.red, s)) != HN_OK) return rc;
+    if (residual) { if (dx != dy) return launch_add_into(dy, dx, (long)rows * qd, 0, s); return HN_OK; }
+    { int rc_ = launch_fill(dx, 0.0f, (long)((size_t)rows * qd), s); if (rc_ != HN_OK) return rc_; }
+    return HN_OK;
+  }
+  if (one_token) {
     HN_REQUIRE(!ext, HN_E_UNSUPPORTED, "attn_bwd: the one-token shortcut takes no chain hooks");   // ---- one-token context: y_b = LeakyReLU(W_out V_b + b_out) for every row
     if ((rc = launch_segsum(bp.dpre, L, qd, b, bp.dyb, s)) != HN_OK) return rc;
     if (g->b_out && (rc = launch_colsum(bp.dyb, qd, b, qd, 1.0f, g->b_out, 1, s, bp.red)) != HN_OK) return rc;

@@ -1120,6 +1120,162 @@ int launch_kv_weight_grads(const float *G, const float *cs, const float *w, cons
   return HN_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Backward of the one-token cross block (tabular / omic modality; healnet.py:236 with N = 1: y_b = LeakyReLU(W_out V_b + b_out) added
+// to every latent row of sample b, V_b = (c_hat_b * gamma + beta) W_v^T) in FOUR launches instead of nine (round 5: at cfg4 b = 8 the
+// nine were 58 us per layer of 4-10 us launches on 8 rows):
+//   onetok_dyb_kernel          dyb = per-sample sum over the latent rows of dy * LeakyReLU'(.)   (was: leaky_bwd + segsum)
+//   onetok_dv_kernel           dV = dyb W_out
+//                              (a first version ran both in ONE workgroup per sample: 8 workgroups walking 128 rows and 128
+//                              weight rows in dependent trips -- +0.13 ms per cfg4 step instead of a gain; these two keep the
+//                              old kernels' parallelism)
+//   onetok_bwd_weights_kernel  workgroup roles: [0, qd) dW_out[q, :] += sum_b dyb[b, q] V[b, :] and db_out[q] += sum_b dyb[b, q];
+//                              the rest: dW_v += G * gamma + cs (x) beta with G = dV^T c_hat and cs = colsum(dV) formed on the fly
+//                              from the b rows, and the row-chunk partials of dgamma / dbeta (was: two products, two column sums and
+//                              kv_weight_grads_kernel)
+//   kv_affine_reduce_kernel    as before.
+// b <= ONETOK_MAX_B (the sample dimension is the contraction: its operands sit in registers).
+// ------------------------------------------------------------------------------------------------
+constexpr int ONETOK_MAX_B = 32;
+
+// dyb[b, q] = sum over the L latent rows of sample b of dy * LeakyReLU'(y), y = x_out - x_in: 64 columns per workgroup, the four
+// waves split the rows, four rows' loads in flight per trip, fixed-order LDS fold (segsum_kernel with the LeakyReLU factor fused in)
+__global__ __launch_bounds__(256) void onetok_dyb_kernel(const float *__restrict__ dy, const float *__restrict__ x_out, const float *x_in,
+                                                         int L, int qd, float *__restrict__ dyb) {
+  __shared__ float part[4][64];
+  const int bi = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int q = blockIdx.x * 64 + lane;
+  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+  if (q < qd) {
+    const long base = (long)bi * L * qd + q;
+    int r = w;
+    for (; r + 12 < L; r += 16) {
+      float d[4], xo[4], xi[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long i = base + (long)(r + 4 * u) * qd;
+        d[u] = dy[i]; xo[u] = x_out[i]; xi[u] = x_in ? x_in[i] : 0.0f;
+      }
+      s0 += d[0] * ((xo[0] - xi[0]) > 0.0f ? 1.0f : 0.01f); s1 += d[1] * ((xo[1] - xi[1]) > 0.0f ? 1.0f : 0.01f);
+      s2 += d[2] * ((xo[2] - xi[2]) > 0.0f ? 1.0f : 0.01f); s3 += d[3] * ((xo[3] - xi[3]) > 0.0f ? 1.0f : 0.01f);
+    }
+    for (; r < L; r += 4) {
+      const long i = base + (long)r * qd;
+      const float y = x_in ? x_out[i] - x_in[i] : x_out[i];
+      s0 += dy[i] * (y > 0.0f ? 1.0f : 0.01f);
+    }
+  }
+  part[w][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (w == 0 && q < qd) dyb[(long)bi * qd + q] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+}
+
+// dV[b, i] = sum_q dyb[b, q] W_out[q, i]: 64 columns i per workgroup, the four waves split q, eight loads in flight per trip
+__global__ __launch_bounds__(256) void onetok_dv_kernel(const float *__restrict__ dyb, const float *__restrict__ w_out, long ldwo, int qd,
+                                                        int inner, float *__restrict__ dV) {
+  __shared__ float part[4][64];
+  const int bi = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
+  const float *db = dyb + (long)bi * qd;
+  float a0 = 0.0f, a1 = 0.0f;
+  if (i < inner) {
+    int q = w;
+    for (; q + 28 < qd; q += 32) {
+      float wv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) wv[u] = w_out[(long)(q + 4 * u) * ldwo + i];
+#pragma unroll
+      for (int u = 0; u < 8; u += 2) { a0 = fmaf(db[q + 4 * u], wv[u], a0); a1 = fmaf(db[q + 4 * (u + 1)], wv[u + 1], a1); }
+    }
+    for (; q < qd; q += 4) a0 = fmaf(db[q], w_out[(long)q * ldwo + i], a0);
+  }
+  part[w][lane] = a0 + a1;
+  __syncthreads();
+  if (w == 0 && i < inner) dV[(long)bi * inner + i] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+}
+
+__global__ __launch_bounds__(256) void onetok_bwd_weights_kernel(const float *__restrict__ dyb, const float *__restrict__ V,
+                                                                 const float *__restrict__ dV, const float *__restrict__ ctx, int ld_ctx,
+                                                                 const float *__restrict__ w_v, const float *gamma, const float *beta, int b,
+                                                                 int qd, int inner, int D, float *dw_out, long ldwo, float *db_out, float *dw_v,
+                                                                 float *__restrict__ partial, int nchunks, int cblocks) {
+  if ((int)blockIdx.x < qd) {                         // ---- role A: one row q of dW_out, and db_out[q]
+    const int q = blockIdx.x;
+    float dq[ONETOK_MAX_B];
+    float bsum = 0.0f;
+#pragma unroll
+    for (int k = 0; k < ONETOK_MAX_B; ++k) { dq[k] = k < b ? dyb[(long)k * qd + q] : 0.0f; bsum += dq[k]; }
+    if (dw_out)
+      for (int i = threadIdx.x; i < inner; i += blockDim.x) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < ONETOK_MAX_B; ++k)
+          if (k < b) acc = fmaf(dq[k], V[(long)k * inner + i], acc);
+        dw_out[(long)q * ldwo + i] += acc;
+      }
+    if (db_out && threadIdx.x == 0) db_out[q] += bsum;
+    return;
+  }
+  // ---- role B: the value half of to_kv and the context LayerNorm's affine (kv_weight_grads_kernel with G and cs formed here)
+  __shared__ float pg[4][64], pb[4][64];
+  const int r = (int)blockIdx.x - qd, bx = r % cblocks, by = r / cblocks;
+  const int c = bx * 64 + (threadIdx.x & 63), wv = threadIdx.x >> 6;
+  const int chunk = (inner + nchunks - 1) / nchunks;
+  const int n0 = by * chunk, n1 = min(inner, n0 + chunk);
+  float sg = 0.0f, sb = 0.0f;
+  if (c < D) {
+    float zc[ONETOK_MAX_B];
+#pragma unroll
+    for (int k = 0; k < ONETOK_MAX_B; ++k) zc[k] = k < b ? ctx[(long)k * ld_ctx + c] : 0.0f;
+    const float gm = gamma ? gamma[c] : 1.0f, bt = beta ? beta[c] : 0.0f;
+    for (int n = n0 + wv; n < n1; n += 4) {
+      float g = 0.0f, csn = 0.0f;
+#pragma unroll
+      for (int k = 0; k < ONETOK_MAX_B; ++k)
+        if (k < b) { const float dv = dV[(long)k * inner + n]; g = fmaf(dv, zc[k], g); csn += dv; }
+      const float wnc = w_v[(long)n * D + c];
+      if (dw_v) dw_v[(long)n * D + c] += g * gm + csn * bt;
+      sg += wnc * g;
+      sb += wnc * csn;
+    }
+  }
+  pg[wv][threadIdx.x & 63] = sg;
+  pb[wv][threadIdx.x & 63] = sb;
+  __syncthreads();
+  if (wv == 0 && c < D && partial) {      // row-chunk partials of (dgamma, dbeta), summed in fixed order by kv_affine_reduce_kernel
+    partial[((long)by * 2 + 0) * D + c] = pg[0][threadIdx.x] + pg[1][threadIdx.x] + pg[2][threadIdx.x] + pg[3][threadIdx.x];
+    partial[((long)by * 2 + 1) * D + c] = pb[0][threadIdx.x] + pb[1][threadIdx.x] + pb[2][threadIdx.x] + pb[3][threadIdx.x];
+  }
+}
+
+bool onetoken_bwd_fused_ok(int b, int qd) {
+  static const bool off = getenv("HN_NO_ONETOK_FUSED") != nullptr;      // route switch (A/B): the nine-launch sequence
+  return !off && b >= 1 && b <= ONETOK_MAX_B && qd >= 1 && qd <= 4096;
+}
+
+// dyb (b, qd) and dV (b, inner): scratch; `partial`: >= KVG_CHUNKS * 2 * D floats.  Gradient pointers may be NULL.
+int launch_onetoken_bwd(const float *dy, const float *x_out, const float *x_in, int b, int L, int qd, const float *w_out, long ldwo,
+                        int inner, const float *V, const float *ctx, int ld_ctx, int D, const float *w_v, const float *gamma,
+                        const float *beta, float *dyb, float *dV, float *dw_out, float *db_out, float *dw_v, float *dgamma, float *dbeta,
+                        float *partial, hipStream_t s) {
+  HN_REQUIRE(dy && x_out && w_out && V && ctx && w_v && dyb && dV && partial, HN_E_NULL, "onetoken_bwd: NULL pointer");
+  HN_REQUIRE(onetoken_bwd_fused_ok(b, qd), HN_E_UNSUPPORTED, "onetoken_bwd: b=%d qd=%d", b, qd);
+  hipLaunchKernelGGL(onetok_dyb_kernel, dim3(ceil_div(qd, 64), b), dim3(256), 0, s, dy, x_out, x_in, L, qd, dyb);
+  HN_LAUNCH_CHECK("onetok_dyb");
+  hipLaunchKernelGGL(onetok_dv_kernel, dim3(ceil_div(inner, 64), b), dim3(256), 0, s, dyb, w_out, ldwo, qd, inner, dV);
+  HN_LAUNCH_CHECK("onetok_dv");
+  const bool affine = gamma != nullptr && (dgamma != nullptr || dbeta != nullptr);
+  const int cblocks = ceil_div(D, 64);
+  hipLaunchKernelGGL(onetok_bwd_weights_kernel, dim3(qd + cblocks * KVG_CHUNKS), dim3(256), 0, s, dyb, V, dV, ctx, ld_ctx, w_v, gamma, beta, b, qd,
+                     inner, D, dw_out, ldwo, db_out, dw_v, affine ? partial : nullptr, KVG_CHUNKS, cblocks);
+  HN_LAUNCH_CHECK("onetok_bwd_weights");
+  if (affine) {
+    hipLaunchKernelGGL(kv_affine_reduce_kernel, dim3(ceil_div(D, 256)), dim3(256), 0, s, partial, KVG_CHUNKS, D, dgamma, dbeta);
+    HN_LAUNCH_CHECK("kv_affine_reduce");
+  }
+  return HN_OK;
+}
+
 // out[seg, c] = sum of `seg` consecutive rows of X (nseg segments): per-sample sums over the latent rows
 __global__ __launch_bounds__(256) void segsum_kernel(const float *__restrict__ X, int seg, int cols, float *__restrict__ out) {
   // 64 columns per workgroup, the 4 waves split the segment's rows (4 independent chains each), fixed-order LDS reduce

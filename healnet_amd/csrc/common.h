@@ -661,6 +661,12 @@ int launch_srow_affine(const float *saved, const float *dA, const float *gamma, 
 int launch_kv_weight_grads(const float *G, const float *cs, const float *w, const float *gamma, const float *beta, int nrows, int D,
                            float *dw, float *dgamma, float *dbeta, hipStream_t s, float *scratch);
 int launch_segsum(const float *X, int seg, int cols, int nseg, float *out, hipStream_t s);
+// backward of the one-token cross block in three launches (backward.hip)
+bool onetoken_bwd_fused_ok(int b, int qd);
+int launch_onetoken_bwd(const float *dy, const float *x_out, const float *x_in, int b, int L, int qd, const float *w_out, long ldwo,
+                        int inner, const float *V, const float *ctx, int ld_ctx, int D, const float *w_v, const float *gamma,
+                        const float *beta, float *dyb, float *dV, float *dw_out, float *db_out, float *dw_v, float *dgamma, float *dbeta,
+                        float *partial, hipStream_t s);
 
 // misc
 int launch_broadcast_rows(const float *src, float *dst, long n_per, int b, hipStream_t s, int *zero = nullptr, int nzero = 0);
