@@ -137,6 +137,28 @@ def test_fused_backward_equals_the_per_block_launches(name, tmp_path):
     assert differ > 0, "the fused route produced bit-identical gradients: HN_NO_BCHAIN did not change the route?"
 
 
+@pytest.mark.parametrize("switch", ["HN_NO_TN_BATCH", "HN_NO_ONETOK_FUSED", "HN_FORCE_TORCH_OPS"])
+@pytest.mark.parametrize("name", ["three_bindings", "tied_depth3"])
+def test_round5_routes_equal_their_predecessors(name, switch, tmp_path):
+    """Round 5: the chains' weight-gradient products of a layer in one batched launch (duplicate destinations folded in one reduce
+    pass), the one-token block's backward in four launches, and the eager route behind a plain autograd.Function -- each against
+    the route it replaced (its switch, in a subprocess): gradients equal to fp32 summation noise; bit for bit for the host route."""
+    grads = {}
+    for tag, env in (("new", {}), ("old", {switch: "1"})):
+        dst = str(tmp_path / f"{tag}.pt")
+        out = subprocess.run([sys.executable, "-c", _SCRIPT.format(root=ROOT, name=name, dst=dst)], cwd=ROOT, capture_output=True, text=True,
+                             timeout=600, env=dict(os.environ, **env))
+        assert out.returncode == 0, out.stderr[-3000:]
+        grads[tag] = torch.load(dst)
+    scale = max(float(v.abs().max()) for v in grads["old"].values())
+    for k, ref in grads["old"].items():
+        got = grads["new"][k]
+        if switch == "HN_FORCE_TORCH_OPS":
+            assert torch.equal(got, ref), k
+        else:
+            assert float((got - ref).abs().max()) <= 2e-5 * scale + 1e-4 * float(ref.abs().max()), k
+
+
 @pytest.mark.parametrize("b,l_c", [(8, 128), (16, 128), (4, 32)], ids=["64tiles_c4", "128tiles_c2", "8tiles_c4"])
 def test_cluster_mode_gradients_bitwise_reproducible_and_vs_oracle(b, l_c):
     """Row-tile counts that run the forward AND backward chains as clusters (4 workgroups per tile up to 64 tiles, 2 up to 128; two
