@@ -22,6 +22,7 @@
 //
 // Shapes: l_d = 128, hidden 512, nq / nkv / inner_o multiples of 128 (nq + nkv <= 1536), rows % 16 == 0.
 #include "common.h"
+#include <stddef.h>
 #include <stdlib.h>
 
 namespace hn {
@@ -297,10 +298,12 @@ __global__ __launch_bounds__(512) void latent_bchain_kernel(const BChainArgs arg
       __hip_atomic_store(slot + (long)member * (CR * CD) + (4 * fg + r) * CD + ncol, v[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0 && !(args.inject_loss && member == a_C - 1))      // (fault injection: the last member's flag never goes up)
+    if (tid == 0 && !(late_kernarg<int>(offsetof(BChainArgs, inject_loss)) && member == a_C - 1))      // (fault injection: the last member's flag never goes up)
       __hip_atomic_store(flags + member, args.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int timed_out = 0;                         // bounded wait, reported (cluster_wait, chain_common.h): no hang ...
-    if (tid < a_C) timed_out = cluster_wait(flags + tid, args.seq, args.wait_ticks, args.xflags + 2 * ntiles * a_C, args.status, args.token);
+    if (tid < a_C)
+      timed_out = cluster_wait(flags + tid, args.seq, late_kernarg<unsigned>(offsetof(BChainArgs, wait_ticks)), args.xflags + 2 * ntiles * a_C,
+                               late_kernarg<unsigned *>(offsetof(BChainArgs, status)), late_kernarg<unsigned>(offsetof(BChainArgs, token)));
     // ... and no silently incomplete sum either: a tile that gave up on a member becomes NaN (chain.hip explains)
     const bool lost = __syncthreads_or(timed_out) != 0;
     float4 acc = lost ? make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")) : make_float4(0.f, 0.f, 0.f, 0.f);

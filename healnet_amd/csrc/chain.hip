@@ -61,6 +61,7 @@
 #include <stdlib.h>
 #include <mutex>
 #include <string.h>
+#include <stddef.h>
 
 namespace hn {
 
@@ -252,6 +253,18 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
     // order: one group for the usual 8-12 splits, up to four when a small batch needs more splits to fill the wave slots
     float M = -3.0e38f, l = 0.0f;
     float4 o0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // the lane's rows of the folded value projection (dh / 16 <= 4 column tiles), requested WITH the partials: loading each in front
+    // of its four MFMAs was a dependent round trip per tile -- 13.7 k cycles in this prologue against ~2 k without head 3
+    // (tools/chain_profile.py, round 5)
+    float4 bw[4];
+    {
+      const gf32 *wbase = a_wvf + ((long)(wave * a_dh + i) * 16 + 4 * gq);      // tile ct: + ct * 256 floats
+      const int nct = a_dh >> 4;
+      bw[0] = gld4(wbase);
+      bw[1] = gld4(wbase + (1 < nct ? 256 : 0));
+      bw[2] = gld4(wbase + (2 < nct ? 512 : 0));
+      bw[3] = gld4(wbase + (3 < nct ? 768 : 0));
+    }
     for (int s0 = 0; s0 < a_nsplit; s0 += CHAIN_MERGE_GROUP) {
       float mv[CHAIN_MERGE_GROUP], lv[CHAIN_MERGE_GROUP];
       float4 ov[CHAIN_MERGE_GROUP];
@@ -283,9 +296,10 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
       gst1(st, M);
       gst1(st + 1, l);
     }
-    for (int ct = 0; ct < (a_dh >> 4); ++ct) {                            // 16 output columns of the head at a time
-      const gf32 *wrow = a_wvf + ((long)(wave * a_dh + 16 * ct + i) * 16 + 4 * gq);
-      const float4 b0 = gld4(wrow);
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {                                      // 16 output columns of the head at a time
+      if (ct >= (a_dh >> 4)) break;
+      const float4 b0 = bw[ct];
       f32x4 c = {0.f, 0.f, 0.f, 0.f};
       c = __builtin_amdgcn_mfma_f32_16x16x4f32(o0.x, b0.x, c, 0, 0, 0);
       c = __builtin_amdgcn_mfma_f32_16x16x4f32(o0.y, b0.y, c, 0, 0, 0);
@@ -554,7 +568,7 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
       // the flag.
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (tid == 0 && !(args.inject_loss && member == a_C - 1))      // ... before the member's flag goes up (fault injection: the last member's never does)
+      if (tid == 0 && !(late_kernarg<int>(offsetof(ChainArgs, inject_loss)) && member == a_C - 1))      // ... before the member's flag goes up (fault injection: the last member's never does)
         __hip_atomic_store(args.xflags + tile * a_C + member, args.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       // one lane per member flag; bounded wait (cluster_wait, chain_common.h): the dispatch order of a cluster grid keeps the
       // members of a tile together, but a member that still never shows up must not hang the device.  A tile that gives up is NOT
@@ -562,7 +576,8 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
       // sample, and the launch reports itself in the device's status word (HN_E_CORESIDENCY).
       int timed_out = 0;
       if (tid < a_C)
-        timed_out = cluster_wait(args.xflags + tile * a_C + tid, args.seq, args.wait_ticks, args.xflags + ntiles * a_C, args.status, args.token);
+        timed_out = cluster_wait(args.xflags + tile * a_C + tid, args.seq, late_kernarg<unsigned>(offsetof(ChainArgs, wait_ticks)), args.xflags + ntiles * a_C,
+                                 late_kernarg<unsigned *>(offsetof(ChainArgs, status)), late_kernarg<unsigned>(offsetof(ChainArgs, token)));
       const bool lost = __syncthreads_or(timed_out) != 0;
       {
         const int row = tid >> 5, l32 = tid & 31;

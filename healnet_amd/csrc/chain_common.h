@@ -29,6 +29,14 @@ __device__ __forceinline__ void cluster_decode(int bid, int C, int ntiles, int s
   member = r >> 3;
   tile = g * 8 + (r & 7);
 }
+// A field of the by-value argument struct read from the kernel-argument segment WHERE IT IS USED (volatile: not hoisted).  The cluster
+// fields are touched once per launch, in the exchange; loaded at kernel entry like the others they stayed live across the whole weight
+// stream and pushed 17 / 44 SGPRs of the chain kernels into spills (round 5).
+template <typename T>
+__device__ __forceinline__ T late_kernarg(size_t offset) {
+  return *(const volatile T __attribute__((address_space(4))) *)((const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() + offset);
+}
+
 // Wait (one lane per member flag) until `flag` reaches `seq`, for at most `ticks` of the 100 MHz s_memrealtime clock.  A member
 // that never shows up must neither hang the device nor let the tile carry on with an incomplete sum: the caller turns the tile
 // into NaN, and the loss is REPORTED -- the launch's marker word in the workspace, and the launch's token in the host-mapped
