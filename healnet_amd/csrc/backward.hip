@@ -894,9 +894,56 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ X
   }
 }
 
+// Narrow matrices (row pitch 16 or 32 floats: the per-head channel rows of the shared-context backward, 13 or 18 valid columns):
+// the wide kernel above keeps 13 of 64 lanes busy, 64 bytes apart (17 us for 32768 x 16 at cfg2 b = 32, six times per image block).
+// Here a wave covers 64 / ld whole rows per trip -- contiguous 256 bytes -- and the row groups are folded in LDS in a fixed order.
+template <int LD>
+__global__ __launch_bounds__(256) void colsum_narrow_kernel(const float *__restrict__ X, long rows, int cols, float scale,
+                                                            float *__restrict__ out, long out_pitch, int accumulate) {
+  constexpr int RPW = 64 / LD;                       // rows per wave and trip
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = lane % LD, rs = lane / LD;
+  const long chunk = (rows + gridDim.y - 1) / gridDim.y;
+  const long r0 = (long)blockIdx.y * chunk, r1 = min(rows, r0 + chunk);
+  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+  long r = r0 + w * RPW + rs;
+  for (; r + 12 * RPW < r1; r += 16 * RPW) {
+    s0 += X[r * LD + c]; s1 += X[(r + 4 * RPW) * LD + c];
+    s2 += X[(r + 8 * RPW) * LD + c]; s3 += X[(r + 12 * RPW) * LD + c];
+  }
+  for (; r < r1; r += 4 * RPW) s0 += X[r * LD + c];
+  part[w][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (threadIdx.x < LD && (int)threadIdx.x < cols) {
+    float v = 0.0f;
+#pragma unroll
+    for (int ww = 0; ww < 4; ++ww)
+#pragma unroll
+      for (int g = 0; g < RPW; ++g) v += part[ww][g * LD + threadIdx.x];
+    float *dst = out + (long)blockIdx.y * out_pitch + threadIdx.x;
+    *dst = accumulate ? *dst + scale * v : scale * v;
+  }
+}
+
 int launch_colsum(const float *X, long ld, long rows, int cols, float scale, float *out, int accumulate, hipStream_t s,
                   float *scratch) {
   HN_REQUIRE(X && out && rows > 0 && cols > 0, HN_E_SHAPE, "colsum: rows=%ld cols=%d", rows, cols);
+  static const bool no_narrow = getenv("HN_NO_NARROW_COLSUM") != nullptr;      // route switch (A/B)
+  if (!no_narrow && (ld == 16 || ld == 32) && cols <= ld && rows >= 64) {
+    const bool two = scratch != nullptr && rows >= 4096;
+    const int chunks = two ? COLSUM_CHUNKS : 1;
+    float *o1 = two ? scratch : out;
+    if (ld == 16) hipLaunchKernelGGL(colsum_narrow_kernel<16>, dim3(1, chunks), dim3(256), 0, s, X, rows, cols, two ? 1.0f : scale, o1, two ? 16L : 0L, two ? 0 : accumulate);
+    else hipLaunchKernelGGL(colsum_narrow_kernel<32>, dim3(1, chunks), dim3(256), 0, s, X, rows, cols, two ? 1.0f : scale, o1, two ? 32L : 0L, two ? 0 : accumulate);
+    HN_LAUNCH_CHECK("colsum(narrow)");
+    if (two) {      // the 128 chunk rows (pitch ld, columns >= cols never written / never read)
+      if (ld == 16) hipLaunchKernelGGL(colsum_narrow_kernel<16>, dim3(1, 1), dim3(256), 0, s, scratch, (long)COLSUM_CHUNKS, cols, scale, out, 0L, accumulate);
+      else hipLaunchKernelGGL(colsum_narrow_kernel<32>, dim3(1, 1), dim3(256), 0, s, scratch, (long)COLSUM_CHUNKS, cols, scale, out, 0L, accumulate);
+      HN_LAUNCH_CHECK("colsum(narrow, stage 2)");
+    }
+    return HN_OK;
+  }
   if (scratch && rows >= 4096) {
     hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(cols, 64), COLSUM_CHUNKS), dim3(256), 0, s, X, ld, rows, cols, 1.0f, scratch,
                        (long)cols, 0);
