@@ -137,11 +137,12 @@ def test_fused_backward_equals_the_per_block_launches(name, tmp_path):
     assert differ > 0, "the fused route produced bit-identical gradients: HN_NO_BCHAIN did not change the route?"
 
 
-@pytest.mark.parametrize("switch", ["HN_NO_TN_BATCH", "HN_NO_ONETOK_FUSED", "HN_FORCE_TORCH_OPS"])
+@pytest.mark.parametrize("switch", ["HN_NO_TN_BATCH", "HN_NO_ONETOK_FUSED", "HN_NO_NARROW_COLSUM", "HN_FORCE_TORCH_OPS"])
 @pytest.mark.parametrize("name", ["three_bindings", "tied_depth3"])
 def test_round5_routes_equal_their_predecessors(name, switch, tmp_path):
     """Round 5: the chains' weight-gradient products of a layer in one batched launch (duplicate destinations folded in one reduce
-    pass), the one-token block's backward in four launches, and the eager route behind a plain autograd.Function -- each against
+    pass), the one-token block's backward in four launches, the narrow column sums of the shared-context backward, and the eager route
+    behind a plain autograd.Function -- each against
     the route it replaced (its switch, in a subprocess): gradients equal to fp32 summation noise; bit for bit for the host route."""
     grads = {}
     for tag, env in (("new", {}), ("old", {switch: "1"})):
