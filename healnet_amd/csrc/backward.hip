@@ -452,14 +452,21 @@ __global__ __launch_bounds__(256) void splitk_reduce_multi_kernel(GemmTnMulti mm
       float v = l0.out[c];
       for (int e = pi - mm.n; e >= 0; e = mm.ln[e].next) {
         const LnPartial &lp = mm.ln[e];
-        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+        // ONE workgroup walks the nwg = rows / 16 partial rows of an entry: sixteen loads in flight per trip (four were 64 dependent
+        // trips at cfg2 b = 32 -- this loop, not the products' partials, was the launch's 70 us)
+        float a[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) a[u] = 0.0f;
         int k = 0;
-        for (; k + 4 <= lp.nwg; k += 4) {
-          a0 += lp.part[(long)k * lp.stride + c]; a1 += lp.part[(long)(k + 1) * lp.stride + c];
-          a2 += lp.part[(long)(k + 2) * lp.stride + c]; a3 += lp.part[(long)(k + 3) * lp.stride + c];
+        for (; k + 16 <= lp.nwg; k += 16) {
+          float t[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) t[u] = lp.part[(long)(k + u) * lp.stride + c];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) a[u] += t[u];
         }
-        for (; k < lp.nwg; ++k) a0 += lp.part[(long)k * lp.stride + c];
-        v += (a0 + a1) + (a2 + a3);
+        for (; k < lp.nwg; ++k) a[0] += lp.part[(long)k * lp.stride + c];
+        v += (((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) + (((a[8] + a[9]) + (a[10] + a[11])) + ((a[12] + a[13]) + (a[14] + a[15])));
       }
       l0.out[c] = v;
     }
