@@ -128,6 +128,18 @@ class FlatParameters:
         ``grads`` (-1: not trainable), or None when some trainable parameter's ``.grad`` is not its slot of the flat buffer
         (set_to_none zeroing, a foreign ``.grad``) -- the backward then returns ordinary gradients to autograd and
         ``relink()`` repairs the layout before the next optimizer step."""
+        # fast path (a training loop calls this with the same parameter list every step: 146 parameters x three tensor queries were
+        # 0.13 ms of the kirp step's host time): the previous answer holds while every parameter is the same object and still has the
+        # very gradient view this buffer handed out (the objects are kept alive here, so identity cannot be recycled)
+        fast = self.__dict__.get("_direct_fast")
+        if fast is not None and len(params) == len(fast[0]) and fast[3] == self.grads.data_ptr():
+            ok = True
+            for p, q, g in zip(params, fast[0], fast[1]):
+                if p is not q or (g is not None and (p.grad is not g or not p.requires_grad)):
+                    ok = False
+                    break
+            if ok:
+                return fast[2]
         slot = self.__dict__.get("_slot_of")
         if slot is None:
             slot = self._slot_of = {id(p): off for p, off in zip(self.views, self.offsets)}
@@ -144,6 +156,7 @@ class FlatParameters:
             if not p.requires_grad or g is None or not g.is_contiguous() or g.data_ptr() != base + 4 * off:
                 return None
             out.append(off)
+        self._direct_fast = (list(params), [p.grad if o >= 0 else None for p, o in zip(params, out)], out, base)
         return out
 
     def relink(self) -> None:

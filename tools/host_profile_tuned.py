@@ -5,7 +5,9 @@ import cProfile, os, pstats, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import healnet_amd as hn
-kw = dict(depth=2, l_c=25, l_d=119, cross_dim_head=16, latent_dim_head=127, attn_dropout=0.0830, ff_dropout=0.4733)
+TUNED = {"blca": dict(depth=2, l_c=25, l_d=119, cross_dim_head=16, latent_dim_head=127, attn_dropout=0.0830, ff_dropout=0.4733),
+         "kirp": dict(depth=5, l_c=17, l_d=62, cross_dim_head=27, latent_dim_head=113, attn_dropout=0.3179, ff_dropout=0.0474)}
+kw = TUNED[sys.argv[1] if len(sys.argv) > 1 else "blca"]
 extra = dict(x_heads=1, l_heads=8, self_per_cross_attn=0, num_freq_bands=2, max_freq=2.0)
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
@@ -45,3 +47,4 @@ torch.cuda.synchronize()
 pr.disable()
 st = pstats.Stats(pr)
 st.sort_stats("cumulative").print_stats(28)
+st.sort_stats("tottime").print_stats(14)
