@@ -12,7 +12,7 @@ import sys
 from typing import Optional
 
 HN_MAX_AXES = 4
-HN_ABI_VERSION = 10
+HN_ABI_VERSION = 11
 HN_F32, HN_BF16, HN_U8 = 0, 1, 2
 HN_CORE_F32, HN_CORE_BF16, HN_CORE_BF16X3 = 0, 1, 2
 HN_E_SHAPE, HN_E_UNSUPPORTED, HN_E_WORKSPACE, HN_E_HIP, HN_E_NULL, HN_E_CORESIDENCY = -1, -2, -3, -4, -5, -6
@@ -164,6 +164,15 @@ SIGNATURES = {
                               C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(AttnGrads),
                               C.c_void_p, C.c_size_t, C.c_void_p]),
     "hn_attn_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(AttnParams)] + [C.c_int] * 7),
+    # context split, training (ABI v11)
+    "hn_attn_saved_part_width": (C.c_int, [C.POINTER(AttnParams)] + [C.c_int] * 5),
+    "hn_attn_merge_parts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                      C.c_void_p, C.c_void_p]),
+    "hn_attn_finish_fwd": (C.c_int, [C.POINTER(AttnParams), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "hn_attn_bwd_cp": (C.c_int, [C.POINTER(AttnParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(AttnGrads), C.c_int, C.c_void_p, C.c_size_t,
+                                 C.c_void_p]),
     "hn_ff_bwd": (C.c_int, [C.POINTER(FFParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(FFGrads),
                             C.c_void_p, C.c_size_t, C.c_void_p]),
     "hn_ff_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(FFParams), C.c_int]),

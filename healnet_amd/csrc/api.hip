@@ -674,6 +674,11 @@ struct AttnBwdExt {
   const float *xhat_taped;              // in: LN(x_in) from the tape (NULL: recomputed here)
   float *dQ_home, *dKV_home;            // in (defer_proj): where dQ (rows, inner) / dKV of a latent block (rows, 2 inner) are produced instead of
                                         // the op workspace -- they outlive the next block's backward (batched weight-gradient products)
+  bool dx_without_residual;  // context split: `residual` tells where the sign of the pre-activation comes from (x_out - x_in), but dx receives
+                             // the gradient through the queries only -- the residual term is replicated and added once, after the sum over ranks
+  bool skip_replicated;      // context split (hn_attn_bwd_cp): the gradients that do NOT pass through the core backward -- dW_out / db_out, and for a
+                             // shared-context block dW_v and the value side of the context LayerNorm affine -- are computed from replicated
+                             // quantities only; every rank but the owner leaves them out, so that the sum over ranks counts them once
 };
 
 static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float *x_out, int residual, const float *ctx,
@@ -754,8 +759,9 @@ static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float
     O = pl.obuf;
   }
   if (ext) ext->O = O;
-  if (ext && ext->skip_wout) {
-    // dW_out / db_out: the caller's batched weight-gradient launch
+  const bool skip_repl = ext && ext->skip_replicated;
+  if ((ext && ext->skip_wout) || skip_repl) {
+    // dW_out / db_out: the caller's batched weight-gradient launch (or, context split: the owner rank's)
   } else if (g->w_out) {      // dWo += dpre^T O, and db_out += colsum(dpre) from the same pass over dpre
     GemmExArgs e = gex(dpre, 1, qd, O, 1, inner, g->w_out, wo_ld(p), qd, inner, rows, 1);
     e.colsum = g->b_out; e.colsum_accumulate = 1;
@@ -802,7 +808,7 @@ static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float
     const float *wv = p->w_kv + (long)inner * pl.D, *wk = p->w_kv;
     float *dwv = g->w_kv ? g->w_kv + (long)inner * pl.D : nullptr, *dwk = g->w_kv;
     // O_h = A_h W_v,h^T with A = P z * gamma + beta:  dW_v,h += dO_h^T A_h ;  dA_h = dO_h W_v,h
-    if (dwv) {
+    if (dwv && !skip_repl) {
       GemmExArgs e = gex(dO, 1, inner, bp.Abuf, 1, hp, dwv, pl.D, dh, pl.D, rows, 1);
       e.batch = h; e.strideA = dh; e.strideB = pl.dp; e.strideC = (long)dh * pl.D;
       if ((rc = launch_gemm_ex(e, s, bp.red)) != HN_OK) return rc;
@@ -813,7 +819,7 @@ static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float
       e.batch = h; e.strideA = dh; e.strideB = (long)dh * pl.D; e.strideC = pl.dp;
       if ((rc = launch_gemm_ex(e, s, bp.red)) != HN_OK) return rc;
     }
-    if (p->ctx_gamma) {   // dgamma += sum dA * (P z) ; dbeta += sum dA   (over rows and heads)
+    if (p->ctx_gamma && !skip_repl) {   // dgamma += sum dA * (P z) ; dbeta += sum dA   (over rows and heads)
       if ((rc = launch_head_affine(bp.dA, hp, pl.dp, saved, hp, pl.dp, nullptr, nullptr, 1.0f, h, pl.D, pl.dp, hp, rows, bp.E, s)) != HN_OK) return rc;
       if (g->ctx_gamma && (rc = launch_colsum(bp.E, pl.dp, (long)rows * h, pl.D, 1.0f, g->ctx_gamma, 1, s, bp.red)) != HN_OK) return rc;
       if (g->ctx_beta) {
@@ -904,6 +910,7 @@ static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float
     if ((rc = launch_gemm_ex(e, s, bp.red)) != HN_OK) return rc;
   }
   float *dxh = p->norm_w ? bp.dxhat : dx;
+  if (ext && ext->dx_without_residual) residual = 0;      // (from here on `residual` only decides whether dy is added into dx)
   const bool direct_acc = !p->norm_w && residual;     // no LayerNorm: dx = dy + dQ Wq directly
   if (direct_acc && dx != dy && (rc = launch_add_into(dy, dx, (long)rows * qd, 0, s)) != HN_OK) return rc;
   {
@@ -1655,6 +1662,77 @@ int hn_attn_bwd(const hn_attn_params *p, const float *x_in, const float *x_out, 
                 const hn_attn_grads *grads, void *workspace, size_t workspace_bytes, void *stream) {
   return attn_bwd_impl(p, x_in, x_out, residual, ctx, ld_ctx, b, L, N, D, mask, stats, saved, dy, dx, grads, workspace,
                        workspace_bytes, (hipStream_t)stream);
+}
+
+// ---- training with the context split over ranks, block level (ABI v11; include/healnet_hip.h "Context split: training")
+int hn_attn_bwd_cp(const hn_attn_params *p, const float *x_in, const float *x_out, const float *ctx, int ld_ctx, int b, int L, int N,
+                   int D, const float *stats, const float *saved, const float *dy, float *dx, const hn_attn_grads *grads,
+                   int replicated_owner, void *workspace, size_t workspace_bytes, void *stream) {
+  HN_REQUIRE(p && ctx, HN_E_NULL, "attn_bwd_cp: a cross block with its rank's slab of the context");
+  HN_REQUIRE(p->dropout == 0.0f && N >= 2, HN_E_UNSUPPORTED, "attn_bwd_cp: dropout=%g N=%d (no dropout, at least two tokens per rank)", (double)p->dropout, N);
+  AttnBwdExt ext;
+  memset(&ext, 0, sizeof(ext));
+  ext.skip_replicated = replicated_owner == 0;
+  ext.dx_without_residual = true;
+  return attn_bwd_impl(p, x_in, x_out, 1, ctx, ld_ctx, b, L, N, D, nullptr, stats, saved, dy, dx, grads, workspace, workspace_bytes,
+                       (hipStream_t)stream, 0, &ext);
+}
+
+int hn_attn_saved_part_width(const hn_attn_params *p, int ld_ctx, int b, int L, int N, int D) {
+  AttnPlan pl;
+  if (plan_attn(p, true, ld_ctx, b, L, N, D, nullptr, 0, &pl) != HN_OK) return 0;
+  if (pl.N == 1) return 0;
+  return pl.rank_d ? pl.dp : pl.dh;
+}
+
+int hn_attn_merge_parts(const float *o_parts, const float *stats_parts, int n_parts, long o_stride, long stats_stride, int b, int heads,
+                        int L, int width, float *o, float *stats, void *stream) {
+  HN_REQUIRE(o_parts && stats_parts && o && stats, HN_E_NULL, "attn_merge_parts: NULL pointer");
+  HN_REQUIRE(n_parts >= 1 && b > 0 && heads > 0 && L > 0 && width > 0 && o_stride >= (long)b * L * heads * width &&
+                 stats_stride >= (long)b * heads * L * 2, HN_E_SHAPE, "attn_merge_parts: parts=%d b=%d heads=%d L=%d width=%d", n_parts, b, heads, L, width);
+  hipStream_t s = (hipStream_t)stream;
+  const int inner = heads * width;
+  const bool vec = width % 4 == 0 && (((uintptr_t)o_parts | (uintptr_t)o) & 15) == 0 && o_stride % 4 == 0;
+  const long pieces = (long)b * L * (vec ? inner >> 2 : inner);
+  if (vec)
+    hipLaunchKernelGGL(attn_merge_parts_kernel<4>, dim3((unsigned)ceil_div_ll(pieces, 256)), dim3(256), 0, s, o_parts, stats_parts, n_parts, b,
+                       heads, L, width, o, stats, o_stride, stats_stride);
+  else
+    hipLaunchKernelGGL(attn_merge_parts_kernel<1>, dim3((unsigned)ceil_div_ll(pieces, 256)), dim3(256), 0, s, o_parts, stats_parts, n_parts, b,
+                       heads, L, width, o, stats, o_stride, stats_stride);
+  HN_LAUNCH_CHECK("attn_merge_parts");
+  return HN_OK;
+}
+
+int hn_attn_finish_fwd(const hn_attn_params *p, const float *x_in, float *x_out, int residual, int ld_ctx, int b, int L, int N, int D,
+                       const float *saved, void *workspace, size_t workspace_bytes, void *stream) {
+  HN_REQUIRE(p && x_in && x_out && saved && p->w_out && p->w_kv, HN_E_NULL, "attn_finish_fwd: NULL pointer");
+  HN_REQUIRE(p->dropout == 0.0f && N >= 2, HN_E_UNSUPPORTED, "attn_finish_fwd: dropout=%g N=%d", (double)p->dropout, N);
+  hipStream_t s = (hipStream_t)stream;
+  AttnPlan pl;
+  int rc = plan_attn(p, true, ld_ctx, b, L, N, D, nullptr, 0, &pl);
+  if (rc != HN_OK) return rc;
+  if ((rc = check_ws(workspace, workspace_bytes, pl.bytes, "attn_finish_fwd")) != HN_OK) return rc;
+  if ((rc = plan_attn(p, true, ld_ctx, b, L, N, D, workspace, workspace_bytes, &pl)) != HN_OK) return rc;
+  const int rows = b * L, inner = pl.inner, h = p->heads;
+  const float *O = saved;
+  if (pl.rank_d) {      // O = (P z * gamma + beta) W_v^T from the merged context average (as attn_bwd_impl recomputes it)
+    float *A = pl.qf;
+    if ((rc = launch_head_affine(saved, h * pl.dp, pl.dp, nullptr, 0, 0, p->ctx_gamma, p->ctx_beta, 1.0f, h, pl.D, pl.dp, h * pl.dp, rows, A, s)) != HN_OK) return rc;
+    GemmExArgs e = gex(A, (long)h * pl.dp, 1, p->w_kv + (long)inner * pl.D, pl.D, 1, pl.obuf, inner, rows, pl.dh, pl.D, 0);
+    e.batch = h; e.strideA = pl.dp; e.strideB = (long)pl.dh * pl.D; e.strideC = pl.dh;
+    if ((rc = launch_gemm_ex(e, s, nullptr)) != HN_OK) return rc;
+    O = pl.obuf;
+  }
+  GemmArgs go = gemm_defaults();
+  go.A = O; go.lda = inner;
+  go.W = p->w_out; go.ldw = wo_ld(p);
+  go.C = x_out; go.ldc = p->query_dim;
+  go.bias = p->b_out;
+  go.M = rows; go.N = p->query_dim; go.K = inner;
+  go.act = ACT_LEAKY;
+  if (residual) { go.R = x_in; go.ldr = p->query_dim; }
+  return launch_gemm(go, s);
 }
 
 size_t hn_ff_workspace_bytes(const hn_ff_params *p, int rows) {

@@ -285,6 +285,21 @@ def gather_partials(o_part: torch.Tensor, stats: torch.Tensor, group=None) -> Tu
     return out[:, :n_o].reshape((world,) + tuple(o_part.shape)).contiguous(), out[:, n_o:].reshape((world,) + tuple(stats.shape)).contiguous()
 
 
+def allreduce_sum_(tensors: Sequence[torch.Tensor], group=None) -> None:
+    """In-place SUM over the ranks of `group` of a list of tensors, as ONE flat collective (the backward of a split cross block:
+    its partial dx and parameter gradients, b * l_c * l_d + the block's parameter count floats)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1 and not force_collectives():
+        return
+    flat = torch.cat([t.reshape(-1) for t in tensors])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    off = 0
+    for t in tensors:
+        n = t.numel()
+        t.copy_(flat[off:off + n].view_as(t))
+        off += n
+
+
 def _gather_flat(local: torch.Tensor, parts: torch.Tensor, group=None) -> None:
     """parts (world * n floats, rank-major) <- all-gather of local (n floats)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -341,8 +356,8 @@ def _fused_context_parallel(model, slabs, begins, totals, split, world, return_e
 
 def context_parallel_forward(model, tensors: Sequence[Optional[torch.Tensor]], group=None, return_embeddings: bool = False,
                              min_rows_per_rank: int = 1, rank: Optional[int] = None, world: Optional[int] = None,
-                             gather=None, fused: Optional[bool] = None, gather_flat=None) -> torch.Tensor:
-    """Inference forward of a HealNet whose CONTEXTS are split over the ranks of `group` (every rank passes the SAME full-batch
+                             gather=None, fused: Optional[bool] = None, gather_flat=None, reduce=None) -> torch.Tensor:
+    """Forward of a HealNet whose CONTEXTS are split over the ranks of `group` (every rank passes the SAME full-batch
     `tensors`; a rank reads only its slab of each split modality): the reference's fusion loop (healnet.py:225-250) block by
     block through the C ABI --
 
@@ -357,7 +372,14 @@ def context_parallel_forward(model, tensors: Sequence[Optional[torch.Tensor]], g
 
     `fused` (default: try it, fall back): run the whole loop inside ONE C call, hn_fusion_forward_cp -- the fused forward with its
     latent chains, calling back once per split cross block for the all-gather -- instead of block by block (models whose shapes
-    the chains do not take, staged models and bf16 cores stay on the block-by-block route)."""
+    the chains do not take, staged models and bf16 cores stay on the block-by-block route).
+
+    TRAINING (gradients enabled and a parameter that requires them; ABI v11): the block-by-block route under autograd.  A split cross
+    block runs `ops.ContextSplitAttentionFn` -- the training forward on the slab, the all-gather of (O or P z | statistics), the
+    merge into the tape, the output from the merged tape; in the backward the ordinary block backward on the slab with the GLOBAL
+    statistics, then ONE all-reduce (`reduce`, default `allreduce_sum_`) of the partial dx and the block's parameter gradients, the
+    gradients that do not pass through the core computed on rank 0 only.  After `loss.backward()` every rank holds the same,
+    complete gradients: no further reduction (the replicated blocks computed identical ones everywhere).  No dropout."""
     from . import healnet as hm                              # (late: healnet.py imports this package's ops)
     hip = torch.ops.healnet_hip
     if rank is None:
@@ -370,11 +392,12 @@ def context_parallel_forward(model, tensors: Sequence[Optional[torch.Tensor]], g
     if len(tensors) != M or any(t is None for t in tensors):
         raise ValueError("context_parallel_forward takes every modality (missing modalities: use the plain forward)")
     if model.training and model._any_dropout:
-        raise NotImplementedError("context_parallel_forward is an inference path (dropout off)")
+        raise NotImplementedError("context_parallel_forward runs without dropout (eval mode, or attn_dropout = ff_dropout = 0)")
     b = tensors[0].shape[0]
     ctx: List[Optional[torch.Tensor]] = [None] * M          # the rank's normalised slab, or the whole context of a replicated modality
     split = [False] * M
-    can_fuse = not custom_gather and not model.runs_staged() and getattr(model, "core_precision", "fp32") == "fp32"
+    train = fused is not True and torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters())      # (fused=True: the inference entry point, as before)
+    can_fuse = not train and not custom_gather and not model.runs_staged() and getattr(model, "core_precision", "fp32") == "fp32"
     if fused and not can_fuse:
         raise RuntimeError("healnet_amd: hn_fusion_forward_cp (the fused context split) takes unstaged fp32-core models and the flat "
                            "gather; this model / call runs block by block (fused=None or False)")
@@ -397,6 +420,8 @@ def context_parallel_forward(model, tensors: Sequence[Optional[torch.Tensor]], g
             if fused or e.status != _capi_mod().HN_E_UNSUPPORTED:
                 raise
         split = [False] * M
+    from . import ops as _ops
+    reduce = reduce or (lambda ts: allreduce_sum_(ts, group))
     with torch.no_grad():
         for m, data in enumerate(tensors):
             att = model.layers[0][2 * m].fn
@@ -410,14 +435,18 @@ def context_parallel_forward(model, tensors: Sequence[Optional[torch.Tensor]], g
                                               pitch, lo, rows)
             else:
                 ctx[m] = hip.encode_norm(data, model.num_freq_bands, model.max_freq, model.fourier_encode_data, pitch)
-        x = model.latents.detach().unsqueeze(0).expand(b, -1, -1).contiguous()
+    with torch.set_grad_enabled(train):
+        x = (model.latents if train else model.latents.detach()).unsqueeze(0).expand(b, -1, -1).contiguous()
         for layer in model.layers:
             for m in range(M):
                 pn, ff = layer[2 * m], layer[2 * m + 1]
                 a = pn.fn
                 wts = (pn.norm.weight, pn.norm.bias, pn.norm_context.weight, pn.norm_context.bias, a.to_q.weight, a.to_kv.weight,
                        a.to_out[0].weight, a.to_out[0].bias)
-                if split[m]:
+                if split[m] and train:
+                    x = _ops.ContextSplitAttentionFn.apply(lambda part, st: gather(part.reshape(b, -1), st), reduce, rank == 0, a.heads,
+                                                           ctx[m], x, *wts)
+                elif split[m]:
                     o, st = hip.attention_partial(x, ctx[m], None, *wts, a.heads)
                     o_all, st_all = gather(o, st)
                     x, _ = hip.attention_merge(x, o_all, st_all, a.to_q.weight, a.to_out[0].weight, a.to_out[0].bias, a.heads, True)

@@ -504,6 +504,88 @@ def _(x, o_parts, stats_parts, w_q, w_out, b_out, heads, residual):
     return x.new_empty(x.shape, dtype=torch.float32), x.new_empty((x.shape[0], heads, x.shape[1], 2), dtype=torch.float32)
 
 
+# ---- context split, TRAINING (include/healnet_hip.h "Context split: TRAINING, block level"; healnet_amd.dist drives it)
+def cp_local_forward(x, ctx_slab, wts, heads):
+    """The training forward of a cross block on THIS rank's slab -> (stats, saved, part, width): `part` = a view of the first
+    b * L * heads * width floats of `saved` (the shard's normalised O, or P z on the shared-context binding), what the ranks exchange."""
+    lib = _capi.lib()
+    x, ctx = _f32c(x), _f32c(ctx_slab)
+    p, (b, L, N, D, ld) = _attn_params(x, ctx, *wts, heads)
+    width = lib.hn_attn_saved_part_width(C.byref(p), ld, b, L, N, D)
+    if width <= 0:
+        raise RuntimeError("healnet_amd: this block's context cannot be split (one token per rank)")
+    _, stats, saved = _attention_fwd(x, ctx, None, *wts, heads, False, True)
+    return stats, saved, saved[: b * L * heads * width], width
+
+
+def cp_merge(parts, stats_parts, saved, stats, b, heads, L, width):
+    """Fold the shards' (O or P z, statistics) pairs -- (G, b * L * heads * width), (G, b, heads, L, 2), index order -- into the
+    head of `saved` and into `stats` (both overwritten in place)."""
+    parts, stats_parts = _f32c(parts), _f32c(stats_parts)
+    g = int(parts.shape[0])
+    _capi.check(_capi.lib().hn_attn_merge_parts(parts.data_ptr(), stats_parts.data_ptr(), g, parts[0].numel(), stats_parts[0].numel(), b,
+                                                heads, L, width, saved.data_ptr(), stats.data_ptr(), _stream_ptr(saved.device)),
+                "hn_attn_merge_parts")
+
+
+def cp_finish(x, ctx_slab, wts, heads, saved, residual=True):
+    """x_out = LeakyReLU(O W_out^T + b_out) [+ x] from the merged `saved` (bit-identical on every rank)."""
+    lib = _capi.lib()
+    x, ctx = _f32c(x), _f32c(ctx_slab)
+    p, (b, L, N, D, ld) = _attn_params(x, ctx, *wts, heads)
+    ws = WS.get(x.device, lib.hn_attn_workspace_bytes(C.byref(p), 1, ld, b, L, N, D))
+    out = torch.empty_like(x)
+    _capi.check(lib.hn_attn_finish_fwd(C.byref(p), x.data_ptr(), out.data_ptr(), int(residual), ld, b, L, N, D, saved.data_ptr(),
+                                       ws.data_ptr(), ws.numel(), _stream_ptr(x.device)), "hn_attn_finish_fwd")
+    return out
+
+
+def cp_backward(dy, x, out, ctx_slab, wts, heads, stats, saved, owner):
+    """hn_attn_bwd_cp -> [dx through the queries (partial, no residual term), d norm_w, d norm_b, d ctx_gamma, d ctx_beta, d w_q,
+    d w_kv, d w_out, d b_out]: this rank's terms of the sums over ranks (the replicated ones only on the owner, zeros elsewhere)."""
+    lib = _capi.lib()
+    x, dy, out, ctx = _f32c(x), _f32c(dy), _f32c(out), _f32c(ctx_slab)
+    p, (b, L, N, D, ld) = _attn_params(x, ctx, *wts, heads)
+    ws = WS.get(x.device, lib.hn_attn_bwd_workspace_bytes(C.byref(p), 1, ld, b, L, N, D, 0))
+    dx = torch.empty_like(x)
+    g = [torch.zeros_like(t) for t in wts]
+    grads = _capi.AttnGrads(norm_w=g[0].data_ptr(), norm_b=g[1].data_ptr(), ctx_gamma=g[2].data_ptr(), ctx_beta=g[3].data_ptr(),
+                            w_q=g[4].data_ptr(), w_kv=g[5].data_ptr(), w_out=g[6].data_ptr(), b_out=g[7].data_ptr())
+    _capi.check(lib.hn_attn_bwd_cp(C.byref(p), x.data_ptr(), out.data_ptr(), ctx.data_ptr(), ld, b, L, N, D, stats.data_ptr(),
+                                   saved.data_ptr(), dy.data_ptr(), dx.data_ptr(), C.byref(grads), int(bool(owner)), ws.data_ptr(),
+                                   ws.numel(), _stream_ptr(x.device)), "hn_attn_bwd_cp")
+    return [dx] + g
+
+
+class ContextSplitAttentionFn(torch.autograd.Function):
+    """PreNorm(Attention) + residual of a cross block whose context is split over ranks, with its backward.
+    apply(gather, reduce, owner, heads, ctx_slab, x, norm_w, norm_b, ctx_gamma, ctx_beta, w_q, w_kv, w_out, b_out):
+      gather(part, stats) -> (parts (G, ...), stats_parts (G, ...)) in rank order; reduce(list of tensors): sum over ranks, in place."""
+
+    @staticmethod
+    def forward(ctx, gather, reduce, owner, heads, ctx_slab, x, *wts):
+        x = _f32c(x.detach())
+        wts = tuple(t.detach() for t in wts)
+        stats, saved, part, width = cp_local_forward(x, ctx_slab, wts, heads)
+        parts, stats_parts = gather(part, stats)
+        b, L = x.shape[0], x.shape[1]
+        cp_merge(parts.reshape(parts.shape[0], -1), stats_parts, saved, stats, b, heads, L, width)
+        out = cp_finish(x, ctx_slab, wts, heads, saved, True)
+        ctx.save_for_backward(x, out, ctx_slab, stats, saved, *wts)
+        ctx.cp = (reduce, owner, heads)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, out, ctx_slab, stats, saved, *wts = ctx.saved_tensors
+        reduce, owner, heads = ctx.cp
+        dout = dout.contiguous()
+        g = cp_backward(dout, x, out, ctx_slab, wts, heads, stats, saved, owner)
+        reduce(g)
+        g[0] = g[0] + dout          # the residual path is replicated
+        return (None, None, None, None, None, *g)
+
+
 def _opt_out(t: Optional[torch.Tensor], like: Optional[torch.Tensor]):
     """Gradient buffer for an optional parameter: zeros like it, or an empty placeholder when the parameter is absent."""
     return torch.zeros_like(like) if like is not None else t

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HN_ABI_VERSION 10
+#define HN_ABI_VERSION 11
 #define HN_MAX_AXES 4
 
 typedef enum hn_status {
@@ -390,6 +390,33 @@ int hn_fusion_forward(const hn_model *model, const hn_modality_input *inputs, in
                       float **x_trace, void *workspace, size_t workspace_bytes, void *stream,
                       hn_profile *profile);
 size_t hn_fusion_workspace_bytes(const hn_model *model, const hn_modality_input *inputs, int b);
+
+/* Context split: TRAINING, block level (ABI v11).  With the GLOBAL softmax statistics (M, l) and the global attention output of a
+ * split cross block -- both replicated once the shards' pairs are merged -- the ordinary backward of the block run on a rank's slab
+ * yields exactly that slab's contributions: every gradient that passes through the core backward (dQ and with it dW_q, the query
+ * LayerNorm's gradients and dx; dK / dV and with them dW_kv and the context LayerNorm's gradients) is a PARTIAL sum over the slab's
+ * tokens, every other one (dW_out, db_out; for the shared-context binding also dW_v and the value side of the context LayerNorm
+ * affine) is computed from replicated quantities.  So:
+ *   forward   hn_attn_fwd_train on the slab (residual = 0; x_out is scratch) -> stats, saved of the shard;
+ *             all-gather the first b * L * heads * hn_attn_saved_part_width() floats of `saved` (the shard's normalised attention
+ *             output O, or P z for the shared-context binding) and the statistics: b * L * (heads * width + 2 heads) floats per rank;
+ *             hn_attn_merge_parts folds the shards in index order into the same place of `saved` and into `stats` (the tail of
+ *             `saved`, the slab's projected K / V, stays the rank's own);  hn_attn_finish_fwd computes the block's output from the
+ *             merged `saved`: x_out = LeakyReLU(O W_out^T + b_out) [+ x_in], bit-identical on every rank;
+ *   backward  hn_attn_bwd_cp(dy; x_out = the block's output WITH the residual, as hn_attn_finish_fwd(residual = 1) wrote it)
+ *             -> dx = the partial gradient through the queries (no residual term) and += the parameter
+ *             gradients, the replicated ones only where replicated_owner != 0 (pass it on ONE rank); sum dx and every parameter
+ *             gradient of the block over the ranks (one all-reduce), then add dy for the residual.
+ * No dropout, no mask; every rank needs at least two tokens.  healnet_amd.dist.context_parallel_forward drives this when gradients
+ * are enabled (tests/test_gpu_context_split.py: 2 and 3 ranks against the plain backward and oracle autograd). */
+int hn_attn_saved_part_width(const hn_attn_params *p, int ld_ctx, int b, int L, int N, int D);   /* per head; 0: not mergeable */
+int hn_attn_merge_parts(const float *o_parts, const float *stats_parts, int n_parts, long o_stride, long stats_stride, int b,
+                        int heads, int L, int width, float *o, float *stats, void *stream);
+int hn_attn_finish_fwd(const hn_attn_params *p, const float *x_in, float *x_out, int residual, int ld_ctx, int b, int L, int N,
+                       int D, const float *saved, void *workspace, size_t workspace_bytes, void *stream);   /* hn_attn_workspace_bytes(p, 1, ...) */
+int hn_attn_bwd_cp(const hn_attn_params *p, const float *x_in, const float *x_out, const float *ctx, int ld_ctx, int b, int L, int N,
+                   int D, const float *stats, const float *saved, const float *dy, float *dx, const hn_attn_grads *grads,
+                   int replicated_owner, void *workspace, size_t workspace_bytes, void *stream);   /* hn_attn_bwd_workspace_bytes(p, 1, ..., 0) */
 
 /* The fused forward with the CONTEXT of some modalities split over ranks (SURVEY.md 8(e) second axis; ABI v9) -- the fused form of
  * hn_encode_norm_slab + hn_attn_partial_fwd + hn_attn_merge_fwd: inputs[i] of a modality in `split_mask` is THIS rank's slab (rows

@@ -89,6 +89,76 @@ def test_gathered_partials_merge_to_the_whole_attention(world):
         assert (r[2] == results[0][2]).all(), "ranks folded the same parts in the same order: bit-identical"
 
 
+def _train_worker(rank, world, port, q):
+    """The backward of the split block as hn_attn_bwd_cp + allreduce_sum_ arrange it, restated in torch: with the GLOBAL statistics
+    and the global O, a rank's slab yields its dK / dV exactly and a PARTIAL dQ; dW_out / db_out come from replicated quantities and
+    are produced by the owner only; ONE sum over ranks completes every gradient."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    hd.init_from_env("gloo")
+    try:
+        torch.manual_seed(0)
+        b, L, qd, N, D, heads, e = 2, 8, 16, 53, 11, 2, 4
+        inner = heads * e
+        x, ctx, dy = torch.randn(b, L, qd), torch.randn(b, N, D), torch.randn(b, L, qd)
+        w_q, w_kv, w_out, b_out = torch.randn(inner, qd) * 0.3, torch.randn(2 * inner, D) * 0.3, torch.randn(qd, inner) * 0.3, torch.randn(qd)
+        # reference: autograd through the oracle's whole-context attention
+        leaf = [t.clone().requires_grad_(True) for t in (x, w_q, w_kv, w_out, b_out)]
+        O.attention(leaf[0], ctx, leaf[1], leaf[2], leaf[3], leaf[4], heads=heads).backward(dy)
+        want = [t.grad for t in leaf]
+        # forward exchange
+        lo, hi = hd.slab_bounds(N, rank, world)
+        slab = ctx[:, lo:hi]
+        o, st = _partial(x, slab, w_q, w_kv, heads)
+        o_all, st_all = hd.gather_partials(o, st)
+        o_glob = _merge(o_all, st_all, heads)                                   # (b, L, inner), replicated
+        M = st_all[..., 0].amax(0)                                              # (b, heads, L)
+        l = (torch.exp2(st_all[..., 0] - M) * st_all[..., 1]).sum(0)
+        pre = o_glob @ w_out.t() + b_out
+        # backward on the slab with the global (M, l)
+        dpre = dy * torch.where(pre > 0, torch.ones_like(pre), torch.full_like(pre, 0.01))
+        owner = rank == 0
+        d_wout = dpre.reshape(-1, qd).t() @ o_glob.reshape(-1, inner) if owner else torch.zeros_like(w_out)
+        d_bout = dpre.sum((0, 1)) if owner else torch.zeros_like(b_out)
+        heads_of = lambda t: t.reshape(b, -1, heads, e).permute(0, 2, 1, 3)     # noqa: E731
+        dO, Og = heads_of(dpre @ w_out), heads_of(o_glob)
+        qh = heads_of(x @ w_q.t())
+        kv = slab @ w_kv.t()
+        kh, vh = heads_of(kv[..., :inner]), heads_of(kv[..., inner:])
+        c = (e ** -0.5) / 0.5
+        P = torch.exp2((qh @ kh.transpose(-1, -2)) * c * 1.4426950408889634 - M[..., None]) / l[..., None]
+        dS = P * (dO @ vh.transpose(-1, -2) - (dO * Og).sum(-1, keepdim=True))
+        unheads = lambda t: t.permute(0, 2, 1, 3).reshape(b, -1, inner)         # noqa: E731
+        dq, dk, dv = unheads(dS @ kh) * c, unheads(dS.transpose(-1, -2) @ qh) * c, unheads(P.transpose(-1, -2) @ dO)
+        part = [dq @ w_q, dq.reshape(-1, inner).t() @ x.reshape(-1, qd),
+                torch.cat([dk, dv], -1).reshape(-1, 2 * inner).t() @ slab.reshape(-1, D), d_wout, d_bout]
+        hd.allreduce_sum_(part)
+        for name, got, ref in zip(("x", "w_q", "w_kv", "w_out", "b_out"), part, want):
+            err = float((got - ref).abs().max() / ref.abs().max())
+            assert err < 2e-5, (name, err)
+        q.put((rank, "ok", part[2].numpy()))
+    except Exception as e_:  # pragma: no cover
+        import traceback
+        q.put((rank, "".join(traceback.format_exception(type(e_), e_, e_.__traceback__)), None))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_slab_backwards_with_global_statistics_sum_to_the_whole_gradient(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+    assert [r[1] for r in results] == ["ok"] * world, [r[1] for r in results]
+    for r in results[1:]:
+        assert (r[2] == results[0][2]).all(), "every rank holds the same summed gradient"
+
+
 def test_slab_bounds_cover_the_axis():
     for n, world in [(224, 8), (37, 3), (5, 8), (12, 1)]:
         spans = [hd.slab_bounds(n, r, world) for r in range(world)]

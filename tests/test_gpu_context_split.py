@@ -111,6 +111,69 @@ def test_partial_plus_merge_equals_the_whole_block(kw):
     assert_close(got.cpu(), want, rel=2e-4, floor=2e-5, what="merged shards vs the oracle")
 
 
+TRAIN_CASES = [c for c in CASES if not c.get("masked")]
+
+
+@pytest.mark.parametrize("kw", TRAIN_CASES, ids=[f"case{i}" for i in range(len(TRAIN_CASES))])
+def test_shard_backwards_sum_to_the_whole_block_backward(kw):
+    """Context split, TRAINING (ABI v11): the training forward per shard, the merge of the shards' (O or P z, statistics) pairs, the
+    output from the merged tape, and hn_attn_bwd_cp per shard with the GLOBAL statistics -- the shards' gradients (replicated terms on
+    the owner only) sum to the gradients of the whole block: against the plain block's autograd on the GPU and oracle autograd."""
+    from healnet_amd import _capi, ops
+    from healnet_amd import dist as hd
+    from oracle import healnet_cpu as O
+    hip = torch.ops.healnet_hip
+    b, L, N, D, heads, dh, qd, parts = (kw[k] for k in ("b", "L", "N", "D", "heads", "dh", "qd", "parts"))
+    pn = _block(qd, D, heads, dh, 7).train()
+    a = pn.fn
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(b, L, qd, generator=gen).to(DEV)
+    ctx = torch.randn(b, N, D, generator=gen)
+    dy = torch.randn(b, L, qd, generator=gen).to(DEV)
+    pitch = _capi.lib().hn_context_pitch(D, dh)
+    z = hip.encode_norm(ctx.to(DEV).unsqueeze(2).reshape(b, N, D), 0, 0.0, False, pitch)
+    names = ("norm.weight", "norm.bias", "norm_context.weight", "norm_context.bias", "fn.to_q.weight", "fn.to_kv.weight", "fn.to_out.0.weight",
+             "fn.to_out.0.bias")
+    params = dict(pn.named_parameters())
+    wts = tuple(params[n] for n in names)
+    # the whole block through its own autograd
+    xw = x.clone().requires_grad_(True)
+    whole = hip.attention(xw, z, None, *wts, heads, True)
+    g_whole = torch.autograd.grad(whole, (xw,) + wts, dy)
+    # shards
+    wd = tuple(t.detach() for t in wts)
+    slabs = [z[:, lo:hi].contiguous() for lo, hi in (hd.slab_bounds(N, r, parts) for r in range(parts))]
+    local = [ops.cp_local_forward(x, sl, wd, heads) for sl in slabs]
+    width = local[0][3]
+    all_parts = torch.stack([lc[2].clone() for lc in local])
+    all_stats = torch.stack([lc[0].clone() for lc in local])
+    outs = []
+    for (stats, saved, _, _), sl in zip(local, slabs):
+        ops.cp_merge(all_parts, all_stats, saved, stats, b, heads, L, width)
+        outs.append(ops.cp_finish(x, sl, wd, heads, saved, True))
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0]), "the ranks' block outputs differ"
+    assert_close(outs[0].cpu(), whole.detach().cpu(), rel=2e-5, floor=2e-6, what="context-split training forward vs the whole block")
+    total = None
+    for r, ((stats, saved, _, _), sl) in enumerate(zip(local, slabs)):
+        g = ops.cp_backward(dy, x, outs[0], sl, wd, heads, stats, saved, owner=(r == 1 % parts))
+        total = g if total is None else [t + u for t, u in zip(total, g)]
+    total[0] = total[0] + dy
+    scale = max(float(t.abs().max()) for t in g_whole)
+    for name, got, ref in zip(("x",) + names, total, g_whole):
+        assert_close(got.cpu(), ref.cpu(), rel=3e-4, floor=1e-4, abs_floor=2e-6 * scale, what=f"sum over shards: d {name}")
+    # oracle autograd on the same numbers
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in pn.state_dict().items()}
+    xc = x.cpu().clone().requires_grad_(True)
+    xn = O.layer_norm(xc, sd["norm.weight"], sd["norm.bias"])
+    cn = O.layer_norm(ctx, sd["norm_context.weight"], sd["norm_context.bias"])
+    want = O.attention(xn, cn, sd["fn.to_q.weight"], sd["fn.to_kv.weight"], sd["fn.to_out.0.weight"], sd["fn.to_out.0.bias"], heads=heads) + xc
+    want.backward(dy.cpu())
+    for name, got in zip(("x",) + names, total):
+        ref = xc.grad if name == "x" else sd[name].grad
+        assert_close(got.cpu(), ref, rel=2e-3, floor=1e-3, abs_floor=1e-5 * scale, what=f"sum over shards vs oracle: d {name}")
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -143,8 +206,9 @@ def _cp_worker(rank, world, port, b, q, kw=None, fused=None):
         torch.manual_seed(5)
         model = hn.HealNet(**(kw or KW)).eval().to(dev)
         ins = [t.to(dev) for t in _inputs(b)]
-        out = hd.context_parallel_forward(model, ins, fused=fused)
-        emb = hd.context_parallel_forward(model, ins, return_embeddings=True, fused=fused)
+        with torch.no_grad():      # (with gradients enabled the call takes the training route: the test below)
+            out = hd.context_parallel_forward(model, ins, fused=fused)
+            emb = hd.context_parallel_forward(model, ins, return_embeddings=True, fused=fused)
         torch.cuda.synchronize()
         q.put((rank, "ok", out.cpu().numpy(), emb.cpu().numpy()))
     except Exception as e:  # pragma: no cover
@@ -184,6 +248,69 @@ def test_context_parallel_forward_matches_the_plain_forward(world, b, route):
         assert_close(torch.from_numpy(emb), plain_emb, rel=2e-5, floor=2e-6, what=f"rank {rank}: embeddings")
         assert_close(torch.from_numpy(out), want, rel=1e-4, floor=1e-5, what=f"rank {rank}: context-parallel logits vs the oracle")
         assert np.array_equal(out, results[0][2]) and np.array_equal(emb, results[0][3]), "ranks diverged"
+
+
+def _cp_train_worker(rank, world, port, b, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    import healnet_amd as hn
+    from healnet_amd import dist as hd
+    try:
+        torch.cuda.set_device(0)
+        hd.init_from_env("gloo")
+        dev = torch.device("cuda", 0)
+        torch.manual_seed(5)
+        model = hn.HealNet(**KW).eval().to(dev)          # (eval: no dropout modules in play; the parameters still require grad)
+        ins = [t.to(dev) for t in _inputs(b)]
+        dl = torch.randn(b, KW["out_dims"], generator=torch.Generator().manual_seed(9)).to(dev)
+        out = hd.context_parallel_forward(model, ins)
+        (out * dl).sum().backward()
+        torch.cuda.synchronize()
+        q.put((rank, "ok", out.detach().cpu().numpy(), {k: p.grad.cpu().numpy() for k, p in model.named_parameters()}))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "".join(traceback.format_exception(type(e), e, e.__traceback__)), None, None))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,b", [(2, 2), (3, 1)], ids=["2-ranks-b2", "3-ranks-b1"])
+def test_context_parallel_training_step_matches_the_plain_backward(world, b):
+    """Training with the contexts split over 2 / 3 processes (one GPU, gloo): after loss.backward() EVERY rank holds the complete
+    gradients -- equal to the plain model's fused backward and to oracle autograd, and equal across ranks up to the all-reduce."""
+    import healnet_amd as hn
+    from oracle import healnet_cpu as O
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cp_train_worker, args=(r, world, port, b, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=600) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+    assert [r[1] for r in results] == ["ok"] * world, [r[1] for r in results]
+    torch.manual_seed(5)
+    model = hn.HealNet(**KW).eval().to(DEV)
+    ins = _inputs(b)
+    dl = torch.randn(b, KW["out_dims"], generator=torch.Generator().manual_seed(9))
+    plain = model([t.to(DEV) for t in ins])
+    (plain * dl.to(DEV)).sum().backward()
+    g_plain = {k: p.grad.cpu() for k, p in model.named_parameters()}
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    want = O.fusion_forward(sd, O.FusionConfig(**KW), [t.clone() for t in ins])
+    (want * dl).sum().backward()
+    scale = max(float(v.abs().max()) for v in g_plain.values())
+    for rank, _, out, grads in results:
+        assert_close(torch.from_numpy(out), plain.detach().cpu(), rel=2e-5, floor=2e-6, what=f"rank {rank}: logits")
+        assert set(grads) == set(g_plain)
+        for k, g in grads.items():
+            assert_close(torch.from_numpy(g), g_plain[k], rel=5e-4, floor=2e-4, abs_floor=2e-6 * scale, what=f"rank {rank}: grad[{k}] vs the plain backward")
+            ref = sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])
+            assert_close(torch.from_numpy(g), ref, rel=2e-3, floor=1e-3, abs_floor=1e-5 * scale, what=f"rank {rank}: grad[{k}] vs oracle autograd")
+            assert_close(torch.from_numpy(g), torch.from_numpy(results[0][3][k]), rel=1e-5, floor=1e-6, abs_floor=1e-7 * scale, what=f"rank {rank} vs rank 0: grad[{k}]")
 
 
 def test_single_rank_and_validation():

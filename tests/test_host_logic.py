@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     lib = _capi.lib()                      # raises if the .so is missing: build() must have run
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.hn_abi_version() == _capi.HN_ABI_VERSION == 10
+    assert lib.hn_abi_version() == _capi.HN_ABI_VERSION == 11
     assert lib.hn_context_pitch(13, 64) == 16 and lib.hn_context_pitch(18, 64) == 32
     assert lib.hn_context_pitch(773, 64) == 776 and lib.hn_context_pitch(2005, 64) == 2008
     assert lib.hn_context_pitch(20, 16) == 20          # rank-D path would not pay: dp 32 > dim_head 16
