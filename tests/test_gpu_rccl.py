@@ -103,6 +103,32 @@ def _worker(port, q):
         assert o_all.shape == (1, 2, 32, 128) and st_all.shape == (1, 2, 4, 32, 2)
         assert torch.equal(o_all[0], o) and torch.equal(st_all[0], st), "all_gather_into_tensor over one rank must return the input"
         report["context_split_gather_floats"] = int(o.numel() + st.numel())
+        # the context split's TRAINING exchange (ABI v11): ncclAllGather of the shard's (P z | statistics) in the forward, ONE
+        # ncclAllReduce(SUM) of the partial dx + the block's parameter gradients in the backward -- one rank holding the whole context,
+        # so the gradients must be those of the plain block
+        before = dict(calls)
+        ts2 = [torch.randn(n, generator=gen).to(dev) for n in (5, 300)]
+        w2 = [t.clone() for t in ts2]
+        hd.allreduce_sum_(ts2)
+        assert all(torch.equal(a, b_) for a, b_ in zip(ts2, w2)) and calls["all_reduce"] == before["all_reduce"] + 1
+        torch.manual_seed(11)
+        pn = hn.healnet.PreNorm(64, hn.Attention(64, 13, heads=4, dim_head=32), context_dim=13).to(dev)
+        a_ = pn.fn
+        wts = (pn.norm.weight, pn.norm.bias, pn.norm_context.weight, pn.norm_context.bias, a_.to_q.weight, a_.to_kv.weight, a_.to_out[0].weight,
+               a_.to_out[0].bias)
+        xq = torch.randn(2, 32, 64, generator=gen).to(dev)
+        z = torch.ops.healnet_hip.encode_norm(torch.randn(2, 700, 1, 13, generator=gen).to(dev).reshape(2, 700, 13), 0, 0.0, False, 16)
+        dyq = torch.randn(2, 32, 64, generator=gen).to(dev)
+        x1 = xq.clone().requires_grad_(True)
+        g_plain = torch.autograd.grad(torch.ops.healnet_hip.attention(x1, z, None, *wts, 4, True), (x1,) + wts, dyq)
+        x2 = xq.clone().requires_grad_(True)
+        y2 = hn.ops.ContextSplitAttentionFn.apply(lambda part, st_: hd.gather_partials(part.reshape(2, -1), st_), hd.allreduce_sum_, True, 4, z, x2, *wts)
+        g_cp = torch.autograd.grad(y2, (x2,) + wts, dyq)
+        torch.cuda.synchronize(dev)
+        assert calls["all_reduce"] == before["all_reduce"] + 2
+        for ga, gb in zip(g_cp, g_plain):
+            assert float((ga - gb).abs().max()) <= 3e-4 * float(gb.abs().max()) + 1e-6, "context-split training step over RCCL"
+        report["context_split_training_allreduce_floats"] = int(sum(t.numel() for t in g_cp))
         report["helpers"] = dict(calls)
 
         # ---- the overlapped gradient all-reduce on real backwards ----------------------------------------------------
