@@ -17,6 +17,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--json", default="")
 ap.add_argument("--steps", type=int, default=20)
+ap.add_argument("--depth", type=int, default=12, help="slices of the volume modality (cfg3: 12)")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 b = args.batch
@@ -24,7 +25,7 @@ torch.manual_seed(0)
 model = hn.HealNet(n_modalities=3, channel_dims=[2000, 3, 3], num_spatial_axes=[1, 2, 3], out_dims=4).eval().to(dev)
 gen = torch.Generator().manual_seed(1234)
 ins = [torch.rand(b, 1, 2000, generator=gen).to(dev), torch.rand(b, 224, 224, 3, generator=gen).to(dev),
-       torch.rand(b, 12, 224, 224, 3, generator=gen).to(dev)]
+       torch.rand(b, args.depth, 224, 224, 3, generator=gen).to(dev)]
 
 
 def timeit(fn, n=args.steps, warm=3):
@@ -49,7 +50,8 @@ for G in (1, 2, 4, 8):
         gathered["floats_per_rank"] = o.numel() + st.numel()
         return o.unsqueeze(0).expand(G, *o.shape).contiguous(), st.unsqueeze(0).expand(G, *st.shape).contiguous()
 
-    ms = timeit(lambda: hd.context_parallel_forward(model, ins, rank=0, world=G, gather=fake_gather))
+    with torch.no_grad():
+        ms = timeit(lambda: hd.context_parallel_forward(model, ins, rank=0, world=G, gather=fake_gather))
     row = dict(path="block-by-block, rank 0 of G (stand-in gather)", ranks=G, ms=round(ms, 3),
                gathered_kb_per_rank_and_block=round(gathered.get("floats_per_rank", 0) * 4 / 1024, 1),
                speedup_vs_one_rank=None)
@@ -58,7 +60,23 @@ for G in (1, 2, 4, 8):
     ms = timeit(lambda: hd.context_parallel_forward(model, ins, rank=0, world=G, fused=True,
                                                     gather_flat=lambda lo, pa, G=G: pa.copy_(lo.repeat(G))))
     rows.append(dict(path="fused (hn_fusion_forward_cp), rank 0 of G (stand-in gather)", ranks=G, ms=round(ms, 3), speedup_vs_one_rank=None))
-for kind in ("block", "fused ("):
+
+    # TRAINING (ABI v11): forward + backward of rank 0 of G under autograd, block by block; the all-reduce of the backward is a no-op
+    # stand-in (same launches, no communication)
+    def train_step(G=G):
+        model.zero_grad(set_to_none=True)
+        hd.context_parallel_forward(model, ins, rank=0, world=G, gather=fake_gather, reduce=lambda ts: None).sum().backward()
+
+    rows.append(dict(path="training step, block-by-block, rank 0 of G (stand-in gather / reduce)", ranks=G, ms=round(timeit(train_step, n=10), 3),
+                     speedup_vs_one_rank=None))
+def plain_train():
+    model.zero_grad(set_to_none=True)
+    model(ins).sum().backward()
+
+
+rows.insert(1, dict(path="plain training step (hn_fusion_forward_train + hn_fusion_backward, one GPU holds the whole context)", ranks=1,
+                    ms=round(timeit(plain_train, n=10), 3)))
+for kind in ("block", "fused (", "training step, block"):
     one = next(r["ms"] for r in rows if r["ranks"] == 1 and r["path"].startswith(kind))
     for r in rows:
         if r["path"].startswith(kind):
@@ -69,7 +87,7 @@ with torch.no_grad():
     got_f = hd.context_parallel_forward(model, ins, rank=0, world=1, fused=True)
 err = float((got - ref).abs().max() / ref.abs().max())
 err_f = float((got_f - ref).abs().max() / ref.abs().max())
-doc = dict(workload=f"cfg3-shaped model, b = {b}: tab (b,1,2000) + img (b,224,224,3) + vol (b,12,224,224,3), fp32, eval", rows=rows,
+doc = dict(workload=f"cfg3-shaped model, b = {b}: tab (b,1,2000) + img (b,224,224,3) + vol (b,{args.depth},224,224,3), fp32, eval", rows=rows,
            block_by_block_vs_fused_rel_err=err, fused_cp_one_part_vs_fused_rel_err=err_f,
            note="compute of ONE rank on one GPU; no communication is measured (stand-in gather); no multi-GPU number is claimed")
 for r in rows:
