@@ -111,7 +111,10 @@ def test_partial_plus_merge_equals_the_whole_block(kw):
     assert_close(got.cpu(), want, rel=2e-4, floor=2e-5, what="merged shards vs the oracle")
 
 
-TRAIN_CASES = [c for c in CASES if not c.get("masked")]
+TRAIN_CASES = [c for c in CASES if not c.get("masked")] + [
+    dict(b=2, L=24, N=500, D=18, heads=2, dh=27, qd=40, parts=2),                    # shared-context binding on 32-column rows, padded head width
+    dict(b=3, L=17, N=333, D=40, heads=3, dh=20, qd=30, parts=4),                    # explicit binding, odd sizes everywhere, four ragged shards
+]
 
 
 @pytest.mark.parametrize("kw", TRAIN_CASES, ids=[f"case{i}" for i in range(len(TRAIN_CASES))])
