@@ -368,7 +368,8 @@ def context_parallel_forward(model, tensors: Sequence[Optional[torch.Tensor]], g
                                         tokens per rank, e.g. the one-token tabular input), feed-forward blocks, latent self blocks, head.
 
     Partition = the first spatial axis (image rows, volume slices, bag patches), contiguous slabs.  For b >= #GPUs shard the BATCH
-    instead (no forward collective at all).  No mask, no dropout, no missing modalities (the plain inference forward).
+    instead (no forward collective at all).  No mask, no dropout; a missing modality (None) is skipped as in the plain forward, on the
+    block-by-block route.
 
     `fused` (default: try it, fall back): run the whole loop inside ONE C call, hn_fusion_forward_cp -- the fused forward with its
     latent chains, calling back once per split cross block for the all-gather -- instead of block by block (models whose shapes
@@ -389,15 +390,21 @@ def context_parallel_forward(model, tensors: Sequence[Optional[torch.Tensor]], g
     custom_gather = gather is not None
     gather = gather or (lambda o, st: gather_partials(o, st, group))
     M = model.modalities
-    if len(tensors) != M or any(t is None for t in tensors):
-        raise ValueError("context_parallel_forward takes every modality (missing modalities: use the plain forward)")
+    if len(tensors) > M:
+        raise ValueError(f"{len(tensors)} tensors passed to a model with {M} modalities")
+    # a missing modality (a None entry, or a list shorter than the model: healnet.py:193,238) skips its cross-attention and
+    # feed-forward blocks; the latent self block of that iteration still runs (the verbose=True quirk is the plain forward's)
+    present = [i < len(tensors) and tensors[i] is not None for i in range(M)]
+    if not any(present):
+        raise ValueError("at least one modality must be present")
+    tensors = [tensors[i] if present[i] else None for i in range(M)]
     if model.training and model._any_dropout:
         raise NotImplementedError("context_parallel_forward runs without dropout (eval mode, or attn_dropout = ff_dropout = 0)")
-    b = tensors[0].shape[0]
+    b = next(t for t in tensors if t is not None).shape[0]
     ctx: List[Optional[torch.Tensor]] = [None] * M          # the rank's normalised slab, or the whole context of a replicated modality
     split = [False] * M
     train = fused is not True and torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters())      # (fused=True: the inference entry point, as before)
-    can_fuse = not train and not custom_gather and not model.runs_staged() and getattr(model, "core_precision", "fp32") == "fp32"
+    can_fuse = not train and all(present) and not custom_gather and not model.runs_staged() and getattr(model, "core_precision", "fp32") == "fp32"
     if fused and not can_fuse:
         raise RuntimeError("healnet_amd: hn_fusion_forward_cp (the fused context split) takes unstaged fp32-core models and the flat "
                            "gather; this model / call runs block by block (fused=None or False)")
@@ -424,6 +431,8 @@ def context_parallel_forward(model, tensors: Sequence[Optional[torch.Tensor]], g
     reduce = reduce or (lambda ts: allreduce_sum_(ts, group))
     with torch.no_grad():
         for m, data in enumerate(tensors):
+            if data is None:
+                continue
             att = model.layers[0][2 * m].fn
             pitch = _capi_lib().hn_context_pitch(model.context_dims[m], att.dim_head)
             rows = data.shape[1]
@@ -439,6 +448,10 @@ def context_parallel_forward(model, tensors: Sequence[Optional[torch.Tensor]], g
         x = (model.latents if train else model.latents.detach()).unsqueeze(0).expand(b, -1, -1).contiguous()
         for layer in model.layers:
             for m in range(M):
+                if not present[m]:
+                    if model.self_per_cross_attn > 0:
+                        x = hm.latent_block(layer[2 * M][0], layer[2 * M][1], x)
+                    continue
                 pn, ff = layer[2 * m], layer[2 * m + 1]
                 a = pn.fn
                 wts = (pn.norm.weight, pn.norm.bias, pn.norm_context.weight, pn.norm_context.bias, a.to_q.weight, a.to_kv.weight,

@@ -253,7 +253,7 @@ def test_context_parallel_forward_matches_the_plain_forward(world, b, route):
         assert np.array_equal(out, results[0][2]) and np.array_equal(emb, results[0][3]), "ranks diverged"
 
 
-def _cp_train_worker(rank, world, port, b, q):
+def _cp_train_worker(rank, world, port, b, q, missing=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch.distributed as dist
@@ -265,12 +265,12 @@ def _cp_train_worker(rank, world, port, b, q):
         dev = torch.device("cuda", 0)
         torch.manual_seed(5)
         model = hn.HealNet(**KW).eval().to(dev)          # (eval: no dropout modules in play; the parameters still require grad)
-        ins = [t.to(dev) for t in _inputs(b)]
+        ins = [None if i == missing else t.to(dev) for i, t in enumerate(_inputs(b))]
         dl = torch.randn(b, KW["out_dims"], generator=torch.Generator().manual_seed(9)).to(dev)
         out = hd.context_parallel_forward(model, ins)
         (out * dl).sum().backward()
         torch.cuda.synchronize()
-        q.put((rank, "ok", out.detach().cpu().numpy(), {k: p.grad.cpu().numpy() for k, p in model.named_parameters()}))
+        q.put((rank, "ok", out.detach().cpu().numpy(), {k: p.grad.cpu().numpy() for k, p in model.named_parameters() if p.grad is not None}))
     except Exception as e:  # pragma: no cover
         import traceback
         q.put((rank, "".join(traceback.format_exception(type(e), e, e.__traceback__)), None, None))
@@ -279,8 +279,8 @@ def _cp_train_worker(rank, world, port, b, q):
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,b", [(2, 2), (3, 1)], ids=["2-ranks-b2", "3-ranks-b1"])
-def test_context_parallel_training_step_matches_the_plain_backward(world, b):
+@pytest.mark.parametrize("world,b,missing", [(2, 2, None), (3, 1, None), (2, 1, 1)], ids=["2-ranks-b2", "3-ranks-b1", "2-ranks-b1-image-missing"])
+def test_context_parallel_training_step_matches_the_plain_backward(world, b, missing):
     """Training with the contexts split over 2 / 3 processes (one GPU, gloo): after loss.backward() EVERY rank holds the complete
     gradients -- equal to the plain model's fused backward and to oracle autograd, and equal across ranks up to the all-reduce."""
     import healnet_amd as hn
@@ -288,7 +288,7 @@ def test_context_parallel_training_step_matches_the_plain_backward(world, b):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_cp_train_worker, args=(r, world, port, b, q)) for r in range(world)]
+    procs = [ctx.Process(target=_cp_train_worker, args=(r, world, port, b, q, missing)) for r in range(world)]
     for p in procs:
         p.start()
     results = sorted([q.get(timeout=600) for _ in procs], key=lambda r: r[0])
@@ -297,18 +297,19 @@ def test_context_parallel_training_step_matches_the_plain_backward(world, b):
     assert [r[1] for r in results] == ["ok"] * world, [r[1] for r in results]
     torch.manual_seed(5)
     model = hn.HealNet(**KW).eval().to(DEV)
-    ins = _inputs(b)
+    ins = [None if i == missing else t for i, t in enumerate(_inputs(b))]
     dl = torch.randn(b, KW["out_dims"], generator=torch.Generator().manual_seed(9))
-    plain = model([t.to(DEV) for t in ins])
+    plain = model([None if t is None else t.to(DEV) for t in ins])
     (plain * dl.to(DEV)).sum().backward()
-    g_plain = {k: p.grad.cpu() for k, p in model.named_parameters()}
+    g_plain = {k: p.grad.cpu() for k, p in model.named_parameters() if p.grad is not None}
     sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
-    want = O.fusion_forward(sd, O.FusionConfig(**KW), [t.clone() for t in ins])
+    want = O.fusion_forward(sd, O.FusionConfig(**KW), [None if t is None else t.clone() for t in ins])
     (want * dl).sum().backward()
     scale = max(float(v.abs().max()) for v in g_plain.values())
     for rank, _, out, grads in results:
         assert_close(torch.from_numpy(out), plain.detach().cpu(), rel=2e-5, floor=2e-6, what=f"rank {rank}: logits")
-        assert set(grads) == set(g_plain)
+        # (a skipped modality's blocks: no gradient on the block route, zeros from the fused backward)
+        assert set(grads) <= set(g_plain) and all(float(g_plain[k].abs().max()) == 0.0 for k in set(g_plain) - set(grads))
         for k, g in grads.items():
             assert_close(torch.from_numpy(g), g_plain[k], rel=5e-4, floor=2e-4, abs_floor=2e-6 * scale, what=f"rank {rank}: grad[{k}] vs the plain backward")
             ref = sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])
@@ -325,8 +326,9 @@ def test_single_rank_and_validation():
     ins = [t.to(DEV) for t in _inputs(2)]
     with torch.no_grad():
         plain = model(ins)
-    got = hd.context_parallel_forward(model, ins, rank=0, world=1, fused=False)
-    assert_close(got.cpu(), plain.cpu(), rel=2e-5, floor=2e-6, what="block-by-block forward vs the fused forward")
+    got = hd.context_parallel_forward(model, ins, rank=0, world=1, fused=False)      # (gradients enabled: the autograd route)
+    assert got.requires_grad
+    assert_close(got.detach().cpu(), plain.cpu(), rel=2e-5, floor=2e-6, what="block-by-block forward vs the fused forward")
     # the fused route: refused for this model (l_d = 64: not a chain shape) with fused=True, silently replaced by default
     with pytest.raises(RuntimeError):
         hd.context_parallel_forward(model, ins, rank=1, world=2, fused=True, gather_flat=lambda lo, pa: pa.copy_(lo.repeat(2)))
@@ -340,5 +342,15 @@ def test_single_rank_and_validation():
     assert_close(got_big.cpu(), plain_big.cpu(), rel=2e-5, floor=2e-6, what="hn_fusion_forward_cp with one part vs hn_fusion_forward")
     half = hd.context_parallel_forward(big, ins, rank=1, world=2, fused=True, gather_flat=lambda lo, pa: pa.copy_(lo.repeat(2)))
     assert torch.isfinite(half).all()
+    # a missing modality is skipped as in the plain forward (block-by-block route)
+    with torch.no_grad():
+        plain_missing = model([ins[0], None, ins[2]])
+        got_missing = hd.context_parallel_forward(model, [ins[0], None, ins[2]], rank=0, world=1)
+        got_short = hd.context_parallel_forward(model, [ins[0], ins[1]], rank=0, world=1)
+        plain_short = model([ins[0], ins[1]])
+    assert_close(got_missing.cpu(), plain_missing.cpu(), rel=2e-5, floor=2e-6, what="missing modality")
+    assert_close(got_short.cpu(), plain_short.cpu(), rel=2e-5, floor=2e-6, what="shorter list")
     with pytest.raises(ValueError):
-        hd.context_parallel_forward(model, [ins[0], None, ins[2]], rank=0, world=1)
+        hd.context_parallel_forward(model, [None, None, None], rank=0, world=1)
+    with pytest.raises(ValueError):
+        hd.context_parallel_forward(model, ins + [ins[0]], rank=0, world=1)
