@@ -177,6 +177,37 @@ def test_shard_backwards_sum_to_the_whole_block_backward(kw):
         assert_close(got.cpu(), ref, rel=2e-3, floor=1e-3, abs_floor=1e-5 * scale, what=f"sum over shards vs oracle: d {name}")
 
 
+def test_context_split_training_refusals():
+    """What the training entry points do not take says so: a one-token shard has nothing to merge (hn_attn_saved_part_width = 0), a
+    dropping block is refused by hn_attn_finish_fwd / hn_attn_bwd_cp with HN_E_UNSUPPORTED (never a silent dropout-free result)."""
+    import ctypes as C
+    from healnet_amd import _capi, ops
+    pn = _block(32, 13, 2, 16, 3)
+    a = pn.fn
+    wts = tuple(t.detach() for t in (pn.norm.weight, pn.norm.bias, pn.norm_context.weight, pn.norm_context.bias, a.to_q.weight, a.to_kv.weight,
+                                     a.to_out[0].weight, a.to_out[0].bias))
+    x = torch.randn(2, 16, 32, device=DEV)
+    z = torch.ops.healnet_hip.encode_norm(torch.randn(2, 40, 13, device=DEV), 0, 0.0, False, 16)
+    with pytest.raises(RuntimeError, match="cannot be split"):
+        ops.cp_local_forward(x, z[:, :1].contiguous(), wts, 2)
+    stats, saved, _, _ = ops.cp_local_forward(x, z, wts, 2)
+    p, (b, L, N, D, ld) = ops._attn_params(x, z, *wts, 2)
+    p.dropout = 0.25
+    lib = _capi.lib()
+    ws = torch.empty(lib.hn_attn_bwd_workspace_bytes(C.byref(p), 1, ld, b, L, N, D, 0) // 4 + 64, device=DEV)
+    out = torch.empty_like(x)
+    rc = lib.hn_attn_finish_fwd(C.byref(p), x.data_ptr(), out.data_ptr(), 1, ld, b, L, N, D, saved.data_ptr(), ws.data_ptr(), ws.numel() * 4,
+                                torch.cuda.current_stream().cuda_stream)
+    assert rc == _capi.HN_E_UNSUPPORTED
+    g = [torch.zeros_like(t) for t in wts]
+    grads = _capi.AttnGrads(norm_w=g[0].data_ptr(), norm_b=g[1].data_ptr(), ctx_gamma=g[2].data_ptr(), ctx_beta=g[3].data_ptr(),
+                            w_q=g[4].data_ptr(), w_kv=g[5].data_ptr(), w_out=g[6].data_ptr(), b_out=g[7].data_ptr())
+    rc = lib.hn_attn_bwd_cp(C.byref(p), x.data_ptr(), out.data_ptr(), z.data_ptr(), ld, b, L, N, D, stats.data_ptr(), saved.data_ptr(),
+                            x.data_ptr(), out.data_ptr(), C.byref(grads), 1, ws.data_ptr(), ws.numel() * 4, torch.cuda.current_stream().cuda_stream)
+    assert rc == _capi.HN_E_UNSUPPORTED
+    assert all(float(t.abs().max()) == 0.0 for t in g)
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
