@@ -875,13 +875,18 @@ static int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float
       ba.dO = bp.dOp; ba.do_b = (long)L * qp; ba.do_h = pl.dhp; ba.lddo = qp;
     }
     ba.dKV = bp.dKV; ba.dk_scale = 0.69314718055994530942f;
+    // one token split (the latent self-attention, short contexts): the dQ kernel writes the finished, scaled rows itself -- what
+    // dq_reduce makes of a single partial, bit for bit -- and that launch is gone (HN_NO_DQ_DIRECT=1: partial + reduce)
+    static const bool no_dq_direct = getenv("HN_NO_DQ_DIRECT") != nullptr;
+    const bool dq_direct = !no_dq_direct && pl.nsplit_bwd == 1 && !attn_bwd_dq_lds_eligible(ba);
+    if (dq_direct) { ba.dQfinal = bp.dQ; ba.dq_ld = inner; ba.dq_pitch = dh; ba.dq_width = dh; ba.dq_scale = two_scale; }
     int rc_pair = HN_OK;
     if (!has_ctx && launch_attn_bwd_self_pair(ba, dh, inner, s, &rc_pair)) {      // latent self-attention: both products in one launch
       if (rc_pair != HN_OK) return rc_pair;
-      if ((rc = launch_dq_reduce(bp.dQpart, pl.nsplit_bwd, b, h, L, pl.Lp, pl.dp, dh, two_scale, bp.dQ, inner, dh, s)) != HN_OK) return rc;
+      if (!dq_direct && (rc = launch_dq_reduce(bp.dQpart, pl.nsplit_bwd, b, h, L, pl.Lp, pl.dp, dh, two_scale, bp.dQ, inner, dh, s)) != HN_OK) return rc;
     } else {
       if ((rc = launch_attn_bwd_dq(ba, s)) != HN_OK) return rc;
-      if ((rc = launch_dq_reduce(bp.dQpart, pl.nsplit_bwd, b, h, L, pl.Lp, pl.dp, dh, two_scale, bp.dQ, inner, dh, s)) != HN_OK) return rc;
+      if (!dq_direct && (rc = launch_dq_reduce(bp.dQpart, pl.nsplit_bwd, b, h, L, pl.Lp, pl.dp, dh, two_scale, bp.dQ, inner, dh, s)) != HN_OK) return rc;
       if ((rc = launch_attn_bwd_dkv(ba, dh, inner, s)) != HN_OK) return rc;
     }
     const long krows = (long)b * pl.N;

@@ -224,6 +224,21 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnBwdArgs &a, int ngrou
   }
 
   const long prow = ((long)bh * a.nsplit + split) * a.Lp;
+  if (a.dQfinal != nullptr) {      // one split: the finished rows, as dq_reduce would write them (wave-uniform)
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int tile = qg * NQ + i;
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int q = tile * 16 + 4 * g + r, c = 16 * d + j;
+          const float v = dQ[i][d][r] * __shfl(invl[i], 4 * g + r);
+          if (q < L && c < a.dq_width) a.dQfinal[((long)bi * L + q) * a.dq_ld + (long)hi * a.dq_pitch + c] = v * a.dq_scale;
+        }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < NQ; ++i) {
     const int tile = qg * NQ + i;
@@ -246,6 +261,7 @@ static int bwd_nq(int dt) { return dt == 1 ? 4 : (dt == 2 ? 2 : (dt == 4 ? 2 : 1
 
 int launch_attn_bwd_dq(const AttnBwdArgs &a, hipStream_t s) {
   HN_REQUIRE(a.dp == 16 || a.dp == 32 || a.dp == 64 || a.dp == 128, HN_E_UNSUPPORTED, "attn_bwd_dq: dp=%d", a.dp);
+  HN_REQUIRE(a.dQfinal == nullptr || (a.nsplit == 1 && !attn_bwd_dq_lds_eligible(a)), HN_E_SHAPE, "attn_bwd_dq: direct rows need one split (nsplit=%d)", a.nsplit);
   if (attn_bwd_dq_lds_eligible(a)) return launch_attn_bwd_dq_lds(a, s);
   const int dt = a.dp / 16, nq = bwd_nq(dt);
   const int ngroups = ceil_div(a.Lp / 16, nq);

@@ -639,6 +639,9 @@ struct AttnBwdArgs {
   DropCfg drop;                                  // the forward's dropout on the probabilities (thr == 0: off)
   int drop_rowsum;                               // shared-context binding under dropout: V carries a ones column dp-1
   int qk_steps;                                  // > 0: packed shared context, k-steps of the channel contractions (see attn_core)
+  // one split (the latent self-attention, short contexts): the dQ kernel writes the finished rows itself -- (b*Lq rows, ld dq_ld), head hi
+  // at column hi * dq_pitch, dq_width valid columns, times dq_scale -- exactly what dq_reduce would make of the single partial; NULL: partials
+  float *dQfinal; int dq_ld, dq_pitch, dq_width; float dq_scale;
 };
 int launch_pack_fold(float *x, int ld, int h, int D, int dp, int ks, int mode, long rows, hipStream_t s, int srow = 0);
 int launch_attn_bwd_dq(const AttnBwdArgs &a, hipStream_t s);

@@ -137,13 +137,14 @@ def test_fused_backward_equals_the_per_block_launches(name, tmp_path):
     assert differ > 0, "the fused route produced bit-identical gradients: HN_NO_BCHAIN did not change the route?"
 
 
-@pytest.mark.parametrize("switch", ["HN_NO_TN_BATCH", "HN_NO_ONETOK_FUSED", "HN_NO_NARROW_COLSUM", "HN_FORCE_TORCH_OPS"])
+@pytest.mark.parametrize("switch", ["HN_NO_TN_BATCH", "HN_NO_ONETOK_FUSED", "HN_NO_NARROW_COLSUM", "HN_FORCE_TORCH_OPS", "HN_NO_DQ_DIRECT"])
 @pytest.mark.parametrize("name", ["three_bindings", "tied_depth3"])
 def test_round5_routes_equal_their_predecessors(name, switch, tmp_path):
     """Round 5: the chains' weight-gradient products of a layer in one batched launch (duplicate destinations folded in one reduce
     pass), the one-token block's backward in four launches, the narrow column sums of the shared-context backward, and the eager route
-    behind a plain autograd.Function -- each against
-    the route it replaced (its switch, in a subprocess): gradients equal to fp32 summation noise; bit for bit for the host route."""
+    behind a plain autograd.Function, and the single-split dQ kernel writing its finished rows itself instead of a partial + dq_reduce
+    -- each against the route it replaced (its switch, in a subprocess): gradients equal to fp32 summation noise; bit for bit for
+    the host route and for the direct dQ rows."""
     grads = {}
     for tag, env in (("new", {}), ("old", {switch: "1"})):
         dst = str(tmp_path / f"{tag}.pt")
@@ -154,7 +155,7 @@ def test_round5_routes_equal_their_predecessors(name, switch, tmp_path):
     scale = max(float(v.abs().max()) for v in grads["old"].values())
     for k, ref in grads["old"].items():
         got = grads["new"][k]
-        if switch == "HN_FORCE_TORCH_OPS":
+        if switch in ("HN_FORCE_TORCH_OPS", "HN_NO_DQ_DIRECT"):
             assert torch.equal(got, ref), k
         else:
             assert float((got - ref).abs().max()) <= 2e-5 * scale + 1e-4 * float(ref.abs().max()), k
