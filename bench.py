@@ -39,6 +39,7 @@ import ctypes
 import json
 import os
 import sys
+import threading
 import time
 
 import torch
@@ -298,6 +299,11 @@ def train_step_record(dev, rank, world, distributed, barrier, steps, warmup):
     import healnet_amd as hn
     from healnet_amd import dist as hdist
     import torch.distributed as dist
+    inject = os.environ.get("HN_BENCH_INJECT", "")       # tests only ("raise:<rank>" / "hang:<rank>"): a rank that dies / never
+    if inject == f"raise:{rank}":                         # returns here must not cost the driver the headline line (main())
+        raise RuntimeError("injected failure (HN_BENCH_INJECT)")
+    if inject == f"hang:{rank}":
+        time.sleep(1e6)
     torch.manual_seed(0)
     model = hn.HealNet(**TRAIN_KW).train().to(dev)
     gen = torch.Generator().manual_seed(4321 + rank)
@@ -623,6 +629,8 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip the per-config record (cfg1 / cfg3 / cfg4 / cfg5 forwards at N = 1)")
     ap.add_argument("--no-train-step", action="store_true", help="skip the cfg4 training-step record")
     ap.add_argument("--train-steps", type=int, default=30)
+    ap.add_argument("--train-watchdog-s", type=float, default=240.0,
+                    help="N > 1: print the line without the training-step record if that record has not returned by then")
     ap.add_argument("--core-precision", choices=["fp32", "bf16", "bf16x3"], default="fp32",
                     help="development switch: bf16 MFMA in the image cross-attention core (the headline is fp32)")
     args = ap.parse_args()
@@ -775,25 +783,58 @@ def main():
                         "prices the same launch at the reference formulation's 13.15 GF/sample",
             },
         }
-    train_rec = None
+    # ---- secondary records.  None of them may cost the driver the headline line measured above: an exception becomes an
+    # {"error": ...} entry, and at N > 1 -- where the training-step record runs collectives on a fabric this code has never met --
+    # a watchdog prints the line without it and ends every rank if the record has not returned in time (a hung collective cannot
+    # be caught as an exception; every rank arms the same timer, so none is left behind holding the launcher).
+    def emit():
+        if rank == 0:
+            print(json.dumps(result), flush=True)
+
+    def guarded(fn, *a):
+        try:
+            return fn(*a)
+        except Exception as e:      # noqa: BLE001
+            return {"error": f"{type(e).__name__}: {e}"[:400]}
+
+    if rank == 0:
+        result["build_id"] = _capi.lib().hn_build_id().decode()
     if not args.no_train_step:
         del model, tab, img
         torch.cuda.empty_cache()
-        train_rec = train_step_record(dev, rank, world, distributed, barrier, args.train_steps, 5)
-    if rank == 0:
-        result["build_id"] = _capi.lib().hn_build_id().decode()
-        if train_rec is not None:
-            if world == 1 and not args.no_cpu_baseline:
-                train_rec["cpu_baseline_forward"] = cpu_baseline_cfg4()
+        watchdog = None
+        if world > 1:
+            def fire():
+                if rank == 0:
+                    result["train_step"] = {"error": f"watchdog: the training-step record did not return within {args.train_watchdog_s} s "
+                                                     "(hung collective or a dead rank); the headline above was measured before it"}
+                emit()
+                os._exit(0)
+            watchdog = threading.Timer(args.train_watchdog_s, fire)
+            watchdog.daemon = True
+            watchdog.start()
+        train_rec = guarded(train_step_record, dev, rank, world, distributed, barrier, args.train_steps, 5)
+        if watchdog is not None:
+            watchdog.cancel()
+        if world > 1 and "error" in train_rec:      # the peers may be parked in a collective this rank left: no clean shutdown
+            if rank == 0:
+                result["train_step"] = train_rec
+            emit()
+            sys.stdout.flush()
+            os._exit(0)
+        if rank == 0:
+            if world == 1 and not args.no_cpu_baseline and "error" not in train_rec:
+                train_rec["cpu_baseline_forward"] = guarded(cpu_baseline_cfg4)
             result["train_step"] = train_rec
+    if rank == 0:
         if world == 1 and not args.no_staged_models:
-            result["staged_models"] = staged_models_record(dev)
-            result["patch_bag_precisions"] = patch_bag_record(dev)
+            result["staged_models"] = guarded(staged_models_record, dev)
+            result["patch_bag_precisions"] = guarded(patch_bag_record, dev)
         if world == 1 and not args.no_configs:
-            result["configs"] = configs_record(dev)
+            result["configs"] = guarded(configs_record, dev)
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(result))
+            result["cpu_baseline"] = guarded(cpu_baseline)
+    emit()
     if distributed:
         dist.destroy_process_group()
 

@@ -77,3 +77,21 @@ def test_plain_gpus_n_command_launches_its_own_ranks():
     t = j["train_step"]
     assert t["world_size"] == 2 and t["global_batch"] == 16 and t["backend"] == "gloo"
     assert "ms_per_step_blocking_allreduce" in t and "allreduce_alone_ms" in t
+
+
+@pytest.mark.parametrize("inject", ["raise:1", "hang:1", "raise:0"])
+def test_a_failing_training_record_at_n2_still_prints_the_headline_line(inject):
+    """N > 1: the training-step record runs collectives; a rank that raises in it, or never returns from it, must not cost the
+    driver the line (bench.py main(): guarded records + a watchdog armed on every rank).  One JSON line, the headline intact,
+    `train_step.error` says what happened, exit code 0."""
+    env = dict(os.environ, HN_BENCH_SHARED_GPU="1", HN_BENCH_INJECT=inject)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+                          "--train-steps", "3", "--train-watchdog-s", "25"], cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["value"] > 0 and j["roofline"]["frac"] > 0.2 and j["build_id"]
+    assert "error" in j["train_step"], j["train_step"]

@@ -85,6 +85,35 @@ def test_cfg2_full_size_gradients_vs_oracle_autograd(hn):
     _grad_parity(hn, kw, ins, seed=42, what="cfg2_b2_224")
 
 
+def test_cfg2_b32_inference_forward_every_sample_vs_oracle(hn):
+    """The driver's metric exactly: the eval / no_grad forward (hn_fusion_forward: folded queries in the chains, the score-bound
+    core, the merge inside the chains) of the seed-0 default model on bench.py's own inputs (generator 1234, tab then img) at
+    b = 32 -- ALL 32 logit rows against the oracle (the inference forward at the headline batch had the oracle on a
+    2-sample slice only).  The oracle runs sample by sample (0.6 GB of scores per sample and layer); nothing couples samples."""
+    kw = dict(n_modalities=2, channel_dims=[2000, 3], num_spatial_axes=[1, 2], out_dims=4)
+    torch.manual_seed(0)
+    model = hn.HealNet(**kw).eval()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    gen = torch.Generator().manual_seed(1234)
+    tab = torch.rand(32, 1, 2000, generator=gen)
+    img = torch.rand(32, 224, 224, 3, generator=gen)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(32, threads))
+    try:
+        with torch.no_grad():
+            want = torch.cat([O.fusion_forward(sd, O.FusionConfig(**kw), [tab[i:i + 1], img[i:i + 1]]) for i in range(32)])
+    finally:
+        torch.set_num_threads(threads)
+    model.to(DEV)
+    with torch.no_grad():
+        got = model([tab.to(DEV), img.to(DEV)])
+    assert got.shape == (32, 4) and torch.isfinite(got).all()
+    worst = max(rel_err(got[i].cpu(), want[i]) for i in range(32))
+    print(f"cfg2 b=32 inference forward: worst per-sample rel err vs oracle {worst:.2e}")
+    for i in range(32):
+        assert_close(got[i].cpu(), want[i], rel=TOL, what=f"cfg2_b32.inference[{i}]")
+
+
 def test_cfg2_b32_full_size_training_step_vs_oracle_autograd(hn):
     """The headline batch itself: cfg2 at b = 32 on the full 224x224x3 image -- the split geometry, the 256-workgroup chains
     (one per row tile, no cluster), the batched weight-gradient launches over 4096 rows that only this size runs.  The oracle's
