@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""PMC passes of the cfg2 forward on the GPU box and their per-kernel summary (profiles/rNN_*_pmc_cfg2_b32.json).
+"""PMC passes of a forward on the GPU box and their per-kernel summary (profiles/rNN_*_pmc_cfg2_b32.json; with --cfg the other
+BASELINE configs: profiles/rNN_*_pmc_cfg3_b16_bf16.json ...).
 
     python tools/pmc_collect.py --out gpurun_out/pmc --json gpurun_out/r01_pmc_cfg2_b32.json [--core-precision fp32]
+    python tools/pmc_collect.py --cfg 3 --core-precision bf16 --out gpurun_out/pmc3 --json gpurun_out/pmc_cfg3_b16_bf16.json
 
 Runs three separate `rocprofv3 --kernel-trace --pmc ...` passes (FETCH_SIZE | WRITE_SIZE | SQ_* + GRBM_GUI_ACTIVE: one
 counter set per pass, never combined with a sys/hip/hsa trace) over `tools/quick_cfg2.py 32 3`, then averages the
@@ -24,7 +26,13 @@ def main():
     ap.add_argument("--out", default="gpurun_out/pmc")
     ap.add_argument("--json", default="gpurun_out/pmc_cfg2_b32.json")
     ap.add_argument("--core-precision", default="fp32")
+    ap.add_argument("--cfg", type=int, default=2, help="BASELINE config (2: tools/quick_cfg2.py 32 3; 3 / 4 / 5: tools/bench_configs.py at its batch, 3 steps)")
     args = ap.parse_args()
+    if args.cfg == 2:
+        workload = [sys.executable, os.path.join(ROOT, "tools/quick_cfg2.py"), "32", "3"]
+    else:
+        workload = [sys.executable, os.path.join(ROOT, "tools/bench_configs.py"), "--cfg", str(args.cfg), "--core-precision", args.core_precision,
+                    "--steps", "3"]
     out = os.path.abspath(args.out)
     os.makedirs(out, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp", HN_QUICK_PRECISION=args.core_precision)
@@ -32,8 +40,7 @@ def main():
     durations = collections.defaultdict(list)
     for tag, counters in PASSES.items():
         d = os.path.join(out, tag)
-        cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + counters.split() + ["--output-format", "csv", "-d", d, "-o", tag, "--",
-                                                                               sys.executable, os.path.join(ROOT, "tools/quick_cfg2.py"), "32", "3"]
+        cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + counters.split() + ["--output-format", "csv", "-d", d, "-o", tag, "--"] + workload
         subprocess.run(cmd, cwd="/tmp", env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
         assert files, f"no counter_collection.csv under {d}"
@@ -66,15 +73,16 @@ def main():
     doc = {
         "source_sha256": {"attention.hip": sha("healnet_amd/csrc/attention.hip")},     # bench.py drops the traffic figure when this no longer matches
         "git_head": os.environ.get("HN_GIT_HEAD"),
-        "command": "python tools/pmc_collect.py (three rocprofv3 --kernel-trace --pmc passes over tools/quick_cfg2.py 32 3: "
+        "command": "python tools/pmc_collect.py (three rocprofv3 --kernel-trace --pmc passes over " + " ".join(os.path.relpath(w, ROOT) if os.path.isabs(w) and w.startswith(ROOT) else w for w in workload[1:]) + ": "
                    + " | ".join(PASSES.values()) + ")",
+        "config": "cfg%d" % args.cfg,
         "core_precision": args.core_precision,
         "note": "FETCH_SIZE/WRITE_SIZE are KiB per dispatch; gfx950: FETCH_SIZE reads 1/2 of the bytes of wide coalesced streams "
                 "(MI355X_MICROARCH.md) -> upper estimate (2*FETCH + WRITE) KiB, raw (FETCH + WRITE) KiB",
         "dominant_kernel": dom,
         "dominant_kernel_traffic_bytes_per_launch": {"raw": kernels[dom].get("hbm_bytes_raw"),
                                                      "fetch_doubled": kernels[dom].get("hbm_bytes_fetch_doubled")},
-        "algorithmic_bytes_per_launch": {"z_context_read_once": 32 * 50176 * 16 * 4, "partials_written": 32 * 8 * 8 * 128 * 18 * 4},
+        "algorithmic_bytes_per_launch": ({"z_context_read_once": 32 * 50176 * 16 * 4, "partials_written": 32 * 8 * 8 * 128 * 18 * 4} if args.cfg == 2 else None),
         "kernels": kernels,
     }
     with open(args.json, "w") as f:
