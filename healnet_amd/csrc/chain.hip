@@ -275,6 +275,9 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
         lv[s] = gld1(a_Lpart + pr);
         ov[s] = gld4(a_Opart + pr * 16 + 4 * gq);
       }
+      // (the scheduler otherwise sinks some of the partial-O requests to just in front of their use to save registers: three
+      // load / s_waitcnt vmcnt(0) / fma round trips one behind the other in this prologue -- the ISA, end of round 5)
+      __builtin_amdgcn_sched_barrier(0);
       float Mn = M;
 #pragma unroll
       for (int s = 0; s < CHAIN_MERGE_GROUP; ++s) Mn = fmaxf(Mn, s0 + s < a_nsplit ? mv[s] : -3.0e38f);
@@ -347,10 +350,22 @@ __global__ __launch_bounds__(512) void latent_chain_kernel(const ChainArgs args)
     if (a_head == 1) {
       const gf32 *orow = a_O + (long)(m0 + row) * a_ldo;
       const int a_o_cols = EXT && args.o_cols > 0 ? args.o_cols : a_inner_o;
-      for (int q = l32; q < a_inner_o / 4; q += 32) {       // 16-byte chunk q of the row: k-tile q >> 3, slot q & 7
-        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);         // (staged models: the contraction beyond O's own columns is zero)
-        if (4 * q < a_o_cols) o = gld4(orow + 4 * q);
-        lst4(lds, Abig + (q >> 3) * ATILE + row * WK + (((q & 7) ^ (row & 7)) * 4), o);
+      // 16-byte chunk q of the row: k-tile q >> 3, slot q & 7.  A lane owns at most FOUR chunks (inner_o <= 16 WK = 512 floats,
+      // launch_latent_chain), and all of them are requested before the first is parked: as a loop with a run-time trip count this
+      // was one dependent round trip per chunk (global_load, s_waitcnt vmcnt(0), ds_write, four times over) -- the prologue of a
+      // chain behind an out-projection took 7.6 k cycles against 3.5-4 k for one without the tile (tools/chain_profile.py, round 5)
+      const int nq4 = a_inner_o >> 2;
+      float4 o[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int q = l32 + 32 * u;
+        o[u] = make_float4(0.f, 0.f, 0.f, 0.f);             // (staged models: the contraction beyond O's own columns is zero)
+        if (q < nq4 && 4 * q < a_o_cols) o[u] = gld4(orow + 4 * q);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int q = l32 + 32 * u;
+        if (q < nq4) lst4(lds, Abig + (q >> 3) * ATILE + row * WK + (((q & 7) ^ (row & 7)) * 4), o[u]);
       }
     }
   }
