@@ -781,9 +781,13 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
 }
 
 // gemm_skinny_kernel with per-entry operands (blockIdx.z): see GemmSkinnyMulti.  SM = 8 for batches of up to 8 samples, as above.
-template <int SM>
+// SN = weight rows (output columns) per workgroup.  (32, 4): every workgroup re-reads all 32 activation rows for its four weight rows --
+// at K = 2005, N = 3 x 512 (the one-token block's value projection, cfg2 b = 32) that is 98 MB through the L2s for 12 MB of weights, and
+// it is that traffic, not the four round trips, the launch's 14.8 us were (eight waves on two trips: 18.9 us).  (16, 8) has the same 128
+// accumulators per lane and two thirds of the requests: 8 weight + 16 activation rows per k.
+template <int SM, int SN = 4>
 __global__ __launch_bounds__(256) void gemm_skinny_multi_kernel(GemmSkinnyMulti g) {
-  constexpr int SN = 4, U = SM == 8 ? 4 : 2;      // k-chunks in flight per trip
+  constexpr int U = SM == 8 ? 4 : 2;      // k-chunks in flight per trip
   __shared__ float part[4][SM * SN];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n0 = blockIdx.x * SN, z = blockIdx.z, m0 = blockIdx.y * SM;
@@ -819,7 +823,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_multi_kernel(GemmSkinnyMulti 
         for (int j = 0; j < SN; ++j) acc[m * SN + j] = fmaf(a, w[u][j], acc[m * SN + j]);
       }
   }
-  if constexpr (SM == 32) {
+  if constexpr (SM * SN == 128) {
     fold_half<64>(acc, lane, 32);
     fold_half<32>(acc, lane, 16);
     fold_half<16>(acc, lane, 8);
@@ -854,7 +858,10 @@ int launch_gemm_skinny_multi(const GemmSkinnyMulti &g, hipStream_t s) {
              g.nz, g.M, g.N, g.K);
   HN_REQUIRE(((long)(g.M + 64) * g.lda) * 4 < (1L << 31) && ((long)(g.N + 64) * g.ldw) * 4 < (1L << 31), HN_E_UNSUPPORTED,
              "gemm_skinny_multi: an operand spans more than 2 GiB");
+  static const bool no_wide = getenv("HN_NO_SKINNY_WIDE") != nullptr;      // development switch: four weight rows per workgroup for every shape
   if (g.M <= 8) hipLaunchKernelGGL(gemm_skinny_multi_kernel<8>, dim3(ceil_div(g.N, 4), 1, g.nz), dim3(256), 0, s, g);
+  else if (g.K >= 1024 && g.N % 8 == 0 && !no_wide)
+    hipLaunchKernelGGL((gemm_skinny_multi_kernel<16, 8>), dim3(g.N / 8, ceil_div(g.M, 16), g.nz), dim3(256), 0, s, g);
   else hipLaunchKernelGGL(gemm_skinny_multi_kernel<32>, dim3(ceil_div(g.N, 4), ceil_div(g.M, 32), g.nz), dim3(256), 0, s, g);
   HN_LAUNCH_CHECK("gemm_skinny_multi");
   return HN_OK;
