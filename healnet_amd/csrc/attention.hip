@@ -32,6 +32,7 @@
 //               is below dim_head: 4.5x fewer executed FLOPs, identical math up to fp32 rounding.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace hn {
 
@@ -56,8 +57,10 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 // KS = number of QK^T k-steps (4 per 16-column block); < 4*DT only with the packed context layout (common.h).
 __device__ __forceinline__ float f4c(const float4 &v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); }
 
+// (second launch bound = waves per SIMD the register allocation must leave room for: the dp = 16 image core is planned for FOUR --
+// attn_core_geometry's 4096 resident waves; a fifth of the 512 registers each -- whatever the two instances of its token loop do)
 template <int DT, int NQ, bool ONES, int KS = 4 * DT, bool DROP = false>
-__global__ __launch_bounds__(256) void attn_core_kernel(AttnCoreArgs a, int ngroups, int gy, int waves_per_block) {
+__global__ __launch_bounds__(256, (DT == 1 && NQ == 4 && !DROP) ? 4 : 1) void attn_core_kernel(AttnCoreArgs a, int ngroups, int gy, int waves_per_block) {
   constexpr int DP = 16 * DT;
   const int L = a.Lq;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -148,7 +151,12 @@ __global__ __launch_bounds__(256) void attn_core_kernel(AttnCoreArgs a, int ngro
   };
 
   // one 16-token step on the (kf, vf) fragments; prefetches the following tile into (kn, vn)
-  auto step = [&](int t0, float4 (&kf)[DT], float (&vf)[DT][4], float4 (&kn)[DT], float (&vn)[DT][4]) {
+  // BND (a std::integral_constant<bool, ...> tag): the fixed-reference mode as a COMPILE-TIME property of the loop.  As a run-time
+  // scalar the wave-uniform switch still cost two vector instructions per step (the `rescale` flag's i1 copy through a VGPR:
+  // v_cndmask + v_cmp in front of the branch) plus the branch itself, in a loop where every vector cycle is matrix time lost; the
+  // token loop below is therefore instantiated twice and the switch taken once, in front of it.
+  auto step = [&](auto BND, int t0, float4 (&kf)[DT], float (&vf)[DT][4], float4 (&kn)[DT], float (&vn)[DT][4]) {
+    constexpr bool kBounded = decltype(BND)::value;
     // Unconditional: past the split the rows belong to the next split (read and never used), past the context they read 0
     // through the descriptor.  Behind a branch the request count differs between the two paths into the join, and the
     // compiler then waits vmcnt(0) -- for the prefetch it has just issued -- in front of the tile's first MFMA.
@@ -209,8 +217,11 @@ __global__ __launch_bounds__(256) void attn_core_kernel(AttnCoreArgs a, int ngro
       }
       // (one scalar branch on `bounded`: folded into the per-lane `need` it came back as v_cndmask / v_cmp pairs in front of two
       // branches -- four VALU instructions per step in a loop where every VALU cycle is MFMA time lost)
+      // (all sixteen exponentials in front of the first P V product: with nothing between them the scheduler pairs each with its
+      // MFMA -- exp, wait states, MFMA, sixteen times over)
+      if constexpr (kBounded) __builtin_amdgcn_sched_barrier(0);
       bool rescale = false;
-      if (unbounded != 0) {
+      if constexpr (!kBounded) {
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
           ps0 += P[i][0] + P[i][2];
@@ -331,9 +342,16 @@ __global__ __launch_bounds__(256) void attn_core_kernel(AttnCoreArgs a, int ngro
   float4 kA[DT], kB[DT];
   float vA[DT][4], vB[DT][4];
   if (t_begin < t_end) load_kv(t_begin, kA, vA);
-  for (int t0 = t_begin; t0 < t_end; t0 += 32) {
-    step(t0, kA, vA, kB, vB);
-    if (t0 + 16 < t_end) step(t0 + 16, kB, vB, kA, vA);
+  auto walk = [&](auto BND) {
+    for (int t0 = t_begin; t0 < t_end; t0 += 32) {
+      step(BND, t0, kA, vA, kB, vB);
+      if (t0 + 16 < t_end) step(BND, t0 + 16, kB, vB, kA, vA);
+    }
+  };
+  if constexpr (ONES) {
+    if (bounded) walk(std::true_type{}); else walk(std::false_type{});
+  } else {
+    walk(std::false_type{});
   }
 
   // ---- single split (latent self-attention, short contexts): normalise and write O in its final layout
