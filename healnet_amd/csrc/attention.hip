@@ -151,12 +151,12 @@ __global__ __launch_bounds__(256, (DT == 1 && NQ == 4 && !DROP) ? 4 : 1) void at
   };
 
   // one 16-token step on the (kf, vf) fragments; prefetches the following tile into (kn, vn)
-  // BND (a std::integral_constant<bool, ...> tag): the fixed-reference mode as a COMPILE-TIME property of the loop.  As a run-time
+  // BND (a std::integral_constant<int, ...> tag): the fixed-reference mode as a COMPILE-TIME property of the loop (image core).  As a run-time
   // scalar the wave-uniform switch still cost two vector instructions per step (the `rescale` flag's i1 copy through a VGPR:
   // v_cndmask + v_cmp in front of the branch) plus the branch itself, in a loop where every vector cycle is matrix time lost; the
   // token loop below is therefore instantiated twice and the switch taken once, in front of it.
-  auto step = [&](auto BND, int t0, float4 (&kf)[DT], float (&vf)[DT][4], float4 (&kn)[DT], float (&vn)[DT][4]) {
-    constexpr bool kBounded = decltype(BND)::value;
+  auto step = [&](auto BND, int t0, float4 (&kf)[DT], float (&vf)[DT][4], float4 (&kn)[DT], float (&vn)[DT][4]) __attribute__((always_inline)) {
+    constexpr int kMode = decltype(BND)::value;      // 0: running reference, 1: fixed reference, 2: decided per launch (run-time switch)
     // Unconditional: past the split the rows belong to the next split (read and never used), past the context they read 0
     // through the descriptor.  Behind a branch the request count differs between the two paths into the join, and the
     // compiler then waits vmcnt(0) -- for the prefetch it has just issued -- in front of the tile's first MFMA.
@@ -219,9 +219,11 @@ __global__ __launch_bounds__(256, (DT == 1 && NQ == 4 && !DROP) ? 4 : 1) void at
       // branches -- four VALU instructions per step in a loop where every VALU cycle is MFMA time lost)
       // (all sixteen exponentials in front of the first P V product: with nothing between them the scheduler pairs each with its
       // MFMA -- exp, wait states, MFMA, sixteen times over)
-      if constexpr (kBounded) __builtin_amdgcn_sched_barrier(0);
+      if constexpr (kMode == 1) __builtin_amdgcn_sched_barrier(0);
       bool rescale = false;
-      if constexpr (!kBounded) {
+      bool guard = kMode == 0;
+      if constexpr (kMode == 2) guard = unbounded != 0;
+      if (guard) {
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
           ps0 += P[i][0] + P[i][2];
@@ -342,16 +344,23 @@ __global__ __launch_bounds__(256, (DT == 1 && NQ == 4 && !DROP) ? 4 : 1) void at
   float4 kA[DT], kB[DT];
   float vA[DT][4], vB[DT][4];
   if (t_begin < t_end) load_kv(t_begin, kA, vA);
-  auto walk = [&](auto BND) {
+  // (both lambdas are force-inlined: left to the inliner's budget, the dropout variants -- whose step carries the generator -- kept `step`
+  // as a function of its own, and the fragment / accumulator arrays it takes by reference moved to scratch: 832 bytes per lane, 4x the time)
+  auto walk = [&](auto BND) __attribute__((always_inline)) {
     for (int t0 = t_begin; t0 < t_end; t0 += 32) {
       step(BND, t0, kA, vA, kB, vB);
       if (t0 + 16 < t_end) step(BND, t0 + 16, kB, vB, kA, vA);
     }
   };
-  if constexpr (ONES) {
-    if (bounded) walk(std::true_type{}); else walk(std::false_type{});
+  // Two instances only where it was measured to pay and the registers are there: the dp = 16 image core with four tiles per wave.
+  // Everywhere else ONE loop with the run-time switch, as before -- the second instance costs every variant ~20 VGPRs (the
+  // allocation is the maximum over both), which takes the dp = 32 cores with 7 / 8 k-steps from four waves per SIMD to three.
+  if constexpr (ONES && DT == 1 && NQ == 4 && !DROP) {
+    if (bounded) walk(std::integral_constant<int, 1>{}); else walk(std::integral_constant<int, 0>{});
+  } else if constexpr (ONES) {
+    walk(std::integral_constant<int, 2>{});
   } else {
-    walk(std::false_type{});
+    walk(std::integral_constant<int, 0>{});
   }
 
   // ---- single split (latent self-attention, short contexts): normalise and write O in its final layout
