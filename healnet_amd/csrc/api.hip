@@ -1811,7 +1811,7 @@ size_t hn_l1_adam_workspace_bytes(void) { return L1_ADAM_PARTIALS * sizeof(float
 int hn_l1_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, long n, double l1, double grad_scale,
                     double lr, double beta1, double beta2, double eps, int step, float *reg_loss, void *workspace,
                     size_t workspace_bytes, void *stream) {
-  { const int prc = cluster_poll("hn_l1_adam_step"); if (prc != HN_OK) return prc; }
+  { const int prc = cluster_poll("hn_l1_adam_step", (hipStream_t)stream); if (prc != HN_OK) return prc; }
   int rc = check_ws(workspace, workspace_bytes, hn_l1_adam_workspace_bytes(), "l1_adam");
   if (rc != HN_OK) return rc;
   return launch_l1_adam(params, grads, exp_avg, exp_avg_sq, n, l1, grad_scale, lr, beta1, beta2, eps, step, reg_loss,
@@ -3037,7 +3037,7 @@ size_t hn_context_split_floats(const hn_model *m, int b) {
 
 int hn_fusion_forward_cp(const hn_model *m, const hn_modality_input *in, int b, int return_embeddings, const hn_context_split *cp,
                          float *out, void *workspace, size_t workspace_bytes, void *stream) {
-  { const int prc = cluster_poll("hn_fusion_forward_cp"); if (prc != HN_OK) return prc; }
+  { const int prc = cluster_poll("hn_fusion_forward_cp", (hipStream_t)stream); if (prc != HN_OK) return prc; }
   HN_REQUIRE(m && in && cp && out, HN_E_NULL, "fusion_cp: NULL pointer");
   HN_REQUIRE(cp->n_parts >= 1 && cp->local && cp->parts && cp->exchange, HN_E_NULL, "fusion_cp: exchange buffers / callback missing");
   HN_REQUIRE(m->n_modalities <= 16, HN_E_UNSUPPORTED, "fusion_cp: %d modalities", m->n_modalities);
@@ -3049,7 +3049,7 @@ int hn_fusion_forward_cp(const hn_model *m, const hn_modality_input *in, int b, 
 int hn_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, const uint8_t *mask, int skip_self_on_missing,
                       int return_embeddings, float *out, float **attn_stats, float **x_trace, void *workspace,
                       size_t workspace_bytes, void *stream, hn_profile *prof) {
-  { const int prc = cluster_poll("hn_fusion_forward"); if (prc != HN_OK) return prc; }
+  { const int prc = cluster_poll("hn_fusion_forward", (hipStream_t)stream); if (prc != HN_OK) return prc; }
   if (!stage_wanted(m))
     return impl_fusion_forward(m, in, b, mask, skip_self_on_missing, return_embeddings, out, attn_stats, x_trace, workspace, workspace_bytes,
                                stream, prof);
@@ -3123,7 +3123,7 @@ int hn_fusion_tape_layout(const hn_model *m, const hn_modality_input *in, int b,
 int hn_fusion_forward_train(const hn_model *m, const hn_modality_input *in, int b, const uint8_t *mask, int skip_self_on_missing,
                             int return_embeddings, float *out, float **attn_stats, float **x_trace, void *tape,
                             size_t tape_bytes, void *workspace, size_t workspace_bytes, void *stream) {
-  { const int prc = cluster_poll("hn_fusion_forward_train"); if (prc != HN_OK) return prc; }
+  { const int prc = cluster_poll("hn_fusion_forward_train", (hipStream_t)stream); if (prc != HN_OK) return prc; }
   if (!stage_wanted(m))
     return impl_fusion_forward_train(m, in, b, mask, skip_self_on_missing, return_embeddings, out, attn_stats, x_trace, tape, tape_bytes,
                                      workspace, workspace_bytes, stream);
@@ -3179,7 +3179,7 @@ size_t hn_fusion_backward_workspace_bytes(const hn_model *m, const hn_modality_i
 int hn_fusion_backward(const hn_model *m, const hn_modality_input *in, int b, const uint8_t *mask, int skip_self_on_missing,
                        int return_embeddings, const float *dout, const void *tape, const hn_model_grads *g, void *workspace,
                        size_t workspace_bytes, void *stream, const hn_grad_ready *ready) {
-  { const int prc = cluster_poll("hn_fusion_backward"); if (prc != HN_OK) return prc; }
+  { const int prc = cluster_poll("hn_fusion_backward", (hipStream_t)stream); if (prc != HN_OK) return prc; }
   if (!stage_wanted(m))
     return impl_fusion_backward(m, in, b, mask, skip_self_on_missing, return_embeddings, dout, tape, g, workspace, workspace_bytes, stream, ready);
   hipStream_t s = (hipStream_t)stream;

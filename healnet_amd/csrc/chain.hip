@@ -878,6 +878,7 @@ struct ClusterDev {
   unsigned *word_host = nullptr, *word_dev = nullptr;
   bool alloc_failed = false;
   bool disabled = false;
+  bool reported = false;                  // the word's current token has been counted by a poll that could not clear it
   bool inject = false;                    // hn_cluster_config(enable = 2): test hook, every cluster launch loses an exchange
   unsigned next_token = 0, lost = 0, last_token = 0;
   int timeout_us = -1;                    // -1: HN_CLUSTER_TIMEOUT_US or the default
@@ -961,7 +962,7 @@ void cluster_after_launch(int dev, hipStream_t s) {
   if (!g.ev_valid) (void)hipGetLastError();
 }
 
-int cluster_poll(const char *who) {
+int cluster_poll(const char *who, hipStream_t s) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return HN_OK; }
   if (dev < 0 || dev >= 64) return HN_OK;
@@ -971,9 +972,19 @@ int cluster_poll(const char *who) {
   const unsigned v = *(volatile unsigned *)g.word_host;
   if (v == 0) return HN_OK;
   g.disabled = true;
-  g.lost += 1;
+  if (!g.reported || g.last_token != v) g.lost += 1;
+  g.reported = true;
   g.last_token = v;
-  *(volatile unsigned *)g.word_host = 0;
+  // The word is cleared only once the device has DRAINED: an hn_l1_adam_step enqueued before this call (the host running ahead of
+  // a stalled chain) decides on the device whether to skip by reading this word, and must still find it set when it executes.
+  // Under stream capture nothing can be waited for: the word stays set -- every fused entry point keeps returning
+  // HN_E_CORESIDENCY -- until the caller has drained the device itself and acknowledged through hn_cluster_status.
+  if (!stream_capturing(s) && hipDeviceSynchronize() == hipSuccess) {
+    *(volatile unsigned *)g.word_host = 0;
+    g.reported = false;
+  } else {
+    (void)hipGetLastError();
+  }
   return fail(HN_E_CORESIDENCY,
               "%s: a cluster-mode latent chain launched earlier on device %d (launch token %u) gave up waiting for a member "
               "workgroup (co-residency lost: busy / masked CUs); the rows of that tile -- and what was computed from them since "
@@ -998,7 +1009,8 @@ int cluster_status(int dev, int acknowledge, hn_cluster_info *info) {
   unsigned v = g.word_host ? *(volatile unsigned *)g.word_host : 0u;
   if (v != 0 && acknowledge) {
     g.disabled = true;
-    g.lost += 1;
+    if (!g.reported || g.last_token != v) g.lost += 1;      // (a poll that could not drain has counted this loss already)
+    g.reported = false;
     g.last_token = v;
     *(volatile unsigned *)g.word_host = 0;
   }

@@ -567,13 +567,15 @@ int launch_dropout_mask(uint8_t *mask, long rows, int cols, const DropCfg &d, hi
 //    only ever compared, never used after the call it arrived in (the old guard recorded on a possibly destroyed stream);
 //  * a wait that still runs into its bound (HN_CLUSTER_TIMEOUT_US, default 100 ms) turns the tile into NaN and stores the
 //    launch's token into the device's host-mapped STATUS WORD.  cluster_poll() -- called first thing by every fused entry point
-//    -- sees a non-zero word, switches cluster mode off for the device (sticky), clears the word and returns HN_E_CORESIDENCY
-//    once; hn_l1_adam_step's kernel reads the word and leaves parameters and moments alone while it is set.
+//    -- sees a non-zero word, switches cluster mode off for the device (sticky), DRAINS the device, clears the word and returns
+//    HN_E_CORESIDENCY once (cleared before the drain, an Adam step enqueued earlier could still read a clean word);
+//    hn_l1_adam_step's kernel reads the word and leaves parameters and moments alone while it is set.  On a capturing stream
+//    nothing can be drained: the word stays set (every entry point keeps failing) until hn_cluster_status acknowledges it.
 struct ClusterTicket { unsigned *status; unsigned token, wait_ticks; int inject_loss; };
 bool cluster_enabled(int dev);                                         // false after a lost exchange / hn_cluster_config(enable = 0) / HN_NO_CHAIN_CLUSTER
 void cluster_before_launch(int dev, hipStream_t s, ClusterTicket *t);
 void cluster_after_launch(int dev, hipStream_t s);
-int cluster_poll(const char *who);                                     // HN_OK or HN_E_CORESIDENCY (current device)
+int cluster_poll(const char *who, hipStream_t s);                      // HN_OK or HN_E_CORESIDENCY (current device)
 const unsigned *cluster_status_device_word(int dev);                   // device-visible address of the status word, or NULL (never allocated)
 int cluster_status(int dev, int acknowledge, hn_cluster_info *info);
 int cluster_config(int dev, int enable, int timeout_us);

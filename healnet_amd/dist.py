@@ -27,6 +27,29 @@ def _active() -> bool:
     return dist.is_initialized() and (dist.get_world_size() > 1 or force_collectives())
 
 
+_cluster_off_devices = set()
+
+
+def keep_ranks_in_step(device: Optional[torch.device]) -> None:
+    """Data-parallel training with more than one rank: switch the latent chains' CLUSTER mode off on this rank's device.
+
+    The failure handling of a cluster launch is per process (include/healnet_hip.h "failure signal": the rank that lost an
+    exchange gets NaN rows, its hn_l1_adam_step skips, the host repeats the step).  Under a gradient all-reduce that is not
+    enough: the NaN gradients of that rank have been summed into every peer before any host sees the report, the peers' status
+    words are clean, they apply the step, and the ranks diverge for good.  The case the mode's bounded wait exists for
+    -- an RCCL kernel holding CUs beside the chain -- is exactly the data-parallel step, so the ranks of a group of more than one
+    run the same arithmetic without clusters (slower latent side at b <= 8 per rank, identical results), and a lost exchange can
+    no longer happen.  Called by every gradient-averaging entry of this module; idempotent."""
+    if device is None or device.type != "cuda" or not dist.is_initialized() or dist.get_world_size() <= 1:
+        return
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx in _cluster_off_devices:
+        return
+    from . import _capi
+    _capi.cluster_config(idx, enable=False)
+    _cluster_off_devices.add(idx)
+
+
 def _free_port() -> int:
     import socket
     with socket.socket() as sock:
@@ -86,6 +109,9 @@ def allreduce_mean_(tensors: Iterable[torch.Tensor], bucket_bytes: int = 32 << 2
     if not _active():
         return
     world = dist.get_world_size()
+    tensors = list(tensors)
+    if tensors:
+        keep_ranks_in_step(tensors[0].device)
     bucket: List[torch.Tensor] = []
     size = 0
 
@@ -181,6 +207,7 @@ class GradReadyAllReduce:
         from . import _capi, ops
         self.flat = flat
         self.device = flat.grads.device
+        keep_ranks_in_step(self.device)                      # world > 1: no cluster launches beside the collectives (see there)
         depth = int(model.depth)
         self.buckets = grad_ready_buckets(model, flat.views, flat.offsets)
         self.depth = depth

@@ -771,17 +771,35 @@ class GraphedForward:
             _require_gpu(t, "modality tensor")
             self.inputs.append((t if t.dtype in (torch.bfloat16, torch.uint8) else t.float()).contiguous().clone())
         self.mask = None if mask is None else mask.to(dev).clone()
+        self.warmup = max(1, int(warmup))
+        self.captures = 0
+        self._capture()
+
+    def _dev_index(self) -> int:
+        return self.device.index if self.device.index is not None else torch.cuda.current_device()
+
+    def _capture(self) -> None:
+        model, dev = self.model, self.device
         self.graph = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.no_grad(), torch.cuda.stream(side):
-            for _ in range(max(1, warmup)):          # first-call work (LDS opt-in of the chain kernel, workspace growth) stays outside
+            for _ in range(self.warmup):             # first-call work (LDS opt-in of the chain kernel, workspace growth) stays outside
                 model(list(self.inputs), mask=self.mask, return_embeddings=self.return_embeddings)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
+        with torch.cuda.device(dev):
+            st = _capi.cluster_status(self._dev_index())
+            if st["pending"]:                        # a warm-up run lost a cluster exchange: consume it, capture without clusters
+                _capi.note_coresidency(_capi.CoresidencyLost(_capi.HN_E_CORESIDENCY, "GraphedForward", "a warm-up run lost a cluster "
+                                                             "exchange; capturing without cluster mode"), self._dev_index(), lambda: None)
+                st = _capi.cluster_status(self._dev_index())
+        # the cluster decision is baked into the captured launches: remember the state it was taken under (see __call__)
+        self._cluster_epoch = (st["lost"], st["enabled"])
         with torch.no_grad(), torch.cuda.graph(self.graph):
             self.out = model(list(self.inputs), mask=self.mask, return_embeddings=self.return_embeddings)
         self._last = model._last                       # statistics / trace buffers of the capture: rewritten by every replay
+        self.captures += 1
 
     def __call__(self, tensors=None, mask=None) -> torch.Tensor:
         """Replay on new values of the captured shapes (``None`` / omitted: whatever the static inputs hold)."""
@@ -800,6 +818,18 @@ class GraphedForward:
             if self.mask is None:
                 raise ValueError("captured without a mask")
             self.mask.copy_(mask, non_blocking=True)
+        # No entry point of the library runs during a replay, so the cluster-mode failure signal (include/healnet_hip.h) is polled
+        # here (one read of a host-mapped word): after a lost exchange -- reported by a replay of this graph, or consumed elsewhere
+        # since the capture -- the graph still holds cluster launches and is captured again without them.  The outputs of the
+        # replay that LOST the exchange hold NaN rows (never a silently incomplete sum); the next call is clean.
+        st = _capi.cluster_status(self._dev_index())
+        if st["pending"] or self._cluster_epoch != (st["lost"], st["enabled"]):
+            torch.cuda.synchronize(self.device)
+            if st["pending"]:
+                _capi.note_coresidency(_capi.CoresidencyLost(_capi.HN_E_CORESIDENCY, "GraphedForward", "a replayed cluster-mode latent "
+                                                             "chain lost an exchange; the forward is captured again without cluster mode"),
+                                       self._dev_index(), lambda: None)
+            self._capture()
         self.graph.replay()
         if self._last is not None:
             self._last.pop("zcache", None)             # normalised contexts cached by an attention-weight export of older inputs

@@ -324,7 +324,9 @@ class GraphedStep:
         self._graphs: Dict[tuple, "_CapturedStep"] = {}
         self._pool = None
         self.captures = 0
-        _capi.cluster_status(self._dev_index())          # (creates the device's status word before anything is captured)
+        with torch.cuda.device(self.device):             # (hn_cluster_status creates the word only for the CURRENT device)
+            st = _capi.cluster_status(self._dev_index())     # creates the device's status word before anything is captured
+        self._cluster_epoch = (st["lost"], st["enabled"])    # what the captured launches were decided under (see __call__)
         if example_inputs is not None:
             self._get(self._signature(example_inputs, loss_args, mask), example_inputs, loss_args, mask)
 
@@ -360,17 +362,24 @@ class GraphedStep:
         for t in list(inputs) + list(loss_args) + [mask]:
             if t is not None and not isinstance(t, torch.Tensor):
                 raise TypeError(f"GraphedStep: expected tensors, got {type(t).__name__}")
-        if _capi.cluster_status(self._dev_index())["pending"]:
-            # a replayed cluster launch lost an exchange (the device-side skip kept the optimizer from applying that step): every
-            # graph holds such launches -- drop them all, consume the report (cluster mode goes off), capture afresh below
+        st = _capi.cluster_status(self._dev_index())
+        if st["pending"] or self._cluster_epoch != (st["lost"], st["enabled"]):
+            # a replayed cluster launch lost an exchange (the device-side skip kept the optimizer from applying that step).  The
+            # report may already have been consumed elsewhere -- FusedL1Adam.step's hn_l1_adam_step polls too, and is as likely to
+            # see it first -- so the test is not `pending` alone but the device's loss counter / enabled flag against
+            # what they were when the graphs were captured: the cluster decision is baked into a captured launch, every graph
+            # holds such launches -- drop them all, consume a pending report (cluster mode goes off), capture afresh below
             torch.cuda.synchronize(self.device)
             self._graphs.clear()
             self._pool = None                      # (the shared pool dies with its last graph)
-            try:
-                raise _capi.CoresidencyLost(_capi.HN_E_CORESIDENCY, "GraphedStep", "a replayed cluster-mode latent chain lost an exchange; "
-                                            "the captured graphs were dropped and the step is captured again without cluster mode")
-            except _capi.CoresidencyLost as err:
-                _capi.note_coresidency(err, self._dev_index(), lambda: None)
+            if st["pending"]:
+                try:
+                    raise _capi.CoresidencyLost(_capi.HN_E_CORESIDENCY, "GraphedStep", "a replayed cluster-mode latent chain lost an exchange; "
+                                                "the captured graphs were dropped and the step is captured again without cluster mode")
+                except _capi.CoresidencyLost as err:
+                    _capi.note_coresidency(err, self._dev_index(), lambda: None)
+            st = _capi.cluster_status(self._dev_index())
+            self._cluster_epoch = (st["lost"], st["enabled"])
         g = self._get(self._signature(inputs, loss_args, mask), inputs, loss_args, mask)
         g.load(inputs, loss_args, mask)
         g.graph.replay()
@@ -426,6 +435,9 @@ class _CapturedStep:
             owner._pool = torch.cuda.graph_pool_handle()
         with torch.cuda.graph(self.graph, pool=owner._pool):
             self.loss, self.output = body()
+        if not owner._graphs:                        # first graph of a (new) set: the state its cluster decisions were taken under
+            st = _capi.cluster_status(owner._dev_index())
+            owner._cluster_epoch = (st["lost"], st["enabled"])
 
     def load(self, inputs, loss_args, mask) -> None:
         # (presence, shapes and dtypes are the signature this object was looked up by: they match)

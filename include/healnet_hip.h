@@ -353,8 +353,11 @@ int hn_set_kernel_timers(hn_kernel_timer *timers, int n);
  * (64 bytes of pinned memory, the only allocation this library ever makes; created by the first eager cluster launch or
  * hn_cluster_status call on the device).  From then on:
  *   - the NEXT call of hn_fusion_forward / hn_fusion_forward_cp / hn_fusion_forward_train / hn_fusion_backward / hn_l1_adam_step
- *     on that device launches nothing, switches cluster mode off for the device (sticky), clears the word and returns
- *     HN_E_CORESIDENCY (hn_last_error_string names the launch).  Outputs produced since the lost exchange may hold NaN: repeat
+ *     on that device launches nothing, switches cluster mode off for the device (sticky), waits for the device to drain
+ *     (hipDeviceSynchronize: work enqueued before this call still sees the word set), clears the word and returns
+ *     HN_E_CORESIDENCY (hn_last_error_string names the launch).  On a capturing stream nothing can be waited for: the word stays
+ *     set, and every entry point keeps returning HN_E_CORESIDENCY, until the caller has drained the device and acknowledged
+ *     through hn_cluster_status.  Outputs produced since the lost exchange may hold NaN: repeat
  *     the step (all later launches run the same arithmetic without clusters);
  *   - an hn_l1_adam_step that was ALREADY enqueued when the exchange was lost reads the word on the device and leaves
  *     parameters and moments untouched, so a poisoned gradient never reaches the weights of this process;
