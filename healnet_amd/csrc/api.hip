@@ -1094,7 +1094,9 @@ struct FusionPlan {
   int dominant;   // modality with the most tokens among the present ones
   bool chain;     // the latent side runs on latent_chain_kernel (chain.hip): l_d = 128, l_c % 16 == 0
   float *cq, *ckv;   // ... which writes the NEXT attention block's projections here (outside op_ws: the block in front still owns it)
+  float *lk, *lvt;   // layer chains (lchain.hip, inference): LAYER_KV_SLOTS K images (b, 8, 128, 64) and V^T images (b, 8, 64, 128), or NULL
 };
+constexpr int LAYER_KV_SLOTS = LSEG_MAX / 2;
 
 static int plan_fusion(const hn_model *m, const hn_modality_input *in, int b, void *ws, size_t ws_bytes, FusionPlan *fp,
                        bool inference = false) {
@@ -1250,6 +1252,11 @@ static int plan_fusion(const hn_model *m, const hn_modality_input *in, int b, vo
       fp->cbound = ar.take<float>((size_t)b * 8 * m->l_c);
       fp->cq = ar.take<float>(rows16((size_t)b * m->l_c) * max_inner);
       fp->ckv = ar.take<float>(rows16((size_t)b * m->l_c) * 2 * (max_inner_self > 0 ? max_inner_self : 1));
+    }
+    fp->lk = fp->lvt = nullptr;
+    if (fp->chain && inference && m->l_c == 128 && m->self_per_cross_attn > 0 && max_inner_self == 512 && latent_layer_enabled()) {
+      fp->lk = ar.take<float>((size_t)LAYER_KV_SLOTS * b * 8 * 128 * 64);
+      fp->lvt = ar.take<float>((size_t)LAYER_KV_SLOTS * b * 8 * 128 * 64);
     }
   }
   fp->op_ws_bytes = op_max;
@@ -2001,6 +2008,125 @@ static int impl_fusion_forward(const hn_model *m, const hn_modality_input *in, i
     ca.xchg = fp.xchg; ca.xflags = fp.flags + m->depth * M; ca.seq = ++chain_seq;
     return launch_latent_chain(ca, s);
   };
+  // ---- layer chains (lchain.hip): the whole latent side between two shared-context cores as ONE launch, the latent self-attention
+  // inside it.  All or nothing per forward: every step must be a one-token block computed ahead, a shared-context block whose merge
+  // and query fold the chains take over, or a latent self-attention block of 8 heads x 64 -- each followed by its feed-forward block.
+  {
+    int dev = 0;
+    HN_HIP_CHECK(hipGetDevice(&dev));
+    static const bool force_small = getenv("HN_FORCE_SELF_IN_CHAIN") != nullptr;      // route switch (tests): also below the size gate
+    bool layer_ok = use_chain && latent_layer_enabled() && cluster_enabled(dev) && !staged && mask == nullptr && cp == nullptr &&
+                    L == 128 && d == 128 && fp.lk != nullptr &&
+                    (b * 8 > 128 || force_small) && (b + 7) / 8 * 64 + 1 <= CHAIN_XCHG_FLAGS && nsteps >= 2 && nsteps % 2 == 0 && al16(cur);
+    int max_seg = 0;
+    for (int k = 0, nseg = 0, nself = 0; layer_ok && k < nsteps; k += 2) {
+      const Step &st = steps[k];
+      layer_ok = is_attn(st) && !is_attn(steps[k + 1]);
+      if (!layer_ok) break;
+      const hn_ff_params *fq = ff_of(steps[k + 1]);
+      layer_ok = fq->dim == d && fq->w1 && fq->b1 && fq->w2 && fq->b2 && chain_ff_aligned(fq) && al16(fq->b1) && al16(fq->b2) &&
+                 (fq->norm_w == nullptr) == (fq->norm_b == nullptr);
+      if (!layer_ok) break;
+      ChainArgs scratch;
+      memset(&scratch, 0, sizeof(scratch));
+      if (st.kind == STEP_SELF_ATTN) {
+        const hn_attn_params *an = &m->self_attn[st.layer];
+        if ((rc = add_next_proj(scratch, k)) != HN_OK) return rc;
+        layer_ok = nseg > 0 && nself < LAYER_KV_SLOTS && q_done && kv_done && an->heads == 8 && an->dim_head == 64 && scratch.nq == 512 && scratch.nkv == 1024 &&
+                   an->w_out && an->b_out && chain_out_aligned(an) && al16(an->b_out) && (an->norm_w == nullptr) == (an->norm_b == nullptr);
+        ++nself;
+      } else if (is_tab(st)) {
+        layer_ok = m->cross_attn[st.layer * M + st.m].query_dim == d;
+      } else {
+        const hn_attn_params *an = &m->cross_attn[st.layer * M + st.m];
+        AttnPlan pn;
+        if ((rc = plan_attn(an, true, fp.ldz[st.m], b, L, fp.N[st.m], fp.D[st.m], nullptr, 0, &pn)) != HN_OK) return rc;
+        if ((rc = add_next_proj(scratch, k)) != HN_OK) return rc;
+        layer_ok = qf_done && vmerge[st.m] && pn.rank_d && pn.ones && pn.dp == 16 && pn.nsplit <= CHAIN_MERGE_MAX_SPLITS && an->heads <= 8 &&
+                   (pn.dh == 16 || pn.dh == 32 || pn.dh == 64) && pn.inner == 512 && an->heads * pn.dh == 512 && scratch.qf_heads == 8 &&
+                   an->w_out && an->b_out && chain_out_aligned(an) && al16(an->b_out);
+        nseg = 0; nself = 0;                 // (a launch boundary: the core runs between two layer chains)
+      }
+      ++nseg;
+      if (nseg > max_seg) max_seg = nseg;
+    }
+    q_done = kv_done = qf_done = false;
+    if (layer_ok && max_seg <= LSEG_MAX) {
+      LayerChainArgs la;
+      memset(&la, 0, sizeof(la));
+      int nself = 0;
+      auto begin_launch = [&]() {
+        memset(&la, 0, sizeof(la));
+        la.b = b; la.x_in = cur;
+        la.kbuf = fp.lk; la.vtbuf = fp.lvt; la.kv_stride = (long)b * 8 * 128 * 64;
+        la.xflags = fp.flags + m->depth * M; la.flag_count = CHAIN_XCHG_FLAGS;
+        nself = 0;
+      };
+      // x after the segment of steps (k, k + 1) is the input of step k + 2: kept where hn_attn_probs re-reads it (its trace slot)
+      // when there is one; otherwise it only leaves LDS at the end of a launch (in place: a workgroup reads and writes its own rows)
+      float *nxt = cur;
+      auto flush = [&]() -> int {
+        if (la.nseg == 0) return HN_OK;
+        la.seg[la.nseg - 1].x_out = nxt;
+        cur = nxt;
+        la.seq = chain_seq + 1;
+        chain_seq += nself;
+        return launch_latent_layer(la, s);
+      };
+      begin_launch();
+      for (int k = 0; k < nsteps; k += 2) {
+        const Step &st = steps[k];
+        const hn_ff_params *fq = ff_of(steps[k + 1]);
+        LSeg sg;
+        memset(&sg, 0, sizeof(sg));
+        if (st.kind == STEP_SELF_ATTN) {
+          const hn_attn_params *an = &m->self_attn[st.layer];
+          AttnPlan pn;
+          if ((rc = plan_attn(an, false, 0, b, L, L, d, nullptr, 0, &pn)) != HN_OK) return rc;
+          LSeg &pv = la.seg[la.nseg - 1];    // the segment in front projects for this block and runs its core
+          pv.proj = 1; pv.kv_slot = nself++; pv.alpha_q = pn.cscale;
+          pv.stats = attn_stats ? attn_stats[slot_of(st)] : nullptr;
+          pv.p_nw = an->norm_w; pv.p_nb = an->norm_b; pv.wq = an->w_q; pv.wkv = an->w_kv;
+          sg.head = 4; sg.w_out = an->w_out; sg.b_out = an->b_out;
+        } else if (is_tab(st)) {
+          const hn_attn_params *an = &m->cross_attn[st.layer * M + st.m];
+          sg.head = 2; sg.y = fp.taby[st.m] + (size_t)st.layer * b * an->query_dim;
+        } else {
+          const hn_attn_params *an = &m->cross_attn[st.layer * M + st.m];
+          ChainArgs ca;
+          memset(&ca, 0, sizeof(ca));
+          if ((rc = add_next_proj(ca, k)) != HN_OK) return rc;      // (sets the folded-query fields; qf_done)
+          if (la.nseg > 0) {
+            LSeg &pv = la.seg[la.nseg - 1];
+            pv.proj = 2; pv.p_nw = ca.p_nw; pv.p_nb = ca.p_nb; pv.wq = ca.wq;
+            la.qf = ca.qf; la.qf_bound = ca.qf_bound; la.qf_flag = ca.qf_flag; la.qf_D = ca.qf_D;
+            if ((rc = flush()) != HN_OK) return rc;
+          } else {                           // the forward starts with this block: its query fold is a chain of its own
+            ca.x_in = cur;
+            if ((rc = launch_chain(ca)) != HN_OK) return rc;
+          }
+          AttnExt ext = {fp.cq, fp.ckv, false, false, true, nullptr, 0, false, false, nullptr, nullptr, nullptr, 0, 0, 0};
+          ext.qf = fp.cq; ext.qf_bound = fp.cbound; ext.qf_done = true; ext.allow_defer_merge = true;
+          if ((rc = run_attn(st, cur, nullptr, &ext)) != HN_OK) return rc;
+          HN_REQUIRE(ext.merge_deferred, HN_E_UNSUPPORTED, "fusion: the shared-context block of layer %d, modality %d did not leave its merge to the chain", st.layer, st.m);
+          begin_launch();
+          la.Opart = ext.opart; la.Mpart = ext.mpart; la.Lpart = ext.lpart; la.nsplit = ext.nsplit; la.Lp = ext.Lp;
+          la.heads = an->heads; la.dh = an->dim_head;
+          la.wvf = fp.wvf[st.m] + (size_t)st.layer * an->heads * an->dim_head * 16;
+          la.stats3 = attn_stats ? attn_stats[slot_of(st)] : nullptr;
+          sg.head = 3; sg.w_out = an->w_out; sg.b_out = an->b_out;
+        }
+        sg.gate = fq->gate; sg.f_nw = fq->norm_w; sg.f_nb = fq->norm_b; sg.w1 = fq->w1; sg.b1 = fq->b1; sg.w2 = fq->w2; sg.b2 = fq->b2;
+        nxt = input_buffer(k + 2);
+        if (nxt != cur) sg.x_out = nxt;      // a trace slot (or back to the plan's buffer behind one)
+        la.seg[la.nseg++] = sg;
+      }
+      if ((rc = flush()) != HN_OK) return rc;
+      q_done = kv_done = qf_done = false;
+      if (head) return launch_head(cur, b, L, d, m->head_norm_w, m->head_norm_b, m->head_w, m->head_b, m->out_dims, out, s, m->l_d_valid);
+      return launch_copy(out, cur, (long)((xbytes) / sizeof(float)), s);
+    }
+  }
   if (staged && use_chain && nsteps > 0 && is_attn(steps[0]) && !is_tab(steps[0])) {      // the first block's projections: a chain of their own
     ChainArgs ca;
     memset(&ca, 0, sizeof(ca));

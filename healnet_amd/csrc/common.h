@@ -393,9 +393,41 @@ struct ChainArgs {
   int inject_loss;                      // internal: hn_cluster_config(enable = 2) -- the last member of every tile withholds its flag
 };
 constexpr int CHAIN_XCHG_FLOATS = 256 * 16 * 128;      // <= 256 workgroups x one partial tile
-constexpr int CHAIN_XCHG_FLAGS = 256 + 1;
+constexpr int CHAIN_XCHG_FLAGS = 2048 + 1;           // cluster chains: <= 256 (tile, member) flags; layer chains (lchain.hip): one per row tile, b <= 256
 bool latent_chain_supported(int rows, int d, int hidden);
 int launch_latent_chain(const ChainArgs &a, hipStream_t s);
+// ------------------------------------------------------------------------------------------------
+// layer chain (lchain.hip): the whole latent side between two shared-context cores -- segments of [head] -> feed-forward block ->
+// [projections -> latent self-attention], the x tile in LDS throughout, the self-attention a stage family of the weight ring
+// ------------------------------------------------------------------------------------------------
+constexpr int LSEG_MAX = 8;
+struct LSeg {
+  int head;                             // 0: x as it is; 2: x += y[sample]; 3: out-projection of the core's merged split partials (segment 0 only);
+                                        // 4: out-projection of the self-attention output the previous segment (proj = 1) left in LDS
+  int gate;                             // feed-forward block (hn_gate)
+  int proj;                             // 0: none; 1: Q | K | V (512 each) + the latent self-attention; 2: folded query of the next rank-D block (last segment)
+  int kv_slot;                          // proj 1: which K / V^T image of the launch (0, 1, ...: in segment order)
+  float alpha_q;                        // proj 1: scale of the query projection (softmax scale in log2 units)
+  const float *w_out, *b_out;           // head 3 / 4: (128, 512), (128)
+  const float *y;                       // head 2: (b, 128)
+  const float *f_nw, *f_nb, *w1, *b1, *w2, *b2;
+  const float *p_nw, *p_nb, *wq, *wkv;  // proj: LayerNorm on x, (512 | 128, 128) query weights, (1024, 128) key / value weights
+  float *x_out;                         // x after the feed-forward block, (rows, 128), or NULL
+  float *stats;                         // proj 1: (b, 8, 128, 2) softmax (max, sum) of the self-attention rows for hn_attn_probs, or NULL
+};
+struct LayerChainArgs {
+  int b, nseg;                          // samples (l_c = 128 rows each, 8 workgroups), segments
+  const float *x_in;                    // (b * 128, 128)
+  const float *Opart, *Mpart, *Lpart, *wvf; int nsplit, Lp, heads, dh;      // head 3 (ChainArgs)
+  float *stats3;                        // head 3: (b, heads, 128, 2) merged (max, sum) per row, or NULL
+  float *qf, *qf_bound; int *qf_flag; int qf_D;                             // proj 2 (ChainArgs)
+  float *kbuf, *vtbuf; long kv_stride;  // K (b, 8, 128, 64) and V^T (b, 8, 64, 128) images, kv_stride floats between the slots
+  int *xflags; int flag_count, seq;     // one flag per row tile + a marker, zeroed at the start of the forward; first sequence number (one per proj 1 segment)
+  unsigned *status; unsigned token, wait_ticks; int inject_loss, flag_marker;      // internal (cluster_before_launch)
+  LSeg seg[LSEG_MAX];
+};
+bool latent_layer_enabled();            // false: HN_NO_SELF_IN_CHAIN (route switch)
+int launch_latent_layer(const LayerChainArgs &a, hipStream_t s);
 // backward of the latent chain (bchain.hip): projection backward of an attention block -> feed-forward block backward -> the
 // out-projection backward of the attention block in front of it, one launch; weight gradients by launch_gemm_tn_multi
 struct BChainArgs {
