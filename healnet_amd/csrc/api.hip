@@ -1896,6 +1896,20 @@ static int impl_fusion_forward(const hn_model *m, const hn_modality_input *in, i
     tab_ready[i] = true;
   }
 
+  // The latent array moves through a chain of buffers instead of being updated in place: the block in front of an
+  // attention block writes straight into that block's x_trace slot (the input hn_attn_probs re-reads later), so
+  // keeping the trace costs no copy.  Without trace slots every block works in place on fp.x as before.
+  static thread_local Step steps[kMaxSteps];
+  const int nsteps = build_schedule(m, in, skip_self_on_missing, steps, kMaxSteps);
+  HN_REQUIRE(nsteps >= 0, HN_E_UNSUPPORTED, "fusion: more than %d blocks", kMaxSteps);
+  auto slot_of = [&](const Step &st) { return st.layer * (M + 1) + (st.kind == STEP_CROSS_ATTN ? st.m : M); };
+  auto input_buffer = [&](int k) -> float * {      // where step k wants to find x
+    if (k < nsteps && x_trace && (steps[k].kind == STEP_CROSS_ATTN || steps[k].kind == STEP_SELF_ATTN) && x_trace[slot_of(steps[k])])
+      return x_trace[slot_of(steps[k])];
+    return fp.x;
+  };
+  float *cur = input_buffer(0);
+  bool broadcast_done = false;      // the latent broadcast (:225) + the flags rode on a vfold launch
   // folded value projections for the chains that merge the split partials of a shared-context block themselves (one launch per
   // modality and forward; only when the chain is the route)
   bool vmerge[16], qfolded[16];
@@ -1923,24 +1937,17 @@ static int impl_fusion_forward(const hn_model *m, const hn_modality_input *in, i
         vf.w_k[layer] = al.w_kv; vf.w_q[layer] = al.w_q;
       }
     }
+    static const bool no_bc_role = getenv("HN_NO_VFOLD_BROADCAST") != nullptr;      // route switch (A/B)
+    if (!broadcast_done && !no_bc_role && ((long)L * d) % 4 == 0 && al16(m->latents) && al16(cur)) {
+      vf.bc_src = m->latents; vf.bc_dst = cur; vf.bc_per = (long)L * d; vf.bc_total = (long)L * d * b;
+      vf.bc_zero = fp.flags; vf.bc_nzero = m->depth * M + CHAIN_XCHG_FLAGS;
+      broadcast_done = true;
+    }
     if ((rc = launch_vfold(vf, s)) != HN_OK) return rc;
     vmerge[i] = true;
   }
 
-  // The latent array moves through a chain of buffers instead of being updated in place: the block in front of an
-  // attention block writes straight into that block's x_trace slot (the input hn_attn_probs re-reads later), so
-  // keeping the trace costs no copy.  Without trace slots every block works in place on fp.x as before.
-  static thread_local Step steps[kMaxSteps];
-  const int nsteps = build_schedule(m, in, skip_self_on_missing, steps, kMaxSteps);
-  HN_REQUIRE(nsteps >= 0, HN_E_UNSUPPORTED, "fusion: more than %d blocks", kMaxSteps);
-  auto slot_of = [&](const Step &st) { return st.layer * (M + 1) + (st.kind == STEP_CROSS_ATTN ? st.m : M); };
-  auto input_buffer = [&](int k) -> float * {      // where step k wants to find x
-    if (k < nsteps && x_trace && (steps[k].kind == STEP_CROSS_ATTN || steps[k].kind == STEP_SELF_ATTN) && x_trace[slot_of(steps[k])])
-      return x_trace[slot_of(steps[k])];
-    return fp.x;
-  };
-  float *cur = input_buffer(0);
-  if ((rc = launch_broadcast_rows(m->latents, cur, (long)L * d, b, s, fp.flags, m->depth * M + CHAIN_XCHG_FLAGS)) != HN_OK) return rc;   // :225 (+ the bound / cluster flags)
+  if (!broadcast_done && (rc = launch_broadcast_rows(m->latents, cur, (long)L * d, b, s, fp.flags, m->depth * M + CHAIN_XCHG_FLAGS)) != HN_OK) return rc;   // :225 (+ the bound / cluster flags)
   int chain_seq = 0;
   const bool head = m->final_classifier_head && !return_embeddings;
   const bool use_chain = fp.chain && !chain_disabled();      // HN_NO_CHAIN: development switch, the unfused launch sequence

@@ -702,6 +702,16 @@ extern "C" __attribute__((visibility("default"))) int hn_debug_chain_prof(unsign
 // merged context average -- gamma folded in, the packed channel order of the context (common.h), and in column dp-1 (the ones
 // column of the average) the beta term.  What merge_vproj_kernel builds per workgroup, once per forward here.
 __global__ __launch_bounds__(256) void vfold_kernel(VfoldMulti v) {
+  if ((int)blockIdx.y >= v.n) {               // broadcast role (common.h): x[i] = latents[i mod (l_c * l_d)], 16 bytes per thread and pass
+    const long nb = (long)gridDim.x * v.bc_rows * gridDim.z;
+    const long bid = ((long)(blockIdx.y - v.n) * gridDim.z + blockIdx.z) * gridDim.x + blockIdx.x;
+    const long n4 = v.bc_total >> 2, per4 = v.bc_per >> 2;
+    for (long i = bid * blockDim.x + threadIdx.x; i < n4; i += nb * blockDim.x)
+      ((f32x4 *)v.bc_dst)[i] = ((const f32x4 *)v.bc_src)[i % per4];
+    if (bid == 0)
+      for (int i = threadIdx.x; i < v.bc_nzero; i += blockDim.x) v.bc_zero[i] = 0;
+    return;
+  }
   const int hi = blockIdx.x, z = blockIdx.y, dp = 16;
   const float *w_v = v.w_v[z], *gamma = v.gamma[z], *beta = v.beta[z];
   float *out = v.out + (long)z * v.out_stride;
@@ -771,7 +781,17 @@ __global__ __launch_bounds__(256) void vfold_kernel(VfoldMulti v) {
 int launch_vfold(const VfoldMulti &v, hipStream_t s) {
   HN_REQUIRE(v.n >= 1 && v.n <= 16 && v.out && v.D >= 1 && v.D <= 15 && v.heads >= 1, HN_E_SHAPE, "vfold: n=%d D=%d heads=%d", v.n, v.D, v.heads);
   HN_REQUIRE(v.qout == nullptr || (v.dh <= 128 && v.l_d >= 1), HN_E_SHAPE, "vfold: query fold dh=%d l_d=%d", v.dh, v.l_d);
-  hipLaunchKernelGGL(vfold_kernel, dim3(v.heads, v.n, v.qout ? 1 + (v.l_d + 31) / 32 : 1), dim3(256), 0, s, v);
+  VfoldMulti vv = v;
+  vv.bc_rows = 0;
+  if (v.bc_dst) {
+    HN_REQUIRE(v.bc_src && v.bc_per > 0 && v.bc_per % 4 == 0 && v.bc_total % v.bc_per == 0 && (((uintptr_t)v.bc_src | (uintptr_t)v.bc_dst) & 15) == 0, HN_E_SHAPE,
+               "vfold: broadcast role per=%ld total=%ld", v.bc_per, v.bc_total);
+    const int gz = v.qout ? 1 + (v.l_d + 31) / 32 : 1;
+    const long want = (v.bc_total / 4 + 256 * 4 - 1) / (256 * 4);      // ~4 passes per thread
+    long rows = (want + (long)v.heads * gz - 1) / ((long)v.heads * gz);
+    vv.bc_rows = (int)(rows < 1 ? 1 : rows > 512 ? 512 : rows);
+  }
+  hipLaunchKernelGGL(vfold_kernel, dim3(v.heads, v.n + vv.bc_rows, v.qout ? 1 + (v.l_d + 31) / 32 : 1), dim3(256), 0, s, vv);
   HN_LAUNCH_CHECK("vfold");
   return HN_OK;
 }

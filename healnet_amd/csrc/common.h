@@ -505,6 +505,9 @@ struct VfoldMulti {                    // one entry per layer of a modality (<= 
   const float *w_k[16], *w_q[16];
   float cscale; int l_d;
   float *qout; long qout_stride;
+  // a second ROLE of the launch (workgroups with blockIdx.y >= n): the latent array's broadcast over the batch + the forward's
+  // pre-zeroed flags (broadcast_rows_kernel's work: a launch at the ~5 us floor less per forward); bc_dst == NULL: none
+  const float *bc_src; float *bc_dst; long bc_per, bc_total; int *bc_zero; int bc_nzero; int bc_rows;
 };
 int launch_vfold(const VfoldMulti &v, hipStream_t s);
 

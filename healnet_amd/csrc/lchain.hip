@@ -46,12 +46,26 @@ constexpr int PRM = 128 + 2 * CHID + 128 + 4 * 128 + 128;     // b_out | b1 | b2
 constexpr int MAXBLK = 512;              // blocks of a launch (one table entry per thread)
 constexpr int STG = 8 * 256;             // per-wave 16 x 16 output staging tiles
 constexpr int LDS_FIXED = 8 * WSLOT + 16 * ATILE + 4 * ATILE + CR * XP + 2 * MAXBLK + STG;
-constexpr int NDUMMY = 5;                // table entries between the projections and the K blocks of a self segment (the ring's lead)
+constexpr int NDUMMY = 0;                // (no filler entries: the ring runs from the Q chunks straight into the K blocks)
 constexpr int NATT = 32;                 // K blocks + V^T blocks
 constexpr int SC1 = 16;                  // cache-policy bit of a buffer load: agent scope (never served from the CU's L1)
 
 template <int V>
 using ic = std::integral_constant<int, V>;
+
+#ifdef LCHAIN_PROFILE
+// development only (tools/lchain_profile.py builds a private library with -DLCHAIN_PROFILE): 100 MHz time stamps of one workgroup
+// at the stage boundaries of the last 8 launches, 64 stamps each
+__device__ unsigned long long g_lchain_prof[8 * 64];
+__device__ int g_lchain_seq;
+#define LC_PROF(i)                                                                                              \
+  do {                                                                                                          \
+    if (blockIdx.x == 100 % gridDim.x && threadIdx.x == 0 && (i) < 63)                                          \
+      g_lchain_prof[(g_lchain_seq & 7) * 64 + (i)] = __builtin_amdgcn_s_memrealtime();                          \
+  } while (0)
+#else
+#define LC_PROF(i)
+#endif
 
 }  // namespace
 
@@ -64,6 +78,7 @@ __global__ __launch_bounds__(512) void latent_layer_kernel(const LayerChainArgs 
   const int a_nsplit = args.nsplit, a_Lp = args.Lp, a_heads = args.heads, a_dh = args.dh;
   const int nseg = args.nseg;
   constexpr int a_L = 128;
+  LC_PROF(0);
   extern __shared__ __attribute__((aligned(16))) float lds_raw[];
   lf32 *lds = (lf32 *)lds_raw;
   constexpr int Wr = 0;                     // [8 waves][WSLOT]  per-wave transpose slot of the block stream
@@ -131,7 +146,7 @@ __global__ __launch_bounds__(512) void latent_layer_kernel(const LayerChainArgs 
       } else {
         if (l2 >= 48 && l2 < 48 + NDUMMY) l2 = 47;
         if (l2 < 32) { W = (const float *)seg_p(s, offsetof(LSeg, wkv)); rb = (long)(l2 >> 2) * WN; k = l2 & 3; ldw = CD; }
-        else if (l2 < 48) { W = (const float *)seg_p(s, offsetof(LSeg, wq)); rb = (long)((l2 - 32) >> 2) * WN; k = l2 & 3; ldw = CD; }
+        else if (l2 < 48) { W = (const float *)seg_p(s, offsetof(LSeg, wq)); rb = (long)((l2 - 32) >> 2) * 16; k = l2 & 3; ldw = CD; }      // wave w: rows 64 w + 16 c + ..
         else {
           // attention blocks: slot of this segment's K / V^T images, this sample
           const int slot = seg_i(s, offsetof(LSeg, kv_slot));
@@ -155,7 +170,7 @@ __global__ __launch_bounds__(512) void latent_layer_kernel(const LayerChainArgs 
   const int pos16 = pos * 16;
   const int vrow = wave * 16 + r8;          // weights: the wave's 16 rows of the 128-row block
   const int vrowK = wave * 128 + r8;        // K image: head `wave`, token r8 of the block's 16
-  const int vrowV = wave * 64 + r8;         // V^T image: head `wave`, dim r8 of the block's 16
+  const int vrowV = wave * 64 + r8;         // V^T image: head `wave`, dim r8 of the block's 16 (and the Q weights: row 64 w + 16 c + r8)
   unsigned long long ent = 0;
   int tp = tbl;
   asm volatile("" : "+v"(tp));
@@ -178,7 +193,51 @@ __global__ __launch_bounds__(512) void latent_layer_kernel(const LayerChainArgs 
     lst4(lds, wslot + 8 * WK, r[1]);
   };
 
-  // ---- head 3 of segment 0: merge the split partials of the shared-context core, folded value projection (chain.hip)
+  __syncthreads();                           // the block table
+  LC_PROF(1);
+  fetch_entry();
+  float4 Bp[2], B0[2], B1[2], B2[2], B3[2];
+  auto issue_w = [&](float4 (&r)[2]) { load2(r, vrow, ic<0>{}); fetch_entry(); };
+  issue_w(Bp);
+  issue_w(B0);
+  issue_w(B1);
+  issue_w(B2);
+  issue_w(B3);
+  // small parameters of every segment (PRM / 4 = 480 pieces each: thread q < 480 takes piece q of EVERY segment -- the segment index is
+  // uniform, so the pointers are scalar loads from the argument segment) and the x tile: all requests first, then the LDS stores.  As
+  // a strided loop with a per-lane segment index this was two dependent round trips per pass (pointer, then data), four passes for a
+  // launch of four segments: 4.6 us of prologue against 2.5 for two segments (tools/lchain_profile.py, round 6)
+  {
+    float4 pv[LSEG_MAX];
+    bool have[LSEG_MAX];
+    const int q = tid;
+#pragma unroll
+    for (int sg2 = 0; sg2 < LSEG_MAX; ++sg2) {
+      have[sg2] = false;
+      if (sg2 < nseg && q < PRM / 4) {
+        const gf32 *src = nullptr;
+        if (q < 32) { const gf32 *p = seg_p(sg2, offsetof(LSeg, b_out)); src = p ? p + 4 * q : nullptr; }
+        else if (q < 288) src = seg_p(sg2, offsetof(LSeg, b1)) + 4 * (q - 32);
+        else if (q < 320) src = seg_p(sg2, offsetof(LSeg, b2)) + 4 * (q - 288);
+        else if (q < 352) { const gf32 *p = seg_p(sg2, offsetof(LSeg, f_nw)); src = p ? p + 4 * (q - 320) : nullptr; }
+        else if (q < 384) { const gf32 *p = seg_p(sg2, offsetof(LSeg, f_nb)); src = p ? p + 4 * (q - 352) : nullptr; }
+        else if (q < 416) { const gf32 *p = seg_p(sg2, offsetof(LSeg, p_nw)); src = p ? p + 4 * (q - 384) : nullptr; }
+        else if (q < 448) { const gf32 *p = seg_p(sg2, offsetof(LSeg, p_nb)); src = p ? p + 4 * (q - 416) : nullptr; }
+        else { const gf32 *p = seg_p(sg2, offsetof(LSeg, y)); src = p ? p + (long)samp * CD + 4 * (q - 448) : nullptr; }
+        if (src) { pv[sg2] = gld4(src); have[sg2] = true; }
+      }
+    }
+    const int row = tid >> 5, l32 = tid & 31;
+    const float4 xv = gld4(a_x_in + (long)(m0 + row) * CD + 4 * l32);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int sg2 = 0; sg2 < LSEG_MAX; ++sg2)
+      if (have[sg2]) lst4(lds, prm0 + sg2 * PRM + 4 * q, pv[sg2]);
+    lst4(lds, xs + row * XP + 4 * l32, xv);
+  }
+  // ---- head 3 of segment 0: merge the split partials of the shared-context core, folded value projection (chain.hip).  Behind the
+  // ring start and the parameter requests, not in front of them as in chain.hip (whose budget is 128 registers): one round trip for
+  // all three instead of two in a row (entry -> table 5.0 us with the merge against 1.3 without: tools/lchain_profile.py)
   const int head0 = seg_i(0, offsetof(LSeg, head));
   if (head0 == 3 && wave < a_heads) {
     const int i = lane & 15, gq = lane >> 4;
@@ -244,35 +303,9 @@ __global__ __launch_bounds__(512) void latent_layer_kernel(const LayerChainArgs 
       }
     }
   }
-  __syncthreads();                           // the block table
-  fetch_entry();
-  float4 Bp[2], B0[2], B1[2], B2[2], B3[2];
-  auto issue_w = [&](float4 (&r)[2]) { load2(r, vrow, ic<0>{}); fetch_entry(); };
-  issue_w(Bp);
-  issue_w(B0);
-  issue_w(B1);
-  issue_w(B2);
-  issue_w(B3);
-  // small parameters of every segment (PRM / 4 = 448 pieces each), the x tile
-  for (int idx = tid; idx < nseg * (PRM / 4); idx += 512) {
-    const int s = idx / (PRM / 4), q = idx - s * (PRM / 4);
-    const gf32 *src = nullptr;
-    if (q < 32) { const gf32 *p = seg_p(s, offsetof(LSeg, b_out)); src = p ? p + 4 * q : nullptr; }
-    else if (q < 288) src = seg_p(s, offsetof(LSeg, b1)) + 4 * (q - 32);
-    else if (q < 320) src = seg_p(s, offsetof(LSeg, b2)) + 4 * (q - 288);
-    else if (q < 352) { const gf32 *p = seg_p(s, offsetof(LSeg, f_nw)); src = p ? p + 4 * (q - 320) : nullptr; }
-    else if (q < 384) { const gf32 *p = seg_p(s, offsetof(LSeg, f_nb)); src = p ? p + 4 * (q - 352) : nullptr; }
-    else if (q < 416) { const gf32 *p = seg_p(s, offsetof(LSeg, p_nw)); src = p ? p + 4 * (q - 384) : nullptr; }
-    else if (q < 448) { const gf32 *p = seg_p(s, offsetof(LSeg, p_nb)); src = p ? p + 4 * (q - 416) : nullptr; }
-    else { const gf32 *p = seg_p(s, offsetof(LSeg, y)); src = p ? p + (long)samp * CD + 4 * (q - 448) : nullptr; }
-    if (src) lst4(lds, prm0 + s * PRM + 4 * q, gld4(src));
-  }
-  {
-    const int row = tid >> 5, l32 = tid & 31;
-    lst4(lds, xs + row * XP + 4 * l32, gld4(a_x_in + (long)(m0 + row) * CD + 4 * l32));
-  }
   park(Bp);
   __syncthreads();
+  LC_PROF(2);
 
   float4 fa0[2], fa1[2], fb0[2], fb1[2];
   auto read_a = [&](float4 (&f)[2], int A, int kt) {
@@ -337,6 +370,13 @@ __global__ __launch_bounds__(512) void latent_layer_kernel(const LayerChainArgs 
     step(ic<0>{}, ic<0>{}, B2, fa0, fb0, fa1, fb1, A, kc + 3, vrow, c0, c1);
     step(ic<0>{}, ic<0>{}, B3, fa1, fb1, fa0, fb0, A, kc + 4 == nk ? 0 : kc + 4, vrow, c0, c1);
   };
+  // ... with the row index register / cache policy of each step's request given (stage transitions into other images)
+  auto run4x = [&](auto x0, auto x1, auto x2, auto x3, int A, int v0, int v1, int v2, int v3, f32x4 &c0, f32x4 &c1) {
+    step(ic<0>{}, x0, B0, fa0, fb0, fa1, fb1, A, 1, v0, c0, c1);
+    step(ic<0>{}, x1, B1, fa1, fb1, fa0, fb0, A, 2, v1, c0, c1);
+    step(ic<0>{}, x2, B2, fa0, fb0, fa1, fb1, A, 3, v2, c0, c1);
+    step(ic<0>{}, x3, B3, fa1, fb1, fa0, fb0, A, 0, v3, c0, c1);
+  };
   auto run_chunk_k128 = [&](int A, f32x4 &c0, f32x4 &c1) { run4(A, 0, 4, c0, c1); };
   auto run_chunk_k512 = [&](int A, f32x4 &c0, f32x4 &c1) {
 #pragma unroll
@@ -371,10 +411,13 @@ __global__ __launch_bounds__(512) void latent_layer_kernel(const LayerChainArgs 
   }
   const int stg = stgb + wave * 256;
   int seq = args.seq;
+  int lostw = 0;                            // this wave gave up waiting for a sibling's K / V (sticky to the end of the launch)
 
   for (int sgi = 0; sgi < nseg; ++sgi) {
     const int prm = prm0 + sgi * PRM;
     const int hd = seg_i(sgi, offsetof(LSeg, head));
+#define LC_PS(j) LC_PROF(3 + sgi * 14 + (j))
+    LC_PS(0);
     // ================= OUT: x += LeakyReLU(O W_out^T + b_out), O in the A tile (head 3: merged above; head 4: the attention below) =====
     if (hd == 3 || hd == 4) {
       f32x4 c0 = zero, c1 = zero;
@@ -390,10 +433,12 @@ __global__ __launch_bounds__(512) void latent_layer_kernel(const LayerChainArgs 
       }
       __syncthreads();
     }
+    LC_PS(1);
     // ================= FF: x += (a * gate(g)) W2^T + b2,  [a | g] = LN(x) W1^T + b1 =================
     {
       layer_norm(seg_p(sgi, offsetof(LSeg, f_nw)) != nullptr, prm + o_fnw, prm + o_fnb, hd == 2 ? prm + o_y : -1);
       __syncthreads();
+      LC_PS(2);
       read_a(fa0, Ahat, 0);
       const int a_gate = seg_i(sgi, offsetof(LSeg, gate));
       for (int hc = 0; hc < 4; ++hc) {
@@ -418,6 +463,7 @@ __global__ __launch_bounds__(512) void latent_layer_kernel(const LayerChainArgs 
         for (int r = 0; r < 4; ++r) lds[hid_at[r] + hc * 4 * ATILE] = (va[r] + ba) * gate[r];
       }
       __syncthreads();
+      LC_PS(3);
       f32x4 c0 = zero, c1 = zero;
       read_a(fa0, Abig, 0);
       run_chunk_k512(Abig, c0, c1);
@@ -426,6 +472,7 @@ __global__ __launch_bounds__(512) void latent_layer_kernel(const LayerChainArgs 
 #pragma unroll
       for (int r = 0; r < 4; ++r) lds[xs + (4 * fg + r) * XP + ncol] += v[r] + bv;
       __syncthreads();
+      LC_PS(4);
     }
     {
       gf32 *xo = (gf32 *)seg_p(sgi, offsetof(LSeg, x_out));
@@ -438,6 +485,7 @@ __global__ __launch_bounds__(512) void latent_layer_kernel(const LayerChainArgs 
     if (pj == 0) continue;
     layer_norm(seg_p(sgi, offsetof(LSeg, p_nw)) != nullptr, prm + o_pnw, prm + o_pnb, -1);
     __syncthreads();
+    LC_PS(5);
     read_a(fa0, Ahat, 0);
     if (pj == 2) {
       // ---- folded query of the next shared-context block (chain.hip): wave w = head w's 16 packed slots + the row's score bound
@@ -460,6 +508,7 @@ __global__ __launch_bounds__(512) void latent_layer_kernel(const LayerChainArgs 
           if (bq > 60.0f) atomicOr(args.qf_flag, 1);
         }
       }
+      LC_PS(6);
       continue;
     }
     // ================= latent self-attention: K | V chunks, Q chunks, exchange, S^T = K Q^T, softmax, O = P V =================
@@ -470,60 +519,91 @@ __global__ __launch_bounds__(512) void latent_layer_kernel(const LayerChainArgs 
       const int t0 = member * CR;
       for (int j = 0; j < 8; ++j) {
         f32x4 c0 = zero, c1 = zero;
-        run_chunk_k128(Ahat, c0, c1);
+        // (the requests of the last five steps are Q blocks: wave w streams the rows of ITS head, 64 w + 16 c + ..)
+        const int vi3 = j == 7 ? vrowV : vrow, vi1 = j >= 6 ? vrowV : vrow;
+        run4x(ic<0>{}, ic<0>{}, ic<0>{}, ic<0>{}, Ahat, vi3, vi3, vi3, vi1, c0, c1);
         const float4 v = make_float4(c0.x + c1.x, c0.y + c1.y, c0.z + c1.z, c0.w + c1.w);
         const int hh = 2 * (j & 3) + (wave >> 2), d0 = (wave & 3) * 16;      // head and first dim of this wave's 16 columns
         if (j < 4) {
           // K rows head-major: through the staging tile to one 16-byte store per lane (16 rows x 64 contiguous bytes per wave)
           lds[stg + (4 * fg + 0) * 16 + fi] = v.x; lds[stg + (4 * fg + 1) * 16 + fi] = v.y;
           lds[stg + (4 * fg + 2) * 16 + fi] = v.z; lds[stg + (4 * fg + 3) * 16 + fi] = v.w;
-          const int srow = lane >> 2, c4 = lane & 3;
+          int ln = lane;
+          asm volatile("" : "+v"(ln));       // (address arithmetic stays here: see the statistics store below)
+          const int srow = ln >> 2, c4 = ln & 3;
           gst4(kb + ((long)hh * 128 + t0 + srow) * 64 + d0 + 4 * c4, lld4(lds, stg + srow * 16 + 4 * c4));
         } else {
           // V transposed: the accumulator IS four consecutive tokens of dim fi
-          gst4(vb + ((long)hh * 64 + d0 + fi) * 128 + t0 + 4 * fg, v);
+          int ln = lane;
+          asm volatile("" : "+v"(ln));
+          gst4(vb + ((long)hh * 64 + d0 + (ln & 15)) * 128 + t0 + 4 * (ln >> 4), v);
         }
       }
-      const float al = late_kernarg<float>(offsetof(LayerChainArgs, seg) + (size_t)sgi * sizeof(LSeg) + offsetof(LSeg, alpha_q));
-      for (int j = 0; j < 4; ++j) {
-        f32x4 c0 = zero, c1 = zero;
-        run_chunk_k128(Ahat, c0, c1);
-        const float v[4] = {c0.x + c1.x, c0.y + c1.y, c0.z + c1.z, c0.w + c1.w};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) lds[hid_at[r] + j * 4 * ATILE] = al * v[r];
-      }
-    }
-    // ---- exchange: every store of this wave acknowledged by the L2, barrier, the tile's flag; then the 8 flags of the sample
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    {
-      int *flags = args.xflags;
+      LC_PS(6);
+      // ---- exchange, first half: every store of this wave acknowledged by the L2 (vmcnt counts stores; the ring's requests in flight
+      // are waited for with them: one load latency), barrier, the TILE's flag.  (One flag per wave instead -- 64 per sample, no barrier
+      // here -- was slower: 512 lanes per workgroup polling two cache lines of one L2 channel held up the very stores they waited
+      // for: 2.612 against 2.580 ms per forward.)  The Q chunks below are the work the flag's way to the siblings hides behind.
+      LC_PS(7);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
       if (tid == 0 && !(late_kernarg<int>(offsetof(LayerChainArgs, inject_loss)) && member == 7))
-        __hip_atomic_store(flags + samp * 8 + member, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      int timed_out = 0;
-      if (tid < 8)
-        timed_out = cluster_wait(flags + samp * 8 + tid, seq, late_kernarg<unsigned>(offsetof(LayerChainArgs, wait_ticks)), flags + args.flag_marker,
-                                 late_kernarg<unsigned *>(offsetof(LayerChainArgs, status)), late_kernarg<unsigned>(offsetof(LayerChainArgs, token)));
-      const bool lost = __syncthreads_or(timed_out) != 0;
+        __hip_atomic_store(args.xflags + samp * 8 + member, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      LC_PS(8);
+      // Q, head by head: wave w projects the 64 columns of head w (chunk c = its columns 16 c .. 16 c + 15: weight rows
+      // 64 w + 16 c + .. through the V^T row index register), so the Q tile of a head is written and read by ONE wave: no barrier
+      const float al = late_kernarg<float>(offsetof(LayerChainArgs, seg) + (size_t)sgi * sizeof(LSeg) + offsetof(LSeg, alpha_q));
+      auto q_epilogue = [&](int c, const f32x4 &c0, const f32x4 &c1) {
+        const float v[4] = {c0.x + c1.x, c0.y + c1.y, c0.z + c1.z, c0.w + c1.w};
+        const int kt = 2 * wave + (c >> 1), cc = 16 * (c & 1) + fi;      // column 64 w + 16 c + fi: k-tile, column inside it
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 4 * fg + r;
+          lds[Abig + kt * ATILE + row * WK + (((cc >> 2) ^ (row & 7)) * 4) + (cc & 3)] = al * v[r];
+        }
+      };
+      {
+        f32x4 c0 = zero, c1 = zero;
+        run4x(ic<0>{}, ic<0>{}, ic<0>{}, ic<0>{}, Ahat, vrowV, vrowV, vrowV, vrowV, c0, c1);
+        q_epilogue(0, c0, c1);
+      }
+      // the sample's 8 flags are REQUESTED here (lanes 0-7 of every wave: each wave decides for itself, no barrier) and looked at a
+      // chunk later: a poll is an L2 round trip, and by then the siblings' flags are usually up
+      int early = seq;
+      if (lane < 8) early = __hip_atomic_load(args.xflags + samp * 8 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      {
+        f32x4 c0 = zero, c1 = zero;
+        run4x(ic<0>{}, ic<0>{}, ic<0>{}, ic<0>{}, Ahat, vrowV, vrowV, vrowV, vrowV, c0, c1);
+        q_epilogue(1, c0, c1);
+      }
+      // ---- exchange, second half: all 8 flags up (else the bounded wait of chain_common.h, lane by lane), BEFORE the first request of
+      // a K block leaves -- the last step of Q chunk 2 asks for K block 0 (the ring's lead is five blocks).  A wave that gives up
+      // poisons its slice of O below: every row of the tile becomes NaN in the out-projection, never a silently incomplete sum.
+      LC_PS(9);
+      if (__builtin_amdgcn_ballot_w64(early < seq) != 0) {
+        int timed_out = 0;
+        if (early < seq)
+          timed_out = cluster_wait(args.xflags + samp * 8 + lane, seq, late_kernarg<unsigned>(offsetof(LayerChainArgs, wait_ticks)), args.xflags + args.flag_marker,
+                                   late_kernarg<unsigned *>(offsetof(LayerChainArgs, status)), late_kernarg<unsigned>(offsetof(LayerChainArgs, token)));
+        if (__builtin_amdgcn_ballot_w64(timed_out != 0) != 0) lostw = 1;
+      }
       seq += 1;
-      if (lost) {                            // never a silently incomplete sum: the tile becomes NaN and stays NaN to the end of the launch
-        const int row = tid >> 5, l32 = tid & 31;
-        const float nn = __builtin_nanf("");
-        lst4(lds, xs + row * XP + 4 * l32, make_float4(nn, nn, nn, nn));
+      LC_PS(10);
+      {
+        f32x4 c0 = zero, c1 = zero;
+        run4x(ic<0>{}, ic<0>{}, ic<0>{}, ic<SC1>{}, Ahat, vrowV, vrowV, vrowV, vrowK, c0, c1);
+        q_epilogue(2, c0, c1);
+        c0 = zero; c1 = zero;
+        run4x(ic<SC1>{}, ic<SC1>{}, ic<SC1>{}, ic<SC1>{}, Ahat, vrowK, vrowK, vrowK, vrowK, c0, c1);
+        q_epilogue(3, c0, c1);
       }
     }
-    // ---- restart the ring on the K blocks (the table's dummy entries absorbed the requests that would have run ahead of the flags)
-    load2(Bp, vrowK, ic<SC1>{}); fetch_entry();
-    load2(B0, vrowK, ic<SC1>{}); fetch_entry();
-    load2(B1, vrowK, ic<SC1>{}); fetch_entry();
-    load2(B2, vrowK, ic<SC1>{}); fetch_entry();
-    load2(B3, vrowK, ic<SC1>{}); fetch_entry();
-    // the wave's Q fragments, both k-halves (B operand of S^T): k-tiles 2 w and 2 w + 1 of the Q tile
+    // the wave's Q fragments, both k-halves (B operand of S^T): k-tiles 2 w and 2 w + 1 of the Q tile, which this wave wrote itself;
+    // fb0 holds K block 0's fragments
     float4 q0[2], q1[2];
     read_a(q0, Abig + 2 * wave * ATILE, 0);
     read_a(q1, Abig + 2 * wave * ATILE, 1);
-    park(Bp);
-    read_b(fb0);
+    LC_PS(11);
     f32x4 S[8];
     {
       f32x4 e0, e1;
@@ -543,6 +623,7 @@ __global__ __launch_bounds__(512) void latent_layer_kernel(const LayerChainArgs 
       LC_S2(6, vrowV, vrowV, vrowV, vrowV)
 #undef LC_S2
     }
+    LC_PS(12);
     // ---- softmax over the row's 128 tokens: 32 values here, the other 96 in the lanes (g', j) (self_attention.hip)
     float mx = -__builtin_inff();
 #pragma unroll
@@ -565,7 +646,10 @@ __global__ __launch_bounds__(512) void latent_layer_kernel(const LayerChainArgs 
     {
       gf32 *st = (gf32 *)seg_p(sgi, offsetof(LSeg, stats));
       if (st && fg == 0) {                   // lane (0, j): query row j of the tile, head `wave`
-        st += ((long)(samp * 8 + wave) * a_L + member * CR + fi) * 2;
+        int fj = fi;
+        asm volatile("" : "+v"(fj));         // (keeps the lane's 64-bit address out of the prologue: hoisted there it was SPILLED, and its
+                                             // reload here -- a scratch load -- waited for the whole ring with vmcnt(0))
+        st += ((long)(samp * 8 + wave) * a_L + member * CR + fj) * 2;
         gst1(st, mx);
         gst1(st + 1, l);
       }
@@ -573,6 +657,7 @@ __global__ __launch_bounds__(512) void latent_layer_kernel(const LayerChainArgs 
     float4 P[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) P[t] = make_float4(S[t][0] * inv, S[t][1] * inv, S[t][2] * inv, S[t][3] * inv);
+    LC_PS(13);
     // ---- O = P V: per dim tile four blocks of 32 tokens; A = P[2 tc], P[2 tc + 1], B = the V^T block.  The requests of the last
     // five steps are the first weight blocks of the next segment.
     f32x4 O[4];
@@ -604,14 +689,29 @@ __global__ __launch_bounds__(512) void latent_layer_kernel(const LayerChainArgs 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = 4 * fg + r;
-        lds[Abig + (col >> 5) * ATILE + row * WK + ((((col & 31) >> 2) ^ (row & 7)) * 4) + (col & 3)] = O[d][r];
+        lds[Abig + (col >> 5) * ATILE + row * WK + ((((col & 31) >> 2) ^ (row & 7)) * 4) + (col & 3)] = lostw ? __builtin_nanf("") : O[d][r];
       }
     }
     __syncthreads();
   }
+#ifdef LCHAIN_PROFILE
+  if (blockIdx.x == 100 % gridDim.x && threadIdx.x == 0) {
+    g_lchain_prof[(g_lchain_seq & 7) * 64 + 63] = (unsigned long long)nseg;
+    __threadfence();
+    g_lchain_seq = g_lchain_seq + 1;
+  }
+#endif
 #undef LC_SB
 #undef LC_MFMA
 }
+
+#ifdef LCHAIN_PROFILE
+extern "C" __attribute__((visibility("default"))) int hn_debug_lchain_prof(unsigned long long *out, int *seq) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lchain_prof), sizeof(unsigned long long) * 512) != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(seq, HIP_SYMBOL(g_lchain_seq), sizeof(int)) != hipSuccess) return -1;
+  return 0;
+}
+#endif
 
 bool latent_layer_enabled() {
   static const bool off = getenv("HN_NO_SELF_IN_CHAIN") != nullptr;      // route switch (A/B): the per-block chains + the self core
