@@ -2025,8 +2025,8 @@ static int impl_fusion_forward(const hn_model *m, const hn_modality_input *in, i
     bool layer_ok = use_chain && latent_layer_enabled() && cluster_enabled(dev) && !staged && mask == nullptr && cp == nullptr &&
                     L == 128 && d == 128 && fp.lk != nullptr &&
                     (b * 8 > 128 || force_small) && (b + 7) / 8 * 64 + 1 <= CHAIN_XCHG_FLAGS && nsteps >= 2 && nsteps % 2 == 0 && al16(cur);
-    int max_seg = 0;
-    for (int k = 0, nseg = 0, nself = 0; layer_ok && k < nsteps; k += 2) {
+    int max_seg = 0, max_blk = 0;
+    for (int k = 0, nseg = 0, nself = 0, nblk = 0; layer_ok && k < nsteps; k += 2) {
       const Step &st = steps[k];
       layer_ok = is_attn(st) && !is_attn(steps[k + 1]);
       if (!layer_ok) break;
@@ -2039,11 +2039,13 @@ static int impl_fusion_forward(const hn_model *m, const hn_modality_input *in, i
       if (st.kind == STEP_SELF_ATTN) {
         const hn_attn_params *an = &m->self_attn[st.layer];
         if ((rc = add_next_proj(scratch, k)) != HN_OK) return rc;
+        nblk += latent_layer_segment_blocks(0, 1) - latent_layer_segment_blocks(0, 0) + latent_layer_segment_blocks(4, 0);      // projections + core on the segment in front, this one's out-projection
         layer_ok = nseg > 0 && nself < LAYER_KV_SLOTS && q_done && kv_done && an->heads == 8 && an->dim_head == 64 && scratch.nq == 512 && scratch.nkv == 1024 &&
                    an->w_out && an->b_out && chain_out_aligned(an) && al16(an->b_out) && (an->norm_w == nullptr) == (an->norm_b == nullptr);
         ++nself;
       } else if (is_tab(st)) {
         layer_ok = m->cross_attn[st.layer * M + st.m].query_dim == d;
+        nblk += latent_layer_segment_blocks(2, 0);
       } else {
         const hn_attn_params *an = &m->cross_attn[st.layer * M + st.m];
         AttnPlan pn;
@@ -2052,13 +2054,17 @@ static int impl_fusion_forward(const hn_model *m, const hn_modality_input *in, i
         layer_ok = qf_done && vmerge[st.m] && pn.rank_d && pn.ones && pn.dp == 16 && pn.nsplit <= CHAIN_MERGE_MAX_SPLITS && an->heads <= 8 &&
                    (pn.dh == 16 || pn.dh == 32 || pn.dh == 64) && pn.inner == 512 && an->heads * pn.dh == 512 && scratch.qf_heads == 8 &&
                    an->w_out && an->b_out && chain_out_aligned(an) && al16(an->b_out);
+        nblk += latent_layer_segment_blocks(0, 2) - latent_layer_segment_blocks(0, 0);      // the query fold closes the launch in front
+        if (nblk > max_blk) max_blk = nblk;
         nseg = 0; nself = 0;                 // (a launch boundary: the core runs between two layer chains)
+        nblk = latent_layer_segment_blocks(3, 0);
       }
       ++nseg;
       if (nseg > max_seg) max_seg = nseg;
+      if (nblk > max_blk) max_blk = nblk;
     }
     q_done = kv_done = qf_done = false;
-    if (layer_ok && max_seg <= LSEG_MAX) {
+    if (layer_ok && max_seg <= LSEG_MAX && max_blk + 6 <= LAYER_MAXBLK) {
       LayerChainArgs la;
       memset(&la, 0, sizeof(la));
       int nself = 0;

@@ -401,6 +401,7 @@ int launch_latent_chain(const ChainArgs &a, hipStream_t s);
 // [projections -> latent self-attention], the x tile in LDS throughout, the self-attention a stage family of the weight ring
 // ------------------------------------------------------------------------------------------------
 constexpr int LSEG_MAX = 8;
+constexpr int LAYER_MAXBLK = 1024;       // weight / K / V^T blocks of one launch (its LDS block table)
 struct LSeg {
   int head;                             // 0: x as it is; 2: x += y[sample]; 3: out-projection of the core's merged split partials (segment 0 only);
                                         // 4: out-projection of the self-attention output the previous segment (proj = 1) left in LDS
@@ -427,6 +428,7 @@ struct LayerChainArgs {
   LSeg seg[LSEG_MAX];
 };
 bool latent_layer_enabled();            // false: HN_NO_SELF_IN_CHAIN (route switch)
+int latent_layer_segment_blocks(int head, int proj);      // blocks a segment adds to its launch (<= LAYER_MAXBLK - 6 per launch)
 int launch_latent_layer(const LayerChainArgs &a, hipStream_t s);
 // backward of the latent chain (bchain.hip): projection backward of an attention block -> feed-forward block backward -> the
 // out-projection backward of the attention block in front of it, one launch; weight gradients by launch_gemm_tn_multi

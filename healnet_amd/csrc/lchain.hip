@@ -43,7 +43,7 @@ namespace {
 
 #include "chain_common.h"
 constexpr int PRM = 128 + 2 * CHID + 128 + 4 * 128 + 128;     // b_out | b1 | b2 | ff gamma, beta | projection gamma, beta | y row (head 2)
-constexpr int MAXBLK = 512;              // blocks of a launch (one table entry per thread)
+constexpr int MAXBLK = LAYER_MAXBLK;     // blocks of a launch (two table entries per thread)
 constexpr int STG = 8 * 256;             // per-wave 16 x 16 output staging tiles
 constexpr int LDS_FIXED = 8 * WSLOT + 16 * ATILE + 4 * ATILE + CR * XP + 2 * MAXBLK + STG;
 constexpr int NDUMMY = 0;                // (no filler entries: the ring runs from the Q chunks straight into the K blocks)
@@ -111,8 +111,8 @@ __global__ __launch_bounds__(512) void latent_layer_kernel(const LayerChainArgs 
   // ---- the block table: thread t describes block t of the launch.  Per segment: [OUT 16] [FF1 32] [FF2 16] then
   //   proj 1: [K|V chunks 8 x 4] [Q chunks 4 x 4] [NDUMMY x the last block] [K blocks 16] [V^T blocks 16]
   //   proj 2: [Q 4]
-  {
-    int sfound = 0, local = tid, found = 0;
+  for (int bi = tid; bi < MAXBLK; bi += 512) {
+    int sfound = 0, local = bi, found = 0;
     for (int s = 0; s < nseg; ++s) {
       const int hd = seg_i(s, offsetof(LSeg, head)), pj = seg_i(s, offsetof(LSeg, proj));
       const int n = ((hd == 3 || hd == 4) ? 16 : 0) + 48 + (pj == 1 ? 48 + NDUMMY + NATT : pj == 2 ? 4 : 0);
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(512) void latent_layer_kernel(const LayerChainArgs 
     }
     const unsigned long long addr = (unsigned long long)(W + rb * ldw + k * WK);
     desc = (addr & 0x0000ffffffffffffull) | ((unsigned long long)(ldw * 4) << 48);
-    *(__attribute__((address_space(3))) unsigned long long *)(lds + tbl + 2 * tid) = desc;
+    *(__attribute__((address_space(3))) unsigned long long *)(lds + tbl + 2 * bi) = desc;
   }
   const int r8 = lane >> 3, pos = lane & 7;
   const int wslot = Wr + wave * WSLOT + r8 * WK + ((pos ^ (r8 & 7)) * 4);
@@ -713,6 +713,10 @@ extern "C" __attribute__((visibility("default"))) int hn_debug_lchain_prof(unsig
 }
 #endif
 
+int latent_layer_segment_blocks(int head, int proj) {
+  return ((head == 3 || head == 4) ? 16 : 0) + 48 + (proj == 1 ? 48 + NDUMMY + NATT : proj == 2 ? 4 : 0);
+}
+
 bool latent_layer_enabled() {
   static const bool off = getenv("HN_NO_SELF_IN_CHAIN") != nullptr;      // route switch (A/B): the per-block chains + the self core
   return !off;
@@ -744,7 +748,7 @@ int launch_latent_layer(const LayerChainArgs &a, hipStream_t s) {
     if (g.x_out) HN_REQUIRE(al16(g.x_out), HN_E_SHAPE, "latent_layer: unaligned x_out");
     nblk += ((g.head == 3 || g.head == 4) ? 16 : 0) + 48 + (g.proj == 1 ? 48 + NDUMMY + NATT : g.proj == 2 ? 4 : 0);
   }
-  HN_REQUIRE(nblk + 6 <= MAXBLK, HN_E_SHAPE, "latent_layer: %d blocks", nblk);
+  HN_REQUIRE(nblk + 6 <= MAXBLK, HN_E_SHAPE, "latent_layer: %d blocks", nblk);      // (the caller plans with latent_layer_segment_blocks)
   if (a.seg[0].head == 3)
     HN_REQUIRE(a.Opart && a.Mpart && a.Lpart && a.wvf && a.heads >= 1 && a.heads <= 8 && (a.dh == 16 || a.dh == 32 || a.dh == 64) && a.heads * a.dh == 512 &&
                    a.nsplit >= 1 && a.nsplit <= CHAIN_MERGE_MAX_SPLITS && a.Lp >= 128 && al16(a.Opart) && al16(a.wvf),

@@ -88,7 +88,7 @@ def test_a_failing_training_record_at_n2_still_prints_the_headline_line(inject):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
-                          "--train-steps", "3", "--train-watchdog-s", "25"], cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+                          "--train-steps", "3", "--train-watchdog-s", "10"], cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
     assert len(lines) == 1, out.stdout

@@ -4,13 +4,23 @@ depth-8 four-modality schedule) are only reached there, so the small-size gradie
 
   cfg4  b=8, N=4096 patch bag   : logits + every parameter gradient vs oracle autograd        (healnet.py:190-250, main.py:464)
   cfg2  b=2, 224x224x3 image    : logits + every parameter gradient vs oracle autograd
-  cfg5  4 modalities, depth 8   : logits vs oracle (full-size patch bags; volume 4x224x224 at b=2, 12x224x224 at b=1)
-  cfg3  b=16 bf16 tensors + core: sample 0 vs the ORACLE (fp32, on the same bf16-rounded inputs) at 2e-2
+  cfg2  b=32 (the headline)     : all 32 logit rows, and the training step's gradients, vs the REFERENCE's own outputs
+  cfg5  4 modalities, depth 8   : logits vs the REFERENCE (full-size patch bags; volume 4x224x224 at b=2, 12x224x224 at b=1)
+  cfg3  b=16 bf16 tensors + core: sample 0 vs the REFERENCE (fp32, on the same bf16-rounded inputs) at 2e-2
+
+Round 6: the expectations of the four largest cases are committed fixtures generated in the build container from
+/root/reference itself (tools/gen_goldens_fullsize.py -> tests/golden/g10_*.npz) instead of oracle forwards / autograd passes re-run
+on the GPU box -- those were 230 s of the suite's 617 s, all of it host time -- which also pins the headline configuration directly to
+reference outputs rather than through the oracle.  One oracle comparison per configuration stays (cfg2 b = 2 and cfg4 gradients
+here, cfg5 below, cfg3 in tests/test_gpu_model.py) so that the oracle route remains exercised at these shapes.
 """
+import os
+
 import pytest
 import torch
 
-from conftest import assert_close, rel_err
+import fullsize_fixtures as F
+from conftest import GOLD, assert_close, rel_err
 from oracle import healnet_cpu as O
 
 pytestmark = pytest.mark.gpu
@@ -85,90 +95,77 @@ def test_cfg2_full_size_gradients_vs_oracle_autograd(hn):
     _grad_parity(hn, kw, ins, seed=42, what="cfg2_b2_224")
 
 
-def test_cfg2_b32_inference_forward_every_sample_vs_oracle(hn):
-    """The driver's metric exactly: the eval / no_grad forward (hn_fusion_forward: folded queries in the chains, the score-bound
-    core, the merge inside the chains) of the seed-0 default model on bench.py's own inputs (generator 1234, tab then img) at
-    b = 32 -- ALL 32 logit rows against the oracle (the inference forward at the headline batch had the oracle on a
-    2-sample slice only).  The oracle runs sample by sample (0.6 GB of scores per sample and layer); nothing couples samples."""
-    kw = dict(n_modalities=2, channel_dims=[2000, 3], num_spatial_axes=[1, 2], out_dims=4)
+def _golden(name):
+    import numpy as np
+    with np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False) as z:
+        return {k: (z[k] if z[k].dtype.kind in "US" else torch.from_numpy(np.asarray(z[k]))) for k in z.files}
+
+
+def test_cfg2_b32_inference_forward_every_sample_vs_reference(hn):
+    """The driver's metric exactly: the eval / no_grad forward (hn_fusion_forward: the layer chains with the latent self-attention
+    inside, folded queries, the score-bound core, the merge inside the chains) of the seed-0 default model on bench.py's own inputs
+    (generator 1234, tab then img) at b = 32 -- ALL 32 logit rows against what the REFERENCE produced on them
+    (tests/golden/g10_cfg2_b32_bench.npz, tools/gen_goldens_fullsize.py; until round 5 the oracle was re-run here, 20 s of host
+    time).  Both routes of the latent side are held to it: the second pass runs after cluster mode was switched off, which is the
+    per-block chains + the self-attention core."""
+    from healnet_amd import _capi
+    want = _golden("g10_cfg2_b32_bench")["logits"]
     torch.manual_seed(0)
-    model = hn.HealNet(**kw).eval()
-    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
-    gen = torch.Generator().manual_seed(1234)
-    tab = torch.rand(32, 1, 2000, generator=gen)
-    img = torch.rand(32, 224, 224, 3, generator=gen)
-    threads = torch.get_num_threads()
-    torch.set_num_threads(min(32, threads))
-    try:
-        with torch.no_grad():
-            want = torch.cat([O.fusion_forward(sd, O.FusionConfig(**kw), [tab[i:i + 1], img[i:i + 1]]) for i in range(32)])
-    finally:
-        torch.set_num_threads(threads)
-    model.to(DEV)
-    with torch.no_grad():
-        got = model([tab.to(DEV), img.to(DEV)])
-    assert got.shape == (32, 4) and torch.isfinite(got).all()
-    worst = max(rel_err(got[i].cpu(), want[i]) for i in range(32))
-    print(f"cfg2 b=32 inference forward: worst per-sample rel err vs oracle {worst:.2e}")
-    for i in range(32):
-        assert_close(got[i].cpu(), want[i], rel=TOL, what=f"cfg2_b32.inference[{i}]")
+    model = hn.HealNet(**F.CFG2).eval().to(DEV)
+    tab, img = F.bench_inputs(32)
+    for route in ("layer chains", "per-block chains"):
+        if route == "per-block chains":
+            _capi.cluster_config(0, enable=False)
+        try:
+            with torch.no_grad():
+                got = model([tab.to(DEV), img.to(DEV)])
+        finally:
+            _capi.cluster_config(0, enable=True)
+        assert got.shape == (32, 4) and torch.isfinite(got).all()
+        worst = max(rel_err(got[i].cpu(), want[i]) for i in range(32))
+        print(f"cfg2 b=32 inference forward ({route}): worst per-sample rel err vs the reference {worst:.2e}")
+        for i in range(32):
+            assert_close(got[i].cpu(), want[i], rel=TOL, what=f"cfg2_b32.inference[{i}] ({route})")
 
 
-def test_cfg2_b32_full_size_training_step_vs_oracle_autograd(hn):
+def test_cfg2_b32_full_size_training_step_vs_reference_gradients(hn):
     """The headline batch itself: cfg2 at b = 32 on the full 224x224x3 image -- the split geometry, the 256-workgroup chains
-    (one per row tile, no cluster), the batched weight-gradient launches over 4096 rows that only this size runs.  The oracle's
-    materialised scores are 0.6 GB per sample and layer, so its gradient is accumulated sample by sample (the model couples no
-    two samples: per-token LayerNorm, per-row softmax, per-sample mean)."""
-    kw = dict(n_modalities=2, channel_dims=[2000, 3], num_spatial_axes=[1, 2], out_dims=4)
-    gen = torch.Generator().manual_seed(4132)
-    b = 32
-    ins = [torch.rand(b, 1, 2000, generator=gen), torch.rand(b, 224, 224, 3, generator=gen)]
+    (one per row tile, no cluster), the batched weight-gradient launches over 4096 rows that only this size runs -- against the
+    REFERENCE's logits and gradients of sum(logits * dl), accumulated there sample by sample (tools/gen_goldens_fullsize.py) and
+    committed in compressed form (tests/fullsize_fixtures.py: norm, scale, a 128-bucket count sketch and 1024 exact elements per
+    parameter tensor).  Criteria as in _grad_parity, on what the fixture allows:
+      * sampled elements: every one within 5e-3 of the tensor's scale; those beyond 5e-4 stay isolated (<= 1e-4 of the sample,
+        at least 8 allowed in all);
+      * the sketch's estimate of |g - g_ref| / |g_ref| <= 3e-4 -- or <= 1e-3 for at most 6 tensors: ~25 M SELU-gate and ~6 M
+        LeakyReLU pre-activations per step make ONE kink flip against the reference the expected case (tools/diag_b32_grads.py:
+        exactly rank 1, one row of one dW1 plus its trace upstream), a dropped split or a mis-scaled partial is far beyond it."""
+    gold = _golden("g10_cfg2_b32_train")
+    ins, dl = F.cfg2_train_inputs(32)
     torch.manual_seed(43)
-    model = hn.HealNet(**kw).train()
-    sd = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
-    dl = torch.randn(b, 4, generator=gen)
-    logits = []
-    threads = torch.get_num_threads()
-    torch.set_num_threads(min(32, threads))                # (a 256-core host runs this small-GEMM mix far slower with every core)
-    try:
-        for i in range(b):
-            out = O.fusion_forward(sd, O.FusionConfig(**kw), [t[i:i + 1] for t in ins])
-            (out * dl[i:i + 1]).sum().backward()           # accumulates into sd[k].grad
-            logits.append(out.detach())
-    finally:
-        torch.set_num_threads(threads)
-    want = torch.cat(logits)
-    model.to(DEV)
+    model = hn.HealNet(**F.CFG2).train().to(DEV)
     got = model([t.to(DEV) for t in ins])
-    assert_close(got.detach().cpu(), want, rel=TOL, floor=0.0, abs_floor=1e-5, what="cfg2_b32.fwd_train")
+    assert_close(got.detach().cpu(), gold["logits"], rel=TOL, floor=0.0, abs_floor=1e-5, what="cfg2_b32.fwd_train")
     (got * dl.to(DEV)).sum().backward()
-    # Criteria as in _grad_parity, plus what 16x more rows bring: ~25 M SELU-gate and ~6 M LeakyReLU pre-activations per step, so ONE
-    # of them landing within fp32 rounding of the kink on the other side than the oracle's is the expected case, not the rare one.
-    # tools/diag_b32_grads.py (this input): fused and per-block GPU routes agree to 7e-6 (L2), the oracle in fp32 and in fp64 to
-    # 6.5e-6, and what separates the two pairs is EXACTLY rank 1 -- one row of one dW1 (128 elements, 4e-3 of the tensor's scale:
-    # one SELU-derivative flip) plus its trace in that block's b1 / LayerNorm gradients and in the rows of the upstream tensors.
-    # So a tensor beyond the 3e-4 L2 bound passes only if its error is such an isolated flip: >= 98 % of the error energy in the
-    # four leading singular directions (2-D), L2 <= 1e-3 (1-D) -- a dropped split or a mis-scaled partial is neither.
-    n_out, n, flips = 0, 0, []
+    keys = [str(k) for k in gold["keys"]]
+    assert keys == [k for k, _ in model.named_parameters()]
+    n_out, n_s, flips, worst = 0, 0, [], 0.0
     for k, p in model.named_parameters():
-        ref = sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])
-        g = p.grad.double().cpu()
-        d = g - ref.double()
-        scale = float(ref.abs().max().clamp_min(1e-30))
-        linf = float(d.abs().max()) / scale
-        l2 = float(d.norm() / ref.double().norm().clamp_min(1e-30))
-        assert linf <= 5e-3, f"cfg2_b32 grad[{k}]: max-norm {linf:.2e}, L2 {l2:.2e}"
+        g = p.grad.double().cpu().reshape(-1)
+        norm, scale = float(gold[f"{k}::norm"]), max(float(gold[f"{k}::scale"]), 1e-30)
+        d_sk = F.sketch(g, k) - gold[f"{k}::sketch"].double()
+        l2 = float(d_sk.pow(2).sum().sqrt()) / max(norm, 1e-30)
+        idx = F.sample_index(k, g.numel())
+        d = (g[idx] - gold[f"{k}::vals"].double()).abs()
+        assert float(d.max()) / scale <= 5e-3, f"cfg2_b32 grad[{k}]: sampled max-norm {float(d.max()) / scale:.2e}, sketch L2 {l2:.2e}"
         if l2 > 3e-4:
-            assert l2 <= 1e-3, f"cfg2_b32 grad[{k}]: L2 {l2:.2e}"
-            if d.dim() == 2:
-                sv = torch.linalg.svdvals(d)
-                lead = float((sv[:4] ** 2).sum() / (sv ** 2).sum())
-                assert lead >= 0.98, f"cfg2_b32 grad[{k}]: L2 {l2:.2e} and only {lead:.2f} of the error in four singular directions"
+            assert l2 <= 1e-3, f"cfg2_b32 grad[{k}]: sketch L2 {l2:.2e}"
             flips.append((k, l2))
-        n_out += int((d.abs() > 5e-4 * scale).sum())
-        n += p.numel()
+        worst = max(worst, l2)
+        n_out += int((d > 5e-4 * scale).sum())
+        n_s += idx.numel()
+    print(f"cfg2 b=32 training step: worst sketch L2 {worst:.2e}, {n_out} of {n_s} sampled elements beyond 5e-4 of their scale, flips {flips}")
     assert len(flips) <= 6, f"cfg2_b32: {len(flips)} tensors beyond the L2 bound: {flips}"
-    assert n_out <= max(64, int(1e-4 * n)), f"cfg2_b32: {n_out} of {n} gradient elements beyond 5e-4 of their tensor's scale"
+    assert n_out <= max(8, int(1e-4 * n_s)), f"cfg2_b32: {n_out} of {n_s} sampled gradient elements beyond 5e-4 of their tensor's scale"
 
 
 def _oracle_logits(model, kw, ins, **kwargs):
@@ -177,60 +174,63 @@ def _oracle_logits(model, kw, ins, **kwargs):
         return O.fusion_forward(sd, O.FusionConfig(**kw), [None if t is None else t.float().cpu() for t in ins], **kwargs)
 
 
-CFG5 = dict(n_modalities=4, channel_dims=[2000, 768, 768, 3], num_spatial_axes=[1, 1, 1, 3], out_dims=4, depth=8)
+CFG5 = F.CFG5
 
 
 @pytest.mark.parametrize("grad_mode", [False, True], ids=["inference", "taping"])
-def test_cfg5_shape_vs_oracle(hn, grad_mode):
-    """BASELINE configs[4]: tab + 2 full-size WSI patch bags (4096 x 768 each) + a volume, depth 8.  The volume is cut to
-    4 x 224 x 224 x 3 (N = 200 704) so that the oracle's materialised scores stay at 0.8 GB per block; b = 2."""
+def test_cfg5_shape_vs_reference(hn, grad_mode):
+    """BASELINE configs[4]: tab + 2 full-size WSI patch bags (4096 x 768 each) + a volume, depth 8; the volume cut to
+    4 x 224 x 224 x 3 (N = 200 704), b = 2 -- against the REFERENCE's logits on the same seeded model and inputs
+    (g10_cfg5_cut_b2: all modalities present / the second bag missing, whose iterations still run the latent self block,
+    Appendix B-1)."""
+    gold = _golden("g10_cfg5_cut_b2")
     torch.manual_seed(51)
     model = hn.HealNet(**CFG5).eval().to(DEV)
-    gen = torch.Generator().manual_seed(4105)
-    ins = [torch.rand(2, 1, 2000, generator=gen), torch.rand(2, 4096, 768, generator=gen),
-           torch.rand(2, 4096, 768, generator=gen), torch.rand(2, 4, 224, 224, 3, generator=gen)]
+    ins = F.cfg5_cut_inputs()
     with torch.set_grad_enabled(grad_mode):
         y = model([t.to(DEV) for t in ins])
-    want = _oracle_logits(model, CFG5, ins)
-    assert_close(y.detach().cpu(), want, rel=TOL, floor=0.0, abs_floor=1e-5, what="cfg5 logits (volume 4x224x224)")
-    # a missing second bag: its iterations still run the latent self block (Appendix B-1)
+    assert_close(y.detach().cpu(), gold["logits"], rel=TOL, floor=0.0, abs_floor=1e-5, what="cfg5 logits (volume 4x224x224)")
     with torch.set_grad_enabled(grad_mode):
         y_m = model([ins[0].to(DEV), ins[1].to(DEV), None, ins[3].to(DEV)])
-    want_m = _oracle_logits(model, CFG5, [ins[0], ins[1], None, ins[3]])
-    assert_close(y_m.detach().cpu(), want_m, rel=TOL, floor=0.0, abs_floor=1e-5, what="cfg5 logits, bag 2 missing")
+    assert_close(y_m.detach().cpu(), gold["logits_bag2_missing"], rel=TOL, floor=0.0, abs_floor=1e-5, what="cfg5 logits, bag 2 missing")
 
 
-def test_cfg5_full_size_one_sample_vs_oracle(hn):
-    """The same model on ONE sample at the config's full sizes (volume 12 x 224 x 224 x 3, N = 602 112)."""
+def test_cfg5_full_size_one_sample_vs_reference(hn):
+    """The same model on ONE sample at the config's full sizes (volume 12 x 224 x 224 x 3, N = 602 112): g10_cfg5_full_b1."""
+    gold = _golden("g10_cfg5_full_b1")
     torch.manual_seed(52)
     model = hn.HealNet(**CFG5).eval().to(DEV)
-    gen = torch.Generator().manual_seed(4106)
+    with torch.no_grad():
+        y = model([t.to(DEV) for t in F.cfg5_full_inputs()])
+    assert_close(y.cpu(), gold["logits"], rel=TOL, floor=0.0, abs_floor=1e-5, what="cfg5 logits (full size, b=1)")
+
+
+def test_cfg5_oracle_spot_check(hn):
+    """The oracle route at this config stays exercised: one sample, volume cut to 2 x 224 x 224 (0.4 GB of scores per block)."""
+    torch.manual_seed(53)
+    model = hn.HealNet(**CFG5).eval().to(DEV)
+    gen = torch.Generator().manual_seed(4107)
     ins = [torch.rand(1, 1, 2000, generator=gen), torch.rand(1, 4096, 768, generator=gen),
-           torch.rand(1, 4096, 768, generator=gen), torch.rand(1, 12, 224, 224, 3, generator=gen)]
+           torch.rand(1, 4096, 768, generator=gen), torch.rand(1, 2, 224, 224, 3, generator=gen)]
     with torch.no_grad():
         y = model([t.to(DEV) for t in ins])
-    want = _oracle_logits(model, CFG5, ins)
-    assert_close(y.cpu(), want, rel=TOL, floor=0.0, abs_floor=1e-5, what="cfg5 logits (full size, b=1)")
+    assert_close(y.cpu(), _oracle_logits(model, CFG5, ins), rel=TOL, floor=0.0, abs_floor=1e-5, what="cfg5 logits (volume 2x224x224, b=1) vs oracle")
 
 
-def test_cfg3_b16_bf16_vs_oracle(hn):
-    """BASELINE configs[2] (b = 16, bf16 tensors, bf16 MFMA core): sample 0 against the fp32 ORACLE on the same
-    bf16-rounded inputs, tolerance 2e-2 max-norm -- not against this build's own fp32 core."""
+def test_cfg3_b16_bf16_vs_reference(hn):
+    """BASELINE configs[2] (b = 16, bf16 tensors, bf16 MFMA core): sample 0 against the fp32 REFERENCE on the same
+    bf16-rounded inputs (g10_cfg3_b16_s0), tolerance 2e-2 max-norm -- not against this build's own fp32 core."""
+    want = _golden("g10_cfg3_b16_s0")["logits"]
     torch.manual_seed(0)
-    kw = dict(n_modalities=3, channel_dims=[2000, 3, 3], num_spatial_axes=[1, 2, 3], out_dims=4)
+    kw = F.CFG3
     low = hn.HealNet(**kw, core_precision="bf16").eval().to(DEV)
-    gen = torch.Generator().manual_seed(1234)
-    b = 16
-    tab = torch.rand(b, 1, 2000, generator=gen).to(torch.bfloat16)
-    img = torch.rand(b, 224, 224, 3, generator=gen).to(torch.bfloat16)
-    vol = torch.rand(b, 12, 224, 224, 3, generator=gen).to(torch.bfloat16)
+    tab, img, vol = F.cfg3_inputs(16)
     with torch.no_grad():
         y = low([tab.to(DEV), img.to(DEV), vol.to(DEV)])
-    want = _oracle_logits(low, kw, [tab[:1], img[:1], vol[:1]])
     assert rel_err(y[:1].cpu(), want) <= 2e-2, rel_err(y[:1].cpu(), want)
-    # the fp32 core on the same inputs must sit (much) closer to the oracle than the bf16 tolerance
+    # the fp32 core on the same inputs must sit (much) closer to the reference than the bf16 tolerance
     ref = hn.HealNet(**kw).eval().to(DEV)
     ref.load_state_dict(low.state_dict())
     with torch.no_grad():
         y32 = ref([tab[:1].to(DEV), img[:1].to(DEV), vol[:1].to(DEV)])
-    assert_close(y32.cpu(), want, rel=TOL, floor=0.0, abs_floor=1e-5, what="cfg3 fp32 core vs oracle (bf16 tensors)")
+    assert_close(y32.cpu(), want, rel=TOL, floor=0.0, abs_floor=1e-5, what="cfg3 fp32 core vs the reference (bf16 tensors)")
