@@ -207,16 +207,18 @@ class Attention(nn.Module):
             w_q=_ptr(self.to_q.weight), w_kv=_ptr(self.to_kv.weight),
             w_out=_ptr(self.to_out[0].weight), b_out=_ptr(self.to_out[0].bias))
 
-    def _check_mode(self) -> None:
-        if self.training and self.dropout_p > 0.0:
-            raise NotImplementedError("healnet_amd: the stand-alone Attention / FeedForward modules run without dropout; dropout "
-                                      "runs through HealNet's fused training path -- call .eval() here")
+    def _draw(self):
+        """nn.Dropout(dropout) on the probabilities (healnet.py:381, :421) of a stand-alone call in TRAINING mode: (p, [seed, offset,
+        stream]) for the kernels' counter-based generator (include/healnet_hip.h hn_rng) -- torch's seed, a per-module call counter
+        (fresh masks every call; the backward replays the forward's), stream 0.  ``_last_rng`` keeps the triple of the last call:
+        hn_dropout_mask rebuilds the mask from it (tests/test_gpu_dropout.py)."""
+        return _draw_rng(self, 0)
 
     def _run(self, x: torch.Tensor, context: Optional[torch.Tensor], mask: Optional[torch.Tensor],
              norm: Optional[nn.LayerNorm], norm_context: Optional[nn.LayerNorm], residual: bool) -> torch.Tensor:
         """torch.ops.healnet_hip.attention_fwd (hn_attn_fwd / hn_attn_fwd_train): differentiable w.r.t. x and the parameters
         (hn_attn_bwd); the context gets no gradient -- a context that requires grad is refused."""
-        self._check_mode()
+        drop_p, drop_rng = self._draw()
         if torch.is_grad_enabled() and context is not None and context.requires_grad:
             raise RuntimeError("healnet_amd: no gradient flows to the context of an Attention block (hn_attn_bwd; HEALNet's contexts "
                                "are encoded modality inputs) -- detach it")
@@ -241,7 +243,9 @@ class Attention(nn.Module):
         args = (opt(norm, "weight"), opt(norm, "bias"), opt(norm_context, "weight"), opt(norm_context, "bias"),
                 self.to_q.weight, self.to_kv.weight, self.to_out[0].weight, self.to_out[0].bias)
         train = torch.is_grad_enabled() and (x.requires_grad or any(t is not None and t.requires_grad for t in args))
-        out, stats, _ = _hip.attention_fwd(x, ctx_z, mask_u8, *args, self.heads, bool(residual), train)
+        # (dropout thins the probabilities in the training form of the entry point, which also keeps what the backward needs;
+        # a training-mode call under no_grad still drops, as nn.Dropout does)
+        out, stats, _ = _hip.attention_fwd(x, ctx_z, mask_u8, *args, self.heads, bool(residual), train or drop_p > 0.0, drop_p, drop_rng)
         xin = x.detach()
 
         def probs(reduced: bool = False) -> torch.Tensor:
@@ -288,15 +292,13 @@ class FeedForward(nn.Module):
 
     def _run(self, x: torch.Tensor, norm: Optional[nn.LayerNorm], residual: bool) -> torch.Tensor:
         """torch.ops.healnet_hip.feed_forward (hn_ff_fwd, autograd through hn_ff_bwd)."""
-        if self.training and self.dropout_p > 0.0:
-            raise NotImplementedError("healnet_amd: the stand-alone FeedForward module runs without dropout; dropout runs "
-                                      "through HealNet's fused training path -- call .eval() here")
+        drop_p, drop_rng = _draw_rng(self, 0)       # nn.Dropout(dropout) on the block output (healnet.py:347), training mode only
         _require_gpu(x, "x")
         if x.shape[-1] != self.dim:
             raise ValueError(f"last dim must be {self.dim}, got {tuple(x.shape)}")
         return _hip.feed_forward(x, norm.weight if norm is not None else None, norm.bias if norm is not None else None,
                                  self.net[0].weight, self.net[0].bias, self.net[2].weight, self.net[2].bias, not self.snn,
-                                 bool(residual))
+                                 bool(residual), drop_p, drop_rng)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return self._run(x, None, residual=False)
@@ -323,6 +325,19 @@ class PreNorm(nn.Module):
         raise TypeError(f"PreNorm cannot wrap {type(self.fn).__name__}")
 
 
+def _draw_rng(mod: nn.Module, stream: int, force: bool = False):
+    """(dropout rate, [seed, offset, stream]) of one stand-alone call of a module with a ``dropout_p``: the rate is 0 (and nothing is
+    drawn) outside training mode or without dropout."""
+    p = float(mod.dropout_p) if (mod.training or force) else 0.0
+    if p <= 0.0 and not force:
+        return 0.0, []
+    off = (mod.__dict__.get("_rng_offset", 0) + 1) & 0xFFFFFFFF
+    mod.__dict__["_rng_offset"] = off
+    rng = [_wrap64(torch.initial_seed()), off, int(stream)]
+    mod.__dict__["_last_rng"] = (rng[0], rng[1], rng[2])
+    return p, rng
+
+
 def _wrap64(seed: int) -> int:
     """torch.initial_seed() is an unsigned 64-bit value; int64 tensors carry it two's-complement."""
     seed &= 0xFFFFFFFFFFFFFFFF
@@ -337,11 +352,17 @@ def latent_block(self_attn: "PreNorm", self_ff: "PreNorm", x: torch.Tensor) -> t
     if not isinstance(att, Attention) or not isinstance(ff, FeedForward) or self_attn.norm_context is not None:
         raise TypeError("latent_block takes PreNorm(Attention without context) and PreNorm(FeedForward)")
     _require_gpu(x, "x")
-    if (att.training and att.dropout_p > 0.0) or (ff.training and ff.dropout_p > 0.0):
-        raise NotImplementedError("healnet_amd: latent_block runs without dropout; dropout runs through HealNet's fused training path")
-    return _hip.latent_block(x, self_attn.norm.weight, self_attn.norm.bias, att.to_q.weight, att.to_kv.weight, att.to_out[0].weight,
-                             att.to_out[0].bias, att.heads, self_ff.norm.weight, self_ff.norm.bias, ff.net[0].weight, ff.net[0].bias,
-                             ff.net[2].weight, ff.net[2].bias, not ff.snn)
+    args = (x, self_attn.norm.weight, self_attn.norm.bias, att.to_q.weight, att.to_kv.weight, att.to_out[0].weight, att.to_out[0].bias,
+            att.heads, self_ff.norm.weight, self_ff.norm.bias, ff.net[0].weight, ff.net[0].bias, ff.net[2].weight, ff.net[2].bias, not ff.snn)
+    pa = att.dropout_p if att.training else 0.0
+    pf = ff.dropout_p if ff.training else 0.0
+    if pa > 0.0 or pf > 0.0:
+        # one (seed, offset) for the block: the attention draws on stream 0, the feed-forward block on stream 1 (ops.py _LB_DROP);
+        # both modules remember their triple (hn_dropout_mask rebuilds the masks from it)
+        _, rng = _draw_rng(att, 0, force=True)
+        ff._last_rng = (rng[0], rng[1], 1)
+        return _hip.latent_block_fwd(*args, True, pa, pf, rng)[0]
+    return _hip.latent_block(*args)
 
 
 class _MeanPool(nn.Module):

@@ -51,18 +51,22 @@ _lib.define("attention_merge(Tensor x, Tensor o_parts, Tensor stats_parts, Tenso
 _ATTN_ARGS = ("Tensor x, Tensor? context, Tensor? mask, Tensor? norm_w, Tensor? norm_b, Tensor? ctx_gamma, Tensor? ctx_beta, "
               "Tensor w_q, Tensor w_kv, Tensor w_out, Tensor b_out, int heads, bool residual")
 _lib.define(f"attention({_ATTN_ARGS}) -> Tensor")
-_lib.define(f"attention_fwd({_ATTN_ARGS}, bool train) -> (Tensor, Tensor, Tensor)")
+# dropout / rng (trailing, defaulted): nn.Dropout of the block in TRAINING calls -- rng = [seed, offset, stream] of hn_rng; the
+# backward replays the forward's masks from the same triple (stand-alone modules: VERDICT r5 item 4)
+_DROP = "float dropout=0.0, int[] rng=[]"
+_lib.define(f"attention_fwd({_ATTN_ARGS}, bool train, {_DROP}) -> (Tensor, Tensor, Tensor)")
 _lib.define("attention_bwd(Tensor dy, Tensor x, Tensor out, Tensor? context, Tensor? mask, Tensor? norm_w, Tensor? norm_b, "
             "Tensor? ctx_gamma, Tensor? ctx_beta, Tensor w_q, Tensor w_kv, Tensor w_out, Tensor b_out, int heads, bool residual, "
-            "Tensor stats, Tensor saved) -> Tensor[]")
+            "Tensor stats, Tensor saved, " + _DROP + ") -> Tensor[]")
 _FF_ARGS = "Tensor x, Tensor? norm_w, Tensor? norm_b, Tensor w1, Tensor b1, Tensor w2, Tensor b2, bool gelu, bool residual"
-_lib.define(f"feed_forward({_FF_ARGS}) -> Tensor")
-_lib.define(f"feed_forward_bwd(Tensor dy, {_FF_ARGS}) -> Tensor[]")
+_lib.define(f"feed_forward({_FF_ARGS}, {_DROP}) -> Tensor")
+_lib.define(f"feed_forward_bwd(Tensor dy, {_FF_ARGS}, {_DROP}) -> Tensor[]")
 _LB_ARGS = ("Tensor x, Tensor? a_norm_w, Tensor? a_norm_b, Tensor w_q, Tensor w_kv, Tensor w_out, Tensor b_out, int heads, "
             "Tensor? f_norm_w, Tensor? f_norm_b, Tensor w1, Tensor b1, Tensor w2, Tensor b2, bool gelu")
 _lib.define(f"latent_block({_LB_ARGS}) -> Tensor")
-_lib.define(f"latent_block_fwd({_LB_ARGS}, bool train) -> (Tensor, Tensor, Tensor, Tensor)")
-_lib.define(f"latent_block_bwd(Tensor dy, Tensor x_mid, Tensor stats, Tensor saved, {_LB_ARGS}) -> Tensor[]")
+_LB_DROP = "float attn_dropout=0.0, float ff_dropout=0.0, int[] rng=[]"      # rng.stream: the attention block's, the feed-forward block takes stream + 1
+_lib.define(f"latent_block_fwd({_LB_ARGS}, bool train, {_LB_DROP}) -> (Tensor, Tensor, Tensor, Tensor)")
+_lib.define(f"latent_block_bwd(Tensor dy, Tensor x_mid, Tensor stats, Tensor saved, {_LB_ARGS}, {_LB_DROP}) -> Tensor[]")
 _lib.define("head(Tensor x, Tensor norm_w, Tensor norm_b, Tensor w, Tensor bias) -> Tensor")
 _lib.define("head_bwd(Tensor dlogits, Tensor x, Tensor norm_w, Tensor norm_b, Tensor w) -> Tensor[]")
 _lib.define("temperature_softmax(Tensor logits, float temperature) -> Tensor")
@@ -414,15 +418,28 @@ def _attn_params(x, context, norm_w, norm_b, ctx_gamma, ctx_beta, w_q, w_kv, w_o
     return p, (int(b), int(L), int(N), int(D), int(ld))
 
 
+def _set_drop(p, dropout, rng, stream_add=0):
+    """hn_attn_params / hn_ff_params .dropout + .rng from the ops' trailing arguments (rng = [seed, offset, stream])."""
+    if dropout and dropout > 0.0:
+        if len(rng) != 3:
+            raise ValueError("healnet_hip: dropout > 0 needs rng = [seed, offset, stream]")
+        p.dropout = float(dropout)
+        p.rng = _capi.Rng(seed=int(rng[0]) & 0xFFFFFFFFFFFFFFFF, offset=int(rng[1]) & 0xFFFFFFFF, stream=(int(rng[2]) + stream_add) & 0x7FFFFFFF,
+                          offset_dev=None)
+    return p
+
+
 def _mask_u8(mask, b):
     return None if mask is None else mask.reshape(b, -1).to(torch.uint8).contiguous()
 
 
-def _attention_fwd(x, context, mask, norm_w, norm_b, ctx_gamma, ctx_beta, w_q, w_kv, w_out, b_out, heads, residual, train):
+def _attention_fwd(x, context, mask, norm_w, norm_b, ctx_gamma, ctx_beta, w_q, w_kv, w_out, b_out, heads, residual, train, dropout=0.0, rng=()):
     lib = _capi.lib()
     x = _f32c(x)
     ctx = None if context is None else _f32c(context)
     p, (b, L, N, D, ld) = _attn_params(x, ctx, norm_w, norm_b, ctx_gamma, ctx_beta, w_q, w_kv, w_out, b_out, heads)
+    if train:
+        _set_drop(p, dropout, rng)
     m = _mask_u8(mask, b)
     has_ctx = int(ctx is not None)
     need = lib.hn_attn_workspace_bytes(C.byref(p), has_ctx, ld, b, L, N, D)
@@ -445,8 +462,10 @@ def _attention_fwd(x, context, mask, norm_w, norm_b, ctx_gamma, ctx_beta, w_q, w
 
 
 @torch.library.register_fake("healnet_hip::attention_fwd")
-def _(x, context, mask, norm_w, norm_b, ctx_gamma, ctx_beta, w_q, w_kv, w_out, b_out, heads, residual, train):
+def _(x, context, mask, norm_w, norm_b, ctx_gamma, ctx_beta, w_q, w_kv, w_out, b_out, heads, residual, train, dropout=0.0, rng=()):
     p, (b, L, N, D, ld) = _attn_params(x, context, norm_w, norm_b, ctx_gamma, ctx_beta, w_q, w_kv, w_out, b_out, heads, fake=True)
+    if train and dropout > 0.0:
+        p.dropout = float(dropout)
     n_saved = 0
     if train:
         n_saved = _capi.lib().hn_attn_saved_floats(C.byref(p), int(context is not None), ld, b, L, N, D, int(mask is not None))
@@ -592,11 +611,12 @@ def _opt_out(t: Optional[torch.Tensor], like: Optional[torch.Tensor]):
 
 
 def _attention_bwd(dy, x, out, context, mask, norm_w, norm_b, ctx_gamma, ctx_beta, w_q, w_kv, w_out, b_out, heads, residual,
-                   stats, saved):
+                   stats, saved, dropout=0.0, rng=()):
     lib = _capi.lib()
     x, dy, out = _f32c(x), _f32c(dy), _f32c(out)
     ctx = None if context is None else _f32c(context)
     p, (b, L, N, D, ld) = _attn_params(x, ctx, norm_w, norm_b, ctx_gamma, ctx_beta, w_q, w_kv, w_out, b_out, heads)
+    _set_drop(p, dropout, rng)
     m = _mask_u8(mask, b)
     has_ctx = int(ctx is not None)
     need = lib.hn_attn_bwd_workspace_bytes(C.byref(p), has_ctx, ld, b, L, N, D, int(m is not None))
@@ -616,15 +636,16 @@ def _attention_bwd(dy, x, out, context, mask, norm_w, norm_b, ctx_gamma, ctx_bet
 
 
 @torch.library.register_fake("healnet_hip::attention_bwd")
-def _(dy, x, out, context, mask, norm_w, norm_b, ctx_gamma, ctx_beta, w_q, w_kv, w_out, b_out, heads, residual, stats, saved):
+def _(dy, x, out, context, mask, norm_w, norm_b, ctx_gamma, ctx_beta, w_q, w_kv, w_out, b_out, heads, residual, stats, saved, dropout=0.0, rng=()):
     empty = x.new_empty((0,), dtype=torch.float32)
     return [torch.empty_like(x)] + [empty if t is None else torch.empty_like(t)
                                     for t in (norm_w, norm_b, ctx_gamma, ctx_beta, w_q, w_kv, w_out, b_out)]
 
 
 def _attn_setup(ctx, inputs, output):
-    (x, context, mask, norm_w, norm_b, ctx_gamma, ctx_beta, w_q, w_kv, w_out, b_out, heads, residual, train) = inputs
+    (x, context, mask, norm_w, norm_b, ctx_gamma, ctx_beta, w_q, w_kv, w_out, b_out, heads, residual, train, dropout, rng) = inputs
     out, stats, saved = output
+    ctx.dropout, ctx.rng = float(dropout), [int(v) for v in rng]
     if not train:
         raise RuntimeError("healnet_hip::attention_fwd was called with train=False on inputs that require grad")
     if context is not None and context.requires_grad:
@@ -641,10 +662,10 @@ def _attn_backward(ctx, dout, dstats, dsaved):
     it = iter(rest)
     context, mask, norm_w, norm_b, ctx_gamma, ctx_beta = [next(it) if have else None for have in ctx.opt]
     g = torch.ops.healnet_hip.attention_bwd(dout.contiguous(), x, out, context, mask, norm_w, norm_b, ctx_gamma, ctx_beta, w_q, w_kv,
-                                            w_out, b_out, ctx.heads, ctx.residual, stats, saved)
+                                            w_out, b_out, ctx.heads, ctx.residual, stats, saved, ctx.dropout, ctx.rng)
     opt = lambda t, have: t if have else None      # noqa: E731
     return (g[0], None, None, opt(g[1], ctx.opt[2]), opt(g[2], ctx.opt[3]), opt(g[3], ctx.opt[4]), opt(g[4], ctx.opt[5]),
-            g[5], g[6], g[7], g[8], None, None, None)
+            g[5], g[6], g[7], g[8], None, None, None, None, None)
 
 
 torch.library.register_autograd("healnet_hip::attention_fwd", _attn_backward, setup_context=_attn_setup)
@@ -667,10 +688,11 @@ def _ff_params(x, norm_w, norm_b, w1, b1, w2, b2, gelu):
                           w2=_ptr(w2), b2=_ptr(b2)), x.numel() // dim
 
 
-def _feed_forward(x, norm_w, norm_b, w1, b1, w2, b2, gelu, residual):
+def _feed_forward(x, norm_w, norm_b, w1, b1, w2, b2, gelu, residual, dropout=0.0, rng=()):
     lib = _capi.lib()
     x = _f32c(x)
     p, rows = _ff_params(x, norm_w, norm_b, w1, b1, w2, b2, gelu)
+    _set_drop(p, dropout, rng)
     ws = WS.get(x.device, lib.hn_ff_workspace_bytes(C.byref(p), rows))
     out = torch.empty_like(x)
     _capi.check(lib.hn_ff_fwd(C.byref(p), x.data_ptr(), out.data_ptr(), int(residual), rows, ws.data_ptr(), ws.numel(),
@@ -679,14 +701,15 @@ def _feed_forward(x, norm_w, norm_b, w1, b1, w2, b2, gelu, residual):
 
 
 @torch.library.register_fake("healnet_hip::feed_forward")
-def _(x, norm_w, norm_b, w1, b1, w2, b2, gelu, residual):
+def _(x, norm_w, norm_b, w1, b1, w2, b2, gelu, residual, dropout=0.0, rng=()):
     return x.new_empty(x.shape, dtype=torch.float32)
 
 
-def _feed_forward_bwd(dy, x, norm_w, norm_b, w1, b1, w2, b2, gelu, residual):
+def _feed_forward_bwd(dy, x, norm_w, norm_b, w1, b1, w2, b2, gelu, residual, dropout=0.0, rng=()):
     lib = _capi.lib()
     x, dy = _f32c(x), _f32c(dy)
     p, rows = _ff_params(x, norm_w, norm_b, w1, b1, w2, b2, gelu)
+    _set_drop(p, dropout, rng)
     ws = WS.get(x.device, lib.hn_ff_bwd_workspace_bytes(C.byref(p), rows))
     empty = torch.empty(0, dtype=torch.float32, device=x.device)
     dx = torch.empty_like(x)
@@ -699,22 +722,23 @@ def _feed_forward_bwd(dy, x, norm_w, norm_b, w1, b1, w2, b2, gelu, residual):
 
 
 @torch.library.register_fake("healnet_hip::feed_forward_bwd")
-def _(dy, x, norm_w, norm_b, w1, b1, w2, b2, gelu, residual):
+def _(dy, x, norm_w, norm_b, w1, b1, w2, b2, gelu, residual, dropout=0.0, rng=()):
     empty = x.new_empty((0,), dtype=torch.float32)
     return [torch.empty_like(x)] + [empty if t is None else torch.empty_like(t) for t in (norm_w, norm_b, w1, b1, w2, b2)]
 
 
 def _ff_setup(ctx, inputs, output):
-    x, norm_w, norm_b, w1, b1, w2, b2, gelu, residual = inputs
+    x, norm_w, norm_b, w1, b1, w2, b2, gelu, residual, dropout, rng = inputs
     ctx.gelu, ctx.residual, ctx.has_norm = gelu, residual, norm_w is not None
+    ctx.dropout, ctx.rng = float(dropout), [int(v) for v in rng]
     ctx.save_for_backward(x, w1, b1, w2, b2, *([norm_w, norm_b] if norm_w is not None else []))
 
 
 def _ff_backward(ctx, dout):
     x, w1, b1, w2, b2, *norm = ctx.saved_tensors
     norm_w, norm_b = norm if ctx.has_norm else (None, None)
-    g = torch.ops.healnet_hip.feed_forward_bwd(dout.contiguous(), x, norm_w, norm_b, w1, b1, w2, b2, ctx.gelu, ctx.residual)
-    return (g[0], g[1] if ctx.has_norm else None, g[2] if ctx.has_norm else None, g[3], g[4], g[5], g[6], None, None)
+    g = torch.ops.healnet_hip.feed_forward_bwd(dout.contiguous(), x, norm_w, norm_b, w1, b1, w2, b2, ctx.gelu, ctx.residual, ctx.dropout, ctx.rng)
+    return (g[0], g[1] if ctx.has_norm else None, g[2] if ctx.has_norm else None, g[3], g[4], g[5], g[6], None, None, None, None)
 
 
 torch.library.register_autograd("healnet_hip::feed_forward", _ff_backward, setup_context=_ff_setup)
@@ -733,10 +757,14 @@ def _lb_params(x, a_norm_w, a_norm_b, w_q, w_kv, w_out, b_out, heads, f_norm_w, 
     return ap, fp, int(b), int(L), int(d)
 
 
-def _latent_block_fwd(x, a_norm_w, a_norm_b, w_q, w_kv, w_out, b_out, heads, f_norm_w, f_norm_b, w1, b1, w2, b2, gelu, train):
+def _latent_block_fwd(x, a_norm_w, a_norm_b, w_q, w_kv, w_out, b_out, heads, f_norm_w, f_norm_b, w1, b1, w2, b2, gelu, train, attn_dropout=0.0,
+                      ff_dropout=0.0, rng=()):
     lib = _capi.lib()
     x = _f32c(x)
     ap, fp, b, L, d = _lb_params(x, a_norm_w, a_norm_b, w_q, w_kv, w_out, b_out, heads, f_norm_w, f_norm_b, w1, b1, w2, b2, gelu)
+    if train:
+        _set_drop(ap, attn_dropout, rng)
+        _set_drop(fp, ff_dropout, rng, 1)
     need = lib.hn_latent_block_workspace_bytes(C.byref(ap), C.byref(fp), b, L)
     if need == 0:
         _capi.check(-1, "hn_latent_block_workspace_bytes")
@@ -755,7 +783,7 @@ def _latent_block_fwd(x, a_norm_w, a_norm_b, w_q, w_kv, w_out, b_out, heads, f_n
 
 
 @torch.library.register_fake("healnet_hip::latent_block_fwd")
-def _(x, a_norm_w, a_norm_b, w_q, w_kv, w_out, b_out, heads, f_norm_w, f_norm_b, w1, b1, w2, b2, gelu, train):
+def _(x, a_norm_w, a_norm_b, w_q, w_kv, w_out, b_out, heads, f_norm_w, f_norm_b, w1, b1, w2, b2, gelu, train, attn_dropout=0.0, ff_dropout=0.0, rng=()):
     ap, fp, b, L, d = _lb_params(x, a_norm_w, a_norm_b, w_q, w_kv, w_out, b_out, heads, f_norm_w, f_norm_b, w1, b1, w2, b2, gelu, fake=True)
     n_saved = _capi.lib().hn_attn_saved_floats(C.byref(ap), 0, 0, b, L, L, d, 0) if train else 0
     e = x.new_empty
@@ -764,10 +792,12 @@ def _(x, a_norm_w, a_norm_b, w_q, w_kv, w_out, b_out, heads, f_norm_w, f_norm_b,
 
 
 def _latent_block_bwd(dy, x_mid, stats, saved, x, a_norm_w, a_norm_b, w_q, w_kv, w_out, b_out, heads, f_norm_w, f_norm_b, w1, b1, w2, b2,
-                      gelu):
+                      gelu, attn_dropout=0.0, ff_dropout=0.0, rng=()):
     lib = _capi.lib()
     x, dy = _f32c(x), _f32c(dy)
     ap, fp, b, L, d = _lb_params(x, a_norm_w, a_norm_b, w_q, w_kv, w_out, b_out, heads, f_norm_w, f_norm_b, w1, b1, w2, b2, gelu)
+    _set_drop(ap, attn_dropout, rng)
+    _set_drop(fp, ff_dropout, rng, 1)
     need = lib.hn_latent_block_bwd_workspace_bytes(C.byref(ap), C.byref(fp), b, L)
     if need == 0:
         _capi.check(-1, "hn_latent_block_bwd_workspace_bytes")
@@ -786,15 +816,17 @@ def _latent_block_bwd(dy, x_mid, stats, saved, x, a_norm_w, a_norm_b, w_q, w_kv,
 
 
 @torch.library.register_fake("healnet_hip::latent_block_bwd")
-def _(dy, x_mid, stats, saved, x, a_norm_w, a_norm_b, w_q, w_kv, w_out, b_out, heads, f_norm_w, f_norm_b, w1, b1, w2, b2, gelu):
+def _(dy, x_mid, stats, saved, x, a_norm_w, a_norm_b, w_q, w_kv, w_out, b_out, heads, f_norm_w, f_norm_b, w1, b1, w2, b2, gelu, attn_dropout=0.0,
+      ff_dropout=0.0, rng=()):
     empty = x.new_empty((0,), dtype=torch.float32)
     return [torch.empty_like(x)] + [empty if t is None else torch.empty_like(t)
                                     for t in (a_norm_w, a_norm_b, w_q, w_kv, w_out, b_out, f_norm_w, f_norm_b, w1, b1, w2, b2)]
 
 
 def _lb_setup(ctx, inputs, output):
-    (x, a_norm_w, a_norm_b, w_q, w_kv, w_out, b_out, heads, f_norm_w, f_norm_b, w1, b1, w2, b2, gelu, train) = inputs
+    (x, a_norm_w, a_norm_b, w_q, w_kv, w_out, b_out, heads, f_norm_w, f_norm_b, w1, b1, w2, b2, gelu, train, attn_dropout, ff_dropout, rng) = inputs
     out, x_mid, stats, saved = output
+    ctx.drop = (float(attn_dropout), float(ff_dropout), [int(v) for v in rng])
     if not train:
         raise RuntimeError("healnet_hip::latent_block_fwd was called with train=False on inputs that require grad")
     ctx.heads, ctx.gelu = heads, gelu
@@ -808,10 +840,10 @@ def _lb_backward(ctx, dout, dmid, dstats, dsaved):
     it = iter(rest)
     a_nw, a_nb, f_nw, f_nb = [next(it) if have else None for have in ctx.opt]
     g = torch.ops.healnet_hip.latent_block_bwd(dout.contiguous(), x_mid, stats, saved, x, a_nw, a_nb, w_q, w_kv, w_out, b_out, ctx.heads,
-                                               f_nw, f_nb, w1, b1, w2, b2, ctx.gelu)
+                                               f_nw, f_nb, w1, b1, w2, b2, ctx.gelu, *ctx.drop)
     o = ctx.opt
     return (g[0], g[1] if o[0] else None, g[2] if o[1] else None, g[3], g[4], g[5], g[6], None,
-            g[7] if o[2] else None, g[8] if o[3] else None, g[9], g[10], g[11], g[12], None, None)
+            g[7] if o[2] else None, g[8] if o[3] else None, g[9], g[10], g[11], g[12], None, None, None, None, None)
 
 
 torch.library.register_autograd("healnet_hip::latent_block_fwd", _lb_backward, setup_context=_lb_setup)

@@ -202,3 +202,119 @@ def test_general_dropout_core_route_still_matches(hn):
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_dropout.py"), "-q", "-x", "-m", "gpu",
                         "-k", "exported_masks"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+# ------------------------------------------------------------------------------------------------
+# stand-alone modules: Attention(query_dim, context_dim, heads, dim_head, dropout) / FeedForward(dim, dropout=)
+# are part of the boundary (healnet.py:369-381, :339-347); in training mode they drop like the reference's nn.Dropout
+# ------------------------------------------------------------------------------------------------
+def _mult(hn, mod, p, is_ff, rows, cols):
+    seed, offset, stream = mod._last_rng
+    return _mask(hn, p, seed, offset, stream, is_ff, rows, cols).float().cpu() / (1 - p)
+
+
+def _grads_close(named, cpu, what):
+    for k, v in cpu.items():
+        if v.grad is None:
+            continue
+        g = named[k].grad
+        assert g is not None, (what, k)
+        assert rel_err(g.cpu(), v.grad) <= 5e-4, (what, k, rel_err(g.cpu(), v.grad))
+
+
+@pytest.mark.parametrize("case", [
+    dict(qd=32, cd=21, heads=2, dh=16, L=16, N=37, b=3, p=0.25, norm_ctx=True),       # cross block, LayerNorm-ed context (rank-D binding refused: D > 15 -> explicit)
+    dict(qd=32, cd=13, heads=4, dh=16, L=16, N=50, b=2, p=0.3, norm_ctx=True),        # narrow context: the shared-context (rank-D) binding
+    dict(qd=48, cd=None, heads=3, dh=16, L=24, N=None, b=2, p=0.2, norm_ctx=False),   # self-attention
+])
+def test_standalone_attention_drops_with_the_exported_mask(hn, case):
+    c = case
+    torch.manual_seed(31)
+    blk = hn.PreNorm(c["qd"], hn.Attention(c["qd"], c["cd"], heads=c["heads"], dim_head=c["dh"], dropout=c["p"]),
+                     context_dim=c["cd"] if c["norm_ctx"] else None).train()
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in blk.state_dict().items()}
+    gen = torch.Generator().manual_seed(32)
+    x = torch.randn(c["b"], c["L"], c["qd"], generator=gen)
+    ctx = None if c["cd"] is None else torch.randn(c["b"], c["N"], c["cd"], generator=gen)
+    target = torch.randn(c["b"], c["L"], c["qd"], generator=gen)
+    blk.to(DEV)
+    xg = x.to(DEV).requires_grad_(True)
+    y = blk(xg, context=None if ctx is None else ctx.to(DEV))
+    ((y - target.to(DEV)) ** 2).sum().backward()
+    n = c["L"] if ctx is None else c["N"]
+    dm = _mult(hn, blk.fn, c["p"], False, c["b"] * c["heads"] * c["L"], n).reshape(c["b"] * c["heads"], c["L"], n)
+    xc = x.clone().requires_grad_(True)
+    xn = O.layer_norm(xc, sd["norm.weight"], sd["norm.bias"])
+    cn = None if ctx is None else (O.layer_norm(ctx, sd["norm_context.weight"], sd["norm_context.bias"]) if c["norm_ctx"] else ctx)
+    yc = O.attention(xn, cn, sd["fn.to_q.weight"], sd["fn.to_kv.weight"], sd["fn.to_out.0.weight"], sd["fn.to_out.0.bias"], c["heads"],
+                     drop_mult=dm)
+    assert_close(y.detach().cpu(), yc.detach(), rel=2e-4, what="stand-alone attention under dropout")
+    ((yc - target) ** 2).sum().backward()
+    assert rel_err(xg.grad.cpu(), xc.grad) <= 5e-4
+    _grads_close(dict(blk.named_parameters()), sd, "attention")
+    # the probabilities the module reports are the UN-thinned ones (healnet.py:420 stores attn before the dropout)
+    pw = blk.fn.attn_weights
+    assert float((pw.sum(-1) - 1).abs().max()) < 1e-5
+    # a second call draws a fresh mask; eval mode draws none
+    y2 = blk(xg.detach(), context=None if ctx is None else ctx.to(DEV))
+    assert not torch.equal(y2, y.detach())
+    blk.eval()
+    with torch.no_grad():
+        ye = blk(xg.detach(), context=None if ctx is None else ctx.to(DEV))
+        want = O.attention(xn, cn, sd["fn.to_q.weight"], sd["fn.to_kv.weight"], sd["fn.to_out.0.weight"], sd["fn.to_out.0.bias"], c["heads"])
+    assert_close(ye.cpu(), want.detach(), rel=2e-4, what="stand-alone attention, eval mode")
+
+
+@pytest.mark.parametrize("dim,snn,p", [(32, True, 0.3), (30, False, 0.15)])
+def test_standalone_feed_forward_drops_with_the_exported_mask(hn, dim, snn, p):
+    torch.manual_seed(41)
+    blk = hn.PreNorm(dim, hn.FeedForward(dim, dropout=p, snn=snn)).train()
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in blk.state_dict().items()}
+    gen = torch.Generator().manual_seed(42)
+    x = torch.randn(3, 10, dim, generator=gen)
+    target = torch.randn(3, 10, dim, generator=gen)
+    blk.to(DEV)
+    xg = x.to(DEV).requires_grad_(True)
+    y = blk(xg)
+    ((y - target.to(DEV)) ** 2).sum().backward()
+    dm = _mult(hn, blk.fn, p, True, 30, dim).reshape(3, 10, dim)
+    xc = x.clone().requires_grad_(True)
+    yc = O.feed_forward(O.layer_norm(xc, sd["norm.weight"], sd["norm.bias"]), sd["fn.net.0.weight"], sd["fn.net.0.bias"], sd["fn.net.2.weight"],
+                        sd["fn.net.2.bias"], snn=snn, drop_mult=dm)
+    assert_close(y.detach().cpu(), yc.detach(), rel=2e-4, what="stand-alone feed-forward under dropout")
+    ((yc - target) ** 2).sum().backward()
+    assert rel_err(xg.grad.cpu(), xc.grad) <= 5e-4
+    _grads_close(dict(blk.named_parameters()), sd, "feed_forward")
+    blk.eval()
+    with torch.no_grad():
+        ye = blk(xg.detach())
+    assert_close(ye.cpu(), O.feed_forward(O.layer_norm(x, sd["norm.weight"], sd["norm.bias"]), sd["fn.net.0.weight"], sd["fn.net.0.bias"],
+                                          sd["fn.net.2.weight"], sd["fn.net.2.bias"], snn=snn).detach(), rel=2e-4, what="feed-forward, eval mode")
+
+
+def test_latent_block_drops_with_the_exported_masks(hn):
+    d, heads, dh, b, L, pa, pf = 128, 8, 64, 2, 32, 0.2, 0.1
+    torch.manual_seed(51)
+    att = hn.PreNorm(d, hn.Attention(d, heads=heads, dim_head=dh, dropout=pa)).train()
+    ff = hn.PreNorm(d, hn.FeedForward(d, dropout=pf, snn=True)).train()
+    sa = {k: v.detach().clone().requires_grad_(True) for k, v in att.state_dict().items()}
+    sf = {k: v.detach().clone().requires_grad_(True) for k, v in ff.state_dict().items()}
+    gen = torch.Generator().manual_seed(52)
+    x = torch.randn(b, L, d, generator=gen)
+    target = torch.randn(b, L, d, generator=gen)
+    att.to(DEV), ff.to(DEV)
+    xg = x.to(DEV).requires_grad_(True)
+    y = hn.latent_block(att, ff, xg)
+    ((y - target.to(DEV)) ** 2).sum().backward()
+    dma = _mult(hn, att.fn, pa, False, b * heads * L, L).reshape(b * heads, L, L)
+    dmf = _mult(hn, ff.fn, pf, True, b * L, d).reshape(b, L, d)
+    xc = x.clone().requires_grad_(True)
+    x1 = O.attention(O.layer_norm(xc, sa["norm.weight"], sa["norm.bias"]), None, sa["fn.to_q.weight"], sa["fn.to_kv.weight"], sa["fn.to_out.0.weight"],
+                     sa["fn.to_out.0.bias"], heads, drop_mult=dma) + xc
+    yc = O.feed_forward(O.layer_norm(x1, sf["norm.weight"], sf["norm.bias"]), sf["fn.net.0.weight"], sf["fn.net.0.bias"], sf["fn.net.2.weight"],
+                        sf["fn.net.2.bias"], snn=True, drop_mult=dmf) + x1
+    assert_close(y.detach().cpu(), yc.detach(), rel=2e-4, what="latent block under dropout")
+    ((yc - target) ** 2).sum().backward()
+    assert rel_err(xg.grad.cpu(), xc.grad) <= 5e-4
+    _grads_close(dict(att.named_parameters()), sa, "latent block attention")
+    _grads_close(dict(ff.named_parameters()), sf, "latent block feed-forward")
