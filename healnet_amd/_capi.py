@@ -12,7 +12,7 @@ import sys
 from typing import Optional
 
 HN_MAX_AXES = 4
-HN_ABI_VERSION = 11
+HN_ABI_VERSION = 12
 HN_F32, HN_BF16, HN_U8 = 0, 1, 2
 HN_CORE_F32, HN_CORE_BF16, HN_CORE_BF16X3 = 0, 1, 2
 HN_E_SHAPE, HN_E_UNSUPPORTED, HN_E_WORKSPACE, HN_E_HIP, HN_E_NULL, HN_E_CORESIDENCY = -1, -2, -3, -4, -5, -6
@@ -93,7 +93,8 @@ class Profile(C.Structure):
 
 class KernelTimer(C.Structure):
     _fields_ = [("kernel", C.c_char_p), ("ev_start", C.POINTER(C.c_void_p)), ("ev_stop", C.POINTER(C.c_void_p)),
-                ("n_events", C.c_int), ("n_recorded", C.c_int)]
+                ("n_events", C.c_int), ("n_recorded", C.c_int),
+                ("stream", C.c_void_p)]       # ABI v12: only launches on this stream are bracketed (None: any stream)
 
 
 READY_FN = C.CFUNCTYPE(None, C.c_int, C.c_void_p)

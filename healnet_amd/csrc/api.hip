@@ -1,6 +1,7 @@
 // C-ABI entry points of libhealnet_hip.so and the host-side orchestration of the fusion forward
 // (the launch schedule that replaces HealNet.forward :190-250 of the reference).
 #include "common.h"
+#include <mutex>
 
 #include <math.h>
 #include <stdlib.h>
@@ -27,17 +28,31 @@ int fail(int code, const char *fmt, ...) {
   return code;
 }
 
-// process-wide on purpose: a training step launches its forward from the caller's thread and its backward from the autograd
-// engine's device thread, and one table has to see both.  Slots are claimed with an atomic increment.
-static hn_kernel_timer *volatile g_timers = nullptr;
-static volatile int g_ntimers = 0;
+// The one process-wide registration of this library (include/healnet_hip.h hn_set_kernel_timers): a training step launches its
+// forward from the caller's thread and its backward from the autograd engine's device thread, and one table has to see both, so
+// it cannot be thread-local.  What keeps it safe beside concurrent callers:
+//   * publication is a seqlock -- a launching thread reads (table, n) as a consistent pair or not at all, never a new table with
+//     an old count while another thread re-arms it;
+//   * an entry only ever brackets launches on ITS stream (hn_kernel_timer.stream; NULL = any stream): a second thread working on
+//     another stream is neither timed nor does it consume event pairs;
+//   * slots are claimed with an atomic increment.
+static hn_kernel_timer *g_timers = nullptr;
+static int g_ntimers = 0;
+static unsigned g_timer_seq = 0;          // even: stable; odd: being rewritten
 KernelTimerScope::KernelTimerScope(const char *kernel, hipStream_t stream) : stop(nullptr), s(stream) {
-  hn_kernel_timer *tab = g_timers;
-  const int n = g_ntimers;
+  hn_kernel_timer *tab;
+  int n;
+  for (;;) {
+    const unsigned s0 = __atomic_load_n(&g_timer_seq, __ATOMIC_ACQUIRE);
+    tab = __atomic_load_n(&g_timers, __ATOMIC_RELAXED);
+    n = __atomic_load_n(&g_ntimers, __ATOMIC_RELAXED);
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    if ((s0 & 1u) == 0 && __atomic_load_n(&g_timer_seq, __ATOMIC_RELAXED) == s0) break;
+  }
   if (tab == nullptr) return;
   for (int i = 0; i < n; ++i) {
     hn_kernel_timer &t = tab[i];
-    if (t.kernel && strcmp(t.kernel, kernel) == 0) {
+    if (t.kernel && strcmp(t.kernel, kernel) == 0 && (t.stream == nullptr || t.stream == (void *)stream)) {
       const int slot = __atomic_fetch_add(&t.n_recorded, 1, __ATOMIC_RELAXED);
       if (slot < t.n_events) {
         (void)hipEventRecord((hipEvent_t)t.ev_start[slot], stream);
@@ -56,7 +71,7 @@ static inline DropCfg drop_of(float p, const hn_rng &r, bool ff) {
 static bool chain_disabled() { static const bool off = getenv("HN_NO_CHAIN") != nullptr; return off; }
 static bool bchain_disabled() { static const bool off = getenv("HN_NO_BCHAIN") != nullptr; return off; }
 static bool qfold_chain_disabled() { static const bool off = getenv("HN_NO_QFOLD_CHAIN") != nullptr; return off; }
-static bool merge_chain_disabled() { static const bool off = getenv("HN_NO_MERGE_CHAIN") != nullptr; return off; }
+static bool merge_chain_disabled() { static const bool off = tuning_env("HN_NO_MERGE_CHAIN") != nullptr; return off; }
 // operands the latent chain reads with 16-byte loads: an unaligned one (a parameter that is a view at an odd float offset of a
 // user-made flat buffer, a tape / trace slot) sends the block down the per-block launches instead of failing the forward
 static inline bool al16(const void *p) { return ((uintptr_t)p & 15) == 0; }
@@ -221,7 +236,7 @@ static float *saved_kv(const AttnPlan &pl, bool has_ctx, bool masked, int b, int
 static int project_ctx_kv(const hn_attn_params *p, const AttnPlan &pl, const float *ctx, int ld_ctx, int b, float *kvbuf, float *wstage,
                           const uint16_t *ctx16, hipStream_t s) {
   const int kvpitch = 2 * p->heads * pl.dhp;
-  static const bool no_glds = getenv("HN_NO_GLDS_GEMM") != nullptr;      // development switch: gemm_big_kernel / gemm_tall_narrow
+  static const bool no_glds = tuning_env("HN_NO_GLDS_GEMM") != nullptr;      // development switch: gemm_big_kernel / gemm_tall_narrow
   // the LDS-DMA projection lays the padded head width out itself (pad columns = 0): no fill in front of it
   const bool kv_nt = !ctx16 && wstage && !no_glds &&
                      gemm_nt_eligible((long)b * pl.N, 2 * pl.inner, pl.D, ld_ctx, ctx, pl.dh, pl.dhp, kvpitch, kvbuf);
@@ -433,7 +448,7 @@ static int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_ou
 
   // ---- explicit binding of a large patch bag under core_precision = bf16 (inference): K / V projected on bf16 MFMA straight into
   // the bf16 images of the explicit bf16 core (heads of 64); otherwise the projection alone (fp32 rows, attn_prepare)
-  static const bool no_expl16 = getenv("HN_NO_BF16_EXPL_CORE") != nullptr;      // development switch
+  static const bool no_expl16 = tuning_env("HN_NO_BF16_EXPL_CORE") != nullptr;      // development switch
   if (pl.ctx16 && pl.wstage && ctx && !pl.rank_d && !dropping && !no_expl16 && pl.dh == 64 && pl.dhp == 64 && p->heads % 2 == 0 && !narrow_ln(p)) {
     GemmArgs gk = gemm_defaults();
     gk.A = ctx; gk.lda = ld_ctx; gk.M = b * pl.N; gk.K = pl.D;
@@ -1338,12 +1353,12 @@ static int plan_tape(const hn_model *m, const hn_modality_input *in, int b, int 
         const size_t rows = rows16((size_t)b * m->l_c);
         tp->q_off[k] = off; off += align_up(rows * (pl.rank_d ? pl.inner : pl.heads * pl.dhp), 64);
         if (!cross) { tp->kv_off[k] = off; off += align_up(rows * 2 * pl.heads * pl.dhp, 64); }
-        static const bool no_xhat_tape = getenv("HN_NO_XHAT_TAPE") != nullptr;
+        static const bool no_xhat_tape = tuning_env("HN_NO_XHAT_TAPE") != nullptr;
         if (ap->norm_w && ap->query_dim == m->l_d && !no_xhat_tape) { tp->xhat_off[k] = off; off += align_up(rows * m->l_d, 64); }
       }
     }
   }
-  static const bool no_z_tape = getenv("HN_NO_Z_TAPE") != nullptr;
+  static const bool no_z_tape = tuning_env("HN_NO_Z_TAPE") != nullptr;
   for (int i = 0; i < m->n_modalities; ++i) {
     tp->z_off[i] = kNoSlot;
     if (no_z_tape || !in[i].data || fp.N[i] <= 0) continue;
@@ -1504,9 +1519,12 @@ int hn_cluster_status(int device, int acknowledge, hn_cluster_info *info) { retu
 int hn_cluster_config(int device, int enable, int timeout_us) { return cluster_config(device, enable, timeout_us); }
 int hn_set_kernel_timers(hn_kernel_timer *timers, int n) {
   if (n < 0 || (n > 0 && timers == nullptr)) return fail(HN_E_SHAPE, "hn_set_kernel_timers: n=%d", n);
-  g_ntimers = 0;
-  g_timers = n > 0 ? timers : nullptr;
-  g_ntimers = n > 0 ? n : 0;
+  static std::mutex writers;                   // (two threads arming at once: one after the other)
+  std::lock_guard<std::mutex> lock(writers);
+  __atomic_fetch_add(&g_timer_seq, 1u, __ATOMIC_ACQ_REL);      // odd: readers retry
+  __atomic_store_n(&g_timers, n > 0 ? timers : (hn_kernel_timer *)nullptr, __ATOMIC_RELAXED);
+  __atomic_store_n(&g_ntimers, n > 0 ? n : 0, __ATOMIC_RELAXED);
+  __atomic_fetch_add(&g_timer_seq, 1u, __ATOMIC_RELEASE);      // even again
   return HN_OK;
 }
 #ifndef HN_BUILD_ID
@@ -1937,7 +1955,7 @@ static int impl_fusion_forward(const hn_model *m, const hn_modality_input *in, i
         vf.w_k[layer] = al.w_kv; vf.w_q[layer] = al.w_q;
       }
     }
-    static const bool no_bc_role = getenv("HN_NO_VFOLD_BROADCAST") != nullptr;      // route switch (A/B)
+    static const bool no_bc_role = tuning_env("HN_NO_VFOLD_BROADCAST") != nullptr;      // route switch (A/B)
     if (!broadcast_done && !no_bc_role && ((long)L * d) % 4 == 0 && al16(m->latents) && al16(cur)) {
       vf.bc_src = m->latents; vf.bc_dst = cur; vf.bc_per = (long)L * d; vf.bc_total = (long)L * d * b;
       vf.bc_zero = fp.flags; vf.bc_nzero = m->depth * M + CHAIN_XCHG_FLAGS;
@@ -2429,7 +2447,7 @@ static int impl_fusion_forward_train(const hn_model *m, const hn_modality_input 
       // the one-token shortcut (tabular / omic modality): its two skinny products run as before, the broadcast add of the block's
       // row, the feed-forward block and the next projections ride on ONE chain (head == 2) as in the inference forward
       // (round 4: add_row + FF1 + FF2 + LayerNorm + projection = 40 us of launches per layer at cfg4 b = 8 became a 22 us chain)
-      static const bool no_tab_chain = getenv("HN_NO_TAB_CHAIN") != nullptr;
+      static const bool no_tab_chain = tuning_env("HN_NO_TAB_CHAIN") != nullptr;
       fuse_tab = !fuse && !no_tab_chain && !staged && st.kind == STEP_CROSS_ATTN && fp.N[st.m] == 1 && mask == nullptr && !(aq.dropout > 0.0f) &&
                  fq.dim == d && fq.dropout >= 0.0f && fq.dropout < 1.0f && aq.query_dim == d && chain_ff_aligned(&fq) && al16(xin) &&
                  al16(xout) && al16(T + tp.x_off[k + 2]) && aq.w_out && aq.b_out;

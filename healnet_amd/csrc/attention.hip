@@ -438,7 +438,7 @@ static int nq_for(int dt) { return dt == 1 ? nq_dt1() : (dt == 2 ? 2 : (dt == 4 
 // from 12 splits or fewer, which the chain behind the block merges itself.  0 = keep the default.
 static int sb_env(const char *name) { const char *e = getenv(name); return e ? atoi(e) : 0; }
 int attn_core_nq_small_batch(int dp, int b, int h, int Lp) {
-  static const bool off = tuning_env("HN_CORE_NQ") != nullptr || getenv("HN_NO_SMALL_BATCH_GEOMETRY") != nullptr;
+  static const bool off = tuning_env("HN_CORE_NQ") != nullptr || tuning_env("HN_NO_SMALL_BATCH_GEOMETRY") != nullptr;
   static const int force_nq = sb_env("HN_SB_NQ");       // development knobs: fixed tiles per wave / split cap of the small-batch plan
   if (off || dp != 16) return 0;
   if (force_nq > 0) return force_nq;

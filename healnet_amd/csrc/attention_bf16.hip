@@ -388,7 +388,7 @@ int launch_attn_core_bf16(const AttnCoreBf16Args &a, hipStream_t s) {
   const long blocks = (long)a.nsplit * gy * a.b * a.h;
   HN_REQUIRE(blocks < (1L << 31), HN_E_UNSUPPORTED, "attn_core_bf16: grid too large");
   dim3 grid((unsigned)blocks), block(64 * wpb);
-  static const bool no_pipeline = getenv("HN_BF16_NO_PIPELINE") != nullptr;
+  static const bool no_pipeline = tuning_env("HN_BF16_NO_PIPELINE") != nullptr;
   AttnCoreBf16Args ap = a;
   ap.no_pipeline = no_pipeline ? 1 : 0;
 #define HN_CORE16(DT_, NS_) hipLaunchKernelGGL((attn_core_bf16_kernel<DT_, NQ, NS_>), grid, block, 0, s, ap, ngroups, gy, wpb)

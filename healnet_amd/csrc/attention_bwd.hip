@@ -666,7 +666,7 @@ __global__ __launch_bounds__(256) void attn_bwd_self_pair_kernel(AttnBwdArgs a, 
 
 // true: both products were launched (the caller still runs dq_reduce); false: not this shape, nothing launched
 bool launch_attn_bwd_self_pair(const AttnBwdArgs &a, int dh, int inner, hipStream_t s, int *rc_out) {
-  static const bool off = getenv("HN_NO_SELF_BWD_PAIR") != nullptr || getenv("HN_NO_DKV_LDS") != nullptr;
+  static const bool off = getenv("HN_NO_SELF_BWD_PAIR") != nullptr || tuning_env("HN_NO_DKV_LDS") != nullptr;
   *rc_out = HN_OK;
   auto al16p = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
   const int ntiles = ceil_div(a.N, 16);
@@ -697,7 +697,7 @@ int launch_attn_bwd_dkv(const AttnBwdArgs &a, int dh, int inner, hipStream_t s) 
   dim3 grid(ceil_div(ntiles, 4), a.b * a.h), block(256);
   HN_REQUIRE(grid.y <= 65535, HN_E_UNSUPPORTED, "attn_bwd_dkv: b*h too large");
   // query side in LDS: dp = 64, <= 128 query rows, no dropout, 16-byte aligned rows on both sides of the DMA and of the stores
-  static const bool no_lds = getenv("HN_NO_DKV_LDS") != nullptr;      // development switch: the register-only kernel
+  static const bool no_lds = tuning_env("HN_NO_DKV_LDS") != nullptr;      // development switch: the register-only kernel
   auto al16p = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
   if (!no_lds && a.dp == 64 && a.Lq <= 128 && a.drop.thr == 0 && dh % 4 == 0 && inner % 4 == 0 && a.ldq % 4 == 0 && a.lddo % 4 == 0 &&
       a.q_b % 4 == 0 && a.q_h % 4 == 0 && a.do_b % 4 == 0 && a.do_h % 4 == 0 && al16p(a.Q) && al16p(a.dO) && al16p(a.dKV) && a.N >= 64) {

@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_lds_kernel(AttnBwdArgs a, int
 }
 
 bool attn_bwd_dq_lds_eligible(const AttnBwdArgs &a) {
-  static const bool off = getenv("HN_NO_ATTN_LDS") != nullptr;
+  static const bool off = tuning_env("HN_NO_ATTN_LDS") != nullptr;
   auto al16 = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
   return !off && a.dp == 64 && a.Kp != a.Vp && a.drop.thr == 0 && a.mask == nullptr && a.qk_steps == 0 && a.N >= 256 && a.ldk % 4 == 0 &&
          a.ldv % 4 == 0 && a.k_b % 4 == 0 && a.k_h % 4 == 0 && a.v_b % 4 == 0 && a.v_h % 4 == 0 && a.ldq % 4 == 0 && a.lddo % 4 == 0 &&

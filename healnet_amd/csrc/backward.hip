@@ -576,7 +576,7 @@ static int launch_gemm_tn(const float *A, long lda, const float *B, long ldb, fl
   HN_REQUIRE(batch == 1 || colsum == nullptr, HN_E_UNSUPPORTED, "gemm_tn: the fused column sum is not batched");
   // long contraction, wide output (the patch-bag G = dKV^T z): the LDS-DMA kernel (gemm_nt.hip).  Every split-k scratch buffer holds
   // at least GEMM_EX_SPLITS * (M N + M) floats (reduce_scratch_floats)
-  static const bool no_glds = getenv("HN_NO_GLDS_GEMM") != nullptr;      // development switch: the round-3 kernels
+  static const bool no_glds = tuning_env("HN_NO_GLDS_GEMM") != nullptr;      // development switch: the round-3 kernels
   if (!no_glds && scratch && batch == 1 && gemm_tn_glds_eligible(A, lda, B, ldb, M, N, K)) {
     size_t cap = (size_t)GEMM_EX_SPLITS * ((size_t)M * N + M);
     if (cap < (size_t)TN_SCRATCH_MIN_FLOATS) cap = (size_t)TN_SCRATCH_MIN_FLOATS;
@@ -836,7 +836,7 @@ int launch_gemm_ex(const GemmExArgs &g, hipStream_t s, float *scratch) {
   HN_REQUIRE(g.A && g.B && g.C, HN_E_NULL, "gemm_ex: NULL operand");
   HN_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.batch > 0, HN_E_SHAPE, "gemm_ex: M=%d N=%d K=%d", g.M, g.N, g.K);
   static int no_tn = -1, no_nn = -1;      // development knobs (flakiness bisect)
-  if (no_tn < 0) { const char *e = getenv("HN_NO_TN"); no_tn = (e && e[0] == '1') ? 1 : 0; e = getenv("HN_NO_NN"); no_nn = (e && e[0] == '1') ? 1 : 0; }
+  if (no_tn < 0) { const char *e = getenv("HN_NO_TN"); no_tn = (e && e[0] == '1') ? 1 : 0; e = tuning_env("HN_NO_NN"); no_nn = (e && e[0] == '1') ? 1 : 0; }
   // TN form (both operands contraction-major, unit stride along their own row index): the MFMA-native kernel
   if (!no_tn && (g.batch == 1 || (!g.colsum && scratch)) && g.a_rs == 1 && g.b_rs == 1 && g.k_total == 0 &&
       (long)g.K * g.a_cs * 4 < (1L << 31) && (long)g.K * g.b_cs * 4 < (1L << 31))

@@ -867,7 +867,7 @@ int launch_latent_chain(const ChainArgs &a, hipStream_t s) {
     ClusterTicket t;
     cluster_before_launch(dev, s, &t);
     ac.status = t.status; ac.token = t.token; ac.wait_ticks = t.wait_ticks; ac.inject_loss = t.inject_loss;
-    static const bool split_order = getenv("HN_FORCE_CLUSTER_SPLIT_ORDER") != nullptr;      // route switch (A/B): the former grid order
+    static const bool split_order = tuning_env("HN_FORCE_CLUSTER_SPLIT_ORDER") != nullptr;      // route switch (A/B): the former grid order
     ac.split_order = split_order ? 1 : 0;
   }
   const bool ext = a.rows % CR != 0 || (a.dv > 0 && a.dv < CD) || a.ff_drop.thr != 0 || (a.o_cols > 0 && a.o_cols < a.inner_o) ||

@@ -858,7 +858,7 @@ int launch_gemm_skinny_multi(const GemmSkinnyMulti &g, hipStream_t s) {
              g.nz, g.M, g.N, g.K);
   HN_REQUIRE(((long)(g.M + 64) * g.lda) * 4 < (1L << 31) && ((long)(g.N + 64) * g.ldw) * 4 < (1L << 31), HN_E_UNSUPPORTED,
              "gemm_skinny_multi: an operand spans more than 2 GiB");
-  static const bool no_wide = getenv("HN_NO_SKINNY_WIDE") != nullptr;      // development switch: four weight rows per workgroup for every shape
+  static const bool no_wide = tuning_env("HN_NO_SKINNY_WIDE") != nullptr;      // development switch: four weight rows per workgroup for every shape
   if (g.M <= 8) hipLaunchKernelGGL(gemm_skinny_multi_kernel<8>, dim3(ceil_div(g.N, 4), 1, g.nz), dim3(256), 0, s, g);
   else if (g.K >= 1024 && g.N % 8 == 0 && !no_wide)
     hipLaunchKernelGGL((gemm_skinny_multi_kernel<16, 8>), dim3(g.N / 8, ceil_div(g.M, 16), g.nz), dim3(256), 0, s, g);
@@ -1019,7 +1019,7 @@ int launch_gemm(const GemmArgs &g_in, hipStream_t s) {
     return HN_OK;
   }
   // tall and narrow (one 16 .. 64-wide head over a patch bag): the register-streaming kernel
-  static const bool no_tall = getenv("HN_NO_TALL_NARROW") != nullptr;      // development switch
+  static const bool no_tall = tuning_env("HN_NO_TALL_NARROW") != nullptr;      // development switch
   if (!no_tall && !glu && g.batch == 1 && (g.pro == PRO_NONE || g.pro == PRO_AFFINE) && g.M >= 2048 && g.K >= 128 && g.N >= 16 && g.N <= 128 &&
       !g.bias && !g.R && g.act == ACT_NONE && g.lda % 4 == 0 && g.lda >= 4 && ((uintptr_t)g.A & 15) == 0 &&
       (g.pro == PRO_NONE || (((uintptr_t)g.gamma | (uintptr_t)g.beta) & 15) == 0)) {

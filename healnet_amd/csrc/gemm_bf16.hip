@@ -493,7 +493,7 @@ size_t gemm_bf16_stage_floats(int N, int K) { return (size_t)N * gemm_bf16_pitch
 
 // shape side of the eligibility (plan time: decides whether a modality keeps a bf16 image of its context rows)
 bool gemm_bf16_shape_ok(long M, int N, int K) {
-  static const bool off = getenv("HN_NO_BF16_PROJ") != nullptr;      // development switch: the fp32 projection under core_precision = bf16
+  static const bool off = tuning_env("HN_NO_BF16_PROJ") != nullptr;      // development switch: the fp32 projection under core_precision = bf16
   return !off && M >= 2048 && M < (1L << 31) && K >= 256 && N >= HNT && N % HNT == 0;
 }
 
@@ -546,7 +546,7 @@ int launch_gemm_bf16(const GemmArgs &g, const uint16_t *Ab, float *stage, hipStr
   a.ntm = (g.M + HM - 1) / HM; a.ntn = g.N / HNT;
   a.abl = 0;
 #ifdef HN_GEMM_BF16_BENCH
-  if (const char *e = getenv("HN_BF16_ABL")) a.abl = atoi(e);
+  if (const char *e = tuning_env("HN_BF16_ABL")) a.abl = atoi(e);
 #endif
   a.K16 = K16; a.V16 = V16; a.inner = g.N / 2; a.heads = g.N / 128; a.tokens = tokens; a.np = (tokens + 31) / 32 * 32;
   if (img && tokens % 32 != 0) {
@@ -564,7 +564,7 @@ int launch_gemm_bf16(const GemmArgs &g, const uint16_t *Ab, float *stage, hipStr
     HN_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     if (dev >= 0 && dev < 64) configured[dev] = true;
   }
-  static const bool no_glds = getenv("HN_NO_GLDS_GEMM") != nullptr;      // development switch: the register-staged kernel
+  static const bool no_glds = tuning_env("HN_NO_GLDS_GEMM") != nullptr;      // development switch: the register-staged kernel
   if (!no_glds && (long)g.M * Kp * 2 < (1L << 31)) {                     // (the DMA descriptors address a tile's rows with 32-bit offsets anyway;
     if (img) hipLaunchKernelGGL(gemm_bf16_glds_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, a);      //  the bound keeps row * pitch in 31 bits)
     else hipLaunchKernelGGL(gemm_bf16_glds_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, a);

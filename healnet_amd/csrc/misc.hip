@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void lds_poison_kernel(float *sink) {
 
 void debug_after_launch(hipStream_t s) {
   static int enabled = -1;
-  if (enabled < 0) { const char *e = getenv("HN_POISON_LDS"); enabled = (e && e[0] == '1') ? 1 : 0; }
+  if (enabled < 0) { const char *e = tuning_env("HN_POISON_LDS"); enabled = (e && e[0] == '1') ? 1 : 0; }
   if (enabled) hipLaunchKernelGGL(lds_poison_kernel, dim3(2048), dim3(256), 0, s, (float *)nullptr);
 }
 

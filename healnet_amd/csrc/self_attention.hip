@@ -144,7 +144,7 @@ __global__ __launch_bounds__(512) void self_core_lds_kernel(AttnCoreArgs a) {
 
 bool self_core_lds_eligible(const AttnCoreArgs &a) {
   static const bool force = getenv("HN_FORCE_SELF_LDS") != nullptr;
-  static const bool off = getenv("HN_NO_SELF_LDS") != nullptr;       // development switch: the split-KV core instead
+  static const bool off = tuning_env("HN_NO_SELF_LDS") != nullptr;       // development switch: the split-KV core instead
   // one workgroup per (sample, head): below ~3/4 of the CUs the split-KV core (one query tile per wave, spread over the chip)
   // wins -- cfg2 forward with / without: b = 8 1.232 / 1.216 ms, b = 32 2.966 / 2.974, b = 64 5.813 / 5.834, b = 128 11.48 / 11.51
   const bool enough = (long)a.b * a.h >= 192 || force;

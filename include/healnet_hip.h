@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HN_ABI_VERSION 11
+#define HN_ABI_VERSION 12
 #define HN_MAX_AXES 4
 
 typedef enum hn_status {
@@ -331,15 +331,20 @@ typedef struct hn_profile {
  * every launch of a kernel class named in it is bracketed by the next unused hipEvent pair of that entry, recorded on the launch
  * stream (n_recorded counts the launches seen, also beyond n_events).  Classes: "gemm_nt_glds" (patch-bag K/V projection),
  * "gemm_tn_glds" (patch-bag weight gradient G = dKV^T z).  The table and the event arrays belong to the caller and must stay valid
- * until hn_set_kernel_timers(NULL, 0) clears them.  PROCESS-WIDE (a training step's backward is launched from the autograd engine's
- * thread, not the caller's): a measurement aid for one step loop at a time, not a facility for concurrent callers.  bench.py's
- * train_step.roofline is read through it. */
+ * until hn_set_kernel_timers(NULL, 0) clears them.  This is the ONE process-wide registration of the library (a training step's
+ * backward is launched from the autograd engine's thread, not the caller's, so the table cannot be thread-local); it is safe beside
+ * concurrent callers: (table, n) is published as a consistent pair, an entry brackets launches on ITS stream only (`stream`; NULL =
+ * any stream), so threads working on other streams are neither timed nor consume event pairs, and slots are claimed atomically.
+ * Every other entry point of this header is re-entrant: no state outlives a call except this table and the per-device cluster
+ * status word below (created once per device under a lock, written by kernels only when a bounded wait expires).  bench.py's
+ * train_step.roofline is read through this hook.  (ABI v12: the `stream` field.) */
 typedef struct hn_kernel_timer {
   const char *kernel;
   void **ev_start;
   void **ev_stop;
   int n_events;
   int n_recorded;
+  void *stream;                   /* hipStream_t: only launches on this stream are bracketed; NULL: launches on any stream */
 } hn_kernel_timer;
 int hn_set_kernel_timers(hn_kernel_timer *timers, int n);
 

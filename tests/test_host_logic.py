@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     lib = _capi.lib()                      # raises if the .so is missing: build() must have run
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.hn_abi_version() == _capi.HN_ABI_VERSION == 11
+    assert lib.hn_abi_version() == _capi.HN_ABI_VERSION == 12
     assert lib.hn_context_pitch(13, 64) == 16 and lib.hn_context_pitch(18, 64) == 32
     assert lib.hn_context_pitch(773, 64) == 776 and lib.hn_context_pitch(2005, 64) == 2008
     assert lib.hn_context_pitch(20, 16) == 20          # rank-D path would not pay: dp 32 > dim_head 16
@@ -109,10 +109,14 @@ def test_cpu_tensors_are_rejected_loudly():
 
 
 def test_unsupported_modes_raise():
-    # the stand-alone modules are inference ops: dropout in training mode goes through HealNet's fused training path
+    # the stand-alone modules drop in training mode like the reference's nn.Dropout (round 6: the rate and a per-call (seed, offset,
+    # stream) triple go to the kernels; tests/test_gpu_dropout.py) -- on the CPU box: a triple is drawn in training mode only
+    from healnet_amd.healnet import _draw_rng
     att = Attention(8, 5, heads=2, dim_head=4, dropout=0.1).train()
-    with pytest.raises(NotImplementedError):
-        att(torch.rand(1, 3, 8), context=torch.rand(1, 4, 5))
+    p, rng = _draw_rng(att, 0)
+    assert p == pytest.approx(0.1) and len(rng) == 3 and rng[1] == 1 and att._last_rng == tuple(rng)
+    assert _draw_rng(att, 0)[1][1] == 2                       # a fresh offset (fresh masks) per call
+    assert _draw_rng(att.eval(), 0) == (0.0, [])
     m = HealNet(n_modalities=1, channel_dims=[4], num_spatial_axes=[1], out_dims=2, l_c=4, l_d=8, x_heads=1, l_heads=1,
                 cross_dim_head=4, latent_dim_head=4, attn_dropout=0.1)
     assert m.train()._dropout_active() and not m.eval()._dropout_active()
