@@ -77,6 +77,18 @@ def test_plain_gpus_n_command_launches_its_own_ranks():
     t = j["train_step"]
     assert t["world_size"] == 2 and t["global_batch"] == 16 and t["backend"] == "gloo"
     assert "ms_per_step_blocking_allreduce" in t and "allreduce_alone_ms" in t
+    # N > 1 dry run: the overlapped all-reduce released every bucket exactly once -- the float ranges add up to
+    # the flat gradient buffer (each parameter rounded up to 4 floats) -- the per-rank batch is the config's, the step really ran,
+    # and the records only rank 0 of a single-GPU run produces are absent (the driver's N = 2 / 4 / 8 lines stay short)
+    assert sum(t["allreduce_buckets_floats"]) == t["gradient_floats"] and len(t["allreduce_buckets_floats"]) >= 2
+    assert t["batch_per_gpu"] == 8 and t["steps"] == 3 and t["final_loss"] == t["final_loss"] and "error" not in t
+    assert abs(t["value"] - 16 * 1000.0 / t["ms_per_step"]) <= 1e-3 * t["value"]
+    for rank0_only in ("cpu_baseline", "configs", "staged_models", "patch_bag_precisions"):
+        assert rank0_only not in j, rank0_only
+    # data-parallel ranks run without cluster launches (healnet_amd.dist.keep_ranks_in_step: a lost exchange on one rank would
+    # poison every peer through the all-reduce): the step's cluster record says so, and nothing was lost or skipped
+    cl = t["cluster"]
+    assert not cl["enabled"] and cl["lost"] == 0 and cl["optimizer_steps_skipped"] == 0
 
 
 @pytest.mark.parametrize("inject", ["raise:1", "hang:1", "raise:0"])
