@@ -19,7 +19,7 @@ HN_E_SHAPE, HN_E_UNSUPPORTED, HN_E_WORKSPACE, HN_E_HIP, HN_E_NULL, HN_E_CORESIDE
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HN_LIB_PATH") or os.path.join(_HERE, "libhealnet_hip.so")   # HN_LIB_PATH: kernel experiments (tools/)
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["api.hip", "gemm.hip", "attention.hip", "attention_bf16.hip", "attention_bwd.hip", "encode.hip", "misc.hip",
+SOURCES = ["api_blocks.hip", "api_fusion.hip", "api_train.hip", "api_entry.hip", "gemm.hip", "attention.hip", "attention_bf16.hip", "attention_bwd.hip", "encode.hip", "misc.hip",
            "backward.hip", "train.hip", "chain.hip", "self_attention.hip", "bchain.hip", "gemm_bf16.hip", "gemm_nt.hip", "attention_lds.hip", "lchain.hip"]
 
 c_float_p = C.POINTER(C.c_float)
@@ -316,12 +316,12 @@ def _build_locked(force: bool, verbose: bool, want: str) -> str:
     jobs, objs = [], []
     for src in SOURCES:
         path, obj = os.path.join(CSRC, src), os.path.join(objdir, src + ".o")
-        # api.hip embeds the library-wide id, so it is rebuilt whenever anything changed
-        unit = _digest(hdrs + [path], flag_text + (want if src == "api.hip" else ""))
+        # api_blocks.hip embeds the library-wide id, so it is rebuilt whenever anything changed
+        unit = _digest(hdrs + [path], flag_text + (want if src == "api_blocks.hip" else ""))
         sha = obj + ".sha"
         fresh = not force and os.path.exists(obj) and os.path.exists(sha) and open(sha).read() == unit
         if not fresh:
-            jobs.append((path, obj, sha, unit, ["-DHN_BUILD_ID=\"%s\"" % want] if src == "api.hip" else []))
+            jobs.append((path, obj, sha, unit, ["-DHN_BUILD_ID=\"%s\"" % want] if src == "api_blocks.hip" else []))
         objs.append(obj)
 
     def compile_one(job):

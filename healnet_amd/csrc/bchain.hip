@@ -540,7 +540,7 @@ __global__ __launch_bounds__(512) void latent_bchain_kernel(const BChainArgs arg
   }
 }
 
-// (any row count: the callers allocate every (rows, .) operand for the count rounded up to 16, api.hip rows16)
+// (any row count: the callers allocate every (rows, .) operand for the count rounded up to 16, api_internal.h rows16)
 bool latent_bchain_supported(int rows, int d, int hidden) { return d == CD && hidden == CHID && rows > 0; }
 
 int launch_latent_bchain(const BChainArgs &a, hipStream_t s) {

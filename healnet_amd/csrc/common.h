@@ -28,7 +28,7 @@ static inline const char *tuning_env(const char *name) { return getenv(name); }
 static inline const char *tuning_env(const char *) { return nullptr; }
 #endif
 
-// hn_set_kernel_timers (api.hip): brackets the launches of a named kernel class with the caller's event pairs
+// hn_set_kernel_timers (api_blocks.hip): brackets the launches of a named kernel class with the caller's event pairs
 struct KernelTimerScope {
   hipEvent_t stop;
   hipStream_t s;
@@ -715,7 +715,7 @@ int launch_broadcast_rows(const float *src, float *dst, long n_per, int b, hipSt
 int launch_head(const float *x, int b, int L, int d, const float *nw, const float *nb, const float *w,
                 const float *bias, int out_dims, float *logits, hipStream_t s, int dv = 0);
 int launch_pad_rows(const float *src, int ld_src, float *dst, int ld_dst, long rows, int cols, hipStream_t s);
-// Staged models (api.hip): a table of 2-D pieces in ONE launch -- dst[r, c] (+)= r < rows_src && c < cols_src ? src[r, c] : 0 over
+// Staged models (api_entry.hip): a table of 2-D pieces in ONE launch -- dst[r, c] (+)= r < rows_src && c < cols_src ? src[r, c] : 0 over
 // the piece's (rows_dst, cols_dst) rectangle.  Weights into their zero-padded images, padded gradients back onto the real ones.
 struct StagePiece { const float *src; float *dst; int rows_src, cols_src, ld_src, rows_dst, cols_dst, ld_dst; };
 constexpr int STAGE_MAX = 84;

@@ -30,7 +30,7 @@ def _mask(hn, p, seed, offset, stream, is_ff, rows, cols):
 
 
 def _oracle_masks(hn, model, kw, b, n_tokens, seed, offset, present):
-    """multipliers per executed block, numbered like build_schedule (api.hip) / oracle.fusion_forward"""
+    """multipliers per executed block, numbered like build_schedule (api_train.hip) / oracle.fusion_forward"""
     M, L, d = kw["n_modalities"], kw["l_c"], kw["l_d"]
     pa, pf = kw.get("attn_dropout", 0.0), kw.get("ff_dropout", 0.0)
     drop, k = {}, 0

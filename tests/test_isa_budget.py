@@ -49,8 +49,8 @@ def meta():
 def test_no_kernel_keeps_its_fragment_arrays_in_scratch(meta):
     """A few spilled registers outside the loops are tolerated (the image core trades 11 for its fourth wave per SIMD); an ARRAY in
     scratch is hundreds of bytes per lane."""
-    for unit, table in meta.items():
-        assert table, unit
+    assert sum(len(t) for t in meta.values()) > 100
+    for unit, table in meta.items():              # (the api_*.hip units hold launch schedules: some define no kernel)
         for name, (scratch, vgprs, spilled) in table.items():
             assert scratch <= 128, f"{unit}: {name} uses {scratch} bytes of scratch per lane ({vgprs} VGPRs, {spilled} spilled)"
 
@@ -75,3 +75,13 @@ def test_chain_and_self_core_keep_two_waves_per_simd(meta):
             assert vgprs <= 160 and scratch == 0, (k, vgprs, scratch)
     for k, (scratch, vgprs, _) in meta["self_attention.hip"].items():
         assert vgprs <= 128 and scratch == 0, (k, vgprs, scratch)
+
+
+def test_layer_chain_holds_its_attention_phase_in_registers(meta):
+    """latent_layer_kernel (lchain.hip): 512-thread workgroups, two waves per SIMD = at most 256 VGPRs, and NOTHING in scratch -- a
+    spilled lane address reloaded inside the attention phase is a scratch load that waits for the whole weight ring with vmcnt(0)
+    (round 6: four spilled registers cost ~1 us per self-attention block until the hoisted addresses were pinned to their use)."""
+    hot = [v for k, v in meta["lchain.hip"].items() if "latent_layer_kernel" in k]
+    assert len(hot) == 1
+    scratch, vgprs, spilled = hot[0]
+    assert scratch == 0 and spilled == 0 and vgprs <= 256, hot[0]
