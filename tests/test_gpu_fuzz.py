@@ -72,3 +72,14 @@ def test_random_op_level_blocks():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.main(["--n", "100", "--seed", "0"]) == 0
+
+
+def test_random_modality_mixes_on_the_layer_chains(monkeypatch):
+    """tools/fuzz_layer_chain.py: default latent widths, random mixes / order / presence of one-token, image and patch-bag modalities,
+    batch sizes on both sides of the layer chains' size gate -- the host's all-or-nothing route plan (api_fusion.hip) and the
+    segment programs it builds (lchain.hip) against the oracle.  (The wide sweep: 100 cases in profiles/r06_fuzz_layer_chain.log.)"""
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_layer_chain.py")
+    spec = importlib.util.spec_from_file_location("fuzz_layer_chain", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main(["--n", "14", "--seed", "5"]) == 0
