@@ -1149,6 +1149,10 @@ class FusionTrainFn(torch.autograd.Function):
         ctx.meta = meta
         ctx.tensors, ctx.params = tensors, params           # (inputs and parameters are alive anyway; the tape is what this step owns)
         ctx.tape = tape
+        # what save_for_backward would have checked (not used: it costs the host time this route exists to avoid): an
+        # in-place update of a parameter between this forward and its backward -- opt.step() before a delayed backward -- must raise,
+        # not differentiate against the new weights
+        ctx.versions = [p._version for p in params]
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(tape, layout)
         return out, tape, layout
@@ -1160,6 +1164,14 @@ class FusionTrainFn(torch.autograd.Function):
         if dout is None:
             return (None,) * n
         params, tensors, tape = ctx.params, ctx.tensors, ctx.tape
+        if tape is None:
+            raise RuntimeError("healnet_amd: backward through the fused forward a second time (its tape was released after the first "
+                               "backward; run the forward again)")
+        for p, v in zip(params, ctx.versions):
+            if p._version != v:
+                raise RuntimeError("healnet_amd: a parameter of the model was modified in place between the forward and its backward "
+                                   f"(version {p._version}, expected {v}): the tape was recorded against the old weights")
+        ctx.tape = None                                     # the step's tape (up to ~450 MB) is not kept alive by a lingering grad_fn
         device = params[0].device
         with torch.cuda.device(device):
             if grad_buffer is not None:

@@ -134,8 +134,11 @@ class FlatParameters:
         fast = self.__dict__.get("_direct_fast")
         if fast is not None and len(params) == len(fast[0]) and fast[3] == self.grads.data_ptr():
             ok = True
-            for p, q, g in zip(params, fast[0], fast[1]):
-                if p is not q or (g is not None and (p.grad is not g or not p.requires_grad)):
+            for p, q, g, off in zip(params, fast[0], fast[1], fast[2]):
+                # identity of the parameter and of its gradient view, the view's address (p.grad.data = ... / set_() keep the object
+                # and move the storage: one integer compare), and requires_grad for EVERY entry -- a parameter cached as
+                # not trainable that has been switched on since must leave the fast path too
+                if p is not q or (g is None) != (not p.requires_grad) or (g is not None and (p.grad is not g or g.data_ptr() != fast[3] + 4 * off)):
                     ok = False
                     break
             if ok:
@@ -153,7 +156,10 @@ class FlatParameters:
                 out.append(-1)
                 continue
             g = p.grad
-            if not p.requires_grad or g is None or not g.is_contiguous() or g.data_ptr() != base + 4 * off:
+            if not p.requires_grad:               # a frozen parameter of the flat buffer: no gradient is written for it
+                out.append(-1)
+                continue
+            if g is None or not g.is_contiguous() or g.data_ptr() != base + 4 * off:
                 return None
             out.append(off)
         self._direct_fast = (list(params), [p.grad if o >= 0 else None for p, o in zip(params, out)], out, base)

@@ -164,3 +164,72 @@ def test_tuned_shapes_on_the_large_tile_routes_vs_oracle(hn, dh, l_d, l_c):
     for k, p in model.named_parameters():
         ref = sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])
         assert_close(p.grad.cpu(), ref, rel=2e-3, floor=1e-3, abs_floor=1e-5 * scale, what=f"tuned shape grad[{k}]")
+
+
+# ------------------------------------------------------------------------------------------------
+# advisor's round-5 findings
+# ------------------------------------------------------------------------------------------------
+def test_status_word_is_cleared_only_after_the_device_has_drained(hn):
+    """ADVICE r5 (chain.hip cluster_poll): an hn_l1_adam_step that was ENQUEUED before the host consumes a lost-exchange report
+    decides on the device, when it executes, whether to skip -- by reading the status word.  The consuming entry point must
+    therefore drain the device BEFORE it clears the word.  Deterministic replay of the window: a long kernel holds the stream, an
+    Adam step is enqueued behind it (its own poll sees a clean word), the report arrives (the host-mapped word is written from
+    the host, as a kernel would), and the next entry point polls: it has to block until the queued Adam has run -- and skipped --
+    before it returns HN_E_CORESIDENCY.  (Before the fix the word was zeroed at once and the queued step applied its update.)"""
+    import ctypes as C
+    import time
+    from healnet_amd import _capi
+    lib = _capi.lib()
+    torch.cuda.synchronize()
+    _capi.cluster_status(0, acknowledge=True)
+    info = _capi.ClusterInfo()
+    _capi.check(lib.hn_cluster_status(0, 0, C.byref(info)), "hn_cluster_status")
+    assert info.status_word, "the device's status word does not exist"
+    n = 4096
+    p = torch.randn(n, device=DEV)
+    g = torch.randn(n, device=DEV)
+    m1, m2 = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    p0 = p.clone()
+    ws = torch.empty(lib.hn_l1_adam_workspace_bytes(), dtype=torch.uint8, device=DEV)
+    s = torch.cuda.current_stream().cuda_stream
+    adam = lambda: lib.hn_l1_adam_step(p.data_ptr(), g.data_ptr(), m1.data_ptr(), m2.data_ptr(), n, 0.0, 1.0, 1e-2, 0.9, 0.999, 1e-8, 1, None,   # noqa: E731
+                                       ws.data_ptr(), ws.numel(), s)
+    try:
+        torch.cuda.synchronize()
+        torch.cuda._sleep(int(2.0e8))                          # ~0.1 s of device time in front of everything below
+        assert adam() == 0                                     # enqueued behind the sleep; its poll saw a clean word
+        info.status_word[0] = 77                               # the report arrives while the Adam step is still queued
+        t0 = time.time()
+        rc = adam()                                            # the next entry point: polls, must drain, then report
+        waited = time.time() - t0
+        assert rc == _capi.HN_E_CORESIDENCY, rc
+        assert waited > 0.02, f"the poll returned after {waited * 1e3:.1f} ms: it did not wait for the device"
+        torch.cuda.synchronize()
+        assert torch.equal(p, p0), "the queued optimizer step applied its update although the report was pending when it ran"
+        st = _capi.cluster_status(0)
+        assert not st["pending"] and not st["enabled"]
+    finally:
+        torch.cuda.synchronize()
+        _capi.cluster_status(0, acknowledge=True)
+        _capi.cluster_config(0, enable=True, timeout_us=0)
+
+
+def test_in_place_parameter_update_between_forward_and_backward_raises(hn):
+    """ADVICE r5 (ops.py FusionTrainFn): the eager training route keeps parameters as plain attributes; what save_for_backward's
+    version counters would have caught -- opt.step() before a delayed backward -- must still raise, and the tape of a finished
+    backward is released (a second backward through the same graph raises as autograd's own would)."""
+    torch.manual_seed(7)
+    kw = dict(n_modalities=2, channel_dims=[40, 3], num_spatial_axes=[1, 2], out_dims=3, depth=1, l_c=16, l_d=32, x_heads=2, l_heads=2,
+              cross_dim_head=16, latent_dim_head=16)
+    model = hn.HealNet(**kw).train().to(DEV)
+    ins = [torch.rand(2, 5, 40, device=DEV), torch.rand(2, 6, 7, 3, device=DEV)]
+    y = model(list(ins))
+    with torch.no_grad():
+        next(model.parameters()).add_(1.0)
+    with pytest.raises(RuntimeError, match="modified in place"):
+        y.sum().backward()
+    y = model(list(ins))
+    loss = y.sum()
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="second time"):
+        loss.backward()
