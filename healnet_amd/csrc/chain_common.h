@@ -95,7 +95,13 @@ __device__ __forceinline__ void lst4(lf32 *base, int off, const float4 &v) {
 // is 6, in an epilogue that runs once per 8 blocks on the VALU the MFMAs share.
 __device__ __forceinline__ float selu_f(float x) {
   const float alpha = 1.6732632423543772848170429916717f, scale = 1.0507009873554804934193349852946f;
+  // (v_exp_f32 on x * log2(e) directly: __expf wraps it in a denormal-range rescale -- v_cmp / v_cndmask / v_ldexp per element -- that
+  // only matters below e^-87, where e - 1 is -1 either way; the epilogue is VALU time the fp32 MFMAs of the chunk cannot overlap)
+#ifdef HN_SELU_EXPF      // (A/B of the epilogue: tools/lchain_profile.py with HN_PROF_EXTRA=-DHN_SELU_EXPF)
   const float e = __expf(fminf(x, 0.0f)) - 1.0f;
+#else
+  const float e = __builtin_amdgcn_exp2f(fminf(x, 0.0f) * 1.44269504088896340736f) - 1.0f;
+#endif
   return scale * (x > 0.0f ? x : alpha * e);
 }
 // sum over the 32 lanes that share a row of the x tile (one half of a wave), delivered to all of them: four DPP steps inside each

@@ -279,7 +279,7 @@ class GraphedStep:
     into a HIP graph per input signature and replayed with one launch (SURVEY.md 8 f; serves the loop body of
     healnet/main.py:425-467).
 
-    Why: the step of a patch-bag model is ~450 kernel launches behind two operator calls.  At BASELINE configs[3] the host needs
+    Why: the step of a patch-bag model is ~130 kernel launches behind two operator calls (450 before the chains and batched products of rounds 3-5).  At BASELINE configs[3] the host needs
     3.8-4.9 ms to enqueue what the GPU runs in 5.5 ms, so on a slow or busy host the step stretches to 6.2-6.8 ms; at the reference's
     tuned TCGA shapes (~90 launches of 5-50 us) the eager step is host-bound outright (driver box, round 4: +60 % for blca).  A
     replay costs ~0.06 ms of host time.

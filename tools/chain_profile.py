@@ -11,7 +11,8 @@ sys.path.insert(0, ROOT)
 lib = os.path.join(ROOT, "healnet_amd", "libhealnet_prof.so")
 if not os.path.exists(lib):
     src = os.path.join(ROOT, "healnet_amd", "csrc")
-    objs = [os.path.join(ROOT, "healnet_amd", "build", f) for f in os.listdir(os.path.join(ROOT, "healnet_amd", "build")) if f.endswith(".hip.o") and not f.startswith("chain")]
+    from healnet_amd import _capi as _c
+    objs = [os.path.join(ROOT, "healnet_amd", "build", src + ".o") for src in _c.SOURCES if src != "chain.hip"]      # (the product's own unit list: a stale object of a removed unit must not be linked)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-DCHAIN_PROFILE",
                            "-c", os.path.join(src, "chain.hip"), "-o", "/tmp/chain_prof.o"])
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["/tmp/chain_prof.o"])

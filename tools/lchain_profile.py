@@ -6,11 +6,13 @@ workgroup), runs cfg2 forwards through it and prints, per layer chain of the las
 import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-lib = os.path.join(ROOT, "healnet_amd", "libhealnet_prof_l.so")
+extra = os.environ.get("HN_PROF_EXTRA", "").split()      # extra hipcc flags for an A/B variant of lchain.hip (own library name)
+lib = os.path.join(ROOT, "healnet_amd", "libhealnet_prof_l%s.so" % ("_" + "".join(c for c in "".join(extra) if c.isalnum()) if extra else ""))
 src = os.path.join(ROOT, "healnet_amd", "csrc")
 if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(os.path.join(src, "lchain.hip")):
-    objs = [os.path.join(ROOT, "healnet_amd", "build", f) for f in os.listdir(os.path.join(ROOT, "healnet_amd", "build")) if f.endswith(".hip.o") and not f.startswith("lchain")]
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-DLCHAIN_PROFILE",
+    from healnet_amd import _capi as _c
+    objs = [os.path.join(ROOT, "healnet_amd", "build", src + ".o") for src in _c.SOURCES if src != "lchain.hip"]      # (the product's own unit list: a stale object of a removed unit must not be linked)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-DLCHAIN_PROFILE"] + extra + [
                            "-c", os.path.join(src, "lchain.hip"), "-o", "/tmp/lchain_prof.o"], stderr=subprocess.DEVNULL)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["/tmp/lchain_prof.o"])
 if len(sys.argv) > 1 and sys.argv[1] == "--build-only":
@@ -32,6 +34,13 @@ buf = (ctypes.c_ulonglong * 512)()
 seq = ctypes.c_int()
 assert L.hn_debug_lchain_prof(buf, ctypes.byref(seq)) == 0
 names = ["PV+O (prev)", "OUT", "LN", "FF1", "FF2", "x_out+LN'", "K|V (or qf)", "-", "drain+flag", "Q01", "wait", "Q23+qread", "S", "softmax"]
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(100):
+    m([tab, img])
+e1.record()
+torch.cuda.synchronize()
+print(f"{e0.elapsed_time(e1) / 100:.4f} ms per forward ({' '.join(extra) or 'product flags'})")
 print("launches so far", seq.value, "(4 per forward)")
 for k in range(4):
     s = (seq.value - 4 + k) & 7
