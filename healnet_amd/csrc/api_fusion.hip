@@ -98,7 +98,8 @@ int plan_fusion(const hn_model *m, const hn_modality_input *in, int b, void *ws,
     // so the inference forward evaluates all layers' vectors up front (weight-streaming GEMV shapes only, equal heads / dims)
     fp->tab_ahead[i] = false;
     fp->tabv[i] = fp->taby[i] = nullptr;
-    if (inference && n == 1 && m->depth <= HN_SKINNY_MAXZ && fp->D[i] >= 512 && b <= 512) {
+    // (the training forward does the same with V written straight into the tape: taby is carved for both, tabv for inference only)
+    if (n == 1 && m->depth <= HN_SKINNY_MAXZ && fp->D[i] >= 512 && b <= 512) {
       bool same = true;
       for (int layer = 1; layer < m->depth; ++layer) {
         const hn_attn_params &a0 = m->cross_attn[i], &al = m->cross_attn[layer * m->n_modalities + i];
@@ -108,7 +109,7 @@ int plan_fusion(const hn_model *m, const hn_modality_input *in, int b, void *ws,
       const int inner0 = ap->heads * ap->dim_head;
       if (same && inner0 >= 512) {
         fp->tab_ahead[i] = true;
-        fp->tabv[i] = ar.take<float>((size_t)m->depth * b * inner0);
+        if (inference) fp->tabv[i] = ar.take<float>((size_t)m->depth * b * inner0);
         fp->taby[i] = ar.take<float>((size_t)m->depth * b * ap->query_dim);
       }
     }

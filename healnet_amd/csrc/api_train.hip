@@ -325,6 +325,59 @@ int impl_fusion_forward_train(const hn_model *m, const hn_modality_input *in, in
     ca.xchg = fp.xchg; ca.xflags = fp.flags + m->depth * M; ca.seq = ++chain_seq;
     return launch_latent_chain(ca, s);
   };
+  // the one-token shortcut (tabular / omic modality) rides on a chain with head == 2 (below); whether the block at step k does
+  auto tab_fusable = [&](int k) -> bool {
+    static const bool no_tab_chain = tuning_env("HN_NO_TAB_CHAIN") != nullptr;
+    const Step &st = tp.steps[k];
+    if (!(use_chain && st.kind == STEP_CROSS_ATTN && k + 1 < tp.nsteps && !is_attn_t(tp.steps[k + 1]))) return false;
+    const Step &sf = tp.steps[k + 1];
+    const hn_ff_params &fq = sf.kind == STEP_CROSS_FF ? m->cross_ff[sf.layer * M + sf.m] : m->self_ff[sf.layer];
+    const hn_attn_params &aq = m->cross_attn[st.layer * M + st.m];
+    return !no_tab_chain && !staged && fp.N[st.m] == 1 && mask == nullptr && !(aq.dropout > 0.0f) && fq.dim == d && fq.dropout >= 0.0f &&
+           fq.dropout < 1.0f && aq.query_dim == d && chain_ff_aligned(&fq) && al16(T + tp.x_off[k]) && al16(T + tp.x_off[k + 1]) &&
+           al16(T + tp.x_off[k + 2]) && aq.w_out && aq.b_out;
+  };
+  // One-token modalities whose blocks ALL take that route: the block outputs y_l = LeakyReLU(W_out,l (W_v,l c_hat) + b_out,l) do not
+  // depend on the latent array, so all layers' value rows (straight into their tape slots) and outputs are two batched launches ahead
+  // of the layer loop, as in the inference forward (round 6: two skinny launches per layer until then, 6 x 5.6 us at cfg4)
+  const float *tab_y[16];
+  for (int i = 0; i < M; ++i) {
+    tab_y[i] = nullptr;
+    if (!in[i].data || !fp.tab_ahead[i] || !fp.taby[i] || mask != nullptr) continue;
+    const hn_attn_params &a0 = m->cross_attn[i];
+    const int inner = a0.heads * a0.dim_head;
+    int slot[HN_SKINNY_MAXZ], found = 0;
+    bool all = true;
+    for (int k = 0; k < tp.nsteps; ++k) {
+      const Step &st = tp.steps[k];
+      if (st.kind != STEP_CROSS_ATTN || st.m != i) continue;
+      all = all && tab_fusable(k) && st.layer < HN_SKINNY_MAXZ && tp.saved_off[k] != kNoSlot;
+      if (st.layer < HN_SKINNY_MAXZ) slot[st.layer] = k;
+      ++found;
+    }
+    if (!all || found != m->depth) continue;
+    GemmSkinnyMulti gv, gy;
+    memset(&gv, 0, sizeof(gv));
+    memset(&gy, 0, sizeof(gy));
+    gv.nz = gy.nz = m->depth;
+    gv.lda = fp.ldz[i]; gv.ldw = fp.D[i]; gv.ldc = inner; gv.M = b; gv.N = inner; gv.K = fp.D[i];
+    gv.pro = a0.ctx_gamma ? PRO_AFFINE : PRO_NONE; gv.act = ACT_NONE;
+    gy.lda = inner; gy.ldw = inner; gy.ldc = a0.query_dim; gy.M = b; gy.N = a0.query_dim; gy.K = inner;
+    gy.pro = PRO_NONE; gy.act = ACT_LEAKY;
+    bool ok = true;
+    for (int layer = 0; layer < m->depth; ++layer) {
+      const hn_attn_params &al = m->cross_attn[layer * M + i];
+      ok = ok && al.w_kv && al.w_out && !(al.dropout > 0.0f) && (al.ctx_gamma != nullptr) == (a0.ctx_gamma != nullptr);
+      gv.A[layer] = fp.z[i]; gv.W[layer] = al.w_kv + (long)inner * fp.D[i]; gv.gamma[layer] = al.ctx_gamma; gv.beta[layer] = al.ctx_beta;
+      gv.C[layer] = T + tp.saved_off[slot[layer]];                     // V of the block: what the backward reads
+      gy.A[layer] = gv.C[layer]; gy.W[layer] = al.w_out; gy.bias[layer] = al.b_out;
+      gy.C[layer] = fp.taby[i] + (size_t)layer * b * a0.query_dim;
+    }
+    if (!ok) continue;
+    if ((rc = launch_gemm_skinny_multi(gv, s)) != HN_OK) return rc;
+    if ((rc = launch_gemm_skinny_multi(gy, s)) != HN_OK) return rc;
+    tab_y[i] = fp.taby[i];
+  }
   if (staged && use_chain && tp.nsteps > 0 && is_attn_t(tp.steps[0])) {      // the first block's projections: a chain of their own
     ChainArgs ca;
     memset(&ca, 0, sizeof(ca));
@@ -370,10 +423,7 @@ int impl_fusion_forward_train(const hn_model *m, const hn_modality_input *in, in
       // the one-token shortcut (tabular / omic modality): its two skinny products run as before, the broadcast add of the block's
       // row, the feed-forward block and the next projections ride on ONE chain (head == 2) as in the inference forward
       // (round 4: add_row + FF1 + FF2 + LayerNorm + projection = 40 us of launches per layer at cfg4 b = 8 became a 22 us chain)
-      static const bool no_tab_chain = tuning_env("HN_NO_TAB_CHAIN") != nullptr;
-      fuse_tab = !fuse && !no_tab_chain && !staged && st.kind == STEP_CROSS_ATTN && fp.N[st.m] == 1 && mask == nullptr && !(aq.dropout > 0.0f) &&
-                 fq.dim == d && fq.dropout >= 0.0f && fq.dropout < 1.0f && aq.query_dim == d && chain_ff_aligned(&fq) && al16(xin) &&
-                 al16(xout) && al16(T + tp.x_off[k + 2]) && aq.w_out && aq.b_out;
+      fuse_tab = !fuse && tab_fusable(k);
       fuse = fuse || fuse_tab;
     }
     // LN(x) of the block's input for the backward's dW_q / dW_kv: the chain that projected for the block wrote it (q_done), else here
@@ -387,7 +437,9 @@ int impl_fusion_forward_train(const hn_model *m, const hn_modality_input *in, in
       ap.rng = rng;
       AttnExt ext = {fp.cq, fp.ckv, q_done, kv_done, true, nullptr, 0, false, false, nullptr, nullptr, nullptr, 0, 0, 0};
       tape_homes(k, &ext);
-      if (self)
+      if (fuse_tab && tab_y[st.m] != nullptr)                    // computed ahead of the loop (V is on the tape already)
+        ext.y_out = tab_y[st.m] + (size_t)st.layer * b * ap.query_dim;
+      else if (self)
         rc = attn_fwd_impl(&ap, xin, nullptr, 1, nullptr, 0, b, L, L, d, nullptr, T + tp.stats_off[k], fp.op_ws, fp.op_ws_bytes, s,
                            nullptr, nullptr, T + tp.saved_off[k], false, 0, nullptr, nullptr, &ext);
       else
@@ -507,9 +559,12 @@ int impl_fusion_backward(const hn_model *m, const hn_modality_input *in, int b, 
       return rc;
   }
   const float *xf = T + tp.x_off[tp.nsteps];
+  const bool use_bchain = cb.ok && fp.chain && !bchain_disabled() && !chain_disabled();
+  bool flags_cleared = false;                // the cluster flags of the backward chains (bchain.hip): cleared by the head's launch when there is one
   if (m->final_classifier_head && !return_embeddings) {
     if ((rc = launch_head_bwd(xf, b, L, d, m->head_norm_w, m->head_norm_b, m->head_w, m->out_dims, dout, dX, g->head_norm_w,
-                              g->head_norm_b, g->head_w, g->head_b, hs, s, m->l_d_valid)) != HN_OK) return rc;
+                              g->head_norm_b, g->head_w, g->head_b, hs, s, m->l_d_valid, use_bchain ? cb.xflags : nullptr, BCHAIN_XFLAGS)) != HN_OK) return rc;
+    flags_cleared = use_bchain;
   } else {
     { int rc_ = launch_copy(dX, dout, (long)(xn), s); if (rc_ != HN_OK) return rc_; }
   }
@@ -529,9 +584,8 @@ int impl_fusion_backward(const hn_model *m, const hn_modality_input *in, int b, 
   // backward of the attention block behind it (whose core backward has just run: `pend`) and the out-projection backward of the
   // attention block in front of it; the weight gradients of the chain follow in one batched launch + one reduce.
   const int rows = b * L;
-  const bool use_bchain = cb.ok && fp.chain && !bchain_disabled() && !chain_disabled();
   int bchain_seq = 0;
-  if (use_bchain && (rc = launch_fill((float *)cb.xflags, 0.0f, BCHAIN_XFLAGS, s)) != HN_OK) return rc;      // cluster flags (bchain.hip)
+  if (use_bchain && !flags_cleared && (rc = launch_fill((float *)cb.xflags, 0.0f, BCHAIN_XFLAGS, s)) != HN_OK) return rc;      // cluster flags (bchain.hip)
   // `durable`: dQ / dKV sit in a buffer set and LN(x) on the tape -- the products may wait for the batch's flush
   struct Pending { bool valid, durable; int layer; hn_attn_params ap; const hn_attn_grads *ag; const float *x_in, *dQ, *dKV, *xhat; } pend;
   memset(&pend, 0, sizeof(pend));

@@ -748,7 +748,8 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict_
 // ---- transposed-weight cache of one backward pass: hn_fusion_backward registers every weight its dX products will need, ONE
 // batched launch per 16 of them transposes them all up front, launch_gemm_nn then finds them here instead of running a
 // transpose launch in front of every product (48 per step at cfg2).  Thread-local, valid between begin and end only.
-constexpr int TC_MAX = 512, TC_BATCH = 16;
+constexpr int TC_MAX = 512, TC_BATCH = 64;      // (40 bytes per entry: 2.5 KB of kernel arguments; a depth-3 model registers 37 weights --
+                                                 // three launches of 5-10 us at 16 per batch, round 6: one)
 struct TransposeEntry { const float *src; long ld; int rows, cols; float *dst; };
 struct TransposeBatch { int n; TransposeEntry e[TC_BATCH]; };
 struct TransposeCache { int n; bool ready; TransposeEntry e[TC_MAX]; };
@@ -1533,9 +1534,30 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float *__restrict__
 
 size_t head_bwd_scratch_floats(int b, int d, int out_dims) { return (size_t)b * ((size_t)out_dims * d + 2 * d + out_dims); }
 
+struct HeadColsum { const float *X; long pitch; int rows; int begin[5]; float *dst[4]; int *zero; int nzero; };
+// out[seg][c - begin[seg]] += sum_r X[r, c]: the summation order of colsum_kernel with one row chunk (four strided partial sums, added
+// in wave order), so the results are the bits the four separate launches produced
+__global__ __launch_bounds__(256) void head_colsum_kernel(HeadColsum h) {
+  __shared__ float part[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+  float s = 0.0f;
+  if (c < h.begin[4])
+    for (long r = w; r < h.rows; r += 4) s += h.X[r * h.pitch + c];
+  part[w][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (w == 0 && c < h.begin[4]) {
+    const float v = 1.0f * (part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+    const int seg = c >= h.begin[3] ? 3 : c >= h.begin[2] ? 2 : c >= h.begin[1] ? 1 : 0;
+    float *dst = h.dst[seg];
+    if (dst) dst[c - h.begin[seg]] += v;
+  }
+  if (blockIdx.x == 0)
+    for (int i = threadIdx.x; i < h.nzero; i += blockDim.x) h.zero[i] = 0;
+}
+
 int launch_head_bwd(const float *x, int b, int L, int d, const float *nw, const float *nb, const float *w, int out_dims,
                     const float *dlogits, float *dx, float *dnw, float *dnb, float *dw, float *dbias, float *scratch,
-                    hipStream_t s, int dv) {
+                    hipStream_t s, int dv, int *zero, int nzero) {
   HN_REQUIRE(x && nw && nb && w && dlogits && dx && scratch, HN_E_NULL, "head_bwd: NULL pointer");
   HN_REQUIRE(dv >= 0 && dv <= d, HN_E_SHAPE, "head_bwd: valid=%d of d=%d", dv, d);
   if (dv == 0) dv = d;
@@ -1544,12 +1566,17 @@ int launch_head_bwd(const float *x, int b, int L, int d, const float *nw, const 
   HN_REQUIRE(lds <= 64 * 1024, HN_E_UNSUPPORTED, "head_bwd: l_d=%d too large", d);
   hipLaunchKernelGGL(head_bwd_kernel, dim3(b), dim3(256), lds, s, x, L, d, nw, nb, w, out_dims, dlogits, dx, scratch, dv);
   HN_LAUNCH_CHECK("head_bwd");
-  const long pitch = (long)out_dims * d + 2 * d + out_dims;
-  int rc;
-  if (dw && (rc = launch_colsum(scratch, pitch, b, out_dims * d, 1.0f, dw, 1, s)) != HN_OK) return rc;
-  if (dnw && (rc = launch_colsum(scratch + (long)out_dims * d, pitch, b, d, 1.0f, dnw, 1, s)) != HN_OK) return rc;
-  if (dnb && (rc = launch_colsum(scratch + (long)out_dims * d + d, pitch, b, d, 1.0f, dnb, 1, s)) != HN_OK) return rc;
-  if (dbias && (rc = launch_colsum(scratch + (long)out_dims * d + 2 * d, pitch, b, out_dims, 1.0f, dbias, 1, s)) != HN_OK) return rc;
+  // the four parameter gradients are column sums over the b rows of `scratch`, in adjacent column ranges: ONE launch (four colsum
+  // launches at the ~4.6 us floor until round 6), which also clears the cluster flags of the backward chains (`zero`)
+  HeadColsum hc;
+  const int widths[4] = {out_dims * d, d, d, out_dims};
+  float *dsts[4] = {dw, dnw, dnb, dbias};
+  int off = 0;
+  for (int i = 0; i < 4; ++i) { hc.begin[i] = off; hc.dst[i] = dsts[i]; off += widths[i]; }
+  hc.begin[4] = off;
+  hc.X = scratch; hc.pitch = (long)out_dims * d + 2 * d + out_dims; hc.rows = b; hc.zero = zero; hc.nzero = zero ? nzero : 0;
+  hipLaunchKernelGGL(head_colsum_kernel, dim3(ceil_div(off, 64)), dim3(256), 0, s, hc);
+  HN_LAUNCH_CHECK("head_colsum");
   return HN_OK;
 }
 

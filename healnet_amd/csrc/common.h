@@ -659,7 +659,7 @@ int launch_add_into(const float *src, float *dst, long n, int accumulate, hipStr
 size_t head_bwd_scratch_floats(int b, int d, int out_dims);
 int launch_head_bwd(const float *x, int b, int L, int d, const float *nw, const float *nb, const float *w, int out_dims,
                     const float *dlogits, float *dx, float *dnw, float *dnb, float *dw, float *dbias, float *scratch,
-                    hipStream_t s, int dv = 0);
+                    hipStream_t s, int dv = 0, int *zero = nullptr, int nzero = 0);      // zero: nzero ints cleared on the way (the backward chains' cluster flags)
 
 // ------------------------------------------------------------------------------------------------
 // attention backward (attention_bwd.hip)

@@ -70,10 +70,13 @@ class _SurvNLL(torch.autograd.Function):
                                     rk.data_ptr(), _stream(dev)), "hn_surv_nll")
         ctx.save_for_backward(dl)
         ctx.mark_non_differentiable(hz, sv, rk)
+        ctx.set_materialize_grads(False)      # (otherwise autograd fills a zero gradient for each of hz / sv / rk: three launches per step)
         return loss, hz, sv, rk
 
     @staticmethod
     def backward(ctx, dloss, *_):
+        if dloss is None:
+            return None, None, None, None, None, None
         (dl,) = ctx.saved_tensors
         return dl * dloss, None, None, None, None, None
 
