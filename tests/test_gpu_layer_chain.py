@@ -37,6 +37,8 @@ CASES = {
                            [(28, 28, 3), (1, 2000)], 24, True),
     "missing_tab_b18": (dict(n_modalities=3, channel_dims=[2000, 600, 3], num_spatial_axes=[1, 1, 2], out_dims=4, depth=2),
                         [(1, 2000), None, (32, 24, 3)], 18, True),
+    "no_head_b19": (dict(n_modalities=2, channel_dims=[2000, 3], num_spatial_axes=[1, 2], out_dims=4, depth=2, final_classifier_head=False),
+                    [(1, 2000), (16, 24, 3)], 19, True),
     "forced_small_b3": (dict(n_modalities=2, channel_dims=[2000, 3], num_spatial_axes=[1, 2], out_dims=4, depth=2), [(1, 2000), (20, 20, 3)], 3, True),
 }
 
