@@ -197,11 +197,38 @@ int impl_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, c
   const size_t xbytes = (size_t)b * L * d * sizeof(float);
   if (prof) prof->n_recorded = 0;
 
+  // The prelude as ONE launch (encode.hip prelude_kernel): the one-token modality's encode + the vfold roles of the first image
+  // modality + that image's encode are mutually independent; as three launches in a row they were 38 us in front of the skinny
+  // products that only need the first (round 6).  Candidates: fp32 inputs, no context split, the static RGB-image encode.
+  int pre_tab = -1, pre_img = -1;
+  EncodeCall pre_tc, pre_ic;
+  {
+    static const bool no_prelude = tuning_env("HN_NO_PRELUDE_MERGE") != nullptr;      // development switch (A/B)
+    auto call_of = [&](int i) {
+      EncodeCall c;
+      c.data = in[i].data; c.dtype = in[i].dtype; c.b = b; c.n_axes = m->num_spatial_axes[i]; c.spatial = in[i].spatial; c.C = m->channel_dims[i];
+      c.F = m->num_freq_bands; c.max_freq = m->max_freq; c.fourier = m->fourier_encode_data; c.normalize = 1; c.eps = 1e-5f;
+      c.out = fp.z[i]; c.ld_out = fp.ldz[i]; c.ones_col = fp.ones[i] ? fp.ldz[i] - 1 : -1; c.pack_ks = fp.pack[i];
+      return c;
+    };
+    if (!no_prelude && cp == nullptr && fp.chain && !merge_chain_disabled() && !chain_disabled()) {
+      int ti = -1, ii = -1;
+      for (int i = 0; i < M; ++i) {
+        if (!in[i].data || fp.bf16[i] || fp.z16[i] || in[i].dtype != HN_F32) continue;
+        if (ti < 0 && fp.N[i] == 1) ti = i;
+        if (ii < 0 && fp.N[i] > 1 && fp.wvf[i]) ii = i;
+      }
+      if (ti >= 0 && ii >= 0) {
+        pre_tc = call_of(ti); pre_ic = call_of(ii);
+        if (encode_prelude_eligible(pre_tc, pre_ic)) { pre_tab = ti; pre_img = ii; }
+      }
+    }
+  }
   // K1 once per forward: the normalised context of every present modality (layer independent)
   // (measured and dropped, round 4: the long modalities' encode on a side stream beside the one-token prelude -- the two
   // HBM-bound kernels slow each other down (skinny GEMMs 10 -> 18 us) and the join costs what is left: -1 % at cfg2 b = 32)
   for (int i = 0; i < M; ++i) {
-    if (!in[i].data) continue;
+    if (!in[i].data || i == pre_tab || i == pre_img) continue;      // (the prelude pair is encoded by the merged launch below)
     HN_REQUIRE(!is_split(i) || (!fp.bf16[i] && fp.N[i] >= 2), HN_E_UNSUPPORTED,
                "fusion: a split modality needs the fp32 core and at least two tokens per rank (modality %d: N=%ld)", i, (long)fp.N[i]);
     if (fp.bf16[i]) {
@@ -217,34 +244,6 @@ int impl_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, c
     }
     if (rc != HN_OK) return rc;
   }
-  // one-token modalities: all layers' block outputs in two batched launches (a key mask routes them through the general path)
-  bool tab_ready[16];
-  for (int i = 0; i < M; ++i) {
-    tab_ready[i] = false;
-    if (!in[i].data || !fp.tab_ahead[i] || mask != nullptr) continue;
-    const hn_attn_params &a0 = m->cross_attn[i];
-    const int inner = a0.heads * a0.dim_head;
-    GemmSkinnyMulti gv, gy;
-    memset(&gv, 0, sizeof(gv));
-    memset(&gy, 0, sizeof(gy));
-    gv.nz = gy.nz = m->depth;
-    gv.lda = fp.ldz[i]; gv.ldw = fp.D[i]; gv.ldc = inner; gv.M = b; gv.N = inner; gv.K = fp.D[i];
-    gv.pro = a0.ctx_gamma ? PRO_AFFINE : PRO_NONE; gv.act = ACT_NONE;
-    gy.lda = inner; gy.ldw = inner; gy.ldc = a0.query_dim; gy.M = b; gy.N = a0.query_dim; gy.K = inner;
-    gy.pro = PRO_NONE; gy.act = ACT_LEAKY;
-    for (int layer = 0; layer < m->depth; ++layer) {
-      const hn_attn_params &al = m->cross_attn[layer * M + i];
-      HN_REQUIRE(al.w_kv && al.w_out, HN_E_NULL, "attn: weight pointer is NULL");
-      gv.A[layer] = fp.z[i]; gv.W[layer] = al.w_kv + (long)inner * fp.D[i]; gv.gamma[layer] = al.ctx_gamma; gv.beta[layer] = al.ctx_beta;
-      gv.C[layer] = fp.tabv[i] + (size_t)layer * b * inner;
-      gy.A[layer] = gv.C[layer]; gy.W[layer] = al.w_out; gy.bias[layer] = al.b_out;
-      gy.C[layer] = fp.taby[i] + (size_t)layer * b * a0.query_dim;
-    }
-    if ((rc = launch_gemm_skinny_multi(gv, s)) != HN_OK) return rc;
-    if ((rc = launch_gemm_skinny_multi(gy, s)) != HN_OK) return rc;
-    tab_ready[i] = true;
-  }
-
   // The latent array moves through a chain of buffers instead of being updated in place: the block in front of an
   // attention block writes straight into that block's x_trace slot (the input hn_attn_probs re-reads later), so
   // keeping the trace costs no copy.  Without trace slots every block works in place on fp.x as before.
@@ -292,9 +291,40 @@ int impl_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, c
       vf.bc_zero = fp.flags; vf.bc_nzero = m->depth * M + CHAIN_XCHG_FLAGS;
       broadcast_done = true;
     }
-    if ((rc = launch_vfold(vf, s)) != HN_OK) return rc;
+    if (i == pre_img) rc = launch_encode_prelude(pre_tc, pre_ic, vf, s);      // + both encodes of the prelude pair
+    else rc = launch_vfold(vf, s);
+    if (rc != HN_OK) return rc;
     vmerge[i] = true;
   }
+  HN_REQUIRE(pre_img < 0 || vmerge[pre_img], HN_E_UNSUPPORTED, "fusion: the prelude pair was not launched");
+  // one-token modalities: all layers' block outputs in two batched launches (a key mask routes them through the general path)
+  bool tab_ready[16];
+  for (int i = 0; i < M; ++i) {
+    tab_ready[i] = false;
+    if (!in[i].data || !fp.tab_ahead[i] || mask != nullptr) continue;
+    const hn_attn_params &a0 = m->cross_attn[i];
+    const int inner = a0.heads * a0.dim_head;
+    GemmSkinnyMulti gv, gy;
+    memset(&gv, 0, sizeof(gv));
+    memset(&gy, 0, sizeof(gy));
+    gv.nz = gy.nz = m->depth;
+    gv.lda = fp.ldz[i]; gv.ldw = fp.D[i]; gv.ldc = inner; gv.M = b; gv.N = inner; gv.K = fp.D[i];
+    gv.pro = a0.ctx_gamma ? PRO_AFFINE : PRO_NONE; gv.act = ACT_NONE;
+    gy.lda = inner; gy.ldw = inner; gy.ldc = a0.query_dim; gy.M = b; gy.N = a0.query_dim; gy.K = inner;
+    gy.pro = PRO_NONE; gy.act = ACT_LEAKY;
+    for (int layer = 0; layer < m->depth; ++layer) {
+      const hn_attn_params &al = m->cross_attn[layer * M + i];
+      HN_REQUIRE(al.w_kv && al.w_out, HN_E_NULL, "attn: weight pointer is NULL");
+      gv.A[layer] = fp.z[i]; gv.W[layer] = al.w_kv + (long)inner * fp.D[i]; gv.gamma[layer] = al.ctx_gamma; gv.beta[layer] = al.ctx_beta;
+      gv.C[layer] = fp.tabv[i] + (size_t)layer * b * inner;
+      gy.A[layer] = gv.C[layer]; gy.W[layer] = al.w_out; gy.bias[layer] = al.b_out;
+      gy.C[layer] = fp.taby[i] + (size_t)layer * b * a0.query_dim;
+    }
+    if ((rc = launch_gemm_skinny_multi(gv, s)) != HN_OK) return rc;
+    if ((rc = launch_gemm_skinny_multi(gy, s)) != HN_OK) return rc;
+    tab_ready[i] = true;
+  }
+
 
   if (!broadcast_done && (rc = launch_broadcast_rows(m->latents, cur, (long)L * d, b, s, fp.flags, m->depth * M + CHAIN_XCHG_FLAGS)) != HN_OK) return rc;   // :225 (+ the bound / cluster flags)
   int chain_seq = 0;

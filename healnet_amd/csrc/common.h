@@ -512,13 +512,22 @@ struct VfoldMulti {                    // one entry per layer of a modality (<= 
   const float *bc_src; float *bc_dst; long bc_per, bc_total; int *bc_zero; int bc_nzero; int bc_rows;
 };
 int launch_vfold(const VfoldMulti &v, hipStream_t s);
+int vfold_plan(const VfoldMulti &v, VfoldMulti *vv, int *gx, int *gy, int *gz);      // the grid + argument block of the vfold roles (chain.hip)
 
 // ------------------------------------------------------------------------------------------------
 // encode
 // ------------------------------------------------------------------------------------------------
 int launch_encode(const void *data, int in_dtype, int b, int n_axes, const int *spatial, int C, int F, float max_freq,
                   int fourier, int normalize, float eps, float *out, int ld_out, hipStream_t s, int ones_col = -1,
-                  int pack_ks = 0, int axis0_begin = 0, int axis0_total = 0);      // axis0_total > 0: `spatial[0]` rows from axis0_begin of a longer axis
+                  int pack_ks = 0, int axis0_begin = 0, int axis0_total = 0);
+// the arguments of one launch_encode call, and the inference forward's prelude as ONE launch (encode.hip prelude_kernel): the
+// one-token modality's encode + vfold's roles (folded projections, latent broadcast, flags) + the RGB image's encode
+struct EncodeCall {
+  const void *data; int dtype, b, n_axes; const int *spatial; int C, F; float max_freq; int fourier, normalize; float eps;
+  float *out; int ld_out, ones_col, pack_ks;
+};
+bool encode_prelude_eligible(const EncodeCall &tab, const EncodeCall &img);
+int launch_encode_prelude(const EncodeCall &tab, const EncodeCall &img, const VfoldMulti &v, hipStream_t s);      // axis0_total > 0: `spatial[0]` rows from axis0_begin of a longer axis
 int launch_encode_bf16ctx(const void *data, int in_dtype, int b, int n_axes, const int *spatial, int C, int F, float max_freq,
                           int fourier, float eps, uint16_t *zb, uint16_t *zT, int Np, int DV, int ns, hipStream_t s);
 

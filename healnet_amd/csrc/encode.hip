@@ -94,10 +94,9 @@ __device__ __forceinline__ uint16_t to_bf16(float f) {     // round to nearest e
 // SC / SA / SF > 0: channel count, axes and frequency bands known at compile time (RGB image: 3, 2, 2; RGB volume: 3, 3, 2) --
 // every predicate and index computation of the generic formulation folds away
 template <int PACK, typename IN, int LD, int SC = 0, int SA = 0, int SF = 0>
-__global__ __launch_bounds__(256) void encode_token_kernel(const IN *__restrict__ data, float *__restrict__ out,
-                                                           EncGeom g, long total) {
+__device__ __forceinline__ void encode_token_body(const IN *__restrict__ data, float *__restrict__ out, EncGeom g, long total, const long block) {
   if (SC > 0) { g.C = SC; g.n_axes = SA; g.F = SF; g.D = SC + SA * (2 * SF + 1); }
-  long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long gid = block * blockDim.x + threadIdx.x;
   // 16-float rows leave through LDS (below): every lane of a wave takes part, the ones past the end on the last token's data
   const bool staged_store = (LD == 16 || LD == 32) && g.ld_out == LD;
   const bool live = gid < total;
@@ -174,7 +173,7 @@ __global__ __launch_bounds__(256) void encode_token_kernel(const IN *__restrict_
 #pragma unroll
     for (int q = 0; q < Q; ++q) stage[wv][Q * lane + (q ^ sw)] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
     __builtin_amdgcn_wave_barrier();
-    const long wave_tok0 = (long)blockIdx.x * blockDim.x + 64 * wv;      // first token of this wave
+    const long wave_tok0 = block * blockDim.x + 64 * wv;      // first token of this wave
 #pragma unroll
     for (int k = 0; k < Q; ++k) {
       const int slot = lane + 64 * k, tl = slot / Q;                     // token tl of the wave, position slot % Q of its row image
@@ -195,6 +194,12 @@ __global__ __launch_bounds__(256) void encode_token_kernel(const IN *__restrict_
     for (int c = 0; c < LD; ++c)
       if (c < g.ld_out) dst[c] = v[c];
   }
+}
+
+template <int PACK, typename IN, int LD, int SC = 0, int SA = 0, int SF = 0>
+__global__ __launch_bounds__(256) void encode_token_kernel(const IN *__restrict__ data, float *__restrict__ out,
+                                                           EncGeom g, long total) {
+  encode_token_body<PACK, IN, LD, SC, SA, SF>(data, out, g, total, (long)blockIdx.x);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -338,9 +343,8 @@ __device__ __forceinline__ float block_sum(float v, float *red) {
 }
 
 template <typename IN>
-__global__ __launch_bounds__(256) void encode_block_kernel(const IN *__restrict__ data, float *__restrict__ out, EncGeom g) {
+__device__ __forceinline__ void encode_block_body(const IN *__restrict__ data, float *__restrict__ out, const EncGeom &g, const long tok) {
   __shared__ float red[4];
-  const long tok = blockIdx.x;
   const int tid = threadIdx.x;
   long n = tok % g.N;
   int idx[HN_MAX_AXES];
@@ -365,6 +369,37 @@ __global__ __launch_bounds__(256) void encode_block_kernel(const IN *__restrict_
     dst[g.C + j] = g.normalize ? (p - mean) * rstd : p;
   }
   for (int c = g.D + tid; c < g.ld_out; c += 256) dst[c] = c == g.ones_col ? 1.0f : 0.0f;
+}
+
+template <typename IN>
+__global__ __launch_bounds__(256) void encode_block_kernel(const IN *__restrict__ data, float *__restrict__ out, EncGeom g) {
+  encode_block_body<IN>(data, out, g, (long)blockIdx.x);
+}
+
+// The prelude of the inference forward as ONE launch (round 6): the one-token modality's encode, the folded projections + latent
+// broadcast (vfold.h) and the image encode are mutually independent, and until now ran as three launches one behind the other
+// (8.6 + 8.0 + 21.4 us at cfg2 b = 32) in front of the skinny products that only need the first.  Roles by workgroup index, the small
+// ones first (they are dispatched first and finish under the image encode, which is an HBM stream over all CUs): fp32 inputs, the
+// static RGB-image instance of the token encode.
+#include "vfold.h"
+struct PreludeArgs {
+  const float *tab; float *ztab; EncGeom gt; int tab_tokens;
+  VfoldMulti v; int vf_gx, vf_gy, vf_gz;
+  const float *img; float *zimg; EncGeom gi; long total;
+};
+template <int PACK>
+__global__ __launch_bounds__(256) void prelude_kernel(PreludeArgs a) {
+  int bid = (int)blockIdx.x;
+  if (bid < a.tab_tokens) { encode_block_body<float>(a.tab, a.ztab, a.gt, (long)bid); return; }
+  bid -= a.tab_tokens;
+  const int nvf = a.vf_gx * a.vf_gy * a.vf_gz;
+  if (bid < nvf) {
+    const int bx = bid % a.vf_gx, by = (bid / a.vf_gx) % a.vf_gy, bz = bid / (a.vf_gx * a.vf_gy);
+    vfold_body(a.v, bx, by, bz, a.vf_gx, a.vf_gz);
+    return;
+  }
+  bid -= nvf;
+  encode_token_body<PACK, float, 16, 3, 2, 2>(a.img, a.zimg, a.gi, a.total, (long)bid);
 }
 
 static int fill_geom(EncGeom *g, int b, int n_axes, const int *spatial, int C, int F, float max_freq, int fourier, int normalize,
@@ -464,6 +499,41 @@ int launch_encode(const void *data, int in_dtype, int b, int n_axes, const int *
   if (in_dtype == HN_BF16) return launch_encode_t((const uint16_t *)data, g, b, out, ld_out, s, pack_ks);
   if (in_dtype == HN_U8) return launch_encode_t((const uint8_t *)data, g, b, out, ld_out, s, pack_ks);
   return launch_encode_t((const float *)data, g, b, out, ld_out, s, pack_ks);
+}
+
+// The prelude as one launch (prelude_kernel above).  `tab` / `img`: the arguments launch_encode would get for the one-token modality
+// and for the RGB image (fp32, no axis window); false from encode_prelude_eligible = run the launches separately.
+bool encode_prelude_eligible(const EncodeCall &tab, const EncodeCall &img) {
+  auto tokens = [](const EncodeCall &c) { long n = 1; for (int a = 0; a < c.n_axes; ++a) n *= c.spatial[a]; return n; };
+  const int Dt = tab.C + (tab.fourier ? tab.n_axes * (2 * tab.F + 1) : 0);
+  const long total_t = (long)tab.b * tokens(tab);
+  return tab.data && tab.out && img.data && img.out && tab.dtype == HN_F32 && img.dtype == HN_F32 && tab.n_axes >= 1 && tab.n_axes <= HN_MAX_AXES &&
+         Dt > kMaxNarrow && Dt >= 512 && total_t >= 1 && total_t <= 2048 && tab.pack_ks == 0 && tab.ld_out >= Dt && tab.normalize && img.normalize &&
+         img.fourier && img.C == 3 && img.F == 2 && img.n_axes == 2 && img.ld_out == 16 && (img.pack_ks == 0 || img.pack_ks == 3) &&
+         (long)img.b * tokens(img) < (1L << 30);
+}
+
+int launch_encode_prelude(const EncodeCall &tab, const EncodeCall &img, const VfoldMulti &v, hipStream_t s) {
+  HN_REQUIRE(encode_prelude_eligible(tab, img), HN_E_UNSUPPORTED, "encode_prelude: shapes not eligible");
+  PreludeArgs a;
+  int rc = fill_geom(&a.gt, tab.b, tab.n_axes, tab.spatial, tab.C, tab.F, tab.max_freq, tab.fourier, tab.normalize, tab.eps);
+  if (rc != HN_OK) return rc;
+  a.gt.ld_out = tab.ld_out;
+  a.gt.ones_col = (tab.ones_col >= a.gt.D && tab.ones_col < tab.ld_out) ? tab.ones_col : -1;
+  if ((rc = fill_geom(&a.gi, img.b, img.n_axes, img.spatial, img.C, img.F, img.max_freq, img.fourier, img.normalize, img.eps)) != HN_OK) return rc;
+  a.gi.ld_out = img.ld_out;
+  a.gi.ones_col = (img.ones_col >= a.gi.D && img.ones_col < img.ld_out) ? img.ones_col : -1;
+  HN_REQUIRE(img.ld_out >= a.gi.D && (img.pack_ks == 0 || img.pack_ks == packed_steps(a.gi.D, img.ld_out)), HN_E_SHAPE, "encode_prelude: image row D=%d pack=%d", a.gi.D, img.pack_ks);
+  a.tab = (const float *)tab.data; a.ztab = tab.out; a.tab_tokens = (int)((long)tab.b * a.gt.N);
+  a.img = (const float *)img.data; a.zimg = img.out; a.total = (long)img.b * a.gi.N;
+  if ((rc = vfold_plan(v, &a.v, &a.vf_gx, &a.vf_gy, &a.vf_gz)) != HN_OK) return rc;
+  const long token_blocks = ceil_div_ll(a.total, 256);
+  const long blocks = a.tab_tokens + (long)a.vf_gx * a.vf_gy * a.vf_gz + token_blocks;
+  HN_REQUIRE(blocks < (1L << 31), HN_E_UNSUPPORTED, "encode_prelude: grid too large");
+  if (img.pack_ks == 3) hipLaunchKernelGGL(prelude_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(prelude_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  HN_LAUNCH_CHECK("prelude");
+  return HN_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

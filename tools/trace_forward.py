@@ -4,7 +4,7 @@ duration and the gap to the previous launch's end (us).   python tools/trace_for
 import csv, glob, os, re, sys
 
 d = sys.argv[1]
-first = sys.argv[2] if len(sys.argv) > 2 else "encode"
+first = sys.argv[2] if len(sys.argv) > 2 else "prelude_kernel"      # first launch of a forward ("encode" for routes without the merged prelude)
 f = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 starts = [i for i, r in enumerate(rows) if first in r["Kernel_Name"]]
