@@ -19,7 +19,9 @@
 //   * a workgroup still owns 16 latent rows (one row tile); the 8 tiles of a sample (l_c = 128) are the MEMBERS of a cluster in the
 //     sense of chain_common.h: adjacent in their XCD's dispatch order, one L2.  The KV stage writes the tile's K rows head-major,
 //     (b, 8, 128, 64), and V TRANSPOSED, (b, 8, 64, 128) -- straight from the accumulators: lane (g, j) holds four consecutive
-//     tokens of column j -- the tile raises its flag, waits (bounded, reported: HN_E_CORESIDENCY) for its 7 siblings;
+//     tokens of column j -- and the tile raises its flag.  The Q stage then runs HEAD BY HEAD (wave w projects the 64 columns of head w:
+//     the Q tile of a head is written and read by one wave, no barrier) and hides the flags' way to the siblings; every wave requests
+//     the sample's 8 flags a chunk early and checks them itself (bounded, reported wait otherwise: HN_E_CORESIDENCY);
 //   * both images are then ordinary "weight matrices" for the per-wave register ring (full 128-byte lines, private LDS transpose
 //     slot, descriptor from the block table), with wave w = head w: K as rows = tokens (16 blocks of 16 tokens x 32 dims), V^T as
 //     rows = dims (16 blocks of 16 dims x 32 tokens); the loads carry sc1 (agent scope: they never hit in the CU's L1);
@@ -32,7 +34,8 @@
 //
 // Shapes: l_d = 128, hidden 512, l_c = 128, self-attention heads 8 x dim_head 64, image blocks heads * dh = 512 with the folded
 // value / query projections staged (vfold_kernel), no dropout, no tape: the inference forward at b * 8 > 128 row tiles.  Anything
-// else runs the per-block chains (HN_NO_SELF_IN_CHAIN=1 forces them: the A/B switch of tests/test_gpu_chain.py).
+// else runs the per-block chains (HN_NO_SELF_IN_CHAIN=1 forces them, HN_FORCE_SELF_IN_CHAIN=1 this kernel below its size gate: the A/B
+// switches of tests/test_gpu_layer_chain.py).  Stage times, what was tried and what it cost: DESIGN.md 4.2, tools/lchain_profile.py.
 #include "common.h"
 #include <stddef.h>
 #include <type_traits>
@@ -46,7 +49,6 @@ constexpr int PRM = 128 + 2 * CHID + 128 + 4 * 128 + 128;     // b_out | b1 | b2
 constexpr int MAXBLK = LAYER_MAXBLK;     // blocks of a launch (two table entries per thread)
 constexpr int STG = 8 * 256;             // per-wave 16 x 16 output staging tiles
 constexpr int LDS_FIXED = 8 * WSLOT + 16 * ATILE + 4 * ATILE + CR * XP + 2 * MAXBLK + STG;
-constexpr int NDUMMY = 0;                // (no filler entries: the ring runs from the Q chunks straight into the K blocks)
 constexpr int NATT = 32;                 // K blocks + V^T blocks
 constexpr int SC1 = 16;                  // cache-policy bit of a buffer load: agent scope (never served from the CU's L1)
 
@@ -109,13 +111,13 @@ __global__ __launch_bounds__(512) void latent_layer_kernel(const LayerChainArgs 
   };
 
   // ---- the block table: thread t describes block t of the launch.  Per segment: [OUT 16] [FF1 32] [FF2 16] then
-  //   proj 1: [K|V chunks 8 x 4] [Q chunks 4 x 4] [NDUMMY x the last block] [K blocks 16] [V^T blocks 16]
+  //   proj 1: [K|V chunks 8 x 4] [Q chunks 4 x 4, head by head] [K blocks 16] [V^T blocks 16]   (the ring runs from the Q blocks straight into the K blocks)
   //   proj 2: [Q 4]
   for (int bi = tid; bi < MAXBLK; bi += 512) {
     int sfound = 0, local = bi, found = 0;
     for (int s = 0; s < nseg; ++s) {
       const int hd = seg_i(s, offsetof(LSeg, head)), pj = seg_i(s, offsetof(LSeg, proj));
-      const int n = ((hd == 3 || hd == 4) ? 16 : 0) + 48 + (pj == 1 ? 48 + NDUMMY + NATT : pj == 2 ? 4 : 0);
+      const int n = ((hd == 3 || hd == 4) ? 16 : 0) + 48 + (pj == 1 ? 48 + NATT : pj == 2 ? 4 : 0);
       if (!found) {
         if (local < n) { sfound = s; found = 1; }
         else local -= n;
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(512) void latent_layer_kernel(const LayerChainArgs 
     const int s = sfound;
     const int hd = seg_i(s, offsetof(LSeg, head)), pj = seg_i(s, offsetof(LSeg, proj));
     const int n_out = (hd == 3 || hd == 4) ? 16 : 0;
-    const int n_all = n_out + 48 + (pj == 1 ? 48 + NDUMMY + NATT : pj == 2 ? 4 : 0);
+    const int n_all = n_out + 48 + (pj == 1 ? 48 + NATT : pj == 2 ? 4 : 0);
     if (local < 0) local = n_all - 1;
     const float *W;
     long rb;
@@ -144,13 +146,12 @@ __global__ __launch_bounds__(512) void latent_layer_kernel(const LayerChainArgs 
       if (pj == 2) {
         W = (const float *)seg_p(s, offsetof(LSeg, wq)); rb = 0; k = l2 & 3; ldw = CD;
       } else {
-        if (l2 >= 48 && l2 < 48 + NDUMMY) l2 = 47;
         if (l2 < 32) { W = (const float *)seg_p(s, offsetof(LSeg, wkv)); rb = (long)(l2 >> 2) * WN; k = l2 & 3; ldw = CD; }
         else if (l2 < 48) { W = (const float *)seg_p(s, offsetof(LSeg, wq)); rb = (long)((l2 - 32) >> 2) * 16; k = l2 & 3; ldw = CD; }      // wave w: rows 64 w + 16 c + ..
         else {
           // attention blocks: slot of this segment's K / V^T images, this sample
           const int slot = seg_i(s, offsetof(LSeg, kv_slot));
-          const int a2 = l2 - 48 - NDUMMY;
+          const int a2 = l2 - 48;
           if (a2 < 16) {                     // K block (token tile tt, k-half kk): rows = tokens of head `wave`, 64 floats apart
             const int tt = a2 >> 1, kk = a2 & 1;
             W = args.kbuf + (long)slot * args.kv_stride + (long)samp * (8 * 128 * 64) + tt * 16 * 64; rb = 0; k = kk; ldw = 64;
@@ -714,7 +715,7 @@ extern "C" __attribute__((visibility("default"))) int hn_debug_lchain_prof(unsig
 #endif
 
 int latent_layer_segment_blocks(int head, int proj) {
-  return ((head == 3 || head == 4) ? 16 : 0) + 48 + (proj == 1 ? 48 + NDUMMY + NATT : proj == 2 ? 4 : 0);
+  return ((head == 3 || head == 4) ? 16 : 0) + 48 + (proj == 1 ? 48 + NATT : proj == 2 ? 4 : 0);
 }
 
 bool latent_layer_enabled() {
@@ -746,7 +747,7 @@ int launch_latent_layer(const LayerChainArgs &a, hipStream_t s) {
     }
     if (g.proj == 2) HN_REQUIRE(a.qf && a.qf_bound && a.qf_flag && a.qf_D >= 1 && al16(a.qf), HN_E_NULL, "latent_layer: folded query operands");
     if (g.x_out) HN_REQUIRE(al16(g.x_out), HN_E_SHAPE, "latent_layer: unaligned x_out");
-    nblk += ((g.head == 3 || g.head == 4) ? 16 : 0) + 48 + (g.proj == 1 ? 48 + NDUMMY + NATT : g.proj == 2 ? 4 : 0);
+    nblk += ((g.head == 3 || g.head == 4) ? 16 : 0) + 48 + (g.proj == 1 ? 48 + NATT : g.proj == 2 ? 4 : 0);
   }
   HN_REQUIRE(nblk + 6 <= MAXBLK, HN_E_SHAPE, "latent_layer: %d blocks", nblk);      // (the caller plans with latent_layer_segment_blocks)
   if (a.seg[0].head == 3)
