@@ -20,7 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HN_LIB_PATH") or os.path.join(_HERE, "libhealnet_hip.so")   # HN_LIB_PATH: kernel experiments (tools/)
 CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ["api_blocks.hip", "api_fusion.hip", "api_train.hip", "api_entry.hip", "gemm.hip", "attention.hip", "attention_bf16.hip", "attention_bwd.hip", "encode.hip", "misc.hip",
-           "backward.hip", "train.hip", "chain.hip", "self_attention.hip", "bchain.hip", "gemm_bf16.hip", "gemm_nt.hip", "attention_lds.hip", "lchain.hip"]
+           "backward.hip", "train.hip", "chain.hip", "self_attention.hip", "bchain.hip", "gemm_bf16.hip", "gemm_nt.hip", "attention_lds.hip", "lchain.hip", "gemm_x6.hip"]
 
 c_float_p = C.POINTER(C.c_float)
 

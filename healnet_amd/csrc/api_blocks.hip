@@ -108,8 +108,11 @@ int plan_attn(const hn_attn_params *p, bool has_ctx, int ld_ctx, int b, int L, i
     pl->kv = ar.take<float>((size_t)b * pl->N * 2 * p->heads * pl->dhp);
   }
   pl->ctx16 = nullptr;
+  pl->ctx3 = nullptr;
   {
-    const size_t w16 = gemm_bf16_stage_floats(2 * pl->inner, pl->D), w32 = gemm_nt_stage_floats(2 * p->heads * pl->dhp, pl->D);
+    // (fp32 staging + the three-plane image of the staged weight behind it: gemm_x6.hip)
+    const size_t w16 = gemm_bf16_stage_floats(2 * pl->inner, pl->D),
+                 w32 = gemm_nt_stage_floats(2 * p->heads * pl->dhp, pl->D) + x6_plane_bytes(2 * p->heads * pl->dhp, pl->D, X6_ROW_TILE) / sizeof(float) + 64;
     pl->wstage = (has_ctx && !pl->rank_d && pl->N > 1) ? ar.take<float>(w16 > w32 ? w16 : w32) : nullptr;
   }
   const size_t prow = (size_t)b * p->heads * pl->nsplit * pl->Lp;
@@ -147,7 +150,7 @@ float *saved_kv(const AttnPlan &pl, bool has_ctx, bool masked, int b, int L, flo
 // zero): the bf16 product on the bf16 context image (inference, core_precision = bf16), the LDS-DMA fp32 product on the staged
 // weight (patch bags), or the generic GEMM.  `wstage`: the plan's staging scratch.
 int project_ctx_kv(const hn_attn_params *p, const AttnPlan &pl, const float *ctx, int ld_ctx, int b, float *kvbuf, float *wstage,
-                          const uint16_t *ctx16, hipStream_t s) {
+                          const uint16_t *ctx16, hipStream_t s, const uint16_t *ctx3) {
   const int kvpitch = 2 * p->heads * pl.dhp;
   static const bool no_glds = tuning_env("HN_NO_GLDS_GEMM") != nullptr;      // development switch: gemm_big_kernel / gemm_tall_narrow
   // the LDS-DMA projection lays the padded head width out itself (pad columns = 0): no fill in front of it
@@ -169,6 +172,16 @@ int project_ctx_kv(const hn_attn_params *p, const AttnPlan &pl, const float *ctx
     float *ws_w = wstage, *ws_b = wstage + (size_t)np * gemm_nt_ldws(gk.K);
     if ((rc = launch_gemm_nt_stage(gk.W, gk.ldw, gk.pro == PRO_AFFINE ? gk.gamma : nullptr, gk.pro == PRO_AFFINE ? gk.beta : nullptr, nullptr,
                                    gk.N, gk.K, ws_w, ws_b, s, gk.col_group, gk.col_group_pitch)) != HN_OK) return rc;
+    if (ctx3 && gemm_nt_x6_eligible(gk.M, np, gk.K)) {
+      // ... on the bf16 pipe from three-plane images (fp32-exact, gemm_x6.hip): the bag's image was built once behind its encode,
+      // the staged weight's is built here
+      unsigned short *wp = (unsigned short *)(wstage + align_up(gemm_nt_stage_floats(np, gk.K), 64));
+      if ((rc = launch_x6_split(ws_w, gemm_nt_ldws(gk.K), nullptr, np, gk.K, X6_ROW_TILE, wp, s)) != HN_OK) return rc;
+      GemmX6Args gx{};
+      gx.Ap = ctx3; gx.a_rt = x6_row_tiles(gk.M); gx.Wp = wp; gx.w_rt = x6_row_tiles(np); gx.bias = ws_b; gx.C = gk.C; gx.ldc = gk.ldc;
+      gx.M = gk.M; gx.N = np; gx.KT = (gk.K + 15) / 16; gx.alpha = 1.0f;
+      return launch_gemm_nt_x6(gx, 0, s);
+    }
     GemmNtArgs gn;
     gn.A = gk.A; gn.lda = gk.lda; gn.W = ws_w; gn.ldw = gemm_nt_ldws(gk.K); gn.bias = ws_b; gn.C = gk.C; gn.ldc = gk.ldc;
     gn.M = gk.M; gn.N = np; gn.K = gk.K; gn.alpha = 1.0f; gn.col_group = 0; gn.col_group_pitch = 0;
@@ -257,7 +270,7 @@ int attn_prepare(const hn_attn_params *p, const AttnPlan &pl, const float *x_in,
     }
     if (!q_done && (rc = launch_gemm(gq, s)) != HN_OK) return rc;
     if (!kv_ready && ctx) {
-      if ((rc = project_ctx_kv(p, pl, ctx, ld_ctx, b, kvbuf, pl.wstage, pl.ctx16, s)) != HN_OK) return rc;
+      if ((rc = project_ctx_kv(p, pl, ctx, ld_ctx, b, kvbuf, pl.wstage, pl.ctx16, s, pl.ctx3)) != HN_OK) return rc;
     } else if (!kv_ready && !fused_kv) {   // self-attention behind a chain that projected Q only: context = normalised x (healnet.py:404)
       GemmArgs gk = gemm_defaults();
       gk.A = x_in; gk.lda = p->query_dim; gk.M = rows; gk.K = p->query_dim;
@@ -278,7 +291,7 @@ int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_out, int 
                          int ld_ctx, int b, int L, int N, int D, const uint8_t *mask, float *stats, void *ws,
                          size_t ws_bytes, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, float *o_save,
                          bool ctx_has_ones, int ctx_pack_ks, const Bf16Context *bc, int *bound_flag,
-                         AttnExt *ext, const uint16_t *ctx16) {
+                         AttnExt *ext, const uint16_t *ctx16, const uint16_t *ctx3) {
   HN_REQUIRE(x_in && (x_out || (ext && ext->defer_out)), HN_E_NULL, "attn: x is NULL");
   HN_REQUIRE(p && p->w_q && p->w_kv && p->w_out, HN_E_NULL, "attn: weight pointer is NULL");
   AttnPlan pl;
@@ -287,6 +300,7 @@ int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_out, int 
   if ((rc = check_ws(ws, ws_bytes, pl.bytes, "attn")) != HN_OK) return rc;
   if ((rc = plan_attn(p, ctx != nullptr, ld_ctx, b, L, N, D, ws, ws_bytes, &pl, bc ? bc->ns : 0)) != HN_OK) return rc;
   pl.ctx16 = o_save == nullptr ? ctx16 : nullptr;      // (training keeps the fp32 projection: the backward differentiates THAT product)
+  pl.ctx3 = ctx3;                                      // (fp32-exact: both forwards)
 
   // ---- one-token context without a mask (tabular / omic modality): softmax over a single key is exactly 1, so the
   // block reduces to y = LeakyReLU(W_out (W_v c) + b_out) broadcast over the latent rows; Q and K are dead

@@ -21,6 +21,7 @@ int plan_fusion(const hn_model *m, const hn_modality_input *in, int b, void *ws,
   for (int i = 0; i < m->n_modalities; ++i) {
     fp->z[i] = nullptr;
     fp->z16[i] = nullptr;
+    fp->z3[i] = nullptr;
     if (in[i].data == nullptr) continue;
     const int axes = m->num_spatial_axes[i];
     HN_REQUIRE(axes >= 1 && axes <= HN_MAX_AXES, HN_E_UNSUPPORTED, "fusion: modality %d has %d spatial axes (1..%d)", i, axes,
@@ -114,18 +115,23 @@ int plan_fusion(const hn_model *m, const hn_modality_input *in, int b, void *ws,
       }
     }
     if (n > best) { best = n; fp->dominant = i; }
+    bool x6 = n > 1 && !fp->ones[i] && !fp->z16[i] && fp->ldz[i] % 4 == 0;
     for (int layer = 0; layer < m->depth; ++layer) {
       AttnPlan pl;
       int rc = plan_attn(&m->cross_attn[layer * m->n_modalities + i], true, fp->ldz[i], b, m->l_c, (int)n, fp->D[i], nullptr,
                          0, &pl, 0);
       if (rc != HN_OK) return rc;
       if (pl.bytes > op_max) op_max = pl.bytes;
+      x6 = x6 && !pl.rank_d && gemm_nt_x6_eligible((long)b * n, 2 * pl.heads * pl.dhp, fp->D[i]);
       if (want_bf16) {
         if ((rc = plan_attn(&m->cross_attn[layer * m->n_modalities + i], true, fp->ldz[i], b, m->l_c, (int)n, fp->D[i], nullptr,
                             0, &pl, ns)) != HN_OK) return rc;
         if (pl.bytes > op_max) op_max = pl.bytes;
       }
     }
+    // a large patch bag under the explicit binding: its K/V projections (and their weight gradients) run fp32-exact on the bf16
+    // pipe from a three-plane image of the normalised rows, built once per forward behind the encode (gemm_x6.hip)
+    fp->z3[i] = x6 ? (uint16_t *)ar.take<char>(x6_plane_bytes((long)b * n, fp->D[i], X6_ROW_TILE)) : nullptr;
   }
   HN_REQUIRE(fp->dominant >= 0, HN_E_SHAPE, "fusion: every modality is missing");
   if (m->self_per_cross_attn > 0) {
@@ -241,6 +247,7 @@ int impl_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, c
                          m->max_freq, m->fourier_encode_data, 1, 1e-5f, fp.z[i], fp.ldz[i], s, fp.ones[i] ? fp.ldz[i] - 1 : -1,
                          fp.pack[i], is_split(i) ? cp->axis0_begin[i] : 0, is_split(i) ? cp->axis0_total[i] : 0);
       if (rc == HN_OK && fp.z16[i]) rc = launch_rows_to_bf16(fp.z[i], fp.ldz[i], (long)b * fp.N[i], fp.D[i], fp.z16[i], s);
+      if (rc == HN_OK && fp.z3[i] && !is_split(i)) rc = launch_x6_split(fp.z[i], fp.ldz[i], nullptr, (long)b * fp.N[i], fp.D[i], X6_ROW_TILE, fp.z3[i], s);
     }
     if (rc != HN_OK) return rc;
   }
@@ -351,7 +358,7 @@ int impl_fusion_forward(const hn_model *m, const hn_modality_input *in, int b, c
     return attn_fwd_impl(ap, xin, xout, 1, fp.z[i], fp.ldz[i], b, L, fp.N[i], fp.D[i], mask,
                          stats_override ? stats_override : (attn_stats ? attn_stats[slot_of(st)] : nullptr), fp.op_ws, fp.op_ws_bytes, s, e0, e1, nullptr,
                          fp.ones[i], fp.pack[i], fp.bf16[i] ? &bc : nullptr, fp.flags + layer * M + i, ext,
-                         fp.z16[i]);
+                         fp.z16[i], is_split(i) ? nullptr : fp.z3[i]);
   };
   auto ff_of = [&](const Step &st) { return st.kind == STEP_CROSS_FF ? &m->cross_ff[st.layer * M + st.m] : &m->self_ff[st.layer]; };
   auto is_attn = [](const Step &st) { return st.kind == STEP_CROSS_ATTN || st.kind == STEP_SELF_ATTN; };

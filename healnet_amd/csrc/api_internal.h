@@ -65,6 +65,7 @@ struct AttnPlan {
   int heads, dh, inner, dhp, Lp, N, D, dp;
   bool rank_d, self_attn, ones, bf16core;
   const uint16_t *ctx16;          // explicit binding under core_precision = bf16 (inference): bf16 image of the context rows -> the K/V projection runs on bf16 MFMA
+  const uint16_t *ctx3;           // explicit binding of a large patch bag: three-plane bf16 image of the context rows (gemm_x6.hip) -> the fp32-exact K/V projection on the bf16 pipe
   int nsplit, chunk;
   int nq;                         // query tiles per wave the forward split was planned for (0: the kernel's default)
   int nsplit_bwd, chunk_bwd;      // token split of attn_bwd_dq_kernel (≈150 VGPRs: 3 waves per SIMD)
@@ -144,6 +145,7 @@ struct FusionPlan {
   int pack[16];    // ... and uses the packed channel layout with this many QK^T k-steps (0 = natural)
   bool bf16[16];   // core_precision = bf16: z holds the bf16 images (zb, then zT) instead of the fp32 rows
   uint16_t *z16[16];   // core_precision = bf16, explicit binding of a large patch bag: bf16 image of the rows of z (pitch gemm_bf16_pitch(D)) for the K/V projections, or NULL
+  uint16_t *z3[16];    // explicit binding of a large patch bag: three-plane bf16 image of the rows of z (gemm_x6.hip: fp32-exact products on the bf16 pipe), or NULL
   int Np[16], ns[16];
   int *flags;      // one pre-zeroed fallback flag of the score-bound softmax per (layer, modality), then the chain cluster flags
   float *xchg;     // exchange buffer of the latent chain's cluster mode (small batches)
@@ -240,7 +242,7 @@ int check_ws(void *ws, size_t ws_bytes, size_t need, const char *who);
 GemmArgs gemm_defaults();
 float *saved_kv(const AttnPlan &pl, bool has_ctx, bool masked, int b, int L, float *saved);
 int project_ctx_kv(const hn_attn_params *p, const AttnPlan &pl, const float *ctx, int ld_ctx, int b, float *kvbuf, float *wstage,
-                          const uint16_t *ctx16, hipStream_t s);
+                          const uint16_t *ctx16, hipStream_t s, const uint16_t *ctx3 = nullptr);
 bool qfold_core_ok(const hn_attn_params *p, const AttnPlan &pl, int pack_ks, int L);
 int attn_prepare(const hn_attn_params *p, const AttnPlan &pl, const float *x_in, const float *ctx, int ld_ctx,
                         int b, int L, hipStream_t s, AttnCoreArgs *core, int pack_ks = 0, float *kv_tape = nullptr,
@@ -249,7 +251,7 @@ int attn_fwd_impl(const hn_attn_params *p, const float *x_in, float *x_out, int 
                          int ld_ctx, int b, int L, int N, int D, const uint8_t *mask, float *stats, void *ws,
                          size_t ws_bytes, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, float *o_save = nullptr,
                          bool ctx_has_ones = false, int ctx_pack_ks = 0, const Bf16Context *bc = nullptr, int *bound_flag = nullptr,
-                         AttnExt *ext = nullptr, const uint16_t *ctx16 = nullptr);
+                         AttnExt *ext = nullptr, const uint16_t *ctx16 = nullptr, const uint16_t *ctx3 = nullptr);
 size_t attn_saved_floats(const AttnPlan &pl, bool has_ctx, bool masked, int b, int L);
 int plan_attn_bwd(const hn_attn_params *p, const AttnPlan &pl, bool has_ctx, bool masked, int b, int L, void *ws,
                          size_t ws_bytes, AttnBwdPlan *bp);

@@ -267,6 +267,7 @@ int impl_fusion_forward_train(const hn_model *m, const hn_modality_input *in, in
                             m->max_freq, m->fourier_encode_data, 1, 1e-5f, fp.z[i], fp.ldz[i], s, tones[i] ? fp.ldz[i] - 1 : -1,
                             tpack[i])) != HN_OK)
       return rc;
+    if (fp.z3[i] && (rc = launch_x6_split(fp.z[i], fp.ldz[i], nullptr, (long)b * fp.N[i], fp.D[i], X6_ROW_TILE, fp.z3[i], s)) != HN_OK) return rc;
   }
   // (the launch also zeroes the cluster flags of the latent chains: small batches run them as clusters, chain.hip)
   if ((rc = launch_broadcast_rows(m->latents, T + tp.x_off[0], (long)L * d, b, s, fp.flags + m->depth * M, CHAIN_XCHG_FLAGS)) != HN_OK) return rc;
@@ -445,7 +446,7 @@ int impl_fusion_forward_train(const hn_model *m, const hn_modality_input *in, in
       else
         rc = attn_fwd_impl(&ap, xin, nullptr, 1, fp.z[st.m], fp.ldz[st.m], b, L, fp.N[st.m], fp.D[st.m], mask, T + tp.stats_off[k],
                            fp.op_ws, fp.op_ws_bytes, s, nullptr, nullptr, T + tp.saved_off[k], tones[st.m], tpack[st.m], nullptr, nullptr,
-                           &ext);
+                           &ext, nullptr, fp.z3[st.m]);
       if (rc != HN_OK) return rc;
       HN_REQUIRE(fuse_tab ? ext.y_out != nullptr : ext.o_out != nullptr, HN_E_UNSUPPORTED,
                  "fusion_forward_train: attention block did not defer its out-projection");
@@ -483,7 +484,7 @@ int impl_fusion_forward_train(const hn_model *m, const hn_modality_input *in, in
         ap.rng = rng;
         rc = attn_fwd_impl(&ap, xin, xout, 1, fp.z[st.m], fp.ldz[st.m], b, L, fp.N[st.m], fp.D[st.m],
                            mask, T + tp.stats_off[k], fp.op_ws, fp.op_ws_bytes, s, nullptr, nullptr, T + tp.saved_off[k],
-                           tones[st.m], tpack[st.m], nullptr, nullptr, extp);
+                           tones[st.m], tpack[st.m], nullptr, nullptr, extp, nullptr, fp.z3[st.m]);
         break;
       }
       case STEP_SELF_ATTN: {

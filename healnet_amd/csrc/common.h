@@ -66,6 +66,7 @@ int fail(int code, const char *fmt, ...);
 // With a descriptor whose num_records ends at the last valid row, out-of-range rows simply read as 0 in
 // hardware: no predicate, no branch, all loads of a tile in flight together.
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ f32x4 hn_buffer_load_x4_raw(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
 __device__ float hn_buffer_load_x1_raw(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
 #ifndef HN_LOAD_AUX
@@ -315,6 +316,24 @@ int gemm_nt_padded_cols(int N, int col_group, int col_group_pitch);
 int launch_gemm_nt_stage(const float *W, long ldw, const float *gamma, const float *beta, const float *bias, int N, int K, float *Ws,
                          float *bs, hipStream_t s, int col_group = 0, int col_group_pitch = 0);
 int launch_gemm_nt(const GemmNtArgs &g, int variant, hipStream_t s);
+// fp32-exact GEMMs on the bf16 matrix pipe from three-plane operand images (gemm_x6.hip)
+struct GemmX6Args {
+  const unsigned short *Ap; int a_rt;          // planes of the context rows: (KT, a_rt, 3, 64, 8) bf16, a_rt padded to the tile
+  const unsigned short *Wp; int w_rt;          // planes of the staged weight rows, w_rt padded to the tile
+  const float *bias;                           // staged bias row (N) or NULL
+  float *C; long ldc;
+  int M, N, KT;                                // KT = ceil(K / 16) k-steps
+  float alpha;
+  int ntm, ntn; size_t a_bytes, w_bytes;       // internal
+};
+size_t x6_plane_bytes(long rows, int K, int row_tile);
+int launch_x6_split(const float *X, long ldx, const float *scale, long R, int K, int row_tile, unsigned short *P, hipStream_t s,
+                    int col_group = 0, int col_group_pitch = 0);
+int launch_gemm_nt_x6(const GemmX6Args &g, int variant, hipStream_t s);
+constexpr int X6_ROW_TILE = 8;                 // plane images are padded to 8 row tiles of 32 (the 256-row tile of the product kernels)
+bool gemm_x6_enabled();                        // route switch HN_NO_X6_GEMM=1: the fp32-MFMA kernels of gemm_nt.hip (A/B tests)
+bool gemm_nt_x6_eligible(long M, int N, int K);
+static inline int x6_row_tiles(long rows) { return (int)(((rows + 31) / 32 + X6_ROW_TILE - 1) / X6_ROW_TILE * X6_ROW_TILE); }
 // long-contraction TN product C (+)= alpha * A^T B (+ colsum of A) on LDS-DMA staged k-tiles (gemm_nt.hip): G = dKV^T z of a patch bag
 bool gemm_tn_glds_eligible(const float *A, long lda, const float *B, long ldb, int M, int N, int K);
 int launch_gemm_tn_glds(const float *A, long lda, const float *B, long ldb, float *C, long ldc, int M, int N, int K, float alpha,
