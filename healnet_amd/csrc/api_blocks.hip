@@ -543,6 +543,8 @@ int plan_attn_bwd(const hn_attn_params *p, const AttnPlan &pl, bool has_ctx, boo
       if (has_ctx) {
         bp->G = ar.take<float>(2 * inner * pl.D);
         bp->cs = ar.take<float>(2 * inner);
+        if (gemm_tn_x6_eligible((long)b * pl.N, (int)(2 * inner), pl.D))
+          bp->dkv3 = (uint16_t *)ar.take<char>(gemm_tn_x6_image_bytes((long)b * pl.N, (int)(2 * inner), 8));
       }
     }
   }
@@ -770,9 +772,18 @@ int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float *x_out
     }
     const long krows = (long)b * pl.N;
     if (has_ctx) {   // gradients of to_kv and of the context LayerNorm affine from G = dKV^T z and colsum(dKV)
-      GemmExArgs e = gex(bp.dKV, 1, 2 * inner, ctx, 1, ld_ctx, bp.G, pl.D, 2 * inner, pl.D, (int)krows, 0);
-      e.colsum = bp.cs; e.colsum_accumulate = 0;          // colsum(dKV) rides on the same pass
-      if ((rc = launch_gemm_ex(e, s, bp.red)) != HN_OK) return rc;
+      if (bp.dkv3 && ext && ext->ctx3t) {
+        // ... fp32-exact on the bf16 pipe (gemm_x6.hip): the transposed three-plane image of dKV is built here, the context's (with
+        // its ones column: colsum(dKV) is one more column of the product) once per backward by the caller
+        const long kdim = pl.D > (int)p->query_dim ? pl.D : (long)p->query_dim;
+        const size_t red_floats = reduce_scratch_floats(2L * inner * kdim, (int)(2 * inner > p->query_dim ? 2 * inner : p->query_dim));
+        if ((rc = launch_x6_split_t(bp.dKV, 2 * inner, krows, 2 * inner, 8, -1, bp.dkv3, s)) != HN_OK) return rc;
+        if ((rc = launch_gemm_tn_x6(bp.dkv3, ext->ctx3t, krows, 2 * inner, pl.D, bp.G, pl.D, bp.cs, bp.red, red_floats, s)) != HN_OK) return rc;
+      } else {
+        GemmExArgs e = gex(bp.dKV, 1, 2 * inner, ctx, 1, ld_ctx, bp.G, pl.D, 2 * inner, pl.D, (int)krows, 0);
+        e.colsum = bp.cs; e.colsum_accumulate = 0;          // colsum(dKV) rides on the same pass
+        if ((rc = launch_gemm_ex(e, s, bp.red)) != HN_OK) return rc;
+      }
       if ((rc = launch_kv_weight_grads(bp.G, bp.cs, p->w_kv, p->ctx_gamma, p->ctx_beta, 2 * inner, pl.D, g->w_kv, g->ctx_gamma,
                                        g->ctx_beta, s, bp.red)) != HN_OK) return rc;
     } else if (g->w_kv && !(ext && ext->defer_proj)) {   // self-attention: K, V come from x_hat

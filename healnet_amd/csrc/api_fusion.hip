@@ -22,6 +22,7 @@ int plan_fusion(const hn_model *m, const hn_modality_input *in, int b, void *ws,
     fp->z[i] = nullptr;
     fp->z16[i] = nullptr;
     fp->z3[i] = nullptr;
+    fp->x6[i] = false;
     if (in[i].data == nullptr) continue;
     const int axes = m->num_spatial_axes[i];
     HN_REQUIRE(axes >= 1 && axes <= HN_MAX_AXES, HN_E_UNSUPPORTED, "fusion: modality %d has %d spatial axes (1..%d)", i, axes,
@@ -131,7 +132,12 @@ int plan_fusion(const hn_model *m, const hn_modality_input *in, int b, void *ws,
     }
     // a large patch bag under the explicit binding: its K/V projections (and their weight gradients) run fp32-exact on the bf16
     // pipe from a three-plane image of the normalised rows, built once per forward behind the encode (gemm_x6.hip)
-    fp->z3[i] = x6 ? (uint16_t *)ar.take<char>(x6_plane_bytes((long)b * n, fp->D[i], X6_ROW_TILE)) : nullptr;
+    // (the backward holds the TRANSPOSED image in the same place: G = dKV^T z contracts over the rows)
+    fp->x6[i] = x6;
+    if (x6) {
+      const size_t nt = x6_plane_bytes((long)b * n, fp->D[i], X6_ROW_TILE), tn = gemm_tn_x6_image_bytes((long)b * n, fp->D[i] + 1, 5);
+      fp->z3[i] = (uint16_t *)ar.take<char>(nt > tn ? nt : tn);
+    }
   }
   HN_REQUIRE(fp->dominant >= 0, HN_E_SHAPE, "fusion: every modality is missing");
   if (m->self_per_cross_attn > 0) {

@@ -102,6 +102,7 @@ struct AttnExt {
 
 struct AttnBwdPlan {
   float *dpre, *dO, *xhat, *dxhat, *lns, *delta, *dOp, *dQpart, *dQ, *dKV, *G, *cs, *Abuf, *dA, *E, *T, *dT, *dyb, *dV, *red;
+  uint16_t *dkv3;            // explicit binding of a large patch bag: transposed three-plane image of dKV for G = dKV^T z on the bf16 pipe (gemm_x6.hip), or NULL
   void *fwd_ws; size_t fwd_bytes, bytes;
 };
 
@@ -110,6 +111,7 @@ struct AttnBwdPlan {
 // will run the projection backward (dx_hat = dQ W_q + dKV W_kv, LayerNorm backward, residual) and the batched weight-gradient
 // launch takes dW_q / dW_kv (and dW_out when the block's O is on the tape).
 struct AttnBwdExt {
+  const uint16_t *ctx3t;     // in: transposed three-plane image of the context rows with the ones column at D (gemm_x6.hip), or NULL: fp32-MFMA products
   const float *dpre, *dO;    // given (rows, query_dim) / (rows, inner): the LeakyReLU backward and the dO product are skipped
   bool skip_wout;            // dW_out / db_out are left to the caller's batched launch (O = the tape's, explicit bindings only)
   bool defer_proj;           // stop behind the core: no dW_q / dW_kv, no dx; dQ / dKV / xhat are reported instead
@@ -145,6 +147,7 @@ struct FusionPlan {
   int pack[16];    // ... and uses the packed channel layout with this many QK^T k-steps (0 = natural)
   bool bf16[16];   // core_precision = bf16: z holds the bf16 images (zb, then zT) instead of the fp32 rows
   uint16_t *z16[16];   // core_precision = bf16, explicit binding of a large patch bag: bf16 image of the rows of z (pitch gemm_bf16_pitch(D)) for the K/V projections, or NULL
+  bool x6[16];         // ... planned for this modality (z3 itself is NULL in a sizing pass)
   uint16_t *z3[16];    // explicit binding of a large patch bag: three-plane bf16 image of the rows of z (gemm_x6.hip: fp32-exact products on the bf16 pipe), or NULL
   int Np[16], ns[16];
   int *flags;      // one pre-zeroed fallback flag of the score-bound softmax per (layer, modality), then the chain cluster flags

@@ -131,6 +131,8 @@ int fusion_bwd_workspace(const hn_model *m, const hn_modality_input *in, int b, 
   for (int i = 0; i < m->n_modalities; ++i) {
     fp->z[i] = nullptr;
     if (in[i].data) fp->z[i] = ar.take<float>((size_t)b * fp->N[i] * fp->ldz[i]);
+    // (a large patch bag: the transposed three-plane image of its rows, gemm_x6.hip)
+    fp->z3[i] = (in[i].data && fp->x6[i]) ? (uint16_t *)ar.take<char>(gemm_tn_x6_image_bytes((long)b * fp->N[i], fp->D[i] + 1, 5)) : nullptr;
   }
   *dX = ar.take<float>(rows16((size_t)b * m->l_c) * m->l_d);
   *head_scratch = ar.take<float>(head_bwd_scratch_floats(b, m->l_d, m->out_dims > 0 ? m->out_dims : 1));
@@ -553,11 +555,15 @@ int impl_fusion_backward(const hn_model *m, const hn_modality_input *in, int b, 
   train_context_layout(m, fp, tones, tpack);
   for (int i = 0; i < M; ++i) {     // the normalised contexts: from the tape, or recomputed (one HBM pass) when they were not kept
     if (!in[i].data) continue;
-    if (tp.z_off[i] != kNoSlot && fp.z[i]) { fp.z[i] = const_cast<float *>(T) + tp.z_off[i]; continue; }
-    if ((rc = launch_encode(in[i].data, in[i].dtype, b, m->num_spatial_axes[i], in[i].spatial, m->channel_dims[i], m->num_freq_bands,
-                            m->max_freq, m->fourier_encode_data, 1, 1e-5f, fp.z[i], fp.ldz[i], s, tones[i] ? fp.ldz[i] - 1 : -1,
-                            tpack[i])) != HN_OK)
+    if (tp.z_off[i] != kNoSlot && fp.z[i]) fp.z[i] = const_cast<float *>(T) + tp.z_off[i];
+    else if ((rc = launch_encode(in[i].data, in[i].dtype, b, m->num_spatial_axes[i], in[i].spatial, m->channel_dims[i], m->num_freq_bands,
+                                 m->max_freq, m->fourier_encode_data, 1, 1e-5f, fp.z[i], fp.ldz[i], s, tones[i] ? fp.ldz[i] - 1 : -1,
+                                 tpack[i])) != HN_OK)
       return rc;
+    // a large patch bag: the transposed three-plane image of its rows for the weight-gradient products of all its layers (gemm_x6.hip)
+    if (fp.z3[i] && gemm_tn_x6_eligible((long)b * fp.N[i], 2 * m->cross_attn[i].heads * m->cross_attn[i].dim_head, fp.D[i])) {
+      if ((rc = launch_x6_split_t(fp.z[i], fp.ldz[i], (long)b * fp.N[i], fp.D[i], 5, fp.D[i], fp.z3[i], s)) != HN_OK) return rc;
+    } else fp.z3[i] = nullptr;
   }
   const float *xf = T + tp.x_off[tp.nsteps];
   const bool use_bchain = cb.ok && fp.chain && !bchain_disabled() && !chain_disabled();
@@ -725,10 +731,11 @@ int impl_fusion_backward(const hn_model *m, const hn_modality_input *in, int b, 
     AttnBwdExt ext;
     memset(&ext, 0, sizeof(ext));
     ext.dpre = dpre; ext.dO = dO_in; ext.skip_wout = skip_wout; ext.defer_proj = defer;
+    if (st.kind == STEP_CROSS_ATTN) ext.ctx3t = fp.z3[st.m];
     if (tp.q_off[k] != kNoSlot) ext.q_taped = T + tp.q_off[k];
     if (tp.kv_off[k] != kNoSlot) ext.kv_taped = T + tp.kv_off[k];
     if (tp.xhat_off[k] != kNoSlot) ext.xhat_taped = T + tp.xhat_off[k];
-    AttnBwdExt *extp = (dpre || defer || ext.q_taped || ext.xhat_taped) ? &ext : nullptr;
+    AttnBwdExt *extp = (dpre || defer || ext.q_taped || ext.xhat_taped || ext.ctx3t) ? &ext : nullptr;
     if (defer) {      // dQ / dKV for the NEXT chain's products: into that chain's buffer set
       const BChainSet &ns = cb.set[chain_no % BCHAIN_SETS];
       ext.dQ_home = ns.dQ; ext.dKV_home = ns.dKV;

@@ -325,6 +325,7 @@ struct GemmX6Args {
   int M, N, KT;                                // KT = ceil(K / 16) k-steps
   float alpha;
   int ntm, ntn; size_t a_bytes, w_bytes;       // internal
+  int nsplit, kslice;                          // internal (split-k mode: C = partials (nsplit, M, ldc))
 };
 size_t x6_plane_bytes(long rows, int K, int row_tile);
 int launch_x6_split(const float *X, long ldx, const float *scale, long R, int K, int row_tile, unsigned short *P, hipStream_t s,
@@ -333,6 +334,13 @@ int launch_gemm_nt_x6(const GemmX6Args &g, int variant, hipStream_t s);
 constexpr int X6_ROW_TILE = 8;                 // plane images are padded to 8 row tiles of 32 (the 256-row tile of the product kernels)
 bool gemm_x6_enabled();                        // route switch HN_NO_X6_GEMM=1: the fp32-MFMA kernels of gemm_nt.hip (A/B tests)
 bool gemm_nt_x6_eligible(long M, int N, int K);
+static inline int x6_col_tiles(int cols, int pad) { return ((cols + 31) / 32 + pad - 1) / pad * pad; }
+// transposed images (rows of the image = columns of X, k = row index of X) and the long-contraction TN product on them
+int launch_x6_split_t(const float *X, long ldx, long R, int C, int col_tile, int ones_col, unsigned short *P, hipStream_t s);
+bool gemm_tn_x6_eligible(long K, int M, int N);
+size_t gemm_tn_x6_image_bytes(long K, int cols, int col_tile);
+int launch_gemm_tn_x6(const unsigned short *At, const unsigned short *Bt, long K, int M, int N, float *G, long ldg, float *colsum, float *scratch,
+                      size_t scratch_floats, hipStream_t s);
 static inline int x6_row_tiles(long rows) { return (int)(((rows + 31) / 32 + X6_ROW_TILE - 1) / X6_ROW_TILE * X6_ROW_TILE); }
 // long-contraction TN product C (+)= alpha * A^T B (+ colsum of A) on LDS-DMA staged k-tiles (gemm_nt.hip): G = dKV^T z of a patch bag
 bool gemm_tn_glds_eligible(const float *A, long lda, const float *B, long ldb, int M, int N, int K);

@@ -115,34 +115,53 @@ __global__ __launch_bounds__(256) void x6_split_kernel(X6SplitArgs g) {
 // ------------------------------------------------------------------------------------------------
 // ABL: development ablations (tools/ubench/gemm_x6_bench.hip): 1 = no output stores, 2 = no operand loads behind the prologue,
 // 4 = no barrier / load waits in the loop, 8 = no fragment reads in the loop.  The product instantiates ABL = 0 only.
-template <int WM, int WN, int NWM, int NWN, int S, int ABL = 0>
+template <int WM, int WN, int NWM, int NWN, int S, int MODE = 0, int ABL = 0>
 __global__ __launch_bounds__(NWM *NWN * 64) void gemm_nt_x6_kernel(GemmX6Args g) {
   constexpr int NW = NWM * NWN, TA = NWM * WM, TW = NWN * WN;            // row tiles of 32 per workgroup
-  constexpr int PIECES = (TA + TW) * 3, LW = PIECES / NW;                // 1 KB pieces per stage; per wave
-  constexpr int STAGE = PIECES * 1024;
-  constexpr int LWA = TA * 3 / NW;                                       // the first LWA of a wave's pieces are context fragments
-  static_assert((TA * 3) % NW == 0 && (TW * 3) % NW == 0, "stage pieces must split evenly over the waves");
+  constexpr int LWA = TA * 3 / NW, LWW = (TW * 3 + NW - 1) / NW, LW = LWA + LWW;   // 1 KB pieces per stage and wave: context, weight
+  // (every wave issues the same number of pieces -- the counted waits rely on it: when the weight pieces do not split evenly the
+  // last ones are fetched twice into pad slots)
+  constexpr int STAGE = (TA * 3 + LWW * NW) * 1024;
+  static_assert((TA * 3) % NW == 0, "the context pieces of a stage must split evenly over the waves");
   extern __shared__ __attribute__((aligned(16))) unsigned char x6_lds[];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int id = blockIdx.x, xcd = id & 7, seq = id >> 3;
-  const int n_tile = seq % g.ntn, m_tile = (seq / g.ntn) * 8 + xcd;      // the column tiles of one row block back to back on one XCD
-  if (m_tile >= g.ntm) return;
+  int m_tile, n_tile, kt_begin = 0, nk = g.KT, z = 0;
+  if (MODE == 0) {
+    const int id = blockIdx.x, xcd = id & 7, seq = id >> 3;
+    n_tile = seq % g.ntn; m_tile = (seq / g.ntn) * 8 + xcd;              // the column tiles of one row block back to back on one XCD
+    if (m_tile >= g.ntm) return;
+  } else {
+    // split-k: slice-major runs of consecutive work items per XCD (an XCD streams ~nsplit / 8 slices of both operands)
+    const int tiles = g.ntm * g.ntn, total = tiles * g.nsplit, per = (total + 7) >> 3;
+    const int lin = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (lin >= total) return;
+    z = lin / tiles;
+    const int tile = lin - z * tiles;
+    m_tile = tile % g.ntm; n_tile = tile / g.ntm;
+    kt_begin = z * g.kslice;
+    nk = min(g.kslice, g.KT - kt_begin);
+  }
   const i32x4 rsA = make_rsrc(g.Ap, (unsigned)min((size_t)0xfffffff0u, g.a_bytes));
   const i32x4 rsW = make_rsrc(g.Wp, (unsigned)min((size_t)0xfffffff0u, g.w_bytes));
   const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char *)x6_lds);
   const int voff = lane << 4;
   const unsigned a_step = (unsigned)g.a_rt * 3072u, w_step = (unsigned)g.w_rt * 3072u;   // bytes per k-step of the whole image
-  const unsigned a_tile = (unsigned)(m_tile * TA) * 3072u, w_tile = (unsigned)(n_tile * TW) * 3072u;
+  const unsigned a_tile = (unsigned)kt_begin * a_step + (unsigned)(m_tile * TA) * 3072u;
+  const unsigned w_tile = (unsigned)kt_begin * w_step + (unsigned)(n_tile * TW) * 3072u;
 
   auto issue = [&](int kt) {
 #pragma unroll
     for (int q = 0; q < LW; ++q) {
-      const int u = wave + NW * q;
-      const unsigned dst = lds_base + (unsigned)((kt % S) * STAGE + u * 1024);
-      if (q < LWA) x6_glds16(rsA, dst, voff, (unsigned)kt * a_step + a_tile + (unsigned)u * 1024u);
-      else x6_glds16(rsW, dst, voff, (unsigned)kt * w_step + w_tile + (unsigned)(u - TA * 3) * 1024u);
+      if (q < LWA) {
+        const int u = wave + NW * q;
+        x6_glds16(rsA, lds_base + (unsigned)((kt % S) * STAGE + u * 1024), voff, (unsigned)kt * a_step + a_tile + (unsigned)u * 1024u);
+      } else {
+        const int u = wave + NW * (q - LWA);
+        x6_glds16(rsW, lds_base + (unsigned)((kt % S) * STAGE + (TA * 3 + u) * 1024), voff,
+                  (unsigned)kt * w_step + w_tile + (unsigned)min(u, TW * 3 - 1) * 1024u);
+      }
     }
   };
 
@@ -155,7 +174,6 @@ __global__ __launch_bounds__(NWM *NWN * 64) void gemm_nt_x6_kernel(GemmX6Args g)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-  const int nk = g.KT;
   const unsigned char *fa = x6_lds + (wm * WM * 3) * 1024 + lane * 16;
   const unsigned char *fw = x6_lds + ((TA + wn * WN) * 3) * 1024 + lane * 16;
   auto mfma_set = [&](const x6_bf16x8(&af)[WM], const x6_bf16x8(&wf)[WN]) {
@@ -229,6 +247,7 @@ __global__ __launch_bounds__(NWM *NWN * 64) void gemm_nt_x6_kernel(GemmX6Args g)
   // epilogue.  D of mfma(W fragment, A fragment): row (= output column within the 32-block) (r & 3) + 8 (r >> 2) + 4 (lane >> 5),
   // column (= output row) lane & 31
   const int m0 = m_tile * TA * 32, n0 = n_tile * TW * 32;
+  float *out = MODE == 0 ? g.C : g.C + (long)z * g.M * g.ldc;           // split-k: slice z's partial, (M, ldc) with ldc = the padded width
 #pragma unroll
   for (int i = 0; i < WM; ++i) {
     const int m = m0 + (wm * WM + i) * 32 + (lane & 31);
@@ -239,12 +258,79 @@ __global__ __launch_bounds__(NWM *NWN * 64) void gemm_nt_x6_kernel(GemmX6Args g)
       for (int q = 0; q < 4; ++q) {
         const int n = n0 + (wn * WN + j) * 32 + 8 * q + 4 * (lane >> 5);
         if (n >= g.N || ((ABL & 1) && g.alpha != 12345.0f)) continue;
-        const f32x4 bv = g.bias ? *(const f32x4 *)&g.bias[n] : (f32x4){0.f, 0.f, 0.f, 0.f};
         f32x4 o;
+        if (MODE == 0) {
+          const f32x4 bv = g.bias ? *(const f32x4 *)&g.bias[n] : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = acc[i][j][4 * q + e] * g.alpha + bv[e];
-        *(f32x4 *)&g.C[(long)m * g.ldc + n] = o;
+          for (int e = 0; e < 4; ++e) o[e] = acc[i][j][4 * q + e] * g.alpha + bv[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = acc[i][j][4 * q + e];
+        }
+        *(f32x4 *)&out[(long)m * g.ldc + n] = o;
       }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Long-contraction TN product G[i, j] = sum_r A[r, i] B[r, j] (the patch-bag weight gradient G = dKV^T z, healnet.py:405's autograd:
+// 1024 x 773 over 32 768 rows) is the SAME kernel on TRANSPOSED plane images -- "rows" = the columns i (j) of A (B), k = the row
+// index r -- cut into k-slices (MODE 1) whose partials x6_tn_reduce_kernel folds in a fixed order.
+//   * x6_split_t_kernel builds such an image: lane (column c = ct * 32 + (lane & 31), rows r0 + (lane >> 5) * 8 + 0 .. 7) gathers its
+//     eight values with eight dword loads (each a pair of full 128-byte segments per wave) and writes three 16-byte pieces.
+//   * colsum_i = sum_r A[r, i] (the bias-gradient / LayerNorm-beta term) is one more column of the product: the image of B carries a
+//     synthetic ONES column at index N (its pad), so G[:, N] is the column sum, accumulated like everything else.
+// ------------------------------------------------------------------------------------------------
+struct X6SplitTArgs {
+  const float *X; long ldx;
+  long R; int C;                      // X is (R, C); the image has KT = ceil(R / 16) k-steps of Ct column tiles
+  int Ct, KT, ones_col;               // ones_col >= C: that image row is all ones (h = 1, m = l = 0) for r < R; -1: none
+  unsigned short *P;
+};
+
+__global__ __launch_bounds__(256) void x6_split_t_kernel(X6SplitTArgs g) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ct = blockIdx.x, kt0 = (blockIdx.y * 4 + wave) * 4;
+  if (kt0 >= g.KT) return;
+  const int col = ct * 32 + (lane & 31);
+  const bool live = col < g.C, ones = col == g.ones_col;
+  const float *x = g.X + (live ? col : 0);
+  float v[4][8];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const long r0 = (long)(kt0 + q) * 16 + (lane >> 5) * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[q][e] = (live && r0 + e < g.R) ? x[(r0 + e) * g.ldx] : ((ones && r0 + e < g.R) ? 1.0f : 0.0f);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (kt0 + q >= g.KT) break;
+    u32x4 h, m, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      unsigned hh, mm, ll;
+      x6_split2(v[q][2 * e], v[q][2 * e + 1], hh, mm, ll);
+      h[e] = hh; m[e] = mm; l[e] = ll;
+    }
+    u32x4 *dst = (u32x4 *)(g.P + ((((long)(kt0 + q) * g.Ct + ct) * 3) * 64 + lane) * 8);
+    dst[0] = h; dst[64] = m; dst[128] = l;
+  }
+}
+
+// G[i, j] = sum_z part[z][i][j] (j < N), colsum[i] = sum_z part[z][i][N]; one thread per four columns
+__global__ __launch_bounds__(256) void x6_tn_reduce_kernel(const float *__restrict__ part, int nsplit, int M, int N, int ldp, float *__restrict__ G,
+                                                           long ldg, float *__restrict__ colsum) {
+  const int q4 = ldp >> 2;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)M * q4) return;
+  const int i = (int)(idx / q4), j = (int)(idx % q4) * 4;
+  if (j > N) return;
+  f32x4 acc = *(const f32x4 *)&part[(long)i * ldp + j];
+  for (int z = 1; z < nsplit; ++z) acc += *(const f32x4 *)&part[((long)z * M + i) * ldp + j];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (j + e < N) G[(long)i * ldg + j + e] = acc[e];
+    else if (j + e == N && colsum) colsum[i] = acc[e];
   }
 }
 
@@ -277,46 +363,111 @@ int launch_x6_split(const float *X, long ldx, const float *scale, long R, int K,
   return HN_OK;
 }
 
+static int x6_set_lds(const void *fn, int bytes) {
+  HN_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  return HN_OK;
+}
+
 int launch_gemm_nt_x6(const GemmX6Args &g_in, int variant, hipStream_t s) {
   GemmX6Args g = g_in;
   HN_REQUIRE(g.Ap && g.Wp && g.C, HN_E_NULL, "gemm_nt_x6: NULL operand");
   HN_REQUIRE((g.ldc & 3) == 0 && ((uintptr_t)g.C & 15) == 0 && (g.N & 3) == 0, HN_E_SHAPE, "gemm_nt_x6: output rows must be 16-byte aligned");
   const int bm = 256, bn = variant == 1 ? 128 : 256;
-#ifdef HN_GEMM_NT_BENCH
-  if (variant >= 10) {
-    const void *fns[] = {(const void *)gemm_nt_x6_kernel<4, 2, 2, 4, 3, 1>, (const void *)gemm_nt_x6_kernel<4, 2, 2, 4, 3, 2>,
-                         (const void *)gemm_nt_x6_kernel<4, 2, 2, 4, 3, 4>, (const void *)gemm_nt_x6_kernel<4, 2, 2, 4, 3, 15>,
-                         (const void *)gemm_nt_x6_kernel<4, 2, 2, 4, 3, 7>, (const void *)gemm_nt_x6_kernel<4, 2, 2, 4, 3, 6>};
-    for (const void *f : fns) HN_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 48 * 1024));
-  }
-#endif
   g.ntm = ceil_div(g.M, bm); g.ntn = ceil_div(g.N, bn);
   HN_REQUIRE(g.a_rt % (bm / 32) == 0 && g.a_rt >= g.ntm * (bm / 32) && g.w_rt % (bn / 32) == 0 && g.w_rt >= g.ntn * (bn / 32), HN_E_SHAPE,
              "gemm_nt_x6: plane images are not padded to the tile (%d, %d row tiles)", g.a_rt, g.w_rt);
   g.a_bytes = (size_t)g.KT * g.a_rt * 3072; g.w_bytes = (size_t)g.KT * g.w_rt * 3072;
   HN_REQUIRE(g.a_bytes < 0xfffffff0u && g.w_bytes < 0xfffffff0u, HN_E_UNSUPPORTED, "gemm_nt_x6: plane image beyond 4 GB");
+  g.nsplit = 1; g.kslice = g.KT;
   const long blocks = (long)ceil_div(g.ntm, 8) * 8 * g.ntn;
   KernelTimerScope timer("gemm_nt_x6", s);
   static bool attr = false;
   if (!attr) {
-    HN_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_nt_x6_kernel<4, 2, 2, 4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 48 * 1024));
-    HN_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_nt_x6_kernel<4, 2, 2, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 36 * 1024));
+    int rc;
+    if ((rc = x6_set_lds((const void *)gemm_nt_x6_kernel<4, 2, 2, 4, 3>, 3 * 48 * 1024)) != HN_OK) return rc;
+    if ((rc = x6_set_lds((const void *)gemm_nt_x6_kernel<4, 2, 2, 2, 2>, 2 * 36 * 1024)) != HN_OK) return rc;
+#ifdef HN_GEMM_NT_BENCH
+    if ((rc = x6_set_lds((const void *)gemm_nt_x6_kernel<4, 2, 2, 4, 3, 0, 1>, 3 * 48 * 1024)) != HN_OK) return rc;
+    if ((rc = x6_set_lds((const void *)gemm_nt_x6_kernel<4, 2, 2, 4, 3, 0, 2>, 3 * 48 * 1024)) != HN_OK) return rc;
+    if ((rc = x6_set_lds((const void *)gemm_nt_x6_kernel<4, 2, 2, 4, 3, 0, 4>, 3 * 48 * 1024)) != HN_OK) return rc;
+    if ((rc = x6_set_lds((const void *)gemm_nt_x6_kernel<4, 2, 2, 4, 3, 0, 15>, 3 * 48 * 1024)) != HN_OK) return rc;
+#endif
     attr = true;
   }
   switch (variant) {
     case 0: hipLaunchKernelGGL((gemm_nt_x6_kernel<4, 2, 2, 4, 3>), dim3((unsigned)blocks), dim3(512), 3 * 48 * 1024, s, g); break;
     case 1: hipLaunchKernelGGL((gemm_nt_x6_kernel<4, 2, 2, 2, 2>), dim3((unsigned)blocks), dim3(256), 2 * 36 * 1024, s, g); break;
 #ifdef HN_GEMM_NT_BENCH
-    case 10: hipLaunchKernelGGL((gemm_nt_x6_kernel<4, 2, 2, 4, 3, 1>), dim3((unsigned)blocks), dim3(512), 3 * 48 * 1024, s, g); break;
-    case 11: hipLaunchKernelGGL((gemm_nt_x6_kernel<4, 2, 2, 4, 3, 2>), dim3((unsigned)blocks), dim3(512), 3 * 48 * 1024, s, g); break;
-    case 12: hipLaunchKernelGGL((gemm_nt_x6_kernel<4, 2, 2, 4, 3, 4>), dim3((unsigned)blocks), dim3(512), 3 * 48 * 1024, s, g); break;
-    case 13: hipLaunchKernelGGL((gemm_nt_x6_kernel<4, 2, 2, 4, 3, 15>), dim3((unsigned)blocks), dim3(512), 3 * 48 * 1024, s, g); break;
-    case 14: hipLaunchKernelGGL((gemm_nt_x6_kernel<4, 2, 2, 4, 3, 7>), dim3((unsigned)blocks), dim3(512), 3 * 48 * 1024, s, g); break;
-    case 15: hipLaunchKernelGGL((gemm_nt_x6_kernel<4, 2, 2, 4, 3, 6>), dim3((unsigned)blocks), dim3(512), 3 * 48 * 1024, s, g); break;
+    case 10: hipLaunchKernelGGL((gemm_nt_x6_kernel<4, 2, 2, 4, 3, 0, 1>), dim3((unsigned)blocks), dim3(512), 3 * 48 * 1024, s, g); break;
+    case 11: hipLaunchKernelGGL((gemm_nt_x6_kernel<4, 2, 2, 4, 3, 0, 2>), dim3((unsigned)blocks), dim3(512), 3 * 48 * 1024, s, g); break;
+    case 12: hipLaunchKernelGGL((gemm_nt_x6_kernel<4, 2, 2, 4, 3, 0, 4>), dim3((unsigned)blocks), dim3(512), 3 * 48 * 1024, s, g); break;
+    case 13: hipLaunchKernelGGL((gemm_nt_x6_kernel<4, 2, 2, 4, 3, 0, 15>), dim3((unsigned)blocks), dim3(512), 3 * 48 * 1024, s, g); break;
 #endif
     default: return fail(HN_E_UNSUPPORTED, "gemm_nt_x6: variant %d", variant);
   }
   HN_LAUNCH_CHECK("gemm_nt_x6");
+  return HN_OK;
+}
+
+int launch_x6_split_t(const float *X, long ldx, long R, int C, int col_tile, int ones_col, unsigned short *P, hipStream_t s) {
+  HN_REQUIRE(X && P, HN_E_NULL, "x6_split_t: NULL operand");
+  X6SplitTArgs a{};
+  a.X = X; a.ldx = ldx; a.R = R; a.C = C; a.ones_col = ones_col; a.P = P;
+  a.Ct = x6_col_tiles(C + (ones_col >= 0 ? 1 : 0), col_tile);
+  HN_REQUIRE(ones_col < 0 || (ones_col >= C && ones_col < a.Ct * 32), HN_E_SHAPE, "x6_split_t: ones column %d", ones_col);
+  a.KT = (int)((R + 15) / 16);
+  KernelTimerScope timer("x6_split_t", s);
+  hipLaunchKernelGGL(x6_split_t_kernel, dim3((unsigned)a.Ct, (unsigned)ceil_div(a.KT, 16)), dim3(256), 0, s, a);
+  HN_LAUNCH_CHECK("x6_split_t");
+  return HN_OK;
+}
+
+// the TN tile: 256 (i) x 160 (j), 8 waves of 32 x 160 -- 773 + 1 columns are 25 tiles of 32 = 5 x 160 exactly
+constexpr int X6_TN_TI = 8, X6_TN_TJ = 5;
+bool gemm_tn_x6_eligible(long K, int M, int N) {
+  return gemm_x6_enabled() && K >= 16384 && M >= 256 && N >= 64 &&
+         (size_t)((K + 15) / 16) * x6_col_tiles(M, X6_TN_TI) * 3072 < 0xfffffff0u && (size_t)((K + 15) / 16) * x6_col_tiles(N + 1, X6_TN_TJ) * 3072 < 0xfffffff0u;
+}
+size_t gemm_tn_x6_image_bytes(long K, int cols, int col_tile) { return (size_t)((K + 15) / 16) * x6_col_tiles(cols, col_tile) * 3072; }
+
+// G (M, N) = A^T B and colsum (M) = column sums of A from the transposed images At (x6_col_tiles(M, 8) tiles) and Bt (x6_col_tiles(N + 1, 5)
+// tiles, ones column at N); `scratch` holds the k-slice partials
+int launch_gemm_tn_x6(const unsigned short *At, const unsigned short *Bt, long K, int M, int N, float *G, long ldg, float *colsum, float *scratch,
+                      size_t scratch_floats, hipStream_t s) {
+  HN_REQUIRE(At && Bt && G && scratch, HN_E_NULL, "gemm_tn_x6: NULL operand");
+  GemmX6Args g{};
+  g.Ap = At; g.a_rt = x6_col_tiles(M, X6_TN_TI); g.Wp = Bt; g.w_rt = x6_col_tiles(N + 1, X6_TN_TJ);
+  g.KT = (int)((K + 15) / 16);
+  g.M = M; g.N = g.w_rt * 32; g.ldc = g.w_rt * 32; g.C = scratch; g.alpha = 1.0f;
+  g.ntm = g.a_rt / X6_TN_TI; g.ntn = g.w_rt / X6_TN_TJ;
+  g.a_bytes = (size_t)g.KT * g.a_rt * 3072; g.w_bytes = (size_t)g.KT * g.w_rt * 3072;
+  HN_REQUIRE(g.a_bytes < 0xfffffff0u && g.w_bytes < 0xfffffff0u, HN_E_UNSUPPORTED, "gemm_tn_x6: plane image beyond 4 GB");
+  // one round of workgroups (1 per CU): as many slices as fit 256 workgroups, at least 16 k-steps each
+  const int tiles = g.ntm * g.ntn;
+  int nsplit = 256 / tiles;
+  if (nsplit < 1) nsplit = 1;
+  if (nsplit > g.KT / 16) nsplit = g.KT / 16 > 0 ? g.KT / 16 : 1;
+  while (nsplit > 1 && (size_t)nsplit * M * g.ldc > scratch_floats) --nsplit;
+  HN_REQUIRE((size_t)nsplit * M * g.ldc <= scratch_floats, HN_E_WORKSPACE, "gemm_tn_x6: scratch %zu floats < one partial", scratch_floats);
+  g.kslice = ceil_div(g.KT, nsplit);
+  g.nsplit = ceil_div(g.KT, g.kslice);
+  const int total = tiles * g.nsplit, blocks = ceil_div(total, 8) * 8;
+  constexpr int LDS = 3 * (X6_TN_TI * 3 + 16) * 1024;
+  static bool attr = false;
+  if (!attr) {
+    int rc = x6_set_lds((const void *)gemm_nt_x6_kernel<1, X6_TN_TJ, X6_TN_TI, 1, 3, 1>, LDS);
+    if (rc != HN_OK) return rc;
+    attr = true;
+  }
+  {
+    KernelTimerScope timer("gemm_tn_x6", s);
+    hipLaunchKernelGGL((gemm_nt_x6_kernel<1, X6_TN_TJ, X6_TN_TI, 1, 3, 1>), dim3((unsigned)blocks), dim3(512), LDS, s, g);
+    HN_LAUNCH_CHECK("gemm_tn_x6");
+  }
+  KernelTimerScope timer("x6_tn_reduce", s);
+  const long threads = (long)M * (g.ldc / 4);
+  hipLaunchKernelGGL(x6_tn_reduce_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, scratch, g.nsplit, M, N, (int)g.ldc, G, ldg, colsum);
+  HN_LAUNCH_CHECK("x6_tn_reduce");
   return HN_OK;
 }
 

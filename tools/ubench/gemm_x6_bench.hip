@@ -64,7 +64,7 @@ int main(int argc, char **argv) {
   split();
   CK(hipStreamSynchronize(s));
 
-  const int ids[] = {-1, 0, 1, 10, 11, 12, 13, 14, 15};      // -1: fp32 MFMA; 0 / 1: x6 variants; >= 10: ablations (wrong results)
+  const int ids[] = {-1, 0, 1, 10, 11, 12, 13};      // -1: fp32 MFMA; 0 / 1: x6 variants; >= 10: ablations (wrong results)
   const int nvar = sizeof(ids) / sizeof(ids[0]);
   auto run = [&](int v) { return ids[v] < 0 ? hn::launch_gemm_nt(g1, 0, s) : hn::launch_gemm_nt_x6(g2, ids[v], s); };
 
@@ -128,6 +128,66 @@ int main(int argc, char **argv) {
     CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     printf("round %d split (bag + weight): %8.1f us\n", r, ms * 1000 / iters);
+  }
+
+  // ---- the weight gradient G = dKV^T z: (M x K rows) ... here A2 = C0 (K2 = M rows x N columns: stands for dKV), B2 = A (the bag)
+  {
+    const int K2 = M, M2 = N, N2 = K;      // contraction over the bag's rows
+    float *G0, *G1, *cs0, *cs1, *scr;
+    const size_t scr_floats = (size_t)32 * ((size_t)M2 * 800 + M2) + (6u << 20);
+    CK(hipMalloc(&G0, (size_t)M2 * N2 * 4)); CK(hipMalloc(&G1, (size_t)M2 * N2 * 4)); CK(hipMalloc(&cs0, M2 * 4)); CK(hipMalloc(&cs1, M2 * 4));
+    CK(hipMalloc(&scr, scr_floats * 4));
+    unsigned short *At, *Bt;
+    CK(hipMalloc(&At, hn::gemm_tn_x6_image_bytes(K2, M2, 8))); CK(hipMalloc(&Bt, hn::gemm_tn_x6_image_bytes(K2, N2 + 1, 5)));
+    auto tn32 = [&]() { return hn::launch_gemm_tn_glds(C0, N, A, lda, G0, N2, M2, N2, K2, 1.0f, 0, scr, scr_floats, cs0, 0, s); };
+    auto splitA = [&]() { return hn::launch_x6_split_t(C0, N, K2, M2, 8, -1, At, s); };
+    auto splitB = [&]() { return hn::launch_x6_split_t(A, lda, K2, N2, 5, N2, Bt, s); };
+    auto tnx6 = [&]() { return hn::launch_gemm_tn_x6(At, Bt, K2, M2, N2, G1, N2, cs1, scr, scr_floats, s); };
+    if (!hn::gemm_tn_x6_eligible(K2, M2, N2)) { printf("TN: shape not eligible\n"); return 0; }
+    run(0);      // C0 = the fp32 product: the stand-in for dKV
+    CK(hipStreamSynchronize(s));
+    std::vector<float> hD((size_t)M * N), g0((size_t)M2 * N2), g1((size_t)M2 * N2), c0(M2), c1(M2);
+    CK(hipMemcpy(hD.data(), C0, hD.size() * 4, hipMemcpyDeviceToHost));
+    if (tn32() != 0 || splitA() != 0 || splitB() != 0 || tnx6() != 0) return 1;
+    CK(hipStreamSynchronize(s));
+    CK(hipMemcpy(g0.data(), G0, g0.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(g1.data(), G1, g1.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(c0.data(), cs0, M2 * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(c1.data(), cs1, M2 * 4, hipMemcpyDeviceToHost));
+    double w0 = 0, w1 = 0, q0 = 0, q1 = 0, sc = 0, cw0 = 0, cw1 = 0, csc = 0;
+    std::mt19937 r3(11);
+    const int NS = 600;
+    for (int t = 0; t < NS; ++t) {
+      const int i = t < 8 ? t * 131 % M2 : (int)(r3() % M2), j = t < 8 ? (t & 1 ? N2 - 1 - t : t) : (int)(r3() % N2);
+      double acc = 0.0;
+      for (int r = 0; r < K2; ++r) acc += (double)hD[(size_t)r * N + i] * (double)hA[(size_t)r * lda + j];
+      const double d0 = fabs(acc - g0[(size_t)i * N2 + j]), d1 = fabs(acc - g1[(size_t)i * N2 + j]);
+      w0 = std::max(w0, d0); w1 = std::max(w1, d1); q0 += d0 * d0; q1 += d1 * d1; sc = std::max(sc, fabs(acc));
+    }
+    for (int t = 0; t < 64; ++t) {
+      const int i = (int)(r3() % M2);
+      double acc = 0.0;
+      for (int r = 0; r < K2; ++r) acc += (double)hD[(size_t)r * N + i];
+      cw0 = std::max(cw0, fabs(acc - c0[i])); cw1 = std::max(cw1, fabs(acc - c1[i])); csc = std::max(csc, fabs(acc));
+    }
+    double md = 0; size_t nan = 0;
+    for (size_t i = 0; i < g0.size(); ++i) { if (!(g1[i] == g1[i])) ++nan; else md = std::max(md, (double)fabsf(g0[i] - g1[i])); }
+    printf("TN %d x %d over %d rows (|G|max %.3f): fp32-MFMA vs fp64 max %.3e rms %.3e | x6 max %.3e rms %.3e | x6 vs fp32 everywhere %.3e, %zu NaN\n",
+           M2, N2, K2, sc, w0, sqrt(q0 / NS), w1, sqrt(q1 / NS), md, nan);
+    printf("TN column sums (|cs|max %.3f): fp32-MFMA max err %.3e | x6 max err %.3e\n", csc, cw0, cw1);
+    auto timeit = [&](const char *name, auto fn) {
+      fn();
+      CK(hipEventRecord(e0, s));
+      for (int i = 0; i < iters; ++i) fn();
+      CK(hipEventRecord(e1, s));
+      CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      printf("  %-28s %8.1f us\n", name, ms * 1000 / iters);
+    };
+    for (int r = 0; r < rounds; ++r) {
+      timeit("TN fp32-MFMA (gemm_tn_glds)", tn32);
+      timeit("TN x6 (+ reduce)", tnx6);
+      timeit("split_t dKV (32768 x 1024)", splitA);
+      timeit("split_t bag (32768 x 773)", splitB);
+    }
   }
   return 0;
 }
