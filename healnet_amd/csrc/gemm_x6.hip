@@ -338,9 +338,14 @@ bool gemm_x6_enabled() {
   static const bool off = getenv("HN_NO_X6_GEMM") != nullptr;      // route switch (A/B): the fp32-MFMA kernels
   return !off;
 }
-// large row counts only: a 256 x 256 tile per workgroup, 1 workgroup per CU (below ~2 rounds of the chip the fp32 tilings win)
+static bool x6_forced() {
+  static const bool on = getenv("HN_FORCE_X6_GEMM") != nullptr;    // route switch (A/B tests): this route below its size gates
+  return on;
+}
+// large row counts only: a 256 x 256 tile per workgroup, 1 workgroup per CU (below one round of the chip the fp32 tilings win)
 bool gemm_nt_x6_eligible(long M, int N, int K) {
-  return gemm_x6_enabled() && M >= 16384 && N >= 256 && N % 4 == 0 && K >= 64 && x6_plane_bytes(M, K, X6_ROW_TILE) < 0xfffffff0u;
+  const bool big = x6_forced() ? (M >= 64 && N >= 32 && K >= 8) : (M >= 16384 && N >= 256 && K >= 64);
+  return gemm_x6_enabled() && big && N % 4 == 0 && x6_plane_bytes(M, K, X6_ROW_TILE) < 0xfffffff0u;
 }
 
 size_t x6_plane_bytes(long rows, int K, int row_tile) {
@@ -425,7 +430,8 @@ int launch_x6_split_t(const float *X, long ldx, long R, int C, int col_tile, int
 // the TN tile: 256 (i) x 160 (j), 8 waves of 32 x 160 -- 773 + 1 columns are 25 tiles of 32 = 5 x 160 exactly
 constexpr int X6_TN_TI = 8, X6_TN_TJ = 5;
 bool gemm_tn_x6_eligible(long K, int M, int N) {
-  return gemm_x6_enabled() && K >= 16384 && M >= 256 && N >= 64 &&
+  const bool big = x6_forced() ? (K >= 64 && M >= 32 && N >= 8) : (K >= 16384 && M >= 256 && N >= 64);
+  return gemm_x6_enabled() && big &&
          (size_t)((K + 15) / 16) * x6_col_tiles(M, X6_TN_TI) * 3072 < 0xfffffff0u && (size_t)((K + 15) / 16) * x6_col_tiles(N + 1, X6_TN_TJ) * 3072 < 0xfffffff0u;
 }
 size_t gemm_tn_x6_image_bytes(long K, int cols, int col_tile) { return (size_t)((K + 15) / 16) * x6_col_tiles(cols, col_tile) * 3072; }
