@@ -62,6 +62,7 @@ ALGO_FLOPS_CORE_PER_SAMPLE = 4.0 * L_C * N_IMG * DIM_HEAD * HEADS        # 13.15
 # the softmax-denominator ones column, 3 idle) -> 2.88 GF (contraction dims 12 / 16, not 64 / 64)
 EXEC_FLOPS_CORE_PER_SAMPLE = 2.0 * L_C * N_IMG * (QK_DIM + DP) * HEADS
 PEAK_FP32_MFMA_TFLOPS = 157.3                                            # MI355X_MICROARCH.md chip table
+PEAK_BF16_MFMA_TFLOPS = 2500.0                                           # dense bf16 MFMA, same table (16 x the fp32 pipe)
 
 
 def exec_flops_forward_per_sample(depth=3, l_d=128):
@@ -373,7 +374,8 @@ def train_step_record(dev, rank, world, distributed, barrier, steps, warmup):
     # GEMMs -- half of the step's executed FLOPs -- recorded on the launch stream inside the training forward / backward)
     fwd_f, bwd_f, gemm_f = exec_flops_train_step_per_sample()
     per_launch = 2.0 * (b * TRAIN_SHAPES[1][0]) * (TRAIN_SHAPES[1][1] + 5) * 1024        # 2 M K N of either GEMM (D = 768 + 5)
-    with KernelTimers(["gemm_nt_glds", "gemm_tn_glds"], 3 * steps + 8) as kt:
+    timed_names = ["gemm_nt_x6", "gemm_tn_x6", "x6_split", "x6_split_t", "x6_tn_reduce", "gemm_nt_glds", "gemm_tn_glds"]
+    with KernelTimers(timed_names, 4 * steps + 8) as kt:
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -382,25 +384,46 @@ def train_step_record(dev, rank, world, distributed, barrier, steps, warmup):
         dt_instr = time.perf_counter() - t0
     avg = kt.averages_ms()
     step_s = dt / steps
+    x6 = avg["gemm_nt_x6"][1] > 0
     roof = {"bound": "mfma", "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "flops_executed_per_step": (fwd_f + bwd_f) * b,
             "achieved": round((fwd_f + bwd_f) * b / step_s / 1e12, 2),
             "frac": round((fwd_f + bwd_f) * b / step_s / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
             "forward_flops": fwd_f * b, "backward_flops": bwd_f * b,
             "dominant_kernels": {}, "instrumented_ms_per_step": round(dt_instr / steps * 1e3, 4),
-            "timing": "hipEvent pairs on the launch stream around every launch of the two kernels (hn_set_kernel_timers), in an "
+            "patch_bag_gemm_route": "x6 (fp32-exact on the bf16 pipe, gemm_x6.hip)" if x6 else "fp32 MFMA (gemm_nt.hip)",
+            "timing": "hipEvent pairs on the launch stream around every launch of the patch-bag GEMM classes (hn_set_kernel_timers), in an "
                       "instrumented replay of the same K steps right after the timed region",
-            "note": "frac = executed matrix FLOPs of the whole step (forward with tape + backward: exec_flops_train_step_per_sample, "
-                    "real dimensions) / driver-timed step / fp32 MFMA peak; the survival loss, L1 + Adam sweep, LayerNorm / softmax "
-                    "vector work and the all-reduce are time without matrix FLOPs"}
-    for name, what in (("gemm_nt_glds", "hn::gemm_nt_glds_kernel (bag K/V projection, forward)"),
-                       ("gemm_tn_glds", "hn::gemm_tn_glds_kernel (bag weight gradient G = dKV^T z, backward)")):
-        ms, n = avg[name]
-        roof["dominant_kernels"][name] = {
-            "kernel": what, "launches_timed": n, "launches_per_step": 3, "flops_per_launch": per_launch,
-            "avg_launch_ms": None if ms is None else round(ms, 4),
-            "achieved": None if not ms else round(per_launch / (ms * 1e-3) / 1e12, 2),
-            "frac": None if not ms else round(per_launch / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
+            "note": "frac = fp32 matrix FLOPs the step RETURNS (forward with tape + backward: exec_flops_train_step_per_sample, real "
+                    "dimensions) / driver-timed step / fp32 MFMA peak; the survival loss, L1 + Adam sweep, LayerNorm / softmax vector work "
+                    "and the all-reduce are time without matrix FLOPs.  On the x6 route the two patch-bag GEMMs (half of those FLOPs) run "
+                    "on the bf16 pipe -- each fp32 product as six bf16 products of three-plane operands, error not above the fp32 MFMA's "
+                    "(tests/test_gpu_x6.py) -- so this figure is a rate of fp32 results, no longer a utilisation of the fp32 pipe; the "
+                    "per-kernel entries price those launches against the bf16 peak with the 6 x FLOPs they execute"}
+    if x6:
+        kp = (TRAIN_SHAPES[1][1] + 5 + 15) // 16 * 16
+        exec_nt = 6 * 2.0 * (b * TRAIN_SHAPES[1][0]) * kp * 1024                         # 6 products over the padded contraction
+        exec_tn = 6 * 2.0 * (b * TRAIN_SHAPES[1][0]) * 800 * 1024                        # 773 + ones column -> 25 tiles of 32
+        for name, what, ex in (("gemm_nt_x6", "hn::gemm_nt_x6_kernel<4,2,2,4,3,0> (bag K/V projection, forward)", exec_nt),
+                               ("gemm_tn_x6", "hn::gemm_nt_x6_kernel<1,5,8,1,3,1> (bag weight gradient G = dKV^T z + colsum, backward, split-k)", exec_tn)):
+            ms, n = avg[name]
+            roof["dominant_kernels"][name] = {
+                "kernel": what, "launches_timed": n, "launches_per_step": 3, "fp32_flops_returned_per_launch": per_launch,
+                "bf16_flops_executed_per_launch": ex, "avg_launch_ms": None if ms is None else round(ms, 4),
+                "fp32_equivalent_tflops": None if not ms else round(per_launch / (ms * 1e-3) / 1e12, 2),
+                "achieved": None if not ms else round(ex / (ms * 1e-3) / 1e12, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s (bf16 MFMA)",
+                "frac": None if not ms else round(ex / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)}
+        roof["x6_image_kernels_us_per_step"] = {
+            k: (None if avg[k][0] is None else round(avg[k][0] * 1e3 * avg[k][1] / steps, 1)) for k in ("x6_split", "x6_split_t", "x6_tn_reduce")}
+    else:
+        for name, what in (("gemm_nt_glds", "hn::gemm_nt_glds_kernel (bag K/V projection, forward)"),
+                           ("gemm_tn_glds", "hn::gemm_tn_glds_kernel (bag weight gradient G = dKV^T z, backward)")):
+            ms, n = avg[name]
+            roof["dominant_kernels"][name] = {
+                "kernel": what, "launches_timed": n, "launches_per_step": 3, "flops_per_launch": per_launch,
+                "avg_launch_ms": None if ms is None else round(ms, 4),
+                "achieved": None if not ms else round(per_launch / (ms * 1e-3) / 1e12, 2),
+                "frac": None if not ms else round(per_launch / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
     rec["roofline"] = roof
     # forward (tape-recording) share of the step
     with torch.enable_grad():
@@ -485,15 +508,27 @@ def configs_record(dev, steps=20, warmup=3):
             assert torch.isfinite(res).all(), name
             # instrumented replay
             if kind == "bag":
-                with KernelTimers(["gemm_nt_glds"], depth * n_dom * steps + 8) as kt:
+                with KernelTimers(["gemm_nt_x6", "gemm_nt_glds"], depth * n_dom * steps + 8) as kt:
                     for _ in range(steps):
                         model(list(ins))
                     torch.cuda.synchronize(dev)
-                avg_ms, n_timed = kt.averages_ms()["gemm_nt_glds"]
-                work = 2.0 * b * n_tok * d_ctx * 2 * HEADS * DIM_HEAD
-                entry_k = {"kernel": "hn::gemm_nt_glds_kernel (patch-bag K/V projection, LDS-DMA operands)", "launches_per_forward": depth * n_dom,
-                           "work_per_launch": work, "work_unit": "executed fp32 MFMA FLOPs",
-                           "formula": "2 (b N) D (2 inner), N = 4096, D = 773, inner = 512", "bound": "mfma", "peak": PEAK_FP32_MFMA_TFLOPS * 1e12}
+                avgs = kt.averages_ms()
+                if avgs["gemm_nt_x6"][1] > 0:      # the default route: fp32-exact on the bf16 pipe (gemm_x6.hip)
+                    avg_ms, n_timed = avgs["gemm_nt_x6"]
+                    kp = (d_ctx + 15) // 16 * 16
+                    work = 6 * 2.0 * b * n_tok * kp * 2 * HEADS * DIM_HEAD
+                    entry_k = {"kernel": "hn::gemm_nt_x6_kernel (patch-bag K/V projection, fp32-exact on the bf16 pipe: 3 bf16 planes per "
+                                         "operand, 6 products per fp32 product; HN_NO_X6_GEMM=1 for the fp32-MFMA kernel)",
+                               "launches_per_forward": depth * n_dom, "work_per_launch": work, "work_unit": "executed bf16 MFMA FLOPs",
+                               "formula": "6 x 2 (b N) Dp (2 inner), N = 4096, Dp = 784 (773 padded to 16), inner = 512", "bound": "mfma (bf16 pipe)",
+                               "peak": PEAK_BF16_MFMA_TFLOPS * 1e12,
+                               "fp32_equivalent_per_s_note": "2 (b N) D (2 inner) / time: the fp32 product this launch returns"}
+                else:
+                    avg_ms, n_timed = avgs["gemm_nt_glds"]
+                    work = 2.0 * b * n_tok * d_ctx * 2 * HEADS * DIM_HEAD
+                    entry_k = {"kernel": "hn::gemm_nt_glds_kernel (patch-bag K/V projection, LDS-DMA operands)", "launches_per_forward": depth * n_dom,
+                               "work_per_launch": work, "work_unit": "executed fp32 MFMA FLOPs",
+                               "formula": "2 (b N) D (2 inner), N = 4096, D = 773, inner = 512", "bound": "mfma", "peak": PEAK_FP32_MFMA_TFLOPS * 1e12}
             else:
                 events = HipEvents(depth * steps)
                 prof = _capi.Profile(ev_start=events.start, ev_stop=events.stop, n_events=0, n_recorded=0)

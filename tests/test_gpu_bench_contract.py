@@ -33,13 +33,18 @@ def test_bench_prints_one_contract_line():
     assert t["batch_per_gpu"] == 8 and t["world_size"] == 1 and t["unit"] == "samples/s" and t["steps"] == 3
     assert abs(t["value"] - 8 * 1000.0 / t["ms_per_step"]) <= 1e-3 * t["value"] and t["final_loss"] == t["final_loss"]
     assert sum(t["allreduce_buckets_floats"]) == t["gradient_floats"]
-    tr = t["roofline"]                                    # the step on the fp32 MFMA roof + its two dominant kernels, timed in the same run
-    assert tr["bound"] == "mfma" and tr["peak"] == 157.3 and 0.2 < tr["frac"] <= 1.0
+    tr = t["roofline"]                                    # the step's rate of fp32 results + its two dominant kernels, timed in the same run
+    # (the two patch-bag GEMMs run fp32-exact on the bf16 pipe -- gemm_x6.hip -- so `frac` is a rate against the fp32 MFMA peak, not a
+    # utilisation of that pipe; the kernels themselves are priced against the bf16 peak with the 6 x FLOPs they execute)
+    assert tr["bound"] == "mfma" and tr["peak"] == 157.3 and 0.2 < tr["frac"] <= 1.5
     assert abs(tr["frac"] - tr["flops_executed_per_step"] / (t["ms_per_step"] * 1e-3) / 1e12 / 157.3) < 2e-3
-    for name in ("gemm_nt_glds", "gemm_tn_glds"):
+    assert tr["patch_bag_gemm_route"].startswith("x6")
+    for name in ("gemm_nt_x6", "gemm_tn_x6"):
         k = tr["dominant_kernels"][name]
-        assert k["launches_timed"] == 3 * t["steps"] and 0.5 < k["frac"] <= 1.0, (name, k)
-        assert abs(k["frac"] - k["flops_per_launch"] / (k["avg_launch_ms"] * 1e-3) / 1e12 / 157.3) < 2e-3
+        assert k["launches_timed"] == 3 * t["steps"] and 0.3 < k["frac"] <= 1.0 and k["peak"] == 2500.0, (name, k)
+        assert abs(k["frac"] - k["bf16_flops_executed_per_launch"] / (k["avg_launch_ms"] * 1e-3) / 1e12 / 2500.0) < 2e-3
+        assert k["bf16_flops_executed_per_launch"] >= 6 * k["fp32_flops_returned_per_launch"]
+        assert k["fp32_equivalent_tflops"] > 157.3, (name, k)      # what the route is for: more fp32 results per second than the fp32 pipe's peak
     assert len(j["build_id"]) == 16
     sm = j["staged_models"]                               # the reference's tuned TCGA shapes, run as zero-padded images
     assert set(sm["configs"]) == {"blca", "brca", "kirp", "ucec"} and sm["unit"] == "ms"
@@ -54,7 +59,7 @@ def test_bench_prints_one_contract_line():
         assert k["launches_timed"] == k["launches_per_forward"] * c["steps"], (name, k)
         assert 0.2 < k["frac"] <= 1.0 and abs(k["frac"] - k["work_per_launch"] / (k["avg_launch_ms"] * 1e-3) / k["peak"]) < 2e-3, (name, k)
         assert 0.1 < k["share_of_forward"] <= 1.0, (name, k)
-    assert cf["cfg3"]["dominant_kernel"]["bound"].startswith("valu") and cf["cfg4"]["dominant_kernel"]["bound"] == "mfma"
+    assert cf["cfg3"]["dominant_kernel"]["bound"].startswith("valu") and cf["cfg4"]["dominant_kernel"]["bound"].startswith("mfma")
     cl = t["cluster"]                                     # the cluster-mode failure signal of the step (include/healnet_hip.h, ABI v10)
     assert cl["lost"] == 0 and cl["fallbacks"] == 0 and cl["enabled"] and cl["optimizer_steps_skipped"] == 0
 

@@ -85,3 +85,13 @@ def test_layer_chain_holds_its_attention_phase_in_registers(meta):
     assert len(hot) == 1
     scratch, vgprs, spilled = hot[0]
     assert scratch == 0 and spilled == 0 and vgprs <= 256, hot[0]
+
+
+def test_x6_gemms_keep_accumulators_and_fragments_in_registers(meta):
+    """gemm_nt_x6_kernel (gemm_x6.hip): 512-thread workgroups at one per CU = two waves per SIMD, at most 256 VGPRs; 128 (NT) / 80
+    (TN) accumulator registers and the double-buffered fragment sets must not spill -- a scratch access inside the k-loop would sit
+    behind the LDS-DMA ring (the kernel's waits on it are counted by hand)."""
+    hot = {k: v for k, v in meta["gemm_x6.hip"].items() if "gemm_nt_x6_kernel" in k}
+    assert len(hot) >= 3, sorted(hot)
+    for k, (scratch, vgprs, spilled) in hot.items():
+        assert scratch == 0 and spilled == 0 and vgprs <= 256, (k, scratch, vgprs, spilled)
