@@ -762,13 +762,15 @@ int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float *x_out
     const bool dq_direct = !no_dq_direct && pl.nsplit_bwd == 1 && !attn_bwd_dq_lds_eligible(ba);
     if (dq_direct) { ba.dQfinal = bp.dQ; ba.dq_ld = inner; ba.dq_pitch = dh; ba.dq_width = dh; ba.dq_scale = two_scale; }
     int rc_pair = HN_OK;
+    bool dkv_planes = false;       // the dK/dV kernel wrote the transposed three-plane image itself (dKV is then not materialised)
     if (!has_ctx && launch_attn_bwd_self_pair(ba, dh, inner, s, &rc_pair)) {      // latent self-attention: both products in one launch
       if (rc_pair != HN_OK) return rc_pair;
       if (!dq_direct && (rc = launch_dq_reduce(bp.dQpart, pl.nsplit_bwd, b, h, L, pl.Lp, pl.dp, dh, two_scale, bp.dQ, inner, dh, s)) != HN_OK) return rc;
     } else {
       if ((rc = launch_attn_bwd_dq(ba, s)) != HN_OK) return rc;
       if (!dq_direct && (rc = launch_dq_reduce(bp.dQpart, pl.nsplit_bwd, b, h, L, pl.Lp, pl.dp, dh, two_scale, bp.dQ, inner, dh, s)) != HN_OK) return rc;
-      if ((rc = launch_attn_bwd_dkv(ba, dh, inner, s)) != HN_OK) return rc;
+      if (has_ctx && bp.dkv3 && ext && ext->ctx3t) { ba.dkv3 = bp.dkv3; ba.dkv3_ct = x6_col_tiles(2 * inner, 8); }
+      if ((rc = launch_attn_bwd_dkv(ba, dh, inner, s, &dkv_planes)) != HN_OK) return rc;
     }
     const long krows = (long)b * pl.N;
     if (has_ctx) {   // gradients of to_kv and of the context LayerNorm affine from G = dKV^T z and colsum(dKV)
@@ -777,7 +779,7 @@ int attn_bwd_impl(const hn_attn_params *p, const float *x_in, const float *x_out
         // its ones column: colsum(dKV) is one more column of the product) once per backward by the caller
         const long kdim = pl.D > (int)p->query_dim ? pl.D : (long)p->query_dim;
         const size_t red_floats = reduce_scratch_floats(2L * inner * kdim, (int)(2 * inner > p->query_dim ? 2 * inner : p->query_dim));
-        if ((rc = launch_x6_split_t(bp.dKV, 2 * inner, krows, 2 * inner, 8, -1, bp.dkv3, s)) != HN_OK) return rc;
+        if (!dkv_planes && (rc = launch_x6_split_t(bp.dKV, 2 * inner, krows, 2 * inner, 8, -1, bp.dkv3, s)) != HN_OK) return rc;
         if ((rc = launch_gemm_tn_x6(bp.dkv3, ext->ctx3t, krows, 2 * inner, pl.D, bp.G, pl.D, bp.cs, bp.red, red_floats, s)) != HN_OK) return rc;
       } else {
         GemmExArgs e = gex(bp.dKV, 1, 2 * inner, ctx, 1, ld_ctx, bp.G, pl.D, 2 * inner, pl.D, (int)krows, 0);

@@ -482,6 +482,14 @@ __device__ __forceinline__ void dkv_glds16(const i32x4 &rsrc, unsigned lds_byte,
                : "s"(lds_byte), "v"(voffset), "s"(rsrc), "s"(soffset)
                : "memory", "m0");
 }
+// two fp32 -> three bf16 pairs (h, m, l) with x = h + m + l exactly (gemm_x6.hip's split)
+__device__ __forceinline__ void dkv_split2(float a, float b, unsigned &h, unsigned &m, unsigned &l) {
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(h) : "v"(a), "v"(b));
+  const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(m) : "v"(ra), "v"(rb));
+  const float sa = ra - __uint_as_float(m << 16), sb = rb - __uint_as_float(m & 0xffff0000u);
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(l) : "v"(sa), "v"(sb));
+}
 template <int N> __device__ __forceinline__ void dkv_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <int TPW>
@@ -627,7 +635,36 @@ __device__ __forceinline__ void attn_bwd_dkv_lds_body(const AttnBwdArgs &a, int 
       }
     }
   }
-  // accumulator e, element r: token 4 g + r, column 4 j + e.  Compact (b*N, 2*inner) layout: [dK | dV]
+  // accumulator e, element r: token 4 g + r, column 4 j + e.
+  if (TPW == 2 && a.dkv3 != nullptr) {
+    // Straight into the transposed three-plane image of gemm_x6.hip (the weight-gradient product G = dKV^T z contracts over the
+    // tokens): a fragment slot is one column's eight k-values of a 16-token k-step; in PAIR order (x6_pair_order, common.h) those
+    // are this lane's rows 4 g .. 4 g + 3 of BOTH its tiles, so a lane writes whole 16-byte slots and dKV itself is never stored.
+    if (tile0 + 1 >= ntiles || 4 * j >= dh) return;
+    const long kt = (((long)bi * a.N) >> 4) + tile0 + (g >> 1);
+    const int slot = 32 * (g & 1);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {               // dK columns, then dV columns
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int col = half * inner + hi * dh + 4 * j + e;
+        unsigned hh[4], mm[4], ll[4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const f32x4 v = half == 0 ? dK[u][e] * a.dk_scale : dV[u][e];
+          dkv_split2(v[0], v[1], hh[2 * u], mm[2 * u], ll[2 * u]);
+          dkv_split2(v[2], v[3], hh[2 * u + 1], mm[2 * u + 1], ll[2 * u + 1]);
+        }
+        typedef unsigned dkv_u32x4 __attribute__((ext_vector_type(4)));
+        dkv_u32x4 *dst = (dkv_u32x4 *)(a.dkv3 + ((((kt * a.dkv3_ct + (col >> 5)) * 3) * 64) + slot + (col & 31)) * 8);
+        dst[0] = (dkv_u32x4){hh[0], hh[1], hh[2], hh[3]};
+        dst[64] = (dkv_u32x4){mm[0], mm[1], mm[2], mm[3]};
+        dst[128] = (dkv_u32x4){ll[0], ll[1], ll[2], ll[3]};
+      }
+    }
+    return;
+  }
+  // Compact (b*N, 2*inner) layout: [dK | dV]
 #pragma unroll
   for (int u = 0; u < TPW; ++u) {
     if (tile0 + u >= ntiles) continue;
@@ -691,7 +728,9 @@ bool launch_attn_bwd_self_pair(const AttnBwdArgs &a, int dh, int inner, hipStrea
   return true;
 }
 
-int launch_attn_bwd_dkv(const AttnBwdArgs &a, int dh, int inner, hipStream_t s) {
+int launch_attn_bwd_dkv(const AttnBwdArgs &a_in, int dh, int inner, hipStream_t s, bool *wrote_planes) {
+  AttnBwdArgs a = a_in;
+  if (wrote_planes) *wrote_planes = false;
   HN_REQUIRE(a.dp == 16 || a.dp == 32 || a.dp == 64 || a.dp == 128, HN_E_UNSUPPORTED, "attn_bwd_dkv: dp=%d", a.dp);
   const int ntiles = ceil_div(a.N, 16);
   dim3 grid(ceil_div(ntiles, 4), a.b * a.h), block(256);
@@ -701,11 +740,19 @@ int launch_attn_bwd_dkv(const AttnBwdArgs &a, int dh, int inner, hipStream_t s) 
   auto al16p = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
   if (!no_lds && a.dp == 64 && a.Lq <= 128 && a.drop.thr == 0 && dh % 4 == 0 && inner % 4 == 0 && a.ldq % 4 == 0 && a.lddo % 4 == 0 &&
       a.q_b % 4 == 0 && a.q_h % 4 == 0 && a.do_b % 4 == 0 && a.do_h % 4 == 0 && al16p(a.Q) && al16p(a.dO) && al16p(a.dKV) && a.N >= 64) {
+    // the transposed three-plane image instead of dKV: two token tiles per wave, whole pairs inside every sample, every image row
+    // (column of dKV) owned by some lane -- else the caller's x6_split_t builds it from the compact layout
+    static const bool no_planes = getenv("HN_NO_DKV_PLANES") != nullptr;      // route switch (A/B)
+    const bool planes = a.dkv3 != nullptr && !no_planes && ntiles >= 64 && a.N % 32 == 0 && (2 * inner) % 256 == 0 && a.h * dh == inner &&
+                        a.dkv3_ct * 32 == 2 * inner;
+    if (!planes) a.dkv3 = nullptr;
     if (ntiles >= 64) hipLaunchKernelGGL(attn_bwd_dkv_lds_kernel<2>, dim3(ceil_div(ntiles, 8), a.b * a.h), block, 0, s, a, ntiles, dh, inner);
     else hipLaunchKernelGGL(attn_bwd_dkv_lds_kernel<1>, dim3(ceil_div(ntiles, 4), a.b * a.h), block, 0, s, a, ntiles, dh, inner);
     HN_LAUNCH_CHECK("attn_bwd_dkv_lds");
+    if (wrote_planes) *wrote_planes = planes;
     return HN_OK;
   }
+  a.dkv3 = nullptr;
 #define HN_DKV(DT_)                                                                                              \
   if (a.drop.thr != 0) hipLaunchKernelGGL((attn_bwd_dkv_kernel<DT_, true>), grid, block, 0, s, a, ntiles, dh, inner); \
   else hipLaunchKernelGGL((attn_bwd_dkv_kernel<DT_, false>), grid, block, 0, s, a, ntiles, dh, inner);

@@ -336,6 +336,11 @@ bool gemm_x6_enabled();                        // route switch HN_NO_X6_GEMM=1: 
 bool gemm_nt_x6_eligible(long M, int N, int K);
 static inline int x6_col_tiles(int cols, int pad) { return ((cols + 31) / 32 + pad - 1) / pad * pad; }
 // transposed images (rows of the image = columns of X, k = row index of X) and the long-contraction TN product on them
+// pair order of the k index (rows of X) inside a transposed image: the 32 rows of a PAIR of 16-row tiles are dealt to two k-steps
+// so that lane group g of the attention backward (rows 4 g .. 4 g + 3 of each tile) owns whole 16-byte fragment slots:
+// k-step 2 P + gg, half h, element e  <-  row 32 P + 8 gg + 4 h + (e & 3) + 16 (e >> 2).  Any order works as long as both operands of
+// a product use the same one; images of R % 32 == 0 rows are always built in pair order (x6_pair_order).
+static inline bool x6_pair_order(long R) { return R % 32 == 0; }
 int launch_x6_split_t(const float *X, long ldx, long R, int C, int col_tile, int ones_col, unsigned short *P, hipStream_t s);
 bool gemm_tn_x6_eligible(long K, int M, int N);
 size_t gemm_tn_x6_image_bytes(long K, int cols, int col_tile);
@@ -710,6 +715,8 @@ struct AttnBwdArgs {
   const float *delta;                            // (b, h, Lq): sum_d dO * O
   float *dQpart;                                 // (b, h, nsplit, Lp, dp)
   float *dKV; float dk_scale;                    // dkv kernel: compact (b*N, 2*inner) output
+  unsigned short *dkv3; int dkv3_ct;             // ... or (LDS kernel, two token tiles per wave) straight into the transposed three-plane image of
+                                                 // gemm_x6.hip (dkv3_ct column tiles, k-steps in PAIR order: x6_pair_row), dKV itself not written
   int b, h, Lq, Lp, N, dp, nsplit, chunk;
   DropCfg drop;                                  // the forward's dropout on the probabilities (thr == 0: off)
   int drop_rowsum;                               // shared-context binding under dropout: V carries a ones column dp-1
@@ -725,7 +732,7 @@ bool attn_bwd_dq_lds_eligible(const AttnBwdArgs &a);
 int launch_attn_bwd_dq_lds(const AttnBwdArgs &a, hipStream_t s);
 int launch_dq_reduce(const float *part, int nsplit, int b, int h, int L, int Lp, int dp, int width, float scale, float *out,
                      int ld_out, int head_pitch, hipStream_t s);
-int launch_attn_bwd_dkv(const AttnBwdArgs &a, int dh, int inner, hipStream_t s);
+int launch_attn_bwd_dkv(const AttnBwdArgs &a, int dh, int inner, hipStream_t s, bool *wrote_planes = nullptr);
 // latent self-attention: dQ and dK/dV side by side in one launch (attention_bwd.hip); false = not this shape, nothing launched
 bool launch_attn_bwd_self_pair(const AttnBwdArgs &a, int dh, int inner, hipStream_t s, int *rc_out);
 int launch_rowdot_heads(const float *X, int ldx, int xpitch, const float *Y, int ldy, int ypitch, int h, int L, int width,

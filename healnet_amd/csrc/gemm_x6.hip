@@ -285,6 +285,7 @@ struct X6SplitTArgs {
   const float *X; long ldx;
   long R; int C;                      // X is (R, C); the image has KT = ceil(R / 16) k-steps of Ct column tiles
   int Ct, KT, ones_col;               // ones_col >= C: that image row is all ones (h = 1, m = l = 0) for r < R; -1: none
+  int pair;                           // k index in pair order (x6_pair_order, common.h)
   unsigned short *P;
 };
 
@@ -298,9 +299,12 @@ __global__ __launch_bounds__(256) void x6_split_t_kernel(X6SplitTArgs g) {
   float v[4][8];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const long r0 = (long)(kt0 + q) * 16 + (lane >> 5) * 8;
+    const int kt = kt0 + q, h = lane >> 5;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[q][e] = (live && r0 + e < g.R) ? x[(r0 + e) * g.ldx] : ((ones && r0 + e < g.R) ? 1.0f : 0.0f);
+    for (int e = 0; e < 8; ++e) {
+      const long r = g.pair ? (long)(kt >> 1) * 32 + 8 * (kt & 1) + 4 * h + (e & 3) + 16 * (e >> 2) : (long)kt * 16 + h * 8 + e;
+      v[q][e] = (live && r < g.R) ? x[r * g.ldx] : ((ones && r < g.R) ? 1.0f : 0.0f);
+    }
   }
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -421,6 +425,7 @@ int launch_x6_split_t(const float *X, long ldx, long R, int C, int col_tile, int
   a.Ct = x6_col_tiles(C + (ones_col >= 0 ? 1 : 0), col_tile);
   HN_REQUIRE(ones_col < 0 || (ones_col >= C && ones_col < a.Ct * 32), HN_E_SHAPE, "x6_split_t: ones column %d", ones_col);
   a.KT = (int)((R + 15) / 16);
+  a.pair = x6_pair_order(R) ? 1 : 0;
   KernelTimerScope timer("x6_split_t", s);
   hipLaunchKernelGGL(x6_split_t_kernel, dim3((unsigned)a.Ct, (unsigned)ceil_div(a.KT, 16)), dim3(256), 0, s, a);
   HN_LAUNCH_CHECK("x6_split_t");
