@@ -639,15 +639,21 @@ __device__ __forceinline__ void attn_bwd_dkv_lds_body(const AttnBwdArgs &a, int 
   if (TPW == 2 && a.dkv3 != nullptr) {
     // Straight into the transposed three-plane image of gemm_x6.hip (the weight-gradient product G = dKV^T z contracts over the
     // tokens): a fragment slot is one column's eight k-values of a 16-token k-step; in PAIR order (x6_pair_order, common.h) those
-    // are this lane's rows 4 g .. 4 g + 3 of BOTH its tiles, so a lane writes whole 16-byte slots and dKV itself is never stored.
-    if (tile0 + 1 >= ntiles || 4 * j >= dh) return;
-    const long kt = (((long)bi * a.N) >> 4) + tile0 + (g >> 1);
-    const int slot = 32 * (g & 1);
+    // are this lane's rows 4 g .. 4 g + 3 of BOTH its tiles, so a lane owns whole 16-byte slots and dKV itself is never stored.
+    // The slots of a wave (2 k-steps x 2 column tiles x 3 planes per half = twelve 1 KB fragments) are assembled in the wave's own
+    // 12 KB of the Q / dO images' LDS (free behind the barrier) and leave as full, lane-linear 1 KB stores: written slot by slot
+    // from the accumulator layout the same bytes were 64 partial lines per instruction and cost the kernel 55 us of 145.
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (tile0 + 1 >= ntiles) return;
+    typedef unsigned dkv_u32x4 __attribute__((ext_vector_type(4)));
+    unsigned char *stg = (unsigned char *)lds + wave * 12288;
+    const long ktb = (((long)bi * a.N) >> 4) + tile0;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {               // dK columns, then dV columns
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int col = half * inner + hi * dh + 4 * j + e;
+        const int c = 4 * j + e;                          // column within the head: 0 .. 63
         unsigned hh[4], mm[4], ll[4];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -655,12 +661,20 @@ __device__ __forceinline__ void attn_bwd_dkv_lds_body(const AttnBwdArgs &a, int 
           dkv_split2(v[0], v[1], hh[2 * u], mm[2 * u], ll[2 * u]);
           dkv_split2(v[2], v[3], hh[2 * u + 1], mm[2 * u + 1], ll[2 * u + 1]);
         }
-        typedef unsigned dkv_u32x4 __attribute__((ext_vector_type(4)));
-        dkv_u32x4 *dst = (dkv_u32x4 *)(a.dkv3 + ((((kt * a.dkv3_ct + (col >> 5)) * 3) * 64) + slot + (col & 31)) * 8);
+        dkv_u32x4 *dst = (dkv_u32x4 *)(stg + ((((g >> 1) * 2 + (c >> 5)) * 3) * 64 + 32 * (g & 1) + (c & 31)) * 16);
         dst[0] = (dkv_u32x4){hh[0], hh[1], hh[2], hh[3]};
         dst[64] = (dkv_u32x4){mm[0], mm[1], mm[2], mm[3]};
         dst[128] = (dkv_u32x4){ll[0], ll[1], ll[2], ll[3]};
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const int ct0 = (half * inner + hi * 64) >> 5;
+#pragma unroll
+      for (int f = 0; f < 12; ++f) {                       // f = (k-step * 2 + column tile) * 3 + plane
+        const dkv_u32x4 v = *(const dkv_u32x4 *)(stg + f * 1024 + lane * 16);
+        const int ktl = f / 6, ctl = (f / 3) & 1, pl = f % 3;
+        *(dkv_u32x4 *)(a.dkv3 + ((((ktb + ktl) * a.dkv3_ct + ct0 + ctl) * 3 + pl) * 64 + lane) * 8) = v;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // (the reads above have left the LDS before the next half overwrites it)
     }
     return;
   }
@@ -743,7 +757,7 @@ int launch_attn_bwd_dkv(const AttnBwdArgs &a_in, int dh, int inner, hipStream_t 
     // the transposed three-plane image instead of dKV: two token tiles per wave, whole pairs inside every sample, every image row
     // (column of dKV) owned by some lane -- else the caller's x6_split_t builds it from the compact layout
     static const bool no_planes = getenv("HN_NO_DKV_PLANES") != nullptr;      // route switch (A/B)
-    const bool planes = a.dkv3 != nullptr && !no_planes && ntiles >= 64 && a.N % 32 == 0 && (2 * inner) % 256 == 0 && a.h * dh == inner &&
+    const bool planes = a.dkv3 != nullptr && !no_planes && ntiles >= 64 && a.N % 32 == 0 && (2 * inner) % 256 == 0 && a.h * dh == inner && dh == 64 &&
                         a.dkv3_ct * 32 == 2 * inner;
     if (!planes) a.dkv3 = nullptr;
     if (ntiles >= 64) hipLaunchKernelGGL(attn_bwd_dkv_lds_kernel<2>, dim3(ceil_div(ntiles, 8), a.b * a.h), block, 0, s, a, ntiles, dh, inner);
