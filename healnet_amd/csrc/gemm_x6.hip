@@ -2,10 +2,11 @@
 //
 //     x = h + m + l,   h = bf16(x),  m = bf16(x - h),  l = bf16(x - h - m)        (round to nearest even; both differences exact)
 //
-// 3 x 8 significand bits (+ the signs of m and l) hold all 24 bits of an fp32, so the split is EXACT for every finite x whose
-// last piece does not underflow; a product x y is then the sum of nine bf16 x bf16 products, each exact in fp32.  Six of them are
-// formed (h h, h m, m h, h l, m m, l h) -- the three dropped ones are below 2^-25 |x y|, less than the rounding of ONE fp32
-// product -- by v_mfma_f32_32x32x16_bf16 with fp32 accumulation: 6 x 32 cycles for 32 x 32 x 16 products against 16 x 32 cycles
+// 3 x 8 significand bits (+ the signs of m and l) hold all 24 bits of an fp32, so the split is EXACT for every normal x below the
+// largest bf16 (3.39e38: the top 0.4 % of the last binade rounds to Inf) whose last piece does not underflow; a product x y is then the sum of nine bf16 x bf16 products, each exact in fp32.  Six of them are
+// formed (h h, h m, m h, h l, m m, l h) -- the three dropped ones are 2^-27.4 |x y| rms (at most 2^-23 in the worst alignment of
+// both operands; tests/test_x6_split_math.py), a quarter of the rms rounding error of ONE fp32 product (2^-25.2) -- by
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation: 6 x 32 cycles for 32 x 32 x 16 products against 16 x 32 cycles
 // of v_mfma_f32_16x16x4_f32, i.e. the fp32 result at 3/8 of the fp32 MFMA time (the bf16 pipe is 16 x the fp32 pipe on gfx950).
 // tools/ubench/gemm_x6_bench.hip measures both kernels against an fp64 reference: the error of this one is not larger.
 //
