@@ -49,7 +49,12 @@ typedef enum hn_gate { HN_GATE_SELU = 0, HN_GATE_GELU = 1 } hn_gate;
 typedef enum hn_dtype { HN_F32 = 0, HN_BF16 = 1, HN_U8 = 2 } hn_dtype;
 
 /* Matrix-instruction precision of the shared-context (image / volume) cross-attention core of hn_fusion_forward:
- * HN_CORE_F32  fp32 MFMA on the fp32 context (default; the <= 1e-3 parity configuration);
+ * HN_CORE_F32  fp32 MFMA on the fp32 context (default; the <= 1e-3 parity configuration).  Under this setting (inference and
+ *              training alike) the K/V projection of a LARGE patch bag (>= 16 384 context rows per call) and its weight
+ *              gradient are still fp32 products, but formed on the bf16 pipe: every fp32 operand as three bf16 planes whose sum
+ *              is the operand exactly, six bf16 x bf16 products (each exact in fp32) with fp32 accumulation per fp32 product;
+ *              the error against an fp64 product is not above the fp32 MFMA's (gemm_x6.hip; tests/test_gpu_x6.py,
+ *              tests/test_x6_split_math.py).  HN_NO_X6_GEMM=1 in the environment takes the fp32 MFMA for those two products;
  * HN_CORE_BF16 bf16 MFMA with fp32 accumulation: context, folded queries and probabilities rounded to bf16 once
  *              (BASELINE configs[2], tolerance 2e-2 max-norm against the fp32 oracle); and, for a modality on the explicit
  *              K/V binding (patch bags: BASELINE configs[3] / [4]), the context-side K/V projection on bf16 MFMA -- context
