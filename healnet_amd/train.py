@@ -427,12 +427,35 @@ class _CapturedStep:
             loss.backward()
             return loss.detach(), out.detach()
 
+        # A replay writes gradients where the CAPTURE wrote them: every parameter's .grad has to be its slot of the flat buffer before
+        # the warm-up runs (model.zero_grad() -- set_to_none by default -- leaves them None: the backward would then hand ordinary
+        # gradients to autograd, the capture would record accumulations into tensors of its own that flat.zero_grad() never clears and
+        # the fused optimizer never reads) ...
+        flat.relink()
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
+        import warnings
+        with torch.cuda.stream(side), warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
             for _ in range(owner.warmup):            # allocator, workspaces, descriptor caches and the autograd thread's state settle
                 retry_step(body)
         torch.cuda.current_stream(dev).wait_stream(side)
+        # An autograd graph of an EARLIER eager step that is still referenced (a kept `loss` / output tensor) keeps the parameters'
+        # AccumulateGrad nodes alive on the stream that step ran on; the engine then joins that stream at the end of every backward,
+        # which inside a capture on the side stream invalidates the capture -- hipStreamEndCapture has been seen to take the process
+        # down with it.  torch reports the mismatch as a warning in the warm-up runs: refuse to capture instead.
+        # ... and still after them (a loss_fn that re-points a .grad, a parameter outside the flat buffer)
+        if flat.direct_offsets(list(flat.views)) is None:
+            raise RuntimeError("GraphedStep: a parameter's .grad is not its slot of the flat gradient buffer after the warm-up runs "
+                               "(the loss function or a hook replaces .grad?) -- a captured step could not deliver its gradients")
+        stale = [w for w in caught if "AccumulateGrad node's stream does not match" in str(w.message)]
+        for w in caught:
+            if w not in stale:
+                warnings.warn_explicit(w.message, w.category, w.filename, w.lineno)
+        if stale:
+            raise RuntimeError("GraphedStep: an autograd graph of an earlier eager step is still alive (a loss or output tensor of it is "
+                               "referenced: keep `.detach()`-ed copies / `.item()` values instead, or `del` it) -- its AccumulateGrad "
+                               "nodes belong to another stream and a capture with them cannot end cleanly")
         # nothing may be pending when the capture starts (an entry point that finds a report returns HN_E_CORESIDENCY, which would
         # abort the capture): drain, and consume a report of the warm-up runs -- the capture then holds no cluster launches
         torch.cuda.synchronize(dev)

@@ -233,3 +233,38 @@ def test_in_place_parameter_update_between_forward_and_backward_raises(hn):
     loss.backward(retain_graph=True)
     with pytest.raises(RuntimeError, match="second time"):
         loss.backward()
+
+
+def test_graphed_step_after_model_zero_grad_set_to_none():
+    """Found with tests/test_gpu_x6.py (round 6): `model.zero_grad()` (set_to_none by default) on a flattened model leaves every
+    .grad None; the eager loop repairs that in FusedL1Adam.step (FlatParameters.relink), a GraphedStep created right behind it did
+    not -- its warm-up backward handed ordinary gradients to autograd, the capture recorded `p.grad += g` into tensors of its own
+    that flat.zero_grad() never clears (4 x the gradient after three warm-ups and one replay, none of it where the fused optimizer
+    reads), and with an output tensor of an earlier eager step still referenced the capture could not even end (SIGSEGV inside
+    hipStreamEndCapture: the old AccumulateGrad nodes belong to another stream).  GraphedStep now relinks before its warm-up runs,
+    checks the layout again behind them, and refuses to capture when torch reports an AccumulateGrad stream mismatch in them.
+    In a subprocess: the failure mode being guarded against is a crash."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = f"""
+import sys, torch
+sys.path.insert(0, {root!r})
+import healnet_amd as hn
+model = hn.HealNet(n_modalities=2, channel_dims=[300, 60], num_spatial_axes=[1, 1], out_dims=3, depth=2, x_heads=2).train().to("cuda:0")
+flat = hn.train.flatten_parameters(model)
+gen = torch.Generator().manual_seed(1)
+ins = [torch.rand(3, 1, 300, generator=gen).cuda(), torch.rand(3, 301, 60, generator=gen).cuda()]
+y = model(list(ins))                    # (kept alive on purpose)
+y.sum().backward()
+want = {{k: p.grad.detach().clone() for k, p in model.named_parameters()}}
+model.zero_grad()                       # set_to_none: every .grad leaves the flat buffer
+g = hn.train.GraphedStep(model, lambda logits: logits.sum(), list(ins), ())
+g(ins, ())
+torch.cuda.synchronize()
+ok = all(p.grad is not None and torch.equal(p.grad, want[k]) for k, p in model.named_parameters())
+inflat = flat.direct_offsets(list(flat.views)) is not None
+print("REPLAYED", ok, inflat)
+"""
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stderr[-1500:])
+    assert "REPLAYED True True" in r.stdout, r.stdout + r.stderr[-800:]

@@ -173,6 +173,8 @@ CASES = {
                                  cross_dim_head=27), [(1, 300), (701, 60)], 3, True),
     "two_bags": (dict(n_modalities=3, channel_dims=[120, 64, 90], num_spatial_axes=[1, 1, 1], out_dims=4, depth=2, x_heads=4,
                       cross_dim_head=32), [(1, 120), (1100, 64), (530, 90)], 4, True),
+    "masked_single_bag": (dict(n_modalities=1, channel_dims=[96], num_spatial_axes=[1], out_dims=2, depth=2, x_heads=4),
+                          [(803, 96)], 5, True),      # key-padding mask on the bag (healnet.py:412-416): masked rows carry no gradient
     "cfg4_b8_default_gates": (dict(n_modalities=2, channel_dims=[2000, 768], num_spatial_axes=[1, 1], out_dims=4),
                               [(1, 2000), (4096, 768)], 8, False),
 }
@@ -187,16 +189,37 @@ res = {{}}
 for name, (kw, shapes, b, forced) in CASES.items():
     torch.manual_seed(3)
     model = hn.HealNet(**kw).train().to("cuda:0")
+    flat = hn.train.flatten_parameters(model)
     gen = torch.Generator().manual_seed(5)
     ins = [torch.rand(b, *s, generator=gen).to("cuda:0") for s in shapes]
-    y = model(list(ins))
-    (y * torch.linspace(0.5, 1.5, y.numel(), device=y.device).view_as(y)).sum().backward()
-    out = {{"logits": y.detach().cpu()}}
-    for k, p in model.named_parameters():
-        out["grad." + k] = p.grad.detach().cpu()
+    mask = None
+    if name.startswith("masked"):
+        mask = (torch.rand(b, shapes[0][0], generator=gen) > 0.3).to("cuda:0")
+        mask[:, 0] = True
+
+    def step():
+        flat.zero_grad()
+        y = model(list(ins), mask=mask)
+        wts = torch.linspace(0.5, 1.5, y.numel(), device=y.device).view_as(y)
+        (y * wts).sum().backward()
+        return y.detach().clone(), wts, {{k: p.grad.detach().clone() for k, p in model.named_parameters()}}
+
+    y, wts, g = step()
+    out = {{"logits": y.cpu()}}
+    for k, v in g.items():
+        out["grad." + k] = v.cpu()
+    # the same step again: the route is deterministic (fixed-order split-k, no atomics)
+    y2, _, g2 = step()
+    out["deterministic"] = torch.tensor(torch.equal(y2, y) and all(torch.equal(g2[k], g[k]) for k in g))
+    # ... and as ONE graph replay (healnet_amd.train.GraphedStep): the captured launches are the eager ones
+    gstep = hn.train.GraphedStep(model, lambda logits, w: (logits * w).sum(), list(ins), (wts,), mask=mask)
+    gstep(ins, (wts,), mask=mask)
+    torch.cuda.synchronize()
+    out["graph_equals_eager"] = torch.tensor(all(torch.equal(p.grad, g[k]) for k, p in model.named_parameters()))
+    gstep.close()
     model.eval()
     with torch.no_grad():
-        out["logits_eval"] = model(list(ins)).cpu()
+        out["logits_eval"] = model(list(ins), mask=mask).cpu()
     res[name] = out
 torch.save(res, sys.argv[1])
 """
@@ -226,7 +249,12 @@ def test_the_two_routes_agree_to_fp32_rounding(routes, name):
     a, p = routes["x6" if forced else "default"][name], routes["fp32"][name]
     assert a.keys() == p.keys()
     differs = 0
+    for flag in ("deterministic", "graph_equals_eager"):
+        for r in (a, p):
+            assert flag not in r or bool(r[flag]), f"{name}: {flag} is false"
     for k in a:
+        if k in ("deterministic", "graph_equals_eager"):
+            continue
         assert torch.isfinite(a[k]).all(), f"{name}: {k} of the split route is not finite"
         # logits to 2e-5; gradients to 1e-4 of their tensor's scale (LeakyReLU / SELU kinks may flip on single elements downstream of
         # a last-bit difference -- tests/test_gpu_fullsize.py's allowance: a handful of elements beyond 5e-4, none beyond 5e-3)
