@@ -276,3 +276,28 @@ def test_the_default_route_of_small_bags_is_the_fp32_mfma(routes):
             continue
         for k, v in routes["default"][name].items():
             assert torch.equal(v, routes["fp32"][name][k]), f"{name}: {k} differs between the default and the fp32 route"
+
+
+def test_the_first_forward_of_a_process_may_be_a_capture_on_this_route():
+    """HealNet.capture() as the very first call of a process at BASELINE configs[3]'s size: the route's one-time set-up (dynamic-LDS
+    attributes of its kernels) happens inside the warm-up run of the capture, the replay holds the image kernels and both GEMMs, and
+    equals the eager forward bit for bit."""
+    script = f"""
+import sys, torch
+sys.path.insert(0, {ROOT!r})
+import healnet_amd as hn
+torch.manual_seed(0)
+model = hn.HealNet(n_modalities=2, channel_dims=[2000, 768], num_spatial_axes=[1, 1], out_dims=4).eval().to("cuda:0")
+gen = torch.Generator().manual_seed(2)
+ins = [torch.rand(8, 1, 2000, generator=gen).cuda(), torch.rand(8, 4096, 768, generator=gen).cuda()]
+with torch.no_grad():
+    g = model.capture(list(ins))
+    a = g().clone()
+    b = g([t.clone() for t in ins]).clone()
+    e = model(list(ins))
+print("EQUAL", bool(torch.equal(a, e) and torch.equal(b, e) and torch.isfinite(e).all()))
+"""
+    env = {k: v for k, v in os.environ.items() if k not in ("HN_FORCE_X6_GEMM", "HN_NO_X6_GEMM")}
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, (r.returncode, r.stderr[-1500:])
+    assert "EQUAL True" in r.stdout, r.stdout + r.stderr[-800:]
