@@ -301,3 +301,37 @@ print("EQUAL", bool(torch.equal(a, e) and torch.equal(b, e) and torch.isfinite(e
     r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, (r.returncode, r.stderr[-1500:])
     assert "EQUAL True" in r.stdout, r.stdout + r.stderr[-800:]
+
+
+def test_batch_sizes_on_both_sides_of_the_size_gate_in_one_process():
+    """b = 8 (32 768 bag rows: this route), 4 (16 384: this route, exactly at the gate), 3 (12 288: the fp32-MFMA kernels), 8 again, on
+    one model in one process, inference and training forward + backward: the per-sample results do not depend on which route or
+    batch they were computed in beyond fp32 rounding, and the last b = 8 run is bit-equal to the first (no state survives a call)."""
+    import healnet_amd as hn
+    torch.manual_seed(1)
+    kw = dict(n_modalities=2, channel_dims=[2000, 768], num_spatial_axes=[1, 1], out_dims=4)
+    model = hn.HealNet(**kw).to(DEV)
+    gen = torch.Generator().manual_seed(6)
+    full = [torch.rand(8, 1, 2000, generator=gen).to(DEV), torch.rand(8, 4096, 768, generator=gen).to(DEV)]
+
+    def run(b, train):
+        model.train(train)
+        ins = [t[:b].contiguous() for t in full]
+        if not train:
+            with torch.no_grad():
+                return model(list(ins)).clone(), None
+        model.zero_grad(set_to_none=True)
+        y = model(list(ins))
+        y.sum().backward()
+        return y.detach().clone(), model.layers[0][2].fn.to_kv.weight.grad.clone()      # layer 0, the bag's cross-attention: to_kv
+
+    for train in (False, True):
+        first, g_first = run(8, train)
+        assert torch.isfinite(first).all()
+        for b in (4, 3):
+            y, _ = run(b, train)
+            assert_close(y, first[:b], rel=2e-5, floor=2e-6, what=f"b={b} ({'training' if train else 'inference'}) against the first {b} samples of b=8")
+        again, g_again = run(8, train)
+        assert torch.equal(again, first), "the second b = 8 run differs from the first"
+        if g_first is not None:
+            assert torch.equal(g_again, g_first)
