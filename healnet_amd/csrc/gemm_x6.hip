@@ -3,11 +3,12 @@
 //     x = h + m + l,   h = bf16(x),  m = bf16(x - h),  l = bf16(x - h - m)        (round to nearest even; both differences exact)
 //
 // 3 x 8 significand bits (+ the signs of m and l) hold all 24 bits of an fp32, so the split is EXACT for every normal x below the
-// largest bf16 (3.39e38: the top 0.4 % of the last binade rounds to Inf) whose last piece does not underflow; a product x y is then the sum of nine bf16 x bf16 products, each exact in fp32.  Six of them are
-// formed (h h, h m, m h, h l, m m, l h) -- the three dropped ones are 2^-27.4 |x y| rms (at most 2^-23 in the worst alignment of
-// both operands; tests/test_x6_split_math.py), a quarter of the rms rounding error of ONE fp32 product (2^-25.2) -- by
-// v_mfma_f32_32x32x16_bf16 with fp32 accumulation: 6 x 32 cycles for 32 x 32 x 16 products against 16 x 32 cycles
-// of v_mfma_f32_16x16x4_f32, i.e. the fp32 result at 3/8 of the fp32 MFMA time (the bf16 pipe is 16 x the fp32 pipe on gfx950).
+// largest bf16 (3.39e38: the top 0.4 % of the last binade rounds to Inf) whose last piece does not underflow; a product x y is then
+// the sum of nine bf16 x bf16 products, each exact in fp32.  Six of them are formed (h h, h m, m h, h l, m m, l h) -- the three
+// dropped ones are 2^-27.4 |x y| rms (at most 2^-23 in the worst alignment of both operands; tests/test_x6_split_math.py), a quarter
+// of the rms rounding error of ONE fp32 product (2^-25.2) -- by v_mfma_f32_32x32x16_bf16 with fp32 accumulation: 6 x 32 cycles for
+// 32 x 32 x 16 products against 16 x 32 cycles of v_mfma_f32_16x16x4_f32, i.e. the fp32 result at 3/8 of the fp32 MFMA time (the
+// bf16 pipe is 16 x the fp32 pipe on gfx950).
 // tools/ubench/gemm_x6_bench.hip measures both kernels against an fp64 reference: the error of this one is not larger.
 //
 // The K/V projection of healnet/models/healnet.py:405 on a (b * N, D) patch bag (32 768 x 773 -> 1024 at BASELINE configs[3]) and
@@ -27,7 +28,6 @@
 namespace hn {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 x6_bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 __device__ __forceinline__ void x6_glds16(const i32x4 &rsrc, unsigned lds_byte, int voffset, unsigned soffset) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
