@@ -373,6 +373,13 @@ int launch_x6_split(const float *X, long ldx, const float *scale, long R, int K,
   return HN_OK;
 }
 
+// the dynamic-LDS attribute of a kernel is a per-device property: one flag per device ordinal and entry point (a benign race: two
+// threads of a first call may both set it)
+static bool *x6_attr_flag(bool (&flags)[64]) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 63;
+  return &flags[dev];
+}
 static int x6_set_lds(const void *fn, int bytes) {
   HN_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
   return HN_OK;
@@ -391,7 +398,8 @@ int launch_gemm_nt_x6(const GemmX6Args &g_in, int variant, hipStream_t s) {
   g.nsplit = 1; g.kslice = g.KT;
   const long blocks = (long)ceil_div(g.ntm, 8) * 8 * g.ntn;
   KernelTimerScope timer("gemm_nt_x6", s);
-  static bool attr = false;
+  static bool attr_dev[64] = {};
+  bool &attr = *x6_attr_flag(attr_dev);
   if (!attr) {
     int rc;
     if ((rc = x6_set_lds((const void *)gemm_nt_x6_kernel<4, 2, 2, 4, 3>, 3 * 48 * 1024)) != HN_OK) return rc;
@@ -465,7 +473,8 @@ int launch_gemm_tn_x6(const unsigned short *At, const unsigned short *Bt, long K
   g.nsplit = ceil_div(g.KT, g.kslice);
   const int total = tiles * g.nsplit, blocks = ceil_div(total, 8) * 8;
   constexpr int LDS = 3 * (X6_TN_TI * 3 + 16) * 1024;
-  static bool attr = false;
+  static bool attr_dev[64] = {};
+  bool &attr = *x6_attr_flag(attr_dev);
   if (!attr) {
     int rc = x6_set_lds((const void *)gemm_nt_x6_kernel<1, X6_TN_TJ, X6_TN_TI, 1, 3, 1>, LDS);
     if (rc != HN_OK) return rc;
