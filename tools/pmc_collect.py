@@ -27,8 +27,12 @@ def main():
     ap.add_argument("--json", default="gpurun_out/pmc_cfg2_b32.json")
     ap.add_argument("--core-precision", default="fp32")
     ap.add_argument("--cfg", type=int, default=2, help="BASELINE config (2: tools/quick_cfg2.py 32 3; 3 / 4 / 5: tools/bench_configs.py at its batch, 3 steps)")
+    ap.add_argument("--train", action="store_true", help="the cfg4 training step instead of a forward (tools/train_step.py --steps 3 --warmup 2)")
     args = ap.parse_args()
-    if args.cfg == 2:
+    if args.train:
+        args.cfg = 4
+        workload = [sys.executable, os.path.join(ROOT, "tools/train_step.py"), "--config", "cfg4", "--steps", "3", "--warmup", "2"]
+    elif args.cfg == 2:
         workload = [sys.executable, os.path.join(ROOT, "tools/quick_cfg2.py"), "32", "3"]
     else:
         workload = [sys.executable, os.path.join(ROOT, "tools/bench_configs.py"), "--cfg", str(args.cfg), "--core-precision", args.core_precision,
@@ -75,7 +79,7 @@ def main():
         "git_head": os.environ.get("HN_GIT_HEAD"),
         "command": "python tools/pmc_collect.py (three rocprofv3 --kernel-trace --pmc passes over " + " ".join(os.path.relpath(w, ROOT) if os.path.isabs(w) and w.startswith(ROOT) else w for w in workload[1:]) + ": "
                    + " | ".join(PASSES.values()) + ")",
-        "config": "cfg%d" % args.cfg,
+        "config": "cfg%d%s" % (args.cfg, " training step" if args.train else ""),
         "core_precision": args.core_precision,
         "note": "FETCH_SIZE/WRITE_SIZE are KiB per dispatch; gfx950: FETCH_SIZE reads 1/2 of the bytes of wide coalesced streams "
                 "(MI355X_MICROARCH.md) -> upper estimate (2*FETCH + WRITE) KiB, raw (FETCH + WRITE) KiB",
