@@ -180,7 +180,7 @@ int project_ctx_kv(const hn_attn_params *p, const AttnPlan &pl, const float *ctx
       GemmX6Args gx{};
       gx.Ap = ctx3; gx.a_rt = x6_row_tiles(gk.M); gx.Wp = wp; gx.w_rt = x6_row_tiles(np); gx.bias = ws_b; gx.C = gk.C; gx.ldc = gk.ldc;
       gx.M = gk.M; gx.N = np; gx.KT = (gk.K + 15) / 16; gx.alpha = 1.0f;
-      return launch_gemm_nt_x6(gx, 0, s);
+      return launch_gemm_nt_x6(gx, gemm_nt_x6_variant(gk.M), s);
     }
     GemmNtArgs gn;
     gn.A = gk.A; gn.lda = gk.lda; gn.W = ws_w; gn.ldw = gemm_nt_ldws(gk.K); gn.bias = ws_b; gn.C = gk.C; gn.ldc = gk.ldc;

@@ -334,6 +334,7 @@ int launch_gemm_nt_x6(const GemmX6Args &g, int variant, hipStream_t s);
 constexpr int X6_ROW_TILE = 8;                 // plane images are padded to 8 row tiles of 32 (the 256-row tile of the product kernels)
 bool gemm_x6_enabled();                        // route switch HN_NO_X6_GEMM=1: the fp32-MFMA kernels of gemm_nt.hip (A/B tests)
 bool gemm_nt_x6_eligible(long M, int N, int K);
+int gemm_nt_x6_variant(long M);                // tile geometry by row count (launch_gemm_nt_x6's `variant`)
 static inline int x6_col_tiles(int cols, int pad) { return ((cols + 31) / 32 + pad - 1) / pad * pad; }
 // transposed images (rows of the image = columns of X, k = row index of X) and the long-contraction TN product on them
 // pair order of the k index (rows of X) inside a transposed image: the 32 rows of a PAIR of 16-row tiles are dealt to two k-steps

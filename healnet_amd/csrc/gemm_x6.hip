@@ -347,11 +347,16 @@ static bool x6_forced() {
   static const bool on = getenv("HN_FORCE_X6_GEMM") != nullptr;    // route switch (A/B tests): this route below its size gates
   return on;
 }
-// large row counts only: a 256 x 256 tile per workgroup, 1 workgroup per CU (below one round of the chip the fp32 tilings win)
+// large row counts only.  Measured at N = 1024, K = 773 (tools/ubench/gemm_x6_bench.hip), fp32 MFMA / 256 x 256 tiles at one
+// workgroup per CU / 256 x 128 tiles at two: 32 768 rows 425 / 232 / 256 us, 12 288 rows 200 / 103 / 109, 8192 rows 106 / 98 / 70,
+// 4096 rows 63 / 93 / 62 (+ the image of the bag: 14 us per 8192 rows, once per forward) -- from 8192 rows on this route wins,
+// below 12 288 rows on the smaller tile (gemm_nt_x6_variant)
 bool gemm_nt_x6_eligible(long M, int N, int K) {
-  const bool big = x6_forced() ? (M >= 64 && N >= 32 && K >= 8) : (M >= 16384 && N >= 256 && K >= 64);
+  const bool big = x6_forced() ? (M >= 64 && N >= 32 && K >= 8) : (M >= 8192 && N >= 256 && K >= 64);
   return gemm_x6_enabled() && big && N % 4 == 0 && x6_plane_bytes(M, K, X6_ROW_TILE) < 0xfffffff0u;
 }
+
+int gemm_nt_x6_variant(long M) { return M < 12288 ? 1 : 0; }
 
 size_t x6_plane_bytes(long rows, int K, int row_tile) {
   const long rt = (rows + 31) / 32, rtp = (rt + row_tile - 1) / row_tile * row_tile;
@@ -444,7 +449,8 @@ int launch_x6_split_t(const float *X, long ldx, long R, int C, int col_tile, int
 // the TN tile: 256 (i) x 160 (j), 8 waves of 32 x 160 -- 773 + 1 columns are 25 tiles of 32 = 5 x 160 exactly
 constexpr int X6_TN_TI = 8, X6_TN_TJ = 5;
 bool gemm_tn_x6_eligible(long K, int M, int N) {
-  const bool big = x6_forced() ? (K >= 64 && M >= 32 && N >= 8) : (K >= 16384 && M >= 256 && N >= 64);
+  // (8192 rows: 78 us + the two images against 131 us on the fp32 MFMA; 12 288: 110 against 185)
+  const bool big = x6_forced() ? (K >= 64 && M >= 32 && N >= 8) : (K >= 8192 && M >= 256 && N >= 64);
   return gemm_x6_enabled() && big &&
          (size_t)((K + 15) / 16) * x6_col_tiles(M, X6_TN_TI) * 3072 < 0xfffffff0u && (size_t)((K + 15) / 16) * x6_col_tiles(N + 1, X6_TN_TJ) * 3072 < 0xfffffff0u;
 }

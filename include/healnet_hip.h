@@ -50,7 +50,7 @@ typedef enum hn_dtype { HN_F32 = 0, HN_BF16 = 1, HN_U8 = 2 } hn_dtype;
 
 /* Matrix-instruction precision of the shared-context (image / volume) cross-attention core of hn_fusion_forward:
  * HN_CORE_F32  fp32 MFMA on the fp32 context (default; the <= 1e-3 parity configuration).  Under this setting (inference and
- *              training alike) the K/V projection of a LARGE patch bag (>= 16 384 context rows per call) and its weight
+ *              training alike) the K/V projection of a LARGE patch bag (>= 8192 context rows per call) and its weight
  *              gradient are still fp32 products, but formed on the bf16 pipe: every fp32 operand as three bf16 planes whose sum
  *              is the operand exactly, six bf16 x bf16 products (each exact in fp32) with fp32 accumulation per fp32 product;
  *              the error against an fp64 product is not above the fp32 MFMA's (gemm_x6.hip; tests/test_gpu_x6.py,

@@ -270,7 +270,7 @@ def test_the_two_routes_agree_to_fp32_rounding(routes, name):
 
 
 def test_the_default_route_of_small_bags_is_the_fp32_mfma(routes):
-    """Below the size gates (16 384 rows) nothing changes: the default run of the small models is bit-equal to HN_NO_X6_GEMM=1."""
+    """Below the size gates (8192 rows) nothing changes: the default run of the small models is bit-equal to HN_NO_X6_GEMM=1."""
     for name, (_, _, _, forced) in CASES.items():
         if not forced:
             continue
@@ -304,8 +304,8 @@ print("EQUAL", bool(torch.equal(a, e) and torch.equal(b, e) and torch.isfinite(e
 
 
 def test_batch_sizes_on_both_sides_of_the_size_gate_in_one_process():
-    """b = 8 (32 768 bag rows: this route), 4 (16 384: this route, exactly at the gate), 3 (12 288: the fp32-MFMA kernels), 8 again, on
-    one model in one process, inference and training forward + backward: the per-sample results do not depend on which route or
+    """b = 8 (32 768 bag rows: this route on 256 x 256 tiles), 3 (12 288: the same), 2 (8192: this route on 256 x 128 tiles, exactly at
+    the gate), 1 (4096: the fp32-MFMA kernels), 8 again, on one model in one process, inference and training forward + backward: the per-sample results do not depend on which route or
     batch they were computed in beyond fp32 rounding, and the last b = 8 run is bit-equal to the first (no state survives a call)."""
     import healnet_amd as hn
     torch.manual_seed(1)
@@ -328,7 +328,7 @@ def test_batch_sizes_on_both_sides_of_the_size_gate_in_one_process():
     for train in (False, True):
         first, g_first = run(8, train)
         assert torch.isfinite(first).all()
-        for b in (4, 3):
+        for b in (3, 2, 1):
             y, _ = run(b, train)
             assert_close(y, first[:b], rel=2e-5, floor=2e-6, what=f"b={b} ({'training' if train else 'inference'}) against the first {b} samples of b=8")
         again, g_again = run(8, train)

@@ -14,7 +14,7 @@ torch.cuda.set_device(dev)
 torch.manual_seed(0)
 model = hn.HealNet(**bench.TRAIN_KW).train().to(dev)
 gen = torch.Generator().manual_seed(4321)
-b = bench.TRAIN_BATCH
+b = int(os.environ.get("X6_BATCH", bench.TRAIN_BATCH))
 ins = [torch.rand(b, *s, generator=gen).to(dev) for s in bench.TRAIN_SHAPES]
 y = torch.randint(0, bench.TRAIN_KW["out_dims"], (b,), generator=gen).to(dev)
 c = torch.randint(0, 2, (b,), generator=gen).to(dev)
