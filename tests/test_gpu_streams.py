@@ -92,7 +92,7 @@ def test_training_steps_from_two_threads(hn):
 
 def test_kernel_timers_armed_on_one_stream_beside_a_second_thread(hn):
     """The library's one process-wide registration (hn_set_kernel_timers, include/healnet_hip.h) beside a concurrent caller
-    (VERDICT r5 item 5): thread A arms a table for ITS stream and runs patch-bag forwards (gemm_nt_glds: the K/V projection);
+    (VERDICT r5 item 5): thread A arms a table for ITS stream and runs patch-bag forwards (gemm_nt_x6: the K/V projection of a bag of 8192 rows);
     thread B runs the same forwards on another stream at the same time, and a third thread keeps re-arming / clearing the table.
     A's entry must count exactly A's launches (B's are on another stream: neither timed nor counted), both threads must reproduce
     the bits of the quiet run, and nobody may crash on a half-published table."""
@@ -117,7 +117,7 @@ def test_kernel_timers_armed_on_one_stream_beside_a_second_thread(hn):
     table = (_capi.KernelTimer * 1)()
     start = (C.c_void_p * n_ev)(*[e.cuda_event for e in evs[0]])
     stop = (C.c_void_p * n_ev)(*[e.cuda_event for e in evs[1]])
-    table[0].kernel = b"gemm_nt_glds"
+    table[0].kernel = b"gemm_nt_x6"
     table[0].ev_start, table[0].ev_stop = C.cast(start, C.POINTER(C.c_void_p)), C.cast(stop, C.POINTER(C.c_void_p))
     table[0].n_events, table[0].n_recorded, table[0].stream = n_ev, 0, sa.cuda_stream
     # how many launches of the class one forward makes: measured alone first
@@ -126,7 +126,7 @@ def test_kernel_timers_armed_on_one_stream_beside_a_second_thread(hn):
         model(list(ins))
     sa.synchronize()
     per_forward = int(table[0].n_recorded)
-    assert per_forward >= 1, "the patch-bag projection did not run on gemm_nt_glds: the test lost its subject"
+    assert per_forward >= 1, "the patch-bag projection did not run on gemm_nt_x6: the test lost its subject"
     table[0].n_recorded = 0
     outs, errs, stop_flag = {}, [], threading.Event()
     other = (_capi.KernelTimer * 1)()                  # what the third thread arms in between: a class nobody launches
